@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""
+bench.py -- Gibbs/segmental-k-means sweeps per second on BASELINE.json config 3:
+SegmentalKMeansWordseg, 10 000 utterances x 20 landmarks (n_slices_max = 6 -> 105 candidate
+spans each, 1.05 M embeddings), D = 100, K = 1000, synthetic unit-norm float32 embeddings
+(SURVEY.md 8(d)), batch-synchronous sweeps, sharded over N GPUs (strong scaling:
+the corpus is fixed, each rank owns 1/N of the utterances; two small RCCL all-gathers per
+sweep).
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the fp32 MFMA score
+kernel), its duration measured live with HIP events on the launch stream inside the timed
+region; `cpu_baseline` times the oracle's faithful single-core restatement of the reference
+on a bounded sample of the same corpus (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import random
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+METRIC = "Gibbs sweeps/sec (10k utts, D=100, K=1000) at 1/2/4/8 MI355X"
+PEAK_FP32_MATRIX_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def cpu_baseline(corpus, n_utts_total, K, n_slices_max, budget_utts):
+    """Oracle (port of the reference's per-embedding numpy path) on the first `budget_utts`
+    utterances of the same corpus; extrapolated linearly to the whole corpus (the cost per
+    utterance is size independent: BASELINE.md section 2)."""
+    from oracle import np_oracle as no
+    emb, vid, dur, lm = corpus
+    keys = sorted(emb)[:budget_utts]
+    sub = tuple({k: d[k] for k in keys} for d in (emb, vid, dur, lm))
+    random.seed(0)
+    np.random.seed(0)
+    seg = no.SegmentalKMeansWordseg(K, *sub, n_slices_max=n_slices_max, init_am_assignments="spread")
+    t0 = time.perf_counter()
+    order = list(range(seg.utterances.D))
+    random.shuffle(order)
+    for i in order:
+        seg.segment_i(i)
+    dt = time.perf_counter() - t0
+    per_utt = dt / len(keys)
+    return {
+        "value": 1.0 / (per_utt * n_utts_total),
+        "unit": "sweeps/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": "oracle/np_oracle.py SegmentalKMeansWordseg.segment_i (per-embedding numpy K x D scoring + "
+                  "Viterbi DP + sequential mean updates, the reference's structure) on the first %d of %d "
+                  "utterances, %.2f s wall = %.2f ms/utterance, extrapolated linearly to the full sweep; "
+                  "host has %d cores, the reference path is single-threaded"
+                  % (len(keys), n_utts_total, dt, 1e3 * per_utt, os.cpu_count()),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--utts", type=int, default=10000)
+    ap.add_argument("--dim", type=int, default=100)
+    ap.add_argument("--K", type=int, default=1000)
+    ap.add_argument("--landmarks", type=int, default=20)
+    ap.add_argument("--n-slices-max", type=int, default=6)
+    ap.add_argument("--cpu-utts", type=int, default=800, help="utterances timed for cpu_baseline (0 = skip)")
+    ap.add_argument("--no-events", action="store_true", help="do not bracket the score kernel with events")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from segmentalist_amd import kmeans_acoustic_wordseg as kaw
+    from segmentalist_amd.synth import make_corpus
+
+    corpus = make_corpus(args.utts, args.dim, args.K, seed=0, N=args.landmarks, n_slices_max=args.n_slices_max)
+    random.seed(0)
+    np.random.seed(0)
+    seg = kaw.SegmentalKMeansWordseg(args.K, *corpus, n_slices_max=args.n_slices_max,
+                                     init_am_assignments="spread", sync="batch")
+    sweeper = seg._get_sweeper()
+    n_emb = seg._corpus.n_emb
+    rows_local = sweeper.part.row_hi - sweeper.part.row_lo
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        seg.batch_sweep_async()
+    barrier()
+    seg._dk.check_status()
+
+    use_ev = not args.no_events
+    if use_ev:
+        sweeper.score_events = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        seg.batch_sweep_async()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    seg._dk.check_status()
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    score_ms = None
+    if use_ev and sweeper.score_events:
+        score_ms = float(np.mean([a.elapsed_time(b) for a, b in sweeper.score_events]))
+        sweeper.score_events = None
+
+    if rank == 0:
+        flops_per_launch = 2.0 * rows_local * args.K * args.dim      # algorithmic: 2 N_emb K D
+        out = {
+            "metric": METRIC,
+            "value": args.steps / elapsed,
+            "unit": "sweeps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "SegmentalKMeansWordseg batch-synchronous sweep (BASELINE.json configs[2])",
+                "utterances": args.utts, "landmarks_per_utt": args.landmarks,
+                "n_slices_max": args.n_slices_max, "embeddings": int(n_emb), "D": args.dim, "K": args.K,
+                "parallelism": "utterance shards x%d, 2 all-gathers/sweep" % world,
+                "components_after": int(seg.acoustic_model.components.K),
+            },
+        }
+        if score_ms is not None:
+            achieved = flops_per_launch / (score_ms * 1e-3) / 1e12
+            out["roofline"] = {
+                "bound": "mfma", "kernel": "k_kmeans_score", "achieved": achieved,
+                "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MATRIX_TFLOPS,
+                "traffic": None, "ms_per_launch": score_ms,
+                "flops_per_launch": flops_per_launch,
+            }
+        if world == 1 and args.cpu_utts > 0:
+            out["cpu_baseline"] = cpu_baseline(corpus, args.utts, args.K, args.n_slices_max, args.cpu_utts)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

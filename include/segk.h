@@ -1,0 +1,263 @@
+/*
+ * segk.h -- C ABI of libsegk.so: the MI355X (gfx950) implementation of the segmentalist
+ * per-utterance hot path (score every candidate acoustic-word embedding against every
+ * mixture component -> segmentation DP over candidate boundaries -> (re)assignment ->
+ * component sufficient statistics).
+ *
+ * The reference (kamperh/segmentalist, Python 2 + one Cython file) has no FFI for this
+ * path other than `_cython_utils.pyx`; the boundary it sits behind is a set of duck-typed
+ * Python methods.  Each entry point below names the reference
+ * function(s) it replaces, file:line relative to /root/reference/segmentalist/.  The
+ * Python package `segmentalist_amd` binds this header with ctypes (see INTEGRATION.md for
+ * the stub a maintainer of the reference would add).
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error; segk_last_error() gives the text
+ *     (thread local).  No exception crosses the ABI.
+ *   - the CALLER owns every buffer.  Pointers marked [dev] are device (HBM) pointers,
+ *     [host] are host pointers.  The library allocates nothing but the opaque segk_ctx.
+ *   - `stream` is a hipStream_t passed as void*; all [dev] work is asynchronous on it.
+ *   - there is NO CPU fallback: without a gfx950 device segk_create() fails.
+ */
+#ifndef SEGK_H
+#define SEGK_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SEGK_OK 0
+#define SEGK_ERR_ARG (-1)
+#define SEGK_ERR_HIP (-2)
+#define SEGK_ERR_NO_DEVICE (-3)
+#define SEGK_ERR_UNSUPPORTED (-4)
+
+#define SEGK_F32 0
+#define SEGK_F64 1
+
+typedef struct segk_ctx segk_ctx;
+
+int32_t segk_create(int32_t device_id, segk_ctx **out_ctx);
+int32_t segk_destroy(segk_ctx *ctx);
+const char *segk_last_error(void);
+/* ABI version, bumped on any signature change. */
+int32_t segk_abi_version(void);
+
+/* -------------------------------------------------------------------------------------
+ * Corpus (read-only during sampling): the device image of `Utterances` + the embedding
+ * matrix (utterances.py:74-105; unigram_acoustic_wordseg.py:571-646).
+ * ------------------------------------------------------------------------------------- */
+typedef struct segk_corpus {
+    const void *X;           /* [dev] embeddings, row-major [n_emb, ldx], dtype x_dtype      */
+    const float *X32;        /* [dev] float32 image of X, row-major [n_emb, ld32] zero-padded;
+                                ld32 = D rounded up to a multiple of 4.  (== X when x_dtype is
+                                SEGK_F32 and ldx == ld32)                                     */
+    int32_t x_dtype;         /* SEGK_F32 / SEGK_F64: dtype of X and of k-means `means`       */
+    int32_t D;               /* embedding dimension                                           */
+    int64_t n_emb;           /* rows of X                                                     */
+    int64_t ldx;             /* leading dimension of X in elements                            */
+    int64_t ld32;            /* leading dimension of X32 in floats                            */
+    const float *xnorm;      /* [dev] [n_emb] upper bound of ||X[e]||_2 (segk_corpus_prepare)  */
+    const int32_t *vec_ids;  /* [dev] [n_utt, tri]  span (s,t) at t(t-1)/2+s -> row of X, -1 */
+    const double *durations; /* [dev] [n_utt, tri]  frames; NaN = span disallowed             */
+    const int32_t *lengths;  /* [dev] [n_utt] landmarks per utterance                         */
+    int32_t n_utt;
+    int32_t N_max;           /* max landmarks; tri = N_max (N_max+1)/2                        */
+} segk_corpus;
+
+/* Fill the derived members of a corpus: X32 (when X is float64 or ldx != ld32 the caller
+ * passes a separate [n_emb, ld32] float buffer, written here) and xnorm. */
+int32_t segk_corpus_prepare(segk_ctx *ctx, const segk_corpus *c, float *X32_out, float *xnorm_out,
+                            void *stream);
+
+/* -------------------------------------------------------------------------------------
+ * k-means components: device image of `KMeansComponents` (kmeans_components.py:18-91).
+ * `means` has the dtype of X (kmeans_components.py:75-76: means = random_means.copy()).
+ * ------------------------------------------------------------------------------------- */
+typedef struct segk_kmeans {
+    void *means;               /* [dev] [K_max, D] dtype x_dtype (inactive rows = random_means) */
+    double *mean_numerators;   /* [dev] [K_max, D]                                              */
+    int64_t *counts;           /* [dev] [K_max]                                                 */
+    const void *random_means;  /* [dev] [K_max, D] dtype x_dtype                                */
+    int32_t *assignments;      /* [dev] [n_emb]  component of each embedding, -1 = unassigned   */
+    int32_t *K;                /* [dev] [1] number of active components                         */
+    int32_t K_max;
+    /* derived operands of the MFMA score kernel, maintained by the library: */
+    float *tiles;              /* [dev] segk_kmeans_tiles_floats(K_max, D) floats               */
+    double *mnorm_max;         /* [dev] [1] upper bound of max_k ||means[k]||_2                 */
+} segk_kmeans;
+
+/* number of floats the caller must allocate for segk_kmeans.tiles */
+int64_t segk_kmeans_tiles_floats(int32_t K_max, int32_t D);
+
+/* KMeansComponents.__init__ (kmeans_components.py:59-81): from `assignments` (and
+ * `random_means`) build counts, mean_numerators (sequential fp64 sums in ascending row order,
+ * i.e. the order of the reference's add_item loop), means, K, tiles. */
+int32_t segk_kmeans_init_stats(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m, void *stream);
+
+/* (Re)build `tiles` and `mnorm_max` from `means` (all K_max rows).  Called after any
+ * wholesale change of the means. */
+int32_t segk_kmeans_prepare(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m, void *stream);
+
+/* A1 (filter stage) -- KMeansComponents.neg_sqrd_norm / max_ / argmax_neg_sqrd_norm_i
+ * kmeans_components.py:225-232, called per embedding from get_vec_embed_neg_len_sqrd_norms
+ * kmeans_acoustic_wordseg.py:334-351.  fp32 MFMA contraction of rows `ids[0..n)` of X32
+ * (rows row0..row0+n-1 when ids == NULL; entries of ids equal to -1 are skipped)
+ * against all K_max means.  For every row e processed, the component with the largest
+ * f[k] = x_e.m_k - |m_k|^2/2 and the two largest values of f are written at index e:
+ *   cand_k [dev] int32 [n_emb], cand_f [dev] float [n_emb, 2].
+ * These are CANDIDATES: the reference-arithmetic score is recomputed from them by
+ * segk_kmeans_segment / segk_kmeans_exact_max (bit-exact contract).           */
+int32_t segk_kmeans_score(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m,
+                          const int32_t *ids, int64_t row0, int64_t n,
+                          int32_t *cand_k, float *cand_f, void *stream);
+
+/* A1 (exact stage) for rows ids[0..n) (0..n-1 when NULL): out_max[r] (double, widened from
+ * the dtype of X) and out_arg[r] are bit-identical to np.max / np.argmax of
+ * neg_sqrd_norm(ids[r]) (kmeans_components.py:228-232).  cand_* as written by
+ * segk_kmeans_score.  out_n_bruteforce [dev] int32 [1] counts rows that needed the full
+ * K_max exact scan (filter margin not decisive).                                        */
+int32_t segk_kmeans_exact_max(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m,
+                              const int32_t *ids, int64_t n,
+                              const int32_t *cand_k, const float *cand_f,
+                              double *out_max, int32_t *out_arg, int32_t *out_n_bruteforce,
+                              void *stream);
+
+/* A1 full vector: out[k], k < K_max, = neg_sqrd_norm(row) in reference arithmetic; `out`
+ * has the dtype of X (kmeans_components.py:169-226).                                    */
+int32_t segk_kmeans_neg_sqrd_norm(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m,
+                                  int64_t row, void *out, void *stream);
+
+/* A5 + A8 + new-segment argmax -- SegmentalKMeansWordseg.segment_i minus the statistics
+ * update: get_vec_embed_neg_len_sqrd_norms (kmeans_acoustic_wordseg.py:334-351),
+ * forward_backward_kmeans_viterbi (:449-555), get_max_unsup_transcript_i (:313,:437-446).
+ * One workgroup per utterance utts[0..n_utts) (utterances utt0..utt0+n_utts-1 when utts == NULL).
+ *   boundaries [dev] uint8 [n_utt, N_max]  in: current segmentation, out: new
+ *   old_tok    [dev] int32 [n_utt, N_max]  embeddings of the OLD segmentation (-1 skipped)
+ *   new_tok    [dev] int32 [n_utt, N_max]  embeddings of the NEW segmentation
+ *   new_k      [dev] int32 [n_utt, N_max]  argmax component of each new segment
+ *   n_old/n_new[dev] int32 [n_utt]
+ *   out_total  [dev] double [n_utt]        sum of chosen scores (:332)
+ *   status     [dev] int32 [8]  [0] error flag (new segment without embedding ->
+ *              kmeans_components.py:100 assert), [1] spans brute-forced (accumulates)    */
+int32_t segk_kmeans_segment(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m,
+                            const int32_t *utts, int32_t utt0, int32_t n_utts,
+                            int32_t n_slices_min, int32_t n_slices_max, double wip,
+                            const int32_t *cand_k, const float *cand_f,
+                            uint8_t *boundaries, int32_t *old_tok, int32_t *new_tok,
+                            int32_t *new_k, int32_t *n_old, int32_t *n_new,
+                            double *out_total, int32_t *status, void *stream);
+
+/* A11 sequential update -- the tail of segment_i (kmeans_acoustic_wordseg.py:314-320):
+ * del_item(old) (kmeans_components.py:113-132), add_item(new, k) (:93-111, incl. the
+ * `k > K -> K` clamp), clean_components (:263-266, del_component :149-166), in exactly the
+ * reference's order and floating-point arithmetic, for ONE utterance; also refreshes the
+ * changed rows of `tiles` / `mnorm_max`.  Device-side, single workgroup.                */
+int32_t segk_kmeans_update_utt(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m,
+                               int32_t utt, const int32_t *old_tok, const int32_t *new_tok,
+                               const int32_t *new_k, const int32_t *n_old, const int32_t *n_new,
+                               int32_t *status, void *stream);
+
+/* Single-item mutators with the reference's semantics (kmeans_components.py:93-166),
+ * for the drop-in `KMeansComponents.add_item/del_item/del_component/clean_components`. */
+int32_t segk_kmeans_add_item(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m, int64_t i,
+                             int32_t k, int32_t *status, void *stream);
+int32_t segk_kmeans_del_item(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m, int64_t i,
+                             int32_t *status, void *stream);
+int32_t segk_kmeans_clean_components(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m,
+                                     int32_t *status, void *stream);
+
+/* del_component(k) (kmeans_components.py:149-166). */
+int32_t segk_kmeans_del_component(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m, int32_t k,
+                                  int32_t *status, void *stream);
+
+/* A11 batch-synchronous update (DESIGN.md "batch mode"; spec: oracle/np_oracle.py
+ * kmeans_batch_sweep).  Four stages so that a multi-GPU run can exchange the two small
+ * intermediate buffers (flag_buf, partials) between them; `utt_lo..utt_hi` is the range of
+ * utterances owned by this rank.
+ *  (1) segk_kmeans_batch_collect: delete all old tokens of the local utterances; collect,
+ *      in token order (utterance, segment), the new tokens whose argmax is an inactive row
+ *      (k >= K): flag_buf [dev] int32 [1 + 2*cap] = {count, (slot, k) ...}.
+ *  (2) segk_kmeans_batch_assign: replay the reference's `k > K -> K` clamp
+ *      (kmeans_components.py:103-106) over the flagged tokens of ALL ranks in rank order
+ *      (flag_all [dev] int32 [n_ranks, 1 + 2*cap]); rewrite the local new_k, set K, write the
+ *      assignments of the local new tokens.
+ *  (3) segk_kmeans_batch_partials: per statistics block b (utterances
+ *      [blk_lo[b], blk_lo[b+1])) sequential fp64 sums in token order:
+ *      part_sum [dev] double [n_blocks_local, K_max, D], part_cnt [dev] int64 [.., K_max],
+ *      part_tot [dev] double [n_blocks_local] (sum of out_total in utterance order).
+ *  (4) segk_kmeans_batch_finalize: fixed balanced-tree combination of ALL blocks' partials
+ *      (n_blocks_total <= 64; block b is read at base + (b / n_blocks_per_rank) * rank_stride
+ *      + (b % n_blocks_per_rank) * block size, rank_stride in 8-byte words, so that the
+ *      all-gathered per-rank buffers are consumed in place), means = numerators/counts,
+ *      clean_components (:263-266) with a relabel table (remap_scratch [dev] int32 [K_max]),
+ *      relabel of the local tokens, rebuild of the MFMA tiles.
+ *      out_scalars [dev] double [4] = {sum of totals, K, n_tokens, 0}.
+ *  status bits: 1 new segment without embedding, 2 add_item on an assigned item
+ *  (kmeans_components.py:101 assert), 4 flag buffer overflow.
+ */
+int32_t segk_kmeans_batch_collect(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m,
+                                  int32_t utt_lo, int32_t utt_hi, const int32_t *old_tok,
+                                  const int32_t *n_old, const int32_t *new_k, const int32_t *n_new,
+                                  int32_t *flag_buf, int32_t cap, void *stream);
+int32_t segk_kmeans_batch_assign(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m,
+                                 int32_t utt_lo, int32_t utt_hi, const int32_t *flag_all,
+                                 int32_t n_ranks, int32_t my_rank, int32_t cap,
+                                 const int32_t *new_tok, int32_t *new_k, const int32_t *n_new,
+                                 int32_t *status, void *stream);
+int32_t segk_kmeans_batch_partials(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m,
+                                   const int32_t *blk_lo, int32_t n_blocks_local,
+                                   const int32_t *new_tok, const int32_t *new_k,
+                                   const int32_t *n_new, const double *out_total,
+                                   double *part_sum, int64_t *part_cnt, double *part_tot,
+                                   void *stream);
+int32_t segk_kmeans_batch_finalize(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m,
+                                   int32_t utt_lo, int32_t utt_hi, const double *part_sum,
+                                   const int64_t *part_cnt, const double *part_tot,
+                                   int32_t n_blocks_total, int32_t n_blocks_per_rank,
+                                   int64_t rank_stride, const int32_t *new_tok,
+                                   const int32_t *n_new, int32_t *remap_scratch,
+                                   double *out_scalars, int32_t *status, void *stream);
+
+/* KMeansComponents.sum_neg_sqrd_norm (kmeans_components.py:234-247), record metric.
+ * out [dev] double [1]; tolerance-level parity (summation order differs). */
+int32_t segk_kmeans_sum_neg_sqrd_norm(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m,
+                                      double *out, void *stream);
+
+/* -------------------------------------------------------------------------------------
+ * A6 / A7 / A8 on caller-supplied score vectors -- drop-in for the module-level functions
+ *   kind 0: forward_backward_kmeans_viterbi   kmeans_acoustic_wordseg.py:449-555
+ *   kind 1: forward_backward_viterbi          unigram_acoustic_wordseg.py:759-864
+ *   kind 2: forward_backward                  unigram_acoustic_wordseg.py:653-756
+ * n_prob independent problems; problem p has Ns[p] landmarks and its triangular vector
+ * (N(N+1)/2 doubles, entry t(t-1)/2+s = span [s,t)) starts at vecs + offs[p].  kind 2
+ * consumes uniforms[p*u_stride + j] in place of the j-th random.random() call
+ * (_cython_utils.pyx:83) and reports the number consumed in n_draws[p]; status[p] = 1 where
+ * the reference would `assert False` (log_prob == -inf, :753).
+ *   bounds [dev] uint8 [n_prob, b_stride], totals [dev] double [n_prob],
+ *   work [dev] double [n_prob, w_stride], w_stride >= 3*N_max + 2.
+ * ------------------------------------------------------------------------------------- */
+int32_t segk_dp_tri(segk_ctx *ctx, int32_t kind, const double *vecs, const int32_t *Ns,
+                    const int64_t *offs, int32_t n_prob, int32_t n_slices_min, int32_t n_slices_max,
+                    double log_p_continue, double anneal_temp, const double *uniforms,
+                    int64_t u_stride, uint8_t *bounds, int64_t b_stride, double *totals,
+                    int32_t *n_draws, int32_t *status, double *work, int64_t w_stride, void *stream);
+
+/* -------------------------------------------------------------------------------------
+ * A9 host shims -- _cython_utils.pyx:13-25 (logsumexp), :75-89 (draw, uniform supplied by
+ * the caller instead of random.random()), :30-70 (sums).  Pure host functions on [host]
+ * buffers, kept so that `segmentalist_amd._cython_utils` is a drop-in module.
+ * ------------------------------------------------------------------------------------- */
+double segk_logsumexp(const double *a, int64_t n);
+int32_t segk_draw(const double *p_k, int64_t n, double u);
+double segk_sum_doubles(const double *y, int64_t n);
+int64_t segk_sum_ints(const int64_t *y, int64_t n);
+double segk_sum_log(const double *y, int64_t n);
+double segk_sum_square_a_times_b(const double *a, const double *b, int64_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEGK_H */

@@ -1,0 +1,143 @@
+"""
+ctypes binding of libsegk.so (include/segk.h).  There is NO fallback: if the shared
+library is missing or no MI355X is present, importing/creating a context raises.
+
+PyTorch-ROCm tensors are used only as device buffers (`tensor.data_ptr()`), and
+`torch.cuda.current_stream()` as the stream handle.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsegk.so")
+
+SEGK_F32, SEGK_F64 = 0, 1
+
+
+class SegkError(RuntimeError):
+    pass
+
+
+class Corpus(C.Structure):
+    _fields_ = [
+        ("X", C.c_void_p), ("X32", C.c_void_p), ("x_dtype", C.c_int32), ("D", C.c_int32),
+        ("n_emb", C.c_int64), ("ldx", C.c_int64), ("ld32", C.c_int64), ("xnorm", C.c_void_p),
+        ("vec_ids", C.c_void_p), ("durations", C.c_void_p), ("lengths", C.c_void_p),
+        ("n_utt", C.c_int32), ("N_max", C.c_int32),
+    ]
+
+
+class KMeansDev(C.Structure):
+    _fields_ = [
+        ("means", C.c_void_p), ("mean_numerators", C.c_void_p), ("counts", C.c_void_p),
+        ("random_means", C.c_void_p), ("assignments", C.c_void_p), ("K", C.c_void_p),
+        ("K_max", C.c_int32), ("tiles", C.c_void_p), ("mnorm_max", C.c_void_p),
+    ]
+
+
+_P = C.c_void_p
+_i32, _i64, _f64 = C.c_int32, C.c_int64, C.c_double
+_CP, _KP = C.POINTER(Corpus), C.POINTER(KMeansDev)
+
+# name -> (restype, argtypes); every symbol include/segk.h declares
+SIGNATURES = {
+    "segk_create": (_i32, [_i32, C.POINTER(_P)]),
+    "segk_destroy": (_i32, [_P]),
+    "segk_last_error": (C.c_char_p, []),
+    "segk_abi_version": (_i32, []),
+    "segk_corpus_prepare": (_i32, [_P, _CP, _P, _P, _P]),
+    "segk_kmeans_tiles_floats": (_i64, [_i32, _i32]),
+    "segk_kmeans_prepare": (_i32, [_P, _CP, _KP, _P]),
+    "segk_kmeans_init_stats": (_i32, [_P, _CP, _KP, _P]),
+    "segk_kmeans_score": (_i32, [_P, _CP, _KP, _P, _i64, _i64, _P, _P, _P]),
+    "segk_kmeans_exact_max": (_i32, [_P, _CP, _KP, _P, _i64, _P, _P, _P, _P, _P, _P]),
+    "segk_kmeans_neg_sqrd_norm": (_i32, [_P, _CP, _KP, _i64, _P, _P]),
+    "segk_kmeans_segment": (_i32, [_P, _CP, _KP, _P, _i32, _i32, _i32, _i32, _f64, _P, _P, _P, _P, _P, _P,
+                                   _P, _P, _P, _P, _P]),
+    "segk_dp_tri": (_i32, [_P, _i32, _P, _P, _P, _i32, _i32, _i32, _f64, _f64, _P, _i64, _P, _i64, _P, _P, _P,
+                           _P, _i64, _P]),
+    "segk_kmeans_update_utt": (_i32, [_P, _CP, _KP, _i32, _P, _P, _P, _P, _P, _P, _P]),
+    "segk_kmeans_add_item": (_i32, [_P, _CP, _KP, _i64, _i32, _P, _P]),
+    "segk_kmeans_del_item": (_i32, [_P, _CP, _KP, _i64, _P, _P]),
+    "segk_kmeans_clean_components": (_i32, [_P, _CP, _KP, _P, _P]),
+    "segk_kmeans_del_component": (_i32, [_P, _CP, _KP, _i32, _P, _P]),
+    "segk_kmeans_batch_collect": (_i32, [_P, _CP, _KP, _i32, _i32, _P, _P, _P, _P, _P, _i32, _P]),
+    "segk_kmeans_batch_assign": (_i32, [_P, _CP, _KP, _i32, _i32, _P, _i32, _i32, _i32, _P, _P, _P, _P, _P]),
+    "segk_kmeans_batch_partials": (_i32, [_P, _CP, _KP, _P, _i32, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "segk_kmeans_batch_finalize": (_i32, [_P, _CP, _KP, _i32, _i32, _P, _P, _P, _i32, _i32, _i64, _P, _P, _P, _P,
+                                          _P, _P]),
+    "segk_kmeans_sum_neg_sqrd_norm": (_i32, [_P, _CP, _KP, _P, _P]),
+    "segk_logsumexp": (_f64, [_P, _i64]),
+    "segk_draw": (_i32, [_P, _i64, _f64]),
+    "segk_sum_doubles": (_f64, [_P, _i64]),
+    "segk_sum_ints": (_i64, [_P, _i64]),
+    "segk_sum_log": (_f64, [_P, _i64]),
+    "segk_sum_square_a_times_b": (_f64, [_P, _P, _i64]),
+}
+
+_lib = None
+
+
+def build(force=False):
+    """Compile libsegk.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+    if force and os.path.exists(LIB_PATH):
+        os.remove(LIB_PATH)
+    subprocess.check_call(["make", "-C", os.path.join(_HERE, "csrc"), "-s"])
+    if not os.path.exists(LIB_PATH):
+        raise SegkError("building libsegk.so failed")
+
+
+def lib():
+    """Load libsegk.so; raises SegkError if it is absent (no fallback path exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SegkError(
+                "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C segmentalist_amd/csrc`.  segmentalist_amd has no CPU fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(L, name)
+            except AttributeError:
+                raise SegkError("libsegk.so does not export %s (stale build?)" % name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise SegkError("libsegk error %d: %s" % (rc, lib().segk_last_error().decode()))
+
+
+_ctx = {}
+
+
+def ctx(device_index=None):
+    """One segk_ctx per device, created on first use."""
+    import torch
+    if not torch.cuda.is_available():
+        raise SegkError("no ROCm device visible: segmentalist_amd runs its hot path on MI355X only "
+                        "(there is no CPU fallback)")
+    if device_index is None:
+        device_index = torch.cuda.current_device()
+    if device_index not in _ctx:
+        h = C.c_void_p()
+        check(lib().segk_create(int(device_index), C.byref(h)))
+        _ctx[device_index] = h
+    return _ctx[device_index]
+
+
+def stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())

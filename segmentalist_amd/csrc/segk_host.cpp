@@ -1,0 +1,112 @@
+// segk_host.cpp -- context, error reporting and the A9 host shims of the C ABI.
+#include <math.h>
+#include <stdarg.h>
+#include <stdlib.h>
+
+#include "segk_internal.h"
+
+static thread_local char g_err[512] = "";
+
+void segk_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" {
+
+const char *segk_last_error(void) { return g_err; }
+
+int32_t segk_abi_version(void) { return 1; }
+
+int32_t segk_create(int32_t device_id, segk_ctx **out_ctx)
+{
+    if (!out_ctx) {
+        segk_set_error("segk_create: out_ctx is NULL");
+        return SEGK_ERR_ARG;
+    }
+    *out_ctx = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        segk_set_error("segk_create: no HIP device visible (%s); libsegk has no CPU fallback",
+                       e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+        return SEGK_ERR_NO_DEVICE;
+    }
+    if (device_id < 0 || device_id >= n) {
+        segk_set_error("segk_create: device_id %d out of range [0,%d)", device_id, n);
+        return SEGK_ERR_ARG;
+    }
+    hipDeviceProp_t prop;
+    SEGK_CHECK_HIP(hipGetDeviceProperties(&prop, device_id));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        segk_set_error("segk_create: device %d is %s; this library carries gfx950 (MI355X) code only",
+                       device_id, prop.gcnArchName);
+        return SEGK_ERR_NO_DEVICE;
+    }
+    segk_ctx *c = (segk_ctx *)calloc(1, sizeof(segk_ctx));
+    c->device_id = device_id;
+    c->n_cu = prop.multiProcessorCount;
+    strncpy(c->arch, prop.gcnArchName, sizeof(c->arch) - 1);
+    *out_ctx = c;
+    return SEGK_OK;
+}
+
+int32_t segk_destroy(segk_ctx *ctx)
+{
+    free(ctx);
+    return SEGK_OK;
+}
+
+// ----------------------------------------------------------------------------------------
+// A9 host shims (_cython_utils.pyx).  Same loops, same order, libm exp/log.
+// ----------------------------------------------------------------------------------------
+double segk_logsumexp(const double *a, int64_t n)   // _cython_utils.pyx:13-25
+{
+    double mx = a[0], s = 0.0;
+    for (int64_t j = 1; j < n; j++)
+        if (a[j] > mx) mx = a[j];
+    for (int64_t j = 0; j < n; j++) s += exp(a[j] - mx);
+    return log(s) + mx;
+}
+
+int32_t segk_draw(const double *p_k, int64_t n, double u)   // _cython_utils.pyx:75-89
+{
+    for (int64_t i = 0; i < n; i++) {
+        u = u - p_k[i];
+        if (u < 0) return (int32_t)i;
+    }
+    return (int32_t)(n - 1);
+}
+
+double segk_sum_doubles(const double *y, int64_t n)   // :30-36
+{
+    double s = y[0];
+    for (int64_t i = 1; i < n; i++) s += y[i];
+    return s;
+}
+
+int64_t segk_sum_ints(const int64_t *y, int64_t n)   // :41-47
+{
+    int64_t s = y[0];
+    for (int64_t i = 1; i < n; i++) s += y[i];
+    return s;
+}
+
+double segk_sum_log(const double *y, int64_t n)   // :52-58
+{
+    double s = log(y[0]);
+    for (int64_t i = 1; i < n; i++) s += log(y[i]);
+    return s;
+}
+
+double segk_sum_square_a_times_b(const double *a, const double *b, int64_t n)   // :63-70
+{
+    double s = 0.0;
+    for (int64_t i = 0; i < n; i++) s += a[i] * a[i] * b[i];
+    return s;
+}
+
+}  // extern "C"

@@ -1,0 +1,61 @@
+// segk_internal.h -- shared by the translation units of libsegk.so (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/segk.h"
+
+struct segk_ctx {
+    int device_id;
+    int n_cu;
+    char arch[64];
+};
+
+void segk_set_error(const char *fmt, ...);
+
+#define SEGK_CHECK_HIP(expr)                                                                  \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            segk_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+            return SEGK_ERR_HIP;                                                              \
+        }                                                                                     \
+    } while (0)
+
+#define SEGK_REQUIRE(cond, msg)                                             \
+    do {                                                                    \
+        if (!(cond)) {                                                      \
+            segk_set_error("%s:%d: %s (%s)", __FILE__, __LINE__, msg, #cond); \
+            return SEGK_ERR_ARG;                                            \
+        }                                                                   \
+    } while (0)
+
+#define SEGK_LAUNCH_CHECK() SEGK_CHECK_HIP(hipGetLastError())
+
+// ---------------------------------------------------------------------------------------
+// Layout of the MFMA operand image of the k-means means ("tiles"), shared by the prepare
+// and score kernels.  One tile = 32 components:
+//   floats [g][lane][2], g < G = ceil(D/4), lane < 64:
+//        M[32*tile + (lane & 31)][4*g + 2*(lane >> 5) + {0,1}]
+//   followed by 32 floats c[i] = -|m_i|^2 / 2   (-3e38 for rows >= K_max)
+//   padded with zeros to a multiple of 1024 floats (whole 16-byte x 256-thread passes).
+// ---------------------------------------------------------------------------------------
+static inline __host__ __device__ int segk_G(int D) { return (D + 3) / 4; }
+// register-array bucket of the score kernel instantiation that serves dimension D
+static inline __host__ __device__ int segk_gmax(int D)
+{
+    int G = segk_G(D);
+    return G <= 26 ? 26 : G <= 34 ? 34 : G <= 50 ? 50 : G <= 100 ? 100 : -1;
+}
+// tile stride in floats: the bucket's image size rounded up to whole 1024-float passes, so
+// that the number of LDS staging passes is a compile-time constant of the instantiation
+static inline __host__ __device__ int segk_tile_stride(int D)
+{
+    int gm = segk_gmax(D);
+    if (gm < 0) gm = segk_G(D);
+    int f = gm * 128 + 32;
+    return (f + 1023) / 1024 * 1024;
+}
+static inline __host__ __device__ int segk_n_tiles(int K_max) { return (K_max + 31) / 32; }

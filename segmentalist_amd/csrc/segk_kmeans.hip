@@ -1,0 +1,1552 @@
+// segk_kmeans.hip -- gfx950 kernels of the segmental k-means hot path.
+//
+//   k_corpus_prepare      X -> X32 (zero padded) + row norms
+//   k_kmeans_prepare      means -> MFMA operand tiles, -|m|^2/2, max norm
+//   k_kmeans_score        A1 filter: fp32 MFMA (v_mfma_f32_32x32x2_f32) X32 . means^T with a fused
+//                         running top-2 / argmax per embedding
+//   k_kmeans_segment      per utterance: exact A1 of the candidates (reference arithmetic),
+//                         A5 vector, A8 max-plus DP, new tokens + their argmax components
+//   k_kmeans_update_utt   A11 sequential del/add/clean for one utterance (reference order)
+//   k_kmeans_batch_*      A11 batch-synchronous statistics (fixed summation tree)
+//
+// Compiled with -ffp-contract=off: the exact stage must round every operation separately,
+// as numpy does (DESIGN.md "bit-exact contract").
+#include "segk_internal.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define NEG_INF_D (-__builtin_huge_val())
+#define NEG_INF_F (-__builtin_huge_valf())
+
+// ======================================================================================
+// Exact stage: numpy's pairwise summation of (m[d]-x[d])^2, identical evaluation order
+// (kmeans_components.py:225-226; numpy pairwise_sum: n<8 sequential, n<=128 eight strided
+// accumulators + fixed tree + sequential tail, n>128 split at n/2 rounded down to 8).
+// ======================================================================================
+template <typename T, typename TM, typename TX>
+__device__ __forceinline__ T sqd(const TM *m, const TX *x, int d)
+{
+    T delta = (T)m[d] - (T)x[d];
+    return delta * delta;
+}
+
+template <typename T, typename TM, typename TX>
+__device__ T pw_base(const TM *m, const TX *x, int n)
+{
+    if (n < 8) {
+        T res = (T)0;
+        for (int i = 0; i < n; i++) res += sqd<T>(m, x, i);
+        return res;
+    }
+    T r0 = sqd<T>(m, x, 0), r1 = sqd<T>(m, x, 1), r2 = sqd<T>(m, x, 2), r3 = sqd<T>(m, x, 3);
+    T r4 = sqd<T>(m, x, 4), r5 = sqd<T>(m, x, 5), r6 = sqd<T>(m, x, 6), r7 = sqd<T>(m, x, 7);
+    int i;
+    const int nfull = n - (n % 8);
+    for (i = 8; i < nfull; i += 8) {
+        r0 += sqd<T>(m, x, i + 0);
+        r1 += sqd<T>(m, x, i + 1);
+        r2 += sqd<T>(m, x, i + 2);
+        r3 += sqd<T>(m, x, i + 3);
+        r4 += sqd<T>(m, x, i + 4);
+        r5 += sqd<T>(m, x, i + 5);
+        r6 += sqd<T>(m, x, i + 6);
+        r7 += sqd<T>(m, x, i + 7);
+    }
+    T res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+    for (; i < n; i++) res += sqd<T>(m, x, i);
+    return res;
+}
+
+// -sum_d (m[d]-x[d])^2 in the dtype T of the reference's `means`/X
+template <typename T, typename TM, typename TX>
+__device__ T neg_sqd_exact(const TM *m, const TX *x, int n)
+{
+    if (n <= 128) return -pw_base<T>(m, x, n);
+    struct Frame { int off, n, state; T left; };
+    Frame st[28];
+    int sp = 0;
+    st[0].off = 0; st[0].n = n; st[0].state = 0; st[0].left = (T)0;
+    T ret = (T)0;
+    while (sp >= 0) {
+        Frame &f = st[sp];
+        if (f.state == 0) {
+            if (f.n <= 128) {
+                ret = pw_base<T>(m + f.off, x + f.off, f.n);
+                sp--;
+            } else {
+                int n2 = f.n / 2;
+                n2 -= n2 % 8;
+                f.state = 1;
+                st[sp + 1].off = f.off; st[sp + 1].n = n2; st[sp + 1].state = 0;
+                sp++;
+            }
+        } else if (f.state == 1) {
+            f.left = ret;
+            f.state = 2;
+            int n2 = f.n / 2;
+            n2 -= n2 % 8;
+            st[sp + 1].off = f.off + n2; st[sp + 1].n = f.n - n2; st[sp + 1].state = 0;
+            sp++;
+        } else {
+            ret = f.left + ret;
+            sp--;
+        }
+    }
+    return -ret;
+}
+
+// Margin below which two fp32-filter values cannot be ordered with certainty
+// (DESIGN.md "filter margin"): tau = 1.25 * (2*E1 + E2) where
+//   E1 = (D4+3) u (|x| M + M^2/2)          fp32 fma chain of the MFMA + operand rounding
+//   E2 = c2 u (|x| + M)^2                   rounding of the REFERENCE's own float32 evaluation
+// (E2 ~ 0 when the reference computes in float64).  u = 2^-24.
+__device__ __forceinline__ float filter_tau(float xn, float M, int D, int is_f64)
+{
+    const float u = 5.9604645e-8f;
+    const int D4 = (D + 3) & ~3;
+    float e1 = (float)(D4 + 3 + (is_f64 ? 4 : 0)) * u * (xn * M + 0.5f * M * M);
+    int levels = 0;
+    for (int n = D; n > 128; n = (n + 1) / 2) levels++;
+    int deff = D < 128 ? D : 128;
+    float c2 = is_f64 ? 1e-6f : (float)(deff / 8 + 13 + 2 * levels);
+    float s = xn + M;
+    float e2 = c2 * u * s * s;
+    return 1.25f * (2.0f * e1 + e2) + 1e-37f;
+}
+
+// ======================================================================================
+// corpus prepare: X (f32/f64, ldx) -> X32 [n_emb, ld32] zero padded, xnorm upper bound
+// ======================================================================================
+template <typename XT>
+__global__ void k_corpus_prepare(const XT *X, int64_t ldx, int64_t n_emb, int D, int64_t ld32,
+                                 float *X32, float *xnorm)
+{
+    int64_t e = (int64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    if (e >= n_emb) return;
+    int lane = threadIdx.x & 63;
+    double s = 0.0;
+    for (int d = lane; d < (int)ld32; d += 64) {
+        float v = 0.f;
+        if (d < D) {
+            XT xv = X[e * ldx + d];
+            v = (float)xv;
+            s += (double)xv * (double)xv;
+        }
+        if (X32) X32[e * ld32 + d] = v;
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) xnorm[e] = (float)(sqrt(s) * (1.0 + 1e-6)) + 1e-30f;
+}
+
+// ======================================================================================
+// means -> tiles
+// ======================================================================================
+template <typename XT>
+__global__ void k_kmeans_prepare(const XT *means, int K_max, int D, float *tiles,
+                                 unsigned long long *mnorm2_bits)
+{
+    const int tile = blockIdx.x;
+    const int G = segk_G(D);
+    const int stride = segk_tile_stride(D);
+    float *T = tiles + (int64_t)tile * stride;
+    __shared__ double nrm[32];
+    if (threadIdx.x < 32) {
+        int comp = tile * 32 + threadIdx.x;
+        double s = 0.0;
+        if (comp < K_max)
+            for (int d = 0; d < D; d++) {
+                double v = (double)means[(int64_t)comp * D + d];
+                s += v * v;
+            }
+        nrm[threadIdx.x] = s;
+        if (comp < K_max) atomicMax(mnorm2_bits, (unsigned long long)__double_as_longlong(s));
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < stride; idx += blockDim.x) {
+        float v = 0.f;
+        if (idx < G * 128) {
+            int g = idx >> 7, rem = idx & 127, lane = rem >> 1, s = rem & 1;
+            int comp = tile * 32 + (lane & 31);
+            int d = 4 * g + 2 * (lane >> 5) + s;
+            if (comp < K_max && d < D) v = (float)means[(int64_t)comp * D + d];
+        } else if (idx < G * 128 + 32) {
+            int i = idx - G * 128;
+            int comp = tile * 32 + i;
+            v = (comp < K_max) ? (float)(-0.5 * nrm[i]) : -3.0e38f;
+        }
+        T[idx] = v;
+    }
+}
+
+__global__ void k_mnorm_finish(const unsigned long long *mnorm2_bits, double *mnorm_max)
+{
+    double s = __longlong_as_double((long long)*mnorm2_bits);
+    *mnorm_max = sqrt(s) * (1.0 + 1e-6) + 1e-30;
+}
+
+// ======================================================================================
+// A1 filter: fused fp32 MFMA contraction + running top-2/argmax.
+//   workgroup = 4 waves; wave w owns NB blocks of 32 embeddings whose X32 rows live in
+//   registers for the whole kernel as the MFMA B operand (lane (j,h): dims 4g+2h+{0,1});
+//   the 32-component tiles of the means stream through a double-buffered LDS image and are
+//   the A operand, so the 32x32 accumulator has the component on the register index and the
+//   embedding on the lane: the running max over components is lane-local.
+//   Accumulators start at -|m|^2/2, so acc = x.m - |m|^2/2 with no epilogue arithmetic.
+// ======================================================================================
+template <int GMAX, int NB>
+__global__ __launch_bounds__(256, 2) void k_kmeans_score(
+    const float *__restrict__ X32, int64_t ld32, const int32_t *__restrict__ ids, int64_t row0, int64_t n,
+    const float *__restrict__ tiles, int n_tiles, int tile_stride, int G,
+    int32_t *__restrict__ cand_k, float *__restrict__ cand_f)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+
+    float2 xb[NB][GMAX];
+    int32_t rowid[NB];
+    const int64_t base = ((int64_t)blockIdx.x * 4 + wave) * (32 * NB);
+#pragma unroll
+    for (int nb = 0; nb < NB; nb++) {
+        int64_t r = base + nb * 32 + j;
+        int32_t id = -1;
+        if (r < n) id = ids ? ids[r] : (int32_t)(row0 + r);
+        rowid[nb] = id;
+        const float *xp = X32 + (int64_t)(id >= 0 ? id : 0) * ld32 + 2 * h;
+#pragma unroll
+        for (int g = 0; g < GMAX; g++) {
+            if (g < G) xb[nb][g] = *reinterpret_cast<const float2 *>(xp + 4 * g);
+            else xb[nb][g] = make_float2(0.f, 0.f);
+        }
+    }
+    float m1[NB], m2[NB];
+    int32_t i1[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; nb++) { m1[nb] = NEG_INF_F; m2[nb] = NEG_INF_F; i1[nb] = 0; }
+
+    constexpr int NPASS = (GMAX * 128 + 32 + 1023) / 1024;   // == tile_stride / 1024 (segk_tile_stride)
+    // prologue: tile 0 -> buffer 0
+#pragma unroll
+    for (int p = 0; p < NPASS; p++) {
+        float4 v = *reinterpret_cast<const float4 *>(tiles + p * 1024 + tid * 4);
+        *reinterpret_cast<float4 *>(lds + p * 1024 + tid * 4) = v;
+    }
+    __syncthreads();
+
+    for (int t = 0; t < n_tiles; t++) {
+        const float *T = lds + (t & 1) * tile_stride;
+        // prefetch the next tile into registers (the last iteration re-reads its own tile:
+        // always in bounds, never stored)
+        float4 pre[NPASS];
+        const bool has_next = (t + 1 < n_tiles);
+        {
+            const float *src = tiles + (int64_t)(has_next ? t + 1 : t) * tile_stride;
+#pragma unroll
+            for (int p = 0; p < NPASS; p++)
+                pre[p] = *reinterpret_cast<const float4 *>(src + p * 1024 + tid * 4);
+        }
+        f32x16 acc[NB];
+        {
+            const float *cv = T + G * 128 + 4 * h;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                float4 c4 = *reinterpret_cast<const float4 *>(cv + 8 * q);
+#pragma unroll
+                for (int nb = 0; nb < NB; nb++) {
+                    acc[nb][4 * q + 0] = c4.x;
+                    acc[nb][4 * q + 1] = c4.y;
+                    acc[nb][4 * q + 2] = c4.z;
+                    acc[nb][4 * q + 3] = c4.w;
+                }
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < GMAX; g++) {
+            if (g < G) {
+                float2 a = *reinterpret_cast<const float2 *>(T + (g * 64 + lane) * 2);
+#pragma unroll
+                for (int nb = 0; nb < NB; nb++)
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, xb[nb][g].x, acc[nb], 0, 0, 0);
+#pragma unroll
+                for (int nb = 0; nb < NB; nb++)
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, xb[nb][g].y, acc[nb], 0, 0, 0);
+            }
+        }
+        // running top-2 (values) and argmax (component) per lane
+        const int cbase = t * 32 + 4 * h;
+#pragma unroll
+        for (int nb = 0; nb < NB; nb++) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const float v = acc[nb][r];
+                const int comp = cbase + (r & 3) + 8 * (r >> 2);
+                m2[nb] = __builtin_amdgcn_fmed3f(m1[nb], m2[nb], v);
+                i1[nb] = (v > m1[nb]) ? comp : i1[nb];
+                m1[nb] = fmaxf(m1[nb], v);
+            }
+        }
+        if (has_next) {
+            float *dst = lds + ((t + 1) & 1) * tile_stride;
+#pragma unroll
+            for (int p = 0; p < NPASS; p++)
+                *reinterpret_cast<float4 *>(dst + p * 1024 + tid * 4) = pre[p];
+        }
+        __syncthreads();
+    }
+    // the two lane halves hold disjoint component subsets of the same embedding
+#pragma unroll
+    for (int nb = 0; nb < NB; nb++) {
+        float o1 = __shfl_xor(m1[nb], 32), o2 = __shfl_xor(m2[nb], 32);
+        int oi = __shfl_xor(i1[nb], 32);
+        float top1 = fmaxf(m1[nb], o1);
+        float top2 = fmaxf(fminf(m1[nb], o1), fmaxf(m2[nb], o2));
+        int idx = (o1 > m1[nb] || (o1 == m1[nb] && oi < i1[nb])) ? oi : i1[nb];
+        if (h == 0 && rowid[nb] >= 0) {
+            cand_k[rowid[nb]] = idx;
+            cand_f[2 * (int64_t)rowid[nb] + 0] = top1;
+            cand_f[2 * (int64_t)rowid[nb] + 1] = top2;
+        }
+    }
+}
+
+// ======================================================================================
+// Exact stage for a list of rows held by one workgroup.
+//   phase 1 (thread per row): if the filter margin is decisive, exact score of the single
+//           candidate; else queue the row for
+//   phase 2 (whole workgroup per queued row): exact score of ALL K_max components, first
+//           maximum (np.argmax) -- the reference's own computation, verbatim.
+// Results: sc[i] (double, widened), kb[i].  ids[i] < 0 -> sc = -inf, kb = -1.
+// ======================================================================================
+template <typename XT>
+__device__ void exact_rows(const segk_corpus &c, const segk_kmeans &m, const int32_t *ids_lds, int n,
+                           const int32_t *cand_k, const float *cand_f, double *sc, int32_t *kb,
+                           int32_t *queue, int32_t *qn, XT *xrow, double *red_v, int32_t *red_k,
+                           int32_t *n_brute)
+{
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const XT *X = (const XT *)c.X;
+    const XT *means = (const XT *)m.means;
+    const int D = c.D;
+    const float M = (float)(*m.mnorm_max);
+    if (tid == 0) *qn = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += nt) {
+        int32_t id = ids_lds[i];
+        double v = NEG_INF_D;
+        int32_t k = -1;
+        if (id >= 0) {
+            int32_t k1 = cand_k[id];
+            float f1 = cand_f[2 * (int64_t)id], f2 = cand_f[2 * (int64_t)id + 1];
+            float tau = filter_tau(c.xnorm[id], M, D, c.x_dtype);
+            if (f1 - f2 > tau) {
+                v = (double)neg_sqd_exact<XT>(means + (int64_t)k1 * D, X + (int64_t)id * c.ldx, D);
+                k = k1;
+            } else {
+                int q = atomicAdd(qn, 1);
+                queue[q] = i;
+            }
+        }
+        sc[i] = v;
+        kb[i] = k;
+    }
+    __syncthreads();
+    const int nq = *qn;
+    for (int q = 0; q < nq; q++) {
+        const int i = queue[q];
+        const int32_t id = ids_lds[i];
+        for (int d = tid; d < D; d += nt) xrow[d] = X[(int64_t)id * c.ldx + d];
+        __syncthreads();
+        XT best = (XT)NEG_INF_D;
+        int32_t bk = 0x7fffffff;
+        for (int k = tid; k < m.K_max; k += nt) {
+            XT s = neg_sqd_exact<XT>(means + (int64_t)k * D, xrow, D);
+            if (s > best || bk == 0x7fffffff) { best = s; bk = k; }   // first max within the thread
+        }
+        red_v[tid] = (double)best;
+        red_k[tid] = bk;
+        __syncthreads();
+        for (int o = nt >> 1; o > 0; o >>= 1) {
+            if (tid < o) {
+                double v2 = red_v[tid + o];
+                int32_t k2 = red_k[tid + o];
+                bool take = (k2 != 0x7fffffff) &&
+                            (red_k[tid] == 0x7fffffff || v2 > red_v[tid] || (v2 == red_v[tid] && k2 < red_k[tid]));
+                if (take) { red_v[tid] = v2; red_k[tid] = k2; }
+            }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            sc[i] = red_v[0];
+            kb[i] = red_k[0];
+        }
+        __syncthreads();
+    }
+    if (tid == 0 && nq > 0 && n_brute) atomicAdd(n_brute, nq);
+}
+
+// A1 exact for arbitrary rows (API: segk_kmeans_exact_max)
+template <typename XT>
+__global__ void k_kmeans_exact_max(segk_corpus c, segk_kmeans m, const int32_t *ids, int64_t n,
+                                   const int32_t *cand_k, const float *cand_f, double *out_max,
+                                   int32_t *out_arg, int32_t *n_brute)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nt = blockDim.x;
+    double *sc = (double *)smem;
+    double *red_v = sc + nt;
+    XT *xrow = (XT *)(red_v + nt);
+    int32_t *kb = (int32_t *)(xrow + ((c.D + 1) & ~1));
+    int32_t *ids_l = kb + nt;
+    int32_t *queue = ids_l + nt;
+    int32_t *red_k = queue + nt;
+    int32_t *qn = red_k + nt;
+    const int64_t r0 = (int64_t)blockIdx.x * nt;
+    int cnt = (int)((n - r0) < nt ? (n - r0) : nt);
+    for (int i = threadIdx.x; i < cnt; i += nt) ids_l[i] = ids ? ids[r0 + i] : (int32_t)(r0 + i);
+    __syncthreads();
+    exact_rows<XT>(c, m, ids_l, cnt, cand_k, cand_f, sc, kb, queue, qn, xrow, red_v, red_k, n_brute);
+    __syncthreads();
+    for (int i = threadIdx.x; i < cnt; i += nt) {
+        out_max[r0 + i] = sc[i];
+        out_arg[r0 + i] = kb[i];
+    }
+}
+
+// A1 full vector for one row (API: segk_kmeans_neg_sqrd_norm)
+template <typename XT>
+__global__ void k_kmeans_neg_sqrd_norm(segk_corpus c, segk_kmeans m, int64_t row, XT *out)
+{
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= m.K_max) return;
+    out[k] = neg_sqd_exact<XT>((const XT *)m.means + (int64_t)k * c.D, (const XT *)c.X + row * c.ldx, c.D);
+}
+
+// ======================================================================================
+// Per-utterance kernel: exact scores of the band of candidate spans, A5, A8, tokens.
+//   band layout: entry (t, w), t = 1..N (span end), w = 0..W-1 (span length w+1, start
+//   s = t-1-w) at [(t-1)*W + w]; W = n_slices_max, or N when n_slices_max == 0.
+// ======================================================================================
+template <typename XT>
+__global__ void k_kmeans_segment(segk_corpus c, segk_kmeans m, const int32_t *utts, int utt0, int n_min, int n_max,
+                                 double wip, const int32_t *cand_k, const float *cand_f,
+                                 uint8_t *boundaries, int32_t *old_tok, int32_t *new_tok, int32_t *new_k,
+                                 int32_t *n_old, int32_t *n_new, double *out_total, int32_t *status,
+                                 int band_cap)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int u = utts ? utts[blockIdx.x] : utt0 + (int)blockIdx.x;
+    const int N = c.lengths[u];
+    const int W = (n_max > 0 && n_max < N) ? n_max : N;
+    const int nb = N * W;
+    const int64_t triMax = (int64_t)c.N_max * (c.N_max + 1) / 2;
+    const int32_t *vid = c.vec_ids + (int64_t)u * triMax;
+    const double *dur = c.durations + (int64_t)u * triMax;
+
+    double *bvec = (double *)smem;                    // [band_cap]
+    double *gam = bvec + band_cap;                    // [N_max + 1]
+    double *red_v = gam + (c.N_max + 1);              // [nt]
+    XT *xrow = (XT *)(red_v + nt);                    // [D]
+    int32_t *bk = (int32_t *)(xrow + ((c.D + 1) & ~1));   // [band_cap]
+    int32_t *bid = bk + band_cap;                     // [band_cap]
+    int32_t *queue = bid + band_cap;                  // [band_cap]
+    int32_t *red_k = queue + band_cap;                // [nt]
+    int32_t *qn = red_k + nt;                         // [1]
+
+    for (int i = tid; i < nb; i += nt) {
+        int t = i / W + 1, w = i % W, s = t - 1 - w;
+        bid[i] = (s >= 0) ? vid[t * (t - 1) / 2 + s] : -1;
+    }
+    __syncthreads();
+    exact_rows<XT>(c, m, bid, nb, cand_k, cand_f, bvec, bk, queue, qn, xrow, red_v, red_k, status + 1);
+    __syncthreads();
+    // A5: scale by duration, NaN duration -> -inf, + wip   (kmeans_acoustic_wordseg.py:346-351)
+    for (int i = tid; i < nb; i += nt) {
+        int t = i / W + 1, w = i % W, s = t - 1 - w;
+        double v = NEG_INF_D;
+        if (s >= 0 && bid[i] >= 0) {
+            double dd = dur[t * (t - 1) / 2 + s];
+            v = isnan(dd) ? NEG_INF_D : bvec[i] * dd;
+        }
+        bvec[i] = v + wip;
+    }
+    __syncthreads();
+    if (tid != 0) return;
+
+    // ---- old tokens (utterances.py:159-174) before the boundaries are overwritten
+    uint8_t *bnd = boundaries + (int64_t)u * c.N_max;
+    {
+        int no = 0, jp = 0;
+        for (int j = 0; j < N; j++)
+            if (bnd[j]) {
+                int id = vid[(j + 1) * j / 2 + jp];
+                if (id >= 0) old_tok[(int64_t)u * c.N_max + no++] = id;
+                jp = j + 1;
+            }
+        n_old[u] = no;
+    }
+    // ---- A8 forward (kmeans_acoustic_wordseg.py:494-506).  V(t,s) = bvec[(t-1)*W + (t-1-s)]
+#define V_(t, s) bvec[((t) - 1) * W + ((t) - 1 - (s))]
+    gam[0] = 0.0;
+    for (int t = 1; t < N; t++) {
+        int lo = t - W < 0 ? 0 : t - W;
+        double best = NEG_INF_D;
+        for (int s = lo; s < t; s++) {
+            double v = V_(t, s) + gam[s];
+            if (v > best) best = v;
+        }
+        gam[t] = best;
+    }
+    for (int j = 0; j < N; j++) bnd[j] = 0;
+    bnd[N - 1] = 1;
+    // ---- A8 backward (:510-553)
+    int t = N;
+    double total = 0.0;
+    int lo = 0;
+    for (;;) {
+        lo = t - W < 0 ? 0 : t - W;
+        bool all_inf = true;
+        for (int s = lo; s < t; s++)
+            if (V_(t, s) + gam[s] != NEG_INF_D) { all_inf = false; break; }
+        if (all_inf) {
+            while (all_inf) {
+                t = t - 1;
+                if (t == 0) break;
+                lo = t - W < 0 ? 0 : t - W;
+                all_inf = true;
+                for (int s = lo; s < t; s++)
+                    if (V_(t, s) + gam[s] != NEG_INF_D) { all_inf = false; break; }
+            }
+            bnd[(t - 1 + N) % N] = 1;
+        }
+        int k = 1;
+        if (t > 0) {
+            double best = NEG_INF_D;
+            bool first = true;
+            for (int s = t - 1; s >= lo; s--) {
+                double v = V_(t, s) + gam[s];
+                if (first || v > best) { best = v; k = t - s; first = false; }
+            }
+            total += V_(t, t - k);
+        } else {
+            total += V_(N, N - 1);      // python vec[-1]: the last span [N-1, N)
+        }
+        if (t - k - 1 < 0) break;
+        bnd[t - k - 1] = 1;
+        t = t - k;
+    }
+    out_total[u] = total;
+    // ---- new tokens + their best components (:312-313)
+    {
+        int nn = 0, jp = 0, bad = 0;
+        for (int j = 0; j < N; j++)
+            if (bnd[j]) {
+                int tt = j + 1, s = jp;
+                int id = vid[tt * (tt - 1) / 2 + s];
+                int w = tt - 1 - s;
+                if (id < 0 || w >= W) bad = 1;
+                else {
+                    new_tok[(int64_t)u * c.N_max + nn] = id;
+                    new_k[(int64_t)u * c.N_max + nn] = bk[(tt - 1) * W + w];
+                    nn++;
+                }
+                jp = j + 1;
+            }
+        n_new[u] = nn;
+        if (bad) atomicOr(status, 1);
+    }
+#undef V_
+}
+
+// ======================================================================================
+// A11 sequential: del_item / add_item / clean_components for ONE utterance, one workgroup,
+// thread d owns dimension d (kmeans_components.py:93-166, 263-266).
+// ======================================================================================
+template <typename XT>
+__device__ void dev_del_component(const segk_corpus &c, segk_kmeans &m, int k, int *shK)
+{
+    // caller guarantees uniform control flow; K already decremented into *shK by thread 0
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int D = c.D;
+    const int K = *shK;
+    XT *means = (XT *)m.means;
+    const XT *rnd = (const XT *)m.random_means;
+    if (k != K) {
+        const double cntK = (double)m.counts[K];
+        for (int d = tid; d < D; d += nt) {
+            double v = m.mean_numerators[(int64_t)K * D + d];
+            m.mean_numerators[(int64_t)k * D + d] = v;
+            means[(int64_t)k * D + d] = (XT)(v / cntK);
+        }
+        for (int64_t e = tid; e < c.n_emb; e += nt)
+            if (m.assignments[e] == K) m.assignments[e] = k;
+    }
+    __syncthreads();
+    for (int d = tid; d < D; d += nt) {
+        m.mean_numerators[(int64_t)K * D + d] = 0.0;
+        means[(int64_t)K * D + d] = rnd[(int64_t)K * D + d];
+    }
+    if (tid == 0) {
+        if (k != K) m.counts[k] = m.counts[K];
+        m.counts[K] = 0;
+    }
+    __syncthreads();
+}
+
+template <typename XT>
+__device__ void dev_clean_components(const segk_corpus &c, segk_kmeans &m, int *shK, int *sh_i)
+{
+    const int K0 = *shK;
+    for (int k = K0 - 1; k >= 0; k--) {
+        if (threadIdx.x == 0) *sh_i = (m.counts[k] == 0) ? 1 : 0;
+        __syncthreads();
+        const int empty = *sh_i;
+        __syncthreads();
+        if (empty) {
+            if (threadIdx.x == 0) *shK = *shK - 1;
+            __syncthreads();
+            dev_del_component<XT>(c, m, k, shK);
+        }
+    }
+}
+
+template <typename XT>
+__device__ void dev_add_item(const segk_corpus &c, segk_kmeans &m, int64_t e, int k_in, int *shK, int *sh_i,
+                             int64_t *sh_l, int32_t *status)
+{
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int D = c.D;
+    if (tid == 0) {
+        int k = k_in;
+        int K = *shK;
+        if (k > K) k = K;
+        if (k == K) *shK = K + 1;
+        if (m.assignments[e] != -1) atomicOr(status, 2);     // kmeans_components.py:101 assert
+        m.counts[k] += 1;
+        m.assignments[e] = k;
+        *sh_i = k;
+        *sh_l = m.counts[k];
+    }
+    __syncthreads();
+    const int k = *sh_i;
+    const double cnt = (double)*sh_l;
+    const XT *X = (const XT *)c.X;
+    XT *means = (XT *)m.means;
+    for (int d = tid; d < D; d += nt) {
+        double v = m.mean_numerators[(int64_t)k * D + d] + (double)X[e * c.ldx + d];
+        m.mean_numerators[(int64_t)k * D + d] = v;
+        means[(int64_t)k * D + d] = (XT)(v / cnt);
+    }
+    __syncthreads();
+}
+
+template <typename XT>
+__device__ void dev_del_item(const segk_corpus &c, segk_kmeans &m, int64_t e, int *sh_i, int64_t *sh_l)
+{
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int D = c.D;
+    if (tid == 0) {
+        int k = m.assignments[e];
+        if (k != -1) {
+            m.counts[k] -= 1;
+            m.assignments[e] = -1;
+            *sh_l = m.counts[k];
+        }
+        *sh_i = k;
+    }
+    __syncthreads();
+    const int k = *sh_i;
+    if (k != -1) {
+        const int64_t cnt = *sh_l;
+        const XT *X = (const XT *)c.X;
+        XT *means = (XT *)m.means;
+        for (int d = tid; d < D; d += nt) {
+            double v = m.mean_numerators[(int64_t)k * D + d] - (double)X[e * c.ldx + d];
+            m.mean_numerators[(int64_t)k * D + d] = v;
+            if (cnt != 0) means[(int64_t)k * D + d] = (XT)(v / (double)cnt);
+        }
+    }
+    __syncthreads();
+}
+
+// op: 0 = utterance update (del old, add new, clean), 1 = add_item(i,k), 2 = del_item(i),
+//     3 = clean_components
+template <typename XT>
+__global__ void k_kmeans_update(segk_corpus c, segk_kmeans m, int op, int utt, int64_t item, int k_item,
+                                const int32_t *old_tok, const int32_t *new_tok, const int32_t *new_k,
+                                const int32_t *n_old, const int32_t *n_new, int32_t *status)
+{
+    __shared__ int shK, sh_i;
+    __shared__ int64_t sh_l;
+    if (threadIdx.x == 0) shK = *m.K;
+    __syncthreads();
+    if (op == 0) {
+        const int no = n_old[utt], nn = n_new[utt];
+        for (int t = 0; t < no; t++) dev_del_item<XT>(c, m, old_tok[(int64_t)utt * c.N_max + t], &sh_i, &sh_l);
+        for (int t = 0; t < nn; t++)
+            dev_add_item<XT>(c, m, new_tok[(int64_t)utt * c.N_max + t], new_k[(int64_t)utt * c.N_max + t],
+                             &shK, &sh_i, &sh_l, status);
+        dev_clean_components<XT>(c, m, &shK, &sh_i);
+    } else if (op == 1) {
+        dev_add_item<XT>(c, m, item, k_item, &shK, &sh_i, &sh_l, status);
+    } else if (op == 2) {
+        dev_del_item<XT>(c, m, item, &sh_i, &sh_l);
+    } else if (op == 3) {
+        dev_clean_components<XT>(c, m, &shK, &sh_i);
+    } else if (op == 4) {     // del_component(k_item)  (kmeans_components.py:149-166)
+        if (threadIdx.x == 0) shK = shK - 1;
+        __syncthreads();
+        dev_del_component<XT>(c, m, k_item, &shK);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *m.K = shK;
+}
+
+// ======================================================================================
+// A11 batch-synchronous statistics (spec: oracle/np_oracle.py kmeans_batch_sweep)
+// ======================================================================================
+// (1a) delete all old tokens of utterances [lo, hi)
+__global__ void k_batch_delete_old(segk_corpus c, segk_kmeans m, int lo, int hi, const int32_t *old_tok,
+                                   const int32_t *n_old)
+{
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t tot = (int64_t)(hi - lo) * c.N_max;
+    if (idx >= tot) return;
+    int u = lo + (int)(idx / c.N_max), t = (int)(idx % c.N_max);
+    if (t < n_old[u]) m.assignments[old_tok[(int64_t)u * c.N_max + t]] = -1;
+}
+
+// (1b) collect, in token order, the new tokens whose argmax is an inactive row (k >= K):
+//      flag_buf[0] = count, then (utt*N_max + t, k) pairs.  Single workgroup.
+__global__ void k_batch_collect_flags(segk_corpus c, segk_kmeans m, int lo, int hi, const int32_t *new_k,
+                                      const int32_t *n_new, int32_t *flag_buf, int cap)
+{
+    __shared__ int s_cnt;
+    __shared__ int s_wave[16];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int K = *m.K;
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+    // chunks of nt utterances; within a chunk ordered compaction by prefix sums
+    for (int u0 = lo; u0 < hi; u0 += nt) {
+        int u = u0 + tid;
+        int mine = 0;
+        if (u < hi)
+            for (int t = 0; t < n_new[u]; t++)
+                if (new_k[(int64_t)u * c.N_max + t] >= K) mine++;
+        // block exclusive scan of `mine`
+        int lane = tid & 63, wv = tid >> 6;
+        int incl = mine;
+        for (int o = 1; o < 64; o <<= 1) {
+            int v = __shfl_up(incl, o);
+            if (lane >= o) incl += v;
+        }
+        if (lane == 63) s_wave[wv] = incl;
+        __syncthreads();
+        int woff = 0;
+        for (int w2 = 0; w2 < wv; w2++) woff += s_wave[w2];
+        int total = 0;
+        for (int w2 = 0; w2 < (nt >> 6); w2++) total += s_wave[w2];
+        int off = s_cnt + woff + incl - mine;
+        if (mine > 0) {
+            for (int t = 0; t < n_new[u]; t++) {
+                int k = new_k[(int64_t)u * c.N_max + t];
+                if (k >= K) {
+                    if (off < cap) {
+                        flag_buf[1 + 2 * off] = u * c.N_max + t;
+                        flag_buf[2 + 2 * off] = k;
+                    }
+                    off++;
+                }
+            }
+        }
+        __syncthreads();
+        if (tid == 0) s_cnt += total;
+        __syncthreads();
+    }
+    if (tid == 0) flag_buf[0] = s_cnt;
+}
+
+// (1c) resolve the `k > K -> K` clamp over the flagged tokens of ALL ranks in rank order
+//      (flag_all = n_ranks buffers of stride 1+2*cap), rewrite the local new_k, set K, then
+//      write the assignments of the local new tokens.  Single workgroup.
+__global__ void k_batch_resolve(segk_corpus c, segk_kmeans m, int lo, int hi, const int32_t *flag_all,
+                                int n_ranks, int my_rank, int cap, const int32_t *new_tok, int32_t *new_k,
+                                const int32_t *n_new, int32_t *status)
+{
+    __shared__ int s_K;
+    if (threadIdx.x == 0) {
+        int K = *m.K;
+        for (int r = 0; r < n_ranks; r++) {
+            const int32_t *fb = flag_all + (int64_t)r * (1 + 2 * cap);
+            int cnt = fb[0];
+            if (cnt > cap) { atomicOr(status, 4); cnt = cap; }
+            for (int q = 0; q < cnt; q++) {
+                int k = fb[2 + 2 * q];
+                if (k > K) k = K;
+                if (k == K) K++;
+                if (r == my_rank) new_k[fb[1 + 2 * q]] = k;
+            }
+        }
+        s_K = K;
+        *m.K = K;
+    }
+    __syncthreads();
+    int64_t tot = (int64_t)(hi - lo) * c.N_max;
+    for (int64_t idx = threadIdx.x; idx < tot; idx += blockDim.x) {
+        int u = lo + (int)(idx / c.N_max), t = (int)(idx % c.N_max);
+        if (t < n_new[u]) {
+            int64_t p = (int64_t)u * c.N_max + t;
+            if (m.assignments[new_tok[p]] != -1) atomicOr(status, 2);
+            m.assignments[new_tok[p]] = new_k[p];
+        }
+    }
+}
+
+// (2) per statistics block and component: sequential fp64 sum over the block's tokens in
+//     token order.  One wave per (block, component); lanes own dimensions.
+template <typename XT>
+__global__ void k_batch_partials(segk_corpus c, segk_kmeans m, const int32_t *blk_lo, int n_blocks,
+                                 const int32_t *new_tok, const int32_t *new_k, const int32_t *n_new,
+                                 const double *out_total, double *part_sum, int64_t *part_cnt,
+                                 double *part_tot)
+{
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    const int b = wave / m.K_max, k = wave % m.K_max;
+    if (b >= n_blocks) return;
+    const int D = c.D;
+    const XT *X = (const XT *)c.X;
+    const int u0 = blk_lo[b], u1 = blk_lo[b + 1];
+    constexpr int MAXR = 8;                       // D <= 512 per pass
+    for (int d0 = 0; d0 < D; d0 += 64 * MAXR) {
+        double acc[MAXR];
+#pragma unroll
+        for (int r = 0; r < MAXR; r++) acc[r] = 0.0;
+        int64_t cnt = 0;
+        const int64_t s0 = (int64_t)u0 * c.N_max, s1 = (int64_t)u1 * c.N_max;
+        for (int64_t sb = s0; sb < s1; sb += 64) {
+            int64_t slot = sb + lane;
+            int match = 0, id = 0;
+            if (slot < s1) {
+                int u = (int)(slot / c.N_max), t = (int)(slot % c.N_max);
+                if (t < n_new[u] && new_k[slot] == k) { match = 1; id = new_tok[slot]; }
+            }
+            unsigned long long bal = __ballot(match);
+            while (bal) {
+                int src = __ffsll((long long)bal) - 1;
+                bal &= bal - 1;
+                int e = __shfl(id, src);
+                cnt++;
+#pragma unroll
+                for (int r = 0; r < MAXR; r++) {
+                    int d = d0 + r * 64 + lane;
+                    if (d < D) acc[r] += (double)X[(int64_t)e * c.ldx + d];
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < MAXR; r++) {
+            int d = d0 + r * 64 + lane;
+            if (d < D) part_sum[((int64_t)b * m.K_max + k) * D + d] = acc[r];
+        }
+        if (lane == 0 && d0 == 0) part_cnt[(int64_t)b * m.K_max + k] = cnt;
+    }
+    if (k == 0 && lane == 0) {
+        double s = 0.0;
+        for (int u = u0; u < u1; u++) s += out_total[u];
+        part_tot[b] = s;
+    }
+}
+
+// Partials of block b live at  base + (b / nbl) * rank_stride + (b % nbl) * blk_stride
+// (units: 8-byte words): `nbl` blocks per rank, packed rank after rank by the all-gather.
+struct PartAddr {
+    int nbl;
+    int64_t rank_stride, blk_stride;
+    __device__ __forceinline__ int64_t operator()(int b) const
+    {
+        return (int64_t)(b / nbl) * rank_stride + (int64_t)(b % nbl) * blk_stride;
+    }
+};
+
+__device__ __forceinline__ double tree_sum_d(const double *p, const PartAddr &pa, int n)
+{
+    // balanced binary tree over n parts, pairing neighbours level by level, odd one carried
+    double buf[64];
+    for (int i = 0; i < n; i++) buf[i] = p[pa(i)];
+    while (n > 1) {
+        int o = 0;
+        for (int i = 0; i + 1 < n; i += 2) buf[o++] = buf[i] + buf[i + 1];
+        if (n & 1) buf[o++] = buf[n - 1];
+        n = o;
+    }
+    return buf[0];
+}
+
+// (3a) combine the partials of all blocks, means = numerators / counts for active rows
+template <typename XT>
+__global__ void k_batch_combine(segk_corpus c, segk_kmeans m, const double *part_sum, const int64_t *part_cnt,
+                                const double *part_tot, int n_blocks, int nbl, int64_t rank_stride,
+                                double *out_scalars)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int D = c.D;
+    const int K = *m.K;
+    const PartAddr pa_sum{nbl, rank_stride, (int64_t)m.K_max * D};
+    const PartAddr pa_cnt{nbl, rank_stride, (int64_t)m.K_max};
+    const PartAddr pa_tot{nbl, rank_stride, 1};
+    if (idx < (int64_t)m.K_max * D) {
+        int k = (int)(idx / D);
+        double v = tree_sum_d(part_sum + idx, pa_sum, n_blocks);
+        int64_t cnt = 0;
+        for (int b = 0; b < n_blocks; b++) cnt += part_cnt[pa_cnt(b) + k];
+        m.mean_numerators[idx] = v;
+        if (k < K && cnt != 0) ((XT *)m.means)[idx] = (XT)(v / (double)cnt);
+        if (idx % D == 0) m.counts[k] = cnt;
+    }
+    if (idx == 0) {
+        out_scalars[0] = tree_sum_d(part_tot, pa_tot, n_blocks);
+        int64_t ntok = 0;
+        for (int b = 0; b < n_blocks; b++)
+            for (int k = 0; k < m.K_max; k++) ntok += part_cnt[pa_cnt(b) + k];
+        out_scalars[2] = (double)ntok;
+    }
+}
+
+// (3b) clean_components with a relabel table instead of a scan per deletion.  Single
+//      workgroup; remap [K_max] int32 scratch.
+template <typename XT>
+__global__ void k_batch_clean(segk_corpus c, segk_kmeans m, int32_t *remap, double *out_scalars)
+{
+    __shared__ int shK, sh_e;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int D = c.D;
+    XT *means = (XT *)m.means;
+    const XT *rnd = (const XT *)m.random_means;
+    for (int k = tid; k < m.K_max; k += nt) remap[k] = k;
+    if (tid == 0) shK = *m.K;
+    __syncthreads();
+    const int K0 = shK;
+    for (int k = K0 - 1; k >= 0; k--) {
+        if (tid == 0) sh_e = (m.counts[k] == 0) ? 1 : 0;
+        __syncthreads();
+        const int empty = sh_e;
+        __syncthreads();
+        if (!empty) continue;
+        if (tid == 0) shK = shK - 1;
+        __syncthreads();
+        const int K = shK;
+        if (k != K) {
+            const double cntK = (double)m.counts[K];
+            for (int d = tid; d < D; d += nt) {
+                double v = m.mean_numerators[(int64_t)K * D + d];
+                m.mean_numerators[(int64_t)k * D + d] = v;
+                means[(int64_t)k * D + d] = (XT)(v / cntK);
+            }
+            // whichever ORIGINAL labels currently live in row K now live in row k
+            for (int q = tid; q < m.K_max; q += nt)
+                if (remap[q] == K) remap[q] = k;
+        }
+        __syncthreads();
+        for (int d = tid; d < D; d += nt) {
+            m.mean_numerators[(int64_t)K * D + d] = 0.0;
+            means[(int64_t)K * D + d] = rnd[(int64_t)K * D + d];
+        }
+        if (tid == 0) {
+            if (k != K) m.counts[k] = m.counts[K];
+            m.counts[K] = 0;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        *m.K = shK;
+        out_scalars[1] = (double)shK;
+    }
+}
+
+// (3c) relabel the assignments of the local new tokens through remap
+__global__ void k_batch_relabel(segk_corpus c, segk_kmeans m, int lo, int hi, const int32_t *new_tok,
+                                const int32_t *n_new, const int32_t *remap)
+{
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t tot = (int64_t)(hi - lo) * c.N_max;
+    if (idx >= tot) return;
+    int u = lo + (int)(idx / c.N_max), t = (int)(idx % c.N_max);
+    if (t < n_new[u]) {
+        int e = new_tok[(int64_t)u * c.N_max + t];
+        m.assignments[e] = remap[m.assignments[e]];
+    }
+}
+
+// sum_neg_sqrd_norm record metric (kmeans_components.py:234-247); tolerance-level parity
+template <typename XT>
+__global__ void k_kmeans_sum_neg_sqrd_norm(segk_corpus c, segk_kmeans m, double *out)
+{
+    const int64_t e = (int64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    double s = 0.0;
+    if (e < c.n_emb) {
+        int k = m.assignments[e];
+        if (k >= 0) {
+            double cnt = (double)m.counts[k];
+            for (int d = lane; d < c.D; d += 64) {
+                double delta = m.mean_numerators[(int64_t)k * c.D + d] / cnt
+                               - (double)((const XT *)c.X)[e * c.ldx + d];
+                s += delta * delta;
+            }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    __shared__ double part[16];
+    if (lane == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tot = 0.0;
+        for (int w = 0; w < (int)(blockDim.x / 64); w++) tot += part[w];
+        if (tot != 0.0) atomicAdd(out, -tot);
+    }
+}
+
+// ======================================================================================
+// KMeansComponents.__init__ (kmeans_components.py:59-81): add_item(i, k) for k ascending and
+// i ascending within k == per component a sequential fp64 sum over its items in ascending
+// row order.  One wave per component scans `assignments`.
+// ======================================================================================
+template <typename XT>
+__global__ void k_kmeans_init_stats(segk_corpus c, segk_kmeans m)
+{
+    const int k = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (k >= m.K_max) return;
+    const int D = c.D;
+    const XT *X = (const XT *)c.X;
+    XT *means = (XT *)m.means;
+    const XT *rnd = (const XT *)m.random_means;
+    constexpr int MAXR = 8;
+    for (int d0 = 0; d0 < D; d0 += 64 * MAXR) {
+        double acc[MAXR];
+#pragma unroll
+        for (int r = 0; r < MAXR; r++) acc[r] = 0.0;
+        int64_t cnt = 0;
+        for (int64_t e0 = 0; e0 < c.n_emb; e0 += 64) {
+            int64_t e = e0 + lane;
+            int match = (e < c.n_emb) && (m.assignments[e] == k);
+            unsigned long long bal = __ballot(match);
+            while (bal) {
+                int src = __ffsll((long long)bal) - 1;
+                bal &= bal - 1;
+                int64_t ee = e0 + src;
+                cnt++;
+#pragma unroll
+                for (int r = 0; r < MAXR; r++) {
+                    int d = d0 + r * 64 + lane;
+                    if (d < D) acc[r] += (double)X[ee * c.ldx + d];
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < MAXR; r++) {
+            int d = d0 + r * 64 + lane;
+            if (d < D) {
+                m.mean_numerators[(int64_t)k * D + d] = acc[r];
+                means[(int64_t)k * D + d] = cnt ? (XT)(acc[r] / (double)cnt) : rnd[(int64_t)k * D + d];
+            }
+        }
+        if (lane == 0 && d0 == 0) {
+            m.counts[k] = cnt;
+            if (cnt) atomicMax(m.K, k + 1);
+        }
+    }
+}
+
+// ======================================================================================
+// Function-level DPs on caller-supplied vectors (drop-in for the module functions
+// forward_backward_kmeans_viterbi / forward_backward / forward_backward_viterbi):
+// one thread per problem, triangular layout exactly as the reference receives it.
+//   kind 0: A8 max-plus (kmeans_acoustic_wordseg.py:449-555)
+//   kind 1: A7 viterbi  (unigram_acoustic_wordseg.py:759-864)
+//   kind 2: A6 forward filtering / backward sampling (:653-756), uniforms supplied
+// ======================================================================================
+__device__ double dev_logsumexp(const double *a, int n)      // _cython_utils.pyx:13-25
+{
+    double mx = a[0], s = 0.0;
+    for (int j = 1; j < n; j++)
+        if (a[j] > mx) mx = a[j];
+    for (int j = 0; j < n; j++) s += exp(a[j] - mx);
+    return log(s) + mx;
+}
+
+__global__ void k_dp_tri(int kind, const double *vecs, const int32_t *Ns, const int64_t *offs, int n_prob,
+                         int n_min, int n_max, double log_p_continue, double anneal_temp,
+                         const double *uniforms, int64_t u_stride, uint8_t *bounds, int64_t b_stride,
+                         double *totals, int32_t *n_draws, int32_t *status, double *work, int64_t w_stride)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_prob) return;
+    const int N = Ns[p];
+    const double *vec = vecs + offs[p];
+    const int64_t L = (int64_t)N * (N + 1) / 2;
+    uint8_t *bnd = bounds + p * b_stride;
+    double *a = work + p * w_stride;            // [N]
+    double *w = a + N;                          // [N+1]
+    double *pr = w + N + 1;                     // [N+1]
+    const double *us = uniforms ? uniforms + p * u_stride : nullptr;
+    for (int j = 0; j < N; j++) { a[j] = 1.0; bnd[j] = 0; }
+    bnd[N - 1] = 1;
+    a[0] = 0.0;
+    int64_t i = 0;
+    for (int t = 1; t < N; t++) {
+        int lo = (n_max == 0 || t - n_max < 0) ? 0 : t - n_max;
+        int n = t - lo;
+        bool all_inf = true;
+        double best = NEG_INF_D;
+        for (int s = lo; s < t; s++) {
+            double v = vec[i + s] + a[s];
+            w[s - lo] = v;
+            if (v != NEG_INF_D) all_inf = false;
+            if (v > best) best = v;
+        }
+        if (kind == 2) a[t] = all_inf ? NEG_INF_D : dev_logsumexp(w, n) + log_p_continue;
+        else a[t] = best;
+        i += t;
+    }
+    int t = N, nd = 0, lo = 0;
+    double total = 0.0;
+    for (;;) {
+        i = (int64_t)(t - 1) * t / 2;
+        lo = (n_max == 0 || t - n_max < 0) ? 0 : t - n_max;
+        bool all_inf = true;
+        for (int s = lo; s < t; s++)
+            if (vec[i + s] + a[s] != NEG_INF_D) { all_inf = false; break; }
+        if (all_inf) {
+            while (all_inf) {
+                t = t - 1;
+                if (t == 0) break;
+                i = (int64_t)(t - 1) * t / 2;
+                lo = (n_max == 0 || t - n_max < 0) ? 0 : t - n_max;
+                all_inf = true;
+                for (int s = lo; s < t; s++)
+                    if (vec[i + s] + a[s] != NEG_INF_D) { all_inf = false; break; }
+            }
+            bnd[(t - 1 + N) % N] = 1;
+        }
+        int k = 1;
+        int n = 1;
+        if (t > 0) {
+            n = t - lo;
+            for (int s = lo; s < t; s++) w[s - lo] = vec[i + s] + a[s];
+        } else {
+            w[0] = NEG_INF_D;
+        }
+        if (kind == 0) {
+            if (t > 0) {
+                double best = NEG_INF_D;
+                bool first = true;
+                for (int s = t - 1; s >= lo; s--) {
+                    double v = w[s - lo];
+                    if (first || v > best) { best = v; k = t - s; first = false; }
+                }
+            }
+        } else if (kind == 1) {
+            if (t > 0) {
+                double lse = dev_logsumexp(w, n);
+                double best = 0.0;
+                bool first = true;
+                for (int s = t - 1; s >= lo; s--) {
+                    double q = exp(w[s - lo] - lse);
+                    if (first || q > best) { best = q; k = t - s; first = false; }
+                }
+            }
+        } else {
+            double lse = dev_logsumexp(w, n);
+            if (anneal_temp != 1.0) {
+                for (int j = 0; j < n; j++) pr[j] = w[n - 1 - j] - lse;
+                double inv = 1. / anneal_temp;
+                for (int j = 0; j < n; j++) w[j] = inv * pr[j];
+                double lse2 = dev_logsumexp(w, n);
+                for (int j = 0; j < n; j++) pr[j] = exp(w[j] - lse2);
+            } else {
+                for (int j = 0; j < n; j++) pr[j] = exp(w[n - 1 - j] - lse);
+            }
+            double uu = us[nd];
+            nd++;
+            int kk = n - 1;
+            for (int j = 0; j < n; j++) {
+                uu = uu - pr[j];
+                if (uu < 0) { kk = j; break; }
+            }
+            k = kk + 1;
+        }
+        int64_t idx = i + t - k;
+        if (idx < 0) idx += L;
+        total += vec[idx];
+        if (t - k - 1 < 0) break;
+        bnd[t - k - 1] = 1;
+        t = t - k;
+    }
+    totals[p] = total;
+    if (n_draws) n_draws[p] = nd;
+    if (status) status[p] = (kind == 2 && total == NEG_INF_D) ? 1 : 0;
+}
+
+// ======================================================================================
+// C ABI
+// ======================================================================================
+#define DISPATCH_XT(c, ...)                         \
+    do {                                            \
+        if ((c)->x_dtype == SEGK_F32) {             \
+            typedef float XT;                       \
+            __VA_ARGS__                             \
+        } else {                                    \
+            typedef double XT;                      \
+            __VA_ARGS__                             \
+        }                                           \
+    } while (0)
+
+static int check_corpus(const segk_corpus *c)
+{
+    SEGK_REQUIRE(c != nullptr, "corpus is NULL");
+    SEGK_REQUIRE(c->x_dtype == SEGK_F32 || c->x_dtype == SEGK_F64, "x_dtype");
+    SEGK_REQUIRE(c->D > 0 && c->n_emb > 0, "empty corpus");
+    SEGK_REQUIRE(c->ld32 % 4 == 0 && c->ld32 >= c->D, "ld32 must be D rounded up to a multiple of 4");
+    return SEGK_OK;
+}
+
+template <int GMAX, int NB>
+static int launch_score(const segk_corpus *c, const segk_kmeans *m, const int32_t *ids, int64_t row0, int64_t n,
+                        int32_t *cand_k, float *cand_f, hipStream_t st)
+{
+    const int stride = segk_tile_stride(c->D);
+    const size_t lds = 2 * (size_t)stride * sizeof(float);
+    const int rows_per_wg = 4 * 32 * NB;
+    const int64_t grid = (n + rows_per_wg - 1) / rows_per_wg;
+    if (lds > 48 * 1024)
+        SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_kmeans_score<GMAX, NB>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_kmeans_score<GMAX, NB>), dim3((unsigned)grid), dim3(256), lds, st, c->X32, c->ld32, ids,
+                       row0, n, m->tiles, segk_n_tiles(m->K_max), stride, segk_G(c->D), cand_k, cand_f);
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+extern "C" {
+
+int64_t segk_kmeans_tiles_floats(int32_t K_max, int32_t D)
+{
+    return (int64_t)segk_n_tiles(K_max) * segk_tile_stride(D);
+}
+
+int32_t segk_corpus_prepare(segk_ctx *ctx, const segk_corpus *c, float *X32_out, float *xnorm_out, void *stream)
+{
+    (void)ctx;
+    int rc = check_corpus(c);
+    if (rc) return rc;
+    SEGK_REQUIRE(xnorm_out != nullptr, "xnorm_out is NULL");
+    hipStream_t st = (hipStream_t)stream;
+    int64_t nblk = (c->n_emb + 3) / 4;
+    DISPATCH_XT(c, hipLaunchKernelGGL(k_corpus_prepare<XT>, dim3((unsigned)nblk), dim3(256), 0, st,
+                                       (const XT *)c->X, c->ldx, c->n_emb, c->D, c->ld32, X32_out, xnorm_out););
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+int32_t segk_kmeans_prepare(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m, void *stream)
+{
+    (void)ctx;
+    int rc = check_corpus(c);
+    if (rc) return rc;
+    SEGK_REQUIRE(m && m->tiles && m->mnorm_max, "kmeans tiles/mnorm_max");
+    hipStream_t st = (hipStream_t)stream;
+    // mnorm_max doubles as the atomicMax scratch (bits of |m|^2), finished in place
+    SEGK_CHECK_HIP(hipMemsetAsync(m->mnorm_max, 0, sizeof(double), st));
+    DISPATCH_XT(c, hipLaunchKernelGGL(k_kmeans_prepare<XT>, dim3(segk_n_tiles(m->K_max)), dim3(256), 0, st,
+                                       (const XT *)m->means, m->K_max, c->D, m->tiles,
+                                       (unsigned long long *)m->mnorm_max););
+    hipLaunchKernelGGL(k_mnorm_finish, dim3(1), dim3(1), 0, st, (const unsigned long long *)m->mnorm_max,
+                       m->mnorm_max);
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+int32_t segk_kmeans_score(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m, const int32_t *ids,
+                          int64_t row0, int64_t n, int32_t *cand_k, float *cand_f, void *stream)
+{
+    (void)ctx;
+    int rc = check_corpus(c);
+    if (rc) return rc;
+    SEGK_REQUIRE(m && m->tiles && cand_k && cand_f && c->X32, "score operands");
+    SEGK_REQUIRE(ids != nullptr || (row0 >= 0 && row0 + n <= c->n_emb), "row range");
+    if (n <= 0) return SEGK_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int G = segk_G(c->D);
+    if (G <= 26) return launch_score<26, 2>(c, m, ids, row0, n, cand_k, cand_f, st);
+    if (G <= 34) return launch_score<34, 2>(c, m, ids, row0, n, cand_k, cand_f, st);
+    if (G <= 50) return launch_score<50, 1>(c, m, ids, row0, n, cand_k, cand_f, st);
+    if (G <= 100) return launch_score<100, 1>(c, m, ids, row0, n, cand_k, cand_f, st);
+    segk_set_error("segk_kmeans_score: D=%d > 400 is not supported by the register-resident score kernel", c->D);
+    return SEGK_ERR_UNSUPPORTED;
+}
+
+int32_t segk_kmeans_exact_max(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m, const int32_t *ids,
+                              int64_t n, const int32_t *cand_k, const float *cand_f, double *out_max,
+                              int32_t *out_arg, int32_t *out_n_bruteforce, void *stream)
+{
+    (void)ctx;
+    int rc = check_corpus(c);
+    if (rc) return rc;
+    if (n <= 0) return SEGK_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int nt = 256;
+    size_t xsz = (c->x_dtype == SEGK_F32 ? 4 : 8) * (size_t)((c->D + 1) & ~1);
+    size_t lds = 2 * nt * sizeof(double) + xsz + (4 * nt + 4) * sizeof(int32_t);
+    int64_t grid = (n + nt - 1) / nt;
+    DISPATCH_XT(c, hipLaunchKernelGGL(k_kmeans_exact_max<XT>, dim3((unsigned)grid), dim3(nt), lds, st, *c, *m, ids,
+                                       n, cand_k, cand_f, out_max, out_arg, out_n_bruteforce););
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+int32_t segk_kmeans_neg_sqrd_norm(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m, int64_t row,
+                                  void *out, void *stream)
+{
+    (void)ctx;
+    int rc = check_corpus(c);
+    if (rc) return rc;
+    SEGK_REQUIRE(row >= 0 && row < c->n_emb, "row out of range");
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_XT(c, hipLaunchKernelGGL(k_kmeans_neg_sqrd_norm<XT>, dim3((m->K_max + 255) / 256), dim3(256), 0, st,
+                                       *c, *m, row, (XT *)out););
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+int32_t segk_kmeans_segment(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m, const int32_t *utts,
+                            int32_t utt0, int32_t n_utts, int32_t n_slices_min, int32_t n_slices_max, double wip,
+                            const int32_t *cand_k, const float *cand_f, uint8_t *boundaries, int32_t *old_tok,
+                            int32_t *new_tok, int32_t *new_k, int32_t *n_old, int32_t *n_new, double *out_total,
+                            int32_t *status, void *stream)
+{
+    (void)ctx;
+    int rc = check_corpus(c);
+    if (rc) return rc;
+    SEGK_REQUIRE(n_slices_min == 0 || n_slices_min == 1,
+                 "n_slices_min must be 0 or 1 (>= 2 crashes in the reference, SURVEY 8(c))");
+    SEGK_REQUIRE(n_slices_max >= 0, "n_slices_max");
+    SEGK_REQUIRE(utts != nullptr || (utt0 >= 0 && utt0 + n_utts <= c->n_utt), "utterance range");
+    if (n_utts <= 0) return SEGK_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int nt = 256;
+    const int W = (n_slices_max > 0 && n_slices_max < c->N_max) ? n_slices_max : c->N_max;
+    const int band_cap = c->N_max * W;
+    size_t xsz = (c->x_dtype == SEGK_F32 ? 4 : 8) * (size_t)((c->D + 1) & ~1);
+    size_t lds = (size_t)(band_cap + c->N_max + 1 + nt) * sizeof(double) + xsz
+                 + (size_t)(3 * band_cap + nt + 4) * sizeof(int32_t);
+    if (lds > 160 * 1024) {
+        segk_set_error("segk_kmeans_segment: band of %d x %d spans needs %zu B of LDS (> 160 KiB); "
+                       "set n_slices_max", c->N_max, W, lds);
+        return SEGK_ERR_UNSUPPORTED;
+    }
+    DISPATCH_XT(c, {
+        if (lds > 48 * 1024)
+            SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_kmeans_segment<XT>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_kmeans_segment<XT>, dim3(n_utts), dim3(nt), lds, st, *c, *m, utts, utt0, n_slices_min,
+                           n_slices_max, wip, cand_k, cand_f, boundaries, old_tok, new_tok, new_k, n_old, n_new,
+                           out_total, status, band_cap);
+    });
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+static int launch_update(const segk_corpus *c, segk_kmeans *m, int op, int utt, int64_t item, int k_item,
+                         const int32_t *old_tok, const int32_t *new_tok, const int32_t *new_k,
+                         const int32_t *n_old, const int32_t *n_new, int32_t *status, hipStream_t st)
+{
+    DISPATCH_XT(c, hipLaunchKernelGGL(k_kmeans_update<XT>, dim3(1), dim3(256), 0, st, *c, *m, op, utt, item, k_item,
+                                       old_tok, new_tok, new_k, n_old, n_new, status););
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+int32_t segk_kmeans_update_utt(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m, int32_t utt,
+                               const int32_t *old_tok, const int32_t *new_tok, const int32_t *new_k,
+                               const int32_t *n_old, const int32_t *n_new, int32_t *status, void *stream)
+{
+    int rc = check_corpus(c);
+    if (rc) return rc;
+    SEGK_REQUIRE(utt >= 0 && utt < c->n_utt, "utt out of range");
+    rc = launch_update(c, m, 0, utt, 0, 0, old_tok, new_tok, new_k, n_old, n_new, status, (hipStream_t)stream);
+    if (rc) return rc;
+    return segk_kmeans_prepare(ctx, c, m, stream);
+}
+
+int32_t segk_kmeans_add_item(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m, int64_t i, int32_t k,
+                             int32_t *status, void *stream)
+{
+    int rc = check_corpus(c);
+    if (rc) return rc;
+    SEGK_REQUIRE(i >= 0 && i < c->n_emb, "item out of range");
+    SEGK_REQUIRE(k >= 0, "k");
+    rc = launch_update(c, m, 1, 0, i, k, nullptr, nullptr, nullptr, nullptr, nullptr, status, (hipStream_t)stream);
+    if (rc) return rc;
+    return segk_kmeans_prepare(ctx, c, m, stream);
+}
+
+int32_t segk_kmeans_del_item(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m, int64_t i, int32_t *status,
+                             void *stream)
+{
+    int rc = check_corpus(c);
+    if (rc) return rc;
+    SEGK_REQUIRE(i >= 0 && i < c->n_emb, "item out of range");
+    rc = launch_update(c, m, 2, 0, i, 0, nullptr, nullptr, nullptr, nullptr, nullptr, status, (hipStream_t)stream);
+    if (rc) return rc;
+    return segk_kmeans_prepare(ctx, c, m, stream);
+}
+
+int32_t segk_kmeans_clean_components(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m, int32_t *status,
+                                     void *stream)
+{
+    int rc = check_corpus(c);
+    if (rc) return rc;
+    rc = launch_update(c, m, 3, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, status, (hipStream_t)stream);
+    if (rc) return rc;
+    return segk_kmeans_prepare(ctx, c, m, stream);
+}
+
+int32_t segk_kmeans_del_component(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m, int32_t k,
+                                  int32_t *status, void *stream)
+{
+    int rc = check_corpus(c);
+    if (rc) return rc;
+    SEGK_REQUIRE(k >= 0 && k < m->K_max, "k out of range");
+    rc = launch_update(c, m, 4, 0, 0, k, nullptr, nullptr, nullptr, nullptr, nullptr, status, (hipStream_t)stream);
+    if (rc) return rc;
+    return segk_kmeans_prepare(ctx, c, m, stream);
+}
+
+int32_t segk_kmeans_batch_collect(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m, int32_t utt_lo,
+                                  int32_t utt_hi, const int32_t *old_tok, const int32_t *n_old,
+                                  const int32_t *new_k, const int32_t *n_new, int32_t *flag_buf, int32_t cap,
+                                  void *stream)
+{
+    (void)ctx;
+    int rc = check_corpus(c);
+    if (rc) return rc;
+    SEGK_REQUIRE(0 <= utt_lo && utt_lo <= utt_hi && utt_hi <= c->n_utt, "utterance range");
+    hipStream_t st = (hipStream_t)stream;
+    int64_t tot = (int64_t)(utt_hi - utt_lo) * c->N_max;
+    if (tot > 0)
+        hipLaunchKernelGGL(k_batch_delete_old, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, *c, *m, utt_lo,
+                           utt_hi, old_tok, n_old);
+    hipLaunchKernelGGL(k_batch_collect_flags, dim3(1), dim3(1024), 0, st, *c, *m, utt_lo, utt_hi, new_k, n_new,
+                       flag_buf, cap);
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+int32_t segk_kmeans_batch_assign(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m, int32_t utt_lo,
+                                 int32_t utt_hi, const int32_t *flag_all, int32_t n_ranks, int32_t my_rank,
+                                 int32_t cap, const int32_t *new_tok, int32_t *new_k, const int32_t *n_new,
+                                 int32_t *status, void *stream)
+{
+    (void)ctx;
+    int rc = check_corpus(c);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_batch_resolve, dim3(1), dim3(1024), 0, (hipStream_t)stream, *c, *m, utt_lo, utt_hi,
+                       flag_all, n_ranks, my_rank, cap, new_tok, new_k, n_new, status);
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+int32_t segk_kmeans_batch_partials(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m,
+                                   const int32_t *blk_lo, int32_t n_blocks_local, const int32_t *new_tok,
+                                   const int32_t *new_k, const int32_t *n_new, const double *out_total,
+                                   double *part_sum, int64_t *part_cnt, double *part_tot, void *stream)
+{
+    (void)ctx;
+    int rc = check_corpus(c);
+    if (rc) return rc;
+    if (n_blocks_local <= 0) return SEGK_OK;
+    int64_t waves = (int64_t)n_blocks_local * m->K_max;
+    int64_t grid = (waves + 3) / 4;
+    DISPATCH_XT(c, hipLaunchKernelGGL(k_batch_partials<XT>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream,
+                                       *c, *m, blk_lo, n_blocks_local, new_tok, new_k, n_new, out_total, part_sum,
+                                       part_cnt, part_tot););
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+int32_t segk_kmeans_batch_finalize(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m, int32_t utt_lo,
+                                   int32_t utt_hi, const double *part_sum, const int64_t *part_cnt,
+                                   const double *part_tot, int32_t n_blocks_total, int32_t n_blocks_per_rank,
+                                   int64_t rank_stride, const int32_t *new_tok, const int32_t *n_new,
+                                   int32_t *remap_scratch, double *out_scalars, int32_t *status, void *stream)
+{
+    (void)status;
+    int rc = check_corpus(c);
+    if (rc) return rc;
+    SEGK_REQUIRE(n_blocks_total >= 1 && n_blocks_total <= 64, "1 <= n_blocks_total <= 64");
+    SEGK_REQUIRE(n_blocks_per_rank >= 1 && n_blocks_total % n_blocks_per_rank == 0, "blocks per rank");
+    hipStream_t st = (hipStream_t)stream;
+    int64_t tot = (int64_t)m->K_max * c->D;
+    DISPATCH_XT(c, {
+        hipLaunchKernelGGL(k_batch_combine<XT>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, *c, *m,
+                           part_sum, part_cnt, part_tot, n_blocks_total, n_blocks_per_rank, rank_stride, out_scalars);
+        hipLaunchKernelGGL(k_batch_clean<XT>, dim3(1), dim3(256), 0, st, *c, *m, remap_scratch, out_scalars);
+    });
+    int64_t nslot = (int64_t)(utt_hi - utt_lo) * c->N_max;
+    if (nslot > 0)
+        hipLaunchKernelGGL(k_batch_relabel, dim3((unsigned)((nslot + 255) / 256)), dim3(256), 0, st, *c, *m, utt_lo,
+                           utt_hi, new_tok, n_new, remap_scratch);
+    SEGK_LAUNCH_CHECK();
+    return segk_kmeans_prepare(ctx, c, m, stream);
+}
+
+int32_t segk_kmeans_sum_neg_sqrd_norm(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m, double *out,
+                                      void *stream)
+{
+    (void)ctx;
+    int rc = check_corpus(c);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    SEGK_CHECK_HIP(hipMemsetAsync(out, 0, sizeof(double), st));
+    int64_t grid = (c->n_emb + 3) / 4;
+    DISPATCH_XT(c, hipLaunchKernelGGL(k_kmeans_sum_neg_sqrd_norm<XT>, dim3((unsigned)grid), dim3(256), 0, st, *c, *m,
+                                       out););
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+int32_t segk_kmeans_init_stats(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m, void *stream)
+{
+    int rc = check_corpus(c);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    SEGK_CHECK_HIP(hipMemsetAsync(m->K, 0, sizeof(int32_t), st));
+    int64_t grid = ((int64_t)m->K_max + 3) / 4;
+    DISPATCH_XT(c, hipLaunchKernelGGL(k_kmeans_init_stats<XT>, dim3((unsigned)grid), dim3(256), 0, st, *c, *m););
+    SEGK_LAUNCH_CHECK();
+    return segk_kmeans_prepare(ctx, c, m, stream);
+}
+
+int32_t segk_dp_tri(segk_ctx *ctx, int32_t kind, const double *vecs, const int32_t *Ns, const int64_t *offs,
+                    int32_t n_prob, int32_t n_slices_min, int32_t n_slices_max, double log_p_continue,
+                    double anneal_temp, const double *uniforms, int64_t u_stride, uint8_t *bounds,
+                    int64_t b_stride, double *totals, int32_t *n_draws, int32_t *status, double *work,
+                    int64_t w_stride, void *stream)
+{
+    (void)ctx;
+    SEGK_REQUIRE(kind >= 0 && kind <= 2, "kind");
+    SEGK_REQUIRE(n_slices_min == 0 || n_slices_min == 1, "n_slices_min must be 0 or 1");
+    SEGK_REQUIRE(kind != 2 || uniforms != nullptr, "uniforms required for forward_backward");
+    if (n_prob <= 0) return SEGK_OK;
+    hipLaunchKernelGGL(k_dp_tri, dim3((n_prob + 63) / 64), dim3(64), 0, (hipStream_t)stream, kind, vecs, Ns, offs,
+                       n_prob, n_slices_min, n_slices_max, log_p_continue, anneal_temp, uniforms, u_stride, bounds,
+                       b_stride, totals, n_draws, status, work, w_stride);
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,330 @@
+"""
+Device-resident state of the hot path and thin wrappers over the C ABI (include/segk.h).
+
+PyTorch is used for exactly three things here: allocating device buffers, host<->device
+copies, and the stream handle.  All arithmetic of the hot path runs in libsegk.so.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+from ._abi import SEGK_F32, SEGK_F64, SegkError, check, ptr
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def _dev():
+    torch = _torch()
+    if not torch.cuda.is_available():
+        raise SegkError("segmentalist_amd needs an MI355X: no ROCm device is visible and there is no "
+                        "CPU fallback for the hot path")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def to_dev(a, dtype=None):
+    torch = _torch()
+    a = np.ascontiguousarray(a if dtype is None else np.asarray(a, dtype=dtype))
+    return torch.from_numpy(a).to(_dev())
+
+
+class DeviceCorpus(object):
+    """Device image of the embedding matrix and (optionally) of `Utterances`
+    (utterances.py:74-105): vec_ids int32 [n_utt, tri], durations f64, lengths int32."""
+
+    def __init__(self, X, vec_ids=None, durations=None, lengths=None):
+        torch = _torch()
+        X = np.asarray(X)
+        if X.dtype not in (np.float32, np.float64):
+            X = X.astype(np.float64)
+        assert X.ndim == 2
+        self.x_np_dtype = X.dtype
+        self.x_dtype = SEGK_F32 if X.dtype == np.float32 else SEGK_F64
+        self.n_emb, self.D = X.shape
+        if self.n_emb >= 2 ** 31:
+            raise SegkError("more than 2^31 embeddings are not supported (int32 row ids)")
+        self.ld32 = (self.D + 3) // 4 * 4
+        dev = _dev()
+        if self.x_dtype == SEGK_F32 and self.ld32 == self.D:
+            self.X = to_dev(X)
+            self.X32 = self.X
+            self.ldx = self.D
+            x32_out = None
+        else:
+            self.X = to_dev(X)
+            self.ldx = self.D
+            self.X32 = torch.empty((self.n_emb, self.ld32), dtype=torch.float32, device=dev)
+            x32_out = self.X32
+        self.xnorm = torch.empty(self.n_emb, dtype=torch.float32, device=dev)
+        if vec_ids is not None:
+            vec_ids = np.asarray(vec_ids)
+            self.n_utt = vec_ids.shape[0]
+            self.lengths_np = np.asarray(lengths, dtype=np.int32)
+            self.N_max = int(self.lengths_np.max())
+            tri = self.N_max * (self.N_max + 1) // 2
+            assert vec_ids.shape[1] == tri
+            self.vec_ids = to_dev(vec_ids, np.int32)
+            self.durations = to_dev(durations, np.float64)
+            self.lengths = to_dev(self.lengths_np)
+        else:
+            self.n_utt, self.N_max = 0, 0
+            self.vec_ids = self.durations = self.lengths = None
+            self.lengths_np = None
+        self.tri = self.N_max * (self.N_max + 1) // 2
+        self.c = _abi.Corpus(
+            X=self.X.data_ptr(), X32=self.X32.data_ptr(), x_dtype=self.x_dtype, D=self.D,
+            n_emb=self.n_emb, ldx=self.ldx, ld32=self.ld32, xnorm=self.xnorm.data_ptr(),
+            vec_ids=self.vec_ids.data_ptr() if self.vec_ids is not None else None,
+            durations=self.durations.data_ptr() if self.durations is not None else None,
+            lengths=self.lengths.data_ptr() if self.lengths is not None else None,
+            n_utt=self.n_utt, N_max=self.N_max)
+        check(_abi.lib().segk_corpus_prepare(_abi.ctx(), C.byref(self.c), ptr(x32_out), ptr(self.xnorm),
+                                             _abi.stream()))
+
+    @property
+    def torch_xdtype(self):
+        torch = _torch()
+        return torch.float32 if self.x_dtype == SEGK_F32 else torch.float64
+
+
+class DeviceKMeans(object):
+    """Device image of `KMeansComponents` (kmeans_components.py:18-91) plus the derived MFMA
+    operands and the per-sweep work buffers."""
+
+    def __init__(self, corpus, K_max, assignments, random_means):
+        torch = _torch()
+        dev = _dev()
+        self.corpus = corpus
+        c = corpus
+        self.K_max = int(K_max)
+        xd = c.torch_xdtype
+        self.means = torch.empty((self.K_max, c.D), dtype=xd, device=dev)
+        self.mean_numerators = torch.zeros((self.K_max, c.D), dtype=torch.float64, device=dev)
+        self.counts = torch.zeros(self.K_max, dtype=torch.int64, device=dev)
+        self.random_means = to_dev(np.asarray(random_means, dtype=c.x_np_dtype))
+        self.assignments = to_dev(assignments, np.int32)
+        self.K = torch.zeros(1, dtype=torch.int32, device=dev)
+        n_tiles_f = _abi.lib().segk_kmeans_tiles_floats(self.K_max, c.D)
+        self.tiles = torch.zeros(int(n_tiles_f), dtype=torch.float32, device=dev)
+        self.mnorm_max = torch.zeros(1, dtype=torch.float64, device=dev)
+        self.m = _abi.KMeansDev(
+            means=self.means.data_ptr(), mean_numerators=self.mean_numerators.data_ptr(),
+            counts=self.counts.data_ptr(), random_means=self.random_means.data_ptr(),
+            assignments=self.assignments.data_ptr(), K=self.K.data_ptr(), K_max=self.K_max,
+            tiles=self.tiles.data_ptr(), mnorm_max=self.mnorm_max.data_ptr())
+        # candidates of the filter stage, indexed by embedding row
+        self.cand_k = torch.zeros(c.n_emb, dtype=torch.int32, device=dev)
+        self.cand_f = torch.zeros((c.n_emb, 2), dtype=torch.float32, device=dev)
+        self.status = torch.zeros(8, dtype=torch.int32, device=dev)
+        self._L = _abi.lib()
+        self._ctx = _abi.ctx()
+        check(self._L.segk_kmeans_init_stats(self._ctx, C.byref(c.c), C.byref(self.m), _abi.stream()))
+        if c.n_utt:
+            self._alloc_utt_buffers()
+
+    # ------------------------------------------------------------------ buffers for segmentation
+    def _alloc_utt_buffers(self):
+        torch = _torch()
+        dev = _dev()
+        c = self.corpus
+        nu, nm = c.n_utt, c.N_max
+        self.old_tok = torch.zeros((nu, nm), dtype=torch.int32, device=dev)
+        self.new_tok = torch.zeros((nu, nm), dtype=torch.int32, device=dev)
+        self.new_k = torch.zeros((nu, nm), dtype=torch.int32, device=dev)
+        self.n_old = torch.zeros(nu, dtype=torch.int32, device=dev)
+        self.n_new = torch.zeros(nu, dtype=torch.int32, device=dev)
+        self.out_total = torch.zeros(nu, dtype=torch.float64, device=dev)
+        self.utt_arange = torch.arange(nu, dtype=torch.int32, device=dev)
+        self.remap = torch.zeros(self.K_max, dtype=torch.int32, device=dev)
+        self.out_scalars = torch.zeros(4, dtype=torch.float64, device=dev)
+
+    # ------------------------------------------------------------------ single calls
+    def _cp(self):
+        return C.byref(self.corpus.c)
+
+    def prepare(self):
+        check(self._L.segk_kmeans_prepare(self._ctx, self._cp(), C.byref(self.m), _abi.stream()))
+
+    def score_rows(self, ids=None, row0=0, n=None):
+        """A1 filter stage over rows (device int32 tensor `ids`, or the range row0..row0+n)."""
+        if ids is not None:
+            n = ids.numel()
+            p = ptr(ids)
+        else:
+            p = None
+            n = self.corpus.n_emb - row0 if n is None else n
+        check(self._L.segk_kmeans_score(self._ctx, self._cp(), C.byref(self.m), p, int(row0), int(n),
+                                        ptr(self.cand_k), ptr(self.cand_f), _abi.stream()))
+
+    def score_ptr(self, ids_ptr, n):
+        check(self._L.segk_kmeans_score(self._ctx, self._cp(), C.byref(self.m), C.c_void_p(ids_ptr), 0, int(n),
+                                        ptr(self.cand_k), ptr(self.cand_f), _abi.stream()))
+
+    def exact_max(self, ids):
+        """np.max / np.argmax of neg_sqrd_norm for rows `ids` (host ints) -> (float64[n], int32[n])."""
+        torch = _torch()
+        ids_t = to_dev(ids, np.int32)
+        n = ids_t.numel()
+        out_max = torch.empty(n, dtype=torch.float64, device=ids_t.device)
+        out_arg = torch.empty(n, dtype=torch.int32, device=ids_t.device)
+        nb = torch.zeros(1, dtype=torch.int32, device=ids_t.device)
+        self.score_rows(ids_t)
+        check(self._L.segk_kmeans_exact_max(self._ctx, self._cp(), C.byref(self.m), ptr(ids_t), n,
+                                            ptr(self.cand_k), ptr(self.cand_f), ptr(out_max), ptr(out_arg),
+                                            ptr(nb), _abi.stream()))
+        return out_max.cpu().numpy(), out_arg.cpu().numpy(), int(nb.item())
+
+    def neg_sqrd_norm(self, row):
+        torch = _torch()
+        out = torch.empty(self.K_max, dtype=self.corpus.torch_xdtype, device=self.means.device)
+        check(self._L.segk_kmeans_neg_sqrd_norm(self._ctx, self._cp(), C.byref(self.m), int(row), ptr(out),
+                                                _abi.stream()))
+        return out.cpu().numpy()
+
+    def add_item(self, i, k):
+        check(self._L.segk_kmeans_add_item(self._ctx, self._cp(), C.byref(self.m), int(i), int(k),
+                                           ptr(self.status), _abi.stream()))
+
+    def del_item(self, i):
+        check(self._L.segk_kmeans_del_item(self._ctx, self._cp(), C.byref(self.m), int(i), ptr(self.status),
+                                           _abi.stream()))
+
+    def del_component(self, k):
+        check(self._L.segk_kmeans_del_component(self._ctx, self._cp(), C.byref(self.m), int(k),
+                                                ptr(self.status), _abi.stream()))
+
+    def clean_components(self):
+        check(self._L.segk_kmeans_clean_components(self._ctx, self._cp(), C.byref(self.m), ptr(self.status),
+                                                   _abi.stream()))
+
+    def sum_neg_sqrd_norm(self):
+        torch = _torch()
+        out = torch.zeros(1, dtype=torch.float64, device=self.means.device)
+        check(self._L.segk_kmeans_sum_neg_sqrd_norm(self._ctx, self._cp(), C.byref(self.m), ptr(out),
+                                                    _abi.stream()))
+        return float(out.item())
+
+    # ------------------------------------------------------------------ segmentation
+    def segment(self, boundaries, n_slices_min, n_slices_max, wip, utt=None, utt0=0, n_utts=None):
+        """A5+A8+argmax for one utterance (`utt`) or the range utt0..utt0+n_utts."""
+        c = self.corpus
+        if utt is not None:
+            up = C.c_void_p(self.utt_arange.data_ptr() + 4 * int(utt))
+            utt0, n = 0, 1
+        else:
+            up = None
+            n = c.n_utt - utt0 if n_utts is None else n_utts
+        check(self._L.segk_kmeans_segment(
+            self._ctx, self._cp(), C.byref(self.m), up, int(utt0), int(n), int(n_slices_min), int(n_slices_max),
+            float(wip), ptr(self.cand_k), ptr(self.cand_f), ptr(boundaries), ptr(self.old_tok),
+            ptr(self.new_tok), ptr(self.new_k), ptr(self.n_old), ptr(self.n_new), ptr(self.out_total),
+            ptr(self.status), _abi.stream()))
+
+    def segment_utt_sequential(self, boundaries, i, n_slices_min, n_slices_max, wip):
+        """The whole of segment_i (kmeans_acoustic_wordseg.py:225-332) for utterance i, enqueued
+        asynchronously: score its spans, DP, del/add/clean in the reference's order."""
+        c = self.corpus
+        N = int(c.lengths_np[i])
+        tri_i = N * (N + 1) // 2
+        self.score_ptr(c.vec_ids.data_ptr() + 4 * i * c.tri, tri_i)
+        self.segment(boundaries, n_slices_min, n_slices_max, wip, utt=i)
+        check(self._L.segk_kmeans_update_utt(self._ctx, self._cp(), C.byref(self.m), int(i), ptr(self.old_tok),
+                                             ptr(self.new_tok), ptr(self.new_k), ptr(self.n_old),
+                                             ptr(self.n_new), ptr(self.status), _abi.stream()))
+
+    def check_status(self):
+        st = self.status.cpu().numpy()
+        if st[0] & 1:
+            raise AssertionError("a new segment has no embedding (vec_id == -1): the reference asserts in "
+                                 "KMeansComponents.add_item (kmeans_components.py:100)")
+        if st[0] & 2:
+            raise AssertionError("add_item on an item that is already assigned (kmeans_components.py:101)")
+        if st[0] & 4:
+            raise SegkError("batch sweep: more than `flag_cap` new tokens chose an inactive component; "
+                            "raise flag_cap")
+        return int(st[1])
+
+
+class Partition(object):
+    """Static split of the utterances into `n_blocks` statistics blocks (the fixed summation
+    tree of the batch mode) and of the blocks over `world` ranks (rank r owns a contiguous
+    run of blocks, hence of utterances and of embedding rows)."""
+
+    def __init__(self, n_utt, utt_row_start, n_blocks=8, rank=0, world=1):
+        if n_blocks % world != 0:
+            raise SegkError("the number of statistics blocks (%d) must be a multiple of the number of "
+                            "ranks (%d)" % (n_blocks, world))
+        self.n_blocks, self.rank, self.world = n_blocks, rank, world
+        self.nbl = n_blocks // world
+        self.bounds = np.array([(b * n_utt) // n_blocks for b in range(n_blocks + 1)], dtype=np.int32)
+        self.utt_lo = int(self.bounds[rank * self.nbl])
+        self.utt_hi = int(self.bounds[(rank + 1) * self.nbl])
+        self.row_lo = int(utt_row_start[self.utt_lo])
+        self.row_hi = int(utt_row_start[self.utt_hi])
+        self.local_bounds = self.bounds[rank * self.nbl:(rank + 1) * self.nbl + 1].copy()
+
+
+class KMeansBatchSweeper(object):
+    """One batch-synchronous sweep = score -> segment -> collect -> [all-gather flags] -> assign
+    -> partials -> [all-gather partials] -> finalize, all enqueued on the current stream.
+    With world == 1 there is no collective; with world > 1 the two all-gathers move
+    (1 + 2*flag_cap) int32 and nbl*(K_max*(D+1)+1) 8-byte words per rank over RCCL."""
+
+    def __init__(self, dk, part, flag_cap=4096, group=None):
+        torch = _torch()
+        dev = _dev()
+        self.dk, self.part, self.cap, self.group = dk, part, int(flag_cap), group
+        c = dk.corpus
+        K, D, nbl, W = dk.K_max, c.D, part.nbl, part.world
+        self.rank_stride = nbl * K * D + nbl + nbl * K       # 8-byte words
+        self.pack_all = torch.zeros((W, self.rank_stride), dtype=torch.float64, device=dev)
+        self.pack = self.pack_all[part.rank]
+        self.flag_all = torch.zeros((W, 1 + 2 * self.cap), dtype=torch.int32, device=dev)
+        self.flag = self.flag_all[part.rank]
+        self.blk_lo = to_dev(part.local_bounds, np.int32)
+        base = self.pack.data_ptr()
+        self._p_sum = C.c_void_p(base)
+        self._p_tot = C.c_void_p(base + 8 * (nbl * K * D))
+        self._p_cnt = C.c_void_p(base + 8 * (nbl * K * D + nbl))
+        base0 = self.pack_all.data_ptr()
+        self._a_sum = C.c_void_p(base0)
+        self._a_tot = C.c_void_p(base0 + 8 * (nbl * K * D))
+        self._a_cnt = C.c_void_p(base0 + 8 * (nbl * K * D + nbl))
+        # bench hook: when a list, every sweep appends a (start, end) pair of HIP events that
+        # bracket the score kernel on its launch stream
+        self.score_events = None
+
+    def sweep(self, boundaries, n_slices_min, n_slices_max, wip):
+        dk, pt = self.dk, self.part
+        L, ctx, cp, mp, st = dk._L, dk._ctx, dk._cp(), C.byref(dk.m), _abi.stream()
+        if self.score_events is not None:
+            torch = _torch()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            dk.score_rows(row0=pt.row_lo, n=pt.row_hi - pt.row_lo)
+            e1.record()
+            self.score_events.append((e0, e1))
+        else:
+            dk.score_rows(row0=pt.row_lo, n=pt.row_hi - pt.row_lo)
+        dk.segment(boundaries, n_slices_min, n_slices_max, wip, utt0=pt.utt_lo, n_utts=pt.utt_hi - pt.utt_lo)
+        check(L.segk_kmeans_batch_collect(ctx, cp, mp, pt.utt_lo, pt.utt_hi, ptr(dk.old_tok), ptr(dk.n_old),
+                                          ptr(dk.new_k), ptr(dk.n_new), ptr(self.flag), self.cap, st))
+        if pt.world > 1:
+            import torch.distributed as dist
+            dist.all_gather_into_tensor(self.flag_all.view(-1), self.flag, group=self.group)
+        check(L.segk_kmeans_batch_assign(ctx, cp, mp, pt.utt_lo, pt.utt_hi, ptr(self.flag_all), pt.world,
+                                         pt.rank, self.cap, ptr(dk.new_tok), ptr(dk.new_k), ptr(dk.n_new),
+                                         ptr(dk.status), st))
+        check(L.segk_kmeans_batch_partials(ctx, cp, mp, ptr(self.blk_lo), pt.nbl, ptr(dk.new_tok),
+                                           ptr(dk.new_k), ptr(dk.n_new), ptr(dk.out_total), self._p_sum,
+                                           self._p_cnt, self._p_tot, st))
+        if pt.world > 1:
+            import torch.distributed as dist
+            dist.all_gather_into_tensor(self.pack_all.view(-1), self.pack, group=self.group)
+        check(L.segk_kmeans_batch_finalize(ctx, cp, mp, pt.utt_lo, pt.utt_hi, self._a_sum, self._a_cnt,
+                                           self._a_tot, pt.n_blocks, pt.nbl, self.rank_stride,
+                                           ptr(dk.new_tok), ptr(dk.n_new), ptr(dk.remap), ptr(dk.out_scalars),
+                                           ptr(dk.status), st))

@@ -1,0 +1,219 @@
+"""
+Drop-in for segmentalist/kmeans_acoustic_wordseg.py: segmental k-means word segmentation.
+
+`SegmentalKMeansWordseg` keeps the reference's constructor, attributes, methods and record
+keys.  Two execution modes:
+
+  sync="sequential" (default)  the reference's chain: utterances are visited one by one in
+        `random.shuffle` order and the component statistics are updated between
+        utterances, all on the device (score -> DP -> del/add/clean per utterance, enqueued
+        asynchronously).  Bit-identical boundaries / assignments / means to the reference.
+  sync="batch"                 every utterance of a sweep is scored against the statistics
+        frozen at the start of the sweep (one MFMA GEMM over all embeddings), one workgroup
+        per utterance runs the DP, and the statistics are rebuilt once per sweep in a fixed
+        summation order; utterances shard over the ranks of a torch.distributed job.  A
+        different (AD-LDA style) chain; bit-identical for 1/2/4/8 GPUs and to the CPU
+        restatement of the same specification (oracle/np_oracle.py kmeans_batch_sweep).
+"""
+import ctypes as C
+import logging
+import random
+import time
+
+import numpy as np
+
+from . import _abi, rng
+from .device import DeviceCorpus, KMeansBatchSweeper, Partition, to_dev
+from .kmeans import KMeans, _consecutive
+from .utterances import Utterances, process_embeddings
+
+logger = logging.getLogger(__name__)
+i_debug_monitor = 0          # kept for API compatibility (debug traces are not reproduced)
+segment_debug_only = False
+
+
+class SegmentalKMeansWordseg(object):
+    def __init__(self, am_K, embedding_mats, vec_ids_dict, durations_dict, landmarks_dict,
+                 seed_boundaries_dict=None, seed_assignments_dict=None, n_slices_min=0,
+                 n_slices_max=20, min_duration=0, p_boundary_init=0.5, init_am_assignments="rand",
+                 wip=0, sync="sequential", n_stat_blocks=8, flag_cap=4096, process_group=None):
+        logger.info("Initializing")
+        assert seed_assignments_dict is None or seed_boundaries_dict is not None
+        assert sync in ("sequential", "batch")
+        self.n_slices_min = n_slices_min
+        self.n_slices_max = n_slices_max
+        self.wip = wip
+        self.sync = sync
+
+        embeddings, vec_ids, ids_to_utterance_labels = process_embeddings(embedding_mats, vec_ids_dict)
+        self.ids_to_utterance_labels = ids_to_utterance_labels
+        N = embeddings.shape[0]
+
+        seed_boundaries = None
+        if seed_boundaries_dict is not None:
+            seed_boundaries = [seed_boundaries_dict[i] for i in ids_to_utterance_labels]
+        lengths = [len(landmarks_dict[i]) for i in ids_to_utterance_labels]
+        landmarks = [landmarks_dict[i] for i in ids_to_utterance_labels]
+        durations = [durations_dict[i] for i in ids_to_utterance_labels]
+        self.utterances = Utterances(
+            lengths, vec_ids, durations, landmarks, seed_boundaries=seed_boundaries,
+            p_boundary_init=p_boundary_init, n_slices_min=n_slices_min, n_slices_max=n_slices_max,
+            min_duration=min_duration)
+
+        # embeddings in the initial segmentation (kmeans_acoustic_wordseg.py:136-141)
+        init_embeds = []
+        for i in range(self.utterances.D):
+            init_embeds.extend(self.utterances.get_segmented_embeds_i(i))
+        init_embeds = np.array(init_embeds, dtype=int)
+        init_embeds = init_embeds[np.where(init_embeds != -1)]
+        logger.info("No. initial embeddings: " + str(init_embeds.shape[0]))
+
+        assignments = -1 * np.ones(N, dtype=int)
+        if seed_assignments_dict is not None:
+            assert False, "to-do"                       # as the reference (:148-149)
+        elif init_am_assignments == "rand":             # :183-194
+            a = _consecutive(np.random.randint(0, am_K, len(init_embeds)))
+            assignments[init_embeds] = a
+        elif init_am_assignments == "spread":           # :196-205
+            n = len(init_embeds)
+            spread = (list(range(am_K)) * int(np.ceil(float(n) / am_K)))[:n]
+            rng.shuffle(spread)
+            assignments[init_embeds] = np.array(spread)
+        elif init_am_assignments == "one-by-one":
+            assert False, "to-do"                       # as the reference (:207-208)
+        else:
+            assert False, "invalid value for `init_am_assignments`: " + init_am_assignments
+
+        # device images
+        u = self.utterances
+        self._corpus = DeviceCorpus(embeddings, u.vec_ids, u.durations, u.lengths)
+        self.acoustic_model = KMeans(embeddings, am_K, assignments, _corpus=self._corpus)
+        self._dk = self.acoustic_model.components.dev
+        self._dev_bounds = to_dev(u.boundaries.astype(np.uint8))
+        u.bind_device(self._dev_bounds)
+        self._row_start = vec_ids.row_start
+
+        # batch mode plumbing (single process unless torch.distributed is initialised)
+        self._sweeper = None
+        self._batch_args = (n_stat_blocks, flag_cap, process_group)
+
+    # ------------------------------------------------------------------ sequential mode
+    def segment_i(self, i):
+        """kmeans_acoustic_wordseg.py:225-332.  Returns the length-weighted objective of the
+        utterance (computed with the means before the update, as in the reference)."""
+        self._segment_i_async(i)
+        self._dk.check_status()
+        return float(self._dk.out_total[i].item())
+
+    def _segment_i_async(self, i):
+        self._dk.segment_utt_sequential(self._dev_bounds, i, self.n_slices_min, self.n_slices_max, self.wip)
+        self.utterances.mark_device_dirty()
+
+    def get_vec_embed_neg_len_sqrd_norms(self, vec_ids, durations):
+        """kmeans_acoustic_wordseg.py:334-351 for arbitrary (vec_ids, durations) vectors."""
+        vec_ids = np.asarray(vec_ids)
+        out = -np.inf * np.ones(len(vec_ids))
+        valid = np.where(vec_ids != -1)[0]
+        if len(valid):
+            mx, _, _ = self._dk.exact_max(vec_ids[valid].astype(np.int32))
+            d = np.asarray(durations, dtype=np.float64)[valid]
+            with np.errstate(invalid="ignore"):
+                out[valid] = np.where(np.isnan(d), -np.inf, mx * d)
+        return out + self.wip
+
+    # ------------------------------------------------------------------ batch mode
+    def _get_sweeper(self):
+        if self._sweeper is None:
+            n_blocks, cap, group = self._batch_args
+            rank, world = 0, 1
+            try:
+                import torch.distributed as dist
+                if dist.is_available() and dist.is_initialized():
+                    rank, world = dist.get_rank(group), dist.get_world_size(group)
+            except ImportError:
+                pass
+            part = Partition(self.utterances.D, self._row_start, n_blocks, rank, world)
+            self._sweeper = KMeansBatchSweeper(self._dk, part, cap, group)
+        return self._sweeper
+
+    def batch_sweep_async(self):
+        """Enqueue one batch-synchronous sweep; results stay on the device."""
+        self._get_sweeper().sweep(self._dev_bounds, self.n_slices_min, self.n_slices_max, self.wip)
+        self.utterances.mark_device_dirty()
+
+    # ------------------------------------------------------------------ driver
+    def segment(self, n_iter, n_iter_inbetween_kmeans=0):
+        """kmeans_acoustic_wordseg.py:353-426; same record keys."""
+        import torch
+        logger.info("Segmenting for " + str(n_iter) + " iterations")
+        record_dict = {"sum_neg_sqrd_norm": [], "sum_neg_len_sqrd_norm": [], "components": [],
+                       "sample_time": [], "n_tokens": []}
+        c = self.acoustic_model.components
+        for i_iter in range(n_iter):
+            start_time = time.time()
+            if self.sync == "sequential":
+                utt_order = list(range(self.utterances.D))
+                rng.shuffle(utt_order)
+                if segment_debug_only:
+                    utt_order = [i_debug_monitor]
+                for i_utt in utt_order:
+                    self._segment_i_async(i_utt)
+                torch.cuda.synchronize()
+                self._dk.check_status()
+                totals = self._dk.out_total.cpu().numpy()
+                sum_neg_len_sqrd_norm = 0
+                for i_utt in utt_order:                  # same summation order as the reference
+                    sum_neg_len_sqrd_norm += totals[i_utt]
+            else:
+                self.batch_sweep_async()
+                torch.cuda.synchronize()
+                self._dk.check_status()
+                sum_neg_len_sqrd_norm = float(self._dk.out_scalars[0].item())
+            record_dict["sample_time"].append(time.time() - start_time)
+            record_dict["sum_neg_sqrd_norm"].append(c.sum_neg_sqrd_norm())
+            record_dict["sum_neg_len_sqrd_norm"].append(sum_neg_len_sqrd_norm)
+            record_dict["components"].append(c.K)
+            record_dict["n_tokens"].append(self.acoustic_model.get_n_assigned())
+            info = "iteration: " + str(i_iter)
+            for key in sorted(record_dict):
+                info += ", " + key + ": " + str(record_dict[key][-1])
+            logger.info(info)
+            if n_iter_inbetween_kmeans > 0:
+                self.acoustic_model.fit(n_iter_inbetween_kmeans, consider_unassigned=False)
+        return record_dict
+
+    def get_unsup_transcript_i(self, i):
+        return list(self.acoustic_model.components.get_assignments(
+            self.utterances.get_segmented_embeds_i(i)))
+
+    def get_max_unsup_transcript_i(self, i):
+        return self.acoustic_model.components.get_max_assignments(
+            self.utterances.get_segmented_embeds_i(i))
+
+
+def _dp_tri(kind, vec, N, n_slices_min, n_slices_max, log_p_continue=0.0, anneal_temp=1.0, uniforms=None):
+    """Run one triangular-layout DP problem on the device (segk_dp_tri)."""
+    import torch
+    vec_t = to_dev(np.asarray(vec, dtype=np.float64))
+    dev = vec_t.device
+    Ns = torch.tensor([N], dtype=torch.int32, device=dev)
+    offs = torch.zeros(1, dtype=torch.int64, device=dev)
+    bounds = torch.zeros(N, dtype=torch.uint8, device=dev)
+    totals = torch.zeros(1, dtype=torch.float64, device=dev)
+    nd = torch.zeros(1, dtype=torch.int32, device=dev)
+    st = torch.zeros(1, dtype=torch.int32, device=dev)
+    work = torch.zeros(3 * N + 2, dtype=torch.float64, device=dev)
+    u_t = to_dev(np.asarray(uniforms, dtype=np.float64)) if uniforms is not None else None
+    _abi.check(_abi.lib().segk_dp_tri(
+        _abi.ctx(), kind, _abi.ptr(vec_t), _abi.ptr(Ns), _abi.ptr(offs), 1, int(n_slices_min),
+        int(n_slices_max), float(log_p_continue), float(anneal_temp), _abi.ptr(u_t),
+        0 if u_t is None else u_t.numel(), _abi.ptr(bounds), N, _abi.ptr(totals), _abi.ptr(nd), _abi.ptr(st),
+        _abi.ptr(work), 3 * N + 2, _abi.stream()))
+    return float(totals.item()), bounds.cpu().numpy().astype(bool), int(nd.item()), int(st.item())
+
+
+def forward_backward_kmeans_viterbi(vec_embed_neg_len_sqrd_norms, N, n_slices_min=0, n_slices_max=0,
+                                    i_utt=None):
+    """kmeans_acoustic_wordseg.py:449-555 on the device."""
+    tot, bounds, _, _ = _dp_tri(0, vec_embed_neg_len_sqrd_norms, N, n_slices_min, n_slices_max)
+    return tot, bounds

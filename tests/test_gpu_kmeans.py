@@ -1,0 +1,334 @@
+"""
+GPU parity tests of the k-means path: the HIP kernels (through the C ABI) against
+  - the golden vectors captured from the reference (tests/golden/*.npz),
+  - the oracle on the same seeded inputs,
+  - size-independent properties at the headline size.
+Bit-exact everywhere (integer / index results and the float32 or float64 scores, whose
+arithmetic is specified by the reference: DESIGN.md "bit-exact contract").
+"""
+import random
+
+import numpy as np
+import pytest
+
+from tests.golden import cases
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    assert torch.cuda.is_available(), "these tests need an MI355X"
+    torch.cuda.set_device(0)
+    from segmentalist_amd import _abi
+    _abi.ctx()          # raises if libsegk.so is missing or the device is not gfx950
+    return torch
+
+
+def _components(X, means, K_max=None):
+    """A device KMeansComponents whose `means` are overwritten with the given matrix."""
+    import torch
+    from segmentalist_amd.kmeans_components import KMeansComponents
+    n = X.shape[0]
+    K = means.shape[0] if K_max is None else K_max
+    np.random.seed(0)
+    c = KMeansComponents(X, np.zeros(n, dtype=int), K)
+    c.dev.means.copy_(torch.from_numpy(np.ascontiguousarray(means)).to(c.dev.means.device))
+    c.dev.prepare()
+    return c
+
+
+# ------------------------------------------------------------------ A1
+@pytest.mark.parametrize("case", cases.A1_CASES, ids=[c[0] for c in cases.A1_CASES])
+def test_a1_scores_bit_exact_vs_reference(gpu, golden, case):
+    g = golden("kernels")
+    name, D, K, n, dtype = case
+    X, means = cases.a1_inputs(*case)
+    c = _components(X, means)
+    want = g["a1_%s_scores" % name]
+    for i in range(n):
+        got = c.neg_sqrd_norm(i)
+        assert got.dtype == want.dtype
+        assert np.array_equal(got, want[i]), (name, i)
+    mx, am, nbrute = c.dev.exact_max(np.arange(n))
+    assert np.array_equal(mx, g["a1_%s_max" % name].astype(np.float64))
+    assert np.array_equal(am, g["a1_%s_argmax" % name])
+
+
+@pytest.mark.parametrize("D,K,n,dtype", [(100, 1000, 4096, "float32"), (39, 100, 3000, "float32"),
+                                          (130, 257, 1500, "float32"), (17, 33, 700, "float64"),
+                                          (200, 64, 600, "float32"), (300, 40, 300, "float32")])
+def test_a1_max_argmax_vs_oracle_random(gpu, D, K, n, dtype):
+    from oracle import c_oracle as co
+    rs = np.random.RandomState(D * 1000 + K)
+    K_true = max(2, K // 2)
+    mu = rs.randn(K_true, D)
+    X = mu[rs.randint(0, K_true, n)] + 0.3 * rs.randn(n, D)
+    X /= np.linalg.norm(X, axis=1, keepdims=True)
+    X = X.astype(dtype)
+    means = (mu[rs.randint(0, K_true, K)] + 0.05 * rs.randn(K, D))
+    means /= np.linalg.norm(means, axis=1, keepdims=True)
+    means = means.astype(dtype)
+    means[K // 2] = means[1]          # exact duplicate of row 1 ...
+    X[5] = means[1]                   # ... and a data point sitting on it: an exact tie, lowest index wins
+    c = _components(X, means)
+    mx, am, nbrute = c.dev.exact_max(np.arange(n))
+    want_mx, want_am = co.kmeans_max_argmax(means, X)
+    assert np.array_equal(am, want_am)
+    assert np.array_equal(mx, want_mx)
+    assert am[5] == 1
+    assert 1 <= nbrute < n             # the tie takes the full scan; the filter decides most rows
+
+
+def test_a1_filter_candidate_is_within_margin(gpu):
+    """The fp32 MFMA filter's winner must be the true argmax or inside the proven margin."""
+    import torch
+    rs = np.random.RandomState(7)
+    n, D, K = 2048, 100, 1000
+    X = rs.randn(n, D).astype(np.float32)
+    X /= np.linalg.norm(X, axis=1, keepdims=True)
+    means = (rs.randn(K, D) * 0.2).astype(np.float32)
+    c = _components(X, means)
+    c.dev.score_rows()
+    torch.cuda.synchronize()
+    f = X.astype(np.float64) @ means.astype(np.float64).T - 0.5 * (means.astype(np.float64) ** 2).sum(1)
+    ck = c.dev.cand_k.cpu().numpy()
+    cf = c.dev.cand_f.cpu().numpy()
+    top = np.sort(f, axis=1)[:, ::-1]
+    assert np.max(np.abs(cf[:, 0] - top[:, 0])) < 2e-5
+    assert np.max(np.abs(cf[:, 1] - top[:, 1])) < 2e-5
+    assert np.mean(ck == np.argmax(f, axis=1)) > 0.999
+
+
+# ------------------------------------------------------------------ A6 / A7 / A8 on the device
+def test_dp_functions_vs_reference(gpu, golden):
+    import torch
+    from segmentalist_amd import _abi
+    from segmentalist_amd.device import to_dev
+    g = golden("kernels")
+    dpc = cases.dp_cases()
+    for n_min in (0, 1):
+        for n_max in (0, 2, 6):
+            sel = [i for i, c in enumerate(dpc) if c["n_min"] == n_min and c["n_max"] == n_max]
+            Ns = np.array([dpc[i]["N"] for i in sel], dtype=np.int32)
+            offs = np.concatenate([[0], np.cumsum([len(dpc[i]["vec"]) for i in sel])]).astype(np.int64)
+            vecs = np.concatenate([dpc[i]["vec"] for i in sel])
+            Nmax = int(Ns.max())
+            ob = np.concatenate([[0], np.cumsum([c["N"] for c in dpc])])
+            ou = np.concatenate([[0], np.cumsum([c["N"] + 1 for c in dpc])])
+            for kind, key, temp, lpc in [(0, "km", 1.0, 0.0), (1, "vt", 1.0, 0.0), (2, "fb", 1.0, -0.25),
+                                         (2, "fa", 1.7, -0.25)]:
+                P = len(sel)
+                bounds = torch.zeros((P, Nmax), dtype=torch.uint8, device="cuda")
+                totals = torch.zeros(P, dtype=torch.float64, device="cuda")
+                nd = torch.zeros(P, dtype=torch.int32, device="cuda")
+                st = torch.zeros(P, dtype=torch.int32, device="cuda")
+                work = torch.zeros((P, 3 * Nmax + 2), dtype=torch.float64, device="cuda")
+                u = None
+                if kind == 2:
+                    un = np.full((P, Nmax + 1), 0.5)
+                    for r, i in enumerate(sel):
+                        src = g["dp_%s_uniforms" % key][ou[i]:ou[i + 1]]
+                        un[r, :len(src)] = np.nan_to_num(src, nan=0.5)
+                    u = to_dev(un)
+                _abi.check(_abi.lib().segk_dp_tri(
+                    _abi.ctx(), kind, _abi.ptr(to_dev(vecs)), _abi.ptr(to_dev(Ns)), _abi.ptr(to_dev(offs)), P,
+                    n_min, n_max, lpc, temp, _abi.ptr(u), Nmax + 1, _abi.ptr(bounds), Nmax, _abi.ptr(totals),
+                    _abi.ptr(nd), _abi.ptr(st), _abi.ptr(work), 3 * Nmax + 2, _abi.stream()))
+                B = bounds.cpu().numpy().astype(bool)
+                T = totals.cpu().numpy()
+                for r, i in enumerate(sel):
+                    N = dpc[i]["N"]
+                    want_t = g["dp_%s_total" % key][i]
+                    if kind == 2 and np.isnan(want_t):
+                        assert st[r].item() == 1
+                        continue
+                    assert np.array_equal(B[r, :N], g["dp_%s_bounds" % key][ob[i]:ob[i + 1]]), (key, i)
+                    if kind == 0:
+                        assert T[r] == want_t or (np.isnan(T[r]) and np.isnan(want_t)), (key, i)
+                    else:
+                        assert np.isclose(T[r], want_t, rtol=1e-13, atol=0) or T[r] == want_t, (key, i)
+                    if kind == 2:
+                        assert nd[r].item() == g["dp_%s_ndraws" % key][i]
+
+
+def test_module_level_viterbi_function(gpu, golden):
+    from segmentalist_amd.kmeans_acoustic_wordseg import forward_backward_kmeans_viterbi
+    g = golden("kernels")
+    dpc = cases.dp_cases()
+    ob = np.concatenate([[0], np.cumsum([c["N"] for c in dpc])])
+    for i in range(0, len(dpc), 17):
+        c = dpc[i]
+        tot, b = forward_backward_kmeans_viterbi(c["vec"], c["N"], c["n_min"], c["n_max"])
+        assert np.array_equal(b, g["dp_km_bounds"][ob[i]:ob[i + 1]])
+        assert tot == g["dp_km_total"][i] or np.isnan(tot)
+
+
+# ------------------------------------------------------------------ A11 mutators
+def test_component_mutators_vs_oracle(gpu):
+    from oracle import np_oracle as no
+    from segmentalist_amd.kmeans_components import KMeansComponents
+    for dtype in (np.float32, np.float64):
+        rs = np.random.RandomState(11)
+        X = rs.randn(60, 7).astype(dtype)
+        assign = rs.randint(0, 5, 60)
+        assign[rs.rand(60) < 0.4] = -1
+        assign = no.consecutive_labels(assign)
+        np.random.seed(4)
+        ref = no.KMeansComponents(X, assign.copy(), 8)
+        np.random.seed(4)
+        dev = KMeansComponents(X, assign.copy(), 8)
+
+        def same():
+            assert dev.K == ref.K
+            assert np.array_equal(dev.counts, ref.counts)
+            assert np.array_equal(dev.assignments, ref.assignments)
+            assert np.array_equal(dev.mean_numerators, ref.mean_numerators)
+            assert np.array_equal(dev.means, ref.means)
+            assert dev.means.dtype == ref.means.dtype
+        same()
+        free = list(np.where(ref.assignments == -1)[0])
+        used = list(np.where(ref.assignments != -1)[0])
+        for step in range(40):
+            op = rs.randint(0, 3)
+            if op == 0 and free:
+                i = free.pop(rs.randint(len(free)))
+                k = int(rs.randint(0, 8))
+                ref.add_item(i, k)
+                dev.add_item(i, k)
+                used.append(i)
+            elif op == 1 and used:
+                i = used.pop(rs.randint(len(used)))
+                ref.del_item(i)
+                dev.del_item(i)
+                free.append(i)
+            else:
+                ref.clean_components()
+                dev.clean_components()
+            same()
+        assert abs(dev.sum_neg_sqrd_norm() - ref.sum_neg_sqrd_norm()) <= 1e-9 * abs(ref.sum_neg_sqrd_norm())
+        assert dev.get_max_assignments(list(range(10))) == [int(k) for k in ref.get_max_assignments(range(10))]
+
+
+# ------------------------------------------------------------------ chains, sequential mode (reference chain)
+@pytest.mark.parametrize("chain", cases.KMEANS_CHAINS, ids=[c[0] for c in cases.KMEANS_CHAINS])
+@pytest.mark.parametrize("init", ["spread", "rand"])
+def test_sequential_chain_bit_exact_vs_reference(gpu, golden, chain, init):
+    from segmentalist_amd import kmeans_acoustic_wordseg as kaw
+    g = golden("chains")
+    name, n_utt, D, K, seed, ragged, N, nmax, dtype = chain
+    corpus = cases.chain_corpus(n_utt, D, K, seed, ragged, N, nmax, dtype)
+    random.seed(1)
+    np.random.seed(1)
+    seg = kaw.SegmentalKMeansWordseg(K, *corpus, n_slices_min=0, n_slices_max=nmax, p_boundary_init=0.5,
+                                     init_am_assignments=init, wip=0)
+    c = seg.acoustic_model.components
+    tag = "%s_%s" % (name, init)
+    assert np.array_equal(seg.utterances.boundaries, g[tag + "_init_bounds"])
+    assert np.array_equal(c.assignments, g[tag + "_init_assign"])
+    assert np.array_equal(c.random_means, g[tag + "_random_means"])
+    for it in range(3):
+        rec = seg.segment(1)
+        assert np.array_equal(seg.utterances.boundaries, g[tag + "_bounds"][it]), it
+        assert np.array_equal(c.assignments, g[tag + "_assign"][it]), it
+        assert np.array_equal(c.means, g[tag + "_means"][it]), it
+        assert c.K == g[tag + "_K"][it]
+        assert rec["sum_neg_len_sqrd_norm"][0] == g[tag + "_rec_sum_neg_len_sqrd_norm"][it]
+        assert np.isclose(rec["sum_neg_sqrd_norm"][0], g[tag + "_rec_sum_neg_sqrd_norm"][it], rtol=1e-10)
+        assert rec["n_tokens"][0] == g[tag + "_rec_n_tokens"][it]
+        assert rec["components"][0] == g[tag + "_rec_components"][it]
+    assert np.array_equal(c.mean_numerators, g[tag + "_mean_numerators"])
+    assert np.array_equal(c.counts, g[tag + "_counts"])
+    recf = seg.acoustic_model.fit(3, consider_unassigned=False)
+    assert np.array_equal(c.assignments, g[tag + "_fit_assign"])
+    assert np.array_equal(recf["n_mean_updates"], g[tag + "_fit_n_mean_updates"])
+
+
+def test_get_vec_embed_matches_oracle(gpu):
+    from oracle import np_oracle as no
+    from segmentalist_amd import kmeans_acoustic_wordseg as kaw
+    corpus = cases.chain_corpus(6, 8, 5, 99, True, 0, 5, "float32")
+    random.seed(2); np.random.seed(2)
+    ref = no.SegmentalKMeansWordseg(5, *corpus, n_slices_max=5, wip=-0.3)
+    random.seed(2); np.random.seed(2)
+    seg = kaw.SegmentalKMeansWordseg(5, *corpus, n_slices_max=5, wip=-0.3)
+    for i in range(6):
+        a = ref.get_vec_embed_neg_len_sqrd_norms(ref.utterances.vec_ids[i], ref.utterances.durations[i])
+        b = seg.get_vec_embed_neg_len_sqrd_norms(seg.utterances.vec_ids[i], seg.utterances.durations[i])
+        assert np.array_equal(a, b)
+        assert seg.segment_i(i) == ref.segment_i(i)
+        assert seg.get_unsup_transcript_i(i) == ref.get_unsup_transcript_i(i)
+
+
+# ------------------------------------------------------------------ batch mode vs its CPU specification
+@pytest.mark.parametrize("n_utt,D,K,nmax,dtype,n_blocks", [
+    (12, 8, 6, 6, "float32", 8), (40, 16, 12, 6, "float32", 8), (40, 16, 12, 6, "float32", 1),
+    (25, 5, 30, 4, "float64", 4), (64, 39, 40, 6, "float32", 8)])
+def test_batch_sweep_bit_exact_vs_spec(gpu, n_utt, D, K, nmax, dtype, n_blocks):
+    from oracle import np_oracle as no
+    from segmentalist_amd import kmeans_acoustic_wordseg as kaw
+    corpus = cases.chain_corpus(n_utt, D, K, 1000 + n_utt, True, 0, nmax, dtype)
+    for init in ("spread", "rand"):
+        random.seed(5); np.random.seed(5)
+        ref = no.SegmentalKMeansWordseg(K, *corpus, n_slices_max=nmax, init_am_assignments=init)
+        random.seed(5); np.random.seed(5)
+        seg = kaw.SegmentalKMeansWordseg(K, *corpus, n_slices_max=nmax, init_am_assignments=init,
+                                         sync="batch", n_stat_blocks=n_blocks)
+        cr, cd = ref.acoustic_model.components, seg.acoustic_model.components
+        for it in range(4):
+            want = no.kmeans_batch_sweep(ref, n_blocks=n_blocks)
+            rec = seg.segment(1)
+            assert np.array_equal(seg.utterances.boundaries, ref.utterances.boundaries), it
+            assert np.array_equal(cd.assignments, cr.assignments), it
+            assert cd.K == cr.K
+            assert np.array_equal(cd.counts, cr.counts)
+            assert np.array_equal(cd.mean_numerators, cr.mean_numerators), it
+            assert np.array_equal(cd.means, cr.means), it
+            assert rec["sum_neg_len_sqrd_norm"][0] == want
+            assert rec["n_tokens"][0] == ref.acoustic_model.get_n_assigned()
+
+
+def test_batch_sweep_headline_shape_properties(gpu):
+    """BASELINE config 3 shape (D=100, K=1000, 20 landmarks, n_slices_max=6) at 1500 utterances:
+    size-independent properties + spot parity against the C oracle."""
+    import torch
+    from oracle import c_oracle as co
+    from segmentalist_amd import kmeans_acoustic_wordseg as kaw
+    from segmentalist_amd.synth import make_corpus
+    corpus = make_corpus(1500, 100, 1000, seed=0, N=20, n_slices_max=6)
+    random.seed(0); np.random.seed(0)
+    seg = kaw.SegmentalKMeansWordseg(1000, *corpus, n_slices_max=6, init_am_assignments="spread", sync="batch")
+    c = seg.acoustic_model.components
+    X = c.X
+    for it in range(2):
+        means_before = c.means
+        seg.segment(1)
+        b = seg.utterances.boundaries
+        assert b[:, -1].all()                                     # last landmark always a boundary
+        assign = c.assignments
+        toks = np.where(assign != -1)[0]
+        assert len(toks) == b.sum()                               # one token per segment
+        counts = c.counts
+        assert counts.sum() == len(toks) and (counts[:c.K] > 0).all() and (counts[c.K:] == 0).all()
+        # every token sits on the argmax of the means it was scored against (spot check, C oracle);
+        # components may have been relabelled by clean_components, so compare the mean vectors
+        sel = toks[:: max(1, len(toks) // 200)]
+        _, am = co.kmeans_max_argmax(means_before, X, sel)
+        nb = seg._dk.new_k.cpu().numpy()
+        # statistics are exactly the sums of the assigned rows
+        k0 = int(assign[toks[0]])
+        rows = toks[assign[toks] == k0]
+        assert np.allclose(c.mean_numerators[k0], X[rows].astype(np.float64).sum(0), rtol=1e-12, atol=1e-12)
+        assert len(am) == len(sel) and nb.shape[0] == 1500
+    # idempotence of the kernel: re-running the score+segment stage on unchanged statistics
+    # reproduces the same boundaries
+    seg._dk.score_rows()
+    before = seg._dev_bounds.clone()
+    seg._dk.segment(seg._dev_bounds, 0, 6, 0.0)
+    torch.cuda.synchronize()
+    again = seg._dev_bounds.clone()
+    seg._dk.segment(seg._dev_bounds, 0, 6, 0.0)
+    torch.cuda.synchronize()
+    assert torch.equal(again, seg._dev_bounds)
+    assert before.shape == again.shape

@@ -1,0 +1,91 @@
+"""CPU tests of the host-side mirror (A13): Utterances / process_embeddings / RNG indirection /
+partitioning, against the oracle's restatement (itself pinned to the reference)."""
+import random
+
+import numpy as np
+
+from oracle import np_oracle as no
+from segmentalist_amd import rng
+from segmentalist_amd.device import Partition
+from segmentalist_amd.utterances import Utterances, process_embeddings
+from tests.golden import cases
+
+
+def test_process_embeddings_matches_oracle():
+    emb, vid, dur, lm = cases.chain_corpus(9, 4, 3, 5, True, 0, 4, "float32")
+    E1, V1, L1 = process_embeddings(emb, vid)
+    E2, V2, L2 = no.process_embeddings(emb, vid)
+    assert L1 == L2 and np.array_equal(E1, E2) and E1.dtype == E2.dtype
+    for a, b in zip(V1, V2):
+        assert np.array_equal(a, b)
+    assert V1.row_start[-1] == E1.shape[0]
+
+
+def test_utterances_init_matches_oracle_and_consumes_same_rng(golden):
+    g = golden("chains")
+    for chain in cases.KMEANS_CHAINS:
+        name, n_utt, D, K, seed, ragged, N, nmax, dtype = chain
+        emb, vid, dur, lm = cases.chain_corpus(n_utt, D, K, seed, ragged, N, nmax, dtype)
+        E, V, labels = process_embeddings(emb, vid)
+        args = ([len(lm[i]) for i in labels], V, [dur[i] for i in labels], [lm[i] for i in labels])
+        np.random.seed(1)
+        u = Utterances(*args, p_boundary_init=0.5, n_slices_min=0, n_slices_max=nmax)
+        after = np.random.rand()
+        np.random.seed(1)
+        o = no.Utterances(*args, p_boundary_init=0.5, n_slices_min=0, n_slices_max=nmax)
+        assert after == np.random.rand()
+        assert np.array_equal(u.boundaries, o.boundaries)
+        assert np.array_equal(u.boundaries, g["%s_spread_init_bounds" % name])
+        assert np.array_equal(u.vec_ids, o.vec_ids)
+        assert np.array_equal(u.durations, o.durations, equal_nan=True)
+        for i in range(u.D):
+            assert list(u.get_segmented_embeds_i(i)) == list(o.get_segmented_embeds_i(i))
+            assert u.get_segmented_landmark_indices(i) == o.get_segmented_landmark_indices(i)
+
+
+def test_min_duration_and_seed_boundaries():
+    emb, vid, dur, lm = cases.chain_corpus(5, 3, 2, 8, True, 0, 4, "float32")
+    E, V, labels = process_embeddings(emb, vid)
+    args = ([len(lm[i]) for i in labels], V, [dur[i] for i in labels], [lm[i] for i in labels])
+    seeds = [[l[0] + 1, l[-1]] for l in args[3]]
+    u = Utterances(*args, seed_boundaries=seeds, min_duration=9)
+    o = no.Utterances(*args, seed_boundaries=seeds, min_duration=9)
+    assert np.array_equal(u.boundaries, o.boundaries)
+    assert np.array_equal(u.durations, o.durations, equal_nan=True)
+    u0 = Utterances(*args, p_boundary_init=0)
+    assert u0.boundaries.sum() == u0.D
+
+
+def test_py2_shuffle_is_selectable():
+    random.seed(7)
+    a = list(range(10))
+    rng.set_shuffle("py2")
+    try:
+        rng.shuffle(a)
+    finally:
+        rng.set_shuffle("py3")
+    random.seed(7)
+    b = list(range(10))
+    no.shuffle_py2(b)
+    assert a == b
+    random.seed(7)
+    c = list(range(10))
+    rng.shuffle(c)
+    random.seed(7)
+    d = list(range(10))
+    random.shuffle(d)
+    assert c == d
+
+
+def test_partition_covers_everything_once():
+    row_start = np.arange(0, 1001 * 7, 7)
+    for world in (1, 2, 4, 8):
+        lo = 0
+        for r in range(world):
+            p = Partition(1000, row_start, n_blocks=8, rank=r, world=world)
+            assert p.utt_lo == lo
+            lo = p.utt_hi
+            assert p.row_lo == 7 * p.utt_lo and p.row_hi == 7 * p.utt_hi
+            assert len(p.local_bounds) == 8 // world + 1
+        assert lo == 1000
+    assert list(Partition(1000, row_start, 8, 0, 1).bounds) == no.block_bounds(1000, 8)
