@@ -176,14 +176,17 @@ int32_t segk_kmeans_del_component(segk_ctx *ctx, const segk_corpus *c, segk_kmea
 /* A11 batch-synchronous update (DESIGN.md "batch mode"; spec: oracle/np_oracle.py
  * kmeans_batch_sweep).  Four stages so that a multi-GPU run can exchange the two small
  * intermediate buffers (flag_buf, partials) between them; `utt_lo..utt_hi` is the range of
- * utterances owned by this rank.
- *  (1) segk_kmeans_batch_collect: delete all old tokens of the local utterances; collect,
- *      in token order (utterance, segment), the new tokens whose argmax is an inactive row
- *      (k >= K): flag_buf [dev] int32 [1 + 2*cap] = {count, (slot, k) ...}.
+ * utterances owned by this rank.  The sweep never touches `assignments` (all old items are
+ * deleted, all new tokens added: the array is a pure function of the token lists) -- it is
+ * materialised on demand by segk_kmeans_assignments_from_tokens.
+ *  (1) segk_kmeans_batch_collect: exclusive prefix of n_new -> tok_off [dev] int32
+ *      [utt_hi-utt_lo+1]; collect, in token order (utterance, segment), the new tokens whose
+ *      argmax is an inactive row (k >= K): flag_buf [dev] int32 [1 + 2*cap] =
+ *      {count, (slot, k) ...}.
  *  (2) segk_kmeans_batch_assign: replay the reference's `k > K -> K` clamp
  *      (kmeans_components.py:103-106) over the flagged tokens of ALL ranks in rank order
- *      (flag_all [dev] int32 [n_ranks, 1 + 2*cap]); rewrite the local new_k, set K, write the
- *      assignments of the local new tokens.
+ *      (flag_all [dev] int32 [n_ranks, 1 + 2*cap]); patch the local new_k, set K; write the
+ *      compact token list ctok_id / ctok_k [dev] int32 [>= local tokens] in token order.
  *  (3) segk_kmeans_batch_partials: per statistics block b (utterances
  *      [blk_lo[b], blk_lo[b+1])) sequential fp64 sums in token order:
  *      part_sum [dev] double [n_blocks_local, K_max, D], part_cnt [dev] int64 [.., K_max],
@@ -193,33 +196,40 @@ int32_t segk_kmeans_del_component(segk_ctx *ctx, const segk_corpus *c, segk_kmea
  *      + (b % n_blocks_per_rank) * block size, rank_stride in 8-byte words, so that the
  *      all-gathered per-rank buffers are consumed in place), means = numerators/counts,
  *      clean_components (:263-266) with a relabel table (remap_scratch [dev] int32 [K_max]),
- *      relabel of the local tokens, rebuild of the MFMA tiles.
+ *      relabel of the local tokens' new_k, rebuild of the MFMA tiles.
  *      out_scalars [dev] double [4] = {sum of totals, K, n_tokens, 0}.
  *  status bits: 1 new segment without embedding, 2 add_item on an assigned item
  *  (kmeans_components.py:101 assert), 4 flag buffer overflow.
  */
 int32_t segk_kmeans_batch_collect(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m,
-                                  int32_t utt_lo, int32_t utt_hi, const int32_t *old_tok,
-                                  const int32_t *n_old, const int32_t *new_k, const int32_t *n_new,
-                                  int32_t *flag_buf, int32_t cap, void *stream);
+                                  int32_t utt_lo, int32_t utt_hi, const int32_t *new_k,
+                                  const int32_t *n_new, int32_t *tok_off, int32_t *flag_buf,
+                                  int32_t cap, void *stream);
 int32_t segk_kmeans_batch_assign(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m,
                                  int32_t utt_lo, int32_t utt_hi, const int32_t *flag_all,
                                  int32_t n_ranks, int32_t my_rank, int32_t cap,
                                  const int32_t *new_tok, int32_t *new_k, const int32_t *n_new,
+                                 const int32_t *tok_off, int32_t *ctok_id, int32_t *ctok_k,
                                  int32_t *status, void *stream);
 int32_t segk_kmeans_batch_partials(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m,
-                                   const int32_t *blk_lo, int32_t n_blocks_local,
-                                   const int32_t *new_tok, const int32_t *new_k,
-                                   const int32_t *n_new, const double *out_total,
+                                   const int32_t *blk_lo, int32_t n_blocks_local, int32_t utt_lo,
+                                   const int32_t *tok_off, const int32_t *ctok_id,
+                                   const int32_t *ctok_k, const double *out_total,
                                    double *part_sum, int64_t *part_cnt, double *part_tot,
                                    void *stream);
 int32_t segk_kmeans_batch_finalize(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m,
                                    int32_t utt_lo, int32_t utt_hi, const double *part_sum,
                                    const int64_t *part_cnt, const double *part_tot,
                                    int32_t n_blocks_total, int32_t n_blocks_per_rank,
-                                   int64_t rank_stride, const int32_t *new_tok,
-                                   const int32_t *n_new, int32_t *remap_scratch,
-                                   double *out_scalars, int32_t *status, void *stream);
+                                   int64_t rank_stride, int32_t *new_k, const int32_t *n_new,
+                                   int32_t *remap_scratch, double *out_scalars, int32_t *status,
+                                   void *stream);
+/* assignments[:] = -1, then assignments[new_tok] = new_k for the tokens of utterances
+ * [utt_lo, utt_hi). */
+int32_t segk_kmeans_assignments_from_tokens(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m,
+                                            int32_t utt_lo, int32_t utt_hi, const int32_t *new_tok,
+                                            const int32_t *new_k, const int32_t *n_new,
+                                            void *stream);
 
 /* KMeansComponents.sum_neg_sqrd_norm (kmeans_components.py:234-247), record metric.
  * out [dev] double [1]; tolerance-level parity (summation order differs). */

@@ -62,11 +62,13 @@ SIGNATURES = {
     "segk_kmeans_del_item": (_i32, [_P, _CP, _KP, _i64, _P, _P]),
     "segk_kmeans_clean_components": (_i32, [_P, _CP, _KP, _P, _P]),
     "segk_kmeans_del_component": (_i32, [_P, _CP, _KP, _i32, _P, _P]),
-    "segk_kmeans_batch_collect": (_i32, [_P, _CP, _KP, _i32, _i32, _P, _P, _P, _P, _P, _i32, _P]),
-    "segk_kmeans_batch_assign": (_i32, [_P, _CP, _KP, _i32, _i32, _P, _i32, _i32, _i32, _P, _P, _P, _P, _P]),
-    "segk_kmeans_batch_partials": (_i32, [_P, _CP, _KP, _P, _i32, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "segk_kmeans_batch_collect": (_i32, [_P, _CP, _KP, _i32, _i32, _P, _P, _P, _P, _i32, _P]),
+    "segk_kmeans_batch_assign": (_i32, [_P, _CP, _KP, _i32, _i32, _P, _i32, _i32, _i32, _P, _P, _P, _P, _P, _P,
+                                        _P, _P]),
+    "segk_kmeans_batch_partials": (_i32, [_P, _CP, _KP, _P, _i32, _i32, _P, _P, _P, _P, _P, _P, _P, _P]),
     "segk_kmeans_batch_finalize": (_i32, [_P, _CP, _KP, _i32, _i32, _P, _P, _P, _i32, _i32, _i64, _P, _P, _P, _P,
                                           _P, _P]),
+    "segk_kmeans_assignments_from_tokens": (_i32, [_P, _CP, _KP, _i32, _i32, _P, _P, _P, _P]),
     "segk_kmeans_sum_neg_sqrd_norm": (_i32, [_P, _CP, _KP, _P, _P]),
     "segk_logsumexp": (_f64, [_P, _i64]),
     "segk_draw": (_i32, [_P, _i64, _f64]),

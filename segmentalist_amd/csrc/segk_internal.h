@@ -39,18 +39,25 @@ void segk_set_error(const char *fmt, ...);
 // and score kernels.  One tile = 32 components:
 //   floats [g][lane][2], g < G = ceil(D/4), lane < 64:
 //        M[32*tile + (lane & 31)][4*g + 2*(lane >> 5) + {0,1}]
-//   followed by 32 floats c[i] = -|m_i|^2 / 2   (-3e38 for rows >= K_max)
+//   (g runs to the bucket GB = segk_gmax(D) >= G, zero filled beyond D)
+//   followed, at float offset GB*128, by 32 floats c[i] = -|m_i|^2 / 2   (-3e38 for rows >= K_max)
 //   padded with zeros to a multiple of 1024 floats (whole 16-byte x 256-thread passes).
 // ---------------------------------------------------------------------------------------
 static inline __host__ __device__ int segk_G(int D) { return (D + 3) / 4; }
-// register-array bucket of the score kernel instantiation that serves dimension D
+// k-extent bucket (in groups of 4 dims) of the score-kernel instantiation that serves
+// dimension D: exact for the common embedding sizes, next larger bucket otherwise (the
+// operands are zero padded to the bucket, so the surplus MFMAs add exact zeros).
+#define SEGK_G_BUCKETS {1, 2, 4, 6, 8, 10, 13, 16, 20, 25, 26, 28, 32, 33, 34, 40, 50, 64, 75, 100}
 static inline __host__ __device__ int segk_gmax(int D)
 {
+    const int b[] = SEGK_G_BUCKETS;
     int G = segk_G(D);
-    return G <= 26 ? 26 : G <= 34 ? 34 : G <= 50 ? 50 : G <= 100 ? 100 : -1;
+    for (unsigned i = 0; i < sizeof(b) / sizeof(b[0]); i++)
+        if (G <= b[i]) return b[i];
+    return -1;
 }
-// tile stride in floats: the bucket's image size rounded up to whole 1024-float passes, so
-// that the number of LDS staging passes is a compile-time constant of the instantiation
+// tile stride in floats: the bucket's image ([GB][64][2] operand floats + 32 constants)
+// rounded up to whole 1024-float passes
 static inline __host__ __device__ int segk_tile_stride(int D)
 {
     int gm = segk_gmax(D);

@@ -146,7 +146,7 @@ __global__ void k_kmeans_prepare(const XT *means, int K_max, int D, float *tiles
                                  unsigned long long *mnorm2_bits)
 {
     const int tile = blockIdx.x;
-    const int G = segk_G(D);
+    const int G = segk_gmax(D);          // bucket extent; dims >= D are zero filled
     const int stride = segk_tile_stride(D);
     float *T = tiles + (int64_t)tile * stride;
     __shared__ double nrm[32];
@@ -196,7 +196,7 @@ __global__ void k_mnorm_finish(const unsigned long long *mnorm2_bits, double *mn
 template <int GMAX, int NB>
 __global__ __launch_bounds__(256, 2) void k_kmeans_score(
     const float *__restrict__ X32, int64_t ld32, const int32_t *__restrict__ ids, int64_t row0, int64_t n,
-    const float *__restrict__ tiles, int n_tiles, int tile_stride, int G,
+    const float *__restrict__ tiles, int n_tiles, int tile_stride, int G /* groups present in X32 rows */,
     int32_t *__restrict__ cand_k, float *__restrict__ cand_f)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256, 2) void k_kmeans_score(
         }
         f32x16 acc[NB];
         {
-            const float *cv = T + G * 128 + 4 * h;
+            const float *cv = T + GMAX * 128 + 4 * h;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 float4 c4 = *reinterpret_cast<const float4 *>(cv + 8 * q);
@@ -263,15 +263,13 @@ __global__ __launch_bounds__(256, 2) void k_kmeans_score(
         }
 #pragma unroll
         for (int g = 0; g < GMAX; g++) {
-            if (g < G) {
-                float2 a = *reinterpret_cast<const float2 *>(T + (g * 64 + lane) * 2);
+            float2 a = *reinterpret_cast<const float2 *>(T + (g * 64 + lane) * 2);
 #pragma unroll
-                for (int nb = 0; nb < NB; nb++)
-                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, xb[nb][g].x, acc[nb], 0, 0, 0);
+            for (int nb = 0; nb < NB; nb++)
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, xb[nb][g].x, acc[nb], 0, 0, 0);
 #pragma unroll
-                for (int nb = 0; nb < NB; nb++)
-                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, xb[nb][g].y, acc[nb], 0, 0, 0);
-            }
+            for (int nb = 0; nb < NB; nb++)
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, xb[nb][g].y, acc[nb], 0, 0, 0);
         }
         // running top-2 (values) and argmax (component) per lane
         const int cbase = t * 32 + 4 * h;
@@ -472,91 +470,106 @@ __global__ void k_kmeans_segment(segk_corpus c, segk_kmeans m, const int32_t *ut
         bvec[i] = v + wip;
     }
     __syncthreads();
-    if (tid != 0) return;
 
-    // ---- old tokens (utterances.py:159-174) before the boundaries are overwritten
-    uint8_t *bnd = boundaries + (int64_t)u * c.N_max;
-    {
+    // The serial part (one thread) works on LDS only: boundaries, token lists and the DP
+    // tables are staged in LDS and written out by the whole workgroup afterwards.
+    uint8_t *gbnd = boundaries + (int64_t)u * c.N_max;
+    int32_t *l_old = queue;                    // [N]   (queue is free after the exact stage)
+    int32_t *l_new = queue + c.N_max;          // [N]   band_cap >= 3*N_max is guaranteed by the launcher
+    int32_t *l_newk = queue + 2 * c.N_max;     // [N]
+    uint8_t *l_bnd = (uint8_t *)red_k;         // [N]   (nt*4 bytes >= N_max checked by the launcher)
+    for (int j = tid; j < N; j += nt) l_bnd[j] = gbnd[j];
+    __syncthreads();
+    if (tid == 0) {
+#define V_(t, s) bvec[((t) - 1) * W + ((t) - 1 - (s))]
+#define ID_(t, s) (((t) - 1 - (s)) < W ? bid[((t) - 1) * W + ((t) - 1 - (s))] : vid[(t) * ((t) - 1) / 2 + (s)])
+        // ---- old tokens (utterances.py:159-174) before the boundaries are overwritten
         int no = 0, jp = 0;
         for (int j = 0; j < N; j++)
-            if (bnd[j]) {
-                int id = vid[(j + 1) * j / 2 + jp];
-                if (id >= 0) old_tok[(int64_t)u * c.N_max + no++] = id;
+            if (l_bnd[j]) {
+                int id = ID_(j + 1, jp);
+                if (id >= 0) l_old[no++] = id;
                 jp = j + 1;
             }
-        n_old[u] = no;
-    }
-    // ---- A8 forward (kmeans_acoustic_wordseg.py:494-506).  V(t,s) = bvec[(t-1)*W + (t-1-s)]
-#define V_(t, s) bvec[((t) - 1) * W + ((t) - 1 - (s))]
-    gam[0] = 0.0;
-    for (int t = 1; t < N; t++) {
-        int lo = t - W < 0 ? 0 : t - W;
-        double best = NEG_INF_D;
-        for (int s = lo; s < t; s++) {
-            double v = V_(t, s) + gam[s];
-            if (v > best) best = v;
-        }
-        gam[t] = best;
-    }
-    for (int j = 0; j < N; j++) bnd[j] = 0;
-    bnd[N - 1] = 1;
-    // ---- A8 backward (:510-553)
-    int t = N;
-    double total = 0.0;
-    int lo = 0;
-    for (;;) {
-        lo = t - W < 0 ? 0 : t - W;
-        bool all_inf = true;
-        for (int s = lo; s < t; s++)
-            if (V_(t, s) + gam[s] != NEG_INF_D) { all_inf = false; break; }
-        if (all_inf) {
-            while (all_inf) {
-                t = t - 1;
-                if (t == 0) break;
-                lo = t - W < 0 ? 0 : t - W;
-                all_inf = true;
-                for (int s = lo; s < t; s++)
-                    if (V_(t, s) + gam[s] != NEG_INF_D) { all_inf = false; break; }
-            }
-            bnd[(t - 1 + N) % N] = 1;
-        }
-        int k = 1;
-        if (t > 0) {
+        // ---- A8 forward (kmeans_acoustic_wordseg.py:494-506)
+        gam[0] = 0.0;
+        for (int t = 1; t < N; t++) {
+            int lo = t - W < 0 ? 0 : t - W;
             double best = NEG_INF_D;
-            bool first = true;
-            for (int s = t - 1; s >= lo; s--) {
+            for (int s = lo; s < t; s++) {
                 double v = V_(t, s) + gam[s];
-                if (first || v > best) { best = v; k = t - s; first = false; }
+                if (v > best) best = v;
             }
-            total += V_(t, t - k);
-        } else {
-            total += V_(N, N - 1);      // python vec[-1]: the last span [N-1, N)
+            gam[t] = best;
         }
-        if (t - k - 1 < 0) break;
-        bnd[t - k - 1] = 1;
-        t = t - k;
-    }
-    out_total[u] = total;
-    // ---- new tokens + their best components (:312-313)
-    {
-        int nn = 0, jp = 0, bad = 0;
+        for (int j = 0; j < N; j++) l_bnd[j] = 0;
+        l_bnd[N - 1] = 1;
+        // ---- A8 backward (:510-553)
+        int t = N;
+        double total = 0.0;
+        int lo = 0;
+        for (;;) {
+            lo = t - W < 0 ? 0 : t - W;
+            bool all_inf = true;
+            for (int s = lo; s < t; s++)
+                if (V_(t, s) + gam[s] != NEG_INF_D) { all_inf = false; break; }
+            if (all_inf) {
+                while (all_inf) {
+                    t = t - 1;
+                    if (t == 0) break;
+                    lo = t - W < 0 ? 0 : t - W;
+                    all_inf = true;
+                    for (int s = lo; s < t; s++)
+                        if (V_(t, s) + gam[s] != NEG_INF_D) { all_inf = false; break; }
+                }
+                l_bnd[(t - 1 + N) % N] = 1;
+            }
+            int k = 1;
+            if (t > 0) {
+                double best = NEG_INF_D;
+                bool first = true;
+                for (int s = t - 1; s >= lo; s--) {
+                    double v = V_(t, s) + gam[s];
+                    if (first || v > best) { best = v; k = t - s; first = false; }
+                }
+                total += V_(t, t - k);
+            } else {
+                total += V_(N, N - 1);      // python vec[-1]: the last span [N-1, N)
+            }
+            if (t - k - 1 < 0) break;
+            l_bnd[t - k - 1] = 1;
+            t = t - k;
+        }
+        // ---- new tokens + their best components (:312-313)
+        int nn = 0, bad = 0;
+        jp = 0;
         for (int j = 0; j < N; j++)
-            if (bnd[j]) {
-                int tt = j + 1, s = jp;
-                int id = vid[tt * (tt - 1) / 2 + s];
-                int w = tt - 1 - s;
-                if (id < 0 || w >= W) bad = 1;
+            if (l_bnd[j]) {
+                int tt = j + 1, w = tt - 1 - jp;
+                if (w >= W || bid[(tt - 1) * W + w] < 0) bad = 1;
                 else {
-                    new_tok[(int64_t)u * c.N_max + nn] = id;
-                    new_k[(int64_t)u * c.N_max + nn] = bk[(tt - 1) * W + w];
+                    l_new[nn] = bid[(tt - 1) * W + w];
+                    l_newk[nn] = bk[(tt - 1) * W + w];
                     nn++;
                 }
                 jp = j + 1;
             }
+        out_total[u] = total;
+        n_old[u] = no;
         n_new[u] = nn;
+        *qn = no | (nn << 16);
         if (bad) atomicOr(status, 1);
-    }
 #undef V_
+#undef ID_
+    }
+    __syncthreads();
+    const int no = *qn & 0xffff, nn = *qn >> 16;
+    for (int j = tid; j < N; j += nt) gbnd[j] = l_bnd[j];
+    for (int j = tid; j < no; j += nt) old_tok[(int64_t)u * c.N_max + j] = l_old[j];
+    for (int j = tid; j < nn; j += nt) {
+        new_tok[(int64_t)u * c.N_max + j] = l_new[j];
+        new_k[(int64_t)u * c.N_max + j] = l_newk[j];
+    }
 }
 
 // ======================================================================================
@@ -706,51 +719,45 @@ __global__ void k_kmeans_update(segk_corpus c, segk_kmeans m, int op, int utt, i
 // ======================================================================================
 // A11 batch-synchronous statistics (spec: oracle/np_oracle.py kmeans_batch_sweep)
 // ======================================================================================
-// (1a) delete all old tokens of utterances [lo, hi)
-__global__ void k_batch_delete_old(segk_corpus c, segk_kmeans m, int lo, int hi, const int32_t *old_tok,
-                                   const int32_t *n_old)
+// (1) one workgroup: (a) exclusive prefix sum of n_new over the local utterances ->
+//     tok_off[u - lo] (tok_off[hi - lo] = number of local tokens); (b) collect, in token order,
+//     the new tokens whose argmax is an inactive row (k >= K):
+//     flag_buf[0] = count, then (slot = utt*N_max + t, k) pairs.
+__global__ void k_batch_collect(segk_corpus c, segk_kmeans m, int lo, int hi, const int32_t *new_k,
+                                const int32_t *n_new, int32_t *tok_off, int32_t *flag_buf, int cap)
 {
-    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int64_t tot = (int64_t)(hi - lo) * c.N_max;
-    if (idx >= tot) return;
-    int u = lo + (int)(idx / c.N_max), t = (int)(idx % c.N_max);
-    if (t < n_old[u]) m.assignments[old_tok[(int64_t)u * c.N_max + t]] = -1;
-}
-
-// (1b) collect, in token order, the new tokens whose argmax is an inactive row (k >= K):
-//      flag_buf[0] = count, then (utt*N_max + t, k) pairs.  Single workgroup.
-__global__ void k_batch_collect_flags(segk_corpus c, segk_kmeans m, int lo, int hi, const int32_t *new_k,
-                                      const int32_t *n_new, int32_t *flag_buf, int cap)
-{
-    __shared__ int s_cnt;
-    __shared__ int s_wave[16];
+    __shared__ int s_cnt, s_tok;
+    __shared__ int s_wave[16], s_wave2[16];
     const int tid = threadIdx.x, nt = blockDim.x;
+    const int lane = tid & 63, wv = tid >> 6, nw = nt >> 6;
     const int K = *m.K;
-    if (tid == 0) s_cnt = 0;
+    if (tid == 0) { s_cnt = 0; s_tok = 0; }
     __syncthreads();
-    // chunks of nt utterances; within a chunk ordered compaction by prefix sums
     for (int u0 = lo; u0 < hi; u0 += nt) {
-        int u = u0 + tid;
-        int mine = 0;
-        if (u < hi)
-            for (int t = 0; t < n_new[u]; t++)
+        const int u = u0 + tid;
+        int mine = 0, ntok = 0;
+        if (u < hi) {
+            ntok = n_new[u];
+            for (int t = 0; t < ntok; t++)
                 if (new_k[(int64_t)u * c.N_max + t] >= K) mine++;
-        // block exclusive scan of `mine`
-        int lane = tid & 63, wv = tid >> 6;
-        int incl = mine;
-        for (int o = 1; o < 64; o <<= 1) {
-            int v = __shfl_up(incl, o);
-            if (lane >= o) incl += v;
         }
-        if (lane == 63) s_wave[wv] = incl;
+        int incl = mine, incl2 = ntok;
+        for (int o = 1; o < 64; o <<= 1) {
+            int v = __shfl_up(incl, o), v2 = __shfl_up(incl2, o);
+            if (lane >= o) { incl += v; incl2 += v2; }
+        }
+        if (lane == 63) { s_wave[wv] = incl; s_wave2[wv] = incl2; }
         __syncthreads();
-        int woff = 0;
-        for (int w2 = 0; w2 < wv; w2++) woff += s_wave[w2];
-        int total = 0;
-        for (int w2 = 0; w2 < (nt >> 6); w2++) total += s_wave[w2];
+        int woff = 0, woff2 = 0, total = 0, total2 = 0;
+        for (int w2 = 0; w2 < nw; w2++) {
+            if (w2 < wv) { woff += s_wave[w2]; woff2 += s_wave2[w2]; }
+            total += s_wave[w2];
+            total2 += s_wave2[w2];
+        }
+        if (u < hi) tok_off[u - lo] = s_tok + woff2 + incl2 - ntok;
         int off = s_cnt + woff + incl - mine;
         if (mine > 0) {
-            for (int t = 0; t < n_new[u]; t++) {
+            for (int t = 0; t < ntok; t++) {
                 int k = new_k[(int64_t)u * c.N_max + t];
                 if (k >= K) {
                     if (off < cap) {
@@ -762,53 +769,57 @@ __global__ void k_batch_collect_flags(segk_corpus c, segk_kmeans m, int lo, int 
             }
         }
         __syncthreads();
-        if (tid == 0) s_cnt += total;
+        if (tid == 0) { s_cnt += total; s_tok += total2; }
         __syncthreads();
     }
-    if (tid == 0) flag_buf[0] = s_cnt;
+    if (tid == 0) {
+        flag_buf[0] = s_cnt;
+        tok_off[hi - lo] = s_tok;
+    }
 }
 
-// (1c) resolve the `k > K -> K` clamp over the flagged tokens of ALL ranks in rank order
-//      (flag_all = n_ranks buffers of stride 1+2*cap), rewrite the local new_k, set K, then
-//      write the assignments of the local new tokens.  Single workgroup.
-__global__ void k_batch_resolve(segk_corpus c, segk_kmeans m, int lo, int hi, const int32_t *flag_all,
-                                int n_ranks, int my_rank, int cap, const int32_t *new_tok, int32_t *new_k,
-                                const int32_t *n_new, int32_t *status)
+// (2) replay the `k > K -> K` clamp (kmeans_components.py:103-106) over the flagged tokens of
+//     ALL ranks in rank order; patch the local new_k; set K.  One thread (the list is short).
+__global__ void k_batch_resolve(segk_kmeans m, const int32_t *flag_all, int n_ranks, int my_rank, int cap,
+                                int32_t *new_k, int32_t *status)
 {
-    __shared__ int s_K;
-    if (threadIdx.x == 0) {
-        int K = *m.K;
-        for (int r = 0; r < n_ranks; r++) {
-            const int32_t *fb = flag_all + (int64_t)r * (1 + 2 * cap);
-            int cnt = fb[0];
-            if (cnt > cap) { atomicOr(status, 4); cnt = cap; }
-            for (int q = 0; q < cnt; q++) {
-                int k = fb[2 + 2 * q];
-                if (k > K) k = K;
-                if (k == K) K++;
-                if (r == my_rank) new_k[fb[1 + 2 * q]] = k;
-            }
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int K = *m.K;
+    for (int r = 0; r < n_ranks; r++) {
+        const int32_t *fb = flag_all + (int64_t)r * (1 + 2 * cap);
+        int cnt = fb[0];
+        if (cnt > cap) { atomicOr(status, 4); cnt = cap; }
+        for (int q = 0; q < cnt; q++) {
+            int k = fb[2 + 2 * q];
+            if (k > K) k = K;
+            if (k == K) K++;
+            if (r == my_rank) new_k[fb[1 + 2 * q]] = k;
         }
-        s_K = K;
-        *m.K = K;
     }
-    __syncthreads();
+    *m.K = K;
+}
+
+// (3) compact the local tokens in token order: ctok[tok_off[u-lo] + t] = (embedding, component)
+__global__ void k_batch_compact(segk_corpus c, int lo, int hi, const int32_t *new_tok, const int32_t *new_k,
+                                const int32_t *n_new, const int32_t *tok_off, int32_t *ctok_id, int32_t *ctok_k)
+{
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t tot = (int64_t)(hi - lo) * c.N_max;
-    for (int64_t idx = threadIdx.x; idx < tot; idx += blockDim.x) {
-        int u = lo + (int)(idx / c.N_max), t = (int)(idx % c.N_max);
-        if (t < n_new[u]) {
-            int64_t p = (int64_t)u * c.N_max + t;
-            if (m.assignments[new_tok[p]] != -1) atomicOr(status, 2);
-            m.assignments[new_tok[p]] = new_k[p];
-        }
+    if (idx >= tot) return;
+    int u = lo + (int)(idx / c.N_max), t = (int)(idx % c.N_max);
+    if (t < n_new[u]) {
+        int p = tok_off[u - lo] + t;
+        ctok_id[p] = new_tok[(int64_t)u * c.N_max + t];
+        ctok_k[p] = new_k[(int64_t)u * c.N_max + t];
     }
 }
 
-// (2) per statistics block and component: sequential fp64 sum over the block's tokens in
-//     token order.  One wave per (block, component); lanes own dimensions.
+// (4) per statistics block and component: sequential fp64 sum over the block's tokens in
+//     token order.  One wave per (block, component); lanes own dimensions; the four waves of
+//     a workgroup share the block, scanning the compact token list 64 entries at a time.
 template <typename XT>
-__global__ void k_batch_partials(segk_corpus c, segk_kmeans m, const int32_t *blk_lo, int n_blocks,
-                                 const int32_t *new_tok, const int32_t *new_k, const int32_t *n_new,
+__global__ void k_batch_partials(segk_corpus c, segk_kmeans m, const int32_t *blk_lo, int n_blocks, int lo,
+                                 const int32_t *tok_off, const int32_t *ctok_id, const int32_t *ctok_k,
                                  const double *out_total, double *part_sum, int64_t *part_cnt,
                                  double *part_tot)
 {
@@ -819,20 +830,17 @@ __global__ void k_batch_partials(segk_corpus c, segk_kmeans m, const int32_t *bl
     const int D = c.D;
     const XT *X = (const XT *)c.X;
     const int u0 = blk_lo[b], u1 = blk_lo[b + 1];
+    const int p0 = tok_off[u0 - lo], p1 = tok_off[u1 - lo];
     constexpr int MAXR = 8;                       // D <= 512 per pass
     for (int d0 = 0; d0 < D; d0 += 64 * MAXR) {
         double acc[MAXR];
 #pragma unroll
         for (int r = 0; r < MAXR; r++) acc[r] = 0.0;
         int64_t cnt = 0;
-        const int64_t s0 = (int64_t)u0 * c.N_max, s1 = (int64_t)u1 * c.N_max;
-        for (int64_t sb = s0; sb < s1; sb += 64) {
-            int64_t slot = sb + lane;
+        for (int pb = p0; pb < p1; pb += 64) {
+            int p = pb + lane;
             int match = 0, id = 0;
-            if (slot < s1) {
-                int u = (int)(slot / c.N_max), t = (int)(slot % c.N_max);
-                if (t < n_new[u] && new_k[slot] == k) { match = 1; id = new_tok[slot]; }
-            }
+            if (p < p1 && ctok_k[p] == k) { match = 1; id = ctok_id[p]; }
             unsigned long long bal = __ballot(match);
             while (bal) {
                 int src = __ffsll((long long)bal) - 1;
@@ -871,9 +879,9 @@ struct PartAddr {
     }
 };
 
+// balanced binary tree over n <= 64 parts, pairing neighbours level by level, odd one carried
 __device__ __forceinline__ double tree_sum_d(const double *p, const PartAddr &pa, int n)
 {
-    // balanced binary tree over n parts, pairing neighbours level by level, odd one carried
     double buf[64];
     for (int i = 0; i < n; i++) buf[i] = p[pa(i)];
     while (n > 1) {
@@ -885,7 +893,7 @@ __device__ __forceinline__ double tree_sum_d(const double *p, const PartAddr &pa
     return buf[0];
 }
 
-// (3a) combine the partials of all blocks, means = numerators / counts for active rows
+// (5a) combine the partials of all blocks, means = numerators / counts for active rows
 template <typename XT>
 __global__ void k_batch_combine(segk_corpus c, segk_kmeans m, const double *part_sum, const int64_t *part_cnt,
                                 const double *part_tot, int n_blocks, int nbl, int64_t rank_stride,
@@ -906,77 +914,107 @@ __global__ void k_batch_combine(segk_corpus c, segk_kmeans m, const double *part
         if (k < K && cnt != 0) ((XT *)m.means)[idx] = (XT)(v / (double)cnt);
         if (idx % D == 0) m.counts[k] = cnt;
     }
-    if (idx == 0) {
-        out_scalars[0] = tree_sum_d(part_tot, pa_tot, n_blocks);
-        int64_t ntok = 0;
-        for (int b = 0; b < n_blocks; b++)
-            for (int k = 0; k < m.K_max; k++) ntok += part_cnt[pa_cnt(b) + k];
-        out_scalars[2] = (double)ntok;
-    }
+    if (idx == 0) out_scalars[0] = tree_sum_d(part_tot, pa_tot, n_blocks);
 }
 
-// (3b) clean_components with a relabel table instead of a scan per deletion.  Single
-//      workgroup; remap [K_max] int32 scratch.
+// (5b) clean_components (kmeans_components.py:263-266) with a relabel table instead of a scan
+//      of `assignments` per deletion.  Single workgroup: the empty rows are found in parallel
+//      (bitmap), then deleted one by one in descending order as the reference does;
+//      remap [K_max]: original label -> final row.  Also n_tokens = sum(counts).
 template <typename XT>
 __global__ void k_batch_clean(segk_corpus c, segk_kmeans m, int32_t *remap, double *out_scalars)
 {
-    __shared__ int shK, sh_e;
+    __shared__ int shK;
+    __shared__ unsigned int bitmap[1024];            // K_max <= 32768
+    __shared__ long long red[256];
     const int tid = threadIdx.x, nt = blockDim.x;
     const int D = c.D;
     XT *means = (XT *)m.means;
     const XT *rnd = (const XT *)m.random_means;
+    const int K0 = *m.K;
+    const int nwords = (K0 + 31) / 32;
+    for (int w = tid; w < nwords; w += nt) bitmap[w] = 0;
     for (int k = tid; k < m.K_max; k += nt) remap[k] = k;
-    if (tid == 0) shK = *m.K;
+    if (tid == 0) shK = K0;
     __syncthreads();
-    const int K0 = shK;
-    for (int k = K0 - 1; k >= 0; k--) {
-        if (tid == 0) sh_e = (m.counts[k] == 0) ? 1 : 0;
-        __syncthreads();
-        const int empty = sh_e;
-        __syncthreads();
-        if (!empty) continue;
-        if (tid == 0) shK = shK - 1;
-        __syncthreads();
-        const int K = shK;
-        if (k != K) {
-            const double cntK = (double)m.counts[K];
-            for (int d = tid; d < D; d += nt) {
-                double v = m.mean_numerators[(int64_t)K * D + d];
-                m.mean_numerators[(int64_t)k * D + d] = v;
-                means[(int64_t)k * D + d] = (XT)(v / cntK);
-            }
-            // whichever ORIGINAL labels currently live in row K now live in row k
-            for (int q = tid; q < m.K_max; q += nt)
-                if (remap[q] == K) remap[q] = k;
-        }
-        __syncthreads();
-        for (int d = tid; d < D; d += nt) {
-            m.mean_numerators[(int64_t)K * D + d] = 0.0;
-            means[(int64_t)K * D + d] = rnd[(int64_t)K * D + d];
-        }
-        if (tid == 0) {
-            if (k != K) m.counts[k] = m.counts[K];
-            m.counts[K] = 0;
-        }
+    long long csum = 0;
+    for (int k = tid; k < m.K_max; k += nt) {
+        long long cn = m.counts[k];
+        csum += cn;
+        if (k < K0 && cn == 0) atomicOr(&bitmap[k >> 5], 1u << (k & 31));
+    }
+    red[tid] = csum;
+    __syncthreads();
+    for (int o = nt >> 1; o > 0; o >>= 1) {
+        if (tid < o) red[tid] += red[tid + o];
         __syncthreads();
     }
+    if (tid == 0) out_scalars[2] = (double)red[0];
+    for (int w = nwords - 1; w >= 0; w--) {
+        unsigned int bits = bitmap[w];                 // uniform across the workgroup
+        while (bits) {
+            const int bit = 31 - __clz((int)bits);
+            bits &= ~(1u << bit);
+            const int k = w * 32 + bit;
+            __syncthreads();
+            if (tid == 0) shK = shK - 1;
+            __syncthreads();
+            const int K = shK;
+            if (k != K) {
+                const double cntK = (double)m.counts[K];
+                for (int d = tid; d < D; d += nt) {
+                    double v = m.mean_numerators[(int64_t)K * D + d];
+                    m.mean_numerators[(int64_t)k * D + d] = v;
+                    means[(int64_t)k * D + d] = (XT)(v / cntK);
+                }
+                // whichever ORIGINAL labels currently live in row K now live in row k
+                for (int q = tid; q < m.K_max; q += nt)
+                    if (remap[q] == K) remap[q] = k;
+            }
+            __syncthreads();
+            for (int d = tid; d < D; d += nt) {
+                m.mean_numerators[(int64_t)K * D + d] = 0.0;
+                means[(int64_t)K * D + d] = rnd[(int64_t)K * D + d];
+            }
+            if (tid == 0) {
+                if (k != K) m.counts[k] = m.counts[K];
+                m.counts[K] = 0;
+            }
+        }
+    }
+    __syncthreads();
     if (tid == 0) {
         *m.K = shK;
         out_scalars[1] = (double)shK;
     }
 }
 
-// (3c) relabel the assignments of the local new tokens through remap
-__global__ void k_batch_relabel(segk_corpus c, segk_kmeans m, int lo, int hi, const int32_t *new_tok,
-                                const int32_t *n_new, const int32_t *remap)
+// (5c) final labels of the local tokens
+__global__ void k_batch_relabel(segk_corpus c, int lo, int hi, int32_t *new_k, const int32_t *n_new,
+                                const int32_t *remap)
 {
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t tot = (int64_t)(hi - lo) * c.N_max;
     if (idx >= tot) return;
     int u = lo + (int)(idx / c.N_max), t = (int)(idx % c.N_max);
     if (t < n_new[u]) {
-        int e = new_tok[(int64_t)u * c.N_max + t];
-        m.assignments[e] = remap[m.assignments[e]];
+        int64_t p = (int64_t)u * c.N_max + t;
+        new_k[p] = remap[new_k[p]];
+    }
+}
+
+// `assignments` from the token lists of utterances [lo, hi) (everything else unassigned):
+// the batch sweep does not touch `assignments`; it is materialised on demand.
+__global__ void k_assign_from_tokens(segk_corpus c, segk_kmeans m, int lo, int hi, const int32_t *new_tok,
+                                     const int32_t *new_k, const int32_t *n_new)
+{
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t tot = (int64_t)(hi - lo) * c.N_max;
+    if (idx >= tot) return;
+    int u = lo + (int)(idx / c.N_max), t = (int)(idx % c.N_max);
+    if (t < n_new[u]) {
+        int64_t p = (int64_t)u * c.N_max + t;
+        m.assignments[new_tok[p]] = new_k[p];
     }
 }
 
@@ -1280,11 +1318,16 @@ int32_t segk_kmeans_score(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans
     SEGK_REQUIRE(ids != nullptr || (row0 >= 0 && row0 + n <= c->n_emb), "row range");
     if (n <= 0) return SEGK_OK;
     hipStream_t st = (hipStream_t)stream;
-    const int G = segk_G(c->D);
-    if (G <= 26) return launch_score<26, 2>(c, m, ids, row0, n, cand_k, cand_f, st);
-    if (G <= 34) return launch_score<34, 2>(c, m, ids, row0, n, cand_k, cand_f, st);
-    if (G <= 50) return launch_score<50, 1>(c, m, ids, row0, n, cand_k, cand_f, st);
-    if (G <= 100) return launch_score<100, 1>(c, m, ids, row0, n, cand_k, cand_f, st);
+    const int GB = segk_gmax(c->D);
+    switch (GB) {
+#define SEGK_CASE(g, nb) case g: return launch_score<g, nb>(c, m, ids, row0, n, cand_k, cand_f, st);
+        SEGK_CASE(1, 2) SEGK_CASE(2, 2) SEGK_CASE(4, 2) SEGK_CASE(6, 2) SEGK_CASE(8, 2) SEGK_CASE(10, 2)
+        SEGK_CASE(13, 2) SEGK_CASE(16, 2) SEGK_CASE(20, 2) SEGK_CASE(25, 2) SEGK_CASE(26, 2) SEGK_CASE(28, 2)
+        SEGK_CASE(32, 2) SEGK_CASE(33, 2) SEGK_CASE(34, 2) SEGK_CASE(40, 1) SEGK_CASE(50, 1) SEGK_CASE(64, 1)
+        SEGK_CASE(75, 1) SEGK_CASE(100, 1)
+#undef SEGK_CASE
+        default: break;
+    }
     segk_set_error("segk_kmeans_score: D=%d > 400 is not supported by the register-resident score kernel", c->D);
     return SEGK_ERR_UNSUPPORTED;
 }
@@ -1337,9 +1380,11 @@ int32_t segk_kmeans_segment(segk_ctx *ctx, const segk_corpus *c, const segk_kmea
     SEGK_REQUIRE(utts != nullptr || (utt0 >= 0 && utt0 + n_utts <= c->n_utt), "utterance range");
     if (n_utts <= 0) return SEGK_OK;
     hipStream_t st = (hipStream_t)stream;
-    const int nt = 256;
     const int W = (n_slices_max > 0 && n_slices_max < c->N_max) ? n_slices_max : c->N_max;
-    const int band_cap = c->N_max * W;
+    // band entries, padded so that the token staging lists (3 x N_max ints) fit in `queue`
+    const int band_cap = c->N_max * (W < 3 ? 3 : W);
+    const int nt = (band_cap <= 128 && c->N_max <= 512) ? 128 : 256;
+    SEGK_REQUIRE(c->N_max <= 4 * nt && c->N_max < 65536, "N_max too large for the boundary staging buffer");
     size_t xsz = (c->x_dtype == SEGK_F32 ? 4 : 8) * (size_t)((c->D + 1) & ~1);
     size_t lds = (size_t)(band_cap + c->N_max + 1 + nt) * sizeof(double) + xsz
                  + (size_t)(3 * band_cap + nt + 4) * sizeof(int32_t);
@@ -1427,21 +1472,15 @@ int32_t segk_kmeans_del_component(segk_ctx *ctx, const segk_corpus *c, segk_kmea
 }
 
 int32_t segk_kmeans_batch_collect(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m, int32_t utt_lo,
-                                  int32_t utt_hi, const int32_t *old_tok, const int32_t *n_old,
-                                  const int32_t *new_k, const int32_t *n_new, int32_t *flag_buf, int32_t cap,
-                                  void *stream)
+                                  int32_t utt_hi, const int32_t *new_k, const int32_t *n_new, int32_t *tok_off,
+                                  int32_t *flag_buf, int32_t cap, void *stream)
 {
     (void)ctx;
     int rc = check_corpus(c);
     if (rc) return rc;
     SEGK_REQUIRE(0 <= utt_lo && utt_lo <= utt_hi && utt_hi <= c->n_utt, "utterance range");
-    hipStream_t st = (hipStream_t)stream;
-    int64_t tot = (int64_t)(utt_hi - utt_lo) * c->N_max;
-    if (tot > 0)
-        hipLaunchKernelGGL(k_batch_delete_old, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, *c, *m, utt_lo,
-                           utt_hi, old_tok, n_old);
-    hipLaunchKernelGGL(k_batch_collect_flags, dim3(1), dim3(1024), 0, st, *c, *m, utt_lo, utt_hi, new_k, n_new,
-                       flag_buf, cap);
+    hipLaunchKernelGGL(k_batch_collect, dim3(1), dim3(1024), 0, (hipStream_t)stream, *c, *m, utt_lo, utt_hi, new_k,
+                       n_new, tok_off, flag_buf, cap);
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;
 }
@@ -1449,21 +1488,27 @@ int32_t segk_kmeans_batch_collect(segk_ctx *ctx, const segk_corpus *c, segk_kmea
 int32_t segk_kmeans_batch_assign(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m, int32_t utt_lo,
                                  int32_t utt_hi, const int32_t *flag_all, int32_t n_ranks, int32_t my_rank,
                                  int32_t cap, const int32_t *new_tok, int32_t *new_k, const int32_t *n_new,
-                                 int32_t *status, void *stream)
+                                 const int32_t *tok_off, int32_t *ctok_id, int32_t *ctok_k, int32_t *status,
+                                 void *stream)
 {
     (void)ctx;
     int rc = check_corpus(c);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_batch_resolve, dim3(1), dim3(1024), 0, (hipStream_t)stream, *c, *m, utt_lo, utt_hi,
-                       flag_all, n_ranks, my_rank, cap, new_tok, new_k, n_new, status);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_batch_resolve, dim3(1), dim3(64), 0, st, *m, flag_all, n_ranks, my_rank, cap, new_k, status);
+    int64_t tot = (int64_t)(utt_hi - utt_lo) * c->N_max;
+    if (tot > 0)
+        hipLaunchKernelGGL(k_batch_compact, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, *c, utt_lo, utt_hi,
+                           new_tok, new_k, n_new, tok_off, ctok_id, ctok_k);
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;
 }
 
 int32_t segk_kmeans_batch_partials(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m,
-                                   const int32_t *blk_lo, int32_t n_blocks_local, const int32_t *new_tok,
-                                   const int32_t *new_k, const int32_t *n_new, const double *out_total,
-                                   double *part_sum, int64_t *part_cnt, double *part_tot, void *stream)
+                                   const int32_t *blk_lo, int32_t n_blocks_local, int32_t utt_lo,
+                                   const int32_t *tok_off, const int32_t *ctok_id, const int32_t *ctok_k,
+                                   const double *out_total, double *part_sum, int64_t *part_cnt,
+                                   double *part_tot, void *stream)
 {
     (void)ctx;
     int rc = check_corpus(c);
@@ -1472,8 +1517,8 @@ int32_t segk_kmeans_batch_partials(segk_ctx *ctx, const segk_corpus *c, const se
     int64_t waves = (int64_t)n_blocks_local * m->K_max;
     int64_t grid = (waves + 3) / 4;
     DISPATCH_XT(c, hipLaunchKernelGGL(k_batch_partials<XT>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream,
-                                       *c, *m, blk_lo, n_blocks_local, new_tok, new_k, n_new, out_total, part_sum,
-                                       part_cnt, part_tot););
+                                       *c, *m, blk_lo, n_blocks_local, utt_lo, tok_off, ctok_id, ctok_k, out_total,
+                                       part_sum, part_cnt, part_tot););
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;
 }
@@ -1481,7 +1526,7 @@ int32_t segk_kmeans_batch_partials(segk_ctx *ctx, const segk_corpus *c, const se
 int32_t segk_kmeans_batch_finalize(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m, int32_t utt_lo,
                                    int32_t utt_hi, const double *part_sum, const int64_t *part_cnt,
                                    const double *part_tot, int32_t n_blocks_total, int32_t n_blocks_per_rank,
-                                   int64_t rank_stride, const int32_t *new_tok, const int32_t *n_new,
+                                   int64_t rank_stride, int32_t *new_k, const int32_t *n_new,
                                    int32_t *remap_scratch, double *out_scalars, int32_t *status, void *stream)
 {
     (void)status;
@@ -1489,6 +1534,7 @@ int32_t segk_kmeans_batch_finalize(segk_ctx *ctx, const segk_corpus *c, segk_kme
     if (rc) return rc;
     SEGK_REQUIRE(n_blocks_total >= 1 && n_blocks_total <= 64, "1 <= n_blocks_total <= 64");
     SEGK_REQUIRE(n_blocks_per_rank >= 1 && n_blocks_total % n_blocks_per_rank == 0, "blocks per rank");
+    SEGK_REQUIRE(m->K_max <= 32768, "K_max <= 32768");
     hipStream_t st = (hipStream_t)stream;
     int64_t tot = (int64_t)m->K_max * c->D;
     DISPATCH_XT(c, {
@@ -1498,10 +1544,27 @@ int32_t segk_kmeans_batch_finalize(segk_ctx *ctx, const segk_corpus *c, segk_kme
     });
     int64_t nslot = (int64_t)(utt_hi - utt_lo) * c->N_max;
     if (nslot > 0)
-        hipLaunchKernelGGL(k_batch_relabel, dim3((unsigned)((nslot + 255) / 256)), dim3(256), 0, st, *c, *m, utt_lo,
-                           utt_hi, new_tok, n_new, remap_scratch);
+        hipLaunchKernelGGL(k_batch_relabel, dim3((unsigned)((nslot + 255) / 256)), dim3(256), 0, st, *c, utt_lo,
+                           utt_hi, new_k, n_new, remap_scratch);
     SEGK_LAUNCH_CHECK();
     return segk_kmeans_prepare(ctx, c, m, stream);
+}
+
+int32_t segk_kmeans_assignments_from_tokens(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m,
+                                            int32_t utt_lo, int32_t utt_hi, const int32_t *new_tok,
+                                            const int32_t *new_k, const int32_t *n_new, void *stream)
+{
+    (void)ctx;
+    int rc = check_corpus(c);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    SEGK_CHECK_HIP(hipMemsetAsync(m->assignments, 0xff, sizeof(int32_t) * (size_t)c->n_emb, st));
+    int64_t nslot = (int64_t)(utt_hi - utt_lo) * c->N_max;
+    if (nslot > 0)
+        hipLaunchKernelGGL(k_assign_from_tokens, dim3((unsigned)((nslot + 255) / 256)), dim3(256), 0, st, *c, *m,
+                           utt_lo, utt_hi, new_tok, new_k, n_new);
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
 }
 
 int32_t segk_kmeans_sum_neg_sqrd_norm(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m, double *out,

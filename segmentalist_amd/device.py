@@ -119,6 +119,7 @@ class DeviceKMeans(object):
         self.cand_k = torch.zeros(c.n_emb, dtype=torch.int32, device=dev)
         self.cand_f = torch.zeros((c.n_emb, 2), dtype=torch.float32, device=dev)
         self.status = torch.zeros(8, dtype=torch.int32, device=dev)
+        self.assign_stale = None
         self._L = _abi.lib()
         self._ctx = _abi.ctx()
         check(self._L.segk_kmeans_init_stats(self._ctx, C.byref(c.c), C.byref(self.m), _abi.stream()))
@@ -140,10 +141,28 @@ class DeviceKMeans(object):
         self.utt_arange = torch.arange(nu, dtype=torch.int32, device=dev)
         self.remap = torch.zeros(self.K_max, dtype=torch.int32, device=dev)
         self.out_scalars = torch.zeros(4, dtype=torch.float64, device=dev)
+        self.tok_off = torch.zeros(nu + 1, dtype=torch.int32, device=dev)
+        self.ctok_id = torch.zeros(nu * nm, dtype=torch.int32, device=dev)
+        self.ctok_k = torch.zeros(nu * nm, dtype=torch.int32, device=dev)
+        # batch sweeps leave `assignments` untouched: `assign_stale` = (lo, hi, world) of the token
+        # lists it must be rebuilt from, or None when it is current
 
     # ------------------------------------------------------------------ single calls
     def _cp(self):
         return C.byref(self.corpus.c)
+
+    def ensure_assignments(self, group=None):
+        """Materialise `assignments` after batch sweeps (they only maintain the token lists)."""
+        if self.assign_stale is None:
+            return
+        lo, hi, world = self.assign_stale
+        check(self._L.segk_kmeans_assignments_from_tokens(self._ctx, self._cp(), C.byref(self.m), lo, hi,
+                                                          ptr(self.new_tok), ptr(self.new_k), ptr(self.n_new),
+                                                          _abi.stream()))
+        if world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(self.assignments, op=dist.ReduceOp.MAX, group=group)
+        self.assign_stale = None
 
     def prepare(self):
         check(self._L.segk_kmeans_prepare(self._ctx, self._cp(), C.byref(self.m), _abi.stream()))
@@ -185,22 +204,27 @@ class DeviceKMeans(object):
         return out.cpu().numpy()
 
     def add_item(self, i, k):
+        self.ensure_assignments()
         check(self._L.segk_kmeans_add_item(self._ctx, self._cp(), C.byref(self.m), int(i), int(k),
                                            ptr(self.status), _abi.stream()))
 
     def del_item(self, i):
+        self.ensure_assignments()
         check(self._L.segk_kmeans_del_item(self._ctx, self._cp(), C.byref(self.m), int(i), ptr(self.status),
                                            _abi.stream()))
 
     def del_component(self, k):
+        self.ensure_assignments()
         check(self._L.segk_kmeans_del_component(self._ctx, self._cp(), C.byref(self.m), int(k),
                                                 ptr(self.status), _abi.stream()))
 
     def clean_components(self):
+        self.ensure_assignments()
         check(self._L.segk_kmeans_clean_components(self._ctx, self._cp(), C.byref(self.m), ptr(self.status),
                                                    _abi.stream()))
 
     def sum_neg_sqrd_norm(self):
+        self.ensure_assignments()
         torch = _torch()
         out = torch.zeros(1, dtype=torch.float64, device=self.means.device)
         check(self._L.segk_kmeans_sum_neg_sqrd_norm(self._ctx, self._cp(), C.byref(self.m), ptr(out),
@@ -227,6 +251,7 @@ class DeviceKMeans(object):
         """The whole of segment_i (kmeans_acoustic_wordseg.py:225-332) for utterance i, enqueued
         asynchronously: score its spans, DP, del/add/clean in the reference's order."""
         c = self.corpus
+        self.ensure_assignments()
         N = int(c.lengths_np[i])
         tri_i = N * (N + 1) // 2
         self.score_ptr(c.vec_ids.data_ptr() + 4 * i * c.tri, tri_i)
@@ -310,21 +335,22 @@ class KMeansBatchSweeper(object):
         else:
             dk.score_rows(row0=pt.row_lo, n=pt.row_hi - pt.row_lo)
         dk.segment(boundaries, n_slices_min, n_slices_max, wip, utt0=pt.utt_lo, n_utts=pt.utt_hi - pt.utt_lo)
-        check(L.segk_kmeans_batch_collect(ctx, cp, mp, pt.utt_lo, pt.utt_hi, ptr(dk.old_tok), ptr(dk.n_old),
-                                          ptr(dk.new_k), ptr(dk.n_new), ptr(self.flag), self.cap, st))
+        check(L.segk_kmeans_batch_collect(ctx, cp, mp, pt.utt_lo, pt.utt_hi, ptr(dk.new_k), ptr(dk.n_new),
+                                          ptr(dk.tok_off), ptr(self.flag), self.cap, st))
         if pt.world > 1:
             import torch.distributed as dist
             dist.all_gather_into_tensor(self.flag_all.view(-1), self.flag, group=self.group)
         check(L.segk_kmeans_batch_assign(ctx, cp, mp, pt.utt_lo, pt.utt_hi, ptr(self.flag_all), pt.world,
                                          pt.rank, self.cap, ptr(dk.new_tok), ptr(dk.new_k), ptr(dk.n_new),
-                                         ptr(dk.status), st))
-        check(L.segk_kmeans_batch_partials(ctx, cp, mp, ptr(self.blk_lo), pt.nbl, ptr(dk.new_tok),
-                                           ptr(dk.new_k), ptr(dk.n_new), ptr(dk.out_total), self._p_sum,
+                                         ptr(dk.tok_off), ptr(dk.ctok_id), ptr(dk.ctok_k), ptr(dk.status), st))
+        check(L.segk_kmeans_batch_partials(ctx, cp, mp, ptr(self.blk_lo), pt.nbl, pt.utt_lo, ptr(dk.tok_off),
+                                           ptr(dk.ctok_id), ptr(dk.ctok_k), ptr(dk.out_total), self._p_sum,
                                            self._p_cnt, self._p_tot, st))
         if pt.world > 1:
             import torch.distributed as dist
             dist.all_gather_into_tensor(self.pack_all.view(-1), self.pack, group=self.group)
         check(L.segk_kmeans_batch_finalize(ctx, cp, mp, pt.utt_lo, pt.utt_hi, self._a_sum, self._a_cnt,
                                            self._a_tot, pt.n_blocks, pt.nbl, self.rank_stride,
-                                           ptr(dk.new_tok), ptr(dk.n_new), ptr(dk.remap), ptr(dk.out_scalars),
+                                           ptr(dk.new_k), ptr(dk.n_new), ptr(dk.remap), ptr(dk.out_scalars),
                                            ptr(dk.status), st))
+        dk.assign_stale = (pt.utt_lo, pt.utt_hi, pt.world)

@@ -59,6 +59,7 @@ class KMeansComponents(object):
 
     @property
     def assignments(self):
+        self.dev.ensure_assignments()
         return self.dev.assignments.cpu().numpy().astype(np.int64)
 
     # ---------------------------------------------------------------- mutators (A11)

@@ -115,6 +115,7 @@ def test_dp_functions_vs_reference(gpu, golden):
             offs = np.concatenate([[0], np.cumsum([len(dpc[i]["vec"]) for i in sel])]).astype(np.int64)
             vecs = np.concatenate([dpc[i]["vec"] for i in sel])
             Nmax = int(Ns.max())
+            vecs_t, Ns_t, offs_t = to_dev(vecs), to_dev(Ns), to_dev(offs)   # keep the buffers alive
             ob = np.concatenate([[0], np.cumsum([c["N"] for c in dpc])])
             ou = np.concatenate([[0], np.cumsum([c["N"] + 1 for c in dpc])])
             for kind, key, temp, lpc in [(0, "km", 1.0, 0.0), (1, "vt", 1.0, 0.0), (2, "fb", 1.0, -0.25),
@@ -133,7 +134,7 @@ def test_dp_functions_vs_reference(gpu, golden):
                         un[r, :len(src)] = np.nan_to_num(src, nan=0.5)
                     u = to_dev(un)
                 _abi.check(_abi.lib().segk_dp_tri(
-                    _abi.ctx(), kind, _abi.ptr(to_dev(vecs)), _abi.ptr(to_dev(Ns)), _abi.ptr(to_dev(offs)), P,
+                    _abi.ctx(), kind, _abi.ptr(vecs_t), _abi.ptr(Ns_t), _abi.ptr(offs_t), P,
                     n_min, n_max, lpc, temp, _abi.ptr(u), Nmax + 1, _abi.ptr(bounds), Nmax, _abi.ptr(totals),
                     _abi.ptr(nd), _abi.ptr(st), _abi.ptr(work), 3 * Nmax + 2, _abi.stream()))
                 B = bounds.cpu().numpy().astype(bool)
