@@ -107,12 +107,14 @@ int32_t segk_kmeans_prepare(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m,
  * (rows row0..row0+n-1 when ids == NULL; entries of ids equal to -1 are skipped)
  * against all K_max means.  For every row e processed, the component with the largest
  * f[k] = x_e.m_k - |m_k|^2/2 and the two largest values of f are written at index e:
- *   cand_k [dev] int32 [n_emb], cand_f [dev] float [n_emb, 2].
+ *   cand_k [dev] int32 [n_emb], cand_f [dev] float [n_emb, 2],
+ *   cand_s [dev] float [n_emb]: the winner's score in REFERENCE arithmetic (float32 data with
+ *   8 <= D <= 128: fused in the kernel epilogue from the register-resident row), else NaN.
  * These are CANDIDATES: the reference-arithmetic score is recomputed from them by
  * segk_kmeans_segment / segk_kmeans_exact_max (bit-exact contract).           */
 int32_t segk_kmeans_score(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m,
                           const int32_t *ids, int64_t row0, int64_t n,
-                          int32_t *cand_k, float *cand_f, void *stream);
+                          int32_t *cand_k, float *cand_f, float *cand_s, void *stream);
 
 /* A1 (exact stage) for rows ids[0..n) (0..n-1 when NULL): out_max[r] (double, widened from
  * the dtype of X) and out_arg[r] are bit-identical to np.max / np.argmax of
@@ -121,7 +123,7 @@ int32_t segk_kmeans_score(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans
  * K_max exact scan (filter margin not decisive).                                        */
 int32_t segk_kmeans_exact_max(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m,
                               const int32_t *ids, int64_t n,
-                              const int32_t *cand_k, const float *cand_f,
+                              const int32_t *cand_k, const float *cand_f, const float *cand_s,
                               double *out_max, int32_t *out_arg, int32_t *out_n_bruteforce,
                               void *stream);
 
@@ -145,7 +147,7 @@ int32_t segk_kmeans_neg_sqrd_norm(segk_ctx *ctx, const segk_corpus *c, const seg
 int32_t segk_kmeans_segment(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m,
                             const int32_t *utts, int32_t utt0, int32_t n_utts,
                             int32_t n_slices_min, int32_t n_slices_max, double wip,
-                            const int32_t *cand_k, const float *cand_f,
+                            const int32_t *cand_k, const float *cand_f, const float *cand_s,
                             uint8_t *boundaries, int32_t *old_tok, int32_t *new_tok,
                             int32_t *new_k, int32_t *n_old, int32_t *n_new,
                             double *out_total, int32_t *status, void *stream);

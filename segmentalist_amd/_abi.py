@@ -50,10 +50,10 @@ SIGNATURES = {
     "segk_kmeans_tiles_floats": (_i64, [_i32, _i32]),
     "segk_kmeans_prepare": (_i32, [_P, _CP, _KP, _P]),
     "segk_kmeans_init_stats": (_i32, [_P, _CP, _KP, _P]),
-    "segk_kmeans_score": (_i32, [_P, _CP, _KP, _P, _i64, _i64, _P, _P, _P]),
-    "segk_kmeans_exact_max": (_i32, [_P, _CP, _KP, _P, _i64, _P, _P, _P, _P, _P, _P]),
+    "segk_kmeans_score": (_i32, [_P, _CP, _KP, _P, _i64, _i64, _P, _P, _P, _P]),
+    "segk_kmeans_exact_max": (_i32, [_P, _CP, _KP, _P, _i64, _P, _P, _P, _P, _P, _P, _P]),
     "segk_kmeans_neg_sqrd_norm": (_i32, [_P, _CP, _KP, _i64, _P, _P]),
-    "segk_kmeans_segment": (_i32, [_P, _CP, _KP, _P, _i32, _i32, _i32, _i32, _f64, _P, _P, _P, _P, _P, _P,
+    "segk_kmeans_segment": (_i32, [_P, _CP, _KP, _P, _i32, _i32, _i32, _i32, _f64, _P, _P, _P, _P, _P, _P, _P,
                                    _P, _P, _P, _P, _P]),
     "segk_dp_tri": (_i32, [_P, _i32, _P, _P, _P, _i32, _i32, _i32, _f64, _f64, _P, _i64, _P, _i64, _P, _P, _P,
                            _P, _i64, _P]),

@@ -24,14 +24,15 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // accumulators + fixed tree + sequential tail, n>128 split at n/2 rounded down to 8).
 // ======================================================================================
 template <typename T, typename TM, typename TX>
-__device__ __forceinline__ T sqd(const TM *m, const TX *x, int d)
+__device__ __forceinline__ T sqd(const TM &m, const TX *x, int d)
 {
     T delta = (T)m[d] - (T)x[d];
     return delta * delta;
 }
 
+// TM: anything indexable (`const float*`, `const double*`, TileRow)
 template <typename T, typename TM, typename TX>
-__device__ T pw_base(const TM *m, const TX *x, int n)
+__device__ T pw_base(const TM &m, const TX *x, int n)
 {
     if (n < 8) {
         T res = (T)0;
@@ -57,9 +58,10 @@ __device__ T pw_base(const TM *m, const TX *x, int n)
     return res;
 }
 
-// -sum_d (m[d]-x[d])^2 in the dtype T of the reference's `means`/X
+// -sum_d (m[d]-x[d])^2 in the dtype T of the reference's `means`/X.  Offsets into m are
+// multiples of 8 (numpy's split points), which TileRow::operator+ relies on.
 template <typename T, typename TM, typename TX>
-__device__ T neg_sqd_exact(const TM *m, const TX *x, int n)
+__device__ T neg_sqd_exact(const TM &m, const TX *x, int n)
 {
     if (n <= 128) return -pw_base<T>(m, x, n);
     struct Frame { int off, n, state; T left; };
@@ -93,6 +95,23 @@ __device__ T neg_sqd_exact(const TM *m, const TX *x, int n)
         }
     }
     return -ret;
+}
+
+// A component's row read from the MFMA tile image instead of from `means`: the image holds
+// the same float32 values with the component index contiguous (stride 2 floats), so that
+// consecutive lanes scanning consecutive components touch a few cache lines per load instead
+// of one line per lane.  Only valid when the means are float32 (the image is a float copy).
+struct TileRow {
+    const float *base;      // tiles + tile*stride + 2*(k & 31)
+    __device__ __forceinline__ float operator[](int d) const
+    {
+        return base[(d >> 2) * 128 + ((d >> 1) & 1) * 64 + (d & 1)];
+    }
+    __device__ __forceinline__ TileRow operator+(int off) const { return TileRow{base + (off >> 2) * 128}; }
+};
+__device__ __forceinline__ TileRow tile_row(const float *tiles, int tile_stride, int k)
+{
+    return TileRow{tiles + (int64_t)(k >> 5) * tile_stride + 2 * (k & 31)};
 }
 
 // Margin below which two fp32-filter values cannot be ordered with certainty
@@ -197,7 +216,8 @@ template <int GMAX, int NB>
 __global__ __launch_bounds__(256, 2) void k_kmeans_score(
     const float *__restrict__ X32, int64_t ld32, const int32_t *__restrict__ ids, int64_t row0, int64_t n,
     const float *__restrict__ tiles, int n_tiles, int tile_stride, int G /* groups present in X32 rows */,
-    int32_t *__restrict__ cand_k, float *__restrict__ cand_f)
+    int D, int fuse_exact, int32_t *__restrict__ cand_k, float *__restrict__ cand_f,
+    float *__restrict__ cand_s)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
@@ -293,6 +313,8 @@ __global__ __launch_bounds__(256, 2) void k_kmeans_score(
         __syncthreads();
     }
     // the two lane halves hold disjoint component subsets of the same embedding
+    const int nb8 = D >> 3;            // full blocks of 8 dims (numpy's strided accumulators)
+    const int rem = D & 7;             // sequential tail
 #pragma unroll
     for (int nb = 0; nb < NB; nb++) {
         float o1 = __shfl_xor(m1[nb], 32), o2 = __shfl_xor(m2[nb], 32);
@@ -300,10 +322,54 @@ __global__ __launch_bounds__(256, 2) void k_kmeans_score(
         float top1 = fmaxf(m1[nb], o1);
         float top2 = fmaxf(fminf(m1[nb], o1), fmaxf(m2[nb], o2));
         int idx = (o1 > m1[nb] || (o1 == m1[nb] && oi < i1[nb])) ? oi : i1[nb];
+        // Fused exact stage for the winner (float32 data, 8 <= D <= 128): the reference's
+        // float32 -(deltas*deltas).sum() in numpy's pairwise order.  Dim d = 4g+2h+s sits on
+        // lane half h, and d mod 8 = 4(g&1)+2h+s selects the strided accumulator, so half 0
+        // owns r0,r1,r4,r5 and half 1 owns r2,r3,r6,r7; the combine tree and the sequential
+        // tail exchange values between the two halves with lane^32 shuffles.
+        float sexact = __builtin_nanf("");
+        if (fuse_exact) {
+            const float *mrow = tiles + (int64_t)(idx >> 5) * tile_stride + (h * 32 + (idx & 31)) * 2;
+            float A0 = 0.f, A1 = 0.f, A2 = 0.f, A3 = 0.f, T0 = 0.f, T1 = 0.f, T2 = 0.f, T3 = 0.f;
+#pragma unroll
+            for (int g = 0; g < GMAX; g++) {
+                const int i8 = g >> 1;
+                float2 mv = *reinterpret_cast<const float2 *>(mrow + g * 128);
+                float dx = mv.x - xb[nb][g].x, dy = mv.y - xb[nb][g].y;
+                float qx = dx * dx, qy = dy * dy;
+                if ((g & 1) == 0) {
+                    if (i8 == 0) { A0 = qx; A1 = qy; }
+                    else if (i8 < nb8) { A0 += qx; A1 += qy; }
+                    if (i8 == nb8) { T0 = qx; T1 = qy; }
+                } else {
+                    if (i8 == 0) { A2 = qx; A3 = qy; }
+                    else if (i8 < nb8) { A2 += qx; A3 += qy; }
+                    if (i8 == nb8) { T2 = qx; T3 = qy; }
+                }
+            }
+            float p = A0 + A1, q = A2 + A3;                      // (r0+r1),(r4+r5) | (r2+r3),(r6+r7)
+            float po = __shfl_xor(p, 32), qo = __shfl_xor(q, 32);
+            float res = (h == 0) ? ((p + po) + (q + qo)) : ((po + p) + (qo + q));
+            float U0 = __shfl_xor(T0, 32), U1 = __shfl_xor(T1, 32), U2 = __shfl_xor(T2, 32),
+                  U3 = __shfl_xor(T3, 32);
+            // tail element jj (dim 8*nb8 + jj) lives on half (jj>>1)&1, slot (jj&1) + 2*(jj>>2)
+            const float t0 = h == 0 ? T0 : U0, t1 = h == 0 ? T1 : U1, t2 = h == 0 ? U0 : T0,
+                        t3 = h == 0 ? U1 : T1, t4 = h == 0 ? T2 : U2, t5 = h == 0 ? T3 : U3,
+                        t6 = h == 0 ? U2 : T2;
+            if (rem > 0) res += t0;
+            if (rem > 1) res += t1;
+            if (rem > 2) res += t2;
+            if (rem > 3) res += t3;
+            if (rem > 4) res += t4;
+            if (rem > 5) res += t5;
+            if (rem > 6) res += t6;
+            sexact = -res;
+        }
         if (h == 0 && rowid[nb] >= 0) {
             cand_k[rowid[nb]] = idx;
             cand_f[2 * (int64_t)rowid[nb] + 0] = top1;
             cand_f[2 * (int64_t)rowid[nb] + 1] = top2;
+            cand_s[rowid[nb]] = sexact;
         }
     }
 }
@@ -318,7 +384,7 @@ __global__ __launch_bounds__(256, 2) void k_kmeans_score(
 // ======================================================================================
 template <typename XT>
 __device__ void exact_rows(const segk_corpus &c, const segk_kmeans &m, const int32_t *ids_lds, int n,
-                           const int32_t *cand_k, const float *cand_f, double *sc, int32_t *kb,
+                           const int32_t *cand_k, const float *cand_f, const float *cand_s, double *sc, int32_t *kb,
                            int32_t *queue, int32_t *qn, XT *xrow, double *red_v, int32_t *red_k,
                            int32_t *n_brute)
 {
@@ -338,7 +404,9 @@ __device__ void exact_rows(const segk_corpus &c, const segk_kmeans &m, const int
             float f1 = cand_f[2 * (int64_t)id], f2 = cand_f[2 * (int64_t)id + 1];
             float tau = filter_tau(c.xnorm[id], M, D, c.x_dtype);
             if (f1 - f2 > tau) {
-                v = (double)neg_sqd_exact<XT>(means + (int64_t)k1 * D, X + (int64_t)id * c.ldx, D);
+                const float se = cand_s[id];        // exact score of the winner, fused in the score kernel
+                if (se == se) v = (double)se;
+                else v = (double)neg_sqd_exact<XT>(means + (int64_t)k1 * D, X + (int64_t)id * c.ldx, D);
                 k = k1;
             } else {
                 int q = atomicAdd(qn, 1);
@@ -357,9 +425,17 @@ __device__ void exact_rows(const segk_corpus &c, const segk_kmeans &m, const int
         __syncthreads();
         XT best = (XT)NEG_INF_D;
         int32_t bk = 0x7fffffff;
-        for (int k = tid; k < m.K_max; k += nt) {
-            XT s = neg_sqd_exact<XT>(means + (int64_t)k * D, xrow, D);
-            if (s > best || bk == 0x7fffffff) { best = s; bk = k; }   // first max within the thread
+        if constexpr (sizeof(XT) == 4) {
+            const int tstride = segk_tile_stride(D);
+            for (int k = tid; k < m.K_max; k += nt) {
+                XT s = neg_sqd_exact<XT>(tile_row(m.tiles, tstride, k), xrow, D);
+                if (s > best || bk == 0x7fffffff) { best = s; bk = k; }   // first max within the thread
+            }
+        } else {
+            for (int k = tid; k < m.K_max; k += nt) {
+                XT s = neg_sqd_exact<XT>(means + (int64_t)k * D, xrow, D);
+                if (s > best || bk == 0x7fffffff) { best = s; bk = k; }
+            }
         }
         red_v[tid] = (double)best;
         red_k[tid] = bk;
@@ -386,7 +462,7 @@ __device__ void exact_rows(const segk_corpus &c, const segk_kmeans &m, const int
 // A1 exact for arbitrary rows (API: segk_kmeans_exact_max)
 template <typename XT>
 __global__ void k_kmeans_exact_max(segk_corpus c, segk_kmeans m, const int32_t *ids, int64_t n,
-                                   const int32_t *cand_k, const float *cand_f, double *out_max,
+                                   const int32_t *cand_k, const float *cand_f, const float *cand_s, double *out_max,
                                    int32_t *out_arg, int32_t *n_brute)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -403,7 +479,7 @@ __global__ void k_kmeans_exact_max(segk_corpus c, segk_kmeans m, const int32_t *
     int cnt = (int)((n - r0) < nt ? (n - r0) : nt);
     for (int i = threadIdx.x; i < cnt; i += nt) ids_l[i] = ids ? ids[r0 + i] : (int32_t)(r0 + i);
     __syncthreads();
-    exact_rows<XT>(c, m, ids_l, cnt, cand_k, cand_f, sc, kb, queue, qn, xrow, red_v, red_k, n_brute);
+    exact_rows<XT>(c, m, ids_l, cnt, cand_k, cand_f, cand_s, sc, kb, queue, qn, xrow, red_v, red_k, n_brute);
     __syncthreads();
     for (int i = threadIdx.x; i < cnt; i += nt) {
         out_max[r0 + i] = sc[i];
@@ -427,7 +503,7 @@ __global__ void k_kmeans_neg_sqrd_norm(segk_corpus c, segk_kmeans m, int64_t row
 // ======================================================================================
 template <typename XT>
 __global__ void k_kmeans_segment(segk_corpus c, segk_kmeans m, const int32_t *utts, int utt0, int n_min, int n_max,
-                                 double wip, const int32_t *cand_k, const float *cand_f,
+                                 double wip, const int32_t *cand_k, const float *cand_f, const float *cand_s,
                                  uint8_t *boundaries, int32_t *old_tok, int32_t *new_tok, int32_t *new_k,
                                  int32_t *n_old, int32_t *n_new, double *out_total, int32_t *status,
                                  int band_cap)
@@ -457,7 +533,7 @@ __global__ void k_kmeans_segment(segk_corpus c, segk_kmeans m, const int32_t *ut
         bid[i] = (s >= 0) ? vid[t * (t - 1) / 2 + s] : -1;
     }
     __syncthreads();
-    exact_rows<XT>(c, m, bid, nb, cand_k, cand_f, bvec, bk, queue, qn, xrow, red_v, red_k, status + 1);
+    exact_rows<XT>(c, m, bid, nb, cand_k, cand_f, cand_s, bvec, bk, queue, qn, xrow, red_v, red_k, status + 1);
     __syncthreads();
     // A5: scale by duration, NaN duration -> -inf, + wip   (kmeans_acoustic_wordseg.py:346-351)
     for (int i = tid; i < nb; i += nt) {
@@ -1254,7 +1330,7 @@ static int check_corpus(const segk_corpus *c)
 
 template <int GMAX, int NB>
 static int launch_score(const segk_corpus *c, const segk_kmeans *m, const int32_t *ids, int64_t row0, int64_t n,
-                        int32_t *cand_k, float *cand_f, hipStream_t st)
+                        int32_t *cand_k, float *cand_f, float *cand_s, hipStream_t st)
 {
     const int stride = segk_tile_stride(c->D);
     const size_t lds = 2 * (size_t)stride * sizeof(float);
@@ -1264,7 +1340,8 @@ static int launch_score(const segk_corpus *c, const segk_kmeans *m, const int32_
         SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_kmeans_score<GMAX, NB>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((k_kmeans_score<GMAX, NB>), dim3((unsigned)grid), dim3(256), lds, st, c->X32, c->ld32, ids,
-                       row0, n, m->tiles, segk_n_tiles(m->K_max), stride, segk_G(c->D), cand_k, cand_f);
+                       row0, n, m->tiles, segk_n_tiles(m->K_max), stride, segk_G(c->D), c->D,
+                       (c->x_dtype == SEGK_F32 && c->D >= 8 && c->D <= 128) ? 1 : 0, cand_k, cand_f, cand_s);
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;
 }
@@ -1309,18 +1386,18 @@ int32_t segk_kmeans_prepare(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m,
 }
 
 int32_t segk_kmeans_score(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m, const int32_t *ids,
-                          int64_t row0, int64_t n, int32_t *cand_k, float *cand_f, void *stream)
+                          int64_t row0, int64_t n, int32_t *cand_k, float *cand_f, float *cand_s, void *stream)
 {
     (void)ctx;
     int rc = check_corpus(c);
     if (rc) return rc;
-    SEGK_REQUIRE(m && m->tiles && cand_k && cand_f && c->X32, "score operands");
+    SEGK_REQUIRE(m && m->tiles && cand_k && cand_f && cand_s && c->X32, "score operands");
     SEGK_REQUIRE(ids != nullptr || (row0 >= 0 && row0 + n <= c->n_emb), "row range");
     if (n <= 0) return SEGK_OK;
     hipStream_t st = (hipStream_t)stream;
     const int GB = segk_gmax(c->D);
     switch (GB) {
-#define SEGK_CASE(g, nb) case g: return launch_score<g, nb>(c, m, ids, row0, n, cand_k, cand_f, st);
+#define SEGK_CASE(g, nb) case g: return launch_score<g, nb>(c, m, ids, row0, n, cand_k, cand_f, cand_s, st);
         SEGK_CASE(1, 2) SEGK_CASE(2, 2) SEGK_CASE(4, 2) SEGK_CASE(6, 2) SEGK_CASE(8, 2) SEGK_CASE(10, 2)
         SEGK_CASE(13, 2) SEGK_CASE(16, 2) SEGK_CASE(20, 2) SEGK_CASE(25, 2) SEGK_CASE(26, 2) SEGK_CASE(28, 2)
         SEGK_CASE(32, 2) SEGK_CASE(33, 2) SEGK_CASE(34, 2) SEGK_CASE(40, 1) SEGK_CASE(50, 1) SEGK_CASE(64, 1)
@@ -1333,8 +1410,8 @@ int32_t segk_kmeans_score(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans
 }
 
 int32_t segk_kmeans_exact_max(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m, const int32_t *ids,
-                              int64_t n, const int32_t *cand_k, const float *cand_f, double *out_max,
-                              int32_t *out_arg, int32_t *out_n_bruteforce, void *stream)
+                              int64_t n, const int32_t *cand_k, const float *cand_f, const float *cand_s,
+                              double *out_max, int32_t *out_arg, int32_t *out_n_bruteforce, void *stream)
 {
     (void)ctx;
     int rc = check_corpus(c);
@@ -1346,7 +1423,7 @@ int32_t segk_kmeans_exact_max(segk_ctx *ctx, const segk_corpus *c, const segk_km
     size_t lds = 2 * nt * sizeof(double) + xsz + (4 * nt + 4) * sizeof(int32_t);
     int64_t grid = (n + nt - 1) / nt;
     DISPATCH_XT(c, hipLaunchKernelGGL(k_kmeans_exact_max<XT>, dim3((unsigned)grid), dim3(nt), lds, st, *c, *m, ids,
-                                       n, cand_k, cand_f, out_max, out_arg, out_n_bruteforce););
+                                       n, cand_k, cand_f, cand_s, out_max, out_arg, out_n_bruteforce););
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;
 }
@@ -1367,7 +1444,8 @@ int32_t segk_kmeans_neg_sqrd_norm(segk_ctx *ctx, const segk_corpus *c, const seg
 
 int32_t segk_kmeans_segment(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m, const int32_t *utts,
                             int32_t utt0, int32_t n_utts, int32_t n_slices_min, int32_t n_slices_max, double wip,
-                            const int32_t *cand_k, const float *cand_f, uint8_t *boundaries, int32_t *old_tok,
+                            const int32_t *cand_k, const float *cand_f, const float *cand_s, uint8_t *boundaries,
+                            int32_t *old_tok,
                             int32_t *new_tok, int32_t *new_k, int32_t *n_old, int32_t *n_new, double *out_total,
                             int32_t *status, void *stream)
 {
@@ -1398,7 +1476,7 @@ int32_t segk_kmeans_segment(segk_ctx *ctx, const segk_corpus *c, const segk_kmea
             SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_kmeans_segment<XT>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k_kmeans_segment<XT>, dim3(n_utts), dim3(nt), lds, st, *c, *m, utts, utt0, n_slices_min,
-                           n_slices_max, wip, cand_k, cand_f, boundaries, old_tok, new_tok, new_k, n_old, n_new,
+                           n_slices_max, wip, cand_k, cand_f, cand_s, boundaries, old_tok, new_tok, new_k, n_old, n_new,
                            out_total, status, band_cap);
     });
     SEGK_LAUNCH_CHECK();

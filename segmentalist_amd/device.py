@@ -118,6 +118,7 @@ class DeviceKMeans(object):
         # candidates of the filter stage, indexed by embedding row
         self.cand_k = torch.zeros(c.n_emb, dtype=torch.int32, device=dev)
         self.cand_f = torch.zeros((c.n_emb, 2), dtype=torch.float32, device=dev)
+        self.cand_s = torch.zeros(c.n_emb, dtype=torch.float32, device=dev)
         self.status = torch.zeros(8, dtype=torch.int32, device=dev)
         self.assign_stale = None
         self._L = _abi.lib()
@@ -176,11 +177,11 @@ class DeviceKMeans(object):
             p = None
             n = self.corpus.n_emb - row0 if n is None else n
         check(self._L.segk_kmeans_score(self._ctx, self._cp(), C.byref(self.m), p, int(row0), int(n),
-                                        ptr(self.cand_k), ptr(self.cand_f), _abi.stream()))
+                                        ptr(self.cand_k), ptr(self.cand_f), ptr(self.cand_s), _abi.stream()))
 
     def score_ptr(self, ids_ptr, n):
         check(self._L.segk_kmeans_score(self._ctx, self._cp(), C.byref(self.m), C.c_void_p(ids_ptr), 0, int(n),
-                                        ptr(self.cand_k), ptr(self.cand_f), _abi.stream()))
+                                        ptr(self.cand_k), ptr(self.cand_f), ptr(self.cand_s), _abi.stream()))
 
     def exact_max(self, ids):
         """np.max / np.argmax of neg_sqrd_norm for rows `ids` (host ints) -> (float64[n], int32[n])."""
@@ -192,7 +193,7 @@ class DeviceKMeans(object):
         nb = torch.zeros(1, dtype=torch.int32, device=ids_t.device)
         self.score_rows(ids_t)
         check(self._L.segk_kmeans_exact_max(self._ctx, self._cp(), C.byref(self.m), ptr(ids_t), n,
-                                            ptr(self.cand_k), ptr(self.cand_f), ptr(out_max), ptr(out_arg),
+                                            ptr(self.cand_k), ptr(self.cand_f), ptr(self.cand_s), ptr(out_max), ptr(out_arg),
                                             ptr(nb), _abi.stream()))
         return out_max.cpu().numpy(), out_arg.cpu().numpy(), int(nb.item())
 
@@ -243,7 +244,7 @@ class DeviceKMeans(object):
             n = c.n_utt - utt0 if n_utts is None else n_utts
         check(self._L.segk_kmeans_segment(
             self._ctx, self._cp(), C.byref(self.m), up, int(utt0), int(n), int(n_slices_min), int(n_slices_max),
-            float(wip), ptr(self.cand_k), ptr(self.cand_f), ptr(boundaries), ptr(self.old_tok),
+            float(wip), ptr(self.cand_k), ptr(self.cand_f), ptr(self.cand_s), ptr(boundaries), ptr(self.old_tok),
             ptr(self.new_tok), ptr(self.new_k), ptr(self.n_old), ptr(self.n_new), ptr(self.out_total),
             ptr(self.status), _abi.stream()))
 
