@@ -86,7 +86,7 @@ typedef struct segk_kmeans {
     int32_t K_max;
     /* derived operands of the MFMA score kernel, maintained by the library: */
     float *tiles;              /* [dev] segk_kmeans_tiles_floats(K_max, D) floats               */
-    double *mnorm_max;         /* [dev] [1] upper bound of max_k ||means[k]||_2                 */
+    double *mnorm_max;         /* [dev] [1] max_k ||means[k]||_2^2 (kept with atomicMax on the bits) */
 } segk_kmeans;
 
 /* number of floats the caller must allocate for segk_kmeans.tiles */
@@ -141,6 +141,7 @@ int32_t segk_kmeans_neg_sqrd_norm(segk_ctx *ctx, const segk_corpus *c, const seg
  *   new_tok    [dev] int32 [n_utt, N_max]  embeddings of the NEW segmentation
  *   new_k      [dev] int32 [n_utt, N_max]  argmax component of each new segment
  *   n_old/n_new[dev] int32 [n_utt]
+ *   n_flag     [dev] int32 [n_utt] or NULL: new segments whose argmax is an inactive row (k >= K)
  *   out_total  [dev] double [n_utt]        sum of chosen scores (:332)
  *   status     [dev] int32 [8]  [0] error flag (new segment without embedding ->
  *              kmeans_components.py:100 assert), [1] spans brute-forced (accumulates)    */
@@ -149,7 +150,7 @@ int32_t segk_kmeans_segment(segk_ctx *ctx, const segk_corpus *c, const segk_kmea
                             int32_t n_slices_min, int32_t n_slices_max, double wip,
                             const int32_t *cand_k, const float *cand_f, const float *cand_s,
                             uint8_t *boundaries, int32_t *old_tok, int32_t *new_tok,
-                            int32_t *new_k, int32_t *n_old, int32_t *n_new,
+                            int32_t *new_k, int32_t *n_old, int32_t *n_new, int32_t *n_flag,
                             double *out_total, int32_t *status, void *stream);
 
 /* A11 sequential update -- the tail of segment_i (kmeans_acoustic_wordseg.py:314-320):
@@ -205,8 +206,8 @@ int32_t segk_kmeans_del_component(segk_ctx *ctx, const segk_corpus *c, segk_kmea
  */
 int32_t segk_kmeans_batch_collect(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m,
                                   int32_t utt_lo, int32_t utt_hi, const int32_t *new_k,
-                                  const int32_t *n_new, int32_t *tok_off, int32_t *flag_buf,
-                                  int32_t cap, void *stream);
+                                  const int32_t *n_new, const int32_t *n_flag, int32_t *tok_off,
+                                  int32_t *flag_buf, int32_t cap, void *stream);
 int32_t segk_kmeans_batch_assign(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m,
                                  int32_t utt_lo, int32_t utt_hi, const int32_t *flag_all,
                                  int32_t n_ranks, int32_t my_rank, int32_t cap,

@@ -54,7 +54,7 @@ SIGNATURES = {
     "segk_kmeans_exact_max": (_i32, [_P, _CP, _KP, _P, _i64, _P, _P, _P, _P, _P, _P, _P]),
     "segk_kmeans_neg_sqrd_norm": (_i32, [_P, _CP, _KP, _i64, _P, _P]),
     "segk_kmeans_segment": (_i32, [_P, _CP, _KP, _P, _i32, _i32, _i32, _i32, _f64, _P, _P, _P, _P, _P, _P, _P,
-                                   _P, _P, _P, _P, _P]),
+                                   _P, _P, _P, _P, _P, _P]),
     "segk_dp_tri": (_i32, [_P, _i32, _P, _P, _P, _i32, _i32, _i32, _f64, _f64, _P, _i64, _P, _i64, _P, _P, _P,
                            _P, _i64, _P]),
     "segk_kmeans_update_utt": (_i32, [_P, _CP, _KP, _i32, _P, _P, _P, _P, _P, _P, _P]),
@@ -62,7 +62,7 @@ SIGNATURES = {
     "segk_kmeans_del_item": (_i32, [_P, _CP, _KP, _i64, _P, _P]),
     "segk_kmeans_clean_components": (_i32, [_P, _CP, _KP, _P, _P]),
     "segk_kmeans_del_component": (_i32, [_P, _CP, _KP, _i32, _P, _P]),
-    "segk_kmeans_batch_collect": (_i32, [_P, _CP, _KP, _i32, _i32, _P, _P, _P, _P, _i32, _P]),
+    "segk_kmeans_batch_collect": (_i32, [_P, _CP, _KP, _i32, _i32, _P, _P, _P, _P, _P, _i32, _P]),
     "segk_kmeans_batch_assign": (_i32, [_P, _CP, _KP, _i32, _i32, _P, _i32, _i32, _i32, _P, _P, _P, _P, _P, _P,
                                         _P, _P]),
     "segk_kmeans_batch_partials": (_i32, [_P, _CP, _KP, _P, _i32, _i32, _P, _P, _P, _P, _P, _P, _P, _P]),

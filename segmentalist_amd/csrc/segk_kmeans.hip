@@ -11,6 +11,8 @@
 //
 // Compiled with -ffp-contract=off: the exact stage must round every operation separately,
 // as numpy does (DESIGN.md "bit-exact contract").
+#include <stdlib.h>
+
 #include "segk_internal.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -169,16 +171,23 @@ __global__ void k_kmeans_prepare(const XT *means, int K_max, int D, float *tiles
     const int stride = segk_tile_stride(D);
     float *T = tiles + (int64_t)tile * stride;
     __shared__ double nrm[32];
-    if (threadIdx.x < 32) {
-        int comp = tile * 32 + threadIdx.x;
+    // |m|^2 of the tile's 32 components: 8 lanes per component, fp64
+    {
+        const int ci = threadIdx.x >> 3, sub = threadIdx.x & 7;      // 256 threads = 32 x 8
+        const int comp = tile * 32 + ci;
         double s = 0.0;
         if (comp < K_max)
-            for (int d = 0; d < D; d++) {
+            for (int d = sub; d < D; d += 8) {
                 double v = (double)means[(int64_t)comp * D + d];
                 s += v * v;
             }
-        nrm[threadIdx.x] = s;
-        if (comp < K_max) atomicMax(mnorm2_bits, (unsigned long long)__double_as_longlong(s));
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        s += __shfl_xor(s, 4);
+        if (sub == 0) {
+            nrm[ci] = s;
+            if (comp < K_max) atomicMax(mnorm2_bits, (unsigned long long)__double_as_longlong(s));
+        }
     }
     __syncthreads();
     for (int idx = threadIdx.x; idx < stride; idx += blockDim.x) {
@@ -197,10 +206,12 @@ __global__ void k_kmeans_prepare(const XT *means, int K_max, int D, float *tiles
     }
 }
 
-__global__ void k_mnorm_finish(const unsigned long long *mnorm2_bits, double *mnorm_max)
+// single-instruction max (fmaxf() makes hipcc add a canonicalising v_max on MFMA outputs)
+__device__ __forceinline__ float vmax_f32(float a, float b)
 {
-    double s = __longlong_as_double((long long)*mnorm2_bits);
-    *mnorm_max = sqrt(s) * (1.0 + 1e-6) + 1e-30;
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
 }
 
 // ======================================================================================
@@ -216,7 +227,8 @@ template <int GMAX, int NB>
 __global__ __launch_bounds__(256, 2) void k_kmeans_score(
     const float *__restrict__ X32, int64_t ld32, const int32_t *__restrict__ ids, int64_t row0, int64_t n,
     const float *__restrict__ tiles, int n_tiles, int tile_stride, int G /* groups present in X32 rows */,
-    int D, int fuse_exact, int32_t *__restrict__ cand_k, float *__restrict__ cand_f,
+    int D, int fuse_exact, int dbg /* timing-only ablation bits, 0 in production */,
+    int32_t *__restrict__ cand_k, float *__restrict__ cand_f,
     float *__restrict__ cand_s)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -240,78 +252,129 @@ __global__ __launch_bounds__(256, 2) void k_kmeans_score(
             else xb[nb][g] = make_float2(0.f, 0.f);
         }
     }
+    // running top-2 values, and the argmax as (tile, row code) -- per lane
     float m1[NB], m2[NB];
-    int32_t i1[NB];
+    int32_t irow[NB], itile[NB];
 #pragma unroll
-    for (int nb = 0; nb < NB; nb++) { m1[nb] = NEG_INF_F; m2[nb] = NEG_INF_F; i1[nb] = 0; }
+    for (int nb = 0; nb < NB; nb++) { m1[nb] = NEG_INF_F; m2[nb] = NEG_INF_F; irow[nb] = 0; itile[nb] = 0; }
 
     constexpr int NPASS = (GMAX * 128 + 32 + 1023) / 1024;   // == tile_stride / 1024 (segk_tile_stride)
-    // prologue: tile 0 -> buffer 0
-#pragma unroll
-    for (int p = 0; p < NPASS; p++) {
-        float4 v = *reinterpret_cast<const float4 *>(tiles + p * 1024 + tid * 4);
-        *reinterpret_cast<float4 *>(lds + p * 1024 + tid * 4) = v;
-    }
+    typedef const __attribute__((address_space(1))) void *gptr_t;
+    typedef __attribute__((address_space(3))) void *lptr_t;
+    // stage tile `tt` into LDS buffer `buf` with direct global->LDS loads: one wave instruction
+    // moves 64 x 16 B = 1 KiB to a wave-uniform base + lane*16, i.e. a straight copy of the image
+#define SEGK_STAGE(tt, buf)                                                                         \
+    do {                                                                                            \
+        const float *src_ = tiles + (int64_t)(tt) * tile_stride + tid * 4;                          \
+        float *dst_ = lds + (buf) * tile_stride + wave * 256;                                       \
+        _Pragma("unroll") for (int p = 0; p < NPASS; p++)                                           \
+            __builtin_amdgcn_global_load_lds((gptr_t)(src_ + p * 1024), (lptr_t)(dst_ + p * 1024), 16, 0, 0); \
+    } while (0)
+
+    SEGK_STAGE(0, 0);
     __syncthreads();
 
-    for (int t = 0; t < n_tiles; t++) {
-        const float *T = lds + (t & 1) * tile_stride;
-        // prefetch the next tile into registers (the last iteration re-reads its own tile:
-        // always in bounds, never stored)
-        float4 pre[NPASS];
-        const bool has_next = (t + 1 < n_tiles);
-        {
-            const float *src = tiles + (int64_t)(has_next ? t + 1 : t) * tile_stride;
+    // Software pipeline over the component tiles with two accumulator sets: while the MFMAs of
+    // tile t fill one set, the top-2/argmax update (VALU) of tile t-1 drains the other, a slice
+    // per k-step, so that the matrix and vector pipes overlap inside one wave.  The drained set
+    // starts at -inf, which makes the first drain a no-op.
+    f32x16 accA[NB], accB[NB];
 #pragma unroll
-            for (int p = 0; p < NPASS; p++)
-                pre[p] = *reinterpret_cast<const float4 *>(src + p * 1024 + tid * 4);
-        }
-        f32x16 acc[NB];
-        {
-            const float *cv = T + GMAX * 128 + 4 * h;
+    for (int nb = 0; nb < NB; nb++)
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                float4 c4 = *reinterpret_cast<const float4 *>(cv + 8 * q);
-#pragma unroll
-                for (int nb = 0; nb < NB; nb++) {
-                    acc[nb][4 * q + 0] = c4.x;
-                    acc[nb][4 * q + 1] = c4.y;
-                    acc[nb][4 * q + 2] = c4.z;
-                    acc[nb][4 * q + 3] = c4.w;
-                }
-            }
-        }
-#pragma unroll
-        for (int g = 0; g < GMAX; g++) {
-            float2 a = *reinterpret_cast<const float2 *>(T + (g * 64 + lane) * 2);
-#pragma unroll
-            for (int nb = 0; nb < NB; nb++)
-                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, xb[nb][g].x, acc[nb], 0, 0, 0);
-#pragma unroll
-            for (int nb = 0; nb < NB; nb++)
-                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, xb[nb][g].y, acc[nb], 0, 0, 0);
-        }
-        // running top-2 (values) and argmax (component) per lane
-        const int cbase = t * 32 + 4 * h;
-#pragma unroll
-        for (int nb = 0; nb < NB; nb++) {
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const float v = acc[nb][r];
-                const int comp = cbase + (r & 3) + 8 * (r >> 2);
-                m2[nb] = __builtin_amdgcn_fmed3f(m1[nb], m2[nb], v);
-                i1[nb] = (v > m1[nb]) ? comp : i1[nb];
-                m1[nb] = fmaxf(m1[nb], v);
-            }
-        }
-        if (has_next) {
-            float *dst = lds + ((t + 1) & 1) * tile_stride;
-#pragma unroll
-            for (int p = 0; p < NPASS; p++)
-                *reinterpret_cast<float4 *>(dst + p * 1024 + tid * 4) = pre[p];
-        }
-        __syncthreads();
+        for (int r = 0; r < 16; r++) { accA[nb][r] = NEG_INF_F; accB[nb][r] = NEG_INF_F; }
+
+    constexpr int VPS = (16 * NB + GMAX - 1) / GMAX;     // drained values per k-step
+
+    // One drained value = one asm statement of 4 VALU instructions, so that the compiler can
+    // neither sink it out of its k-step nor split it.  Order: the compare and the median read
+    // the OLD running maximum; two instructions separate v_cmp (writes VCC) from v_cndmask
+    // (reads VCC), which covers the 2 wait states gfx950 needs there.
+    //   vcc   = !(v > m1);  m2 = med3(m1, m2, v);  m1 = max(m1, v);  irow = vcc ? irow : code
+#define SEGK_DRAIN(ACC, vi)                                                           \
+    do {                                                                              \
+        const int nb_ = (vi) >> 4;                                                    \
+        asm volatile("v_cmp_ngt_f32 vcc, %3, %0\n\t"                                  \
+                     "v_med3_f32 %1, %0, %1, %3\n\t"                                  \
+                     "v_max_f32 %0, %0, %3\n\t"                                       \
+                     "v_cndmask_b32 %2, %4, %2, vcc"                                  \
+                     : "+v"(m1[nb_]), "+v"(m2[nb_]), "+v"(irow[nb_])                  \
+                     : "v"(ACC[nb_][(vi) & 15]), "n"((vi) & 15)                       \
+                     : "vcc");                                                        \
+    } while (0)
+
+#define SEGK_TILE(ACC_NEW, ACC_OLD, t_)                                                               \
+    do {                                                                                              \
+        const float *T = lds + ((t_) & 1) * tile_stride;                                              \
+        /* 18 wait states between the last MFMA that wrote ACC_OLD and its first VALU reader */       \
+        asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 1" ::: "memory");                                  \
+        if ((t_) + 1 < n_tiles && !(dbg & 8)) SEGK_STAGE((t_) + 1, ((t_) + 1) & 1);               \
+        {                                                                                             \
+            const float *cv = T + GMAX * 128 + 4 * h;                                                 \
+            _Pragma("unroll") for (int q = 0; q < 4; q++) {                                           \
+                float4 c4 = *reinterpret_cast<const float4 *>(cv + 8 * q);                            \
+                _Pragma("unroll") for (int nb = 0; nb < NB; nb++) {                                   \
+                    ACC_NEW[nb][4 * q + 0] = c4.x;                                                    \
+                    ACC_NEW[nb][4 * q + 1] = c4.y;                                                    \
+                    ACC_NEW[nb][4 * q + 2] = c4.z;                                                    \
+                    ACC_NEW[nb][4 * q + 3] = c4.w;                                                    \
+                }                                                                                     \
+            }                                                                                         \
+        }                                                                                             \
+        float m1s[NB];                                                                                \
+        _Pragma("unroll") for (int nb = 0; nb < NB; nb++) m1s[nb] = m1[nb];                           \
+        float2 a_cur = *reinterpret_cast<const float2 *>(T + lane * 2);                               \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        _Pragma("unroll") for (int g = 0; g < GMAX; g++) {                                            \
+            float2 a_nxt = a_cur;                                                                     \
+            if (g + 1 < GMAX) a_nxt = *reinterpret_cast<const float2 *>(T + ((g + 1) * 64 + lane) * 2); \
+            _Pragma("unroll") for (int nb = 0; nb < NB; nb++)                                         \
+                ACC_NEW[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.x, xb[nb][g].x, ACC_NEW[nb], 0, 0, 0); \
+            _Pragma("unroll") for (int nb = 0; nb < NB; nb++)                                         \
+                ACC_NEW[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.y, xb[nb][g].y, ACC_NEW[nb], 0, 0, 0); \
+            if (!(dbg & 4)) {                                                                     \
+                _Pragma("unroll") for (int q = 0; q < VPS; q++)                                       \
+                    if (g * VPS + q < 16 * NB) SEGK_DRAIN(ACC_OLD, g * VPS + q);                      \
+            }                                                                                         \
+            a_cur = a_nxt;                                                                            \
+            __builtin_amdgcn_sched_barrier(0);                                                        \
+        }                                                                                             \
+        /* the drained tile was t-1: fix up the tile id where the maximum moved */                    \
+        _Pragma("unroll") for (int nb = 0; nb < NB; nb++)                                             \
+            itile[nb] = (m1[nb] > m1s[nb]) ? ((t_) - 1) : itile[nb];                                  \
+        if (!(dbg & 2)) __syncthreads();                                                          \
+    } while (0)
+
+    int t = 0;
+    for (; t + 1 < n_tiles; t += 2) {
+        SEGK_TILE(accA, accB, t);
+        SEGK_TILE(accB, accA, t + 1);
     }
+    {
+        float m1s[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; nb++) m1s[nb] = m1[nb];
+        if (t < n_tiles) {
+            SEGK_TILE(accA, accB, t);
+#pragma unroll
+            for (int nb = 0; nb < NB; nb++) m1s[nb] = m1[nb];
+#pragma unroll
+            for (int vi = 0; vi < 16 * NB; vi++) SEGK_DRAIN(accA, vi);     // last tile, held by accA
+        } else {
+#pragma unroll
+            for (int vi = 0; vi < 16 * NB; vi++) SEGK_DRAIN(accB, vi);     // last tile, held by accB
+        }
+#pragma unroll
+        for (int nb = 0; nb < NB; nb++) itile[nb] = (m1[nb] > m1s[nb]) ? (n_tiles - 1) : itile[nb];
+    }
+#undef SEGK_TILE
+#undef SEGK_DRAIN
+#undef SEGK_STAGE
+    // component index of (tile, row code) on this lane half
+    int32_t i1[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; nb++) i1[nb] = itile[nb] * 32 + 4 * h + (irow[nb] & 3) + 8 * (irow[nb] >> 2);
+
     // the two lane halves hold disjoint component subsets of the same embedding
     const int nb8 = D >> 3;            // full blocks of 8 dims (numpy's strided accumulators)
     const int rem = D & 7;             // sequential tail
@@ -392,7 +455,8 @@ __device__ void exact_rows(const segk_corpus &c, const segk_kmeans &m, const int
     const XT *X = (const XT *)c.X;
     const XT *means = (const XT *)m.means;
     const int D = c.D;
-    const float M = (float)(*m.mnorm_max);
+    // mnorm_max holds max_k |m_k|^2 (maintained with atomicMax on the bit pattern)
+    const float M = (float)(sqrt(*m.mnorm_max) * (1.0 + 1e-6)) + 1e-30f;
     if (tid == 0) *qn = 0;
     __syncthreads();
     for (int i = tid; i < n; i += nt) {
@@ -505,8 +569,8 @@ template <typename XT>
 __global__ void k_kmeans_segment(segk_corpus c, segk_kmeans m, const int32_t *utts, int utt0, int n_min, int n_max,
                                  double wip, const int32_t *cand_k, const float *cand_f, const float *cand_s,
                                  uint8_t *boundaries, int32_t *old_tok, int32_t *new_tok, int32_t *new_k,
-                                 int32_t *n_old, int32_t *n_new, double *out_total, int32_t *status,
-                                 int band_cap)
+                                 int32_t *n_old, int32_t *n_new, int32_t *n_flag, double *out_total,
+                                 int32_t *status, int band_cap, int dbg)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -533,7 +597,8 @@ __global__ void k_kmeans_segment(segk_corpus c, segk_kmeans m, const int32_t *ut
         bid[i] = (s >= 0) ? vid[t * (t - 1) / 2 + s] : -1;
     }
     __syncthreads();
-    exact_rows<XT>(c, m, bid, nb, cand_k, cand_f, cand_s, bvec, bk, queue, qn, xrow, red_v, red_k, status + 1);
+    if (!(dbg & 1))
+        exact_rows<XT>(c, m, bid, nb, cand_k, cand_f, cand_s, bvec, bk, queue, qn, xrow, red_v, red_k, status + 1);
     __syncthreads();
     // A5: scale by duration, NaN duration -> -inf, + wip   (kmeans_acoustic_wordseg.py:346-351)
     for (int i = tid; i < nb; i += nt) {
@@ -556,7 +621,7 @@ __global__ void k_kmeans_segment(segk_corpus c, segk_kmeans m, const int32_t *ut
     uint8_t *l_bnd = (uint8_t *)red_k;         // [N]   (nt*4 bytes >= N_max checked by the launcher)
     for (int j = tid; j < N; j += nt) l_bnd[j] = gbnd[j];
     __syncthreads();
-    if (tid == 0) {
+    if (tid == 0 && !(dbg & 2)) {
 #define V_(t, s) bvec[((t) - 1) * W + ((t) - 1 - (s))]
 #define ID_(t, s) (((t) - 1 - (s)) < W ? bid[((t) - 1) * W + ((t) - 1 - (s))] : vid[(t) * ((t) - 1) / 2 + (s)])
         // ---- old tokens (utterances.py:159-174) before the boundaries are overwritten
@@ -617,7 +682,8 @@ __global__ void k_kmeans_segment(segk_corpus c, segk_kmeans m, const int32_t *ut
             t = t - k;
         }
         // ---- new tokens + their best components (:312-313)
-        int nn = 0, bad = 0;
+        int nn = 0, bad = 0, nf = 0;
+        const int Kact = *m.K;
         jp = 0;
         for (int j = 0; j < N; j++)
             if (l_bnd[j]) {
@@ -626,6 +692,7 @@ __global__ void k_kmeans_segment(segk_corpus c, segk_kmeans m, const int32_t *ut
                 else {
                     l_new[nn] = bid[(tt - 1) * W + w];
                     l_newk[nn] = bk[(tt - 1) * W + w];
+                    if (l_newk[nn] >= Kact) nf++;
                     nn++;
                 }
                 jp = j + 1;
@@ -633,6 +700,7 @@ __global__ void k_kmeans_segment(segk_corpus c, segk_kmeans m, const int32_t *ut
         out_total[u] = total;
         n_old[u] = no;
         n_new[u] = nn;
+        if (n_flag) n_flag[u] = nf;
         *qn = no | (nn << 16);
         if (bad) atomicOr(status, 1);
 #undef V_
@@ -797,10 +865,11 @@ __global__ void k_kmeans_update(segk_corpus c, segk_kmeans m, int op, int utt, i
 // ======================================================================================
 // (1) one workgroup: (a) exclusive prefix sum of n_new over the local utterances ->
 //     tok_off[u - lo] (tok_off[hi - lo] = number of local tokens); (b) collect, in token order,
-//     the new tokens whose argmax is an inactive row (k >= K):
-//     flag_buf[0] = count, then (slot = utt*N_max + t, k) pairs.
+//     the new tokens whose argmax is an inactive row (k >= K; per-utterance counts n_flag come
+//     from the segment kernel): flag_buf[0] = count, then (slot = utt*N_max + t, k) pairs.
 __global__ void k_batch_collect(segk_corpus c, segk_kmeans m, int lo, int hi, const int32_t *new_k,
-                                const int32_t *n_new, int32_t *tok_off, int32_t *flag_buf, int cap)
+                                const int32_t *n_new, const int32_t *n_flag, int32_t *tok_off,
+                                int32_t *flag_buf, int cap)
 {
     __shared__ int s_cnt, s_tok;
     __shared__ int s_wave[16], s_wave2[16];
@@ -812,11 +881,7 @@ __global__ void k_batch_collect(segk_corpus c, segk_kmeans m, int lo, int hi, co
     for (int u0 = lo; u0 < hi; u0 += nt) {
         const int u = u0 + tid;
         int mine = 0, ntok = 0;
-        if (u < hi) {
-            ntok = n_new[u];
-            for (int t = 0; t < ntok; t++)
-                if (new_k[(int64_t)u * c.N_max + t] >= K) mine++;
-        }
+        if (u < hi) { ntok = n_new[u]; mine = n_flag[u]; }
         int incl = mine, incl2 = ntok;
         for (int o = 1; o < 64; o <<= 1) {
             int v = __shfl_up(incl, o), v2 = __shfl_up(incl2, o);
@@ -831,8 +896,8 @@ __global__ void k_batch_collect(segk_corpus c, segk_kmeans m, int lo, int hi, co
             total2 += s_wave2[w2];
         }
         if (u < hi) tok_off[u - lo] = s_tok + woff2 + incl2 - ntok;
-        int off = s_cnt + woff + incl - mine;
         if (mine > 0) {
+            int off = s_cnt + woff + incl - mine;
             for (int t = 0; t < ntok; t++) {
                 int k = new_k[(int64_t)u * c.N_max + t];
                 if (k >= K) {
@@ -855,24 +920,41 @@ __global__ void k_batch_collect(segk_corpus c, segk_kmeans m, int lo, int hi, co
 }
 
 // (2) replay the `k > K -> K` clamp (kmeans_components.py:103-106) over the flagged tokens of
-//     ALL ranks in rank order; patch the local new_k; set K.  One thread (the list is short).
+//     ALL ranks in rank order; patch the local new_k; set K.  One wave: the (short) lists are
+//     fetched in parallel, lane 0 replays them.
 __global__ void k_batch_resolve(segk_kmeans m, const int32_t *flag_all, int n_ranks, int my_rank, int cap,
                                 int32_t *new_k, int32_t *status)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    __shared__ int32_t l_k[1024], l_slot[1024];
+    const int lane = threadIdx.x;
     int K = *m.K;
     for (int r = 0; r < n_ranks; r++) {
         const int32_t *fb = flag_all + (int64_t)r * (1 + 2 * cap);
         int cnt = fb[0];
-        if (cnt > cap) { atomicOr(status, 4); cnt = cap; }
-        for (int q = 0; q < cnt; q++) {
-            int k = fb[2 + 2 * q];
-            if (k > K) k = K;
-            if (k == K) K++;
-            if (r == my_rank) new_k[fb[1 + 2 * q]] = k;
+        if (cnt > cap) { if (lane == 0) atomicOr(status, 4); cnt = cap; }
+        for (int q0 = 0; q0 < cnt; q0 += 1024) {
+            int nq = cnt - q0 < 1024 ? cnt - q0 : 1024;
+            for (int q = lane; q < nq; q += 64) {
+                l_slot[q] = fb[1 + 2 * (q0 + q)];
+                l_k[q] = fb[2 + 2 * (q0 + q)];
+            }
+            __syncthreads();
+            if (lane == 0) {
+                for (int q = 0; q < nq; q++) {
+                    int k = l_k[q];
+                    if (k > K) k = K;
+                    if (k == K) K++;
+                    l_k[q] = k;
+                }
+            }
+            __syncthreads();
+            K = __shfl(K, 0);
+            if (r == my_rank)
+                for (int q = lane; q < nq; q += 64) new_k[l_slot[q]] = l_k[q];
+            __syncthreads();
         }
     }
-    *m.K = K;
+    if (lane == 0) *m.K = K;
 }
 
 // (3) compact the local tokens in token order: ctok[tok_off[u-lo] + t] = (embedding, component)
@@ -891,18 +973,23 @@ __global__ void k_batch_compact(segk_corpus c, int lo, int hi, const int32_t *ne
 }
 
 // (4) per statistics block and component: sequential fp64 sum over the block's tokens in
-//     token order.  One wave per (block, component); lanes own dimensions; the four waves of
-//     a workgroup share the block, scanning the compact token list 64 entries at a time.
+//     token order.  A workgroup = (block, 8 consecutive components), one wave per component;
+//     lanes own dimensions.  The block's token keys are staged in LDS chunk by chunk with
+//     coalesced loads, so the per-wave scan never waits on global memory; only the (few)
+//     matching tokens touch X.
+#define PART_CHUNK 8192
 template <typename XT>
-__global__ void k_batch_partials(segk_corpus c, segk_kmeans m, const int32_t *blk_lo, int n_blocks, int lo,
-                                 const int32_t *tok_off, const int32_t *ctok_id, const int32_t *ctok_k,
-                                 const double *out_total, double *part_sum, int64_t *part_cnt,
-                                 double *part_tot)
+__global__ __launch_bounds__(512) void k_batch_partials(
+    segk_corpus c, segk_kmeans m, const int32_t *blk_lo, int n_blocks, int lo, const int32_t *tok_off,
+    const int32_t *ctok_id, const int32_t *ctok_k, const double *out_total, double *part_sum,
+    int64_t *part_cnt, double *part_tot)
 {
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int lane = threadIdx.x & 63;
-    const int b = wave / m.K_max, k = wave % m.K_max;
-    if (b >= n_blocks) return;
+    __shared__ __attribute__((aligned(16))) int32_t keys[PART_CHUNK];
+    const int groups = (m.K_max + 7) / 8;
+    const int b = blockIdx.x / groups, kg = blockIdx.x % groups;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int k = kg * 8 + wv;
+    const bool active = k < m.K_max;
     const int D = c.D;
     const XT *X = (const XT *)c.X;
     const int u0 = blk_lo[b], u1 = blk_lo[b + 1];
@@ -913,34 +1000,81 @@ __global__ void k_batch_partials(segk_corpus c, segk_kmeans m, const int32_t *bl
 #pragma unroll
         for (int r = 0; r < MAXR; r++) acc[r] = 0.0;
         int64_t cnt = 0;
-        for (int pb = p0; pb < p1; pb += 64) {
-            int p = pb + lane;
-            int match = 0, id = 0;
-            if (p < p1 && ctok_k[p] == k) { match = 1; id = ctok_id[p]; }
-            unsigned long long bal = __ballot(match);
-            while (bal) {
-                int src = __ffsll((long long)bal) - 1;
-                bal &= bal - 1;
-                int e = __shfl(id, src);
-                cnt++;
+        for (int pc = p0; pc < p1; pc += PART_CHUNK) {
+            const int nch = p1 - pc < PART_CHUNK ? p1 - pc : PART_CHUNK;
+            __syncthreads();
+            {   // coalesced staging, 4 independent loads in flight per thread
+                const int nt4 = 4 * blockDim.x;
+                for (int i0 = threadIdx.x; i0 < nch; i0 += nt4) {
+                    int v[4];
 #pragma unroll
-                for (int r = 0; r < MAXR; r++) {
-                    int d = d0 + r * 64 + lane;
-                    if (d < D) acc[r] += (double)X[(int64_t)e * c.ldx + d];
+                    for (int q = 0; q < 4; q++) {
+                        const int i = i0 + q * blockDim.x;
+                        v[q] = (i < nch) ? ctok_k[pc + i] : -1;
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const int i = i0 + q * blockDim.x;
+                        if (i < nch) keys[i] = v[q];
+                    }
+                }
+            }
+            __syncthreads();
+            if (active) {
+                for (int pb = 0; pb < nch; pb += 64) {
+                    const int i = pb + lane;
+                    const int match = (i < nch) && (keys[i] == k);
+                    unsigned long long bal = __ballot(match);
+                    if (bal) {
+                        int id = match ? ctok_id[pc + i] : 0;
+                        while (bal) {
+                            int src = __ffsll((long long)bal) - 1;
+                            bal &= bal - 1;
+                            int e = __shfl(id, src);
+                            cnt++;
+#pragma unroll
+                            for (int r = 0; r < MAXR; r++) {
+                                int d = d0 + r * 64 + lane;
+                                if (d < D) acc[r] += (double)X[(int64_t)e * c.ldx + d];
+                            }
+                        }
+                    }
                 }
             }
         }
+        if (active) {
 #pragma unroll
-        for (int r = 0; r < MAXR; r++) {
-            int d = d0 + r * 64 + lane;
-            if (d < D) part_sum[((int64_t)b * m.K_max + k) * D + d] = acc[r];
+            for (int r = 0; r < MAXR; r++) {
+                int d = d0 + r * 64 + lane;
+                if (d < D) part_sum[((int64_t)b * m.K_max + k) * D + d] = acc[r];
+            }
+            if (lane == 0 && d0 == 0) part_cnt[(int64_t)b * m.K_max + k] = cnt;
         }
-        if (lane == 0 && d0 == 0) part_cnt[(int64_t)b * m.K_max + k] = cnt;
     }
-    if (k == 0 && lane == 0) {
+    if (kg == 0) {
+        // sequential (utterance order) sum of the block's totals, staged through LDS so that the
+        // single summing thread never waits on global memory
+        double *stage = reinterpret_cast<double *>(keys);
         double s = 0.0;
-        for (int u = u0; u < u1; u++) s += out_total[u];
-        part_tot[b] = s;
+        for (int uc = u0; uc < u1; uc += PART_CHUNK / 2) {
+            const int nu = u1 - uc < PART_CHUNK / 2 ? u1 - uc : PART_CHUNK / 2;
+            __syncthreads();
+            for (int i = threadIdx.x; i < nu; i += blockDim.x) stage[i] = out_total[uc + i];
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                // strictly sequential adds; the LDS reads are issued 16 at a time
+                int i = 0;
+                for (; i + 16 <= nu; i += 16) {
+                    double v[16];
+#pragma unroll
+                    for (int q = 0; q < 16; q++) v[q] = stage[i + q];
+#pragma unroll
+                    for (int q = 0; q < 16; q++) s += v[q];
+                }
+                for (; i < nu; i++) s += stage[i];
+            }
+        }
+        if (threadIdx.x == 0) part_tot[b] = s;
     }
 }
 
@@ -1341,7 +1475,8 @@ static int launch_score(const segk_corpus *c, const segk_kmeans *m, const int32_
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((k_kmeans_score<GMAX, NB>), dim3((unsigned)grid), dim3(256), lds, st, c->X32, c->ld32, ids,
                        row0, n, m->tiles, segk_n_tiles(m->K_max), stride, segk_G(c->D), c->D,
-                       (c->x_dtype == SEGK_F32 && c->D >= 8 && c->D <= 128) ? 1 : 0, cand_k, cand_f, cand_s);
+                       (c->x_dtype == SEGK_F32 && c->D >= 8 && c->D <= 128) ? 1 : 0,
+                       getenv("SEGK_SCORE_DBG") ? atoi(getenv("SEGK_SCORE_DBG")) : 0, cand_k, cand_f, cand_s);
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;
 }
@@ -1374,13 +1509,11 @@ int32_t segk_kmeans_prepare(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m,
     if (rc) return rc;
     SEGK_REQUIRE(m && m->tiles && m->mnorm_max, "kmeans tiles/mnorm_max");
     hipStream_t st = (hipStream_t)stream;
-    // mnorm_max doubles as the atomicMax scratch (bits of |m|^2), finished in place
+    // mnorm_max = max_k |m_k|^2, maintained by atomicMax on the bit pattern (non-negative doubles)
     SEGK_CHECK_HIP(hipMemsetAsync(m->mnorm_max, 0, sizeof(double), st));
     DISPATCH_XT(c, hipLaunchKernelGGL(k_kmeans_prepare<XT>, dim3(segk_n_tiles(m->K_max)), dim3(256), 0, st,
                                        (const XT *)m->means, m->K_max, c->D, m->tiles,
                                        (unsigned long long *)m->mnorm_max););
-    hipLaunchKernelGGL(k_mnorm_finish, dim3(1), dim3(1), 0, st, (const unsigned long long *)m->mnorm_max,
-                       m->mnorm_max);
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;
 }
@@ -1446,8 +1579,8 @@ int32_t segk_kmeans_segment(segk_ctx *ctx, const segk_corpus *c, const segk_kmea
                             int32_t utt0, int32_t n_utts, int32_t n_slices_min, int32_t n_slices_max, double wip,
                             const int32_t *cand_k, const float *cand_f, const float *cand_s, uint8_t *boundaries,
                             int32_t *old_tok,
-                            int32_t *new_tok, int32_t *new_k, int32_t *n_old, int32_t *n_new, double *out_total,
-                            int32_t *status, void *stream)
+                            int32_t *new_tok, int32_t *new_k, int32_t *n_old, int32_t *n_new, int32_t *n_flag,
+                            double *out_total, int32_t *status, void *stream)
 {
     (void)ctx;
     int rc = check_corpus(c);
@@ -1471,13 +1604,16 @@ int32_t segk_kmeans_segment(segk_ctx *ctx, const segk_corpus *c, const segk_kmea
                        "set n_slices_max", c->N_max, W, lds);
         return SEGK_ERR_UNSUPPORTED;
     }
+    // development knob (timing experiments only): SEGK_DEBUG_SKIP bit0 = skip the exact stage,
+    // bit1 = skip the serial DP
+    static const int dbg = getenv("SEGK_DEBUG_SKIP") ? atoi(getenv("SEGK_DEBUG_SKIP")) : 0;
     DISPATCH_XT(c, {
         if (lds > 48 * 1024)
             SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_kmeans_segment<XT>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k_kmeans_segment<XT>, dim3(n_utts), dim3(nt), lds, st, *c, *m, utts, utt0, n_slices_min,
                            n_slices_max, wip, cand_k, cand_f, cand_s, boundaries, old_tok, new_tok, new_k, n_old, n_new,
-                           out_total, status, band_cap);
+                           n_flag, out_total, status, band_cap, dbg);
     });
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;
@@ -1550,15 +1686,15 @@ int32_t segk_kmeans_del_component(segk_ctx *ctx, const segk_corpus *c, segk_kmea
 }
 
 int32_t segk_kmeans_batch_collect(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m, int32_t utt_lo,
-                                  int32_t utt_hi, const int32_t *new_k, const int32_t *n_new, int32_t *tok_off,
-                                  int32_t *flag_buf, int32_t cap, void *stream)
+                                  int32_t utt_hi, const int32_t *new_k, const int32_t *n_new, const int32_t *n_flag,
+                                  int32_t *tok_off, int32_t *flag_buf, int32_t cap, void *stream)
 {
     (void)ctx;
     int rc = check_corpus(c);
     if (rc) return rc;
     SEGK_REQUIRE(0 <= utt_lo && utt_lo <= utt_hi && utt_hi <= c->n_utt, "utterance range");
     hipLaunchKernelGGL(k_batch_collect, dim3(1), dim3(1024), 0, (hipStream_t)stream, *c, *m, utt_lo, utt_hi, new_k,
-                       n_new, tok_off, flag_buf, cap);
+                       n_new, n_flag, tok_off, flag_buf, cap);
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;
 }
@@ -1592,9 +1728,8 @@ int32_t segk_kmeans_batch_partials(segk_ctx *ctx, const segk_corpus *c, const se
     int rc = check_corpus(c);
     if (rc) return rc;
     if (n_blocks_local <= 0) return SEGK_OK;
-    int64_t waves = (int64_t)n_blocks_local * m->K_max;
-    int64_t grid = (waves + 3) / 4;
-    DISPATCH_XT(c, hipLaunchKernelGGL(k_batch_partials<XT>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream,
+    int64_t grid = (int64_t)n_blocks_local * ((m->K_max + 7) / 8);
+    DISPATCH_XT(c, hipLaunchKernelGGL(k_batch_partials<XT>, dim3((unsigned)grid), dim3(512), 0, (hipStream_t)stream,
                                        *c, *m, blk_lo, n_blocks_local, utt_lo, tok_off, ctok_id, ctok_k, out_total,
                                        part_sum, part_cnt, part_tot););
     SEGK_LAUNCH_CHECK();

@@ -138,6 +138,7 @@ class DeviceKMeans(object):
         self.new_k = torch.zeros((nu, nm), dtype=torch.int32, device=dev)
         self.n_old = torch.zeros(nu, dtype=torch.int32, device=dev)
         self.n_new = torch.zeros(nu, dtype=torch.int32, device=dev)
+        self.n_flag = torch.zeros(nu, dtype=torch.int32, device=dev)
         self.out_total = torch.zeros(nu, dtype=torch.float64, device=dev)
         self.utt_arange = torch.arange(nu, dtype=torch.int32, device=dev)
         self.remap = torch.zeros(self.K_max, dtype=torch.int32, device=dev)
@@ -245,8 +246,8 @@ class DeviceKMeans(object):
         check(self._L.segk_kmeans_segment(
             self._ctx, self._cp(), C.byref(self.m), up, int(utt0), int(n), int(n_slices_min), int(n_slices_max),
             float(wip), ptr(self.cand_k), ptr(self.cand_f), ptr(self.cand_s), ptr(boundaries), ptr(self.old_tok),
-            ptr(self.new_tok), ptr(self.new_k), ptr(self.n_old), ptr(self.n_new), ptr(self.out_total),
-            ptr(self.status), _abi.stream()))
+            ptr(self.new_tok), ptr(self.new_k), ptr(self.n_old), ptr(self.n_new), ptr(self.n_flag),
+            ptr(self.out_total), ptr(self.status), _abi.stream()))
 
     def segment_utt_sequential(self, boundaries, i, n_slices_min, n_slices_max, wip):
         """The whole of segment_i (kmeans_acoustic_wordseg.py:225-332) for utterance i, enqueued
@@ -337,7 +338,7 @@ class KMeansBatchSweeper(object):
             dk.score_rows(row0=pt.row_lo, n=pt.row_hi - pt.row_lo)
         dk.segment(boundaries, n_slices_min, n_slices_max, wip, utt0=pt.utt_lo, n_utts=pt.utt_hi - pt.utt_lo)
         check(L.segk_kmeans_batch_collect(ctx, cp, mp, pt.utt_lo, pt.utt_hi, ptr(dk.new_k), ptr(dk.n_new),
-                                          ptr(dk.tok_off), ptr(self.flag), self.cap, st))
+                                          ptr(dk.n_flag), ptr(dk.tok_off), ptr(self.flag), self.cap, st))
         if pt.world > 1:
             import torch.distributed as dist
             dist.all_gather_into_tensor(self.flag_all.view(-1), self.flag, group=self.group)
