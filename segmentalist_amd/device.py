@@ -163,7 +163,12 @@ class DeviceKMeans(object):
                                                           _abi.stream()))
         if world > 1:
             import torch.distributed as dist
-            dist.all_reduce(self.assignments, op=dist.ReduceOp.MAX, group=group)
+            if dist.get_backend(group) == "nccl":
+                dist.all_reduce(self.assignments, op=dist.ReduceOp.MAX, group=group)
+            else:
+                h = self.assignments.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.MAX, group=group)
+                self.assignments.copy_(h)
         self.assign_stale = None
 
     def prepare(self):
@@ -294,6 +299,21 @@ class Partition(object):
         self.local_bounds = self.bounds[rank * self.nbl:(rank + 1) * self.nbl + 1].copy()
 
 
+def all_gather_rows(out, inp, group=None):
+    """out[r] <- inp of rank r.  `inp` is out[rank] (in-place all-gather).  RCCL directly on the
+    device buffers; under the gloo backend (CPU tests, several ranks sharing one GPU) the rows
+    are staged through host memory."""
+    import torch
+    import torch.distributed as dist
+    if dist.get_backend(group) == "nccl":
+        dist.all_gather_into_tensor(out.view(-1), inp, group=group)
+    else:
+        host = [torch.empty(inp.shape, dtype=inp.dtype) for _ in range(dist.get_world_size(group))]
+        dist.all_gather(host, inp.cpu(), group=group)
+        for r, h in enumerate(host):
+            out[r].copy_(h)
+
+
 class KMeansBatchSweeper(object):
     """One batch-synchronous sweep = score -> segment -> collect -> [all-gather flags] -> assign
     -> partials -> [all-gather partials] -> finalize, all enqueued on the current stream.
@@ -340,8 +360,7 @@ class KMeansBatchSweeper(object):
         check(L.segk_kmeans_batch_collect(ctx, cp, mp, pt.utt_lo, pt.utt_hi, ptr(dk.new_k), ptr(dk.n_new),
                                           ptr(dk.n_flag), ptr(dk.tok_off), ptr(self.flag), self.cap, st))
         if pt.world > 1:
-            import torch.distributed as dist
-            dist.all_gather_into_tensor(self.flag_all.view(-1), self.flag, group=self.group)
+            all_gather_rows(self.flag_all, self.flag, self.group)
         check(L.segk_kmeans_batch_assign(ctx, cp, mp, pt.utt_lo, pt.utt_hi, ptr(self.flag_all), pt.world,
                                          pt.rank, self.cap, ptr(dk.new_tok), ptr(dk.new_k), ptr(dk.n_new),
                                          ptr(dk.tok_off), ptr(dk.ctok_id), ptr(dk.ctok_k), ptr(dk.status), st))
@@ -349,8 +368,7 @@ class KMeansBatchSweeper(object):
                                            ptr(dk.ctok_id), ptr(dk.ctok_k), ptr(dk.out_total), self._p_sum,
                                            self._p_cnt, self._p_tot, st))
         if pt.world > 1:
-            import torch.distributed as dist
-            dist.all_gather_into_tensor(self.pack_all.view(-1), self.pack, group=self.group)
+            all_gather_rows(self.pack_all, self.pack, self.group)
         check(L.segk_kmeans_batch_finalize(ctx, cp, mp, pt.utt_lo, pt.utt_hi, self._a_sum, self._a_cnt,
                                            self._a_tot, pt.n_blocks, pt.nbl, self.rank_stride,
                                            ptr(dk.new_k), ptr(dk.n_new), ptr(dk.remap), ptr(dk.out_scalars),

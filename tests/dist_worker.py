@@ -1,0 +1,54 @@
+"""Worker of tests/test_gpu_dist.py: runs batch sweeps of the PRODUCT under torch.distributed
+(any world size, gloo or nccl) and writes the final state of rank 0 to an .npz file."""
+import os
+import random
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    out_path, backend, n_sweeps = sys.argv[1], sys.argv[2], int(sys.argv[3])
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    ngpu = torch.cuda.device_count()
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % max(ngpu, 1))
+    if world > 1:
+        dist.init_process_group(backend)
+    from segmentalist_amd import kmeans_acoustic_wordseg as kaw
+    from segmentalist_amd.synth import make_corpus
+    corpus = make_corpus(96, 24, 40, seed=3, ragged=True, n_slices_max=5, N_range=(4, 14))
+    random.seed(11)
+    np.random.seed(11)
+    seg = kaw.SegmentalKMeansWordseg(40, *corpus, n_slices_max=5, init_am_assignments="rand", sync="batch",
+                                     n_stat_blocks=8)
+    rec = seg.segment(n_sweeps)
+    c = seg.acoustic_model.components
+    state = dict(assignments=c.assignments, means=c.means, mean_numerators=c.mean_numerators, counts=c.counts,
+                 K=np.array(c.K), totals=np.array(rec["sum_neg_len_sqrd_norm"]),
+                 n_tokens=np.array(rec["n_tokens"]))
+    # boundaries of the utterances owned by other ranks live on those ranks: gather them
+    b = seg._dev_bounds.cpu()
+    if world > 1:
+        gathered = [torch.empty_like(b) for _ in range(world)]
+        dist.all_gather(gathered, b)
+        part = seg._get_sweeper().part
+        full = b.clone()
+        for r in range(world):
+            lo, hi = int(part.bounds[r * part.nbl]), int(part.bounds[(r + 1) * part.nbl])
+            full[lo:hi] = gathered[r][lo:hi]
+        b = full
+    state["boundaries"] = b.numpy()
+    if rank == 0:
+        np.savez(out_path, **state)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,33 @@
+"""Multi-rank batch mode of the PRODUCT: 1, 2 and 4 ranks (gloo, all ranks on the one GPU of
+the test box) must produce bit-identical state -- the fixed summation tree and the replayed
+`k > K -> K` clamp make the result independent of the sharding."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run(world, out, n_sweeps=3):
+    worker = os.path.join(ROOT, "tests", "dist_worker.py")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    if world == 1:
+        cmd = [sys.executable, worker, out, "gloo", str(n_sweeps)]
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+               "--master-addr", "127.0.0.1", "--master-port", str(29500 + world), worker, out, "gloo",
+               str(n_sweeps)]
+    subprocess.run(cmd, check=True, env=env, timeout=600, cwd=ROOT)
+    return np.load(out)
+
+
+def test_batch_mode_is_independent_of_the_number_of_ranks(tmp_path):
+    ref = run(1, str(tmp_path / "w1.npz"))
+    for world in (2, 4):
+        got = run(world, str(tmp_path / ("w%d.npz" % world)))
+        for k in ref.files:
+            assert np.array_equal(ref[k], got[k]), (world, k)
