@@ -240,6 +240,84 @@ int32_t segk_kmeans_sum_neg_sqrd_norm(segk_ctx *ctx, const segk_corpus *c, const
                                       double *out, void *stream);
 
 /* -------------------------------------------------------------------------------------
+ * FBGMM components: device image of `GaussianComponentsFixedVar`
+ * (gaussian_components_fixedvar.py:20-126) or `GaussianComponentsDiag`
+ * (gaussian_components_diag.py:19-120) plus the mixture hyper-parameters of `FBGMM`
+ * (fbgmm.py:57-64).  All statistics are float64 as in the reference.
+ *   cov_type 0 "fixed": prior_a = precision (1/var), prior_b = mu_0, prior_c = precision_0;
+ *        stat_a = mu_N_numerators, stat_b = precision_Ns, log_prod = log_prod_precision_preds,
+ *        pred = precision_preds
+ *   cov_type 1 "diag":  prior_a = S_0, prior_b = m_0, (prior_c unused), k_0, v_0;
+ *        stat_a = m_N_numerators, stat_b = S_N_partials, log_prod = log_prod_vars,
+ *        pred = inv_vars
+ * ------------------------------------------------------------------------------------- */
+typedef struct segk_fbgmm {
+    int32_t cov_type;
+    int32_t K_max;
+    double alpha;              /* Dirichlet concentration (fbgmm.py:59)                       */
+    double lms;                /* language-model scaling factor (fbgmm.py:62)                 */
+    double k_0, v_0;           /* NIW scalars (diag only)                                     */
+    const double *prior_a;     /* [dev] [D]                                                   */
+    const double *prior_b;     /* [dev] [D]                                                   */
+    const double *prior_c;     /* [dev] [D]                                                   */
+    double *stat_a;            /* [dev] [K_max, D]                                            */
+    double *stat_b;            /* [dev] [K_max, D]                                            */
+    double *log_prod;          /* [dev] [K_max]                                               */
+    double *pred;              /* [dev] [K_max, D]                                            */
+    int64_t *counts;           /* [dev] [K_max]                                               */
+    int32_t *assignments;      /* [dev] [n_emb]                                               */
+    int32_t *K;                /* [dev] [1]                                                   */
+} segk_fbgmm;
+
+/* Components __init__ from `assignments` (fixedvar:110-120 / diag:114-120): statistics summed in
+ * the order of the reference's add_item loop (k ascending, rows ascending), counts, K. */
+int32_t segk_fbgmm_init_stats(segk_ctx *ctx, const segk_corpus *c, segk_fbgmm *f, void *stream);
+
+/* A11 for FBGMM components, reference order and arithmetic, one workgroup:
+ *   op 0: del_item for every segment of the CURRENT segmentation of utterance `utt`
+ *         (unigram_acoustic_wordseg.py:270-273; boundaries [dev] uint8 [n_utt, N_max])
+ *   op 1: add_item(item, k)  (fixedvar:153-170 / diag:162-177)
+ *   op 2: del_item(item)     (fixedvar:172-188 / diag:179-194; deletes the component when it
+ *         empties: del_component fixedvar:190-221 / diag:196-213, swap-last compaction)
+ *   op 4: del_component(k)                                                                 */
+int32_t segk_fbgmm_update(segk_ctx *ctx, const segk_corpus *c, segk_fbgmm *f, int32_t op,
+                          int32_t utt, int64_t item, int32_t k, const uint8_t *boundaries,
+                          void *stream);
+
+/* A2/A3/A4 -- FBGMM.log_marg_i (fbgmm.py:256-285) = logsumexp over K_max of
+ * lms*(log(alpha/K_max + counts) - log(sum counts + alpha)) + log_post_pred (k < K,
+ * fixedvar:242-253 / diag:237-259) or log_prior (k >= K, fixedvar:224-231 / diag:215-222), for
+ * rows ids[0..n) (row0..row0+n-1 when NULL; -1 skipped); out [dev] double [n_emb] indexed by row. */
+int32_t segk_fbgmm_score(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *f,
+                         const int32_t *ids, int64_t row0, int64_t n, double *out, void *stream);
+
+/* A2/A3 vector API: out [dev] double [K_max + 1]: out[k] = log_post_pred(row)[k] for k < K
+ * (fixedvar:242-253 / diag:237-259), out[K_max] = log_prior(row) (fixedvar:224-231 / diag:215-222). */
+int32_t segk_fbgmm_pred_vector(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *f,
+                               int64_t row, double *out, void *stream);
+
+/* A5 + A6/A7 for one utterance -- get_vec_embed_log_probs (unigram_acoustic_wordseg.py:474-511)
+ * from the per-row scores, then forward_backward (:653-756) or forward_backward_viterbi
+ * (:759-864).  Backward sampling consumes ustream[*ucursor ...] (one value per emitted segment,
+ * the reference's random.random() calls) and advances the device-resident cursor.
+ *   new_tok [dev] int32 [n_utt, N_max], n_new [dev] int32 [n_utt], out_logprob [dev] double [n_utt]
+ *   status bits: 8 uniform stream exhausted, 16 log_prob == -inf (the reference asserts, :753) */
+int32_t segk_unigram_segment(segk_ctx *ctx, const segk_corpus *c, int32_t utt, int32_t viterbi,
+                             int32_t n_slices_min, int32_t n_slices_max, double wip,
+                             double time_power_term, double log_p_continue, double anneal_temp,
+                             const double *score, const double *ustream, int64_t *ucursor,
+                             int64_t ucap, uint8_t *boundaries, int32_t *new_tok, int32_t *n_new,
+                             double *out_logprob, int32_t *status, void *stream);
+
+/* A10 for the new segments of one utterance, in order, statistics updated between segments:
+ * gibbs_sample_inside_loop_i (fbgmm.py:422-463; one uniform per segment, utils.draw forward
+ * order, `k > K -> K`) or map_assign_i (:465-494) when map_assign != 0.                     */
+int32_t segk_fbgmm_assign(segk_ctx *ctx, const segk_corpus *c, segk_fbgmm *f, int32_t utt,
+                          int32_t map_assign, double anneal_temp, const int32_t *new_tok,
+                          const int32_t *n_new, const double *ustream, int64_t *ucursor,
+                          int64_t ucap, int32_t *status, void *stream);
+
+/* -------------------------------------------------------------------------------------
  * A6 / A7 / A8 on caller-supplied score vectors -- drop-in for the module-level functions
  *   kind 0: forward_backward_kmeans_viterbi   kmeans_acoustic_wordseg.py:449-555
  *   kind 1: forward_backward_viterbi          unigram_acoustic_wordseg.py:759-864

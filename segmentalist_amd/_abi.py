@@ -36,9 +36,18 @@ class KMeansDev(C.Structure):
     ]
 
 
+class FbgmmDev(C.Structure):
+    _fields_ = [
+        ("cov_type", C.c_int32), ("K_max", C.c_int32), ("alpha", C.c_double), ("lms", C.c_double),
+        ("k_0", C.c_double), ("v_0", C.c_double), ("prior_a", C.c_void_p), ("prior_b", C.c_void_p),
+        ("prior_c", C.c_void_p), ("stat_a", C.c_void_p), ("stat_b", C.c_void_p), ("log_prod", C.c_void_p),
+        ("pred", C.c_void_p), ("counts", C.c_void_p), ("assignments", C.c_void_p), ("K", C.c_void_p),
+    ]
+
+
 _P = C.c_void_p
 _i32, _i64, _f64 = C.c_int32, C.c_int64, C.c_double
-_CP, _KP = C.POINTER(Corpus), C.POINTER(KMeansDev)
+_CP, _KP, _FP = C.POINTER(Corpus), C.POINTER(KMeansDev), C.POINTER(FbgmmDev)
 
 # name -> (restype, argtypes); every symbol include/segk.h declares
 SIGNATURES = {
@@ -70,6 +79,13 @@ SIGNATURES = {
                                           _P, _P]),
     "segk_kmeans_assignments_from_tokens": (_i32, [_P, _CP, _KP, _i32, _i32, _P, _P, _P, _P]),
     "segk_kmeans_sum_neg_sqrd_norm": (_i32, [_P, _CP, _KP, _P, _P]),
+    "segk_fbgmm_init_stats": (_i32, [_P, _CP, _FP, _P]),
+    "segk_fbgmm_update": (_i32, [_P, _CP, _FP, _i32, _i32, _i64, _i32, _P, _P]),
+    "segk_fbgmm_score": (_i32, [_P, _CP, _FP, _P, _i64, _i64, _P, _P]),
+    "segk_fbgmm_pred_vector": (_i32, [_P, _CP, _FP, _i64, _P, _P]),
+    "segk_unigram_segment": (_i32, [_P, _CP, _i32, _i32, _i32, _i32, _f64, _f64, _f64, _f64, _P, _P, _P, _i64, _P,
+                                    _P, _P, _P, _P, _P]),
+    "segk_fbgmm_assign": (_i32, [_P, _CP, _FP, _i32, _i32, _f64, _P, _P, _P, _P, _i64, _P, _P]),
     "segk_logsumexp": (_f64, [_P, _i64]),
     "segk_draw": (_i32, [_P, _i64, _f64]),
     "segk_sum_doubles": (_f64, [_P, _i64]),

@@ -1,0 +1,761 @@
+// segk_fbgmm.hip -- gfx950 kernels of the FBGMM (collapsed finite Bayesian GMM) Gibbs path,
+// sequential-exact mode: everything one utterance needs, in the reference's order, in fp64.
+//
+//   k_fbgmm_update      A11  del_item / add_item / del_component for fixed-variance and diagonal
+//                            components (gaussian_components_fixedvar.py:153-221, _diag.py:162-213)
+//   k_fbgmm_score       A2/A3/A4  log_marg_i(e) for a list of embeddings (fbgmm.py:256-285)
+//   k_unigram_segment   A5/A6/A7  vec building + forward filtering / backward sampling (or Viterbi)
+//                            for one utterance, uniforms taken from a device-resident stream
+//   k_fbgmm_assign      A10  gibbs_sample_inside_loop_i / map_assign_i for the new segments of one
+//                            utterance, sequentially, statistics updated between segments
+//
+// Tolerance contract (BASELINE north_star): log-likelihoods within 1e-4 relative of the
+// reference; everything here is fp64 with device libm, which lands at ~1e-15.
+#include <stdlib.h>
+
+#include "segk_internal.h"
+
+#define NEG_INF_D (-__builtin_huge_val())
+#define LOG_2PI 1.8378770664093453
+#define LOG_PI 1.1447298858494002
+
+// ---------------------------------------------------------------------------------------
+// block-wide helpers (blockDim.x a power of two <= 1024, `red` has blockDim.x doubles)
+// ---------------------------------------------------------------------------------------
+__device__ double block_sum(double v, double *red)
+{
+    const int tid = threadIdx.x, nt = blockDim.x;
+    __syncthreads();
+    red[tid] = v;
+    __syncthreads();
+    for (int o = nt >> 1; o > 0; o >>= 1) {
+        if (tid < o) red[tid] += red[tid + o];
+        __syncthreads();
+    }
+    double r = red[0];
+    __syncthreads();
+    return r;
+}
+
+__device__ double block_max(double v, double *red)
+{
+    const int tid = threadIdx.x, nt = blockDim.x;
+    __syncthreads();
+    red[tid] = v;
+    __syncthreads();
+    for (int o = nt >> 1; o > 0; o >>= 1) {
+        if (tid < o) red[tid] = red[tid + o] > red[tid] ? red[tid + o] : red[tid];
+        __syncthreads();
+    }
+    double r = red[0];
+    __syncthreads();
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------
+// derived statistics of component k (all threads of the block cooperate over D)
+//   fixed: precision_pred = P_N * P / (P_N + P); log_prod = sum log(precision_pred)   (:317-325)
+//   diag : var = (k_N+1)/(k_N v_N) (S_N_partial - k_N m_N^2); log_prod_vars = sum log var;
+//          inv_vars = 1/var                                                            (:332-345)
+// ---------------------------------------------------------------------------------------
+__device__ void fb_update_derived(const segk_fbgmm &f, int D, int k, double *red)
+{
+    const int tid = threadIdx.x, nt = blockDim.x;
+    double part = 0.0;
+    if (f.cov_type == 0) {
+        for (int d = tid; d < D; d += nt) {
+            double pn = f.stat_b[(int64_t)k * D + d], p = f.prior_a[d];
+            double pp = pn * p / (pn + p);
+            f.pred[(int64_t)k * D + d] = pp;
+            part += log(pp);
+        }
+    } else {
+        const double cnt = (double)f.counts[k];
+        const double k_N = f.k_0 + cnt, v_N = f.v_0 + cnt;
+        for (int d = tid; d < D; d += nt) {
+            double m_N = f.stat_a[(int64_t)k * D + d] / k_N;
+            double var = (k_N + 1.) / (k_N * v_N) * (f.stat_b[(int64_t)k * D + d] - k_N * (m_N * m_N));
+            f.pred[(int64_t)k * D + d] = 1. / var;
+            part += log(var);
+        }
+    }
+    double tot = block_sum(part, red);
+    if (tid == 0) f.log_prod[k] = tot;
+    __syncthreads();
+}
+
+template <typename XT>
+__device__ void fb_del_component(const segk_corpus &c, const segk_fbgmm &f, int k, int *shK)
+{
+    // *shK already decremented
+    const int tid = threadIdx.x, nt = blockDim.x, D = c.D;
+    const int K = *shK;
+    if (k != K) {
+        for (int d = tid; d < D; d += nt) {
+            f.stat_a[(int64_t)k * D + d] = f.stat_a[(int64_t)K * D + d];
+            f.stat_b[(int64_t)k * D + d] = f.stat_b[(int64_t)K * D + d];
+            f.pred[(int64_t)k * D + d] = f.pred[(int64_t)K * D + d];
+        }
+        for (int64_t e = tid; e < c.n_emb; e += nt)
+            if (f.assignments[e] == K) f.assignments[e] = k;
+    }
+    __syncthreads();
+    for (int d = tid; d < D; d += nt) {
+        f.stat_a[(int64_t)K * D + d] = 0.0;
+        f.stat_b[(int64_t)K * D + d] = 0.0;
+        f.pred[(int64_t)K * D + d] = 0.0;
+    }
+    if (tid == 0) {
+        if (k != K) {
+            f.log_prod[k] = f.log_prod[K];
+            f.counts[k] = f.counts[K];
+        }
+        f.log_prod[K] = 0.0;
+        f.counts[K] = 0;
+    }
+    __syncthreads();
+}
+
+// x and x^2 as the reference sees them: X[i] is widened to double; the diagonal model caches
+// np.square(X) in the dtype of X (gaussian_components_diag.py:125) -> float32 square for f32 data
+template <typename XT>
+__device__ __forceinline__ double x_sq(XT x)
+{
+    XT q = x * x;
+    return (double)q;
+}
+
+template <typename XT>
+__device__ void fb_add_item(const segk_corpus &c, const segk_fbgmm &f, int64_t e, int k_in, int *shK, int *sh_i,
+                            double *red)
+{
+    const int tid = threadIdx.x, nt = blockDim.x, D = c.D;
+    const XT *X = (const XT *)c.X;
+    if (tid == 0) {
+        *sh_i = (k_in == *shK) ? 1 : 0;
+        if (k_in == *shK) *shK = *shK + 1;
+    }
+    __syncthreads();
+    const int is_new = *sh_i;
+    const int k = k_in;
+    for (int d = tid; d < D; d += nt) {
+        const double x = (double)X[e * c.ldx + d];
+        double a = f.stat_a[(int64_t)k * D + d], b = f.stat_b[(int64_t)k * D + d];
+        if (f.cov_type == 0) {
+            if (is_new) { a = f.prior_c[d] * f.prior_b[d]; b = f.prior_c[d]; }     // precision_0*mu_0, precision_0
+            a += f.prior_a[d] * x;
+            b += f.prior_a[d];
+        } else {
+            if (is_new) { a = f.k_0 * f.prior_b[d]; b = f.prior_a[d] + f.k_0 * (f.prior_b[d] * f.prior_b[d]); }
+            a += x;
+            b += x_sq<XT>(X[e * c.ldx + d]);
+        }
+        f.stat_a[(int64_t)k * D + d] = a;
+        f.stat_b[(int64_t)k * D + d] = b;
+    }
+    if (tid == 0) {
+        f.counts[k] += 1;
+        f.assignments[e] = k;
+    }
+    __syncthreads();
+    fb_update_derived(f, D, k, red);
+}
+
+template <typename XT>
+__device__ void fb_del_item(const segk_corpus &c, const segk_fbgmm &f, int64_t e, int *shK, int *sh_i, double *red)
+{
+    const int tid = threadIdx.x, nt = blockDim.x, D = c.D;
+    const XT *X = (const XT *)c.X;
+    __shared__ int sh_cnt0;
+    if (tid == 0) {
+        int k = f.assignments[e];
+        if (k != -1) {
+            f.counts[k] -= 1;
+            f.assignments[e] = -1;
+            sh_cnt0 = (f.counts[k] == 0) ? 1 : 0;
+        }
+        *sh_i = k;
+    }
+    __syncthreads();
+    const int k = *sh_i;
+    if (k == -1) return;
+    if (sh_cnt0) {
+        if (tid == 0) *shK = *shK - 1;
+        __syncthreads();
+        fb_del_component<XT>(c, f, k, shK);
+    } else {
+        for (int d = tid; d < D; d += nt) {
+            const double x = (double)X[e * c.ldx + d];
+            if (f.cov_type == 0) {
+                f.stat_a[(int64_t)k * D + d] -= f.prior_a[d] * x;
+                f.stat_b[(int64_t)k * D + d] -= f.prior_a[d];
+            } else {
+                f.stat_a[(int64_t)k * D + d] -= x;
+                f.stat_b[(int64_t)k * D + d] -= x_sq<XT>(X[e * c.ldx + d]);
+            }
+        }
+        __syncthreads();
+        fb_update_derived(f, D, k, red);
+    }
+}
+
+// op 0: delete the OLD segments of utterance `utt` (listed from the boundaries + vec_ids)
+// op 1: add_item(item, k_item)   op 2: del_item(item)   op 4: del_component(k_item)
+template <typename XT>
+__global__ void k_fbgmm_update(segk_corpus c, segk_fbgmm f, int op, int utt, int64_t item, int k_item,
+                               const uint8_t *boundaries)
+{
+    __shared__ int shK, sh_i;
+    __shared__ double red[256];
+    if (threadIdx.x == 0) shK = *f.K;
+    __syncthreads();
+    if (op == 0) {
+        const int N = c.lengths[utt];
+        const int64_t triMax = (int64_t)c.N_max * (c.N_max + 1) / 2;
+        const int32_t *vid = c.vec_ids + (int64_t)utt * triMax;
+        const uint8_t *bnd = boundaries + (int64_t)utt * c.N_max;
+        int jp = 0;
+        for (int j = 0; j < N; j++) {
+            if (bnd[j]) {               // uniform: every thread reads the same byte
+                int id = vid[(j + 1) * j / 2 + jp];
+                jp = j + 1;
+                if (id >= 0) fb_del_item<XT>(c, f, id, &shK, &sh_i, red);
+            }
+        }
+    } else if (op == 1) {
+        fb_add_item<XT>(c, f, item, k_item, &shK, &sh_i, red);
+    } else if (op == 2) {
+        fb_del_item<XT>(c, f, item, &shK, &sh_i, red);
+    } else if (op == 4) {
+        if (threadIdx.x == 0) shK = shK - 1;
+        __syncthreads();
+        fb_del_component<XT>(c, f, k_item, &shK);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *f.K = shK;
+}
+
+// ---------------------------------------------------------------------------------------
+// per-component log predictive of embedding x (A2/A3) and the prior predictive
+// ---------------------------------------------------------------------------------------
+template <typename XT>
+__device__ double fb_log_post_pred_k(const segk_fbgmm &f, int D, int k, const XT *x)
+{
+    if (f.cov_type == 0) {      // gaussian_components_fixedvar.py:242-253
+        double s = 0.0;
+        for (int d = 0; d < D; d++) {
+            double mu = f.stat_a[(int64_t)k * D + d] / f.stat_b[(int64_t)k * D + d];
+            double delta = mu - (double)x[d];
+            s += (delta * delta) * f.pred[(int64_t)k * D + d];
+        }
+        return -0.5 * (double)D * LOG_2PI + 0.5 * f.log_prod[k] - 0.5 * s;
+    } else {                    // gaussian_components_diag.py:237-259
+        const double cnt = (double)f.counts[k];
+        const double k_N = f.k_0 + cnt, v_N = f.v_0 + cnt;
+        double s = 0.0;
+        for (int d = 0; d < D; d++) {
+            double m = f.stat_a[(int64_t)k * D + d] / k_N;
+            double delta = m - (double)x[d];
+            s += log(1. + (delta * delta) * f.pred[(int64_t)k * D + d] * (1. / v_N));
+        }
+        return (double)D * (lgamma((v_N + 1.) / 2.) - lgamma(v_N / 2.) - 0.5 * log(v_N) - 0.5 * LOG_PI)
+               - 0.5 * f.log_prod[k] - (v_N + 1.) / 2. * s;
+    }
+}
+
+template <typename XT>
+__device__ double fb_log_prior(const segk_fbgmm &f, int D, const XT *x)
+{
+    if (f.cov_type == 0) {      // gaussian_components_fixedvar.py:224-231 (precision_0 used as the predictive precision)
+        double slog = 0.0, ss = 0.0;
+        for (int d = 0; d < D; d++) {
+            slog += log(f.prior_c[d]);
+            double delta = (double)x[d] - f.prior_b[d];
+            ss += delta * delta * f.prior_c[d];
+        }
+        return -0.5 * (double)D * LOG_2PI + 0.5 * slog - 0.5 * ss;
+    } else {                    // gaussian_components_diag.py:215-222
+        double lpv = 0.0, s = 0.0;
+        for (int d = 0; d < D; d++) {
+            double var = (f.k_0 + 1.) / (f.k_0 * f.v_0) * f.prior_a[d];
+            lpv += log(var);
+            double delta = (double)x[d] - f.prior_b[d];
+            s += log(1. + 1. / f.v_0 * (delta * delta) * (1. / var));
+        }
+        return (double)D * (lgamma((f.v_0 + 1.) / 2.) - lgamma(f.v_0 / 2.) - 0.5 * log(f.v_0) - 0.5 * LOG_PI)
+               - 0.5 * lpv - (f.v_0 + 1.) / 2. * s;
+    }
+}
+
+// logits z[k], k < K_max, of embedding `e` into LDS (fbgmm.py:268-284 / :436-445).
+// with_norm: subtract lms*log(sum counts + alpha) (log_marg_i) ; with_lms 0 -> map_assign_i
+template <typename XT>
+__device__ void fb_logits(const segk_corpus &c, const segk_fbgmm &f, int64_t e, int with_norm, int with_lms, XT *xrow,
+                          double *z, double *red)
+{
+    const int tid = threadIdx.x, nt = blockDim.x, D = c.D;
+    const XT *X = (const XT *)c.X;
+    const int K = *f.K;
+    __syncthreads();
+    for (int d = tid; d < D; d += nt) xrow[d] = X[e * c.ldx + d];
+    double csum = 0.0;
+    for (int k = tid; k < f.K_max; k += nt) csum += (double)f.counts[k];
+    const double total = block_sum(csum, red);          // exact: integer-valued
+    const double denom = with_norm ? log(total + f.alpha) : 0.0;
+    const double lms = with_lms ? f.lms : 1.0;
+    double lprior = 0.0;
+    bool have_prior = false;
+    for (int k = tid; k < f.K_max; k += nt) {
+        double v = lms * (log(f.alpha / (double)f.K_max + (double)f.counts[k]) - denom);
+        if (k < K) v += fb_log_post_pred_k<XT>(f, D, k, xrow);
+        else {
+            if (!have_prior) { lprior = fb_log_prior<XT>(f, D, xrow); have_prior = true; }
+            v += lprior;
+        }
+        z[k] = v;
+    }
+    __syncthreads();
+}
+
+// A4: out[ids[r]] = log_marg_i(ids[r]) for r < n (entries -1 skipped).  One workgroup per row.
+template <typename XT>
+__global__ void k_fbgmm_score(segk_corpus c, segk_fbgmm f, const int32_t *ids, int64_t row0, double *out)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *z = (double *)smem;                      // [K_max]
+    double *red = z + f.K_max;                       // [nt]
+    XT *xrow = (XT *)(red + blockDim.x);             // [D]
+    const int64_t e = ids ? (int64_t)ids[blockIdx.x] : row0 + blockIdx.x;
+    if (e < 0) return;
+    fb_logits<XT>(c, f, e, 1, 1, xrow, z, red);
+    double mx = NEG_INF_D;
+    for (int k = threadIdx.x; k < f.K_max; k += blockDim.x) mx = z[k] > mx ? z[k] : mx;
+    mx = block_max(mx, red);
+    double s = 0.0;
+    for (int k = threadIdx.x; k < f.K_max; k += blockDim.x) s += exp(z[k] - mx);
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) out[e] = log(s) + mx;
+}
+
+// A2/A3 vector API: out[k] = log_post_pred_k(row) for k < K, 0 for K <= k < K_max,
+// out[K_max] = log_prior(row)
+template <typename XT>
+__global__ void k_fbgmm_pred_vector(segk_corpus c, segk_fbgmm f, int64_t row, double *out)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const XT *x = (const XT *)c.X + row * c.ldx;
+    const int K = *f.K;
+    if (k < K) out[k] = fb_log_post_pred_k<XT>(f, c.D, k, x);
+    else if (k < f.K_max) out[k] = 0.0;
+    else if (k == f.K_max) out[k] = fb_log_prior<XT>(f, c.D, x);
+}
+
+__device__ double fb_logsumexp_seq(const double *a, int n)     // _cython_utils.pyx:13-25
+{
+    double mx = a[0], s = 0.0;
+    for (int j = 1; j < n; j++)
+        if (a[j] > mx) mx = a[j];
+    for (int j = 0; j < n; j++) s += exp(a[j] - mx);
+    return log(s) + mx;
+}
+
+// ---------------------------------------------------------------------------------------
+// A5 + A6/A7 for one utterance: vec from the per-embedding scores, DP, new boundaries.
+// Single thread does the DP (N <= N_max landmarks, fp64, reference order); uniforms are taken
+// from ustream[*ucursor ...] and the cursor advanced (one per backward-sampling step).
+// ---------------------------------------------------------------------------------------
+__global__ void k_unigram_segment(segk_corpus c, int utt, int viterbi, int n_min, int n_max, double wip,
+                                  double time_power_term, double log_p_continue, double anneal_temp,
+                                  const double *score, const double *ustream, int64_t *ucursor, int64_t ucap,
+                                  uint8_t *boundaries, int32_t *new_tok, int32_t *n_new, double *out_logprob,
+                                  int32_t *status)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    (void)n_min;
+    const int N = c.lengths[utt];
+    const int tri = N * (N + 1) / 2;
+    const int64_t triMax = (int64_t)c.N_max * (c.N_max + 1) / 2;
+    const int32_t *vid = c.vec_ids + (int64_t)utt * triMax;
+    const double *dur = c.durations + (int64_t)utt * triMax;
+    double *vec = (double *)smem;           // [tri]
+    double *a = vec + triMax;               // [N]
+    double *w = a + c.N_max;                // [N+1]
+    double *pr = w + c.N_max + 1;           // [N+1]
+    for (int j = threadIdx.x; j < tri; j += blockDim.x) {       // unigram_acoustic_wordseg.py:474-511
+        int id = vid[j];
+        double v = NEG_INF_D;
+        if (id >= 0) {
+            double dd = dur[j];
+            v = isnan(dd) ? NEG_INF_D : score[id] * pow(dd, time_power_term);
+        }
+        vec[j] = v + wip;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    uint8_t *bnd = boundaries + (int64_t)utt * c.N_max;
+    for (int j = 0; j < N; j++) { a[j] = 1.0; bnd[j] = 0; }
+    bnd[N - 1] = 1;
+    a[0] = 0.0;
+    int64_t cur = *ucursor;
+    int i = 0;
+    for (int t = 1; t < N; t++) {
+        int lo = (n_max == 0 || t - n_max < 0) ? 0 : t - n_max;
+        int n = t - lo;
+        bool all_inf = true;
+        double best = NEG_INF_D;
+        for (int s = lo; s < t; s++) {
+            double v = vec[i + s] + a[s];
+            w[s - lo] = v;
+            if (v != NEG_INF_D) all_inf = false;
+            if (v > best) best = v;
+        }
+        if (viterbi) a[t] = best;
+        else a[t] = all_inf ? NEG_INF_D : fb_logsumexp_seq(w, n) + log_p_continue;
+        i += t;
+    }
+    int t = N, lo = 0;
+    double total = 0.0;
+    for (;;) {
+        i = (t - 1) * t / 2;
+        lo = (n_max == 0 || t - n_max < 0) ? 0 : t - n_max;
+        bool all_inf = true;
+        for (int s = lo; s < t; s++)
+            if (vec[i + s] + a[s] != NEG_INF_D) { all_inf = false; break; }
+        if (all_inf) {
+            while (all_inf) {
+                t = t - 1;
+                if (t == 0) break;
+                i = (t - 1) * t / 2;
+                lo = (n_max == 0 || t - n_max < 0) ? 0 : t - n_max;
+                all_inf = true;
+                for (int s = lo; s < t; s++)
+                    if (vec[i + s] + a[s] != NEG_INF_D) { all_inf = false; break; }
+            }
+            bnd[(t - 1 + N) % N] = 1;
+        }
+        int k = 1, n = 1;
+        if (t > 0) {
+            n = t - lo;
+            for (int s = lo; s < t; s++) w[s - lo] = vec[i + s] + a[s];
+        } else {
+            w[0] = NEG_INF_D;
+        }
+        double lse = fb_logsumexp_seq(w, n);
+        if (viterbi) {
+            if (t > 0) {
+                double best = 0.0;
+                bool first = true;
+                for (int s = t - 1; s >= lo; s--) {
+                    double q = exp(w[s - lo] - lse);
+                    if (first || q > best) { best = q; k = t - s; first = false; }
+                }
+            }
+        } else {
+            if (anneal_temp != 1.0) {
+                for (int j = 0; j < n; j++) pr[j] = w[n - 1 - j] - lse;
+                double inv = 1. / anneal_temp;
+                for (int j = 0; j < n; j++) w[j] = inv * pr[j];
+                double lse2 = fb_logsumexp_seq(w, n);
+                for (int j = 0; j < n; j++) pr[j] = exp(w[j] - lse2);
+            } else {
+                for (int j = 0; j < n; j++) pr[j] = exp(w[n - 1 - j] - lse);
+            }
+            double uu = (cur < ucap) ? ustream[cur] : 0.5;
+            if (cur >= ucap) atomicOr(status, 8);
+            cur++;
+            int kk = n - 1;
+            for (int j = 0; j < n; j++) {
+                uu = uu - pr[j];
+                if (uu < 0) { kk = j; break; }
+            }
+            k = kk + 1;
+        }
+        int idx = i + t - k;
+        if (idx < 0) idx += tri;
+        total += vec[idx];
+        if (t - k - 1 < 0) break;
+        bnd[t - k - 1] = 1;
+        t = t - k;
+    }
+    if (!viterbi && total == NEG_INF_D) atomicOr(status, 16);      // unigram_acoustic_wordseg.py:753
+    *ucursor = cur;
+    out_logprob[utt] = total;
+    int nn = 0, jp = 0;
+    for (int j = 0; j < N; j++)
+        if (bnd[j]) {
+            int id = vid[(j + 1) * j / 2 + jp];
+            if (id >= 0) new_tok[(int64_t)utt * c.N_max + nn++] = id;      // -1 skipped (:340-342)
+            jp = j + 1;
+        }
+    n_new[utt] = nn;
+}
+
+// ---------------------------------------------------------------------------------------
+// A10 for the new segments of one utterance, in order (fbgmm.py:422-494).  One workgroup.
+// ---------------------------------------------------------------------------------------
+template <typename XT>
+__global__ void k_fbgmm_assign(segk_corpus c, segk_fbgmm f, int utt, int map_assign, double anneal_temp,
+                               const int32_t *new_tok, const int32_t *n_new, const double *ustream,
+                               int64_t *ucursor, int64_t ucap, int32_t *status)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *z = (double *)smem;                      // [K_max]
+    double *red = z + f.K_max;                       // [nt]
+    XT *xrow = (XT *)(red + blockDim.x);             // [D]
+    __shared__ int shK, sh_i, sh_k;
+    if (threadIdx.x == 0) shK = *f.K;
+    __syncthreads();
+    const int nn = n_new[utt];
+    for (int t = 0; t < nn; t++) {
+        const int64_t e = new_tok[(int64_t)utt * c.N_max + t];
+        if (threadIdx.x == 0) *f.K = shK;            // fb_logits reads K from memory
+        __syncthreads();
+        fb_logits<XT>(c, f, e, 0, map_assign ? 0 : 1, xrow, z, red);
+        // scipy logsumexp: max-shift, sum, log
+        double mx = NEG_INF_D;
+        for (int k = threadIdx.x; k < f.K_max; k += blockDim.x) mx = z[k] > mx ? z[k] : mx;
+        mx = block_max(mx, red);
+        double s = 0.0;
+        for (int k = threadIdx.x; k < f.K_max; k += blockDim.x) s += exp(z[k] - mx);
+        s = block_sum(s, red);
+        double lse = log(s) + mx;
+        if (!map_assign && anneal_temp != 1.0) {     // :446-449
+            for (int k = threadIdx.x; k < f.K_max; k += blockDim.x) z[k] = (1. / anneal_temp) * (z[k] - lse);
+            __syncthreads();
+            double mx2 = NEG_INF_D;
+            for (int k = threadIdx.x; k < f.K_max; k += blockDim.x) mx2 = z[k] > mx2 ? z[k] : mx2;
+            mx2 = block_max(mx2, red);
+            double s2 = 0.0;
+            for (int k = threadIdx.x; k < f.K_max; k += blockDim.x) s2 += exp(z[k] - mx2);
+            s2 = block_sum(s2, red);
+            lse = log(s2) + mx2;
+        }
+        for (int k = threadIdx.x; k < f.K_max; k += blockDim.x) z[k] = exp(z[k] - lse);      // prob_z
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int k;
+            if (map_assign) {                         // np.argmax(prob_z): first maximum
+                k = 0;
+                for (int q = 1; q < f.K_max; q++)
+                    if (z[q] > z[k]) k = q;
+            } else {                                  // utils.draw (utils.py:10-21), forward order
+                int64_t cur = *ucursor;
+                double uu = (cur < ucap) ? ustream[cur] : 0.5;
+                if (cur >= ucap) atomicOr(status, 8);
+                *ucursor = cur + 1;
+                k = f.K_max - 1;
+                for (int q = 0; q < f.K_max; q++) {
+                    uu = uu - z[q];
+                    if (uu < 0) { k = q; break; }
+                }
+            }
+            if (k > shK) k = shK;                     // :459-460
+            sh_k = k;
+        }
+        __syncthreads();
+        fb_add_item<XT>(c, f, e, sh_k, &shK, &sh_i, red);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *f.K = shK;
+}
+
+// ---------------------------------------------------------------------------------------
+// Components __init__ (fixedvar:110-120 / diag:114-120): add_item(i, k) for k ascending and i
+// ascending within k.  One wave per component scans `assignments`; statistics are accumulated
+// in exactly that order (including the repeated `+= precision`), derived values once at the end.
+// ---------------------------------------------------------------------------------------
+template <typename XT>
+__global__ void k_fbgmm_init_stats(segk_corpus c, segk_fbgmm f)
+{
+    const int k = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (k >= f.K_max) return;
+    const int D = c.D;
+    const XT *X = (const XT *)c.X;
+    int64_t cnt = 0;
+    double lp_part = 0.0;
+    for (int d0 = 0; d0 < D; d0 += 64) {
+        const int d = d0 + lane;
+        double a = 0.0, b = 0.0;
+        if (d < D) {
+            if (f.cov_type == 0) { a = f.prior_c[d] * f.prior_b[d]; b = f.prior_c[d]; }
+            else { a = f.k_0 * f.prior_b[d]; b = f.prior_a[d] + f.k_0 * (f.prior_b[d] * f.prior_b[d]); }
+        }
+        int64_t n = 0;
+        for (int64_t e0 = 0; e0 < c.n_emb; e0 += 64) {
+            int64_t e = e0 + lane;
+            int match = (e < c.n_emb) && (f.assignments[e] == k);
+            unsigned long long bal = __ballot(match);
+            while (bal) {
+                int src = __ffsll((long long)bal) - 1;
+                bal &= bal - 1;
+                int64_t ee = e0 + src;
+                n++;
+                if (d < D) {
+                    const double x = (double)X[ee * c.ldx + d];
+                    if (f.cov_type == 0) { a += f.prior_a[d] * x; b += f.prior_a[d]; }
+                    else { a += x; b += x_sq<XT>(X[ee * c.ldx + d]); }
+                }
+            }
+        }
+        cnt = n;
+        if (d < D) {
+            double pr = 0.0;
+            if (n > 0) {
+                if (f.cov_type == 0) {
+                    pr = b * f.prior_a[d] / (b + f.prior_a[d]);
+                    lp_part += log(pr);
+                } else {
+                    const double k_N = f.k_0 + (double)n, v_N = f.v_0 + (double)n;
+                    double m_N = a / k_N;
+                    double var = (k_N + 1.) / (k_N * v_N) * (b - k_N * (m_N * m_N));
+                    pr = 1. / var;
+                    lp_part += log(var);
+                }
+            } else { a = 0.0; b = 0.0; }
+            f.stat_a[(int64_t)k * D + d] = a;
+            f.stat_b[(int64_t)k * D + d] = b;
+            f.pred[(int64_t)k * D + d] = pr;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) lp_part += __shfl_xor(lp_part, o);
+    if (lane == 0) {
+        f.counts[k] = cnt;
+        f.log_prod[k] = cnt ? lp_part : 0.0;
+        if (cnt) atomicMax(f.K, k + 1);
+    }
+}
+
+// ======================================================================================
+// C ABI
+// ======================================================================================
+#define DISPATCH_XT(c, ...)                         \
+    do {                                            \
+        if ((c)->x_dtype == SEGK_F32) {             \
+            typedef float XT;                       \
+            __VA_ARGS__                             \
+        } else {                                    \
+            typedef double XT;                      \
+            __VA_ARGS__                             \
+        }                                           \
+    } while (0)
+
+static int check_fb(const segk_corpus *c, const segk_fbgmm *f)
+{
+    SEGK_REQUIRE(c && f, "NULL corpus / fbgmm");
+    SEGK_REQUIRE(f->cov_type == 0 || f->cov_type == 1, "cov_type must be 0 (fixed) or 1 (diag)");
+    SEGK_REQUIRE(f->K_max > 0 && c->D > 0, "sizes");
+    return SEGK_OK;
+}
+
+static size_t fb_lds(const segk_corpus *c, const segk_fbgmm *f, int nt)
+{
+    return (size_t)(f->K_max + nt) * sizeof(double) + (size_t)((c->D + 1) & ~1) * (c->x_dtype == SEGK_F32 ? 4 : 8);
+}
+
+extern "C" {
+
+int32_t segk_fbgmm_update(segk_ctx *ctx, const segk_corpus *c, segk_fbgmm *f, int32_t op, int32_t utt,
+                          int64_t item, int32_t k, const uint8_t *boundaries, void *stream)
+{
+    (void)ctx;
+    int rc = check_fb(c, f);
+    if (rc) return rc;
+    SEGK_REQUIRE(op == 0 || op == 1 || op == 2 || op == 4, "op");
+    DISPATCH_XT(c, hipLaunchKernelGGL(k_fbgmm_update<XT>, dim3(1), dim3(256), 0, (hipStream_t)stream, *c, *f, op, utt,
+                                       item, k, boundaries););
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+int32_t segk_fbgmm_init_stats(segk_ctx *ctx, const segk_corpus *c, segk_fbgmm *f, void *stream)
+{
+    (void)ctx;
+    int rc = check_fb(c, f);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    SEGK_CHECK_HIP(hipMemsetAsync(f->K, 0, sizeof(int32_t), st));
+    int64_t grid = ((int64_t)f->K_max + 3) / 4;
+    DISPATCH_XT(c, hipLaunchKernelGGL(k_fbgmm_init_stats<XT>, dim3((unsigned)grid), dim3(256), 0, st, *c, *f););
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+int32_t segk_fbgmm_score(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *f, const int32_t *ids,
+                         int64_t row0, int64_t n, double *out, void *stream)
+{
+    (void)ctx;
+    int rc = check_fb(c, f);
+    if (rc) return rc;
+    if (n <= 0) return SEGK_OK;
+    const int nt = 128;
+    size_t lds = fb_lds(c, f, nt);
+    SEGK_REQUIRE(lds <= 160 * 1024, "K_max too large for the LDS logits buffer");
+    DISPATCH_XT(c, {
+        if (lds > 48 * 1024)
+            SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_fbgmm_score<XT>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_fbgmm_score<XT>, dim3((unsigned)n), dim3(nt), lds, (hipStream_t)stream, *c, *f, ids, row0,
+                           out);
+    });
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+int32_t segk_fbgmm_pred_vector(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *f, int64_t row,
+                               double *out, void *stream)
+{
+    (void)ctx;
+    int rc = check_fb(c, f);
+    if (rc) return rc;
+    SEGK_REQUIRE(row >= 0 && row < c->n_emb, "row out of range");
+    DISPATCH_XT(c, hipLaunchKernelGGL(k_fbgmm_pred_vector<XT>, dim3((f->K_max + 1 + 127) / 128), dim3(128), 0,
+                                       (hipStream_t)stream, *c, *f, row, out););
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+int32_t segk_unigram_segment(segk_ctx *ctx, const segk_corpus *c, int32_t utt, int32_t viterbi,
+                             int32_t n_slices_min, int32_t n_slices_max, double wip, double time_power_term,
+                             double log_p_continue, double anneal_temp, const double *score,
+                             const double *ustream, int64_t *ucursor, int64_t ucap, uint8_t *boundaries,
+                             int32_t *new_tok, int32_t *n_new, double *out_logprob, int32_t *status, void *stream)
+{
+    (void)ctx;
+    SEGK_REQUIRE(c && utt >= 0 && utt < c->n_utt, "utterance");
+    SEGK_REQUIRE(n_slices_min == 0 || n_slices_min == 1, "n_slices_min must be 0 or 1");
+    const int64_t triMax = (int64_t)c->N_max * (c->N_max + 1) / 2;
+    size_t lds = (size_t)(triMax + 3 * c->N_max + 2) * sizeof(double);
+    SEGK_REQUIRE(lds <= 160 * 1024, "N_max too large for the LDS score vector");
+    if (lds > 48 * 1024)
+        SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_unigram_segment, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds));
+    hipLaunchKernelGGL(k_unigram_segment, dim3(1), dim3(128), lds, (hipStream_t)stream, *c, utt, viterbi, n_slices_min,
+                       n_slices_max, wip, time_power_term, log_p_continue, anneal_temp, score, ustream, ucursor, ucap,
+                       boundaries, new_tok, n_new, out_logprob, status);
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+int32_t segk_fbgmm_assign(segk_ctx *ctx, const segk_corpus *c, segk_fbgmm *f, int32_t utt, int32_t map_assign,
+                          double anneal_temp, const int32_t *new_tok, const int32_t *n_new,
+                          const double *ustream, int64_t *ucursor, int64_t ucap, int32_t *status, void *stream)
+{
+    (void)ctx;
+    int rc = check_fb(c, f);
+    if (rc) return rc;
+    const int nt = 256;
+    size_t lds = fb_lds(c, f, nt);
+    SEGK_REQUIRE(lds <= 160 * 1024, "K_max too large for the LDS logits buffer");
+    DISPATCH_XT(c, {
+        if (lds > 48 * 1024)
+            SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_fbgmm_assign<XT>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_fbgmm_assign<XT>, dim3(1), dim3(nt), lds, (hipStream_t)stream, *c, *f, utt, map_assign,
+                           anneal_temp, new_tok, n_new, ustream, ucursor, ucap, status);
+    });
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+}  // extern "C"

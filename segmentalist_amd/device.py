@@ -374,3 +374,122 @@ class KMeansBatchSweeper(object):
                                            ptr(dk.new_k), ptr(dk.n_new), ptr(dk.remap), ptr(dk.out_scalars),
                                            ptr(dk.status), st))
         dk.assign_stale = (pt.utt_lo, pt.utt_hi, pt.world)
+
+
+class DeviceFbgmm(object):
+    """Device image of FBGMM + its Gaussian components (fixed-variance or diagonal), see
+    include/segk.h `segk_fbgmm`."""
+
+    def __init__(self, corpus, cov_type, K_max, alpha, lms, prior_a, prior_b, prior_c, k_0, v_0, assignments):
+        torch = _torch()
+        dev = _dev()
+        self.corpus = corpus
+        c = corpus
+        self.K_max = int(K_max)
+        self.cov_type = int(cov_type)
+        f64 = torch.float64
+        self.prior_a = to_dev(prior_a, np.float64)
+        self.prior_b = to_dev(prior_b, np.float64)
+        self.prior_c = to_dev(prior_c if prior_c is not None else np.zeros(c.D), np.float64)
+        self.stat_a = torch.zeros((self.K_max, c.D), dtype=f64, device=dev)
+        self.stat_b = torch.zeros((self.K_max, c.D), dtype=f64, device=dev)
+        self.log_prod = torch.zeros(self.K_max, dtype=f64, device=dev)
+        self.pred = torch.zeros((self.K_max, c.D), dtype=f64, device=dev)
+        self.counts = torch.zeros(self.K_max, dtype=torch.int64, device=dev)
+        self.assignments = to_dev(assignments, np.int32)
+        self.K = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.f = _abi.FbgmmDev(
+            cov_type=self.cov_type, K_max=self.K_max, alpha=float(alpha), lms=float(lms), k_0=float(k_0),
+            v_0=float(v_0), prior_a=self.prior_a.data_ptr(), prior_b=self.prior_b.data_ptr(),
+            prior_c=self.prior_c.data_ptr(), stat_a=self.stat_a.data_ptr(), stat_b=self.stat_b.data_ptr(),
+            log_prod=self.log_prod.data_ptr(), pred=self.pred.data_ptr(), counts=self.counts.data_ptr(),
+            assignments=self.assignments.data_ptr(), K=self.K.data_ptr())
+        self.score = torch.zeros(c.n_emb, dtype=f64, device=dev)
+        self.status = torch.zeros(8, dtype=torch.int32, device=dev)
+        self._L = _abi.lib()
+        self._ctx = _abi.ctx()
+        # scratch for single-item calls
+        self._tok1 = torch.zeros(max(c.N_max, 1), dtype=torch.int32, device=dev)
+        self._n1 = torch.ones(1, dtype=torch.int32, device=dev)
+        self._u1 = torch.zeros(1, dtype=f64, device=dev)
+        self._cur1 = torch.zeros(1, dtype=torch.int64, device=dev)
+        check(self._L.segk_fbgmm_init_stats(self._ctx, self._cp(), C.byref(self.f), _abi.stream()))
+        if c.n_utt:
+            nu, nm = c.n_utt, c.N_max
+            self.new_tok = torch.zeros((nu, nm), dtype=torch.int32, device=dev)
+            self.n_new = torch.zeros(nu, dtype=torch.int32, device=dev)
+            self.out_logprob = torch.zeros(nu, dtype=f64, device=dev)
+            self.ucursor = torch.zeros(1, dtype=torch.int64, device=dev)
+            self.ustream = torch.zeros(1, dtype=f64, device=dev)
+
+    def _cp(self):
+        return C.byref(self.corpus.c)
+
+    def set_lms_alpha(self, alpha, lms):
+        self.f.alpha, self.f.lms = float(alpha), float(lms)
+
+    def update(self, op, utt=0, item=0, k=0, boundaries=None):
+        check(self._L.segk_fbgmm_update(self._ctx, self._cp(), C.byref(self.f), int(op), int(utt), int(item),
+                                        int(k), ptr(boundaries), _abi.stream()))
+
+    def score_rows(self, ids_ptr=None, row0=0, n=None):
+        n = self.corpus.n_emb - row0 if n is None else n
+        p = C.c_void_p(ids_ptr) if ids_ptr is not None else None
+        check(self._L.segk_fbgmm_score(self._ctx, self._cp(), C.byref(self.f), p, int(row0), int(n),
+                                       ptr(self.score), _abi.stream()))
+
+    def log_marg_rows(self, ids):
+        """log_marg_i for a list of rows -> numpy float64."""
+        ids_t = to_dev(ids, np.int32)
+        check(self._L.segk_fbgmm_score(self._ctx, self._cp(), C.byref(self.f), ptr(ids_t), 0, ids_t.numel(),
+                                       ptr(self.score), _abi.stream()))
+        return self.score[ids_t.long()].cpu().numpy()
+
+    def pred_vector(self, row):
+        """(log_post_pred(row)[:K], log_prior(row)) evaluated on the device."""
+        torch = _torch()
+        out = torch.zeros(self.K_max + 1, dtype=torch.float64, device=self.stat_a.device)
+        check(self._L.segk_fbgmm_pred_vector(self._ctx, self._cp(), C.byref(self.f), int(row), ptr(out),
+                                             _abi.stream()))
+        o = out.cpu().numpy()
+        return o[:int(self.K.item())].copy(), float(o[self.K_max])
+
+    def assign_item(self, i, u, anneal_temp=1.0, map_assign=False):
+        """gibbs_sample_inside_loop_i / map_assign_i for one row with the uniform `u`."""
+        self._tok1[0] = int(i)
+        self._u1[0] = float(u)
+        self._cur1.zero_()
+        check(self._L.segk_fbgmm_assign(self._ctx, self._cp(), C.byref(self.f), 0, 1 if map_assign else 0,
+                                        float(anneal_temp), ptr(self._tok1), ptr(self._n1), ptr(self._u1),
+                                        ptr(self._cur1), 1, ptr(self.status), _abi.stream()))
+
+    def set_uniform_stream(self, u):
+        self.ustream = to_dev(u, np.float64)
+        self.ucursor.zero_()
+
+    def gibbs_utt(self, boundaries, i, viterbi, n_slices_min, n_slices_max, wip, time_power_term,
+                  log_p_continue, anneal_temp_fb, anneal_temp_am):
+        """gibbs_sample_i (unigram_acoustic_wordseg.py:252-360) for utterance i, enqueued
+        asynchronously: remove its segments, score its spans, sample boundaries, assign."""
+        c = self.corpus
+        L, ctx, cp, fp, st = self._L, self._ctx, self._cp(), C.byref(self.f), _abi.stream()
+        N = int(c.lengths_np[i])
+        tri_i = N * (N + 1) // 2
+        check(L.segk_fbgmm_update(ctx, cp, fp, 0, int(i), 0, 0, ptr(boundaries), st))
+        check(L.segk_fbgmm_score(ctx, cp, fp, C.c_void_p(c.vec_ids.data_ptr() + 4 * i * c.tri), 0, tri_i,
+                                 ptr(self.score), st))
+        check(L.segk_unigram_segment(ctx, cp, int(i), 1 if viterbi else 0, int(n_slices_min), int(n_slices_max),
+                                     float(wip), float(time_power_term), float(log_p_continue),
+                                     float(anneal_temp_fb), ptr(self.score), ptr(self.ustream), ptr(self.ucursor),
+                                     self.ustream.numel(), ptr(boundaries), ptr(self.new_tok), ptr(self.n_new),
+                                     ptr(self.out_logprob), ptr(self.status), st))
+        check(L.segk_fbgmm_assign(ctx, cp, fp, int(i), 1 if viterbi else 0, float(anneal_temp_am),
+                                  ptr(self.new_tok), ptr(self.n_new), ptr(self.ustream), ptr(self.ucursor),
+                                  self.ustream.numel(), ptr(self.status), st))
+
+    def check_status(self):
+        st = int(self.status[0].item())
+        if st & 8:
+            raise SegkError("uniform stream exhausted")
+        if st & 16:
+            raise AssertionError("forward_backward: log_prob == -inf (unigram_acoustic_wordseg.py:753)")

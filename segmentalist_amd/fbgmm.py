@@ -1,0 +1,77 @@
+"""
+Drop-in for segmentalist/fbgmm.py: finite Bayesian Gaussian mixture model, device backed.
+"""
+import logging
+import random
+
+import numpy as np
+from scipy.special import gammaln
+
+from .gaussian_components_diag import GaussianComponentsDiag
+from .gaussian_components_fixedvar import GaussianComponentsFixedVar
+from .kmeans import _consecutive
+
+logger = logging.getLogger(__name__)
+
+
+class FBGMM(object):
+    def __init__(self, X, prior, alpha, K, assignments="rand", covariance_type="full", lms=1.0, _corpus=None):
+        self.alpha = alpha
+        self.prior = prior
+        self.covariance_type = covariance_type
+        self.lms = lms
+        self._corpus = _corpus
+        self.setup_components(K, assignments, X)
+
+    def setup_components(self, K, assignments="rand", X=None):
+        """fbgmm.py:93-137."""
+        if X is None:
+            assert hasattr(self, "components")
+            X = self.components.X
+        N, D = X.shape
+        if isinstance(assignments, str) and assignments == "rand":
+            assignments = np.random.randint(0, K, N)
+        elif isinstance(assignments, str) and assignments == "each-in-own":
+            assignments = np.arange(N)
+        assignments = _consecutive(np.asarray(assignments))
+        kw = dict(_corpus=self._corpus, _alpha=self.alpha, _lms=self.lms)
+        if self.covariance_type == "diag":
+            self.components = GaussianComponentsDiag(X, self.prior, assignments, K_max=K, **kw)
+        elif self.covariance_type == "fixed":
+            self.components = GaussianComponentsFixedVar(X, self.prior, assignments, K_max=K, **kw)
+        elif self.covariance_type == "full":
+            raise NotImplementedError(
+                "full-covariance components are outside the accelerated hot path (SURVEY.md section 2, #8)")
+        else:
+            assert False, "Invalid covariance type."
+
+    # record metrics (host, from device snapshots) ------------------------------------------------
+    def log_prob_z(self):
+        """fbgmm.py:208-225."""
+        counts = self.components.counts
+        K_max = self.components.K_max
+        return (gammaln(self.alpha) - gammaln(self.alpha + np.sum(counts))
+                + np.sum(gammaln(counts + float(self.alpha) / K_max) - gammaln(self.alpha / K_max)))
+
+    def log_prob_X_given_z(self):
+        return self.components.log_marg()
+
+    def log_marg(self):
+        return self.log_prob_z() + self.log_prob_X_given_z()
+
+    # hot path --------------------------------------------------------------------------------------
+    def log_marg_i(self, i):
+        """fbgmm.py:256-285 (A4), on the device."""
+        assert i != -1
+        return float(self.components.dev.log_marg_rows([i])[0])
+
+    def gibbs_sample_inside_loop_i(self, i, anneal_temp=1):
+        """fbgmm.py:422-463 (A10); consumes one random.random() like the reference."""
+        self.components.dev.assign_item(i, random.random(), anneal_temp, map_assign=False)
+
+    def map_assign_i(self, i):
+        """fbgmm.py:465-494."""
+        self.components.dev.assign_item(i, 0.0, 1.0, map_assign=True)
+
+    def get_n_assigned(self):
+        return int(np.count_nonzero(self.components.assignments != -1))

