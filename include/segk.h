@@ -101,31 +101,40 @@ int32_t segk_kmeans_init_stats(segk_ctx *ctx, const segk_corpus *c, segk_kmeans 
  * wholesale change of the means. */
 int32_t segk_kmeans_prepare(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m, void *stream);
 
-/* A1 (filter stage) -- KMeansComponents.neg_sqrd_norm / max_ / argmax_neg_sqrd_norm_i
- * kmeans_components.py:225-232, called per embedding from get_vec_embed_neg_len_sqrd_norms
- * kmeans_acoustic_wordseg.py:334-351.  fp32 MFMA contraction of rows `ids[0..n)` of X32
- * (rows row0..row0+n-1 when ids == NULL; entries of ids equal to -1 are skipped)
- * against all K_max means.  For every row e processed, the component with the largest
- * f[k] = x_e.m_k - |m_k|^2/2 and the two largest values of f are written at index e:
- *   cand_k [dev] int32 [n_emb], cand_f [dev] float [n_emb, 2],
- *   cand_s [dev] float [n_emb]: the winner's score in REFERENCE arithmetic (float32 data with
- *   8 <= D <= 128: fused in the kernel epilogue from the register-resident row), else NaN.
- * These are CANDIDATES: the reference-arithmetic score is recomputed from them by
- * segk_kmeans_segment / segk_kmeans_exact_max (bit-exact contract).           */
-int32_t segk_kmeans_score(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m,
-                          const int32_t *ids, int64_t row0, int64_t n,
-                          int32_t *cand_k, float *cand_f, float *cand_s, void *stream);
+/* Candidate buffers of the A1 stage, indexed by embedding row (caller-owned, n_emb entries). */
+typedef struct segk_cand {
+    int32_t *k;      /* [dev] [n_emb]    argmax component                                       */
+    float *f;        /* [dev] [n_emb, 2] the two largest values of the fp32 filter              */
+    double *s;       /* [dev] [n_emb]    max score in REFERENCE arithmetic, widened to double   */
+    int32_t *queue;  /* [dev] [n_emb]    rows the filter could not decide                       */
+    int32_t *count;  /* [dev] [1]        length of `queue`                                      */
+} segk_cand;
 
-/* A1 (exact stage) for rows ids[0..n) (0..n-1 when NULL): out_max[r] (double, widened from
- * the dtype of X) and out_arg[r] are bit-identical to np.max / np.argmax of
- * neg_sqrd_norm(ids[r]) (kmeans_components.py:228-232).  cand_* as written by
- * segk_kmeans_score.  out_n_bruteforce [dev] int32 [1] counts rows that needed the full
- * K_max exact scan (filter margin not decisive).                                        */
+/* A1 -- KMeansComponents.neg_sqrd_norm / max_ / argmax_neg_sqrd_norm_i
+ * kmeans_components.py:225-232, called per embedding from get_vec_embed_neg_len_sqrd_norms
+ * kmeans_acoustic_wordseg.py:334-351, for rows `ids[0..n)` (rows row0..row0+n-1 when ids == NULL;
+ * entries of ids equal to -1 are skipped).  Three kernels on the stream:
+ *   (1) filter: fp32 MFMA contraction of the rows of X32 against all K_max means; per row the
+ *       component with the largest f[k] = x.m_k - |m_k|^2/2 and the two largest values; for
+ *       float32 data with 8 <= D <= 128 the winner's score in reference arithmetic is fused in
+ *       the epilogue; rows whose two best filter values are closer than the proven error
+ *       margin are queued;
+ *   (2) (other dtypes / D) the winner's reference-arithmetic score per row;
+ *   (3) full scan of the queued rows: the reference's own computation over all K_max
+ *       components, first maximum.
+ * Afterwards cand->k[e] / cand->s[e] are bit-identical to np.argmax / np.max of
+ * neg_sqrd_norm(e) for every processed row e (bit-exact contract).
+ * status [dev] int32 [8] or NULL: status[1] accumulates the number of fully scanned rows. */
+int32_t segk_kmeans_score(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m,
+                          const int32_t *ids, int64_t row0, int64_t n, const segk_cand *cand,
+                          int32_t *status, void *stream);
+
+/* Gather of the A1 results for rows ids[0..n) (0..n-1 when NULL): out_max[r] (double, widened
+ * from the dtype of X) and out_arg[r] = np.max / np.argmax of neg_sqrd_norm(ids[r])
+ * (kmeans_components.py:228-232), from a `cand` filled by segk_kmeans_score. */
 int32_t segk_kmeans_exact_max(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m,
-                              const int32_t *ids, int64_t n,
-                              const int32_t *cand_k, const float *cand_f, const float *cand_s,
-                              double *out_max, int32_t *out_arg, int32_t *out_n_bruteforce,
-                              void *stream);
+                              const int32_t *ids, int64_t n, const segk_cand *cand,
+                              double *out_max, int32_t *out_arg, void *stream);
 
 /* A1 full vector: out[k], k < K_max, = neg_sqrd_norm(row) in reference arithmetic; `out`
  * has the dtype of X (kmeans_components.py:169-226).                                    */
@@ -133,9 +142,9 @@ int32_t segk_kmeans_neg_sqrd_norm(segk_ctx *ctx, const segk_corpus *c, const seg
                                   int64_t row, void *out, void *stream);
 
 /* A5 + A8 + new-segment argmax -- SegmentalKMeansWordseg.segment_i minus the statistics
- * update: get_vec_embed_neg_len_sqrd_norms (kmeans_acoustic_wordseg.py:334-351),
+ * update: get_vec_embed_neg_len_sqrd_norms (kmeans_acoustic_wordseg.py:334-351) from `cand`,
  * forward_backward_kmeans_viterbi (:449-555), get_max_unsup_transcript_i (:313,:437-446).
- * One workgroup per utterance utts[0..n_utts) (utterances utt0..utt0+n_utts-1 when utts == NULL).
+ * One wavefront per utterance utts[0..n_utts) (utterances utt0..utt0+n_utts-1 when utts == NULL).
  *   boundaries [dev] uint8 [n_utt, N_max]  in: current segmentation, out: new
  *   old_tok    [dev] int32 [n_utt, N_max]  embeddings of the OLD segmentation (-1 skipped)
  *   new_tok    [dev] int32 [n_utt, N_max]  embeddings of the NEW segmentation
@@ -143,15 +152,14 @@ int32_t segk_kmeans_neg_sqrd_norm(segk_ctx *ctx, const segk_corpus *c, const seg
  *   n_old/n_new[dev] int32 [n_utt]
  *   n_flag     [dev] int32 [n_utt] or NULL: new segments whose argmax is an inactive row (k >= K)
  *   out_total  [dev] double [n_utt]        sum of chosen scores (:332)
- *   status     [dev] int32 [8]  [0] error flag (new segment without embedding ->
- *              kmeans_components.py:100 assert), [1] spans brute-forced (accumulates)    */
+ *   status     [dev] int32 [8]  [0] bit 1: a new segment has no embedding
+ *              (kmeans_components.py:100 assert)                                        */
 int32_t segk_kmeans_segment(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m,
                             const int32_t *utts, int32_t utt0, int32_t n_utts,
                             int32_t n_slices_min, int32_t n_slices_max, double wip,
-                            const int32_t *cand_k, const float *cand_f, const float *cand_s,
-                            uint8_t *boundaries, int32_t *old_tok, int32_t *new_tok,
-                            int32_t *new_k, int32_t *n_old, int32_t *n_new, int32_t *n_flag,
-                            double *out_total, int32_t *status, void *stream);
+                            const segk_cand *cand, uint8_t *boundaries, int32_t *old_tok,
+                            int32_t *new_tok, int32_t *new_k, int32_t *n_old, int32_t *n_new,
+                            int32_t *n_flag, double *out_total, int32_t *status, void *stream);
 
 /* A11 sequential update -- the tail of segment_i (kmeans_acoustic_wordseg.py:314-320):
  * del_item(old) (kmeans_components.py:113-132), add_item(new, k) (:93-111, incl. the

@@ -36,6 +36,11 @@ class KMeansDev(C.Structure):
     ]
 
 
+class CandDev(C.Structure):
+    _fields_ = [("k", C.c_void_p), ("f", C.c_void_p), ("s", C.c_void_p), ("queue", C.c_void_p),
+                ("count", C.c_void_p)]
+
+
 class FbgmmDev(C.Structure):
     _fields_ = [
         ("cov_type", C.c_int32), ("K_max", C.c_int32), ("alpha", C.c_double), ("lms", C.c_double),
@@ -47,7 +52,7 @@ class FbgmmDev(C.Structure):
 
 _P = C.c_void_p
 _i32, _i64, _f64 = C.c_int32, C.c_int64, C.c_double
-_CP, _KP, _FP = C.POINTER(Corpus), C.POINTER(KMeansDev), C.POINTER(FbgmmDev)
+_CP, _KP, _FP, _DP = C.POINTER(Corpus), C.POINTER(KMeansDev), C.POINTER(FbgmmDev), C.POINTER(CandDev)
 
 # name -> (restype, argtypes); every symbol include/segk.h declares
 SIGNATURES = {
@@ -59,11 +64,11 @@ SIGNATURES = {
     "segk_kmeans_tiles_floats": (_i64, [_i32, _i32]),
     "segk_kmeans_prepare": (_i32, [_P, _CP, _KP, _P]),
     "segk_kmeans_init_stats": (_i32, [_P, _CP, _KP, _P]),
-    "segk_kmeans_score": (_i32, [_P, _CP, _KP, _P, _i64, _i64, _P, _P, _P, _P]),
-    "segk_kmeans_exact_max": (_i32, [_P, _CP, _KP, _P, _i64, _P, _P, _P, _P, _P, _P, _P]),
+    "segk_kmeans_score": (_i32, [_P, _CP, _KP, _P, _i64, _i64, _DP, _P, _P]),
+    "segk_kmeans_exact_max": (_i32, [_P, _CP, _KP, _P, _i64, _DP, _P, _P, _P]),
     "segk_kmeans_neg_sqrd_norm": (_i32, [_P, _CP, _KP, _i64, _P, _P]),
-    "segk_kmeans_segment": (_i32, [_P, _CP, _KP, _P, _i32, _i32, _i32, _i32, _f64, _P, _P, _P, _P, _P, _P, _P,
-                                   _P, _P, _P, _P, _P, _P]),
+    "segk_kmeans_segment": (_i32, [_P, _CP, _KP, _P, _i32, _i32, _i32, _i32, _f64, _DP, _P, _P, _P, _P, _P, _P,
+                                   _P, _P, _P, _P]),
     "segk_dp_tri": (_i32, [_P, _i32, _P, _P, _P, _i32, _i32, _i32, _f64, _f64, _P, _i64, _P, _i64, _P, _P, _P,
                            _P, _i64, _P]),
     "segk_kmeans_update_utt": (_i32, [_P, _CP, _KP, _i32, _P, _P, _P, _P, _P, _P, _P]),

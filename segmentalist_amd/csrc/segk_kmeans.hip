@@ -99,6 +99,44 @@ __device__ T neg_sqd_exact(const TM &m, const TX *x, int n)
     return -ret;
 }
 
+// Four rows at once for 8 <= n <= 128 (numpy's single-block case): identical arithmetic per
+// row, interleaved so that 4 x 8 loads are in flight per step.
+template <typename T, typename TM, typename TX>
+__device__ void neg_sqd_exact_x4(const TM &m0, const TM &m1, const TM &m2, const TM &m3, const TX *x, int n, T *out)
+{
+    T r[4][8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        r[0][j] = sqd<T>(m0, x, j);
+        r[1][j] = sqd<T>(m1, x, j);
+        r[2][j] = sqd<T>(m2, x, j);
+        r[3][j] = sqd<T>(m3, x, j);
+    }
+    int i;
+    const int nfull = n - (n % 8);
+    for (i = 8; i < nfull; i += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            r[0][j] += sqd<T>(m0, x, i + j);
+            r[1][j] += sqd<T>(m1, x, i + j);
+            r[2][j] += sqd<T>(m2, x, i + j);
+            r[3][j] += sqd<T>(m3, x, i + j);
+        }
+    }
+    T res[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+        res[q] = ((r[q][0] + r[q][1]) + (r[q][2] + r[q][3])) + ((r[q][4] + r[q][5]) + (r[q][6] + r[q][7]));
+    for (; i < n; i++) {
+        res[0] += sqd<T>(m0, x, i);
+        res[1] += sqd<T>(m1, x, i);
+        res[2] += sqd<T>(m2, x, i);
+        res[3] += sqd<T>(m3, x, i);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) out[q] = -res[q];
+}
+
 // A component's row read from the MFMA tile image instead of from `means`: the image holds
 // the same float32 values with the component index contiguous (stride 2 floats), so that
 // consecutive lanes scanning consecutive components touch a few cache lines per load instead
@@ -223,22 +261,38 @@ __device__ __forceinline__ float vmax_f32(float a, float b)
 //   embedding on the lane: the running max over components is lane-local.
 //   Accumulators start at -|m|^2/2, so acc = x.m - |m|^2/2 with no epilogue arithmetic.
 // ======================================================================================
-template <int GMAX, int NB>
-__global__ __launch_bounds__(256, 2) void k_kmeans_score(
-    const float *__restrict__ X32, int64_t ld32, const int32_t *__restrict__ ids, int64_t row0, int64_t n,
-    const float *__restrict__ tiles, int n_tiles, int tile_stride, int G /* groups present in X32 rows */,
-    int D, int fuse_exact, int dbg /* timing-only ablation bits, 0 in production */,
-    int32_t *__restrict__ cand_k, float *__restrict__ cand_f,
-    float *__restrict__ cand_s)
+struct ScoreArgs {
+    const float *X32;
+    int64_t ld32;
+    const int32_t *ids;
+    int64_t row0, n;
+    const float *tiles;
+    int n_tiles, tile_stride, G /* groups present in X32 rows */, D, fuse_exact, is_f64;
+    int dbg;                     /* timing-only ablation bits, 0 in production */
+    const float *xnorm;
+    const double *mnorm2;
+    segk_cand cand;
+    int amb_cap;
+};
+
+template <int GMAX, int NB, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 2) void k_kmeans_score(ScoreArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    const float *__restrict__ X32 = A.X32;
+    const int64_t ld32 = A.ld32;
+    const int32_t *__restrict__ ids = A.ids;
+    const int64_t row0 = A.row0, n = A.n;
+    const float *__restrict__ tiles = A.tiles;
+    const int n_tiles = A.n_tiles, tile_stride = A.tile_stride, G = A.G, D = A.D, fuse_exact = A.fuse_exact,
+              dbg = A.dbg;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
 
     float2 xb[NB][GMAX];
     int32_t rowid[NB];
-    const int64_t base = ((int64_t)blockIdx.x * 4 + wave) * (32 * NB);
+    const int64_t base = ((int64_t)blockIdx.x * WAVES + wave) * (32 * NB);
 #pragma unroll
     for (int nb = 0; nb < NB; nb++) {
         int64_t r = base + nb * 32 + j;
@@ -246,10 +300,14 @@ __global__ __launch_bounds__(256, 2) void k_kmeans_score(
         if (r < n) id = ids ? ids[r] : (int32_t)(row0 + r);
         rowid[nb] = id;
         const float *xp = X32 + (int64_t)(id >= 0 ? id : 0) * ld32 + 2 * h;
+        // unconditional loads (a select around a load makes hipcc branch and wait per element):
+        // groups beyond the row's G are read from a clamped in-row offset and zeroed afterwards
 #pragma unroll
-        for (int g = 0; g < GMAX; g++) {
-            if (g < G) xb[nb][g] = *reinterpret_cast<const float2 *>(xp + 4 * g);
-            else xb[nb][g] = make_float2(0.f, 0.f);
+        for (int g = 0; g < GMAX; g++) xb[nb][g] = *reinterpret_cast<const float2 *>(xp + 4 * (g < G ? g : 0));
+        if (G < GMAX) {
+#pragma unroll
+            for (int g = 0; g < GMAX; g++)
+                if (g >= G) xb[nb][g] = make_float2(0.f, 0.f);
         }
     }
     // running top-2 values, and the argmax as (tile, row code) -- per lane
@@ -258,7 +316,9 @@ __global__ __launch_bounds__(256, 2) void k_kmeans_score(
 #pragma unroll
     for (int nb = 0; nb < NB; nb++) { m1[nb] = NEG_INF_F; m2[nb] = NEG_INF_F; irow[nb] = 0; itile[nb] = 0; }
 
-    constexpr int NPASS = (GMAX * 128 + 32 + 1023) / 1024;   // == tile_stride / 1024 (segk_tile_stride)
+    constexpr int STRIDE = (GMAX * 128 + 32 + 1023) / 1024 * 1024;   // == tile_stride (segk_tile_stride)
+    constexpr int PASS = WAVES * 256;                                 // floats moved per pass by the workgroup
+    constexpr int NPASS = (STRIDE + PASS - 1) / PASS;
     typedef const __attribute__((address_space(1))) void *gptr_t;
     typedef __attribute__((address_space(3))) void *lptr_t;
     // stage tile `tt` into LDS buffer `buf` with direct global->LDS loads: one wave instruction
@@ -268,7 +328,8 @@ __global__ __launch_bounds__(256, 2) void k_kmeans_score(
         const float *src_ = tiles + (int64_t)(tt) * tile_stride + tid * 4;                          \
         float *dst_ = lds + (buf) * tile_stride + wave * 256;                                       \
         _Pragma("unroll") for (int p = 0; p < NPASS; p++)                                           \
-            __builtin_amdgcn_global_load_lds((gptr_t)(src_ + p * 1024), (lptr_t)(dst_ + p * 1024), 16, 0, 0); \
+            if (p * PASS + wave * 256 < STRIDE)       /* wave-uniform: a wave moves 256 floats */   \
+                __builtin_amdgcn_global_load_lds((gptr_t)(src_ + p * PASS), (lptr_t)(dst_ + p * PASS), 16, 0, 0); \
     } while (0)
 
     SEGK_STAGE(0, 0);
@@ -429,76 +490,77 @@ __global__ __launch_bounds__(256, 2) void k_kmeans_score(
             sexact = -res;
         }
         if (h == 0 && rowid[nb] >= 0) {
-            cand_k[rowid[nb]] = idx;
-            cand_f[2 * (int64_t)rowid[nb] + 0] = top1;
-            cand_f[2 * (int64_t)rowid[nb] + 1] = top2;
-            cand_s[rowid[nb]] = sexact;
+            const int32_t id = rowid[nb];
+            A.cand.k[id] = idx;
+            A.cand.f[2 * (int64_t)id + 0] = top1;
+            A.cand.f[2 * (int64_t)id + 1] = top2;
+            A.cand.s[id] = (double)sexact;        // NaN when not fused
+            // the filter cannot order the two best components with certainty: queue the row for
+            // the full reference-arithmetic scan (k_kmeans_brute)
+            const float M = (float)(sqrt(*A.mnorm2) * (1.0 + 1e-6)) + 1e-30f;
+            const float tau = filter_tau(A.xnorm[id], M, D, A.is_f64);
+            if (!(top1 - top2 > tau)) {
+                int q = atomicAdd(A.cand.count, 1);
+                if (q < A.amb_cap) A.cand.queue[q] = id;
+            }
         }
     }
 }
 
 // ======================================================================================
-// Exact stage for a list of rows held by one workgroup.
-//   phase 1 (thread per row): if the filter margin is decisive, exact score of the single
-//           candidate; else queue the row for
-//   phase 2 (whole workgroup per queued row): exact score of ALL K_max components, first
-//           maximum (np.argmax) -- the reference's own computation, verbatim.
-// Results: sc[i] (double, widened), kb[i].  ids[i] < 0 -> sc = -inf, kb = -1.
+// Exact stage.
+//   k_kmeans_brute       every queued (ambiguous) row: the reference's own computation for ALL
+//                        K_max components, first maximum (np.argmax); one workgroup per row,
+//                        components contiguous across lanes (tile image) for float32 data
+//   k_kmeans_exact_fill  rows whose winner was not evaluated in the score kernel's epilogue
+//                        (float64 data, D < 8 or D > 128): exact score of the winner
+// After these, cand.k / cand.s hold np.argmax / np.max of neg_sqrd_norm for every scored row.
 // ======================================================================================
 template <typename XT>
-__device__ void exact_rows(const segk_corpus &c, const segk_kmeans &m, const int32_t *ids_lds, int n,
-                           const int32_t *cand_k, const float *cand_f, const float *cand_s, double *sc, int32_t *kb,
-                           int32_t *queue, int32_t *qn, XT *xrow, double *red_v, int32_t *red_k,
-                           int32_t *n_brute)
+__global__ void k_kmeans_brute(segk_corpus c, segk_kmeans m, segk_cand cand, int cap, int32_t *n_brute)
 {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, nt = blockDim.x;
+    double *red_v = (double *)smem;                  // [nt]
+    XT *xrow = (XT *)(red_v + nt);                   // [D]
+    int32_t *red_k = (int32_t *)(xrow + ((c.D + 1) & ~1));   // [nt]
     const XT *X = (const XT *)c.X;
     const XT *means = (const XT *)m.means;
     const int D = c.D;
-    // mnorm_max holds max_k |m_k|^2 (maintained with atomicMax on the bit pattern)
-    const float M = (float)(sqrt(*m.mnorm_max) * (1.0 + 1e-6)) + 1e-30f;
-    if (tid == 0) *qn = 0;
-    __syncthreads();
-    for (int i = tid; i < n; i += nt) {
-        int32_t id = ids_lds[i];
-        double v = NEG_INF_D;
-        int32_t k = -1;
-        if (id >= 0) {
-            int32_t k1 = cand_k[id];
-            float f1 = cand_f[2 * (int64_t)id], f2 = cand_f[2 * (int64_t)id + 1];
-            float tau = filter_tau(c.xnorm[id], M, D, c.x_dtype);
-            if (f1 - f2 > tau) {
-                const float se = cand_s[id];        // exact score of the winner, fused in the score kernel
-                if (se == se) v = (double)se;
-                else v = (double)neg_sqd_exact<XT>(means + (int64_t)k1 * D, X + (int64_t)id * c.ldx, D);
-                k = k1;
-            } else {
-                int q = atomicAdd(qn, 1);
-                queue[q] = i;
-            }
-        }
-        sc[i] = v;
-        kb[i] = k;
-    }
-    __syncthreads();
-    const int nq = *qn;
-    for (int q = 0; q < nq; q++) {
-        const int i = queue[q];
-        const int32_t id = ids_lds[i];
+    int nq = *cand.count;
+    if (nq > cap) nq = cap;
+    if (blockIdx.x == 0 && tid == 0 && n_brute && nq > 0) atomicAdd(n_brute, nq);
+    for (int q = blockIdx.x; q < nq; q += gridDim.x) {
+        const int32_t id = cand.queue[q];
+        __syncthreads();
         for (int d = tid; d < D; d += nt) xrow[d] = X[(int64_t)id * c.ldx + d];
         __syncthreads();
         XT best = (XT)NEG_INF_D;
         int32_t bk = 0x7fffffff;
         if constexpr (sizeof(XT) == 4) {
             const int tstride = segk_tile_stride(D);
-            for (int k = tid; k < m.K_max; k += nt) {
-                XT s = neg_sqd_exact<XT>(tile_row(m.tiles, tstride, k), xrow, D);
-                if (s > best || bk == 0x7fffffff) { best = s; bk = k; }   // first max within the thread
+            int k = tid;
+            if (D >= 8 && D <= 128) {
+                // four components per thread in flight: the same numpy-ordered accumulation for
+                // each, but their loads are independent, which hides the L2 latency
+                for (; k + 3 * nt < m.K_max; k += 4 * nt) {
+                    XT sc[4];
+                    neg_sqd_exact_x4<XT>(tile_row(m.tiles, tstride, k), tile_row(m.tiles, tstride, k + nt),
+                                         tile_row(m.tiles, tstride, k + 2 * nt), tile_row(m.tiles, tstride, k + 3 * nt),
+                                         xrow, D, sc);
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+                        if (sc[q] > best || bk == 0x7fffffff) { best = sc[q]; bk = k + q * nt; }
+                }
+            }
+            for (; k < m.K_max; k += nt) {
+                XT sc = neg_sqd_exact<XT>(tile_row(m.tiles, tstride, k), xrow, D);
+                if (sc > best || bk == 0x7fffffff) { best = sc; bk = k; }   // first max within the thread
             }
         } else {
             for (int k = tid; k < m.K_max; k += nt) {
-                XT s = neg_sqd_exact<XT>(means + (int64_t)k * D, xrow, D);
-                if (s > best || bk == 0x7fffffff) { best = s; bk = k; }
+                XT sc = neg_sqd_exact<XT>(means + (int64_t)k * D, xrow, D);
+                if (sc > best || bk == 0x7fffffff) { best = sc; bk = k; }
             }
         }
         red_v[tid] = (double)best;
@@ -515,40 +577,34 @@ __device__ void exact_rows(const segk_corpus &c, const segk_kmeans &m, const int
             __syncthreads();
         }
         if (tid == 0) {
-            sc[i] = red_v[0];
-            kb[i] = red_k[0];
+            cand.k[id] = red_k[0];
+            cand.s[id] = red_v[0];
         }
-        __syncthreads();
     }
-    if (tid == 0 && nq > 0 && n_brute) atomicAdd(n_brute, nq);
 }
 
-// A1 exact for arbitrary rows (API: segk_kmeans_exact_max)
 template <typename XT>
-__global__ void k_kmeans_exact_max(segk_corpus c, segk_kmeans m, const int32_t *ids, int64_t n,
-                                   const int32_t *cand_k, const float *cand_f, const float *cand_s, double *out_max,
-                                   int32_t *out_arg, int32_t *n_brute)
+__global__ void k_kmeans_exact_fill(segk_corpus c, segk_kmeans m, const int32_t *ids, int64_t row0, int64_t n,
+                                    segk_cand cand)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int nt = blockDim.x;
-    double *sc = (double *)smem;
-    double *red_v = sc + nt;
-    XT *xrow = (XT *)(red_v + nt);
-    int32_t *kb = (int32_t *)(xrow + ((c.D + 1) & ~1));
-    int32_t *ids_l = kb + nt;
-    int32_t *queue = ids_l + nt;
-    int32_t *red_k = queue + nt;
-    int32_t *qn = red_k + nt;
-    const int64_t r0 = (int64_t)blockIdx.x * nt;
-    int cnt = (int)((n - r0) < nt ? (n - r0) : nt);
-    for (int i = threadIdx.x; i < cnt; i += nt) ids_l[i] = ids ? ids[r0 + i] : (int32_t)(r0 + i);
-    __syncthreads();
-    exact_rows<XT>(c, m, ids_l, cnt, cand_k, cand_f, cand_s, sc, kb, queue, qn, xrow, red_v, red_k, n_brute);
-    __syncthreads();
-    for (int i = threadIdx.x; i < cnt; i += nt) {
-        out_max[r0 + i] = sc[i];
-        out_arg[r0 + i] = kb[i];
-    }
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const int64_t id = ids ? (int64_t)ids[r] : row0 + r;
+    if (id < 0) return;
+    const double sv = cand.s[id];
+    if (sv == sv) return;
+    cand.s[id] = (double)neg_sqd_exact<XT>((const XT *)m.means + (int64_t)cand.k[id] * c.D,
+                                           (const XT *)c.X + id * c.ldx, c.D);
+}
+
+__global__ void k_kmeans_gather_cand(segk_cand cand, const int32_t *ids, int64_t n, double *out_max,
+                                     int32_t *out_arg)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const int64_t id = ids ? (int64_t)ids[r] : r;
+    out_max[r] = cand.s[id];
+    out_arg[r] = cand.k[id];
 }
 
 // A1 full vector for one row (API: segk_kmeans_neg_sqrd_norm)
@@ -561,67 +617,70 @@ __global__ void k_kmeans_neg_sqrd_norm(segk_corpus c, segk_kmeans m, int64_t row
 }
 
 // ======================================================================================
-// Per-utterance kernel: exact scores of the band of candidate spans, A5, A8, tokens.
+// Per-utterance kernel: A5 (vec from the candidates), A8 (max-plus DP), tokens.
+//   ONE WAVE per utterance, no workgroup barriers: lanes gather the band of candidate spans,
+//   lane 0 runs the DP on LDS, lanes write the results.
 //   band layout: entry (t, w), t = 1..N (span end), w = 0..W-1 (span length w+1, start
 //   s = t-1-w) at [(t-1)*W + w]; W = n_slices_max, or N when n_slices_max == 0.
 // ======================================================================================
-template <typename XT>
-__global__ void k_kmeans_segment(segk_corpus c, segk_kmeans m, const int32_t *utts, int utt0, int n_min, int n_max,
-                                 double wip, const int32_t *cand_k, const float *cand_f, const float *cand_s,
-                                 uint8_t *boundaries, int32_t *old_tok, int32_t *new_tok, int32_t *new_k,
-                                 int32_t *n_old, int32_t *n_new, int32_t *n_flag, double *out_total,
-                                 int32_t *status, int band_cap, int dbg)
+#define WAVE_SYNC()                                             \
+    do {                                                        \
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  \
+        __builtin_amdgcn_wave_barrier();                        \
+    } while (0)
+
+__global__ void k_kmeans_segment(segk_corpus c, segk_kmeans m, const int32_t *utts, int utt0, int n_utts,
+                                 int n_min, int n_max, double wip, segk_cand cand, uint8_t *boundaries,
+                                 int32_t *old_tok, int32_t *new_tok, int32_t *new_k, int32_t *n_old,
+                                 int32_t *n_new, int32_t *n_flag, double *out_total, int32_t *status, int band_cap,
+                                 int wave_bytes)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, nt = blockDim.x;
-    const int u = utts ? utts[blockIdx.x] : utt0 + (int)blockIdx.x;
+    (void)n_min;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int slot = blockIdx.x * (blockDim.x >> 6) + wv;
+    if (slot >= n_utts) return;
+    const int u = utts ? utts[slot] : utt0 + slot;
     const int N = c.lengths[u];
     const int W = (n_max > 0 && n_max < N) ? n_max : N;
     const int nb = N * W;
     const int64_t triMax = (int64_t)c.N_max * (c.N_max + 1) / 2;
     const int32_t *vid = c.vec_ids + (int64_t)u * triMax;
     const double *dur = c.durations + (int64_t)u * triMax;
-
-    double *bvec = (double *)smem;                    // [band_cap]
-    double *gam = bvec + band_cap;                    // [N_max + 1]
-    double *red_v = gam + (c.N_max + 1);              // [nt]
-    XT *xrow = (XT *)(red_v + nt);                    // [D]
-    int32_t *bk = (int32_t *)(xrow + ((c.D + 1) & ~1));   // [band_cap]
-    int32_t *bid = bk + band_cap;                     // [band_cap]
-    int32_t *queue = bid + band_cap;                  // [band_cap]
-    int32_t *red_k = queue + band_cap;                // [nt]
-    int32_t *qn = red_k + nt;                         // [1]
-
-    for (int i = tid; i < nb; i += nt) {
-        int t = i / W + 1, w = i % W, s = t - 1 - w;
-        bid[i] = (s >= 0) ? vid[t * (t - 1) / 2 + s] : -1;
-    }
-    __syncthreads();
-    if (!(dbg & 1))
-        exact_rows<XT>(c, m, bid, nb, cand_k, cand_f, cand_s, bvec, bk, queue, qn, xrow, red_v, red_k, status + 1);
-    __syncthreads();
-    // A5: scale by duration, NaN duration -> -inf, + wip   (kmeans_acoustic_wordseg.py:346-351)
-    for (int i = tid; i < nb; i += nt) {
-        int t = i / W + 1, w = i % W, s = t - 1 - w;
-        double v = NEG_INF_D;
-        if (s >= 0 && bid[i] >= 0) {
-            double dd = dur[t * (t - 1) / 2 + s];
-            v = isnan(dd) ? NEG_INF_D : bvec[i] * dd;
-        }
-        bvec[i] = v + wip;
-    }
-    __syncthreads();
-
-    // The serial part (one thread) works on LDS only: boundaries, token lists and the DP
-    // tables are staged in LDS and written out by the whole workgroup afterwards.
     uint8_t *gbnd = boundaries + (int64_t)u * c.N_max;
-    int32_t *l_old = queue;                    // [N]   (queue is free after the exact stage)
-    int32_t *l_new = queue + c.N_max;          // [N]   band_cap >= 3*N_max is guaranteed by the launcher
-    int32_t *l_newk = queue + 2 * c.N_max;     // [N]
-    uint8_t *l_bnd = (uint8_t *)red_k;         // [N]   (nt*4 bytes >= N_max checked by the launcher)
-    for (int j = tid; j < N; j += nt) l_bnd[j] = gbnd[j];
-    __syncthreads();
-    if (tid == 0 && !(dbg & 2)) {
+
+    char *base = smem + (size_t)wv * wave_bytes;
+    double *bvec = (double *)base;                    // [band_cap]
+    double *gam = bvec + band_cap;                    // [N_max + 1]
+    int32_t *bk = (int32_t *)(gam + c.N_max + 1);     // [band_cap]
+    int32_t *bid = bk + band_cap;                     // [band_cap]
+    int32_t *l_old = bid + band_cap;                  // [N_max]
+    int32_t *l_new = l_old + c.N_max;                 // [N_max]
+    int32_t *l_newk = l_new + c.N_max;                // [N_max]
+    int32_t *l_cnt = l_newk + c.N_max;                // [2]
+    uint8_t *l_bnd = (uint8_t *)(l_cnt + 2);          // [N_max]
+
+    for (int i = lane; i < nb; i += 64) {
+        const int t = i / W + 1, w = i % W, s = t - 1 - w;
+        int id = -1;
+        double v = NEG_INF_D;
+        int k = -1;
+        if (s >= 0) {
+            const int j = t * (t - 1) / 2 + s;
+            id = vid[j];
+            if (id >= 0) {
+                k = cand.k[id];
+                const double dd = dur[j];
+                v = isnan(dd) ? NEG_INF_D : cand.s[id] * dd;      // :346-349
+            }
+        }
+        bid[i] = id;
+        bk[i] = k;
+        bvec[i] = v + wip;                                       // :351
+    }
+    for (int j = lane; j < N; j += 64) l_bnd[j] = gbnd[j];
+    WAVE_SYNC();
+    if (lane == 0) {
 #define V_(t, s) bvec[((t) - 1) * W + ((t) - 1 - (s))]
 #define ID_(t, s) (((t) - 1 - (s)) < W ? bid[((t) - 1) * W + ((t) - 1 - (s))] : vid[(t) * ((t) - 1) / 2 + (s)])
         // ---- old tokens (utterances.py:159-174) before the boundaries are overwritten
@@ -701,16 +760,17 @@ __global__ void k_kmeans_segment(segk_corpus c, segk_kmeans m, const int32_t *ut
         n_old[u] = no;
         n_new[u] = nn;
         if (n_flag) n_flag[u] = nf;
-        *qn = no | (nn << 16);
+        l_cnt[0] = no;
+        l_cnt[1] = nn;
         if (bad) atomicOr(status, 1);
 #undef V_
 #undef ID_
     }
-    __syncthreads();
-    const int no = *qn & 0xffff, nn = *qn >> 16;
-    for (int j = tid; j < N; j += nt) gbnd[j] = l_bnd[j];
-    for (int j = tid; j < no; j += nt) old_tok[(int64_t)u * c.N_max + j] = l_old[j];
-    for (int j = tid; j < nn; j += nt) {
+    WAVE_SYNC();
+    const int no = l_cnt[0], nn = l_cnt[1];
+    for (int j = lane; j < N; j += 64) gbnd[j] = l_bnd[j];
+    for (int j = lane; j < no; j += 64) old_tok[(int64_t)u * c.N_max + j] = l_old[j];
+    for (int j = lane; j < nn; j += 64) {
         new_tok[(int64_t)u * c.N_max + j] = l_new[j];
         new_k[(int64_t)u * c.N_max + j] = l_newk[j];
     }
@@ -975,16 +1035,20 @@ __global__ void k_batch_compact(segk_corpus c, int lo, int hi, const int32_t *ne
 // (4) per statistics block and component: sequential fp64 sum over the block's tokens in
 //     token order.  A workgroup = (block, 8 consecutive components), one wave per component;
 //     lanes own dimensions.  The block's token keys are staged in LDS chunk by chunk with
-//     coalesced loads, so the per-wave scan never waits on global memory; only the (few)
-//     matching tokens touch X.
+//     coalesced loads; a wave compacts its matching token ids (token order) into an LDS list and
+//     drains it 16 rows at a time -- the row loads are unconditional (clamped index, select after
+//     the load) so that all 16 are in flight together; the adds stay strictly in order.
 #define PART_CHUNK 8192
+#define PART_MLIST 512
+#define PART_BATCH 16
 template <typename XT>
 __global__ __launch_bounds__(512) void k_batch_partials(
     segk_corpus c, segk_kmeans m, const int32_t *blk_lo, int n_blocks, int lo, const int32_t *tok_off,
     const int32_t *ctok_id, const int32_t *ctok_k, const double *out_total, double *part_sum,
-    int64_t *part_cnt, double *part_tot)
+    int64_t *part_cnt, double *part_tot, int dbg)
 {
     __shared__ __attribute__((aligned(16))) int32_t keys[PART_CHUNK];
+    __shared__ int32_t mlists[8 * PART_MLIST];
     const int groups = (m.K_max + 7) / 8;
     const int b = blockIdx.x / groups, kg = blockIdx.x % groups;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -994,11 +1058,17 @@ __global__ __launch_bounds__(512) void k_batch_partials(
     const XT *X = (const XT *)c.X;
     const int u0 = blk_lo[b], u1 = blk_lo[b + 1];
     const int p0 = tok_off[u0 - lo], p1 = tok_off[u1 - lo];
-    constexpr int MAXR = 8;                       // D <= 512 per pass
+    int32_t *mlist = mlists + wv * PART_MLIST;
+    constexpr int MAXR = 2;                       // 128 dims per pass over the tokens
     for (int d0 = 0; d0 < D; d0 += 64 * MAXR) {
         double acc[MAXR];
+        int dcl[MAXR];                            // clamped dimension (always a valid address)
 #pragma unroll
-        for (int r = 0; r < MAXR; r++) acc[r] = 0.0;
+        for (int r = 0; r < MAXR; r++) {
+            acc[r] = 0.0;
+            const int d = d0 + r * 64 + lane;
+            dcl[r] = d < D ? d : 0;
+        }
         int64_t cnt = 0;
         for (int pc = p0; pc < p1; pc += PART_CHUNK) {
             const int nch = p1 - pc < PART_CHUNK ? p1 - pc : PART_CHUNK;
@@ -1010,7 +1080,7 @@ __global__ __launch_bounds__(512) void k_batch_partials(
 #pragma unroll
                     for (int q = 0; q < 4; q++) {
                         const int i = i0 + q * blockDim.x;
-                        v[q] = (i < nch) ? ctok_k[pc + i] : -1;
+                        v[q] = ctok_k[pc + (i < nch ? i : 0)];
                     }
 #pragma unroll
                     for (int q = 0; q < 4; q++) {
@@ -1020,25 +1090,48 @@ __global__ __launch_bounds__(512) void k_batch_partials(
                 }
             }
             __syncthreads();
-            if (active) {
-                for (int pb = 0; pb < nch; pb += 64) {
-                    const int i = pb + lane;
-                    const int match = (i < nch) && (keys[i] == k);
-                    unsigned long long bal = __ballot(match);
-                    if (bal) {
-                        int id = match ? ctok_id[pc + i] : 0;
-                        while (bal) {
-                            int src = __ffsll((long long)bal) - 1;
-                            bal &= bal - 1;
-                            int e = __shfl(id, src);
-                            cnt++;
+            if (!active || (dbg & 1)) continue;
+            int nm = 0;          // wave-uniform length of the match list
+            for (int pb = 0; pb < nch; pb += 256) {
+                // four keys per lane per iteration (tokens pb + lane + 64 j): token order = j-major
+                int mt[4];
+                unsigned long long bal[4];
 #pragma unroll
-                            for (int r = 0; r < MAXR; r++) {
-                                int d = d0 + r * 64 + lane;
-                                if (d < D) acc[r] += (double)X[(int64_t)e * c.ldx + d];
-                            }
+                for (int j = 0; j < 4; j++) {
+                    const int i = pb + lane + 64 * j;
+                    mt[j] = (i < nch) && (keys[i < PART_CHUNK ? i : 0] == k);
+                    bal[j] = __ballot(mt[j]);
+                }
+                if (bal[0] | bal[1] | bal[2] | bal[3]) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        if (mt[j])
+                            mlist[nm + __popcll(bal[j] & ((1ull << lane) - 1ull))] = ctok_id[pc + pb + lane + 64 * j];
+                        nm += __popcll(bal[j]);
+                    }
+                }
+                if (nm > PART_MLIST - 256 || (pb + 256 >= nch && nm > 0)) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    for (int q0 = 0; q0 < nm && !(dbg & 2); q0 += PART_BATCH) {
+                        double xv[PART_BATCH][MAXR];
+#pragma unroll
+                        for (int q = 0; q < PART_BATCH; q++) {
+                            const int e = mlist[q0 + q < nm ? q0 + q : q0];       // clamped: always valid
+#pragma unroll
+                            for (int r = 0; r < MAXR; r++) xv[q][r] = (double)X[(int64_t)e * c.ldx + dcl[r]];
+                        }
+#pragma unroll
+                        for (int q = 0; q < PART_BATCH; q++) {
+                            const bool ok = q0 + q < nm;
+#pragma unroll
+                            for (int r = 0; r < MAXR; r++) acc[r] += ok ? xv[q][r] : 0.0;
                         }
                     }
+                    cnt += nm;
+                    nm = 0;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
                 }
             }
         }
@@ -1051,7 +1144,7 @@ __global__ __launch_bounds__(512) void k_batch_partials(
             if (lane == 0 && d0 == 0) part_cnt[(int64_t)b * m.K_max + k] = cnt;
         }
     }
-    if (kg == 0) {
+    if (kg == 0 && !(dbg & 4)) {
         // sequential (utterance order) sum of the block's totals, staged through LDS so that the
         // single summing thread never waits on global memory
         double *stage = reinterpret_cast<double *>(keys);
@@ -1462,21 +1555,16 @@ static int check_corpus(const segk_corpus *c)
     return SEGK_OK;
 }
 
-template <int GMAX, int NB>
-static int launch_score(const segk_corpus *c, const segk_kmeans *m, const int32_t *ids, int64_t row0, int64_t n,
-                        int32_t *cand_k, float *cand_f, float *cand_s, hipStream_t st)
+template <int GMAX, int NB, int WAVES>
+static int launch_score(const ScoreArgs &A, hipStream_t st)
 {
-    const int stride = segk_tile_stride(c->D);
-    const size_t lds = 2 * (size_t)stride * sizeof(float);
-    const int rows_per_wg = 4 * 32 * NB;
-    const int64_t grid = (n + rows_per_wg - 1) / rows_per_wg;
+    const size_t lds = 2 * (size_t)A.tile_stride * sizeof(float);
+    const int rows_per_wg = WAVES * 32 * NB;
+    const int64_t grid = (A.n + rows_per_wg - 1) / rows_per_wg;
     if (lds > 48 * 1024)
-        SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_kmeans_score<GMAX, NB>,
+        SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_kmeans_score<GMAX, NB, WAVES>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_kmeans_score<GMAX, NB>), dim3((unsigned)grid), dim3(256), lds, st, c->X32, c->ld32, ids,
-                       row0, n, m->tiles, segk_n_tiles(m->K_max), stride, segk_G(c->D), c->D,
-                       (c->x_dtype == SEGK_F32 && c->D >= 8 && c->D <= 128) ? 1 : 0,
-                       getenv("SEGK_SCORE_DBG") ? atoi(getenv("SEGK_SCORE_DBG")) : 0, cand_k, cand_f, cand_s);
+    hipLaunchKernelGGL((k_kmeans_score<GMAX, NB, WAVES>), dim3((unsigned)grid), dim3(64 * WAVES), lds, st, A);
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;
 }
@@ -1519,44 +1607,70 @@ int32_t segk_kmeans_prepare(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m,
 }
 
 int32_t segk_kmeans_score(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m, const int32_t *ids,
-                          int64_t row0, int64_t n, int32_t *cand_k, float *cand_f, float *cand_s, void *stream)
+                          int64_t row0, int64_t n, const segk_cand *cand, int32_t *status, void *stream)
 {
     (void)ctx;
     int rc = check_corpus(c);
     if (rc) return rc;
-    SEGK_REQUIRE(m && m->tiles && cand_k && cand_f && cand_s && c->X32, "score operands");
+    SEGK_REQUIRE(m && m->tiles && cand && cand->k && cand->f && cand->s && cand->queue && cand->count && c->X32,
+                 "score operands");
     SEGK_REQUIRE(ids != nullptr || (row0 >= 0 && row0 + n <= c->n_emb), "row range");
     if (n <= 0) return SEGK_OK;
     hipStream_t st = (hipStream_t)stream;
+    SEGK_CHECK_HIP(hipMemsetAsync(cand->count, 0, sizeof(int32_t), st));
+    ScoreArgs A;
+    A.X32 = c->X32; A.ld32 = c->ld32; A.ids = ids; A.row0 = row0; A.n = n;
+    A.tiles = m->tiles; A.n_tiles = segk_n_tiles(m->K_max); A.tile_stride = segk_tile_stride(c->D);
+    A.G = segk_G(c->D); A.D = c->D;
+    A.fuse_exact = (c->x_dtype == SEGK_F32 && c->D >= 8 && c->D <= 128) ? 1 : 0;
+    A.is_f64 = c->x_dtype == SEGK_F64;
+    A.dbg = getenv("SEGK_SCORE_DBG") ? atoi(getenv("SEGK_SCORE_DBG")) : 0;
+    A.xnorm = c->xnorm; A.mnorm2 = m->mnorm_max; A.cand = *cand; A.amb_cap = (int)c->n_emb;
+    // 4-wave workgroups, two per CU: the two waves sharing a SIMD belong to DIFFERENT workgroups
+    // and drift apart, covering each other's barrier/staging gaps.  (Measured: an 8-wave
+    // workgroup, one barrier for all eight waves, locks the SIMD partners in step and is 15 %
+    // slower although it halves the staging instructions per wave.)
     const int GB = segk_gmax(c->D);
+    rc = SEGK_ERR_UNSUPPORTED;
     switch (GB) {
-#define SEGK_CASE(g, nb) case g: return launch_score<g, nb>(c, m, ids, row0, n, cand_k, cand_f, cand_s, st);
+#define SEGK_CASE(g, nb) \
+    case g: rc = launch_score<g, nb, 4>(A, st); break;
         SEGK_CASE(1, 2) SEGK_CASE(2, 2) SEGK_CASE(4, 2) SEGK_CASE(6, 2) SEGK_CASE(8, 2) SEGK_CASE(10, 2)
         SEGK_CASE(13, 2) SEGK_CASE(16, 2) SEGK_CASE(20, 2) SEGK_CASE(25, 2) SEGK_CASE(26, 2) SEGK_CASE(28, 2)
         SEGK_CASE(32, 2) SEGK_CASE(33, 2) SEGK_CASE(34, 2) SEGK_CASE(40, 1) SEGK_CASE(50, 1) SEGK_CASE(64, 1)
         SEGK_CASE(75, 1) SEGK_CASE(100, 1)
 #undef SEGK_CASE
-        default: break;
+        default:
+            segk_set_error("segk_kmeans_score: D=%d > 400 is not supported by the register-resident score kernel",
+                           c->D);
+            return SEGK_ERR_UNSUPPORTED;
     }
-    segk_set_error("segk_kmeans_score: D=%d > 400 is not supported by the register-resident score kernel", c->D);
-    return SEGK_ERR_UNSUPPORTED;
+    if (rc) return rc;
+    if (!A.fuse_exact)
+        DISPATCH_XT(c, hipLaunchKernelGGL(k_kmeans_exact_fill<XT>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                                           *c, *m, ids, row0, n, *cand););
+    {
+        const int nt = 256;
+        size_t xsz = (c->x_dtype == SEGK_F32 ? 4 : 8) * (size_t)((c->D + 1) & ~1);
+        size_t lds = nt * sizeof(double) + xsz + nt * sizeof(int32_t);
+        int64_t grid = n < 1024 ? n : 1024;
+        DISPATCH_XT(c, hipLaunchKernelGGL(k_kmeans_brute<XT>, dim3((unsigned)grid), dim3(nt), lds, st, *c, *m, *cand,
+                                           (int)c->n_emb, status ? status + 1 : nullptr););
+    }
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
 }
 
 int32_t segk_kmeans_exact_max(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m, const int32_t *ids,
-                              int64_t n, const int32_t *cand_k, const float *cand_f, const float *cand_s,
-                              double *out_max, int32_t *out_arg, int32_t *out_n_bruteforce, void *stream)
+                              int64_t n, const segk_cand *cand, double *out_max, int32_t *out_arg, void *stream)
 {
     (void)ctx;
+    (void)m;
     int rc = check_corpus(c);
     if (rc) return rc;
     if (n <= 0) return SEGK_OK;
-    hipStream_t st = (hipStream_t)stream;
-    const int nt = 256;
-    size_t xsz = (c->x_dtype == SEGK_F32 ? 4 : 8) * (size_t)((c->D + 1) & ~1);
-    size_t lds = 2 * nt * sizeof(double) + xsz + (4 * nt + 4) * sizeof(int32_t);
-    int64_t grid = (n + nt - 1) / nt;
-    DISPATCH_XT(c, hipLaunchKernelGGL(k_kmeans_exact_max<XT>, dim3((unsigned)grid), dim3(nt), lds, st, *c, *m, ids,
-                                       n, cand_k, cand_f, cand_s, out_max, out_arg, out_n_bruteforce););
+    hipLaunchKernelGGL(k_kmeans_gather_cand, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       *cand, ids, n, out_max, out_arg);
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;
 }
@@ -1577,10 +1691,9 @@ int32_t segk_kmeans_neg_sqrd_norm(segk_ctx *ctx, const segk_corpus *c, const seg
 
 int32_t segk_kmeans_segment(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m, const int32_t *utts,
                             int32_t utt0, int32_t n_utts, int32_t n_slices_min, int32_t n_slices_max, double wip,
-                            const int32_t *cand_k, const float *cand_f, const float *cand_s, uint8_t *boundaries,
-                            int32_t *old_tok,
-                            int32_t *new_tok, int32_t *new_k, int32_t *n_old, int32_t *n_new, int32_t *n_flag,
-                            double *out_total, int32_t *status, void *stream)
+                            const segk_cand *cand, uint8_t *boundaries, int32_t *old_tok, int32_t *new_tok,
+                            int32_t *new_k, int32_t *n_old, int32_t *n_new, int32_t *n_flag, double *out_total,
+                            int32_t *status, void *stream)
 {
     (void)ctx;
     int rc = check_corpus(c);
@@ -1592,29 +1705,24 @@ int32_t segk_kmeans_segment(segk_ctx *ctx, const segk_corpus *c, const segk_kmea
     if (n_utts <= 0) return SEGK_OK;
     hipStream_t st = (hipStream_t)stream;
     const int W = (n_slices_max > 0 && n_slices_max < c->N_max) ? n_slices_max : c->N_max;
-    // band entries, padded so that the token staging lists (3 x N_max ints) fit in `queue`
-    const int band_cap = c->N_max * (W < 3 ? 3 : W);
-    const int nt = (band_cap <= 128 && c->N_max <= 512) ? 128 : 256;
-    SEGK_REQUIRE(c->N_max <= 4 * nt && c->N_max < 65536, "N_max too large for the boundary staging buffer");
-    size_t xsz = (c->x_dtype == SEGK_F32 ? 4 : 8) * (size_t)((c->D + 1) & ~1);
-    size_t lds = (size_t)(band_cap + c->N_max + 1 + nt) * sizeof(double) + xsz
-                 + (size_t)(3 * band_cap + nt + 4) * sizeof(int32_t);
+    const int band_cap = c->N_max * W;
+    size_t wave_bytes = (size_t)(band_cap + c->N_max + 1) * sizeof(double)
+                        + (size_t)(2 * band_cap + 3 * c->N_max + 2) * sizeof(int32_t) + (size_t)c->N_max;
+    wave_bytes = (wave_bytes + 15) & ~(size_t)15;
+    int waves = 4;
+    while (waves > 1 && waves * wave_bytes > 64 * 1024) waves >>= 1;
+    size_t lds = waves * wave_bytes;
     if (lds > 160 * 1024) {
         segk_set_error("segk_kmeans_segment: band of %d x %d spans needs %zu B of LDS (> 160 KiB); "
                        "set n_slices_max", c->N_max, W, lds);
         return SEGK_ERR_UNSUPPORTED;
     }
-    // development knob (timing experiments only): SEGK_DEBUG_SKIP bit0 = skip the exact stage,
-    // bit1 = skip the serial DP
-    static const int dbg = getenv("SEGK_DEBUG_SKIP") ? atoi(getenv("SEGK_DEBUG_SKIP")) : 0;
-    DISPATCH_XT(c, {
-        if (lds > 48 * 1024)
-            SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_kmeans_segment<XT>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_kmeans_segment<XT>, dim3(n_utts), dim3(nt), lds, st, *c, *m, utts, utt0, n_slices_min,
-                           n_slices_max, wip, cand_k, cand_f, cand_s, boundaries, old_tok, new_tok, new_k, n_old, n_new,
-                           n_flag, out_total, status, band_cap, dbg);
-    });
+    if (lds > 48 * 1024)
+        SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_kmeans_segment, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds));
+    hipLaunchKernelGGL(k_kmeans_segment, dim3((n_utts + waves - 1) / waves), dim3(64 * waves), lds, st, *c, *m, utts,
+                       utt0, n_utts, n_slices_min, n_slices_max, wip, *cand, boundaries, old_tok, new_tok, new_k, n_old,
+                       n_new, n_flag, out_total, status, band_cap, (int)wave_bytes);
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;
 }
@@ -1731,7 +1839,8 @@ int32_t segk_kmeans_batch_partials(segk_ctx *ctx, const segk_corpus *c, const se
     int64_t grid = (int64_t)n_blocks_local * ((m->K_max + 7) / 8);
     DISPATCH_XT(c, hipLaunchKernelGGL(k_batch_partials<XT>, dim3((unsigned)grid), dim3(512), 0, (hipStream_t)stream,
                                        *c, *m, blk_lo, n_blocks_local, utt_lo, tok_off, ctok_id, ctok_k, out_total,
-                                       part_sum, part_cnt, part_tot););
+                                       part_sum, part_cnt, part_tot,
+                                       getenv("SEGK_PART_DBG") ? atoi(getenv("SEGK_PART_DBG")) : 0););
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;
 }

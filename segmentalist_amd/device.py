@@ -118,7 +118,11 @@ class DeviceKMeans(object):
         # candidates of the filter stage, indexed by embedding row
         self.cand_k = torch.zeros(c.n_emb, dtype=torch.int32, device=dev)
         self.cand_f = torch.zeros((c.n_emb, 2), dtype=torch.float32, device=dev)
-        self.cand_s = torch.zeros(c.n_emb, dtype=torch.float32, device=dev)
+        self.cand_s = torch.zeros(c.n_emb, dtype=torch.float64, device=dev)
+        self.cand_queue = torch.zeros(c.n_emb, dtype=torch.int32, device=dev)
+        self.cand_count = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.cand = _abi.CandDev(k=self.cand_k.data_ptr(), f=self.cand_f.data_ptr(), s=self.cand_s.data_ptr(),
+                                 queue=self.cand_queue.data_ptr(), count=self.cand_count.data_ptr())
         self.status = torch.zeros(8, dtype=torch.int32, device=dev)
         self.assign_stale = None
         self._L = _abi.lib()
@@ -175,7 +179,8 @@ class DeviceKMeans(object):
         check(self._L.segk_kmeans_prepare(self._ctx, self._cp(), C.byref(self.m), _abi.stream()))
 
     def score_rows(self, ids=None, row0=0, n=None):
-        """A1 filter stage over rows (device int32 tensor `ids`, or the range row0..row0+n)."""
+        """A1 over rows (device int32 tensor `ids`, or the range row0..row0+n): afterwards
+        cand_k / cand_s hold np.argmax / np.max of neg_sqrd_norm for those rows."""
         if ids is not None:
             n = ids.numel()
             p = ptr(ids)
@@ -183,25 +188,24 @@ class DeviceKMeans(object):
             p = None
             n = self.corpus.n_emb - row0 if n is None else n
         check(self._L.segk_kmeans_score(self._ctx, self._cp(), C.byref(self.m), p, int(row0), int(n),
-                                        ptr(self.cand_k), ptr(self.cand_f), ptr(self.cand_s), _abi.stream()))
+                                        C.byref(self.cand), ptr(self.status), _abi.stream()))
 
     def score_ptr(self, ids_ptr, n):
         check(self._L.segk_kmeans_score(self._ctx, self._cp(), C.byref(self.m), C.c_void_p(ids_ptr), 0, int(n),
-                                        ptr(self.cand_k), ptr(self.cand_f), ptr(self.cand_s), _abi.stream()))
+                                        C.byref(self.cand), ptr(self.status), _abi.stream()))
 
     def exact_max(self, ids):
-        """np.max / np.argmax of neg_sqrd_norm for rows `ids` (host ints) -> (float64[n], int32[n])."""
+        """np.max / np.argmax of neg_sqrd_norm for rows `ids` (host ints) ->
+        (float64[n], int32[n], number of rows that needed the full scan)."""
         torch = _torch()
         ids_t = to_dev(ids, np.int32)
         n = ids_t.numel()
         out_max = torch.empty(n, dtype=torch.float64, device=ids_t.device)
         out_arg = torch.empty(n, dtype=torch.int32, device=ids_t.device)
-        nb = torch.zeros(1, dtype=torch.int32, device=ids_t.device)
         self.score_rows(ids_t)
         check(self._L.segk_kmeans_exact_max(self._ctx, self._cp(), C.byref(self.m), ptr(ids_t), n,
-                                            ptr(self.cand_k), ptr(self.cand_f), ptr(self.cand_s), ptr(out_max), ptr(out_arg),
-                                            ptr(nb), _abi.stream()))
-        return out_max.cpu().numpy(), out_arg.cpu().numpy(), int(nb.item())
+                                            C.byref(self.cand), ptr(out_max), ptr(out_arg), _abi.stream()))
+        return out_max.cpu().numpy(), out_arg.cpu().numpy(), int(self.cand_count.item())
 
     def neg_sqrd_norm(self, row):
         torch = _torch()
@@ -250,7 +254,7 @@ class DeviceKMeans(object):
             n = c.n_utt - utt0 if n_utts is None else n_utts
         check(self._L.segk_kmeans_segment(
             self._ctx, self._cp(), C.byref(self.m), up, int(utt0), int(n), int(n_slices_min), int(n_slices_max),
-            float(wip), ptr(self.cand_k), ptr(self.cand_f), ptr(self.cand_s), ptr(boundaries), ptr(self.old_tok),
+            float(wip), C.byref(self.cand), ptr(boundaries), ptr(self.old_tok),
             ptr(self.new_tok), ptr(self.new_k), ptr(self.n_old), ptr(self.n_new), ptr(self.n_flag),
             ptr(self.out_total), ptr(self.status), _abi.stream()))
 

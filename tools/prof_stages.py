@@ -84,6 +84,29 @@ def main():
     for name, fn in stages:
         med, mn = timeit(fn, reps=5, warm=1)
         print("%-10s median %.3f ms  min %.3f ms" % (name, med, mn))
+    # batch statistics stages one by one (state left as the last full sweep produced it)
+    def collect():
+        check(L.segk_kmeans_batch_collect(ctx, cp, mp, pt.utt_lo, pt.utt_hi, ptr(dk.new_k), ptr(dk.n_new),
+                                          ptr(dk.n_flag), ptr(dk.tok_off), ptr(sw.flag), sw.cap, st))
+
+    def assign():
+        check(L.segk_kmeans_batch_assign(ctx, cp, mp, pt.utt_lo, pt.utt_hi, ptr(sw.flag_all), pt.world, pt.rank,
+                                         sw.cap, ptr(dk.new_tok), ptr(dk.new_k), ptr(dk.n_new), ptr(dk.tok_off),
+                                         ptr(dk.ctok_id), ptr(dk.ctok_k), ptr(dk.status), st))
+
+    def partials():
+        check(L.segk_kmeans_batch_partials(ctx, cp, mp, ptr(sw.blk_lo), pt.nbl, pt.utt_lo, ptr(dk.tok_off),
+                                           ptr(dk.ctok_id), ptr(dk.ctok_k), ptr(dk.out_total), sw._p_sum,
+                                           sw._p_cnt, sw._p_tot, st))
+    for name, fn in [("collect", collect), ("assign", assign), ("partials", partials)]:
+        med, mn = timeit(fn, reps=5, warm=1)
+        print("%-10s median %.3f ms  min %.3f ms" % (name, med, mn))
+    for dbg in (1, 2, 4, 7):       # timing-only ablations inside the partials kernel
+        os.environ["SEGK_PART_DBG"] = str(dbg)
+        med, mn = timeit(partials, reps=5, warm=1)
+        print("partials dbg=%d median %.3f ms" % (dbg, med))
+    os.environ["SEGK_PART_DBG"] = "0"
+    partials()
     med, mn = timeit(lambda: seg.batch_sweep_async(), reps=10, warm=2)
     print("full sweep: median %.3f ms  min %.3f ms" % (med, mn))
     t0 = time.perf_counter()
