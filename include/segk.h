@@ -129,6 +129,17 @@ int32_t segk_kmeans_score(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans
                           const int32_t *ids, int64_t row0, int64_t n, const segk_cand *cand,
                           int32_t *status, void *stream);
 
+/* The three steps of segk_kmeans_score as separate calls (same arguments), for callers that
+ * want to time or overlap them: clear_queue (cand->count = 0), filter (kernel 1), resolve
+ * (kernels 2 and 3). */
+int32_t segk_kmeans_clear_queue(segk_ctx *ctx, const segk_cand *cand, void *stream);
+int32_t segk_kmeans_filter(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m,
+                           const int32_t *ids, int64_t row0, int64_t n, const segk_cand *cand,
+                           void *stream);
+int32_t segk_kmeans_resolve(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m,
+                            const int32_t *ids, int64_t row0, int64_t n, const segk_cand *cand,
+                            int32_t *status, void *stream);
+
 /* Gather of the A1 results for rows ids[0..n) (0..n-1 when NULL): out_max[r] (double, widened
  * from the dtype of X) and out_arg[r] = np.max / np.argmax of neg_sqrd_norm(ids[r])
  * (kmeans_components.py:228-232), from a `cand` filled by segk_kmeans_score. */

@@ -994,3 +994,207 @@ class UnigramAcousticWordseg(object):
     def get_unsup_transcript_i(self, i):
         return list(self.acoustic_model.components.get_assignments(
             self.utterances.get_segmented_embeds_i(i)))
+
+
+# --------------------------------------------------------------------------- #
+# Bigram variant (config 5): BigramSmoothLM (bigram_lms.py:17-114), BigramFBGMM
+# (bigram_fbgmm.py:19-100), BigramAcousticWordseg (bigram_acoustic_wordseg.py:32-725).
+# Only fb_type="unigram" works in the reference (the bigram DP is a stub, :694-695).
+# --------------------------------------------------------------------------- #
+class BigramSmoothLM(object):
+    def __init__(self, intrp_lambda, a, b, K):
+        self.intrp_lambda, self.a, self.b, self.K = intrp_lambda, a, b, K
+        self.unigram_counts = np.zeros(K, np.int64)
+        self.bigram_counts = np.zeros((K, K), np.int64)
+
+    def prob_i(self, i):
+        return (self.unigram_counts[i] + float(self.a) / self.K) / (int(np.sum(self.unigram_counts)) + self.a)
+
+    def prob_i_given_j(self, i, j):
+        p = (self.bigram_counts[j, i] + float(self.b) / self.K) / (self.unigram_counts[j] + float(self.b))
+        return self.intrp_lambda * self.prob_i(i) + (1 - self.intrp_lambda) * p
+
+    def log_prob_vec_i(self):                                         # :64-69
+        return (np.log(self.unigram_counts + float(self.a) / self.K)
+                - np.log(int(np.sum(self.unigram_counts)) + self.a))
+
+    def prob_vec_i(self):
+        return (self.unigram_counts + float(self.a) / self.K) / (int(np.sum(self.unigram_counts)) + self.a)
+
+    def prob_vec_given_j(self, j):                                    # :84-91
+        return (self.intrp_lambda * self.prob_vec_i() + (1 - self.intrp_lambda)
+                * (self.bigram_counts[j, :] + float(self.b) / self.K) / (self.unigram_counts[j] + float(self.b)))
+
+    def counts_from_utterance(self, utterance):                       # :98-105
+        j_prev = None
+        for i_cur in utterance:
+            self.unigram_counts[i_cur] += 1
+            if j_prev is not None:
+                self.bigram_counts[j_prev, i_cur] += 1
+            j_prev = i_cur
+
+    def remove_counts_from_utterance(self, utterance):                # :107-114
+        j_prev = None
+        for i_cur in utterance:
+            self.unigram_counts[i_cur] -= 1
+            if j_prev is not None:
+                self.bigram_counts[j_prev, i_cur] -= 1
+            j_prev = i_cur
+
+
+class BigramFBGMM(object):
+    def __init__(self, X, prior, K, assignments="rand", covariance_type="fixed", lms=1.0, lm=None):
+        self.prior, self.covariance_type, self.lms = prior, covariance_type, lms
+        N = X.shape[0]
+        if isinstance(assignments, str) and assignments == "rand":
+            assignments = np.random.randint(0, K, N)
+        elif isinstance(assignments, str) and assignments == "each-in-own":
+            assignments = np.arange(N)
+        assignments = consecutive_labels(np.asarray(assignments))
+        if covariance_type == "diag":
+            self.components = GaussianComponentsDiag(X, prior, assignments, K_max=K)
+        elif covariance_type == "fixed":
+            self.components = GaussianComponentsFixedVar(X, prior, assignments, K_max=K, lm=lm)
+        else:
+            raise ValueError("full covariance is outside the hot-path scope")
+
+    def log_prob_X_given_z(self):
+        return self.components.log_marg()
+
+    def get_n_assigned(self):
+        return len(np.where(self.components.assignments != -1)[0])
+
+
+class BigramAcousticWordseg(object):
+    def __init__(self, am_K, am_param_prior, lm_params, embedding_mats, vec_ids_dict, durations_dict,
+                 landmarks_dict, seed_boundaries_dict=None, seed_assignments_dict=None, covariance_type="fixed",
+                 n_slices_min=0, n_slices_max=20, min_duration=0, p_boundary_init=0.5, beta_sent_boundary=2.0,
+                 lms=1., wip=0., fb_type="bigram", init_am_assignments="rand", time_power_term=1.):
+        assert seed_assignments_dict is None
+        assert fb_type == "unigram", "the bigram DP is a stub in the reference"
+        self.n_slices_min, self.n_slices_max = n_slices_min, n_slices_max
+        self.beta_sent_boundary, self.wip, self.lms = beta_sent_boundary, wip, lms
+        self.time_power_term, self.fb_type = time_power_term, fb_type
+        embeddings, vec_ids, labels = process_embeddings(embedding_mats, vec_ids_dict)
+        self.ids_to_utterance_labels = labels
+        N = embeddings.shape[0]
+        seeds = [seed_boundaries_dict[i] for i in labels] if seed_boundaries_dict is not None else None
+        self.utterances = Utterances(
+            [len(landmarks_dict[i]) for i in labels], vec_ids, [durations_dict[i] for i in labels],
+            [landmarks_dict[i] for i in labels], seed_boundaries=seeds, p_boundary_init=p_boundary_init,
+            n_slices_min=n_slices_min, n_slices_max=n_slices_max, min_duration=min_duration)
+        init = []
+        for i in range(self.utterances.D):
+            init.extend(self.utterances.get_segmented_embeds_i(i))
+        init = np.array(init, dtype=int)
+        init = init[np.where(init != -1)]
+        assert lm_params["type"] == "smooth"
+        self.lm = BigramSmoothLM(lm_params["intrp_lambda"], lm_params["a"], lm_params["b"], am_K)
+        assignments = -1 * np.ones(N, dtype=int)
+        assert init_am_assignments == "rand"
+        assignments[init] = consecutive_labels(np.random.randint(0, am_K, len(init)))
+        self.acoustic_model = BigramFBGMM(embeddings, am_param_prior, am_K, assignments,
+                                          covariance_type=covariance_type, lms=lms, lm=self.lm)
+        for i_utt in range(self.utterances.D):                         # set_lm_counts :271-276
+            self.lm.counts_from_utterance(self.get_unsup_transcript_i(i_utt))
+
+    def get_unsup_transcript_i(self, i):
+        return list(self.acoustic_model.components.get_assignments(self.utterances.get_segmented_embeds_i(i)))
+
+    def log_prob_z(self):                                               # :287-305
+        tmp = BigramSmoothLM(self.lm.intrp_lambda, self.lm.a, self.lm.b, self.lm.K)
+        lp = 0.
+        for i_utt in range(self.utterances.D):
+            j_prev = None
+            for i_cur in self.get_unsup_transcript_i(i_utt):
+                if j_prev is not None:
+                    lp += np.log(tmp.prob_i_given_j(i_cur, j_prev))
+                    tmp.bigram_counts[j_prev, i_cur] += 1
+                else:
+                    lp += np.log(tmp.prob_i(i_cur))
+                tmp.unigram_counts[i_cur] += 1
+                # NB: the reference never updates j_prev here (:298-304), so the bigram branch is
+                # dead code and this is a unigram predictive likelihood -- kept as is.
+        return lp
+
+    def log_marg(self):
+        return self.log_prob_z() + self.acoustic_model.log_prob_X_given_z()
+
+    def log_marg_i_embed_unigram(self, e):                              # :314-329
+        c = self.acoustic_model.components
+        z = self.lms * self.lm.log_prob_vec_i()
+        z[:c.K] += c.log_post_pred(e)
+        z[c.K:] += c.log_prior(e)
+        return logsumexp(z)
+
+    def gibbs_sample_inside_loop_i_embed(self, e, j_prev=None, anneal_temp=1, u=None):   # :332-384
+        c = self.acoustic_model.components
+        if j_prev is not None:
+            z = np.log(self.lm.prob_vec_given_j(j_prev))
+        else:
+            z = self.lm.log_prob_vec_i()
+        z = z * self.lms
+        z[:c.K] += c.log_post_pred(e)
+        z[c.K:] += c.log_prior(e)
+        if anneal_temp != 1:
+            z = z - logsumexp(z)
+            za = 1. / anneal_temp * z - logsumexp(1. / anneal_temp * z)
+            p = np.exp(za)
+        else:
+            p = np.exp(z - logsumexp(z))
+        k = draw(p, u)
+        if k > c.K:
+            k = c.K
+        c.add_item(e, k)
+        return k
+
+    def get_vec_embed_log_probs(self, vec_ids, durations):             # :673-692
+        out = -np.inf * np.ones(len(vec_ids))
+        for j, e in enumerate(vec_ids):
+            if e == -1:
+                continue
+            out[j] = self.log_marg_i_embed_unigram(e)
+            if np.isnan(durations[j]):
+                out[j] = -np.inf
+            else:
+                out[j] *= durations[j] ** self.time_power_term
+        return out + self.wip
+
+    def gibbs_sample_i(self, i, anneal_temp=1, anneal_gibbs_am=False, uniforms=None):   # :386-551
+        u, am = self.utterances, self.acoustic_model
+        self.lm.remove_counts_from_utterance(self.get_unsup_transcript_i(i))
+        for e in u.get_segmented_embeds_i(i):
+            if e == -1:
+                continue
+            am.components.del_item(e)
+        N = u.lengths[i]
+        tri = (N * N + N) // 2
+        vec = self.get_vec_embed_log_probs(u.vec_ids[i, :tri], u.durations[i, :tri])
+        assert self.beta_sent_boundary == -1
+        log_prob, u.boundaries[i, :N] = forward_backward(
+            vec, 0.0, N, self.n_slices_min, self.n_slices_max, i, anneal_temp, uniforms=uniforms)
+        j_prev = None
+        for e in u.get_segmented_embeds_i(i):
+            if e == -1:
+                continue
+            j_prev = self.gibbs_sample_inside_loop_i_embed(
+                e, j_prev, anneal_temp if anneal_gibbs_am else 1, None if uniforms is None else next(uniforms))
+        self.lm.counts_from_utterance(self.get_unsup_transcript_i(i))
+        return log_prob
+
+    def gibbs_sample(self, n_iter, anneal_temp=1):                      # :553-671
+        rec = {"log_marg": [], "log_marg*length": [], "log_prob_z": [], "log_prob_X_given_z": [],
+               "components": [], "n_tokens": []}
+        for _ in range(n_iter):
+            order = list(range(self.utterances.D))
+            _shuffle(order)
+            lp = 0
+            for i_utt in order:
+                lp += self.gibbs_sample_i(i_utt, anneal_temp)
+            rec["log_marg"].append(self.log_marg())
+            rec["log_marg*length"].append(lp)
+            rec["log_prob_z"].append(self.log_prob_z())
+            rec["log_prob_X_given_z"].append(self.acoustic_model.log_prob_X_given_z())
+            rec["components"].append(self.acoustic_model.components.K)
+            rec["n_tokens"].append(self.acoustic_model.get_n_assigned())
+        return rec

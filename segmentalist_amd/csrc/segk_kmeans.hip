@@ -1606,18 +1606,33 @@ int32_t segk_kmeans_prepare(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m,
     return SEGK_OK;
 }
 
-int32_t segk_kmeans_score(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m, const int32_t *ids,
-                          int64_t row0, int64_t n, const segk_cand *cand, int32_t *status, void *stream)
+static int score_checks(const segk_corpus *c, const segk_kmeans *m, const int32_t *ids, int64_t row0, int64_t n,
+                        const segk_cand *cand)
 {
-    (void)ctx;
     int rc = check_corpus(c);
     if (rc) return rc;
     SEGK_REQUIRE(m && m->tiles && cand && cand->k && cand->f && cand->s && cand->queue && cand->count && c->X32,
                  "score operands");
     SEGK_REQUIRE(ids != nullptr || (row0 >= 0 && row0 + n <= c->n_emb), "row range");
+    return SEGK_OK;
+}
+
+int32_t segk_kmeans_clear_queue(segk_ctx *ctx, const segk_cand *cand, void *stream)
+{
+    (void)ctx;
+    SEGK_REQUIRE(cand && cand->count, "cand");
+    SEGK_CHECK_HIP(hipMemsetAsync(cand->count, 0, sizeof(int32_t), (hipStream_t)stream));
+    return SEGK_OK;
+}
+
+int32_t segk_kmeans_filter(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m, const int32_t *ids,
+                           int64_t row0, int64_t n, const segk_cand *cand, void *stream)
+{
+    (void)ctx;
+    int rc = score_checks(c, m, ids, row0, n, cand);
+    if (rc) return rc;
     if (n <= 0) return SEGK_OK;
     hipStream_t st = (hipStream_t)stream;
-    SEGK_CHECK_HIP(hipMemsetAsync(cand->count, 0, sizeof(int32_t), st));
     ScoreArgs A;
     A.X32 = c->X32; A.ld32 = c->ld32; A.ids = ids; A.row0 = row0; A.n = n;
     A.tiles = m->tiles; A.n_tiles = segk_n_tiles(m->K_max); A.tile_stride = segk_tile_stride(c->D);
@@ -1630,35 +1645,50 @@ int32_t segk_kmeans_score(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans
     // and drift apart, covering each other's barrier/staging gaps.  (Measured: an 8-wave
     // workgroup, one barrier for all eight waves, locks the SIMD partners in step and is 15 %
     // slower although it halves the staging instructions per wave.)
-    const int GB = segk_gmax(c->D);
-    rc = SEGK_ERR_UNSUPPORTED;
-    switch (GB) {
+    switch (segk_gmax(c->D)) {
 #define SEGK_CASE(g, nb) \
-    case g: rc = launch_score<g, nb, 4>(A, st); break;
+    case g: return launch_score<g, nb, 4>(A, st);
         SEGK_CASE(1, 2) SEGK_CASE(2, 2) SEGK_CASE(4, 2) SEGK_CASE(6, 2) SEGK_CASE(8, 2) SEGK_CASE(10, 2)
         SEGK_CASE(13, 2) SEGK_CASE(16, 2) SEGK_CASE(20, 2) SEGK_CASE(25, 2) SEGK_CASE(26, 2) SEGK_CASE(28, 2)
         SEGK_CASE(32, 2) SEGK_CASE(33, 2) SEGK_CASE(34, 2) SEGK_CASE(40, 1) SEGK_CASE(50, 1) SEGK_CASE(64, 1)
         SEGK_CASE(75, 1) SEGK_CASE(100, 1)
 #undef SEGK_CASE
-        default:
-            segk_set_error("segk_kmeans_score: D=%d > 400 is not supported by the register-resident score kernel",
-                           c->D);
-            return SEGK_ERR_UNSUPPORTED;
+        default: break;
     }
+    segk_set_error("segk_kmeans_filter: D=%d > 400 is not supported by the register-resident score kernel", c->D);
+    return SEGK_ERR_UNSUPPORTED;
+}
+
+int32_t segk_kmeans_resolve(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m, const int32_t *ids,
+                            int64_t row0, int64_t n, const segk_cand *cand, int32_t *status, void *stream)
+{
+    (void)ctx;
+    int rc = score_checks(c, m, ids, row0, n, cand);
     if (rc) return rc;
-    if (!A.fuse_exact)
+    if (n <= 0) return SEGK_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const bool fused = (c->x_dtype == SEGK_F32 && c->D >= 8 && c->D <= 128);
+    if (!fused)
         DISPATCH_XT(c, hipLaunchKernelGGL(k_kmeans_exact_fill<XT>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
                                            *c, *m, ids, row0, n, *cand););
-    {
-        const int nt = 256;
-        size_t xsz = (c->x_dtype == SEGK_F32 ? 4 : 8) * (size_t)((c->D + 1) & ~1);
-        size_t lds = nt * sizeof(double) + xsz + nt * sizeof(int32_t);
-        int64_t grid = n < 1024 ? n : 1024;
-        DISPATCH_XT(c, hipLaunchKernelGGL(k_kmeans_brute<XT>, dim3((unsigned)grid), dim3(nt), lds, st, *c, *m, *cand,
-                                           (int)c->n_emb, status ? status + 1 : nullptr););
-    }
+    const int nt = 256;
+    size_t xsz = (c->x_dtype == SEGK_F32 ? 4 : 8) * (size_t)((c->D + 1) & ~1);
+    size_t lds = nt * sizeof(double) + xsz + nt * sizeof(int32_t);
+    int64_t grid = n < 1024 ? n : 1024;
+    DISPATCH_XT(c, hipLaunchKernelGGL(k_kmeans_brute<XT>, dim3((unsigned)grid), dim3(nt), lds, st, *c, *m, *cand,
+                                       (int)c->n_emb, status ? status + 1 : nullptr););
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;
+}
+
+int32_t segk_kmeans_score(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m, const int32_t *ids,
+                          int64_t row0, int64_t n, const segk_cand *cand, int32_t *status, void *stream)
+{
+    int rc = segk_kmeans_clear_queue(ctx, cand, stream);
+    if (rc) return rc;
+    rc = segk_kmeans_filter(ctx, c, m, ids, row0, n, cand, stream);
+    if (rc) return rc;
+    return segk_kmeans_resolve(ctx, c, m, ids, row0, n, cand, status, stream);
 }
 
 int32_t segk_kmeans_exact_max(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m, const int32_t *ids,

@@ -352,11 +352,15 @@ class KMeansBatchSweeper(object):
         dk, pt = self.dk, self.part
         L, ctx, cp, mp, st = dk._L, dk._ctx, dk._cp(), C.byref(dk.m), _abi.stream()
         if self.score_events is not None:
+            # the events bracket exactly the MFMA filter kernel on its launch stream
             torch = _torch()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            nrow = pt.row_hi - pt.row_lo
+            check(L.segk_kmeans_clear_queue(ctx, C.byref(dk.cand), st))
             e0.record()
-            dk.score_rows(row0=pt.row_lo, n=pt.row_hi - pt.row_lo)
+            check(L.segk_kmeans_filter(ctx, cp, mp, None, pt.row_lo, nrow, C.byref(dk.cand), st))
             e1.record()
+            check(L.segk_kmeans_resolve(ctx, cp, mp, None, pt.row_lo, nrow, C.byref(dk.cand), ptr(dk.status), st))
             self.score_events.append((e0, e1))
         else:
             dk.score_rows(row0=pt.row_lo, n=pt.row_hi - pt.row_lo)

@@ -118,6 +118,17 @@ UNIGRAM_CHAINS = [
 ]
 
 
+# (name, n_utt, D, K, seed, ragged, N, n_slices_max, dtype, cov).  Only "fixed": the reference's
+# del_component rewires the LM counts for fixed-variance components only
+# (gaussian_components_fixedvar.py:204-221); with "diag" its LM counts go negative and it asserts.
+BIGRAM_CHAINS = [
+    ("bg_fixed", 6, 6, 5, 41, True, 0, 4, "float32", "fixed"),
+    ("bg_fixed_mid", 16, 10, 8, 42, True, 0, 6, "float32", "fixed"),
+    ("bg_fixed_k", 10, 8, 12, 43, True, 0, 5, "float32", "fixed"),
+]
+BIGRAM_LM = {"type": "smooth", "intrp_lambda": 0.1, "a": 0.5, "b": 0.5}
+
+
 def chain_corpus(n_utt, D, K, seed, ragged, N, n_slices_max, dtype):
     import os
     import sys

@@ -20,11 +20,12 @@ import cases  # noqa: E402
 scratch = sys.argv[1] if len(sys.argv) > 1 else "/tmp/segk_ref"
 sys.path.insert(0, scratch)
 
-from segmentalist import (fbgmm, gaussian_components_diag, gaussian_components_fixedvar,  # noqa: E402
+from segmentalist import (bigram_acoustic_wordseg, fbgmm, gaussian_components_diag, gaussian_components_fixedvar,  # noqa: E402
                           kmeans, kmeans_acoustic_wordseg, kmeans_components, niw,
                           unigram_acoustic_wordseg, _cython_utils)
 
 unigram_acoustic_wordseg.i_debug_monitor = -1
+bigram_acoustic_wordseg.i_debug_monitor = -1
 kmeans_acoustic_wordseg.i_debug_monitor = -1
 
 
@@ -276,6 +277,46 @@ def gen_chains():
     print("chains.npz:", len(out), "arrays")
 
 
+# ----------------------------------------------------------------------------- bigram chains (config 5)
+def gen_bigram():
+    out = {}
+    for name, n_utt, D, K, seed, ragged, N, nmax, dtype, cov in cases.BIGRAM_CHAINS:
+        corpus = cases.chain_corpus(n_utt, D, K, seed, ragged, N, nmax, dtype)
+        random.seed(1)
+        np.random.seed(1)
+        if cov == "fixed":
+            prior = gaussian_components_fixedvar.FixedVarPrior(*cases.fixed_prior_params(D))
+        else:
+            prior = niw.NIW(*cases.diag_prior_params(D))
+        seg = bigram_acoustic_wordseg.BigramAcousticWordseg(
+            K, prior, dict(cases.BIGRAM_LM), *corpus, covariance_type=cov, n_slices_min=0, n_slices_max=nmax,
+            p_boundary_init=0.5, beta_sent_boundary=-1, lms=1.0, wip=0.0, fb_type="unigram",
+            init_am_assignments="rand", time_power_term=1.0)
+        c = seg.acoustic_model.components
+        out[name + "_init_bounds"] = seg.utterances.boundaries.copy()
+        out[name + "_init_assign"] = c.assignments.copy()
+        out[name + "_init_unigram"] = seg.lm.unigram_counts.copy()
+        out[name + "_init_bigram"] = seg.lm.bigram_counts.copy()
+        bounds, assigns, unis, bis = [], [], [], []
+        rec_all = {}
+        for it in range(4):
+            rec = seg.gibbs_sample(1)
+            for k, v in rec.items():
+                rec_all.setdefault(k, []).extend(v)
+            bounds.append(seg.utterances.boundaries.copy())
+            assigns.append(c.assignments.copy())
+            unis.append(seg.lm.unigram_counts.copy())
+            bis.append(seg.lm.bigram_counts.copy())
+        out[name + "_bounds"] = np.stack(bounds)
+        out[name + "_assign"] = np.stack(assigns)
+        out[name + "_unigram"] = np.stack(unis)
+        out[name + "_bigram"] = np.stack(bis)
+        for k in ["log_marg", "log_marg*length", "log_prob_z", "log_prob_X_given_z", "components", "n_tokens"]:
+            out[name + "_rec_" + k] = np.array(rec_all[k])
+    np.savez_compressed(os.path.join(HERE, "bigram.npz"), **out)
+    print("bigram.npz:", len(out), "arrays")
+
+
 # ----------------------------------------------------------------------------- notebook (config 1)
 def gen_notebook():
     """examples/clustering_examples.ipynb cells, with the python-2 shuffle."""
@@ -330,6 +371,7 @@ if __name__ == "__main__":
     gen_kernels()
     gen_gauss()
     gen_chains()
+    gen_bigram()
     gen_notebook()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):

@@ -395,3 +395,50 @@ def test_batch_sweep_equals_sequential_for_single_utterance(golden):
         assert np.array_equal(a.acoustic_model.components.assignments,
                               b.acoustic_model.components.assignments)
         assert a.acoustic_model.components.K == b.acoustic_model.components.K
+
+
+# ------------------------------------------------------------------ chains: bigram driver (config 5)
+@pytest.mark.parametrize("chain", cases.BIGRAM_CHAINS, ids=[c[0] for c in cases.BIGRAM_CHAINS])
+def test_bigram_wordseg_chain_matches_reference(golden, chain):
+    g = golden("bigram")
+    name, n_utt, D, K, seed, ragged, N, nmax, dtype, cov = chain
+    corpus = cases.chain_corpus(n_utt, D, K, seed, ragged, N, nmax, dtype)
+    random.seed(1)
+    np.random.seed(1)
+    no.set_shuffle("py3")
+    prior = no.FixedVarPrior(*cases.fixed_prior_params(D))
+    seg = no.BigramAcousticWordseg(K, prior, dict(cases.BIGRAM_LM), *corpus, covariance_type=cov,
+                                   n_slices_min=0, n_slices_max=nmax, p_boundary_init=0.5,
+                                   beta_sent_boundary=-1, lms=1.0, wip=0.0, fb_type="unigram",
+                                   init_am_assignments="rand", time_power_term=1.0)
+    c = seg.acoustic_model.components
+    assert np.array_equal(seg.utterances.boundaries, g[name + "_init_bounds"])
+    assert np.array_equal(c.assignments, g[name + "_init_assign"])
+    assert np.array_equal(seg.lm.unigram_counts, g[name + "_init_unigram"])
+    assert np.array_equal(seg.lm.bigram_counts, g[name + "_init_bigram"])
+    for it in range(4):
+        rec = seg.gibbs_sample(1)
+        assert np.array_equal(seg.utterances.boundaries, g[name + "_bounds"][it]), it
+        assert np.array_equal(c.assignments, g[name + "_assign"][it]), it
+        assert np.array_equal(seg.lm.unigram_counts, g[name + "_unigram"][it]), it
+        assert np.array_equal(seg.lm.bigram_counts, g[name + "_bigram"][it]), it
+        for k in ["log_marg", "log_marg*length", "log_prob_z", "log_prob_X_given_z"]:
+            npt.assert_allclose(rec[k][0], g[name + "_rec_" + k][it], rtol=1e-10, err_msg=k)
+        assert rec["components"][0] == g[name + "_rec_components"][it]
+
+
+def test_reference_test_bigram_lms():
+    """tests/test_bigram_lms.py:13-76 of the reference (closed-form checks)."""
+    lm = no.BigramSmoothLM(0.1, 1, 2, 5)
+    for utt in [[1, 1, 3, 4, 0], [4, 4], [1, 0, 2, 2, 2, 2, 3, 1], [3, 3, 1]]:
+        lm.counts_from_utterance(utt)
+    npt.assert_almost_equal(lm.prob_i_given_j(1, 3), 0.1 * lm.prob_i(1) + 0.9 * (2. + 2. / 5) / (4 + 2))
+    npt.assert_almost_equal(lm.prob_i(1), (5. + 1. / 5) / (18 + 1))
+    pv = lm.prob_vec_i()
+    pj = lm.prob_vec_given_j(3)
+    for i in range(5):
+        assert pv[i] == lm.prob_i(i)
+        npt.assert_almost_equal(pj[i], lm.prob_i_given_j(i, 3))
+        npt.assert_almost_equal(lm.log_prob_vec_i()[i], np.log(lm.prob_i(i)))
+    lm.remove_counts_from_utterance([3, 3, 1])
+    assert lm.unigram_counts.sum() == 15 and lm.bigram_counts[3, 3] == 0
