@@ -286,6 +286,14 @@ typedef struct segk_fbgmm {
     int64_t *counts;           /* [dev] [K_max]                                               */
     int32_t *assignments;      /* [dev] [n_emb]                                               */
     int32_t *K;                /* [dev] [1]                                                   */
+    /* optional bigram language model tied to the components (BigramSmoothLM, bigram_lms.py:17-47;
+     * passed to GaussianComponentsFixedVar as `lm`, gaussian_components_fixedvar.py:90): when
+     * lm_unigram != NULL the assignment prior of the Dirichlet-multinomial is replaced by the LM
+     * (bigram_acoustic_wordseg.py:314-384) and del_component rewires the LM counts
+     * (gaussian_components_fixedvar.py:204-221). */
+    int64_t *lm_unigram;       /* [dev] [K_max] or NULL                                       */
+    int64_t *lm_bigram;        /* [dev] [K_max, K_max]: (j, i) = count of i following j       */
+    double lm_lambda, lm_a, lm_b;
 } segk_fbgmm;
 
 /* Components __init__ from `assignments` (fixedvar:110-120 / diag:114-120): statistics summed in
@@ -298,7 +306,10 @@ int32_t segk_fbgmm_init_stats(segk_ctx *ctx, const segk_corpus *c, segk_fbgmm *f
  *   op 1: add_item(item, k)  (fixedvar:153-170 / diag:162-177)
  *   op 2: del_item(item)     (fixedvar:172-188 / diag:179-194; deletes the component when it
  *         empties: del_component fixedvar:190-221 / diag:196-213, swap-last compaction)
- *   op 4: del_component(k)                                                                 */
+ *   op 4: del_component(k)
+ *   op 5 / op 6: lm.remove_counts_from_utterance / lm.counts_from_utterance for the current
+ *         transcript of utterance `utt` (bigram_lms.py:98-114; bigram_acoustic_wordseg.py:410,496);
+ *         utt < 0: every utterance (set_lm_counts, bigram_acoustic_wordseg.py:271-276)          */
 int32_t segk_fbgmm_update(segk_ctx *ctx, const segk_corpus *c, segk_fbgmm *f, int32_t op,
                           int32_t utt, int64_t item, int32_t k, const uint8_t *boundaries,
                           void *stream);
@@ -320,7 +331,9 @@ int32_t segk_fbgmm_pred_vector(segk_ctx *ctx, const segk_corpus *c, const segk_f
  * (:759-864).  Backward sampling consumes ustream[*ucursor ...] (one value per emitted segment,
  * the reference's random.random() calls) and advances the device-resident cursor.
  *   new_tok [dev] int32 [n_utt, N_max], n_new [dev] int32 [n_utt], out_logprob [dev] double [n_utt]
- *   status bits: 8 uniform stream exhausted, 16 log_prob == -inf (the reference asserts, :753) */
+ *   status bits: 8 uniform stream exhausted, 16 log_prob == -inf (the reference asserts, :753)
+ * viterbi == 2: `assignments_only` of bigram_acoustic_wordseg.py:386-387 -- boundaries are kept,
+ * new_tok / n_new list the current segments and out_logprob[utt] = 0.                         */
 int32_t segk_unigram_segment(segk_ctx *ctx, const segk_corpus *c, int32_t utt, int32_t viterbi,
                              int32_t n_slices_min, int32_t n_slices_max, double wip,
                              double time_power_term, double log_p_continue, double anneal_temp,
@@ -330,9 +343,13 @@ int32_t segk_unigram_segment(segk_ctx *ctx, const segk_corpus *c, int32_t utt, i
 
 /* A10 for the new segments of one utterance, in order, statistics updated between segments:
  * gibbs_sample_inside_loop_i (fbgmm.py:422-463; one uniform per segment, utils.draw forward
- * order, `k > K -> K`) or map_assign_i (:465-494) when map_assign != 0.                     */
+ * order, `k > K -> K`) or map_assign_i (:465-494) when map_assign != 0.
+ * With an LM attached (f->lm_unigram != NULL): log_marg_i_embed_unigram and
+ * gibbs_sample_inside_loop_i_embed (bigram_acoustic_wordseg.py:314-384): the prior of the first
+ * segment is lms*lm.log_prob_vec_i(), of every later one lms*log(lm.prob_vec_given_j(k_prev)).
+ * j_prev: component of the segment preceding new_tok[utt][0], -1 = none (read only with an LM). */
 int32_t segk_fbgmm_assign(segk_ctx *ctx, const segk_corpus *c, segk_fbgmm *f, int32_t utt,
-                          int32_t map_assign, double anneal_temp, const int32_t *new_tok,
+                          int32_t map_assign, int32_t j_prev, double anneal_temp, const int32_t *new_tok,
                           const int32_t *n_new, const double *ustream, int64_t *ucursor,
                           int64_t ucap, int32_t *status, void *stream);
 

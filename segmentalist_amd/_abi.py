@@ -47,6 +47,8 @@ class FbgmmDev(C.Structure):
         ("k_0", C.c_double), ("v_0", C.c_double), ("prior_a", C.c_void_p), ("prior_b", C.c_void_p),
         ("prior_c", C.c_void_p), ("stat_a", C.c_void_p), ("stat_b", C.c_void_p), ("log_prod", C.c_void_p),
         ("pred", C.c_void_p), ("counts", C.c_void_p), ("assignments", C.c_void_p), ("K", C.c_void_p),
+        ("lm_unigram", C.c_void_p), ("lm_bigram", C.c_void_p), ("lm_lambda", C.c_double), ("lm_a", C.c_double),
+        ("lm_b", C.c_double),
     ]
 
 
@@ -93,7 +95,7 @@ SIGNATURES = {
     "segk_fbgmm_pred_vector": (_i32, [_P, _CP, _FP, _i64, _P, _P]),
     "segk_unigram_segment": (_i32, [_P, _CP, _i32, _i32, _i32, _i32, _f64, _f64, _f64, _f64, _P, _P, _P, _i64, _P,
                                     _P, _P, _P, _P, _P]),
-    "segk_fbgmm_assign": (_i32, [_P, _CP, _FP, _i32, _i32, _f64, _P, _P, _P, _P, _i64, _P, _P]),
+    "segk_fbgmm_assign": (_i32, [_P, _CP, _FP, _i32, _i32, _i32, _f64, _P, _P, _P, _P, _i64, _P, _P]),
     "segk_logsumexp": (_f64, [_P, _i64]),
     "segk_draw": (_i32, [_P, _i64, _f64]),
     "segk_sum_doubles": (_f64, [_P, _i64]),

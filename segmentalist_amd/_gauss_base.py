@@ -11,7 +11,7 @@ class _DeviceGaussianComponents(object):
     _cov_type = None
 
     def _setup(self, X, assignments, K_max, prior_a, prior_b, prior_c, k_0, v_0, alpha=1.0, lms=1.0,
-               _corpus=None):
+               _corpus=None, lm=None):
         self.X = X
         self.N, self.D = X.shape
         self.K_max = K_max
@@ -24,7 +24,7 @@ class _DeviceGaussianComponents(object):
             assert set(assignments).difference([-1]) == set(range(assignments.max() + 1))
         corpus = _corpus if _corpus is not None else DeviceCorpus(X)
         self.dev = DeviceFbgmm(corpus, self._cov_type, K_max, alpha, lms, prior_a, prior_b, prior_c, k_0, v_0,
-                               assignments)
+                               assignments, lm=lm)
 
     # state snapshots -------------------------------------------------------------------
     @property

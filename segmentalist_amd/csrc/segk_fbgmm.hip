@@ -113,6 +113,21 @@ __device__ void fb_del_component(const segk_corpus &c, const segk_fbgmm &f, int 
         f.log_prod[K] = 0.0;
         f.counts[K] = 0;
     }
+    if (f.lm_unigram) {          // gaussian_components_fixedvar.py:204-221, same statement order
+        const int KM = f.K_max;
+        __syncthreads();
+        if (k != K) {
+            if (tid == 0) f.lm_unigram[k] = f.lm_unigram[K];
+            for (int q = tid; q < KM; q += nt) f.lm_bigram[(int64_t)k * KM + q] = f.lm_bigram[(int64_t)K * KM + q];
+            __syncthreads();
+            for (int q = tid; q < KM; q += nt) f.lm_bigram[(int64_t)q * KM + k] = f.lm_bigram[(int64_t)q * KM + K];
+            __syncthreads();
+        }
+        if (tid == 0) f.lm_unigram[K] = 0;
+        for (int q = tid; q < KM; q += nt) f.lm_bigram[(int64_t)K * KM + q] = 0;
+        __syncthreads();
+        for (int q = tid; q < KM; q += nt) f.lm_bigram[(int64_t)q * KM + K] = 0;
+    }
     __syncthreads();
 }
 
@@ -230,6 +245,33 @@ __global__ void k_fbgmm_update(segk_corpus c, segk_fbgmm f, int op, int utt, int
         if (threadIdx.x == 0) shK = shK - 1;
         __syncthreads();
         fb_del_component<XT>(c, f, k_item, &shK);
+    } else if ((op == 5 || op == 6) && f.lm_unigram) {
+        // lm.remove_counts_from_utterance / lm.counts_from_utterance over the CURRENT transcript
+        // (bigram_lms.py:98-114): sequential integer updates, one thread
+        // integer adds commute, so utterances may go in parallel (utt < 0: the whole corpus,
+        // set_lm_counts, bigram_acoustic_wordseg.py:271-276)
+        const long long sgn = (op == 6) ? 1 : -1;
+        const int64_t triMax = (int64_t)c.N_max * (c.N_max + 1) / 2;
+        const int u_lo = utt < 0 ? (int)threadIdx.x : utt, u_hi = utt < 0 ? c.n_utt : utt + 1;
+        const int u_step = utt < 0 ? (int)blockDim.x : 1;
+        for (int u = u_lo; u < u_hi && (utt < 0 || threadIdx.x == 0); u += u_step) {
+            const int N = c.lengths[u];
+            const int32_t *vid = c.vec_ids + (int64_t)u * triMax;
+            const uint8_t *bnd = boundaries + (int64_t)u * c.N_max;
+            int jp = 0, kprev = -1;
+            for (int j = 0; j < N; j++)
+                if (bnd[j]) {
+                    int64_t id = vid[(j + 1) * j / 2 + jp];
+                    jp = j + 1;
+                    if (id < 0) id += c.n_emb;          // python assignments[-1]
+                    int k = f.assignments[id];
+                    if (k < 0) k += f.K_max;            // python unigram_counts[-1]
+                    atomicAdd((unsigned long long *)&f.lm_unigram[k], (unsigned long long)sgn);
+                    if (kprev >= 0)
+                        atomicAdd((unsigned long long *)&f.lm_bigram[(int64_t)kprev * f.K_max + k], (unsigned long long)sgn);
+                    kprev = k;
+                }
+        }
     }
     __syncthreads();
     if (threadIdx.x == 0) *f.K = shK;
@@ -287,26 +329,40 @@ __device__ double fb_log_prior(const segk_fbgmm &f, int D, const XT *x)
     }
 }
 
-// logits z[k], k < K_max, of embedding `e` into LDS (fbgmm.py:268-284 / :436-445).
-// with_norm: subtract lms*log(sum counts + alpha) (log_marg_i) ; with_lms 0 -> map_assign_i
+// logits z[k], k < K_max, of embedding `e` into LDS.  Assignment prior by `mode`:
+//   0  FBGMM.log_marg_i:   lms*(log(alpha/K_max + counts) - log(sum counts + alpha))   fbgmm.py:268-272
+//   1  gibbs_sample_inside_loop_i: lms*log(alpha/K_max + counts)                        fbgmm.py:436-440
+//   2  map_assign_i:       log(alpha/K_max + counts)                                    fbgmm.py:475-479
+//   3  LM unigram:         lms*lm.log_prob_vec_i()             bigram_lms.py:64-69 (scoring and first segment)
+//   4  LM bigram:          lms*log(lm.prob_vec_given_j(j_prev))                          bigram_lms.py:84-91
 template <typename XT>
-__device__ void fb_logits(const segk_corpus &c, const segk_fbgmm &f, int64_t e, int with_norm, int with_lms, XT *xrow,
+__device__ void fb_logits(const segk_corpus &c, const segk_fbgmm &f, int64_t e, int mode, int j_prev, XT *xrow,
                           double *z, double *red)
 {
     const int tid = threadIdx.x, nt = blockDim.x, D = c.D;
     const XT *X = (const XT *)c.X;
     const int K = *f.K;
+    const int KM = f.K_max;
     __syncthreads();
     for (int d = tid; d < D; d += nt) xrow[d] = X[e * c.ldx + d];
     double csum = 0.0;
-    for (int k = tid; k < f.K_max; k += nt) csum += (double)f.counts[k];
+    const int64_t *cnts = (mode >= 3) ? f.lm_unigram : f.counts;
+    for (int k = tid; k < KM; k += nt) csum += (double)cnts[k];
     const double total = block_sum(csum, red);          // exact: integer-valued
-    const double denom = with_norm ? log(total + f.alpha) : 0.0;
-    const double lms = with_lms ? f.lms : 1.0;
     double lprior = 0.0;
     bool have_prior = false;
-    for (int k = tid; k < f.K_max; k += nt) {
-        double v = lms * (log(f.alpha / (double)f.K_max + (double)f.counts[k]) - denom);
+    for (int k = tid; k < KM; k += nt) {
+        double v;
+        if (mode == 0) v = f.lms * (log(f.alpha / (double)KM + (double)f.counts[k]) - log(total + f.alpha));
+        else if (mode == 1) v = f.lms * log(f.alpha / (double)KM + (double)f.counts[k]);
+        else if (mode == 2) v = log(f.alpha / (double)KM + (double)f.counts[k]);
+        else if (mode == 3) v = (log((double)f.lm_unigram[k] + f.lm_a / (double)KM) - log(total + f.lm_a)) * f.lms;
+        else {
+            const double pi = ((double)f.lm_unigram[k] + f.lm_a / (double)KM) / (total + f.lm_a);
+            const double pij = (1. - f.lm_lambda) * ((double)f.lm_bigram[(int64_t)j_prev * KM + k] + f.lm_b / (double)KM)
+                               / ((double)f.lm_unigram[j_prev] + f.lm_b);
+            v = log(f.lm_lambda * pi + pij) * f.lms;
+        }
         if (k < K) v += fb_log_post_pred_k<XT>(f, D, k, xrow);
         else {
             if (!have_prior) { lprior = fb_log_prior<XT>(f, D, xrow); have_prior = true; }
@@ -327,7 +383,7 @@ __global__ void k_fbgmm_score(segk_corpus c, segk_fbgmm f, const int32_t *ids, i
     XT *xrow = (XT *)(red + blockDim.x);             // [D]
     const int64_t e = ids ? (int64_t)ids[blockIdx.x] : row0 + blockIdx.x;
     if (e < 0) return;
-    fb_logits<XT>(c, f, e, 1, 1, xrow, z, red);
+    fb_logits<XT>(c, f, e, f.lm_unigram ? 3 : 0, -1, xrow, z, red);
     double mx = NEG_INF_D;
     for (int k = threadIdx.x; k < f.K_max; k += blockDim.x) mx = z[k] > mx ? z[k] : mx;
     mx = block_max(mx, red);
@@ -364,6 +420,20 @@ __device__ double fb_logsumexp_seq(const double *a, int n)     // _cython_utils.
 // Single thread does the DP (N <= N_max landmarks, fp64, reference order); uniforms are taken
 // from ustream[*ucursor ...] and the cursor advanced (one per backward-sampling step).
 // ---------------------------------------------------------------------------------------
+// embedding ids of the segments the boundaries of one utterance select, -1 (no embedding) skipped
+// (unigram_acoustic_wordseg.py:340-342)
+__device__ int fb_collect_tokens(const int32_t *vid, const uint8_t *bnd, int N, int32_t *tok)
+{
+    int nn = 0, jp = 0;
+    for (int j = 0; j < N; j++)
+        if (bnd[j]) {
+            int id = vid[(j + 1) * j / 2 + jp];
+            if (id >= 0) tok[nn++] = id;
+            jp = j + 1;
+        }
+    return nn;
+}
+
 __global__ void k_unigram_segment(segk_corpus c, int utt, int viterbi, int n_min, int n_max, double wip,
                                   double time_power_term, double log_p_continue, double anneal_temp,
                                   const double *score, const double *ustream, int64_t *ucursor, int64_t ucap,
@@ -393,6 +463,11 @@ __global__ void k_unigram_segment(segk_corpus c, int utt, int viterbi, int n_min
     __syncthreads();
     if (threadIdx.x != 0) return;
     uint8_t *bnd = boundaries + (int64_t)utt * c.N_max;
+    if (viterbi == 2) {      // assignments_only (bigram_acoustic_wordseg.py:386-387,548-549): keep the boundaries
+        out_logprob[utt] = 0.0;
+        n_new[utt] = fb_collect_tokens(vid, bnd, N, new_tok + (int64_t)utt * c.N_max);
+        return;
+    }
     for (int j = 0; j < N; j++) { a[j] = 1.0; bnd[j] = 0; }
     bnd[N - 1] = 1;
     a[0] = 0.0;
@@ -480,21 +555,14 @@ __global__ void k_unigram_segment(segk_corpus c, int utt, int viterbi, int n_min
     if (!viterbi && total == NEG_INF_D) atomicOr(status, 16);      // unigram_acoustic_wordseg.py:753
     *ucursor = cur;
     out_logprob[utt] = total;
-    int nn = 0, jp = 0;
-    for (int j = 0; j < N; j++)
-        if (bnd[j]) {
-            int id = vid[(j + 1) * j / 2 + jp];
-            if (id >= 0) new_tok[(int64_t)utt * c.N_max + nn++] = id;      // -1 skipped (:340-342)
-            jp = j + 1;
-        }
-    n_new[utt] = nn;
+    n_new[utt] = fb_collect_tokens(vid, bnd, N, new_tok + (int64_t)utt * c.N_max);
 }
 
 // ---------------------------------------------------------------------------------------
 // A10 for the new segments of one utterance, in order (fbgmm.py:422-494).  One workgroup.
 // ---------------------------------------------------------------------------------------
 template <typename XT>
-__global__ void k_fbgmm_assign(segk_corpus c, segk_fbgmm f, int utt, int map_assign, double anneal_temp,
+__global__ void k_fbgmm_assign(segk_corpus c, segk_fbgmm f, int utt, int map_assign, int j_prev0, double anneal_temp,
                                const int32_t *new_tok, const int32_t *n_new, const double *ustream,
                                int64_t *ucursor, int64_t ucap, int32_t *status)
 {
@@ -502,15 +570,19 @@ __global__ void k_fbgmm_assign(segk_corpus c, segk_fbgmm f, int utt, int map_ass
     double *z = (double *)smem;                      // [K_max]
     double *red = z + f.K_max;                       // [nt]
     XT *xrow = (XT *)(red + blockDim.x);             // [D]
-    __shared__ int shK, sh_i, sh_k;
-    if (threadIdx.x == 0) shK = *f.K;
+    __shared__ int shK, sh_i, sh_k, sh_jprev;
+    if (threadIdx.x == 0) { shK = *f.K; sh_jprev = j_prev0; }
     __syncthreads();
     const int nn = n_new[utt];
     for (int t = 0; t < nn; t++) {
         const int64_t e = new_tok[(int64_t)utt * c.N_max + t];
         if (threadIdx.x == 0) *f.K = shK;            // fb_logits reads K from memory
         __syncthreads();
-        fb_logits<XT>(c, f, e, 0, map_assign ? 0 : 1, xrow, z, red);
+        {
+            int mode = map_assign ? 2 : 1;
+            if (f.lm_unigram) mode = (sh_jprev < 0) ? 3 : 4;
+            fb_logits<XT>(c, f, e, mode, sh_jprev, xrow, z, red);
+        }
         // scipy logsumexp: max-shift, sum, log
         double mx = NEG_INF_D;
         for (int k = threadIdx.x; k < f.K_max; k += blockDim.x) mx = z[k] > mx ? z[k] : mx;
@@ -554,6 +626,8 @@ __global__ void k_fbgmm_assign(segk_corpus c, segk_fbgmm f, int utt, int map_ass
         }
         __syncthreads();
         fb_add_item<XT>(c, f, e, sh_k, &shK, &sh_i, red);
+        if (threadIdx.x == 0) sh_jprev = sh_k;      // bigram_acoustic_wordseg.py:482-494
+        __syncthreads();
     }
     __syncthreads();
     if (threadIdx.x == 0) *f.K = shK;
@@ -661,7 +735,7 @@ int32_t segk_fbgmm_update(segk_ctx *ctx, const segk_corpus *c, segk_fbgmm *f, in
     (void)ctx;
     int rc = check_fb(c, f);
     if (rc) return rc;
-    SEGK_REQUIRE(op == 0 || op == 1 || op == 2 || op == 4, "op");
+    SEGK_REQUIRE(op == 0 || op == 1 || op == 2 || op == 4 || op == 5 || op == 6, "op");
     DISPATCH_XT(c, hipLaunchKernelGGL(k_fbgmm_update<XT>, dim3(1), dim3(256), 0, (hipStream_t)stream, *c, *f, op, utt,
                                        item, k, boundaries););
     SEGK_LAUNCH_CHECK();
@@ -738,7 +812,7 @@ int32_t segk_unigram_segment(segk_ctx *ctx, const segk_corpus *c, int32_t utt, i
 }
 
 int32_t segk_fbgmm_assign(segk_ctx *ctx, const segk_corpus *c, segk_fbgmm *f, int32_t utt, int32_t map_assign,
-                          double anneal_temp, const int32_t *new_tok, const int32_t *n_new,
+                          int32_t j_prev, double anneal_temp, const int32_t *new_tok, const int32_t *n_new,
                           const double *ustream, int64_t *ucursor, int64_t ucap, int32_t *status, void *stream)
 {
     (void)ctx;
@@ -752,7 +826,7 @@ int32_t segk_fbgmm_assign(segk_ctx *ctx, const segk_corpus *c, segk_fbgmm *f, in
             SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_fbgmm_assign<XT>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k_fbgmm_assign<XT>, dim3(1), dim3(nt), lds, (hipStream_t)stream, *c, *f, utt, map_assign,
-                           anneal_temp, new_tok, n_new, ustream, ucursor, ucap, status);
+                           j_prev, anneal_temp, new_tok, n_new, ustream, ucursor, ucap, status);
     });
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;

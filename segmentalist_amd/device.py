@@ -388,7 +388,8 @@ class DeviceFbgmm(object):
     """Device image of FBGMM + its Gaussian components (fixed-variance or diagonal), see
     include/segk.h `segk_fbgmm`."""
 
-    def __init__(self, corpus, cov_type, K_max, alpha, lms, prior_a, prior_b, prior_c, k_0, v_0, assignments):
+    def __init__(self, corpus, cov_type, K_max, alpha, lms, prior_a, prior_b, prior_c, k_0, v_0, assignments,
+                 lm=None):
         torch = _torch()
         dev = _dev()
         self.corpus = corpus
@@ -412,6 +413,12 @@ class DeviceFbgmm(object):
             prior_c=self.prior_c.data_ptr(), stat_a=self.stat_a.data_ptr(), stat_b=self.stat_b.data_ptr(),
             log_prod=self.log_prod.data_ptr(), pred=self.pred.data_ptr(), counts=self.counts.data_ptr(),
             assignments=self.assignments.data_ptr(), K=self.K.data_ptr())
+        self.lm = lm
+        if lm is not None:        # bigram_lms.BigramSmoothLM: its count tensors are tied to the components
+            assert lm.K == self.K_max and self.cov_type == 0
+            self.f.lm_unigram = lm._unigram.data_ptr()
+            self.f.lm_bigram = lm._bigram.data_ptr()
+            self.f.lm_lambda, self.f.lm_a, self.f.lm_b = float(lm.intrp_lambda), float(lm.a), float(lm.b)
         self.score = torch.zeros(c.n_emb, dtype=f64, device=dev)
         self.status = torch.zeros(8, dtype=torch.int32, device=dev)
         self._L = _abi.lib()
@@ -462,38 +469,52 @@ class DeviceFbgmm(object):
         o = out.cpu().numpy()
         return o[:int(self.K.item())].copy(), float(o[self.K_max])
 
-    def assign_item(self, i, u, anneal_temp=1.0, map_assign=False):
-        """gibbs_sample_inside_loop_i / map_assign_i for one row with the uniform `u`."""
+    def assign_item(self, i, u, anneal_temp=1.0, map_assign=False, j_prev=None):
+        """gibbs_sample_inside_loop_i / map_assign_i for one row with the uniform `u`; with an LM
+        attached gibbs_sample_inside_loop_i_embed given the previous component `j_prev`.
+        Returns the component the row went to."""
         self._tok1[0] = int(i)
         self._u1[0] = float(u)
         self._cur1.zero_()
         check(self._L.segk_fbgmm_assign(self._ctx, self._cp(), C.byref(self.f), 0, 1 if map_assign else 0,
-                                        float(anneal_temp), ptr(self._tok1), ptr(self._n1), ptr(self._u1),
-                                        ptr(self._cur1), 1, ptr(self.status), _abi.stream()))
+                                        -1 if j_prev is None else int(j_prev), float(anneal_temp),
+                                        ptr(self._tok1), ptr(self._n1), ptr(self._u1), ptr(self._cur1), 1,
+                                        ptr(self.status), _abi.stream()))
+        return int(self.assignments[int(i)].item())
 
     def set_uniform_stream(self, u):
         self.ustream = to_dev(u, np.float64)
         self.ucursor.zero_()
 
     def gibbs_utt(self, boundaries, i, viterbi, n_slices_min, n_slices_max, wip, time_power_term,
-                  log_p_continue, anneal_temp_fb, anneal_temp_am):
-        """gibbs_sample_i (unigram_acoustic_wordseg.py:252-360) for utterance i, enqueued
-        asynchronously: remove its segments, score its spans, sample boundaries, assign."""
+                  log_p_continue, anneal_temp_fb, anneal_temp_am, assignments_only=False, map_assign=None):
+        """gibbs_sample_i (unigram_acoustic_wordseg.py:252-360; with an LM attached
+        bigram_acoustic_wordseg.py:386-551) for utterance i, enqueued asynchronously: [remove its
+        LM counts,] remove its segments, score its spans, sample boundaries, assign[, add its LM
+        counts]."""
         c = self.corpus
         L, ctx, cp, fp, st = self._L, self._ctx, self._cp(), C.byref(self.f), _abi.stream()
         N = int(c.lengths_np[i])
         tri_i = N * (N + 1) // 2
+        if map_assign is None:
+            map_assign = viterbi
+        if self.lm is not None:
+            check(L.segk_fbgmm_update(ctx, cp, fp, 5, int(i), 0, 0, ptr(boundaries), st))
         check(L.segk_fbgmm_update(ctx, cp, fp, 0, int(i), 0, 0, ptr(boundaries), st))
-        check(L.segk_fbgmm_score(ctx, cp, fp, C.c_void_p(c.vec_ids.data_ptr() + 4 * i * c.tri), 0, tri_i,
-                                 ptr(self.score), st))
-        check(L.segk_unigram_segment(ctx, cp, int(i), 1 if viterbi else 0, int(n_slices_min), int(n_slices_max),
+        if not assignments_only:
+            check(L.segk_fbgmm_score(ctx, cp, fp, C.c_void_p(c.vec_ids.data_ptr() + 4 * i * c.tri), 0, tri_i,
+                                     ptr(self.score), st))
+        mode = 2 if assignments_only else (1 if viterbi else 0)
+        check(L.segk_unigram_segment(ctx, cp, int(i), mode, int(n_slices_min), int(n_slices_max),
                                      float(wip), float(time_power_term), float(log_p_continue),
                                      float(anneal_temp_fb), ptr(self.score), ptr(self.ustream), ptr(self.ucursor),
                                      self.ustream.numel(), ptr(boundaries), ptr(self.new_tok), ptr(self.n_new),
                                      ptr(self.out_logprob), ptr(self.status), st))
-        check(L.segk_fbgmm_assign(ctx, cp, fp, int(i), 1 if viterbi else 0, float(anneal_temp_am),
+        check(L.segk_fbgmm_assign(ctx, cp, fp, int(i), 1 if map_assign else 0, -1, float(anneal_temp_am),
                                   ptr(self.new_tok), ptr(self.n_new), ptr(self.ustream), ptr(self.ucursor),
                                   self.ustream.numel(), ptr(self.status), st))
+        if self.lm is not None:
+            check(L.segk_fbgmm_update(ctx, cp, fp, 6, int(i), 0, 0, ptr(boundaries), st))
 
     def check_status(self):
         st = int(self.status[0].item())

@@ -29,11 +29,9 @@ class GaussianComponentsFixedVar(_DeviceGaussianComponents):
         self.precision = 1. / np.asarray(prior.var, dtype=np.float64)
         self.mu_0 = np.asarray(prior.mu_0, dtype=np.float64)
         self.precision_0 = 1. / np.asarray(prior.var_0, dtype=np.float64)
-        self.lm = lm
-        if lm is not None:
-            raise NotImplementedError("language-model tied components (bigram) are not on the device path yet")
+        self.lm = lm          # bigram_lms.BigramSmoothLM whose counts follow del_component (:204-221)
         self._setup(X, assignments, K_max, self.precision, self.mu_0, self.precision_0, 0.0, 0.0, _alpha, _lms,
-                    _corpus)
+                    _corpus, lm=lm)
 
     # statistics (host snapshots, reference names)
     @property
