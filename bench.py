@@ -73,7 +73,7 @@ def main():
     ap.add_argument("--K", type=int, default=1000)
     ap.add_argument("--landmarks", type=int, default=20)
     ap.add_argument("--n-slices-max", type=int, default=6)
-    ap.add_argument("--cpu-utts", type=int, default=800, help="utterances timed for cpu_baseline (0 = skip)")
+    ap.add_argument("--cpu-utts", type=int, default=2500, help="utterances timed for cpu_baseline (0 = skip)")
     ap.add_argument("--no-events", action="store_true", help="do not bracket the score kernel with events")
     args = ap.parse_args()
 
@@ -153,11 +153,22 @@ def main():
             },
         }
         if score_ms is not None:
+            # HBM bytes per launch of the same kernel from the PMC passes committed under profiles/
+            # (collected in separate rocprofv3 --pmc runs, gfx950-corrected); only quoted for the
+            # workload they were measured on
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "score_kernel_traffic.json")
+            if os.path.exists(tpath):
+                tj = json.load(open(tpath))
+                wl = tj["workload"]
+                if (wl["utterances"], wl["landmarks_per_utt"], wl["n_slices_max"], wl["D"], wl["K"], wl["n_gpus"]) == \
+                        (args.utts, args.landmarks, args.n_slices_max, args.dim, args.K, world):
+                    traffic = tj["traffic_bytes_per_launch"]
             achieved = flops_per_launch / (score_ms * 1e-3) / 1e12
             out["roofline"] = {
                 "bound": "mfma", "kernel": "k_kmeans_score", "achieved": achieved,
                 "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MATRIX_TFLOPS,
-                "traffic": None, "ms_per_launch": score_ms,
+                "traffic": traffic, "ms_per_launch": score_ms,
                 "flops_per_launch": flops_per_launch,
             }
         if world == 1 and args.cpu_utts > 0:
