@@ -294,6 +294,8 @@ typedef struct segk_fbgmm {
     int64_t *lm_unigram;       /* [dev] [K_max] or NULL                                       */
     int64_t *lm_bigram;        /* [dev] [K_max, K_max]: (j, i) = count of i following j       */
     double lm_lambda, lm_a, lm_b;
+    double *kconst;            /* [dev] [K_max + 1] derived: x-independent constant of each component's
+                                * predictive; entry K_max = that of the prior predictive        */
 } segk_fbgmm;
 
 /* Components __init__ from `assignments` (fixedvar:110-120 / diag:114-120): statistics summed in

@@ -48,7 +48,7 @@ class FbgmmDev(C.Structure):
         ("prior_c", C.c_void_p), ("stat_a", C.c_void_p), ("stat_b", C.c_void_p), ("log_prod", C.c_void_p),
         ("pred", C.c_void_p), ("counts", C.c_void_p), ("assignments", C.c_void_p), ("K", C.c_void_p),
         ("lm_unigram", C.c_void_p), ("lm_bigram", C.c_void_p), ("lm_lambda", C.c_double), ("lm_a", C.c_double),
-        ("lm_b", C.c_double),
+        ("lm_b", C.c_double), ("kconst", C.c_void_p),
     ]
 
 

@@ -20,35 +20,34 @@
 #define LOG_PI 1.1447298858494002
 
 // ---------------------------------------------------------------------------------------
-// block-wide helpers (blockDim.x a power of two <= 1024, `red` has blockDim.x doubles)
+// block-wide helpers (blockDim.x a multiple of 64, <= 1024; `red` has >= 16 doubles)
 // ---------------------------------------------------------------------------------------
+// Butterfly inside each wave, then the per-wave partials (<= 16) are added in wave order by every
+// thread: two barriers per reduction and a fixed, launch-independent order.
 __device__ double block_sum(double v, double *red)
 {
-    const int tid = threadIdx.x, nt = blockDim.x;
+    const int tid = threadIdx.x, nw = blockDim.x >> 6;
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();                      // `red` may still be read from a previous reduction
+    if ((tid & 63) == 0) red[tid >> 6] = v;
     __syncthreads();
-    red[tid] = v;
-    __syncthreads();
-    for (int o = nt >> 1; o > 0; o >>= 1) {
-        if (tid < o) red[tid] += red[tid + o];
-        __syncthreads();
-    }
     double r = red[0];
-    __syncthreads();
+    for (int w = 1; w < nw; w++) r += red[w];
     return r;
 }
 
 __device__ double block_max(double v, double *red)
 {
-    const int tid = threadIdx.x, nt = blockDim.x;
-    __syncthreads();
-    red[tid] = v;
-    __syncthreads();
-    for (int o = nt >> 1; o > 0; o >>= 1) {
-        if (tid < o) red[tid] = red[tid + o] > red[tid] ? red[tid + o] : red[tid];
-        __syncthreads();
+    const int tid = threadIdx.x, nw = blockDim.x >> 6;
+    for (int o = 32; o > 0; o >>= 1) {
+        const double other = __shfl_xor(v, o);
+        v = other > v ? other : v;
     }
-    double r = red[0];
     __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    double r = red[0];
+    for (int w = 1; w < nw; w++) r = red[w] > r ? red[w] : r;
     return r;
 }
 
@@ -58,6 +57,15 @@ __device__ double block_max(double v, double *red)
 //   diag : var = (k_N+1)/(k_N v_N) (S_N_partial - k_N m_N^2); log_prod_vars = sum log var;
 //          inv_vars = 1/var                                                            (:332-345)
 // ---------------------------------------------------------------------------------------
+// x-independent constant of a diagonal component with `cnt` items: D*(lgamma((v_N+1)/2) -
+// lgamma(v_N/2) - log(v_N)/2 - log(pi)/2)  (gaussian_components_diag.py:248-251; the reference
+// reads the lgamma values from tables indexed by the count, :128-131)
+__device__ double fb_diag_const(const segk_fbgmm &f, int D, double cnt)
+{
+    const double v_N = f.v_0 + cnt;
+    return (double)D * (lgamma((v_N + 1.) / 2.) - lgamma(v_N / 2.) - 0.5 * log(v_N) - 0.5 * LOG_PI);
+}
+
 __device__ void fb_update_derived(const segk_fbgmm &f, int D, int k, double *red)
 {
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -80,7 +88,10 @@ __device__ void fb_update_derived(const segk_fbgmm &f, int D, int k, double *red
         }
     }
     double tot = block_sum(part, red);
-    if (tid == 0) f.log_prod[k] = tot;
+    if (tid == 0) {
+        f.log_prod[k] = tot;
+        f.kconst[k] = f.cov_type == 0 ? -0.5 * (double)D * LOG_2PI : fb_diag_const(f, D, (double)f.counts[k]);
+    }
     __syncthreads();
 }
 
@@ -108,9 +119,11 @@ __device__ void fb_del_component(const segk_corpus &c, const segk_fbgmm &f, int 
     if (tid == 0) {
         if (k != K) {
             f.log_prod[k] = f.log_prod[K];
+            f.kconst[k] = f.kconst[K];
             f.counts[k] = f.counts[K];
         }
         f.log_prod[K] = 0.0;
+        f.kconst[K] = 0.0;
         f.counts[K] = 0;
     }
     if (f.lm_unigram) {          // gaussian_components_fixedvar.py:204-221, same statement order
@@ -280,53 +293,73 @@ __global__ void k_fbgmm_update(segk_corpus c, segk_fbgmm f, int op, int utt, int
 // ---------------------------------------------------------------------------------------
 // per-component log predictive of embedding x (A2/A3) and the prior predictive
 // ---------------------------------------------------------------------------------------
+// sum over the dimensions d0, d0+dstep, ... of the x-dependent terms of component k
 template <typename XT>
-__device__ double fb_log_post_pred_k(const segk_fbgmm &f, int D, int k, const XT *x)
+__device__ __forceinline__ double fb_pred_sum(const segk_fbgmm &f, int D, int k, const XT *x, int d0, int dstep)
 {
+    double s = 0.0;
     if (f.cov_type == 0) {      // gaussian_components_fixedvar.py:242-253
-        double s = 0.0;
-        for (int d = 0; d < D; d++) {
+        for (int d = d0; d < D; d += dstep) {
             double mu = f.stat_a[(int64_t)k * D + d] / f.stat_b[(int64_t)k * D + d];
             double delta = mu - (double)x[d];
             s += (delta * delta) * f.pred[(int64_t)k * D + d];
         }
-        return -0.5 * (double)D * LOG_2PI + 0.5 * f.log_prod[k] - 0.5 * s;
     } else {                    // gaussian_components_diag.py:237-259
         const double cnt = (double)f.counts[k];
         const double k_N = f.k_0 + cnt, v_N = f.v_0 + cnt;
-        double s = 0.0;
-        for (int d = 0; d < D; d++) {
+        for (int d = d0; d < D; d += dstep) {
             double m = f.stat_a[(int64_t)k * D + d] / k_N;
             double delta = m - (double)x[d];
             s += log(1. + (delta * delta) * f.pred[(int64_t)k * D + d] * (1. / v_N));
         }
-        return (double)D * (lgamma((v_N + 1.) / 2.) - lgamma(v_N / 2.) - 0.5 * log(v_N) - 0.5 * LOG_PI)
-               - 0.5 * f.log_prod[k] - (v_N + 1.) / 2. * s;
     }
+    return s;
+}
+
+__device__ __forceinline__ double fb_pred_finish(const segk_fbgmm &f, int k, double s)
+{
+    if (f.cov_type == 0) return f.kconst[k] + 0.5 * f.log_prod[k] - 0.5 * s;
+    const double v_N = f.v_0 + (double)f.counts[k];
+    return f.kconst[k] - 0.5 * f.log_prod[k] - (v_N + 1.) / 2. * s;
+}
+
+template <typename XT>
+__device__ double fb_log_post_pred_k(const segk_fbgmm &f, int D, int k, const XT *x)
+{
+    return fb_pred_finish(f, k, fb_pred_sum<XT>(f, D, k, x, 0, 1));
+}
+
+// prior predictive (an empty component): x-dependent sum over d0, d0+dstep, ... and the finish;
+// the x-independent part is kconst[K_max] (k_fbgmm_init_stats)
+template <typename XT>
+__device__ __forceinline__ double fb_prior_sum(const segk_fbgmm &f, int D, const XT *x, int d0, int dstep)
+{
+    double s = 0.0;
+    if (f.cov_type == 0) {      // gaussian_components_fixedvar.py:224-231 (precision_0 as the predictive precision)
+        for (int d = d0; d < D; d += dstep) {
+            double delta = (double)x[d] - f.prior_b[d];
+            s += delta * delta * f.prior_c[d];
+        }
+    } else {                    // gaussian_components_diag.py:215-222
+        for (int d = d0; d < D; d += dstep) {
+            double var = (f.k_0 + 1.) / (f.k_0 * f.v_0) * f.prior_a[d];
+            double delta = (double)x[d] - f.prior_b[d];
+            s += log(1. + 1. / f.v_0 * (delta * delta) * (1. / var));
+        }
+    }
+    return s;
+}
+
+__device__ __forceinline__ double fb_prior_finish(const segk_fbgmm &f, double s)
+{
+    if (f.cov_type == 0) return f.kconst[f.K_max] - 0.5 * s;
+    return f.kconst[f.K_max] - (f.v_0 + 1.) / 2. * s;
 }
 
 template <typename XT>
 __device__ double fb_log_prior(const segk_fbgmm &f, int D, const XT *x)
 {
-    if (f.cov_type == 0) {      // gaussian_components_fixedvar.py:224-231 (precision_0 used as the predictive precision)
-        double slog = 0.0, ss = 0.0;
-        for (int d = 0; d < D; d++) {
-            slog += log(f.prior_c[d]);
-            double delta = (double)x[d] - f.prior_b[d];
-            ss += delta * delta * f.prior_c[d];
-        }
-        return -0.5 * (double)D * LOG_2PI + 0.5 * slog - 0.5 * ss;
-    } else {                    // gaussian_components_diag.py:215-222
-        double lpv = 0.0, s = 0.0;
-        for (int d = 0; d < D; d++) {
-            double var = (f.k_0 + 1.) / (f.k_0 * f.v_0) * f.prior_a[d];
-            lpv += log(var);
-            double delta = (double)x[d] - f.prior_b[d];
-            s += log(1. + 1. / f.v_0 * (delta * delta) * (1. / var));
-        }
-        return (double)D * (lgamma((f.v_0 + 1.) / 2.) - lgamma(f.v_0 / 2.) - 0.5 * log(f.v_0) - 0.5 * LOG_PI)
-               - 0.5 * lpv - (f.v_0 + 1.) / 2. * s;
-    }
+    return fb_prior_finish(f, fb_prior_sum<XT>(f, D, x, 0, 1));
 }
 
 // logits z[k], k < K_max, of embedding `e` into LDS.  Assignment prior by `mode`:
@@ -335,6 +368,8 @@ __device__ double fb_log_prior(const segk_fbgmm &f, int D, const XT *x)
 //   2  map_assign_i:       log(alpha/K_max + counts)                                    fbgmm.py:475-479
 //   3  LM unigram:         lms*lm.log_prob_vec_i()             bigram_lms.py:64-69 (scoring and first segment)
 //   4  LM bigram:          lms*log(lm.prob_vec_given_j(j_prev))                          bigram_lms.py:84-91
+// Work split: a group of G lanes (G | 64, K_max*G <= blockDim where possible) shares one
+// component and strides over the dimensions; partial sums are combined by a butterfly.
 template <typename XT>
 __device__ void fb_logits(const segk_corpus &c, const segk_fbgmm &f, int64_t e, int mode, int j_prev, XT *xrow,
                           double *z, double *red)
@@ -348,27 +383,31 @@ __device__ void fb_logits(const segk_corpus &c, const segk_fbgmm &f, int64_t e, 
     double csum = 0.0;
     const int64_t *cnts = (mode >= 3) ? f.lm_unigram : f.counts;
     for (int k = tid; k < KM; k += nt) csum += (double)cnts[k];
-    const double total = block_sum(csum, red);          // exact: integer-valued
+    const double total = block_sum(csum, red);          // exact: integer-valued (also publishes xrow)
     double lprior = 0.0;
-    bool have_prior = false;
-    for (int k = tid; k < KM; k += nt) {
-        double v;
-        if (mode == 0) v = f.lms * (log(f.alpha / (double)KM + (double)f.counts[k]) - log(total + f.alpha));
-        else if (mode == 1) v = f.lms * log(f.alpha / (double)KM + (double)f.counts[k]);
-        else if (mode == 2) v = log(f.alpha / (double)KM + (double)f.counts[k]);
-        else if (mode == 3) v = (log((double)f.lm_unigram[k] + f.lm_a / (double)KM) - log(total + f.lm_a)) * f.lms;
-        else {
-            const double pi = ((double)f.lm_unigram[k] + f.lm_a / (double)KM) / (total + f.lm_a);
-            const double pij = (1. - f.lm_lambda) * ((double)f.lm_bigram[(int64_t)j_prev * KM + k] + f.lm_b / (double)KM)
-                               / ((double)f.lm_unigram[j_prev] + f.lm_b);
-            v = log(f.lm_lambda * pi + pij) * f.lms;
+    if (K < KM) lprior = fb_prior_finish(f, block_sum(fb_prior_sum<XT>(f, D, xrow, tid, nt), red));
+    int G = 1;
+    while (G < 64 && KM * (G * 2) <= nt) G *= 2;
+    const int g = tid & (G - 1), kk0 = tid / G, kstep = nt / G;
+    for (int kb = 0; kb < KM; kb += kstep) {
+        const int k = kb + kk0;
+        double s = 0.0;
+        if (k < K) s = fb_pred_sum<XT>(f, D, k, xrow, g, G);
+        for (int o = G >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (g == 0 && k < KM) {
+            double v;
+            if (mode == 0) v = f.lms * (log(f.alpha / (double)KM + (double)f.counts[k]) - log(total + f.alpha));
+            else if (mode == 1) v = f.lms * log(f.alpha / (double)KM + (double)f.counts[k]);
+            else if (mode == 2) v = log(f.alpha / (double)KM + (double)f.counts[k]);
+            else if (mode == 3) v = (log((double)f.lm_unigram[k] + f.lm_a / (double)KM) - log(total + f.lm_a)) * f.lms;
+            else {
+                const double pi = ((double)f.lm_unigram[k] + f.lm_a / (double)KM) / (total + f.lm_a);
+                const double pij = (1. - f.lm_lambda) * ((double)f.lm_bigram[(int64_t)j_prev * KM + k] + f.lm_b / (double)KM)
+                                   / ((double)f.lm_unigram[j_prev] + f.lm_b);
+                v = log(f.lm_lambda * pi + pij) * f.lms;
+            }
+            z[k] = v + (k < K ? fb_pred_finish(f, k, s) : lprior);
         }
-        if (k < K) v += fb_log_post_pred_k<XT>(f, D, k, xrow);
-        else {
-            if (!have_prior) { lprior = fb_log_prior<XT>(f, D, xrow); have_prior = true; }
-            v += lprior;
-        }
-        z[k] = v;
     }
     __syncthreads();
 }
@@ -406,12 +445,31 @@ __global__ void k_fbgmm_pred_vector(segk_corpus c, segk_fbgmm f, int64_t row, do
     else if (k == f.K_max) out[k] = fb_log_prior<XT>(f, c.D, x);
 }
 
-__device__ double fb_logsumexp_seq(const double *a, int n)     // _cython_utils.pyx:13-25
+__device__ __forceinline__ double fb_readlane(double v, int l)       // l wave-uniform
 {
-    double mx = a[0], s = 0.0;
-    for (int j = 1; j < n; j++)
-        if (a[j] > mx) mx = a[j];
-    for (int j = 0; j < n; j++) s += exp(a[j] - mx);
+    union { double d; int i[2]; } u;
+    u.d = v;
+    u.i[0] = __builtin_amdgcn_readlane(u.i[0], l);
+    u.i[1] = __builtin_amdgcn_readlane(u.i[1], l);
+    return u.d;
+}
+
+// _cython_utils.pyx:13-25 (max, then the sum of exp(a[j] - max) in index order, then log) by one
+// full wave: the exponentials are evaluated one per lane, the additions stay sequential.
+__device__ double fb_logsumexp_wave(const double *a, int n, int lane)
+{
+    double mx = NEG_INF_D;
+    for (int j = lane; j < n; j += 64) mx = a[j] > mx ? a[j] : mx;
+    for (int o = 32; o > 0; o >>= 1) {
+        double other = __shfl_xor(mx, o);
+        mx = other > mx ? other : mx;
+    }
+    double s = 0.0;
+    for (int j0 = 0; j0 < n; j0 += 64) {
+        const double ej = (j0 + lane < n) ? exp(a[j0 + lane] - mx) : 0.0;
+        const int cnt = n - j0 < 64 ? n - j0 : 64;
+        for (int q = 0; q < cnt; q++) s += fb_readlane(ej, q);
+    }
     return log(s) + mx;
 }
 
@@ -461,16 +519,22 @@ __global__ void k_unigram_segment(segk_corpus c, int utt, int viterbi, int n_min
         vec[j] = v + wip;
     }
     __syncthreads();
-    if (threadIdx.x != 0) return;
+    if (threadIdx.x >= 64) return;
+    // wave 0 runs the DP: control flow and values are wave-uniform, the exponentials of each
+    // logsumexp / normalisation are spread over the lanes, sums and draws keep the reference order
+    const int lane = threadIdx.x;
     uint8_t *bnd = boundaries + (int64_t)utt * c.N_max;
     if (viterbi == 2) {      // assignments_only (bigram_acoustic_wordseg.py:386-387,548-549): keep the boundaries
-        out_logprob[utt] = 0.0;
-        n_new[utt] = fb_collect_tokens(vid, bnd, N, new_tok + (int64_t)utt * c.N_max);
+        if (lane == 0) {
+            out_logprob[utt] = 0.0;
+            n_new[utt] = fb_collect_tokens(vid, bnd, N, new_tok + (int64_t)utt * c.N_max);
+        }
         return;
     }
-    for (int j = 0; j < N; j++) { a[j] = 1.0; bnd[j] = 0; }
-    bnd[N - 1] = 1;
+    for (int j = lane; j < N; j += 64) { a[j] = 1.0; bnd[j] = (j == N - 1) ? 1 : 0; }
+    __builtin_amdgcn_wave_barrier();
     a[0] = 0.0;
+    __builtin_amdgcn_wave_barrier();
     int64_t cur = *ucursor;
     int i = 0;
     for (int t = 1; t < N; t++) {
@@ -480,12 +544,16 @@ __global__ void k_unigram_segment(segk_corpus c, int utt, int viterbi, int n_min
         double best = NEG_INF_D;
         for (int s = lo; s < t; s++) {
             double v = vec[i + s] + a[s];
-            w[s - lo] = v;
+            if (lane == 0) w[s - lo] = v;
             if (v != NEG_INF_D) all_inf = false;
             if (v > best) best = v;
         }
-        if (viterbi) a[t] = best;
-        else a[t] = all_inf ? NEG_INF_D : fb_logsumexp_seq(w, n) + log_p_continue;
+        __builtin_amdgcn_wave_barrier();
+        double at;
+        if (viterbi) at = best;
+        else at = all_inf ? NEG_INF_D : fb_logsumexp_wave(w, n, lane) + log_p_continue;
+        if (lane == 0) a[t] = at;
+        __builtin_amdgcn_wave_barrier();
         i += t;
     }
     int t = N, lo = 0;
@@ -506,37 +574,43 @@ __global__ void k_unigram_segment(segk_corpus c, int utt, int viterbi, int n_min
                 for (int s = lo; s < t; s++)
                     if (vec[i + s] + a[s] != NEG_INF_D) { all_inf = false; break; }
             }
-            bnd[(t - 1 + N) % N] = 1;
+            if (lane == 0) bnd[(t - 1 + N) % N] = 1;
         }
         int k = 1, n = 1;
         if (t > 0) {
             n = t - lo;
-            for (int s = lo; s < t; s++) w[s - lo] = vec[i + s] + a[s];
+            for (int j = lane; j < n; j += 64) w[j] = vec[i + lo + j] + a[lo + j];
         } else {
-            w[0] = NEG_INF_D;
+            if (lane == 0) w[0] = NEG_INF_D;
         }
-        double lse = fb_logsumexp_seq(w, n);
+        __builtin_amdgcn_wave_barrier();
+        const double lse = fb_logsumexp_wave(w, n, lane);
         if (viterbi) {
             if (t > 0) {
+                for (int j = lane; j < n; j += 64) pr[j] = exp(w[j] - lse);
+                __builtin_amdgcn_wave_barrier();
                 double best = 0.0;
                 bool first = true;
                 for (int s = t - 1; s >= lo; s--) {
-                    double q = exp(w[s - lo] - lse);
+                    double q = pr[s - lo];
                     if (first || q > best) { best = q; k = t - s; first = false; }
                 }
             }
         } else {
             if (anneal_temp != 1.0) {
-                for (int j = 0; j < n; j++) pr[j] = w[n - 1 - j] - lse;
-                double inv = 1. / anneal_temp;
-                for (int j = 0; j < n; j++) w[j] = inv * pr[j];
-                double lse2 = fb_logsumexp_seq(w, n);
-                for (int j = 0; j < n; j++) pr[j] = exp(w[j] - lse2);
+                const double inv = 1. / anneal_temp;
+                for (int j = lane; j < n; j += 64) pr[j] = w[n - 1 - j] - lse;
+                __builtin_amdgcn_wave_barrier();
+                for (int j = lane; j < n; j += 64) w[j] = inv * pr[j];
+                __builtin_amdgcn_wave_barrier();
+                const double lse2 = fb_logsumexp_wave(w, n, lane);
+                for (int j = lane; j < n; j += 64) pr[j] = exp(w[j] - lse2);
             } else {
-                for (int j = 0; j < n; j++) pr[j] = exp(w[n - 1 - j] - lse);
+                for (int j = lane; j < n; j += 64) pr[j] = exp(w[n - 1 - j] - lse);
             }
+            __builtin_amdgcn_wave_barrier();
             double uu = (cur < ucap) ? ustream[cur] : 0.5;
-            if (cur >= ucap) atomicOr(status, 8);
+            if (cur >= ucap && lane == 0) atomicOr(status, 8);
             cur++;
             int kk = n - 1;
             for (int j = 0; j < n; j++) {
@@ -549,9 +623,10 @@ __global__ void k_unigram_segment(segk_corpus c, int utt, int viterbi, int n_min
         if (idx < 0) idx += tri;
         total += vec[idx];
         if (t - k - 1 < 0) break;
-        bnd[t - k - 1] = 1;
+        if (lane == 0) bnd[t - k - 1] = 1;
         t = t - k;
     }
+    if (lane != 0) return;
     if (!viterbi && total == NEG_INF_D) atomicOr(status, 16);      // unigram_acoustic_wordseg.py:753
     *ucursor = cur;
     out_logprob[utt] = total;
@@ -643,8 +718,17 @@ __global__ void k_fbgmm_init_stats(segk_corpus c, segk_fbgmm f)
 {
     const int k = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
-    if (k >= f.K_max) return;
+    if (k > f.K_max) return;
     const int D = c.D;
+    if (k == f.K_max) {         // x-independent part of the prior predictive (fixedvar:224-231, diag:215-222)
+        double part = 0.0;
+        for (int d = lane; d < D; d += 64)
+            part += f.cov_type == 0 ? log(f.prior_c[d]) : log((f.k_0 + 1.) / (f.k_0 * f.v_0) * f.prior_a[d]);
+        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+        if (lane == 0)
+            f.kconst[k] = f.cov_type == 0 ? -0.5 * (double)D * LOG_2PI + 0.5 * part : fb_diag_const(f, D, 0.0) - 0.5 * part;
+        return;
+    }
     const XT *X = (const XT *)c.X;
     int64_t cnt = 0;
     double lp_part = 0.0;
@@ -696,6 +780,7 @@ __global__ void k_fbgmm_init_stats(segk_corpus c, segk_fbgmm f)
     if (lane == 0) {
         f.counts[k] = cnt;
         f.log_prod[k] = cnt ? lp_part : 0.0;
+        f.kconst[k] = !cnt ? 0.0 : (f.cov_type == 0 ? -0.5 * (double)D * LOG_2PI : fb_diag_const(f, D, (double)cnt));
         if (cnt) atomicMax(f.K, k + 1);
     }
 }
@@ -719,8 +804,12 @@ static int check_fb(const segk_corpus *c, const segk_fbgmm *f)
     SEGK_REQUIRE(c && f, "NULL corpus / fbgmm");
     SEGK_REQUIRE(f->cov_type == 0 || f->cov_type == 1, "cov_type must be 0 (fixed) or 1 (diag)");
     SEGK_REQUIRE(f->K_max > 0 && c->D > 0, "sizes");
+    SEGK_REQUIRE(f->kconst != NULL, "kconst buffer missing");
     return SEGK_OK;
 }
+
+// workgroup width of the logits kernels: small component banks get several lanes per component
+static int fb_nt(const segk_fbgmm *f) { return f->K_max >= 256 ? 256 : 512; }
 
 static size_t fb_lds(const segk_corpus *c, const segk_fbgmm *f, int nt)
 {
@@ -749,7 +838,7 @@ int32_t segk_fbgmm_init_stats(segk_ctx *ctx, const segk_corpus *c, segk_fbgmm *f
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     SEGK_CHECK_HIP(hipMemsetAsync(f->K, 0, sizeof(int32_t), st));
-    int64_t grid = ((int64_t)f->K_max + 3) / 4;
+    int64_t grid = ((int64_t)f->K_max + 1 + 3) / 4;
     DISPATCH_XT(c, hipLaunchKernelGGL(k_fbgmm_init_stats<XT>, dim3((unsigned)grid), dim3(256), 0, st, *c, *f););
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;
@@ -762,7 +851,7 @@ int32_t segk_fbgmm_score(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *
     int rc = check_fb(c, f);
     if (rc) return rc;
     if (n <= 0) return SEGK_OK;
-    const int nt = 128;
+    const int nt = fb_nt(f);
     size_t lds = fb_lds(c, f, nt);
     SEGK_REQUIRE(lds <= 160 * 1024, "K_max too large for the LDS logits buffer");
     DISPATCH_XT(c, {
@@ -818,7 +907,7 @@ int32_t segk_fbgmm_assign(segk_ctx *ctx, const segk_corpus *c, segk_fbgmm *f, in
     (void)ctx;
     int rc = check_fb(c, f);
     if (rc) return rc;
-    const int nt = 256;
+    const int nt = fb_nt(f);
     size_t lds = fb_lds(c, f, nt);
     SEGK_REQUIRE(lds <= 160 * 1024, "K_max too large for the LDS logits buffer");
     DISPATCH_XT(c, {

@@ -404,6 +404,7 @@ class DeviceFbgmm(object):
         self.stat_b = torch.zeros((self.K_max, c.D), dtype=f64, device=dev)
         self.log_prod = torch.zeros(self.K_max, dtype=f64, device=dev)
         self.pred = torch.zeros((self.K_max, c.D), dtype=f64, device=dev)
+        self.kconst = torch.zeros(self.K_max + 1, dtype=f64, device=dev)
         self.counts = torch.zeros(self.K_max, dtype=torch.int64, device=dev)
         self.assignments = to_dev(assignments, np.int32)
         self.K = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -412,7 +413,7 @@ class DeviceFbgmm(object):
             v_0=float(v_0), prior_a=self.prior_a.data_ptr(), prior_b=self.prior_b.data_ptr(),
             prior_c=self.prior_c.data_ptr(), stat_a=self.stat_a.data_ptr(), stat_b=self.stat_b.data_ptr(),
             log_prod=self.log_prod.data_ptr(), pred=self.pred.data_ptr(), counts=self.counts.data_ptr(),
-            assignments=self.assignments.data_ptr(), K=self.K.data_ptr())
+            assignments=self.assignments.data_ptr(), K=self.K.data_ptr(), kconst=self.kconst.data_ptr())
         self.lm = lm
         if lm is not None:        # bigram_lms.BigramSmoothLM: its count tensors are tied to the components
             assert lm.K == self.K_max and self.cov_type == 0
