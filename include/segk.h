@@ -355,6 +355,16 @@ int32_t segk_fbgmm_assign(segk_ctx *ctx, const segk_corpus *c, segk_fbgmm *f, in
                           const int32_t *n_new, const double *ustream, int64_t *ucursor,
                           int64_t ucap, int32_t *status, void *stream);
 
+/* Inner loop of FBGMM.gibbs_sample (fbgmm.py:352-405) over the rows ids[0..n) (ids == NULL: rows
+ * 0..n-1) in order: cache_component_stats, del_item, logits (:364-372), annealing, utils.draw with
+ * one uniform of the stream per considered row, then restore_component_from_stats when the row
+ * went back to its component and no component was deleted, add_item otherwise.  Rows whose
+ * assignment is -1 are skipped unless consider_unassigned != 0.                                */
+int32_t segk_fbgmm_gibbs_items(segk_ctx *ctx, const segk_corpus *c, segk_fbgmm *f, const int32_t *ids,
+                               int64_t n, int32_t consider_unassigned, double anneal_temp,
+                               const double *ustream, int64_t *ucursor, int64_t ucap, int32_t *status,
+                               void *stream);
+
 /* -------------------------------------------------------------------------------------
  * A6 / A7 / A8 on caller-supplied score vectors -- drop-in for the module-level functions
  *   kind 0: forward_backward_kmeans_viterbi   kmeans_acoustic_wordseg.py:449-555

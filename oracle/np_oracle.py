@@ -640,6 +640,17 @@ class GaussianComponentsFixedVar(_GaussBase):
         self.log_prod_precision_preds[k] = np.log(pp).sum()
         self.precision_preds[k, :] = pp
 
+    def cache_component_stats(self, k):                              # :128-141
+        return (self.mu_N_numerators[k].copy(), self.precision_Ns[k].copy(), self.log_prod_precision_preds[k],
+                self.precision_preds[k].copy(), self.counts[k])
+
+    def restore_component_from_stats(self, k, a, b, lp, pp, count):   # :143-151
+        self.mu_N_numerators[k, :] = a
+        self.precision_Ns[k, :] = b
+        self.log_prod_precision_preds[k] = lp
+        self.precision_preds[k, :] = pp
+        self.counts[k] = count
+
     def add_item(self, i, k):                                       # :153-170
         assert not i == -1
         if k == self.K:
@@ -750,6 +761,17 @@ class GaussianComponentsDiag(_GaussBase):
         self.log_prod_vars[k] = np.log(var).sum()
         self.inv_vars[k, :] = 1. / var
 
+    def cache_component_stats(self, k):                              # :137-150
+        return (self.m_N_numerators[k].copy(), self.S_N_partials[k].copy(), self.log_prod_vars[k],
+                self.inv_vars[k].copy(), self.counts[k])
+
+    def restore_component_from_stats(self, k, a, b, lp, iv, count):   # :152-161
+        self.m_N_numerators[k, :] = a
+        self.S_N_partials[k, :] = b
+        self.log_prod_vars[k] = lp
+        self.inv_vars[k, :] = iv
+        self.counts[k] = count
+
     def add_item(self, i, k):                                       # :162-177
         if k == self.K:
             self.K += 1
@@ -826,6 +848,19 @@ class GaussianComponentsDiag(_GaussBase):
 # --------------------------------------------------------------------------- #
 # A4/A10  FBGMM (fbgmm.py:27-494)
 # --------------------------------------------------------------------------- #
+def anneal_temps(n_iter, schedule, start_inv, end_inv, n_steps):
+    """The three annealing schedules shared by the samplers (fbgmm.py:330-347)."""
+    if schedule is None:
+        return []
+    if schedule == "linear":
+        if n_steps == -1:
+            n_steps = n_iter
+        return list(1. / np.linspace(start_inv, end_inv, n_steps))
+    assert schedule == "step" and n_steps != -1
+    per = int(round(float(n_iter) / n_steps))
+    return list(np.repeat(1. / np.linspace(start_inv, end_inv, n_steps), per))
+
+
 class FBGMM(object):
     def __init__(self, X, prior, alpha, K, assignments="rand", covariance_type="full", lms=1.0):
         self.alpha, self.prior, self.covariance_type, self.lms = alpha, prior, covariance_type, lms
@@ -885,6 +920,42 @@ class FBGMM(object):
             k = c.K
         c.add_item(i, k)
         return k
+
+    def gibbs_sample(self, n_iter, consider_unassigned=True, anneal_schedule=None, anneal_start_temp_inv=0.1,
+                     anneal_end_temp_inv=1, n_anneal_steps=-1):        # :288-420
+        rec = {"log_marg": [], "log_prob_z": [], "log_prob_X_given_z": [], "anneal_temp": [], "components": []}
+        temps = iter(anneal_temps(n_iter, anneal_schedule, anneal_start_temp_inv, anneal_end_temp_inv,
+                                  n_anneal_steps))
+        c = self.components
+        for _ in range(n_iter):
+            anneal_temp = next(temps, anneal_end_temp_inv)
+            for i in range(c.N):
+                k_old = c.assignments[i]
+                if not consider_unassigned and k_old == -1:
+                    continue
+                K_old = c.K
+                stats_old = c.cache_component_stats(k_old)
+                c.del_item(i)
+                z = self._logits(i)
+                if anneal_temp != 1:
+                    z = z - _sp_logsumexp(z)
+                    p = np.exp(1. / anneal_temp * z - _sp_logsumexp(1. / anneal_temp * z))
+                else:
+                    p = np.exp(z - _sp_logsumexp(z))
+                k = draw(p)
+                if k > c.K:
+                    k = c.K
+                if k == k_old and c.K == K_old:
+                    c.restore_component_from_stats(k_old, *stats_old)
+                    c.assignments[i] = k_old
+                else:
+                    c.add_item(i, k)
+            rec["log_marg"].append(self.log_marg())
+            rec["log_prob_z"].append(self.log_prob_z())
+            rec["log_prob_X_given_z"].append(self.log_prob_X_given_z())
+            rec["anneal_temp"].append(anneal_temp)
+            rec["components"].append(c.K)
+        return rec
 
     def map_assign_i(self, i):                                      # :465-494
         c = self.components
@@ -973,10 +1044,12 @@ class UnigramAcousticWordseg(object):
                 am.map_assign_i(e)
         return log_prob
 
-    def gibbs_sample(self, n_iter, anneal_temp=1):                    # :362-472 (no annealing schedule)
+    def gibbs_sample(self, n_iter, anneal_temp=1, am_n_iter=0):       # :362-472 (no annealing schedule)
         rec = {"log_marg": [], "log_marg*length": [], "log_prob_z": [], "log_prob_X_given_z": [],
                "components": [], "n_tokens": []}
         for _ in range(n_iter):
+            if am_n_iter > 0:                                            # :440-443
+                self.acoustic_model.gibbs_sample(am_n_iter, consider_unassigned=False)
             order = list(range(self.utterances.D))
             _shuffle(order)
             lp = 0

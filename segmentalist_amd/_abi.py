@@ -96,6 +96,7 @@ SIGNATURES = {
     "segk_unigram_segment": (_i32, [_P, _CP, _i32, _i32, _i32, _i32, _f64, _f64, _f64, _f64, _P, _P, _P, _i64, _P,
                                     _P, _P, _P, _P, _P]),
     "segk_fbgmm_assign": (_i32, [_P, _CP, _FP, _i32, _i32, _i32, _f64, _P, _P, _P, _P, _i64, _P, _P]),
+    "segk_fbgmm_gibbs_items": (_i32, [_P, _CP, _FP, _P, _i64, _i32, _f64, _P, _P, _i64, _P, _P]),
     "segk_logsumexp": (_f64, [_P, _i64]),
     "segk_draw": (_i32, [_P, _i64, _f64]),
     "segk_sum_doubles": (_f64, [_P, _i64]),

@@ -633,6 +633,56 @@ __global__ void k_unigram_segment(segk_corpus c, int utt, int viterbi, int n_min
     n_new[utt] = fb_collect_tokens(vid, bnd, N, new_tok + (int64_t)utt * c.N_max);
 }
 
+// softmax of the logits in z (scipy logsumexp order: max-shift, sum, log), optional annealing
+// (fbgmm.py:446-449), then utils.draw in forward order with one uniform of the stream -- or the
+// first maximum when map_assign -- and the `k > K -> K` clamp (:459-460).  Result in *sh_k.
+__device__ void fb_draw_component(const segk_fbgmm &f, double *z, double *red, int map_assign, double anneal_temp,
+                                  const double *ustream, int64_t *ucursor, int64_t ucap, int32_t *status, int shK,
+                                  int *sh_k_out)
+{
+    // scipy logsumexp: max-shift, sum, log
+    double mx = NEG_INF_D;
+    for (int k = threadIdx.x; k < f.K_max; k += blockDim.x) mx = z[k] > mx ? z[k] : mx;
+    mx = block_max(mx, red);
+    double s = 0.0;
+    for (int k = threadIdx.x; k < f.K_max; k += blockDim.x) s += exp(z[k] - mx);
+    s = block_sum(s, red);
+    double lse = log(s) + mx;
+    if (!map_assign && anneal_temp != 1.0) {     // :446-449
+        for (int k = threadIdx.x; k < f.K_max; k += blockDim.x) z[k] = (1. / anneal_temp) * (z[k] - lse);
+        __syncthreads();
+        double mx2 = NEG_INF_D;
+        for (int k = threadIdx.x; k < f.K_max; k += blockDim.x) mx2 = z[k] > mx2 ? z[k] : mx2;
+        mx2 = block_max(mx2, red);
+        double s2 = 0.0;
+        for (int k = threadIdx.x; k < f.K_max; k += blockDim.x) s2 += exp(z[k] - mx2);
+        s2 = block_sum(s2, red);
+        lse = log(s2) + mx2;
+    }
+    for (int k = threadIdx.x; k < f.K_max; k += blockDim.x) z[k] = exp(z[k] - lse);      // prob_z
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int k;
+        if (map_assign) {                         // np.argmax(prob_z): first maximum
+            k = 0;
+            for (int q = 1; q < f.K_max; q++)
+                if (z[q] > z[k]) k = q;
+        } else {                                  // utils.draw (utils.py:10-21), forward order
+            int64_t cur = *ucursor;
+            double uu = (cur < ucap) ? ustream[cur] : 0.5;
+            if (cur >= ucap) atomicOr(status, 8);
+            *ucursor = cur + 1;
+            k = f.K_max - 1;
+            for (int q = 0; q < f.K_max; q++) {
+                uu = uu - z[q];
+                if (uu < 0) { k = q; break; }
+            }
+        }
+        if (k > shK) k = shK;                     // :459-460
+        *sh_k_out = k;
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // A10 for the new segments of one utterance, in order (fbgmm.py:422-494).  One workgroup.
 // ---------------------------------------------------------------------------------------
@@ -658,47 +708,7 @@ __global__ void k_fbgmm_assign(segk_corpus c, segk_fbgmm f, int utt, int map_ass
             if (f.lm_unigram) mode = (sh_jprev < 0) ? 3 : 4;
             fb_logits<XT>(c, f, e, mode, sh_jprev, xrow, z, red);
         }
-        // scipy logsumexp: max-shift, sum, log
-        double mx = NEG_INF_D;
-        for (int k = threadIdx.x; k < f.K_max; k += blockDim.x) mx = z[k] > mx ? z[k] : mx;
-        mx = block_max(mx, red);
-        double s = 0.0;
-        for (int k = threadIdx.x; k < f.K_max; k += blockDim.x) s += exp(z[k] - mx);
-        s = block_sum(s, red);
-        double lse = log(s) + mx;
-        if (!map_assign && anneal_temp != 1.0) {     // :446-449
-            for (int k = threadIdx.x; k < f.K_max; k += blockDim.x) z[k] = (1. / anneal_temp) * (z[k] - lse);
-            __syncthreads();
-            double mx2 = NEG_INF_D;
-            for (int k = threadIdx.x; k < f.K_max; k += blockDim.x) mx2 = z[k] > mx2 ? z[k] : mx2;
-            mx2 = block_max(mx2, red);
-            double s2 = 0.0;
-            for (int k = threadIdx.x; k < f.K_max; k += blockDim.x) s2 += exp(z[k] - mx2);
-            s2 = block_sum(s2, red);
-            lse = log(s2) + mx2;
-        }
-        for (int k = threadIdx.x; k < f.K_max; k += blockDim.x) z[k] = exp(z[k] - lse);      // prob_z
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            int k;
-            if (map_assign) {                         // np.argmax(prob_z): first maximum
-                k = 0;
-                for (int q = 1; q < f.K_max; q++)
-                    if (z[q] > z[k]) k = q;
-            } else {                                  // utils.draw (utils.py:10-21), forward order
-                int64_t cur = *ucursor;
-                double uu = (cur < ucap) ? ustream[cur] : 0.5;
-                if (cur >= ucap) atomicOr(status, 8);
-                *ucursor = cur + 1;
-                k = f.K_max - 1;
-                for (int q = 0; q < f.K_max; q++) {
-                    uu = uu - z[q];
-                    if (uu < 0) { k = q; break; }
-                }
-            }
-            if (k > shK) k = shK;                     // :459-460
-            sh_k = k;
-        }
+        fb_draw_component(f, z, red, map_assign, anneal_temp, ustream, ucursor, ucap, status, shK, &sh_k);
         __syncthreads();
         fb_add_item<XT>(c, f, e, sh_k, &shK, &sh_i, red);
         if (threadIdx.x == 0) sh_jprev = sh_k;      // bigram_acoustic_wordseg.py:482-494
@@ -706,6 +716,72 @@ __global__ void k_fbgmm_assign(segk_corpus c, segk_fbgmm f, int utt, int map_ass
     }
     __syncthreads();
     if (threadIdx.x == 0) *f.K = shK;
+}
+
+// ---------------------------------------------------------------------------------------
+// FBGMM.gibbs_sample inner loop (fbgmm.py:352-405) over the items ids[0..n) (NULL: rows 0..n) in
+// order, one workgroup: cache the old component's statistics, del_item, logits, draw, then either
+// restore the cached statistics (same component, no component deleted) or add_item.
+// ---------------------------------------------------------------------------------------
+template <typename XT>
+__global__ void k_fbgmm_gibbs_items(segk_corpus c, segk_fbgmm f, const int32_t *ids, int64_t n,
+                                    int consider_unassigned, double anneal_temp, const double *ustream,
+                                    int64_t *ucursor, int64_t ucap, int32_t *status)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *z = (double *)smem;                      // [K_max]
+    double *red = z + f.K_max;                       // [nt]
+    double *cache = red + blockDim.x;                // [3 D]
+    XT *xrow = (XT *)(cache + 3 * c.D);              // [D]
+    __shared__ int shK, sh_i, sh_k, sh_kold;
+    __shared__ double sh_lp, sh_kc;
+    __shared__ long long sh_cnt;
+    const int D = c.D, tid = threadIdx.x, nt = blockDim.x;
+    if (tid == 0) shK = *f.K;
+    __syncthreads();
+    for (int64_t t = 0; t < n; t++) {
+        const int64_t e = ids ? (int64_t)ids[t] : t;
+        if (tid == 0) sh_kold = f.assignments[e];
+        __syncthreads();
+        const int k_old = sh_kold;
+        __syncthreads();                                         // sh_kold is rewritten next iteration
+        if (!consider_unassigned && k_old == -1) continue;
+        const int K_old = shK;
+        const int kc = k_old < 0 ? k_old + f.K_max : k_old;      // python row -1 for an unassigned item
+        for (int d = tid; d < D; d += nt) {                      // cache_component_stats
+            cache[d] = f.stat_a[(int64_t)kc * D + d];
+            cache[D + d] = f.stat_b[(int64_t)kc * D + d];
+            cache[2 * D + d] = f.pred[(int64_t)kc * D + d];
+        }
+        if (tid == 0) { sh_lp = f.log_prod[kc]; sh_kc = f.kconst[kc]; sh_cnt = f.counts[kc]; }
+        __syncthreads();
+        fb_del_item<XT>(c, f, e, &shK, &sh_i, red);
+        __syncthreads();
+        if (tid == 0) *f.K = shK;
+        __syncthreads();
+        fb_logits<XT>(c, f, e, 1, -1, xrow, z, red);
+        fb_draw_component(f, z, red, 0, anneal_temp, ustream, ucursor, ucap, status, shK, &sh_k);
+        __syncthreads();
+        if (sh_k == k_old && shK == K_old) {                     // restore_component_from_stats (:397-400)
+            for (int d = tid; d < D; d += nt) {
+                f.stat_a[(int64_t)kc * D + d] = cache[d];
+                f.stat_b[(int64_t)kc * D + d] = cache[D + d];
+                f.pred[(int64_t)kc * D + d] = cache[2 * D + d];
+            }
+            if (tid == 0) {
+                f.log_prod[kc] = sh_lp;
+                f.kconst[kc] = sh_kc;
+                f.counts[kc] = sh_cnt;
+                f.assignments[e] = k_old;
+            }
+            __syncthreads();
+        } else {
+            fb_add_item<XT>(c, f, e, sh_k, &shK, &sh_i, red);
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    if (tid == 0) *f.K = shK;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -916,6 +992,30 @@ int32_t segk_fbgmm_assign(segk_ctx *ctx, const segk_corpus *c, segk_fbgmm *f, in
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k_fbgmm_assign<XT>, dim3(1), dim3(nt), lds, (hipStream_t)stream, *c, *f, utt, map_assign,
                            j_prev, anneal_temp, new_tok, n_new, ustream, ucursor, ucap, status);
+    });
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+int32_t segk_fbgmm_gibbs_items(segk_ctx *ctx, const segk_corpus *c, segk_fbgmm *f, const int32_t *ids, int64_t n,
+                               int32_t consider_unassigned, double anneal_temp, const double *ustream,
+                               int64_t *ucursor, int64_t ucap, int32_t *status, void *stream)
+{
+    (void)ctx;
+    int rc = check_fb(c, f);
+    if (rc) return rc;
+    SEGK_REQUIRE(f->lm_unigram == NULL, "FBGMM.gibbs_sample has no language-model variant in the reference");
+    SEGK_REQUIRE(ids != NULL || n <= c->n_emb, "n exceeds the number of rows");
+    if (n <= 0) return SEGK_OK;
+    const int nt = fb_nt(f);
+    size_t lds = fb_lds(c, f, nt) + (size_t)3 * c->D * sizeof(double);
+    SEGK_REQUIRE(lds <= 160 * 1024, "K_max too large for the LDS logits buffer");
+    DISPATCH_XT(c, {
+        if (lds > 48 * 1024)
+            SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_fbgmm_gibbs_items<XT>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_fbgmm_gibbs_items<XT>, dim3(1), dim3(nt), lds, (hipStream_t)stream, *c, *f, ids, n,
+                           consider_unassigned, anneal_temp, ustream, ucursor, ucap, status);
     });
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;

@@ -483,6 +483,20 @@ class DeviceFbgmm(object):
                                         ptr(self.status), _abi.stream()))
         return int(self.assignments[int(i)].item())
 
+    def gibbs_items(self, uniforms, consider_unassigned=True, anneal_temp=1.0, ids=None):
+        """One pass of FBGMM.gibbs_sample's inner loop (fbgmm.py:352-405) over `ids` (default: all
+        rows, in index order) consuming `uniforms` in order."""
+        torch = _torch()
+        u = to_dev(np.asarray(uniforms, dtype=np.float64)) if len(uniforms) else torch.zeros(1, dtype=torch.float64,
+                                                                                             device=self.K.device)
+        cur = torch.zeros(1, dtype=torch.int64, device=self.K.device)
+        ids_t = None if ids is None else to_dev(ids, np.int32)
+        n = self.corpus.n_emb if ids is None else ids_t.numel()
+        check(self._L.segk_fbgmm_gibbs_items(self._ctx, self._cp(), C.byref(self.f), ptr(ids_t), int(n),
+                                             1 if consider_unassigned else 0, float(anneal_temp), ptr(u), ptr(cur),
+                                             len(uniforms), ptr(self.status), _abi.stream()))
+        return int(cur.item())
+
     def set_uniform_stream(self, u):
         self.ustream = to_dev(u, np.float64)
         self.ucursor.zero_()

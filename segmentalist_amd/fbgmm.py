@@ -3,6 +3,7 @@ Drop-in for segmentalist/fbgmm.py: finite Bayesian Gaussian mixture model, devic
 """
 import logging
 import random
+import time
 
 import numpy as np
 from scipy.special import gammaln
@@ -72,6 +73,48 @@ class FBGMM(object):
     def map_assign_i(self, i):
         """fbgmm.py:465-494."""
         self.components.dev.assign_item(i, 0.0, 1.0, map_assign=True)
+
+    def gibbs_sample(self, n_iter, consider_unassigned=True, anneal_schedule=None, anneal_start_temp_inv=0.1,
+                     anneal_end_temp_inv=1, n_anneal_steps=-1):
+        """fbgmm.py:288-420 on the device: per iteration one kernel walks the items in index order
+        (cache statistics, del_item, logits, draw, restore or add_item); the uniforms are the
+        `random.random()` values the reference would consume -- one per considered item."""
+        record_dict = {k: [] for k in ["sample_time", "log_marg", "log_prob_z", "log_prob_X_given_z",
+                                       "anneal_temp", "components"]}
+        start_time = time.time()
+        if anneal_schedule is None:
+            get_anneal_temp = iter([])
+        elif anneal_schedule == "linear":
+            if n_anneal_steps == -1:
+                n_anneal_steps = n_iter
+            get_anneal_temp = iter(1. / np.linspace(anneal_start_temp_inv, anneal_end_temp_inv, n_anneal_steps))
+        elif anneal_schedule == "step":
+            assert not n_anneal_steps == -1, "`n_anneal_steps` of -1 not allowed for step annealing schedule"
+            n_iter_per_step = int(round(float(n_iter) / n_anneal_steps))
+            anneal_list = 1. / np.linspace(anneal_start_temp_inv, anneal_end_temp_inv, n_anneal_steps)
+            get_anneal_temp = iter(np.repeat(anneal_list, n_iter_per_step))
+        else:
+            assert False, "invalid anneal_schedule"
+        c = self.components
+        dev = c.dev
+        for i_iter in range(n_iter):
+            anneal_temp = next(get_anneal_temp, anneal_end_temp_inv)
+            n_draws = c.N if consider_unassigned else int(np.count_nonzero(c.assignments != -1))
+            used = dev.gibbs_items([random.random() for _ in range(n_draws)], consider_unassigned, anneal_temp)
+            dev.check_status()
+            assert used == n_draws
+            record_dict["sample_time"].append(time.time() - start_time)
+            start_time = time.time()
+            record_dict["log_marg"].append(self.log_marg())
+            record_dict["log_prob_z"].append(self.log_prob_z())
+            record_dict["log_prob_X_given_z"].append(self.log_prob_X_given_z())
+            record_dict["anneal_temp"].append(anneal_temp)
+            record_dict["components"].append(c.K)
+            info = "iteration: " + str(i_iter)
+            for key in sorted(record_dict):
+                info += ", " + key + ": " + str(record_dict[key][-1])
+            logger.info(info)
+        return record_dict
 
     def get_n_assigned(self):
         return int(np.count_nonzero(self.components.assignments != -1))

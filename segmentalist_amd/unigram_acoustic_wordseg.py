@@ -146,9 +146,6 @@ class UnigramAcousticWordseg(object):
                      anneal_end_temp_inv=1, n_anneal_steps=-1, anneal_gibbs_am=False):
         """unigram_acoustic_wordseg.py:362-472; same record keys."""
         import torch
-        if am_n_iter > 0:
-            raise NotImplementedError("intermediate FBGMM.gibbs_sample sweeps (am_n_iter) are not on the "
-                                      "device path yet")
         if anneal_schedule is None:
             get_anneal_temp = iter([])
         elif anneal_schedule == "linear":
@@ -168,6 +165,8 @@ class UnigramAcousticWordseg(object):
         am = self.acoustic_model
         for i_iter in range(n_iter):
             start_time = time.time()
+            if am_n_iter > 0:                                     # unigram_acoustic_wordseg.py:440-443
+                self.acoustic_model.gibbs_sample(am_n_iter, consider_unassigned=False)
             anneal_temp = next(get_anneal_temp, anneal_end_temp_inv)
             utt_order = list(range(self.utterances.D))
             rng.shuffle(utt_order)

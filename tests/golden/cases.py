@@ -118,6 +118,18 @@ UNIGRAM_CHAINS = [
 ]
 
 
+# FBGMM.gibbs_sample (fbgmm.py:288-420) standalone: (name, D, K_max, n_items, seed, cov, consider_unassigned,
+# anneal_schedule); data and the partial initial assignment come from gauss_state(D, K_max, n_items, seed)
+AM_GIBBS = [
+    ("amg_fixed", 5, 6, 40, 51, "fixed", True, None),
+    ("amg_diag", 5, 6, 40, 52, "diag", True, None),
+    ("amg_fixed_assigned", 8, 10, 90, 53, "fixed", False, None),
+    ("amg_diag_assigned", 8, 10, 90, 54, "diag", False, "linear"),
+    ("amg_fixed_anneal", 6, 8, 60, 55, "fixed", True, "step"),
+]
+# unigram chains with intermediate acoustic-model sweeps (unigram_acoustic_wordseg.py:440-443)
+AM_ITER_CHAINS = [c for c in UNIGRAM_CHAINS if c[0] in ("ug_fixed", "ug_diag_mid")]
+
 # (name, n_utt, D, K, seed, ragged, N, n_slices_max, dtype, cov).  Only "fixed": the reference's
 # del_component rewires the LM counts for fixed-variance components only
 # (gaussian_components_fixedvar.py:204-221); with "diag" its LM counts go negative and it asserts.

@@ -317,6 +317,58 @@ def gen_bigram():
     print("bigram.npz:", len(out), "arrays")
 
 
+# ----------------------------------------------------------------------------- FBGMM.gibbs_sample (8(f).1)
+def gen_amgibbs():
+    out = {}
+    for name, D, K_max, n_items, seed, cov, unassigned, sched in cases.AM_GIBBS:
+        X, assign = cases.gauss_state(D, K_max, n_items, seed)
+        if cov == "fixed":
+            prior = gaussian_components_fixedvar.FixedVarPrior(*cases.fixed_prior_params(D))
+        else:
+            prior = niw.NIW(*cases.diag_prior_params(D))
+        random.seed(3)
+        np.random.seed(3)
+        fm = fbgmm.FBGMM(X, prior, 1.0, K_max, assign.copy(), covariance_type=cov, lms=1.0)
+        assigns, Ks, nus = [], [], []
+        rec_all = {}
+        kw = {}
+        if sched == "linear":
+            kw = dict(anneal_schedule="linear", anneal_start_temp_inv=0.5, anneal_end_temp_inv=1.0)
+        elif sched == "step":
+            kw = dict(anneal_schedule="step", anneal_start_temp_inv=0.25, anneal_end_temp_inv=1.0, n_anneal_steps=2)
+        with UniformLog() as ul:
+            rec = fm.gibbs_sample(4, consider_unassigned=unassigned, **kw)
+        out[name + "_n_uniforms"] = np.array(len(ul.log))
+        out[name + "_assign"] = fm.components.assignments.copy()
+        out[name + "_counts"] = fm.components.counts.copy()
+        for k in ["log_marg", "log_prob_z", "log_prob_X_given_z", "anneal_temp", "components"]:
+            out[name + "_rec_" + k] = np.array(rec[k])
+        # one more sweep, one iteration at a time, to pin the per-iteration state
+        rec = fm.gibbs_sample(1, consider_unassigned=unassigned)
+        out[name + "_assign_5"] = fm.components.assignments.copy()
+        out[name + "_log_marg_5"] = np.array(rec["log_marg"])
+    for name, n_utt, D, K, seed, ragged, N, nmax, dtype, cov in cases.AM_ITER_CHAINS:
+        corpus = cases.chain_corpus(n_utt, D, K, seed, ragged, N, nmax, dtype)
+        random.seed(1)
+        np.random.seed(1)
+        if cov == "fixed":
+            prior = gaussian_components_fixedvar.FixedVarPrior(*cases.fixed_prior_params(D))
+        else:
+            prior = niw.NIW(*cases.diag_prior_params(D))
+        seg = unigram_acoustic_wordseg.UnigramAcousticWordseg(
+            fbgmm.FBGMM, 1.0, K, prior, *corpus, covariance_type=cov, n_slices_min=0,
+            n_slices_max=nmax, p_boundary_init=0.5, beta_sent_boundary=-1, lms=1.0, wip=0.0,
+            fb_type="standard", init_am_assignments="rand", time_power_term=1.0)
+        rec = seg.gibbs_sample(3, am_n_iter=2)
+        tag = name + "_amiter"
+        out[tag + "_bounds"] = seg.utterances.boundaries.copy()
+        out[tag + "_assign"] = seg.acoustic_model.components.assignments.copy()
+        for k in ["log_marg", "log_marg*length", "components", "n_tokens"]:
+            out[tag + "_rec_" + k] = np.array(rec[k])
+    np.savez_compressed(os.path.join(HERE, "amgibbs.npz"), **out)
+    print("amgibbs.npz:", len(out), "arrays")
+
+
 # ----------------------------------------------------------------------------- notebook (config 1)
 def gen_notebook():
     """examples/clustering_examples.ipynb cells, with the python-2 shuffle."""
@@ -368,10 +420,15 @@ def gen_notebook():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 2:
+        for which in sys.argv[2:]:
+            globals()["gen_" + which]()
+        sys.exit(0)
     gen_kernels()
     gen_gauss()
     gen_chains()
     gen_bigram()
+    gen_amgibbs()
     gen_notebook()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):

@@ -201,3 +201,60 @@ def test_module_level_dp_functions_consume_rng_like_the_reference(gpu):
             want_t, want_b = no.forward_backward_viterbi(c["vec"], 0.0, c["N"], c["n_min"], c["n_max"])
         got_t, got_b = uaw.forward_backward_viterbi(c["vec"], 0.0, c["N"], c["n_min"], c["n_max"])
         assert np.array_equal(got_b, want_b)
+
+
+# ------------------------------------------------------------------ FBGMM.gibbs_sample
+def _amg_kw(sched):
+    if sched == "linear":
+        return dict(anneal_schedule="linear", anneal_start_temp_inv=0.5, anneal_end_temp_inv=1.0)
+    if sched == "step":
+        return dict(anneal_schedule="step", anneal_start_temp_inv=0.25, anneal_end_temp_inv=1.0, n_anneal_steps=2)
+    return {}
+
+
+@pytest.mark.parametrize("case", cases.AM_GIBBS, ids=[c[0] for c in cases.AM_GIBBS])
+def test_fbgmm_gibbs_sample_vs_reference(gpu, golden, case):
+    """fbgmm.py:288-420 through segk_fbgmm_gibbs_items against trajectories of the reference."""
+    from segmentalist_amd import fbgmm
+    from segmentalist_amd.gaussian_components_fixedvar import FixedVarPrior
+    from segmentalist_amd.niw import NIW
+    g = golden("amgibbs")
+    name, D, K_max, n_items, seed, cov, unassigned, sched = case
+    X, assign = cases.gauss_state(D, K_max, n_items, seed)
+    prior = FixedVarPrior(*cases.fixed_prior_params(D)) if cov == "fixed" else NIW(*cases.diag_prior_params(D))
+    random.seed(3)
+    np.random.seed(3)
+    fm = fbgmm.FBGMM(X, prior, 1.0, K_max, assign.copy(), covariance_type=cov, lms=1.0)
+    rec = fm.gibbs_sample(4, consider_unassigned=unassigned, **_amg_kw(sched))
+    assert np.array_equal(fm.components.assignments, g[name + "_assign"])
+    assert np.array_equal(fm.components.counts, g[name + "_counts"])
+    for k in ["log_marg", "log_prob_z", "log_prob_X_given_z", "anneal_temp"]:
+        npt.assert_allclose(rec[k], g[name + "_rec_" + k], rtol=1e-8, err_msg=k)
+    assert list(rec["components"]) == list(g[name + "_rec_components"])
+    rec = fm.gibbs_sample(1, consider_unassigned=unassigned)
+    assert np.array_equal(fm.components.assignments, g[name + "_assign_5"])
+    npt.assert_allclose(rec["log_marg"], g[name + "_log_marg_5"], rtol=1e-8)
+
+
+@pytest.mark.parametrize("chain", cases.AM_ITER_CHAINS, ids=[c[0] for c in cases.AM_ITER_CHAINS])
+def test_unigram_chain_with_am_iterations_vs_reference(gpu, golden, chain):
+    """gibbs_sample(n, am_n_iter=2): the in-between acoustic-model sweeps of unigram...:440-443."""
+    from segmentalist_amd import fbgmm, unigram_acoustic_wordseg as uaw
+    from segmentalist_amd.gaussian_components_fixedvar import FixedVarPrior
+    from segmentalist_amd.niw import NIW
+    g = golden("amgibbs")
+    name, n_utt, D, K, seed, ragged, N, nmax, dtype, cov = chain
+    corpus = cases.chain_corpus(n_utt, D, K, seed, ragged, N, nmax, dtype)
+    random.seed(1)
+    np.random.seed(1)
+    prior = FixedVarPrior(*cases.fixed_prior_params(D)) if cov == "fixed" else NIW(*cases.diag_prior_params(D))
+    seg = uaw.UnigramAcousticWordseg(fbgmm.FBGMM, 1.0, K, prior, *corpus, covariance_type=cov, n_slices_min=0,
+                                     n_slices_max=nmax, p_boundary_init=0.5, beta_sent_boundary=-1, lms=1.0,
+                                     wip=0.0, fb_type="standard", init_am_assignments="rand", time_power_term=1.0)
+    rec = seg.gibbs_sample(3, am_n_iter=2)
+    tag = name + "_amiter"
+    assert np.array_equal(seg.utterances.boundaries, g[tag + "_bounds"])
+    assert np.array_equal(seg.acoustic_model.components.assignments, g[tag + "_assign"])
+    npt.assert_allclose(rec["log_marg"], g[tag + "_rec_log_marg"], rtol=1e-8)
+    assert list(rec["components"]) == list(g[tag + "_rec_components"])
+    assert list(rec["n_tokens"]) == list(g[tag + "_rec_n_tokens"])
