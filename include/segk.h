@@ -366,6 +366,84 @@ int32_t segk_fbgmm_gibbs_items(segk_ctx *ctx, const segk_corpus *c, segk_fbgmm *
                                void *stream);
 
 /* -------------------------------------------------------------------------------------
+ * Batch-synchronous ("blocked parallel Gibbs") sweep of the FBGMM / bigram samplers.  The
+ * reference's samplers (unigram_acoustic_wordseg.py:252-472, bigram_acoustic_wordseg.py:386-671)
+ * are serial chains with no parallel mode; this family implements the sampler specified in
+ * oracle/np_fbgmm_batch.py from the same building blocks: the utterances are cut into n_slices
+ * contiguous slices (unit of GPU ownership and of the fixed summation order) x n_blocks blocks;
+ * Gibbs step b resamples block b of every slice in parallel conditioned on all other blocks.
+ * Component labels are "slots" 0..K_max-1 that are not renumbered during a sweep (count 0 = empty
+ * component = prior predictive); segk_fbb_canonical gives the reference's contiguous labelling.
+ * ------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t n_slices, n_blocks;   /* S (<= 16), B (>= 2)                                          */
+    int32_t u_max;                /* max utterances of a (slice, block); 0 without an LM store    */
+    int32_t pad_;
+    const int32_t *utt_range;     /* [dev] [S, B, 2] utterances [lo, hi) of (slice, block)        */
+    const int32_t *row_range;     /* [dev] [S, B, 2] embedding rows [lo, hi) of (slice, block)    */
+    double *partials;             /* [dev] [B, S, K_max*(2D+1)]: counts [K_max] (as doubles), sum x
+                                   * [K_max, D], sum x^2 [K_max, D] of the tokens of (block, slice) */
+    double *cnt;                  /* [dev] [K_max]   counts of the current exclusion              */
+    double *mean_t, *q_t;         /* [dev] [D, K_max] predictive mean / scale, slot-contiguous    */
+    double *lconst, *zconst, *half; /* [dev] [K_max] likelihood constant, + assignment prior, multiplier */
+    double *scal;                 /* [dev] [2]: total count, number of occupied slots             */
+    int32_t *slot;                /* [dev] [n_emb]   slot of every embedding row, -1 = unassigned */
+    int32_t *lm_tok;              /* [dev] [B, S, u_max, N_max] slots of every utterance's segments,
+                                   * -1 padded (replicated on every rank); NULL without an LM     */
+    uint64_t seed;                /* of the counter-based uniforms u01(seed, sweep, utt, j)       */
+} segk_fbatch;
+
+/* token lists of all utterances from the boundaries: new_tok [n_utt, N_max], n_new [n_utt]     */
+int32_t segk_fbb_collect(segk_ctx *ctx, const segk_corpus *c, const uint8_t *boundaries,
+                         int32_t *new_tok, int32_t *n_new, void *stream);
+/* partials[b][s] for the slices s_lo .. s_lo+s_n-1 from their token lists and bt->slot: per slot
+ * sequential in token order (utterance, then segment); x^2 is the square in the dtype of X
+ * (gaussian_components_diag.py:125).                                                            */
+int32_t segk_fbb_partials(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *f,
+                          const segk_fbatch *bt, int32_t s_lo, int32_t s_n, int32_t b,
+                          const int32_t *new_tok, const int32_t *n_new, void *stream);
+/* statistics of all tokens outside block b (b = -1: all): per slice the partials of the blocks
+ * b' != b in increasing b', slices combined by the balanced tree of the specification; then the
+ * predictive parameters of every slot (fixedvar:153-170,317-325 / diag:162-177,332-345).        */
+int32_t segk_fbb_prepare(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *f,
+                         const segk_fbatch *bt, int32_t b, void *stream);
+/* log_marg_i (fbgmm.py:256-285; with an LM bigram_acoustic_wordseg.py:314-329) of every row of
+ * block b of the local slices under the prepared statistics -> score[row].
+ * n_rows [host] [s_n]: rows of (s_lo + i, b).                                                    */
+int32_t segk_fbb_score(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *f,
+                       const segk_fbatch *bt, int32_t s_lo, int32_t s_n, int32_t b,
+                       const int32_t *n_rows, double *score, void *stream);
+/* get_vec_embed_log_probs + forward_backward (unigram...:474-511, 653-756) for every utterance of
+ * block b of the local slices with the uniforms u01(seed, sweep, utt, 0, 1, ...); the slots of the
+ * old segments are cleared.  n_utts [host] [s_n].  status bit 16: log_prob == -inf.            */
+int32_t segk_fbb_segment(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *f,
+                         const segk_fbatch *bt, int32_t s_lo, int32_t s_n, int32_t b,
+                         const int32_t *n_utts, uint64_t sweep, int32_t n_slices_min,
+                         int32_t n_slices_max, double wip, double time_power_term,
+                         double anneal_temp, const double *score, uint8_t *boundaries,
+                         int32_t *new_tok, int32_t *n_new, double *out_logprob, int32_t *status,
+                         void *stream);
+/* slot of every new segment: softmax of the logits (fbgmm.py:436-457; with an LM
+ * bigram_acoustic_wordseg.py:332-384 chained over the utterance's segments), utils.draw with
+ * u01(seed, sweep, utt, N_max + position); no `k > K` clamp -- slots are drawn as such.        */
+int32_t segk_fbb_assign(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *f,
+                        const segk_fbatch *bt, int32_t s_lo, int32_t s_n, int32_t b,
+                        const int32_t *n_utts, uint64_t sweep, double anneal_temp,
+                        const int32_t *new_tok, const int32_t *n_new, void *stream);
+/* bigram table += sign * (transcripts of block b, all slices) from bt->lm_tok                  */
+int32_t segk_fbb_lm_apply(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *f,
+                          const segk_fbatch *bt, int32_t b, int32_t sign, void *stream);
+/* bt->lm_tok[b][s] <- slots of the new tokens of the local slices                              */
+int32_t segk_fbb_lm_fill(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *f,
+                         const segk_fbatch *bt, int32_t s_lo, int32_t s_n, int32_t b,
+                         const int32_t *n_utts, const int32_t *new_tok, const int32_t *n_new,
+                         void *stream);
+/* after segk_fbb_prepare(b = -1): remap [dev] [K_max] occupied slots -> 0..K-1 in increasing slot
+ * order (-1 for empty), f->assignments[row] = remap[slot[row]], *f->K = K.                      */
+int32_t segk_fbb_canonical(segk_ctx *ctx, const segk_corpus *c, segk_fbgmm *f,
+                           const segk_fbatch *bt, int32_t *remap, void *stream);
+
+/* -------------------------------------------------------------------------------------
  * A6 / A7 / A8 on caller-supplied score vectors -- drop-in for the module-level functions
  *   kind 0: forward_backward_kmeans_viterbi   kmeans_acoustic_wordseg.py:449-555
  *   kind 1: forward_backward_viterbi          unigram_acoustic_wordseg.py:759-864

@@ -36,6 +36,16 @@ class KMeansDev(C.Structure):
     ]
 
 
+class FbatchDev(C.Structure):
+    _fields_ = [
+        ("n_slices", C.c_int32), ("n_blocks", C.c_int32), ("u_max", C.c_int32), ("pad_", C.c_int32),
+        ("utt_range", C.c_void_p), ("row_range", C.c_void_p), ("partials", C.c_void_p), ("cnt", C.c_void_p),
+        ("mean_t", C.c_void_p), ("q_t", C.c_void_p), ("lconst", C.c_void_p), ("zconst", C.c_void_p),
+        ("half", C.c_void_p), ("scal", C.c_void_p), ("slot", C.c_void_p), ("lm_tok", C.c_void_p),
+        ("seed", C.c_uint64),
+    ]
+
+
 class CandDev(C.Structure):
     _fields_ = [("k", C.c_void_p), ("f", C.c_void_p), ("s", C.c_void_p), ("queue", C.c_void_p),
                 ("count", C.c_void_p)]
@@ -53,8 +63,9 @@ class FbgmmDev(C.Structure):
 
 
 _P = C.c_void_p
-_i32, _i64, _f64 = C.c_int32, C.c_int64, C.c_double
+_i32, _i64, _f64, _u64 = C.c_int32, C.c_int64, C.c_double, C.c_uint64
 _CP, _KP, _FP, _DP = C.POINTER(Corpus), C.POINTER(KMeansDev), C.POINTER(FbgmmDev), C.POINTER(CandDev)
+_BP = C.POINTER(FbatchDev)
 
 # name -> (restype, argtypes); every symbol include/segk.h declares
 SIGNATURES = {
@@ -97,6 +108,16 @@ SIGNATURES = {
                                     _P, _P, _P, _P, _P]),
     "segk_fbgmm_assign": (_i32, [_P, _CP, _FP, _i32, _i32, _i32, _f64, _P, _P, _P, _P, _i64, _P, _P]),
     "segk_fbgmm_gibbs_items": (_i32, [_P, _CP, _FP, _P, _i64, _i32, _f64, _P, _P, _i64, _P, _P]),
+    "segk_fbb_collect": (_i32, [_P, _CP, _P, _P, _P, _P]),
+    "segk_fbb_partials": (_i32, [_P, _CP, _FP, _BP, _i32, _i32, _i32, _P, _P, _P]),
+    "segk_fbb_prepare": (_i32, [_P, _CP, _FP, _BP, _i32, _P]),
+    "segk_fbb_score": (_i32, [_P, _CP, _FP, _BP, _i32, _i32, _i32, _P, _P, _P]),
+    "segk_fbb_segment": (_i32, [_P, _CP, _FP, _BP, _i32, _i32, _i32, _P, _u64, _i32, _i32, _f64, _f64, _f64, _P, _P,
+                                _P, _P, _P, _P, _P]),
+    "segk_fbb_assign": (_i32, [_P, _CP, _FP, _BP, _i32, _i32, _i32, _P, _u64, _f64, _P, _P, _P]),
+    "segk_fbb_lm_apply": (_i32, [_P, _CP, _FP, _BP, _i32, _i32, _P]),
+    "segk_fbb_lm_fill": (_i32, [_P, _CP, _FP, _BP, _i32, _i32, _i32, _P, _P, _P, _P]),
+    "segk_fbb_canonical": (_i32, [_P, _CP, _FP, _BP, _P, _P]),
     "segk_logsumexp": (_f64, [_P, _i64]),
     "segk_draw": (_i32, [_P, _i64, _f64]),
     "segk_sum_doubles": (_f64, [_P, _i64]),

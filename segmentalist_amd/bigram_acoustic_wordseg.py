@@ -44,8 +44,15 @@ class BigramAcousticWordseg(object):
     def __init__(self, am_K, am_param_prior, lm_params, embedding_mats, vec_ids_dict, durations_dict,
                  landmarks_dict, seed_boundaries_dict=None, seed_assignments_dict=None, covariance_type="fixed",
                  n_slices_min=0, n_slices_max=20, min_duration=0, p_boundary_init=0.5, beta_sent_boundary=2.0,
-                 lms=1., wip=0., fb_type="bigram", init_am_assignments="rand", time_power_term=1.):
+                 lms=1., wip=0., fb_type="bigram", init_am_assignments="rand", time_power_term=1.,
+                 sync="sequential", n_gibbs_blocks=8, n_stat_blocks=8, batch_seed=0, process_group=None):
+        """Same arguments as the reference (bigram_acoustic_wordseg.py:129-136) plus the execution
+        mode of UnigramAcousticWordseg (sync="batch": oracle/np_fbgmm_batch.py)."""
         logger.info("Initializing")
+        assert sync in ("sequential", "batch")
+        self.sync = sync
+        self._batch_args = (n_gibbs_blocks, n_stat_blocks, batch_seed, process_group)
+        self._sweeper = None
         assert seed_assignments_dict is None or seed_boundaries_dict is not None
         self.n_slices_min = n_slices_min
         self.n_slices_max = n_slices_max
@@ -57,6 +64,7 @@ class BigramAcousticWordseg(object):
 
         embeddings, vec_ids, ids_to_utterance_labels = process_embeddings(embedding_mats, vec_ids_dict)
         self.ids_to_utterance_labels = ids_to_utterance_labels
+        self._row_start = vec_ids.row_start
         N = embeddings.shape[0]
         seed_boundaries = None
         if seed_boundaries_dict is not None:
@@ -106,6 +114,10 @@ class BigramAcousticWordseg(object):
     _close_stream = UnigramAcousticWordseg._close_stream
     calc_p_continue = UnigramAcousticWordseg.calc_p_continue
     get_unsup_transcript_i = UnigramAcousticWordseg.get_unsup_transcript_i
+    _get_sweeper = UnigramAcousticWordseg._get_sweeper
+    batch_sweep_async = UnigramAcousticWordseg.batch_sweep_async
+    materialise = UnigramAcousticWordseg.materialise
+    _leave_batch = UnigramAcousticWordseg._leave_batch
 
     def set_fb_type(self, fb_type):
         self.fb_type = fb_type
@@ -171,6 +183,7 @@ class BigramAcousticWordseg(object):
 
     def gibbs_sample_i(self, i, anneal_temp=1, anneal_gibbs_am=False, assignments_only=False):
         """bigram_acoustic_wordseg.py:386-551."""
+        self._leave_batch()
         self._open_stream([i])
         self._gibbs_i_async(i, anneal_temp, anneal_gibbs_am, assignments_only)
         self._close_stream()
@@ -209,16 +222,25 @@ class BigramAcousticWordseg(object):
             rng.shuffle(utt_order)
             if debug_gibbs_only:
                 utt_order = [i_debug_monitor]
-            self._open_stream(utt_order)
-            for i_utt in utt_order:
-                self._gibbs_i_async(i_utt, anneal_temp, anneal_gibbs_am, assignments_only)
-            torch.cuda.synchronize()
-            self._close_stream()
-            self._df.check_status()
-            lps = self._df.out_logprob.cpu().numpy()
-            log_prob = 0
-            for i_utt in utt_order:
-                log_prob += 0. if assignments_only else lps[i_utt]
+            if self.sync == "batch":
+                assert self.fb_type == "unigram" and not assignments_only
+                self.batch_sweep_async(anneal_temp, anneal_gibbs_am)
+                torch.cuda.synchronize()
+                self._df.check_status()
+                log_prob = float(self._df.out_logprob.sum().item())
+                self.materialise()
+            else:
+                self._leave_batch()
+                self._open_stream(utt_order)
+                for i_utt in utt_order:
+                    self._gibbs_i_async(i_utt, anneal_temp, anneal_gibbs_am, assignments_only)
+                torch.cuda.synchronize()
+                self._close_stream()
+                self._df.check_status()
+                lps = self._df.out_logprob.cpu().numpy()
+                log_prob = 0
+                for i_utt in utt_order:
+                    log_prob += 0. if assignments_only else lps[i_utt]
 
             record_dict["sample_time"].append(time.time() - start_time)
             record_dict["log_marg"].append(self.log_marg())

@@ -1,0 +1,224 @@
+// Device helpers shared by the FBGMM kernels (segk_fbgmm.hip: the reference's serial chain;
+// segk_fbbatch.hip: the batch-synchronous sampler).  Everything is `static`: each translation
+// unit gets its own copy (no relocatable device code).
+#pragma once
+#include "segk_internal.h"
+
+#define NEG_INF_D (-__builtin_huge_val())
+#define LOG_2PI 1.8378770664093453
+#define LOG_PI 1.1447298858494002
+
+// ---------------------------------------------------------------------------------------
+// block-wide helpers (blockDim.x a multiple of 64, <= 1024; `red` has >= 16 doubles)
+// ---------------------------------------------------------------------------------------
+// Butterfly inside each wave, then the per-wave partials (<= 16) are added in wave order by every
+// thread: two barriers per reduction and a fixed, launch-independent order.
+static __device__ double block_sum(double v, double *red)
+{
+    const int tid = threadIdx.x, nw = blockDim.x >> 6;
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();                      // `red` may still be read from a previous reduction
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    double r = red[0];
+    for (int w = 1; w < nw; w++) r += red[w];
+    return r;
+}
+
+static __device__ double block_max(double v, double *red)
+{
+    const int tid = threadIdx.x, nw = blockDim.x >> 6;
+    for (int o = 32; o > 0; o >>= 1) {
+        const double other = __shfl_xor(v, o);
+        v = other > v ? other : v;
+    }
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    double r = red[0];
+    for (int w = 1; w < nw; w++) r = red[w] > r ? red[w] : r;
+    return r;
+}
+
+static __device__ __forceinline__ double fb_readlane(double v, int l)       // l wave-uniform
+{
+    union { double d; int i[2]; } u;
+    u.d = v;
+    u.i[0] = __builtin_amdgcn_readlane(u.i[0], l);
+    u.i[1] = __builtin_amdgcn_readlane(u.i[1], l);
+    return u.d;
+}
+
+// _cython_utils.pyx:13-25 (max, then the sum of exp(a[j] - max) in index order, then log) by one
+// full wave: the exponentials are evaluated one per lane, the additions stay sequential.
+static __device__ double fb_logsumexp_wave(const double *a, int n, int lane)
+{
+    double mx = NEG_INF_D;
+    for (int j = lane; j < n; j += 64) mx = a[j] > mx ? a[j] : mx;
+    for (int o = 32; o > 0; o >>= 1) {
+        double other = __shfl_xor(mx, o);
+        mx = other > mx ? other : mx;
+    }
+    double s = 0.0;
+    for (int j0 = 0; j0 < n; j0 += 64) {
+        const double ej = (j0 + lane < n) ? exp(a[j0 + lane] - mx) : 0.0;
+        const int cnt = n - j0 < 64 ? n - j0 : 64;
+        for (int q = 0; q < cnt; q++) s += fb_readlane(ej, q);
+    }
+    return log(s) + mx;
+}
+
+// embedding ids of the segments the boundaries of one utterance select, -1 (no embedding) skipped
+// (unigram_acoustic_wordseg.py:340-342)
+static __device__ int fb_collect_tokens(const int32_t *vid, const uint8_t *bnd, int N, int32_t *tok)
+{
+    int nn = 0, jp = 0;
+    for (int j = 0; j < N; j++)
+        if (bnd[j]) {
+            int id = vid[(j + 1) * j / 2 + jp];
+            if (id >= 0) tok[nn++] = id;
+            jp = j + 1;
+        }
+    return nn;
+}
+
+
+// Counter-based uniform in [0, 1) of the batch sampler: u01(seed, sweep, utterance, j) -- two rounds
+// of the splitmix64 finaliser over a linear combination of the counters (oracle/np_fbgmm_batch.py).
+static __device__ __forceinline__ double segk_u01(uint64_t seed, uint64_t sweep, uint64_t utt, uint64_t j)
+{
+    uint64_t z = seed * 0x9E3779B97F4A7C15ull + sweep * 0xBF58476D1CE4E5B9ull + utt * 0x94D049BB133111EBull
+                 + j * 0xD6E8FEB86659FD93ull + 0x2545F4914F6CDD1Dull;
+    for (int r = 0; r < 2; r++) {
+        z ^= z >> 30;
+        z *= 0xBF58476D1CE4E5B9ull;
+        z ^= z >> 27;
+        z *= 0x94D049BB133111EBull;
+        z ^= z >> 31;
+    }
+    return (double)(z >> 11) * (1.0 / 9007199254740992.0);
+}
+
+// where the backward-sampling steps take their uniforms from
+struct StreamUniforms {        // the pre-drawn `random.random()` values of the serial chain
+    const double *us;
+    int64_t cur, cap;
+    int32_t *status;
+    __device__ double next(int lane)
+    {
+        const double u = (cur < cap) ? us[cur] : 0.5;
+        if (cur >= cap && lane == 0) atomicOr(status, 8);
+        cur++;
+        return u;
+    }
+};
+
+struct CounterUniforms {       // the batch sampler's counter-based stream
+    uint64_t seed, sweep, utt, j;
+    __device__ double next(int) { return segk_u01(seed, sweep, utt, j++); }
+};
+
+// A6 / A7 by one full wave (unigram_acoustic_wordseg.py:653-864): forward filtering, then backward
+// sampling (or Viterbi back-tracking) writing the boundaries; returns the summed score of the chosen
+// segments.  Control flow and values are wave-uniform; the exponentials of each logsumexp /
+// normalisation are spread over the lanes, sums and draws keep the reference order.
+//   vec [tri] scores (LDS), a [N], w [N+1], pr [N+1] scratch (LDS), bnd [N] boundaries (global)
+template <typename USRC>
+static __device__ double fb_dp_sample(const double *vec, double *a, double *w, double *pr, int N, int tri, int n_max,
+                                      int viterbi, double log_p_continue, double anneal_temp, uint8_t *bnd, int lane,
+                                      USRC &usrc)
+{
+    for (int j = lane; j < N; j += 64) { a[j] = 1.0; bnd[j] = (j == N - 1) ? 1 : 0; }
+    __builtin_amdgcn_wave_barrier();
+    a[0] = 0.0;
+    __builtin_amdgcn_wave_barrier();
+    int i = 0;
+    for (int t = 1; t < N; t++) {
+        int lo = (n_max == 0 || t - n_max < 0) ? 0 : t - n_max;
+        int n = t - lo;
+        bool all_inf = true;
+        double best = NEG_INF_D;
+        for (int s = lo; s < t; s++) {
+            double v = vec[i + s] + a[s];
+            if (lane == 0) w[s - lo] = v;
+            if (v != NEG_INF_D) all_inf = false;
+            if (v > best) best = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+        double at;
+        if (viterbi) at = best;
+        else at = all_inf ? NEG_INF_D : fb_logsumexp_wave(w, n, lane) + log_p_continue;
+        if (lane == 0) a[t] = at;
+        __builtin_amdgcn_wave_barrier();
+        i += t;
+    }
+    int t = N, lo = 0;
+    double total = 0.0;
+    for (;;) {
+        i = (t - 1) * t / 2;
+        lo = (n_max == 0 || t - n_max < 0) ? 0 : t - n_max;
+        bool all_inf = true;
+        for (int s = lo; s < t; s++)
+            if (vec[i + s] + a[s] != NEG_INF_D) { all_inf = false; break; }
+        if (all_inf) {
+            while (all_inf) {
+                t = t - 1;
+                if (t == 0) break;
+                i = (t - 1) * t / 2;
+                lo = (n_max == 0 || t - n_max < 0) ? 0 : t - n_max;
+                all_inf = true;
+                for (int s = lo; s < t; s++)
+                    if (vec[i + s] + a[s] != NEG_INF_D) { all_inf = false; break; }
+            }
+            if (lane == 0) bnd[(t - 1 + N) % N] = 1;
+        }
+        int k = 1, n = 1;
+        if (t > 0) {
+            n = t - lo;
+            for (int j = lane; j < n; j += 64) w[j] = vec[i + lo + j] + a[lo + j];
+        } else {
+            if (lane == 0) w[0] = NEG_INF_D;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const double lse = fb_logsumexp_wave(w, n, lane);
+        if (viterbi) {
+            if (t > 0) {
+                for (int j = lane; j < n; j += 64) pr[j] = exp(w[j] - lse);
+                __builtin_amdgcn_wave_barrier();
+                double best = 0.0;
+                bool first = true;
+                for (int s = t - 1; s >= lo; s--) {
+                    double q = pr[s - lo];
+                    if (first || q > best) { best = q; k = t - s; first = false; }
+                }
+            }
+        } else {
+            if (anneal_temp != 1.0) {
+                const double inv = 1. / anneal_temp;
+                for (int j = lane; j < n; j += 64) pr[j] = w[n - 1 - j] - lse;
+                __builtin_amdgcn_wave_barrier();
+                for (int j = lane; j < n; j += 64) w[j] = inv * pr[j];
+                __builtin_amdgcn_wave_barrier();
+                const double lse2 = fb_logsumexp_wave(w, n, lane);
+                for (int j = lane; j < n; j += 64) pr[j] = exp(w[j] - lse2);
+            } else {
+                for (int j = lane; j < n; j += 64) pr[j] = exp(w[n - 1 - j] - lse);
+            }
+            __builtin_amdgcn_wave_barrier();
+            double uu = usrc.next(lane);
+            int kk = n - 1;
+            for (int j = 0; j < n; j++) {
+                uu = uu - pr[j];
+                if (uu < 0) { kk = j; break; }
+            }
+            k = kk + 1;
+        }
+        int idx = i + t - k;
+        if (idx < 0) idx += tri;
+        total += vec[idx];
+        if (t - k - 1 < 0) break;
+        if (lane == 0) bnd[t - k - 1] = 1;
+        t = t - k;
+    }
+    return total;
+}

@@ -1,0 +1,717 @@
+// segk_fbbatch.hip -- batch-synchronous ("blocked parallel Gibbs") sweep of the FBGMM / bigram
+// word-segmentation samplers on gfx950.  The reference has no parallel mode; the sampler is
+// specified in oracle/np_fbgmm_batch.py and built from the reference's pieces: log_marg_i
+// (fbgmm.py:256-285), the predictive densities (gaussian_components_fixedvar.py:224-253,
+// gaussian_components_diag.py:215-259), forward filtering / backward sampling
+// (unigram_acoustic_wordseg.py:653-756), utils.draw (utils.py:10-21), the bigram LM prior
+// (bigram_lms.py:64-91).
+//
+// One Gibbs step b of a sweep (host: device.py FbgmmBatchSweeper):
+//   k_fbb_prepare   statistics of all tokens outside block b from the per-(block, slice) partial
+//                   sums, in the fixed order of the specification, and the per-slot predictive
+//                   parameters derived from them (transposed [D, K_max] for coalesced slot lanes)
+//   k_fbb_score     log_marg_i of every candidate span of the block: R rows x all slots per
+//                   workgroup, online logsumexp per row                         (fp64 VALU)
+//   k_fbb_segment   one workgroup per utterance: score vector, DP, backward sampling with the
+//                   counter-based uniforms, new token list
+//   k_fbb_assign    one workgroup per utterance: logits -> softmax -> draw for each new token
+//                   (with a language model: the bigram prior of the previous token's slot)
+//   k_fbb_partials  the block's partial sums from its new tokens (token order per slot)
+// Everything is fp64; the 1e-4 contract of the path would allow fp32 matrix arithmetic for the
+// fixed-variance score -- left for a later round.
+#include <stdlib.h>
+
+#include "segk_fb_common.h"
+
+#define FBB_R 8            // rows per workgroup of the score kernel
+#define FBB_MAXCH 4        // dimension chunks of 64 lanes held in registers (D <= 256)
+
+static __device__ __forceinline__ int64_t fbb_rec(const segk_fbgmm &f, int D) { return (int64_t)f.K_max * (2 * D + 1); }
+
+template <typename XT>
+static __device__ __forceinline__ double fbb_sq(XT x)      // np.square(X) in the dtype of X (diag:125)
+{
+    XT q = x * x;
+    return (double)q;
+}
+
+// which (slice, local index) a workgroup works on: `off` is the prefix of the per-slice counts
+struct FbbMap {
+    int n;
+    int lo[16];
+    int off[17];
+};
+
+static __device__ __forceinline__ bool fbb_locate(const FbbMap &m, int wg, int *slice, int *idx)
+{
+    for (int s = 0; s < m.n; s++)
+        if (wg < m.off[s + 1]) {
+            *slice = s;
+            *idx = wg - m.off[s];
+            return true;
+        }
+    return false;
+}
+
+// ---------------------------------------------------------------------------------------
+// partial sums of (slice s, block b) from the current token lists: one wave per (s, slot)
+// ---------------------------------------------------------------------------------------
+template <typename XT>
+__global__ void k_fbb_partials(segk_corpus c, segk_fbgmm f, segk_fbatch bt, int s_lo, int s_n, int b,
+                               const int32_t *new_tok, const int32_t *n_new)
+{
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (wave >= s_n * f.K_max) return;
+    const int s = s_lo + wave / f.K_max, k = wave % f.K_max;
+    const int D = c.D;
+    const XT *X = (const XT *)c.X;
+    const int u0 = bt.utt_range[(s * bt.n_blocks + b) * 2], u1 = bt.utt_range[(s * bt.n_blocks + b) * 2 + 1];
+    double ax[FBB_MAXCH], axx[FBB_MAXCH];
+#pragma unroll
+    for (int q = 0; q < FBB_MAXCH; q++) { ax[q] = 0.0; axx[q] = 0.0; }
+    double n = 0.0;
+    for (int u = u0; u < u1; u++) {
+        const int nn = n_new[u];
+        int id = -1, match = 0;
+        if (lane < nn) {
+            id = new_tok[(int64_t)u * c.N_max + lane];
+            match = bt.slot[id] == k;
+        }
+        unsigned long long bal = __ballot(match);
+        while (bal) {                                   // token order
+            const int src = __ffsll((long long)bal) - 1;
+            bal &= bal - 1;
+            const int64_t e = __shfl(id, src);
+            n += 1.0;
+#pragma unroll
+            for (int q = 0; q < FBB_MAXCH; q++) {
+                const int d = q * 64 + lane;
+                if (d < D) {
+                    const XT x = X[e * c.ldx + d];
+                    ax[q] += (double)x;
+                    axx[q] += fbb_sq<XT>(x);
+                }
+            }
+        }
+    }
+    double *rec = bt.partials + ((int64_t)b * bt.n_slices + s) * fbb_rec(f, D);
+    if (lane == 0) rec[k] = n;
+#pragma unroll
+    for (int q = 0; q < FBB_MAXCH; q++) {
+        const int d = q * 64 + lane;
+        if (d < D) {
+            rec[f.K_max + (int64_t)k * D + d] = ax[q];
+            rec[f.K_max + (int64_t)f.K_max * D + (int64_t)k * D + d] = axx[q];
+        }
+    }
+}
+
+// the pairing of oracle tree_sum: [(0+1), (2+3), ...], odd element carried
+static __device__ __forceinline__ double fbb_tree(double *p, int n, int stride)
+{
+    while (n > 1) {
+        const int h = n >> 1;
+        for (int j = 0; j < h; j++) p[j * stride] = p[2 * j * stride] + p[(2 * j + 1) * stride];
+        if (n & 1) p[h * stride] = p[(n - 1) * stride];
+        n = (n + 1) >> 1;
+    }
+    return p[0];
+}
+
+// ---------------------------------------------------------------------------------------
+// statistics without block b (b = -1: all) and the per-slot predictive parameters.
+// One wave per slot; lanes over the dimensions.  Shared scratch: [waves][16 slices][64 lanes].
+// ---------------------------------------------------------------------------------------
+__global__ void k_fbb_prepare(segk_fbgmm f, segk_fbatch bt, int D, int b, double prior_alpha)
+{
+    __shared__ double scr[4][16][64];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int k = blockIdx.x * 4 + w;
+    if (k >= f.K_max) return;
+    const int S = bt.n_slices, B = bt.n_blocks, KM = f.K_max;
+    const int64_t rec = fbb_rec(f, D);
+    double (*my)[64] = scr[w];
+    // counts
+    for (int s = 0; s < S; s++) {
+        double a = 0.0;
+        for (int bp = 0; bp < B; bp++)
+            if (bp != b) a += bt.partials[((int64_t)bp * S + s) * rec + k];
+        my[s][lane] = a;
+    }
+    const double n = fbb_tree(&my[0][lane], S, 64);
+    double lsum = 0.0;
+    const double k_N = f.k_0 + n, v_N = f.v_0 + n;
+    for (int d0 = 0; d0 < D; d0 += 64) {
+        const int d = d0 + lane;
+        double sx = 0.0, sxx = 0.0;
+        if (d < D) {
+            for (int s = 0; s < S; s++) {
+                double a = 0.0;
+                for (int bp = 0; bp < B; bp++)
+                    if (bp != b) a += bt.partials[((int64_t)bp * S + s) * rec + KM + (int64_t)k * D + d];
+                my[s][lane] = a;
+            }
+            sx = fbb_tree(&my[0][lane], S, 64);
+            if (f.cov_type == 1) {
+                for (int s = 0; s < S; s++) {
+                    double a = 0.0;
+                    for (int bp = 0; bp < B; bp++)
+                        if (bp != b) a += bt.partials[((int64_t)bp * S + s) * rec + KM + (int64_t)KM * D + (int64_t)k * D + d];
+                    my[s][lane] = a;
+                }
+                sxx = fbb_tree(&my[0][lane], S, 64);
+            }
+            double mean, q, lt;
+            if (f.cov_type == 0) {          // fixedvar:153-170, 317-325
+                const double pN = f.prior_c[d] + n * f.prior_a[d];
+                mean = (f.prior_c[d] * f.prior_b[d] + f.prior_a[d] * sx) / pN;
+                q = pN * f.prior_a[d] / (pN + f.prior_a[d]);
+                lt = log(q);
+            } else {                        // diag:162-177, 332-345
+                mean = (f.k_0 * f.prior_b[d] + sx) / k_N;
+                const double var = (k_N + 1.) / (k_N * v_N)
+                                   * (f.prior_a[d] + f.k_0 * (f.prior_b[d] * f.prior_b[d]) + sxx - k_N * (mean * mean));
+                q = 1. / var * (1. / v_N);
+                lt = log(var);
+            }
+            bt.mean_t[(int64_t)d * KM + k] = mean;
+            bt.q_t[(int64_t)d * KM + k] = q;
+            lsum += lt;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) lsum += __shfl_xor(lsum, o);
+    if (lane == 0) {
+        double lconst;
+        if (f.cov_type == 0) lconst = -0.5 * (double)D * 1.8378770664093453 + 0.5 * lsum;
+        else lconst = (double)D * (lgamma((v_N + 1.) / 2.) - lgamma(v_N / 2.) - 0.5 * log(v_N) - 0.5 * 1.1447298858494002) - 0.5 * lsum;
+        bt.cnt[k] = n;
+        bt.lconst[k] = lconst;
+        bt.zconst[k] = f.lms * log(prior_alpha / (double)KM + n) + (n > 0.0 ? lconst : 0.0);
+        bt.half[k] = f.cov_type == 0 ? 0.5 : (v_N + 1.) / 2.;
+        atomicAdd(&bt.scal[0], n);                       // integer valued: exact in any order
+        if (n > 0.0) atomicAdd(&bt.scal[1], 1.0);
+    }
+}
+
+// x-dependent part of the prior predictive of one row, by one wave (lanes over d); result in all lanes
+template <typename XT>
+static __device__ double fbb_prior_row(const segk_fbgmm &f, int D, const double *x, int lane)
+{
+    double s = 0.0;
+    for (int d = lane; d < D; d += 64) {
+        const double delta = x[d] - f.prior_b[d];
+        if (f.cov_type == 0) s += delta * delta * f.prior_c[d];
+        else {
+            const double var = (f.k_0 + 1.) / (f.k_0 * f.v_0) * f.prior_a[d];
+            s += log(1. + 1. / f.v_0 * (delta * delta) * (1. / var));
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    return f.cov_type == 0 ? f.kconst[f.K_max] - 0.5 * s : f.kconst[f.K_max] - (f.v_0 + 1.) / 2. * s;
+}
+
+// ---------------------------------------------------------------------------------------
+// score of FBB_R rows against all slots per workgroup; online logsumexp per row and thread,
+// merged across the workgroup at the end.
+// ---------------------------------------------------------------------------------------
+template <typename XT, int COV>
+__global__ void k_fbb_score(segk_corpus c, segk_fbgmm f, segk_fbatch bt, FbbMap map, int b, double prior_alpha,
+                            double *score)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int D = c.D, KM = f.K_max, tid = threadIdx.x, nt = blockDim.x;
+    double *xs = (double *)smem;                 // [R][D]
+    double *lpr = xs + FBB_R * D;                // [R]
+    double *red = lpr + FBB_R;                   // [16]
+    int s, idx;
+    if (!fbb_locate(map, blockIdx.x, &s, &idx)) return;
+    const int slice = map.lo[s];
+    const int64_t r_lo = bt.row_range[(slice * bt.n_blocks + b) * 2], r_hi = bt.row_range[(slice * bt.n_blocks + b) * 2 + 1];
+    const int64_t row0 = r_lo + (int64_t)idx * FBB_R;
+    const int nr = (int)((r_hi - row0) < FBB_R ? (r_hi - row0) : FBB_R);
+    const XT *X = (const XT *)c.X;
+    for (int j = tid; j < FBB_R * D; j += nt) {
+        const int r = j / D, d = j - r * D;
+        xs[j] = r < nr ? (double)X[(row0 + r) * c.ldx + d] : 0.0;
+    }
+    __syncthreads();
+    {
+        const int w = tid >> 6, lane = tid & 63, nw = nt >> 6;
+        for (int r = w; r < FBB_R; r += nw) {
+            const double v = fbb_prior_row<XT>(f, D, xs + r * D, lane);
+            if (lane == 0) lpr[r] = v;
+        }
+    }
+    __syncthreads();
+    const double zc_empty = f.lms * log(prior_alpha / (double)KM);
+    double mx[FBB_R], sm[FBB_R];
+#pragma unroll
+    for (int r = 0; r < FBB_R; r++) { mx[r] = NEG_INF_D; sm[r] = 0.0; }
+    for (int k = tid; k < KM; k += nt) {
+        double z[FBB_R];
+        if (bt.cnt[k] > 0.0) {
+            double acc[FBB_R];
+#pragma unroll
+            for (int r = 0; r < FBB_R; r++) acc[r] = 0.0;
+            for (int d = 0; d < D; d++) {
+                const double m = bt.mean_t[(int64_t)d * KM + k], q = bt.q_t[(int64_t)d * KM + k];
+#pragma unroll
+                for (int r = 0; r < FBB_R; r++) {
+                    const double delta = m - xs[r * D + d];
+                    if (COV == 0) acc[r] += (delta * delta) * q;
+                    else acc[r] += log(1. + (delta * delta) * q);
+                }
+            }
+            const double zc = bt.zconst[k], h = bt.half[k];
+#pragma unroll
+            for (int r = 0; r < FBB_R; r++) z[r] = zc - h * acc[r];
+        } else {
+#pragma unroll
+            for (int r = 0; r < FBB_R; r++) z[r] = zc_empty + lpr[r];
+        }
+#pragma unroll
+        for (int r = 0; r < FBB_R; r++) {
+            if (z[r] > mx[r]) {
+                sm[r] = sm[r] * exp(mx[r] - z[r]) + 1.0;       // exp(-inf) = 0 on the first value
+                mx[r] = z[r];
+            } else {
+                sm[r] += exp(z[r] - mx[r]);
+            }
+        }
+    }
+    const double norm = f.lms * log(bt.scal[0] + prior_alpha);
+#pragma unroll
+    for (int r = 0; r < FBB_R; r++) {
+        const double M = block_max(mx[r], red);
+        const double part = mx[r] == NEG_INF_D ? 0.0 : sm[r] * exp(mx[r] - M);
+        const double S = block_sum(part, red);
+        if (tid == 0 && r < nr) score[row0 + r] = log(S) + M - norm;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// boundaries of one utterance per workgroup (128 threads; wave 0 runs the DP)
+// ---------------------------------------------------------------------------------------
+__global__ void k_fbb_segment(segk_corpus c, segk_fbatch bt, FbbMap map, int b, uint64_t sweep, int n_max, double wip,
+                              double time_power_term, double anneal_temp, const double *score, uint8_t *boundaries,
+                              int32_t *new_tok, int32_t *n_new, double *out_logprob, int32_t *status)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int s, idx;
+    if (!fbb_locate(map, blockIdx.x, &s, &idx)) return;
+    const int slice = map.lo[s];
+    const int utt = bt.utt_range[(slice * bt.n_blocks + b) * 2] + idx;
+    const int N = c.lengths[utt];
+    const int tri = N * (N + 1) / 2;
+    const int64_t triMax = (int64_t)c.N_max * (c.N_max + 1) / 2;
+    const int32_t *vid = c.vec_ids + (int64_t)utt * triMax;
+    const double *dur = c.durations + (int64_t)utt * triMax;
+    double *vec = (double *)smem;           // [tri]
+    double *a = vec + triMax;               // [N]
+    double *w = a + c.N_max;                // [N+1]
+    double *pr = w + c.N_max + 1;           // [N+1]
+    int32_t *old = (int32_t *)(pr + c.N_max + 1);      // [N_max]
+    for (int j = threadIdx.x; j < tri; j += blockDim.x) {       // unigram_acoustic_wordseg.py:474-511
+        const int id = vid[j];
+        double v = NEG_INF_D;
+        if (id >= 0) {
+            const double dd = dur[j];
+            v = isnan(dd) ? NEG_INF_D : score[id] * pow(dd, time_power_term);
+        }
+        vec[j] = v + wip;
+    }
+    __syncthreads();
+    if (threadIdx.x >= 64) return;
+    const int lane = threadIdx.x;
+    uint8_t *bnd = boundaries + (int64_t)utt * c.N_max;
+    int n_old = 0;
+    if (lane == 0) n_old = fb_collect_tokens(vid, bnd, N, old);
+    n_old = __shfl(n_old, 0);
+    __builtin_amdgcn_wave_barrier();
+    CounterUniforms usrc = {bt.seed, sweep, (uint64_t)utt, 0};
+    const double total = fb_dp_sample(vec, a, w, pr, N, tri, n_max, 0, 0.0, anneal_temp, bnd, lane, usrc);
+    for (int j = lane; j < n_old; j += 64) bt.slot[old[j]] = -1;
+    if (lane != 0) return;
+    if (total == NEG_INF_D) atomicOr(status, 16);
+    out_logprob[utt] = total;
+    n_new[utt] = fb_collect_tokens(vid, bnd, N, new_tok + (int64_t)utt * c.N_max);
+}
+
+// ---------------------------------------------------------------------------------------
+// slots of the new tokens of one utterance per workgroup
+// ---------------------------------------------------------------------------------------
+template <typename XT, int COV>
+__global__ void k_fbb_assign(segk_corpus c, segk_fbgmm f, segk_fbatch bt, FbbMap map, int b, uint64_t sweep,
+                             double prior_alpha, double anneal_temp, const int32_t *new_tok, const int32_t *n_new)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int D = c.D, KM = f.K_max, tid = threadIdx.x, nt = blockDim.x;
+    double *z = (double *)smem;                  // [K_max]
+    double *xs = z + KM;                         // [D]
+    double *red = xs + D;                        // [16]
+    __shared__ double sh_lpr;
+    __shared__ int sh_k;
+    int s, idx;
+    if (!fbb_locate(map, blockIdx.x, &s, &idx)) return;
+    const int slice = map.lo[s];
+    const int utt = bt.utt_range[(slice * bt.n_blocks + b) * 2] + idx;
+    const XT *X = (const XT *)c.X;
+    const int nn = n_new[utt];
+    const double zc_empty = f.lms * log(prior_alpha / (double)KM);
+    const double tot = bt.scal[0];
+    int j_prev = -1;
+    for (int t = 0; t < nn; t++) {
+        const int64_t e = new_tok[(int64_t)utt * c.N_max + t];
+        __syncthreads();
+        for (int d = tid; d < D; d += nt) xs[d] = (double)X[e * c.ldx + d];
+        __syncthreads();
+        if (tid < 64) {
+            const double v = fbb_prior_row<XT>(f, D, xs, tid);
+            if (tid == 0) sh_lpr = v;
+        }
+        __syncthreads();
+        const double lpr = sh_lpr;
+        for (int k = tid; k < KM; k += nt) {
+            const double n = bt.cnt[k];
+            double ll = lpr;
+            if (n > 0.0) {
+                double acc = 0.0;
+                for (int d = 0; d < D; d++) {
+                    const double delta = bt.mean_t[(int64_t)d * KM + k] - xs[d];
+                    if (COV == 0) acc += (delta * delta) * bt.q_t[(int64_t)d * KM + k];
+                    else acc += log(1. + (delta * delta) * bt.q_t[(int64_t)d * KM + k]);
+                }
+                ll = bt.lconst[k] - bt.half[k] * acc;
+            }
+            double pz;
+            if (!f.lm_unigram) pz = n > 0.0 ? f.lms * log(prior_alpha / (double)KM + n) : zc_empty;   // fbgmm.py:436-440
+            else if (j_prev < 0) pz = (log(n + f.lm_a / (double)KM) - log(tot + f.lm_a)) * f.lms;  // bigram_lms.py:64-69
+            else {                                                                                // bigram_lms.py:84-91
+                const double pi = (n + f.lm_a / (double)KM) / (tot + f.lm_a);
+                const double pij = (1. - f.lm_lambda) * ((double)f.lm_bigram[(int64_t)j_prev * KM + k] + f.lm_b / (double)KM)
+                                   / (bt.cnt[j_prev] + f.lm_b);
+                pz = log(f.lm_lambda * pi + pij) * f.lms;
+            }
+            z[k] = pz + ll;
+        }
+        __syncthreads();
+        // softmax (scipy logsumexp order), optional annealing (fbgmm.py:446-449), utils.draw
+        double mx = NEG_INF_D;
+        for (int k = tid; k < KM; k += nt) mx = z[k] > mx ? z[k] : mx;
+        mx = block_max(mx, red);
+        double sm = 0.0;
+        for (int k = tid; k < KM; k += nt) sm += exp(z[k] - mx);
+        sm = block_sum(sm, red);
+        double lse = log(sm) + mx;
+        if (anneal_temp != 1.0) {
+            for (int k = tid; k < KM; k += nt) z[k] = (1. / anneal_temp) * (z[k] - lse);
+            __syncthreads();
+            double mx2 = NEG_INF_D;
+            for (int k = tid; k < KM; k += nt) mx2 = z[k] > mx2 ? z[k] : mx2;
+            mx2 = block_max(mx2, red);
+            double s2 = 0.0;
+            for (int k = tid; k < KM; k += nt) s2 += exp(z[k] - mx2);
+            s2 = block_sum(s2, red);
+            lse = log(s2) + mx2;
+        }
+        for (int k = tid; k < KM; k += nt) z[k] = exp(z[k] - lse);
+        __syncthreads();
+        if (tid == 0) {
+            double uu = segk_u01(bt.seed, sweep, (uint64_t)utt, (uint64_t)(c.N_max + t));
+            int k = KM - 1;
+            for (int q = 0; q < KM; q++) {
+                uu = uu - z[q];
+                if (uu < 0) { k = q; break; }
+            }
+            bt.slot[e] = k;
+            sh_k = k;
+        }
+        __syncthreads();
+        if (f.lm_unigram) j_prev = sh_k;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// language-model tables (integers): transcripts of block b, all slices, +/-; and the fill of the
+// replicated transcript store from the local slices' new tokens.
+//   lm_tok [B][S][U_max][N_max] int32 slots, -1 padded
+// ---------------------------------------------------------------------------------------
+__global__ void k_fbb_lm_apply(segk_fbgmm f, segk_fbatch bt, int N_max, int b, int sign)
+{
+    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n_rows = (int64_t)bt.n_slices * bt.u_max;
+    if (row >= n_rows) return;
+    const int32_t *t = bt.lm_tok + ((int64_t)b * n_rows + row) * N_max;
+    int prev = -1;
+    for (int j = 0; j < N_max; j++) {
+        const int k = t[j];
+        if (k < 0) break;
+        if (prev >= 0)
+            atomicAdd((unsigned long long *)&f.lm_bigram[(int64_t)prev * f.K_max + k], (unsigned long long)(long long)sign);
+        prev = k;
+    }
+}
+
+__global__ void k_fbb_lm_fill(segk_corpus c, segk_fbatch bt, FbbMap map, int b, const int32_t *new_tok,
+                              const int32_t *n_new)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    int s, idx;
+    if (!fbb_locate(map, g, &s, &idx)) return;
+    const int slice = map.lo[s];
+    const int utt = bt.utt_range[(slice * bt.n_blocks + b) * 2] + idx;
+    int32_t *t = bt.lm_tok + (((int64_t)b * bt.n_slices + slice) * bt.u_max + idx) * c.N_max;
+    const int nn = n_new[utt];
+    for (int j = 0; j < c.N_max; j++) t[j] = j < nn ? bt.slot[new_tok[(int64_t)utt * c.N_max + j]] : -1;
+}
+
+// token lists of all utterances from the boundaries (entering batch mode)
+__global__ void k_fbb_collect(segk_corpus c, const uint8_t *boundaries, int32_t *new_tok, int32_t *n_new)
+{
+    const int utt = blockIdx.x * blockDim.x + threadIdx.x;
+    if (utt >= c.n_utt) return;
+    const int64_t triMax = (int64_t)c.N_max * (c.N_max + 1) / 2;
+    n_new[utt] = fb_collect_tokens(c.vec_ids + (int64_t)utt * triMax, boundaries + (int64_t)utt * c.N_max,
+                                   c.lengths[utt], new_tok + (int64_t)utt * c.N_max);
+}
+
+// the reference's view: occupied slots relabelled 0..K-1 in increasing slot order
+__global__ void k_fbb_remap(segk_fbgmm f, segk_fbatch bt, int32_t *remap)
+{
+    __shared__ int base;
+    if (threadIdx.x == 0) base = 0;
+    __syncthreads();
+    for (int k0 = 0; k0 < f.K_max; k0 += blockDim.x) {
+        const int k = k0 + threadIdx.x;
+        const int occ = (k < f.K_max) && (bt.cnt[k] > 0.0);
+        // ranks inside this chunk of blockDim slots (blockDim = 64: one wave)
+        const unsigned long long bal = __ballot(occ);
+        const int before = __popcll(bal & ((1ull << threadIdx.x) - 1ull));
+        if (k < f.K_max) remap[k] = occ ? base + before : -1;
+        __syncthreads();
+        if (threadIdx.x == 0) base += __popcll(bal);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *f.K = base;
+}
+
+__global__ void k_fbb_apply_remap(segk_fbgmm f, segk_fbatch bt, int64_t n_emb, const int32_t *remap)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_emb) return;
+    const int sl = bt.slot[e];
+    f.assignments[e] = sl >= 0 ? remap[sl] : -1;
+}
+
+// ======================================================================================
+// C ABI
+// ======================================================================================
+#define DISPATCH_XT(c, ...)                         \
+    do {                                            \
+        if ((c)->x_dtype == SEGK_F32) {             \
+            typedef float XT;                       \
+            __VA_ARGS__                             \
+        } else {                                    \
+            typedef double XT;                      \
+            __VA_ARGS__                             \
+        }                                           \
+    } while (0)
+
+static int check_fbb(const segk_corpus *c, const segk_fbgmm *f, const segk_fbatch *bt)
+{
+    SEGK_REQUIRE(c && f && bt, "NULL corpus / fbgmm / batch state");
+    SEGK_REQUIRE(f->cov_type == 0 || f->cov_type == 1, "cov_type must be 0 (fixed) or 1 (diag)");
+    SEGK_REQUIRE(c->D > 0 && c->D <= 64 * FBB_MAXCH, "batch mode supports D <= 256");
+    SEGK_REQUIRE(c->N_max > 0 && c->N_max <= 64, "batch mode supports at most 64 landmarks per utterance");
+    SEGK_REQUIRE(bt->n_slices >= 1 && bt->n_slices <= 16, "n_slices must be in 1..16");
+    SEGK_REQUIRE(bt->n_blocks >= 2, "n_blocks must be >= 2 (with one block nothing is conditioned on)");
+    SEGK_REQUIRE(f->kconst != NULL, "kconst buffer missing");
+    return SEGK_OK;
+}
+
+// host copies of the ranges are passed in: counts[s] = work items of local slice s_lo + s
+static int make_map(FbbMap *m, int s_lo, int s_n, const int32_t *counts, int per_wg)
+{
+    SEGK_REQUIRE(s_n >= 1 && s_n <= 16, "at most 16 local slices");
+    m->n = s_n;
+    m->off[0] = 0;
+    for (int s = 0; s < s_n; s++) {
+        m->lo[s] = s_lo + s;
+        m->off[s + 1] = m->off[s] + (counts[s] + per_wg - 1) / per_wg;
+    }
+    return SEGK_OK;
+}
+
+extern "C" {
+
+int32_t segk_fbb_collect(segk_ctx *ctx, const segk_corpus *c, const uint8_t *boundaries, int32_t *new_tok,
+                         int32_t *n_new, void *stream)
+{
+    (void)ctx;
+    SEGK_REQUIRE(c && c->n_utt > 0, "corpus without utterances");
+    hipLaunchKernelGGL(k_fbb_collect, dim3((c->n_utt + 127) / 128), dim3(128), 0, (hipStream_t)stream, *c, boundaries,
+                       new_tok, n_new);
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+int32_t segk_fbb_partials(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *f, const segk_fbatch *bt,
+                          int32_t s_lo, int32_t s_n, int32_t b, const int32_t *new_tok, const int32_t *n_new,
+                          void *stream)
+{
+    (void)ctx;
+    int rc = check_fbb(c, f, bt);
+    if (rc) return rc;
+    SEGK_REQUIRE(s_lo >= 0 && s_n >= 1 && s_lo + s_n <= bt->n_slices && b >= 0 && b < bt->n_blocks, "slice / block range");
+    const int64_t waves = (int64_t)s_n * f->K_max;
+    DISPATCH_XT(c, hipLaunchKernelGGL(k_fbb_partials<XT>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0,
+                                       (hipStream_t)stream, *c, *f, *bt, s_lo, s_n, b, new_tok, n_new););
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+int32_t segk_fbb_prepare(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *f, const segk_fbatch *bt, int32_t b,
+                         void *stream)
+{
+    (void)ctx;
+    int rc = check_fbb(c, f, bt);
+    if (rc) return rc;
+    SEGK_REQUIRE(b >= -1 && b < bt->n_blocks, "block");
+    hipStream_t st = (hipStream_t)stream;
+    SEGK_CHECK_HIP(hipMemsetAsync(bt->scal, 0, 2 * sizeof(double), st));
+    const double alpha = f->lm_unigram ? f->lm_a : f->alpha;
+    hipLaunchKernelGGL(k_fbb_prepare, dim3((f->K_max + 3) / 4), dim3(256), 0, st, *f, *bt, c->D, b, alpha);
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+int32_t segk_fbb_score(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *f, const segk_fbatch *bt, int32_t s_lo,
+                       int32_t s_n, int32_t b, const int32_t *n_rows, double *score, void *stream)
+{
+    (void)ctx;
+    int rc = check_fbb(c, f, bt);
+    if (rc) return rc;
+    FbbMap m;
+    rc = make_map(&m, s_lo, s_n, n_rows, FBB_R);
+    if (rc) return rc;
+    if (m.off[s_n] == 0) return SEGK_OK;
+    const double alpha = f->lm_unigram ? f->lm_a : f->alpha;
+    const size_t lds = (size_t)(FBB_R * c->D + FBB_R + 16) * sizeof(double);
+    DISPATCH_XT(c, {
+        if (f->cov_type == 0)
+            hipLaunchKernelGGL((k_fbb_score<XT, 0>), dim3(m.off[s_n]), dim3(256), lds, (hipStream_t)stream, *c, *f, *bt, m,
+                               b, alpha, score);
+        else
+            hipLaunchKernelGGL((k_fbb_score<XT, 1>), dim3(m.off[s_n]), dim3(256), lds, (hipStream_t)stream, *c, *f, *bt, m,
+                               b, alpha, score);
+    });
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+int32_t segk_fbb_segment(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *f, const segk_fbatch *bt, int32_t s_lo,
+                         int32_t s_n, int32_t b, const int32_t *n_utts, uint64_t sweep, int32_t n_slices_min,
+                         int32_t n_slices_max, double wip, double time_power_term, double anneal_temp,
+                         const double *score, uint8_t *boundaries, int32_t *new_tok, int32_t *n_new,
+                         double *out_logprob, int32_t *status, void *stream)
+{
+    (void)ctx;
+    int rc = check_fbb(c, f, bt);
+    if (rc) return rc;
+    SEGK_REQUIRE(n_slices_min == 0 || n_slices_min == 1, "n_slices_min must be 0 or 1");
+    FbbMap m;
+    rc = make_map(&m, s_lo, s_n, n_utts, 1);
+    if (rc) return rc;
+    if (m.off[s_n] == 0) return SEGK_OK;
+    const int64_t triMax = (int64_t)c->N_max * (c->N_max + 1) / 2;
+    const size_t lds = (size_t)(triMax + 3 * c->N_max + 2) * sizeof(double) + (size_t)c->N_max * sizeof(int32_t);
+    SEGK_REQUIRE(lds <= 64 * 1024, "N_max too large for the LDS score vector");
+    hipLaunchKernelGGL(k_fbb_segment, dim3(m.off[s_n]), dim3(128), lds, (hipStream_t)stream, *c, *bt, m, b, sweep,
+                       n_slices_max, wip, time_power_term, anneal_temp, score, boundaries, new_tok, n_new, out_logprob,
+                       status);
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+int32_t segk_fbb_assign(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *f, const segk_fbatch *bt, int32_t s_lo,
+                        int32_t s_n, int32_t b, const int32_t *n_utts, uint64_t sweep, double anneal_temp,
+                        const int32_t *new_tok, const int32_t *n_new, void *stream)
+{
+    (void)ctx;
+    int rc = check_fbb(c, f, bt);
+    if (rc) return rc;
+    FbbMap m;
+    rc = make_map(&m, s_lo, s_n, n_utts, 1);
+    if (rc) return rc;
+    if (m.off[s_n] == 0) return SEGK_OK;
+    const double alpha = f->lm_unigram ? f->lm_a : f->alpha;
+    const size_t lds = (size_t)(f->K_max + c->D + 16) * sizeof(double);
+    SEGK_REQUIRE(lds <= 160 * 1024, "K_max too large for the LDS logits buffer");
+    DISPATCH_XT(c, {
+        if (f->cov_type == 0) {
+            if (lds > 48 * 1024)
+                SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_fbb_assign<XT, 0>,
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((k_fbb_assign<XT, 0>), dim3(m.off[s_n]), dim3(256), lds, (hipStream_t)stream, *c, *f, *bt, m,
+                               b, sweep, alpha, anneal_temp, new_tok, n_new);
+        } else {
+            if (lds > 48 * 1024)
+                SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_fbb_assign<XT, 1>,
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((k_fbb_assign<XT, 1>), dim3(m.off[s_n]), dim3(256), lds, (hipStream_t)stream, *c, *f, *bt, m,
+                               b, sweep, alpha, anneal_temp, new_tok, n_new);
+        }
+    });
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+int32_t segk_fbb_lm_apply(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *f, const segk_fbatch *bt, int32_t b,
+                          int32_t sign, void *stream)
+{
+    (void)ctx;
+    int rc = check_fbb(c, f, bt);
+    if (rc) return rc;
+    SEGK_REQUIRE(f->lm_unigram && bt->lm_tok && bt->u_max > 0, "no language model attached");
+    SEGK_REQUIRE(sign == 1 || sign == -1, "sign");
+    const int64_t rows = (int64_t)bt->n_slices * bt->u_max;
+    hipLaunchKernelGGL(k_fbb_lm_apply, dim3((unsigned)((rows + 127) / 128)), dim3(128), 0, (hipStream_t)stream, *f, *bt,
+                       c->N_max, b, sign);
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+int32_t segk_fbb_lm_fill(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *f, const segk_fbatch *bt, int32_t s_lo,
+                         int32_t s_n, int32_t b, const int32_t *n_utts, const int32_t *new_tok, const int32_t *n_new,
+                         void *stream)
+{
+    (void)ctx;
+    int rc = check_fbb(c, f, bt);
+    if (rc) return rc;
+    SEGK_REQUIRE(bt->lm_tok && bt->u_max > 0, "no transcript store");
+    FbbMap m;
+    rc = make_map(&m, s_lo, s_n, n_utts, 1);
+    if (rc) return rc;
+    if (m.off[s_n] == 0) return SEGK_OK;
+    hipLaunchKernelGGL(k_fbb_lm_fill, dim3((m.off[s_n] + 127) / 128), dim3(128), 0, (hipStream_t)stream, *c, *bt, m, b,
+                       new_tok, n_new);
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+int32_t segk_fbb_canonical(segk_ctx *ctx, const segk_corpus *c, segk_fbgmm *f, const segk_fbatch *bt, int32_t *remap,
+                           void *stream)
+{
+    (void)ctx;
+    int rc = check_fbb(c, f, bt);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_fbb_remap, dim3(1), dim3(64), 0, st, *f, *bt, remap);
+    hipLaunchKernelGGL(k_fbb_apply_remap, dim3((unsigned)((c->n_emb + 255) / 256)), dim3(256), 0, st, *f, *bt, c->n_emb,
+                       remap);
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+}  // extern "C"

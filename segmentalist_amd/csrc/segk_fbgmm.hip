@@ -14,42 +14,7 @@
 #include <stdlib.h>
 
 #include "segk_internal.h"
-
-#define NEG_INF_D (-__builtin_huge_val())
-#define LOG_2PI 1.8378770664093453
-#define LOG_PI 1.1447298858494002
-
-// ---------------------------------------------------------------------------------------
-// block-wide helpers (blockDim.x a multiple of 64, <= 1024; `red` has >= 16 doubles)
-// ---------------------------------------------------------------------------------------
-// Butterfly inside each wave, then the per-wave partials (<= 16) are added in wave order by every
-// thread: two barriers per reduction and a fixed, launch-independent order.
-__device__ double block_sum(double v, double *red)
-{
-    const int tid = threadIdx.x, nw = blockDim.x >> 6;
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    __syncthreads();                      // `red` may still be read from a previous reduction
-    if ((tid & 63) == 0) red[tid >> 6] = v;
-    __syncthreads();
-    double r = red[0];
-    for (int w = 1; w < nw; w++) r += red[w];
-    return r;
-}
-
-__device__ double block_max(double v, double *red)
-{
-    const int tid = threadIdx.x, nw = blockDim.x >> 6;
-    for (int o = 32; o > 0; o >>= 1) {
-        const double other = __shfl_xor(v, o);
-        v = other > v ? other : v;
-    }
-    __syncthreads();
-    if ((tid & 63) == 0) red[tid >> 6] = v;
-    __syncthreads();
-    double r = red[0];
-    for (int w = 1; w < nw; w++) r = red[w] > r ? red[w] : r;
-    return r;
-}
+#include "segk_fb_common.h"
 
 // ---------------------------------------------------------------------------------------
 // derived statistics of component k (all threads of the block cooperate over D)
@@ -445,53 +410,11 @@ __global__ void k_fbgmm_pred_vector(segk_corpus c, segk_fbgmm f, int64_t row, do
     else if (k == f.K_max) out[k] = fb_log_prior<XT>(f, c.D, x);
 }
 
-__device__ __forceinline__ double fb_readlane(double v, int l)       // l wave-uniform
-{
-    union { double d; int i[2]; } u;
-    u.d = v;
-    u.i[0] = __builtin_amdgcn_readlane(u.i[0], l);
-    u.i[1] = __builtin_amdgcn_readlane(u.i[1], l);
-    return u.d;
-}
-
-// _cython_utils.pyx:13-25 (max, then the sum of exp(a[j] - max) in index order, then log) by one
-// full wave: the exponentials are evaluated one per lane, the additions stay sequential.
-__device__ double fb_logsumexp_wave(const double *a, int n, int lane)
-{
-    double mx = NEG_INF_D;
-    for (int j = lane; j < n; j += 64) mx = a[j] > mx ? a[j] : mx;
-    for (int o = 32; o > 0; o >>= 1) {
-        double other = __shfl_xor(mx, o);
-        mx = other > mx ? other : mx;
-    }
-    double s = 0.0;
-    for (int j0 = 0; j0 < n; j0 += 64) {
-        const double ej = (j0 + lane < n) ? exp(a[j0 + lane] - mx) : 0.0;
-        const int cnt = n - j0 < 64 ? n - j0 : 64;
-        for (int q = 0; q < cnt; q++) s += fb_readlane(ej, q);
-    }
-    return log(s) + mx;
-}
-
 // ---------------------------------------------------------------------------------------
 // A5 + A6/A7 for one utterance: vec from the per-embedding scores, DP, new boundaries.
 // Single thread does the DP (N <= N_max landmarks, fp64, reference order); uniforms are taken
 // from ustream[*ucursor ...] and the cursor advanced (one per backward-sampling step).
 // ---------------------------------------------------------------------------------------
-// embedding ids of the segments the boundaries of one utterance select, -1 (no embedding) skipped
-// (unigram_acoustic_wordseg.py:340-342)
-__device__ int fb_collect_tokens(const int32_t *vid, const uint8_t *bnd, int N, int32_t *tok)
-{
-    int nn = 0, jp = 0;
-    for (int j = 0; j < N; j++)
-        if (bnd[j]) {
-            int id = vid[(j + 1) * j / 2 + jp];
-            if (id >= 0) tok[nn++] = id;
-            jp = j + 1;
-        }
-    return nn;
-}
-
 __global__ void k_unigram_segment(segk_corpus c, int utt, int viterbi, int n_min, int n_max, double wip,
                                   double time_power_term, double log_p_continue, double anneal_temp,
                                   const double *score, const double *ustream, int64_t *ucursor, int64_t ucap,
@@ -531,101 +454,9 @@ __global__ void k_unigram_segment(segk_corpus c, int utt, int viterbi, int n_min
         }
         return;
     }
-    for (int j = lane; j < N; j += 64) { a[j] = 1.0; bnd[j] = (j == N - 1) ? 1 : 0; }
-    __builtin_amdgcn_wave_barrier();
-    a[0] = 0.0;
-    __builtin_amdgcn_wave_barrier();
-    int64_t cur = *ucursor;
-    int i = 0;
-    for (int t = 1; t < N; t++) {
-        int lo = (n_max == 0 || t - n_max < 0) ? 0 : t - n_max;
-        int n = t - lo;
-        bool all_inf = true;
-        double best = NEG_INF_D;
-        for (int s = lo; s < t; s++) {
-            double v = vec[i + s] + a[s];
-            if (lane == 0) w[s - lo] = v;
-            if (v != NEG_INF_D) all_inf = false;
-            if (v > best) best = v;
-        }
-        __builtin_amdgcn_wave_barrier();
-        double at;
-        if (viterbi) at = best;
-        else at = all_inf ? NEG_INF_D : fb_logsumexp_wave(w, n, lane) + log_p_continue;
-        if (lane == 0) a[t] = at;
-        __builtin_amdgcn_wave_barrier();
-        i += t;
-    }
-    int t = N, lo = 0;
-    double total = 0.0;
-    for (;;) {
-        i = (t - 1) * t / 2;
-        lo = (n_max == 0 || t - n_max < 0) ? 0 : t - n_max;
-        bool all_inf = true;
-        for (int s = lo; s < t; s++)
-            if (vec[i + s] + a[s] != NEG_INF_D) { all_inf = false; break; }
-        if (all_inf) {
-            while (all_inf) {
-                t = t - 1;
-                if (t == 0) break;
-                i = (t - 1) * t / 2;
-                lo = (n_max == 0 || t - n_max < 0) ? 0 : t - n_max;
-                all_inf = true;
-                for (int s = lo; s < t; s++)
-                    if (vec[i + s] + a[s] != NEG_INF_D) { all_inf = false; break; }
-            }
-            if (lane == 0) bnd[(t - 1 + N) % N] = 1;
-        }
-        int k = 1, n = 1;
-        if (t > 0) {
-            n = t - lo;
-            for (int j = lane; j < n; j += 64) w[j] = vec[i + lo + j] + a[lo + j];
-        } else {
-            if (lane == 0) w[0] = NEG_INF_D;
-        }
-        __builtin_amdgcn_wave_barrier();
-        const double lse = fb_logsumexp_wave(w, n, lane);
-        if (viterbi) {
-            if (t > 0) {
-                for (int j = lane; j < n; j += 64) pr[j] = exp(w[j] - lse);
-                __builtin_amdgcn_wave_barrier();
-                double best = 0.0;
-                bool first = true;
-                for (int s = t - 1; s >= lo; s--) {
-                    double q = pr[s - lo];
-                    if (first || q > best) { best = q; k = t - s; first = false; }
-                }
-            }
-        } else {
-            if (anneal_temp != 1.0) {
-                const double inv = 1. / anneal_temp;
-                for (int j = lane; j < n; j += 64) pr[j] = w[n - 1 - j] - lse;
-                __builtin_amdgcn_wave_barrier();
-                for (int j = lane; j < n; j += 64) w[j] = inv * pr[j];
-                __builtin_amdgcn_wave_barrier();
-                const double lse2 = fb_logsumexp_wave(w, n, lane);
-                for (int j = lane; j < n; j += 64) pr[j] = exp(w[j] - lse2);
-            } else {
-                for (int j = lane; j < n; j += 64) pr[j] = exp(w[n - 1 - j] - lse);
-            }
-            __builtin_amdgcn_wave_barrier();
-            double uu = (cur < ucap) ? ustream[cur] : 0.5;
-            if (cur >= ucap && lane == 0) atomicOr(status, 8);
-            cur++;
-            int kk = n - 1;
-            for (int j = 0; j < n; j++) {
-                uu = uu - pr[j];
-                if (uu < 0) { kk = j; break; }
-            }
-            k = kk + 1;
-        }
-        int idx = i + t - k;
-        if (idx < 0) idx += tri;
-        total += vec[idx];
-        if (t - k - 1 < 0) break;
-        if (lane == 0) bnd[t - k - 1] = 1;
-        t = t - k;
-    }
+    StreamUniforms usrc = {ustream, *ucursor, ucap, status};
+    const double total = fb_dp_sample(vec, a, w, pr, N, tri, n_max, viterbi, log_p_continue, anneal_temp, bnd, lane, usrc);
+    const int64_t cur = usrc.cur;
     if (lane != 0) return;
     if (!viterbi && total == NEG_INF_D) atomicOr(status, 16);      // unigram_acoustic_wordseg.py:753
     *ucursor = cur;

@@ -537,3 +537,184 @@ class DeviceFbgmm(object):
             raise SegkError("uniform stream exhausted")
         if st & 16:
             raise AssertionError("forward_backward: log_prob == -inf (unigram_acoustic_wordseg.py:753)")
+
+
+class FbgmmBatchSweeper(object):
+    """Batch-synchronous ("blocked parallel Gibbs") sweeps of the FBGMM / bigram samplers --
+    specification oracle/np_fbgmm_batch.py, C ABI `segk_fbb_*` (include/segk.h).
+
+    The utterances are cut into `n_stat_blocks` slices (rank r owns a contiguous run of them) x
+    `n_gibbs_blocks` blocks.  Per Gibbs step b every rank resamples block b of its slices against
+    the statistics of all other blocks, recomputes the block's partial sums and all-gathers them
+    (one RCCL all-gather of S/P * K_max*(2D+1) doubles per rank and step; with a language model a
+    second one of the block's transcripts).  All partial sums are replicated, so every rank derives
+    the same statistics in the same fixed order: results do not depend on the number of ranks."""
+
+    def __init__(self, df, row_start, n_gibbs_blocks=8, n_stat_blocks=8, seed=0, group=None):
+        torch = _torch()
+        dev = _dev()
+        self.df, self.group = df, group
+        c = df.corpus
+        self.S, self.B = int(n_stat_blocks), int(n_gibbs_blocks)
+        rank, world = 0, 1
+        try:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                rank, world = dist.get_rank(group), dist.get_world_size(group)
+        except ImportError:
+            pass
+        if self.S % world != 0:
+            raise SegkError("the number of statistics slices (%d) must be a multiple of the number of ranks (%d)"
+                            % (self.S, world))
+        self.rank, self.world = rank, world
+        self.s_n = self.S // world
+        self.s_lo = rank * self.s_n
+        n_utt = c.n_utt
+        sb = [(s * n_utt) // self.S for s in range(self.S + 1)]
+        ur = np.zeros((self.S, self.B, 2), np.int32)
+        rr = np.zeros((self.S, self.B, 2), np.int32)
+        row_start = np.asarray(row_start, dtype=np.int64)
+        for s in range(self.S):
+            n_s = sb[s + 1] - sb[s]
+            for b in range(self.B):
+                lo, hi = sb[s] + (b * n_s) // self.B, sb[s] + ((b + 1) * n_s) // self.B
+                ur[s, b] = (lo, hi)
+                rr[s, b] = (row_start[lo], row_start[hi])
+        self.utt_range_np, self.row_range_np = ur, rr
+        self.utt_range, self.row_range = to_dev(ur), to_dev(rr)
+        K, D = df.K_max, c.D
+        self.rec = K * (2 * D + 1)
+        f64 = torch.float64
+        self.partials = torch.zeros((self.B, self.S, self.rec), dtype=f64, device=dev)
+        self.cnt = torch.zeros(K, dtype=f64, device=dev)
+        self.mean_t = torch.zeros((D, K), dtype=f64, device=dev)
+        self.q_t = torch.zeros((D, K), dtype=f64, device=dev)
+        self.lconst = torch.zeros(K, dtype=f64, device=dev)
+        self.zconst = torch.zeros(K, dtype=f64, device=dev)
+        self.half = torch.zeros(K, dtype=f64, device=dev)
+        self.scal = torch.zeros(2, dtype=f64, device=dev)
+        self.slot = torch.zeros(c.n_emb, dtype=torch.int32, device=dev)
+        self.remap = torch.zeros(K, dtype=torch.int32, device=dev)
+        self.u_max = int((ur[:, :, 1] - ur[:, :, 0]).max())
+        self.lm_tok = None
+        # the batch state keeps its own bigram table (indexed by slots); the sequential-mode tables of
+        # the LM object are only written by materialise()
+        self.f = _abi.FbgmmDev.from_buffer_copy(df.f)
+        if df.lm is not None:
+            self.lm_tok = torch.full((self.B, self.S, self.u_max, c.N_max), -1, dtype=torch.int32, device=dev)
+            self.lm_big = torch.zeros((K, K), dtype=torch.int64, device=dev)
+            self.f.lm_bigram = self.lm_big.data_ptr()
+        self.bt = _abi.FbatchDev(
+            n_slices=self.S, n_blocks=self.B, u_max=self.u_max if df.lm is not None else 0, pad_=0,
+            utt_range=self.utt_range.data_ptr(), row_range=self.row_range.data_ptr(),
+            partials=self.partials.data_ptr(), cnt=self.cnt.data_ptr(), mean_t=self.mean_t.data_ptr(),
+            q_t=self.q_t.data_ptr(), lconst=self.lconst.data_ptr(), zconst=self.zconst.data_ptr(),
+            half=self.half.data_ptr(), scal=self.scal.data_ptr(), slot=self.slot.data_ptr(),
+            lm_tok=self.lm_tok.data_ptr() if self.lm_tok is not None else None, seed=int(seed) & (2 ** 64 - 1))
+        # host-side per-step launch tables
+        I32 = C.c_int32 * self.s_n
+        self._n_rows = [I32(*[int(rr[self.s_lo + i, b, 1] - rr[self.s_lo + i, b, 0]) for i in range(self.s_n)])
+                        for b in range(self.B)]
+        self._n_utts = [I32(*[int(ur[self.s_lo + i, b, 1] - ur[self.s_lo + i, b, 0]) for i in range(self.s_n)])
+                        for b in range(self.B)]
+        self.in_batch_state = False
+        self.sweep_index = 0
+
+    # ------------------------------------------------------------------ plumbing
+    def _args(self):
+        df = self.df
+        self.f.alpha, self.f.lms = df.f.alpha, df.f.lms
+        return df._L, df._ctx, df._cp(), C.byref(self.f), C.byref(self.bt), _abi.stream()
+
+    def _gather(self, full, b):
+        """in-place all-gather of full[b] ([S, ...]): every rank contributes its slices."""
+        if self.world == 1:
+            return
+        out = full[b].view(self.world, -1)
+        all_gather_rows(out, out[self.rank], self.group)
+
+    def enter(self, boundaries):
+        """Build the batch state (slots, token lists, all partial sums, transcripts) from the
+        sequential-mode state of the components."""
+        df = self.df
+        L, ctx, cp, fp, bp, st = self._args()
+        self.slot.copy_(df.assignments)
+        if df.lm is not None:
+            self.lm_big.copy_(df.lm._bigram)
+        check(L.segk_fbb_collect(ctx, cp, ptr(boundaries), ptr(df.new_tok), ptr(df.n_new), st))
+        for b in range(self.B):
+            check(L.segk_fbb_partials(ctx, cp, fp, bp, self.s_lo, self.s_n, b, ptr(df.new_tok), ptr(df.n_new), st))
+            self._gather(self.partials, b)
+            if self.lm_tok is not None:
+                check(L.segk_fbb_lm_fill(ctx, cp, fp, bp, self.s_lo, self.s_n, b, self._n_utts[b], ptr(df.new_tok),
+                                         ptr(df.n_new), st))
+                self._gather(self.lm_tok, b)
+        self.in_batch_state = True
+
+    def sweep(self, boundaries, n_slices_min, n_slices_max, wip, time_power_term, anneal_temp_fb=1.0,
+              anneal_temp_am=1.0):
+        """One sweep = n_gibbs_blocks steps, all enqueued on the current stream."""
+        df = self.df
+        if not self.in_batch_state:
+            self.enter(boundaries)
+        L, ctx, cp, fp, bp, st = self._args()
+        sw = self.sweep_index
+        for b in range(self.B):
+            if self.lm_tok is not None:
+                check(L.segk_fbb_lm_apply(ctx, cp, fp, bp, b, -1, st))
+            check(L.segk_fbb_prepare(ctx, cp, fp, bp, b, st))
+            check(L.segk_fbb_score(ctx, cp, fp, bp, self.s_lo, self.s_n, b, self._n_rows[b], ptr(df.score), st))
+            check(L.segk_fbb_segment(ctx, cp, fp, bp, self.s_lo, self.s_n, b, self._n_utts[b], sw, int(n_slices_min),
+                                     int(n_slices_max), float(wip), float(time_power_term), float(anneal_temp_fb),
+                                     ptr(df.score), ptr(boundaries), ptr(df.new_tok), ptr(df.n_new),
+                                     ptr(df.out_logprob), ptr(df.status), st))
+            check(L.segk_fbb_assign(ctx, cp, fp, bp, self.s_lo, self.s_n, b, self._n_utts[b], sw, float(anneal_temp_am),
+                                    ptr(df.new_tok), ptr(df.n_new), st))
+            if self.lm_tok is not None:
+                check(L.segk_fbb_lm_fill(ctx, cp, fp, bp, self.s_lo, self.s_n, b, self._n_utts[b], ptr(df.new_tok),
+                                         ptr(df.n_new), st))
+                self._gather(self.lm_tok, b)
+                check(L.segk_fbb_lm_apply(ctx, cp, fp, bp, b, 1, st))
+            check(L.segk_fbb_partials(ctx, cp, fp, bp, self.s_lo, self.s_n, b, ptr(df.new_tok), ptr(df.n_new), st))
+            self._gather(self.partials, b)
+        self.sweep_index += 1
+
+    def totals(self):
+        """(counts per slot as float64 numpy, total, occupied) of the current state."""
+        L, ctx, cp, fp, bp, st = self._args()
+        check(L.segk_fbb_prepare(ctx, cp, fp, bp, -1, st))
+        sc = self.scal.cpu().numpy()
+        return self.cnt.cpu().numpy(), float(sc[0]), int(sc[1])
+
+    def invalidate(self):
+        """The sequential-mode state was mutated: rebuild the batch state before the next sweep."""
+        self.in_batch_state = False
+
+    def materialise(self):
+        """The reference's view of the current batch state, without touching it: contiguous
+        component labels in `assignments` / K, the LM tables of the LM object, and the
+        sequential-mode statistics rebuilt from the assignments (Components.__init__ order)."""
+        if not self.in_batch_state:
+            return
+        torch = _torch()
+        df = self.df
+        L, ctx, cp, fp, bp, st = self._args()
+        check(L.segk_fbb_prepare(ctx, cp, fp, bp, -1, st))
+        check(L.segk_fbb_canonical(ctx, cp, C.byref(df.f), bp, ptr(self.remap), st))
+        if self.world > 1:
+            # every rank holds the slots of its own rows only
+            lo, hi = int(self.row_range_np[self.s_lo, 0, 0]), int(self.row_range_np[self.s_lo + self.s_n - 1, -1, 1])
+            import torch.distributed as dist
+            parts = [None] * self.world
+            dist.all_gather_object(parts, (lo, hi, df.assignments[lo:hi].cpu()), group=self.group)
+            for plo, phi, t in parts:
+                df.assignments[plo:phi] = t.to(df.assignments.device)
+        if df.lm is not None:
+            occ = torch.nonzero(self.remap >= 0).flatten()
+            K = occ.numel()
+            big = df.lm._bigram
+            big.zero_()
+            big[:K, :K] = self.lm_big[occ][:, occ]
+            df.lm._unigram.zero_()
+            df.lm._unigram[:K] = self.cnt[occ].round().long()
+        check(L.segk_fbgmm_init_stats(ctx, cp, C.byref(df.f), st))

@@ -31,8 +31,18 @@ class UnigramAcousticWordseg(object):
     def __init__(self, am_class, am_alpha, am_K, am_param_prior, embedding_mats, vec_ids_dict, durations_dict,
                  landmarks_dict, seed_boundaries_dict=None, seed_assignments_dict=None, covariance_type="fixed",
                  n_slices_min=0, n_slices_max=20, min_duration=0, p_boundary_init=0.5, beta_sent_boundary=2.0,
-                 lms=1., wip=0., fb_type="standard", init_am_assignments="rand", time_power_term=1.):
+                 lms=1., wip=0., fb_type="standard", init_am_assignments="rand", time_power_term=1.,
+                 sync="sequential", n_gibbs_blocks=8, n_stat_blocks=8, batch_seed=0, process_group=None):
+        """Same arguments as the reference (unigram_acoustic_wordseg.py:107-123), plus the execution
+        mode: sync="sequential" is the reference's serial chain (draw for draw); sync="batch" the
+        batch-synchronous blocked Gibbs sampler specified in oracle/np_fbgmm_batch.py
+        (`n_gibbs_blocks` steps per sweep, statistics summed over `n_stat_blocks` slices, sharded
+        over the ranks of `process_group` when torch.distributed is initialised)."""
         logger.info("Initializing")
+        assert sync in ("sequential", "batch")
+        self.sync = sync
+        self._batch_args = (n_gibbs_blocks, n_stat_blocks, batch_seed, process_group)
+        self._sweeper = None
         assert seed_assignments_dict is None or seed_boundaries_dict is not None
         self.n_slices_min = n_slices_min
         self.n_slices_max = n_slices_max
@@ -43,6 +53,7 @@ class UnigramAcousticWordseg(object):
 
         embeddings, vec_ids, ids_to_utterance_labels = process_embeddings(embedding_mats, vec_ids_dict)
         self.ids_to_utterance_labels = ids_to_utterance_labels
+        self._row_start = vec_ids.row_start
         N = embeddings.shape[0]
 
         seed_boundaries = None
@@ -124,6 +135,31 @@ class UnigramAcousticWordseg(object):
             random.random()
         return used
 
+    # ------------------------------------------------------------------ batch mode
+    def _get_sweeper(self):
+        if self._sweeper is None:
+            from .device import FbgmmBatchSweeper
+            B, S, seed, group = self._batch_args
+            self._sweeper = FbgmmBatchSweeper(self._df, self._row_start, B, S, seed, group)
+        return self._sweeper
+
+    def batch_sweep_async(self, anneal_temp=1, anneal_gibbs_am=False):
+        """Enqueue one batch-synchronous sweep (fb_type "standard" sampling); results stay on the device."""
+        self._get_sweeper().sweep(self._dev_bounds, self.n_slices_min, self.n_slices_max, self.wip,
+                                  self.time_power_term, anneal_temp, anneal_temp if anneal_gibbs_am else 1.0)
+        self.utterances.mark_device_dirty()
+
+    def materialise(self):
+        """Bring the reference's view (components.K / assignments / statistics) up to date with the
+        batch state."""
+        if self._sweeper is not None:
+            self._sweeper.materialise()
+
+    def _leave_batch(self):
+        if self._sweeper is not None and self._sweeper.in_batch_state:
+            self._sweeper.materialise()
+            self._sweeper.invalidate()
+
     # ------------------------------------------------------------------ one utterance
     def _gibbs_i_async(self, i, anneal_temp, anneal_gibbs_am):
         viterbi = self.fb_type == "viterbi"
@@ -135,6 +171,7 @@ class UnigramAcousticWordseg(object):
 
     def gibbs_sample_i(self, i, anneal_temp=1, anneal_gibbs_am=False):
         """unigram_acoustic_wordseg.py:252-360."""
+        self._leave_batch()
         self._open_stream([i])
         self._gibbs_i_async(i, anneal_temp, anneal_gibbs_am)
         self._close_stream()
@@ -166,22 +203,32 @@ class UnigramAcousticWordseg(object):
         for i_iter in range(n_iter):
             start_time = time.time()
             if am_n_iter > 0:                                     # unigram_acoustic_wordseg.py:440-443
+                self._leave_batch()
                 self.acoustic_model.gibbs_sample(am_n_iter, consider_unassigned=False)
             anneal_temp = next(get_anneal_temp, anneal_end_temp_inv)
-            utt_order = list(range(self.utterances.D))
-            rng.shuffle(utt_order)
-            if debug_gibbs_only:
-                utt_order = [i_debug_monitor]
-            self._open_stream(utt_order)
-            for i_utt in utt_order:
-                self._gibbs_i_async(i_utt, anneal_temp, anneal_gibbs_am)
-            torch.cuda.synchronize()
-            self._close_stream()
-            self._df.check_status()
-            lps = self._df.out_logprob.cpu().numpy()
-            log_prob = 0
-            for i_utt in utt_order:
-                log_prob += lps[i_utt]
+            if self.sync == "batch":
+                assert self.fb_type == "standard", "batch mode samples boundaries (fb_type=\"standard\")"
+                self.batch_sweep_async(anneal_temp, anneal_gibbs_am)
+                torch.cuda.synchronize()
+                self._df.check_status()
+                log_prob = float(self._df.out_logprob.sum().item())
+                self.materialise()                                # the record metrics read the reference's view
+            else:
+                self._leave_batch()
+                utt_order = list(range(self.utterances.D))
+                rng.shuffle(utt_order)
+                if debug_gibbs_only:
+                    utt_order = [i_debug_monitor]
+                self._open_stream(utt_order)
+                for i_utt in utt_order:
+                    self._gibbs_i_async(i_utt, anneal_temp, anneal_gibbs_am)
+                torch.cuda.synchronize()
+                self._close_stream()
+                self._df.check_status()
+                lps = self._df.out_logprob.cpu().numpy()
+                log_prob = 0
+                for i_utt in utt_order:
+                    log_prob += lps[i_utt]
 
             record_dict["sample_time"].append(time.time() - start_time)
             record_dict["log_marg"].append(am.log_marg())

@@ -1,0 +1,164 @@
+"""GPU parity of the batch-synchronous (blocked parallel Gibbs) FBGMM / bigram sampler against its
+executable specification oracle/np_fbgmm_batch.py (the reference has no parallel mode).  Sampled
+boundaries and slots must coincide with the specification's (same counter-based uniforms);
+log-probabilities to 1e-9 relative (contract 1e-4)."""
+import random
+
+import numpy as np
+import numpy.testing as npt
+import pytest
+
+from oracle import np_fbgmm_batch as nb
+from oracle import np_oracle as no
+from tests.golden import cases
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    assert torch.cuda.is_available(), "these tests need an MI355X"
+    torch.cuda.set_device(0)
+    from segmentalist_amd import _abi
+    _abi.ctx()
+    return torch
+
+
+def _pair(kind, n_utt, D, K, cseed, nmax, B, S, seed=5, dtype="float32", **kw):
+    """(oracle segmenter + batch state, product segmenter) from identical initial states."""
+    from segmentalist_amd import bigram_acoustic_wordseg as baw, fbgmm, unigram_acoustic_wordseg as uaw
+    from segmentalist_amd.gaussian_components_fixedvar import FixedVarPrior
+    from segmentalist_amd.niw import NIW
+    corpus = cases.chain_corpus(n_utt, D, K, cseed, True, 0, nmax, dtype)
+    args = dict(n_slices_min=0, n_slices_max=nmax, p_boundary_init=0.5, beta_sent_boundary=-1, lms=1.0, wip=0.0,
+                init_am_assignments="rand", time_power_term=1.0)
+    args.update(kw)
+    bargs = dict(sync="batch", n_gibbs_blocks=B, n_stat_blocks=S, batch_seed=11)
+    out = []
+    for side in ("oracle", "product"):
+        random.seed(seed)
+        np.random.seed(seed)
+        if kind == "bigram":
+            if side == "oracle":
+                seg = no.BigramAcousticWordseg(K, no.FixedVarPrior(*cases.fixed_prior_params(D)), dict(cases.BIGRAM_LM),
+                                               *corpus, covariance_type="fixed", fb_type="unigram", **args)
+            else:
+                seg = baw.BigramAcousticWordseg(K, FixedVarPrior(*cases.fixed_prior_params(D)), dict(cases.BIGRAM_LM),
+                                                *corpus, covariance_type="fixed", fb_type="unigram", **args, **bargs)
+        else:
+            if side == "oracle":
+                prior = (no.FixedVarPrior(*cases.fixed_prior_params(D)) if kind == "fixed"
+                         else no.NIW(*cases.diag_prior_params(D)))
+                seg = no.UnigramAcousticWordseg(no.FBGMM, 1.0, K, prior, *corpus, covariance_type=kind,
+                                                fb_type="standard", **args)
+            else:
+                prior = FixedVarPrior(*cases.fixed_prior_params(D)) if kind == "fixed" else NIW(*cases.diag_prior_params(D))
+                seg = uaw.UnigramAcousticWordseg(fbgmm.FBGMM, 1.0, K, prior, *corpus, covariance_type=kind,
+                                                 fb_type="standard", **args, **bargs)
+        out.append(seg)
+    ref, seg = out
+    return ref, nb.FbgmmBatch(ref, n_gibbs_blocks=B, n_stat_blocks=S, seed=11), seg
+
+
+CASES = [
+    ("fixed", 24, 8, 10, 77, 5, 3, 4, {}),
+    ("diag", 24, 8, 10, 78, 5, 3, 4, {}),
+    ("fixed", 40, 12, 30, 79, 6, 4, 8, dict(lms=0.7, wip=-0.2, time_power_term=1.2)),
+    ("diag", 33, 70, 12, 80, 4, 2, 2, {}),          # D > 64: two dimension chunks
+    ("fixed", 19, 6, 300, 81, 5, 5, 1, {}),         # K_max > workgroup width
+]
+
+
+@pytest.mark.parametrize("kind,n_utt,D,K,cseed,nmax,B,S,kw", CASES,
+                         ids=["%s_u%d_D%d_K%d_B%d_S%d" % (c[0], c[1], c[2], c[3], c[6], c[7]) for c in CASES])
+def test_batch_sweeps_match_specification(gpu, kind, n_utt, D, K, cseed, nmax, B, S, kw):
+    ref, spec, seg = _pair(kind, n_utt, D, K, cseed, nmax, B, S, **kw)
+    for sw in range(3):
+        lp = spec.sweep(sw)
+        seg.batch_sweep_async()
+        gpu.cuda.synchronize()
+        seg._df.check_status()
+        assert np.array_equal(seg.utterances.boundaries, ref.utterances.boundaries), sw
+        slots = seg._get_sweeper().slot.cpu().numpy()
+        assert np.array_equal(slots, spec.slot), sw
+        npt.assert_allclose(seg._df.out_logprob.cpu().numpy(), lp, rtol=1e-9)
+        # the reference's view
+        seg.materialise()
+        a, Kc = spec.canonical()
+        c = seg.acoustic_model.components
+        assert c.K == Kc
+        assert np.array_equal(c.assignments, a)
+        cnt = spec.stats_excluding(-1)[0]
+        assert np.array_equal(c.counts[:Kc], cnt[cnt > 0])
+
+
+def test_batch_statistics_and_scores_match_specification(gpu):
+    """The prepared statistics and the span scores of one step, value by value."""
+    ref, spec, seg = _pair("diag", 24, 8, 10, 78, 5, 3, 4)
+    sw = seg._get_sweeper()
+    sw.enter(seg._dev_bounds)
+    from segmentalist_amd import _abi
+    from segmentalist_amd._abi import check, ptr
+    L, ctx, cp, fp, bp, st = sw._args()
+    for b in (0, 2, -1):
+        check(L.segk_fbb_prepare(ctx, cp, fp, bp, b, st))
+        cnt, sx, sxx = spec.stats_excluding(b)
+        d = spec.derive(cnt, sx, sxx)
+        assert np.array_equal(sw.cnt.cpu().numpy(), cnt.astype(np.float64))
+        occ = cnt > 0
+        npt.assert_allclose(sw.mean_t.cpu().numpy().T[occ], d["mean"][occ], rtol=1e-13)
+        npt.assert_allclose(sw.q_t.cpu().numpy().T[occ], d["q"][occ], rtol=1e-12)
+        npt.assert_allclose(sw.lconst.cpu().numpy()[occ], d["const"][occ], rtol=1e-12)
+    b = 1
+    check(L.segk_fbb_prepare(ctx, cp, fp, bp, b, st))
+    check(L.segk_fbb_score(ctx, cp, fp, bp, sw.s_lo, sw.s_n, b, sw._n_rows[b], ptr(seg._df.score), st))
+    d = spec.derive(*spec.stats_excluding(b))
+    score = seg._df.score.cpu().numpy()
+    for s in range(sw.S):
+        lo, hi = sw.row_range_np[s, b]
+        for row in range(lo, hi):
+            npt.assert_allclose(score[row], spec.log_marg(d, spec.X[row]), rtol=1e-11)
+
+
+def test_bigram_batch_sweeps_match_specification(gpu):
+    ref, spec, seg = _pair("bigram", 30, 8, 12, 91, 5, 3, 4)
+    for sw in range(3):
+        lp = spec.sweep(sw)
+        seg.batch_sweep_async()
+        gpu.cuda.synchronize()
+        seg._df.check_status()
+        assert np.array_equal(seg.utterances.boundaries, ref.utterances.boundaries), sw
+        assert np.array_equal(seg._get_sweeper().slot.cpu().numpy(), spec.slot), sw
+        assert np.array_equal(seg._get_sweeper().lm_big.cpu().numpy(), spec.big), sw
+        npt.assert_allclose(seg._df.out_logprob.cpu().numpy(), lp, rtol=1e-9)
+    seg.materialise()
+    a, Kc = spec.canonical()
+    assert np.array_equal(seg.acoustic_model.components.assignments, a)
+    # LM tables of the LM object in the reference's labelling
+    cnt = spec.stats_excluding(-1)[0]
+    occ = np.where(cnt > 0)[0]
+    assert np.array_equal(seg.lm.unigram_counts[:Kc], cnt[occ])
+    assert np.array_equal(seg.lm.bigram_counts[:Kc, :Kc], spec.big[np.ix_(occ, occ)])
+
+
+def test_sequential_after_batch_continues_from_the_materialised_state(gpu):
+    """Mode switch: batch sweeps, then the reference's serial chain on the same object, compared
+    with the oracle continuing from the specification's canonical state."""
+    ref, spec, seg = _pair("fixed", 16, 6, 8, 93, 4, 2, 2)
+    spec.sweep(0)
+    seg.batch_sweep_async()
+    seg.materialise()
+    a, Kc = spec.canonical()
+    # oracle: rebuild its components from the canonical assignment
+    prior = no.FixedVarPrior(*cases.fixed_prior_params(6))
+    ref.acoustic_model.components = no.GaussianComponentsFixedVar(ref.acoustic_model.components.X, prior, a.copy(), K_max=8)
+    random.seed(3)
+    st = random.getstate()
+    ref.gibbs_sample(1)
+    random.setstate(st)
+    seg.sync = "sequential"
+    rec = seg.gibbs_sample(1)
+    assert np.array_equal(seg.utterances.boundaries, ref.utterances.boundaries)
+    assert np.array_equal(seg.acoustic_model.components.assignments, ref.acoustic_model.components.assignments)
+    assert rec["components"][0] == ref.acoustic_model.components.K
