@@ -69,8 +69,14 @@ def u01(seed, sweep, utt, j):
 class FbgmmBatch(object):
     """Batch sampler state built from an oracle UnigramAcousticWordseg / BigramAcousticWordseg."""
 
-    def __init__(self, seg, n_gibbs_blocks=8, n_stat_blocks=8, seed=0):
+    def __init__(self, seg, n_gibbs_blocks=8, n_stat_blocks=8, seed=0, rank=0, world=1, all_gather_object=None):
+        """rank / world / all_gather_object: the rank-split protocol of the multi-GPU path (rank r
+        resamples only its slices and exchanges the block's partial sums -- and transcripts, with a
+        language model -- after every step); world = 1 is the plain specification."""
         self.seg = seg
+        assert n_stat_blocks % world == 0
+        self.rank, self.world, self.ago = rank, world, all_gather_object
+        self.s_lo, self.s_hi = rank * (n_stat_blocks // world), (rank + 1) * (n_stat_blocks // world)
         am = seg.acoustic_model
         c = am.components
         self.X = c.X
@@ -106,6 +112,8 @@ class FbgmmBatch(object):
         if self.lm is not None:
             self.uni = self.lm.unigram_counts.copy()
             self.big = self.lm.bigram_counts.copy()
+            # replicated transcripts (slots of every utterance's segments)
+            self.tr = [[self.slot[e] for e in self._tokens(i)] for i in range(u.D)]
 
     # ------------------------------------------------------------------ statistics
     def _tokens(self, i):
@@ -220,9 +228,9 @@ class FbgmmBatch(object):
                 uni, big = self.uni.copy(), self.big.copy()
                 for s in range(self.S):
                     for i in range(*self.ranges[s][b]):
-                        self._lm_count(uni, big, [self.slot[e] for e in self._tokens(i)], -1)
+                        self._lm_count(uni, big, self.tr[i], -1)
             new_state = {}
-            for s in range(self.S):
+            for s in range(self.s_lo, self.s_hi):
                 for i in range(*self.ranges[s][b]):
                     N = u.lengths[i]
                     tri = (N * N + N) // 2
@@ -260,12 +268,18 @@ class FbgmmBatch(object):
                     k = no.draw(p, u01(self.seed, sweep_index, i, u.N_max + t))
                     self.slot[e] = k
                     j_prev = k if self.lm is not None else None
-            for s in range(self.S):
-                self.P[s][b] = self._partial(s, b)
+            mine = {s: self._partial(s, b) for s in range(self.s_lo, self.s_hi)}
+            for part in ([mine] if self.world == 1 else self.ago(mine)):
+                for s, p in part.items():
+                    self.P[s][b] = p
             if self.lm is not None:
+                mine = {i: [self.slot[e] for e in self._tokens(i)] for i in new_state}
+                for part in ([mine] if self.world == 1 else self.ago(mine)):
+                    for i, t in part.items():
+                        self.tr[i] = t
                 for s in range(self.S):
                     for i in range(*self.ranges[s][b]):
-                        self._lm_count(uni, big, [self.slot[e] for e in self._tokens(i)], +1)
+                        self._lm_count(uni, big, self.tr[i], +1)
                 self.uni, self.big = uni, big
         return log_probs
 

@@ -227,7 +227,7 @@ class BigramAcousticWordseg(object):
                 self.batch_sweep_async(anneal_temp, anneal_gibbs_am)
                 torch.cuda.synchronize()
                 self._df.check_status()
-                log_prob = float(self._df.out_logprob.sum().item())
+                log_prob = float(np.sum(self._get_sweeper().utt_values(self._df.out_logprob)))
                 self.materialise()
             else:
                 self._leave_batch()

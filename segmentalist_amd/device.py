@@ -679,6 +679,19 @@ class FbgmmBatchSweeper(object):
             self._gather(self.partials, b)
         self.sweep_index += 1
 
+    def utt_values(self, t):
+        """numpy copy of a per-utterance device vector with every rank's own utterances filled in."""
+        v = t.cpu().numpy().copy()
+        if self.world > 1:
+            import torch.distributed as dist
+            lo = int(self.utt_range_np[self.s_lo, 0, 0])
+            hi = int(self.utt_range_np[self.s_lo + self.s_n - 1, -1, 1])
+            parts = [None] * self.world
+            dist.all_gather_object(parts, (lo, hi, v[lo:hi]), group=self.group)
+            for plo, phi, x in parts:
+                v[plo:phi] = x
+        return v
+
     def totals(self):
         """(counts per slot as float64 numpy, total, occupied) of the current state."""
         L, ctx, cp, fp, bp, st = self._args()
@@ -690,7 +703,7 @@ class FbgmmBatchSweeper(object):
         """The sequential-mode state was mutated: rebuild the batch state before the next sweep."""
         self.in_batch_state = False
 
-    def materialise(self):
+    def materialise(self, boundaries=None):
         """The reference's view of the current batch state, without touching it: contiguous
         component labels in `assignments` / K, the LM tables of the LM object, and the
         sequential-mode statistics rebuilt from the assignments (Components.__init__ order)."""
@@ -709,6 +722,12 @@ class FbgmmBatchSweeper(object):
             dist.all_gather_object(parts, (lo, hi, df.assignments[lo:hi].cpu()), group=self.group)
             for plo, phi, t in parts:
                 df.assignments[plo:phi] = t.to(df.assignments.device)
+            if boundaries is not None:          # the boundaries of the other ranks' utterances
+                ulo = int(self.utt_range_np[self.s_lo, 0, 0])
+                uhi = int(self.utt_range_np[self.s_lo + self.s_n - 1, -1, 1])
+                dist.all_gather_object(parts, (ulo, uhi, boundaries[ulo:uhi].cpu()), group=self.group)
+                for plo, phi, t in parts:
+                    boundaries[plo:phi] = t.to(boundaries.device)
         if df.lm is not None:
             occ = torch.nonzero(self.remap >= 0).flatten()
             K = occ.numel()

@@ -153,11 +153,12 @@ class UnigramAcousticWordseg(object):
         """Bring the reference's view (components.K / assignments / statistics) up to date with the
         batch state."""
         if self._sweeper is not None:
-            self._sweeper.materialise()
+            self._sweeper.materialise(self._dev_bounds)
+            self.utterances.mark_device_dirty()
 
     def _leave_batch(self):
         if self._sweeper is not None and self._sweeper.in_batch_state:
-            self._sweeper.materialise()
+            self.materialise()
             self._sweeper.invalidate()
 
     # ------------------------------------------------------------------ one utterance
@@ -211,7 +212,7 @@ class UnigramAcousticWordseg(object):
                 self.batch_sweep_async(anneal_temp, anneal_gibbs_am)
                 torch.cuda.synchronize()
                 self._df.check_status()
-                log_prob = float(self._df.out_logprob.sum().item())
+                log_prob = float(np.sum(self._get_sweeper().utt_values(self._df.out_logprob)))
                 self.materialise()                                # the record metrics read the reference's view
             else:
                 self._leave_batch()

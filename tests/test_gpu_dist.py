@@ -12,15 +12,15 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run(world, out, n_sweeps=3):
-    worker = os.path.join(ROOT, "tests", "dist_worker.py")
+def run(world, out, n_sweeps=3, worker="dist_worker.py", extra=()):
+    worker = os.path.join(ROOT, "tests", worker)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     if world == 1:
-        cmd = [sys.executable, worker, out, "gloo", str(n_sweeps)]
+        cmd = [sys.executable, worker, out, "gloo", str(n_sweeps)] + list(extra)
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
                "--master-addr", "127.0.0.1", "--master-port", str(29500 + world), worker, out, "gloo",
-               str(n_sweeps)]
+               str(n_sweeps)] + list(extra)
     subprocess.run(cmd, check=True, env=env, timeout=600, cwd=ROOT)
     return np.load(out)
 
@@ -29,5 +29,16 @@ def test_batch_mode_is_independent_of_the_number_of_ranks(tmp_path):
     ref = run(1, str(tmp_path / "w1.npz"))
     for world in (2, 4):
         got = run(world, str(tmp_path / ("w%d.npz" % world)))
+        for k in ref.files:
+            assert np.array_equal(ref[k], got[k]), (world, k)
+
+
+@pytest.mark.parametrize("kind", ["diag", "bigram"])
+def test_fbgmm_batch_mode_is_independent_of_the_number_of_ranks(tmp_path, kind):
+    """The blocked-Gibbs sampler of the FBGMM / bigram drivers on 1, 2 and 4 ranks: boundaries,
+    assignments, statistics, LM tables and record values bit-identical."""
+    ref = run(1, str(tmp_path / "f1.npz"), 2, "dist_worker_fbgmm.py", [kind])
+    for world in (2, 4):
+        got = run(world, str(tmp_path / ("f%d.npz" % world)), 2, "dist_worker_fbgmm.py", [kind])
         for k in ref.files:
             assert np.array_equal(ref[k], got[k]), (world, k)
