@@ -26,7 +26,8 @@ by all OTHER blocks:
      those statistics; a slot with count 0 is an empty component (prior predictive);
   3. boundaries: forward filtering / backward sampling (unigram...:653-756) with the uniforms
      u01(seed, sweep, utterance, step);
-  4. every new segment draws its slot from softmax(logits) (fbgmm.py:436-457) with
+  4. every new segment draws its slot from softmax(logits) (fbgmm.py:436-457) by inverse CDF
+     (`draw_chunked`, a two-level walk of utils.draw's cumulative sum) with
      u01(seed, sweep, utterance, N_max + position) -- all segments of the block against the same
      statistics of step 1 (the serial chain would see the utterance's earlier segments);
      with a language model the prior of segment t is lm.prob_vec_given_j(slot of segment t-1),
@@ -64,6 +65,29 @@ def u01(seed, sweep, utt, j):
         z = (z * 0x94D049BB133111EB) & _M
         z ^= z >> 31
     return (z >> 11) * (1.0 / 9007199254740992.0)
+
+
+def draw_chunked(p, u):
+    """Inverse-CDF draw of the batch sampler: same distribution as utils.draw (utils.py:10-21) with
+    a two-level walk -- the n probabilities are cut into 64 runs of ceil(n/64) consecutive entries,
+    run sums are accumulated left to right, the runs are walked in order subtracting whole run sums
+    from u, and the run in which the remainder would turn negative is walked entry by entry."""
+    n = len(p)
+    per = (n + 63) // 64
+    r = u
+    for l in range(64):
+        lo, hi = min(l * per, n), min(l * per + per, n)
+        s = np.float64(0.0)
+        for q in range(lo, hi):
+            s = s + p[q]
+        if r - s < 0:
+            for q in range(lo, hi):
+                r = r - p[q]
+                if r < 0:
+                    return q
+            return max(hi - 1, 0)
+        r = r - s
+    return n - 1
 
 
 class FbgmmBatch(object):
@@ -265,7 +289,7 @@ class FbgmmBatch(object):
                         p = np.exp(1. / temp * z - _sp_logsumexp(1. / temp * z))
                     else:
                         p = np.exp(z - _sp_logsumexp(z))
-                    k = no.draw(p, u01(self.seed, sweep_index, i, u.N_max + t))
+                    k = draw_chunked(p, u01(self.seed, sweep_index, i, u.N_max + t))
                     self.slot[e] = k
                     j_prev = k if self.lm is not None else None
             mine = {s: self._partial(s, b) for s in range(self.s_lo, self.s_hi)}

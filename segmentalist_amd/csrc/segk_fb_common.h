@@ -83,6 +83,59 @@ static __device__ int fb_collect_tokens(const int32_t *vid, const uint8_t *bnd, 
 }
 
 
+// utils.draw (utils.py:10-21): the first q with u - p[0] - ... - p[q] < 0, subtractions in index
+// order (else n - 1).  Executed redundantly by every calling lane (uniform LDS addresses are
+// broadcast reads): sixteen probabilities are fetched per step, then sixteen dependent
+// subtractions, then the exit checks.
+static __device__ int fb_draw_seq(const double *p, int n, double u)
+{
+    double uu = u;
+    for (int q0 = 0; q0 < n; q0 += 16) {
+        double v[16], r[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const int q = q0 + j < n ? q0 + j : n - 1;      // clamped, unconditional load
+            v[j] = p[q];
+        }
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            uu = uu - (q0 + j < n ? v[j] : 0.0);
+            r[j] = uu;
+        }
+#pragma unroll
+        for (int j = 0; j < 16; j++)
+            if (q0 + j < n && r[j] < 0) return q0 + j;
+    }
+    return n - 1;
+}
+
+// Inverse-CDF draw of the batch sampler (oracle/np_fbgmm_batch.py `draw_chunked`): the n
+// probabilities are cut into 64 runs of per = ceil(n/64) consecutive entries; run sums are
+// accumulated left to right, the runs are walked in order subtracting whole run sums from u, and
+// the run where the remainder would turn negative is walked entry by entry.  One full wave;
+// result in all lanes.  Same distribution as utils.draw, O(n/64 + 64) dependent steps.
+static __device__ int fb_draw_chunked(const double *p, int n, double u, int lane)
+{
+    const int per = (n + 63) >> 6;
+    const int lo = lane * per < n ? lane * per : n, hi = lo + per < n ? lo + per : n;
+    double s = 0.0;
+    for (int q = lo; q < hi; q++) s += p[q];
+    double r = u;
+    int run = -1;
+    for (int l = 0; l < 64; l++) {
+        const double sl = fb_readlane(s, l);
+        if (r - sl < 0) { run = l; break; }
+        r = r - sl;
+    }
+    if (run < 0) return n - 1;
+    const int rlo = run * per < n ? run * per : n, rhi = rlo + per < n ? rlo + per : n;
+    for (int q = rlo; q < rhi; q++) {
+        r = r - p[q];
+        if (r < 0) return q;
+    }
+    return rhi - 1 >= 0 ? rhi - 1 : 0;
+}
+
 // Counter-based uniform in [0, 1) of the batch sampler: u01(seed, sweep, utterance, j) -- two rounds
 // of the splitmix64 finaliser over a linear combination of the counters (oracle/np_fbgmm_batch.py).
 static __device__ __forceinline__ double segk_u01(uint64_t seed, uint64_t sweep, uint64_t utt, uint64_t j)

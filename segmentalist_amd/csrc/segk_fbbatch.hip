@@ -194,6 +194,42 @@ __global__ void k_fbb_prepare(segk_fbgmm f, segk_fbatch bt, int D, int b, double
     }
 }
 
+// acc[r] += sum_d term(mean[d, k], q[d, k], xs[r][d]) for the FBB_R rows in LDS; the parameters of
+// four dimensions are fetched ahead of their use (the loads are independent, the compiler keeps
+// them in flight together), dimensions in increasing order.
+template <int COV>
+static __device__ __forceinline__ void fbb_accumulate(const segk_fbatch &bt, int KM, int k, int D, const double *xs,
+                                                      double *acc)
+{
+    int d = 0;
+    for (; d + 4 <= D; d += 4) {
+        double m[4], q[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            m[j] = bt.mean_t[(int64_t)(d + j) * KM + k];
+            q[j] = bt.q_t[(int64_t)(d + j) * KM + k];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+#pragma unroll
+            for (int r = 0; r < FBB_R; r++) {
+                const double delta = m[j] - xs[r * D + d + j];
+                if (COV == 0) acc[r] += (delta * delta) * q[j];
+                else acc[r] += log(1. + (delta * delta) * q[j]);
+            }
+        }
+    }
+    for (; d < D; d++) {
+        const double m = bt.mean_t[(int64_t)d * KM + k], q = bt.q_t[(int64_t)d * KM + k];
+#pragma unroll
+        for (int r = 0; r < FBB_R; r++) {
+            const double delta = m - xs[r * D + d];
+            if (COV == 0) acc[r] += (delta * delta) * q;
+            else acc[r] += log(1. + (delta * delta) * q);
+        }
+    }
+}
+
 // x-dependent part of the prior predictive of one row, by one wave (lanes over d); result in all lanes
 template <typename XT>
 static __device__ double fbb_prior_row(const segk_fbgmm &f, int D, const double *x, int lane)
@@ -254,15 +290,7 @@ __global__ void k_fbb_score(segk_corpus c, segk_fbgmm f, segk_fbatch bt, FbbMap 
             double acc[FBB_R];
 #pragma unroll
             for (int r = 0; r < FBB_R; r++) acc[r] = 0.0;
-            for (int d = 0; d < D; d++) {
-                const double m = bt.mean_t[(int64_t)d * KM + k], q = bt.q_t[(int64_t)d * KM + k];
-#pragma unroll
-                for (int r = 0; r < FBB_R; r++) {
-                    const double delta = m - xs[r * D + d];
-                    if (COV == 0) acc[r] += (delta * delta) * q;
-                    else acc[r] += log(1. + (delta * delta) * q);
-                }
-            }
+            fbb_accumulate<COV>(bt, KM, k, D, xs, acc);
             const double zc = bt.zconst[k], h = bt.half[k];
 #pragma unroll
             for (int r = 0; r < FBB_R; r++) z[r] = zc - h * acc[r];
@@ -343,14 +371,20 @@ __global__ void k_fbb_segment(segk_corpus c, segk_fbatch bt, FbbMap map, int b, 
 // ---------------------------------------------------------------------------------------
 template <typename XT, int COV>
 __global__ void k_fbb_assign(segk_corpus c, segk_fbgmm f, segk_fbatch bt, FbbMap map, int b, uint64_t sweep,
-                             double prior_alpha, double anneal_temp, const int32_t *new_tok, const int32_t *n_new)
+                             double prior_alpha, double anneal_temp, const int32_t *new_tok, const int32_t *n_new,
+                             int rcap, int dbg)
 {
+    // The likelihood part of the logits does not depend on the previous segment's slot, so it is
+    // evaluated for up to `rcap` (<= FBB_R) tokens of the utterance at once -- the component
+    // parameters are streamed once per chunk -- and kept in LDS; the draws then run in token order
+    // (with a language model each needs the slot of the one before).
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int D = c.D, KM = f.K_max, tid = threadIdx.x, nt = blockDim.x;
     double *z = (double *)smem;                  // [K_max]
-    double *xs = z + KM;                         // [D]
-    double *red = xs + D;                        // [16]
-    __shared__ double sh_lpr;
+    double *ll = z + KM;                         // [rcap][K_max]
+    double *xs = ll + (int64_t)rcap * KM;        // [FBB_R][D]
+    double *lpr = xs + FBB_R * D;                // [FBB_R]
+    double *red = lpr + FBB_R;                   // [16]
     __shared__ int sh_k;
     int s, idx;
     if (!fbb_locate(map, blockIdx.x, &s, &idx)) return;
@@ -361,74 +395,86 @@ __global__ void k_fbb_assign(segk_corpus c, segk_fbgmm f, segk_fbatch bt, FbbMap
     const double zc_empty = f.lms * log(prior_alpha / (double)KM);
     const double tot = bt.scal[0];
     int j_prev = -1;
-    for (int t = 0; t < nn; t++) {
-        const int64_t e = new_tok[(int64_t)utt * c.N_max + t];
+    for (int t0 = 0; t0 < nn; t0 += rcap) {
+        const int nr = nn - t0 < rcap ? nn - t0 : rcap;
         __syncthreads();
-        for (int d = tid; d < D; d += nt) xs[d] = (double)X[e * c.ldx + d];
-        __syncthreads();
-        if (tid < 64) {
-            const double v = fbb_prior_row<XT>(f, D, xs, tid);
-            if (tid == 0) sh_lpr = v;
+        for (int j = tid; j < FBB_R * D; j += nt) {
+            const int r = j / D, d = j - r * D;
+            xs[j] = r < nr ? (double)X[(int64_t)new_tok[(int64_t)utt * c.N_max + t0 + r] * c.ldx + d] : 0.0;
         }
         __syncthreads();
-        const double lpr = sh_lpr;
+        {
+            const int w = tid >> 6, lane = tid & 63, nw = nt >> 6;
+            for (int r = w; r < nr; r += nw) {
+                const double v = fbb_prior_row<XT>(f, D, xs + r * D, lane);
+                if (lane == 0) lpr[r] = v;
+            }
+        }
+        __syncthreads();
         for (int k = tid; k < KM; k += nt) {
-            const double n = bt.cnt[k];
-            double ll = lpr;
-            if (n > 0.0) {
-                double acc = 0.0;
-                for (int d = 0; d < D; d++) {
-                    const double delta = bt.mean_t[(int64_t)d * KM + k] - xs[d];
-                    if (COV == 0) acc += (delta * delta) * bt.q_t[(int64_t)d * KM + k];
-                    else acc += log(1. + (delta * delta) * bt.q_t[(int64_t)d * KM + k]);
+            if (bt.cnt[k] > 0.0) {
+                double acc[FBB_R];
+#pragma unroll
+                for (int r = 0; r < FBB_R; r++) acc[r] = 0.0;
+                fbb_accumulate<COV>(bt, KM, k, (dbg & 1) ? 1 : D, xs, acc);
+                const double lc = bt.lconst[k], h = bt.half[k];
+#pragma unroll
+                for (int r = 0; r < FBB_R; r++)
+                    if (r < nr) ll[(int64_t)r * KM + k] = lc - h * acc[r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < FBB_R; r++)
+                    if (r < nr) ll[(int64_t)r * KM + k] = lpr[r];
+            }
+        }
+        __syncthreads();
+        for (int r = 0; r < ((dbg & 2) ? 1 : nr); r++) {
+            const int64_t e = new_tok[(int64_t)utt * c.N_max + t0 + r];
+            for (int k = tid; k < KM; k += nt) {
+                const double n = bt.cnt[k];
+                double pz;
+                if (!f.lm_unigram) pz = n > 0.0 ? f.lms * log(prior_alpha / (double)KM + n) : zc_empty;   // fbgmm.py:436-440
+                else if (j_prev < 0) pz = (log(n + f.lm_a / (double)KM) - log(tot + f.lm_a)) * f.lms;  // bigram_lms.py:64-69
+                else {                                                                                // bigram_lms.py:84-91
+                    const double pi = (n + f.lm_a / (double)KM) / (tot + f.lm_a);
+                    const double pij = (1. - f.lm_lambda) * ((double)f.lm_bigram[(int64_t)j_prev * KM + k] + f.lm_b / (double)KM)
+                                       / (bt.cnt[j_prev] + f.lm_b);
+                    pz = log(f.lm_lambda * pi + pij) * f.lms;
                 }
-                ll = bt.lconst[k] - bt.half[k] * acc;
+                z[k] = pz + ll[(int64_t)r * KM + k];
             }
-            double pz;
-            if (!f.lm_unigram) pz = n > 0.0 ? f.lms * log(prior_alpha / (double)KM + n) : zc_empty;   // fbgmm.py:436-440
-            else if (j_prev < 0) pz = (log(n + f.lm_a / (double)KM) - log(tot + f.lm_a)) * f.lms;  // bigram_lms.py:64-69
-            else {                                                                                // bigram_lms.py:84-91
-                const double pi = (n + f.lm_a / (double)KM) / (tot + f.lm_a);
-                const double pij = (1. - f.lm_lambda) * ((double)f.lm_bigram[(int64_t)j_prev * KM + k] + f.lm_b / (double)KM)
-                                   / (bt.cnt[j_prev] + f.lm_b);
-                pz = log(f.lm_lambda * pi + pij) * f.lms;
-            }
-            z[k] = pz + ll;
-        }
-        __syncthreads();
-        // softmax (scipy logsumexp order), optional annealing (fbgmm.py:446-449), utils.draw
-        double mx = NEG_INF_D;
-        for (int k = tid; k < KM; k += nt) mx = z[k] > mx ? z[k] : mx;
-        mx = block_max(mx, red);
-        double sm = 0.0;
-        for (int k = tid; k < KM; k += nt) sm += exp(z[k] - mx);
-        sm = block_sum(sm, red);
-        double lse = log(sm) + mx;
-        if (anneal_temp != 1.0) {
-            for (int k = tid; k < KM; k += nt) z[k] = (1. / anneal_temp) * (z[k] - lse);
             __syncthreads();
-            double mx2 = NEG_INF_D;
-            for (int k = tid; k < KM; k += nt) mx2 = z[k] > mx2 ? z[k] : mx2;
-            mx2 = block_max(mx2, red);
-            double s2 = 0.0;
-            for (int k = tid; k < KM; k += nt) s2 += exp(z[k] - mx2);
-            s2 = block_sum(s2, red);
-            lse = log(s2) + mx2;
-        }
-        for (int k = tid; k < KM; k += nt) z[k] = exp(z[k] - lse);
-        __syncthreads();
-        if (tid == 0) {
-            double uu = segk_u01(bt.seed, sweep, (uint64_t)utt, (uint64_t)(c.N_max + t));
-            int k = KM - 1;
-            for (int q = 0; q < KM; q++) {
-                uu = uu - z[q];
-                if (uu < 0) { k = q; break; }
+            // softmax (scipy logsumexp order), optional annealing (fbgmm.py:446-449), utils.draw
+            double mx = NEG_INF_D;
+            for (int k = tid; k < KM; k += nt) mx = z[k] > mx ? z[k] : mx;
+            mx = block_max(mx, red);
+            double sm = 0.0;
+            for (int k = tid; k < KM; k += nt) sm += exp(z[k] - mx);
+            sm = block_sum(sm, red);
+            double lse = log(sm) + mx;
+            if (anneal_temp != 1.0) {
+                for (int k = tid; k < KM; k += nt) z[k] = (1. / anneal_temp) * (z[k] - lse);
+                __syncthreads();
+                double mx2 = NEG_INF_D;
+                for (int k = tid; k < KM; k += nt) mx2 = z[k] > mx2 ? z[k] : mx2;
+                mx2 = block_max(mx2, red);
+                double s2 = 0.0;
+                for (int k = tid; k < KM; k += nt) s2 += exp(z[k] - mx2);
+                s2 = block_sum(s2, red);
+                lse = log(s2) + mx2;
             }
-            bt.slot[e] = k;
-            sh_k = k;
+            for (int k = tid; k < KM; k += nt) z[k] = exp(z[k] - lse);
+            __syncthreads();
+            if (tid < 64) {
+                const int k = (dbg & 4) ? 0 : fb_draw_chunked(z, KM, segk_u01(bt.seed, sweep, (uint64_t)utt, (uint64_t)(c.N_max + t0 + r)), tid);
+                if (tid == 0) {
+                    bt.slot[e] = k;
+                    sh_k = k;
+                }
+            }
+            __syncthreads();
+            if (f.lm_unigram) j_prev = sh_k;
         }
-        __syncthreads();
-        if (f.lm_unigram) j_prev = sh_k;
     }
 }
 
@@ -646,7 +692,14 @@ int32_t segk_fbb_assign(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *f
     if (rc) return rc;
     if (m.off[s_n] == 0) return SEGK_OK;
     const double alpha = f->lm_unigram ? f->lm_a : f->alpha;
-    const size_t lds = (size_t)(f->K_max + c->D + 16) * sizeof(double);
+    // timing-only ablation knob (development): 1 = one dimension, 2 = one token, 4 = no draw
+    const char *dbg_s = getenv("SEGK_FBB_DBG");
+    const int dbg = dbg_s ? atoi(dbg_s) : 0;
+    // tokens per chunk: as many likelihood rows as fit beside the logits (two workgroups per CU)
+    int rcap = FBB_R;
+    const size_t fixed_b = (size_t)(f->K_max + FBB_R * c->D + FBB_R + 16) * sizeof(double);
+    while (rcap > 1 && fixed_b + (size_t)rcap * f->K_max * sizeof(double) > 80 * 1024) rcap >>= 1;
+    const size_t lds = fixed_b + (size_t)rcap * f->K_max * sizeof(double);
     SEGK_REQUIRE(lds <= 160 * 1024, "K_max too large for the LDS logits buffer");
     DISPATCH_XT(c, {
         if (f->cov_type == 0) {
@@ -654,13 +707,13 @@ int32_t segk_fbb_assign(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *f
                 SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_fbb_assign<XT, 0>,
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL((k_fbb_assign<XT, 0>), dim3(m.off[s_n]), dim3(256), lds, (hipStream_t)stream, *c, *f, *bt, m,
-                               b, sweep, alpha, anneal_temp, new_tok, n_new);
+                               b, sweep, alpha, anneal_temp, new_tok, n_new, rcap, dbg);
         } else {
             if (lds > 48 * 1024)
                 SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_fbb_assign<XT, 1>,
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL((k_fbb_assign<XT, 1>), dim3(m.off[s_n]), dim3(256), lds, (hipStream_t)stream, *c, *f, *bt, m,
-                               b, sweep, alpha, anneal_temp, new_tok, n_new);
+                               b, sweep, alpha, anneal_temp, new_tok, n_new, rcap, dbg);
         }
     });
     SEGK_LAUNCH_CHECK();

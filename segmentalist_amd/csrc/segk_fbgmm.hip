@@ -492,25 +492,29 @@ __device__ void fb_draw_component(const segk_fbgmm &f, double *z, double *red, i
     }
     for (int k = threadIdx.x; k < f.K_max; k += blockDim.x) z[k] = exp(z[k] - lse);      // prob_z
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x < 64) {
         int k;
         if (map_assign) {                         // np.argmax(prob_z): first maximum
+            double bm = z[0];
             k = 0;
-            for (int q = 1; q < f.K_max; q++)
-                if (z[q] > z[k]) k = q;
+            for (int q = threadIdx.x; q < f.K_max; q += 64)
+                if (z[q] > bm) { bm = z[q]; k = q; }
+            for (int o = 32; o > 0; o >>= 1) {
+                const double om = __shfl_xor(bm, o);
+                const int ok = __shfl_xor(k, o);
+                if (om > bm || (om == bm && ok < k)) { bm = om; k = ok; }
+            }
         } else {                                  // utils.draw (utils.py:10-21), forward order
-            int64_t cur = *ucursor;
-            double uu = (cur < ucap) ? ustream[cur] : 0.5;
-            if (cur >= ucap) atomicOr(status, 8);
-            *ucursor = cur + 1;
-            k = f.K_max - 1;
-            for (int q = 0; q < f.K_max; q++) {
-                uu = uu - z[q];
-                if (uu < 0) { k = q; break; }
+            const int64_t cur = *ucursor;
+            const double uu = (cur < ucap) ? ustream[cur] : 0.5;
+            k = fb_draw_seq(z, f.K_max, uu);
+            if (threadIdx.x == 0) {
+                if (cur >= ucap) atomicOr(status, 8);
+                *ucursor = cur + 1;
             }
         }
         if (k > shK) k = shK;                     // :459-460
-        *sh_k_out = k;
+        if (threadIdx.x == 0) *sh_k_out = k;
     }
 }
 

@@ -20,6 +20,8 @@ def main():
     ap.add_argument("--sweeps", type=int, default=3)
     ap.add_argument("--cpu-utts", type=int, default=40)
     ap.add_argument("--which", default="diag,fixed,bigram")
+    ap.add_argument("--sync", default="sequential")
+    ap.add_argument("--blocks", type=int, default=8)
     args = ap.parse_args()
     import torch
     from segmentalist_amd import bigram_acoustic_wordseg as baw, fbgmm, unigram_acoustic_wordseg as uaw
@@ -35,6 +37,9 @@ def main():
     diag = (np.zeros(D), 0.05, D + 3, 0.002 * (D + 3) * np.ones(D))
     kw = dict(n_slices_min=0, n_slices_max=6, p_boundary_init=0.5, beta_sent_boundary=-1, lms=1.0, wip=0.0,
               init_am_assignments="rand", time_power_term=1.0)
+    okw = dict(kw)
+    if args.sync == "batch":
+        kw.update(sync="batch", n_gibbs_blocks=args.blocks)
     lm = {"type": "smooth", "intrp_lambda": 0.1, "a": 0.5, "b": 0.5}
     for which in args.which.split(","):
         random.seed(0)
@@ -51,8 +56,21 @@ def main():
                                             fb_type="unigram", **kw)
         torch.cuda.synchronize()
         t_init = time.perf_counter() - t0
-        rec = seg.gibbs_sample(args.sweeps)
-        st = rec["sample_time"]
+        if args.sync == "batch":
+            st = []
+            for _ in range(args.sweeps + 1):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                seg.batch_sweep_async()
+                torch.cuda.synchronize()
+                st.append(time.perf_counter() - t1)
+            seg._df.check_status()
+            st = st[1:]
+            cnt, tot, occ = seg._get_sweeper().totals()
+            rec = {"components": [occ]}
+        else:
+            rec = seg.gibbs_sample(args.sweeps)
+            st = rec["sample_time"]
         print("%-6s init %.2f s; sweep times %s s -> %.2f sweeps/s (%.1f us/utterance); K=%d"
               % (which, t_init, ["%.3f" % x for x in st], 1.0 / min(st), 1e6 * min(st) / args.utts,
                  rec["components"][-1]), flush=True)
@@ -61,13 +79,13 @@ def main():
         np.random.seed(0)
         if which == "diag":
             ref = no.UnigramAcousticWordseg(no.FBGMM, 1.0, K, no.NIW(*diag), *sub, covariance_type="diag",
-                                            fb_type="standard", **kw)
+                                            fb_type="standard", **okw)
         elif which == "fixed":
             ref = no.UnigramAcousticWordseg(no.FBGMM, 1.0, K, no.FixedVarPrior(*fixed), *sub,
-                                            covariance_type="fixed", fb_type="standard", **kw)
+                                            covariance_type="fixed", fb_type="standard", **okw)
         else:
             ref = no.BigramAcousticWordseg(K, no.FixedVarPrior(*fixed), lm, *sub, covariance_type="fixed",
-                                           fb_type="unigram", **kw)
+                                           fb_type="unigram", **okw)
         t0 = time.perf_counter()
         for i in range(len(keys)):
             ref.gibbs_sample_i(i)
