@@ -109,9 +109,13 @@ def main():
     barrier()
     seg._dk.check_status()
 
+    # HIP events around the main launch of the score kernel, recorded by the library on the launch
+    # stream (segk_profile_enable / segk_profile_read, include/segk.h)
+    import ctypes as C
+    from segmentalist_amd import _abi
     use_ev = not args.no_events
     if use_ev:
-        sweeper.score_events = []
+        _abi.check(_abi.lib().segk_profile_enable(_abi.ctx(), 1))
     t0 = time.perf_counter()
     for _ in range(args.steps):
         seg.batch_sweep_async()
@@ -124,13 +128,19 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
-    score_ms = None
-    if use_ev and sweeper.score_events:
-        score_ms = float(np.mean([a.elapsed_time(b) for a, b in sweeper.score_events]))
-        sweeper.score_events = None
+    score_ms, score_rows = None, rows_local
+    if use_ev:
+        nmax = min(args.steps, 256)
+        ms = (C.c_float * nmax)()
+        rows = (C.c_int64 * nmax)()
+        got = _abi.lib().segk_profile_read(_abi.ctx(), ms, rows, nmax)
+        if got > 0:
+            score_ms = float(np.mean(ms[:got]))
+            score_rows = int(rows[got - 1])
+        _abi.check(_abi.lib().segk_profile_enable(_abi.ctx(), 0))
 
     if rank == 0:
-        flops_per_launch = 2.0 * rows_local * args.K * args.dim      # algorithmic: 2 N_emb K D
+        flops_per_launch = 2.0 * score_rows * args.K * args.dim      # algorithmic: 2 rows K D of the timed launch
         out = {
             "metric": METRIC,
             "value": args.steps / elapsed,
@@ -166,7 +176,9 @@ def main():
                     traffic = tj["traffic_bytes_per_launch"]
             achieved = flops_per_launch / (score_ms * 1e-3) / 1e12
             out["roofline"] = {
-                "bound": "mfma", "kernel": "k_kmeans_score", "achieved": achieved,
+                "bound": "mfma", "kernel": "k_kmeans_score<25, 1, 4, 0> (main launch: %d of %d rows; the last partial "
+                                           "round runs split-K in k_kmeans_score<..., 1>)" % (score_rows, rows_local),
+                "achieved": achieved,
                 "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MATRIX_TFLOPS,
                 "traffic": traffic, "ms_per_launch": score_ms,
                 "flops_per_launch": flops_per_launch,

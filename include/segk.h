@@ -45,6 +45,13 @@ const char *segk_last_error(void);
 /* ABI version, bumped on any signature change. */
 int32_t segk_abi_version(void);
 
+/* Timing of the MAIN launch of the MFMA score kernel (k_kmeans_score<..., 0>) with HIP events
+ * recorded on its launch stream inside segk_kmeans_filter -- what bench.py's roofline.achieved is
+ * computed from.  segk_profile_read synchronises and returns, oldest first, the duration (ms) and
+ * the row count of the most recent recorded launches (at most `max`, at most 256 kept).          */
+int32_t segk_profile_enable(segk_ctx *ctx, int32_t on);
+int32_t segk_profile_read(segk_ctx *ctx, float *ms_out, int64_t *rows_out, int32_t max);
+
 /* -------------------------------------------------------------------------------------
  * Corpus (read-only during sampling): the device image of `Utterances` + the embedding
  * matrix (utterances.py:74-105; unigram_acoustic_wordseg.py:571-646).

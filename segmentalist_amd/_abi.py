@@ -118,6 +118,8 @@ SIGNATURES = {
     "segk_fbb_lm_apply": (_i32, [_P, _CP, _FP, _BP, _i32, _i32, _P]),
     "segk_fbb_lm_fill": (_i32, [_P, _CP, _FP, _BP, _i32, _i32, _i32, _P, _P, _P, _P]),
     "segk_fbb_canonical": (_i32, [_P, _CP, _FP, _BP, _P, _P]),
+    "segk_profile_enable": (_i32, [_P, _i32]),
+    "segk_profile_read": (_i32, [_P, _P, _P, _i32]),
     "segk_logsumexp": (_f64, [_P, _i64]),
     "segk_draw": (_i32, [_P, _i64, _f64]),
     "segk_sum_doubles": (_f64, [_P, _i64]),

@@ -50,14 +50,57 @@ int32_t segk_create(int32_t device_id, segk_ctx **out_ctx)
     c->device_id = device_id;
     c->n_cu = prop.multiProcessorCount;
     strncpy(c->arch, prop.gcnArchName, sizeof(c->arch) - 1);
+    int prev = 0;
+    SEGK_CHECK_HIP(hipGetDevice(&prev));
+    SEGK_CHECK_HIP(hipSetDevice(device_id));
+    SEGK_CHECK_HIP(hipMalloc((void **)&c->ws_k, sizeof(int32_t) * SEGK_WS_ENTRIES));
+    SEGK_CHECK_HIP(hipMalloc((void **)&c->ws_f, sizeof(float) * 2 * SEGK_WS_ENTRIES));
+    SEGK_CHECK_HIP(hipSetDevice(prev));
     *out_ctx = c;
     return SEGK_OK;
 }
 
 int32_t segk_destroy(segk_ctx *ctx)
 {
+    if (ctx) {
+        if (ctx->ws_k) (void)hipFree(ctx->ws_k);
+        if (ctx->ws_f) (void)hipFree(ctx->ws_f);
+        for (int i = 0; i < SEGK_PROF_SLOTS; i++)
+            for (int j = 0; j < 2; j++)
+                if (ctx->prof_ev[i][j]) (void)hipEventDestroy(ctx->prof_ev[i][j]);
+    }
     free(ctx);
     return SEGK_OK;
+}
+
+// Timing of the main launch of the MFMA score kernel with HIP events recorded on its launch stream
+// (bench.py: roofline.achieved).  While enabled every segk_kmeans_filter call records one pair.
+int32_t segk_profile_enable(segk_ctx *ctx, int32_t on)
+{
+    SEGK_REQUIRE(ctx, "ctx");
+    if (on)
+        for (int i = 0; i < SEGK_PROF_SLOTS; i++)
+            for (int j = 0; j < 2; j++)
+                if (!ctx->prof_ev[i][j]) SEGK_CHECK_HIP(hipEventCreate(&ctx->prof_ev[i][j]));
+    ctx->prof_on = on ? 1 : 0;
+    ctx->prof_n = 0;
+    return SEGK_OK;
+}
+
+// Synchronises the recorded events; ms_out / rows_out [max]: duration and row count of the main
+// score launch of the most recent calls (oldest first).  Returns the number written, < 0 on error.
+int32_t segk_profile_read(segk_ctx *ctx, float *ms_out, int64_t *rows_out, int32_t max)
+{
+    SEGK_REQUIRE(ctx && ms_out && rows_out, "arguments");
+    const int have = ctx->prof_n < SEGK_PROF_SLOTS ? ctx->prof_n : SEGK_PROF_SLOTS;
+    const int n = have < max ? have : max;
+    for (int i = 0; i < n; i++) {
+        const int slot = (ctx->prof_n - n + i) % SEGK_PROF_SLOTS;
+        SEGK_CHECK_HIP(hipEventSynchronize(ctx->prof_ev[slot][1]));
+        SEGK_CHECK_HIP(hipEventElapsedTime(&ms_out[i], ctx->prof_ev[slot][0], ctx->prof_ev[slot][1]));
+        rows_out[i] = ctx->prof_rows[slot];
+    }
+    return n;
 }
 
 // ----------------------------------------------------------------------------------------

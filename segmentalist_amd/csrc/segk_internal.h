@@ -7,10 +7,20 @@
 
 #include "../../include/segk.h"
 
+#define SEGK_WS_ENTRIES (256 * 1024)      /* (row, split) partial candidates of a split-K score launch */
+#define SEGK_PROF_SLOTS 256
+
 struct segk_ctx {
     int device_id;
     int n_cu;
     char arch[64];
+    // workspace of the split-K tail of the score stage: k [entries] int32, f [entries][2] float
+    int32_t *ws_k;
+    float *ws_f;
+    // optional timing of the main score launch (segk_profile_*): event pairs used round-robin
+    int prof_on, prof_n;
+    hipEvent_t prof_ev[SEGK_PROF_SLOTS][2];
+    int64_t prof_rows[SEGK_PROF_SLOTS];
 };
 
 void segk_set_error(const char *fmt, ...);

@@ -273,9 +273,18 @@ struct ScoreArgs {
     const double *mnorm2;
     segk_cand cand;
     int amb_cap;
+    // split-K launch (SPLIT = 1): workgroup b scores chunk b % n_chunks against the tiles
+    // [(b / n_chunks) * tiles_per_split, ...) and writes its partial candidates to part_k / part_f
+    int n_chunks, tiles_per_split;
+    int32_t *part_k;
+    float *part_f;
 };
 
-template <int GMAX, int NB, int WAVES>
+// SPLIT = 0: the whole component range per workgroup, winner + margin test + fused exact score.
+// SPLIT = 1: the tail of a launch whose last round would leave most of the chip idle (or a launch
+//            smaller than one round): every 32*NB*WAVES-row chunk is scored by several workgroups,
+//            each against a slice of the component tiles; k_score_merge combines the partial top-2.
+template <int GMAX, int NB, int WAVES, int SPLIT>
 __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 2) void k_kmeans_score(ScoreArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -283,16 +292,19 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 2) void k_kmeans_score
     const int64_t ld32 = A.ld32;
     const int32_t *__restrict__ ids = A.ids;
     const int64_t row0 = A.row0, n = A.n;
-    const float *__restrict__ tiles = A.tiles;
-    const int n_tiles = A.n_tiles, tile_stride = A.tile_stride, G = A.G, D = A.D, fuse_exact = A.fuse_exact,
-              dbg = A.dbg;
+    const int tile_stride = A.tile_stride, G = A.G, D = A.D, fuse_exact = A.fuse_exact, dbg = A.dbg;
+    const int chunk = SPLIT ? (int)(blockIdx.x % A.n_chunks) : (int)blockIdx.x;
+    const int split = SPLIT ? (int)(blockIdx.x / A.n_chunks) : 0;
+    const int tile0 = SPLIT ? split * A.tiles_per_split : 0;
+    const int n_tiles = SPLIT ? (A.n_tiles - tile0 < A.tiles_per_split ? A.n_tiles - tile0 : A.tiles_per_split) : A.n_tiles;
+    const float *__restrict__ tiles = A.tiles + (int64_t)tile0 * tile_stride;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
 
     float2 xb[NB][GMAX];
     int32_t rowid[NB];
-    const int64_t base = ((int64_t)blockIdx.x * WAVES + wave) * (32 * NB);
+    const int64_t base = ((int64_t)chunk * WAVES + wave) * (32 * NB);
 #pragma unroll
     for (int nb = 0; nb < NB; nb++) {
         int64_t r = base + nb * 32 + j;
@@ -446,6 +458,16 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 2) void k_kmeans_score
         float top1 = fmaxf(m1[nb], o1);
         float top2 = fmaxf(fminf(m1[nb], o1), fmaxf(m2[nb], o2));
         int idx = (o1 > m1[nb] || (o1 == m1[nb] && oi < i1[nb])) ? oi : i1[nb];
+        if (SPLIT) {
+            const int64_t r = base + nb * 32 + j;
+            if (h == 0 && r < n) {
+                const int64_t e = (int64_t)split * n + r;
+                A.part_k[e] = idx + tile0 * 32;
+                A.part_f[2 * e + 0] = top1;
+                A.part_f[2 * e + 1] = top2;
+            }
+            continue;
+        }
         // Fused exact stage for the winner (float32 data, 8 <= D <= 128): the reference's
         // float32 -(deltas*deltas).sum() in numpy's pairwise order.  Dim d = 4g+2h+s sits on
         // lane half h, and d mod 8 = 4(g&1)+2h+s selects the strided accumulator, so half 0
@@ -504,6 +526,42 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 2) void k_kmeans_score
                 if (q < A.amb_cap) A.cand.queue[q] = id;
             }
         }
+    }
+}
+
+// Combine the partial candidates of a split-K launch: per row the largest filter value (ties: the
+// lower component), the second largest over everything else, then the same margin test as the
+// unsplit epilogue.  The winner's exact score is left to k_kmeans_exact_fill (cand.s = NaN).
+__global__ void k_score_merge(ScoreArgs A, int n_split)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= A.n) return;
+    const int32_t id = A.ids ? A.ids[r] : (int32_t)(A.row0 + r);
+    if (id < 0) return;
+    float top1 = NEG_INF_F, top2 = NEG_INF_F;
+    int idx = 0x7fffffff;
+    for (int sp = 0; sp < n_split; sp++) {
+        const int64_t e = (int64_t)sp * A.n + r;
+        const float f1 = A.part_f[2 * e], f2 = A.part_f[2 * e + 1];
+        const int k = A.part_k[e];
+        if (f1 > top1 || (f1 == top1 && k < idx)) {
+            top2 = fmaxf(top2, top1);
+            top1 = f1;
+            idx = k;
+        } else {
+            top2 = fmaxf(top2, f1);
+        }
+        top2 = fmaxf(top2, f2);
+    }
+    A.cand.k[id] = idx;
+    A.cand.f[2 * (int64_t)id + 0] = top1;
+    A.cand.f[2 * (int64_t)id + 1] = top2;
+    A.cand.s[id] = (double)__builtin_nanf("");
+    const float M = (float)(sqrt(*A.mnorm2) * (1.0 + 1e-6)) + 1e-30f;
+    const float tau = filter_tau(A.xnorm[id], M, A.D, A.is_f64);
+    if (!(top1 - top2 > tau)) {
+        int q = atomicAdd(A.cand.count, 1);
+        if (q < A.amb_cap) A.cand.queue[q] = id;
     }
 }
 
@@ -1227,8 +1285,15 @@ __global__ void k_batch_combine(segk_corpus c, segk_kmeans m, const double *part
 template <typename XT>
 __global__ void k_batch_clean(segk_corpus c, segk_kmeans m, int32_t *remap, double *out_scalars)
 {
-    __shared__ int shK;
-    __shared__ unsigned int bitmap[1024];            // K_max <= 32768
+    // The reference deletes the empty components one at a time in descending order, each time moving
+    // the last active row into the hole (kmeans_components.py:129-151, 263-266).  Because the holes
+    // above the current one are already gone, the row that moves is never empty, every moved row
+    // originates at or above the final K and lands below it -- so the bookkeeping (which original row
+    // ends where) is replayed serially on indices only, and the rows are then moved in parallel.
+    __shared__ int shK, n_holes;
+    __shared__ unsigned int bitmap[256];             // K_max <= 8192
+    __shared__ unsigned short pos2orig[8192];        // position -> original row living there
+    __shared__ unsigned short holes[8192];           // hole positions, descending
     __shared__ long long red[256];
     const int tid = threadIdx.x, nt = blockDim.x;
     const int D = c.D;
@@ -1238,7 +1303,7 @@ __global__ void k_batch_clean(segk_corpus c, segk_kmeans m, int32_t *remap, doub
     const int nwords = (K0 + 31) / 32;
     for (int w = tid; w < nwords; w += nt) bitmap[w] = 0;
     for (int k = tid; k < m.K_max; k += nt) remap[k] = k;
-    if (tid == 0) shK = K0;
+    for (int k = tid; k < K0; k += nt) pos2orig[k] = (unsigned short)k;
     __syncthreads();
     long long csum = 0;
     for (int k = tid; k < m.K_max; k += nt) {
@@ -1252,43 +1317,52 @@ __global__ void k_batch_clean(segk_corpus c, segk_kmeans m, int32_t *remap, doub
         if (tid < o) red[tid] += red[tid + o];
         __syncthreads();
     }
-    if (tid == 0) out_scalars[2] = (double)red[0];
-    for (int w = nwords - 1; w >= 0; w--) {
-        unsigned int bits = bitmap[w];                 // uniform across the workgroup
-        while (bits) {
-            const int bit = 31 - __clz((int)bits);
-            bits &= ~(1u << bit);
-            const int k = w * 32 + bit;
-            __syncthreads();
-            if (tid == 0) shK = shK - 1;
-            __syncthreads();
-            const int K = shK;
-            if (k != K) {
-                const double cntK = (double)m.counts[K];
-                for (int d = tid; d < D; d += nt) {
-                    double v = m.mean_numerators[(int64_t)K * D + d];
-                    m.mean_numerators[(int64_t)k * D + d] = v;
-                    means[(int64_t)k * D + d] = (XT)(v / cntK);
-                }
-                // whichever ORIGINAL labels currently live in row K now live in row k
-                for (int q = tid; q < m.K_max; q += nt)
-                    if (remap[q] == K) remap[q] = k;
+    if (tid == 0) {
+        out_scalars[2] = (double)red[0];
+        int K = K0, nh = 0;
+        for (int w = nwords - 1; w >= 0; w--) {
+            unsigned int bits = bitmap[w];
+            while (bits) {
+                const int bit = 31 - __clz((int)bits);
+                bits &= ~(1u << bit);
+                const int k = w * 32 + bit;
+                K--;
+                if (k != K) pos2orig[k] = pos2orig[K];
+                holes[nh++] = (unsigned short)k;
             }
-            __syncthreads();
-            for (int d = tid; d < D; d += nt) {
-                m.mean_numerators[(int64_t)K * D + d] = 0.0;
-                means[(int64_t)K * D + d] = rnd[(int64_t)K * D + d];
-            }
-            if (tid == 0) {
-                if (k != K) m.counts[k] = m.counts[K];
-                m.counts[K] = 0;
-            }
+        }
+        shK = K;
+        n_holes = nh;
+    }
+    __syncthreads();
+    const int K = shK, nh = n_holes;
+    // move: one wave per filled hole below the final K
+    for (int h = tid >> 6; h < nh; h += nt >> 6) {
+        const int k = holes[h];
+        if (k >= K) continue;
+        const int src = pos2orig[k];
+        const double cnt = (double)m.counts[src];
+        for (int d = tid & 63; d < D; d += 64) {
+            const double v = m.mean_numerators[(int64_t)src * D + d];
+            m.mean_numerators[(int64_t)k * D + d] = v;
+            means[(int64_t)k * D + d] = (XT)(v / cnt);
+        }
+        if ((tid & 63) == 0) {
+            m.counts[k] = m.counts[src];
+            remap[src] = k;
         }
     }
     __syncthreads();
+    // rows [K, K0) are inactive again
+    for (int64_t j = tid; j < (int64_t)(K0 - K) * D; j += nt) {
+        const int64_t row = K + j / D, d = j % D;
+        m.mean_numerators[row * D + d] = 0.0;
+        means[row * D + d] = rnd[row * D + d];
+    }
+    for (int k = K + tid; k < K0; k += nt) m.counts[k] = 0;
     if (tid == 0) {
-        *m.K = shK;
-        out_scalars[1] = (double)shK;
+        *m.K = K;
+        out_scalars[1] = (double)K;
     }
 }
 
@@ -1555,16 +1629,75 @@ static int check_corpus(const segk_corpus *c)
     return SEGK_OK;
 }
 
+// Launch plan of the filter stage.  Let slots = resident workgroups of the chip and chunks =
+// ceil(n / rows per workgroup).  The first floor(chunks / slots) * slots chunks go to the plain
+// kernel (whole rounds); the remaining r < slots chunks -- a last round that would leave most of
+// the chip idle while a few workgroups walk all component tiles, or the whole launch when n is
+// small (a shard of a multi-GPU run, one utterance of the serial chain) -- are scored split-K:
+// each chunk by `s` workgroups over disjoint tile ranges, merged by k_score_merge.
 template <int GMAX, int NB, int WAVES>
-static int launch_score(const ScoreArgs &A, hipStream_t st)
+static int launch_score(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m, ScoreArgs A, hipStream_t st)
 {
     const size_t lds = 2 * (size_t)A.tile_stride * sizeof(float);
     const int rows_per_wg = WAVES * 32 * NB;
-    const int64_t grid = (A.n + rows_per_wg - 1) / rows_per_wg;
-    if (lds > 48 * 1024)
-        SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_kmeans_score<GMAX, NB, WAVES>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_kmeans_score<GMAX, NB, WAVES>), dim3((unsigned)grid), dim3(64 * WAVES), lds, st, A);
+    static int wg_per_cu = 0;
+    if (!wg_per_cu) {
+        if (lds > 48 * 1024) {
+            SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_kmeans_score<GMAX, NB, WAVES, 0>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_kmeans_score<GMAX, NB, WAVES, 1>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        }
+        int occ = 0;
+        SEGK_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)k_kmeans_score<GMAX, NB, WAVES, 0>,
+                                                                    64 * WAVES, lds));
+        wg_per_cu = occ > 0 ? occ : 1;
+    }
+    const int64_t slots = (int64_t)wg_per_cu * ctx->n_cu;
+    const int64_t chunks = (A.n + rows_per_wg - 1) / rows_per_wg;
+    int64_t main_chunks = (chunks / slots) * slots, tail_chunks = chunks - main_chunks;
+    int n_split = 1;
+    if (tail_chunks > 0) {
+        n_split = (int)(slots / tail_chunks);
+        if (n_split > A.n_tiles) n_split = A.n_tiles;
+        if ((int64_t)n_split * tail_chunks * rows_per_wg > SEGK_WS_ENTRIES) n_split = (int)(SEGK_WS_ENTRIES / (tail_chunks * rows_per_wg));
+    }
+    const char *no_split = getenv("SEGK_SCORE_NOSPLIT");
+    if (n_split < 2 || (no_split && atoi(no_split))) {          // the tail fills at least half a round: no split
+        main_chunks = chunks;
+        tail_chunks = 0;
+    }
+    const int64_t n_main = main_chunks * rows_per_wg < A.n ? main_chunks * rows_per_wg : A.n;
+    if (main_chunks > 0) {
+        ScoreArgs M = A;
+        M.n = n_main;
+        const bool prof = ctx->prof_on != 0;
+        const int slot = ctx->prof_n % SEGK_PROF_SLOTS;
+        if (prof) SEGK_CHECK_HIP(hipEventRecord(ctx->prof_ev[slot][0], st));
+        hipLaunchKernelGGL((k_kmeans_score<GMAX, NB, WAVES, 0>), dim3((unsigned)main_chunks), dim3(64 * WAVES), lds, st, M);
+        if (prof) {
+            SEGK_CHECK_HIP(hipEventRecord(ctx->prof_ev[slot][1], st));
+            ctx->prof_rows[slot] = n_main;
+            ctx->prof_n++;
+        }
+    }
+    if (tail_chunks > 0) {
+        ScoreArgs T = A;
+        T.n = A.n - n_main;
+        T.row0 = A.row0 + n_main;
+        T.ids = A.ids ? A.ids + n_main : nullptr;
+        T.n_chunks = (int)tail_chunks;
+        T.tiles_per_split = (A.n_tiles + n_split - 1) / n_split;
+        const int s_eff = (A.n_tiles + T.tiles_per_split - 1) / T.tiles_per_split;
+        T.part_k = ctx->ws_k;
+        T.part_f = ctx->ws_f;
+        hipLaunchKernelGGL((k_kmeans_score<GMAX, NB, WAVES, 1>), dim3((unsigned)(tail_chunks * s_eff)), dim3(64 * WAVES), lds,
+                           st, T);
+        hipLaunchKernelGGL(k_score_merge, dim3((unsigned)((T.n + 255) / 256)), dim3(256), 0, st, T, s_eff);
+        if (A.fuse_exact)       // rows scored split-K get their winner's exact score here
+            DISPATCH_XT(c, hipLaunchKernelGGL(k_kmeans_exact_fill<XT>, dim3((unsigned)((T.n + 255) / 256)), dim3(256), 0, st,
+                                               *c, *m, T.ids, T.row0, T.n, A.cand););
+    }
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;
 }
@@ -1628,7 +1761,7 @@ int32_t segk_kmeans_clear_queue(segk_ctx *ctx, const segk_cand *cand, void *stre
 int32_t segk_kmeans_filter(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m, const int32_t *ids,
                            int64_t row0, int64_t n, const segk_cand *cand, void *stream)
 {
-    (void)ctx;
+    SEGK_REQUIRE(ctx, "ctx");
     int rc = score_checks(c, m, ids, row0, n, cand);
     if (rc) return rc;
     if (n <= 0) return SEGK_OK;
@@ -1641,13 +1774,19 @@ int32_t segk_kmeans_filter(segk_ctx *ctx, const segk_corpus *c, const segk_kmean
     A.is_f64 = c->x_dtype == SEGK_F64;
     A.dbg = getenv("SEGK_SCORE_DBG") ? atoi(getenv("SEGK_SCORE_DBG")) : 0;
     A.xnorm = c->xnorm; A.mnorm2 = m->mnorm_max; A.cand = *cand; A.amb_cap = (int)c->n_emb;
+    A.n_chunks = 0; A.tiles_per_split = 0; A.part_k = nullptr; A.part_f = nullptr;
     // 4-wave workgroups, two per CU: the two waves sharing a SIMD belong to DIFFERENT workgroups
     // and drift apart, covering each other's barrier/staging gaps.  (Measured: an 8-wave
     // workgroup, one barrier for all eight waves, locks the SIMD partners in step and is 15 %
     // slower although it halves the staging instructions per wave.)
+    // Rows per wave: one 32-row MFMA column block per wave (108 VGPRs, four workgroups per CU) beat
+    // two blocks sharing every LDS tile fetch (194 VGPRs, two per CU) at every row count measured
+    // (D = 100: 77 % vs 73 % of the fp32 matrix peak); SEGK_SCORE_NB=2 selects the latter.
+    const char *nb_env = getenv("SEGK_SCORE_NB");
+    const bool one_block = nb_env ? atoi(nb_env) == 1 : true;   // measured faster at every size for D = 100
     switch (segk_gmax(c->D)) {
 #define SEGK_CASE(g, nb) \
-    case g: return launch_score<g, nb, 4>(A, st);
+    case g: return (nb == 2 && !one_block) ? launch_score<g, nb, 4>(ctx, c, m, A, st) : launch_score<g, 1, 4>(ctx, c, m, A, st);
         SEGK_CASE(1, 2) SEGK_CASE(2, 2) SEGK_CASE(4, 2) SEGK_CASE(6, 2) SEGK_CASE(8, 2) SEGK_CASE(10, 2)
         SEGK_CASE(13, 2) SEGK_CASE(16, 2) SEGK_CASE(20, 2) SEGK_CASE(25, 2) SEGK_CASE(26, 2) SEGK_CASE(28, 2)
         SEGK_CASE(32, 2) SEGK_CASE(33, 2) SEGK_CASE(34, 2) SEGK_CASE(40, 1) SEGK_CASE(50, 1) SEGK_CASE(64, 1)
@@ -1886,7 +2025,7 @@ int32_t segk_kmeans_batch_finalize(segk_ctx *ctx, const segk_corpus *c, segk_kme
     if (rc) return rc;
     SEGK_REQUIRE(n_blocks_total >= 1 && n_blocks_total <= 64, "1 <= n_blocks_total <= 64");
     SEGK_REQUIRE(n_blocks_per_rank >= 1 && n_blocks_total % n_blocks_per_rank == 0, "blocks per rank");
-    SEGK_REQUIRE(m->K_max <= 32768, "K_max <= 32768");
+    SEGK_REQUIRE(m->K_max <= 8192, "batch mode supports K_max <= 8192");
     hipStream_t st = (hipStream_t)stream;
     int64_t tot = (int64_t)m->K_max * c->D;
     DISPATCH_XT(c, {

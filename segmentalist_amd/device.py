@@ -344,26 +344,11 @@ class KMeansBatchSweeper(object):
         self._a_sum = C.c_void_p(base0)
         self._a_tot = C.c_void_p(base0 + 8 * (nbl * K * D))
         self._a_cnt = C.c_void_p(base0 + 8 * (nbl * K * D + nbl))
-        # bench hook: when a list, every sweep appends a (start, end) pair of HIP events that
-        # bracket the score kernel on its launch stream
-        self.score_events = None
 
     def sweep(self, boundaries, n_slices_min, n_slices_max, wip):
         dk, pt = self.dk, self.part
         L, ctx, cp, mp, st = dk._L, dk._ctx, dk._cp(), C.byref(dk.m), _abi.stream()
-        if self.score_events is not None:
-            # the events bracket exactly the MFMA filter kernel on its launch stream
-            torch = _torch()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            nrow = pt.row_hi - pt.row_lo
-            check(L.segk_kmeans_clear_queue(ctx, C.byref(dk.cand), st))
-            e0.record()
-            check(L.segk_kmeans_filter(ctx, cp, mp, None, pt.row_lo, nrow, C.byref(dk.cand), st))
-            e1.record()
-            check(L.segk_kmeans_resolve(ctx, cp, mp, None, pt.row_lo, nrow, C.byref(dk.cand), ptr(dk.status), st))
-            self.score_events.append((e0, e1))
-        else:
-            dk.score_rows(row0=pt.row_lo, n=pt.row_hi - pt.row_lo)
+        dk.score_rows(row0=pt.row_lo, n=pt.row_hi - pt.row_lo)
         dk.segment(boundaries, n_slices_min, n_slices_max, wip, utt0=pt.utt_lo, n_utts=pt.utt_hi - pt.utt_lo)
         check(L.segk_kmeans_batch_collect(ctx, cp, mp, pt.utt_lo, pt.utt_hi, ptr(dk.new_k), ptr(dk.n_new),
                                           ptr(dk.n_flag), ptr(dk.tok_off), ptr(self.flag), self.cap, st))

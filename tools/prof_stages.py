@@ -53,12 +53,16 @@ def main():
     print("K after %d sweeps: %d" % (args.sweeps, seg.acoustic_model.components.K))
 
     # score kernel alone at several row counts
-    for n in [n_emb, 1048576, 1048576 - 131072, 524288, 131072, 65536]:
-        if n > n_emb:
-            continue
-        med, mn = timeit(lambda: dk.score_rows(row0=0, n=n))
-        tf = 2.0 * n * args.K * args.dim / (med * 1e-3) / 1e12
-        print("score n=%8d  median %.3f ms  min %.3f ms  %.1f TFLOP/s (%.1f%% of 157.3)" % (n, med, mn, tf, 100 * tf / 157.3))
+    for nb in ("2", "1"):
+        os.environ["SEGK_SCORE_NB"] = nb
+        for n in [n_emb, 1048576, 524288, 393216, 262144, 131072, 65536, 16384]:
+            if n > n_emb:
+                continue
+            med, mn = timeit(lambda: dk.score_rows(row0=0, n=n))
+            tf = 2.0 * n * args.K * args.dim / (med * 1e-3) / 1e12
+            print("NB=%s score n=%8d  median %.3f ms  min %.3f ms  %.1f TFLOP/s (%.1f%% of 157.3)"
+                  % (nb, n, med, mn, tf, 100 * tf / 157.3))
+    del os.environ["SEGK_SCORE_NB"]
     if args.score_only:
         return
 
