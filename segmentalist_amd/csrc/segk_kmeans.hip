@@ -641,6 +641,114 @@ __global__ void k_kmeans_brute(segk_corpus c, segk_kmeans m, segk_cand cand, int
     }
 }
 
+// Full scan of BR queued rows per workgroup for float32 data with 8 <= D <= 128 (numpy's
+// single-block case): a thread walks the components tid, tid + nt, ... and evaluates each against
+// the BR rows held in LDS -- every component value is fetched once for BR rows, which takes the scan
+// from L2-bandwidth bound (one pass over the tile image per row) to latency/compute bound.  Per
+// (row, component) the arithmetic is neg_sqd_exact's: eight strided accumulators, the fixed combine
+// tree, the sequential tail; first maximum per row.
+#define SEGK_BR 8
+__global__ __launch_bounds__(256) void k_kmeans_brute_rows(segk_corpus c, segk_kmeans m, segk_cand cand, int cap, int32_t *n_brute)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, nt = blockDim.x, D = c.D;
+    float *xs = (float *)smem;                               // [BR][D]
+    float *red_v = xs + SEGK_BR * D;                         // [nt]
+    int32_t *red_k = (int32_t *)(red_v + nt);                // [nt]
+    __shared__ int32_t ids[SEGK_BR];
+    const float *X = (const float *)c.X;
+    int nq = *cand.count;
+    if (nq > cap) nq = cap;
+    if (blockIdx.x == 0 && tid == 0 && n_brute && nq > 0) atomicAdd(n_brute, nq);
+    const int tstride = segk_tile_stride(D);
+    const int nfull = D - (D % 8);
+    for (int q0 = blockIdx.x * SEGK_BR; q0 < nq; q0 += gridDim.x * SEGK_BR) {
+        const int nr = nq - q0 < SEGK_BR ? nq - q0 : SEGK_BR;
+        __syncthreads();
+        if (tid < SEGK_BR) ids[tid] = cand.queue[q0 + (tid < nr ? tid : nr - 1)];
+        __syncthreads();
+        for (int j = tid; j < SEGK_BR * D; j += nt) {
+            const int r = j / D, d = j - r * D;
+            xs[j] = X[(int64_t)ids[r] * c.ldx + d];
+        }
+        __syncthreads();
+        float best[SEGK_BR];
+        int32_t bk[SEGK_BR];
+#pragma unroll
+        for (int r = 0; r < SEGK_BR; r++) { best[r] = NEG_INF_F; bk[r] = 0x7fffffff; }
+        for (int k = tid; k < m.K_max; k += nt) {
+            const TileRow mr = tile_row(m.tiles, tstride, k);
+            float acc[SEGK_BR][8];
+            float mv[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) mv[j] = mr[j];
+#pragma unroll
+            for (int r = 0; r < SEGK_BR; r++)
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const float delta = mv[j] - xs[r * D + j];
+                    acc[r][j] = delta * delta;
+                }
+            int i;
+            for (i = 8; i < nfull; i += 8) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) mv[j] = mr[i + j];
+#pragma unroll
+                for (int r = 0; r < SEGK_BR; r++)
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        const float delta = mv[j] - xs[r * D + i + j];
+                        acc[r][j] += delta * delta;
+                    }
+            }
+            float res[SEGK_BR];
+#pragma unroll
+            for (int r = 0; r < SEGK_BR; r++)
+                res[r] = ((acc[r][0] + acc[r][1]) + (acc[r][2] + acc[r][3])) + ((acc[r][4] + acc[r][5]) + (acc[r][6] + acc[r][7]));
+            for (; i < D; i++) {
+                const float mvi = mr[i];
+#pragma unroll
+                for (int r = 0; r < SEGK_BR; r++) {
+                    const float delta = mvi - xs[r * D + i];
+                    res[r] += delta * delta;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < SEGK_BR; r++) {
+                const float sc = -res[r];
+                if (sc > best[r] || bk[r] == 0x7fffffff) { best[r] = sc; bk[r] = k; }   // first max within the thread
+            }
+        }
+        for (int r = 0; r < nr; r++) {
+            // wave butterfly (ties -> lower component), then the waves' results through LDS
+            float v = best[0];
+            int32_t kk = bk[0];
+#pragma unroll
+            for (int q = 1; q < SEGK_BR; q++)
+                if (q == r) { v = best[q]; kk = bk[q]; }
+            for (int o = 32; o > 0; o >>= 1) {
+                const float v2 = __shfl_xor(v, o);
+                const int32_t k2 = __shfl_xor(kk, o);
+                const bool take = (k2 != 0x7fffffff) && (kk == 0x7fffffff || v2 > v || (v2 == v && k2 < kk));
+                if (take) { v = v2; kk = k2; }
+            }
+            __syncthreads();
+            if ((tid & 63) == 0) { red_v[tid >> 6] = v; red_k[tid >> 6] = kk; }
+            __syncthreads();
+            if (tid == 0) {
+                for (int w = 1; w < (nt >> 6); w++) {
+                    const float v2 = red_v[w];
+                    const int32_t k2 = red_k[w];
+                    const bool take = (k2 != 0x7fffffff) && (kk == 0x7fffffff || v2 > v || (v2 == v && k2 < kk));
+                    if (take) { v = v2; kk = k2; }
+                }
+                cand.k[ids[r]] = kk;
+                cand.s[ids[r]] = (double)v;
+            }
+        }
+    }
+}
+
 template <typename XT>
 __global__ void k_kmeans_exact_fill(segk_corpus c, segk_kmeans m, const int32_t *ids, int64_t row0, int64_t n,
                                     segk_cand cand)
@@ -1811,11 +1919,19 @@ int32_t segk_kmeans_resolve(segk_ctx *ctx, const segk_corpus *c, const segk_kmea
         DISPATCH_XT(c, hipLaunchKernelGGL(k_kmeans_exact_fill<XT>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
                                            *c, *m, ids, row0, n, *cand););
     const int nt = 256;
-    size_t xsz = (c->x_dtype == SEGK_F32 ? 4 : 8) * (size_t)((c->D + 1) & ~1);
-    size_t lds = nt * sizeof(double) + xsz + nt * sizeof(int32_t);
-    int64_t grid = n < 1024 ? n : 1024;
-    DISPATCH_XT(c, hipLaunchKernelGGL(k_kmeans_brute<XT>, dim3((unsigned)grid), dim3(nt), lds, st, *c, *m, *cand,
-                                       (int)c->n_emb, status ? status + 1 : nullptr););
+    if (fused) {         // float32 data, 8 <= D <= 128: SEGK_BR queued rows per workgroup
+        const size_t lds = (size_t)SEGK_BR * c->D * sizeof(float) + nt * (sizeof(float) + sizeof(int32_t));
+        const int64_t groups = (n + SEGK_BR - 1) / SEGK_BR;
+        const int64_t grid = groups < 2048 ? groups : 2048;
+        hipLaunchKernelGGL(k_kmeans_brute_rows, dim3((unsigned)grid), dim3(nt), lds, st, *c, *m, *cand, (int)c->n_emb,
+                           status ? status + 1 : nullptr);
+    } else {
+        size_t xsz = (c->x_dtype == SEGK_F32 ? 4 : 8) * (size_t)((c->D + 1) & ~1);
+        size_t lds = nt * sizeof(double) + xsz + nt * sizeof(int32_t);
+        int64_t grid = n < 1024 ? n : 1024;
+        DISPATCH_XT(c, hipLaunchKernelGGL(k_kmeans_brute<XT>, dim3((unsigned)grid), dim3(nt), lds, st, *c, *m, *cand,
+                                           (int)c->n_emb, status ? status + 1 : nullptr););
+    }
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;
 }
