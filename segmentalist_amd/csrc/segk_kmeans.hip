@@ -529,6 +529,19 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 2) void k_kmeans_score
     }
 }
 
+// A handful of left-over rows (fewer than SEGK_TAIL_QUEUE): not worth three more launches -- they
+// are appended to the ambiguity queue and take the full reference-arithmetic scan.
+#define SEGK_TAIL_QUEUE 2048
+__global__ void k_score_queue_rows(ScoreArgs A)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= A.n) return;
+    const int32_t id = A.ids ? A.ids[r] : (int32_t)(A.row0 + r);
+    if (id < 0) return;
+    const int q = atomicAdd(A.cand.count, 1);
+    if (q < A.amb_cap) A.cand.queue[q] = id;
+}
+
 // Combine the partial candidates of a split-K launch: per row the largest filter value (ties: the
 // lower component), the second largest over everything else, then the same margin test as the
 // unsplit epilogue.  The winner's exact score is left to k_kmeans_exact_fill (cand.s = NaN).
@@ -1742,7 +1755,8 @@ static int check_corpus(const segk_corpus *c)
 // kernel (whole rounds); the remaining r < slots chunks -- a last round that would leave most of
 // the chip idle while a few workgroups walk all component tiles, or the whole launch when n is
 // small (a shard of a multi-GPU run, one utterance of the serial chain) -- are scored split-K:
-// each chunk by `s` workgroups over disjoint tile ranges, merged by k_score_merge.
+// each chunk by `s` workgroups over disjoint tile ranges, merged by k_score_merge; fewer than
+// SEGK_TAIL_QUEUE left-over rows simply join the ambiguity queue (full scan).
 template <int GMAX, int NB, int WAVES>
 static int launch_score(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m, ScoreArgs A, hipStream_t st)
 {
@@ -1789,7 +1803,13 @@ static int launch_score(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *
             ctx->prof_n++;
         }
     }
-    if (tail_chunks > 0) {
+    if (tail_chunks > 0 && A.n - n_main < SEGK_TAIL_QUEUE && A.fuse_exact && !(no_split && atoi(no_split) == 2)) {
+        ScoreArgs T = A;
+        T.n = A.n - n_main;
+        T.row0 = A.row0 + n_main;
+        T.ids = A.ids ? A.ids + n_main : nullptr;
+        hipLaunchKernelGGL(k_score_queue_rows, dim3((unsigned)((T.n + 255) / 256)), dim3(256), 0, st, T);
+    } else if (tail_chunks > 0) {
         ScoreArgs T = A;
         T.n = A.n - n_main;
         T.row0 = A.row0 + n_main;
