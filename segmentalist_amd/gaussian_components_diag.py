@@ -49,14 +49,18 @@ class GaussianComponentsDiag(_DeviceGaussianComponents):
     def log_post_pred_k(self, i, k):
         return self.log_post_pred(i)[k]
 
-    def log_marg_k(self, k):
+    def _snapshot(self):
+        return dict(assignments=self.assignments, K=self.K, counts=self.counts, a=self.m_N_numerators,
+                    b=self.S_N_partials)
+
+    def _log_marg_k(self, k, snap, rows):
         """gaussian_components_diag.py:271-290 (record metric, host)."""
         p = self.prior
-        cnt = self.counts[k]
+        cnt = snap["counts"][k]
         k_N = p.k_0 + cnt
         v_N = p.v_0 + cnt
-        m_N = self.m_N_numerators[k] / k_N
-        S_N = self.S_N_partials[k] - k_N * np.square(m_N)
+        m_N = snap["a"][k] / k_N
+        S_N = snap["b"][k] - k_N * np.square(m_N)
         return (-cnt * self.D / 2. * math.log(np.pi) + self.D / 2. * math.log(p.k_0) - self.D / 2. * math.log(k_N)
                 + p.v_0 / 2. * np.log(p.S_0).sum() - v_N / 2. * np.log(S_N).sum()
                 + self.D * (gammaln(v_N / 2.) - gammaln(p.v_0 / 2.)))

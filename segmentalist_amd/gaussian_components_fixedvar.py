@@ -65,10 +65,13 @@ class GaussianComponentsFixedVar(_DeviceGaussianComponents):
     def _logits_parts(self, i):
         return self.dev.pred_vector(i)
 
-    def log_marg_k(self, k):
+    def _snapshot(self):
+        return dict(assignments=self.assignments, K=self.K, counts=self.counts)
+
+    def _log_marg_k(self, k, snap, rows):
         """gaussian_components_fixedvar.py:261-283 (record metric, host)."""
-        X = self.X[np.where(self.assignments == k)]
-        N = self.counts[k]
+        X = self.X[rows]
+        N = snap["counts"][k]
         p, p0, m0 = self.precision, self.precision_0, self.mu_0
         return np.sum(
             (N - 1) / 2. * np.log(p) - 0.5 * N * math.log(2 * np.pi) - 0.5 * np.log(N / p0 + 1. / p)

@@ -63,6 +63,13 @@ def main():
             print("NB=%s score n=%8d  median %.3f ms  min %.3f ms  %.1f TFLOP/s (%.1f%% of 157.3)"
                   % (nb, n, med, mn, tf, 100 * tf / 157.3))
     del os.environ["SEGK_SCORE_NB"]
+    for dbg in (0, 2, 4, 8, 6, 12, 14):      # timing-only ablations: 2 no barrier, 4 no drain, 8 no staging
+        os.environ["SEGK_SCORE_DBG"] = str(dbg)
+        for n in (1048576, 131072):
+            med, mn = timeit(lambda: dk.score_rows(row0=0, n=n))
+            tf = 2.0 * n * args.K * args.dim / (med * 1e-3) / 1e12
+            print("dbg=%2d n=%8d  median %.3f ms  %.1f TFLOP/s (%.1f%%)" % (dbg, n, med, tf, 100 * tf / 157.3))
+    os.environ["SEGK_SCORE_DBG"] = "0"
     if args.score_only:
         return
 
