@@ -369,6 +369,39 @@ def gen_amgibbs():
     print("amgibbs.npz:", len(out), "arrays")
 
 
+# ----------------------------------------------------------------------------- edge cases of the drivers
+def gen_edge():
+    mods = dict(SegmentalKMeansWordseg=kmeans_acoustic_wordseg.SegmentalKMeansWordseg,
+                UnigramAcousticWordseg=unigram_acoustic_wordseg.UnigramAcousticWordseg,
+                BigramAcousticWordseg=bigram_acoustic_wordseg.BigramAcousticWordseg, FBGMM=fbgmm.FBGMM,
+                FixedVarPrior=gaussian_components_fixedvar.FixedVarPrior, NIW=niw.NIW)
+    out = {}
+    for case in cases.EDGE_CHAINS:
+        name, driver = case[0], case[1]
+        random.seed(1)
+        np.random.seed(1)
+        seg = cases.edge_build(mods, case)
+        c = seg.acoustic_model.components
+        out[name + "_init_bounds"] = seg.utterances.boundaries.copy()
+        out[name + "_init_assign"] = c.assignments.copy()
+        out[name + "_durations_nan"] = np.isnan(seg.utterances.durations)
+        bounds, assigns = [], []
+        recs = {}
+        for it in range(3):
+            rec = seg.segment(1) if driver == "kmeans" else seg.gibbs_sample(1)
+            for k, v in rec.items():
+                recs.setdefault(k, []).extend(v)
+            bounds.append(seg.utterances.boundaries.copy())
+            assigns.append(c.assignments.copy())
+        out[name + "_bounds"] = np.stack(bounds)
+        out[name + "_assign"] = np.stack(assigns)
+        for k in (["sum_neg_len_sqrd_norm", "components", "n_tokens"] if driver == "kmeans"
+                  else ["log_marg", "log_marg*length", "components", "n_tokens"]):
+            out[name + "_rec_" + k] = np.array(recs[k])
+    np.savez_compressed(os.path.join(HERE, "edge.npz"), **out)
+    print("edge.npz:", len(out), "arrays")
+
+
 # ----------------------------------------------------------------------------- notebook (config 1)
 def gen_notebook():
     """examples/clustering_examples.ipynb cells, with the python-2 shuffle."""
@@ -429,6 +462,7 @@ if __name__ == "__main__":
     gen_chains()
     gen_bigram()
     gen_amgibbs()
+    gen_edge()
     gen_notebook()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):

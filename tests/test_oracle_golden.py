@@ -491,3 +491,33 @@ def test_unigram_chain_with_am_iterations_matches_reference(golden, chain):
     assert np.array_equal(seg.acoustic_model.components.assignments, g[tag + "_assign"])
     npt.assert_allclose(rec["log_marg"], g[tag + "_rec_log_marg"], rtol=1e-10)
     assert list(rec["components"]) == list(g[tag + "_rec_components"])
+
+
+# ------------------------------------------------------------------ edge cases of the drivers
+def _edge_mods(ns):
+    return dict(SegmentalKMeansWordseg=ns.SegmentalKMeansWordseg, UnigramAcousticWordseg=ns.UnigramAcousticWordseg,
+                BigramAcousticWordseg=ns.BigramAcousticWordseg, FBGMM=ns.FBGMM, FixedVarPrior=ns.FixedVarPrior,
+                NIW=ns.NIW)
+
+
+@pytest.mark.parametrize("case", cases.EDGE_CHAINS, ids=[c[0] for c in cases.EDGE_CHAINS])
+def test_edge_case_chains_match_reference(golden, case):
+    """1- and 2-landmark utterances, NaN durations (min_duration), n_slices_min = 1, a single initial
+    span, snapped seed boundaries: trajectories of the reference itself."""
+    g = golden("edge")
+    name, driver = case[0], case[1]
+    random.seed(1)
+    np.random.seed(1)
+    no.set_shuffle("py3")
+    seg = cases.edge_build(_edge_mods(no), case)
+    c = seg.acoustic_model.components
+    assert np.array_equal(seg.utterances.boundaries, g[name + "_init_bounds"])
+    assert np.array_equal(c.assignments, g[name + "_init_assign"])
+    assert np.array_equal(np.isnan(seg.utterances.durations), g[name + "_durations_nan"])
+    for it in range(3):
+        rec = seg.segment(1) if driver == "kmeans" else seg.gibbs_sample(1)
+        assert np.array_equal(seg.utterances.boundaries, g[name + "_bounds"][it]), it
+        assert np.array_equal(c.assignments, g[name + "_assign"][it]), it
+        key = "sum_neg_len_sqrd_norm" if driver == "kmeans" else "log_marg"
+        npt.assert_allclose(rec[key][0], g[name + "_rec_" + key][it], rtol=1e-10)
+        assert rec["components"][0] == g[name + "_rec_components"][it]
