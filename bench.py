@@ -82,10 +82,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # RCCL over xGMI; SEGK_BENCH_BACKEND=gloo exists only to rehearse the N > 1 code path with
+        # several ranks sharing one GPU (RCCL refuses two ranks on one device)
+        backend = os.environ.get("SEGK_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     from segmentalist_amd import kmeans_acoustic_wordseg as kaw
     from segmentalist_amd.synth import make_corpus
@@ -123,10 +129,10 @@ def main():
     elapsed = time.perf_counter() - t0
     seg._dk.check_status()
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+        elapsed = float(t.item())
 
     score_ms, score_rows = None, rows_local
     if use_ev:
