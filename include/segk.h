@@ -398,6 +398,12 @@ typedef struct {
     int32_t *lm_tok;              /* [dev] [B, S, u_max, N_max] slots of every utterance's segments,
                                    * -1 padded (replicated on every rank); NULL without an LM     */
     uint64_t seed;                /* of the counter-based uniforms u01(seed, sweep, utt, j)       */
+    /* optional fp32 matrix-core span score of fixed-variance components (segk_fbb_score_f32):      */
+    float *y;                     /* [dev] [n_emb, ldy] rows [x_0^2, x_0, x_1^2, x_1, ...] (segk_fbb_make_y) */
+    int64_t ldy;                  /* 2D rounded up to a multiple of 4                             */
+    float *tiles32;               /* [dev] segk_kmeans_tiles_floats(K_max + 1, 2D) floats: operand
+                                   * image of the per-slot [-pp/2, pp*mu] rows, written by
+                                   * segk_fbb_prepare when non-NULL                               */
 } segk_fbatch;
 
 /* token lists of all utterances from the boundaries: new_tok [n_utt, N_max], n_new [n_utt]     */
@@ -420,6 +426,16 @@ int32_t segk_fbb_prepare(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *
 int32_t segk_fbb_score(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *f,
                        const segk_fbatch *bt, int32_t s_lo, int32_t s_n, int32_t b,
                        const int32_t *n_rows, double *score, void *stream);
+/* The same scores within the 1e-4 tolerance of the path, on the fp32 matrix cores (fixed-variance
+ * components only): the logit of slot k is a contraction of [x^2, x] with [-pp_k/2, pp_k*mu_k] plus
+ * a constant, all empty slots together are one more pseudo-component (the prior predictive, weight
+ * = their number); log-sum-exp accumulated online in the MFMA kernel's epilogue.  Needs bt->y
+ * (segk_fbb_make_y once) and bt->tiles32 (filled by segk_fbb_prepare).                            */
+int32_t segk_fbb_make_y(segk_ctx *ctx, const segk_corpus *c, const segk_fbatch *bt, void *stream);
+int32_t segk_fbb_score_f32(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *f,
+                           const segk_fbatch *bt, int32_t s_lo, int32_t s_n, int32_t b,
+                           const int32_t *row_lo, const int32_t *n_rows, double *score,
+                           void *stream);   /* row_lo, n_rows [host] [s_n]: rows of (s_lo + i, b) */
 /* get_vec_embed_log_probs + forward_backward (unigram...:474-511, 653-756) for every utterance of
  * block b of the local slices with the uniforms u01(seed, sweep, utt, 0, 1, ...); the slots of the
  * old segments are cleared.  n_utts [host] [s_n].  status bit 16: log_prob == -inf.            */

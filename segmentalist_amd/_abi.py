@@ -42,7 +42,7 @@ class FbatchDev(C.Structure):
         ("utt_range", C.c_void_p), ("row_range", C.c_void_p), ("partials", C.c_void_p), ("cnt", C.c_void_p),
         ("mean_t", C.c_void_p), ("q_t", C.c_void_p), ("lconst", C.c_void_p), ("zconst", C.c_void_p),
         ("half", C.c_void_p), ("scal", C.c_void_p), ("slot", C.c_void_p), ("lm_tok", C.c_void_p),
-        ("seed", C.c_uint64),
+        ("seed", C.c_uint64), ("y", C.c_void_p), ("ldy", C.c_int64), ("tiles32", C.c_void_p),
     ]
 
 
@@ -112,6 +112,8 @@ SIGNATURES = {
     "segk_fbb_partials": (_i32, [_P, _CP, _FP, _BP, _i32, _i32, _i32, _P, _P, _P]),
     "segk_fbb_prepare": (_i32, [_P, _CP, _FP, _BP, _i32, _P]),
     "segk_fbb_score": (_i32, [_P, _CP, _FP, _BP, _i32, _i32, _i32, _P, _P, _P]),
+    "segk_fbb_make_y": (_i32, [_P, _CP, _BP, _P]),
+    "segk_fbb_score_f32": (_i32, [_P, _CP, _FP, _BP, _i32, _i32, _i32, _P, _P, _P, _P]),
     "segk_fbb_segment": (_i32, [_P, _CP, _FP, _BP, _i32, _i32, _i32, _P, _u64, _i32, _i32, _f64, _f64, _f64, _P, _P,
                                 _P, _P, _P, _P, _P]),
     "segk_fbb_assign": (_i32, [_P, _CP, _FP, _BP, _i32, _i32, _i32, _P, _u64, _f64, _P, _P, _P]),

@@ -45,13 +45,14 @@ class BigramAcousticWordseg(object):
                  landmarks_dict, seed_boundaries_dict=None, seed_assignments_dict=None, covariance_type="fixed",
                  n_slices_min=0, n_slices_max=20, min_duration=0, p_boundary_init=0.5, beta_sent_boundary=2.0,
                  lms=1., wip=0., fb_type="bigram", init_am_assignments="rand", time_power_term=1.,
-                 sync="sequential", n_gibbs_blocks=8, n_stat_blocks=8, batch_seed=0, process_group=None):
+                 sync="sequential", n_gibbs_blocks=8, n_stat_blocks=8, batch_seed=0, process_group=None,
+                 score_precision="f64"):
         """Same arguments as the reference (bigram_acoustic_wordseg.py:129-136) plus the execution
         mode of UnigramAcousticWordseg (sync="batch": oracle/np_fbgmm_batch.py)."""
         logger.info("Initializing")
         assert sync in ("sequential", "batch")
         self.sync = sync
-        self._batch_args = (n_gibbs_blocks, n_stat_blocks, batch_seed, process_group)
+        self._batch_args = (n_gibbs_blocks, n_stat_blocks, batch_seed, process_group, score_precision)
         self._sweeper = None
         assert seed_assignments_dict is None or seed_boundaries_dict is not None
         self.n_slices_min = n_slices_min

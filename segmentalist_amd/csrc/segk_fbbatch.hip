@@ -550,6 +550,88 @@ __global__ void k_fbb_apply_remap(segk_fbgmm f, segk_fbatch bt, int64_t n_emb, c
     f.assignments[e] = sl >= 0 ? remap[sl] : -1;
 }
 
+// ---------------------------------------------------------------------------------------
+// fp32 matrix-core span score of fixed-variance components (the MFMA kernel of segk_kmeans.hip in
+// log-sum-exp mode): operands.
+//   Y[row] = [x_0^2, x_0, x_1^2, x_1, ...]                                    (once per corpus)
+//   tile row of slot k (count > 0):  [-pp_kd/2, pp_kd*mu_kd]_d * log2(e),
+//       constant (zconst_k - sum_d pp_kd mu_kd^2 / 2) * log2(e)
+//   pseudo-component K_max = all empty slots: [-p0_d/2, p0_d*mu0_d]_d * log2(e), constant
+//       (lms*log(alpha/K_max) + log(#empty) + kconst[K_max] - sum_d p0_d mu0_d^2 / 2) * log2(e)
+//   so that acc_k = z_k * log2(e) and sum_k 2^acc_k = sum over ALL K_max slots of exp(z).
+// Tile image layout: segk_internal.h (32 slots per tile, dims 4g + 2(lane>>5) + {0,1}).
+// ---------------------------------------------------------------------------------------
+template <typename XT>
+__global__ void k_fbb_make_y(segk_corpus c, float *y, int64_t ldy)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= c.n_emb * ldy) return;
+    const int64_t row = idx / ldy;
+    const int j = (int)(idx - row * ldy), d = j >> 1;
+    float v = 0.f;
+    if (d < c.D) {
+        const float x = (float)((const XT *)c.X)[row * c.ldx + d];
+        v = (j & 1) ? x : x * x;
+    }
+    y[idx] = v;
+}
+
+__global__ void k_fbb_tiles32(segk_fbgmm f, segk_fbatch bt, int D, double prior_alpha)
+{
+    const double LOG2E = 1.4426950408889634;
+    const int tile = blockIdx.x, KM = f.K_max, D2 = 2 * D;
+    const int G = segk_gmax(D2), stride = segk_tile_stride(D2);
+    float *T = bt.tiles32 + (int64_t)tile * stride;
+    __shared__ double cst[32];
+    {
+        const int ci = threadIdx.x >> 3, sub = threadIdx.x & 7;      // 256 threads = 32 slots x 8 lanes
+        const int k = tile * 32 + ci;
+        double s = 0.0;
+        if (k < KM && bt.cnt[k] > 0.0)
+            for (int d = sub; d < D; d += 8) {
+                const double m = bt.mean_t[(int64_t)d * KM + k];
+                s += bt.q_t[(int64_t)d * KM + k] * m * m;
+            }
+        else if (k == KM)
+            for (int d = sub; d < D; d += 8) s += f.prior_c[d] * f.prior_b[d] * f.prior_b[d];
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        s += __shfl_xor(s, 4);
+        if (sub == 0) {
+            // the normaliser of log_marg_i, lms*log(total + alpha) (fbgmm.py:268-272), is folded into the constants
+            const double norm = f.lms * log(bt.scal[0] + prior_alpha);
+            double v = -3.0e38;
+            if (k < KM && bt.cnt[k] > 0.0) v = (bt.zconst[k] - 0.5 * s - norm) * LOG2E;
+            else if (k == KM) {
+                const double n_empty = (double)KM - bt.scal[1];
+                if (n_empty > 0.0)
+                    v = (f.lms * log(prior_alpha / (double)KM) + log(n_empty) + f.kconst[KM] - 0.5 * s - norm) * LOG2E;
+            }
+            cst[ci] = v;
+        }
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < stride; idx += blockDim.x) {
+        float v = 0.f;
+        if (idx < G * 128) {
+            const int g = idx >> 7, rem = idx & 127, lane = rem >> 1, sel = rem & 1;
+            const int k = tile * 32 + (lane & 31);
+            const int j = 4 * g + 2 * (lane >> 5) + sel, d = j >> 1;
+            if (d < D) {
+                if (k < KM && bt.cnt[k] > 0.0) {
+                    const double q = bt.q_t[(int64_t)d * KM + k];
+                    v = (float)(((j & 1) ? q * bt.mean_t[(int64_t)d * KM + k] : -0.5 * q) * LOG2E);
+                } else if (k == KM) {
+                    v = (float)(((j & 1) ? f.prior_c[d] * f.prior_b[d] : -0.5 * f.prior_c[d]) * LOG2E);
+                }
+            }
+        } else if (idx < G * 128 + 32) {
+            v = (float)cst[idx - G * 128];
+        }
+        T[idx] = v;
+    }
+}
+
 // ======================================================================================
 // C ABI
 // ======================================================================================
@@ -628,7 +710,40 @@ int32_t segk_fbb_prepare(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *
     SEGK_CHECK_HIP(hipMemsetAsync(bt->scal, 0, 2 * sizeof(double), st));
     const double alpha = f->lm_unigram ? f->lm_a : f->alpha;
     hipLaunchKernelGGL(k_fbb_prepare, dim3((f->K_max + 3) / 4), dim3(256), 0, st, *f, *bt, c->D, b, alpha);
+    if (bt->tiles32 && f->cov_type == 0)
+        hipLaunchKernelGGL(k_fbb_tiles32, dim3(segk_n_tiles(f->K_max + 1)), dim3(256), 0, st, *f, *bt, c->D, alpha);
     SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+int32_t segk_fbb_make_y(segk_ctx *ctx, const segk_corpus *c, const segk_fbatch *bt, void *stream)
+{
+    (void)ctx;
+    SEGK_REQUIRE(c && bt && bt->y && bt->ldy >= 2 * c->D && (bt->ldy & 3) == 0, "y buffer / ldy");
+    const int64_t tot = c->n_emb * bt->ldy;
+    DISPATCH_XT(c, hipLaunchKernelGGL(k_fbb_make_y<XT>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                                       *c, bt->y, bt->ldy););
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+int32_t segk_fbb_score_f32(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *f, const segk_fbatch *bt, int32_t s_lo,
+                           int32_t s_n, int32_t b, const int32_t *row_lo, const int32_t *n_rows, double *score,
+                           void *stream)
+{
+    (void)ctx;
+    int rc = check_fbb(c, f, bt);
+    if (rc) return rc;
+    SEGK_REQUIRE(f->cov_type == 0, "the matrix-core score exists for fixed-variance components only");
+    SEGK_REQUIRE(bt->y && bt->tiles32, "y / tiles32 buffers missing");
+    SEGK_REQUIRE(s_lo >= 0 && s_n >= 1 && s_lo + s_n <= bt->n_slices && b >= 0 && b < bt->n_blocks, "slice / block range");
+    SEGK_REQUIRE(row_lo && n_rows, "row ranges");
+    for (int s = 0; s < s_n; s++) {
+        SEGK_REQUIRE(n_rows[s] >= 0 && row_lo[s] >= 0 && (int64_t)row_lo[s] + n_rows[s] <= c->n_emb, "row range");
+        rc = segk_launch_score_lse(bt->y, bt->ldy, 2 * c->D, row_lo[s], n_rows[s], bt->tiles32,
+                                   segk_n_tiles(f->K_max + 1), 0.0, score, stream);
+        if (rc) return rc;
+    }
     return SEGK_OK;
 }
 

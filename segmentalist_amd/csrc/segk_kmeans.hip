@@ -278,15 +278,24 @@ struct ScoreArgs {
     int n_chunks, tiles_per_split;
     int32_t *part_k;
     float *part_f;
+    // MODE = 1 (log-sum-exp over the components instead of the top-2): out[row] = ln2 * log2 sum_k 2^acc - lse_norm
+    double *lse_out;
+    double lse_norm;
 };
 
 // SPLIT = 0: the whole component range per workgroup, winner + margin test + fused exact score.
 // SPLIT = 1: the tail of a launch whose last round would leave most of the chip idle (or a launch
 //            smaller than one round): every 32*NB*WAVES-row chunk is scored by several workgroups,
 //            each against a slice of the component tiles; k_score_merge combines the partial top-2.
-template <int GMAX, int NB, int WAVES, int SPLIT>
+// MODE = 0: running top-2 / argmax (the k-means filter).
+// MODE = 1: online log-sum-exp of the accumulator values, base 2 (the operands are pre-scaled by
+//           log2 e): the span score of the fixed-variance FBGMM batch sampler, whose logit is a
+//           contraction of [x^2, x] with per-component [-pp/2, pp*mu] plus a constant
+//           (segk_fbbatch.hip k_fbb_tiles32); within the 1e-4 contract of that path.
+template <int GMAX, int NB, int WAVES, int SPLIT, int MODE = 0>
 __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 2) void k_kmeans_score(ScoreArgs A)
 {
+    static_assert(!(MODE == 1 && SPLIT == 1), "the log-sum-exp mode has no split-K variant");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const float *__restrict__ X32 = A.X32;
     const int64_t ld32 = A.ld32;
@@ -326,7 +335,13 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 2) void k_kmeans_score
     float m1[NB], m2[NB];
     int32_t irow[NB], itile[NB];
 #pragma unroll
-    for (int nb = 0; nb < NB; nb++) { m1[nb] = NEG_INF_F; m2[nb] = NEG_INF_F; irow[nb] = 0; itile[nb] = 0; }
+    for (int nb = 0; nb < NB; nb++) {
+        // MODE 1 reuses m1 / m2 as the running maximum (finite start: -inf - -inf would be NaN) and sum
+        m1[nb] = MODE == 1 ? -3.0e38f : NEG_INF_F;
+        m2[nb] = MODE == 1 ? 0.f : NEG_INF_F;
+        irow[nb] = 0;
+        itile[nb] = 0;
+    }
 
     constexpr int STRIDE = (GMAX * 128 + 32 + 1023) / 1024 * 1024;   // == tile_stride (segk_tile_stride)
     constexpr int PASS = WAVES * 256;                                 // floats moved per pass by the workgroup
@@ -367,6 +382,13 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 2) void k_kmeans_score
 #define SEGK_DRAIN(ACC, vi)                                                           \
     do {                                                                              \
         const int nb_ = (vi) >> 4;                                                    \
+        if constexpr (MODE == 1) {                                                    \
+            /* nm = max(mx, v); sm = sm * 2^(mx - nm) + 2^(v - nm); mx = nm */         \
+            const float v_ = ACC[nb_][(vi) & 15];                                     \
+            const float nm_ = vmax_f32(m1[nb_], v_);                                  \
+            m2[nb_] = m2[nb_] * __builtin_amdgcn_exp2f(m1[nb_] - nm_) + __builtin_amdgcn_exp2f(v_ - nm_); \
+            m1[nb_] = nm_;                                                            \
+        } else                                                                        \
         asm volatile("v_cmp_ngt_f32 vcc, %3, %0\n\t"                                  \
                      "v_med3_f32 %1, %0, %1, %3\n\t"                                  \
                      "v_max_f32 %0, %0, %3\n\t"                                       \
@@ -453,6 +475,15 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 2) void k_kmeans_score
     const int rem = D & 7;             // sequential tail
 #pragma unroll
     for (int nb = 0; nb < NB; nb++) {
+        if constexpr (MODE == 1) {
+            // the two lane halves summed disjoint component subsets of the same row
+            const float om = __shfl_xor(m1[nb], 32), os = __shfl_xor(m2[nb], 32);
+            const float M = fmaxf(m1[nb], om);
+            const float S = m2[nb] * exp2f(m1[nb] - M) + os * exp2f(om - M);
+            if (h == 0 && rowid[nb] >= 0)
+                A.lse_out[rowid[nb]] = (double)(M + log2f(S)) * 0.6931471805599453 - A.lse_norm;
+            continue;
+        }
         float o1 = __shfl_xor(m1[nb], 32), o2 = __shfl_xor(m2[nb], 32);
         int oi = __shfl_xor(i1[nb], 32);
         float top1 = fmaxf(m1[nb], o1);
@@ -1828,6 +1859,48 @@ static int launch_score(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *
     }
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;
+}
+
+template <int GMAX>
+static int launch_score_lse(const ScoreArgs &A, hipStream_t st)
+{
+    const size_t lds = 2 * (size_t)A.tile_stride * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set && lds > 48 * 1024) {
+        SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_kmeans_score<GMAX, 1, 4, 0, 1>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    const int64_t chunks = (A.n + 127) / 128;
+    hipLaunchKernelGGL((k_kmeans_score<GMAX, 1, 4, 0, 1>), dim3((unsigned)chunks), dim3(256), lds, st, A);
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+// out[row0 + r] = ln sum_k exp(z_k) - norm for r < n, where z_k * log2(e) = tile constant of component k +
+// <Y[row], tile row k> with Y [n_emb, ldy] float32 rows of D2 dimensions (segk_fbbatch.hip).  Internal, not ABI.
+int segk_launch_score_lse(const float *Y, int64_t ldy, int D2, int64_t row0, int64_t n, const float *tiles,
+                          int n_tiles, double norm, double *out, void *stream)
+{
+    if (n <= 0) return SEGK_OK;
+    ScoreArgs A;
+    memset(&A, 0, sizeof(A));
+    A.X32 = Y; A.ld32 = ldy; A.ids = nullptr; A.row0 = row0; A.n = n;
+    A.tiles = tiles; A.n_tiles = n_tiles; A.tile_stride = segk_tile_stride(D2);
+    A.G = segk_G(D2); A.D = D2;
+    A.lse_out = out; A.lse_norm = norm;
+    hipStream_t st = (hipStream_t)stream;
+    switch (segk_gmax(D2)) {
+#define SEGK_CASE(g) \
+    case g: return launch_score_lse<g>(A, st);
+        SEGK_CASE(1) SEGK_CASE(2) SEGK_CASE(4) SEGK_CASE(6) SEGK_CASE(8) SEGK_CASE(10) SEGK_CASE(13) SEGK_CASE(16)
+        SEGK_CASE(20) SEGK_CASE(25) SEGK_CASE(26) SEGK_CASE(28) SEGK_CASE(32) SEGK_CASE(33) SEGK_CASE(34) SEGK_CASE(40)
+        SEGK_CASE(50) SEGK_CASE(64) SEGK_CASE(75) SEGK_CASE(100)
+#undef SEGK_CASE
+        default: break;
+    }
+    segk_set_error("segk_launch_score_lse: 2D=%d > 400 is not supported by the register-resident score kernel", D2);
+    return SEGK_ERR_UNSUPPORTED;
 }
 
 extern "C" {

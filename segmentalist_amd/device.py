@@ -535,10 +535,14 @@ class FbgmmBatchSweeper(object):
     second one of the block's transcripts).  All partial sums are replicated, so every rank derives
     the same statistics in the same fixed order: results do not depend on the number of ranks."""
 
-    def __init__(self, df, row_start, n_gibbs_blocks=8, n_stat_blocks=8, seed=0, group=None):
+    def __init__(self, df, row_start, n_gibbs_blocks=8, n_stat_blocks=8, seed=0, group=None, score_precision="f64"):
         torch = _torch()
         dev = _dev()
         self.df, self.group = df, group
+        assert score_precision in ("f64", "f32")
+        if score_precision == "f32" and df.cov_type != 0:
+            raise SegkError("score_precision='f32' (matrix-core span score) exists for fixed-variance components only")
+        self.score_f32 = score_precision == "f32"
         c = df.corpus
         self.S, self.B = int(n_stat_blocks), int(n_gibbs_blocks)
         rank, world = 0, 1
@@ -589,7 +593,15 @@ class FbgmmBatchSweeper(object):
             self.lm_tok = torch.full((self.B, self.S, self.u_max, c.N_max), -1, dtype=torch.int32, device=dev)
             self.lm_big = torch.zeros((K, K), dtype=torch.int64, device=dev)
             self.f.lm_bigram = self.lm_big.data_ptr()
+        self.y = self.tiles32 = None
+        ldy = (2 * D + 3) // 4 * 4
+        if self.score_f32:
+            self.y = torch.zeros((c.n_emb, ldy), dtype=torch.float32, device=dev)
+            self.tiles32 = torch.zeros(int(_abi.lib().segk_kmeans_tiles_floats(K + 1, 2 * D)), dtype=torch.float32,
+                                       device=dev)
         self.bt = _abi.FbatchDev(
+            y=self.y.data_ptr() if self.y is not None else None, ldy=ldy,
+            tiles32=self.tiles32.data_ptr() if self.tiles32 is not None else None,
             n_slices=self.S, n_blocks=self.B, u_max=self.u_max if df.lm is not None else 0, pad_=0,
             utt_range=self.utt_range.data_ptr(), row_range=self.row_range.data_ptr(),
             partials=self.partials.data_ptr(), cnt=self.cnt.data_ptr(), mean_t=self.mean_t.data_ptr(),
@@ -602,6 +614,9 @@ class FbgmmBatchSweeper(object):
                         for b in range(self.B)]
         self._n_utts = [I32(*[int(ur[self.s_lo + i, b, 1] - ur[self.s_lo + i, b, 0]) for i in range(self.s_n)])
                         for b in range(self.B)]
+        self._row_lo = [I32(*[int(rr[self.s_lo + i, b, 0]) for i in range(self.s_n)]) for b in range(self.B)]
+        if self.score_f32:
+            check(df._L.segk_fbb_make_y(df._ctx, df._cp(), C.byref(self.bt), _abi.stream()))
         self.in_batch_state = False
         self.sweep_index = 0
 
@@ -648,7 +663,11 @@ class FbgmmBatchSweeper(object):
             if self.lm_tok is not None:
                 check(L.segk_fbb_lm_apply(ctx, cp, fp, bp, b, -1, st))
             check(L.segk_fbb_prepare(ctx, cp, fp, bp, b, st))
-            check(L.segk_fbb_score(ctx, cp, fp, bp, self.s_lo, self.s_n, b, self._n_rows[b], ptr(df.score), st))
+            if self.score_f32:
+                check(L.segk_fbb_score_f32(ctx, cp, fp, bp, self.s_lo, self.s_n, b, self._row_lo[b], self._n_rows[b],
+                                           ptr(df.score), st))
+            else:
+                check(L.segk_fbb_score(ctx, cp, fp, bp, self.s_lo, self.s_n, b, self._n_rows[b], ptr(df.score), st))
             check(L.segk_fbb_segment(ctx, cp, fp, bp, self.s_lo, self.s_n, b, self._n_utts[b], sw, int(n_slices_min),
                                      int(n_slices_max), float(wip), float(time_power_term), float(anneal_temp_fb),
                                      ptr(df.score), ptr(boundaries), ptr(df.new_tok), ptr(df.n_new),

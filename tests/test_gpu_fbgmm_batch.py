@@ -25,7 +25,7 @@ def gpu():
     return torch
 
 
-def _pair(kind, n_utt, D, K, cseed, nmax, B, S, seed=5, dtype="float32", **kw):
+def _pair(kind, n_utt, D, K, cseed, nmax, B, S, seed=5, dtype="float32", score_precision="f64", **kw):
     """(oracle segmenter + batch state, product segmenter) from identical initial states."""
     from segmentalist_amd import bigram_acoustic_wordseg as baw, fbgmm, unigram_acoustic_wordseg as uaw
     from segmentalist_amd.gaussian_components_fixedvar import FixedVarPrior
@@ -34,7 +34,7 @@ def _pair(kind, n_utt, D, K, cseed, nmax, B, S, seed=5, dtype="float32", **kw):
     args = dict(n_slices_min=0, n_slices_max=nmax, p_boundary_init=0.5, beta_sent_boundary=-1, lms=1.0, wip=0.0,
                 init_am_assignments="rand", time_power_term=1.0)
     args.update(kw)
-    bargs = dict(sync="batch", n_gibbs_blocks=B, n_stat_blocks=S, batch_seed=11)
+    bargs = dict(sync="batch", n_gibbs_blocks=B, n_stat_blocks=S, batch_seed=11, score_precision=score_precision)
     out = []
     for side in ("oracle", "product"):
         random.seed(seed)
@@ -162,3 +162,53 @@ def test_sequential_after_batch_continues_from_the_materialised_state(gpu):
     assert np.array_equal(seg.utterances.boundaries, ref.utterances.boundaries)
     assert np.array_equal(seg.acoustic_model.components.assignments, ref.acoustic_model.components.assignments)
     assert rec["components"][0] == ref.acoustic_model.components.K
+
+
+@pytest.mark.parametrize("kind,n_utt,D,K,nmax", [("fixed", 40, 12, 30, 6), ("bigram", 30, 100, 64, 5), ("fixed", 25, 39, 100, 6)])
+def test_matrix_core_span_scores_within_tolerance(gpu, kind, n_utt, D, K, nmax):
+    """score_precision="f32": the MFMA log-sum-exp kernel against the specification's log_marg_i on the
+    same state -- 1e-4 relative is the contract of the path (BASELINE north_star); measured ~1e-6."""
+    from segmentalist_amd._abi import check, ptr
+    ref, spec, seg = _pair(kind, n_utt, D, K, 123, nmax, 3, 2, score_precision="f32")
+    sw = seg._get_sweeper()
+    assert sw.score_f32
+    sw.enter(seg._dev_bounds)
+    L, ctx, cp, fp, bp, st = sw._args()
+    worst = worst_abs = 0.0
+    mags = []
+    for b in range(sw.B):
+        check(L.segk_fbb_prepare(ctx, cp, fp, bp, b, st))
+        check(L.segk_fbb_score_f32(ctx, cp, fp, bp, sw.s_lo, sw.s_n, b, sw._row_lo[b], sw._n_rows[b], ptr(seg._df.score), st))
+        d = spec.derive(*spec.stats_excluding(b))
+        # with a language model the unigram counts of "all other blocks" are the slot counts
+        uni, big = (d["cnt"], spec.big) if kind == "bigram" else (None, None)
+        score = seg._df.score.cpu().numpy()
+        for s in range(sw.S):
+            lo, hi = sw.row_range_np[s, b]
+            for row in range(lo, hi):
+                want = spec.log_marg(d, spec.X[row], uni, big)
+                mags.append(abs(want))
+                worst_abs = max(worst_abs, abs(score[row] - want))
+                worst = max(worst, abs(score[row] - want) / max(abs(want), 10.0))
+    print("f32 span score: worst abs err %.3g, worst rel err (floor 10) %.3g, median |log_marg| %.3g"
+          % (worst_abs, worst, float(np.median(mags))))
+    # 1e-4 relative is the contract of the path; spans whose log-marginal happens to be near zero are
+    # held to the same absolute error as a span of magnitude 10 (the probabilities they enter change by
+    # a factor exp(1e-3) at most)
+    assert worst < 1e-4, (worst, worst_abs)
+
+
+def test_matrix_core_mode_samples_a_valid_chain(gpu):
+    """Full sweeps in f32 score mode: same invariants as the exact mode, and the chain stays close to the
+    f64 chain in distribution (equal boundaries for the vast majority of utterances after one sweep)."""
+    ref, spec, seg = _pair("fixed", 60, 16, 24, 321, 6, 3, 4, score_precision="f32")
+    lp = spec.sweep(0)
+    seg.batch_sweep_async()
+    gpu.cuda.synchronize()
+    seg._df.check_status()
+    same = np.mean(np.all(seg.utterances.boundaries == ref.utterances.boundaries, axis=1))
+    assert same > 0.9, same
+    npt.assert_allclose(float(seg._df.out_logprob.sum().item()), lp.sum(), rtol=5e-2)
+    seg.materialise()
+    c = seg.acoustic_model.components
+    assert c.counts[:c.K].sum() == seg.acoustic_model.get_n_assigned()

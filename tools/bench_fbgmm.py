@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--which", default="diag,fixed,bigram")
     ap.add_argument("--sync", default="sequential")
     ap.add_argument("--blocks", type=int, default=8)
+    ap.add_argument("--precision", default="f64")
     args = ap.parse_args()
     import torch
     from segmentalist_amd import bigram_acoustic_wordseg as baw, fbgmm, unigram_acoustic_wordseg as uaw
@@ -40,6 +41,7 @@ def main():
     okw = dict(kw)
     if args.sync == "batch":
         kw.update(sync="batch", n_gibbs_blocks=args.blocks)
+    pk = dict(score_precision=args.precision) if args.sync == "batch" else {}
     lm = {"type": "smooth", "intrp_lambda": 0.1, "a": 0.5, "b": 0.5}
     for which in args.which.split(","):
         random.seed(0)
@@ -50,10 +52,10 @@ def main():
                                              fb_type="standard", **kw)
         elif which == "fixed":
             seg = uaw.UnigramAcousticWordseg(fbgmm.FBGMM, 1.0, K, FixedVarPrior(*fixed), *corpus,
-                                             covariance_type="fixed", fb_type="standard", **kw)
+                                             covariance_type="fixed", fb_type="standard", **kw, **pk)
         else:
             seg = baw.BigramAcousticWordseg(K, FixedVarPrior(*fixed), lm, *corpus, covariance_type="fixed",
-                                            fb_type="unigram", **kw)
+                                            fb_type="unigram", **kw, **pk)
         torch.cuda.synchronize()
         t_init = time.perf_counter() - t0
         if args.sync == "batch":
