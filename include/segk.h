@@ -433,9 +433,8 @@ int32_t segk_fbb_score(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *f,
  * (segk_fbb_make_y once) and bt->tiles32 (filled by segk_fbb_prepare).                            */
 int32_t segk_fbb_make_y(segk_ctx *ctx, const segk_corpus *c, const segk_fbatch *bt, void *stream);
 int32_t segk_fbb_score_f32(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *f,
-                           const segk_fbatch *bt, int32_t s_lo, int32_t s_n, int32_t b,
-                           const int32_t *row_lo, const int32_t *n_rows, double *score,
-                           void *stream);   /* row_lo, n_rows [host] [s_n]: rows of (s_lo + i, b) */
+                           const segk_fbatch *bt, const int32_t *rows, int64_t n, double *score,
+                           void *stream);   /* rows [dev] [n]: the embedding rows to score (a block) */
 /* get_vec_embed_log_probs + forward_backward (unigram...:474-511, 653-756) for every utterance of
  * block b of the local slices with the uniforms u01(seed, sweep, utt, 0, 1, ...); the slots of the
  * old segments are cleared.  n_utts [host] [s_n].  status bit 16: log_prob == -inf.            */

@@ -727,24 +727,17 @@ int32_t segk_fbb_make_y(segk_ctx *ctx, const segk_corpus *c, const segk_fbatch *
     return SEGK_OK;
 }
 
-int32_t segk_fbb_score_f32(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *f, const segk_fbatch *bt, int32_t s_lo,
-                           int32_t s_n, int32_t b, const int32_t *row_lo, const int32_t *n_rows, double *score,
-                           void *stream)
+int32_t segk_fbb_score_f32(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *f, const segk_fbatch *bt,
+                           const int32_t *rows, int64_t n, double *score, void *stream)
 {
     (void)ctx;
     int rc = check_fbb(c, f, bt);
     if (rc) return rc;
     SEGK_REQUIRE(f->cov_type == 0, "the matrix-core score exists for fixed-variance components only");
     SEGK_REQUIRE(bt->y && bt->tiles32, "y / tiles32 buffers missing");
-    SEGK_REQUIRE(s_lo >= 0 && s_n >= 1 && s_lo + s_n <= bt->n_slices && b >= 0 && b < bt->n_blocks, "slice / block range");
-    SEGK_REQUIRE(row_lo && n_rows, "row ranges");
-    for (int s = 0; s < s_n; s++) {
-        SEGK_REQUIRE(n_rows[s] >= 0 && row_lo[s] >= 0 && (int64_t)row_lo[s] + n_rows[s] <= c->n_emb, "row range");
-        rc = segk_launch_score_lse(bt->y, bt->ldy, 2 * c->D, row_lo[s], n_rows[s], bt->tiles32,
-                                   segk_n_tiles(f->K_max + 1), 0.0, score, stream);
-        if (rc) return rc;
-    }
-    return SEGK_OK;
+    SEGK_REQUIRE(rows != NULL && n >= 0, "row list");
+    return segk_launch_score_lse(bt->y, bt->ldy, 2 * c->D, rows, 0, n, bt->tiles32, segk_n_tiles(f->K_max + 1), 0.0, score,
+                                 stream);
 }
 
 int32_t segk_fbb_score(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *f, const segk_fbatch *bt, int32_t s_lo,

@@ -1877,15 +1877,15 @@ static int launch_score_lse(const ScoreArgs &A, hipStream_t st)
     return SEGK_OK;
 }
 
-// out[row0 + r] = ln sum_k exp(z_k) - norm for r < n, where z_k * log2(e) = tile constant of component k +
+// out[row] = ln sum_k exp(z_k) - norm for the rows ids[r] (ids == NULL: row0 + r), r < n, where z_k * log2(e) = tile constant of component k +
 // <Y[row], tile row k> with Y [n_emb, ldy] float32 rows of D2 dimensions (segk_fbbatch.hip).  Internal, not ABI.
-int segk_launch_score_lse(const float *Y, int64_t ldy, int D2, int64_t row0, int64_t n, const float *tiles,
-                          int n_tiles, double norm, double *out, void *stream)
+int segk_launch_score_lse(const float *Y, int64_t ldy, int D2, const int32_t *ids, int64_t row0, int64_t n,
+                          const float *tiles, int n_tiles, double norm, double *out, void *stream)
 {
     if (n <= 0) return SEGK_OK;
     ScoreArgs A;
     memset(&A, 0, sizeof(A));
-    A.X32 = Y; A.ld32 = ldy; A.ids = nullptr; A.row0 = row0; A.n = n;
+    A.X32 = Y; A.ld32 = ldy; A.ids = ids; A.row0 = row0; A.n = n;
     A.tiles = tiles; A.n_tiles = n_tiles; A.tile_stride = segk_tile_stride(D2);
     A.G = segk_G(D2); A.D = D2;
     A.lse_out = out; A.lse_norm = norm;

@@ -614,8 +614,11 @@ class FbgmmBatchSweeper(object):
                         for b in range(self.B)]
         self._n_utts = [I32(*[int(ur[self.s_lo + i, b, 1] - ur[self.s_lo + i, b, 0]) for i in range(self.s_n)])
                         for b in range(self.B)]
-        self._row_lo = [I32(*[int(rr[self.s_lo + i, b, 0]) for i in range(self.s_n)]) for b in range(self.B)]
         if self.score_f32:
+            # the rows of block b over the local slices, one launch per step
+            self._block_rows = [to_dev(np.concatenate([np.arange(rr[self.s_lo + i, b, 0], rr[self.s_lo + i, b, 1])
+                                                       for i in range(self.s_n)]).astype(np.int32))
+                                for b in range(self.B)]
             check(df._L.segk_fbb_make_y(df._ctx, df._cp(), C.byref(self.bt), _abi.stream()))
         self.in_batch_state = False
         self.sweep_index = 0
@@ -664,7 +667,7 @@ class FbgmmBatchSweeper(object):
                 check(L.segk_fbb_lm_apply(ctx, cp, fp, bp, b, -1, st))
             check(L.segk_fbb_prepare(ctx, cp, fp, bp, b, st))
             if self.score_f32:
-                check(L.segk_fbb_score_f32(ctx, cp, fp, bp, self.s_lo, self.s_n, b, self._row_lo[b], self._n_rows[b],
+                check(L.segk_fbb_score_f32(ctx, cp, fp, bp, ptr(self._block_rows[b]), self._block_rows[b].numel(),
                                            ptr(df.score), st))
             else:
                 check(L.segk_fbb_score(ctx, cp, fp, bp, self.s_lo, self.s_n, b, self._n_rows[b], ptr(df.score), st))

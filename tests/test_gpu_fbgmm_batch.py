@@ -178,7 +178,7 @@ def test_matrix_core_span_scores_within_tolerance(gpu, kind, n_utt, D, K, nmax):
     mags = []
     for b in range(sw.B):
         check(L.segk_fbb_prepare(ctx, cp, fp, bp, b, st))
-        check(L.segk_fbb_score_f32(ctx, cp, fp, bp, sw.s_lo, sw.s_n, b, sw._row_lo[b], sw._n_rows[b], ptr(seg._df.score), st))
+        check(L.segk_fbb_score_f32(ctx, cp, fp, bp, ptr(sw._block_rows[b]), sw._block_rows[b].numel(), ptr(seg._df.score), st))
         d = spec.derive(*spec.stats_excluding(b))
         # with a language model the unigram counts of "all other blocks" are the slot counts
         uni, big = (d["cnt"], spec.big) if kind == "bigram" else (None, None)
