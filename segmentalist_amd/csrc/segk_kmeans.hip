@@ -1024,16 +1024,42 @@ __device__ void dev_del_component(const segk_corpus &c, segk_kmeans &m, int k, i
 template <typename XT>
 __device__ void dev_clean_components(const segk_corpus &c, segk_kmeans &m, int *shK, int *sh_i)
 {
+    // kmeans_components.py:263-266: every empty component, highest index first.  The empties are
+    // found with one parallel pass (a deletion moves the last ACTIVE row down, it never creates or
+    // hides an empty row below the current one), then deleted one by one in the reference's order.
+    __shared__ unsigned int empty_bits[1024];         // K_max <= 32768
+    const int tid = threadIdx.x, nt = blockDim.x;
     const int K0 = *shK;
-    for (int k = K0 - 1; k >= 0; k--) {
-        if (threadIdx.x == 0) *sh_i = (m.counts[k] == 0) ? 1 : 0;
-        __syncthreads();
-        const int empty = *sh_i;
-        __syncthreads();
-        if (empty) {
-            if (threadIdx.x == 0) *shK = *shK - 1;
+    const int nwords = (K0 + 31) >> 5;
+    (void)sh_i;
+    if (nwords > 1024) {                              // beyond the bitmap: the plain scan
+        for (int k = K0 - 1; k >= 0; k--) {
+            if (tid == 0) *sh_i = (m.counts[k] == 0) ? 1 : 0;
             __syncthreads();
-            dev_del_component<XT>(c, m, k, shK);
+            const int empty = *sh_i;
+            __syncthreads();
+            if (empty) {
+                if (tid == 0) *shK = *shK - 1;
+                __syncthreads();
+                dev_del_component<XT>(c, m, k, shK);
+            }
+        }
+        return;
+    }
+    for (int w = tid; w < nwords; w += nt) empty_bits[w] = 0;
+    __syncthreads();
+    for (int k = tid; k < K0; k += nt)
+        if (m.counts[k] == 0) atomicOr(&empty_bits[k >> 5], 1u << (k & 31));
+    __syncthreads();
+    for (int w = nwords - 1; w >= 0; w--) {
+        unsigned int bits = empty_bits[w];             // uniform across the workgroup
+        while (bits) {
+            const int bit = 31 - __clz((int)bits);
+            bits &= ~(1u << bit);
+            __syncthreads();
+            if (tid == 0) *shK = *shK - 1;
+            __syncthreads();
+            dev_del_component<XT>(c, m, w * 32 + bit, shK);
         }
     }
 }
