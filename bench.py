@@ -63,6 +63,125 @@ def cpu_baseline(corpus, n_utts_total, K, n_slices_max, budget_utts):
     }
 
 
+def main_fbgmm(args):
+    """Secondary workloads (BASELINE.json configs[1] and configs[4]): sweeps/s of the batch-synchronous
+    blocked Gibbs sampler of the FBGMM / bigram drivers, same JSON contract."""
+    import ctypes as C
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
+    if world > 1:
+        import torch.distributed as dist
+        backend = os.environ.get("SEGK_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    from segmentalist_amd import _abi, bigram_acoustic_wordseg as baw, fbgmm, unigram_acoustic_wordseg as uaw
+    from segmentalist_amd.gaussian_components_fixedvar import FixedVarPrior
+    from segmentalist_amd.niw import NIW
+    from segmentalist_amd.synth import make_corpus
+    bigram = args.workload == "bigram_c5"
+    n_utt, D, K = (10000, 100, 1000) if bigram else (1000, 39, 100)
+    corpus = make_corpus(n_utt, D, K, seed=0, N=args.landmarks, n_slices_max=args.n_slices_max)
+    random.seed(0)
+    np.random.seed(0)
+    kw = dict(n_slices_min=0, n_slices_max=args.n_slices_max, p_boundary_init=0.5, beta_sent_boundary=-1, lms=1.0, wip=0.0,
+              init_am_assignments="rand", time_power_term=1.0, sync="batch", n_gibbs_blocks=8, n_stat_blocks=8)
+    if bigram:
+        prior = FixedVarPrior(0.002 * np.ones(D), np.zeros(D), 0.002 / 0.05 * np.ones(D))
+        seg = baw.BigramAcousticWordseg(K, prior, {"type": "smooth", "intrp_lambda": 0.1, "a": 0.5, "b": 0.5}, *corpus,
+                                        covariance_type="fixed", fb_type="unigram", score_precision="f32", **kw)
+    else:
+        prior = NIW(np.zeros(D), 0.05, D + 3, 0.002 * (D + 3) * np.ones(D))
+        seg = uaw.UnigramAcousticWordseg(fbgmm.FBGMM, 1.0, K, prior, *corpus, covariance_type="diag", fb_type="standard", **kw)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        seg.batch_sweep_async()
+    barrier()
+    seg._df.check_status()
+    if bigram:
+        _abi.check(_abi.lib().segk_profile_enable(_abi.ctx(), 1))
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        seg.batch_sweep_async()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    seg._df.check_status()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        sw = seg._get_sweeper()
+        cnt, tot, occ = sw.totals()
+        out = {
+            "metric": "Gibbs sweeps/sec (%s)" % ("BigramAcousticWordseg, 10k utts, D=100, K=1000" if bigram
+                                                  else "UnigramAcousticWordseg + FBGMM diag, 1k utts, D=39, K=100"),
+            "value": args.steps / elapsed, "unit": "sweeps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32 span scores, f64 sampling" if bigram else "f64", "data": "synthetic",
+            "config": {"workload": "%s batch-synchronous blocked Gibbs sweep, 8 blocks (BASELINE.json configs[%d])"
+                                   % ("BigramAcousticWordseg" if bigram else "UnigramAcousticWordseg + FBGMM (diag)",
+                                      4 if bigram else 1),
+                       "utterances": n_utt, "landmarks_per_utt": args.landmarks, "n_slices_max": args.n_slices_max,
+                       "embeddings": int(seg._corpus.n_emb), "D": D, "K": K,
+                       "parallelism": "utterance slices x%d, one all-gather of partial sums per Gibbs step" % world,
+                       "components_after": occ, "tokens": int(tot)},
+        }
+        if bigram:
+            nmax = 256
+            ms = (C.c_float * nmax)()
+            rows = (C.c_int64 * nmax)()
+            got = _abi.lib().segk_profile_read(_abi.ctx(), ms, rows, nmax)
+            if got > 0:
+                score_ms = float(np.mean(ms[:got]))
+                n_rows = float(np.mean(rows[:got]))
+                flops = 2.0 * n_rows * (K + 1) * (2 * D)     # [x^2, x] . [-pp/2, pp*mu] over K_max slots + the empty-slot row
+                achieved = flops / (score_ms * 1e-3) / 1e12
+                out["roofline"] = {"bound": "mfma", "kernel": "k_kmeans_score<50, 1, 4, 0, 1> (log-sum-exp mode, one launch per "
+                                   "Gibbs step)", "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": None, "ms_per_launch": score_ms,
+                                   "flops_per_launch": flops}
+            _abi.check(_abi.lib().segk_profile_enable(_abi.ctx(), 0))
+        if world == 1 and args.cpu_utts > 0:
+            from oracle import np_oracle as no
+            n_cpu = min(args.cpu_utts, 300 if bigram else 1000) // (10 if bigram else 1) or 1
+            keys = sorted(corpus[0])[:n_cpu]
+            sub = tuple({k: d[k] for k in keys} for d in corpus)
+            random.seed(0)
+            np.random.seed(0)
+            okw = dict(kw)
+            for k in ("sync", "n_gibbs_blocks", "n_stat_blocks"):
+                okw.pop(k)
+            if bigram:
+                ref = no.BigramAcousticWordseg(K, no.FixedVarPrior(0.002 * np.ones(D), np.zeros(D), 0.002 / 0.05 * np.ones(D)),
+                                               {"type": "smooth", "intrp_lambda": 0.1, "a": 0.5, "b": 0.5}, *sub,
+                                               covariance_type="fixed", fb_type="unigram", **okw)
+            else:
+                ref = no.UnigramAcousticWordseg(no.FBGMM, 1.0, K, no.NIW(np.zeros(D), 0.05, D + 3, 0.002 * (D + 3) * np.ones(D)),
+                                                *sub, covariance_type="diag", fb_type="standard", **okw)
+            t0 = time.perf_counter()
+            for i in range(len(keys)):
+                ref.gibbs_sample_i(i)
+            dt = time.perf_counter() - t0
+            out["cpu_baseline"] = {"value": len(keys) / dt / n_utt, "unit": "sweeps/s", "cores": 1, "kind": "port",
+                                   "sample": "oracle/np_oracle.py gibbs_sample_i (the reference's serial chain) on the first %d "
+                                             "of %d utterances, %.2f s wall = %.2f ms/utterance, extrapolated linearly"
+                                             % (len(keys), n_utt, dt, 1e3 * dt / len(keys))}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -75,7 +194,13 @@ def main():
     ap.add_argument("--n-slices-max", type=int, default=6)
     ap.add_argument("--cpu-utts", type=int, default=2500, help="utterances timed for cpu_baseline (0 = skip)")
     ap.add_argument("--no-events", action="store_true", help="do not bracket the score kernel with events")
+    ap.add_argument("--workload", default="kmeans_c3", choices=["kmeans_c3", "fbgmm_diag_c2", "bigram_c5"],
+                    help="kmeans_c3 (default) is the headline of BASELINE.json (configs[2]); fbgmm_diag_c2 = configs[1] "
+                         "(UnigramAcousticWordseg + FBGMM diag, 1k utterances, D=39, K=100), bigram_c5 = configs[4] "
+                         "(BigramAcousticWordseg, 10k utterances, D=100, K=1000): the batch (blocked Gibbs) sampler")
     args = ap.parse_args()
+    if args.workload != "kmeans_c3":
+        return main_fbgmm(args)
 
     import torch
     rank = int(os.environ.get("RANK", "0"))

@@ -46,8 +46,8 @@ const char *segk_last_error(void);
 int32_t segk_abi_version(void);
 
 /* Timing of the MAIN launch of the MFMA score kernel (k_kmeans_score<..., 0>) with HIP events
- * recorded on its launch stream inside segk_kmeans_filter -- what bench.py's roofline.achieved is
- * computed from.  segk_profile_read synchronises and returns, oldest first, the duration (ms) and
+ * recorded on its launch stream inside segk_kmeans_filter (and of its log-sum-exp twin inside
+ * segk_fbb_score_f32) -- what bench.py's roofline.achieved is computed from.  segk_profile_read synchronises and returns, oldest first, the duration (ms) and
  * the row count of the most recent recorded launches (at most `max`, at most 256 kept).          */
 int32_t segk_profile_enable(segk_ctx *ctx, int32_t on);
 int32_t segk_profile_read(segk_ctx *ctx, float *ms_out, int64_t *rows_out, int32_t max);

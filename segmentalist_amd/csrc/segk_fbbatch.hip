@@ -730,13 +730,12 @@ int32_t segk_fbb_make_y(segk_ctx *ctx, const segk_corpus *c, const segk_fbatch *
 int32_t segk_fbb_score_f32(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *f, const segk_fbatch *bt,
                            const int32_t *rows, int64_t n, double *score, void *stream)
 {
-    (void)ctx;
     int rc = check_fbb(c, f, bt);
     if (rc) return rc;
     SEGK_REQUIRE(f->cov_type == 0, "the matrix-core score exists for fixed-variance components only");
     SEGK_REQUIRE(bt->y && bt->tiles32, "y / tiles32 buffers missing");
     SEGK_REQUIRE(rows != NULL && n >= 0, "row list");
-    return segk_launch_score_lse(bt->y, bt->ldy, 2 * c->D, rows, 0, n, bt->tiles32, segk_n_tiles(f->K_max + 1), 0.0, score,
+    return segk_launch_score_lse(ctx, bt->y, bt->ldy, 2 * c->D, rows, 0, n, bt->tiles32, segk_n_tiles(f->K_max + 1), 0.0, score,
                                  stream);
 }
 

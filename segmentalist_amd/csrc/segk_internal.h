@@ -78,5 +78,5 @@ static inline __host__ __device__ int segk_tile_stride(int D)
 static inline __host__ __device__ int segk_n_tiles(int K_max) { return (K_max + 31) / 32; }
 
 // segk_kmeans.hip: the MFMA score kernel in log-sum-exp mode (used by segk_fbbatch.hip); not ABI
-int segk_launch_score_lse(const float *Y, int64_t ldy, int D2, const int32_t *ids, int64_t row0, int64_t n,
+int segk_launch_score_lse(segk_ctx *ctx, const float *Y, int64_t ldy, int D2, const int32_t *ids, int64_t row0, int64_t n,
                           const float *tiles, int n_tiles, double norm, double *out, void *stream);

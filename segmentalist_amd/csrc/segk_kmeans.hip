@@ -1888,7 +1888,7 @@ static int launch_score(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *
 }
 
 template <int GMAX>
-static int launch_score_lse(const ScoreArgs &A, hipStream_t st)
+static int launch_score_lse(segk_ctx *ctx, const ScoreArgs &A, hipStream_t st)
 {
     const size_t lds = 2 * (size_t)A.tile_stride * sizeof(float);
     static bool attr_set = false;
@@ -1898,14 +1898,22 @@ static int launch_score_lse(const ScoreArgs &A, hipStream_t st)
         attr_set = true;
     }
     const int64_t chunks = (A.n + 127) / 128;
+    const bool prof = ctx && ctx->prof_on != 0;
+    const int slot = prof ? ctx->prof_n % SEGK_PROF_SLOTS : 0;
+    if (prof) SEGK_CHECK_HIP(hipEventRecord(ctx->prof_ev[slot][0], st));
     hipLaunchKernelGGL((k_kmeans_score<GMAX, 1, 4, 0, 1>), dim3((unsigned)chunks), dim3(256), lds, st, A);
+    if (prof) {
+        SEGK_CHECK_HIP(hipEventRecord(ctx->prof_ev[slot][1], st));
+        ctx->prof_rows[slot] = A.n;
+        ctx->prof_n++;
+    }
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;
 }
 
 // out[row] = ln sum_k exp(z_k) - norm for the rows ids[r] (ids == NULL: row0 + r), r < n, where z_k * log2(e) = tile constant of component k +
 // <Y[row], tile row k> with Y [n_emb, ldy] float32 rows of D2 dimensions (segk_fbbatch.hip).  Internal, not ABI.
-int segk_launch_score_lse(const float *Y, int64_t ldy, int D2, const int32_t *ids, int64_t row0, int64_t n,
+int segk_launch_score_lse(segk_ctx *ctx, const float *Y, int64_t ldy, int D2, const int32_t *ids, int64_t row0, int64_t n,
                           const float *tiles, int n_tiles, double norm, double *out, void *stream)
 {
     if (n <= 0) return SEGK_OK;
@@ -1918,7 +1926,7 @@ int segk_launch_score_lse(const float *Y, int64_t ldy, int D2, const int32_t *id
     hipStream_t st = (hipStream_t)stream;
     switch (segk_gmax(D2)) {
 #define SEGK_CASE(g) \
-    case g: return launch_score_lse<g>(A, st);
+    case g: return launch_score_lse<g>(ctx, A, st);
         SEGK_CASE(1) SEGK_CASE(2) SEGK_CASE(4) SEGK_CASE(6) SEGK_CASE(8) SEGK_CASE(10) SEGK_CASE(13) SEGK_CASE(16)
         SEGK_CASE(20) SEGK_CASE(25) SEGK_CASE(26) SEGK_CASE(28) SEGK_CASE(32) SEGK_CASE(33) SEGK_CASE(34) SEGK_CASE(40)
         SEGK_CASE(50) SEGK_CASE(64) SEGK_CASE(75) SEGK_CASE(100)
