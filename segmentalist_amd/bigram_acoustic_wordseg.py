@@ -120,6 +120,15 @@ class BigramAcousticWordseg(object):
     materialise = UnigramAcousticWordseg.materialise
     _leave_batch = UnigramAcousticWordseg._leave_batch
 
+    # ------------------------------------------------------------------ checkpoint / resume
+    def state_dict(self):
+        from . import checkpoint
+        return checkpoint.state_dict(self)
+
+    def load_state_dict(self, sd):
+        from . import checkpoint
+        checkpoint.load_state_dict(self, sd)
+
     def set_fb_type(self, fb_type):
         self.fb_type = fb_type
         if fb_type == "bigram":

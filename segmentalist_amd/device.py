@@ -654,6 +654,20 @@ class FbgmmBatchSweeper(object):
                 self._gather(self.lm_tok, b)
         self.in_batch_state = True
 
+    def rebuild_from_slots(self, boundaries):
+        """Partial sums and transcripts from the current `slot` labels (checkpoint resume)."""
+        df = self.df
+        L, ctx, cp, fp, bp, st = self._args()
+        check(L.segk_fbb_collect(ctx, cp, ptr(boundaries), ptr(df.new_tok), ptr(df.n_new), st))
+        for b in range(self.B):
+            check(L.segk_fbb_partials(ctx, cp, fp, bp, self.s_lo, self.s_n, b, ptr(df.new_tok), ptr(df.n_new), st))
+            self._gather(self.partials, b)
+            if self.lm_tok is not None:
+                check(L.segk_fbb_lm_fill(ctx, cp, fp, bp, self.s_lo, self.s_n, b, self._n_utts[b], ptr(df.new_tok),
+                                         ptr(df.n_new), st))
+                self._gather(self.lm_tok, b)
+        self.in_batch_state = True
+
     def sweep(self, boundaries, n_slices_min, n_slices_max, wip, time_power_term, anneal_temp_fb=1.0,
               anneal_temp_am=1.0):
         """One sweep = n_gibbs_blocks steps, all enqueued on the current stream."""

@@ -121,6 +121,15 @@ class SegmentalKMeansWordseg(object):
                 out[valid] = np.where(np.isnan(d), -np.inf, mx * d)
         return out + self.wip
 
+    # ------------------------------------------------------------------ checkpoint / resume
+    def state_dict(self):
+        from . import checkpoint
+        return checkpoint.state_dict(self)
+
+    def load_state_dict(self, sd):
+        from . import checkpoint
+        checkpoint.load_state_dict(self, sd)
+
     # ------------------------------------------------------------------ batch mode
     def _get_sweeper(self):
         if self._sweeper is None:
