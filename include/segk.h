@@ -72,12 +72,17 @@ typedef struct segk_corpus {
     const int32_t *lengths;  /* [dev] [n_utt] landmarks per utterance                         */
     int32_t n_utt;
     int32_t N_max;           /* max landmarks; tri = N_max (N_max+1)/2                        */
+    const void *Xb3;         /* [dev] optional (float32 data, D <= 128): the rows as three bf16 pieces,
+                                [n_emb, 3, KP] bf16 with KP = D rounded up to 16, written by
+                                segk_corpus_prepare_b3; enables the bf16x3 k-means filter (NULL: fp32 MFMA) */
 } segk_corpus;
 
 /* Fill the derived members of a corpus: X32 (when X is float64 or ldx != ld32 the caller
  * passes a separate [n_emb, ld32] float buffer, written here) and xnorm. */
 int32_t segk_corpus_prepare(segk_ctx *ctx, const segk_corpus *c, float *X32_out, float *xnorm_out,
                             void *stream);
+/* Xb3_out [dev] [n_emb, 3, KP] bf16 (2 bytes each): x = x1 + x2 + x3 exactly, piece p at [.., p, ..] */
+int32_t segk_corpus_prepare_b3(segk_ctx *ctx, const segk_corpus *c, void *Xb3_out, void *stream);
 
 /* -------------------------------------------------------------------------------------
  * k-means components: device image of `KMeansComponents` (kmeans_components.py:18-91).
@@ -94,10 +99,13 @@ typedef struct segk_kmeans {
     /* derived operands of the MFMA score kernel, maintained by the library: */
     float *tiles;              /* [dev] segk_kmeans_tiles_floats(K_max, D) floats               */
     double *mnorm_max;         /* [dev] [1] max_k ||means[k]||_2^2 (kept with atomicMax on the bits) */
+    float *tiles_b3;           /* [dev] optional: segk_kmeans_tiles_b3_floats(K_max, D) floats, the bf16x3
+                                  operand image of the means (maintained beside `tiles` when non-NULL) */
 } segk_kmeans;
 
-/* number of floats the caller must allocate for segk_kmeans.tiles */
+/* number of floats the caller must allocate for segk_kmeans.tiles / .tiles_b3 */
 int64_t segk_kmeans_tiles_floats(int32_t K_max, int32_t D);
+int64_t segk_kmeans_tiles_b3_floats(int32_t K_max, int32_t D);
 
 /* KMeansComponents.__init__ (kmeans_components.py:59-81): from `assignments` (and
  * `random_means`) build counts, mean_numerators (sequential fp64 sums in ascending row order,

@@ -24,7 +24,7 @@ class Corpus(C.Structure):
         ("X", C.c_void_p), ("X32", C.c_void_p), ("x_dtype", C.c_int32), ("D", C.c_int32),
         ("n_emb", C.c_int64), ("ldx", C.c_int64), ("ld32", C.c_int64), ("xnorm", C.c_void_p),
         ("vec_ids", C.c_void_p), ("durations", C.c_void_p), ("lengths", C.c_void_p),
-        ("n_utt", C.c_int32), ("N_max", C.c_int32),
+        ("n_utt", C.c_int32), ("N_max", C.c_int32), ("Xb3", C.c_void_p),
     ]
 
 
@@ -32,7 +32,7 @@ class KMeansDev(C.Structure):
     _fields_ = [
         ("means", C.c_void_p), ("mean_numerators", C.c_void_p), ("counts", C.c_void_p),
         ("random_means", C.c_void_p), ("assignments", C.c_void_p), ("K", C.c_void_p),
-        ("K_max", C.c_int32), ("tiles", C.c_void_p), ("mnorm_max", C.c_void_p),
+        ("K_max", C.c_int32), ("tiles", C.c_void_p), ("mnorm_max", C.c_void_p), ("tiles_b3", C.c_void_p),
     ]
 
 
@@ -120,6 +120,8 @@ SIGNATURES = {
     "segk_fbb_lm_apply": (_i32, [_P, _CP, _FP, _BP, _i32, _i32, _P]),
     "segk_fbb_lm_fill": (_i32, [_P, _CP, _FP, _BP, _i32, _i32, _i32, _P, _P, _P, _P]),
     "segk_fbb_canonical": (_i32, [_P, _CP, _FP, _BP, _P, _P]),
+    "segk_corpus_prepare_b3": (_i32, [_P, _CP, _P, _P]),
+    "segk_kmeans_tiles_b3_floats": (_i64, [_i32, _i32]),
     "segk_profile_enable": (_i32, [_P, _i32]),
     "segk_profile_read": (_i32, [_P, _P, _P, _i32]),
     "segk_logsumexp": (_f64, [_P, _i64]),

@@ -77,6 +77,21 @@ static inline __host__ __device__ int segk_tile_stride(int D)
 }
 static inline __host__ __device__ int segk_n_tiles(int K_max) { return (K_max + 31) / 32; }
 
+// ---------------------------------------------------------------------------------------
+// bf16x3 operand images of the k-means filter (float32 data, D <= 128).  Every float32 is the
+// exact sum of three bf16 pieces x = x1 + x2 + x3 (8 significand bits each).
+//   rows   Xb3 [n_emb][3][KP] bf16, KP = D rounded up to 16 (zero padded)
+//   tiles  per tile of 32 components: bf16 [s][p][lane 64][8], s < KS = KP/16 (k-step), p < 3
+//          (piece): piece p of M[32*tile + (lane & 31)][16 s + 8 (lane >> 5) + i], i < 8 -- the A
+//          operand of v_mfma_f32_32x32x16_bf16 as one 16-byte load per lane; followed, at float
+//          offset KS*768, by 32 floats -|m|^2/2 (-3e38 beyond K_max); padded to 1024 floats.
+// ---------------------------------------------------------------------------------------
+static inline __host__ __device__ int segk_b3_kp(int D) { return (D + 15) & ~15; }
+static inline __host__ __device__ int segk_b3_tile_stride(int D)
+{
+    return ((segk_b3_kp(D) / 16) * 768 + 32 + 1023) / 1024 * 1024;
+}
+
 // segk_kmeans.hip: the MFMA score kernel in log-sum-exp mode (used by segk_fbbatch.hip); not ABI
 int segk_launch_score_lse(segk_ctx *ctx, const float *Y, int64_t ldy, int D2, const int32_t *ids, int64_t row0, int64_t n,
                           const float *tiles, int n_tiles, double norm, double *out, void *stream);

@@ -560,6 +560,245 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 2) void k_kmeans_score
     }
 }
 
+// ======================================================================================
+// bf16x3 filter (float32 data, D <= 128).  f[k] = x.m_k - |m_k|^2/2 as above, but the contraction
+// runs on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16: 16x the MAC rate of 32x32x2_f32): with
+// x = x1+x2+x3 and m = m1+m2+m3 exact bf16 splits, x.m = sum_ij xi.mj, and products of two bf16
+// are exact in float32.  The six products with i + j <= 4 are kept: m1.x1 accumulates in its own
+// chain (seeded with -|m|^2/2; KP/16 MFMAs = KP roundings at worst), the five small ones
+// (|.| <= 2^-7 |x||m| in total) in a second chain whose rounding error is negligible, the three
+// dropped ones are bounded by 2u |x| M.  The margin below which two filter values cannot be
+// ordered becomes (filter_tau_b3)
+//     E1' = 1.02 (KP + 16) u (|x| M + M^2/2)        (fp32 chain: (D4 + 3) u (...))
+// with E2 (the reference's own rounding) unchanged -- the filter stays only a filter, every
+// decision it cannot make with certainty goes to the exact stage.
+// Layouts: segk_internal.h.  Structure as k_kmeans_score: rows register-resident as the B operand
+// (three pieces), component tiles double-buffered in LDS via global_load_lds, two accumulator sets
+// so that the top-2 update of tile t-1 drains under the MFMAs of tile t.
+// ======================================================================================
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ float filter_tau_b3(float xn, float M, int D, int is_f64)
+{
+    const float u = 5.9604645e-8f;
+    const int KP = (D + 15) & ~15;
+    float e1 = 1.02f * (float)(KP + 16) * u * (xn * M + 0.5f * M * M);
+    int levels = 0;
+    for (int n = D; n > 128; n = (n + 1) / 2) levels++;
+    int deff = D < 128 ? D : 128;
+    float c2 = is_f64 ? 1e-6f : (float)(deff / 8 + 13 + 2 * levels);
+    float s = xn + M;
+    float e2 = c2 * u * s * s;
+    return 1.25f * (2.0f * e1 + e2) + 1e-30f;
+}
+
+// x -> three bf16 pieces (round to nearest each time: the residuals are exact in float32)
+__device__ __forceinline__ void split_b3(float x, __bf16 *p1, __bf16 *p2, __bf16 *p3)
+{
+    const __bf16 a = (__bf16)x;
+    const float r1 = x - (float)a;
+    const __bf16 b = (__bf16)r1;
+    const float r2 = r1 - (float)b;
+    *p1 = a;
+    *p2 = b;
+    *p3 = (__bf16)r2;
+}
+
+__global__ void k_corpus_split_b3(const float *X, int64_t ldx, int64_t n_emb, int D, __bf16 *out)
+{
+    const int KP = segk_b3_kp(D);
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_emb * KP) return;
+    const int64_t e = idx / KP;
+    const int d = (int)(idx - e * KP);
+    const float x = d < D ? X[e * ldx + d] : 0.f;
+    __bf16 a, b, c3;
+    split_b3(x, &a, &b, &c3);
+    __bf16 *row = out + e * 3 * KP;
+    row[d] = a;
+    row[KP + d] = b;
+    row[2 * KP + d] = c3;
+}
+
+__global__ void k_kmeans_prepare_b3(const float *means, int K_max, int D, float *tiles)
+{
+    const int tile = blockIdx.x;
+    const int KS = segk_b3_kp(D) / 16;
+    const int stride = segk_b3_tile_stride(D);
+    float *T = tiles + (int64_t)tile * stride;
+    __bf16 *Tb = (__bf16 *)T;
+    __shared__ double nrm[32];
+    {
+        const int ci = threadIdx.x >> 3, sub = threadIdx.x & 7;      // 256 threads = 32 x 8
+        const int comp = tile * 32 + ci;
+        double s = 0.0;
+        if (comp < K_max)
+            for (int d = sub; d < D; d += 8) {
+                double v = (double)means[(int64_t)comp * D + d];
+                s += v * v;
+            }
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        s += __shfl_xor(s, 4);
+        if (sub == 0) nrm[ci] = s;
+    }
+    __syncthreads();
+    // one thread per (k-step, lane, i): the three pieces of one mean value
+    for (int idx = threadIdx.x; idx < KS * 64 * 8; idx += blockDim.x) {
+        const int sidx = idx >> 9, lane = (idx >> 3) & 63, i = idx & 7;
+        const int comp = tile * 32 + (lane & 31);
+        const int d = 16 * sidx + 8 * (lane >> 5) + i;
+        const float v = (comp < K_max && d < D) ? means[(int64_t)comp * D + d] : 0.f;
+        __bf16 a, b, c3;
+        split_b3(v, &a, &b, &c3);
+        Tb[((sidx * 3 + 0) * 64 + lane) * 8 + i] = a;
+        Tb[((sidx * 3 + 1) * 64 + lane) * 8 + i] = b;
+        Tb[((sidx * 3 + 2) * 64 + lane) * 8 + i] = c3;
+    }
+    for (int idx = threadIdx.x; idx < stride - KS * 768; idx += blockDim.x) {
+        float v = 0.f;
+        if (idx < 32) {
+            const int comp = tile * 32 + idx;
+            v = (comp < K_max) ? (float)(-0.5 * nrm[idx]) : -3.0e38f;
+        }
+        T[KS * 768 + idx] = v;
+    }
+}
+
+template <int KS, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 2) void k_kmeans_score_b3(ScoreArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int32_t *__restrict__ ids = A.ids;
+    const int64_t row0 = A.row0, n = A.n;
+    const float *__restrict__ tiles = A.tiles;
+    const int n_tiles = A.n_tiles, D = A.D;
+    constexpr int KP = KS * 16;
+    constexpr int STRIDE = (KS * 768 + 32 + 1023) / 1024 * 1024;      // floats per tile image
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+
+    bf16x8 xb[3][KS];
+    const int64_t r = ((int64_t)blockIdx.x * WAVES + wave) * 32 + j;
+    int32_t rowid = -1;
+    if (r < n) rowid = ids ? ids[r] : (int32_t)(row0 + r);
+    {
+        const __bf16 *xp = (const __bf16 *)A.X32 + (int64_t)(rowid >= 0 ? rowid : 0) * (3 * KP) + 8 * h;
+#pragma unroll
+        for (int p = 0; p < 3; p++)
+#pragma unroll
+            for (int s = 0; s < KS; s++) xb[p][s] = *reinterpret_cast<const bf16x8 *>(xp + p * KP + 16 * s);
+    }
+    float m1 = NEG_INF_F, m2 = NEG_INF_F;
+    int32_t irow = 0, itile = 0;
+
+    constexpr int PASS = WAVES * 256;
+    constexpr int NPASS = (STRIDE + PASS - 1) / PASS;
+    typedef const __attribute__((address_space(1))) void *gptr_t;
+    typedef __attribute__((address_space(3))) void *lptr_t;
+#define SEGK_STAGE(tt, buf)                                                                         \
+    do {                                                                                            \
+        const float *src_ = tiles + (int64_t)(tt) * STRIDE + tid * 4;                               \
+        float *dst_ = lds + (buf) * STRIDE + wave * 256;                                            \
+        _Pragma("unroll") for (int p = 0; p < NPASS; p++)                                           \
+            if (p * PASS + wave * 256 < STRIDE)                                                     \
+                __builtin_amdgcn_global_load_lds((gptr_t)(src_ + p * PASS), (lptr_t)(dst_ + p * PASS), 16, 0, 0); \
+    } while (0)
+
+    SEGK_STAGE(0, 0);
+    __syncthreads();
+
+    f32x16 accAm, accAl, accBm, accBl;
+#pragma unroll
+    for (int q = 0; q < 16; q++) { accAm[q] = NEG_INF_F; accAl[q] = 0.f; accBm[q] = NEG_INF_F; accBl[q] = 0.f; }
+
+    constexpr int VPS = (16 + KS - 1) / KS;
+#define SEGK_DRAIN(ACCM, ACCL, vi)                                                    \
+    do {                                                                              \
+        const float v_ = ACCM[(vi)] + ACCL[(vi)];                                     \
+        asm volatile("v_cmp_ngt_f32 vcc, %3, %0\n\t"                                  \
+                     "v_med3_f32 %1, %0, %1, %3\n\t"                                  \
+                     "v_max_f32 %0, %0, %3\n\t"                                       \
+                     "v_cndmask_b32 %2, %4, %2, vcc"                                  \
+                     : "+v"(m1), "+v"(m2), "+v"(irow)                                 \
+                     : "v"(v_), "n"((vi))                                             \
+                     : "vcc");                                                        \
+    } while (0)
+
+#define SEGK_TILE(NEWM, NEWL, OLDM, OLDL, t_)                                                         \
+    do {                                                                                              \
+        const float *T = lds + ((t_) & 1) * STRIDE;                                                   \
+        const __bf16 *Tb = (const __bf16 *)T;                                                         \
+        if ((t_) + 1 < n_tiles) SEGK_STAGE((t_) + 1, ((t_) + 1) & 1);                                 \
+        {                                                                                             \
+            const float *cv = T + KS * 768 + 4 * h;                                                   \
+            _Pragma("unroll") for (int q = 0; q < 4; q++) {                                           \
+                float4 c4 = *reinterpret_cast<const float4 *>(cv + 8 * q);                            \
+                NEWM[4 * q + 0] = c4.x; NEWM[4 * q + 1] = c4.y; NEWM[4 * q + 2] = c4.z; NEWM[4 * q + 3] = c4.w; \
+                NEWL[4 * q + 0] = 0.f; NEWL[4 * q + 1] = 0.f; NEWL[4 * q + 2] = 0.f; NEWL[4 * q + 3] = 0.f;     \
+            }                                                                                         \
+        }                                                                                             \
+        const float m1s = m1;                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        _Pragma("unroll") for (int s = 0; s < KS; s++) {                                              \
+            const bf16x8 a1 = *reinterpret_cast<const bf16x8 *>(Tb + ((s * 3 + 0) * 64 + lane) * 8);  \
+            const bf16x8 a2 = *reinterpret_cast<const bf16x8 *>(Tb + ((s * 3 + 1) * 64 + lane) * 8);  \
+            const bf16x8 a3 = *reinterpret_cast<const bf16x8 *>(Tb + ((s * 3 + 2) * 64 + lane) * 8);  \
+            NEWM = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, xb[0][s], NEWM, 0, 0, 0);              \
+            NEWL = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, xb[1][s], NEWL, 0, 0, 0);              \
+            NEWL = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, xb[0][s], NEWL, 0, 0, 0);              \
+            NEWL = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, xb[1][s], NEWL, 0, 0, 0);              \
+            NEWL = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, xb[2][s], NEWL, 0, 0, 0);              \
+            NEWL = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, xb[0][s], NEWL, 0, 0, 0);              \
+            _Pragma("unroll") for (int q = 0; q < VPS; q++)                                           \
+                if (s * VPS + q < 16) SEGK_DRAIN(OLDM, OLDL, s * VPS + q);                            \
+            __builtin_amdgcn_sched_barrier(0);                                                        \
+        }                                                                                             \
+        itile = (m1 > m1s) ? ((t_) - 1) : itile;                                                      \
+        __syncthreads();                                                                              \
+    } while (0)
+
+    int t = 0;
+    for (; t + 1 < n_tiles; t += 2) {
+        SEGK_TILE(accAm, accAl, accBm, accBl, t);
+        SEGK_TILE(accBm, accBl, accAm, accAl, t + 1);
+    }
+    {
+        float m1s = m1;
+        if (t < n_tiles) {
+            SEGK_TILE(accAm, accAl, accBm, accBl, t);
+            m1s = m1;
+#pragma unroll
+            for (int vi = 0; vi < 16; vi++) SEGK_DRAIN(accAm, accAl, vi);
+        } else {
+#pragma unroll
+            for (int vi = 0; vi < 16; vi++) SEGK_DRAIN(accBm, accBl, vi);
+        }
+        itile = (m1 > m1s) ? (n_tiles - 1) : itile;
+    }
+#undef SEGK_TILE
+#undef SEGK_DRAIN
+#undef SEGK_STAGE
+    const int32_t i1 = itile * 32 + 4 * h + (irow & 3) + 8 * (irow >> 2);
+    const float o1 = __shfl_xor(m1, 32), o2 = __shfl_xor(m2, 32);
+    const int oi = __shfl_xor(i1, 32);
+    const float top1 = fmaxf(m1, o1);
+    const float top2 = fmaxf(fminf(m1, o1), fmaxf(m2, o2));
+    const int idx = (o1 > m1 || (o1 == m1 && oi < i1)) ? oi : i1;
+    if (h == 0 && rowid >= 0) {
+        A.cand.k[rowid] = idx;
+        A.cand.f[2 * (int64_t)rowid + 0] = top1;
+        A.cand.f[2 * (int64_t)rowid + 1] = top2;
+        A.cand.s[rowid] = (double)__builtin_nanf("");          // the winner's exact score: k_kmeans_exact_fill
+        const float M = (float)(sqrt(*A.mnorm2) * (1.0 + 1e-6)) + 1e-30f;
+        const float tau = filter_tau_b3(A.xnorm[rowid], M, D, 0);
+        if (!(top1 - top2 > tau)) {
+            int q = atomicAdd(A.cand.count, 1);
+            if (q < A.amb_cap) A.cand.queue[q] = rowid;
+        }
+    }
+}
+
 // A handful of left-over rows (fewer than SEGK_TAIL_QUEUE): not worth three more launches -- they
 // are appended to the ambiguity queue and take the full reference-arithmetic scan.
 #define SEGK_TAIL_QUEUE 2048
@@ -1887,6 +2126,61 @@ static int launch_score(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *
     return SEGK_OK;
 }
 
+static bool segk_use_b3(const segk_corpus *c, const segk_kmeans *m)
+{
+    const char *e = getenv("SEGK_SCORE_B3");
+    if (e && atoi(e) == 0) return false;
+    return c->Xb3 && m->tiles_b3 && c->x_dtype == SEGK_F32 && c->D >= 8 && c->D <= 128;
+}
+
+// bf16x3 filter: whole rounds (and any larger remainder) to k_kmeans_score_b3, a remainder of fewer
+// than SEGK_TAIL_QUEUE rows to the ambiguity queue; exact winner scores by k_kmeans_exact_fill.
+template <int KS>
+static int launch_score_b3(segk_ctx *ctx, ScoreArgs A, hipStream_t st)
+{
+    constexpr int STRIDE = (KS * 768 + 32 + 1023) / 1024 * 1024;
+    const size_t lds = 2 * (size_t)STRIDE * sizeof(float);
+    static int wg_per_cu = 0;
+    if (!wg_per_cu) {
+        if (lds > 48 * 1024)
+            SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_kmeans_score_b3<KS, 4>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        int occ = 0;
+        SEGK_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)k_kmeans_score_b3<KS, 4>, 256, lds));
+        wg_per_cu = occ > 0 ? occ : 1;
+    }
+    const int64_t slots = (int64_t)wg_per_cu * ctx->n_cu;
+    const int64_t chunks = (A.n + 127) / 128;
+    int64_t main_chunks = (chunks / slots) * slots;
+    int64_t n_main = main_chunks * 128 < A.n ? main_chunks * 128 : A.n;
+    if (A.n - n_main >= SEGK_TAIL_QUEUE) {            // a large remainder: one more (partial) round
+        main_chunks = chunks;
+        n_main = A.n;
+    }
+    if (main_chunks > 0) {
+        ScoreArgs M = A;
+        M.n = n_main;
+        const bool prof = ctx->prof_on != 0;
+        const int slot = ctx->prof_n % SEGK_PROF_SLOTS;
+        if (prof) SEGK_CHECK_HIP(hipEventRecord(ctx->prof_ev[slot][0], st));
+        hipLaunchKernelGGL((k_kmeans_score_b3<KS, 4>), dim3((unsigned)main_chunks), dim3(256), lds, st, M);
+        if (prof) {
+            SEGK_CHECK_HIP(hipEventRecord(ctx->prof_ev[slot][1], st));
+            ctx->prof_rows[slot] = n_main;
+            ctx->prof_n++;
+        }
+    }
+    if (A.n > n_main) {
+        ScoreArgs T = A;
+        T.n = A.n - n_main;
+        T.row0 = A.row0 + n_main;
+        T.ids = A.ids ? A.ids + n_main : nullptr;
+        hipLaunchKernelGGL(k_score_queue_rows, dim3((unsigned)((T.n + 255) / 256)), dim3(256), 0, st, T);
+    }
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
 template <int GMAX>
 static int launch_score_lse(segk_ctx *ctx, const ScoreArgs &A, hipStream_t st)
 {
@@ -1970,6 +2264,28 @@ int32_t segk_kmeans_prepare(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m,
     DISPATCH_XT(c, hipLaunchKernelGGL(k_kmeans_prepare<XT>, dim3(segk_n_tiles(m->K_max)), dim3(256), 0, st,
                                        (const XT *)m->means, m->K_max, c->D, m->tiles,
                                        (unsigned long long *)m->mnorm_max););
+    if (m->tiles_b3 && c->x_dtype == SEGK_F32 && c->D >= 8 && c->D <= 128)
+        hipLaunchKernelGGL(k_kmeans_prepare_b3, dim3(segk_n_tiles(m->K_max)), dim3(256), 0, st, (const float *)m->means,
+                           m->K_max, c->D, m->tiles_b3);
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+int64_t segk_kmeans_tiles_b3_floats(int32_t K_max, int32_t D)
+{
+    return (int64_t)segk_n_tiles(K_max) * segk_b3_tile_stride(D);
+}
+
+int32_t segk_corpus_prepare_b3(segk_ctx *ctx, const segk_corpus *c, void *Xb3_out, void *stream)
+{
+    (void)ctx;
+    int rc = check_corpus(c);
+    if (rc) return rc;
+    SEGK_REQUIRE(Xb3_out != nullptr, "Xb3_out is NULL");
+    SEGK_REQUIRE(c->x_dtype == SEGK_F32 && c->D >= 8 && c->D <= 128, "the bf16x3 image exists for float32 data with 8 <= D <= 128");
+    const int64_t tot = c->n_emb * segk_b3_kp(c->D);
+    hipLaunchKernelGGL(k_corpus_split_b3, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float *)c->X, c->ldx, c->n_emb, c->D, (__bf16 *)Xb3_out);
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;
 }
@@ -2014,6 +2330,22 @@ int32_t segk_kmeans_filter(segk_ctx *ctx, const segk_corpus *c, const segk_kmean
     // and drift apart, covering each other's barrier/staging gaps.  (Measured: an 8-wave
     // workgroup, one barrier for all eight waves, locks the SIMD partners in step and is 15 %
     // slower although it halves the staging instructions per wave.)
+    if (segk_use_b3(c, m)) {
+        A.X32 = (const float *)c->Xb3;
+        A.tiles = m->tiles_b3;
+        A.tile_stride = segk_b3_tile_stride(c->D);
+        switch (segk_b3_kp(c->D) / 16) {
+            case 1: return launch_score_b3<1>(ctx, A, st);
+            case 2: return launch_score_b3<2>(ctx, A, st);
+            case 3: return launch_score_b3<3>(ctx, A, st);
+            case 4: return launch_score_b3<4>(ctx, A, st);
+            case 5: return launch_score_b3<5>(ctx, A, st);
+            case 6: return launch_score_b3<6>(ctx, A, st);
+            case 7: return launch_score_b3<7>(ctx, A, st);
+            case 8: return launch_score_b3<8>(ctx, A, st);
+            default: break;
+        }
+    }
     // Rows per wave: one 32-row MFMA column block per wave (108 VGPRs, four workgroups per CU) beat
     // two blocks sharing every LDS tile fetch (194 VGPRs, two per CU) at every row count measured
     // (D = 100: 77 % vs 73 % of the fp32 matrix peak); SEGK_SCORE_NB=2 selects the latter.
@@ -2042,7 +2374,7 @@ int32_t segk_kmeans_resolve(segk_ctx *ctx, const segk_corpus *c, const segk_kmea
     if (n <= 0) return SEGK_OK;
     hipStream_t st = (hipStream_t)stream;
     const bool fused = (c->x_dtype == SEGK_F32 && c->D >= 8 && c->D <= 128);
-    if (!fused)
+    if (!fused || segk_use_b3(c, m))
         DISPATCH_XT(c, hipLaunchKernelGGL(k_kmeans_exact_fill<XT>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
                                            *c, *m, ids, row0, n, *cand););
     const int nt = 256;

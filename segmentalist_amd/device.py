@@ -74,6 +74,8 @@ class DeviceCorpus(object):
             self.vec_ids = self.durations = self.lengths = None
             self.lengths_np = None
         self.tri = self.N_max * (self.N_max + 1) // 2
+        # bf16x3 image of the rows for the k-means filter (float32 data, 8 <= D <= 128); built on demand
+        self.Xb3 = None
         self.c = _abi.Corpus(
             X=self.X.data_ptr(), X32=self.X32.data_ptr(), x_dtype=self.x_dtype, D=self.D,
             n_emb=self.n_emb, ldx=self.ldx, ld32=self.ld32, xnorm=self.xnorm.data_ptr(),
@@ -83,6 +85,16 @@ class DeviceCorpus(object):
             n_utt=self.n_utt, N_max=self.N_max)
         check(_abi.lib().segk_corpus_prepare(_abi.ctx(), C.byref(self.c), ptr(x32_out), ptr(self.xnorm),
                                              _abi.stream()))
+
+    def ensure_b3(self):
+        """The rows as three bf16 pieces (segk_corpus_prepare_b3) for the bf16x3 k-means filter."""
+        if self.Xb3 is None and self.x_dtype == SEGK_F32 and 8 <= self.D <= 128:
+            torch = _torch()
+            kp = (self.D + 15) // 16 * 16
+            self.Xb3 = torch.empty((self.n_emb, 3, kp), dtype=torch.bfloat16, device=self.X.device)
+            check(_abi.lib().segk_corpus_prepare_b3(_abi.ctx(), C.byref(self.c), ptr(self.Xb3), _abi.stream()))
+            self.c.Xb3 = self.Xb3.data_ptr()
+        return self.Xb3 is not None
 
     @property
     def torch_xdtype(self):
@@ -110,7 +122,12 @@ class DeviceKMeans(object):
         n_tiles_f = _abi.lib().segk_kmeans_tiles_floats(self.K_max, c.D)
         self.tiles = torch.zeros(int(n_tiles_f), dtype=torch.float32, device=dev)
         self.mnorm_max = torch.zeros(1, dtype=torch.float64, device=dev)
+        self.tiles_b3 = None
+        if c.ensure_b3():
+            self.tiles_b3 = torch.zeros(int(_abi.lib().segk_kmeans_tiles_b3_floats(self.K_max, c.D)), dtype=torch.float32,
+                                        device=dev)
         self.m = _abi.KMeansDev(
+            tiles_b3=self.tiles_b3.data_ptr() if self.tiles_b3 is not None else None,
             means=self.means.data_ptr(), mean_numerators=self.mean_numerators.data_ptr(),
             counts=self.counts.data_ptr(), random_means=self.random_means.data_ptr(),
             assignments=self.assignments.data_ptr(), K=self.K.data_ptr(), K_max=self.K_max,
