@@ -86,6 +86,16 @@ static inline __host__ __device__ int segk_n_tiles(int K_max) { return (K_max + 
 //          operand of v_mfma_f32_32x32x16_bf16 as one 16-byte load per lane; followed, at float
 //          offset KS*768, by 32 floats -|m|^2/2 (-3e38 beyond K_max); padded to 1024 floats.
 // ---------------------------------------------------------------------------------------
+// Slot -> dimension inside a 16-wide k-step: slot q = 8h + i (h = lane half, i < 8) carries dimension
+// 8 (i >> 2) + 4 h + (i & 3): each lane half owns the dimensions d with (d mod 8) in {4h .. 4h+3} of
+// both 8-blocks of the step -- four complete strided accumulators of numpy's pairwise sum, so the
+// winner's exact score can be finished in the score kernel without exchanging terms (the contraction
+// itself is indifferent to the order of the dimensions).
+static inline __host__ __device__ int segk_b3_dim(int pos)       // position in a piece row -> dimension
+{
+    const int q = pos & 15, h = q >> 3, i = q & 7;
+    return (pos & ~15) + 8 * (i >> 2) + 4 * h + (i & 3);
+}
 static inline __host__ __device__ int segk_b3_kp(int D) { return (D + 15) & ~15; }
 static inline __host__ __device__ int segk_b3_tile_stride(int D)
 {

@@ -281,6 +281,7 @@ struct ScoreArgs {
     // MODE = 1 (log-sum-exp over the components instead of the top-2): out[row] = ln2 * log2 sum_k 2^acc - lse_norm
     double *lse_out;
     double lse_norm;
+    const float *means32;        /* bf16x3 filter: float32 `means` for the fused exact score of the winner */
 };
 
 // SPLIT = 0: the whole component range per workgroup, winner + margin test + fused exact score.
@@ -610,14 +611,14 @@ __global__ void k_corpus_split_b3(const float *X, int64_t ldx, int64_t n_emb, in
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n_emb * KP) return;
     const int64_t e = idx / KP;
-    const int d = (int)(idx - e * KP);
+    const int pos = (int)(idx - e * KP), d = segk_b3_dim(pos);
     const float x = d < D ? X[e * ldx + d] : 0.f;
     __bf16 a, b, c3;
     split_b3(x, &a, &b, &c3);
     __bf16 *row = out + e * 3 * KP;
-    row[d] = a;
-    row[KP + d] = b;
-    row[2 * KP + d] = c3;
+    row[pos] = a;
+    row[KP + pos] = b;
+    row[2 * KP + pos] = c3;
 }
 
 __global__ void k_kmeans_prepare_b3(const float *means, int K_max, int D, float *tiles)
@@ -647,7 +648,7 @@ __global__ void k_kmeans_prepare_b3(const float *means, int K_max, int D, float 
     for (int idx = threadIdx.x; idx < KS * 64 * 8; idx += blockDim.x) {
         const int sidx = idx >> 9, lane = (idx >> 3) & 63, i = idx & 7;
         const int comp = tile * 32 + (lane & 31);
-        const int d = 16 * sidx + 8 * (lane >> 5) + i;
+        const int d = segk_b3_dim(16 * sidx + 8 * (lane >> 5) + i);
         const float v = (comp < K_max && d < D) ? means[(int64_t)comp * D + d] : 0.f;
         __bf16 a, b, c3;
         split_b3(v, &a, &b, &c3);
@@ -694,19 +695,35 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_kmeans_score_b3(ScoreArgs A)
 
     constexpr int PASS = WAVES * 256;
     constexpr int NPASS = (STRIDE + PASS - 1) / PASS;
-    typedef const __attribute__((address_space(1))) void *gptr_t;
     typedef __attribute__((address_space(3))) void *lptr_t;
+    // Staging by LDS-DMA issued from inline asm: hipcc counts a builtin global_load_lds as a pending LDS
+    // write and drains it (s_waitcnt vmcnt(0)) before the next ds_read, which serialises the copy of
+    // tile t+1 with the MFMAs of tile t.  The asm form is outside its bookkeeping; the wait is explicit,
+    // once per tile, right before the barrier that hands the buffer over (cdna_hip_programming.md,
+    // "Pipelining across barriers").  M0 carries the wave-uniform LDS byte address.
 #define SEGK_STAGE(tt, buf)                                                                         \
     do {                                                                                            \
         const float *src_ = tiles + (int64_t)(tt) * STRIDE + tid * 4;                               \
-        float *dst_ = lds + (buf) * STRIDE + wave * 256;                                            \
+        const unsigned dst_ = __builtin_amdgcn_readfirstlane(lds_base + ((buf) * STRIDE + wave * 256) * 4); \
         _Pragma("unroll") for (int p = 0; p < NPASS; p++)                                           \
-            if (p * PASS + wave * 256 < STRIDE)                                                     \
-                __builtin_amdgcn_global_load_lds((gptr_t)(src_ + p * PASS), (lptr_t)(dst_ + p * PASS), 16, 0, 0); \
+            if (p * PASS + wave * 256 < STRIDE) {                                                   \
+                unsigned keep_;                                                                     \
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"                 \
+                             "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"                  \
+                             : "=&s"(keep_)                                                         \
+                             : "v"(src_ + p * PASS), "s"(dst_ + p * PASS * 4)                       \
+                             : "memory");                                                           \
+            }                                                                                       \
+    } while (0)
+#define SEGK_TILE_SYNC()                                                      \
+    do {                                                                      \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");           \
+        __builtin_amdgcn_s_barrier();                                         \
     } while (0)
 
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lptr_t)lds);
     SEGK_STAGE(0, 0);
-    __syncthreads();
+    SEGK_TILE_SYNC();
 
     f32x16 accAm, accAl, accBm, accBl;
 #pragma unroll
@@ -755,7 +772,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_kmeans_score_b3(ScoreArgs A)
             __builtin_amdgcn_sched_barrier(0);                                                        \
         }                                                                                             \
         itile = (m1 > m1s) ? ((t_) - 1) : itile;                                                      \
-        __syncthreads();                                                                              \
+        SEGK_TILE_SYNC();                                                                             \
     } while (0)
 
     int t = 0;
@@ -779,17 +796,59 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_kmeans_score_b3(ScoreArgs A)
 #undef SEGK_TILE
 #undef SEGK_DRAIN
 #undef SEGK_STAGE
+#undef SEGK_TILE_SYNC
     const int32_t i1 = itile * 32 + 4 * h + (irow & 3) + 8 * (irow >> 2);
     const float o1 = __shfl_xor(m1, 32), o2 = __shfl_xor(m2, 32);
     const int oi = __shfl_xor(i1, 32);
     const float top1 = fmaxf(m1, o1);
     const float top2 = fmaxf(fminf(m1, o1), fmaxf(m2, o2));
     const int idx = (o1 > m1 || (o1 == m1 && oi < i1)) ? oi : i1;
+    // Fused exact stage for the winner (D a multiple of 4): the reference's float32 -(deltas*deltas).sum()
+    // in numpy's pairwise order.  This lane half owns the strided accumulators r_{4h..4h+3} in full
+    // (segk_b3_dim), x is rebuilt exactly from its three pieces, the winner's mean comes from `means`.
+    float sexact = __builtin_nanf("");
+    if (A.fuse_exact) {
+        const float *mrow = A.means32 + (int64_t)idx * D + 4 * h;
+        const int nfull = D & ~7, rem = D & 7;
+        float r4[4] = {0.f, 0.f, 0.f, 0.f}, tt[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KS; s++) {
+#pragma unroll
+            for (int b = 0; b < 2; b++) {
+                const int d0 = 16 * s + 8 * b;                     // this half holds d0 + 4h + {0..3}
+                if (d0 + 4 * h < D) {                              // D % 4 == 0: all four or none
+                    const float4 mv = *reinterpret_cast<const float4 *>(mrow + d0);
+                    const float mvv[4] = {mv.x, mv.y, mv.z, mv.w};
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const int i = 4 * b + q;
+                        const float x = ((float)xb[0][s][i] + (float)xb[1][s][i]) + (float)xb[2][s][i];
+                        const float delta = mvv[q] - x;
+                        const float t2 = delta * delta;
+                        if (d0 < nfull) r4[q] = (s == 0 && b == 0) ? t2 : r4[q] + t2;
+                        else tt[q] = t2;                           // the sequential tail block
+                    }
+                }
+            }
+        }
+        float res = (r4[0] + r4[1]) + (r4[2] + r4[3]);
+        const float ro = __shfl_xor(res, 32);
+        res = (h == 0) ? res + ro : ro + res;                      // ((r0+r1)+(r2+r3)) + ((r4+r5)+(r6+r7))
+        const float u0 = __shfl_xor(tt[0], 32), u1 = __shfl_xor(tt[1], 32), u2 = __shfl_xor(tt[2], 32);
+        // tail dimension nfull + jj lives on half jj >> 2, slot jj & 3 (rem < 8, D % 4 == 0: rem is 0 or 4)
+        const float t0 = h == 0 ? tt[0] : u0, t1 = h == 0 ? tt[1] : u1, t2 = h == 0 ? tt[2] : u2;
+        const float t3 = h == 0 ? tt[3] : __shfl_xor(tt[3], 32);
+        if (rem > 0) res += t0;
+        if (rem > 1) res += t1;
+        if (rem > 2) res += t2;
+        if (rem > 3) res += t3;
+        sexact = -res;
+    }
     if (h == 0 && rowid >= 0) {
         A.cand.k[rowid] = idx;
         A.cand.f[2 * (int64_t)rowid + 0] = top1;
         A.cand.f[2 * (int64_t)rowid + 1] = top2;
-        A.cand.s[rowid] = (double)__builtin_nanf("");          // the winner's exact score: k_kmeans_exact_fill
+        A.cand.s[rowid] = (double)sexact;                          // NaN when not fused: k_kmeans_exact_fill
         const float M = (float)(sqrt(*A.mnorm2) * (1.0 + 1e-6)) + 1e-30f;
         const float tau = filter_tau_b3(A.xnorm[rowid], M, D, 0);
         if (!(top1 - top2 > tau)) {
@@ -2334,6 +2393,8 @@ int32_t segk_kmeans_filter(segk_ctx *ctx, const segk_corpus *c, const segk_kmean
         A.X32 = (const float *)c->Xb3;
         A.tiles = m->tiles_b3;
         A.tile_stride = segk_b3_tile_stride(c->D);
+        A.means32 = (const float *)m->means;
+        A.fuse_exact = (c->D % 4 == 0) ? 1 : 0;
         switch (segk_b3_kp(c->D) / 16) {
             case 1: return launch_score_b3<1>(ctx, A, st);
             case 2: return launch_score_b3<2>(ctx, A, st);
