@@ -715,6 +715,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_kmeans_score_b3(ScoreArgs A)
                              : "memory");                                                           \
             }                                                                                       \
     } while (0)
+    // (a third LDS buffer with the copy of tile t+2 kept in flight across the barrier -- counted
+    // vmcnt -- was measured 2 % slower: the copy already lands within one tile time)
 #define SEGK_TILE_SYNC()                                                      \
     do {                                                                      \
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");           \
@@ -756,11 +758,16 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_kmeans_score_b3(ScoreArgs A)
             }                                                                                         \
         }                                                                                             \
         const float m1s = m1;                                                                         \
-        __builtin_amdgcn_sched_barrier(0);                                                            \
+        bf16x8 n1 = *reinterpret_cast<const bf16x8 *>(Tb + (0 * 64 + lane) * 8);                      \
+        bf16x8 n2 = *reinterpret_cast<const bf16x8 *>(Tb + (1 * 64 + lane) * 8);                      \
+        bf16x8 n3 = *reinterpret_cast<const bf16x8 *>(Tb + (2 * 64 + lane) * 8);                      \
         _Pragma("unroll") for (int s = 0; s < KS; s++) {                                              \
-            const bf16x8 a1 = *reinterpret_cast<const bf16x8 *>(Tb + ((s * 3 + 0) * 64 + lane) * 8);  \
-            const bf16x8 a2 = *reinterpret_cast<const bf16x8 *>(Tb + ((s * 3 + 1) * 64 + lane) * 8);  \
-            const bf16x8 a3 = *reinterpret_cast<const bf16x8 *>(Tb + ((s * 3 + 2) * 64 + lane) * 8);  \
+            const bf16x8 a1 = n1, a2 = n2, a3 = n3;                                                   \
+            if (s + 1 < KS) {          /* operands of the next k-step, in flight under this step's MFMAs */ \
+                n1 = *reinterpret_cast<const bf16x8 *>(Tb + (((s + 1) * 3 + 0) * 64 + lane) * 8);     \
+                n2 = *reinterpret_cast<const bf16x8 *>(Tb + (((s + 1) * 3 + 1) * 64 + lane) * 8);     \
+                n3 = *reinterpret_cast<const bf16x8 *>(Tb + (((s + 1) * 3 + 2) * 64 + lane) * 8);     \
+            }                                                                                         \
             NEWM = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, xb[0][s], NEWM, 0, 0, 0);              \
             NEWL = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, xb[1][s], NEWL, 0, 0, 0);              \
             NEWL = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, xb[0][s], NEWL, 0, 0, 0);              \
@@ -769,7 +776,6 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_kmeans_score_b3(ScoreArgs A)
             NEWL = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, xb[0][s], NEWL, 0, 0, 0);              \
             _Pragma("unroll") for (int q = 0; q < VPS; q++)                                           \
                 if (s * VPS + q < 16) SEGK_DRAIN(OLDM, OLDL, s * VPS + q);                            \
-            __builtin_amdgcn_sched_barrier(0);                                                        \
         }                                                                                             \
         itile = (m1 > m1s) ? ((t_) - 1) : itile;                                                      \
         SEGK_TILE_SYNC();                                                                             \
