@@ -30,6 +30,7 @@ import numpy as np  # noqa: E402
 
 METRIC = "Gibbs sweeps/sec (10k utts, D=100, K=1000) at 1/2/4/8 MI355X"
 PEAK_FP32_MATRIX_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MATRIX_TFLOPS = 2516.6    # v_mfma_f32_32x32x16_bf16: 256 CUs x 4 SIMDs x 512 MAC/clk x 2 x 2.4 GHz ("~2.5 PF dense")
 
 
 def cpu_baseline(corpus, n_utts_total, K, n_slices_max, budget_utts):
@@ -298,7 +299,8 @@ def main():
             # (collected in separate rocprofv3 --pmc runs, gfx950-corrected); only quoted for the
             # workload they were measured on
             traffic = None
-            tpath = os.path.join(ROOT, "profiles", "score_kernel_traffic.json")
+            b3_on = getattr(seg._corpus, "Xb3", None) is not None and os.environ.get("SEGK_SCORE_B3", "1") != "0"
+            tpath = os.path.join(ROOT, "profiles", "score_kernel_traffic_b3.json" if b3_on else "score_kernel_traffic.json")
             if os.path.exists(tpath):
                 tj = json.load(open(tpath))
                 wl = tj["workload"]
@@ -306,14 +308,37 @@ def main():
                         (args.utts, args.landmarks, args.n_slices_max, args.dim, args.K, world):
                     traffic = tj["traffic_bytes_per_launch"]
             achieved = flops_per_launch / (score_ms * 1e-3) / 1e12
-            out["roofline"] = {
-                "bound": "mfma", "kernel": "k_kmeans_score<25, 1, 4, 0> (main launch: %d of %d rows; the last partial "
-                                           "round runs split-K in k_kmeans_score<..., 1>)" % (score_rows, rows_local),
-                "achieved": achieved,
-                "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MATRIX_TFLOPS,
-                "traffic": traffic, "ms_per_launch": score_ms,
-                "flops_per_launch": flops_per_launch,
-            }
+            b3 = getattr(seg._corpus, "Xb3", None) is not None and os.environ.get("SEGK_SCORE_B3", "1") != "0"
+            if b3:
+                # The filter runs as six bf16 products per float32 multiply-add (exact three-way splits of
+                # both operands) on v_mfma_f32_32x32x16_bf16.  `achieved` / `frac` follow
+                # the contract (ALGORITHMIC flops 2*rows*K*D over the kernel's duration, against the dense peak
+                # of the dtype the matrix pipe computes in); the executed_* keys count what the pipe really
+                # does: 6 products x (K padded to 32) x (D padded to 16).
+                kp, kpad = (args.dim + 15) // 16 * 16, (args.K + 31) // 32 * 32
+                executed = 6 * 2.0 * score_rows * kpad * kp
+                ex_tf = executed / (score_ms * 1e-3) / 1e12
+                out["dtype"] = "bf16x3"
+                out["roofline"] = {
+                    "bound": "mfma",
+                    "kernel": "k_kmeans_score_b3<%d, 4> (main launch: %d of %d rows; float32 contraction as three-way "
+                              "bf16 splits, results bit-identical to the float32 reference)" % (kp // 16, score_rows, rows_local),
+                    "achieved": achieved, "peak": PEAK_BF16_MATRIX_TFLOPS, "unit": "TFLOP/s",
+                    "frac": achieved / PEAK_BF16_MATRIX_TFLOPS, "traffic": traffic, "ms_per_launch": score_ms,
+                    "flops_per_launch": flops_per_launch,
+                    "executed_flops_per_launch": executed, "executed_achieved": ex_tf,
+                    "executed_frac": ex_tf / PEAK_BF16_MATRIX_TFLOPS,
+                    "achieved_over_fp32_matrix_peak": achieved / PEAK_FP32_MATRIX_TFLOPS,
+                }
+            else:
+                out["roofline"] = {
+                    "bound": "mfma", "kernel": "k_kmeans_score<25, 1, 4, 0> (main launch: %d of %d rows; the last partial "
+                                               "round runs split-K in k_kmeans_score<..., 1>)" % (score_rows, rows_local),
+                    "achieved": achieved,
+                    "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MATRIX_TFLOPS,
+                    "traffic": traffic, "ms_per_launch": score_ms,
+                    "flops_per_launch": flops_per_launch,
+                }
         if world == 1 and args.cpu_utts > 0:
             out["cpu_baseline"] = cpu_baseline(corpus, args.utts, args.K, args.n_slices_max, args.cpu_utts)
         print(json.dumps(out))
