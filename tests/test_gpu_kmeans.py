@@ -333,3 +333,36 @@ def test_batch_sweep_headline_shape_properties(gpu):
     torch.cuda.synchronize()
     assert torch.equal(again, seg._dev_bounds)
     assert before.shape == again.shape
+
+
+@pytest.mark.parametrize("D,K,scale", [(100, 1000, 1.0), (128, 513, 1.0), (40, 257, 30.0), (16, 64, 1e-3)])
+def test_bf16x3_filter_error_is_far_inside_the_proven_bound(gpu, D, K, scale):
+    """The bf16x3 filter's values against float64: the observed error must sit well inside E1' (the
+    bound assumes one rounding of size u per accumulated product and exact bf16 splits; a factor-4
+    head-room shows that neither assumption is violated by the matrix pipe)."""
+    import torch
+    rs = np.random.RandomState(D + K)
+    n = 4096
+    X = (rs.randn(n, D) * scale).astype(np.float32)            # full 24-bit significands, mixed signs
+    means = (rs.randn(K, D) * scale).astype(np.float32)
+    means[: K // 4] *= 3.0                                      # unequal norms: the constants -|m|^2/2 matter
+    c = _components(X, means)
+    assert c.dev.corpus.Xb3 is not None, "bf16x3 images missing"
+    c.dev.score_rows()
+    torch.cuda.synchronize()
+    ck = c.dev.cand_k.cpu().numpy().astype(np.int64)
+    cf = c.dev.cand_f.cpu().numpy().astype(np.float64)
+    X64, M64 = X.astype(np.float64), means.astype(np.float64)
+    f1 = np.einsum("nd,nd->n", X64, M64[ck]) - 0.5 * (M64[ck] ** 2).sum(1)
+    u = 2.0 ** -24
+    KP = (D + 15) // 16 * 16
+    xn = np.linalg.norm(X64, axis=1)
+    Mmax = np.sqrt((M64 ** 2).sum(1).max())
+    e1 = 1.02 * (KP + 16) * u * (xn * Mmax + 0.5 * Mmax ** 2)
+    ratio = np.abs(cf[:, 0] - f1) / e1
+    assert ratio.max() < 0.25, ratio.max()
+    # and the decisions are the reference's: exact argmax / max after the exact stage
+    from oracle import c_oracle as co
+    mx, am, _ = c.dev.exact_max(np.arange(n))
+    want_mx, want_am = co.kmeans_max_argmax(means, X)
+    assert np.array_equal(am, want_am) and np.array_equal(mx, want_mx)
