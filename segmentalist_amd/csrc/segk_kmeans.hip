@@ -347,21 +347,34 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 2) void k_kmeans_score
     constexpr int STRIDE = (GMAX * 128 + 32 + 1023) / 1024 * 1024;   // == tile_stride (segk_tile_stride)
     constexpr int PASS = WAVES * 256;                                 // floats moved per pass by the workgroup
     constexpr int NPASS = (STRIDE + PASS - 1) / PASS;
-    typedef const __attribute__((address_space(1))) void *gptr_t;
     typedef __attribute__((address_space(3))) void *lptr_t;
     // stage tile `tt` into LDS buffer `buf` with direct global->LDS loads: one wave instruction
     // moves 64 x 16 B = 1 KiB to a wave-uniform base + lane*16, i.e. a straight copy of the image
+    // LDS-DMA issued from inline asm (see k_kmeans_score_b3): outside hipcc's waitcnt bookkeeping, so the
+    // copy of tile t+1 is not drained before the ds_reads of tile t; explicit wait before the barrier.
 #define SEGK_STAGE(tt, buf)                                                                         \
     do {                                                                                            \
         const float *src_ = tiles + (int64_t)(tt) * tile_stride + tid * 4;                          \
-        float *dst_ = lds + (buf) * tile_stride + wave * 256;                                       \
+        const unsigned dst_ = __builtin_amdgcn_readfirstlane(lds_base + ((buf) * tile_stride + wave * 256) * 4); \
         _Pragma("unroll") for (int p = 0; p < NPASS; p++)                                           \
-            if (p * PASS + wave * 256 < STRIDE)       /* wave-uniform: a wave moves 256 floats */   \
-                __builtin_amdgcn_global_load_lds((gptr_t)(src_ + p * PASS), (lptr_t)(dst_ + p * PASS), 16, 0, 0); \
+            if (p * PASS + wave * 256 < STRIDE) {                                                   \
+                unsigned keep_;                                                                     \
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"                 \
+                             "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"                  \
+                             : "=&s"(keep_)                                                         \
+                             : "v"(src_ + p * PASS), "s"(dst_ + p * PASS * 4)                       \
+                             : "memory");                                                           \
+            }                                                                                       \
+    } while (0)
+#define SEGK_TILE_SYNC()                                                      \
+    do {                                                                      \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");           \
+        __builtin_amdgcn_s_barrier();                                         \
     } while (0)
 
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lptr_t)lds);
     SEGK_STAGE(0, 0);
-    __syncthreads();
+    SEGK_TILE_SYNC();
 
     // Software pipeline over the component tiles with two accumulator sets: while the MFMAs of
     // tile t fill one set, the top-2/argmax update (VALU) of tile t-1 drains the other, a slice
@@ -438,7 +451,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 2) void k_kmeans_score
         /* the drained tile was t-1: fix up the tile id where the maximum moved */                    \
         _Pragma("unroll") for (int nb = 0; nb < NB; nb++)                                             \
             itile[nb] = (m1[nb] > m1s[nb]) ? ((t_) - 1) : itile[nb];                                  \
-        if (!(dbg & 2)) __syncthreads();                                                          \
+        SEGK_TILE_SYNC();                                                                         \
     } while (0)
 
     int t = 0;
@@ -465,6 +478,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 2) void k_kmeans_score
     }
 #undef SEGK_TILE
 #undef SEGK_DRAIN
+#undef SEGK_TILE_SYNC
 #undef SEGK_STAGE
     // component index of (tile, row code) on this lane half
     int32_t i1[NB];

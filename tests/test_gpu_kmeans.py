@@ -59,8 +59,11 @@ def test_a1_scores_bit_exact_vs_reference(gpu, golden, case):
 @pytest.mark.parametrize("D,K,n,dtype", [(100, 1000, 4096, "float32"), (39, 100, 3000, "float32"),
                                           (130, 257, 1500, "float32"), (17, 33, 700, "float64"),
                                           (200, 64, 600, "float32"), (300, 40, 300, "float32")])
-def test_a1_max_argmax_vs_oracle_random(gpu, D, K, n, dtype):
+@pytest.mark.parametrize("b3", ["1", "0"], ids=["bf16x3", "fp32mfma"])
+def test_a1_max_argmax_vs_oracle_random(gpu, monkeypatch, D, K, n, dtype, b3):
+    """Both filters (SEGK_SCORE_B3=0 forces the fp32-MFMA one where the bf16x3 one would be chosen)."""
     from oracle import c_oracle as co
+    monkeypatch.setenv("SEGK_SCORE_B3", b3)
     rs = np.random.RandomState(D * 1000 + K)
     K_true = max(2, K // 2)
     mu = rs.randn(K_true, D)
