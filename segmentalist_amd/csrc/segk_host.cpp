@@ -55,6 +55,8 @@ int32_t segk_create(int32_t device_id, segk_ctx **out_ctx)
     SEGK_CHECK_HIP(hipSetDevice(device_id));
     SEGK_CHECK_HIP(hipMalloc((void **)&c->ws_k, sizeof(int32_t) * SEGK_WS_ENTRIES));
     SEGK_CHECK_HIP(hipMalloc((void **)&c->ws_f, sizeof(float) * 2 * SEGK_WS_ENTRIES));
+    SEGK_CHECK_HIP(hipMalloc((void **)&c->ws_u64, sizeof(unsigned long long) * SEGK_WS_ENTRIES));
+    SEGK_CHECK_HIP(hipMemset(c->ws_u64, 0, sizeof(unsigned long long) * SEGK_WS_ENTRIES));
     SEGK_CHECK_HIP(hipSetDevice(prev));
     *out_ctx = c;
     return SEGK_OK;
@@ -65,6 +67,7 @@ int32_t segk_destroy(segk_ctx *ctx)
     if (ctx) {
         if (ctx->ws_k) (void)hipFree(ctx->ws_k);
         if (ctx->ws_f) (void)hipFree(ctx->ws_f);
+        if (ctx->ws_u64) (void)hipFree(ctx->ws_u64);
         for (int i = 0; i < SEGK_PROF_SLOTS; i++)
             for (int j = 0; j < 2; j++)
                 if (ctx->prof_ev[i][j]) (void)hipEventDestroy(ctx->prof_ev[i][j]);

@@ -17,6 +17,7 @@ struct segk_ctx {
     // workspace of the split-K tail of the score stage: k [entries] int32, f [entries][2] float
     int32_t *ws_k;
     float *ws_f;
+    unsigned long long *ws_u64;   // split full scan: (score, component) per queue entry, zero between uses
     // optional timing of the main score launch (segk_profile_*): event pairs used round-robin
     int prof_on, prof_n;
     hipEvent_t prof_ev[SEGK_PROF_SLOTS][2];

@@ -1010,7 +1010,8 @@ __global__ void k_kmeans_brute(segk_corpus c, segk_kmeans m, segk_cand cand, int
 // (row, component) the arithmetic is neg_sqd_exact's: eight strided accumulators, the fixed combine
 // tree, the sequential tail; first maximum per row.
 #define SEGK_BR 8
-__global__ __launch_bounds__(256) void k_kmeans_brute_rows(segk_corpus c, segk_kmeans m, segk_cand cand, int cap, int32_t *n_brute)
+__global__ __launch_bounds__(256) void k_kmeans_brute_rows(segk_corpus c, segk_kmeans m, segk_cand cand, int cap, int32_t *n_brute,
+                                                          int n_groups, int ksplit, unsigned long long *ws, int ws_cap)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, nt = blockDim.x, D = c.D;
@@ -1024,7 +1025,16 @@ __global__ __launch_bounds__(256) void k_kmeans_brute_rows(segk_corpus c, segk_k
     if (blockIdx.x == 0 && tid == 0 && n_brute && nq > 0) atomicAdd(n_brute, nq);
     const int tstride = segk_tile_stride(D);
     const int nfull = D - (D % 8);
-    for (int q0 = blockIdx.x * SEGK_BR; q0 < nq; q0 += gridDim.x * SEGK_BR) {
+    // workgroup = (row group, component slice): the slices of a row meet in ws[] through a 64-bit
+    // atomicMax on (orderable score bits, ~component) -- the largest score, the lowest component on ties;
+    // k_brute_finish unpacks.  Queue entries beyond ws_cap keep the unsplit form (slice 0 scans all).
+    const int grp0 = blockIdx.x % n_groups, slice = blockIdx.x / n_groups;
+    const int k_per = (m.K_max + ksplit - 1) / ksplit;
+    for (int q0 = grp0 * SEGK_BR; q0 < nq; q0 += n_groups * SEGK_BR) {
+        const bool split = ksplit > 1 && q0 + SEGK_BR <= ws_cap;
+        if (!split && slice != 0) continue;
+        const int k_lo = split ? slice * k_per : 0;
+        const int k_hi = split ? (k_lo + k_per < m.K_max ? k_lo + k_per : m.K_max) : m.K_max;
         const int nr = nq - q0 < SEGK_BR ? nq - q0 : SEGK_BR;
         __syncthreads();
         if (tid < SEGK_BR) ids[tid] = cand.queue[q0 + (tid < nr ? tid : nr - 1)];
@@ -1038,7 +1048,7 @@ __global__ __launch_bounds__(256) void k_kmeans_brute_rows(segk_corpus c, segk_k
         int32_t bk[SEGK_BR];
 #pragma unroll
         for (int r = 0; r < SEGK_BR; r++) { best[r] = NEG_INF_F; bk[r] = 0x7fffffff; }
-        for (int k = tid; k < m.K_max; k += nt) {
+        for (int k = k_lo + tid; k < k_hi; k += nt) {
             const TileRow mr = tile_row(m.tiles, tstride, k);
             float acc[SEGK_BR][8];
             float mv[8];
@@ -1104,10 +1114,36 @@ __global__ __launch_bounds__(256) void k_kmeans_brute_rows(segk_corpus c, segk_k
                     const bool take = (k2 != 0x7fffffff) && (kk == 0x7fffffff || v2 > v || (v2 == v && k2 < kk));
                     if (take) { v = v2; kk = k2; }
                 }
-                cand.k[ids[r]] = kk;
-                cand.s[ids[r]] = (double)v;
+                if (split) {
+                    if (kk != 0x7fffffff) {
+                        const unsigned int bits = __float_as_uint(v);
+                        const unsigned int ord = (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);
+                        atomicMax(&ws[q0 + r], ((unsigned long long)ord << 32) | (unsigned long long)(0xffffffffu - (unsigned)kk));
+                    }
+                } else {
+                    cand.k[ids[r]] = kk;
+                    cand.s[ids[r]] = (double)v;
+                }
             }
         }
+    }
+}
+
+// unpack the split scan's (score, component) pairs into the candidates and clear the workspace
+__global__ void k_brute_finish(segk_cand cand, int cap, unsigned long long *ws, int ws_cap)
+{
+    int nq = *cand.count;
+    if (nq > cap) nq = cap;
+    // the groups that were scanned in slices: q0 + SEGK_BR <= ws_cap
+    const int lim = nq < (ws_cap / SEGK_BR) * SEGK_BR ? nq : (ws_cap / SEGK_BR) * SEGK_BR;
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < lim; q += gridDim.x * blockDim.x) {
+        const unsigned long long pk = ws[q];
+        ws[q] = 0ull;
+        const unsigned int ord = (unsigned int)(pk >> 32);
+        const unsigned int bits = (ord & 0x80000000u) ? (ord & 0x7fffffffu) : ~ord;
+        const int32_t id = cand.queue[q];
+        cand.k[id] = (int32_t)(0xffffffffu - (unsigned int)(pk & 0xffffffffu));
+        cand.s[id] = (double)__uint_as_float(bits);
     }
 }
 
@@ -2449,7 +2485,7 @@ int32_t segk_kmeans_filter(segk_ctx *ctx, const segk_corpus *c, const segk_kmean
 int32_t segk_kmeans_resolve(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m, const int32_t *ids,
                             int64_t row0, int64_t n, const segk_cand *cand, int32_t *status, void *stream)
 {
-    (void)ctx;
+    SEGK_REQUIRE(ctx, "ctx");
     int rc = score_checks(c, m, ids, row0, n, cand);
     if (rc) return rc;
     if (n <= 0) return SEGK_OK;
@@ -2459,12 +2495,25 @@ int32_t segk_kmeans_resolve(segk_ctx *ctx, const segk_corpus *c, const segk_kmea
         DISPATCH_XT(c, hipLaunchKernelGGL(k_kmeans_exact_fill<XT>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
                                            *c, *m, ids, row0, n, *cand););
     const int nt = 256;
-    if (fused) {         // float32 data, 8 <= D <= 128: SEGK_BR queued rows per workgroup
+    if (fused) {         // float32 data, 8 <= D <= 128: SEGK_BR queued rows per workgroup, components in slices
         const size_t lds = (size_t)SEGK_BR * c->D * sizeof(float) + nt * (sizeof(float) + sizeof(int32_t));
         const int64_t groups = (n + SEGK_BR - 1) / SEGK_BR;
-        const int64_t grid = groups < 2048 ? groups : 2048;
-        hipLaunchKernelGGL(k_kmeans_brute_rows, dim3((unsigned)grid), dim3(nt), lds, st, *c, *m, *cand, (int)c->n_emb,
-                           status ? status + 1 : nullptr);
+        const int n_groups = (int)(groups < 1024 ? groups : 1024);
+        // Few row groups (one utterance of the serial chain, a small shard): slice the components so that
+        // more workgroups share the scan -- one component per thread and slice, up to eight slices.  With
+        // hundreds of groups the chip is full anyway and slicing only repeats the per-group overhead
+        // (measured: 53 -> 77 us on the bench queue), so those launches stay unsliced.
+        int ksplit = 1;
+        if (groups < 256) {
+            ksplit = (m->K_max + nt - 1) / nt;
+            if (ksplit > 8) ksplit = 8;
+            if (ksplit < 1) ksplit = 1;
+        }
+        hipLaunchKernelGGL(k_kmeans_brute_rows, dim3((unsigned)(n_groups * ksplit)), dim3(nt), lds, st, *c, *m, *cand,
+                           (int)c->n_emb, status ? status + 1 : nullptr, n_groups, ksplit, ctx->ws_u64, SEGK_WS_ENTRIES);
+        if (ksplit > 1)
+            hipLaunchKernelGGL(k_brute_finish, dim3((unsigned)(n_groups < 256 ? (n_groups * SEGK_BR + 255) / 256 : 32)), dim3(256),
+                               0, st, *cand, (int)c->n_emb, ctx->ws_u64, SEGK_WS_ENTRIES);
     } else {
         size_t xsz = (c->x_dtype == SEGK_F32 ? 4 : 8) * (size_t)((c->D + 1) & ~1);
         size_t lds = nt * sizeof(double) + xsz + nt * sizeof(int32_t);
