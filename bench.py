@@ -299,7 +299,7 @@ def main():
             # (collected in separate rocprofv3 --pmc runs, gfx950-corrected); only quoted for the
             # workload they were measured on
             traffic = None
-            b3_on = getattr(seg._corpus, "Xb3", None) is not None and os.environ.get("SEGK_SCORE_B3", "1") != "0"
+            b3_on = getattr(seg._corpus, "Xb3", None) is not None and os.environ.get("SEGK_SCORE_B3", "2") != "0"
             tpath = os.path.join(ROOT, "profiles", "score_kernel_traffic_b3.json" if b3_on else "score_kernel_traffic.json")
             if os.path.exists(tpath):
                 tj = json.load(open(tpath))
@@ -308,21 +308,24 @@ def main():
                         (args.utts, args.landmarks, args.n_slices_max, args.dim, args.K, world):
                     traffic = tj["traffic_bytes_per_launch"]
             achieved = flops_per_launch / (score_ms * 1e-3) / 1e12
-            b3 = getattr(seg._corpus, "Xb3", None) is not None and os.environ.get("SEGK_SCORE_B3", "1") != "0"
+            b3 = getattr(seg._corpus, "Xb3", None) is not None and os.environ.get("SEGK_SCORE_B3", "2") != "0"
             if b3:
-                # The filter runs as six bf16 products per float32 multiply-add (exact three-way splits of
-                # both operands) on v_mfma_f32_32x32x16_bf16.  `achieved` / `frac` follow
+                # The filter runs as three fp16 (or six bf16) products per float32 multiply-add on
+                # v_mfma_f32_32x32x16_{f16,bf16} (splits of both operands).  `achieved` / `frac` follow
                 # the contract (ALGORITHMIC flops 2*rows*K*D over the kernel's duration, against the dense peak
                 # of the dtype the matrix pipe computes in); the executed_* keys count what the pipe really
-                # does: 6 products x (K padded to 32) x (D padded to 16).
+                # does: 3 (6) products x (K padded to 32) x (D padded to 16).
                 kp, kpad = (args.dim + 15) // 16 * 16, (args.K + 31) // 32 * 32
-                executed = 6 * 2.0 * score_rows * kpad * kp
+                pieces = int(seg._corpus.c.sp_pieces)
+                n_prod = 3 if pieces == 2 else 6
+                executed = n_prod * 2.0 * score_rows * kpad * kp
                 ex_tf = executed / (score_ms * 1e-3) / 1e12
-                out["dtype"] = "bf16x3"
+                out["dtype"] = "fp16x2" if pieces == 2 else "bf16x3"
                 out["roofline"] = {
                     "bound": "mfma",
-                    "kernel": "k_kmeans_score_b3<%d, 4> (main launch: %d of %d rows; float32 contraction as three-way "
-                              "bf16 splits, results bit-identical to the float32 reference)" % (kp // 16, score_rows, rows_local),
+                    "kernel": "k_kmeans_score_sp<%d, 4, %d> (main launch: %d of %d rows; float32 contraction as %s "
+                              "splits on the 16-bit matrix pipe, results bit-identical to the float32 reference)"
+                              % (kp // 16, pieces, score_rows, rows_local, "two-way fp16" if pieces == 2 else "three-way bf16"),
                     "achieved": achieved, "peak": PEAK_BF16_MATRIX_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / PEAK_BF16_MATRIX_TFLOPS, "traffic": traffic, "ms_per_launch": score_ms,
                     "flops_per_launch": flops_per_launch,

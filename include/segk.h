@@ -72,17 +72,22 @@ typedef struct segk_corpus {
     const int32_t *lengths;  /* [dev] [n_utt] landmarks per utterance                         */
     int32_t n_utt;
     int32_t N_max;           /* max landmarks; tri = N_max (N_max+1)/2                        */
-    const void *Xb3;         /* [dev] optional (float32 data, D <= 128): the rows as three bf16 pieces,
-                                [n_emb, 3, KP] bf16 with KP = D rounded up to 16, written by
-                                segk_corpus_prepare_b3; enables the bf16x3 k-means filter (NULL: fp32 MFMA) */
+    const void *Xb3;         /* [dev] optional (float32 data, 8 <= D <= 128): the rows split into 16-bit pieces
+                                (segk_corpus_b3_bytes bytes, written by segk_corpus_prepare_b3); enables the
+                                split-precision k-means filter on the 16-bit matrix pipe (NULL: fp32 MFMA)  */
+    int32_t sp_pieces;       /* 2 = fp16x2, 3 = bf16x3: what Xb3 holds                        */
+    int32_t pad_;
 } segk_corpus;
 
 /* Fill the derived members of a corpus: X32 (when X is float64 or ldx != ld32 the caller
  * passes a separate [n_emb, ld32] float buffer, written here) and xnorm. */
 int32_t segk_corpus_prepare(segk_ctx *ctx, const segk_corpus *c, float *X32_out, float *xnorm_out,
                             void *stream);
-/* Xb3_out [dev] [n_emb, 3, KP] bf16 (2 bytes each): x = x1 + x2 + x3 exactly, piece p at [.., p, ..] */
-int32_t segk_corpus_prepare_b3(segk_ctx *ctx, const segk_corpus *c, void *Xb3_out, void *stream);
+/* Xb3_out [dev] segk_corpus_b3_bytes(n_emb, D) bytes.  pieces = 3: x = x1 + x2 + x3 exactly in bf16;
+ * pieces = 2: 2^a x = x1 + 2^-11 x2 (+ two dropped bits) in fp16, a chosen from max |x|. */
+int64_t segk_corpus_b3_bytes(int64_t n_emb, int32_t D);
+int32_t segk_corpus_prepare_b3(segk_ctx *ctx, const segk_corpus *c, void *Xb3_out, int32_t pieces,
+                               void *stream);
 
 /* -------------------------------------------------------------------------------------
  * k-means components: device image of `KMeansComponents` (kmeans_components.py:18-91).

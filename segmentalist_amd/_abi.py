@@ -24,7 +24,7 @@ class Corpus(C.Structure):
         ("X", C.c_void_p), ("X32", C.c_void_p), ("x_dtype", C.c_int32), ("D", C.c_int32),
         ("n_emb", C.c_int64), ("ldx", C.c_int64), ("ld32", C.c_int64), ("xnorm", C.c_void_p),
         ("vec_ids", C.c_void_p), ("durations", C.c_void_p), ("lengths", C.c_void_p),
-        ("n_utt", C.c_int32), ("N_max", C.c_int32), ("Xb3", C.c_void_p),
+        ("n_utt", C.c_int32), ("N_max", C.c_int32), ("Xb3", C.c_void_p), ("sp_pieces", C.c_int32), ("pad_", C.c_int32),
     ]
 
 
@@ -120,7 +120,8 @@ SIGNATURES = {
     "segk_fbb_lm_apply": (_i32, [_P, _CP, _FP, _BP, _i32, _i32, _P]),
     "segk_fbb_lm_fill": (_i32, [_P, _CP, _FP, _BP, _i32, _i32, _i32, _P, _P, _P, _P]),
     "segk_fbb_canonical": (_i32, [_P, _CP, _FP, _BP, _P, _P]),
-    "segk_corpus_prepare_b3": (_i32, [_P, _CP, _P, _P]),
+    "segk_corpus_prepare_b3": (_i32, [_P, _CP, _P, _i32, _P]),
+    "segk_corpus_b3_bytes": (_i64, [_i64, _i32]),
     "segk_kmeans_tiles_b3_floats": (_i64, [_i32, _i32]),
     "segk_profile_enable": (_i32, [_P, _i32]),
     "segk_profile_read": (_i32, [_P, _P, _P, _i32]),

@@ -79,14 +79,18 @@ static inline __host__ __device__ int segk_tile_stride(int D)
 static inline __host__ __device__ int segk_n_tiles(int K_max) { return (K_max + 31) / 32; }
 
 // ---------------------------------------------------------------------------------------
-// bf16x3 operand images of the k-means filter (float32 data, D <= 128).  Every float32 is the
-// exact sum of three bf16 pieces x = x1 + x2 + x3 (8 significand bits each).
-//   rows   Xb3 [n_emb][3][KP] bf16, KP = D rounded up to 16 (zero padded)
-//   tiles  per tile of 32 components: bf16 [s][p][lane 64][8], s < KS = KP/16 (k-step), p < 3
-//          (piece): piece p of M[32*tile + (lane & 31)][16 s + 8 (lane >> 5) + i], i < 8 -- the A
-//          operand of v_mfma_f32_32x32x16_bf16 as one 16-byte load per lane; followed, at float
-//          offset KS*768, by 32 floats -|m|^2/2 (-3e38 beyond K_max); padded to 1024 floats.
+// Operand images of the split-precision k-means filter (float32 data, 8 <= D <= 128; segk_kmeans.hip).
+// P = 3: three bf16 pieces, x = x1 + x2 + x3 exactly.  P = 2: two fp16 pieces of 2^a x (power-of-two
+// scaling), the second one carried at 2^11 times its weight.
+//   rows   [SEGK_SP_HEADER bytes: int32 {P, exponent a, bits of max |x_d|}] then [n_emb][P][KP] 16-bit
+//          pieces, KP = D rounded up to 16 (zero padded, dimensions permuted by segk_b3_dim)
+//   tiles  [1024 floats header: int32 exponent b at [0]] then per tile of 32 components:
+//          16-bit [s][p][lane 64][8], s < KS = KP/16 (k-step), p < P (piece): piece p of
+//          2^b M[32*tile + (lane & 31)][segk_b3_dim(16 s + 8 (lane >> 5) + i)], i < 8 -- the A operand of
+//          v_mfma_f32_32x32x16_{f16,bf16} as one 16-byte load per lane; followed, at float offset KS*P*256,
+//          by 32 floats -2^(a+b) |m|^2/2 (-3e38 beyond K_max); padded to a multiple of 1024 floats.
 // ---------------------------------------------------------------------------------------
+#define SEGK_SP_HEADER 64
 // Slot -> dimension inside a 16-wide k-step: slot q = 8h + i (h = lane half, i < 8) carries dimension
 // 8 (i >> 2) + 4 h + (i & 3): each lane half owns the dimensions d with (d mod 8) in {4h .. 4h+3} of
 // both 8-blocks of the step -- four complete strided accumulators of numpy's pairwise sum, so the
@@ -98,9 +102,9 @@ static inline __host__ __device__ int segk_b3_dim(int pos)       // position in 
     return (pos & ~15) + 8 * (i >> 2) + 4 * h + (i & 3);
 }
 static inline __host__ __device__ int segk_b3_kp(int D) { return (D + 15) & ~15; }
-static inline __host__ __device__ int segk_b3_tile_stride(int D)
+static inline __host__ __device__ int segk_sp_tile_stride(int D, int P)
 {
-    return ((segk_b3_kp(D) / 16) * 768 + 32 + 1023) / 1024 * 1024;
+    return ((segk_b3_kp(D) / 16) * P * 256 + 32 + 1023) / 1024 * 1024;
 }
 
 // segk_kmeans.hip: the MFMA score kernel in log-sum-exp mode (used by segk_fbbatch.hip); not ABI

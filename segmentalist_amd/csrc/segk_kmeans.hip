@@ -281,7 +281,8 @@ struct ScoreArgs {
     // MODE = 1 (log-sum-exp over the components instead of the top-2): out[row] = ln2 * log2 sum_k 2^acc - lse_norm
     double *lse_out;
     double lse_norm;
-    const float *means32;        /* bf16x3 filter: float32 `means` for the fused exact score of the winner */
+    const float *means32;        /* split-precision filter: float32 `means` and rows for the fused exact score */
+    const float *xrows32;
 };
 
 // SPLIT = 0: the whole component range per workgroup, winner + margin test + fused exact score.
@@ -576,72 +577,139 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 2) void k_kmeans_score
 }
 
 // ======================================================================================
-// bf16x3 filter (float32 data, D <= 128).  f[k] = x.m_k - |m_k|^2/2 as above, but the contraction
-// runs on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16: 16x the MAC rate of 32x32x2_f32): with
-// x = x1+x2+x3 and m = m1+m2+m3 exact bf16 splits, x.m = sum_ij xi.mj, and products of two bf16
-// are exact in float32.  The six products with i + j <= 4 are kept: m1.x1 accumulates in its own
-// chain (seeded with -|m|^2/2; KP/16 MFMAs = KP roundings at worst), the five small ones
-// (|.| <= 2^-7 |x||m| in total) in a second chain whose rounding error is negligible, the three
-// dropped ones are bounded by 2u |x| M.  The margin below which two filter values cannot be
-// ordered becomes (filter_tau_b3)
-//     E1' = 1.02 (KP + 16) u (|x| M + M^2/2)        (fp32 chain: (D4 + 3) u (...))
-// with E2 (the reference's own rounding) unchanged -- the filter stays only a filter, every
-// decision it cannot make with certainty goes to the exact stage.
+// Split-precision filter (float32 data, 8 <= D <= 128).  f[k] = x.m_k - |m_k|^2/2 as above, but the
+// contraction runs on the 16-bit matrix pipe (v_mfma_f32_32x32x16_{f16,bf16}: 16x the MAC rate of
+// 32x32x2_f32) on exact or almost exact splits of the float32 operands.  Products of two 16-bit
+// pieces are exact in float32.
+//
+//   P = 3, bf16x3:  x = x1 + x2 + x3 exactly (8 significand bits each).  Kept: m1.x1 in its own
+//       chain (seeded with -|m|^2/2; KP/16 MFMAs, KP roundings at worst), the five products of level
+//       2^-8 and 2^-16 in a second chain whose rounding error is negligible; dropped: the three of
+//       level <= 2^-24, bounded by 2u |x| M.  Six MFMAs per k-step.
+//   P = 2, fp16x2 (default):  x' = 2^a x, m' = 2^b m with powers of two chosen so that the largest
+//       element sits in [2^12, 2^13) (exact scaling, well inside fp16's range; the means' exponent
+//       follows max|m| at every prepare).  x' = x1 + 2^-11 x2 + r with x1 = fp16(x'),
+//       x2 = fp16(2^11 (x' - x1)), |r| <= 2^-22 |x'| (two of the 24 significand bits are dropped).
+//       Kept: m1.x1 (main chain) and m1.x2 + m2.x1 (second chain, carried at 2^11 times its weight so
+//       that the small pieces stay normal numbers; multiplied by 2^-11 when read); dropped: m2.x2 and
+//       the r terms, bounded by 9u |x| M.  Three MFMAs per k-step -- half the matrix work of bf16x3.
+//       Elements below 2^-26 of the largest one are subnormal in fp16 (or flushed): their absolute
+//       error is below 2^-39 of |x|max |m|max per dimension, orders below the margin.
+//
+// The margin below which two filter values cannot be ordered (filter_tau_sp):
+//     E1' = (1.02 (KP + 16) + 10 [P = 2]) u (|x| M + M^2/2)      (fp32 chain: (D4 + 3) u (...))
+// with E2 (the reference's own rounding) unchanged -- the filter stays only a filter, every decision
+// it cannot make with certainty goes to the exact stage.  tests/test_gpu_kmeans.py checks that the
+// observed error stays under a quarter of E1'.
 // Layouts: segk_internal.h.  Structure as k_kmeans_score: rows register-resident as the B operand
-// (three pieces), component tiles double-buffered in LDS via global_load_lds, two accumulator sets
-// so that the top-2 update of tile t-1 drains under the MFMAs of tile t.
+// (P pieces), component tiles double-buffered in LDS, two accumulator sets so that the top-2 update of
+// tile t-1 drains under the MFMAs of tile t.
 // ======================================================================================
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+template <int P> struct SegkPiece;
+template <> struct SegkPiece<3> {
+    typedef __bf16 T;
+    typedef __bf16 V8 __attribute__((ext_vector_type(8)));
+};
+template <> struct SegkPiece<2> {
+    typedef _Float16 T;
+    typedef _Float16 V8 __attribute__((ext_vector_type(8)));
+};
+template <int P>
+__device__ __forceinline__ f32x16 mfma_piece(typename SegkPiece<P>::V8 a, typename SegkPiece<P>::V8 b, f32x16 c)
+{
+    if constexpr (P == 3) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
 
-__device__ __forceinline__ float filter_tau_b3(float xn, float M, int D, int is_f64)
+__device__ __forceinline__ float filter_tau_sp(float xn, float M, int D, int pieces)
 {
     const float u = 5.9604645e-8f;
     const int KP = (D + 15) & ~15;
-    float e1 = 1.02f * (float)(KP + 16) * u * (xn * M + 0.5f * M * M);
+    float e1 = (1.02f * (float)(KP + 16) + (pieces == 2 ? 10.f : 0.f)) * u * (xn * M + 0.5f * M * M);
     int levels = 0;
     for (int n = D; n > 128; n = (n + 1) / 2) levels++;
     int deff = D < 128 ? D : 128;
-    float c2 = is_f64 ? 1e-6f : (float)(deff / 8 + 13 + 2 * levels);
+    float c2 = (float)(deff / 8 + 13 + 2 * levels);
     float s = xn + M;
     float e2 = c2 * u * s * s;
     return 1.25f * (2.0f * e1 + e2) + 1e-30f;
 }
 
-// x -> three bf16 pieces (round to nearest each time: the residuals are exact in float32)
-__device__ __forceinline__ void split_b3(float x, __bf16 *p1, __bf16 *p2, __bf16 *p3)
+// pieces of one value (already scaled by its power of two for P = 2)
+template <int P>
+__device__ __forceinline__ void split_sp(float x, typename SegkPiece<P>::T *pc)
 {
-    const __bf16 a = (__bf16)x;
-    const float r1 = x - (float)a;
-    const __bf16 b = (__bf16)r1;
-    const float r2 = r1 - (float)b;
-    *p1 = a;
-    *p2 = b;
-    *p3 = (__bf16)r2;
+    typedef typename SegkPiece<P>::T T;
+    if constexpr (P == 3) {
+        const T a = (T)x;
+        const float r1 = x - (float)a;
+        const T b = (T)r1;
+        const float r2 = r1 - (float)b;
+        pc[0] = a;
+        pc[1] = b;
+        pc[2] = (T)r2;
+    } else {
+        const T a = (T)x;
+        const float r1 = x - (float)a;                   // exact
+        pc[0] = a;
+        pc[1] = (T)(r1 * 2048.f);                        // 2^11 r1: exact scaling, then 11 of its <= 13 bits
+    }
 }
 
-__global__ void k_corpus_split_b3(const float *X, int64_t ldx, int64_t n_emb, int D, __bf16 *out)
+// exponent e such that 2^e * vmax lies in [2^12, 2^13); 0 for vmax = 0 / P = 3
+__device__ __forceinline__ int sp_exponent(float vmax)
 {
-    const int KP = segk_b3_kp(D);
+    if (!(vmax > 0.f)) return 0;
+    int ex;
+    frexpf(vmax, &ex);                                   // vmax = f * 2^ex, f in [0.5, 1)
+    return 13 - ex;
+}
+
+// header of the row image: int32 {pieces, exponent a, bits of max |x_d|}
+__global__ void k_corpus_maxabs(const float *X, int64_t ldx, int64_t n_emb, int D, unsigned int *hdr)
+{
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float v = 0.f;
+    if (idx < n_emb * D) v = fabsf(X[(idx / D) * ldx + (idx % D)]);
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    if ((threadIdx.x & 63) == 0 && v > 0.f) atomicMax(hdr + 2, __float_as_uint(v));
+}
+
+template <int P>
+__global__ void k_corpus_split_sp(const float *X, int64_t ldx, int64_t n_emb, int D, unsigned char *img)
+{
+    typedef typename SegkPiece<P>::T T;
+    const int KP = segk_b3_kp(D);
+    int *hdr = (int *)img;
+    const int ea = P == 2 ? sp_exponent(__uint_as_float(((unsigned int *)img)[2])) : 0;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx == 0) { hdr[0] = P; hdr[1] = ea; }
     if (idx >= n_emb * KP) return;
     const int64_t e = idx / KP;
     const int pos = (int)(idx - e * KP), d = segk_b3_dim(pos);
-    const float x = d < D ? X[e * ldx + d] : 0.f;
-    __bf16 a, b, c3;
-    split_b3(x, &a, &b, &c3);
-    __bf16 *row = out + e * 3 * KP;
-    row[pos] = a;
-    row[KP + pos] = b;
-    row[2 * KP + pos] = c3;
+    const float x = d < D ? ldexpf(X[e * ldx + d], ea) : 0.f;
+    T pc[P];
+    split_sp<P>(x, pc);
+    T *row = (T *)(img + SEGK_SP_HEADER) + e * P * KP;
+#pragma unroll
+    for (int q = 0; q < P; q++) row[q * KP + pos] = pc[q];
 }
 
-__global__ void k_kmeans_prepare_b3(const float *means, int K_max, int D, float *tiles)
+// tiles image: [header 1024 floats: int32 exponent b at [0]] then per tile [s][p][lane][8] pieces + 32 constants
+template <int P>
+__global__ void k_kmeans_prepare_sp(const float *means, int K_max, int D, float *tiles, const double *mnorm2,
+                                    const unsigned char *ximg)
 {
+    typedef typename SegkPiece<P>::T T;
     const int tile = blockIdx.x;
     const int KS = segk_b3_kp(D) / 16;
-    const int stride = segk_b3_tile_stride(D);
-    float *T = tiles + (int64_t)tile * stride;
-    __bf16 *Tb = (__bf16 *)T;
+    const int stride = segk_sp_tile_stride(D, P);
+    // max |m_d| <= sqrt(max |m|^2): every block derives the same exponent
+    const int eb = P == 2 ? sp_exponent((float)(sqrt(*mnorm2) * (1.0 + 1e-6))) : 0;
+    const int ea = ((const int *)ximg)[1];
+    if (tile == 0 && threadIdx.x == 0) ((int *)tiles)[0] = eb;
+    float *Tt = tiles + 1024 + (int64_t)tile * stride;
+    T *Tb = (T *)Tt;
     __shared__ double nrm[32];
     {
         const int ci = threadIdx.x >> 3, sub = threadIdx.x & 7;      // 256 threads = 32 x 8
@@ -658,51 +726,56 @@ __global__ void k_kmeans_prepare_b3(const float *means, int K_max, int D, float 
         if (sub == 0) nrm[ci] = s;
     }
     __syncthreads();
-    // one thread per (k-step, lane, i): the three pieces of one mean value
     for (int idx = threadIdx.x; idx < KS * 64 * 8; idx += blockDim.x) {
         const int sidx = idx >> 9, lane = (idx >> 3) & 63, i = idx & 7;
         const int comp = tile * 32 + (lane & 31);
         const int d = segk_b3_dim(16 * sidx + 8 * (lane >> 5) + i);
-        const float v = (comp < K_max && d < D) ? means[(int64_t)comp * D + d] : 0.f;
-        __bf16 a, b, c3;
-        split_b3(v, &a, &b, &c3);
-        Tb[((sidx * 3 + 0) * 64 + lane) * 8 + i] = a;
-        Tb[((sidx * 3 + 1) * 64 + lane) * 8 + i] = b;
-        Tb[((sidx * 3 + 2) * 64 + lane) * 8 + i] = c3;
+        const float v = (comp < K_max && d < D) ? ldexpf(means[(int64_t)comp * D + d], eb) : 0.f;
+        T pc[P];
+        split_sp<P>(v, pc);
+#pragma unroll
+        for (int q = 0; q < P; q++) Tb[((sidx * P + q) * 64 + lane) * 8 + i] = pc[q];
     }
-    for (int idx = threadIdx.x; idx < stride - KS * 768; idx += blockDim.x) {
+    for (int idx = threadIdx.x; idx < stride - KS * P * 256; idx += blockDim.x) {
         float v = 0.f;
         if (idx < 32) {
             const int comp = tile * 32 + idx;
-            v = (comp < K_max) ? (float)(-0.5 * nrm[idx]) : -3.0e38f;
+            // the accumulators live in the scaled domain 2^(a+b) f
+            v = (comp < K_max) ? (float)ldexp(-0.5 * nrm[idx], ea + eb) : -3.0e38f;
         }
-        T[KS * 768 + idx] = v;
+        Tt[KS * P * 256 + idx] = v;
     }
 }
 
-template <int KS, int WAVES>
-__global__ __launch_bounds__(64 * WAVES, 2) void k_kmeans_score_b3(ScoreArgs A)
+template <int KS, int WAVES, int P>
+__global__ __launch_bounds__(64 * WAVES, 2) void k_kmeans_score_sp(ScoreArgs A)
 {
+    typedef typename SegkPiece<P>::T T;
+    typedef typename SegkPiece<P>::V8 V8;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int32_t *__restrict__ ids = A.ids;
     const int64_t row0 = A.row0, n = A.n;
-    const float *__restrict__ tiles = A.tiles;
+    const float *__restrict__ tiles = A.tiles + 1024;
     const int n_tiles = A.n_tiles, D = A.D;
     constexpr int KP = KS * 16;
-    constexpr int STRIDE = (KS * 768 + 32 + 1023) / 1024 * 1024;      // floats per tile image
+    constexpr int STRIDE = (KS * P * 256 + 32 + 1023) / 1024 * 1024;      // floats per tile image
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
+    // scaled domain: accumulators hold 2^(a+b) f (P = 2), unscaled again before anything leaves the kernel
+    const int e_ab = ((const int *)A.X32)[1] + ((const int *)A.tiles)[0];
+    const float unscale = ldexpf(1.f, -e_ab);
+    constexpr float LS = P == 2 ? 1.f / 2048.f : 1.f;
 
-    bf16x8 xb[3][KS];
+    V8 xb[P][KS];
     const int64_t r = ((int64_t)blockIdx.x * WAVES + wave) * 32 + j;
     int32_t rowid = -1;
     if (r < n) rowid = ids ? ids[r] : (int32_t)(row0 + r);
     {
-        const __bf16 *xp = (const __bf16 *)A.X32 + (int64_t)(rowid >= 0 ? rowid : 0) * (3 * KP) + 8 * h;
+        const T *xp = (const T *)((const unsigned char *)A.X32 + SEGK_SP_HEADER) + (int64_t)(rowid >= 0 ? rowid : 0) * (P * KP) + 8 * h;
 #pragma unroll
-        for (int p = 0; p < 3; p++)
+        for (int p = 0; p < P; p++)
 #pragma unroll
-            for (int s = 0; s < KS; s++) xb[p][s] = *reinterpret_cast<const bf16x8 *>(xp + p * KP + 16 * s);
+            for (int s = 0; s < KS; s++) xb[p][s] = *reinterpret_cast<const V8 *>(xp + p * KP + 16 * s);
     }
     float m1 = NEG_INF_F, m2 = NEG_INF_F;
     int32_t irow = 0, itile = 0;
@@ -748,7 +821,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_kmeans_score_b3(ScoreArgs A)
     constexpr int VPS = (16 + KS - 1) / KS;
 #define SEGK_DRAIN(ACCM, ACCL, vi)                                                    \
     do {                                                                              \
-        const float v_ = ACCM[(vi)] + ACCL[(vi)];                                     \
+        const float v_ = ACCM[(vi)] + ACCL[(vi)] * LS;                                \
         asm volatile("v_cmp_ngt_f32 vcc, %3, %0\n\t"                                  \
                      "v_med3_f32 %1, %0, %1, %3\n\t"                                  \
                      "v_max_f32 %0, %0, %3\n\t"                                       \
@@ -760,11 +833,11 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_kmeans_score_b3(ScoreArgs A)
 
 #define SEGK_TILE(NEWM, NEWL, OLDM, OLDL, t_)                                                         \
     do {                                                                                              \
-        const float *T = lds + ((t_) & 1) * STRIDE;                                                   \
-        const __bf16 *Tb = (const __bf16 *)T;                                                         \
+        const float *Tt = lds + ((t_) & 1) * STRIDE;                                                  \
+        const T *Tb = (const T *)Tt;                                                                  \
         if ((t_) + 1 < n_tiles) SEGK_STAGE((t_) + 1, ((t_) + 1) & 1);                                 \
         {                                                                                             \
-            const float *cv = T + KS * 768 + 4 * h;                                                   \
+            const float *cv = Tt + KS * P * 256 + 4 * h;                                              \
             _Pragma("unroll") for (int q = 0; q < 4; q++) {                                           \
                 float4 c4 = *reinterpret_cast<const float4 *>(cv + 8 * q);                            \
                 NEWM[4 * q + 0] = c4.x; NEWM[4 * q + 1] = c4.y; NEWM[4 * q + 2] = c4.z; NEWM[4 * q + 3] = c4.w; \
@@ -772,22 +845,24 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_kmeans_score_b3(ScoreArgs A)
             }                                                                                         \
         }                                                                                             \
         const float m1s = m1;                                                                         \
-        bf16x8 n1 = *reinterpret_cast<const bf16x8 *>(Tb + (0 * 64 + lane) * 8);                      \
-        bf16x8 n2 = *reinterpret_cast<const bf16x8 *>(Tb + (1 * 64 + lane) * 8);                      \
-        bf16x8 n3 = *reinterpret_cast<const bf16x8 *>(Tb + (2 * 64 + lane) * 8);                      \
+        V8 nx[P];                                                                                     \
+        _Pragma("unroll") for (int p = 0; p < P; p++)                                                 \
+            nx[p] = *reinterpret_cast<const V8 *>(Tb + (p * 64 + lane) * 8);                          \
         _Pragma("unroll") for (int s = 0; s < KS; s++) {                                              \
-            const bf16x8 a1 = n1, a2 = n2, a3 = n3;                                                   \
+            V8 a[P];                                                                                  \
+            _Pragma("unroll") for (int p = 0; p < P; p++) a[p] = nx[p];                               \
             if (s + 1 < KS) {          /* operands of the next k-step, in flight under this step's MFMAs */ \
-                n1 = *reinterpret_cast<const bf16x8 *>(Tb + (((s + 1) * 3 + 0) * 64 + lane) * 8);     \
-                n2 = *reinterpret_cast<const bf16x8 *>(Tb + (((s + 1) * 3 + 1) * 64 + lane) * 8);     \
-                n3 = *reinterpret_cast<const bf16x8 *>(Tb + (((s + 1) * 3 + 2) * 64 + lane) * 8);     \
+                _Pragma("unroll") for (int p = 0; p < P; p++)                                         \
+                    nx[p] = *reinterpret_cast<const V8 *>(Tb + (((s + 1) * P + p) * 64 + lane) * 8);  \
             }                                                                                         \
-            NEWM = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, xb[0][s], NEWM, 0, 0, 0);              \
-            NEWL = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, xb[1][s], NEWL, 0, 0, 0);              \
-            NEWL = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, xb[0][s], NEWL, 0, 0, 0);              \
-            NEWL = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, xb[1][s], NEWL, 0, 0, 0);              \
-            NEWL = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, xb[2][s], NEWL, 0, 0, 0);              \
-            NEWL = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, xb[0][s], NEWL, 0, 0, 0);              \
+            NEWM = mfma_piece<P>(a[0], xb[0][s], NEWM);                                               \
+            NEWL = mfma_piece<P>(a[0], xb[1][s], NEWL);                                               \
+            NEWL = mfma_piece<P>(a[1], xb[0][s], NEWL);                                               \
+            if constexpr (P == 3) {                                                                   \
+                NEWL = mfma_piece<P>(a[1], xb[1][s], NEWL);                                           \
+                NEWL = mfma_piece<P>(a[0], xb[P - 1][s], NEWL);                                       \
+                NEWL = mfma_piece<P>(a[P - 1], xb[0][s], NEWL);                                       \
+            }                                                                                         \
             _Pragma("unroll") for (int q = 0; q < VPS; q++)                                           \
                 if (s * VPS + q < 16) SEGK_DRAIN(OLDM, OLDL, s * VPS + q);                            \
         }                                                                                             \
@@ -820,15 +895,16 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_kmeans_score_b3(ScoreArgs A)
     const int32_t i1 = itile * 32 + 4 * h + (irow & 3) + 8 * (irow >> 2);
     const float o1 = __shfl_xor(m1, 32), o2 = __shfl_xor(m2, 32);
     const int oi = __shfl_xor(i1, 32);
-    const float top1 = fmaxf(m1, o1);
-    const float top2 = fmaxf(fminf(m1, o1), fmaxf(m2, o2));
+    const float top1 = fmaxf(m1, o1) * unscale;                    // powers of two: exact
+    const float top2 = fmaxf(fminf(m1, o1), fmaxf(m2, o2)) * unscale;
     const int idx = (o1 > m1 || (o1 == m1 && oi < i1)) ? oi : i1;
     // Fused exact stage for the winner (D a multiple of 4): the reference's float32 -(deltas*deltas).sum()
     // in numpy's pairwise order.  This lane half owns the strided accumulators r_{4h..4h+3} in full
-    // (segk_b3_dim), x is rebuilt exactly from its three pieces, the winner's mean comes from `means`.
+    // (segk_b3_dim); the row and the winner's mean are read as float32 from X32 / `means`.
     float sexact = __builtin_nanf("");
     if (A.fuse_exact) {
         const float *mrow = A.means32 + (int64_t)idx * D + 4 * h;
+        const float *xrow = A.xrows32 + (int64_t)(rowid >= 0 ? rowid : 0) * A.ld32 + 4 * h;
         const int nfull = D & ~7, rem = D & 7;
         float r4[4] = {0.f, 0.f, 0.f, 0.f}, tt[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -838,12 +914,11 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_kmeans_score_b3(ScoreArgs A)
                 const int d0 = 16 * s + 8 * b;                     // this half holds d0 + 4h + {0..3}
                 if (d0 + 4 * h < D) {                              // D % 4 == 0: all four or none
                     const float4 mv = *reinterpret_cast<const float4 *>(mrow + d0);
-                    const float mvv[4] = {mv.x, mv.y, mv.z, mv.w};
+                    const float4 xv = *reinterpret_cast<const float4 *>(xrow + d0);
+                    const float mvv[4] = {mv.x, mv.y, mv.z, mv.w}, xvv[4] = {xv.x, xv.y, xv.z, xv.w};
 #pragma unroll
                     for (int q = 0; q < 4; q++) {
-                        const int i = 4 * b + q;
-                        const float x = ((float)xb[0][s][i] + (float)xb[1][s][i]) + (float)xb[2][s][i];
-                        const float delta = mvv[q] - x;
+                        const float delta = mvv[q] - xvv[q];
                         const float t2 = delta * delta;
                         if (d0 < nfull) r4[q] = (s == 0 && b == 0) ? t2 : r4[q] + t2;
                         else tt[q] = t2;                           // the sequential tail block
@@ -870,7 +945,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_kmeans_score_b3(ScoreArgs A)
         A.cand.f[2 * (int64_t)rowid + 1] = top2;
         A.cand.s[rowid] = (double)sexact;                          // NaN when not fused: k_kmeans_exact_fill
         const float M = (float)(sqrt(*A.mnorm2) * (1.0 + 1e-6)) + 1e-30f;
-        const float tau = filter_tau_b3(A.xnorm[rowid], M, D, 0);
+        const float tau = filter_tau_sp(A.xnorm[rowid], M, D, P);
         if (!(top1 - top2 > tau)) {
             int q = atomicAdd(A.cand.count, 1);
             if (q < A.amb_cap) A.cand.queue[q] = rowid;
@@ -2245,23 +2320,24 @@ static bool segk_use_b3(const segk_corpus *c, const segk_kmeans *m)
 {
     const char *e = getenv("SEGK_SCORE_B3");
     if (e && atoi(e) == 0) return false;
-    return c->Xb3 && m->tiles_b3 && c->x_dtype == SEGK_F32 && c->D >= 8 && c->D <= 128;
+    return c->Xb3 && (c->sp_pieces == 2 || c->sp_pieces == 3) && m->tiles_b3 && c->x_dtype == SEGK_F32 && c->D >= 8 &&
+           c->D <= 128;
 }
 
-// bf16x3 filter: whole rounds (and any larger remainder) to k_kmeans_score_b3, a remainder of fewer
-// than SEGK_TAIL_QUEUE rows to the ambiguity queue; exact winner scores by k_kmeans_exact_fill.
-template <int KS>
-static int launch_score_b3(segk_ctx *ctx, ScoreArgs A, hipStream_t st)
+// split-precision filter: whole rounds (and any larger remainder) to k_kmeans_score_sp, a remainder of
+// fewer than SEGK_TAIL_QUEUE rows to the ambiguity queue.
+template <int KS, int P>
+static int launch_score_sp(segk_ctx *ctx, ScoreArgs A, hipStream_t st)
 {
-    constexpr int STRIDE = (KS * 768 + 32 + 1023) / 1024 * 1024;
+    constexpr int STRIDE = (KS * P * 256 + 32 + 1023) / 1024 * 1024;
     const size_t lds = 2 * (size_t)STRIDE * sizeof(float);
     static int wg_per_cu = 0;
     if (!wg_per_cu) {
         if (lds > 48 * 1024)
-            SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_kmeans_score_b3<KS, 4>,
+            SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_kmeans_score_sp<KS, 4, P>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int occ = 0;
-        SEGK_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)k_kmeans_score_b3<KS, 4>, 256, lds));
+        SEGK_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)k_kmeans_score_sp<KS, 4, P>, 256, lds));
         wg_per_cu = occ > 0 ? occ : 1;
     }
     const int64_t slots = (int64_t)wg_per_cu * ctx->n_cu;
@@ -2278,7 +2354,7 @@ static int launch_score_b3(segk_ctx *ctx, ScoreArgs A, hipStream_t st)
         const bool prof = ctx->prof_on != 0;
         const int slot = ctx->prof_n % SEGK_PROF_SLOTS;
         if (prof) SEGK_CHECK_HIP(hipEventRecord(ctx->prof_ev[slot][0], st));
-        hipLaunchKernelGGL((k_kmeans_score_b3<KS, 4>), dim3((unsigned)main_chunks), dim3(256), lds, st, M);
+        hipLaunchKernelGGL((k_kmeans_score_sp<KS, 4, P>), dim3((unsigned)main_chunks), dim3(256), lds, st, M);
         if (prof) {
             SEGK_CHECK_HIP(hipEventRecord(ctx->prof_ev[slot][1], st));
             ctx->prof_rows[slot] = n_main;
@@ -2294,6 +2370,24 @@ static int launch_score_b3(segk_ctx *ctx, ScoreArgs A, hipStream_t st)
     }
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;
+}
+
+template <int P>
+static int dispatch_score_sp(segk_ctx *ctx, const ScoreArgs &A, int ks, hipStream_t st)
+{
+    switch (ks) {
+        case 1: return launch_score_sp<1, P>(ctx, A, st);
+        case 2: return launch_score_sp<2, P>(ctx, A, st);
+        case 3: return launch_score_sp<3, P>(ctx, A, st);
+        case 4: return launch_score_sp<4, P>(ctx, A, st);
+        case 5: return launch_score_sp<5, P>(ctx, A, st);
+        case 6: return launch_score_sp<6, P>(ctx, A, st);
+        case 7: return launch_score_sp<7, P>(ctx, A, st);
+        case 8: return launch_score_sp<8, P>(ctx, A, st);
+        default: break;
+    }
+    segk_set_error("split-precision filter: D out of range");
+    return SEGK_ERR_UNSUPPORTED;
 }
 
 template <int GMAX>
@@ -2379,28 +2473,49 @@ int32_t segk_kmeans_prepare(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m,
     DISPATCH_XT(c, hipLaunchKernelGGL(k_kmeans_prepare<XT>, dim3(segk_n_tiles(m->K_max)), dim3(256), 0, st,
                                        (const XT *)m->means, m->K_max, c->D, m->tiles,
                                        (unsigned long long *)m->mnorm_max););
-    if (m->tiles_b3 && c->x_dtype == SEGK_F32 && c->D >= 8 && c->D <= 128)
-        hipLaunchKernelGGL(k_kmeans_prepare_b3, dim3(segk_n_tiles(m->K_max)), dim3(256), 0, st, (const float *)m->means,
-                           m->K_max, c->D, m->tiles_b3);
+    if (m->tiles_b3 && c->Xb3 && c->x_dtype == SEGK_F32 && c->D >= 8 && c->D <= 128) {
+        if (c->sp_pieces == 2)
+            hipLaunchKernelGGL(k_kmeans_prepare_sp<2>, dim3(segk_n_tiles(m->K_max)), dim3(256), 0, st, (const float *)m->means,
+                               m->K_max, c->D, m->tiles_b3, m->mnorm_max, (const unsigned char *)c->Xb3);
+        else if (c->sp_pieces == 3)
+            hipLaunchKernelGGL(k_kmeans_prepare_sp<3>, dim3(segk_n_tiles(m->K_max)), dim3(256), 0, st, (const float *)m->means,
+                               m->K_max, c->D, m->tiles_b3, m->mnorm_max, (const unsigned char *)c->Xb3);
+    }
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;
 }
 
 int64_t segk_kmeans_tiles_b3_floats(int32_t K_max, int32_t D)
 {
-    return (int64_t)segk_n_tiles(K_max) * segk_b3_tile_stride(D);
+    return 1024 + (int64_t)segk_n_tiles(K_max) * segk_sp_tile_stride(D, 3);     // sized for either piece count
 }
 
-int32_t segk_corpus_prepare_b3(segk_ctx *ctx, const segk_corpus *c, void *Xb3_out, void *stream)
+int64_t segk_corpus_b3_bytes(int64_t n_emb, int32_t D)
+{
+    return SEGK_SP_HEADER + n_emb * 3 * (int64_t)segk_b3_kp(D) * 2;             // sized for either piece count
+}
+
+int32_t segk_corpus_prepare_b3(segk_ctx *ctx, const segk_corpus *c, void *Xb3_out, int32_t pieces, void *stream)
 {
     (void)ctx;
     int rc = check_corpus(c);
     if (rc) return rc;
     SEGK_REQUIRE(Xb3_out != nullptr, "Xb3_out is NULL");
-    SEGK_REQUIRE(c->x_dtype == SEGK_F32 && c->D >= 8 && c->D <= 128, "the bf16x3 image exists for float32 data with 8 <= D <= 128");
+    SEGK_REQUIRE(pieces == 2 || pieces == 3, "pieces must be 2 (fp16x2) or 3 (bf16x3)");
+    SEGK_REQUIRE(c->x_dtype == SEGK_F32 && c->D >= 8 && c->D <= 128, "the split images exist for float32 data with 8 <= D <= 128");
+    hipStream_t st = (hipStream_t)stream;
+    SEGK_CHECK_HIP(hipMemsetAsync(Xb3_out, 0, SEGK_SP_HEADER, st));
     const int64_t tot = c->n_emb * segk_b3_kp(c->D);
-    hipLaunchKernelGGL(k_corpus_split_b3, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const float *)c->X, c->ldx, c->n_emb, c->D, (__bf16 *)Xb3_out);
+    if (pieces == 2) {
+        const int64_t nx = c->n_emb * c->D;
+        hipLaunchKernelGGL(k_corpus_maxabs, dim3((unsigned)((nx + 255) / 256)), dim3(256), 0, st, (const float *)c->X, c->ldx,
+                           c->n_emb, c->D, (unsigned int *)Xb3_out);
+        hipLaunchKernelGGL(k_corpus_split_sp<2>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, (const float *)c->X,
+                           c->ldx, c->n_emb, c->D, (unsigned char *)Xb3_out);
+    } else {
+        hipLaunchKernelGGL(k_corpus_split_sp<3>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, (const float *)c->X,
+                           c->ldx, c->n_emb, c->D, (unsigned char *)Xb3_out);
+    }
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;
 }
@@ -2446,22 +2561,14 @@ int32_t segk_kmeans_filter(segk_ctx *ctx, const segk_corpus *c, const segk_kmean
     // workgroup, one barrier for all eight waves, locks the SIMD partners in step and is 15 %
     // slower although it halves the staging instructions per wave.)
     if (segk_use_b3(c, m)) {
+        A.xrows32 = c->X32;
         A.X32 = (const float *)c->Xb3;
         A.tiles = m->tiles_b3;
-        A.tile_stride = segk_b3_tile_stride(c->D);
+        A.tile_stride = segk_sp_tile_stride(c->D, c->sp_pieces);
         A.means32 = (const float *)m->means;
         A.fuse_exact = (c->D % 4 == 0) ? 1 : 0;
-        switch (segk_b3_kp(c->D) / 16) {
-            case 1: return launch_score_b3<1>(ctx, A, st);
-            case 2: return launch_score_b3<2>(ctx, A, st);
-            case 3: return launch_score_b3<3>(ctx, A, st);
-            case 4: return launch_score_b3<4>(ctx, A, st);
-            case 5: return launch_score_b3<5>(ctx, A, st);
-            case 6: return launch_score_b3<6>(ctx, A, st);
-            case 7: return launch_score_b3<7>(ctx, A, st);
-            case 8: return launch_score_b3<8>(ctx, A, st);
-            default: break;
-        }
+        return c->sp_pieces == 2 ? dispatch_score_sp<2>(ctx, A, segk_b3_kp(c->D) / 16, st)
+                                 : dispatch_score_sp<3>(ctx, A, segk_b3_kp(c->D) / 16, st);
     }
     // Rows per wave: one 32-row MFMA column block per wave (108 VGPRs, four workgroups per CU) beat
     // two blocks sharing every LDS tile fetch (194 VGPRs, two per CU) at every row count measured

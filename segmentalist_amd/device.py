@@ -87,13 +87,19 @@ class DeviceCorpus(object):
                                              _abi.stream()))
 
     def ensure_b3(self):
-        """The rows as three bf16 pieces (segk_corpus_prepare_b3) for the bf16x3 k-means filter."""
+        """The rows split into 16-bit pieces (segk_corpus_prepare_b3) for the split-precision k-means
+        filter: fp16x2 by default, bf16x3 with SEGK_SCORE_B3=3, none (fp32 MFMA filter) with 0."""
+        import os
+        pieces = int(os.environ.get("SEGK_SCORE_B3", "2") or 2)
+        if pieces not in (2, 3):
+            return False
         if self.Xb3 is None and self.x_dtype == SEGK_F32 and 8 <= self.D <= 128:
             torch = _torch()
-            kp = (self.D + 15) // 16 * 16
-            self.Xb3 = torch.empty((self.n_emb, 3, kp), dtype=torch.bfloat16, device=self.X.device)
-            check(_abi.lib().segk_corpus_prepare_b3(_abi.ctx(), C.byref(self.c), ptr(self.Xb3), _abi.stream()))
+            nbytes = int(_abi.lib().segk_corpus_b3_bytes(self.n_emb, self.D))
+            self.Xb3 = torch.empty(nbytes, dtype=torch.uint8, device=self.X.device)
+            check(_abi.lib().segk_corpus_prepare_b3(_abi.ctx(), C.byref(self.c), ptr(self.Xb3), pieces, _abi.stream()))
             self.c.Xb3 = self.Xb3.data_ptr()
+            self.c.sp_pieces = pieces
         return self.Xb3 is not None
 
     @property

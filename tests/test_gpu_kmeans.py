@@ -59,7 +59,7 @@ def test_a1_scores_bit_exact_vs_reference(gpu, golden, case):
 @pytest.mark.parametrize("D,K,n,dtype", [(100, 1000, 4096, "float32"), (39, 100, 3000, "float32"),
                                           (130, 257, 1500, "float32"), (17, 33, 700, "float64"),
                                           (200, 64, 600, "float32"), (300, 40, 300, "float32")])
-@pytest.mark.parametrize("b3", ["1", "0"], ids=["bf16x3", "fp32mfma"])
+@pytest.mark.parametrize("b3", ["2", "3", "0"], ids=["fp16x2", "bf16x3", "fp32mfma"])
 def test_a1_max_argmax_vs_oracle_random(gpu, monkeypatch, D, K, n, dtype, b3):
     """Both filters (SEGK_SCORE_B3=0 forces the fp32-MFMA one where the bf16x3 one would be chosen)."""
     from oracle import c_oracle as co
@@ -339,18 +339,20 @@ def test_batch_sweep_headline_shape_properties(gpu):
 
 
 @pytest.mark.parametrize("D,K,scale", [(100, 1000, 1.0), (128, 513, 1.0), (40, 257, 30.0), (16, 64, 1e-3)])
-def test_bf16x3_filter_error_is_far_inside_the_proven_bound(gpu, D, K, scale):
-    """The bf16x3 filter's values against float64: the observed error must sit well inside E1' (the
-    bound assumes one rounding of size u per accumulated product and exact bf16 splits; a factor-4
-    head-room shows that neither assumption is violated by the matrix pipe)."""
+@pytest.mark.parametrize("pieces", ["2", "3"], ids=["fp16x2", "bf16x3"])
+def test_split_precision_filter_error_is_far_inside_the_proven_bound(gpu, monkeypatch, D, K, scale, pieces):
+    """The split-precision filter's values against float64: the observed error must sit well inside
+    E1' (the bound assumes one rounding of size u per accumulated product and the stated split
+    residuals; a factor-4 head-room shows that neither assumption is violated by the matrix pipe)."""
     import torch
+    monkeypatch.setenv("SEGK_SCORE_B3", pieces)
     rs = np.random.RandomState(D + K)
     n = 4096
     X = (rs.randn(n, D) * scale).astype(np.float32)            # full 24-bit significands, mixed signs
     means = (rs.randn(K, D) * scale).astype(np.float32)
     means[: K // 4] *= 3.0                                      # unequal norms: the constants -|m|^2/2 matter
     c = _components(X, means)
-    assert c.dev.corpus.Xb3 is not None, "bf16x3 images missing"
+    assert c.dev.corpus.Xb3 is not None and c.dev.corpus.c.sp_pieces == int(pieces), "split images missing"
     c.dev.score_rows()
     torch.cuda.synchronize()
     ck = c.dev.cand_k.cpu().numpy().astype(np.int64)
@@ -361,7 +363,7 @@ def test_bf16x3_filter_error_is_far_inside_the_proven_bound(gpu, D, K, scale):
     KP = (D + 15) // 16 * 16
     xn = np.linalg.norm(X64, axis=1)
     Mmax = np.sqrt((M64 ** 2).sum(1).max())
-    e1 = 1.02 * (KP + 16) * u * (xn * Mmax + 0.5 * Mmax ** 2)
+    e1 = (1.02 * (KP + 16) + (10 if pieces == "2" else 0)) * u * (xn * Mmax + 0.5 * Mmax ** 2)
     ratio = np.abs(cf[:, 0] - f1) / e1
     assert ratio.max() < 0.25, ratio.max()
     # and the decisions are the reference's: exact argmax / max after the exact stage
