@@ -593,11 +593,13 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 2) void k_kmeans_score
 //       Kept: m1.x1 (main chain) and m1.x2 + m2.x1 (second chain, carried at 2^11 times its weight so
 //       that the small pieces stay normal numbers; multiplied by 2^-11 when read); dropped: m2.x2 and
 //       the r terms, bounded by 9u |x| M.  Three MFMAs per k-step -- half the matrix work of bf16x3.
-//       Elements below 2^-26 of the largest one are subnormal in fp16 (or flushed): their absolute
-//       error is below 2^-39 of |x|max |m|max per dimension, orders below the margin.
+//       Scaled elements below 2^-14 (2^-26 of the largest one) are subnormal in fp16; even if the pipe
+//       flushed them all to zero the error would be at most 2^-14 (sum_d |m'_d| + sum_d |x'_d|) <=
+//       2^-14 sqrt(D) (M' + |x'|), i.e. (sqrt(D)/2) u |x| M relative to |x'| M' >= 2^12 max(|x'|, M'):
+//       5.7u for D = 128.  Budget for P = 2: 9u + 5.7u -> 16u.
 //
 // The margin below which two filter values cannot be ordered (filter_tau_sp):
-//     E1' = (1.02 (KP + 16) + 10 [P = 2]) u (|x| M + M^2/2)      (fp32 chain: (D4 + 3) u (...))
+//     E1' = (1.02 (KP + 16) + 16 [P = 2]) u (|x| M + M^2/2)      (fp32 chain: (D4 + 3) u (...))
 // with E2 (the reference's own rounding) unchanged -- the filter stays only a filter, every decision
 // it cannot make with certainty goes to the exact stage.  tests/test_gpu_kmeans.py checks that the
 // observed error stays under a quarter of E1'.
@@ -625,7 +627,7 @@ __device__ __forceinline__ float filter_tau_sp(float xn, float M, int D, int pie
 {
     const float u = 5.9604645e-8f;
     const int KP = (D + 15) & ~15;
-    float e1 = (1.02f * (float)(KP + 16) + (pieces == 2 ? 10.f : 0.f)) * u * (xn * M + 0.5f * M * M);
+    float e1 = (1.02f * (float)(KP + 16) + (pieces == 2 ? 16.f : 0.f)) * u * (xn * M + 0.5f * M * M);
     int levels = 0;
     for (int n = D; n > 128; n = (n + 1) / 2) levels++;
     int deff = D < 128 ? D : 128;

@@ -363,7 +363,7 @@ def test_split_precision_filter_error_is_far_inside_the_proven_bound(gpu, monkey
     KP = (D + 15) // 16 * 16
     xn = np.linalg.norm(X64, axis=1)
     Mmax = np.sqrt((M64 ** 2).sum(1).max())
-    e1 = (1.02 * (KP + 16) + (10 if pieces == "2" else 0)) * u * (xn * Mmax + 0.5 * Mmax ** 2)
+    e1 = (1.02 * (KP + 16) + (16 if pieces == "2" else 0)) * u * (xn * Mmax + 0.5 * Mmax ** 2)
     ratio = np.abs(cf[:, 0] - f1) / e1
     assert ratio.max() < 0.25, ratio.max()
     # and the decisions are the reference's: exact argmax / max after the exact stage
@@ -371,3 +371,36 @@ def test_split_precision_filter_error_is_far_inside_the_proven_bound(gpu, monkey
     mx, am, _ = c.dev.exact_max(np.arange(n))
     want_mx, want_am = co.kmeans_max_argmax(means, X)
     assert np.array_equal(am, want_am) and np.array_equal(mx, want_mx)
+
+
+@pytest.mark.parametrize("pieces", ["2", "3"], ids=["fp16x2", "bf16x3"])
+def test_split_precision_filter_wide_dynamic_range(gpu, monkeypatch, pieces):
+    """Rows and means whose elements span nine decades (most of them subnormal or flushed in fp16 after
+    the power-of-two scaling), a corpus-wide scale far from 1, duplicated means: the decisions after the
+    exact stage are still the reference's, bit for bit, and the filter error stays inside the bound."""
+    import torch
+    from oracle import c_oracle as co
+    monkeypatch.setenv("SEGK_SCORE_B3", pieces)
+    rs = np.random.RandomState(99)
+    n, D, K = 3000, 64, 200
+    for scale in (1.0, 3e-4, 7e3):
+        X = (rs.randn(n, D) * 10.0 ** rs.uniform(-9, 0, size=(n, D)) * scale).astype(np.float32)
+        means = (rs.randn(K, D) * 10.0 ** rs.uniform(-9, 0, size=(K, D)) * scale).astype(np.float32)
+        means[7] = means[3]                                   # exact duplicate: ties go to the lowest index
+        X[11] = means[3]
+        c = _components(X, means)
+        assert c.dev.corpus.c.sp_pieces == int(pieces)
+        mx, am, nbrute = c.dev.exact_max(np.arange(n))
+        want_mx, want_am = co.kmeans_max_argmax(means, X)
+        assert np.array_equal(am, want_am) and np.array_equal(mx, want_mx)
+        assert am[11] == 3
+        ck = c.dev.cand_k.cpu().numpy().astype(np.int64)
+        cf = c.dev.cand_f.cpu().numpy().astype(np.float64)
+        X64, M64 = X.astype(np.float64), means.astype(np.float64)
+        f1 = np.einsum("nd,nd->n", X64, M64[ck]) - 0.5 * (M64[ck] ** 2).sum(1)
+        u = 2.0 ** -24
+        xn = np.linalg.norm(X64, axis=1)
+        Mmax = np.sqrt((M64 ** 2).sum(1).max())
+        e1 = (1.02 * (64 + 16) + (16 if pieces == "2" else 0)) * u * (xn * Mmax + 0.5 * Mmax ** 2)
+        sel = np.isfinite(cf[:, 0])
+        assert (np.abs(cf[sel, 0] - f1[sel]) / e1[sel]).max() < 0.5
