@@ -670,11 +670,17 @@ __device__ __forceinline__ int sp_exponent(float vmax)
 // header of the row image: int32 {pieces, exponent a, bits of max |x_d|}
 __global__ void k_corpus_maxabs(const float *X, int64_t ldx, int64_t n_emb, int D, unsigned int *hdr)
 {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ float part[4];
     float v = 0.f;
-    if (idx < n_emb * D) v = fabsf(X[(idx / D) * ldx + (idx % D)]);
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n_emb * D; idx += (int64_t)gridDim.x * blockDim.x)
+        v = fmaxf(v, fabsf(X[(idx / D) * ldx + (idx % D)]));
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    if ((threadIdx.x & 63) == 0 && v > 0.f) atomicMax(hdr + 2, __float_as_uint(v));
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        v = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
+        if (v > 0.f) atomicMax(hdr + 2, __float_as_uint(v));
+    }
 }
 
 template <int P>
@@ -1598,35 +1604,39 @@ __global__ void k_batch_collect(segk_corpus c, segk_kmeans m, int lo, int hi, co
                                 const int32_t *n_new, const int32_t *n_flag, int32_t *tok_off,
                                 int32_t *flag_buf, int cap)
 {
-    __shared__ int s_cnt, s_tok;
+    // every thread owns a run of `per` consecutive utterances: local sums, ONE workgroup scan of the
+    // 1024 run totals (wave scan + 16 wave totals), then the run is walked again with its offsets
     __shared__ int s_wave[16], s_wave2[16];
     const int tid = threadIdx.x, nt = blockDim.x;
     const int lane = tid & 63, wv = tid >> 6, nw = nt >> 6;
     const int K = *m.K;
-    if (tid == 0) { s_cnt = 0; s_tok = 0; }
+    const int n = hi - lo;
+    const int per = (n + nt - 1) / nt;
+    const int u_lo = lo + tid * per, u_hi = (u_lo + per < hi) ? u_lo + per : hi;
+    int mine = 0, ntok = 0;
+    for (int u = u_lo; u < u_hi; u++) { ntok += n_new[u]; mine += n_flag[u]; }
+    int incl = mine, incl2 = ntok;
+    for (int o = 1; o < 64; o <<= 1) {
+        int v = __shfl_up(incl, o), v2 = __shfl_up(incl2, o);
+        if (lane >= o) { incl += v; incl2 += v2; }
+    }
+    if (lane == 63) { s_wave[wv] = incl; s_wave2[wv] = incl2; }
     __syncthreads();
-    for (int u0 = lo; u0 < hi; u0 += nt) {
-        const int u = u0 + tid;
-        int mine = 0, ntok = 0;
-        if (u < hi) { ntok = n_new[u]; mine = n_flag[u]; }
-        int incl = mine, incl2 = ntok;
-        for (int o = 1; o < 64; o <<= 1) {
-            int v = __shfl_up(incl, o), v2 = __shfl_up(incl2, o);
-            if (lane >= o) { incl += v; incl2 += v2; }
-        }
-        if (lane == 63) { s_wave[wv] = incl; s_wave2[wv] = incl2; }
-        __syncthreads();
-        int woff = 0, woff2 = 0, total = 0, total2 = 0;
-        for (int w2 = 0; w2 < nw; w2++) {
-            if (w2 < wv) { woff += s_wave[w2]; woff2 += s_wave2[w2]; }
-            total += s_wave[w2];
-            total2 += s_wave2[w2];
-        }
-        if (u < hi) tok_off[u - lo] = s_tok + woff2 + incl2 - ntok;
-        if (mine > 0) {
-            int off = s_cnt + woff + incl - mine;
-            for (int t = 0; t < ntok; t++) {
-                int k = new_k[(int64_t)u * c.N_max + t];
+    int woff = 0, woff2 = 0, total = 0, total2 = 0;
+    for (int w2 = 0; w2 < nw; w2++) {
+        if (w2 < wv) { woff += s_wave[w2]; woff2 += s_wave2[w2]; }
+        total += s_wave[w2];
+        total2 += s_wave2[w2];
+    }
+    int off2 = woff2 + incl2 - ntok;          // tokens before this run
+    int off = woff + incl - mine;             // flagged tokens before this run
+    for (int u = u_lo; u < u_hi; u++) {
+        const int nt_u = n_new[u];
+        tok_off[u - lo] = off2;
+        off2 += nt_u;
+        if (n_flag[u] > 0)
+            for (int t = 0; t < nt_u; t++) {
+                const int k = new_k[(int64_t)u * c.N_max + t];
                 if (k >= K) {
                     if (off < cap) {
                         flag_buf[1 + 2 * off] = u * c.N_max + t;
@@ -1635,14 +1645,10 @@ __global__ void k_batch_collect(segk_corpus c, segk_kmeans m, int lo, int hi, co
                     off++;
                 }
             }
-        }
-        __syncthreads();
-        if (tid == 0) { s_cnt += total; s_tok += total2; }
-        __syncthreads();
     }
     if (tid == 0) {
-        flag_buf[0] = s_cnt;
-        tok_off[hi - lo] = s_tok;
+        flag_buf[0] = total;
+        tok_off[n] = total2;
     }
 }
 
@@ -2510,8 +2516,9 @@ int32_t segk_corpus_prepare_b3(segk_ctx *ctx, const segk_corpus *c, void *Xb3_ou
     const int64_t tot = c->n_emb * segk_b3_kp(c->D);
     if (pieces == 2) {
         const int64_t nx = c->n_emb * c->D;
-        hipLaunchKernelGGL(k_corpus_maxabs, dim3((unsigned)((nx + 255) / 256)), dim3(256), 0, st, (const float *)c->X, c->ldx,
-                           c->n_emb, c->D, (unsigned int *)Xb3_out);
+        const int64_t blocks = (nx + 255) / 256;
+        hipLaunchKernelGGL(k_corpus_maxabs, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st, (const float *)c->X,
+                           c->ldx, c->n_emb, c->D, (unsigned int *)Xb3_out);
         hipLaunchKernelGGL(k_corpus_split_sp<2>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, (const float *)c->X,
                            c->ldx, c->n_emb, c->D, (unsigned char *)Xb3_out);
     } else {
@@ -2600,7 +2607,7 @@ int32_t segk_kmeans_resolve(segk_ctx *ctx, const segk_corpus *c, const segk_kmea
     if (n <= 0) return SEGK_OK;
     hipStream_t st = (hipStream_t)stream;
     const bool fused = (c->x_dtype == SEGK_F32 && c->D >= 8 && c->D <= 128);
-    if (!fused || segk_use_b3(c, m))
+    if (!fused || (segk_use_b3(c, m) && c->D % 4 != 0))       // the split-precision epilogue is fused for D % 4 == 0
         DISPATCH_XT(c, hipLaunchKernelGGL(k_kmeans_exact_fill<XT>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
                                            *c, *m, ids, row0, n, *cand););
     const int nt = 256;
