@@ -95,7 +95,7 @@ def main_fbgmm(args):
     if bigram:
         prior = FixedVarPrior(0.002 * np.ones(D), np.zeros(D), 0.002 / 0.05 * np.ones(D))
         seg = baw.BigramAcousticWordseg(K, prior, {"type": "smooth", "intrp_lambda": 0.1, "a": 0.5, "b": 0.5}, *corpus,
-                                        covariance_type="fixed", fb_type="unigram", score_precision="f32", **kw)
+                                        covariance_type="fixed", fb_type="unigram", score_precision=os.environ.get("SEGK_FBB_PRECISION", "f16"), **kw)
     else:
         prior = NIW(np.zeros(D), 0.05, D + 3, 0.002 * (D + 3) * np.ones(D))
         seg = uaw.UnigramAcousticWordseg(fbgmm.FBGMM, 1.0, K, prior, *corpus, covariance_type="diag", fb_type="standard", **kw)
@@ -148,10 +148,23 @@ def main_fbgmm(args):
                 n_rows = float(np.mean(rows[:got]))
                 flops = 2.0 * n_rows * (K + 1) * (2 * D)     # [x^2, x] . [-pp/2, pp*mu] over K_max slots + the empty-slot row
                 achieved = flops / (score_ms * 1e-3) / 1e12
-                out["roofline"] = {"bound": "mfma", "kernel": "k_kmeans_score<50, 1, 4, 0, 1> (log-sum-exp mode, one launch per "
-                                   "Gibbs step)", "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
-                                   "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": None, "ms_per_launch": score_ms,
-                                   "flops_per_launch": flops}
+                if getattr(sw, "score_f16", False):
+                    kp, kpad = (2 * D + 15) // 16 * 16, (K + 1 + 31) // 32 * 32
+                    executed = 3 * 2.0 * n_rows * kpad * kp
+                    ex_tf = executed / (score_ms * 1e-3) / 1e12
+                    out["dtype"] = "fp16x2 span scores, f64 sampling"
+                    out["roofline"] = {"bound": "mfma", "kernel": "k_kmeans_score_sp<%d, 4, 2, 1> (log-sum-exp mode on two-way fp16 "
+                                       "splits, one launch per Gibbs step)" % (kp // 16), "achieved": achieved,
+                                       "peak": PEAK_BF16_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_MATRIX_TFLOPS,
+                                       "traffic": None, "ms_per_launch": score_ms, "flops_per_launch": flops,
+                                       "executed_flops_per_launch": executed, "executed_achieved": ex_tf,
+                                       "executed_frac": ex_tf / PEAK_BF16_MATRIX_TFLOPS,
+                                       "achieved_over_fp32_matrix_peak": achieved / PEAK_FP32_MATRIX_TFLOPS}
+                else:
+                    out["roofline"] = {"bound": "mfma", "kernel": "k_kmeans_score<50, 1, 4, 0, 1> (log-sum-exp mode, one launch per "
+                                       "Gibbs step)", "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
+                                       "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": None, "ms_per_launch": score_ms,
+                                       "flops_per_launch": flops}
             _abi.check(_abi.lib().segk_profile_enable(_abi.ctx(), 0))
         if world == 1 and args.cpu_utts > 0:
             from oracle import np_oracle as no

@@ -417,6 +417,12 @@ typedef struct {
     float *tiles32;               /* [dev] segk_kmeans_tiles_floats(K_max + 1, 2D) floats: operand
                                    * image of the per-slot [-pp/2, pp*mu] rows, written by
                                    * segk_fbb_prepare when non-NULL                               */
+    /* optional fp16x2 form of the same score (2D <= 208): both operands as two fp16 pieces on the
+     * 16-bit matrix pipe, like the k-means filter; needs y and, when non-NULL, supersedes tiles32:  */
+    void *y16;                    /* [dev] segk_corpus_b3_bytes(n_emb, 2D) bytes (segk_fbb_make_y)  */
+    float *tiles16;               /* [dev] segk_kmeans_tiles_b3_floats(K_max + 1, 2D) floats        */
+    float *rows32;                /* [dev] [(K_max + 1), 2D] scratch: the per-slot rows in float32   */
+    double *consts16;             /* [dev] [K_max + 2] scratch: per-slot constants; [K_max + 1] = max |row|^2 */
 } segk_fbatch;
 
 /* token lists of all utterances from the boundaries: new_tok [n_utt, N_max], n_new [n_utt]     */

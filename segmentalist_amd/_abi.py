@@ -43,6 +43,7 @@ class FbatchDev(C.Structure):
         ("mean_t", C.c_void_p), ("q_t", C.c_void_p), ("lconst", C.c_void_p), ("zconst", C.c_void_p),
         ("half", C.c_void_p), ("scal", C.c_void_p), ("slot", C.c_void_p), ("lm_tok", C.c_void_p),
         ("seed", C.c_uint64), ("y", C.c_void_p), ("ldy", C.c_int64), ("tiles32", C.c_void_p),
+        ("y16", C.c_void_p), ("tiles16", C.c_void_p), ("rows32", C.c_void_p), ("consts16", C.c_void_p),
     ]
 
 

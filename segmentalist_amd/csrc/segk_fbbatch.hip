@@ -632,6 +632,50 @@ __global__ void k_fbb_tiles32(segk_fbgmm f, segk_fbatch bt, int D, double prior_
     }
 }
 
+// fp16x2 form: the same per-slot rows and constants as k_fbb_tiles32, written as a plain float32 matrix
+// [(K_max + 1), 2D] (interleaved [-pp/2, pp*mu] * log2 e) plus constants; consts16[K_max + 1] collects the
+// largest squared row norm (the exponent of the fp16 scaling follows it).  segk_sp_prepare_tiles turns
+// them into the operand image of k_kmeans_score_sp<.., 2, 1>.
+__global__ void k_fbb_rows16(segk_fbgmm f, segk_fbatch bt, int D, double prior_alpha)
+{
+    const double LOG2E = 1.4426950408889634;
+    const int KM = f.K_max, D2 = 2 * D;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int k = blockIdx.x * 4 + w;
+    if (k > KM) return;
+    const bool occupied = k < KM && bt.cnt[k] > 0.0;
+    double s = 0.0, n2 = 0.0;
+    for (int d = lane; d < D; d += 64) {
+        double t0 = 0.0, t1 = 0.0;
+        if (occupied) {
+            const double q = bt.q_t[(int64_t)d * KM + k], m = bt.mean_t[(int64_t)d * KM + k];
+            t0 = -0.5 * q * LOG2E;
+            t1 = q * m * LOG2E;
+            s += q * m * m;
+        } else if (k == KM) {
+            t0 = -0.5 * f.prior_c[d] * LOG2E;
+            t1 = f.prior_c[d] * f.prior_b[d] * LOG2E;
+            s += f.prior_c[d] * f.prior_b[d] * f.prior_b[d];
+        }
+        const float r0 = (float)t0, r1 = (float)t1;
+        bt.rows32[(int64_t)k * D2 + 2 * d] = r0;
+        bt.rows32[(int64_t)k * D2 + 2 * d + 1] = r1;
+        n2 += (double)r0 * r0 + (double)r1 * r1;
+    }
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); n2 += __shfl_xor(n2, o); }
+    if (lane == 0) {
+        const double norm = f.lms * log(bt.scal[0] + prior_alpha);
+        double v = -3.0e38;
+        if (occupied) v = (bt.zconst[k] - 0.5 * s - norm) * LOG2E;
+        else if (k == KM) {
+            const double n_empty = (double)KM - bt.scal[1];
+            if (n_empty > 0.0) v = (f.lms * log(prior_alpha / (double)KM) + log(n_empty) + f.kconst[KM] - 0.5 * s - norm) * LOG2E;
+        }
+        bt.consts16[k] = v;
+        atomicMax((unsigned long long *)&bt.consts16[KM + 1], (unsigned long long)__double_as_longlong(n2));
+    }
+}
+
 // ======================================================================================
 // C ABI
 // ======================================================================================
@@ -710,6 +754,14 @@ int32_t segk_fbb_prepare(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *
     SEGK_CHECK_HIP(hipMemsetAsync(bt->scal, 0, 2 * sizeof(double), st));
     const double alpha = f->lm_unigram ? f->lm_a : f->alpha;
     hipLaunchKernelGGL(k_fbb_prepare, dim3((f->K_max + 3) / 4), dim3(256), 0, st, *f, *bt, c->D, b, alpha);
+    if (bt->tiles16 && bt->y16 && f->cov_type == 0) {
+        SEGK_REQUIRE(bt->rows32 && bt->consts16, "rows32 / consts16 scratch missing");
+        SEGK_CHECK_HIP(hipMemsetAsync(bt->consts16 + f->K_max + 1, 0, sizeof(double), st));
+        hipLaunchKernelGGL(k_fbb_rows16, dim3((f->K_max + 1 + 3) / 4), dim3(256), 0, st, *f, *bt, c->D, alpha);
+        SEGK_LAUNCH_CHECK();
+        return segk_sp_prepare_tiles(bt->rows32, bt->consts16, bt->consts16 + f->K_max + 1, f->K_max + 1, 2 * c->D,
+                                     bt->tiles16, bt->y16, stream);
+    }
     if (bt->tiles32 && f->cov_type == 0)
         hipLaunchKernelGGL(k_fbb_tiles32, dim3(segk_n_tiles(f->K_max + 1)), dim3(256), 0, st, *f, *bt, c->D, alpha);
     SEGK_LAUNCH_CHECK();
@@ -724,6 +776,10 @@ int32_t segk_fbb_make_y(segk_ctx *ctx, const segk_corpus *c, const segk_fbatch *
     DISPATCH_XT(c, hipLaunchKernelGGL(k_fbb_make_y<XT>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                                        *c, bt->y, bt->ldy););
     SEGK_LAUNCH_CHECK();
+    if (bt->y16) {
+        SEGK_REQUIRE(2 * c->D <= 208, "the fp16x2 span score supports 2D <= 208");
+        return segk_sp_prepare_rows(bt->y, bt->ldy, c->n_emb, 2 * c->D, bt->y16, stream);
+    }
     return SEGK_OK;
 }
 
@@ -733,8 +789,11 @@ int32_t segk_fbb_score_f32(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm
     int rc = check_fbb(c, f, bt);
     if (rc) return rc;
     SEGK_REQUIRE(f->cov_type == 0, "the matrix-core score exists for fixed-variance components only");
-    SEGK_REQUIRE(bt->y && bt->tiles32, "y / tiles32 buffers missing");
+    SEGK_REQUIRE(bt->y && (bt->tiles32 || bt->tiles16), "y / tile buffers missing");
     SEGK_REQUIRE(rows != NULL && n >= 0, "row list");
+    if (bt->tiles16 && bt->y16)
+        return segk_launch_score_lse_sp(ctx, bt->y16, 2 * c->D, rows, 0, n, bt->tiles16, segk_n_tiles(f->K_max + 1), 0.0, score,
+                                        stream);
     return segk_launch_score_lse(ctx, bt->y, bt->ldy, 2 * c->D, rows, 0, n, bt->tiles32, segk_n_tiles(f->K_max + 1), 0.0, score,
                                  stream);
 }

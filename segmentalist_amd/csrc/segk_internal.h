@@ -110,3 +110,10 @@ static inline __host__ __device__ int segk_sp_tile_stride(int D, int P)
 // segk_kmeans.hip: the MFMA score kernel in log-sum-exp mode (used by segk_fbbatch.hip); not ABI
 int segk_launch_score_lse(segk_ctx *ctx, const float *Y, int64_t ldy, int D2, const int32_t *ids, int64_t row0, int64_t n,
                           const float *tiles, int n_tiles, double norm, double *out, void *stream);
+
+// segk_kmeans.hip: fp16x2 images of arbitrary float32 matrices and the log-sum-exp kernel on them
+int segk_sp_prepare_rows(const float *Y, int64_t ldy, int64_t n, int D2, void *img, void *stream);
+int segk_sp_prepare_tiles(const float *rows, const double *consts, const double *rowmax2, int K, int D2, float *tiles_sp,
+                          const void *ximg, void *stream);
+int segk_launch_score_lse_sp(segk_ctx *ctx, const void *ximg, int D2, const int32_t *ids, int64_t row0, int64_t n,
+                             const float *tiles_sp, int n_tiles, double norm, double *out, void *stream);

@@ -704,9 +704,11 @@ __global__ void k_corpus_split_sp(const float *X, int64_t ldx, int64_t n_emb, in
 }
 
 // tiles image: [header 1024 floats: int32 exponent b at [0]] then per tile [s][p][lane][8] pieces + 32 constants
+// consts == NULL: the k-means constants -|m|^2/2; otherwise consts[k] (< -1e37: component absent) -- the
+// log-sum-exp use of the kernel (segk_fbbatch.hip), whose rows are not means.
 template <int P>
 __global__ void k_kmeans_prepare_sp(const float *means, int K_max, int D, float *tiles, const double *mnorm2,
-                                    const unsigned char *ximg)
+                                    const unsigned char *ximg, const double *consts)
 {
     typedef typename SegkPiece<P>::T T;
     const int tile = blockIdx.x;
@@ -749,13 +751,14 @@ __global__ void k_kmeans_prepare_sp(const float *means, int K_max, int D, float 
         if (idx < 32) {
             const int comp = tile * 32 + idx;
             // the accumulators live in the scaled domain 2^(a+b) f
-            v = (comp < K_max) ? (float)ldexp(-0.5 * nrm[idx], ea + eb) : -3.0e38f;
+            if (consts) v = (comp < K_max && consts[comp] > -1e37) ? (float)ldexp(consts[comp], ea + eb) : -3.0e38f;
+            else v = (comp < K_max) ? (float)ldexp(-0.5 * nrm[idx], ea + eb) : -3.0e38f;
         }
         Tt[KS * P * 256 + idx] = v;
     }
 }
 
-template <int KS, int WAVES, int P>
+template <int KS, int WAVES, int P, int MODE = 0>
 __global__ __launch_bounds__(64 * WAVES, 2) void k_kmeans_score_sp(ScoreArgs A)
 {
     typedef typename SegkPiece<P>::T T;
@@ -785,7 +788,9 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_kmeans_score_sp(ScoreArgs A)
 #pragma unroll
             for (int s = 0; s < KS; s++) xb[p][s] = *reinterpret_cast<const V8 *>(xp + p * KP + 16 * s);
     }
-    float m1 = NEG_INF_F, m2 = NEG_INF_F;
+    // MODE 1 (log-sum-exp, base 2, of the UNSCALED accumulator values): m1 / m2 are the running maximum
+    // (finite start) and sum, as in k_kmeans_score
+    float m1 = MODE == 1 ? -3.0e38f : NEG_INF_F, m2 = MODE == 1 ? 0.f : NEG_INF_F;
     int32_t irow = 0, itile = 0;
 
     constexpr int PASS = WAVES * 256;
@@ -829,7 +834,13 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_kmeans_score_sp(ScoreArgs A)
     constexpr int VPS = (16 + KS - 1) / KS;
 #define SEGK_DRAIN(ACCM, ACCL, vi)                                                    \
     do {                                                                              \
-        const float v_ = ACCM[(vi)] + ACCL[(vi)] * LS;                                \
+        float v_ = ACCM[(vi)] + ACCL[(vi)] * LS;                                      \
+        if constexpr (MODE == 1) {                                                    \
+            v_ = fmaxf(v_ * unscale, -3.0e38f);                                       \
+            const float nm_ = vmax_f32(m1, v_);                                       \
+            m2 = m2 * __builtin_amdgcn_exp2f(m1 - nm_) + __builtin_amdgcn_exp2f(v_ - nm_); \
+            m1 = nm_;                                                                 \
+        } else                                                                        \
         asm volatile("v_cmp_ngt_f32 vcc, %3, %0\n\t"                                  \
                      "v_med3_f32 %1, %0, %1, %3\n\t"                                  \
                      "v_max_f32 %0, %0, %3\n\t"                                       \
@@ -900,6 +911,14 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_kmeans_score_sp(ScoreArgs A)
 #undef SEGK_DRAIN
 #undef SEGK_STAGE
 #undef SEGK_TILE_SYNC
+    if constexpr (MODE == 1) {
+        // the two lane halves summed disjoint component subsets of the same row
+        const float om = __shfl_xor(m1, 32), os = __shfl_xor(m2, 32);
+        const float M = fmaxf(m1, om);
+        const float S = m2 * exp2f(m1 - M) + os * exp2f(om - M);
+        if (h == 0 && rowid >= 0) A.lse_out[rowid] = (double)(M + log2f(S)) * 0.6931471805599453 - A.lse_norm;
+        return;
+    }
     const int32_t i1 = itile * 32 + 4 * h + (irow & 3) + 8 * (irow >> 2);
     const float o1 = __shfl_xor(m1, 32), o2 = __shfl_xor(m2, 32);
     const int oi = __shfl_xor(i1, 32);
@@ -2398,6 +2417,79 @@ static int dispatch_score_sp(segk_ctx *ctx, const ScoreArgs &A, int ks, hipStrea
     return SEGK_ERR_UNSUPPORTED;
 }
 
+// ---- split-precision images of arbitrary float32 matrices (internal; used by segk_fbbatch.hip) ----
+int segk_sp_prepare_rows(const float *Y, int64_t ldy, int64_t n, int D2, void *img, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    SEGK_CHECK_HIP(hipMemsetAsync(img, 0, SEGK_SP_HEADER, st));
+    const int64_t nx = n * D2, tot = n * segk_b3_kp(D2);
+    const int64_t blocks = (nx + 255) / 256;
+    hipLaunchKernelGGL(k_corpus_maxabs, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st, Y, ldy, n, D2,
+                       (unsigned int *)img);
+    hipLaunchKernelGGL(k_corpus_split_sp<2>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, Y, ldy, n, D2,
+                       (unsigned char *)img);
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+int segk_sp_prepare_tiles(const float *rows, const double *consts, const double *rowmax2, int K, int D2, float *tiles_sp,
+                          const void *ximg, void *stream)
+{
+    hipLaunchKernelGGL(k_kmeans_prepare_sp<2>, dim3(segk_n_tiles(K)), dim3(256), 0, (hipStream_t)stream, rows, K, D2, tiles_sp,
+                       rowmax2, (const unsigned char *)ximg, consts);
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+template <int KS>
+static int launch_score_lse_sp(segk_ctx *ctx, const ScoreArgs &A, hipStream_t st)
+{
+    constexpr int STRIDE = (KS * 2 * 256 + 32 + 1023) / 1024 * 1024;
+    const size_t lds = 2 * (size_t)STRIDE * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set && lds > 48 * 1024) {
+        SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_kmeans_score_sp<KS, 4, 2, 1>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    const int64_t chunks = (A.n + 127) / 128;
+    const bool prof = ctx && ctx->prof_on != 0;
+    const int slot = prof ? ctx->prof_n % SEGK_PROF_SLOTS : 0;
+    if (prof) SEGK_CHECK_HIP(hipEventRecord(ctx->prof_ev[slot][0], st));
+    hipLaunchKernelGGL((k_kmeans_score_sp<KS, 4, 2, 1>), dim3((unsigned)chunks), dim3(256), lds, st, A);
+    if (prof) {
+        SEGK_CHECK_HIP(hipEventRecord(ctx->prof_ev[slot][1], st));
+        ctx->prof_rows[slot] = A.n;
+        ctx->prof_n++;
+    }
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+// the log-sum-exp score on fp16x2 images: out[row] = ln sum_k 2^(acc_k) - norm, D2 <= 208
+int segk_launch_score_lse_sp(segk_ctx *ctx, const void *ximg, int D2, const int32_t *ids, int64_t row0, int64_t n,
+                             const float *tiles_sp, int n_tiles, double norm, double *out, void *stream)
+{
+    if (n <= 0) return SEGK_OK;
+    ScoreArgs A;
+    memset(&A, 0, sizeof(A));
+    A.X32 = (const float *)ximg; A.ids = ids; A.row0 = row0; A.n = n;
+    A.tiles = tiles_sp; A.n_tiles = n_tiles; A.tile_stride = segk_sp_tile_stride(D2, 2);
+    A.D = D2;
+    A.lse_out = out; A.lse_norm = norm;
+    hipStream_t st = (hipStream_t)stream;
+    switch (segk_b3_kp(D2) / 16) {
+#define SEGK_CASE(k) \
+    case k: return launch_score_lse_sp<k>(ctx, A, st);
+        SEGK_CASE(1) SEGK_CASE(2) SEGK_CASE(3) SEGK_CASE(4) SEGK_CASE(5) SEGK_CASE(6) SEGK_CASE(7) SEGK_CASE(8) SEGK_CASE(9)
+        SEGK_CASE(10) SEGK_CASE(11) SEGK_CASE(12) SEGK_CASE(13)
+#undef SEGK_CASE
+        default: break;
+    }
+    segk_set_error("segk_launch_score_lse_sp: 2D=%d > 208 is not supported", D2);
+    return SEGK_ERR_UNSUPPORTED;
+}
+
 template <int GMAX>
 static int launch_score_lse(segk_ctx *ctx, const ScoreArgs &A, hipStream_t st)
 {
@@ -2484,10 +2576,10 @@ int32_t segk_kmeans_prepare(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m,
     if (m->tiles_b3 && c->Xb3 && c->x_dtype == SEGK_F32 && c->D >= 8 && c->D <= 128) {
         if (c->sp_pieces == 2)
             hipLaunchKernelGGL(k_kmeans_prepare_sp<2>, dim3(segk_n_tiles(m->K_max)), dim3(256), 0, st, (const float *)m->means,
-                               m->K_max, c->D, m->tiles_b3, m->mnorm_max, (const unsigned char *)c->Xb3);
+                               m->K_max, c->D, m->tiles_b3, m->mnorm_max, (const unsigned char *)c->Xb3, (const double *)nullptr);
         else if (c->sp_pieces == 3)
             hipLaunchKernelGGL(k_kmeans_prepare_sp<3>, dim3(segk_n_tiles(m->K_max)), dim3(256), 0, st, (const float *)m->means,
-                               m->K_max, c->D, m->tiles_b3, m->mnorm_max, (const unsigned char *)c->Xb3);
+                               m->K_max, c->D, m->tiles_b3, m->mnorm_max, (const unsigned char *)c->Xb3, (const double *)nullptr);
     }
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;

@@ -562,10 +562,14 @@ class FbgmmBatchSweeper(object):
         torch = _torch()
         dev = _dev()
         self.df, self.group = df, group
-        assert score_precision in ("f64", "f32")
-        if score_precision == "f32" and df.cov_type != 0:
-            raise SegkError("score_precision='f32' (matrix-core span score) exists for fixed-variance components only")
-        self.score_f32 = score_precision == "f32"
+        assert score_precision in ("f64", "f32", "f16")
+        if score_precision != "f64" and df.cov_type != 0:
+            raise SegkError("score_precision='%s' (matrix-core span score) exists for fixed-variance components only"
+                            % score_precision)
+        if score_precision == "f16" and 2 * df.corpus.D > 208:
+            raise SegkError("score_precision='f16' supports D <= 104")
+        self.score_f32 = score_precision in ("f32", "f16")
+        self.score_f16 = score_precision == "f16"
         c = df.corpus
         self.S, self.B = int(n_stat_blocks), int(n_gibbs_blocks)
         rank, world = 0, 1
@@ -622,7 +626,18 @@ class FbgmmBatchSweeper(object):
             self.y = torch.zeros((c.n_emb, ldy), dtype=torch.float32, device=dev)
             self.tiles32 = torch.zeros(int(_abi.lib().segk_kmeans_tiles_floats(K + 1, 2 * D)), dtype=torch.float32,
                                        device=dev)
+        self.y16 = self.tiles16 = self.rows32 = self.consts16 = None
+        if self.score_f16:
+            L = _abi.lib()
+            self.y16 = torch.zeros(int(L.segk_corpus_b3_bytes(c.n_emb, 2 * D)), dtype=torch.uint8, device=dev)
+            self.tiles16 = torch.zeros(int(L.segk_kmeans_tiles_b3_floats(K + 1, 2 * D)), dtype=torch.float32, device=dev)
+            self.rows32 = torch.zeros((K + 1, 2 * D), dtype=torch.float32, device=dev)
+            self.consts16 = torch.zeros(K + 2, dtype=f64, device=dev)
         self.bt = _abi.FbatchDev(
+            y16=self.y16.data_ptr() if self.y16 is not None else None,
+            tiles16=self.tiles16.data_ptr() if self.tiles16 is not None else None,
+            rows32=self.rows32.data_ptr() if self.rows32 is not None else None,
+            consts16=self.consts16.data_ptr() if self.consts16 is not None else None,
             y=self.y.data_ptr() if self.y is not None else None, ldy=ldy,
             tiles32=self.tiles32.data_ptr() if self.tiles32 is not None else None,
             n_slices=self.S, n_blocks=self.B, u_max=self.u_max if df.lm is not None else 0, pad_=0,

@@ -39,9 +39,10 @@ class UnigramAcousticWordseg(object):
         batch-synchronous blocked Gibbs sampler specified in oracle/np_fbgmm_batch.py
         (`n_gibbs_blocks` steps per sweep, statistics summed over `n_stat_blocks` slices, sharded
         over the ranks of `process_group` when torch.distributed is initialised).
-        score_precision="f32" (batch mode, fixed-variance components) evaluates the span scores on
-        the fp32 matrix cores -- within the 1e-4 tolerance of the path, about 5x faster; "f64"
-        reproduces the specification to the last draw."""
+        score_precision="f32" / "f16" (batch mode, fixed-variance components) evaluates the span
+        scores on the matrix cores (fp32 MFMA, or two-way fp16 splits of the fp32 operands on the
+        16-bit pipe) -- within the 1e-4 tolerance of the path, 5x / 10x faster; "f64" reproduces the
+        specification to the last draw."""
         logger.info("Initializing")
         assert sync in ("sequential", "batch")
         self.sync = sync

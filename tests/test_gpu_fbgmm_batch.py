@@ -164,14 +164,15 @@ def test_sequential_after_batch_continues_from_the_materialised_state(gpu):
     assert rec["components"][0] == ref.acoustic_model.components.K
 
 
+@pytest.mark.parametrize("prec", ["f32", "f16"])
 @pytest.mark.parametrize("kind,n_utt,D,K,nmax", [("fixed", 40, 12, 30, 6), ("bigram", 30, 100, 64, 5), ("fixed", 25, 39, 100, 6)])
-def test_matrix_core_span_scores_within_tolerance(gpu, kind, n_utt, D, K, nmax):
+def test_matrix_core_span_scores_within_tolerance(gpu, kind, n_utt, D, K, nmax, prec):
     """score_precision="f32": the MFMA log-sum-exp kernel against the specification's log_marg_i on the
     same state -- 1e-4 relative is the contract of the path (BASELINE north_star); measured ~1e-6."""
     from segmentalist_amd._abi import check, ptr
-    ref, spec, seg = _pair(kind, n_utt, D, K, 123, nmax, 3, 2, score_precision="f32")
+    ref, spec, seg = _pair(kind, n_utt, D, K, 123, nmax, 3, 2, score_precision=prec)
     sw = seg._get_sweeper()
-    assert sw.score_f32
+    assert sw.score_f32 and sw.score_f16 == (prec == "f16")
     sw.enter(seg._dev_bounds)
     L, ctx, cp, fp, bp, st = sw._args()
     worst = worst_abs = 0.0
