@@ -470,7 +470,15 @@ int32_t segk_fbb_segment(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *
 int32_t segk_fbb_assign(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *f,
                         const segk_fbatch *bt, int32_t s_lo, int32_t s_n, int32_t b,
                         const int32_t *n_utts, uint64_t sweep, double anneal_temp,
-                        const int32_t *new_tok, const int32_t *n_new, void *stream);
+                        const int32_t *new_tok, const int32_t *n_new, const float *ll_mat,
+                        int64_t ll_ld, void *stream);
+/* ll_mat of segk_fbb_assign (optional; fixed-variance components with the fp16x2 images): the token
+ * likelihoods come from the matrix-core contraction instead of the fp64 VALU loop.  Row j*N_max + t of
+ * ll_mat [n, ll_ld] belongs to segment t of the j-th utterance of the block (local slices in order);
+ * segk_fbb_token_scores fills it for the row list tok_rows[j*N_max + t] = new_tok[utt_j][t].        */
+int32_t segk_fbb_token_scores(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *f,
+                              const segk_fbatch *bt, const int32_t *tok_rows, int64_t n,
+                              float *ll_mat, int64_t ll_ld, void *stream);
 /* bigram table += sign * (transcripts of block b, all slices) from bt->lm_tok                  */
 int32_t segk_fbb_lm_apply(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *f,
                           const segk_fbatch *bt, int32_t b, int32_t sign, void *stream);

@@ -372,7 +372,7 @@ __global__ void k_fbb_segment(segk_corpus c, segk_fbatch bt, FbbMap map, int b, 
 template <typename XT, int COV>
 __global__ void k_fbb_assign(segk_corpus c, segk_fbgmm f, segk_fbatch bt, FbbMap map, int b, uint64_t sweep,
                              double prior_alpha, double anneal_temp, const int32_t *new_tok, const int32_t *n_new,
-                             int rcap, int dbg)
+                             int rcap, int dbg, const float *llmat, int64_t ll_ld)
 {
     // The likelihood part of the logits does not depend on the previous segment's slot, so it is
     // evaluated for up to `rcap` (<= FBB_R) tokens of the utterance at once -- the component
@@ -398,6 +398,19 @@ __global__ void k_fbb_assign(segk_corpus c, segk_fbgmm f, segk_fbatch bt, FbbMap
     for (int t0 = 0; t0 < nn; t0 += rcap) {
         const int nr = nn - t0 < rcap ? nn - t0 : rcap;
         __syncthreads();
+        if (llmat) {
+            // token likelihoods from the matrix-core contraction (segk_fbb_token_scores): row blockIdx.x*N_max + t
+            // holds acc_k = (zconst_k - s_k/2 - norm + <.,.>) log2 e per slot and the empty-slot row at K_max
+            const double LN2 = 0.6931471805599453;
+            const double norm = f.lms * log(tot + prior_alpha);
+            const double n_empty = (double)KM - bt.scal[1];
+            for (int r = 0; r < nr; r++) {
+                const float *mrow = llmat + ((int64_t)blockIdx.x * c.N_max + t0 + r) * ll_ld;
+                for (int k = tid; k < KM; k += nt)
+                    ll[(int64_t)r * KM + k] = bt.cnt[k] > 0.0 ? (double)mrow[k] * LN2 - (bt.zconst[k] - bt.lconst[k]) + norm
+                                                               : (double)mrow[KM] * LN2 - zc_empty - log(n_empty) + norm;
+            }
+        } else {
         for (int j = tid; j < FBB_R * D; j += nt) {
             const int r = j / D, d = j - r * D;
             xs[j] = r < nr ? (double)X[(int64_t)new_tok[(int64_t)utt * c.N_max + t0 + r] * c.ldx + d] : 0.0;
@@ -426,6 +439,7 @@ __global__ void k_fbb_assign(segk_corpus c, segk_fbgmm f, segk_fbatch bt, FbbMap
                 for (int r = 0; r < FBB_R; r++)
                     if (r < nr) ll[(int64_t)r * KM + k] = lpr[r];
             }
+        }
         }
         __syncthreads();
         for (int r = 0; r < ((dbg & 2) ? 1 : nr); r++) {
@@ -846,9 +860,21 @@ int32_t segk_fbb_segment(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *
     return SEGK_OK;
 }
 
+int32_t segk_fbb_token_scores(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *f, const segk_fbatch *bt,
+                              const int32_t *tok_rows, int64_t n, float *ll_mat, int64_t ll_ld, void *stream)
+{
+    (void)ctx;
+    int rc = check_fbb(c, f, bt);
+    if (rc) return rc;
+    SEGK_REQUIRE(f->cov_type == 0 && bt->y16 && bt->tiles16, "needs the fp16x2 images (fixed-variance components)");
+    SEGK_REQUIRE(tok_rows && ll_mat && ll_ld >= 32 * segk_n_tiles(f->K_max + 1) && (ll_ld & 3) == 0, "matrix / leading dimension");
+    return segk_launch_score_mat_sp(bt->y16, 2 * c->D, tok_rows, n, bt->tiles16, segk_n_tiles(f->K_max + 1), ll_mat, ll_ld,
+                                    stream);
+}
+
 int32_t segk_fbb_assign(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *f, const segk_fbatch *bt, int32_t s_lo,
                         int32_t s_n, int32_t b, const int32_t *n_utts, uint64_t sweep, double anneal_temp,
-                        const int32_t *new_tok, const int32_t *n_new, void *stream)
+                        const int32_t *new_tok, const int32_t *n_new, const float *ll_mat, int64_t ll_ld, void *stream)
 {
     (void)ctx;
     int rc = check_fbb(c, f, bt);
@@ -873,13 +899,13 @@ int32_t segk_fbb_assign(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *f
                 SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_fbb_assign<XT, 0>,
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL((k_fbb_assign<XT, 0>), dim3(m.off[s_n]), dim3(256), lds, (hipStream_t)stream, *c, *f, *bt, m,
-                               b, sweep, alpha, anneal_temp, new_tok, n_new, rcap, dbg);
+                               b, sweep, alpha, anneal_temp, new_tok, n_new, rcap, dbg, ll_mat, ll_ld);
         } else {
             if (lds > 48 * 1024)
                 SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_fbb_assign<XT, 1>,
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL((k_fbb_assign<XT, 1>), dim3(m.off[s_n]), dim3(256), lds, (hipStream_t)stream, *c, *f, *bt, m,
-                               b, sweep, alpha, anneal_temp, new_tok, n_new, rcap, dbg);
+                               b, sweep, alpha, anneal_temp, new_tok, n_new, rcap, dbg, ll_mat, ll_ld);
         }
     });
     SEGK_LAUNCH_CHECK();

@@ -117,3 +117,5 @@ int segk_sp_prepare_tiles(const float *rows, const double *consts, const double 
                           const void *ximg, void *stream);
 int segk_launch_score_lse_sp(segk_ctx *ctx, const void *ximg, int D2, const int32_t *ids, int64_t row0, int64_t n,
                              const float *tiles_sp, int n_tiles, double norm, double *out, void *stream);
+int segk_launch_score_mat_sp(const void *ximg, int D2, const int32_t *ids, int64_t n, const float *tiles_sp, int n_tiles,
+                             float *mat, int64_t mat_ld, void *stream);

@@ -283,6 +283,8 @@ struct ScoreArgs {
     double lse_norm;
     const float *means32;        /* split-precision filter: float32 `means` and rows for the fused exact score */
     const float *xrows32;
+    float *mat_out;              /* MODE 2: the accumulator values themselves, [n rows][mat_ld], mat_ld >= 32 n_tiles */
+    int64_t mat_ld;
 };
 
 // SPLIT = 0: the whole component range per workgroup, winner + margin test + fused exact score.
@@ -832,10 +834,17 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_kmeans_score_sp(ScoreArgs A)
     for (int q = 0; q < 16; q++) { accAm[q] = NEG_INF_F; accAl[q] = 0.f; accBm[q] = NEG_INF_F; accBl[q] = 0.f; }
 
     constexpr int VPS = (16 + KS - 1) / KS;
+    float st4[4] = {0.f, 0.f, 0.f, 0.f};
+    int dtile = -1;                       // MODE 2: the tile whose values are being drained
 #define SEGK_DRAIN(ACCM, ACCL, vi)                                                    \
     do {                                                                              \
         float v_ = ACCM[(vi)] + ACCL[(vi)] * LS;                                      \
-        if constexpr (MODE == 1) {                                                    \
+        if constexpr (MODE == 2) {      /* store the unscaled values: row-major [row][component] */ \
+            st4[(vi) & 3] = v_ * unscale;                                             \
+            if ((((vi) & 3) == 3) && dtile >= 0 && r < n)                             \
+                *reinterpret_cast<float4 *>(A.mat_out + r * A.mat_ld + dtile * 32 + 4 * h + 8 * ((vi) >> 2)) = \
+                    make_float4(st4[0], st4[1], st4[2], st4[3]);                      \
+        } else if constexpr (MODE == 1) {                                                    \
             v_ = fmaxf(v_ * unscale, -3.0e38f);                                       \
             const float nm_ = vmax_f32(m1, v_);                                       \
             m2 = m2 * __builtin_amdgcn_exp2f(m1 - nm_) + __builtin_amdgcn_exp2f(v_ - nm_); \
@@ -864,6 +873,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_kmeans_score_sp(ScoreArgs A)
             }                                                                                         \
         }                                                                                             \
         const float m1s = m1;                                                                         \
+        dtile = (t_) - 1;                                                                             \
         V8 nx[P];                                                                                     \
         _Pragma("unroll") for (int p = 0; p < P; p++)                                                 \
             nx[p] = *reinterpret_cast<const V8 *>(Tb + (p * 64 + lane) * 8);                          \
@@ -899,9 +909,11 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_kmeans_score_sp(ScoreArgs A)
         if (t < n_tiles) {
             SEGK_TILE(accAm, accAl, accBm, accBl, t);
             m1s = m1;
+            dtile = n_tiles - 1;
 #pragma unroll
             for (int vi = 0; vi < 16; vi++) SEGK_DRAIN(accAm, accAl, vi);
         } else {
+            dtile = n_tiles - 1;
 #pragma unroll
             for (int vi = 0; vi < 16; vi++) SEGK_DRAIN(accBm, accBl, vi);
         }
@@ -911,6 +923,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_kmeans_score_sp(ScoreArgs A)
 #undef SEGK_DRAIN
 #undef SEGK_STAGE
 #undef SEGK_TILE_SYNC
+    if constexpr (MODE == 2) return;
     if constexpr (MODE == 1) {
         // the two lane halves summed disjoint component subsets of the same row
         const float om = __shfl_xor(m1, 32), os = __shfl_xor(m2, 32);
@@ -2464,6 +2477,47 @@ static int launch_score_lse_sp(segk_ctx *ctx, const ScoreArgs &A, hipStream_t st
     }
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;
+}
+
+template <int KS>
+static int launch_score_mat_sp(const ScoreArgs &A, hipStream_t st)
+{
+    constexpr int STRIDE = (KS * 2 * 256 + 32 + 1023) / 1024 * 1024;
+    const size_t lds = 2 * (size_t)STRIDE * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set && lds > 48 * 1024) {
+        SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_kmeans_score_sp<KS, 4, 2, 2>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_kmeans_score_sp<KS, 4, 2, 2>), dim3((unsigned)((A.n + 127) / 128)), dim3(256), lds, st, A);
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+// mat[r][k] = acc_k of row ids[r] (r < n), k < 32 n_tiles: the contraction itself, for callers that need
+// every component's value (the token likelihoods of the batch sampler's assignment step)
+int segk_launch_score_mat_sp(const void *ximg, int D2, const int32_t *ids, int64_t n, const float *tiles_sp, int n_tiles,
+                             float *mat, int64_t mat_ld, void *stream)
+{
+    if (n <= 0) return SEGK_OK;
+    ScoreArgs A;
+    memset(&A, 0, sizeof(A));
+    A.X32 = (const float *)ximg; A.ids = ids; A.row0 = 0; A.n = n;
+    A.tiles = tiles_sp; A.n_tiles = n_tiles; A.tile_stride = segk_sp_tile_stride(D2, 2);
+    A.D = D2;
+    A.mat_out = mat; A.mat_ld = mat_ld;
+    hipStream_t st = (hipStream_t)stream;
+    switch (segk_b3_kp(D2) / 16) {
+#define SEGK_CASE(k) \
+    case k: return launch_score_mat_sp<k>(A, st);
+        SEGK_CASE(1) SEGK_CASE(2) SEGK_CASE(3) SEGK_CASE(4) SEGK_CASE(5) SEGK_CASE(6) SEGK_CASE(7) SEGK_CASE(8) SEGK_CASE(9)
+        SEGK_CASE(10) SEGK_CASE(11) SEGK_CASE(12) SEGK_CASE(13)
+#undef SEGK_CASE
+        default: break;
+    }
+    segk_set_error("segk_launch_score_mat_sp: 2D=%d > 208 is not supported", D2);
+    return SEGK_ERR_UNSUPPORTED;
 }
 
 // the log-sum-exp score on fp16x2 images: out[row] = ln sum_k 2^(acc_k) - norm, D2 <= 208

@@ -652,6 +652,17 @@ class FbgmmBatchSweeper(object):
                         for b in range(self.B)]
         self._n_utts = [I32(*[int(ur[self.s_lo + i, b, 1] - ur[self.s_lo + i, b, 0]) for i in range(self.s_n)])
                         for b in range(self.B)]
+        self.ll_mat = None
+        if self.score_f16:
+            # token likelihoods of the assignment step from the matrix cores: per block, the positions of its
+            # utterances' token slots in the flat new_tok array (slice order) and the matrix they fill
+            nm = c.N_max
+            self._tok_map = [to_dev(np.concatenate([np.arange(ur[self.s_lo + i, b, 0] * nm, ur[self.s_lo + i, b, 1] * nm)
+                                                    for i in range(self.s_n)]).astype(np.int64))
+                             for b in range(self.B)]
+            self._tok_rows = torch.zeros(max(t.numel() for t in self._tok_map), dtype=torch.int32, device=dev)
+            self.ll_ld = (K + 1 + 31) // 32 * 32
+            self.ll_mat = torch.zeros((self._tok_rows.numel(), self.ll_ld), dtype=torch.float32, device=dev)
         if self.score_f32:
             # the rows of block b over the local slices, one launch per step
             self._block_rows = [to_dev(np.concatenate([np.arange(rr[self.s_lo + i, b, 0], rr[self.s_lo + i, b, 1])
@@ -709,6 +720,7 @@ class FbgmmBatchSweeper(object):
     def sweep(self, boundaries, n_slices_min, n_slices_max, wip, time_power_term, anneal_temp_fb=1.0,
               anneal_temp_am=1.0):
         """One sweep = n_gibbs_blocks steps, all enqueued on the current stream."""
+        torch = _torch()
         df = self.df
         if not self.in_batch_state:
             self.enter(boundaries)
@@ -727,8 +739,16 @@ class FbgmmBatchSweeper(object):
                                      int(n_slices_max), float(wip), float(time_power_term), float(anneal_temp_fb),
                                      ptr(df.score), ptr(boundaries), ptr(df.new_tok), ptr(df.n_new),
                                      ptr(df.out_logprob), ptr(df.status), st))
-            check(L.segk_fbb_assign(ctx, cp, fp, bp, self.s_lo, self.s_n, b, self._n_utts[b], sw, float(anneal_temp_am),
-                                    ptr(df.new_tok), ptr(df.n_new), st))
+            if self.ll_mat is not None:
+                tm = self._tok_map[b]
+                rows = self._tok_rows[:tm.numel()]
+                torch.index_select(df.new_tok.view(-1), 0, tm, out=rows)
+                check(L.segk_fbb_token_scores(ctx, cp, fp, bp, ptr(rows), tm.numel(), ptr(self.ll_mat), self.ll_ld, st))
+                check(L.segk_fbb_assign(ctx, cp, fp, bp, self.s_lo, self.s_n, b, self._n_utts[b], sw, float(anneal_temp_am),
+                                        ptr(df.new_tok), ptr(df.n_new), ptr(self.ll_mat), self.ll_ld, st))
+            else:
+                check(L.segk_fbb_assign(ctx, cp, fp, bp, self.s_lo, self.s_n, b, self._n_utts[b], sw, float(anneal_temp_am),
+                                        ptr(df.new_tok), ptr(df.n_new), None, 0, st))
             if self.lm_tok is not None:
                 check(L.segk_fbb_lm_fill(ctx, cp, fp, bp, self.s_lo, self.s_n, b, self._n_utts[b], ptr(df.new_tok),
                                          ptr(df.n_new), st))

@@ -199,17 +199,27 @@ def test_matrix_core_span_scores_within_tolerance(gpu, kind, n_utt, D, K, nmax, 
     assert worst < 1e-4, (worst, worst_abs)
 
 
-def test_matrix_core_mode_samples_a_valid_chain(gpu):
-    """Full sweeps in f32 score mode: same invariants as the exact mode, and the chain stays close to the
-    f64 chain in distribution (equal boundaries for the vast majority of utterances after one sweep)."""
-    ref, spec, seg = _pair("fixed", 60, 16, 24, 321, 6, 3, 4, score_precision="f32")
+@pytest.mark.parametrize("kind,prec", [("fixed", "f32"), ("fixed", "f16"), ("bigram", "f16")])
+def test_matrix_core_mode_samples_a_valid_chain(gpu, kind, prec):
+    """Full sweeps with matrix-core scores (f16: also the token likelihoods of the assignment step): the
+    chain stays close to the f64 chain (equal boundaries and slots for the vast majority of utterances
+    after one sweep -- a draw only flips when a uniform falls within ~1e-5 of a cumulative boundary) and
+    the state invariants hold."""
+    ref, spec, seg = _pair(kind, 60, 16, 24, 321, 6, 3, 4, score_precision=prec)
     lp = spec.sweep(0)
     seg.batch_sweep_async()
     gpu.cuda.synchronize()
     seg._df.check_status()
     same = np.mean(np.all(seg.utterances.boundaries == ref.utterances.boundaries, axis=1))
     assert same > 0.9, same
+    slots = seg._get_sweeper().slot.cpu().numpy()
+    both = (slots >= 0) & (spec.slot >= 0)
+    assert np.mean(slots[both] == spec.slot[both]) > 0.9
     npt.assert_allclose(float(seg._df.out_logprob.sum().item()), lp.sum(), rtol=5e-2)
+    for _ in range(2):
+        seg.batch_sweep_async()
     seg.materialise()
     c = seg.acoustic_model.components
     assert c.counts[:c.K].sum() == seg.acoustic_model.get_n_assigned()
+    if kind == "bigram":
+        assert seg.lm.unigram_counts.sum() == seg.acoustic_model.get_n_assigned()

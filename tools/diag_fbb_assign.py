@@ -22,7 +22,7 @@ L, ctx, cp, fp, bp, st = sw._args()
 b = 3
 check(L.segk_fbb_prepare(ctx, cp, fp, bp, b, st))
 def run():
-    check(L.segk_fbb_assign(ctx, cp, fp, bp, sw.s_lo, sw.s_n, b, sw._n_utts[b], 7, 1.0, ptr(df.new_tok), ptr(df.n_new), st))
+    check(L.segk_fbb_assign(ctx, cp, fp, bp, sw.s_lo, sw.s_n, b, sw._n_utts[b], 7, 1.0, ptr(df.new_tok), ptr(df.n_new), None, 0, st))
 for dbg in (0, 1, 2, 4, 3, 7):
     os.environ["SEGK_FBB_DBG"] = str(dbg)
     run(); torch.cuda.synchronize()
