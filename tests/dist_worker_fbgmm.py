@@ -12,6 +12,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     out_path, backend, n_sweeps, kind = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
+    prec = sys.argv[5] if len(sys.argv) > 5 else "f64"
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -34,7 +35,7 @@ def main():
     fixed = (0.002 * np.ones(D), np.zeros(D), 0.002 / 0.05 * np.ones(D))
     if kind == "bigram":
         seg = baw.BigramAcousticWordseg(K, FixedVarPrior(*fixed), {"type": "smooth", "intrp_lambda": 0.1, "a": 0.5, "b": 0.5},
-                                        *corpus, covariance_type="fixed", fb_type="unigram", **kw)
+                                        *corpus, covariance_type="fixed", fb_type="unigram", score_precision=prec, **kw)
     else:
         seg = uaw.UnigramAcousticWordseg(fbgmm.FBGMM, 1.0, K, NIW(np.zeros(D), 0.05, D + 3, 0.002 * (D + 3) * np.ones(D)),
                                          *corpus, covariance_type="diag", fb_type="standard", **kw)

@@ -42,3 +42,13 @@ def test_fbgmm_batch_mode_is_independent_of_the_number_of_ranks(tmp_path, kind):
         got = run(world, str(tmp_path / ("f%d.npz" % world)), 2, "dist_worker_fbgmm.py", [kind])
         for k in ref.files:
             assert np.array_equal(ref[k], got[k]), (world, k)
+
+
+def test_bigram_batch_matrix_core_mode_is_independent_of_the_number_of_ranks(tmp_path):
+    """score_precision="f16" (matrix-core span scores and token likelihoods): every row's score is
+    independent of how the rows are grouped into launches, so 1 / 2 / 4 ranks still coincide bit for bit."""
+    ref = run(1, str(tmp_path / "h1.npz"), 2, "dist_worker_fbgmm.py", ["bigram", "f16"])
+    for world in (2, 4):
+        got = run(world, str(tmp_path / ("h%d.npz" % world)), 2, "dist_worker_fbgmm.py", ["bigram", "f16"])
+        for k in ref.files:
+            assert np.array_equal(ref[k], got[k]), (world, k)
