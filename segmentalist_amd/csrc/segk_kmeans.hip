@@ -1455,6 +1455,182 @@ __global__ void k_kmeans_segment(segk_corpus c, segk_kmeans m, const int32_t *ut
     }
 }
 
+// Fast path of the per-utterance kernel for windows of at most 8 slices and utterances of at most 64
+// landmarks (the common configuration: n_slices_max = 6).  Same arithmetic and the same decisions as
+// k_kmeans_segment; what changes is how lane 0 gets at its operands.  The generic kernel walks the
+// DP as a chain of dependent LDS round trips (store gamma[t], load it back for t+1, byte loads of the
+// boundary flags with a branch on each); here the last eight gammas live in registers, the eight
+// candidates of a step are fetched together (predicated, fully unrolled), and the boundary vectors
+// are 64-bit masks.
+__global__ void k_kmeans_segment_w8(segk_corpus c, segk_kmeans m, const int32_t *utts, int utt0, int n_utts,
+                                    int n_max, double wip, segk_cand cand, uint8_t *boundaries, int32_t *old_tok,
+                                    int32_t *new_tok, int32_t *new_k, int32_t *n_old, int32_t *n_new, int32_t *n_flag,
+                                    double *out_total, int32_t *status, int band_cap, int wave_bytes)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int slot = blockIdx.x * (blockDim.x >> 6) + wv;
+    if (slot >= n_utts) return;
+    const int u = utts ? utts[slot] : utt0 + slot;
+    const int N = c.lengths[u];
+    const int W = (n_max > 0 && n_max < N) ? n_max : N;          // <= 8 (host checks n_max <= 8)
+    const int nb = N * W;
+    const int64_t triMax = (int64_t)c.N_max * (c.N_max + 1) / 2;
+    const int32_t *vid = c.vec_ids + (int64_t)u * triMax;
+    const double *dur = c.durations + (int64_t)u * triMax;
+    uint8_t *gbnd = boundaries + (int64_t)u * c.N_max;
+
+    char *base = smem + (size_t)wv * wave_bytes;
+    double *bvec = (double *)base;                    // [band_cap]
+    double *gam = bvec + band_cap;                    // [N_max + 1]
+    int32_t *bk = (int32_t *)(gam + c.N_max + 1);     // [band_cap]
+    int32_t *bid = bk + band_cap;                     // [band_cap]
+    int32_t *l_old = bid + band_cap;                  // [N_max]
+    int32_t *l_new = l_old + c.N_max;                 // [N_max]
+    int32_t *l_newk = l_new + c.N_max;                // [N_max]
+    int32_t *l_cnt = l_newk + c.N_max;                // [4]: n_old, n_new, new boundary mask (2 words)
+
+    for (int i = lane; i < nb; i += 64) {
+        const int t = i / W + 1, w = i % W, s = t - 1 - w;
+        int id = -1;
+        double v = NEG_INF_D;
+        int k = -1;
+        if (s >= 0) {
+            const int j = t * (t - 1) / 2 + s;
+            id = vid[j];
+            if (id >= 0) {
+                k = cand.k[id];
+                const double dd = dur[j];
+                v = isnan(dd) ? NEG_INF_D : cand.s[id] * dd;      // :346-349
+            }
+        }
+        bid[i] = id;
+        bk[i] = k;
+        bvec[i] = v + wip;                                       // :351
+    }
+    const unsigned long long oldb = __ballot(lane < N && gbnd[lane < N ? lane : 0] != 0);
+    WAVE_SYNC();
+    if (lane == 0) {
+#define V_(t, s) bvec[((t) - 1) * W + ((t) - 1 - (s))]
+#define ID_(t, s) (((t) - 1 - (s)) < W ? bid[((t) - 1) * W + ((t) - 1 - (s))] : vid[(t) * ((t) - 1) / 2 + (s)])
+        // ---- old tokens (utterances.py:159-174)
+        int no = 0, jp = 0;
+        for (unsigned long long mb = oldb; mb; mb &= mb - 1) {
+            const int j = __ffsll((long long)mb) - 1;
+            const int id = ID_(j + 1, jp);
+            if (id >= 0) l_old[no++] = id;
+            jp = j + 1;
+        }
+        // ---- A8 forward (kmeans_acoustic_wordseg.py:494-506): g[w] = gamma[t - 1 - w]
+        double g[8];
+#pragma unroll
+        for (int w = 0; w < 8; w++) g[w] = NEG_INF_D;
+        g[0] = 0.0;
+        gam[0] = 0.0;
+        for (int t = 1; t < N; t++) {
+            double v[8];
+#pragma unroll
+            for (int w = 0; w < 8; w++) {                  // unconditional loads from a clamped index, then the predicate
+                const bool ok = w < W && t - 1 - w >= 0;
+                v[w] = bvec[ok ? (t - 1) * W + w : 0];
+            }
+            double best = NEG_INF_D;
+#pragma unroll
+            for (int w = 7; w >= 0; w--) {                 // s ascending, as the reference's max() scans
+                const bool ok = w < W && t - 1 - w >= 0;
+                const double x = v[w] + g[w];
+                if (ok && x > best) best = x;
+            }
+            gam[t] = best;
+#pragma unroll
+            for (int w = 7; w > 0; w--) g[w] = g[w - 1];
+            g[0] = best;
+        }
+        unsigned long long newb = 1ull << (N - 1);
+        // candidates of span end tt: are they all -inf; and the reversed np.argmax (shortest span on ties)
+        auto eval = [&](int tt, int &kb) -> bool {
+            double x[8];
+#pragma unroll
+            for (int w = 0; w < 8; w++) {
+                const bool ok = w < W && tt - 1 - w >= 0;
+                x[w] = bvec[ok ? (tt - 1) * W + w : 0] + gam[ok ? tt - 1 - w : 0];
+            }
+            double best = NEG_INF_D;
+            bool first = true, ai = true;
+#pragma unroll
+            for (int w = 0; w < 8; w++) {                  // s = tt - 1 - w descending
+                const bool ok = w < W && tt - 1 - w >= 0;
+                if (ok) {
+                    if (x[w] != NEG_INF_D) ai = false;
+                    if (first || x[w] > best) { best = x[w]; kb = w + 1; first = false; }
+                }
+            }
+            return ai;
+        };
+        // ---- A8 backward (:510-553)
+        int t = N;
+        double total = 0.0;
+        for (;;) {
+            int kb = 1;
+            bool all_inf = eval(t, kb);
+            if (all_inf) {                                 // step back until some candidate is finite (:516-530)
+                while (all_inf) {
+                    t = t - 1;
+                    if (t == 0) break;
+                    all_inf = eval(t, kb);
+                }
+                newb |= 1ull << ((t - 1 + N) % N);
+            }
+            int k = 1;
+            if (t > 0) {
+                k = kb;
+                total += V_(t, t - k);
+            } else {
+                total += V_(N, N - 1);      // python vec[-1]: the last span [N-1, N)
+            }
+            if (t - k - 1 < 0) break;
+            newb |= 1ull << (t - k - 1);
+            t = t - k;
+        }
+        // ---- new tokens + their best components (:312-313)
+        int nn = 0, bad = 0, nf = 0;
+        const int Kact = *m.K;
+        jp = 0;
+        for (unsigned long long mb = newb; mb; mb &= mb - 1) {
+            const int j = __ffsll((long long)mb) - 1;
+            const int tt = j + 1, w = tt - 1 - jp;
+            if (w >= W || bid[(tt - 1) * W + w] < 0) bad = 1;
+            else {
+                l_new[nn] = bid[(tt - 1) * W + w];
+                l_newk[nn] = bk[(tt - 1) * W + w];
+                if (l_newk[nn] >= Kact) nf++;
+                nn++;
+            }
+            jp = j + 1;
+        }
+        out_total[u] = total;
+        n_old[u] = no;
+        n_new[u] = nn;
+        if (n_flag) n_flag[u] = nf;
+        l_cnt[0] = no;
+        l_cnt[1] = nn;
+        l_cnt[2] = (int32_t)(newb & 0xffffffffull);
+        l_cnt[3] = (int32_t)(newb >> 32);
+        if (bad) atomicOr(status, 1);
+#undef V_
+#undef ID_
+    }
+    WAVE_SYNC();
+    const int no = l_cnt[0], nn = l_cnt[1];
+    const unsigned long long newb = ((unsigned long long)(unsigned int)l_cnt[3] << 32) | (unsigned int)l_cnt[2];
+    if (lane < N) gbnd[lane] = (uint8_t)((newb >> lane) & 1ull);
+    for (int j = lane; j < no; j += 64) old_tok[(int64_t)u * c.N_max + j] = l_old[j];
+    for (int j = lane; j < nn; j += 64) {
+        new_tok[(int64_t)u * c.N_max + j] = l_new[j];
+        new_k[(int64_t)u * c.N_max + j] = l_newk[j];
+    }
+}
+
 // ======================================================================================
 // A11 sequential: del_item / add_item / clean_components for ONE utterance, one workgroup,
 // thread d owns dimension d (kmeans_components.py:93-166, 263-266).
@@ -2843,7 +3019,7 @@ int32_t segk_kmeans_segment(segk_ctx *ctx, const segk_corpus *c, const segk_kmea
     const int W = (n_slices_max > 0 && n_slices_max < c->N_max) ? n_slices_max : c->N_max;
     const int band_cap = c->N_max * W;
     size_t wave_bytes = (size_t)(band_cap + c->N_max + 1) * sizeof(double)
-                        + (size_t)(2 * band_cap + 3 * c->N_max + 2) * sizeof(int32_t) + (size_t)c->N_max;
+                        + (size_t)(2 * band_cap + 3 * c->N_max + 4) * sizeof(int32_t) + (size_t)c->N_max;
     wave_bytes = (wave_bytes + 15) & ~(size_t)15;
     int waves = 4;
     while (waves > 1 && waves * wave_bytes > 64 * 1024) waves >>= 1;
@@ -2856,6 +3032,13 @@ int32_t segk_kmeans_segment(segk_ctx *ctx, const segk_corpus *c, const segk_kmea
     if (lds > 48 * 1024)
         SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_kmeans_segment, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)lds));
+    if (n_slices_max >= 1 && n_slices_max <= 8 && c->N_max <= 64 && !(getenv("SEGK_SEGMENT_GENERIC") && atoi(getenv("SEGK_SEGMENT_GENERIC")))) {
+        hipLaunchKernelGGL(k_kmeans_segment_w8, dim3((n_utts + waves - 1) / waves), dim3(64 * waves), lds, st, *c, *m, utts, utt0,
+                           n_utts, n_slices_max, wip, *cand, boundaries, old_tok, new_tok, new_k, n_old, n_new, n_flag,
+                           out_total, status, band_cap, (int)wave_bytes);
+        SEGK_LAUNCH_CHECK();
+        return SEGK_OK;
+    }
     hipLaunchKernelGGL(k_kmeans_segment, dim3((n_utts + waves - 1) / waves), dim3(64 * waves), lds, st, *c, *m, utts,
                        utt0, n_utts, n_slices_min, n_slices_max, wip, *cand, boundaries, old_tok, new_tok, new_k, n_old,
                        n_new, n_flag, out_total, status, band_cap, (int)wave_bytes);
