@@ -322,7 +322,38 @@ def main():
                     traffic = tj["traffic_bytes_per_launch"]
             achieved = flops_per_launch / (score_ms * 1e-3) / 1e12
             b3 = getattr(seg._corpus, "Xb3", None) is not None and os.environ.get("SEGK_SCORE_B3", "2") != "0"
-            if b3:
+            kind = int(_abi.lib().segk_profile_last_kind(_abi.ctx())) if use_ev else -1
+            if b3 and kind == 1:
+                # One-product fp16 pre-filter (k_kmeans_score_h1) in front of the split-precision kernel: the timed
+                # launch scores every row against every component with ONE v_mfma_f32_32x32x16_f16 product per
+                # 16 dimensions; rows it cannot decide (6 % here) pass to the three-product kernel.  `achieved`
+                # / `frac` are the contract's ALGORITHMIC flops 2*rows*K*D over this launch; executed_* count the
+                # padded product the matrix pipe really does.
+                kp, kpad = (args.dim + 15) // 16 * 16, (args.K + 31) // 32 * 32
+                executed = 2.0 * score_rows * kpad * kp
+                ex_tf = executed / (score_ms * 1e-3) / 1e12
+                tp = os.path.join(ROOT, "profiles", "score_kernel_traffic_pre.json")
+                traffic = None
+                if os.path.exists(tp):
+                    tj = json.load(open(tp))
+                    wl = tj["workload"]
+                    if (wl["utterances"], wl["landmarks_per_utt"], wl["n_slices_max"], wl["D"], wl["K"], wl["n_gpus"]) == \
+                            (args.utts, args.landmarks, args.n_slices_max, args.dim, args.K, world):
+                        traffic = tj["traffic_bytes_per_launch"]
+                out["dtype"] = "fp16 pre-filter + fp16x2"
+                out["roofline"] = {
+                    "bound": "mfma",
+                    "kernel": "k_kmeans_score_h1<%d, 4> (main launch: %d of %d rows; one-product fp16 pre-filter on the 16-bit "
+                              "matrix pipe, undecided rows re-scored by k_kmeans_score_sp, results bit-identical to the float32 "
+                              "reference)" % (kp // 16, score_rows, rows_local),
+                    "achieved": achieved, "peak": PEAK_BF16_MATRIX_TFLOPS, "unit": "TFLOP/s",
+                    "frac": achieved / PEAK_BF16_MATRIX_TFLOPS, "traffic": traffic, "ms_per_launch": score_ms,
+                    "flops_per_launch": flops_per_launch,
+                    "executed_flops_per_launch": executed, "executed_achieved": ex_tf,
+                    "executed_frac": ex_tf / PEAK_BF16_MATRIX_TFLOPS,
+                    "achieved_over_fp32_matrix_peak": achieved / PEAK_FP32_MATRIX_TFLOPS,
+                }
+            elif b3:
                 # The filter runs as three fp16 (or six bf16) products per float32 multiply-add on
                 # v_mfma_f32_32x32x16_{f16,bf16} (splits of both operands).  `achieved` / `frac` follow
                 # the contract (ALGORITHMIC flops 2*rows*K*D over the kernel's duration, against the dense peak

@@ -51,6 +51,10 @@ int32_t segk_abi_version(void);
  * the row count of the most recent recorded launches (at most `max`, at most 256 kept).          */
 int32_t segk_profile_enable(segk_ctx *ctx, int32_t on);
 int32_t segk_profile_read(segk_ctx *ctx, float *ms_out, int64_t *rows_out, int32_t max);
+/* Which kernel the most recent recorded launch was: 0 the fp32-MFMA filter, 2 / 3 the split-precision
+ * filter (fp16x2 / bf16x3), 1 the one-product fp16 pre-filter (k_kmeans_score_h1: rows above ~260 k,
+ * D % 4 == 0), 4 the log-sum-exp kernels of the FBGMM batch sampler; -1 none recorded.               */
+int32_t segk_profile_last_kind(segk_ctx *ctx);
 
 /* -------------------------------------------------------------------------------------
  * Corpus (read-only during sampling): the device image of `Utterances` + the embedding

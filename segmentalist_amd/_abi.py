@@ -127,6 +127,7 @@ SIGNATURES = {
     "segk_kmeans_tiles_b3_floats": (_i64, [_i32, _i32]),
     "segk_profile_enable": (_i32, [_P, _i32]),
     "segk_profile_read": (_i32, [_P, _P, _P, _i32]),
+    "segk_profile_last_kind": (_i32, [_P]),
     "segk_logsumexp": (_f64, [_P, _i64]),
     "segk_draw": (_i32, [_P, _i64, _f64]),
     "segk_sum_doubles": (_f64, [_P, _i64]),

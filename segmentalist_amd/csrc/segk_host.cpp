@@ -68,6 +68,7 @@ int32_t segk_destroy(segk_ctx *ctx)
         if (ctx->ws_k) (void)hipFree(ctx->ws_k);
         if (ctx->ws_f) (void)hipFree(ctx->ws_f);
         if (ctx->ws_u64) (void)hipFree(ctx->ws_u64);
+        if (ctx->pre_queue) (void)hipFree(ctx->pre_queue);
         for (int i = 0; i < SEGK_PROF_SLOTS; i++)
             for (int j = 0; j < 2; j++)
                 if (ctx->prof_ev[i][j]) (void)hipEventDestroy(ctx->prof_ev[i][j]);
@@ -87,6 +88,7 @@ int32_t segk_profile_enable(segk_ctx *ctx, int32_t on)
                 if (!ctx->prof_ev[i][j]) SEGK_CHECK_HIP(hipEventCreate(&ctx->prof_ev[i][j]));
     ctx->prof_on = on ? 1 : 0;
     ctx->prof_n = 0;
+    if (on) ctx->prof_kind = -1;
     return SEGK_OK;
 }
 
@@ -104,6 +106,11 @@ int32_t segk_profile_read(segk_ctx *ctx, float *ms_out, int64_t *rows_out, int32
         rows_out[i] = ctx->prof_rows[slot];
     }
     return n;
+}
+
+int32_t segk_profile_last_kind(segk_ctx *ctx)
+{
+    return ctx ? ctx->prof_kind : -1;
 }
 
 // ----------------------------------------------------------------------------------------

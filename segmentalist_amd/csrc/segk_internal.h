@@ -18,8 +18,11 @@ struct segk_ctx {
     int32_t *ws_k;
     float *ws_f;
     unsigned long long *ws_u64;   // split full scan: (score, component) per queue entry, zero between uses
+    // rows the one-product pre-filter could not decide: [0] count, [16..] row ids (grown on demand)
+    int32_t *pre_queue;
+    int64_t pre_cap;
     // optional timing of the main score launch (segk_profile_*): event pairs used round-robin
-    int prof_on, prof_n;
+    int prof_on, prof_n, prof_kind;
     hipEvent_t prof_ev[SEGK_PROF_SLOTS][2];
     int64_t prof_rows[SEGK_PROF_SLOTS];
 };

@@ -261,6 +261,7 @@ __device__ __forceinline__ float vmax_f32(float a, float b)
 //   embedding on the lane: the running max over components is lane-local.
 //   Accumulators start at -|m|^2/2, so acc = x.m - |m|^2/2 with no epilogue arithmetic.
 // ======================================================================================
+#define SEGK_PAIR_PENDING 0x40000000      /* cand.k: pair (c, c + 1) named by the pre-filter, member not yet chosen */
 struct ScoreArgs {
     const float *X32;
     int64_t ld32;
@@ -285,6 +286,12 @@ struct ScoreArgs {
     const float *xrows32;
     float *mat_out;              /* MODE 2: the accumulator values themselves, [n rows][mat_ld], mat_ld >= 32 n_tiles */
     int64_t mat_ld;
+    // one-product pre-filter (k_kmeans_score_h1): its undecided rows go to pre_queue (pre_cap entries, then to
+    // cand.queue); the split-precision kernel that follows reads its row count from n_dev
+    const int32_t *n_dev;
+    int32_t *pre_queue, *pre_count;
+    int pre_cap, K_max;
+    unsigned long long *stamp;   /* -DSEGK_STAMP development builds: s_memtime at phase boundaries, 8 per workgroup */
 };
 
 // SPLIT = 0: the whole component range per workgroup, winner + margin test + fused exact score.
@@ -760,6 +767,61 @@ __global__ void k_kmeans_prepare_sp(const float *means, int K_max, int D, float 
     }
 }
 
+// The reference's float32 -(deltas*deltas).sum() of one (row, mean) pair in numpy's pairwise order, D a
+// multiple of 4, by two lanes PART apart (h = 0, 1): lane h owns the strided accumulators r_{4h..4h+3} in
+// full (segk_b3_dim); both return the same value.
+template <int KS, int PART>
+__device__ __forceinline__ float sp_exact_score_x(const float *mean, const float *xr, int D, int h)
+{
+    const float *mrow = mean + 4 * h, *xrow = xr + 4 * h;
+    const int nfull = D & ~7, rem = D & 7;
+    float r4[4] = {0.f, 0.f, 0.f, 0.f}, tt[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < KS; s++) {
+#pragma unroll
+        for (int b = 0; b < 2; b++) {
+            const int d0 = 16 * s + 8 * b;                     // this lane holds d0 + 4h + {0..3}
+            if (d0 + 8 <= nfull) {                             // a whole block of 8: both lanes, wave-uniform branch
+                const float4 mv = *reinterpret_cast<const float4 *>(mrow + d0);
+                const float4 xv = *reinterpret_cast<const float4 *>(xrow + d0);
+                const float mvv[4] = {mv.x, mv.y, mv.z, mv.w}, xvv[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const float delta = mvv[q] - xvv[q];
+                    const float t2 = delta * delta;
+                    r4[q] = (s == 0 && b == 0) ? t2 : r4[q] + t2;
+                }
+            } else if (d0 == nfull && d0 + 4 * h < D) {        // the sequential tail block (D % 4 == 0: lane 0 only)
+                const float4 mv = *reinterpret_cast<const float4 *>(mrow + d0);
+                const float4 xv = *reinterpret_cast<const float4 *>(xrow + d0);
+                const float mvv[4] = {mv.x, mv.y, mv.z, mv.w}, xvv[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const float delta = mvv[q] - xvv[q];
+                    tt[q] = delta * delta;
+                }
+            }
+        }
+    }
+    float res = (r4[0] + r4[1]) + (r4[2] + r4[3]);
+    const float ro = __shfl_xor(res, PART);
+    res = (h == 0) ? res + ro : ro + res;                      // ((r0+r1)+(r2+r3)) + ((r4+r5)+(r6+r7))
+    const float u0 = __shfl_xor(tt[0], PART), u1 = __shfl_xor(tt[1], PART), u2 = __shfl_xor(tt[2], PART);
+    // tail dimension nfull + jj lives on half jj >> 2, slot jj & 3 (rem < 8, D % 4 == 0: rem is 0 or 4)
+    const float t0 = h == 0 ? tt[0] : u0, t1 = h == 0 ? tt[1] : u1, t2 = h == 0 ? tt[2] : u2;
+    const float t3 = h == 0 ? tt[3] : __shfl_xor(tt[3], PART);
+    if (rem > 0) res += t0;
+    if (rem > 1) res += t1;
+    if (rem > 2) res += t2;
+    if (rem > 3) res += t3;
+    return -res;
+}
+template <int KS>
+__device__ __forceinline__ float sp_exact_score(const float *mean, const float *xr, int D, int h)
+{
+    return sp_exact_score_x<KS, 32>(mean, xr, D, h);      // the two 32-lane halves of a wave
+}
+
 template <int KS, int WAVES, int P, int MODE = 0>
 __global__ __launch_bounds__(64 * WAVES, 2) void k_kmeans_score_sp(ScoreArgs A)
 {
@@ -767,7 +829,13 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_kmeans_score_sp(ScoreArgs A)
     typedef typename SegkPiece<P>::V8 V8;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int32_t *__restrict__ ids = A.ids;
-    const int64_t row0 = A.row0, n = A.n;
+    const int64_t row0 = A.row0;
+    int64_t n = A.n;
+    if (A.n_dev) {                        // rows queued by the pre-filter: the count lives on the device
+        const int64_t nd = *A.n_dev;
+        n = nd < n ? nd : n;
+        if ((int64_t)blockIdx.x * WAVES * 32 >= n) return;
+    }
     const float *__restrict__ tiles = A.tiles + 1024;
     const int n_tiles = A.n_tiles, D = A.D;
     constexpr int KP = KS * 16;
@@ -942,43 +1010,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_kmeans_score_sp(ScoreArgs A)
     // in numpy's pairwise order.  This lane half owns the strided accumulators r_{4h..4h+3} in full
     // (segk_b3_dim); the row and the winner's mean are read as float32 from X32 / `means`.
     float sexact = __builtin_nanf("");
-    if (A.fuse_exact) {
-        const float *mrow = A.means32 + (int64_t)idx * D + 4 * h;
-        const float *xrow = A.xrows32 + (int64_t)(rowid >= 0 ? rowid : 0) * A.ld32 + 4 * h;
-        const int nfull = D & ~7, rem = D & 7;
-        float r4[4] = {0.f, 0.f, 0.f, 0.f}, tt[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < KS; s++) {
-#pragma unroll
-            for (int b = 0; b < 2; b++) {
-                const int d0 = 16 * s + 8 * b;                     // this half holds d0 + 4h + {0..3}
-                if (d0 + 4 * h < D) {                              // D % 4 == 0: all four or none
-                    const float4 mv = *reinterpret_cast<const float4 *>(mrow + d0);
-                    const float4 xv = *reinterpret_cast<const float4 *>(xrow + d0);
-                    const float mvv[4] = {mv.x, mv.y, mv.z, mv.w}, xvv[4] = {xv.x, xv.y, xv.z, xv.w};
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        const float delta = mvv[q] - xvv[q];
-                        const float t2 = delta * delta;
-                        if (d0 < nfull) r4[q] = (s == 0 && b == 0) ? t2 : r4[q] + t2;
-                        else tt[q] = t2;                           // the sequential tail block
-                    }
-                }
-            }
-        }
-        float res = (r4[0] + r4[1]) + (r4[2] + r4[3]);
-        const float ro = __shfl_xor(res, 32);
-        res = (h == 0) ? res + ro : ro + res;                      // ((r0+r1)+(r2+r3)) + ((r4+r5)+(r6+r7))
-        const float u0 = __shfl_xor(tt[0], 32), u1 = __shfl_xor(tt[1], 32), u2 = __shfl_xor(tt[2], 32);
-        // tail dimension nfull + jj lives on half jj >> 2, slot jj & 3 (rem < 8, D % 4 == 0: rem is 0 or 4)
-        const float t0 = h == 0 ? tt[0] : u0, t1 = h == 0 ? tt[1] : u1, t2 = h == 0 ? tt[2] : u2;
-        const float t3 = h == 0 ? tt[3] : __shfl_xor(tt[3], 32);
-        if (rem > 0) res += t0;
-        if (rem > 1) res += t1;
-        if (rem > 2) res += t2;
-        if (rem > 3) res += t3;
-        sexact = -res;
-    }
+    if (A.fuse_exact)
+        sexact = sp_exact_score<KS>(A.means32 + (int64_t)idx * D, A.xrows32 + (int64_t)(rowid >= 0 ? rowid : 0) * A.ld32, D, h);
     if (h == 0 && rowid >= 0) {
         A.cand.k[rowid] = idx;
         A.cand.f[2 * (int64_t)rowid + 0] = top1;
@@ -991,6 +1024,233 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_kmeans_score_sp(ScoreArgs A)
             if (q < A.amb_cap) A.cand.queue[q] = rowid;
         }
     }
+}
+
+// ======================================================================================
+// A1 pre-filter: ONE fp16 product.
+// The split-precision score kernel is power-bound (the same instruction stream on all-zero rows runs
+// 24 % faster, profiles/README.md r01_h): what shortens it is fewer matrix operations, not a better
+// schedule.  Most rows are decided by far less precision than fp16x2 carries: with only the leading
+// pieces, sum_d x1_d m1_d, both operands are rounded once to fp16 (unit roundoff 2^-11), so
+//     |sum x1 m1 - sum x m| <= (2^-10 + 2^-21) sum |x_d||m_d| + (flushed elements)
+//                           <= 1.01 * 2^-10 |x| M                               (Cauchy-Schwarz)
+// (elements below the fp16 normal range after the power-of-two scaling, max element in [2^12, 2^13),
+// are off by at most 2^-25 in the scaled domain: < 2^-33 |x| M for D <= 128, inside the 1.01).  A row
+// whose two largest values differ by more than tau_A = tau' + 2.5 * 1.01 * 2^-10 |x| M (tau' the
+// split-precision margin, which covers the fp32 accumulation and the exact stage's own rounding) has
+// the reference's argmax as its winner; on the bench corpus that is 94 % of the rows.  The others are
+// queued for k_kmeans_score_sp (all three products), whose own undecided rows take the full scan.
+//
+// One third of the matrix work makes the top-2 update the cost that matters, so it is done on PAIRS
+// of values: m1' = max3(m1, a, b), m2' = max(m2, med3(m1, a, b)), and the index kept is the pair's --
+// five vector operations per two values instead of eight.  Which of the pair won is settled by the
+// exact stage, which scores both members in reference arithmetic (a decisive winner beats its
+// partner there as well).  A wave owns NBLK blocks of 32 rows (tile fragments stay in registers
+// across the blocks; staging, barriers and fragment reads amortise over NBLK x 7 MFMAs), two
+// accumulators: block b's MFMAs run over the drain of block b - 1.
+// Reads the two-piece images (segk_internal.h): piece 0 of the rows, the piece-0 blocks and the
+// constants of the tile image -- each a 1 KiB LDS-DMA piece.
+// ======================================================================================
+__device__ __forceinline__ float filter_tau_h1(float xn, float M, int D)
+{
+    return filter_tau_sp(xn, M, D, 2) + 2.5f * 1.01f * 9.765625e-4f * xn * M;
+}
+
+template <int KS, int NBLK>
+__global__ __launch_bounds__(256, 2) void k_kmeans_score_h1(ScoreArgs A)
+{
+    static_assert(NBLK == 2 || NBLK == 4, "an even number of row blocks per wave (static accumulator parity)");
+    typedef _Float16 T;
+    typedef SegkPiece<2>::V8 V8;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int32_t *__restrict__ ids = A.ids;
+    const int64_t row0 = A.row0, n = A.n;
+    const float *__restrict__ tiles = A.tiles + 1024;
+    const int n_tiles = A.n_tiles, D = A.D;
+    constexpr int P = 2, KP = KS * 16;
+    constexpr int STRIDE = (KS * P * 256 + 32 + 1023) / 1024 * 1024;      // floats per tile image (global)
+    constexpr int TS = (KS + 1) * 256;                                    // floats per LDS buffer: KS blocks + constants
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int e_ab = ((const int *)A.X32)[1] + ((const int *)A.tiles)[0];
+    const float unscale = ldexpf(1.f, -e_ab);
+
+#ifdef SEGK_STAMP
+#define SEGK_STAMP_AT(i) do { if (A.stamp && tid == 0) A.stamp[(int64_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SEGK_STAMP_AT(i) do { } while (0)
+#endif
+    SEGK_STAMP_AT(0);
+    V8 xb[NBLK][KS];
+    int64_t r[NBLK];
+    int32_t rowid[NBLK];
+#pragma unroll
+    for (int b = 0; b < NBLK; b++) {
+        r[b] = ((int64_t)blockIdx.x * 4 + wave) * (32 * NBLK) + 32 * b + j;
+        rowid[b] = -1;
+        if (r[b] < n) rowid[b] = ids ? ids[r[b]] : (int32_t)(row0 + r[b]);
+        const T *xp = (const T *)((const unsigned char *)A.X32 + SEGK_SP_HEADER) + (int64_t)(rowid[b] >= 0 ? rowid[b] : 0) * (P * KP) + 8 * h;
+#pragma unroll
+        for (int s = 0; s < KS; s++) xb[b][s] = *reinterpret_cast<const V8 *>(xp + 16 * s);
+    }
+    float m1[NBLK], m2[NBLK];
+    int32_t ipr[NBLK], itile[NBLK];
+#pragma unroll
+    for (int b = 0; b < NBLK; b++) { m1[b] = NEG_INF_F; m2[b] = NEG_INF_F; ipr[b] = 0; itile[b] = 0; }
+
+    typedef __attribute__((address_space(3))) void *lptr_t;
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lptr_t)lds);
+    constexpr int NPASS = (KS + 1 + 3) / 4;
+    // piece q < KS: the piece-0 block of k-step q; piece KS: the constants.  Wave q % 4 copies it.
+    // (LDS-DMA from inline asm, one explicit wait per tile: see k_kmeans_score_sp)
+#define SEGK_STAGE(tt, buf)                                                                         \
+    do {                                                                                            \
+        _Pragma("unroll") for (int p = 0; p < NPASS; p++) {                                         \
+            const int q_ = p * 4 + wave;                                                            \
+            if (q_ <= KS) {                                                                         \
+                const float *src_ = tiles + (int64_t)(tt) * STRIDE + (q_ < KS ? q_ * P * 256 : KS * P * 256) + lane * 4; \
+                const unsigned dst_ = __builtin_amdgcn_readfirstlane(lds_base + ((buf) * TS + q_ * 256) * 4); \
+                unsigned keep_;                                                                     \
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"                 \
+                             "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"                  \
+                             : "=&s"(keep_)                                                         \
+                             : "v"(src_), "s"(dst_)                                                 \
+                             : "memory");                                                           \
+            }                                                                                       \
+        }                                                                                           \
+    } while (0)
+#define SEGK_TILE_SYNC()                                                      \
+    do {                                                                      \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");           \
+        __builtin_amdgcn_s_barrier();                                         \
+    } while (0)
+
+    SEGK_STAGE(0, 0);
+    SEGK_TILE_SYNC();
+    SEGK_STAMP_AT(1);
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int q = 0; q < 16; q++) { acc[0][q] = NEG_INF_F; acc[1][q] = NEG_INF_F; }
+
+    // values 2 pi, 2 pi + 1 of block O_'s accumulator: components c, c + 1 of this lane half
+#define SEGK_DRAIN2(O_, ACC, pi)                                                      \
+    do {                                                                              \
+        /* the first read of the MFMA results is a compiler-visible instruction: the hazard recogniser */ \
+        /* does not look inside inline asm, and these values can be a few cycles old (block b - 1)     */ \
+        const float tmp_ = __builtin_amdgcn_fmed3f(m1[O_], ACC[2 * (pi)], ACC[2 * (pi) + 1]);          \
+        float nm_;                                                                    \
+        asm volatile("v_max_f32 %1, %1, %3\n\t"                                       \
+                     "v_max3_f32 %0, %4, %5, %6\n\t"                                  \
+                     "v_cmp_nlt_f32 vcc, %4, %0\n\t"                                  \
+                     "v_cndmask_b32 %2, %7, %2, vcc"                                  \
+                     : "=&v"(nm_), "+v"(m2[O_]), "+v"(ipr[O_])                        \
+                     : "v"(tmp_), "v"(m1[O_]), "v"(ACC[2 * (pi)]), "v"(ACC[2 * (pi) + 1]), "n"((pi)) \
+                     : "vcc");                                                        \
+        m1[O_] = nm_;                                                                 \
+    } while (0)
+
+    constexpr int PPS = (8 + KS - 1) / KS;
+    // MFMAs of block N_ on the current tile over the drain of block O_'s values of tile dt_
+#define SEGK_UNIT(N_, O_, dt_)                                                                        \
+    do {                                                                                              \
+        {                                                                                             \
+            const float *cv = Tt + KS * 256 + 4 * h;                                                  \
+            _Pragma("unroll") for (int q = 0; q < 4; q++) {                                           \
+                float4 c4 = *reinterpret_cast<const float4 *>(cv + 8 * q);                            \
+                acc[(N_) & 1][4 * q + 0] = c4.x; acc[(N_) & 1][4 * q + 1] = c4.y;                     \
+                acc[(N_) & 1][4 * q + 2] = c4.z; acc[(N_) & 1][4 * q + 3] = c4.w;                     \
+            }                                                                                         \
+        }                                                                                             \
+        const float m1s = m1[O_];                                                                     \
+        _Pragma("unroll") for (int s = 0; s < KS; s++) {                                              \
+            acc[(N_) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s], xb[N_][s], acc[(N_) & 1], 0, 0, 0); \
+            _Pragma("unroll") for (int q = 0; q < PPS; q++)                                           \
+                if (s * PPS + q < 8) SEGK_DRAIN2(O_, acc[((N_) & 1) ^ 1], s * PPS + q);               \
+        }                                                                                             \
+        itile[O_] = (m1[O_] > m1s) ? (dt_) : itile[O_];                                               \
+    } while (0)
+
+    for (int t = 0; t < n_tiles; t++) {
+        if (t + 1 < n_tiles) SEGK_STAGE(t + 1, (t + 1) & 1);
+        const float *Tt = lds + (t & 1) * TS;
+        const T *Tb = (const T *)Tt;
+        V8 a[KS];
+#pragma unroll
+        for (int s = 0; s < KS; s++) a[s] = *reinterpret_cast<const V8 *>(Tb + (s * 64 + lane) * 8);
+        SEGK_UNIT(0, NBLK - 1, t - 1);
+        SEGK_UNIT(1, 0, t);
+        if constexpr (NBLK == 4) {
+            SEGK_UNIT(2, 1, t);
+            SEGK_UNIT(3, 2, t);
+        }
+        if (t == 15) SEGK_STAMP_AT(4);
+        SEGK_TILE_SYNC();
+        if (t == 15) SEGK_STAMP_AT(5);
+    }
+    SEGK_STAMP_AT(2);
+    {
+        const float m1s = m1[NBLK - 1];
+#pragma unroll
+        for (int pi = 0; pi < 8; pi++) SEGK_DRAIN2(NBLK - 1, acc[(NBLK - 1) & 1], pi);
+        itile[NBLK - 1] = (m1[NBLK - 1] > m1s) ? (n_tiles - 1) : itile[NBLK - 1];
+    }
+#undef SEGK_UNIT
+#undef SEGK_DRAIN2
+#undef SEGK_STAGE
+#undef SEGK_TILE_SYNC
+
+    const float M = (float)(sqrt(*A.mnorm2) * (1.0 + 1e-6)) + 1e-30f;
+    bool undecided[NBLK];
+    int n_und = 0;
+#pragma unroll
+    for (int b = 0; b < NBLK; b++) {
+        // the winning pair: components c, c + 1 (accumulator elements 2 ipr, 2 ipr + 1 of tile itile)
+        const int32_t c0 = itile[b] * 32 + 4 * h + 2 * (ipr[b] & 1) + 8 * (ipr[b] >> 1);
+        const float o1 = __shfl_xor(m1[b], 32), o2 = __shfl_xor(m2[b], 32);
+        const int oc = __shfl_xor(c0, 32);
+        const float top1 = fmaxf(m1[b], o1) * unscale;                 // powers of two: exact
+        const float top2 = fmaxf(fminf(m1[b], o1), fmaxf(m2[b], o2)) * unscale;
+        // equal maxima on the two halves leave a zero margin: the row is queued whichever pair is named
+        const int cw = (o1 > m1[b]) ? oc : c0;
+        undecided[b] = false;
+        if (h == 0 && rowid[b] >= 0) {
+            const int32_t rid = rowid[b];
+            const float tau = filter_tau_h1(A.xnorm[rid], M, D);
+            if (top1 - top2 > tau) {
+                // decided up to the member of the pair: k_kmeans_exact_pair scores both in reference
+                // arithmetic (a decisive winner beats its partner there as well) and clears the mark
+                A.cand.k[rid] = cw | SEGK_PAIR_PENDING;
+                A.cand.f[2 * (int64_t)rid + 0] = top1;
+                A.cand.f[2 * (int64_t)rid + 1] = top2;
+            } else {
+                undecided[b] = true;
+            }
+        }
+        n_und += __popcll(__ballot(undecided[b]));
+    }
+    // ONE queue reservation per wave (a returning atomic is a round trip to L2; one per row block kept the
+    // wave waiting four times over)
+    if (n_und > 0) {                                                   // wave-uniform
+        int base = 0;
+        if (lane == 0) base = atomicAdd(A.pre_count, n_und);
+        base = __shfl(base, 0);
+#pragma unroll
+        for (int b = 0; b < NBLK; b++) {
+            const unsigned long long mask = __ballot(undecided[b]);
+            if (undecided[b]) {
+                const int q = base + __popcll(mask & ((1ull << lane) - 1ull));
+                if (q < A.pre_cap) A.pre_queue[q] = rowid[b];
+                else {                                                 // beyond the second stage's launch: full scan
+                    const int q2 = atomicAdd(A.cand.count, 1);
+                    if (q2 < A.amb_cap) A.cand.queue[q2] = rowid[b];
+                }
+            }
+            base += __popcll(mask);
+        }
+    }
+    SEGK_STAMP_AT(3);
+#undef SEGK_STAMP_AT
 }
 
 // A handful of left-over rows (fewer than SEGK_TAIL_QUEUE): not worth three more launches -- they
@@ -2502,6 +2762,7 @@ static int launch_score(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *
         if (prof) {
             SEGK_CHECK_HIP(hipEventRecord(ctx->prof_ev[slot][1], st));
             ctx->prof_rows[slot] = n_main;
+            ctx->prof_kind = 0;
             ctx->prof_n++;
         }
     }
@@ -2574,6 +2835,7 @@ static int launch_score_sp(segk_ctx *ctx, ScoreArgs A, hipStream_t st)
         if (prof) {
             SEGK_CHECK_HIP(hipEventRecord(ctx->prof_ev[slot][1], st));
             ctx->prof_rows[slot] = n_main;
+            ctx->prof_kind = P;
             ctx->prof_n++;
         }
     }
@@ -2586,6 +2848,243 @@ static int launch_score_sp(segk_ctx *ctx, ScoreArgs A, hipStream_t st)
     }
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;
+}
+
+// Exact stage of the pre-filter's decided rows: cand.k = (c | SEGK_PAIR_PENDING) names the pair (c, c + 1);
+// both members are scored in the reference's float32 arithmetic (sp_exact_score_x) and the larger wins
+// (the lower index on a tie, as np.argmax).  A kernel of its own because inside the MFMA kernel these
+// reads -- 16 bytes per lane from 64 different rows per instruction, eight waves per CU, one row block
+// after the other -- took 60 % of a workgroup's lifetime (s_memtime stamps, profiles/README.md r01_h).
+// The arithmetic wants a lane to own whole strided accumulators of one (row, member), the memory system
+// wants whole lines: rows and pairs of means (a row is 4 D contiguous bytes, a pair 8 D) are read with
+// consecutive lanes on consecutive 16 bytes, written to LDS and scored from there.  One wave per
+// workgroup, 16 rows per step, private LDS (no barrier); the loads of step i + 1 are in flight while
+// step i is scored.  (Copying by LDS-DMA instead was measured at ~500 cycles per 1 KiB piece with 13
+// waves per CU -- the copy engine, not latency, set the pace: 324 us.)  Row stride KS*16 + 8 floats: the
+// float4 reads of 8 items x 2 lanes fall on distinct banks.
+#define SEGK_PAIR_ROWS 16
+template <int KS>
+__global__ __launch_bounds__(64) void k_kmeans_exact_pair(ScoreArgs A)
+{
+    constexpr int R = SEGK_PAIR_ROWS;
+    constexpr int C4 = KS * 4;                                     // 16-byte slots read per row (>= D / 4)
+    constexpr int LD = KS * 16 + 8;                                // floats per staged row
+    constexpr int RPI = 64 / C4;                                   // rows per load instruction (2 for KS 5..8)
+    constexpr int NLA = (R + RPI - 1) / RPI;                       // load instructions per array
+    extern __shared__ __attribute__((aligned(16))) float lds[];    // [3][R][LD]: x rows, member 0, member 1
+    const int lane = threadIdx.x, D = A.D, D4 = D >> 2;
+    const int64_t n_steps = (A.n + R - 1) / R;
+    const int sub = lane / C4, c4 = lane - sub * C4;               // this lane's row within an instruction, its slot
+
+    // Row ids and pair bases of a step live on lanes 0..R-1.  They are fetched ahead of use and nothing
+    // tests them in the iteration that issues the fetch (a test would wait for every older load as well):
+    //   rid2 (step i + 2): issued in iteration i;  k1 = cand.k[rid1] (step i + 1): issued in iteration i,
+    //   decoded in iteration i + 1 right before that step's loads.
+    auto fetch_rid = [&](int64_t step) -> int32_t {
+        const int64_t r = step * R + lane;
+        int32_t rid = -1;
+        if (step < n_steps && lane < R && r < A.n) rid = A.ids ? A.ids[r] : (int32_t)(A.row0 + r);
+        return rid;
+    };
+    auto fetch_k = [&](int32_t rid) -> int32_t { return rid >= 0 ? A.cand.k[rid] : 0; };
+    float4 v[3 * NLA];
+    // rows 2t, 2t + 1 (RPI = 2) of array arr per instruction: consecutive lanes on consecutive 16 bytes
+    uint64_t *rowp = reinterpret_cast<uint64_t *>(lds + 3 * R * LD);     // [3][R] row addresses of the step being loaded
+    auto issue_loads = [&](int32_t rid, int32_t c) {
+        // 64-bit row addresses once per step, by the rows' own lanes, through LDS (0 = skip): the load
+        // instructions below cost a ds_read_b64 and an add each -- no multiply, no lane exchange
+        if (lane < R) {
+            const bool live = rid >= 0;
+            const uint64_t xp = live ? (uint64_t)(uintptr_t)(A.xrows32 + (int64_t)rid * A.ld32) : 0;
+            const uint64_t mp0 = live ? (uint64_t)(uintptr_t)(A.means32 + (int64_t)c * D) : 0;
+            rowp[lane] = xp;
+            rowp[R + lane] = mp0;
+            rowp[2 * R + lane] = (live && c + 1 < A.K_max) ? mp0 + (uint64_t)D * 4 : 0;
+        }
+        uint64_t base[3 * NLA];
+#pragma unroll
+        for (int arr = 0; arr < 3; arr++)
+#pragma unroll
+            for (int t = 0; t < NLA; t++)
+                base[arr * NLA + t] = (sub < RPI && RPI * t + sub < R) ? rowp[arr * R + RPI * t + sub] : 0;
+#pragma unroll
+        for (int i = 0; i < 3 * NLA; i++) {
+            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (base[i] != 0 && c4 < D4) v[i] = *reinterpret_cast<const float4 *>((uintptr_t)(base[i] + 16u * (unsigned)c4));
+        }
+    };
+    auto decode = [&](int32_t &rid, int32_t k) -> int32_t {       // pair base, or -1 (and rid = -1) when not pending
+        if (rid >= 0 && (k & SEGK_PAIR_PENDING)) return k & ~SEGK_PAIR_PENDING;
+        rid = -1;
+        return -1;
+    };
+
+    int64_t step = blockIdx.x;
+    int32_t rid0 = fetch_rid(step);
+    int32_t c0 = decode(rid0, fetch_k(rid0));
+    issue_loads(rid0, c0);
+    int32_t rid1 = fetch_rid(step + gridDim.x);
+    int32_t k1 = fetch_k(rid1);
+    int32_t rid2 = fetch_rid(step + 2 * (int64_t)gridDim.x);
+#ifdef SEGK_STAMP
+#define SEGK_STAMP_P(i) do { if (A.stamp && lane == 0 && it_ == 3) A.stamp[65536 + (int64_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SEGK_STAMP_P(i) do { } while (0)
+#endif
+    int it_ = 0;
+    for (; step < n_steps; step += gridDim.x, it_++) {
+        SEGK_STAMP_P(0);
+#pragma unroll
+        for (int arr = 0; arr < 3; arr++)
+#pragma unroll
+            for (int t = 0; t < NLA; t++)
+                if (sub < RPI && RPI * t + sub < R)
+                    *reinterpret_cast<float4 *>(lds + (arr * R + RPI * t + sub) * LD + 4 * c4) = v[arr * NLA + t];
+        SEGK_STAMP_P(1);
+        const int32_t ridc = rid0, cc0 = c0;
+        const int32_t c1 = decode(rid1, k1);
+        issue_loads(rid1, c1);                                     // the next step's rows: in flight under this step's arithmetic
+        rid0 = rid1; c0 = c1;
+        rid1 = rid2;
+        k1 = fetch_k(rid1);
+        rid2 = fetch_rid(step + 3 * (int64_t)gridDim.x);
+        SEGK_STAMP_P(2);
+        // lanes 4 r + {0, 1}: member 0 of row r; lanes 4 r + {2, 3}: member 1 (LDS operations of one wave
+        // complete in order: the reads below see the writes above)
+        const int item = lane >> 1, h = lane & 1, row = item >> 1, mem = item & 1;
+        const float sc = sp_exact_score_x<KS, 1>(lds + ((1 + mem) * R + row) * LD, lds + row * LD, D, h);
+        const float so = __shfl_xor(sc, 2);
+        const int32_t rid = __shfl(ridc, row), c = __shfl(cc0, row);
+        if ((lane & 3) == 0 && rid >= 0) {
+            const bool second = c + 1 < A.K_max && so > sc;
+            A.cand.k[rid] = second ? c + 1 : c;
+            A.cand.s[rid] = (double)(second ? so : sc);
+        }
+        SEGK_STAMP_P(3);
+    }
+#undef SEGK_STAMP_P
+}
+
+// rows the pre-filter launch does not cover (fewer than SEGK_TAIL_QUEUE): straight to its second stage
+__global__ void k_pre_queue_rows(ScoreArgs A)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= A.n) return;
+    const int32_t id = A.ids ? A.ids[r] : (int32_t)(A.row0 + r);
+    if (id < 0) return;
+    const int q = atomicAdd(A.pre_count, 1);
+    if (q < A.pre_cap) A.pre_queue[q] = id;
+    else {
+        const int q2 = atomicAdd(A.cand.count, 1);
+        if (q2 < A.amb_cap) A.cand.queue[q2] = id;
+    }
+}
+
+// One-product pre-filter over all rows, then the split-precision kernel over the rows it queued.
+template <int KS>
+static int launch_score_pre(segk_ctx *ctx, ScoreArgs A, hipStream_t st)
+{
+    if (ctx->pre_cap < A.n) {                         // queue of the undecided rows, grown on demand
+        if (ctx->pre_queue) SEGK_CHECK_HIP(hipFree(ctx->pre_queue));
+        ctx->pre_queue = nullptr;
+        ctx->pre_cap = 0;
+        SEGK_CHECK_HIP(hipMalloc((void **)&ctx->pre_queue, sizeof(int32_t) * (size_t)(A.n + 16)));
+        ctx->pre_cap = A.n;
+    }
+    A.pre_queue = ctx->pre_queue + 16;
+    A.pre_count = ctx->pre_queue;
+    // the second stage is launched for every row (its row count is read on the device; the workgroups
+    // beyond it leave at once), so the queue cannot overflow whatever the data
+    const int64_t cap2 = A.n;
+    A.pre_cap = (int)cap2;
+#ifdef SEGK_STAMP
+    A.stamp = getenv("SEGK_STAMP_PTR") ? (unsigned long long *)strtoull(getenv("SEGK_STAMP_PTR"), nullptr, 0) : nullptr;
+#endif
+    SEGK_CHECK_HIP(hipMemsetAsync(A.pre_count, 0, sizeof(int32_t), st));
+
+    constexpr size_t lds = 2 * (size_t)(KS + 1) * 256 * sizeof(float);
+    const int64_t slots = 2 * (int64_t)ctx->n_cu;      // two 4-wave workgroups per CU (launch bounds)
+    // whole rounds of 512-row workgroups (four row blocks per wave), the remainder in 256-row workgroups
+    const int64_t round4 = slots * 512;
+    int64_t n4 = (A.n / round4) * round4;
+    if (getenv("SEGK_PRE_NBLK") && atoi(getenv("SEGK_PRE_NBLK")) == 2) n4 = 0;      // development: 256-row workgroups only
+    const bool prof = ctx->prof_on != 0;
+    const int slot = ctx->prof_n % SEGK_PROF_SLOTS;
+    if (prof) SEGK_CHECK_HIP(hipEventRecord(ctx->prof_ev[slot][0], st));
+    // the timed launch (segk_profile_*): the 512-row-workgroup launch when there is one, else the 256-row one
+    auto prof_end = [&](int64_t rows) -> int {
+        if (!prof) return SEGK_OK;
+        SEGK_CHECK_HIP(hipEventRecord(ctx->prof_ev[slot][1], st));
+        ctx->prof_rows[slot] = rows;
+        ctx->prof_kind = 1;
+        ctx->prof_n++;
+        return SEGK_OK;
+    };
+    if (n4 > 0) {
+        ScoreArgs M = A;
+        M.n = n4;
+        hipLaunchKernelGGL((k_kmeans_score_h1<KS, 4>), dim3((unsigned)(n4 / 512)), dim3(256), lds, st, M);
+        if (int rc = prof_end(n4)) return rc;
+    }
+    const int64_t rem = A.n - n4;
+    if (rem > 0) {
+        ScoreArgs T = A;
+        T.n = rem;
+        T.row0 = A.row0 + n4;
+        T.ids = A.ids ? A.ids + n4 : nullptr;
+        if (rem >= SEGK_TAIL_QUEUE || n4 == 0) {
+            hipLaunchKernelGGL((k_kmeans_score_h1<KS, 2>), dim3((unsigned)((rem + 255) / 256)), dim3(256), lds, st, T);
+            if (n4 == 0)
+                if (int rc = prof_end(rem)) return rc;
+        } else {
+            hipLaunchKernelGGL(k_pre_queue_rows, dim3((unsigned)((rem + 255) / 256)), dim3(256), 0, st, T);
+        }
+    }
+    // exact stage of the decided rows
+    {
+        const size_t lds_p = 3 * (size_t)SEGK_PAIR_ROWS * (KS * 16 + 8) * sizeof(float) + 3 * SEGK_PAIR_ROWS * sizeof(uint64_t);
+        const int64_t steps = (A.n + SEGK_PAIR_ROWS - 1) / SEGK_PAIR_ROWS;
+        int64_t waves = (int64_t)ctx->n_cu * (int64_t)(160 * 1024 / lds_p);
+        if (waves > 8 * (int64_t)ctx->n_cu) waves = 8 * (int64_t)ctx->n_cu;
+        if (waves > steps) waves = steps;
+        hipLaunchKernelGGL((k_kmeans_exact_pair<KS>), dim3((unsigned)waves), dim3(64), lds_p, st, A);
+    }
+    // second stage: all three products for the queued rows; the row count is read on the device
+    {
+        constexpr int STRIDE = (KS * 2 * 256 + 32 + 1023) / 1024 * 1024;
+        const size_t lds2 = 2 * (size_t)STRIDE * sizeof(float);
+        static bool attr_set = false;
+        if (!attr_set && lds2 > 48 * 1024) {
+            SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_kmeans_score_sp<KS, 4, 2>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+            attr_set = true;
+        }
+        ScoreArgs B = A;
+        B.ids = A.pre_queue;
+        B.row0 = 0;
+        B.n = cap2;
+        B.n_dev = A.pre_count;
+        hipLaunchKernelGGL((k_kmeans_score_sp<KS, 4, 2>), dim3((unsigned)((cap2 + 127) / 128)), dim3(256), lds2, st, B);
+    }
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+static int dispatch_score_pre(segk_ctx *ctx, const ScoreArgs &A, int ks, hipStream_t st)
+{
+    switch (ks) {
+        case 1: return launch_score_pre<1>(ctx, A, st);
+        case 2: return launch_score_pre<2>(ctx, A, st);
+        case 3: return launch_score_pre<3>(ctx, A, st);
+        case 4: return launch_score_pre<4>(ctx, A, st);
+        case 5: return launch_score_pre<5>(ctx, A, st);
+        case 6: return launch_score_pre<6>(ctx, A, st);
+        case 7: return launch_score_pre<7>(ctx, A, st);
+        case 8: return launch_score_pre<8>(ctx, A, st);
+        default: break;
+    }
+    segk_set_error("pre-filter: D out of range");
+    return SEGK_ERR_UNSUPPORTED;
 }
 
 template <int P>
@@ -2649,6 +3148,7 @@ static int launch_score_lse_sp(segk_ctx *ctx, const ScoreArgs &A, hipStream_t st
     if (prof) {
         SEGK_CHECK_HIP(hipEventRecord(ctx->prof_ev[slot][1], st));
         ctx->prof_rows[slot] = A.n;
+        ctx->prof_kind = 4;
         ctx->prof_n++;
     }
     SEGK_LAUNCH_CHECK();
@@ -2677,7 +3177,7 @@ int segk_launch_score_mat_sp(const void *ximg, int D2, const int32_t *ids, int64
                              float *mat, int64_t mat_ld, void *stream)
 {
     if (n <= 0) return SEGK_OK;
-    ScoreArgs A;
+    ScoreArgs A{};
     memset(&A, 0, sizeof(A));
     A.X32 = (const float *)ximg; A.ids = ids; A.row0 = 0; A.n = n;
     A.tiles = tiles_sp; A.n_tiles = n_tiles; A.tile_stride = segk_sp_tile_stride(D2, 2);
@@ -2701,7 +3201,7 @@ int segk_launch_score_lse_sp(segk_ctx *ctx, const void *ximg, int D2, const int3
                              const float *tiles_sp, int n_tiles, double norm, double *out, void *stream)
 {
     if (n <= 0) return SEGK_OK;
-    ScoreArgs A;
+    ScoreArgs A{};
     memset(&A, 0, sizeof(A));
     A.X32 = (const float *)ximg; A.ids = ids; A.row0 = row0; A.n = n;
     A.tiles = tiles_sp; A.n_tiles = n_tiles; A.tile_stride = segk_sp_tile_stride(D2, 2);
@@ -2738,6 +3238,7 @@ static int launch_score_lse(segk_ctx *ctx, const ScoreArgs &A, hipStream_t st)
     if (prof) {
         SEGK_CHECK_HIP(hipEventRecord(ctx->prof_ev[slot][1], st));
         ctx->prof_rows[slot] = A.n;
+        ctx->prof_kind = 4;
         ctx->prof_n++;
     }
     SEGK_LAUNCH_CHECK();
@@ -2750,7 +3251,7 @@ int segk_launch_score_lse(segk_ctx *ctx, const float *Y, int64_t ldy, int D2, co
                           const float *tiles, int n_tiles, double norm, double *out, void *stream)
 {
     if (n <= 0) return SEGK_OK;
-    ScoreArgs A;
+    ScoreArgs A{};
     memset(&A, 0, sizeof(A));
     A.X32 = Y; A.ld32 = ldy; A.ids = ids; A.row0 = row0; A.n = n;
     A.tiles = tiles; A.n_tiles = n_tiles; A.tile_stride = segk_tile_stride(D2);
@@ -2878,7 +3379,7 @@ int32_t segk_kmeans_filter(segk_ctx *ctx, const segk_corpus *c, const segk_kmean
     if (rc) return rc;
     if (n <= 0) return SEGK_OK;
     hipStream_t st = (hipStream_t)stream;
-    ScoreArgs A;
+    ScoreArgs A{};
     A.X32 = c->X32; A.ld32 = c->ld32; A.ids = ids; A.row0 = row0; A.n = n;
     A.tiles = m->tiles; A.n_tiles = segk_n_tiles(m->K_max); A.tile_stride = segk_tile_stride(c->D);
     A.G = segk_G(c->D); A.D = c->D;
@@ -2898,6 +3399,17 @@ int32_t segk_kmeans_filter(segk_ctx *ctx, const segk_corpus *c, const segk_kmean
         A.tile_stride = segk_sp_tile_stride(c->D, c->sp_pieces);
         A.means32 = (const float *)m->means;
         A.fuse_exact = (c->D % 4 == 0) ? 1 : 0;
+        A.K_max = m->K_max;
+        // one-product pre-filter in front (two-piece images, D % 4 == 0).  Its three extra launches -- and the
+        // second stage's fixed cost, one workgroup's pass over every tile with all three products (~45 us)
+        // -- pay once the split-precision kernel alone would need more than four rounds of the chip
+        // (estimated break-even near 130 k rows; 1 M rows: 0.58 ms against 0.77 ms).
+        // SEGK_SCORE_PRE=0 disables it, =1 forces it at every size (tests).
+        const char *pre_env = getenv("SEGK_SCORE_PRE");
+        const int pre_mode = pre_env ? atoi(pre_env) : -1;
+        if (c->sp_pieces == 2 && A.fuse_exact && pre_mode != 0 && (pre_mode == 1 || n > 1024 * (int64_t)ctx->n_cu) &&
+            n < (int64_t)1 << 30)
+            return dispatch_score_pre(ctx, A, segk_b3_kp(c->D) / 16, st);
         return c->sp_pieces == 2 ? dispatch_score_sp<2>(ctx, A, segk_b3_kp(c->D) / 16, st)
                                  : dispatch_score_sp<3>(ctx, A, segk_b3_kp(c->D) / 16, st);
     }

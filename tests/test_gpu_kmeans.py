@@ -404,3 +404,83 @@ def test_split_precision_filter_wide_dynamic_range(gpu, monkeypatch, pieces):
         e1 = (1.02 * (64 + 16) + (16 if pieces == "2" else 0)) * u * (xn * Mmax + 0.5 * Mmax ** 2)
         sel = np.isfinite(cf[:, 0])
         assert (np.abs(cf[sel, 0] - f1[sel]) / e1[sel]).max() < 0.5
+
+
+# ------------------------------------------------------------------ one-product pre-filter
+@pytest.mark.parametrize("D,K,n,scale", [(100, 1000, 4096, 1.0), (128, 513, 3000, 1.0), (40, 257, 2500, 30.0),
+                                         (16, 64, 1500, 1e-3), (8, 31, 700, 1.0), (64, 33, 5000, 7e3)])
+def test_prefilter_decisions_are_the_references(gpu, monkeypatch, D, K, n, scale):
+    """SEGK_SCORE_PRE=1 forces the one-product fp16 pre-filter (normally used above one round of the
+    chip) in front of the split-precision kernel: max / argmax after the exact stage stay the
+    reference's bit for bit -- clustered rows, an exact tie, a duplicated mean inside one PAIR of
+    components (the pre-filter tracks pairs and lets the exact stage pick the member)."""
+    from oracle import c_oracle as co
+    monkeypatch.setenv("SEGK_SCORE_PRE", "1")
+    rs = np.random.RandomState(D * 1000 + K + 1)
+    K_true = max(2, K // 2)
+    mu = rs.randn(K_true, D)
+    X = mu[rs.randint(0, K_true, n)] + 0.3 * rs.randn(n, D)
+    X /= np.linalg.norm(X, axis=1, keepdims=True)
+    X = (X * scale).astype(np.float32)
+    means = (mu[rs.randint(0, K_true, K)] + 0.05 * rs.randn(K, D))
+    means /= np.linalg.norm(means, axis=1, keepdims=True)
+    means = (means * scale).astype(np.float32)
+    means[K // 2] = means[1]          # exact duplicate in another pair
+    means[7] = means[6]               # exact duplicate inside the pair (6, 7)
+    X[5] = means[1]
+    X[9] = means[6]
+    c = _components(X, means)
+    mx, am, nbrute = c.dev.exact_max(np.arange(n))
+    want_mx, want_am = co.kmeans_max_argmax(means, X)
+    assert np.array_equal(am, want_am)
+    assert np.array_equal(mx, want_mx)
+    assert am[5] == 1 and am[9] == 6
+    assert 1 <= nbrute < n // 4
+
+
+def test_prefilter_wide_dynamic_range(gpu, monkeypatch):
+    """Elements spanning nine decades (mostly flushed or subnormal in fp16), NaN-free: decisions stay exact."""
+    from oracle import c_oracle as co
+    monkeypatch.setenv("SEGK_SCORE_PRE", "1")
+    rs = np.random.RandomState(98)
+    n, D, K = 3000, 64, 200
+    for scale in (1.0, 3e-4, 7e3):
+        X = (rs.randn(n, D) * 10.0 ** rs.uniform(-9, 0, size=(n, D)) * scale).astype(np.float32)
+        means = (rs.randn(K, D) * 10.0 ** rs.uniform(-9, 0, size=(K, D)) * scale).astype(np.float32)
+        means[7] = means[3]
+        X[11] = means[3]
+        c = _components(X, means)
+        mx, am, nbrute = c.dev.exact_max(np.arange(n))
+        want_mx, want_am = co.kmeans_max_argmax(means, X)
+        assert np.array_equal(am, want_am) and np.array_equal(mx, want_mx)
+        assert am[11] == 3
+
+
+@pytest.mark.parametrize("n,force", [(70000, True), (262144 + 1000, False), (262144 + 5000, False)])
+def test_prefilter_large_launches(gpu, monkeypatch, n, force):
+    """Above four rounds of the chip (262 144 rows on 256 CUs) the pre-filter is the default.  The three
+    sizes take the 256-row workgroups alone (forced), whole rounds of 512-row workgroups + a queued
+    remainder, and whole rounds + a second launch for the remainder; the contiguous-row (ids = NULL) form
+    is what the sweeps use."""
+    if force:
+        monkeypatch.setenv("SEGK_SCORE_PRE", "1")
+    import torch
+    from oracle import c_oracle as co
+    rs = np.random.RandomState(n % 1000)
+    D, K = 100, 500
+    mu = rs.randn(K // 2, D)
+    X = mu[rs.randint(0, K // 2, n)] + 0.3 * rs.randn(n, D)
+    X /= np.linalg.norm(X, axis=1, keepdims=True)
+    X = X.astype(np.float32)
+    means = (mu[rs.randint(0, K // 2, K)] + 0.1 * rs.randn(K, D)).astype(np.float32)
+    means /= np.linalg.norm(means, axis=1, keepdims=True)
+    c = _components(X, means)
+    c.dev.score_rows()
+    torch.cuda.synchronize()
+    nbrute = int(c.dev.cand_count.item())
+    am = c.dev.cand_k.cpu().numpy()
+    mx = c.dev.cand_s.cpu().numpy()
+    want_mx, want_am = co.kmeans_max_argmax(means, X)
+    assert np.array_equal(am, want_am)
+    assert np.array_equal(mx, want_mx.astype(np.float64))
+    assert nbrute < n // 50          # near-duplicate means: a third of the rows pass to the second stage, few beyond

@@ -19,6 +19,8 @@ from segmentalist_amd.device import DeviceCorpus, DeviceKMeans  # noqa: E402
 rs = np.random.RandomState(0)
 X = rs.randn(n, D).astype(np.float32)
 X /= np.linalg.norm(X, axis=1, keepdims=True)
+if os.environ.get("DIAG_ZERO"):            # DVFS check: same instruction stream on trivial operands
+    X[:] = 0.0
 corpus = DeviceCorpus(X)
 assign = -np.ones(n, dtype=np.int64)
 assign[:K] = np.arange(K)
