@@ -21,6 +21,11 @@ struct segk_ctx {
     // rows the one-product pre-filter could not decide: [0] count, [16..] row ids (grown on demand)
     int32_t *pre_queue;
     int64_t pre_cap;
+    // second stream of segk_kmeans_score: the pre-filter's second stage and the full scan run on it beside
+    // the exact stage of the decided rows (created on first use)
+    hipStream_t aux;
+    hipEvent_t ev_fork, ev_join;
+    int overlap_req, aux_busy;
     // optional timing of the main score launch (segk_profile_*): event pairs used round-robin
     int prof_on, prof_n, prof_kind;
     hipEvent_t prof_ev[SEGK_PROF_SLOTS][2];

@@ -3040,11 +3040,27 @@ static int launch_score_pre(segk_ctx *ctx, ScoreArgs A, hipStream_t st)
             hipLaunchKernelGGL(k_pre_queue_rows, dim3((unsigned)((rem + 255) / 256)), dim3(256), 0, st, T);
         }
     }
+    // The decided rows' exact stage (this stream) and the undecided rows' second stage + full scan (second
+    // stream, segk_kmeans_score only) touch disjoint rows: side by side, the exact stage leaving LDS for one
+    // second-stage workgroup per CU.  Joined at the end of segk_kmeans_score.
+    const bool overlap = ctx->overlap_req != 0;
+    hipStream_t st2 = st;
+    if (overlap) {
+        if (!ctx->aux) {
+            SEGK_CHECK_HIP(hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking));
+            SEGK_CHECK_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+            SEGK_CHECK_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+        }
+        SEGK_CHECK_HIP(hipEventRecord(ctx->ev_fork, st));
+        SEGK_CHECK_HIP(hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
+        st2 = ctx->aux;
+        ctx->aux_busy = 1;
+    }
     // exact stage of the decided rows
     {
         const size_t lds_p = 3 * (size_t)SEGK_PAIR_ROWS * (KS * 16 + 8) * sizeof(float) + 3 * SEGK_PAIR_ROWS * sizeof(uint64_t);
         const int64_t steps = (A.n + SEGK_PAIR_ROWS - 1) / SEGK_PAIR_ROWS;
-        int64_t waves = (int64_t)ctx->n_cu * (int64_t)(160 * 1024 / lds_p);
+        int64_t waves = (int64_t)ctx->n_cu * (int64_t)(((overlap ? 124 : 160) * 1024) / lds_p);
         if (waves > 8 * (int64_t)ctx->n_cu) waves = 8 * (int64_t)ctx->n_cu;
         if (waves > steps) waves = steps;
         hipLaunchKernelGGL((k_kmeans_exact_pair<KS>), dim3((unsigned)waves), dim3(64), lds_p, st, A);
@@ -3064,7 +3080,7 @@ static int launch_score_pre(segk_ctx *ctx, ScoreArgs A, hipStream_t st)
         B.row0 = 0;
         B.n = cap2;
         B.n_dev = A.pre_count;
-        hipLaunchKernelGGL((k_kmeans_score_sp<KS, 4, 2>), dim3((unsigned)((cap2 + 127) / 128)), dim3(256), lds2, st, B);
+        hipLaunchKernelGGL((k_kmeans_score_sp<KS, 4, 2>), dim3((unsigned)((cap2 + 127) / 128)), dim3(256), lds2, st2, B);
     }
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;
@@ -3432,8 +3448,17 @@ int32_t segk_kmeans_filter(segk_ctx *ctx, const segk_corpus *c, const segk_kmean
     return SEGK_ERR_UNSUPPORTED;
 }
 
+static int resolve_on(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m, const int32_t *ids,
+                      int64_t row0, int64_t n, const segk_cand *cand, int32_t *status, void *stream);
+
 int32_t segk_kmeans_resolve(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m, const int32_t *ids,
                             int64_t row0, int64_t n, const segk_cand *cand, int32_t *status, void *stream)
+{
+    return resolve_on(ctx, c, m, ids, row0, n, cand, status, stream);
+}
+
+static int resolve_on(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m, const int32_t *ids,
+                      int64_t row0, int64_t n, const segk_cand *cand, int32_t *status, void *stream)
 {
     SEGK_REQUIRE(ctx, "ctx");
     int rc = score_checks(c, m, ids, row0, n, cand);
@@ -3480,9 +3505,18 @@ int32_t segk_kmeans_score(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans
 {
     int rc = segk_kmeans_clear_queue(ctx, cand, stream);
     if (rc) return rc;
+    // SEGK_SCORE_OVERLAP=0: everything on the caller's stream
+    const char *ov = getenv("SEGK_SCORE_OVERLAP");
+    ctx->overlap_req = (ov && atoi(ov) == 0) ? 0 : 1;
     rc = segk_kmeans_filter(ctx, c, m, ids, row0, n, cand, stream);
+    ctx->overlap_req = 0;
     if (rc) return rc;
-    return segk_kmeans_resolve(ctx, c, m, ids, row0, n, cand, status, stream);
+    if (!ctx->aux_busy) return resolve_on(ctx, c, m, ids, row0, n, cand, status, stream);
+    rc = resolve_on(ctx, c, m, ids, row0, n, cand, status, (void *)ctx->aux);
+    ctx->aux_busy = 0;
+    SEGK_CHECK_HIP(hipEventRecord(ctx->ev_join, ctx->aux));
+    SEGK_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, ctx->ev_join, 0));
+    return rc;
 }
 
 int32_t segk_kmeans_exact_max(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m, const int32_t *ids,
