@@ -1385,13 +1385,23 @@ __global__ void k_kmeans_brute(segk_corpus c, segk_kmeans m, segk_cand cand, int
 // (row, component) the arithmetic is neg_sqd_exact's: eight strided accumulators, the fixed combine
 // tree, the sequential tail; first maximum per row.
 #define SEGK_BR 8
+// component slices of the full scan for a queue of nq rows on a grid of `grid` workgroups (at most max_split)
+__device__ __forceinline__ int segk_brute_split(int nq, int grid, int max_split)
+{
+    const int groups = (nq + SEGK_BR - 1) / SEGK_BR;
+    int ks = groups > 0 ? grid / groups : 1;
+    if (ks > max_split) ks = max_split;
+    return ks < 1 ? 1 : ks;
+}
+
 __global__ __launch_bounds__(256) void k_kmeans_brute_rows(segk_corpus c, segk_kmeans m, segk_cand cand, int cap, int32_t *n_brute,
                                                           int n_groups, int ksplit, unsigned long long *ws, int ws_cap)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, nt = blockDim.x, D = c.D;
-    float *xs = (float *)smem;                               // [BR][D]
-    float *red_v = xs + SEGK_BR * D;                         // [nt]
+    const int DP = (D + 3) & ~3;                             // row pitch: float4 reads of the staged rows
+    float *xs = (float *)smem;                               // [BR][DP]
+    float *red_v = xs + SEGK_BR * DP;                        // [nt]
     int32_t *red_k = (int32_t *)(red_v + nt);                // [nt]
     __shared__ int32_t ids[SEGK_BR];
     const float *X = (const float *)c.X;
@@ -1403,7 +1413,13 @@ __global__ __launch_bounds__(256) void k_kmeans_brute_rows(segk_corpus c, segk_k
     // workgroup = (row group, component slice): the slices of a row meet in ws[] through a 64-bit
     // atomicMax on (orderable score bits, ~component) -- the largest score, the lowest component on ties;
     // k_brute_finish unpacks.  Queue entries beyond ws_cap keep the unsplit form (slice 0 scans all).
+    // The host does not know the queue length (it lives on the device), so the split is chosen here, from
+    // the launched grid: as many component slices (up to `ksplit`, one component per thread and slice) as
+    // the grid has workgroups per row group.  segk_brute_split() is shared with k_brute_finish.
+    ksplit = segk_brute_split(nq, (int)gridDim.x, ksplit);
+    n_groups = (int)gridDim.x / ksplit;
     const int grp0 = blockIdx.x % n_groups, slice = blockIdx.x / n_groups;
+    if (slice >= ksplit) return;
     const int k_per = (m.K_max + ksplit - 1) / ksplit;
     for (int q0 = grp0 * SEGK_BR; q0 < nq; q0 += n_groups * SEGK_BR) {
         const bool split = ksplit > 1 && q0 + SEGK_BR <= ws_cap;
@@ -1416,7 +1432,7 @@ __global__ __launch_bounds__(256) void k_kmeans_brute_rows(segk_corpus c, segk_k
         __syncthreads();
         for (int j = tid; j < SEGK_BR * D; j += nt) {
             const int r = j / D, d = j - r * D;
-            xs[j] = X[(int64_t)ids[r] * c.ldx + d];
+            xs[r * DP + d] = X[(int64_t)ids[r] * c.ldx + d];
         }
         __syncthreads();
         float best[SEGK_BR];
@@ -1430,23 +1446,29 @@ __global__ __launch_bounds__(256) void k_kmeans_brute_rows(segk_corpus c, segk_k
 #pragma unroll
             for (int j = 0; j < 8; j++) mv[j] = mr[j];
 #pragma unroll
-            for (int r = 0; r < SEGK_BR; r++)
+            for (int r = 0; r < SEGK_BR; r++) {
+                const float4 x0 = *reinterpret_cast<const float4 *>(xs + r * DP), x1 = *reinterpret_cast<const float4 *>(xs + r * DP + 4);
+                const float xv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
-                    const float delta = mv[j] - xs[r * D + j];
+                    const float delta = mv[j] - xv[j];
                     acc[r][j] = delta * delta;
                 }
+            }
             int i;
             for (i = 8; i < nfull; i += 8) {
 #pragma unroll
                 for (int j = 0; j < 8; j++) mv[j] = mr[i + j];
 #pragma unroll
-                for (int r = 0; r < SEGK_BR; r++)
+                for (int r = 0; r < SEGK_BR; r++) {
+                    const float4 x0 = *reinterpret_cast<const float4 *>(xs + r * DP + i), x1 = *reinterpret_cast<const float4 *>(xs + r * DP + i + 4);
+                    const float xv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
 #pragma unroll
                     for (int j = 0; j < 8; j++) {
-                        const float delta = mv[j] - xs[r * D + i + j];
+                        const float delta = mv[j] - xv[j];
                         acc[r][j] += delta * delta;
                     }
+                }
             }
             float res[SEGK_BR];
 #pragma unroll
@@ -1456,7 +1478,7 @@ __global__ __launch_bounds__(256) void k_kmeans_brute_rows(segk_corpus c, segk_k
                 const float mvi = mr[i];
 #pragma unroll
                 for (int r = 0; r < SEGK_BR; r++) {
-                    const float delta = mvi - xs[r * D + i];
+                    const float delta = mvi - xs[r * DP + i];
                     res[r] += delta * delta;
                 }
             }
@@ -1505,10 +1527,11 @@ __global__ __launch_bounds__(256) void k_kmeans_brute_rows(segk_corpus c, segk_k
 }
 
 // unpack the split scan's (score, component) pairs into the candidates and clear the workspace
-__global__ void k_brute_finish(segk_cand cand, int cap, unsigned long long *ws, int ws_cap)
+__global__ void k_brute_finish(segk_cand cand, int cap, unsigned long long *ws, int ws_cap, int scan_grid, int max_split)
 {
     int nq = *cand.count;
     if (nq > cap) nq = cap;
+    if (segk_brute_split(nq, scan_grid, max_split) <= 1) return;       // the scan wrote the candidates itself
     // the groups that were scanned in slices: q0 + SEGK_BR <= ws_cap
     const int lim = nq < (ws_cap / SEGK_BR) * SEGK_BR ? nq : (ws_cap / SEGK_BR) * SEGK_BR;
     for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < lim; q += gridDim.x * blockDim.x) {
@@ -3471,24 +3494,21 @@ static int resolve_on(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m,
                                            *c, *m, ids, row0, n, *cand););
     const int nt = 256;
     if (fused) {         // float32 data, 8 <= D <= 128: SEGK_BR queued rows per workgroup, components in slices
-        const size_t lds = (size_t)SEGK_BR * c->D * sizeof(float) + nt * (sizeof(float) + sizeof(int32_t));
+        const size_t lds = (size_t)SEGK_BR * ((c->D + 3) & ~3) * sizeof(float) + nt * (sizeof(float) + sizeof(int32_t));
+        // grid for the worst case the host can see (every row queued), capped; the kernel reads the queue
+        // length and slices the components over whatever the grid leaves per row group (a queue of 200 rows
+        // on 1024 workgroups: four slices instead of 25 busy workgroups; alone: 15 us + 13 us per 1000 rows)
         const int64_t groups = (n + SEGK_BR - 1) / SEGK_BR;
-        const int n_groups = (int)(groups < 1024 ? groups : 1024);
-        // Few row groups (one utterance of the serial chain, a small shard): slice the components so that
-        // more workgroups share the scan -- one component per thread and slice, up to eight slices.  With
-        // hundreds of groups the chip is full anyway and slicing only repeats the per-group overhead
-        // (measured: 53 -> 77 us on the bench queue), so those launches stay unsliced.
-        int ksplit = 1;
-        if (groups < 256) {
-            ksplit = (m->K_max + nt - 1) / nt;
-            if (ksplit > 8) ksplit = 8;
-            if (ksplit < 1) ksplit = 1;
-        }
-        hipLaunchKernelGGL(k_kmeans_brute_rows, dim3((unsigned)(n_groups * ksplit)), dim3(nt), lds, st, *c, *m, *cand,
-                           (int)c->n_emb, status ? status + 1 : nullptr, n_groups, ksplit, ctx->ws_u64, SEGK_WS_ENTRIES);
-        if (ksplit > 1)
-            hipLaunchKernelGGL(k_brute_finish, dim3((unsigned)(n_groups < 256 ? (n_groups * SEGK_BR + 255) / 256 : 32)), dim3(256),
-                               0, st, *cand, (int)c->n_emb, ctx->ws_u64, SEGK_WS_ENTRIES);
+        int max_split = (m->K_max + nt - 1) / nt;
+        if (max_split > 8) max_split = 8;
+        if (max_split < 1) max_split = 1;
+        int64_t grid = groups * max_split;
+        if (grid > 1024) grid = 1024;
+        hipLaunchKernelGGL(k_kmeans_brute_rows, dim3((unsigned)grid), dim3(nt), lds, st, *c, *m, *cand,
+                           (int)c->n_emb, status ? status + 1 : nullptr, (int)grid, max_split, ctx->ws_u64, SEGK_WS_ENTRIES);
+        if (max_split > 1)
+            hipLaunchKernelGGL(k_brute_finish, dim3(32), dim3(256), 0, st, *cand, (int)c->n_emb, ctx->ws_u64, SEGK_WS_ENTRIES,
+                               (int)grid, max_split);
     } else {
         size_t xsz = (c->x_dtype == SEGK_F32 ? 4 : 8) * (size_t)((c->D + 1) & ~1);
         size_t lds = nt * sizeof(double) + xsz + nt * sizeof(int32_t);
