@@ -202,9 +202,10 @@ __global__ void k_corpus_prepare(const XT *X, int64_t ldx, int64_t n_emb, int D,
 // ======================================================================================
 template <typename XT>
 __global__ void k_kmeans_prepare(const XT *means, int K_max, int D, float *tiles,
-                                 unsigned long long *mnorm2_bits)
+                                 unsigned long long *mnorm2_bits, unsigned int *zero_slot)
 {
     const int tile = blockIdx.x;
+    if (zero_slot && tile == 0 && threadIdx.x == 0) *zero_slot = 0u;     // E_m of the fp16 tile image: k_kmeans_prepare_sp, next on the stream
     const int G = segk_gmax(D);          // bucket extent; dims >= D are zero filled
     const int stride = segk_tile_stride(D);
     float *T = tiles + (int64_t)tile * stride;
@@ -291,6 +292,7 @@ struct ScoreArgs {
     const int32_t *n_dev;
     int32_t *pre_queue, *pre_count;
     int pre_cap, K_max;
+    const float *xerr;           /* pre-filter: |x - x1| per row (k_corpus_resid_sp) */
     unsigned long long *stamp;   /* -DSEGK_STAMP development builds: s_memtime at phase boundaries, 8 per workgroup */
 };
 
@@ -712,6 +714,30 @@ __global__ void k_corpus_split_sp(const float *X, int64_t ldx, int64_t n_emb, in
     for (int q = 0; q < P; q++) row[q * KP + pos] = pc[q];
 }
 
+// |x - x1| per row (x1 = the leading fp16 piece, unscaled): the operand-rounding term of the one-product
+// pre-filter's margin is (|x| + e_x) E_m + e_x M by Cauchy-Schwarz on the actual residual vectors, about a
+// third of the worst case 2^-10 |x| M.  An element whose piece is zero or subnormal in fp16 counts with its
+// full magnitude, which covers a matrix pipe that flushes subnormal inputs as well as one that does not.
+// Stored as float [n_emb] after the two piece planes (the image is sized for three).
+__device__ __forceinline__ double sp_resid2(float scaled)
+{
+    const _Float16 a = (_Float16)scaled;
+    const float af = (float)a;
+    const float r = fabsf(af) < 6.103515625e-5f ? fabsf(scaled) : fabsf(scaled - af);    // 2^-14: smallest normal
+    return (double)r * (double)r;
+}
+__global__ void k_corpus_resid_sp(const float *X, int64_t ldx, int64_t n_emb, int D, unsigned char *img)
+{
+    const int ea = ((const int *)img)[1];
+    const int KP = segk_b3_kp(D);
+    float *xerr = (float *)(img + SEGK_SP_HEADER + n_emb * 2 * (int64_t)KP * 2);
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_emb) return;
+    double s = 0.0;
+    for (int d = 0; d < D; d++) s += sp_resid2(ldexpf(X[e * ldx + d], ea));
+    xerr[e] = (float)(ldexp(sqrt(s), -ea) * (1.0 + 1e-6)) + 1e-37f;
+}
+
 // tiles image: [header 1024 floats: int32 exponent b at [0]] then per tile [s][p][lane][8] pieces + 32 constants
 // consts == NULL: the k-means constants -|m|^2/2; otherwise consts[k] (< -1e37: component absent) -- the
 // log-sum-exp use of the kernel (segk_fbbatch.hip), whose rows are not means.
@@ -733,16 +759,25 @@ __global__ void k_kmeans_prepare_sp(const float *means, int K_max, int D, float 
     {
         const int ci = threadIdx.x >> 3, sub = threadIdx.x & 7;      // 256 threads = 32 x 8
         const int comp = tile * 32 + ci;
-        double s = 0.0;
+        double s = 0.0, rs = 0.0;
         if (comp < K_max)
             for (int d = sub; d < D; d += 8) {
-                double v = (double)means[(int64_t)comp * D + d];
+                const float mv = means[(int64_t)comp * D + d];
+                double v = (double)mv;
                 s += v * v;
+                if (P == 2) rs += sp_resid2(ldexpf(mv, eb));
             }
         s += __shfl_xor(s, 1);
         s += __shfl_xor(s, 2);
         s += __shfl_xor(s, 4);
         if (sub == 0) nrm[ci] = s;
+        if (P == 2) {                     // E_m = max_k |m_k - m1_k|: tiles header [1], zeroed by k_kmeans_prepare just before
+            rs += __shfl_xor(rs, 1);
+            rs += __shfl_xor(rs, 2);
+            rs += __shfl_xor(rs, 4);
+            const float em = (float)(ldexp(sqrt(rs), -eb) * (1.0 + 1e-6));
+            if (sub == 0 && comp < K_max) atomicMax((unsigned int *)tiles + 1, __float_as_uint(em));
+        }
     }
     __syncthreads();
     for (int idx = threadIdx.x; idx < KS * 64 * 8; idx += blockDim.x) {
@@ -1051,9 +1086,14 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_kmeans_score_sp(ScoreArgs A)
 // Reads the two-piece images (segk_internal.h): piece 0 of the rows, the piece-0 blocks and the
 // constants of the tile image -- each a 1 KiB LDS-DMA piece.
 // ======================================================================================
-__device__ __forceinline__ float filter_tau_h1(float xn, float M, int D)
+__device__ __forceinline__ float filter_tau_h1(float xn, float M, int D, float ex, float Em)
 {
-    return filter_tau_sp(xn, M, D, 2) + 2.5f * 1.01f * 9.765625e-4f * xn * M;
+    // operand rounding: |sum x1 m1 - sum x m| <= |x1| |m1 - m| + |x1 - x| |m| <= (|x| + e_x) E_m + e_x M with the
+    // residual norms of THIS row and the worst component (k_corpus_resid_sp / k_kmeans_prepare_sp), never more
+    // than the a-priori 1.01 * 2^-10 |x| M
+    const float meas = (xn + ex) * Em + ex * M;
+    const float apriori = 1.01f * 9.765625e-4f * xn * M;
+    return filter_tau_sp(xn, M, D, 2) + 2.5f * 1.00001f * fminf(meas, apriori);
 }
 
 template <int KS, int NBLK>
@@ -1201,6 +1241,7 @@ __global__ __launch_bounds__(256, 2) void k_kmeans_score_h1(ScoreArgs A)
 #undef SEGK_TILE_SYNC
 
     const float M = (float)(sqrt(*A.mnorm2) * (1.0 + 1e-6)) + 1e-30f;
+    const float Em = ((const float *)A.tiles)[1];
     bool undecided[NBLK];
     int n_und = 0;
 #pragma unroll
@@ -1216,7 +1257,7 @@ __global__ __launch_bounds__(256, 2) void k_kmeans_score_h1(ScoreArgs A)
         undecided[b] = false;
         if (h == 0 && rowid[b] >= 0) {
             const int32_t rid = rowid[b];
-            const float tau = filter_tau_h1(A.xnorm[rid], M, D);
+            const float tau = filter_tau_h1(A.xnorm[rid], M, D, A.xerr[rid], Em);
             if (top1 - top2 > tau) {
                 // decided up to the member of the pair: k_kmeans_exact_pair scores both in reference
                 // arithmetic (a decisive winner beats its partner there as well) and clears the mark
@@ -3342,7 +3383,7 @@ int32_t segk_kmeans_prepare(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m,
     SEGK_CHECK_HIP(hipMemsetAsync(m->mnorm_max, 0, sizeof(double), st));
     DISPATCH_XT(c, hipLaunchKernelGGL(k_kmeans_prepare<XT>, dim3(segk_n_tiles(m->K_max)), dim3(256), 0, st,
                                        (const XT *)m->means, m->K_max, c->D, m->tiles,
-                                       (unsigned long long *)m->mnorm_max););
+                                       (unsigned long long *)m->mnorm_max, m->tiles_b3 ? (unsigned int *)m->tiles_b3 + 1 : nullptr););
     if (m->tiles_b3 && c->Xb3 && c->x_dtype == SEGK_F32 && c->D >= 8 && c->D <= 128) {
         if (c->sp_pieces == 2)
             hipLaunchKernelGGL(k_kmeans_prepare_sp<2>, dim3(segk_n_tiles(m->K_max)), dim3(256), 0, st, (const float *)m->means,
@@ -3382,6 +3423,8 @@ int32_t segk_corpus_prepare_b3(segk_ctx *ctx, const segk_corpus *c, void *Xb3_ou
         hipLaunchKernelGGL(k_corpus_maxabs, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st, (const float *)c->X,
                            c->ldx, c->n_emb, c->D, (unsigned int *)Xb3_out);
         hipLaunchKernelGGL(k_corpus_split_sp<2>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, (const float *)c->X,
+                           c->ldx, c->n_emb, c->D, (unsigned char *)Xb3_out);
+        hipLaunchKernelGGL(k_corpus_resid_sp, dim3((unsigned)((c->n_emb + 255) / 256)), dim3(256), 0, st, (const float *)c->X,
                            c->ldx, c->n_emb, c->D, (unsigned char *)Xb3_out);
     } else {
         hipLaunchKernelGGL(k_corpus_split_sp<3>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, (const float *)c->X,
@@ -3439,6 +3482,7 @@ int32_t segk_kmeans_filter(segk_ctx *ctx, const segk_corpus *c, const segk_kmean
         A.means32 = (const float *)m->means;
         A.fuse_exact = (c->D % 4 == 0) ? 1 : 0;
         A.K_max = m->K_max;
+        A.xerr = (const float *)((const unsigned char *)c->Xb3 + SEGK_SP_HEADER + c->n_emb * 2 * (int64_t)segk_b3_kp(c->D) * 2);
         // one-product pre-filter in front (two-piece images, D % 4 == 0).  Its three extra launches -- and the
         // second stage's fixed cost, one workgroup's pass over every tile with all three products (~45 us)
         // -- pay once the split-precision kernel alone would need more than four rounds of the chip

@@ -50,3 +50,39 @@ def test_operand_rounding_bound_adversarial():
     Mn = (rs.randn(150, D) * 10.0 ** rs.uniform(-9, 0, size=(150, D))).astype(np.float32)
     Mn[3] = X[5]
     assert _worst_ratio(X, Mn) < 1.0
+
+
+def _resid_norms(A):
+    """|a - a1| per row as k_corpus_resid_sp / k_kmeans_prepare_sp compute it: an element whose piece is zero
+    or subnormal in fp16 counts with its full magnitude."""
+    a1, e = _scaled_f16(A)
+    sc = np.ldexp(A.astype(np.float64), e)
+    r = np.where(np.abs(a1) < 2.0 ** -14, np.abs(sc), np.abs(sc - a1))
+    return np.ldexp(np.sqrt((r * r).sum(1)), -e), a1, e
+
+
+@pytest.mark.parametrize("flush", [False, True], ids=["gradual-underflow", "flush-to-zero"])
+def test_measured_residual_bound(flush):
+    """The margin the kernel uses: (|x| + e_x) E_m + e_x M with the measured residual norms -- holds whether
+    the matrix pipe keeps fp16 subnormal inputs or flushes them, and is several times tighter than the
+    a-priori 2^-10 |x| M on ordinary data."""
+    rs = np.random.RandomState(5)
+    for D, scale, wide in ((100, 1.0, False), (128, 30.0, False), (64, 1.0, True), (16, 1e-3, False)):
+        X = (rs.randn(500, D) * scale).astype(np.float32)
+        Mn = (rs.randn(200, D) * scale).astype(np.float32)
+        if wide:
+            X = (X * 10.0 ** rs.uniform(-9, 0, size=X.shape)).astype(np.float32)
+            Mn = (Mn * 10.0 ** rs.uniform(-9, 0, size=Mn.shape)).astype(np.float32)
+        ex, x1, ea = _resid_norms(X)
+        em, m1, eb = _resid_norms(Mn)
+        if flush:
+            x1 = np.where(np.abs(x1) < 2.0 ** -14, 0.0, x1)
+            m1 = np.where(np.abs(m1) < 2.0 ** -14, 0.0, m1)
+        approx = np.ldexp(x1 @ m1.T, -(ea + eb))
+        true = X.astype(np.float64) @ Mn.astype(np.float64).T
+        xn = np.linalg.norm(X.astype(np.float64), axis=1)
+        Mmax = np.linalg.norm(Mn.astype(np.float64), axis=1).max()
+        bound = (xn + ex) * em.max() + ex * Mmax
+        assert (np.abs(approx - true) <= bound[:, None] * (1 + 1e-9)).all()
+        if not wide:
+            assert np.median(bound / (2.0 ** -10 * xn * Mmax)) < 0.5

@@ -35,3 +35,5 @@ cf = c.dev.cand_f.cpu().numpy()
 for i in bad[:20]:
     top = np.sort(f[i])[::-1]
     print(i, "got", am[i], "want", wam[i], "f got/want", f[i, am[i]], f[i, wam[i]], "gap12", top[0] - top[1], "cand_f", cf[i], "mx", mx[i], wmx[i])
+flag = np.nonzero(am >= (1 << 30))[0]
+print("rows still marked pending:", len(flag), flag[:40])
