@@ -12,9 +12,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run(world, out, n_sweeps=3, worker="dist_worker.py", extra=()):
+def run(world, out, n_sweeps=3, worker="dist_worker.py", extra=(), env_extra=None):
     worker = os.path.join(ROOT, "tests", worker)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.update(env_extra or {})
     if world == 1:
         cmd = [sys.executable, worker, out, "gloo", str(n_sweeps)] + list(extra)
     else:
@@ -29,6 +30,17 @@ def test_batch_mode_is_independent_of_the_number_of_ranks(tmp_path):
     ref = run(1, str(tmp_path / "w1.npz"))
     for world in (2, 4):
         got = run(world, str(tmp_path / ("w%d.npz" % world)))
+        for k in ref.files:
+            assert np.array_equal(ref[k], got[k]), (world, k)
+
+
+def test_batch_mode_with_the_prefilter_forced_is_independent_of_the_number_of_ranks(tmp_path):
+    """The same with SEGK_SCORE_PRE=1: every rank scores its row range (first row > 0 on ranks > 0) through
+    the one-product pre-filter, the exact pair kernel and the second stage on the second stream; the result
+    must still be the single-rank, un-prefiltered one bit for bit."""
+    ref = run(1, str(tmp_path / "p0.npz"), env_extra={"SEGK_SCORE_PRE": "0"})
+    for world in (1, 2, 4):
+        got = run(world, str(tmp_path / ("p%d.npz" % world)), env_extra={"SEGK_SCORE_PRE": "1"})
         for k in ref.files:
             assert np.array_equal(ref[k], got[k]), (world, k)
 
