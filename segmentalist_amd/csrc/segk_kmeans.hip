@@ -1425,7 +1425,10 @@ __global__ void k_kmeans_brute(segk_corpus c, segk_kmeans m, segk_cand cand, int
 // from L2-bandwidth bound (one pass over the tile image per row) to latency/compute bound.  Per
 // (row, component) the arithmetic is neg_sqd_exact's: eight strided accumulators, the fixed combine
 // tree, the sequential tail; first maximum per row.
-#define SEGK_BR 8
+// BR = 4 (was 8: 234 VGPRs): in the pre-filter path the scan runs on the second stream beside the exact pair
+// kernel, whose waves hold 144 VGPRs each -- with 8 rows its workgroups could not be placed until those
+// waves ended (121 us in the trace against 65 alone); with 4 the sweep gains 4 %.
+#define SEGK_BR 4
 // component slices of the full scan for a queue of nq rows on a grid of `grid` workgroups (at most max_split)
 __device__ __forceinline__ int segk_brute_split(int nq, int grid, int max_split)
 {
