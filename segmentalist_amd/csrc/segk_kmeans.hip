@@ -3077,7 +3077,6 @@ static int launch_score_pre(segk_ctx *ctx, ScoreArgs A, hipStream_t st)
     if (getenv("SEGK_PRE_NBLK") && atoi(getenv("SEGK_PRE_NBLK")) == 2) n4 = 0;      // development: 256-row workgroups only
     const bool prof = ctx->prof_on != 0;
     const int slot = ctx->prof_n % SEGK_PROF_SLOTS;
-    if (prof) SEGK_CHECK_HIP(hipEventRecord(ctx->prof_ev[slot][0], st));
     // the timed launch (segk_profile_*): the 512-row-workgroup launch when there is one, else the 256-row one
     auto prof_end = [&](int64_t rows) -> int {
         if (!prof) return SEGK_OK;
@@ -3087,25 +3086,26 @@ static int launch_score_pre(segk_ctx *ctx, ScoreArgs A, hipStream_t st)
         ctx->prof_n++;
         return SEGK_OK;
     };
+    // a short remainder is only queued: first, so that nothing small sits between the big launch and the
+    // kernels waiting for it
+    const int64_t rem = A.n - n4;
+    const bool rem_queued = rem > 0 && rem < SEGK_TAIL_QUEUE && n4 > 0;
+    ScoreArgs T = A;
+    T.n = rem;
+    T.row0 = A.row0 + n4;
+    T.ids = A.ids ? A.ids + n4 : nullptr;
+    if (rem_queued) hipLaunchKernelGGL(k_pre_queue_rows, dim3((unsigned)((rem + 255) / 256)), dim3(256), 0, st, T);
+    if (prof) SEGK_CHECK_HIP(hipEventRecord(ctx->prof_ev[slot][0], st));
     if (n4 > 0) {
         ScoreArgs M = A;
         M.n = n4;
         hipLaunchKernelGGL((k_kmeans_score_h1<KS, 4>), dim3((unsigned)(n4 / 512)), dim3(256), lds, st, M);
         if (int rc = prof_end(n4)) return rc;
     }
-    const int64_t rem = A.n - n4;
-    if (rem > 0) {
-        ScoreArgs T = A;
-        T.n = rem;
-        T.row0 = A.row0 + n4;
-        T.ids = A.ids ? A.ids + n4 : nullptr;
-        if (rem >= SEGK_TAIL_QUEUE || n4 == 0) {
-            hipLaunchKernelGGL((k_kmeans_score_h1<KS, 2>), dim3((unsigned)((rem + 255) / 256)), dim3(256), lds, st, T);
-            if (n4 == 0)
-                if (int rc = prof_end(rem)) return rc;
-        } else {
-            hipLaunchKernelGGL(k_pre_queue_rows, dim3((unsigned)((rem + 255) / 256)), dim3(256), 0, st, T);
-        }
+    if (rem > 0 && !rem_queued) {
+        hipLaunchKernelGGL((k_kmeans_score_h1<KS, 2>), dim3((unsigned)((rem + 255) / 256)), dim3(256), lds, st, T);
+        if (n4 == 0)
+            if (int rc = prof_end(rem)) return rc;
     }
     // The decided rows' exact stage (this stream) and the undecided rows' second stage + full scan (second
     // stream, segk_kmeans_score only) touch disjoint rows: side by side, the exact stage leaving LDS for one
