@@ -2981,7 +2981,9 @@ __global__ __launch_bounds__(64) void k_kmeans_exact_pair(ScoreArgs A)
         }
     };
     auto decode = [&](int32_t &rid, int32_t k) -> int32_t {       // pair base, or -1 (and rid = -1) when not pending
-        if (rid >= 0 && (k & SEGK_PAIR_PENDING)) return k & ~SEGK_PAIR_PENDING;
+        // (a valid mark only: non-negative, pair base inside the component range -- whatever else the caller's
+        // candidate buffer holds for a row the pre-filter did not decide is left alone)
+        if (rid >= 0 && k >= 0 && (k & SEGK_PAIR_PENDING) && (k & ~SEGK_PAIR_PENDING) < A.K_max) return k & ~SEGK_PAIR_PENDING;
         rid = -1;
         return -1;
     };

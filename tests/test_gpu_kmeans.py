@@ -484,3 +484,33 @@ def test_prefilter_large_launches(gpu, monkeypatch, n, force):
     assert np.array_equal(am, want_am)
     assert np.array_equal(mx, want_mx.astype(np.float64))
     assert nbrute < n // 50          # near-duplicate means: a third of the rows pass to the second stage, few beyond
+
+
+def test_prefilter_row_lists_with_skipped_entries(gpu, monkeypatch):
+    """ids with -1 entries (skipped) and an arbitrary order through the forced pre-filter path: the listed
+    rows get the reference's max / argmax, rows that are not listed are not touched."""
+    import torch
+    from oracle import c_oracle as co
+    from segmentalist_amd.device import to_dev
+    monkeypatch.setenv("SEGK_SCORE_PRE", "1")
+    rs = np.random.RandomState(21)
+    n, D, K = 3000, 40, 129
+    mu = rs.randn(K // 2, D)
+    X = (mu[rs.randint(0, K // 2, n)] + 0.3 * rs.randn(n, D)).astype(np.float32)
+    means = (mu[rs.randint(0, K // 2, K)] + 0.05 * rs.randn(K, D)).astype(np.float32)
+    c = _components(X, means)
+    ids = rs.permutation(n)[:1777].astype(np.int32)
+    ids[::13] = -1
+    c.dev.cand_k.fill_(-7)
+    c.dev.cand_s.fill_(123.0)
+    ids_t = to_dev(ids, np.int32)
+    c.dev.score_rows(ids_t)
+    torch.cuda.synchronize()
+    am = c.dev.cand_k.cpu().numpy()
+    mx = c.dev.cand_s.cpu().numpy()
+    want_mx, want_am = co.kmeans_max_argmax(means, X)
+    listed = np.zeros(n, dtype=bool)
+    listed[ids[ids >= 0]] = True
+    assert np.array_equal(am[listed], want_am[listed])
+    assert np.array_equal(mx[listed], want_mx[listed].astype(np.float64))
+    assert (am[~listed] == -7).all() and (mx[~listed] == 123.0).all()
