@@ -2957,27 +2957,41 @@ __global__ __launch_bounds__(64) void k_kmeans_exact_pair(ScoreArgs A)
     float4 v[3 * NLA];
     // rows 2t, 2t + 1 (RPI = 2) of array arr per instruction: consecutive lanes on consecutive 16 bytes
     uint64_t *rowp = reinterpret_cast<uint64_t *>(lds + 3 * R * LD);     // [3][R] row addresses of the step being loaded
-    auto issue_loads = [&](int32_t rid, int32_t c) {
-        // 64-bit row addresses once per step, by the rows' own lanes, through LDS (0 = skip): the load
-        // instructions below cost a ds_read_b64 and an add each -- no multiply, no lane exchange
+    auto issue_loads = [&](int32_t rid, int32_t c, int64_t step_) {
+        // 64-bit row addresses once per step, by the rows' own lanes, through LDS: the load instructions
+        // below cost a ds_read_b64 and an add each -- no multiply, no lane exchange.  Every load is
+        // unconditional (a branch around each of the 24 cost more than the loads): a row that is skipped
+        // reads its own float32 row and the first means (never used), a lane without a slot re-reads its
+        // neighbour's last 16 bytes (same cache line).
         if (lane < R) {
             const bool live = rid >= 0;
-            const uint64_t xp = live ? (uint64_t)(uintptr_t)(A.xrows32 + (int64_t)rid * A.ld32) : 0;
-            const uint64_t mp0 = live ? (uint64_t)(uintptr_t)(A.means32 + (int64_t)c * D) : 0;
+            int64_t r_any = rid;
+            if (!live) {                                       // some valid row: this step's own when the rows are a range
+                r_any = A.ids ? 0 : A.row0 + step_ * R + lane;
+                if (r_any >= A.row0 + A.n || A.ids) r_any = A.ids ? 0 : A.row0;
+            }
+            const uint64_t xp = (uint64_t)(uintptr_t)(A.xrows32 + r_any * A.ld32);
+            const uint64_t mp0 = (uint64_t)(uintptr_t)(A.means32 + (int64_t)(live ? c : 0) * D);
             rowp[lane] = xp;
             rowp[R + lane] = mp0;
-            rowp[2 * R + lane] = (live && c + 1 < A.K_max) ? mp0 + (uint64_t)D * 4 : 0;
+            rowp[2 * R + lane] = (live && c + 1 < A.K_max) ? mp0 + (uint64_t)D * 4 : mp0;
         }
+        const int sub_c = sub < RPI ? sub : RPI - 1;
+        const unsigned off = 16u * (unsigned)(c4 < D4 ? c4 : D4 - 1);
         uint64_t base[3 * NLA];
 #pragma unroll
         for (int arr = 0; arr < 3; arr++)
 #pragma unroll
             for (int t = 0; t < NLA; t++)
-                base[arr * NLA + t] = (sub < RPI && RPI * t + sub < R) ? rowp[arr * R + RPI * t + sub] : 0;
+                base[arr * NLA + t] = rowp[arr * R + ((RPI * t + sub_c) & (R - 1))];
 #pragma unroll
         for (int i = 0; i < 3 * NLA; i++) {
-            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (base[i] != 0 && c4 < D4) v[i] = *reinterpret_cast<const float4 *>((uintptr_t)(base[i] + 16u * (unsigned)c4));
+            // an integer turned pointer is a FLAT pointer to the compiler (flat loads, and the staging array in
+            // scratch: 900 us); say that it is global memory
+            typedef float f32x4_t __attribute__((ext_vector_type(4)));
+            typedef const __attribute__((address_space(1))) f32x4_t *gptr_t;
+            const f32x4_t t_ = *reinterpret_cast<gptr_t>((uintptr_t)(base[i] + off));
+            v[i] = make_float4(t_.x, t_.y, t_.z, t_.w);
         }
     };
     auto decode = [&](int32_t &rid, int32_t k) -> int32_t {       // pair base, or -1 (and rid = -1) when not pending
@@ -2991,7 +3005,7 @@ __global__ __launch_bounds__(64) void k_kmeans_exact_pair(ScoreArgs A)
     int64_t step = blockIdx.x;
     int32_t rid0 = fetch_rid(step);
     int32_t c0 = decode(rid0, fetch_k(rid0));
-    issue_loads(rid0, c0);
+    issue_loads(rid0, c0, step);
     int32_t rid1 = fetch_rid(step + gridDim.x);
     int32_t k1 = fetch_k(rid1);
     int32_t rid2 = fetch_rid(step + 2 * (int64_t)gridDim.x);
@@ -3012,7 +3026,7 @@ __global__ __launch_bounds__(64) void k_kmeans_exact_pair(ScoreArgs A)
         SEGK_STAMP_P(1);
         const int32_t ridc = rid0, cc0 = c0;
         const int32_t c1 = decode(rid1, k1);
-        issue_loads(rid1, c1);                                     // the next step's rows: in flight under this step's arithmetic
+        issue_loads(rid1, c1, step + gridDim.x);                   // the next step's rows: in flight under this step's arithmetic
         rid0 = rid1; c0 = c1;
         rid1 = rid2;
         k1 = fetch_k(rid1);
