@@ -809,35 +809,45 @@ template <int KS, int PART>
 __device__ __forceinline__ float sp_exact_score_x(const float *mean, const float *xr, int D, int h)
 {
     const float *mrow = mean + 4 * h, *xrow = xr + 4 * h;
-    const int nfull = D & ~7, rem = D & 7;
+    const int nfull = D & ~7, nblk = nfull >> 3;               // whole blocks of 8: both lanes, wave-uniform
     float r4[4] = {0.f, 0.f, 0.f, 0.f}, tt[4] = {0.f, 0.f, 0.f, 0.f};
+    // the operands of block b + 1 are fetched before block b is accumulated (LDS or global latency under the
+    // arithmetic); the accumulation order is untouched
+    float4 mv = make_float4(0.f, 0.f, 0.f, 0.f), xv = mv;
+    if (nblk > 0) {
+        mv = *reinterpret_cast<const float4 *>(mrow);
+        xv = *reinterpret_cast<const float4 *>(xrow);
+    }
 #pragma unroll
-    for (int s = 0; s < KS; s++) {
-#pragma unroll
-        for (int b = 0; b < 2; b++) {
-            const int d0 = 16 * s + 8 * b;                     // this lane holds d0 + 4h + {0..3}
-            if (d0 + 8 <= nfull) {                             // a whole block of 8: both lanes, wave-uniform branch
-                const float4 mv = *reinterpret_cast<const float4 *>(mrow + d0);
-                const float4 xv = *reinterpret_cast<const float4 *>(xrow + d0);
-                const float mvv[4] = {mv.x, mv.y, mv.z, mv.w}, xvv[4] = {xv.x, xv.y, xv.z, xv.w};
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const float delta = mvv[q] - xvv[q];
-                    const float t2 = delta * delta;
-                    r4[q] = (s == 0 && b == 0) ? t2 : r4[q] + t2;
-                }
-            } else if (d0 == nfull && d0 + 4 * h < D) {        // the sequential tail block (D % 4 == 0: lane 0 only)
-                const float4 mv = *reinterpret_cast<const float4 *>(mrow + d0);
-                const float4 xv = *reinterpret_cast<const float4 *>(xrow + d0);
-                const float mvv[4] = {mv.x, mv.y, mv.z, mv.w}, xvv[4] = {xv.x, xv.y, xv.z, xv.w};
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const float delta = mvv[q] - xvv[q];
-                    tt[q] = delta * delta;
-                }
+    for (int b = 0; b < 2 * KS; b++) {
+        if (b < nblk) {
+            float4 mn = mv, xn = xv;
+            if (b + 1 < nblk) {
+                mn = *reinterpret_cast<const float4 *>(mrow + 8 * (b + 1));
+                xn = *reinterpret_cast<const float4 *>(xrow + 8 * (b + 1));
             }
+            const float mvv[4] = {mv.x, mv.y, mv.z, mv.w}, xvv[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const float delta = mvv[q] - xvv[q];
+                const float t2 = delta * delta;
+                r4[q] = b == 0 ? t2 : r4[q] + t2;
+            }
+            mv = mn;
+            xv = xn;
         }
     }
+    if (nfull + 4 * h < D) {                                   // the sequential tail block (D % 4 == 0: lane 0 only)
+        const float4 mt = *reinterpret_cast<const float4 *>(mrow + nfull);
+        const float4 xt = *reinterpret_cast<const float4 *>(xrow + nfull);
+        const float mvv[4] = {mt.x, mt.y, mt.z, mt.w}, xvv[4] = {xt.x, xt.y, xt.z, xt.w};
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const float delta = mvv[q] - xvv[q];
+            tt[q] = delta * delta;
+        }
+    }
+    const int rem = D & 7;
     float res = (r4[0] + r4[1]) + (r4[2] + r4[3]);
     const float ro = __shfl_xor(res, PART);
     res = (h == 0) ? res + ro : ro + res;                      // ((r0+r1)+(r2+r3)) + ((r4+r5)+(r6+r7))
