@@ -514,3 +514,16 @@ def test_prefilter_row_lists_with_skipped_entries(gpu, monkeypatch):
     assert np.array_equal(am[listed], want_am[listed])
     assert np.array_equal(mx[listed], want_mx[listed].astype(np.float64))
     assert (am[~listed] == -7).all() and (mx[~listed] == 123.0).all()
+
+
+def test_prefilter_randomized_sweep(gpu):
+    """tools/stress_prefilter.py: 48 random (D, K, n, scale, tie structure) cases through the forced pre-filter
+    path -- unit rows, nine-decade dynamic range, exact duplicate means, n = 1 ... 20 000 -- against the C oracle."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_prefilter.py"), "7", "48"],
+                       capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "mismatches: 0" in r.stdout
