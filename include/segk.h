@@ -116,6 +116,13 @@ typedef struct segk_kmeans {
 
 /* number of floats the caller must allocate for segk_kmeans.tiles / .tiles_b3 */
 int64_t segk_kmeans_tiles_floats(int32_t K_max, int32_t D);
+/* After segk_kmeans_prepare (optional; the batch sweeps call it): rows of `means` that are exact duplicates of a
+ * row with a LOWER index are taken out of the filters' tile images (their accumulator seed becomes the "absent"
+ * constant).  Such a row can never be np.argmax (kmeans_components.py:231: the first maximum wins, the scores are
+ * bit-identical), but it turns every embedding near the pair into a tie for the full scan.  The full scan itself
+ * does not read the constants.  n_marked [dev, optional]: += number of rows marked.  No-op for K_max > 2048.    */
+int32_t segk_kmeans_mark_duplicates(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m, int32_t *n_marked,
+                                    void *stream);
 int64_t segk_kmeans_tiles_b3_floats(int32_t K_max, int32_t D);
 
 /* KMeansComponents.__init__ (kmeans_components.py:59-81): from `assignments` (and

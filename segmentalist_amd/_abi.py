@@ -77,6 +77,7 @@ SIGNATURES = {
     "segk_corpus_prepare": (_i32, [_P, _CP, _P, _P, _P]),
     "segk_kmeans_tiles_floats": (_i64, [_i32, _i32]),
     "segk_kmeans_prepare": (_i32, [_P, _CP, _KP, _P]),
+    "segk_kmeans_mark_duplicates": (_i32, [_P, _CP, _KP, _P, _P]),
     "segk_kmeans_init_stats": (_i32, [_P, _CP, _KP, _P]),
     "segk_kmeans_score": (_i32, [_P, _CP, _KP, _P, _i64, _i64, _DP, _P, _P]),
     "segk_kmeans_clear_queue": (_i32, [_P, _DP, _P]),

@@ -69,6 +69,7 @@ int32_t segk_destroy(segk_ctx *ctx)
         if (ctx->ws_f) (void)hipFree(ctx->ws_f);
         if (ctx->ws_u64) (void)hipFree(ctx->ws_u64);
         if (ctx->pre_queue) (void)hipFree(ctx->pre_queue);
+        if (ctx->row_hash) (void)hipFree(ctx->row_hash);
         if (ctx->aux) (void)hipStreamDestroy(ctx->aux);
         if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
         if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);

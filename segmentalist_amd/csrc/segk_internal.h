@@ -26,6 +26,9 @@ struct segk_ctx {
     hipStream_t aux;
     hipEvent_t ev_fork, ev_join;
     int overlap_req, aux_busy;
+    // value hashes of the rows of the means most recently prepared (segk_kmeans_mark_duplicates)
+    unsigned long long *row_hash;
+    const void *row_hash_means;
     // optional timing of the main score launch (segk_profile_*): event pairs used round-robin
     int prof_on, prof_n, prof_kind;
     hipEvent_t prof_ev[SEGK_PROF_SLOTS][2];

@@ -200,9 +200,19 @@ __global__ void k_corpus_prepare(const XT *X, int64_t ldx, int64_t n_emb, int D,
 // ======================================================================================
 // means -> tiles
 // ======================================================================================
+// value hash of one element of a row of `means` (k_kmeans_mark_dups): -0 and +0 hash alike, the per-element
+// terms add up commutatively, so lanes can hash strided parts of a row and sum
+__device__ __forceinline__ unsigned long long segk_elem_hash(double v, int d)
+{
+    unsigned long long z = (unsigned long long)__double_as_longlong(v + 0.0) + 0x9E3779B97F4A7C15ull * (unsigned long long)(d + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
 template <typename XT>
 __global__ void k_kmeans_prepare(const XT *means, int K_max, int D, float *tiles,
-                                 unsigned long long *mnorm2_bits, unsigned int *zero_slot)
+                                 unsigned long long *mnorm2_bits, unsigned int *zero_slot, unsigned long long *row_hash)
 {
     const int tile = blockIdx.x;
     if (zero_slot && tile == 0 && threadIdx.x == 0) *zero_slot = 0u;     // E_m of the fp16 tile image: k_kmeans_prepare_sp, next on the stream
@@ -215,17 +225,23 @@ __global__ void k_kmeans_prepare(const XT *means, int K_max, int D, float *tiles
         const int ci = threadIdx.x >> 3, sub = threadIdx.x & 7;      // 256 threads = 32 x 8
         const int comp = tile * 32 + ci;
         double s = 0.0;
+        unsigned long long hh = 0ull;
         if (comp < K_max)
             for (int d = sub; d < D; d += 8) {
                 double v = (double)means[(int64_t)comp * D + d];
                 s += v * v;
+                hh += segk_elem_hash(v, d);
             }
         s += __shfl_xor(s, 1);
         s += __shfl_xor(s, 2);
         s += __shfl_xor(s, 4);
+        hh += __shfl_xor(hh, 1);
+        hh += __shfl_xor(hh, 2);
+        hh += __shfl_xor(hh, 4);
         if (sub == 0) {
             nrm[ci] = s;
             if (comp < K_max) atomicMax(mnorm2_bits, (unsigned long long)__double_as_longlong(s));
+            if (row_hash && comp < K_max) row_hash[comp] = hh | 1ull;      // never 0: the empty key of the hash table
         }
     }
     __syncthreads();
@@ -3380,6 +3396,64 @@ int segk_launch_score_lse(segk_ctx *ctx, const float *Y, int64_t ldy, int D2, co
     return SEGK_ERR_UNSUPPORTED;
 }
 
+// Exact duplicates among the rows of `means` (clean_components leaves the moved component's old row behind,
+// inactive rows hold copies): a duplicate with the HIGHER index can never be np.argmax -- its score is the
+// lower one's bit for bit and the first maximum wins -- but it makes every row near the pair a tie that only
+// the full scan resolves (2 100 of the 2 200 queued rows of a 1 250-utterance shard had exactly these two
+// contenders).  One workgroup: value hashes of all rows (8 lanes per row), then every row looks for an
+// earlier row with its hash, verifies equality element by element, and if it finds one writes the
+// "absent" constant (-3e38, what the padding components carry) over its accumulator seed in both tile
+// images.  The full scan does not read those constants, so its first-maximum rule is untouched.
+template <typename XT>
+__global__ __launch_bounds__(1024) void k_kmeans_mark_dups(const XT *means, int K_max, int D, float *tiles, int stride32, int G,
+                                                           float *tiles_sp, int stride_sp, int sp_const_off, int32_t *n_marked,
+                                                           const unsigned long long *row_hash)
+{
+    // open-addressing table in LDS: key = row hash, value = the lowest row index with that hash
+    constexpr int TB = 4096;                                      // slots (K_max <= 2048: load factor <= 1/2; 48 KiB)
+    __shared__ unsigned long long keys[TB];
+    __shared__ int32_t first[TB];
+    const int tid = threadIdx.x, sub = tid & 7;
+    for (int i = tid; i < TB; i += blockDim.x) { keys[i] = 0ull; first[i] = 0x7fffffff; }
+    __syncthreads();
+    for (int k = tid; k < K_max; k += blockDim.x) {
+        const unsigned long long h = row_hash[k];
+        for (unsigned slot = (unsigned)(h >> 20) & (TB - 1);; slot = (slot + 1) & (TB - 1)) {
+            const unsigned long long prev = atomicCAS(&keys[slot], 0ull, h);
+            if (prev == 0ull || prev == h) { atomicMin(&first[slot], k); break; }
+        }
+    }
+    __syncthreads();
+    // every row: the first row with its hash; if that is an earlier one, verify element by element (8 lanes per
+    // row, all loads of a lane in flight together) and mark
+    int marked = 0;
+    for (int k0 = 0; k0 < K_max; k0 += 128) {
+        const int k = k0 + (tid >> 3);
+        int i = -1;
+        if (k < K_max) {
+            const unsigned long long h = row_hash[k];
+            unsigned slot = (unsigned)(h >> 20) & (TB - 1);
+            while (keys[slot] != h) slot = (slot + 1) & (TB - 1);
+            i = first[slot];
+            if (i >= k) i = -1;
+        }
+        int eq = i >= 0;
+        if (i >= 0) {
+#pragma unroll 4
+            for (int d = sub; d < D; d += 8) eq &= means[(int64_t)i * D + d] == means[(int64_t)k * D + d];
+        }
+        eq &= __shfl_xor(eq, 1);
+        eq &= __shfl_xor(eq, 2);
+        eq &= __shfl_xor(eq, 4);
+        if (sub == 0 && i >= 0 && eq) {
+            tiles[(int64_t)(k >> 5) * stride32 + G * 128 + (k & 31)] = -3.0e38f;
+            if (tiles_sp) tiles_sp[1024 + (int64_t)(k >> 5) * stride_sp + sp_const_off + (k & 31)] = -3.0e38f;
+            marked++;
+        }
+    }
+    if (n_marked && marked) atomicAdd(n_marked, marked);
+}
+
 extern "C" {
 
 int64_t segk_kmeans_tiles_floats(int32_t K_max, int32_t D)
@@ -3403,16 +3477,23 @@ int32_t segk_corpus_prepare(segk_ctx *ctx, const segk_corpus *c, float *X32_out,
 
 int32_t segk_kmeans_prepare(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m, void *stream)
 {
-    (void)ctx;
     int rc = check_corpus(c);
     if (rc) return rc;
     SEGK_REQUIRE(m && m->tiles && m->mnorm_max, "kmeans tiles/mnorm_max");
     hipStream_t st = (hipStream_t)stream;
+    // value hashes of the rows, for segk_kmeans_mark_duplicates (context-owned, K_max <= 2048 only)
+    unsigned long long *row_hash = nullptr;
+    if (ctx && m->K_max <= 2048) {
+        if (!ctx->row_hash) SEGK_CHECK_HIP(hipMalloc((void **)&ctx->row_hash, 2048 * sizeof(unsigned long long)));
+        row_hash = ctx->row_hash;
+        ctx->row_hash_means = m->means;
+    }
     // mnorm_max = max_k |m_k|^2, maintained by atomicMax on the bit pattern (non-negative doubles)
     SEGK_CHECK_HIP(hipMemsetAsync(m->mnorm_max, 0, sizeof(double), st));
     DISPATCH_XT(c, hipLaunchKernelGGL(k_kmeans_prepare<XT>, dim3(segk_n_tiles(m->K_max)), dim3(256), 0, st,
                                        (const XT *)m->means, m->K_max, c->D, m->tiles,
-                                       (unsigned long long *)m->mnorm_max, m->tiles_b3 ? (unsigned int *)m->tiles_b3 + 1 : nullptr););
+                                       (unsigned long long *)m->mnorm_max, m->tiles_b3 ? (unsigned int *)m->tiles_b3 + 1 : nullptr,
+                                       row_hash););
     if (m->tiles_b3 && c->Xb3 && c->x_dtype == SEGK_F32 && c->D >= 8 && c->D <= 128) {
         if (c->sp_pieces == 2)
             hipLaunchKernelGGL(k_kmeans_prepare_sp<2>, dim3(segk_n_tiles(m->K_max)), dim3(256), 0, st, (const float *)m->means,
@@ -3421,6 +3502,24 @@ int32_t segk_kmeans_prepare(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m,
             hipLaunchKernelGGL(k_kmeans_prepare_sp<3>, dim3(segk_n_tiles(m->K_max)), dim3(256), 0, st, (const float *)m->means,
                                m->K_max, c->D, m->tiles_b3, m->mnorm_max, (const unsigned char *)c->Xb3, (const double *)nullptr);
     }
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+int32_t segk_kmeans_mark_duplicates(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m, int32_t *n_marked, void *stream)
+{
+    int rc = check_corpus(c);
+    if (rc) return rc;
+    SEGK_REQUIRE(m && m->tiles && m->means, "kmeans tiles / means");
+    // needs the row hashes of the segk_kmeans_prepare that built these images (same context, same means buffer)
+    if (!ctx || m->K_max > 2048 || !ctx->row_hash || ctx->row_hash_means != m->means) return SEGK_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const bool sp = m->tiles_b3 && c->Xb3 && c->x_dtype == SEGK_F32 && c->D >= 8 && c->D <= 128 && (c->sp_pieces == 2 || c->sp_pieces == 3);
+    const int kp = segk_b3_kp(c->D);
+    DISPATCH_XT(c, hipLaunchKernelGGL(k_kmeans_mark_dups<XT>, dim3(1), dim3(1024), 0, st,
+                                       (const XT *)m->means, m->K_max, c->D, m->tiles, segk_tile_stride(c->D), segk_gmax(c->D),
+                                       sp ? m->tiles_b3 : (float *)nullptr, sp ? segk_sp_tile_stride(c->D, c->sp_pieces) : 0,
+                                       sp ? (kp / 16) * c->sp_pieces * 256 : 0, n_marked, ctx->row_hash););
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;
 }
@@ -3827,7 +3926,13 @@ int32_t segk_kmeans_batch_finalize(segk_ctx *ctx, const segk_corpus *c, segk_kme
         hipLaunchKernelGGL(k_batch_relabel, dim3((unsigned)((nslot + 255) / 256)), dim3(256), 0, st, *c, utt_lo,
                            utt_hi, new_k, n_new, remap_scratch);
     SEGK_LAUNCH_CHECK();
-    return segk_kmeans_prepare(ctx, c, m, stream);
+    rc = segk_kmeans_prepare(ctx, c, m, stream);
+    if (rc) return rc;
+    // clean_components leaves exact copies behind (the moved rows, the inactive rows): out of the filters' images,
+    // or every embedding near such a pair is a tie for the full scan.  SEGK_MARK_DUPS=0: leave them in.
+    const char *md = getenv("SEGK_MARK_DUPS");
+    if (md && atoi(md) == 0) return SEGK_OK;
+    return segk_kmeans_mark_duplicates(ctx, c, m, nullptr, stream);
 }
 
 int32_t segk_kmeans_assignments_from_tokens(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m,
