@@ -527,3 +527,39 @@ def test_prefilter_randomized_sweep(gpu):
                        capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "mismatches: 0" in r.stdout
+
+
+@pytest.mark.parametrize("pre", ["0", "1"], ids=["fp16x2", "prefilter"])
+def test_duplicate_means_are_taken_out_of_the_filters(gpu, monkeypatch, pre):
+    """segk_kmeans_mark_duplicates: rows of `means` that repeat an earlier row exactly (-0.0 == +0.0 counts) stop
+    being candidates of the filters -- the decisions stay the reference's (first maximum), but rows near a
+    duplicated component no longer need the full scan."""
+    import ctypes as C
+    import torch
+    from oracle import c_oracle as co
+    from segmentalist_amd import _abi
+    from segmentalist_amd.device import ptr
+    monkeypatch.setenv("SEGK_SCORE_PRE", pre)
+    rs = np.random.RandomState(77)
+    n, D, K = 6000, 40, 300
+    mu = rs.randn(K // 2, D)
+    X = (mu[rs.randint(0, K // 2, n)] + 0.2 * rs.randn(n, D)).astype(np.float32)
+    means = (mu[rs.randint(0, K // 2, K)] + 0.3 * rs.randn(K, D)).astype(np.float32)
+    dup_of = {250: 3, 251: 3, 299: 40, 41: 40, 120: 7}
+    for j, i in dup_of.items():
+        means[j] = means[i]
+    means[7, 5] = 0.0
+    means[120, 5] = -0.0                                  # equal by value, different bits
+    means[200] = means[9]
+    means[200, 0] = np.nextafter(means[200, 0], np.float32(10))   # one ulp off: NOT a duplicate
+    want_mx, want_am = co.kmeans_max_argmax(means, X)
+    c = _components(X, means)
+    _, _, nbrute_before = c.dev.exact_max(np.arange(n))
+    n_marked = torch.zeros(1, dtype=torch.int32, device="cuda")
+    _abi.check(_abi.lib().segk_kmeans_mark_duplicates(c.dev._ctx, c.dev._cp(), C.byref(c.dev.m), ptr(n_marked), _abi.stream()))
+    torch.cuda.synchronize()
+    assert int(n_marked.item()) == len(dup_of)
+    mx, am, nbrute_after = c.dev.exact_max(np.arange(n))
+    assert np.array_equal(am, want_am) and np.array_equal(mx, want_mx)
+    assert not np.isin(am, list(dup_of)).any()            # a duplicate never wins
+    assert nbrute_after <= nbrute_before // 2
