@@ -199,8 +199,8 @@ def main_fbgmm(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--utts", type=int, default=10000)
     ap.add_argument("--dim", type=int, default=100)
     ap.add_argument("--K", type=int, default=1000)
