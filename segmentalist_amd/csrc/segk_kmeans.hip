@@ -2514,7 +2514,7 @@ __global__ __launch_bounds__(512) void k_batch_partials(
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
                         if (mt[j])
-                            mlist[nm + __popcll(bal[j] & ((1ull << lane) - 1ull))] = ctok_id[pc + pb + lane + 64 * j];
+                            mlist[nm + __popcll(bal[j] & ((1ull << lane) - 1ull))] = pc + pb + lane + 64 * j;   // the token's POSITION: no global load (and its wait) inside the scan
                         nm += __popcll(bal[j]);
                     }
                 }
@@ -2525,7 +2525,7 @@ __global__ __launch_bounds__(512) void k_batch_partials(
                         double xv[PART_BATCH][MAXR];
 #pragma unroll
                         for (int q = 0; q < PART_BATCH; q++) {
-                            const int e = mlist[q0 + q < nm ? q0 + q : q0];       // clamped: always valid
+                            const int e = ctok_id[mlist[q0 + q < nm ? q0 + q : q0]];       // clamped: always valid
 #pragma unroll
                             for (int r = 0; r < MAXR; r++) xv[q][r] = (double)X[(int64_t)e * c.ldx + dcl[r]];
                         }
