@@ -25,7 +25,7 @@ struct segk_ctx {
     // the exact stage of the decided rows (created on first use)
     hipStream_t aux;
     hipEvent_t ev_fork, ev_join;
-    int overlap_req, aux_busy;
+    int overlap_req, aux_busy, pre_zeroed;
     // value hashes of the rows of the means most recently prepared (segk_kmeans_mark_duplicates)
     unsigned long long *row_hash;
     const void *row_hash_means;

@@ -2762,9 +2762,10 @@ __global__ void k_batch_clean(segk_corpus c, segk_kmeans m, int32_t *remap, doub
 
 // (5c) final labels of the local tokens
 __global__ void k_batch_relabel(segk_corpus c, int lo, int hi, int32_t *new_k, const int32_t *n_new,
-                                const int32_t *remap)
+                                const int32_t *remap, double *zero_me)
 {
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx == 0 && zero_me) *zero_me = 0.0;          // max |m|^2 of the prepare that follows on the stream (saves its memset)
     int64_t tot = (int64_t)(hi - lo) * c.N_max;
     if (idx >= tot) return;
     int u = lo + (int)(idx / c.N_max), t = (int)(idx % c.N_max);
@@ -3317,6 +3318,7 @@ static int launch_score_pre(segk_ctx *ctx, ScoreArgs A, hipStream_t st)
         ctx->pre_cap = 0;
         SEGK_CHECK_HIP(hipMalloc((void **)&ctx->pre_queue, sizeof(int32_t) * (size_t)(A.n + 16)));
         ctx->pre_cap = A.n;
+        ctx->pre_zeroed = 0;                           // a new buffer: its counter has not been cleared
     }
     A.pre_queue = ctx->pre_queue + 16;
     A.pre_count = ctx->pre_queue;
@@ -3327,7 +3329,8 @@ static int launch_score_pre(segk_ctx *ctx, ScoreArgs A, hipStream_t st)
 #ifdef SEGK_STAMP
     A.stamp = getenv("SEGK_STAMP_PTR") ? (unsigned long long *)strtoull(getenv("SEGK_STAMP_PTR"), nullptr, 0) : nullptr;
 #endif
-    SEGK_CHECK_HIP(hipMemsetAsync(A.pre_count, 0, sizeof(int32_t), st));
+    if (ctx->pre_zeroed) ctx->pre_zeroed = 0;          // segk_kmeans_score cleared it together with the caller's queue length
+    else SEGK_CHECK_HIP(hipMemsetAsync(A.pre_count, 0, sizeof(int32_t), st));
 
     constexpr size_t lds = 2 * (size_t)(KS + 1) * 256 * sizeof(float);
     const int64_t slots = 2 * (int64_t)ctx->n_cu;      // two 4-wave workgroups per CU (launch bounds)
@@ -3672,6 +3675,12 @@ __global__ __launch_bounds__(1024) void k_kmeans_mark_dups(const XT *means, int 
     if (n_marked && marked) atomicAdd(n_marked, marked);
 }
 
+__global__ void k_zero_two(int32_t *a, int32_t *b)
+{
+    *a = 0;
+    *b = 0;
+}
+
 extern "C" {
 
 int64_t segk_kmeans_tiles_floats(int32_t K_max, int32_t D)
@@ -3693,7 +3702,14 @@ int32_t segk_corpus_prepare(segk_ctx *ctx, const segk_corpus *c, float *X32_out,
     return SEGK_OK;
 }
 
+static int kmeans_prepare_impl(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m, void *stream, bool mnorm_zeroed);
+
 int32_t segk_kmeans_prepare(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m, void *stream)
+{
+    return kmeans_prepare_impl(ctx, c, m, stream, false);
+}
+
+static int kmeans_prepare_impl(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m, void *stream, bool mnorm_zeroed)
 {
     int rc = check_corpus(c);
     if (rc) return rc;
@@ -3707,7 +3723,7 @@ int32_t segk_kmeans_prepare(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m,
         ctx->row_hash_means = m->means;
     }
     // mnorm_max = max_k |m_k|^2, maintained by atomicMax on the bit pattern (non-negative doubles)
-    SEGK_CHECK_HIP(hipMemsetAsync(m->mnorm_max, 0, sizeof(double), st));
+    if (!mnorm_zeroed) SEGK_CHECK_HIP(hipMemsetAsync(m->mnorm_max, 0, sizeof(double), st));
     DISPATCH_XT(c, hipLaunchKernelGGL(k_kmeans_prepare<XT>, dim3(segk_n_tiles(m->K_max)), dim3(256), 0, st,
                                        (const XT *)m->means, m->K_max, c->D, m->tiles,
                                        (unsigned long long *)m->mnorm_max, m->tiles_b3 ? (unsigned int *)m->tiles_b3 + 1 : nullptr,
@@ -3913,13 +3929,22 @@ static int resolve_on(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m,
 int32_t segk_kmeans_score(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m, const int32_t *ids,
                           int64_t row0, int64_t n, const segk_cand *cand, int32_t *status, void *stream)
 {
-    int rc = segk_kmeans_clear_queue(ctx, cand, stream);
+    int rc;
+    if (ctx && ctx->pre_queue && cand && cand->count) {
+        // one tiny kernel instead of two 4-byte memsets: the caller's queue length and the pre-filter's
+        hipLaunchKernelGGL(k_zero_two, dim3(1), dim3(1), 0, (hipStream_t)stream, cand->count, ctx->pre_queue);
+        ctx->pre_zeroed = 1;
+        rc = SEGK_OK;
+    } else {
+        rc = segk_kmeans_clear_queue(ctx, cand, stream);
+    }
     if (rc) return rc;
     // SEGK_SCORE_OVERLAP=0: everything on the caller's stream
     const char *ov = getenv("SEGK_SCORE_OVERLAP");
     ctx->overlap_req = (ov && atoi(ov) == 0) ? 0 : 1;
     rc = segk_kmeans_filter(ctx, c, m, ids, row0, n, cand, stream);
     ctx->overlap_req = 0;
+    ctx->pre_zeroed = 0;
     if (rc) return rc;
     if (!ctx->aux_busy) return resolve_on(ctx, c, m, ids, row0, n, cand, status, stream);
     rc = resolve_on(ctx, c, m, ids, row0, n, cand, status, (void *)ctx->aux);
@@ -4154,9 +4179,9 @@ int32_t segk_kmeans_batch_finalize(segk_ctx *ctx, const segk_corpus *c, segk_kme
     int64_t nslot = (int64_t)(utt_hi - utt_lo) * c->N_max;
     if (nslot > 0)
         hipLaunchKernelGGL(k_batch_relabel, dim3((unsigned)((nslot + 255) / 256)), dim3(256), 0, st, *c, utt_lo,
-                           utt_hi, new_k, n_new, remap_scratch);
+                           utt_hi, new_k, n_new, remap_scratch, (double *)m->mnorm_max);
     SEGK_LAUNCH_CHECK();
-    rc = segk_kmeans_prepare(ctx, c, m, stream);
+    rc = kmeans_prepare_impl(ctx, c, m, stream, /* mnorm_max already zero */ nslot > 0);
     if (rc) return rc;
     // clean_components leaves exact copies behind (the moved rows, the inactive rows): out of the filters' images,
     // or every embedding near such a pair is a tie for the full scan.  SEGK_MARK_DUPS=0: leave them in.
