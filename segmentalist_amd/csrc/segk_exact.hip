@@ -1,0 +1,353 @@
+// segk_exact.hip -- exact stage: full scan of the ambiguity queue in the reference's arithmetic, A1 vector, candidate gather
+// (one of the translation units of the k-means path; shared helpers: segk_kmeans_dev.h)
+#include "segk_kmeans_dev.h"
+
+// ======================================================================================
+// Exact stage.
+//   k_kmeans_brute       every queued (ambiguous) row: the reference's own computation for ALL
+//                        K_max components, first maximum (np.argmax); one workgroup per row,
+//                        components contiguous across lanes (tile image) for float32 data
+//   k_kmeans_exact_fill  rows whose winner was not evaluated in the score kernel's epilogue
+//                        (float64 data, D < 8 or D > 128): exact score of the winner
+// After these, cand.k / cand.s hold np.argmax / np.max of neg_sqrd_norm for every scored row.
+// ======================================================================================
+template <typename XT>
+__global__ void k_kmeans_brute(segk_corpus c, segk_kmeans m, segk_cand cand, int cap, int32_t *n_brute)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    double *red_v = (double *)smem;                  // [nt]
+    XT *xrow = (XT *)(red_v + nt);                   // [D]
+    int32_t *red_k = (int32_t *)(xrow + ((c.D + 1) & ~1));   // [nt]
+    const XT *X = (const XT *)c.X;
+    const XT *means = (const XT *)m.means;
+    const int D = c.D;
+    int nq = *cand.count;
+    if (nq > cap) nq = cap;
+    if (blockIdx.x == 0 && tid == 0 && n_brute && nq > 0) atomicAdd(n_brute, nq);
+    for (int q = blockIdx.x; q < nq; q += gridDim.x) {
+        const int32_t id = cand.queue[q];
+        __syncthreads();
+        for (int d = tid; d < D; d += nt) xrow[d] = X[(int64_t)id * c.ldx + d];
+        __syncthreads();
+        XT best = (XT)NEG_INF_D;
+        int32_t bk = 0x7fffffff;
+        if constexpr (sizeof(XT) == 4) {
+            const int tstride = segk_tile_stride(D);
+            int k = tid;
+            if (D >= 8 && D <= 128) {
+                // four components per thread in flight: the same numpy-ordered accumulation for
+                // each, but their loads are independent, which hides the L2 latency
+                for (; k + 3 * nt < m.K_max; k += 4 * nt) {
+                    XT sc[4];
+                    neg_sqd_exact_x4<XT>(tile_row(m.tiles, tstride, k), tile_row(m.tiles, tstride, k + nt),
+                                         tile_row(m.tiles, tstride, k + 2 * nt), tile_row(m.tiles, tstride, k + 3 * nt),
+                                         xrow, D, sc);
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+                        if (sc[q] > best || bk == 0x7fffffff) { best = sc[q]; bk = k + q * nt; }
+                }
+            }
+            for (; k < m.K_max; k += nt) {
+                XT sc = neg_sqd_exact<XT>(tile_row(m.tiles, tstride, k), xrow, D);
+                if (sc > best || bk == 0x7fffffff) { best = sc; bk = k; }   // first max within the thread
+            }
+        } else {
+            for (int k = tid; k < m.K_max; k += nt) {
+                XT sc = neg_sqd_exact<XT>(means + (int64_t)k * D, xrow, D);
+                if (sc > best || bk == 0x7fffffff) { best = sc; bk = k; }
+            }
+        }
+        red_v[tid] = (double)best;
+        red_k[tid] = bk;
+        __syncthreads();
+        for (int o = nt >> 1; o > 0; o >>= 1) {
+            if (tid < o) {
+                double v2 = red_v[tid + o];
+                int32_t k2 = red_k[tid + o];
+                bool take = (k2 != 0x7fffffff) &&
+                            (red_k[tid] == 0x7fffffff || v2 > red_v[tid] || (v2 == red_v[tid] && k2 < red_k[tid]));
+                if (take) { red_v[tid] = v2; red_k[tid] = k2; }
+            }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            cand.k[id] = red_k[0];
+            cand.s[id] = red_v[0];
+        }
+    }
+}
+
+// Full scan of BR queued rows per workgroup for float32 data with 8 <= D <= 128 (numpy's
+// single-block case): a thread walks the components tid, tid + nt, ... and evaluates each against
+// the BR rows held in LDS -- every component value is fetched once for BR rows, which takes the scan
+// from L2-bandwidth bound (one pass over the tile image per row) to latency/compute bound.  Per
+// (row, component) the arithmetic is neg_sqd_exact's: eight strided accumulators, the fixed combine
+// tree, the sequential tail; first maximum per row.
+// BR = 4 (was 8: 234 VGPRs): in the pre-filter path the scan runs on the second stream beside the exact pair
+// kernel, whose waves hold 144 VGPRs each -- with 8 rows its workgroups could not be placed until those
+// waves ended (121 us in the trace against 65 alone); with 4 the sweep gains 4 %.
+#define SEGK_BR 4
+// component slices of the full scan for a queue of nq rows on a grid of `grid` workgroups (at most max_split)
+__device__ __forceinline__ int segk_brute_split(int nq, int grid, int max_split)
+{
+    const int groups = (nq + SEGK_BR - 1) / SEGK_BR;
+    int ks = groups > 0 ? grid / groups : 1;
+    if (ks > max_split) ks = max_split;
+    return ks < 1 ? 1 : ks;
+}
+
+__global__ __launch_bounds__(256) void k_kmeans_brute_rows(segk_corpus c, segk_kmeans m, segk_cand cand, int cap, int32_t *n_brute,
+                                                          int n_groups, int ksplit, unsigned long long *ws, int ws_cap)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, nt = blockDim.x, D = c.D;
+    const int DP = (D + 3) & ~3;                             // row pitch: float4 reads of the staged rows
+    float *xs = (float *)smem;                               // [BR][DP]
+    float *red_v = xs + SEGK_BR * DP;                        // [nt]
+    int32_t *red_k = (int32_t *)(red_v + nt);                // [nt]
+    __shared__ int32_t ids[SEGK_BR];
+    const float *X = (const float *)c.X;
+    int nq = *cand.count;
+    if (nq > cap) nq = cap;
+    if (blockIdx.x == 0 && tid == 0 && n_brute && nq > 0) atomicAdd(n_brute, nq);
+    const int tstride = segk_tile_stride(D);
+    const int nfull = D - (D % 8);
+    // workgroup = (row group, component slice): the slices of a row meet in ws[] through a 64-bit
+    // atomicMax on (orderable score bits, ~component) -- the largest score, the lowest component on ties;
+    // k_brute_finish unpacks.  Queue entries beyond ws_cap keep the unsplit form (slice 0 scans all).
+    // The host does not know the queue length (it lives on the device), so the split is chosen here, from
+    // the launched grid: as many component slices (up to `ksplit`, one component per thread and slice) as
+    // the grid has workgroups per row group.  segk_brute_split() is shared with k_brute_finish.
+    ksplit = segk_brute_split(nq, (int)gridDim.x, ksplit);
+    n_groups = (int)gridDim.x / ksplit;
+    const int grp0 = blockIdx.x % n_groups, slice = blockIdx.x / n_groups;
+    if (slice >= ksplit) return;
+    const int k_per = (m.K_max + ksplit - 1) / ksplit;
+    for (int q0 = grp0 * SEGK_BR; q0 < nq; q0 += n_groups * SEGK_BR) {
+        const bool split = ksplit > 1 && q0 + SEGK_BR <= ws_cap;
+        if (!split && slice != 0) continue;
+        const int k_lo = split ? slice * k_per : 0;
+        const int k_hi = split ? (k_lo + k_per < m.K_max ? k_lo + k_per : m.K_max) : m.K_max;
+        const int nr = nq - q0 < SEGK_BR ? nq - q0 : SEGK_BR;
+        __syncthreads();
+        if (tid < SEGK_BR) ids[tid] = cand.queue[q0 + (tid < nr ? tid : nr - 1)];
+        __syncthreads();
+        for (int j = tid; j < SEGK_BR * D; j += nt) {
+            const int r = j / D, d = j - r * D;
+            xs[r * DP + d] = X[(int64_t)ids[r] * c.ldx + d];
+        }
+        __syncthreads();
+        float best[SEGK_BR];
+        int32_t bk[SEGK_BR];
+#pragma unroll
+        for (int r = 0; r < SEGK_BR; r++) { best[r] = NEG_INF_F; bk[r] = 0x7fffffff; }
+        for (int k = k_lo + tid; k < k_hi; k += nt) {
+            const TileRow mr = tile_row(m.tiles, tstride, k);
+            float acc[SEGK_BR][8];
+            float mv[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) mv[j] = mr[j];
+#pragma unroll
+            for (int r = 0; r < SEGK_BR; r++) {
+                const float4 x0 = *reinterpret_cast<const float4 *>(xs + r * DP), x1 = *reinterpret_cast<const float4 *>(xs + r * DP + 4);
+                const float xv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const float delta = mv[j] - xv[j];
+                    acc[r][j] = delta * delta;
+                }
+            }
+            int i;
+            for (i = 8; i < nfull; i += 8) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) mv[j] = mr[i + j];
+#pragma unroll
+                for (int r = 0; r < SEGK_BR; r++) {
+                    const float4 x0 = *reinterpret_cast<const float4 *>(xs + r * DP + i), x1 = *reinterpret_cast<const float4 *>(xs + r * DP + i + 4);
+                    const float xv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        const float delta = mv[j] - xv[j];
+                        acc[r][j] += delta * delta;
+                    }
+                }
+            }
+            float res[SEGK_BR];
+#pragma unroll
+            for (int r = 0; r < SEGK_BR; r++)
+                res[r] = ((acc[r][0] + acc[r][1]) + (acc[r][2] + acc[r][3])) + ((acc[r][4] + acc[r][5]) + (acc[r][6] + acc[r][7]));
+            for (; i < D; i++) {
+                const float mvi = mr[i];
+#pragma unroll
+                for (int r = 0; r < SEGK_BR; r++) {
+                    const float delta = mvi - xs[r * DP + i];
+                    res[r] += delta * delta;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < SEGK_BR; r++) {
+                const float sc = -res[r];
+                if (sc > best[r] || bk[r] == 0x7fffffff) { best[r] = sc; bk[r] = k; }   // first max within the thread
+            }
+        }
+        for (int r = 0; r < nr; r++) {
+            // wave butterfly (ties -> lower component), then the waves' results through LDS
+            float v = best[0];
+            int32_t kk = bk[0];
+#pragma unroll
+            for (int q = 1; q < SEGK_BR; q++)
+                if (q == r) { v = best[q]; kk = bk[q]; }
+            for (int o = 32; o > 0; o >>= 1) {
+                const float v2 = __shfl_xor(v, o);
+                const int32_t k2 = __shfl_xor(kk, o);
+                const bool take = (k2 != 0x7fffffff) && (kk == 0x7fffffff || v2 > v || (v2 == v && k2 < kk));
+                if (take) { v = v2; kk = k2; }
+            }
+            __syncthreads();
+            if ((tid & 63) == 0) { red_v[tid >> 6] = v; red_k[tid >> 6] = kk; }
+            __syncthreads();
+            if (tid == 0) {
+                for (int w = 1; w < (nt >> 6); w++) {
+                    const float v2 = red_v[w];
+                    const int32_t k2 = red_k[w];
+                    const bool take = (k2 != 0x7fffffff) && (kk == 0x7fffffff || v2 > v || (v2 == v && k2 < kk));
+                    if (take) { v = v2; kk = k2; }
+                }
+                if (split) {
+                    if (kk != 0x7fffffff) {
+                        const unsigned int bits = __float_as_uint(v);
+                        const unsigned int ord = (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);
+                        atomicMax(&ws[q0 + r], ((unsigned long long)ord << 32) | (unsigned long long)(0xffffffffu - (unsigned)kk));
+                    }
+                } else {
+                    cand.k[ids[r]] = kk;
+                    cand.s[ids[r]] = (double)v;
+                }
+            }
+        }
+    }
+}
+
+// unpack the split scan's (score, component) pairs into the candidates and clear the workspace
+__global__ void k_brute_finish(segk_cand cand, int cap, unsigned long long *ws, int ws_cap, int scan_grid, int max_split)
+{
+    int nq = *cand.count;
+    if (nq > cap) nq = cap;
+    if (segk_brute_split(nq, scan_grid, max_split) <= 1) return;       // the scan wrote the candidates itself
+    // the groups that were scanned in slices: q0 + SEGK_BR <= ws_cap
+    const int lim = nq < (ws_cap / SEGK_BR) * SEGK_BR ? nq : (ws_cap / SEGK_BR) * SEGK_BR;
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < lim; q += gridDim.x * blockDim.x) {
+        const unsigned long long pk = ws[q];
+        ws[q] = 0ull;
+        const unsigned int ord = (unsigned int)(pk >> 32);
+        const unsigned int bits = (ord & 0x80000000u) ? (ord & 0x7fffffffu) : ~ord;
+        const int32_t id = cand.queue[q];
+        cand.k[id] = (int32_t)(0xffffffffu - (unsigned int)(pk & 0xffffffffu));
+        cand.s[id] = (double)__uint_as_float(bits);
+    }
+}
+
+
+__global__ void k_kmeans_gather_cand(segk_cand cand, const int32_t *ids, int64_t n, double *out_max,
+                                     int32_t *out_arg)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const int64_t id = ids ? (int64_t)ids[r] : r;
+    out_max[r] = cand.s[id];
+    out_arg[r] = cand.k[id];
+}
+
+// A1 full vector for one row (API: segk_kmeans_neg_sqrd_norm)
+template <typename XT>
+__global__ void k_kmeans_neg_sqrd_norm(segk_corpus c, segk_kmeans m, int64_t row, XT *out)
+{
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= m.K_max) return;
+    out[k] = neg_sqd_exact<XT>((const XT *)m.means + (int64_t)k * c.D, (const XT *)c.X + row * c.ldx, c.D);
+}
+
+// ======================================================================================
+
+extern "C" {
+
+int32_t segk_kmeans_resolve(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m, const int32_t *ids,
+                            int64_t row0, int64_t n, const segk_cand *cand, int32_t *status, void *stream)
+{
+    return segk_resolve_on(ctx, c, m, ids, row0, n, cand, status, stream);
+}
+
+}  // extern "C"
+
+int segk_resolve_on(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m, const int32_t *ids,
+                    int64_t row0, int64_t n, const segk_cand *cand, int32_t *status, void *stream)
+{
+    SEGK_REQUIRE(ctx, "ctx");
+    int rc = score_checks(c, m, ids, row0, n, cand);
+    if (rc) return rc;
+    if (n <= 0) return SEGK_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const bool fused = (c->x_dtype == SEGK_F32 && c->D >= 8 && c->D <= 128);
+    if (!fused || (segk_use_b3(c, m) && c->D % 4 != 0))       // the split-precision epilogue is fused for D % 4 == 0
+        DISPATCH_XT(c, hipLaunchKernelGGL(k_kmeans_exact_fill<XT>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                                           *c, *m, ids, row0, n, *cand););
+    const int nt = 256;
+    if (fused) {         // float32 data, 8 <= D <= 128: SEGK_BR queued rows per workgroup, components in slices
+        const size_t lds = (size_t)SEGK_BR * ((c->D + 3) & ~3) * sizeof(float) + nt * (sizeof(float) + sizeof(int32_t));
+        // grid for the worst case the host can see (every row queued), capped; the kernel reads the queue
+        // length and slices the components over whatever the grid leaves per row group (a queue of 200 rows
+        // on 1024 workgroups: four slices instead of 25 busy workgroups; alone: 15 us + 13 us per 1000 rows)
+        const int64_t groups = (n + SEGK_BR - 1) / SEGK_BR;
+        int max_split = (m->K_max + nt - 1) / nt;
+        if (max_split > 8) max_split = 8;
+        if (max_split < 1) max_split = 1;
+        int64_t grid = groups * max_split;
+        if (grid > 1024) grid = 1024;
+        hipLaunchKernelGGL(k_kmeans_brute_rows, dim3((unsigned)grid), dim3(nt), lds, st, *c, *m, *cand,
+                           (int)c->n_emb, status ? status + 1 : nullptr, (int)grid, max_split, ctx->ws_u64, SEGK_WS_ENTRIES);
+        if (max_split > 1)
+            hipLaunchKernelGGL(k_brute_finish, dim3(32), dim3(256), 0, st, *cand, (int)c->n_emb, ctx->ws_u64, SEGK_WS_ENTRIES,
+                               (int)grid, max_split);
+    } else {
+        size_t xsz = (c->x_dtype == SEGK_F32 ? 4 : 8) * (size_t)((c->D + 1) & ~1);
+        size_t lds = nt * sizeof(double) + xsz + nt * sizeof(int32_t);
+        int64_t grid = n < 1024 ? n : 1024;
+        DISPATCH_XT(c, hipLaunchKernelGGL(k_kmeans_brute<XT>, dim3((unsigned)grid), dim3(nt), lds, st, *c, *m, *cand,
+                                           (int)c->n_emb, status ? status + 1 : nullptr););
+    }
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+extern "C" {
+
+int32_t segk_kmeans_exact_max(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m, const int32_t *ids,
+                              int64_t n, const segk_cand *cand, double *out_max, int32_t *out_arg, void *stream)
+{
+    (void)ctx;
+    (void)m;
+    int rc = check_corpus(c);
+    if (rc) return rc;
+    if (n <= 0) return SEGK_OK;
+    hipLaunchKernelGGL(k_kmeans_gather_cand, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       *cand, ids, n, out_max, out_arg);
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+int32_t segk_kmeans_neg_sqrd_norm(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m, int64_t row,
+                                  void *out, void *stream)
+{
+    (void)ctx;
+    int rc = check_corpus(c);
+    if (rc) return rc;
+    SEGK_REQUIRE(row >= 0 && row < c->n_emb, "row out of range");
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_XT(c, hipLaunchKernelGGL(k_kmeans_neg_sqrd_norm<XT>, dim3((m->K_max + 255) / 256), dim3(256), 0, st,
+                                       *c, *m, row, (XT *)out););
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+}  // extern "C"

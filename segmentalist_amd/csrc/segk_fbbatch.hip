@@ -565,7 +565,7 @@ __global__ void k_fbb_apply_remap(segk_fbgmm f, segk_fbatch bt, int64_t n_emb, c
 }
 
 // ---------------------------------------------------------------------------------------
-// fp32 matrix-core span score of fixed-variance components (the MFMA kernel of segk_kmeans.hip in
+// fp32 matrix-core span score of fixed-variance components (the MFMA kernel of segk_score_f32.hip in
 // log-sum-exp mode): operands.
 //   Y[row] = [x_0^2, x_0, x_1^2, x_1, ...]                                    (once per corpus)
 //   tile row of slot k (count > 0):  [-pp_kd/2, pp_kd*mu_kd]_d * log2(e),

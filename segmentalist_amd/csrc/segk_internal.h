@@ -90,7 +90,7 @@ static inline __host__ __device__ int segk_tile_stride(int D)
 static inline __host__ __device__ int segk_n_tiles(int K_max) { return (K_max + 31) / 32; }
 
 // ---------------------------------------------------------------------------------------
-// Operand images of the split-precision k-means filter (float32 data, 8 <= D <= 128; segk_kmeans.hip).
+// Operand images of the split-precision k-means filter (float32 data, 8 <= D <= 128; segk_score_sp.hip, segk_score_h1.hip).
 // P = 3: three bf16 pieces, x = x1 + x2 + x3 exactly.  P = 2: two fp16 pieces of 2^a x (power-of-two
 // scaling), the second one carried at 2^11 times its weight.
 //   rows   [SEGK_SP_HEADER bytes: int32 {P, exponent a, bits of max |x_d|}] then [n_emb][P][KP] 16-bit
@@ -118,11 +118,11 @@ static inline __host__ __device__ int segk_sp_tile_stride(int D, int P)
     return ((segk_b3_kp(D) / 16) * P * 256 + 32 + 1023) / 1024 * 1024;
 }
 
-// segk_kmeans.hip: the MFMA score kernel in log-sum-exp mode (used by segk_fbbatch.hip); not ABI
+// segk_score_f32.hip: the MFMA score kernel in log-sum-exp mode (used by segk_fbbatch.hip); not ABI
 int segk_launch_score_lse(segk_ctx *ctx, const float *Y, int64_t ldy, int D2, const int32_t *ids, int64_t row0, int64_t n,
                           const float *tiles, int n_tiles, double norm, double *out, void *stream);
 
-// segk_kmeans.hip: fp16x2 images of arbitrary float32 matrices and the log-sum-exp kernel on them
+// segk_prepare.hip / segk_score_sp.hip: fp16x2 images of arbitrary float32 matrices and the log-sum-exp kernel on them
 int segk_sp_prepare_rows(const float *Y, int64_t ldy, int64_t n, int D2, void *img, void *stream);
 int segk_sp_prepare_tiles(const float *rows, const double *consts, const double *rowmax2, int K, int D2, float *tiles_sp,
                           const void *ximg, void *stream);

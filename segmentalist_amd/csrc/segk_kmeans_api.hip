@@ -1,0 +1,94 @@
+// segk_kmeans_api.hip -- C ABI of the score stage: filter selection (pre-filter / split precision / fp32 MFMA), two-stream join
+// (one of the translation units of the k-means path; shared helpers: segk_kmeans_dev.h)
+#include "segk_kmeans_dev.h"
+
+__global__ void k_zero_two(int32_t *a, int32_t *b)
+{
+    *a = 0;
+    *b = 0;
+}
+
+extern "C" {
+
+int32_t segk_kmeans_clear_queue(segk_ctx *ctx, const segk_cand *cand, void *stream)
+{
+    (void)ctx;
+    SEGK_REQUIRE(cand && cand->count, "cand");
+    SEGK_CHECK_HIP(hipMemsetAsync(cand->count, 0, sizeof(int32_t), (hipStream_t)stream));
+    return SEGK_OK;
+}
+
+int32_t segk_kmeans_filter(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m, const int32_t *ids,
+                           int64_t row0, int64_t n, const segk_cand *cand, void *stream)
+{
+    SEGK_REQUIRE(ctx, "ctx");
+    int rc = score_checks(c, m, ids, row0, n, cand);
+    if (rc) return rc;
+    if (n <= 0) return SEGK_OK;
+    hipStream_t st = (hipStream_t)stream;
+    ScoreArgs A{};
+    A.X32 = c->X32; A.ld32 = c->ld32; A.ids = ids; A.row0 = row0; A.n = n;
+    A.tiles = m->tiles; A.n_tiles = segk_n_tiles(m->K_max); A.tile_stride = segk_tile_stride(c->D);
+    A.G = segk_G(c->D); A.D = c->D;
+    A.fuse_exact = (c->x_dtype == SEGK_F32 && c->D >= 8 && c->D <= 128) ? 1 : 0;
+    A.is_f64 = c->x_dtype == SEGK_F64;
+    A.dbg = getenv("SEGK_SCORE_DBG") ? atoi(getenv("SEGK_SCORE_DBG")) : 0;
+    A.xnorm = c->xnorm; A.mnorm2 = m->mnorm_max; A.cand = *cand; A.amb_cap = (int)c->n_emb;
+    A.n_chunks = 0; A.tiles_per_split = 0; A.part_k = nullptr; A.part_f = nullptr;
+    // 4-wave workgroups, two per CU: the two waves sharing a SIMD belong to DIFFERENT workgroups
+    // and drift apart, covering each other's barrier/staging gaps.  (Measured: an 8-wave
+    // workgroup, one barrier for all eight waves, locks the SIMD partners in step and is 15 %
+    // slower although it halves the staging instructions per wave.)
+    if (segk_use_b3(c, m)) {
+        A.xrows32 = c->X32;
+        A.X32 = (const float *)c->Xb3;
+        A.tiles = m->tiles_b3;
+        A.tile_stride = segk_sp_tile_stride(c->D, c->sp_pieces);
+        A.means32 = (const float *)m->means;
+        A.fuse_exact = (c->D % 4 == 0) ? 1 : 0;
+        A.K_max = m->K_max;
+        A.xerr = (const float *)((const unsigned char *)c->Xb3 + SEGK_SP_HEADER + c->n_emb * 2 * (int64_t)segk_b3_kp(c->D) * 2);
+        // one-product pre-filter in front (two-piece images, D % 4 == 0).  Its three extra launches -- and the
+        // second stage's fixed cost, one workgroup's pass over every tile with all three products (~45 us)
+        // -- pay once the split-precision kernel alone would need more than four rounds of the chip
+        // (estimated break-even near 130 k rows; 1 M rows: 0.58 ms against 0.77 ms).
+        // SEGK_SCORE_PRE=0 disables it, =1 forces it at every size (tests).
+        const char *pre_env = getenv("SEGK_SCORE_PRE");
+        const int pre_mode = pre_env ? atoi(pre_env) : -1;
+        if (c->sp_pieces == 2 && A.fuse_exact && pre_mode != 0 && (pre_mode == 1 || n > 1024 * (int64_t)ctx->n_cu) &&
+            n < (int64_t)1 << 30)
+            return segk_dispatch_score_pre(ctx, A, segk_b3_kp(c->D) / 16, st);
+        return segk_dispatch_score_sp(ctx, A, segk_b3_kp(c->D) / 16, c->sp_pieces, st);
+    }
+    return segk_dispatch_score_f32(ctx, c, m, A, st);
+}
+
+int32_t segk_kmeans_score(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m, const int32_t *ids,
+                          int64_t row0, int64_t n, const segk_cand *cand, int32_t *status, void *stream)
+{
+    int rc;
+    if (ctx && ctx->pre_queue && cand && cand->count) {
+        // one tiny kernel instead of two 4-byte memsets: the caller's queue length and the pre-filter's
+        hipLaunchKernelGGL(k_zero_two, dim3(1), dim3(1), 0, (hipStream_t)stream, cand->count, ctx->pre_queue);
+        ctx->pre_zeroed = 1;
+        rc = SEGK_OK;
+    } else {
+        rc = segk_kmeans_clear_queue(ctx, cand, stream);
+    }
+    if (rc) return rc;
+    // SEGK_SCORE_OVERLAP=0: everything on the caller's stream
+    const char *ov = getenv("SEGK_SCORE_OVERLAP");
+    ctx->overlap_req = (ov && atoi(ov) == 0) ? 0 : 1;
+    rc = segk_kmeans_filter(ctx, c, m, ids, row0, n, cand, stream);
+    ctx->overlap_req = 0;
+    ctx->pre_zeroed = 0;
+    if (rc) return rc;
+    if (!ctx->aux_busy) return segk_resolve_on(ctx, c, m, ids, row0, n, cand, status, stream);
+    rc = segk_resolve_on(ctx, c, m, ids, row0, n, cand, status, (void *)ctx->aux);
+    ctx->aux_busy = 0;
+    SEGK_CHECK_HIP(hipEventRecord(ctx->ev_join, ctx->aux));
+    SEGK_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, ctx->ev_join, 0));
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,445 @@
+// segk_kmeans_dev.h -- device helpers, launch arguments and cross-unit declarations shared by the
+// translation units of the k-means path (segk_prepare / segk_score_f32 / segk_score_sp / segk_score_h1 /
+// segk_exact / segk_segment / segk_stats / segk_kmeans_api .hip).  Not part of the ABI.
+#pragma once
+#include <stdlib.h>
+
+#include "segk_internal.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define NEG_INF_D (-__builtin_huge_val())
+#define NEG_INF_F (-__builtin_huge_valf())
+
+// ======================================================================================
+// Exact stage: numpy's pairwise summation of (m[d]-x[d])^2, identical evaluation order
+// (kmeans_components.py:225-226; numpy pairwise_sum: n<8 sequential, n<=128 eight strided
+// accumulators + fixed tree + sequential tail, n>128 split at n/2 rounded down to 8).
+// ======================================================================================
+template <typename T, typename TM, typename TX>
+__device__ __forceinline__ T sqd(const TM &m, const TX *x, int d)
+{
+    T delta = (T)m[d] - (T)x[d];
+    return delta * delta;
+}
+
+// TM: anything indexable (`const float*`, `const double*`, TileRow)
+template <typename T, typename TM, typename TX>
+__device__ T pw_base(const TM &m, const TX *x, int n)
+{
+    if (n < 8) {
+        T res = (T)0;
+        for (int i = 0; i < n; i++) res += sqd<T>(m, x, i);
+        return res;
+    }
+    T r0 = sqd<T>(m, x, 0), r1 = sqd<T>(m, x, 1), r2 = sqd<T>(m, x, 2), r3 = sqd<T>(m, x, 3);
+    T r4 = sqd<T>(m, x, 4), r5 = sqd<T>(m, x, 5), r6 = sqd<T>(m, x, 6), r7 = sqd<T>(m, x, 7);
+    int i;
+    const int nfull = n - (n % 8);
+    for (i = 8; i < nfull; i += 8) {
+        r0 += sqd<T>(m, x, i + 0);
+        r1 += sqd<T>(m, x, i + 1);
+        r2 += sqd<T>(m, x, i + 2);
+        r3 += sqd<T>(m, x, i + 3);
+        r4 += sqd<T>(m, x, i + 4);
+        r5 += sqd<T>(m, x, i + 5);
+        r6 += sqd<T>(m, x, i + 6);
+        r7 += sqd<T>(m, x, i + 7);
+    }
+    T res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+    for (; i < n; i++) res += sqd<T>(m, x, i);
+    return res;
+}
+
+// -sum_d (m[d]-x[d])^2 in the dtype T of the reference's `means`/X.  Offsets into m are
+// multiples of 8 (numpy's split points), which TileRow::operator+ relies on.
+template <typename T, typename TM, typename TX>
+__device__ T neg_sqd_exact(const TM &m, const TX *x, int n)
+{
+    if (n <= 128) return -pw_base<T>(m, x, n);
+    struct Frame { int off, n, state; T left; };
+    Frame st[28];
+    int sp = 0;
+    st[0].off = 0; st[0].n = n; st[0].state = 0; st[0].left = (T)0;
+    T ret = (T)0;
+    while (sp >= 0) {
+        Frame &f = st[sp];
+        if (f.state == 0) {
+            if (f.n <= 128) {
+                ret = pw_base<T>(m + f.off, x + f.off, f.n);
+                sp--;
+            } else {
+                int n2 = f.n / 2;
+                n2 -= n2 % 8;
+                f.state = 1;
+                st[sp + 1].off = f.off; st[sp + 1].n = n2; st[sp + 1].state = 0;
+                sp++;
+            }
+        } else if (f.state == 1) {
+            f.left = ret;
+            f.state = 2;
+            int n2 = f.n / 2;
+            n2 -= n2 % 8;
+            st[sp + 1].off = f.off + n2; st[sp + 1].n = f.n - n2; st[sp + 1].state = 0;
+            sp++;
+        } else {
+            ret = f.left + ret;
+            sp--;
+        }
+    }
+    return -ret;
+}
+
+// Four rows at once for 8 <= n <= 128 (numpy's single-block case): identical arithmetic per
+// row, interleaved so that 4 x 8 loads are in flight per step.
+template <typename T, typename TM, typename TX>
+__device__ void neg_sqd_exact_x4(const TM &m0, const TM &m1, const TM &m2, const TM &m3, const TX *x, int n, T *out)
+{
+    T r[4][8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        r[0][j] = sqd<T>(m0, x, j);
+        r[1][j] = sqd<T>(m1, x, j);
+        r[2][j] = sqd<T>(m2, x, j);
+        r[3][j] = sqd<T>(m3, x, j);
+    }
+    int i;
+    const int nfull = n - (n % 8);
+    for (i = 8; i < nfull; i += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            r[0][j] += sqd<T>(m0, x, i + j);
+            r[1][j] += sqd<T>(m1, x, i + j);
+            r[2][j] += sqd<T>(m2, x, i + j);
+            r[3][j] += sqd<T>(m3, x, i + j);
+        }
+    }
+    T res[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+        res[q] = ((r[q][0] + r[q][1]) + (r[q][2] + r[q][3])) + ((r[q][4] + r[q][5]) + (r[q][6] + r[q][7]));
+    for (; i < n; i++) {
+        res[0] += sqd<T>(m0, x, i);
+        res[1] += sqd<T>(m1, x, i);
+        res[2] += sqd<T>(m2, x, i);
+        res[3] += sqd<T>(m3, x, i);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) out[q] = -res[q];
+}
+
+// A component's row read from the MFMA tile image instead of from `means`: the image holds
+// the same float32 values with the component index contiguous (stride 2 floats), so that
+// consecutive lanes scanning consecutive components touch a few cache lines per load instead
+// of one line per lane.  Only valid when the means are float32 (the image is a float copy).
+struct TileRow {
+    const float *base;      // tiles + tile*stride + 2*(k & 31)
+    __device__ __forceinline__ float operator[](int d) const
+    {
+        return base[(d >> 2) * 128 + ((d >> 1) & 1) * 64 + (d & 1)];
+    }
+    __device__ __forceinline__ TileRow operator+(int off) const { return TileRow{base + (off >> 2) * 128}; }
+};
+__device__ __forceinline__ TileRow tile_row(const float *tiles, int tile_stride, int k)
+{
+    return TileRow{tiles + (int64_t)(k >> 5) * tile_stride + 2 * (k & 31)};
+}
+
+// Margin below which two fp32-filter values cannot be ordered with certainty
+// (DESIGN.md "filter margin"): tau = 1.25 * (2*E1 + E2) where
+//   E1 = (D4+3) u (|x| M + M^2/2)          fp32 fma chain of the MFMA + operand rounding
+//   E2 = c2 u (|x| + M)^2                   rounding of the REFERENCE's own float32 evaluation
+// (E2 ~ 0 when the reference computes in float64).  u = 2^-24.
+__device__ __forceinline__ float filter_tau(float xn, float M, int D, int is_f64)
+{
+    const float u = 5.9604645e-8f;
+    const int D4 = (D + 3) & ~3;
+    float e1 = (float)(D4 + 3 + (is_f64 ? 4 : 0)) * u * (xn * M + 0.5f * M * M);
+    int levels = 0;
+    for (int n = D; n > 128; n = (n + 1) / 2) levels++;
+    int deff = D < 128 ? D : 128;
+    float c2 = is_f64 ? 1e-6f : (float)(deff / 8 + 13 + 2 * levels);
+    float s = xn + M;
+    float e2 = c2 * u * s * s;
+    return 1.25f * (2.0f * e1 + e2) + 1e-37f;
+}
+
+// value hash of one element of a row of `means` (k_kmeans_mark_dups): -0 and +0 hash alike, the per-element
+// terms add up commutatively, so lanes can hash strided parts of a row and sum
+__device__ __forceinline__ unsigned long long segk_elem_hash(double v, int d)
+{
+    unsigned long long z = (unsigned long long)__double_as_longlong(v + 0.0) + 0x9E3779B97F4A7C15ull * (unsigned long long)(d + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// single-instruction max (fmaxf() makes hipcc add a canonicalising v_max on MFMA outputs)
+__device__ __forceinline__ float vmax_f32(float a, float b)
+{
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+#define SEGK_PAIR_PENDING 0x40000000      /* cand.k: pair (c, c + 1) named by the pre-filter, member not yet chosen */
+struct ScoreArgs {
+    const float *X32;
+    int64_t ld32;
+    const int32_t *ids;
+    int64_t row0, n;
+    const float *tiles;
+    int n_tiles, tile_stride, G /* groups present in X32 rows */, D, fuse_exact, is_f64;
+    int dbg;                     /* timing-only ablation bits, 0 in production */
+    const float *xnorm;
+    const double *mnorm2;
+    segk_cand cand;
+    int amb_cap;
+    // split-K launch (SPLIT = 1): workgroup b scores chunk b % n_chunks against the tiles
+    // [(b / n_chunks) * tiles_per_split, ...) and writes its partial candidates to part_k / part_f
+    int n_chunks, tiles_per_split;
+    int32_t *part_k;
+    float *part_f;
+    // MODE = 1 (log-sum-exp over the components instead of the top-2): out[row] = ln2 * log2 sum_k 2^acc - lse_norm
+    double *lse_out;
+    double lse_norm;
+    const float *means32;        /* split-precision filter: float32 `means` and rows for the fused exact score */
+    const float *xrows32;
+    float *mat_out;              /* MODE 2: the accumulator values themselves, [n rows][mat_ld], mat_ld >= 32 n_tiles */
+    int64_t mat_ld;
+    // one-product pre-filter (k_kmeans_score_h1): its undecided rows go to pre_queue (pre_cap entries, then to
+    // cand.queue); the split-precision kernel that follows reads its row count from n_dev
+    const int32_t *n_dev;
+    int32_t *pre_queue, *pre_count;
+    int pre_cap, K_max;
+    const float *xerr;           /* pre-filter: |x - x1| per row (k_corpus_resid_sp) */
+    unsigned long long *stamp;   /* -DSEGK_STAMP development builds: s_memtime at phase boundaries, 8 per workgroup */
+};
+
+template <int P> struct SegkPiece;
+template <> struct SegkPiece<3> {
+    typedef __bf16 T;
+    typedef __bf16 V8 __attribute__((ext_vector_type(8)));
+};
+template <> struct SegkPiece<2> {
+    typedef _Float16 T;
+    typedef _Float16 V8 __attribute__((ext_vector_type(8)));
+};
+template <int P>
+__device__ __forceinline__ f32x16 mfma_piece(typename SegkPiece<P>::V8 a, typename SegkPiece<P>::V8 b, f32x16 c)
+{
+    if constexpr (P == 3) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float filter_tau_sp(float xn, float M, int D, int pieces)
+{
+    const float u = 5.9604645e-8f;
+    const int KP = (D + 15) & ~15;
+    float e1 = (1.02f * (float)(KP + 16) + (pieces == 2 ? 16.f : 0.f)) * u * (xn * M + 0.5f * M * M);
+    int levels = 0;
+    for (int n = D; n > 128; n = (n + 1) / 2) levels++;
+    int deff = D < 128 ? D : 128;
+    float c2 = (float)(deff / 8 + 13 + 2 * levels);
+    float s = xn + M;
+    float e2 = c2 * u * s * s;
+    return 1.25f * (2.0f * e1 + e2) + 1e-30f;
+}
+
+// pieces of one value (already scaled by its power of two for P = 2)
+template <int P>
+__device__ __forceinline__ void split_sp(float x, typename SegkPiece<P>::T *pc)
+{
+    typedef typename SegkPiece<P>::T T;
+    if constexpr (P == 3) {
+        const T a = (T)x;
+        const float r1 = x - (float)a;
+        const T b = (T)r1;
+        const float r2 = r1 - (float)b;
+        pc[0] = a;
+        pc[1] = b;
+        pc[2] = (T)r2;
+    } else {
+        const T a = (T)x;
+        const float r1 = x - (float)a;                   // exact
+        pc[0] = a;
+        pc[1] = (T)(r1 * 2048.f);                        // 2^11 r1: exact scaling, then 11 of its <= 13 bits
+    }
+}
+
+// exponent e such that 2^e * vmax lies in [2^12, 2^13); 0 for vmax = 0 / P = 3
+__device__ __forceinline__ int sp_exponent(float vmax)
+{
+    if (!(vmax > 0.f)) return 0;
+    int ex;
+    frexpf(vmax, &ex);                                   // vmax = f * 2^ex, f in [0.5, 1)
+    return 13 - ex;
+}
+
+// |x - x1| per row (x1 = the leading fp16 piece, unscaled): the operand-rounding term of the one-product
+// pre-filter's margin is (|x| + e_x) E_m + e_x M by Cauchy-Schwarz on the actual residual vectors, about a
+// third of the worst case 2^-10 |x| M.  An element whose piece is zero or subnormal in fp16 counts with its
+// full magnitude, which covers a matrix pipe that flushes subnormal inputs as well as one that does not.
+// Stored as float [n_emb] after the two piece planes (the image is sized for three).
+__device__ __forceinline__ double sp_resid2(float scaled)
+{
+    const _Float16 a = (_Float16)scaled;
+    const float af = (float)a;
+    const float r = fabsf(af) < 6.103515625e-5f ? fabsf(scaled) : fabsf(scaled - af);    // 2^-14: smallest normal
+    return (double)r * (double)r;
+}
+
+// The reference's float32 -(deltas*deltas).sum() of one (row, mean) pair in numpy's pairwise order, D a
+// multiple of 4, by two lanes PART apart (h = 0, 1): lane h owns the strided accumulators r_{4h..4h+3} in
+// full (segk_b3_dim); both return the same value.
+template <int KS, int PART>
+__device__ __forceinline__ float sp_exact_score_x(const float *mean, const float *xr, int D, int h)
+{
+    const float *mrow = mean + 4 * h, *xrow = xr + 4 * h;
+    const int nfull = D & ~7, nblk = nfull >> 3;               // whole blocks of 8: both lanes, wave-uniform
+    float r4[4] = {0.f, 0.f, 0.f, 0.f}, tt[4] = {0.f, 0.f, 0.f, 0.f};
+    // the operands of block b + 1 are fetched before block b is accumulated (LDS or global latency under the
+    // arithmetic); the accumulation order is untouched
+    float4 mv = make_float4(0.f, 0.f, 0.f, 0.f), xv = mv;
+    if (nblk > 0) {
+        mv = *reinterpret_cast<const float4 *>(mrow);
+        xv = *reinterpret_cast<const float4 *>(xrow);
+    }
+#pragma unroll
+    for (int b = 0; b < 2 * KS; b++) {
+        if (b < nblk) {
+            float4 mn = mv, xn = xv;
+            if (b + 1 < nblk) {
+                mn = *reinterpret_cast<const float4 *>(mrow + 8 * (b + 1));
+                xn = *reinterpret_cast<const float4 *>(xrow + 8 * (b + 1));
+            }
+            const float mvv[4] = {mv.x, mv.y, mv.z, mv.w}, xvv[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const float delta = mvv[q] - xvv[q];
+                const float t2 = delta * delta;
+                r4[q] = b == 0 ? t2 : r4[q] + t2;
+            }
+            mv = mn;
+            xv = xn;
+        }
+    }
+    if (nfull + 4 * h < D) {                                   // the sequential tail block (D % 4 == 0: lane 0 only)
+        const float4 mt = *reinterpret_cast<const float4 *>(mrow + nfull);
+        const float4 xt = *reinterpret_cast<const float4 *>(xrow + nfull);
+        const float mvv[4] = {mt.x, mt.y, mt.z, mt.w}, xvv[4] = {xt.x, xt.y, xt.z, xt.w};
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const float delta = mvv[q] - xvv[q];
+            tt[q] = delta * delta;
+        }
+    }
+    const int rem = D & 7;
+    float res = (r4[0] + r4[1]) + (r4[2] + r4[3]);
+    const float ro = __shfl_xor(res, PART);
+    res = (h == 0) ? res + ro : ro + res;                      // ((r0+r1)+(r2+r3)) + ((r4+r5)+(r6+r7))
+    const float u0 = __shfl_xor(tt[0], PART), u1 = __shfl_xor(tt[1], PART), u2 = __shfl_xor(tt[2], PART);
+    // tail dimension nfull + jj lives on half jj >> 2, slot jj & 3 (rem < 8, D % 4 == 0: rem is 0 or 4)
+    const float t0 = h == 0 ? tt[0] : u0, t1 = h == 0 ? tt[1] : u1, t2 = h == 0 ? tt[2] : u2;
+    const float t3 = h == 0 ? tt[3] : __shfl_xor(tt[3], PART);
+    if (rem > 0) res += t0;
+    if (rem > 1) res += t1;
+    if (rem > 2) res += t2;
+    if (rem > 3) res += t3;
+    return -res;
+}
+template <int KS>
+__device__ __forceinline__ float sp_exact_score(const float *mean, const float *xr, int D, int h)
+{
+    return sp_exact_score_x<KS, 32>(mean, xr, D, h);      // the two 32-lane halves of a wave
+}
+
+__device__ __forceinline__ float filter_tau_h1(float xn, float M, int D, float ex, float Em)
+{
+    // operand rounding: |sum x1 m1 - sum x m| <= |x1| |m1 - m| + |x1 - x| |m| <= (|x| + e_x) E_m + e_x M with the
+    // residual norms of THIS row and the worst component (k_corpus_resid_sp / k_kmeans_prepare_sp), never more
+    // than the a-priori 1.01 * 2^-10 |x| M
+    const float meas = (xn + ex) * Em + ex * M;
+    const float apriori = 1.01f * 9.765625e-4f * xn * M;
+    return filter_tau_sp(xn, M, D, 2) + 2.5f * 1.00001f * fminf(meas, apriori);
+}
+
+// A handful of left-over rows (fewer than SEGK_TAIL_QUEUE): not worth three more launches -- they
+// are appended to the ambiguity queue and take the full reference-arithmetic scan.
+#define SEGK_TAIL_QUEUE 2048
+static __global__ void k_score_queue_rows(ScoreArgs A)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= A.n) return;
+    const int32_t id = A.ids ? A.ids[r] : (int32_t)(A.row0 + r);
+    if (id < 0) return;
+    const int q = atomicAdd(A.cand.count, 1);
+    if (q < A.amb_cap) A.cand.queue[q] = id;
+}
+
+template <typename XT>
+__global__ void k_kmeans_exact_fill(segk_corpus c, segk_kmeans m, const int32_t *ids, int64_t row0, int64_t n,
+                                    segk_cand cand)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const int64_t id = ids ? (int64_t)ids[r] : row0 + r;
+    if (id < 0) return;
+    const double sv = cand.s[id];
+    if (sv == sv) return;
+    cand.s[id] = (double)neg_sqd_exact<XT>((const XT *)m.means + (int64_t)cand.k[id] * c.D,
+                                           (const XT *)c.X + id * c.ldx, c.D);
+}
+
+#define DISPATCH_XT(c, ...)                         \
+    do {                                            \
+        if ((c)->x_dtype == SEGK_F32) {             \
+            typedef float XT;                       \
+            __VA_ARGS__                             \
+        } else {                                    \
+            typedef double XT;                      \
+            __VA_ARGS__                             \
+        }                                           \
+    } while (0)
+
+static inline int check_corpus(const segk_corpus *c)
+{
+    SEGK_REQUIRE(c != nullptr, "corpus is NULL");
+    SEGK_REQUIRE(c->x_dtype == SEGK_F32 || c->x_dtype == SEGK_F64, "x_dtype");
+    SEGK_REQUIRE(c->D > 0 && c->n_emb > 0, "empty corpus");
+    SEGK_REQUIRE(c->ld32 % 4 == 0 && c->ld32 >= c->D, "ld32 must be D rounded up to a multiple of 4");
+    return SEGK_OK;
+}
+
+static inline bool segk_use_b3(const segk_corpus *c, const segk_kmeans *m)
+{
+    const char *e = getenv("SEGK_SCORE_B3");
+    if (e && atoi(e) == 0) return false;
+    return c->Xb3 && (c->sp_pieces == 2 || c->sp_pieces == 3) && m->tiles_b3 && c->x_dtype == SEGK_F32 && c->D >= 8 &&
+           c->D <= 128;
+}
+
+static inline int score_checks(const segk_corpus *c, const segk_kmeans *m, const int32_t *ids, int64_t row0, int64_t n,
+                        const segk_cand *cand)
+{
+    int rc = check_corpus(c);
+    if (rc) return rc;
+    SEGK_REQUIRE(m && m->tiles && cand && cand->k && cand->f && cand->s && cand->queue && cand->count && c->X32,
+                 "score operands");
+    SEGK_REQUIRE(ids != nullptr || (row0 >= 0 && row0 + n <= c->n_emb), "row range");
+    return SEGK_OK;
+}
+
+// ---- cross-unit entry points (host side; each lives in the unit named) --------------------------------
+// segk_prepare.hip
+int segk_kmeans_prepare_impl(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m, void *stream, bool mnorm_zeroed);
+// segk_score_f32.hip: the fp32-MFMA filter (float64 data, D outside 8..128, SEGK_SCORE_B3=0)
+int segk_dispatch_score_f32(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m, const ScoreArgs &A, hipStream_t st);
+// segk_score_sp.hip: the split-precision filter (pieces = 2 fp16x2, 3 bf16x3) and the pre-filter's second stage
+int segk_dispatch_score_sp(segk_ctx *ctx, const ScoreArgs &A, int ks, int pieces, hipStream_t st);
+int segk_launch_sp_second(const ScoreArgs &B, int ks, hipStream_t st);
+// segk_score_h1.hip: one-product pre-filter + exact pair stage + second stage
+int segk_dispatch_score_pre(segk_ctx *ctx, const ScoreArgs &A, int ks, hipStream_t st);
+// segk_exact.hip: full scan of the ambiguity queue
+int segk_resolve_on(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m, const int32_t *ids, int64_t row0, int64_t n,
+                    const segk_cand *cand, int32_t *status, void *stream);

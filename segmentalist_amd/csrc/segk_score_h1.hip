@@ -1,0 +1,489 @@
+// segk_score_h1.hip -- A1 one-product fp16 pre-filter, the exact stage of its decided rows (k_kmeans_exact_pair), launch plan
+// (one of the translation units of the k-means path; shared helpers: segk_kmeans_dev.h)
+#include "segk_kmeans_dev.h"
+
+// ======================================================================================
+// A1 pre-filter: ONE fp16 product.
+// The split-precision score kernel is power-bound (the same instruction stream on all-zero rows runs
+// 24 % faster, profiles/README.md r01_h): what shortens it is fewer matrix operations, not a better
+// schedule.  Most rows are decided by far less precision than fp16x2 carries: with only the leading
+// pieces, sum_d x1_d m1_d, both operands are rounded once to fp16 (unit roundoff 2^-11), so
+//     |sum x1 m1 - sum x m| <= (2^-10 + 2^-21) sum |x_d||m_d| + (flushed elements)
+//                           <= 1.01 * 2^-10 |x| M                               (Cauchy-Schwarz)
+// (elements below the fp16 normal range after the power-of-two scaling, max element in [2^12, 2^13),
+// are off by at most 2^-25 in the scaled domain: < 2^-33 |x| M for D <= 128, inside the 1.01).  A row
+// whose two largest values differ by more than tau_A = tau' + 2.5 * 1.01 * 2^-10 |x| M (tau' the
+// split-precision margin, which covers the fp32 accumulation and the exact stage's own rounding) has
+// the reference's argmax as its winner; on the bench corpus that is 94 % of the rows.  The others are
+// queued for k_kmeans_score_sp (all three products), whose own undecided rows take the full scan.
+//
+// One third of the matrix work makes the top-2 update the cost that matters, so it is done on PAIRS
+// of values: m1' = max3(m1, a, b), m2' = max(m2, med3(m1, a, b)), and the index kept is the pair's --
+// five vector operations per two values instead of eight.  Which of the pair won is settled by the
+// exact stage, which scores both members in reference arithmetic (a decisive winner beats its
+// partner there as well).  A wave owns NBLK blocks of 32 rows (tile fragments stay in registers
+// across the blocks; staging, barriers and fragment reads amortise over NBLK x 7 MFMAs), two
+// accumulators: block b's MFMAs run over the drain of block b - 1.
+// Reads the two-piece images (segk_internal.h): piece 0 of the rows, the piece-0 blocks and the
+// constants of the tile image -- each a 1 KiB LDS-DMA piece.
+// ======================================================================================
+template <int KS, int NBLK>
+__global__ __launch_bounds__(256, 2) void k_kmeans_score_h1(ScoreArgs A)
+{
+    static_assert(NBLK == 2 || NBLK == 4, "an even number of row blocks per wave (static accumulator parity)");
+    typedef _Float16 T;
+    typedef SegkPiece<2>::V8 V8;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int32_t *__restrict__ ids = A.ids;
+    const int64_t row0 = A.row0, n = A.n;
+    const float *__restrict__ tiles = A.tiles + 1024;
+    const int n_tiles = A.n_tiles, D = A.D;
+    constexpr int P = 2, KP = KS * 16;
+    constexpr int STRIDE = (KS * P * 256 + 32 + 1023) / 1024 * 1024;      // floats per tile image (global)
+    constexpr int TS = (KS + 1) * 256;                                    // floats per LDS buffer: KS blocks + constants
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int e_ab = ((const int *)A.X32)[1] + ((const int *)A.tiles)[0];
+    const float unscale = ldexpf(1.f, -e_ab);
+
+#ifdef SEGK_STAMP
+#define SEGK_STAMP_AT(i) do { if (A.stamp && tid == 0) A.stamp[(int64_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SEGK_STAMP_AT(i) do { } while (0)
+#endif
+    SEGK_STAMP_AT(0);
+    V8 xb[NBLK][KS];
+    int64_t r[NBLK];
+    int32_t rowid[NBLK];
+#pragma unroll
+    for (int b = 0; b < NBLK; b++) {
+        r[b] = ((int64_t)blockIdx.x * 4 + wave) * (32 * NBLK) + 32 * b + j;
+        rowid[b] = -1;
+        if (r[b] < n) rowid[b] = ids ? ids[r[b]] : (int32_t)(row0 + r[b]);
+        const T *xp = (const T *)((const unsigned char *)A.X32 + SEGK_SP_HEADER) + (int64_t)(rowid[b] >= 0 ? rowid[b] : 0) * (P * KP) + 8 * h;
+#pragma unroll
+        for (int s = 0; s < KS; s++) xb[b][s] = *reinterpret_cast<const V8 *>(xp + 16 * s);
+    }
+    float m1[NBLK], m2[NBLK];
+    int32_t ipr[NBLK], itile[NBLK];
+#pragma unroll
+    for (int b = 0; b < NBLK; b++) { m1[b] = NEG_INF_F; m2[b] = NEG_INF_F; ipr[b] = 0; itile[b] = 0; }
+
+    typedef __attribute__((address_space(3))) void *lptr_t;
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lptr_t)lds);
+    constexpr int NPASS = (KS + 1 + 3) / 4;
+    // piece q < KS: the piece-0 block of k-step q; piece KS: the constants.  Wave q % 4 copies it.
+    // (LDS-DMA from inline asm, one explicit wait per tile: see k_kmeans_score_sp)
+#define SEGK_STAGE(tt, buf)                                                                         \
+    do {                                                                                            \
+        _Pragma("unroll") for (int p = 0; p < NPASS; p++) {                                         \
+            const int q_ = p * 4 + wave;                                                            \
+            if (q_ <= KS) {                                                                         \
+                const float *src_ = tiles + (int64_t)(tt) * STRIDE + (q_ < KS ? q_ * P * 256 : KS * P * 256) + lane * 4; \
+                const unsigned dst_ = __builtin_amdgcn_readfirstlane(lds_base + ((buf) * TS + q_ * 256) * 4); \
+                unsigned keep_;                                                                     \
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"                 \
+                             "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"                  \
+                             : "=&s"(keep_)                                                         \
+                             : "v"(src_), "s"(dst_)                                                 \
+                             : "memory");                                                           \
+            }                                                                                       \
+        }                                                                                           \
+    } while (0)
+#define SEGK_TILE_SYNC()                                                      \
+    do {                                                                      \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");           \
+        __builtin_amdgcn_s_barrier();                                         \
+    } while (0)
+
+    SEGK_STAGE(0, 0);
+    SEGK_TILE_SYNC();
+    SEGK_STAMP_AT(1);
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int q = 0; q < 16; q++) { acc[0][q] = NEG_INF_F; acc[1][q] = NEG_INF_F; }
+
+    // values 2 pi, 2 pi + 1 of block O_'s accumulator: components c, c + 1 of this lane half
+#define SEGK_DRAIN2(O_, ACC, pi)                                                      \
+    do {                                                                              \
+        /* the first read of the MFMA results is a compiler-visible instruction: the hazard recogniser */ \
+        /* does not look inside inline asm, and these values can be a few cycles old (block b - 1)     */ \
+        const float tmp_ = __builtin_amdgcn_fmed3f(m1[O_], ACC[2 * (pi)], ACC[2 * (pi) + 1]);          \
+        float nm_;                                                                    \
+        asm volatile("v_max_f32 %1, %1, %3\n\t"                                       \
+                     "v_max3_f32 %0, %4, %5, %6\n\t"                                  \
+                     "v_cmp_nlt_f32 vcc, %4, %0\n\t"                                  \
+                     "v_cndmask_b32 %2, %7, %2, vcc"                                  \
+                     : "=&v"(nm_), "+v"(m2[O_]), "+v"(ipr[O_])                        \
+                     : "v"(tmp_), "v"(m1[O_]), "v"(ACC[2 * (pi)]), "v"(ACC[2 * (pi) + 1]), "n"((pi)) \
+                     : "vcc");                                                        \
+        m1[O_] = nm_;                                                                 \
+    } while (0)
+
+    constexpr int PPS = (8 + KS - 1) / KS;
+    // MFMAs of block N_ on the current tile over the drain of block O_'s values of tile dt_
+#define SEGK_UNIT(N_, O_, dt_)                                                                        \
+    do {                                                                                              \
+        {                                                                                             \
+            const float *cv = Tt + KS * 256 + 4 * h;                                                  \
+            _Pragma("unroll") for (int q = 0; q < 4; q++) {                                           \
+                float4 c4 = *reinterpret_cast<const float4 *>(cv + 8 * q);                            \
+                acc[(N_) & 1][4 * q + 0] = c4.x; acc[(N_) & 1][4 * q + 1] = c4.y;                     \
+                acc[(N_) & 1][4 * q + 2] = c4.z; acc[(N_) & 1][4 * q + 3] = c4.w;                     \
+            }                                                                                         \
+        }                                                                                             \
+        const float m1s = m1[O_];                                                                     \
+        _Pragma("unroll") for (int s = 0; s < KS; s++) {                                              \
+            acc[(N_) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s], xb[N_][s], acc[(N_) & 1], 0, 0, 0); \
+            _Pragma("unroll") for (int q = 0; q < PPS; q++)                                           \
+                if (s * PPS + q < 8) SEGK_DRAIN2(O_, acc[((N_) & 1) ^ 1], s * PPS + q);               \
+        }                                                                                             \
+        itile[O_] = (m1[O_] > m1s) ? (dt_) : itile[O_];                                               \
+    } while (0)
+
+    for (int t = 0; t < n_tiles; t++) {
+        if (t + 1 < n_tiles) SEGK_STAGE(t + 1, (t + 1) & 1);
+        const float *Tt = lds + (t & 1) * TS;
+        const T *Tb = (const T *)Tt;
+        V8 a[KS];
+#pragma unroll
+        for (int s = 0; s < KS; s++) a[s] = *reinterpret_cast<const V8 *>(Tb + (s * 64 + lane) * 8);
+        SEGK_UNIT(0, NBLK - 1, t - 1);
+        SEGK_UNIT(1, 0, t);
+        if constexpr (NBLK == 4) {
+            SEGK_UNIT(2, 1, t);
+            SEGK_UNIT(3, 2, t);
+        }
+        if (t == 15) SEGK_STAMP_AT(4);
+        SEGK_TILE_SYNC();
+        if (t == 15) SEGK_STAMP_AT(5);
+    }
+    SEGK_STAMP_AT(2);
+    {
+        const float m1s = m1[NBLK - 1];
+#pragma unroll
+        for (int pi = 0; pi < 8; pi++) SEGK_DRAIN2(NBLK - 1, acc[(NBLK - 1) & 1], pi);
+        itile[NBLK - 1] = (m1[NBLK - 1] > m1s) ? (n_tiles - 1) : itile[NBLK - 1];
+    }
+#undef SEGK_UNIT
+#undef SEGK_DRAIN2
+#undef SEGK_STAGE
+#undef SEGK_TILE_SYNC
+
+    const float M = (float)(sqrt(*A.mnorm2) * (1.0 + 1e-6)) + 1e-30f;
+    const float Em = ((const float *)A.tiles)[1];
+    bool undecided[NBLK];
+    int n_und = 0;
+#pragma unroll
+    for (int b = 0; b < NBLK; b++) {
+        // the winning pair: components c, c + 1 (accumulator elements 2 ipr, 2 ipr + 1 of tile itile)
+        const int32_t c0 = itile[b] * 32 + 4 * h + 2 * (ipr[b] & 1) + 8 * (ipr[b] >> 1);
+        const float o1 = __shfl_xor(m1[b], 32), o2 = __shfl_xor(m2[b], 32);
+        const int oc = __shfl_xor(c0, 32);
+        const float top1 = fmaxf(m1[b], o1) * unscale;                 // powers of two: exact
+        const float top2 = fmaxf(fminf(m1[b], o1), fmaxf(m2[b], o2)) * unscale;
+        // equal maxima on the two halves leave a zero margin: the row is queued whichever pair is named
+        const int cw = (o1 > m1[b]) ? oc : c0;
+        undecided[b] = false;
+        if (h == 0 && rowid[b] >= 0) {
+            const int32_t rid = rowid[b];
+            const float tau = filter_tau_h1(A.xnorm[rid], M, D, A.xerr[rid], Em);
+            if (top1 - top2 > tau) {
+                // decided up to the member of the pair: k_kmeans_exact_pair scores both in reference
+                // arithmetic (a decisive winner beats its partner there as well) and clears the mark
+                A.cand.k[rid] = cw | SEGK_PAIR_PENDING;
+                A.cand.f[2 * (int64_t)rid + 0] = top1;
+                A.cand.f[2 * (int64_t)rid + 1] = top2;
+            } else {
+                undecided[b] = true;
+            }
+        }
+        n_und += __popcll(__ballot(undecided[b]));
+    }
+    // ONE queue reservation per wave (a returning atomic is a round trip to L2; one per row block kept the
+    // wave waiting four times over)
+    if (n_und > 0) {                                                   // wave-uniform
+        int base = 0;
+        if (lane == 0) base = atomicAdd(A.pre_count, n_und);
+        base = __shfl(base, 0);
+#pragma unroll
+        for (int b = 0; b < NBLK; b++) {
+            const unsigned long long mask = __ballot(undecided[b]);
+            if (undecided[b]) {
+                const int q = base + __popcll(mask & ((1ull << lane) - 1ull));
+                if (q < A.pre_cap) A.pre_queue[q] = rowid[b];
+                else {                                                 // beyond the second stage's launch: full scan
+                    const int q2 = atomicAdd(A.cand.count, 1);
+                    if (q2 < A.amb_cap) A.cand.queue[q2] = rowid[b];
+                }
+            }
+            base += __popcll(mask);
+        }
+    }
+    SEGK_STAMP_AT(3);
+#undef SEGK_STAMP_AT
+}
+
+// Exact stage of the pre-filter's decided rows: cand.k = (c | SEGK_PAIR_PENDING) names the pair (c, c + 1);
+// both members are scored in the reference's float32 arithmetic (sp_exact_score_x) and the larger wins
+// (the lower index on a tie, as np.argmax).  A kernel of its own because inside the MFMA kernel these
+// reads -- 16 bytes per lane from 64 different rows per instruction, eight waves per CU, one row block
+// after the other -- took 60 % of a workgroup's lifetime (s_memtime stamps, profiles/README.md r01_h).
+// The arithmetic wants a lane to own whole strided accumulators of one (row, member), the memory system
+// wants whole lines: rows and pairs of means (a row is 4 D contiguous bytes, a pair 8 D) are read with
+// consecutive lanes on consecutive 16 bytes, written to LDS and scored from there.  One wave per
+// workgroup, 16 rows per step, private LDS (no barrier); the loads of step i + 1 are in flight while
+// step i is scored.  (Copying by LDS-DMA instead was measured at ~500 cycles per 1 KiB piece with 13
+// waves per CU -- the copy engine, not latency, set the pace: 324 us.)  Row stride KS*16 + 8 floats: the
+// float4 reads of 8 items x 2 lanes fall on distinct banks.
+#define SEGK_PAIR_ROWS 16
+template <int KS>
+__global__ __launch_bounds__(64) void k_kmeans_exact_pair(ScoreArgs A)
+{
+    constexpr int R = SEGK_PAIR_ROWS;
+    constexpr int C4 = KS * 4;                                     // 16-byte slots read per row (>= D / 4)
+    constexpr int LD = KS * 16 + 8;                                // floats per staged row
+    constexpr int RPI = 64 / C4;                                   // rows per load instruction (2 for KS 5..8)
+    constexpr int NLA = (R + RPI - 1) / RPI;                       // load instructions per array
+    extern __shared__ __attribute__((aligned(16))) float lds[];    // [3][R][LD]: x rows, member 0, member 1
+    const int lane = threadIdx.x, D = A.D, D4 = D >> 2;
+    const int64_t n_steps = (A.n + R - 1) / R;
+    const int sub = lane / C4, c4 = lane - sub * C4;               // this lane's row within an instruction, its slot
+
+    // Row ids and pair bases of a step live on lanes 0..R-1.  They are fetched ahead of use and nothing
+    // tests them in the iteration that issues the fetch (a test would wait for every older load as well):
+    //   rid2 (step i + 2): issued in iteration i;  k1 = cand.k[rid1] (step i + 1): issued in iteration i,
+    //   decoded in iteration i + 1 right before that step's loads.
+    auto fetch_rid = [&](int64_t step) -> int32_t {
+        const int64_t r = step * R + lane;
+        int32_t rid = -1;
+        if (step < n_steps && lane < R && r < A.n) rid = A.ids ? A.ids[r] : (int32_t)(A.row0 + r);
+        return rid;
+    };
+    auto fetch_k = [&](int32_t rid) -> int32_t { return rid >= 0 ? A.cand.k[rid] : 0; };
+    float4 v[3 * NLA];
+    // rows 2t, 2t + 1 (RPI = 2) of array arr per instruction: consecutive lanes on consecutive 16 bytes
+    uint64_t *rowp = reinterpret_cast<uint64_t *>(lds + 3 * R * LD);     // [3][R] row addresses of the step being loaded
+    auto issue_loads = [&](int32_t rid, int32_t c, int64_t step_) {
+        // 64-bit row addresses once per step, by the rows' own lanes, through LDS: the load instructions
+        // below cost a ds_read_b64 and an add each -- no multiply, no lane exchange.  Every load is
+        // unconditional (a branch around each of the 24 cost more than the loads): a row that is skipped
+        // reads its own float32 row and the first means (never used), a lane without a slot re-reads its
+        // neighbour's last 16 bytes (same cache line).
+        if (lane < R) {
+            const bool live = rid >= 0;
+            int64_t r_any = rid;
+            if (!live) {                                       // some valid row: this step's own when the rows are a range
+                r_any = A.ids ? 0 : A.row0 + step_ * R + lane;
+                if (r_any >= A.row0 + A.n || A.ids) r_any = A.ids ? 0 : A.row0;
+            }
+            const uint64_t xp = (uint64_t)(uintptr_t)(A.xrows32 + r_any * A.ld32);
+            const uint64_t mp0 = (uint64_t)(uintptr_t)(A.means32 + (int64_t)(live ? c : 0) * D);
+            rowp[lane] = xp;
+            rowp[R + lane] = mp0;
+            rowp[2 * R + lane] = (live && c + 1 < A.K_max) ? mp0 + (uint64_t)D * 4 : mp0;
+        }
+        const int sub_c = sub < RPI ? sub : RPI - 1;
+        const unsigned off = 16u * (unsigned)(c4 < D4 ? c4 : D4 - 1);
+        uint64_t base[3 * NLA];
+#pragma unroll
+        for (int arr = 0; arr < 3; arr++)
+#pragma unroll
+            for (int t = 0; t < NLA; t++)
+                base[arr * NLA + t] = rowp[arr * R + ((RPI * t + sub_c) & (R - 1))];
+#pragma unroll
+        for (int i = 0; i < 3 * NLA; i++) {
+            // an integer turned pointer is a FLAT pointer to the compiler (flat loads, and the staging array in
+            // scratch: 900 us); say that it is global memory
+            typedef float f32x4_t __attribute__((ext_vector_type(4)));
+            typedef const __attribute__((address_space(1))) f32x4_t *gptr_t;
+            const f32x4_t t_ = *reinterpret_cast<gptr_t>((uintptr_t)(base[i] + off));
+            v[i] = make_float4(t_.x, t_.y, t_.z, t_.w);
+        }
+    };
+    auto decode = [&](int32_t &rid, int32_t k) -> int32_t {       // pair base, or -1 (and rid = -1) when not pending
+        // (a valid mark only: non-negative, pair base inside the component range -- whatever else the caller's
+        // candidate buffer holds for a row the pre-filter did not decide is left alone)
+        if (rid >= 0 && k >= 0 && (k & SEGK_PAIR_PENDING) && (k & ~SEGK_PAIR_PENDING) < A.K_max) return k & ~SEGK_PAIR_PENDING;
+        rid = -1;
+        return -1;
+    };
+
+    int64_t step = blockIdx.x;
+    int32_t rid0 = fetch_rid(step);
+    int32_t c0 = decode(rid0, fetch_k(rid0));
+    issue_loads(rid0, c0, step);
+    int32_t rid1 = fetch_rid(step + gridDim.x);
+    int32_t k1 = fetch_k(rid1);
+    int32_t rid2 = fetch_rid(step + 2 * (int64_t)gridDim.x);
+#ifdef SEGK_STAMP
+#define SEGK_STAMP_P(i) do { if (A.stamp && lane == 0 && it_ == 3) A.stamp[65536 + (int64_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SEGK_STAMP_P(i) do { } while (0)
+#endif
+    int it_ = 0;
+    for (; step < n_steps; step += gridDim.x, it_++) {
+        SEGK_STAMP_P(0);
+#pragma unroll
+        for (int arr = 0; arr < 3; arr++)
+#pragma unroll
+            for (int t = 0; t < NLA; t++)
+                if (sub < RPI && RPI * t + sub < R)
+                    *reinterpret_cast<float4 *>(lds + (arr * R + RPI * t + sub) * LD + 4 * c4) = v[arr * NLA + t];
+        SEGK_STAMP_P(1);
+        const int32_t ridc = rid0, cc0 = c0;
+        const int32_t c1 = decode(rid1, k1);
+        issue_loads(rid1, c1, step + gridDim.x);                   // the next step's rows: in flight under this step's arithmetic
+        rid0 = rid1; c0 = c1;
+        rid1 = rid2;
+        k1 = fetch_k(rid1);
+        rid2 = fetch_rid(step + 3 * (int64_t)gridDim.x);
+        SEGK_STAMP_P(2);
+        // lanes 4 r + {0, 1}: member 0 of row r; lanes 4 r + {2, 3}: member 1 (LDS operations of one wave
+        // complete in order: the reads below see the writes above)
+        const int item = lane >> 1, h = lane & 1, row = item >> 1, mem = item & 1;
+        const float sc = sp_exact_score_x<KS, 1>(lds + ((1 + mem) * R + row) * LD, lds + row * LD, D, h);
+        const float so = __shfl_xor(sc, 2);
+        const int32_t rid = __shfl(ridc, row), c = __shfl(cc0, row);
+        if ((lane & 3) == 0 && rid >= 0) {
+            const bool second = c + 1 < A.K_max && so > sc;
+            A.cand.k[rid] = second ? c + 1 : c;
+            A.cand.s[rid] = (double)(second ? so : sc);
+        }
+        SEGK_STAMP_P(3);
+    }
+#undef SEGK_STAMP_P
+}
+
+// rows the pre-filter launch does not cover (fewer than SEGK_TAIL_QUEUE): straight to its second stage
+__global__ void k_pre_queue_rows(ScoreArgs A)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= A.n) return;
+    const int32_t id = A.ids ? A.ids[r] : (int32_t)(A.row0 + r);
+    if (id < 0) return;
+    const int q = atomicAdd(A.pre_count, 1);
+    if (q < A.pre_cap) A.pre_queue[q] = id;
+    else {
+        const int q2 = atomicAdd(A.cand.count, 1);
+        if (q2 < A.amb_cap) A.cand.queue[q2] = id;
+    }
+}
+
+// One-product pre-filter over all rows, then the split-precision kernel over the rows it queued.
+template <int KS>
+static int launch_score_pre(segk_ctx *ctx, ScoreArgs A, hipStream_t st)
+{
+    if (ctx->pre_cap < A.n) {                         // queue of the undecided rows, grown on demand
+        if (ctx->pre_queue) SEGK_CHECK_HIP(hipFree(ctx->pre_queue));
+        ctx->pre_queue = nullptr;
+        ctx->pre_cap = 0;
+        SEGK_CHECK_HIP(hipMalloc((void **)&ctx->pre_queue, sizeof(int32_t) * (size_t)(A.n + 16)));
+        ctx->pre_cap = A.n;
+        ctx->pre_zeroed = 0;                           // a new buffer: its counter has not been cleared
+    }
+    A.pre_queue = ctx->pre_queue + 16;
+    A.pre_count = ctx->pre_queue;
+    // the second stage is launched for every row (its row count is read on the device; the workgroups
+    // beyond it leave at once), so the queue cannot overflow whatever the data
+    const int64_t cap2 = A.n;
+    A.pre_cap = (int)cap2;
+#ifdef SEGK_STAMP
+    A.stamp = getenv("SEGK_STAMP_PTR") ? (unsigned long long *)strtoull(getenv("SEGK_STAMP_PTR"), nullptr, 0) : nullptr;
+#endif
+    if (ctx->pre_zeroed) ctx->pre_zeroed = 0;          // segk_kmeans_score cleared it together with the caller's queue length
+    else SEGK_CHECK_HIP(hipMemsetAsync(A.pre_count, 0, sizeof(int32_t), st));
+
+    constexpr size_t lds = 2 * (size_t)(KS + 1) * 256 * sizeof(float);
+    const int64_t slots = 2 * (int64_t)ctx->n_cu;      // two 4-wave workgroups per CU (launch bounds)
+    // whole rounds of 512-row workgroups (four row blocks per wave), the remainder in 256-row workgroups
+    const int64_t round4 = slots * 512;
+    int64_t n4 = (A.n / round4) * round4;
+    if (getenv("SEGK_PRE_NBLK") && atoi(getenv("SEGK_PRE_NBLK")) == 2) n4 = 0;      // development: 256-row workgroups only
+    const bool prof = ctx->prof_on != 0;
+    const int slot = ctx->prof_n % SEGK_PROF_SLOTS;
+    // the timed launch (segk_profile_*): the 512-row-workgroup launch when there is one, else the 256-row one
+    auto prof_end = [&](int64_t rows) -> int {
+        if (!prof) return SEGK_OK;
+        SEGK_CHECK_HIP(hipEventRecord(ctx->prof_ev[slot][1], st));
+        ctx->prof_rows[slot] = rows;
+        ctx->prof_kind = 1;
+        ctx->prof_n++;
+        return SEGK_OK;
+    };
+    // a short remainder is only queued: first, so that nothing small sits between the big launch and the
+    // kernels waiting for it
+    const int64_t rem = A.n - n4;
+    const bool rem_queued = rem > 0 && rem < SEGK_TAIL_QUEUE && n4 > 0;
+    ScoreArgs T = A;
+    T.n = rem;
+    T.row0 = A.row0 + n4;
+    T.ids = A.ids ? A.ids + n4 : nullptr;
+    if (rem_queued) hipLaunchKernelGGL(k_pre_queue_rows, dim3((unsigned)((rem + 255) / 256)), dim3(256), 0, st, T);
+    if (prof) SEGK_CHECK_HIP(hipEventRecord(ctx->prof_ev[slot][0], st));
+    if (n4 > 0) {
+        ScoreArgs M = A;
+        M.n = n4;
+        hipLaunchKernelGGL((k_kmeans_score_h1<KS, 4>), dim3((unsigned)(n4 / 512)), dim3(256), lds, st, M);
+        if (int rc = prof_end(n4)) return rc;
+    }
+    if (rem > 0 && !rem_queued) {
+        hipLaunchKernelGGL((k_kmeans_score_h1<KS, 2>), dim3((unsigned)((rem + 255) / 256)), dim3(256), lds, st, T);
+        if (n4 == 0)
+            if (int rc = prof_end(rem)) return rc;
+    }
+    // The decided rows' exact stage (this stream) and the undecided rows' second stage + full scan (second
+    // stream, segk_kmeans_score only) touch disjoint rows: side by side, the exact stage leaving LDS for one
+    // second-stage workgroup per CU.  Joined at the end of segk_kmeans_score.
+    const bool overlap = ctx->overlap_req != 0;
+    hipStream_t st2 = st;
+    if (overlap) {
+        if (!ctx->aux) {
+            SEGK_CHECK_HIP(hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking));
+            SEGK_CHECK_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+            SEGK_CHECK_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+        }
+        SEGK_CHECK_HIP(hipEventRecord(ctx->ev_fork, st));
+        SEGK_CHECK_HIP(hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
+        st2 = ctx->aux;
+        ctx->aux_busy = 1;
+    }
+    // exact stage of the decided rows
+    {
+        const size_t lds_p = 3 * (size_t)SEGK_PAIR_ROWS * (KS * 16 + 8) * sizeof(float) + 3 * SEGK_PAIR_ROWS * sizeof(uint64_t);
+        const int64_t steps = (A.n + SEGK_PAIR_ROWS - 1) / SEGK_PAIR_ROWS;
+        int64_t waves = (int64_t)ctx->n_cu * (int64_t)(((overlap ? 124 : 160) * 1024) / lds_p);
+        if (waves > 8 * (int64_t)ctx->n_cu) waves = 8 * (int64_t)ctx->n_cu;
+        if (waves > steps) waves = steps;
+        hipLaunchKernelGGL((k_kmeans_exact_pair<KS>), dim3((unsigned)waves), dim3(64), lds_p, st, A);
+    }
+    // second stage: all three products for the queued rows; the row count is read on the device
+    {
+        ScoreArgs B = A;
+        B.ids = A.pre_queue;
+        B.row0 = 0;
+        B.n = cap2;
+        B.n_dev = A.pre_count;
+        if (int rc = segk_launch_sp_second(B, KS, st2)) return rc;
+    }
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+int segk_dispatch_score_pre(segk_ctx *ctx, const ScoreArgs &A, int ks, hipStream_t st)
+{
+    switch (ks) {
+        case 1: return launch_score_pre<1>(ctx, A, st);
+        case 2: return launch_score_pre<2>(ctx, A, st);
+        case 3: return launch_score_pre<3>(ctx, A, st);
+        case 4: return launch_score_pre<4>(ctx, A, st);
+        case 5: return launch_score_pre<5>(ctx, A, st);
+        case 6: return launch_score_pre<6>(ctx, A, st);
+        case 7: return launch_score_pre<7>(ctx, A, st);
+        case 8: return launch_score_pre<8>(ctx, A, st);
+        default: break;
+    }
+    segk_set_error("pre-filter: D out of range");
+    return SEGK_ERR_UNSUPPORTED;
+}

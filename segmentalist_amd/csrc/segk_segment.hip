@@ -1,0 +1,722 @@
+// segk_segment.hip -- per-utterance kernels: A5 vector + A8 max-plus DP + tokens (band layout), function-level DPs (triangular layout)
+// (one of the translation units of the k-means path; shared helpers: segk_kmeans_dev.h)
+#include "segk_kmeans_dev.h"
+
+// Per-utterance kernel: A5 (vec from the candidates), A8 (max-plus DP), tokens.
+//   ONE WAVE per utterance, no workgroup barriers: lanes gather the band of candidate spans,
+//   lane 0 runs the DP on LDS, lanes write the results.
+//   band layout: entry (t, w), t = 1..N (span end), w = 0..W-1 (span length w+1, start
+//   s = t-1-w) at [(t-1)*W + w]; W = n_slices_max, or N when n_slices_max == 0.
+// ======================================================================================
+#define WAVE_SYNC()                                             \
+    do {                                                        \
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  \
+        __builtin_amdgcn_wave_barrier();                        \
+    } while (0)
+
+__global__ void k_kmeans_segment(segk_corpus c, segk_kmeans m, const int32_t *utts, int utt0, int n_utts,
+                                 int n_min, int n_max, double wip, segk_cand cand, uint8_t *boundaries,
+                                 int32_t *old_tok, int32_t *new_tok, int32_t *new_k, int32_t *n_old,
+                                 int32_t *n_new, int32_t *n_flag, double *out_total, int32_t *status, int band_cap,
+                                 int wave_bytes)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    (void)n_min;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int slot = blockIdx.x * (blockDim.x >> 6) + wv;
+    if (slot >= n_utts) return;
+    const int u = utts ? utts[slot] : utt0 + slot;
+    const int N = c.lengths[u];
+    const int W = (n_max > 0 && n_max < N) ? n_max : N;
+    const int nb = N * W;
+    const int64_t triMax = (int64_t)c.N_max * (c.N_max + 1) / 2;
+    const int32_t *vid = c.vec_ids + (int64_t)u * triMax;
+    const double *dur = c.durations + (int64_t)u * triMax;
+    uint8_t *gbnd = boundaries + (int64_t)u * c.N_max;
+
+    char *base = smem + (size_t)wv * wave_bytes;
+    double *bvec = (double *)base;                    // [band_cap]
+    double *gam = bvec + band_cap;                    // [N_max + 1]
+    int32_t *bk = (int32_t *)(gam + c.N_max + 1);     // [band_cap]
+    int32_t *bid = bk + band_cap;                     // [band_cap]
+    int32_t *l_old = bid + band_cap;                  // [N_max]
+    int32_t *l_new = l_old + c.N_max;                 // [N_max]
+    int32_t *l_newk = l_new + c.N_max;                // [N_max]
+    int32_t *l_cnt = l_newk + c.N_max;                // [2]
+    uint8_t *l_bnd = (uint8_t *)(l_cnt + 2);          // [N_max]
+
+    for (int i = lane; i < nb; i += 64) {
+        const int t = i / W + 1, w = i % W, s = t - 1 - w;
+        int id = -1;
+        double v = NEG_INF_D;
+        int k = -1;
+        if (s >= 0) {
+            const int j = t * (t - 1) / 2 + s;
+            id = vid[j];
+            if (id >= 0) {
+                k = cand.k[id];
+                const double dd = dur[j];
+                v = isnan(dd) ? NEG_INF_D : cand.s[id] * dd;      // :346-349
+            }
+        }
+        bid[i] = id;
+        bk[i] = k;
+        bvec[i] = v + wip;                                       // :351
+    }
+    for (int j = lane; j < N; j += 64) l_bnd[j] = gbnd[j];
+    WAVE_SYNC();
+    if (lane == 0) {
+#define V_(t, s) bvec[((t) - 1) * W + ((t) - 1 - (s))]
+#define ID_(t, s) (((t) - 1 - (s)) < W ? bid[((t) - 1) * W + ((t) - 1 - (s))] : vid[(t) * ((t) - 1) / 2 + (s)])
+        // ---- old tokens (utterances.py:159-174) before the boundaries are overwritten
+        int no = 0, jp = 0;
+        for (int j = 0; j < N; j++)
+            if (l_bnd[j]) {
+                int id = ID_(j + 1, jp);
+                if (id >= 0) l_old[no++] = id;
+                jp = j + 1;
+            }
+        // ---- A8 forward (kmeans_acoustic_wordseg.py:494-506)
+        gam[0] = 0.0;
+        for (int t = 1; t < N; t++) {
+            int lo = t - W < 0 ? 0 : t - W;
+            double best = NEG_INF_D;
+            for (int s = lo; s < t; s++) {
+                double v = V_(t, s) + gam[s];
+                if (v > best) best = v;
+            }
+            gam[t] = best;
+        }
+        for (int j = 0; j < N; j++) l_bnd[j] = 0;
+        l_bnd[N - 1] = 1;
+        // ---- A8 backward (:510-553)
+        int t = N;
+        double total = 0.0;
+        int lo = 0;
+        for (;;) {
+            lo = t - W < 0 ? 0 : t - W;
+            bool all_inf = true;
+            for (int s = lo; s < t; s++)
+                if (V_(t, s) + gam[s] != NEG_INF_D) { all_inf = false; break; }
+            if (all_inf) {
+                while (all_inf) {
+                    t = t - 1;
+                    if (t == 0) break;
+                    lo = t - W < 0 ? 0 : t - W;
+                    all_inf = true;
+                    for (int s = lo; s < t; s++)
+                        if (V_(t, s) + gam[s] != NEG_INF_D) { all_inf = false; break; }
+                }
+                l_bnd[(t - 1 + N) % N] = 1;
+            }
+            int k = 1;
+            if (t > 0) {
+                double best = NEG_INF_D;
+                bool first = true;
+                for (int s = t - 1; s >= lo; s--) {
+                    double v = V_(t, s) + gam[s];
+                    if (first || v > best) { best = v; k = t - s; first = false; }
+                }
+                total += V_(t, t - k);
+            } else {
+                total += V_(N, N - 1);      // python vec[-1]: the last span [N-1, N)
+            }
+            if (t - k - 1 < 0) break;
+            l_bnd[t - k - 1] = 1;
+            t = t - k;
+        }
+        // ---- new tokens + their best components (:312-313)
+        int nn = 0, bad = 0, nf = 0;
+        const int Kact = *m.K;
+        jp = 0;
+        for (int j = 0; j < N; j++)
+            if (l_bnd[j]) {
+                int tt = j + 1, w = tt - 1 - jp;
+                if (w >= W || bid[(tt - 1) * W + w] < 0) bad = 1;
+                else {
+                    l_new[nn] = bid[(tt - 1) * W + w];
+                    l_newk[nn] = bk[(tt - 1) * W + w];
+                    if (l_newk[nn] >= Kact) nf++;
+                    nn++;
+                }
+                jp = j + 1;
+            }
+        out_total[u] = total;
+        n_old[u] = no;
+        n_new[u] = nn;
+        if (n_flag) n_flag[u] = nf;
+        l_cnt[0] = no;
+        l_cnt[1] = nn;
+        if (bad) atomicOr(status, 1);
+#undef V_
+#undef ID_
+    }
+    WAVE_SYNC();
+    const int no = l_cnt[0], nn = l_cnt[1];
+    for (int j = lane; j < N; j += 64) gbnd[j] = l_bnd[j];
+    for (int j = lane; j < no; j += 64) old_tok[(int64_t)u * c.N_max + j] = l_old[j];
+    for (int j = lane; j < nn; j += 64) {
+        new_tok[(int64_t)u * c.N_max + j] = l_new[j];
+        new_k[(int64_t)u * c.N_max + j] = l_newk[j];
+    }
+}
+
+// Fast path of the per-utterance kernel for windows of at most 8 slices and utterances of at most 64
+// landmarks (the common configuration: n_slices_max = 6).  Same arithmetic and the same decisions as
+// k_kmeans_segment; what changes is how lane 0 gets at its operands.  The generic kernel walks the
+// DP as a chain of dependent LDS round trips (store gamma[t], load it back for t+1, byte loads of the
+// boundary flags with a branch on each); here the last eight gammas live in registers, the eight
+// candidates of a step are fetched together (predicated, fully unrolled), and the boundary vectors
+// are 64-bit masks.
+__global__ void k_kmeans_segment_w8(segk_corpus c, segk_kmeans m, const int32_t *utts, int utt0, int n_utts,
+                                    int n_max, double wip, segk_cand cand, uint8_t *boundaries, int32_t *old_tok,
+                                    int32_t *new_tok, int32_t *new_k, int32_t *n_old, int32_t *n_new, int32_t *n_flag,
+                                    double *out_total, int32_t *status, int band_cap, int wave_bytes)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int slot = blockIdx.x * (blockDim.x >> 6) + wv;
+    if (slot >= n_utts) return;
+    const int u = utts ? utts[slot] : utt0 + slot;
+    const int N = c.lengths[u];
+    const int W = (n_max > 0 && n_max < N) ? n_max : N;          // <= 8 (host checks n_max <= 8)
+    const int nb = N * W;
+    const int64_t triMax = (int64_t)c.N_max * (c.N_max + 1) / 2;
+    const int32_t *vid = c.vec_ids + (int64_t)u * triMax;
+    const double *dur = c.durations + (int64_t)u * triMax;
+    uint8_t *gbnd = boundaries + (int64_t)u * c.N_max;
+
+    char *base = smem + (size_t)wv * wave_bytes;
+    double *bvec = (double *)base;                    // [band_cap]
+    double *gam = bvec + band_cap;                    // [N_max + 1]
+    int32_t *bk = (int32_t *)(gam + c.N_max + 1);     // [band_cap]
+    int32_t *bid = bk + band_cap;                     // [band_cap]
+    int32_t *l_old = bid + band_cap;                  // [N_max]
+    int32_t *l_new = l_old + c.N_max;                 // [N_max]
+    int32_t *l_newk = l_new + c.N_max;                // [N_max]
+    int32_t *l_cnt = l_newk + c.N_max;                // [4]: n_old, n_new, new boundary mask (2 words)
+
+    for (int i = lane; i < nb; i += 64) {
+        const int t = i / W + 1, w = i % W, s = t - 1 - w;
+        int id = -1;
+        double v = NEG_INF_D;
+        int k = -1;
+        if (s >= 0) {
+            const int j = t * (t - 1) / 2 + s;
+            id = vid[j];
+            if (id >= 0) {
+                k = cand.k[id];
+                const double dd = dur[j];
+                v = isnan(dd) ? NEG_INF_D : cand.s[id] * dd;      // :346-349
+            }
+        }
+        bid[i] = id;
+        bk[i] = k;
+        bvec[i] = v + wip;                                       // :351
+    }
+    const unsigned long long oldb = __ballot(lane < N && gbnd[lane < N ? lane : 0] != 0);
+    WAVE_SYNC();
+    if (lane == 0) {
+#define V_(t, s) bvec[((t) - 1) * W + ((t) - 1 - (s))]
+#define ID_(t, s) (((t) - 1 - (s)) < W ? bid[((t) - 1) * W + ((t) - 1 - (s))] : vid[(t) * ((t) - 1) / 2 + (s)])
+        // ---- old tokens (utterances.py:159-174)
+        int no = 0, jp = 0;
+        for (unsigned long long mb = oldb; mb; mb &= mb - 1) {
+            const int j = __ffsll((long long)mb) - 1;
+            const int id = ID_(j + 1, jp);
+            if (id >= 0) l_old[no++] = id;
+            jp = j + 1;
+        }
+        // ---- A8 forward (kmeans_acoustic_wordseg.py:494-506): g[w] = gamma[t - 1 - w]
+        double g[8];
+#pragma unroll
+        for (int w = 0; w < 8; w++) g[w] = NEG_INF_D;
+        g[0] = 0.0;
+        gam[0] = 0.0;
+        for (int t = 1; t < N; t++) {
+            double v[8];
+#pragma unroll
+            for (int w = 0; w < 8; w++) {                  // unconditional loads from a clamped index, then the predicate
+                const bool ok = w < W && t - 1 - w >= 0;
+                v[w] = bvec[ok ? (t - 1) * W + w : 0];
+            }
+            double best = NEG_INF_D;
+#pragma unroll
+            for (int w = 7; w >= 0; w--) {                 // s ascending, as the reference's max() scans
+                const bool ok = w < W && t - 1 - w >= 0;
+                const double x = v[w] + g[w];
+                if (ok && x > best) best = x;
+            }
+            gam[t] = best;
+#pragma unroll
+            for (int w = 7; w > 0; w--) g[w] = g[w - 1];
+            g[0] = best;
+        }
+        unsigned long long newb = 1ull << (N - 1);
+        // candidates of span end tt: are they all -inf; and the reversed np.argmax (shortest span on ties)
+        auto eval = [&](int tt, int &kb) -> bool {
+            double x[8];
+#pragma unroll
+            for (int w = 0; w < 8; w++) {
+                const bool ok = w < W && tt - 1 - w >= 0;
+                x[w] = bvec[ok ? (tt - 1) * W + w : 0] + gam[ok ? tt - 1 - w : 0];
+            }
+            double best = NEG_INF_D;
+            bool first = true, ai = true;
+#pragma unroll
+            for (int w = 0; w < 8; w++) {                  // s = tt - 1 - w descending
+                const bool ok = w < W && tt - 1 - w >= 0;
+                if (ok) {
+                    if (x[w] != NEG_INF_D) ai = false;
+                    if (first || x[w] > best) { best = x[w]; kb = w + 1; first = false; }
+                }
+            }
+            return ai;
+        };
+        // ---- A8 backward (:510-553)
+        int t = N;
+        double total = 0.0;
+        for (;;) {
+            int kb = 1;
+            bool all_inf = eval(t, kb);
+            if (all_inf) {                                 // step back until some candidate is finite (:516-530)
+                while (all_inf) {
+                    t = t - 1;
+                    if (t == 0) break;
+                    all_inf = eval(t, kb);
+                }
+                newb |= 1ull << ((t - 1 + N) % N);
+            }
+            int k = 1;
+            if (t > 0) {
+                k = kb;
+                total += V_(t, t - k);
+            } else {
+                total += V_(N, N - 1);      // python vec[-1]: the last span [N-1, N)
+            }
+            if (t - k - 1 < 0) break;
+            newb |= 1ull << (t - k - 1);
+            t = t - k;
+        }
+        // ---- new tokens + their best components (:312-313)
+        int nn = 0, bad = 0, nf = 0;
+        const int Kact = *m.K;
+        jp = 0;
+        for (unsigned long long mb = newb; mb; mb &= mb - 1) {
+            const int j = __ffsll((long long)mb) - 1;
+            const int tt = j + 1, w = tt - 1 - jp;
+            if (w >= W || bid[(tt - 1) * W + w] < 0) bad = 1;
+            else {
+                l_new[nn] = bid[(tt - 1) * W + w];
+                l_newk[nn] = bk[(tt - 1) * W + w];
+                if (l_newk[nn] >= Kact) nf++;
+                nn++;
+            }
+            jp = j + 1;
+        }
+        out_total[u] = total;
+        n_old[u] = no;
+        n_new[u] = nn;
+        if (n_flag) n_flag[u] = nf;
+        l_cnt[0] = no;
+        l_cnt[1] = nn;
+        l_cnt[2] = (int32_t)(newb & 0xffffffffull);
+        l_cnt[3] = (int32_t)(newb >> 32);
+        if (bad) atomicOr(status, 1);
+#undef V_
+#undef ID_
+    }
+    WAVE_SYNC();
+    const int no = l_cnt[0], nn = l_cnt[1];
+    const unsigned long long newb = ((unsigned long long)(unsigned int)l_cnt[3] << 32) | (unsigned int)l_cnt[2];
+    if (lane < N) gbnd[lane] = (uint8_t)((newb >> lane) & 1ull);
+    for (int j = lane; j < no; j += 64) old_tok[(int64_t)u * c.N_max + j] = l_old[j];
+    for (int j = lane; j < nn; j += 64) {
+        new_tok[(int64_t)u * c.N_max + j] = l_new[j];
+        new_k[(int64_t)u * c.N_max + j] = l_newk[j];
+    }
+}
+
+// The same with TWO utterances per wave (utterances of at most 32 landmarks): a launch over 10 000 utterances
+// is two rounds of resident waves with one utterance each (7 waves per SIMD), and each round costs a wave's
+// whole latency chain (dependent gathers, the serial DP); with two per wave it is one round.
+__global__ void k_kmeans_segment_w8x2(segk_corpus c, segk_kmeans m, const int32_t *utts, int utt0, int n_utts,
+                                    int n_max, double wip, segk_cand cand, uint8_t *boundaries, int32_t *old_tok,
+                                    int32_t *new_tok, int32_t *new_k, int32_t *n_old, int32_t *n_new, int32_t *n_flag,
+                                    double *out_total, int32_t *status, int band_cap, int wave_bytes)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // two utterances per wave: lanes 0..31 and 32..63 (N <= 32), the two DPs on lanes 0 and 32 in lockstep
+    const int half = (threadIdx.x >> 5) & 1, lane = threadIdx.x & 31, wv = threadIdx.x >> 6;
+    const int slot = (blockIdx.x * (blockDim.x >> 6) + wv) * 2 + half;
+    const bool valid = slot < n_utts;
+    const int u = valid ? (utts ? utts[slot] : utt0 + slot) : (utts ? utts[0] : utt0);
+    const int N = valid ? c.lengths[u] : 0;
+    const int W = (n_max > 0 && n_max < N) ? n_max : N;          // <= 8 (host checks n_max <= 8)
+    const int nb = N * W;
+    const int64_t triMax = (int64_t)c.N_max * (c.N_max + 1) / 2;
+    const int32_t *vid = c.vec_ids + (int64_t)u * triMax;
+    const double *dur = c.durations + (int64_t)u * triMax;
+    uint8_t *gbnd = boundaries + (int64_t)u * c.N_max;
+
+    char *base = smem + (size_t)(wv * 2 + half) * wave_bytes;
+    double *bvec = (double *)base;                    // [band_cap]
+    double *gam = bvec + band_cap;                    // [N_max + 1]
+    int32_t *bk = (int32_t *)(gam + c.N_max + 1);     // [band_cap]
+    int32_t *bid = bk + band_cap;                     // [band_cap]
+    int32_t *l_old = bid + band_cap;                  // [N_max]
+    int32_t *l_new = l_old + c.N_max;                 // [N_max]
+    int32_t *l_newk = l_new + c.N_max;                // [N_max]
+    int32_t *l_cnt = l_newk + c.N_max;                // [4]: n_old, n_new, new boundary mask (2 words)
+
+    for (int i = lane; i < nb; i += 32) {
+        const int t = i / W + 1, w = i % W, s = t - 1 - w;
+        int id = -1;
+        double v = NEG_INF_D;
+        int k = -1;
+        if (s >= 0) {
+            const int j = t * (t - 1) / 2 + s;
+            id = vid[j];
+            if (id >= 0) {
+                k = cand.k[id];
+                const double dd = dur[j];
+                v = isnan(dd) ? NEG_INF_D : cand.s[id] * dd;      // :346-349
+            }
+        }
+        bid[i] = id;
+        bk[i] = k;
+        bvec[i] = v + wip;                                       // :351
+    }
+    const unsigned long long oldb = (__ballot(lane < N && gbnd[lane < N ? lane : 0] != 0) >> (32 * half)) & 0xffffffffull;
+    WAVE_SYNC();
+    if (lane == 0 && valid) {
+#define V_(t, s) bvec[((t) - 1) * W + ((t) - 1 - (s))]
+#define ID_(t, s) (((t) - 1 - (s)) < W ? bid[((t) - 1) * W + ((t) - 1 - (s))] : vid[(t) * ((t) - 1) / 2 + (s)])
+        // ---- old tokens (utterances.py:159-174)
+        int no = 0, jp = 0;
+        for (unsigned long long mb = oldb; mb; mb &= mb - 1) {
+            const int j = __ffsll((long long)mb) - 1;
+            const int id = ID_(j + 1, jp);
+            if (id >= 0) l_old[no++] = id;
+            jp = j + 1;
+        }
+        // ---- A8 forward (kmeans_acoustic_wordseg.py:494-506): g[w] = gamma[t - 1 - w]
+        double g[8];
+#pragma unroll
+        for (int w = 0; w < 8; w++) g[w] = NEG_INF_D;
+        g[0] = 0.0;
+        gam[0] = 0.0;
+        for (int t = 1; t < N; t++) {
+            double v[8];
+#pragma unroll
+            for (int w = 0; w < 8; w++) {                  // unconditional loads from a clamped index, then the predicate
+                const bool ok = w < W && t - 1 - w >= 0;
+                v[w] = bvec[ok ? (t - 1) * W + w : 0];
+            }
+            double best = NEG_INF_D;
+#pragma unroll
+            for (int w = 7; w >= 0; w--) {                 // s ascending, as the reference's max() scans
+                const bool ok = w < W && t - 1 - w >= 0;
+                const double x = v[w] + g[w];
+                if (ok && x > best) best = x;
+            }
+            gam[t] = best;
+#pragma unroll
+            for (int w = 7; w > 0; w--) g[w] = g[w - 1];
+            g[0] = best;
+        }
+        unsigned long long newb = 1ull << (N - 1);
+        // candidates of span end tt: are they all -inf; and the reversed np.argmax (shortest span on ties)
+        auto eval = [&](int tt, int &kb) -> bool {
+            double x[8];
+#pragma unroll
+            for (int w = 0; w < 8; w++) {
+                const bool ok = w < W && tt - 1 - w >= 0;
+                x[w] = bvec[ok ? (tt - 1) * W + w : 0] + gam[ok ? tt - 1 - w : 0];
+            }
+            double best = NEG_INF_D;
+            bool first = true, ai = true;
+#pragma unroll
+            for (int w = 0; w < 8; w++) {                  // s = tt - 1 - w descending
+                const bool ok = w < W && tt - 1 - w >= 0;
+                if (ok) {
+                    if (x[w] != NEG_INF_D) ai = false;
+                    if (first || x[w] > best) { best = x[w]; kb = w + 1; first = false; }
+                }
+            }
+            return ai;
+        };
+        // ---- A8 backward (:510-553)
+        int t = N;
+        double total = 0.0;
+        for (;;) {
+            int kb = 1;
+            bool all_inf = eval(t, kb);
+            if (all_inf) {                                 // step back until some candidate is finite (:516-530)
+                while (all_inf) {
+                    t = t - 1;
+                    if (t == 0) break;
+                    all_inf = eval(t, kb);
+                }
+                newb |= 1ull << ((t - 1 + N) % N);
+            }
+            int k = 1;
+            if (t > 0) {
+                k = kb;
+                total += V_(t, t - k);
+            } else {
+                total += V_(N, N - 1);      // python vec[-1]: the last span [N-1, N)
+            }
+            if (t - k - 1 < 0) break;
+            newb |= 1ull << (t - k - 1);
+            t = t - k;
+        }
+        // ---- new tokens + their best components (:312-313)
+        int nn = 0, bad = 0, nf = 0;
+        const int Kact = *m.K;
+        jp = 0;
+        for (unsigned long long mb = newb; mb; mb &= mb - 1) {
+            const int j = __ffsll((long long)mb) - 1;
+            const int tt = j + 1, w = tt - 1 - jp;
+            if (w >= W || bid[(tt - 1) * W + w] < 0) bad = 1;
+            else {
+                l_new[nn] = bid[(tt - 1) * W + w];
+                l_newk[nn] = bk[(tt - 1) * W + w];
+                if (l_newk[nn] >= Kact) nf++;
+                nn++;
+            }
+            jp = j + 1;
+        }
+        out_total[u] = total;
+        n_old[u] = no;
+        n_new[u] = nn;
+        if (n_flag) n_flag[u] = nf;
+        l_cnt[0] = no;
+        l_cnt[1] = nn;
+        l_cnt[2] = (int32_t)(newb & 0xffffffffull);
+        l_cnt[3] = (int32_t)(newb >> 32);
+        if (bad) atomicOr(status, 1);
+#undef V_
+#undef ID_
+    }
+    WAVE_SYNC();
+    if (!valid) return;
+    const int no = l_cnt[0], nn = l_cnt[1];
+    const unsigned long long newb = ((unsigned long long)(unsigned int)l_cnt[3] << 32) | (unsigned int)l_cnt[2];
+    if (lane < N) gbnd[lane] = (uint8_t)((newb >> lane) & 1ull);
+    for (int j = lane; j < no; j += 32) old_tok[(int64_t)u * c.N_max + j] = l_old[j];
+    for (int j = lane; j < nn; j += 32) {
+        new_tok[(int64_t)u * c.N_max + j] = l_new[j];
+        new_k[(int64_t)u * c.N_max + j] = l_newk[j];
+    }
+}
+
+// ======================================================================================
+// Function-level DPs on caller-supplied vectors (drop-in for the module functions
+// forward_backward_kmeans_viterbi / forward_backward / forward_backward_viterbi):
+// one thread per problem, triangular layout exactly as the reference receives it.
+//   kind 0: A8 max-plus (kmeans_acoustic_wordseg.py:449-555)
+//   kind 1: A7 viterbi  (unigram_acoustic_wordseg.py:759-864)
+//   kind 2: A6 forward filtering / backward sampling (:653-756), uniforms supplied
+// ======================================================================================
+__device__ double dev_logsumexp(const double *a, int n)      // _cython_utils.pyx:13-25
+{
+    double mx = a[0], s = 0.0;
+    for (int j = 1; j < n; j++)
+        if (a[j] > mx) mx = a[j];
+    for (int j = 0; j < n; j++) s += exp(a[j] - mx);
+    return log(s) + mx;
+}
+
+__global__ void k_dp_tri(int kind, const double *vecs, const int32_t *Ns, const int64_t *offs, int n_prob,
+                         int n_min, int n_max, double log_p_continue, double anneal_temp,
+                         const double *uniforms, int64_t u_stride, uint8_t *bounds, int64_t b_stride,
+                         double *totals, int32_t *n_draws, int32_t *status, double *work, int64_t w_stride)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_prob) return;
+    const int N = Ns[p];
+    const double *vec = vecs + offs[p];
+    const int64_t L = (int64_t)N * (N + 1) / 2;
+    uint8_t *bnd = bounds + p * b_stride;
+    double *a = work + p * w_stride;            // [N]
+    double *w = a + N;                          // [N+1]
+    double *pr = w + N + 1;                     // [N+1]
+    const double *us = uniforms ? uniforms + p * u_stride : nullptr;
+    for (int j = 0; j < N; j++) { a[j] = 1.0; bnd[j] = 0; }
+    bnd[N - 1] = 1;
+    a[0] = 0.0;
+    int64_t i = 0;
+    for (int t = 1; t < N; t++) {
+        int lo = (n_max == 0 || t - n_max < 0) ? 0 : t - n_max;
+        int n = t - lo;
+        bool all_inf = true;
+        double best = NEG_INF_D;
+        for (int s = lo; s < t; s++) {
+            double v = vec[i + s] + a[s];
+            w[s - lo] = v;
+            if (v != NEG_INF_D) all_inf = false;
+            if (v > best) best = v;
+        }
+        if (kind == 2) a[t] = all_inf ? NEG_INF_D : dev_logsumexp(w, n) + log_p_continue;
+        else a[t] = best;
+        i += t;
+    }
+    int t = N, nd = 0, lo = 0;
+    double total = 0.0;
+    for (;;) {
+        i = (int64_t)(t - 1) * t / 2;
+        lo = (n_max == 0 || t - n_max < 0) ? 0 : t - n_max;
+        bool all_inf = true;
+        for (int s = lo; s < t; s++)
+            if (vec[i + s] + a[s] != NEG_INF_D) { all_inf = false; break; }
+        if (all_inf) {
+            while (all_inf) {
+                t = t - 1;
+                if (t == 0) break;
+                i = (int64_t)(t - 1) * t / 2;
+                lo = (n_max == 0 || t - n_max < 0) ? 0 : t - n_max;
+                all_inf = true;
+                for (int s = lo; s < t; s++)
+                    if (vec[i + s] + a[s] != NEG_INF_D) { all_inf = false; break; }
+            }
+            bnd[(t - 1 + N) % N] = 1;
+        }
+        int k = 1;
+        int n = 1;
+        if (t > 0) {
+            n = t - lo;
+            for (int s = lo; s < t; s++) w[s - lo] = vec[i + s] + a[s];
+        } else {
+            w[0] = NEG_INF_D;
+        }
+        if (kind == 0) {
+            if (t > 0) {
+                double best = NEG_INF_D;
+                bool first = true;
+                for (int s = t - 1; s >= lo; s--) {
+                    double v = w[s - lo];
+                    if (first || v > best) { best = v; k = t - s; first = false; }
+                }
+            }
+        } else if (kind == 1) {
+            if (t > 0) {
+                double lse = dev_logsumexp(w, n);
+                double best = 0.0;
+                bool first = true;
+                for (int s = t - 1; s >= lo; s--) {
+                    double q = exp(w[s - lo] - lse);
+                    if (first || q > best) { best = q; k = t - s; first = false; }
+                }
+            }
+        } else {
+            double lse = dev_logsumexp(w, n);
+            if (anneal_temp != 1.0) {
+                for (int j = 0; j < n; j++) pr[j] = w[n - 1 - j] - lse;
+                double inv = 1. / anneal_temp;
+                for (int j = 0; j < n; j++) w[j] = inv * pr[j];
+                double lse2 = dev_logsumexp(w, n);
+                for (int j = 0; j < n; j++) pr[j] = exp(w[j] - lse2);
+            } else {
+                for (int j = 0; j < n; j++) pr[j] = exp(w[n - 1 - j] - lse);
+            }
+            double uu = us[nd];
+            nd++;
+            int kk = n - 1;
+            for (int j = 0; j < n; j++) {
+                uu = uu - pr[j];
+                if (uu < 0) { kk = j; break; }
+            }
+            k = kk + 1;
+        }
+        int64_t idx = i + t - k;
+        if (idx < 0) idx += L;
+        total += vec[idx];
+        if (t - k - 1 < 0) break;
+        bnd[t - k - 1] = 1;
+        t = t - k;
+    }
+    totals[p] = total;
+    if (n_draws) n_draws[p] = nd;
+    if (status) status[p] = (kind == 2 && total == NEG_INF_D) ? 1 : 0;
+}
+
+
+extern "C" {
+
+int32_t segk_kmeans_segment(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m, const int32_t *utts,
+                            int32_t utt0, int32_t n_utts, int32_t n_slices_min, int32_t n_slices_max, double wip,
+                            const segk_cand *cand, uint8_t *boundaries, int32_t *old_tok, int32_t *new_tok,
+                            int32_t *new_k, int32_t *n_old, int32_t *n_new, int32_t *n_flag, double *out_total,
+                            int32_t *status, void *stream)
+{
+    int rc = check_corpus(c);
+    if (rc) return rc;
+    SEGK_REQUIRE(n_slices_min == 0 || n_slices_min == 1,
+                 "n_slices_min must be 0 or 1 (>= 2 crashes in the reference, SURVEY 8(c))");
+    SEGK_REQUIRE(n_slices_max >= 0, "n_slices_max");
+    SEGK_REQUIRE(utts != nullptr || (utt0 >= 0 && utt0 + n_utts <= c->n_utt), "utterance range");
+    if (n_utts <= 0) return SEGK_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int W = (n_slices_max > 0 && n_slices_max < c->N_max) ? n_slices_max : c->N_max;
+    const int band_cap = c->N_max * W;
+    size_t wave_bytes = (size_t)(band_cap + c->N_max + 1) * sizeof(double)
+                        + (size_t)(2 * band_cap + 3 * c->N_max + 4) * sizeof(int32_t) + (size_t)c->N_max;
+    wave_bytes = (wave_bytes + 15) & ~(size_t)15;
+    int waves = 4;
+    while (waves > 1 && waves * wave_bytes > 64 * 1024) waves >>= 1;
+    size_t lds = waves * wave_bytes;
+    if (lds > 160 * 1024) {
+        segk_set_error("segk_kmeans_segment: band of %d x %d spans needs %zu B of LDS (> 160 KiB); "
+                       "set n_slices_max", c->N_max, W, lds);
+        return SEGK_ERR_UNSUPPORTED;
+    }
+    if (lds > 48 * 1024)
+        SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_kmeans_segment, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds));
+    const bool w8_ok = n_slices_max >= 1 && n_slices_max <= 8 && c->N_max <= 64 && !(getenv("SEGK_SEGMENT_GENERIC") && atoi(getenv("SEGK_SEGMENT_GENERIC")));
+    // two utterances per wave once one-per-wave would not fit the chip in a single round (8 waves per SIMD);
+    // SEGK_SEGMENT_X2=0 / 1: never / always
+    const char *x2e = getenv("SEGK_SEGMENT_X2");
+    const int n_cu_ = ctx ? ctx->n_cu : 256;
+    if (w8_ok && c->N_max <= 32 && 2 * waves * wave_bytes <= 48 * 1024 && (x2e ? atoi(x2e) != 0 : n_utts > 28 * n_cu_)) {
+        const int per_block = 2 * waves;
+        hipLaunchKernelGGL(k_kmeans_segment_w8x2, dim3((n_utts + per_block - 1) / per_block), dim3(64 * waves), 2 * lds, st, *c, *m, utts,
+                           utt0, n_utts, n_slices_max, wip, *cand, boundaries, old_tok, new_tok, new_k, n_old, n_new, n_flag,
+                           out_total, status, band_cap, (int)wave_bytes);
+        SEGK_LAUNCH_CHECK();
+        return SEGK_OK;
+    }
+    if (n_slices_max >= 1 && n_slices_max <= 8 && c->N_max <= 64 && !(getenv("SEGK_SEGMENT_GENERIC") && atoi(getenv("SEGK_SEGMENT_GENERIC")))) {
+        hipLaunchKernelGGL(k_kmeans_segment_w8, dim3((n_utts + waves - 1) / waves), dim3(64 * waves), lds, st, *c, *m, utts, utt0,
+                           n_utts, n_slices_max, wip, *cand, boundaries, old_tok, new_tok, new_k, n_old, n_new, n_flag,
+                           out_total, status, band_cap, (int)wave_bytes);
+        SEGK_LAUNCH_CHECK();
+        return SEGK_OK;
+    }
+    hipLaunchKernelGGL(k_kmeans_segment, dim3((n_utts + waves - 1) / waves), dim3(64 * waves), lds, st, *c, *m, utts,
+                       utt0, n_utts, n_slices_min, n_slices_max, wip, *cand, boundaries, old_tok, new_tok, new_k, n_old,
+                       n_new, n_flag, out_total, status, band_cap, (int)wave_bytes);
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+int32_t segk_dp_tri(segk_ctx *ctx, int32_t kind, const double *vecs, const int32_t *Ns, const int64_t *offs,
+                    int32_t n_prob, int32_t n_slices_min, int32_t n_slices_max, double log_p_continue,
+                    double anneal_temp, const double *uniforms, int64_t u_stride, uint8_t *bounds,
+                    int64_t b_stride, double *totals, int32_t *n_draws, int32_t *status, double *work,
+                    int64_t w_stride, void *stream)
+{
+    (void)ctx;
+    SEGK_REQUIRE(kind >= 0 && kind <= 2, "kind");
+    SEGK_REQUIRE(n_slices_min == 0 || n_slices_min == 1, "n_slices_min must be 0 or 1");
+    SEGK_REQUIRE(kind != 2 || uniforms != nullptr, "uniforms required for forward_backward");
+    if (n_prob <= 0) return SEGK_OK;
+    hipLaunchKernelGGL(k_dp_tri, dim3((n_prob + 63) / 64), dim3(64), 0, (hipStream_t)stream, kind, vecs, Ns, offs,
+                       n_prob, n_slices_min, n_slices_max, log_p_continue, anneal_temp, uniforms, u_stride, bounds,
+                       b_stride, totals, n_draws, status, work, w_stride);
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+}  // extern "C"

@@ -1,5 +1,5 @@
 """
-The error bound of the one-product fp16 pre-filter (segk_kmeans.hip, k_kmeans_score_h1), checked on a numpy
+The error bound of the one-product fp16 pre-filter (segk_score_h1.hip, k_kmeans_score_h1), checked on a numpy
 model of its operands: rows and means are scaled by a power of two so that the largest element lies in
 [2^12, 2^13) and rounded once to fp16 (np.float16: round-to-nearest-even with gradual underflow, as
 v_cvt_f16_f32); the products are exact in fp32 and their sum is taken here in float64, so what is measured
