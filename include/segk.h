@@ -173,6 +173,13 @@ int32_t segk_kmeans_resolve(segk_ctx *ctx, const segk_corpus *c, const segk_kmea
                             const int32_t *ids, int64_t row0, int64_t n, const segk_cand *cand,
                             int32_t *status, void *stream);
 
+/* Diagnostics of the most recent segk_kmeans_score on this context (no reference counterpart; the
+ * full-size parity tests use it to prove that every stage of the path was exercised): out[0] = rows
+ * the one-product pre-filter passed to its second stage (-1: the pre-filter has never run), out[1] =
+ * rows in the ambiguity queue `cand->queue` (full reference-arithmetic scan).  out [host] int32 [2];
+ * synchronises `stream`.                                                                          */
+int32_t segk_kmeans_stage_counts(segk_ctx *ctx, const segk_cand *cand, int32_t *out, void *stream);
+
 /* Gather of the A1 results for rows ids[0..n) (0..n-1 when NULL): out_max[r] (double, widened
  * from the dtype of X) and out_arg[r] = np.max / np.argmax of neg_sqrd_norm(ids[r])
  * (kmeans_components.py:228-232), from a `cand` filled by segk_kmeans_score. */

@@ -83,6 +83,7 @@ SIGNATURES = {
     "segk_kmeans_clear_queue": (_i32, [_P, _DP, _P]),
     "segk_kmeans_filter": (_i32, [_P, _CP, _KP, _P, _i64, _i64, _DP, _P]),
     "segk_kmeans_resolve": (_i32, [_P, _CP, _KP, _P, _i64, _i64, _DP, _P, _P]),
+    "segk_kmeans_stage_counts": (_i32, [_P, _DP, C.POINTER(_i32), _P]),
     "segk_kmeans_exact_max": (_i32, [_P, _CP, _KP, _P, _i64, _DP, _P, _P, _P]),
     "segk_kmeans_neg_sqrd_norm": (_i32, [_P, _CP, _KP, _i64, _P, _P]),
     "segk_kmeans_segment": (_i32, [_P, _CP, _KP, _P, _i32, _i32, _i32, _i32, _f64, _DP, _P, _P, _P, _P, _P, _P,

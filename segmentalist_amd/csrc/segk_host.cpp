@@ -21,6 +21,8 @@ const char *segk_last_error(void) { return g_err; }
 
 int32_t segk_abi_version(void) { return 1; }
 
+int32_t segk_destroy(segk_ctx *ctx);
+
 int32_t segk_create(int32_t device_id, segk_ctx **out_ctx)
 {
     if (!out_ctx) {
@@ -47,17 +49,32 @@ int32_t segk_create(int32_t device_id, segk_ctx **out_ctx)
         return SEGK_ERR_NO_DEVICE;
     }
     segk_ctx *c = (segk_ctx *)calloc(1, sizeof(segk_ctx));
+    if (!c) {
+        segk_set_error("segk_create: out of host memory");
+        return SEGK_ERR_ARG;
+    }
     c->device_id = device_id;
     c->n_cu = prop.multiProcessorCount;
     strncpy(c->arch, prop.gcnArchName, sizeof(c->arch) - 1);
-    int prev = 0;
-    SEGK_CHECK_HIP(hipGetDevice(&prev));
-    SEGK_CHECK_HIP(hipSetDevice(device_id));
-    SEGK_CHECK_HIP(hipMalloc((void **)&c->ws_k, sizeof(int32_t) * SEGK_WS_ENTRIES));
-    SEGK_CHECK_HIP(hipMalloc((void **)&c->ws_f, sizeof(float) * 2 * SEGK_WS_ENTRIES));
-    SEGK_CHECK_HIP(hipMalloc((void **)&c->ws_u64, sizeof(unsigned long long) * SEGK_WS_ENTRIES));
-    SEGK_CHECK_HIP(hipMemset(c->ws_u64, 0, sizeof(unsigned long long) * SEGK_WS_ENTRIES));
-    SEGK_CHECK_HIP(hipSetDevice(prev));
+    // one exit path: on any failure the partial allocations are released and the caller's current device
+    // is restored before the error is returned
+    int prev = -1;
+    hipError_t err = hipGetDevice(&prev);
+    const char *what = "hipGetDevice";
+    if (err == hipSuccess) { what = "hipSetDevice"; err = hipSetDevice(device_id); }
+    if (err == hipSuccess) { what = "hipMalloc(ws_k)"; err = hipMalloc((void **)&c->ws_k, sizeof(int32_t) * SEGK_WS_ENTRIES); }
+    if (err == hipSuccess) { what = "hipMalloc(ws_f)"; err = hipMalloc((void **)&c->ws_f, sizeof(float) * 2 * SEGK_WS_ENTRIES); }
+    if (err == hipSuccess) { what = "hipMalloc(ws_u64)"; err = hipMalloc((void **)&c->ws_u64, sizeof(unsigned long long) * SEGK_WS_ENTRIES); }
+    if (err == hipSuccess) { what = "hipMemset(ws_u64)"; err = hipMemset(c->ws_u64, 0, sizeof(unsigned long long) * SEGK_WS_ENTRIES); }
+    if (prev >= 0) {
+        const hipError_t back = hipSetDevice(prev);
+        if (err == hipSuccess && back != hipSuccess) { what = "hipSetDevice(previous)"; err = back; }
+    }
+    if (err != hipSuccess) {
+        segk_set_error("segk_create: %s -> %s", what, hipGetErrorString(err));
+        segk_destroy(c);
+        return SEGK_ERR_HIP;
+    }
     *out_ctx = c;
     return SEGK_OK;
 }
@@ -115,6 +132,20 @@ int32_t segk_profile_read(segk_ctx *ctx, float *ms_out, int64_t *rows_out, int32
 int32_t segk_profile_last_kind(segk_ctx *ctx)
 {
     return ctx ? ctx->prof_kind : -1;
+}
+
+// Queue lengths of the most recent segk_kmeans_score on this context: out[0] = rows the one-product
+// pre-filter passed to its second stage (-1 when the pre-filter has never run), out[1] = rows in the
+// caller's ambiguity queue (full scan).  Synchronises `stream`.  Diagnostics / tests.
+int32_t segk_kmeans_stage_counts(segk_ctx *ctx, const segk_cand *cand, int32_t *out, void *stream)
+{
+    SEGK_REQUIRE(ctx && cand && cand->count && out, "arguments");
+    hipStream_t st = (hipStream_t)stream;
+    out[0] = -1;
+    if (ctx->pre_queue) SEGK_CHECK_HIP(hipMemcpyAsync(&out[0], ctx->pre_queue, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    SEGK_CHECK_HIP(hipMemcpyAsync(&out[1], cand->count, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    SEGK_CHECK_HIP(hipStreamSynchronize(st));
+    return SEGK_OK;
 }
 
 // ----------------------------------------------------------------------------------------

@@ -66,8 +66,9 @@ int32_t segk_kmeans_filter(segk_ctx *ctx, const segk_corpus *c, const segk_kmean
 int32_t segk_kmeans_score(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m, const int32_t *ids,
                           int64_t row0, int64_t n, const segk_cand *cand, int32_t *status, void *stream)
 {
+    SEGK_REQUIRE(ctx, "ctx");
     int rc;
-    if (ctx && ctx->pre_queue && cand && cand->count) {
+    if (ctx->pre_queue && cand && cand->count) {
         // one tiny kernel instead of two 4-byte memsets: the caller's queue length and the pre-filter's
         hipLaunchKernelGGL(k_zero_two, dim3(1), dim3(1), 0, (hipStream_t)stream, cand->count, ctx->pre_queue);
         ctx->pre_zeroed = 1;
@@ -82,9 +83,10 @@ int32_t segk_kmeans_score(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans
     rc = segk_kmeans_filter(ctx, c, m, ids, row0, n, cand, stream);
     ctx->overlap_req = 0;
     ctx->pre_zeroed = 0;
-    if (rc) return rc;
-    if (!ctx->aux_busy) return segk_resolve_on(ctx, c, m, ids, row0, n, cand, status, stream);
-    rc = segk_resolve_on(ctx, c, m, ids, row0, n, cand, status, (void *)ctx->aux);
+    if (!ctx->aux_busy) return rc ? rc : segk_resolve_on(ctx, c, m, ids, row0, n, cand, status, stream);
+    // the filter forked the second stream: whatever happened after the fork, join it again, so that the
+    // next call never finds work of this one still running beside the caller's stream
+    if (!rc) rc = segk_resolve_on(ctx, c, m, ids, row0, n, cand, status, (void *)ctx->aux);
     ctx->aux_busy = 0;
     SEGK_CHECK_HIP(hipEventRecord(ctx->ev_join, ctx->aux));
     SEGK_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, ctx->ev_join, 0));

@@ -427,6 +427,9 @@ static inline int score_checks(const segk_corpus *c, const segk_kmeans *m, const
     SEGK_REQUIRE(m && m->tiles && cand && cand->k && cand->f && cand->s && cand->queue && cand->count && c->X32,
                  "score operands");
     SEGK_REQUIRE(ids != nullptr || (row0 >= 0 && row0 + n <= c->n_emb), "row range");
+    // the queues of undecided rows (cand->queue, the context's pre-filter queue) hold n_emb entries: a longer
+    // id list (repeated rows) could overflow them and leave rows with filter-stage values
+    SEGK_REQUIRE(n <= c->n_emb, "at most n_emb rows per score call (split longer id lists)");
     return SEGK_OK;
 }
 

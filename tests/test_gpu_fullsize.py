@@ -1,5 +1,6 @@
-"""FBGMM / bigram drivers at BASELINE sizes (config 2: 1 000 utterances, D = 39, K = 100; config-5
-shape cut to 2 000 utterances, D = 100, K = 1 000), where the oracle is too slow to replay: size-
+"""FBGMM / bigram drivers at BASELINE sizes (configs[1]: 1 000 utterances, D = 39, K = 100; configs[4]:
+10 000 utterances, D = 100, K = 1 000 -- the whole corpus on one GPU), where the oracle is too slow to
+replay a sweep: sampled span scores against the specification's log_marg_i on the same state, and size-
 independent properties -- conservation of tokens, statistics equal to a from-scratch recount,
 language-model tables equal to a recount of the transcripts, valid segmentations, determinism."""
 import random
@@ -92,7 +93,7 @@ def test_config2_serial_chain_properties(gpu, kind):
     assert n0 > 0
 
 
-@pytest.mark.parametrize("kind,n_utt,D,K", [("diag", 1000, 39, 100), ("bigram", 2000, 100, 1000)])
+@pytest.mark.parametrize("kind,n_utt,D,K", [("diag", 1000, 39, 100), ("bigram", 10000, 100, 1000)])
 def test_batch_sampler_properties_and_determinism(gpu, kind, n_utt, D, K):
     """Batch sampler at config-2 size and at config-5 shape: invariants after every sweep, the
     log-probability of the segmentation improves from the random start, two runs coincide."""
@@ -114,3 +115,40 @@ def test_batch_sampler_properties_and_determinism(gpu, kind, n_utt, D, K):
         finals.append((seg.utterances.boundaries.copy(), seg.acoustic_model.components.assignments.copy(), lps))
     assert np.array_equal(finals[0][0], finals[1][0]) and np.array_equal(finals[0][1], finals[1][1])
     assert finals[0][2] == finals[1][2]
+
+
+@pytest.mark.parametrize("prec,tol", [("f16", 1e-4), ("f64", 1e-9)])
+def test_config5_full_size_span_scores_against_the_specification(gpu, prec, tol):
+    """BASELINE configs[4] at its real size (BigramAcousticWordseg, 10 000 utterances, D = 100, K = 1 000; score
+    precision f16 is what `bench.py --workload bigram_c5` runs, f64 the default of the API).  After two sweeps the
+    specification object (oracle/np_fbgmm_batch.py) is built from the materialised state; the span scores the
+    next sweep's first Gibbs step computes for block 0 must equal the specification's log_marg_i
+    (bigram_acoustic_wordseg.py:314-329) under "everything but block 0" within `tol` RELATIVE to
+    max(|log_marg_i|, 1) -- the 1e-4 contract of the path for the matrix-core score, 1e-9 for the fp64 kernel."""
+    from oracle import np_fbgmm_batch as nb
+    seg = _build("bigram", 10000, 100, 1000, "batch", n_gibbs_blocks=8, n_stat_blocks=8, batch_seed=1, score_precision=prec)
+    for _ in range(2):
+        seg.batch_sweep_async()
+    gpu.cuda.synchronize()
+    seg._df.check_status()
+    seg.materialise()
+    spec = nb.FbgmmBatch(seg, n_gibbs_blocks=8, n_stat_blocks=8, seed=1)
+    d = spec.derive(*spec.stats_excluding(0))
+    uni, big = spec.uni.copy(), spec.big.copy()
+    for s_ in range(spec.S):
+        for i in range(*spec.ranges[s_][0]):
+            spec._lm_count(uni, big, spec.tr[i], -1)
+    seg.batch_sweep_async()
+    gpu.cuda.synchronize()
+    seg._df.check_status()
+    score = seg._df.score.cpu().numpy()
+    sw = seg._get_sweeper()
+    rs = np.random.RandomState(0)
+    rows = np.concatenate([rs.randint(sw.row_range_np[s_, 0, 0], sw.row_range_np[s_, 0, 1], size=150)
+                           for s_ in range(sw.S)])
+    worst = 0.0
+    for row in rows:
+        want = spec.log_marg(d, spec.X[row], uni, big)
+        worst = max(worst, abs(score[row] - want) / max(abs(want), 1.0))
+    print("configs[4] full size, %s span scores: worst error relative to max(|log_marg_i|, 1) = %.3g" % (prec, worst))
+    assert worst < tol, worst

@@ -1,0 +1,234 @@
+"""
+BASELINE.json configs[2] -- the headline -- at its REAL size (10 000 utterances x 20 landmarks,
+n_slices_max = 6 -> 1 050 000 candidate embeddings, D = 100, K = 1000, float32) on the path
+bench.py times: default environment, i.e. one-product fp16 pre-filter (k_kmeans_score_h1, 512-row
+workgroups + remainder) -> exact pair stage || second stage (k_kmeans_score_sp) -> full scan, on two
+streams.  Everything is compared with the CPU oracle (oracle/, test infrastructure):
+
+  (a) cand_k / cand_s of EVERY one of the 1.05 M rows == the C oracle's first-argmax / max of
+      neg_sqrd_norm (kmeans_components.py:225-232), bit for bit -- which covers every row that went
+      through the second stage and through the full scan; the stage counters prove both ran;
+  (b) all 10 000 boundary vectors == the C oracle's Viterbi (kmeans_acoustic_wordseg.py:449-555) fed
+      the device scores, and 500 utterances end to end (scores, DP, new tokens, their argmax
+      components) == oracle/np_oracle.py, the per-embedding numpy restatement of segment_i's front half
+      (kmeans_acoustic_wordseg.py:225-260);
+  (c) counts / mean_numerators / means after the sweep == a host recount of the device's token lists in
+      the specification's order (blocks of utterances, sequential inside a block, fixed binary tree:
+      oracle/np_oracle.py kmeans_batch_sweep), bit for bit.
+"""
+import random
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+N_UTT, N_LM, NMAX, D, K = 10000, 20, 6, 100, 1000
+N_BLOCKS = 8
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    assert torch.cuda.is_available(), "these tests need an MI355X"
+    torch.cuda.set_device(0)
+    from segmentalist_amd import _abi
+    _abi.ctx()
+    return torch
+
+
+def _oracle_max_argmax(means, X, ids, threads=12):
+    """C oracle over many rows; ctypes releases the GIL, so plain threads use the host cores."""
+    from oracle import c_oracle as co
+    chunks = np.array_split(np.asarray(ids, dtype=np.int64), max(1, threads * 4))
+    with ThreadPoolExecutor(threads) as ex:
+        res = list(ex.map(lambda ch: co.kmeans_max_argmax(means, X, ch), chunks))
+    return np.concatenate([r[0] for r in res]), np.concatenate([r[1] for r in res])
+
+
+@pytest.fixture(scope="module")
+def headline(gpu, monkeypatch_module):
+    """The headline segmenter after two batch sweeps (default environment)."""
+    from segmentalist_amd import kmeans_acoustic_wordseg as kaw
+    from segmentalist_amd.synth import make_corpus
+    for v in ("SEGK_SCORE_PRE", "SEGK_SCORE_B3", "SEGK_SCORE_OVERLAP", "SEGK_MARK_DUPS", "SEGK_PRE_NBLK"):
+        monkeypatch_module.delenv(v, raising=False)
+    corpus = make_corpus(N_UTT, D, K, seed=0, N=N_LM, n_slices_max=NMAX)
+    random.seed(0)
+    np.random.seed(0)
+    seg = kaw.SegmentalKMeansWordseg(K, *corpus, n_slices_max=NMAX, init_am_assignments="spread", sync="batch",
+                                     n_stat_blocks=N_BLOCKS)
+    for _ in range(2):
+        seg.batch_sweep_async()
+    gpu.cuda.synchronize()
+    seg._dk.check_status()
+    return seg, corpus
+
+
+@pytest.fixture(scope="module")
+def monkeypatch_module():
+    from _pytest.monkeypatch import MonkeyPatch
+    mp = MonkeyPatch()
+    yield mp
+    mp.undo()
+
+
+@pytest.fixture(scope="module")
+def scored(gpu, headline):
+    """Kernel-level score + segment of the whole corpus against the statistics after sweep 2 (into a copy
+    of the boundary buffer: the segmenter's own state is untouched)."""
+    import ctypes as C
+    from segmentalist_amd import _abi
+    seg, _ = headline
+    dk = seg._dk
+    L, ctx = _abi.lib(), _abi.ctx()
+    means = dk.means.cpu().numpy().copy()
+    K_now = int(dk.K.item())
+    _abi.check(L.segk_profile_enable(ctx, 1))
+    dk.score_rows(row0=0, n=dk.corpus.n_emb)
+    counts = (C.c_int32 * 2)()
+    _abi.check(L.segk_kmeans_stage_counts(ctx, C.byref(dk.cand), counts, _abi.stream()))
+    kind = int(L.segk_profile_last_kind(ctx))
+    _abi.check(L.segk_profile_enable(ctx, 0))
+    cand_k = dk.cand_k.cpu().numpy().copy()
+    cand_s = dk.cand_s.cpu().numpy().copy()
+    bounds = seg._dev_bounds.clone()
+    dk.segment(bounds, 0, NMAX, 0.0)
+    gpu.cuda.synchronize()
+    dk.check_status()
+    out = dict(means=means, K=K_now, kind=kind, n_second=int(counts[0]), n_scan=int(counts[1]), cand_k=cand_k,
+               cand_s=cand_s, bounds=bounds.cpu().numpy().astype(bool), new_tok=dk.new_tok.cpu().numpy().copy(),
+               new_k=dk.new_k.cpu().numpy().copy(), n_new=dk.n_new.cpu().numpy().copy(),
+               totals=dk.out_total.cpu().numpy().copy())
+    return out
+
+
+def test_a_every_row_matches_the_oracle_argmax_and_score(headline, scored):
+    seg, _ = headline
+    X = seg.acoustic_model.components.X
+    n_emb = X.shape[0]
+    assert n_emb == N_UTT * 105 and X.dtype == np.float32
+    # the path under test is the one bench.py times: pre-filter launched, second stage and full scan both fed
+    assert scored["kind"] == 1, "the one-product pre-filter was not the kernel launched (kind %d)" % scored["kind"]
+    assert 0 < scored["n_second"] < n_emb // 4, scored["n_second"]
+    assert 0 < scored["n_scan"] <= scored["n_second"], (scored["n_scan"], scored["n_second"])
+    want_s, want_k = _oracle_max_argmax(scored["means"], X, np.arange(n_emb))
+    bad_k = np.flatnonzero(scored["cand_k"] != want_k)
+    assert bad_k.size == 0, "argmax differs on %d rows, first %s" % (bad_k.size, bad_k[:8])
+    bad_s = np.flatnonzero(scored["cand_s"] != want_s)
+    assert bad_s.size == 0, "max differs on %d rows, first %s" % (bad_s.size, bad_s[:8])
+    # no pair mark left behind
+    assert (scored["cand_k"] >= 0).all() and (scored["cand_k"] < K).all()
+
+
+def test_b_all_boundaries_match_the_oracle_viterbi(headline, scored):
+    from oracle import c_oracle as co
+    seg, _ = headline
+    u = seg.utterances
+    vec_ids, durs = np.asarray(u.vec_ids), np.asarray(u.durations, dtype=np.float64)
+    s = scored["cand_s"]
+    tri = N_LM * (N_LM + 1) // 2
+    new_tok, n_new = scored["new_tok"], scored["n_new"]
+    for i in range(N_UTT):
+        vid = vec_ids[i, :tri]
+        # get_vec_embed_neg_len_sqrd_norms (kmeans_acoustic_wordseg.py:334-351): score * duration + wip
+        vec = np.where(vid >= 0, s[np.maximum(vid, 0)] * durs[i, :tri], -np.inf) + 0.0
+        tot, b, _ = co.fb_kmeans_viterbi(vec, N_LM, 0, NMAX)
+        assert np.array_equal(b, scored["bounds"][i, :N_LM]), i
+        assert tot == scored["totals"][i], i
+        # the new tokens are the embeddings of the chosen segments, in order
+        ends = np.flatnonzero(b) + 1
+        starts = np.concatenate([[0], ends[:-1]])
+        want = [int(vid[t * (t - 1) // 2 + st]) for st, t in zip(starts, ends)]
+        assert n_new[i] == len(want) and list(new_tok[i, :len(want)]) == want, i
+    # their components are the argmax of A1
+    rows = np.concatenate([new_tok[i, :n_new[i]] for i in range(N_UTT)])
+    ks = np.concatenate([scored["new_k"][i, :n_new[i]] for i in range(N_UTT)])
+    assert np.array_equal(ks, scored["cand_k"][rows])
+
+
+def test_b_500_utterances_end_to_end_against_np_oracle(headline, scored):
+    """The per-embedding numpy restatement scores, segments and assigns the first 500 utterances against the
+    same means: boundaries, new tokens and their raw argmax components must coincide."""
+    from oracle import np_oracle as no
+    seg, corpus = headline
+    n_sub = 500
+    keys = sorted(corpus[0])[:n_sub]
+    sub = tuple({k: d[k] for k in keys} for d in corpus)
+    random.seed(1)
+    np.random.seed(1)
+    ref = no.SegmentalKMeansWordseg(K, *sub, n_slices_max=NMAX, init_am_assignments="spread")
+    rc = ref.acoustic_model.components
+    # the first 500 utterances own the first 500 * 105 rows of the embedding matrix
+    assert np.array_equal(rc.X, seg.acoustic_model.components.X[:n_sub * 105])
+    rc.means = scored["means"].copy()
+    rc.K = scored["K"]
+    ru = ref.utterances
+    for i in range(n_sub):
+        N = ru.lengths[i]
+        tri = (N * N + N) // 2
+        vec = ref.get_vec_embed_neg_len_sqrd_norms(ru.vec_ids[i, :tri], ru.durations[i, :tri])
+        tot, bnd = no.forward_backward_kmeans_viterbi(vec, N, 0, NMAX, i)
+        assert np.array_equal(np.asarray(bnd, dtype=bool), scored["bounds"][i, :N]), i
+        assert tot == scored["totals"][i], i
+        ru.boundaries[i, :N] = bnd
+        new = ru.get_segmented_embeds_i(i)
+        nn = scored["n_new"][i]
+        assert list(scored["new_tok"][i, :nn]) == [int(e) for e in new], i
+        assert list(scored["new_k"][i, :nn]) == [int(k) for k in rc.get_max_assignments(new)], i
+
+
+def test_c_statistics_equal_a_host_recount_in_the_specified_order(gpu, headline, scored):
+    """Sweep 3 through the product path (score -> segment -> statistics, exactly what bench.py enqueues): the
+    boundaries are the ones checked above, and counts / mean_numerators / means equal the recount of the token
+    lists in the fixed order of the specification."""
+    from oracle import np_oracle as no
+    seg, _ = headline
+    dk = seg._dk
+    c = seg.acoustic_model.components
+    X = c.X
+    seg.batch_sweep_async()
+    gpu.cuda.synchronize()
+    dk.check_status()
+    assert np.array_equal(seg._dev_bounds.cpu().numpy().astype(bool), scored["bounds"])
+    new_tok, new_k, n_new = dk.new_tok.cpu().numpy(), dk.new_k.cpu().numpy(), dk.n_new.cpu().numpy()
+    assert np.array_equal(n_new, scored["n_new"]) and np.array_equal(new_tok, scored["new_tok"])
+    remap = dk.remap.cpu().numpy()
+    # final label = relabelling (clean_components' row moves) of the raw argmax after add_item's clamp, replayed in
+    # global token order: `if k > K: k = K; if k == K: K += 1` (kmeans_components.py:102-106)
+    raw = scored["new_k"]
+    K_cur = scored["K"]
+    n_clamped = 0
+    for i in range(N_UTT):
+        for t in range(n_new[i]):
+            k = int(raw[i, t])
+            if k > K_cur:
+                k = K_cur
+                n_clamped += 1
+            if k == K_cur:
+                K_cur += 1
+            assert new_k[i, t] == remap[k], (i, t)
+    K_after = int(dk.K.item())
+    assert K_after <= K_cur <= K
+    bb = no.block_bounds(N_UTT, N_BLOCKS)
+    part_sum, part_cnt = [], []
+    for b in range(N_BLOCKS):
+        toks = np.concatenate([new_tok[i, :n_new[i]] for i in range(bb[b], bb[b + 1])])
+        ks = np.concatenate([new_k[i, :n_new[i]] for i in range(bb[b], bb[b + 1])])
+        s = np.zeros((K, D), np.float64)
+        np.add.at(s, ks, X[toks].astype(np.float64))         # unbuffered: sequential in token order
+        part_sum.append(s)
+        part_cnt.append(np.bincount(ks, minlength=K).astype(np.int64))
+    want_sum, want_cnt = no.tree_sum(part_sum), no.tree_sum(part_cnt)
+    assert np.array_equal(c.counts, want_cnt)
+    assert (want_cnt[:K_after] > 0).all() and not want_cnt[K_after:].any()
+    assert np.array_equal(c.mean_numerators, want_sum)
+    want_means = (want_sum[:K_after] / want_cnt[:K_after, None]).astype(np.float32)
+    assert np.array_equal(c.means[:K_after], want_means)
+    assert np.array_equal(c.means[K_after:], c.random_means[K_after:])
+    # assignments materialised from the token lists
+    a = c.assignments
+    assert (a >= 0).sum() == n_new.sum()
+    rows = np.concatenate([new_tok[i, :n_new[i]] for i in range(N_UTT)])
+    assert np.array_equal(a[rows], np.concatenate([new_k[i, :n_new[i]] for i in range(N_UTT)]))
