@@ -55,6 +55,21 @@ int32_t segk_profile_read(segk_ctx *ctx, float *ms_out, int64_t *rows_out, int32
  * filter (fp16x2 / bf16x3), 1 the one-product fp16 pre-filter (k_kmeans_score_h1: rows above ~260 k,
  * D % 4 == 0), 4 the log-sum-exp kernels of the FBGMM batch sampler; -1 none recorded.               */
 int32_t segk_profile_last_kind(segk_ctx *ctx);
+/* Number of back-to-back launches of that kernel the most recent recorded interval spans (the one-product
+ * pre-filter runs as up to four launches of one round each, so that the exact stage of one chunk overlaps the
+ * pre-filter of the next); the recorded duration and row count cover all of them.                        */
+int32_t segk_profile_last_launches(segk_ctx *ctx);
+
+/* hipGraph capture of a launch sequence (no reference counterpart: the reference has no device).  Every
+ * kernel the library enqueues on `stream` between begin and end -- including the work segk_kmeans_score
+ * forks onto the context's second stream -- becomes one executable graph; segk_graph_launch replays it
+ * with a single host call.  Run the sequence once before capturing it (workspaces, streams, events and
+ * kernel attributes are created on first use, which a capture cannot contain); `stream` must not be the
+ * legacy default stream; pointers and scalar arguments are frozen into the graph.                    */
+int32_t segk_graph_begin(segk_ctx *ctx, void *stream);
+int32_t segk_graph_end(segk_ctx *ctx, void *stream, void **exec_out);
+int32_t segk_graph_launch(segk_ctx *ctx, void *exec, void *stream);
+int32_t segk_graph_destroy(segk_ctx *ctx, void *exec);
 
 /* -------------------------------------------------------------------------------------
  * Corpus (read-only during sampling): the device image of `Utterances` + the embedding
@@ -236,56 +251,53 @@ int32_t segk_kmeans_del_component(segk_ctx *ctx, const segk_corpus *c, segk_kmea
                                   int32_t *status, void *stream);
 
 /* A11 batch-synchronous update (DESIGN.md "batch mode"; spec: oracle/np_oracle.py
- * kmeans_batch_sweep).  Four stages so that a multi-GPU run can exchange the two small
- * intermediate buffers (flag_buf, partials) between them; `utt_lo..utt_hi` is the range of
- * utterances owned by this rank.  The sweep never touches `assignments` (all old items are
- * deleted, all new tokens added: the array is a pure function of the token lists) -- it is
- * materialised on demand by segk_kmeans_assignments_from_tokens.
- *  (1) segk_kmeans_batch_collect: exclusive prefix of n_new -> tok_off [dev] int32
- *      [utt_hi-utt_lo+1]; collect, in token order (utterance, segment), the new tokens whose
- *      argmax is an inactive row (k >= K): flag_buf [dev] int32 [1 + 2*cap] =
- *      {count, (slot, k) ...}.
- *  (2) segk_kmeans_batch_assign: replay the reference's `k > K -> K` clamp
- *      (kmeans_components.py:103-106) over the flagged tokens of ALL ranks in rank order
- *      (flag_all [dev] int32 [n_ranks, 1 + 2*cap]); patch the local new_k, set K; write the
- *      compact token list ctok_id / ctok_k [dev] int32 [>= local tokens] in token order.
- *  (3) segk_kmeans_batch_partials: per statistics block b (utterances
- *      [blk_lo[b], blk_lo[b+1])) sequential fp64 sums in token order:
- *      part_sum [dev] double [n_blocks_local, K_max, D], part_cnt [dev] int64 [.., K_max],
- *      part_tot [dev] double [n_blocks_local] (sum of out_total in utterance order).
- *  (4) segk_kmeans_batch_finalize: fixed balanced-tree combination of ALL blocks' partials
- *      (n_blocks_total <= 64; block b is read at base + (b / n_blocks_per_rank) * rank_stride
- *      + (b % n_blocks_per_rank) * block size, rank_stride in 8-byte words, so that the
- *      all-gathered per-rank buffers are consumed in place), means = numerators/counts,
- *      clean_components (:263-266) with a relabel table (remap_scratch [dev] int32 [K_max]),
- *      relabel of the local tokens' new_k, rebuild of the MFMA tiles.
- *      out_scalars [dev] double [4] = {sum of totals, K, n_tokens, 0}.
+ * kmeans_batch_sweep, rank split: oracle/np_dist.py).  No reference counterpart: the reference
+ * updates its statistics item by item (kmeans_components.py:93-166); the batch sweep rebuilds
+ * them once per sweep in a fixed order.  Two calls, so that a multi-GPU run can exchange ONE packed
+ * record per rank between them (an all-gather); `utt_lo..utt_hi` is the range of utterances owned
+ * by this rank.  The sweep never touches `assignments` (all old items are deleted, all new tokens
+ * added: the array is a pure function of the token lists) -- it is materialised on demand by
+ * segk_kmeans_assignments_from_tokens.
+ *
+ * Record of one rank, in 8-byte words (nbl = n_blocks_local, FW = (2 + 3*flag_cap + 1) / 2):
+ *   [part_sum nbl*K_max*D double][part_tot nbl double][part_cnt nbl*K_max int64][flags nbl*FW]
+ *   flags of a block, as int32: {count, 0, (slot = utt*N_max + t, k, embedding row) x flag_cap};
+ *   segk_kmeans_batch_record_words() returns its length.
+ *
+ *  (1) segk_kmeans_batch_partials: per statistics block b (utterances [blk_lo[b], blk_lo[b+1]),
+ *      blk_lo [dev] int32 [n_blocks_local + 1]) the sequential fp64 sum of its tokens per component, in
+ *      token order (utterance, segment), read from the slot arrays new_tok / new_k [dev] int32
+ *      [n_utt, N_max] as segk_kmeans_segment leaves them (unused slots: k = -1): a stable counting sort
+ *      of the block's tokens by component (sorted_scratch [dev] int32 [n_utt * N_max], koff_scratch
+ *      [dev] int32 [n_blocks_local * (K_max + 1)]), then one sequential sum per (block, component);
+ *      part_tot = sum of out_total in utterance order.  Tokens whose argmax is an inactive row (k >= K;
+ *      n_flag [dev] int32 [n_utt] counts them per utterance) are listed instead, in token order.
+ *      Writes out_scalars[3] = K (before the sweep) and zeroes m->mnorm_max for (2).
+ *  (2) segk_kmeans_batch_finalize: over the records of ALL ranks (records [dev], rank r at
+ *      records + r * rank_stride words; n_blocks_total <= 64 blocks, n_blocks_per_rank per record):
+ *      replay of the reference's `k > K -> K` clamp (kmeans_components.py:102-106) over the flagged
+ *      tokens in global token order, fixed balanced-tree combination of the blocks' partial sums
+ *      (components founded this sweep: sequential sums of their flagged tokens per block, same tree),
+ *      means = numerators / counts, clean_components (:263-266) as a relabel table (remap_scratch [dev]
+ *      int32 [K_max]), final labels of the local tokens' new_k, rebuild of the MFMA operand images
+ *      (as segk_kmeans_prepare + segk_kmeans_mark_duplicates).
+ *      out_scalars [dev] double [4] = {sum of totals, K, n_tokens, K before the sweep}.
  *  status bits: 1 new segment without embedding, 2 add_item on an assigned item
- *  (kmeans_components.py:101 assert), 4 flag buffer overflow.
+ *  (kmeans_components.py:101 assert), 4 more flagged tokens than flag_cap per block / 2048 per sweep.
  */
-int32_t segk_kmeans_batch_collect(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m,
-                                  int32_t utt_lo, int32_t utt_hi, const int32_t *new_k,
-                                  const int32_t *n_new, const int32_t *n_flag, int32_t *tok_off,
-                                  int32_t *flag_buf, int32_t cap, void *stream);
-int32_t segk_kmeans_batch_assign(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m,
-                                 int32_t utt_lo, int32_t utt_hi, const int32_t *flag_all,
-                                 int32_t n_ranks, int32_t my_rank, int32_t cap,
-                                 const int32_t *new_tok, int32_t *new_k, const int32_t *n_new,
-                                 const int32_t *tok_off, int32_t *ctok_id, int32_t *ctok_k,
-                                 int32_t *status, void *stream);
+int64_t segk_kmeans_batch_record_words(int32_t K_max, int32_t D, int32_t n_blocks_local, int32_t flag_cap);
 int32_t segk_kmeans_batch_partials(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m,
-                                   const int32_t *blk_lo, int32_t n_blocks_local, int32_t utt_lo,
-                                   const int32_t *tok_off, const int32_t *ctok_id,
-                                   const int32_t *ctok_k, const double *out_total,
-                                   double *part_sum, int64_t *part_cnt, double *part_tot,
-                                   void *stream);
+                                   const int32_t *blk_lo, int32_t n_blocks_local,
+                                   const int32_t *new_tok, const int32_t *new_k, const int32_t *n_flag,
+                                   const double *out_total, int32_t *sorted_scratch,
+                                   int32_t *koff_scratch, double *record, int32_t flag_cap,
+                                   double *out_scalars, void *stream);
 int32_t segk_kmeans_batch_finalize(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m,
-                                   int32_t utt_lo, int32_t utt_hi, const double *part_sum,
-                                   const int64_t *part_cnt, const double *part_tot,
+                                   int32_t utt_lo, int32_t utt_hi, const double *records,
                                    int32_t n_blocks_total, int32_t n_blocks_per_rank,
-                                   int64_t rank_stride, int32_t *new_k, const int32_t *n_new,
-                                   int32_t *remap_scratch, double *out_scalars, int32_t *status,
-                                   void *stream);
+                                   int64_t rank_stride, int32_t flag_cap, int32_t my_rank,
+                                   int32_t *new_k, int32_t *remap_scratch, double *out_scalars,
+                                   int32_t *status, void *stream);
 /* assignments[:] = -1, then assignments[new_tok] = new_k for the tokens of utterances
  * [utt_lo, utt_hi). */
 int32_t segk_kmeans_assignments_from_tokens(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m,

@@ -1,10 +1,15 @@
 """
 np_dist.py -- the batch-synchronous k-means sweep (np_oracle.kmeans_batch_sweep) split over
-ranks exactly as the product splits it: rank r owns a contiguous run of statistics blocks,
-exchanges (1) the flagged tokens and (2) the packed block partials with all-gathers, and every
-rank replays the clamp / combines the partials in the same fixed order.  TEST INFRASTRUCTURE:
-used by tests/test_dist_cpu.py under torch.distributed (gloo, world_size 2) to check that the
-protocol reproduces the single-process specification bit for bit.
+ranks exactly as the product splits it: rank r owns a contiguous run of statistics blocks and
+contributes ONE record to ONE all-gather per sweep -- per block the partial sums / counts of its
+tokens whose component is already active, the block's total, and the (normally empty) list of its
+tokens whose argmax is an inactive row, in token order.  Every rank then replays the
+`k > K -> K` clamp over the flagged tokens of all blocks in global token order, sums the new
+components' rows itself (the embedding matrix is replicated; a component founded this sweep
+consists of flagged tokens only, an older one of un-flagged tokens only) and combines all blocks
+in the same fixed tree.  TEST INFRASTRUCTURE: used by tests/test_dist_cpu.py under
+torch.distributed (gloo, world_size 2) to check that the protocol reproduces the single-process
+specification bit for bit.
 """
 import numpy as np
 
@@ -27,36 +32,45 @@ def kmeans_batch_sweep_rank(seg, n_blocks, rank, world, all_gather_object):
         u.boundaries[i, :N] = bnd
         new = u.get_segmented_embeds_i(i)
         toks[i] = (new, [int(k) for k in c.get_max_assignments(new)])
-    # ---- exchange 1: tokens whose argmax is an inactive row, in token order
-    K = c.K
-    flags = [(i, t, k) for i in range(lo, hi) for t, k in enumerate(toks[i][1]) if k >= K]
-    all_flags = all_gather_object(flags)
-    for r, fl in enumerate(all_flags):                      # rank order == utterance order
-        for (i, t, k) in fl:
-            if k > K:
-                k = K
-            if k == K:
-                K += 1
-            if r == rank:
-                toks[i][1][t] = k
-    c.K = K
-    # ---- local block partials, sequential in token order
-    parts = []
+    # ---- local block records: partials of the un-flagged tokens (sequential, token order) + flag lists
+    K0 = c.K
+    record = []
     for b in range(rank * nbl, (rank + 1) * nbl):
         s = np.zeros((c.K_max, c.D), np.float64)
         n = np.zeros(c.K_max, np.int64)
         tot = np.float64(0.)
+        flags = []
         for i in range(bb[b], bb[b + 1]):
-            for e, k in zip(*toks[i]):
-                s[k] += c.X[e]
-                n[k] += 1
+            for t, (e, k) in enumerate(zip(*toks[i])):
+                if k >= K0:
+                    flags.append((i, t, k, e))
+                else:
+                    s[k] += c.X[e]
+                    n[k] += 1
             tot += totals[i]
-        parts.append((s, n, tot))
-    # ---- exchange 2: all block partials; fixed tree on every rank
-    all_parts = [p for rp in all_gather_object(parts) for p in rp]
-    c.mean_numerators = no.tree_sum([p[0] for p in all_parts])
-    c.counts = no.tree_sum([p[1] for p in all_parts])
-    total = no.tree_sum([p[2] for p in all_parts])
+        record.append((s, n, tot, flags))
+    # ---- THE exchange; everything below is replicated arithmetic on identical inputs
+    blocks = [blk for rec in all_gather_object(record) for blk in rec]       # rank order == block order
+    K = K0
+    resolved = []                                     # (block, final label, embedding row) in global token order
+    for b, (_, _, _, flags) in enumerate(blocks):
+        for (i, t, k, e) in flags:
+            if k > K:
+                k = K
+            if k == K:
+                K += 1
+            resolved.append((b, k, e))
+            if lo <= i < hi:
+                toks[i][1][t] = k
+    c.K = K
+    part_sum = [blk[0].copy() for blk in blocks]
+    part_cnt = [blk[1].copy() for blk in blocks]
+    for (b, k, e) in resolved:                        # sequential per (block, new component), token order
+        part_sum[b][k] += c.X[e]
+        part_cnt[b][k] += 1
+    c.mean_numerators = no.tree_sum(part_sum)
+    c.counts = no.tree_sum(part_cnt)
+    total = no.tree_sum([blk[2] for blk in blocks])
     for k in range(c.K):
         if c.counts[k] != 0:
             c.means[k] = c.mean_numerators[k] / c.counts[k]

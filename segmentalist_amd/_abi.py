@@ -95,12 +95,10 @@ SIGNATURES = {
     "segk_kmeans_del_item": (_i32, [_P, _CP, _KP, _i64, _P, _P]),
     "segk_kmeans_clean_components": (_i32, [_P, _CP, _KP, _P, _P]),
     "segk_kmeans_del_component": (_i32, [_P, _CP, _KP, _i32, _P, _P]),
-    "segk_kmeans_batch_collect": (_i32, [_P, _CP, _KP, _i32, _i32, _P, _P, _P, _P, _P, _i32, _P]),
-    "segk_kmeans_batch_assign": (_i32, [_P, _CP, _KP, _i32, _i32, _P, _i32, _i32, _i32, _P, _P, _P, _P, _P, _P,
-                                        _P, _P]),
-    "segk_kmeans_batch_partials": (_i32, [_P, _CP, _KP, _P, _i32, _i32, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "segk_kmeans_batch_finalize": (_i32, [_P, _CP, _KP, _i32, _i32, _P, _P, _P, _i32, _i32, _i64, _P, _P, _P, _P,
-                                          _P, _P]),
+    "segk_kmeans_batch_record_words": (_i64, [_i32, _i32, _i32, _i32]),
+    "segk_kmeans_batch_partials": (_i32, [_P, _CP, _KP, _P, _i32, _P, _P, _P, _P, _P, _P, _P, _i32, _P, _P]),
+    "segk_kmeans_batch_finalize": (_i32, [_P, _CP, _KP, _i32, _i32, _P, _i32, _i32, _i64, _i32, _i32, _P, _P, _P, _P,
+                                          _P]),
     "segk_kmeans_assignments_from_tokens": (_i32, [_P, _CP, _KP, _i32, _i32, _P, _P, _P, _P]),
     "segk_kmeans_sum_neg_sqrd_norm": (_i32, [_P, _CP, _KP, _P, _P]),
     "segk_fbgmm_init_stats": (_i32, [_P, _CP, _FP, _P]),
@@ -127,9 +125,14 @@ SIGNATURES = {
     "segk_corpus_prepare_b3": (_i32, [_P, _CP, _P, _i32, _P]),
     "segk_corpus_b3_bytes": (_i64, [_i64, _i32]),
     "segk_kmeans_tiles_b3_floats": (_i64, [_i32, _i32]),
+    "segk_graph_begin": (_i32, [_P, _P]),
+    "segk_graph_end": (_i32, [_P, _P, C.POINTER(_P)]),
+    "segk_graph_launch": (_i32, [_P, _P, _P]),
+    "segk_graph_destroy": (_i32, [_P, _P]),
     "segk_profile_enable": (_i32, [_P, _i32]),
     "segk_profile_read": (_i32, [_P, _P, _P, _i32]),
     "segk_profile_last_kind": (_i32, [_P]),
+    "segk_profile_last_launches": (_i32, [_P]),
     "segk_logsumexp": (_f64, [_P, _i64]),
     "segk_draw": (_i32, [_P, _i64, _f64]),
     "segk_sum_doubles": (_f64, [_P, _i64]),

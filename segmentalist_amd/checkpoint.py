@@ -30,7 +30,7 @@ def state_dict(seg):
           "py_random": random.getstate(), "np_random": np.random.get_state()}
     if hasattr(seg, "_dk"):                              # SegmentalKMeansWordseg
         dk = seg._dk
-        dk.ensure_assignments(getattr(seg, "_batch_args", (None, None, None))[2])
+        dk.ensure_assignments()      # (multi-rank batch mode: a collective, like the boundaries above)
         for name in _KMEANS_FIELDS:
             sd["km_" + name] = _np(getattr(dk, name))
     else:                                                # Unigram / Bigram drivers
@@ -57,6 +57,7 @@ def load_state_dict(seg, sd):
         for name in _KMEANS_FIELDS:
             _put(getattr(dk, name), sd["km_" + name])
         dk.assign_stale = None
+        dk.bounds_stale = None
         dk.prepare()                                     # the MFMA operand image of the means
     else:
         df = seg._df

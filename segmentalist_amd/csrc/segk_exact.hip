@@ -100,6 +100,8 @@ __device__ __forceinline__ int segk_brute_split(int nq, int grid, int max_split)
 __global__ __launch_bounds__(256) void k_kmeans_brute_rows(segk_corpus c, segk_kmeans m, segk_cand cand, int cap, int32_t *n_brute,
                                                           int n_groups, int ksplit, unsigned long long *ws, int ws_cap)
 {
+    __builtin_amdgcn_s_setprio(3);            // tail of the score stage's critical branch, beside the exact pair kernel's waves
+
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, nt = blockDim.x, D = c.D;
     const int DP = (D + 3) & ~3;                             // row pitch: float4 reads of the staged rows

@@ -90,6 +90,10 @@ int32_t segk_destroy(segk_ctx *ctx)
         if (ctx->aux) (void)hipStreamDestroy(ctx->aux);
         if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
         if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+        if (ctx->aux2) (void)hipStreamDestroy(ctx->aux2);
+        if (ctx->ev_join2) (void)hipEventDestroy(ctx->ev_join2);
+        for (int i = 0; i < 8; i++)
+            if (ctx->ev_chunk[i]) (void)hipEventDestroy(ctx->ev_chunk[i]);
         for (int i = 0; i < SEGK_PROF_SLOTS; i++)
             for (int j = 0; j < 2; j++)
                 if (ctx->prof_ev[i][j]) (void)hipEventDestroy(ctx->prof_ev[i][j]);
@@ -134,6 +138,63 @@ int32_t segk_profile_last_kind(segk_ctx *ctx)
     return ctx ? ctx->prof_kind : -1;
 }
 
+int32_t segk_profile_last_launches(segk_ctx *ctx)
+{
+    return ctx && ctx->prof_launches > 0 ? ctx->prof_launches : 1;
+}
+
+// ----------------------------------------------------------------------------------------
+// hipGraph capture of a launch sequence (a whole batch sweep: ~12 kernels on two streams with their
+// fork / join events).  Everything the library enqueues between begin and end on `stream` -- and on the
+// context's second stream, which joins the capture through the fork event -- becomes one executable graph;
+// replaying it costs one host call instead of a dozen launches.  Lazy initialisation (workspace growth,
+// stream / event creation, function attributes) must have happened before: run the sequence once, then
+// capture the second run.  The stream must not be the legacy default stream.
+// ----------------------------------------------------------------------------------------
+int32_t segk_graph_begin(segk_ctx *ctx, void *stream)
+{
+    SEGK_REQUIRE(ctx && stream, "segk_graph_begin needs a context and a non-default stream");
+    SEGK_REQUIRE(!ctx->capturing, "a capture is already open on this context");
+    SEGK_REQUIRE(!ctx->prof_on, "segk_profile_enable(1) records events between launches: not inside a capture");
+    SEGK_CHECK_HIP(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeRelaxed));
+    ctx->capturing = 1;
+    return SEGK_OK;
+}
+
+int32_t segk_graph_end(segk_ctx *ctx, void *stream, void **exec_out)
+{
+    SEGK_REQUIRE(ctx && stream && exec_out, "arguments");
+    SEGK_REQUIRE(ctx->capturing, "no capture open");
+    ctx->capturing = 0;
+    *exec_out = nullptr;
+    hipGraph_t graph = nullptr;
+    SEGK_CHECK_HIP(hipStreamEndCapture((hipStream_t)stream, &graph));
+    hipGraphExec_t exec = nullptr;
+    const hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) {
+        segk_set_error("segk_graph_end: hipGraphInstantiate -> %s", hipGetErrorString(e));
+        return SEGK_ERR_HIP;
+    }
+    *exec_out = (void *)exec;
+    return SEGK_OK;
+}
+
+int32_t segk_graph_launch(segk_ctx *ctx, void *exec, void *stream)
+{
+    (void)ctx;
+    SEGK_REQUIRE(exec, "exec");
+    SEGK_CHECK_HIP(hipGraphLaunch((hipGraphExec_t)exec, (hipStream_t)stream));
+    return SEGK_OK;
+}
+
+int32_t segk_graph_destroy(segk_ctx *ctx, void *exec)
+{
+    (void)ctx;
+    if (exec) SEGK_CHECK_HIP(hipGraphExecDestroy((hipGraphExec_t)exec));
+    return SEGK_OK;
+}
+
 // Queue lengths of the most recent segk_kmeans_score on this context: out[0] = rows the one-product
 // pre-filter passed to its second stage (-1 when the pre-filter has never run), out[1] = rows in the
 // caller's ambiguity queue (full scan).  Synchronises `stream`.  Diagnostics / tests.
@@ -142,9 +203,14 @@ int32_t segk_kmeans_stage_counts(segk_ctx *ctx, const segk_cand *cand, int32_t *
     SEGK_REQUIRE(ctx && cand && cand->count && out, "arguments");
     hipStream_t st = (hipStream_t)stream;
     out[0] = -1;
-    if (ctx->pre_queue) SEGK_CHECK_HIP(hipMemcpyAsync(&out[0], ctx->pre_queue, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    int32_t hdr[16] = {0};                        // one counter per chunk of the pre-filter pipeline
+    if (ctx->pre_queue) SEGK_CHECK_HIP(hipMemcpyAsync(hdr, ctx->pre_queue, sizeof(hdr), hipMemcpyDeviceToHost, st));
     SEGK_CHECK_HIP(hipMemcpyAsync(&out[1], cand->count, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     SEGK_CHECK_HIP(hipStreamSynchronize(st));
+    if (ctx->pre_queue) {
+        out[0] = 0;
+        for (int i = 0; i < 16; i++) out[0] += hdr[i];
+    }
     return SEGK_OK;
 }
 

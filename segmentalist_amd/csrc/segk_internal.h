@@ -25,7 +25,12 @@ struct segk_ctx {
     // the exact stage of the decided rows (created on first use)
     hipStream_t aux;
     hipEvent_t ev_fork, ev_join;
+    // chunked pre-filter pipeline: the exact stage of chunk i runs on a third stream beside the pre-filter of chunk i + 1
+    hipStream_t aux2;
+    hipEvent_t ev_chunk[8], ev_join2;
+    int aux2_busy, prof_launches;
     int overlap_req, aux_busy, pre_zeroed;
+    int capturing;                // segk_graph_begin .. segk_graph_end
     // value hashes of the rows of the means most recently prepared (segk_kmeans_mark_duplicates)
     unsigned long long *row_hash;
     const void *row_hash_means;

@@ -4,8 +4,8 @@
 
 __global__ void k_zero_two(int32_t *a, int32_t *b)
 {
-    *a = 0;
-    *b = 0;
+    if (threadIdx.x == 0) *a = 0;
+    if (threadIdx.x < 16) b[threadIdx.x] = 0;        // the pre-filter's queue lengths, one per chunk
 }
 
 extern "C" {
@@ -70,7 +70,7 @@ int32_t segk_kmeans_score(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans
     int rc;
     if (ctx->pre_queue && cand && cand->count) {
         // one tiny kernel instead of two 4-byte memsets: the caller's queue length and the pre-filter's
-        hipLaunchKernelGGL(k_zero_two, dim3(1), dim3(1), 0, (hipStream_t)stream, cand->count, ctx->pre_queue);
+        hipLaunchKernelGGL(k_zero_two, dim3(1), dim3(64), 0, (hipStream_t)stream, cand->count, ctx->pre_queue);
         ctx->pre_zeroed = 1;
         rc = SEGK_OK;
     } else {
@@ -90,6 +90,11 @@ int32_t segk_kmeans_score(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans
     ctx->aux_busy = 0;
     SEGK_CHECK_HIP(hipEventRecord(ctx->ev_join, ctx->aux));
     SEGK_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, ctx->ev_join, 0));
+    if (ctx->aux2_busy) {                                  // the exact stages of the pre-filter's chunks
+        ctx->aux2_busy = 0;
+        SEGK_CHECK_HIP(hipEventRecord(ctx->ev_join2, ctx->aux2));
+        SEGK_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, ctx->ev_join2, 0));
+    }
     return rc;
 }
 

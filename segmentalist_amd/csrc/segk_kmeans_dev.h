@@ -433,6 +433,153 @@ static inline int score_checks(const segk_corpus *c, const segk_kmeans *m, const
     return SEGK_OK;
 }
 
+// ======================================================================================
+// means -> fp32 MFMA operand image of ONE tile of 32 components (layout: segk_internal.h): called by a whole
+// workgroup of 256 threads (k_kmeans_prepare, and the batch sweep's finalize kernel for the rows it has just
+// written).  mnorm2_bits: running max_k |m_k|^2 (atomicMax on the bit pattern of non-negative doubles).
+// ======================================================================================
+template <typename XT>
+__device__ __forceinline__ void dev_prepare_tile(const XT *means, int K_max, int D, float *tiles, unsigned long long *mnorm2_bits,
+                                                 unsigned int *zero_slot, unsigned long long *row_hash, const int tile)
+{
+    if (zero_slot && tile == 0 && threadIdx.x == 0) *zero_slot = 0u;     // E_m of the fp16 tile image: k_kmeans_prepare_sp, next on the stream
+    const int G = segk_gmax(D);          // bucket extent; dims >= D are zero filled
+    const int stride = segk_tile_stride(D);
+    float *T = tiles + (int64_t)tile * stride;
+    __shared__ double nrm[32];
+    // |m|^2 of the tile's 32 components: 8 lanes per component, fp64
+    {
+        const int ci = threadIdx.x >> 3, sub = threadIdx.x & 7;      // 256 threads = 32 x 8
+        const int comp = tile * 32 + ci;
+        double s = 0.0;
+        unsigned long long hh = 0ull;
+        if (comp < K_max)
+            for (int d = sub; d < D; d += 8) {
+                double v = (double)means[(int64_t)comp * D + d];
+                s += v * v;
+                hh += segk_elem_hash(v, d);
+            }
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        s += __shfl_xor(s, 4);
+        hh += __shfl_xor(hh, 1);
+        hh += __shfl_xor(hh, 2);
+        hh += __shfl_xor(hh, 4);
+        if (sub == 0) {
+            nrm[ci] = s;
+            if (comp < K_max) atomicMax(mnorm2_bits, (unsigned long long)__double_as_longlong(s));
+            if (row_hash && comp < K_max) row_hash[comp] = hh | 1ull;      // never 0: the empty key of the hash table
+        }
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < stride; idx += blockDim.x) {
+        float v = 0.f;
+        if (idx < G * 128) {
+            int g = idx >> 7, rem = idx & 127, lane = rem >> 1, s = rem & 1;
+            int comp = tile * 32 + (lane & 31);
+            int d = 4 * g + 2 * (lane >> 5) + s;
+            if (comp < K_max && d < D) v = (float)means[(int64_t)comp * D + d];
+        } else if (idx < G * 128 + 32) {
+            int i = idx - G * 128;
+            int comp = tile * 32 + i;
+            v = (comp < K_max) ? (float)(-0.5 * nrm[i]) : -3.0e38f;
+        }
+        T[idx] = v;
+    }
+}
+
+// tiles image: [header 1024 floats: int32 exponent b at [0]] then per tile [s][p][lane][8] pieces + 32 constants
+// consts == NULL: the k-means constants -|m|^2/2; otherwise consts[k] (< -1e37: component absent) -- the
+// log-sum-exp use of the kernel (segk_fbbatch.hip), whose rows are not means.
+template <int P>
+__device__ __forceinline__ void dev_prepare_sp_tile(const float *means, int K_max, int D, float *tiles, const double *mnorm2,
+                                                    const unsigned char *ximg, const double *consts, const int tile)
+{
+    typedef typename SegkPiece<P>::T T;
+    const int KS = segk_b3_kp(D) / 16;
+    const int stride = segk_sp_tile_stride(D, P);
+    // max |m_d| <= sqrt(max |m|^2): every block derives the same exponent
+    const int eb = P == 2 ? sp_exponent((float)(sqrt(*mnorm2) * (1.0 + 1e-6))) : 0;
+    const int ea = ((const int *)ximg)[1];
+    if (tile == 0 && threadIdx.x == 0) ((int *)tiles)[0] = eb;
+    float *Tt = tiles + 1024 + (int64_t)tile * stride;
+    T *Tb = (T *)Tt;
+    __shared__ double nrm[32];
+    {
+        const int ci = threadIdx.x >> 3, sub = threadIdx.x & 7;      // 256 threads = 32 x 8
+        const int comp = tile * 32 + ci;
+        double s = 0.0, rs = 0.0;
+        if (comp < K_max)
+            for (int d = sub; d < D; d += 8) {
+                const float mv = means[(int64_t)comp * D + d];
+                double v = (double)mv;
+                s += v * v;
+                if (P == 2) rs += sp_resid2(ldexpf(mv, eb));
+            }
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        s += __shfl_xor(s, 4);
+        if (sub == 0) nrm[ci] = s;
+        if (P == 2) {                     // E_m = max_k |m_k - m1_k|: tiles header [1], zeroed by k_kmeans_prepare just before
+            rs += __shfl_xor(rs, 1);
+            rs += __shfl_xor(rs, 2);
+            rs += __shfl_xor(rs, 4);
+            const float em = (float)(ldexp(sqrt(rs), -eb) * (1.0 + 1e-6));
+            if (sub == 0 && comp < K_max) atomicMax((unsigned int *)tiles + 1, __float_as_uint(em));
+        }
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < KS * 64 * 8; idx += blockDim.x) {
+        const int sidx = idx >> 9, lane = (idx >> 3) & 63, i = idx & 7;
+        const int comp = tile * 32 + (lane & 31);
+        const int d = segk_b3_dim(16 * sidx + 8 * (lane >> 5) + i);
+        const float v = (comp < K_max && d < D) ? ldexpf(means[(int64_t)comp * D + d], eb) : 0.f;
+        T pc[P];
+        split_sp<P>(v, pc);
+#pragma unroll
+        for (int q = 0; q < P; q++) Tb[((sidx * P + q) * 64 + lane) * 8 + i] = pc[q];
+    }
+    for (int idx = threadIdx.x; idx < stride - KS * P * 256; idx += blockDim.x) {
+        float v = 0.f;
+        if (idx < 32) {
+            const int comp = tile * 32 + idx;
+            // the accumulators live in the scaled domain 2^(a+b) f
+            if (consts) v = (comp < K_max && consts[comp] > -1e37) ? (float)ldexp(consts[comp], ea + eb) : -3.0e38f;
+            else v = (comp < K_max) ? (float)ldexp(-0.5 * nrm[idx], ea + eb) : -3.0e38f;
+        }
+        Tt[KS * P * 256 + idx] = v;
+    }
+}
+
+// ======================================================================================
+// Exact duplicates among the rows of `means` (see k_kmeans_mark_dups in segk_prepare.hip): pieces shared with
+// the batch sweep's post kernel, which marks the duplicates of ONE tile per workgroup.
+//   dev_dup_table: open-addressing table in LDS (SEGK_DUP_TB slots): key = row hash, value = the lowest row
+//                  index with that hash; all threads of the workgroup, K_max <= SEGK_DUP_TB / 2.
+//   dev_dup_first: the first row whose hash equals row k's (k itself when there is no earlier one).
+// ======================================================================================
+#define SEGK_DUP_TB 4096
+__device__ __forceinline__ void dev_dup_table(unsigned long long *keys, int32_t *first, const unsigned long long *row_hash, int K_max)
+{
+    const int tid = threadIdx.x;
+    for (int i = tid; i < SEGK_DUP_TB; i += blockDim.x) { keys[i] = 0ull; first[i] = 0x7fffffff; }
+    __syncthreads();
+    for (int k = tid; k < K_max; k += blockDim.x) {
+        const unsigned long long h = row_hash[k];
+        for (unsigned slot = (unsigned)(h >> 20) & (SEGK_DUP_TB - 1);; slot = (slot + 1) & (SEGK_DUP_TB - 1)) {
+            const unsigned long long prev = atomicCAS(&keys[slot], 0ull, h);
+            if (prev == 0ull || prev == h) { atomicMin(&first[slot], k); break; }
+        }
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ int dev_dup_first(const unsigned long long *keys, const int32_t *first, unsigned long long h)
+{
+    unsigned slot = (unsigned)(h >> 20) & (SEGK_DUP_TB - 1);
+    while (keys[slot] != h) slot = (slot + 1) & (SEGK_DUP_TB - 1);
+    return first[slot];
+}
+
 // ---- cross-unit entry points (host side; each lives in the unit named) --------------------------------
 // segk_prepare.hip
 int segk_kmeans_prepare_impl(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m, void *stream, bool mnorm_zeroed);

@@ -33,51 +33,7 @@ template <typename XT>
 __global__ void k_kmeans_prepare(const XT *means, int K_max, int D, float *tiles,
                                  unsigned long long *mnorm2_bits, unsigned int *zero_slot, unsigned long long *row_hash)
 {
-    const int tile = blockIdx.x;
-    if (zero_slot && tile == 0 && threadIdx.x == 0) *zero_slot = 0u;     // E_m of the fp16 tile image: k_kmeans_prepare_sp, next on the stream
-    const int G = segk_gmax(D);          // bucket extent; dims >= D are zero filled
-    const int stride = segk_tile_stride(D);
-    float *T = tiles + (int64_t)tile * stride;
-    __shared__ double nrm[32];
-    // |m|^2 of the tile's 32 components: 8 lanes per component, fp64
-    {
-        const int ci = threadIdx.x >> 3, sub = threadIdx.x & 7;      // 256 threads = 32 x 8
-        const int comp = tile * 32 + ci;
-        double s = 0.0;
-        unsigned long long hh = 0ull;
-        if (comp < K_max)
-            for (int d = sub; d < D; d += 8) {
-                double v = (double)means[(int64_t)comp * D + d];
-                s += v * v;
-                hh += segk_elem_hash(v, d);
-            }
-        s += __shfl_xor(s, 1);
-        s += __shfl_xor(s, 2);
-        s += __shfl_xor(s, 4);
-        hh += __shfl_xor(hh, 1);
-        hh += __shfl_xor(hh, 2);
-        hh += __shfl_xor(hh, 4);
-        if (sub == 0) {
-            nrm[ci] = s;
-            if (comp < K_max) atomicMax(mnorm2_bits, (unsigned long long)__double_as_longlong(s));
-            if (row_hash && comp < K_max) row_hash[comp] = hh | 1ull;      // never 0: the empty key of the hash table
-        }
-    }
-    __syncthreads();
-    for (int idx = threadIdx.x; idx < stride; idx += blockDim.x) {
-        float v = 0.f;
-        if (idx < G * 128) {
-            int g = idx >> 7, rem = idx & 127, lane = rem >> 1, s = rem & 1;
-            int comp = tile * 32 + (lane & 31);
-            int d = 4 * g + 2 * (lane >> 5) + s;
-            if (comp < K_max && d < D) v = (float)means[(int64_t)comp * D + d];
-        } else if (idx < G * 128 + 32) {
-            int i = idx - G * 128;
-            int comp = tile * 32 + i;
-            v = (comp < K_max) ? (float)(-0.5 * nrm[i]) : -3.0e38f;
-        }
-        T[idx] = v;
-    }
+    dev_prepare_tile<XT>(means, K_max, D, tiles, mnorm2_bits, zero_slot, row_hash, (int)blockIdx.x);
 }
 
 // header of the row image: int32 {pieces, exponent a, bits of max |x_d|}
@@ -128,68 +84,11 @@ __global__ void k_corpus_resid_sp(const float *X, int64_t ldx, int64_t n_emb, in
     xerr[e] = (float)(ldexp(sqrt(s), -ea) * (1.0 + 1e-6)) + 1e-37f;
 }
 
-// tiles image: [header 1024 floats: int32 exponent b at [0]] then per tile [s][p][lane][8] pieces + 32 constants
-// consts == NULL: the k-means constants -|m|^2/2; otherwise consts[k] (< -1e37: component absent) -- the
-// log-sum-exp use of the kernel (segk_fbbatch.hip), whose rows are not means.
 template <int P>
 __global__ void k_kmeans_prepare_sp(const float *means, int K_max, int D, float *tiles, const double *mnorm2,
                                     const unsigned char *ximg, const double *consts)
 {
-    typedef typename SegkPiece<P>::T T;
-    const int tile = blockIdx.x;
-    const int KS = segk_b3_kp(D) / 16;
-    const int stride = segk_sp_tile_stride(D, P);
-    // max |m_d| <= sqrt(max |m|^2): every block derives the same exponent
-    const int eb = P == 2 ? sp_exponent((float)(sqrt(*mnorm2) * (1.0 + 1e-6))) : 0;
-    const int ea = ((const int *)ximg)[1];
-    if (tile == 0 && threadIdx.x == 0) ((int *)tiles)[0] = eb;
-    float *Tt = tiles + 1024 + (int64_t)tile * stride;
-    T *Tb = (T *)Tt;
-    __shared__ double nrm[32];
-    {
-        const int ci = threadIdx.x >> 3, sub = threadIdx.x & 7;      // 256 threads = 32 x 8
-        const int comp = tile * 32 + ci;
-        double s = 0.0, rs = 0.0;
-        if (comp < K_max)
-            for (int d = sub; d < D; d += 8) {
-                const float mv = means[(int64_t)comp * D + d];
-                double v = (double)mv;
-                s += v * v;
-                if (P == 2) rs += sp_resid2(ldexpf(mv, eb));
-            }
-        s += __shfl_xor(s, 1);
-        s += __shfl_xor(s, 2);
-        s += __shfl_xor(s, 4);
-        if (sub == 0) nrm[ci] = s;
-        if (P == 2) {                     // E_m = max_k |m_k - m1_k|: tiles header [1], zeroed by k_kmeans_prepare just before
-            rs += __shfl_xor(rs, 1);
-            rs += __shfl_xor(rs, 2);
-            rs += __shfl_xor(rs, 4);
-            const float em = (float)(ldexp(sqrt(rs), -eb) * (1.0 + 1e-6));
-            if (sub == 0 && comp < K_max) atomicMax((unsigned int *)tiles + 1, __float_as_uint(em));
-        }
-    }
-    __syncthreads();
-    for (int idx = threadIdx.x; idx < KS * 64 * 8; idx += blockDim.x) {
-        const int sidx = idx >> 9, lane = (idx >> 3) & 63, i = idx & 7;
-        const int comp = tile * 32 + (lane & 31);
-        const int d = segk_b3_dim(16 * sidx + 8 * (lane >> 5) + i);
-        const float v = (comp < K_max && d < D) ? ldexpf(means[(int64_t)comp * D + d], eb) : 0.f;
-        T pc[P];
-        split_sp<P>(v, pc);
-#pragma unroll
-        for (int q = 0; q < P; q++) Tb[((sidx * P + q) * 64 + lane) * 8 + i] = pc[q];
-    }
-    for (int idx = threadIdx.x; idx < stride - KS * P * 256; idx += blockDim.x) {
-        float v = 0.f;
-        if (idx < 32) {
-            const int comp = tile * 32 + idx;
-            // the accumulators live in the scaled domain 2^(a+b) f
-            if (consts) v = (comp < K_max && consts[comp] > -1e37) ? (float)ldexp(consts[comp], ea + eb) : -3.0e38f;
-            else v = (comp < K_max) ? (float)ldexp(-0.5 * nrm[idx], ea + eb) : -3.0e38f;
-        }
-        Tt[KS * P * 256 + idx] = v;
-    }
+    dev_prepare_sp_tile<P>(means, K_max, D, tiles, mnorm2, ximg, consts, (int)blockIdx.x);
 }
 
 // ---- split-precision images of arbitrary float32 matrices (internal; used by segk_fbbatch.hip) ----

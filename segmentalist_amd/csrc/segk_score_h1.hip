@@ -356,6 +356,130 @@ __global__ __launch_bounds__(64) void k_kmeans_exact_pair(ScoreArgs A)
 #undef SEGK_STAMP_P
 }
 
+// Second form of the exact pair stage (default; SEGK_PAIR_V=1 selects the first): only the float32 ROWS go through LDS.
+// The two means of an item are read by the item's own two lanes straight into registers -- 16 bytes per lane at the
+// offsets sp_exact_score_x wants (8 b + 4 h), 2 KS + 1 loads per lane, all in flight together.  The 400 KB of `means`
+// live in L2 (and partly in L1), so that what the first form staged and re-read through LDS (two thirds of its LDS
+// traffic, 16 of its 24 staging loads per step, 15 of its 23 KB of LDS per wave) becomes L2 hits into registers:
+// 8 KB of LDS per wave, twice the waves per CU.
+template <int KS>
+__global__ __launch_bounds__(64) void k_kmeans_exact_pair2(ScoreArgs A)
+{
+    constexpr int R = SEGK_PAIR_ROWS;
+    constexpr int C4 = KS * 4;                                     // 16-byte slots read per row (>= D / 4)
+    constexpr int LD = KS * 16 + 8;                                // floats per staged row
+    constexpr int RPI = 64 / C4;                                   // rows per load instruction (2 for KS 5..8)
+    constexpr int NLA = (R + RPI - 1) / RPI;                       // load instructions per step
+    extern __shared__ __attribute__((aligned(16))) float lds[];    // [R][LD] x rows, then [R] row addresses
+    const int lane = threadIdx.x, D = A.D, D4 = D >> 2;
+    const int64_t n_steps = (A.n + R - 1) / R;
+    const int sub = lane / C4, c4 = lane - sub * C4;               // this lane's row within an instruction, its slot
+    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(1))) f32x4_t *gptr_t;
+
+    auto fetch_rid = [&](int64_t step) -> int32_t {
+        const int64_t r = step * R + lane;
+        int32_t rid = -1;
+        if (step < n_steps && lane < R && r < A.n) rid = A.ids ? A.ids[r] : (int32_t)(A.row0 + r);
+        return rid;
+    };
+    auto fetch_k = [&](int32_t rid) -> int32_t { return rid >= 0 ? A.cand.k[rid] : 0; };
+    f32x4_t v[NLA];
+    uint64_t *rowp = reinterpret_cast<uint64_t *>(lds + R * LD);
+    auto issue_x = [&](int32_t rid, int64_t step_) {
+        if (lane < R) {
+            int64_t r_any = rid;
+            if (rid < 0) {                                     // some valid row: this step's own when the rows are a range
+                r_any = A.ids ? 0 : A.row0 + step_ * R + lane;
+                if (r_any >= A.row0 + A.n || A.ids) r_any = A.ids ? 0 : A.row0;
+            }
+            rowp[lane] = (uint64_t)(uintptr_t)(A.xrows32 + r_any * A.ld32);
+        }
+        const int sub_c = sub < RPI ? sub : RPI - 1;
+        const unsigned off = 16u * (unsigned)(c4 < D4 ? c4 : D4 - 1);
+#pragma unroll
+        for (int t = 0; t < NLA; t++) v[t] = *reinterpret_cast<gptr_t>((uintptr_t)(rowp[(RPI * t + sub_c) & (R - 1)] + off));
+    };
+    auto decode = [&](int32_t &rid, int32_t k) -> int32_t {       // pair base, or -1 (and rid = -1) when not pending
+        if (rid >= 0 && k >= 0 && (k & SEGK_PAIR_PENDING) && (k & ~SEGK_PAIR_PENDING) < A.K_max) return k & ~SEGK_PAIR_PENDING;
+        rid = -1;
+        return -1;
+    };
+
+    const int item = lane >> 1, h = lane & 1, row = item >> 1, mem = item & 1;
+    const int nfull = D & ~7, nblk = nfull >> 3, rem = D & 7;
+    const bool tail = nfull + 4 * h < D;
+
+    int64_t step = blockIdx.x;
+    int32_t rid0 = fetch_rid(step);
+    int32_t c0 = decode(rid0, fetch_k(rid0));
+    issue_x(rid0, step);
+    int32_t rid1 = fetch_rid(step + gridDim.x);
+    int32_t k1 = fetch_k(rid1);
+    int32_t rid2 = fetch_rid(step + 2 * (int64_t)gridDim.x);
+    for (; step < n_steps; step += gridDim.x) {
+        // this step's means: the item's member (c + mem, clamped into the table: the result of a member beyond it is dropped)
+        const int32_t rid = __shfl(rid0, row), c = __shfl(c0, row);
+        int cm = rid >= 0 ? c + mem : 0;
+        if (cm >= A.K_max) cm = A.K_max - 1;
+        const uintptr_t mp = (uintptr_t)(A.means32 + (int64_t)cm * D + 4 * h);
+        f32x4_t mreg[2 * KS], mt;
+#pragma unroll
+        for (int b = 0; b < 2 * KS; b++) mreg[b] = *reinterpret_cast<gptr_t>(mp + 32u * (unsigned)(b < nblk ? b : 0));
+        mt = *reinterpret_cast<gptr_t>(mp + 4u * (unsigned)(tail ? nfull : 0));
+        // the staged rows of this step into LDS, the next step's row loads into flight
+#pragma unroll
+        for (int t = 0; t < NLA; t++)
+            if (sub < RPI && RPI * t + sub < R) *reinterpret_cast<f32x4_t *>(lds + (RPI * t + sub) * LD + 4 * c4) = v[t];
+        const int32_t c1 = decode(rid1, k1);
+        issue_x(rid1, step + gridDim.x);
+        rid0 = rid1; c0 = c1;
+        rid1 = rid2;
+        k1 = fetch_k(rid1);
+        rid2 = fetch_rid(step + 3 * (int64_t)gridDim.x);
+        // the reference's float32 -(deltas*deltas).sum() in numpy's pairwise order (sp_exact_score_x with the mean in
+        // registers): this lane owns the strided accumulators r_{4h..4h+3}
+        const float *xrow = lds + row * LD + 4 * h;
+        float r4[4] = {0.f, 0.f, 0.f, 0.f}, tt[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int b = 0; b < 2 * KS; b++) {
+            if (b < nblk) {
+                const f32x4_t xv = *reinterpret_cast<const f32x4_t *>(xrow + 8 * b);
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const float delta = mreg[b][q] - xv[q];
+                    const float t2 = delta * delta;
+                    r4[q] = b == 0 ? t2 : r4[q] + t2;
+                }
+            }
+        }
+        if (tail) {
+            const f32x4_t xt = *reinterpret_cast<const f32x4_t *>(xrow + nfull);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const float delta = mt[q] - xt[q];
+                tt[q] = delta * delta;
+            }
+        }
+        float res = (r4[0] + r4[1]) + (r4[2] + r4[3]);
+        const float ro = __shfl_xor(res, 1);
+        res = (h == 0) ? res + ro : ro + res;                      // ((r0+r1)+(r2+r3)) + ((r4+r5)+(r6+r7))
+        const float u0 = __shfl_xor(tt[0], 1), u1 = __shfl_xor(tt[1], 1), u2 = __shfl_xor(tt[2], 1), u3 = __shfl_xor(tt[3], 1);
+        const float t0 = h == 0 ? tt[0] : u0, t1 = h == 0 ? tt[1] : u1, t2 = h == 0 ? tt[2] : u2, t3 = h == 0 ? tt[3] : u3;
+        if (rem > 0) res += t0;
+        if (rem > 1) res += t1;
+        if (rem > 2) res += t2;
+        if (rem > 3) res += t3;
+        const float sc = -res;
+        const float so = __shfl_xor(sc, 2);
+        if ((lane & 3) == 0 && rid >= 0) {
+            const bool second = c + 1 < A.K_max && so > sc;
+            A.cand.k[rid] = second ? c + 1 : c;
+            A.cand.s[rid] = (double)(second ? so : sc);
+        }
+    }
+}
+
 // rows the pre-filter launch does not cover (fewer than SEGK_TAIL_QUEUE): straight to its second stage
 __global__ void k_pre_queue_rows(ScoreArgs A)
 {
@@ -393,7 +517,7 @@ static int launch_score_pre(segk_ctx *ctx, ScoreArgs A, hipStream_t st)
     A.stamp = getenv("SEGK_STAMP_PTR") ? (unsigned long long *)strtoull(getenv("SEGK_STAMP_PTR"), nullptr, 0) : nullptr;
 #endif
     if (ctx->pre_zeroed) ctx->pre_zeroed = 0;          // segk_kmeans_score cleared it together with the caller's queue length
-    else SEGK_CHECK_HIP(hipMemsetAsync(A.pre_count, 0, sizeof(int32_t), st));
+    else SEGK_CHECK_HIP(hipMemsetAsync(ctx->pre_queue, 0, 16 * sizeof(int32_t), st));
 
     constexpr size_t lds = 2 * (size_t)(KS + 1) * 256 * sizeof(float);
     const int64_t slots = 2 * (int64_t)ctx->n_cu;      // two 4-wave workgroups per CU (launch bounds)
@@ -403,70 +527,150 @@ static int launch_score_pre(segk_ctx *ctx, ScoreArgs A, hipStream_t st)
     if (getenv("SEGK_PRE_NBLK") && atoi(getenv("SEGK_PRE_NBLK")) == 2) n4 = 0;      // development: 256-row workgroups only
     const bool prof = ctx->prof_on != 0;
     const int slot = ctx->prof_n % SEGK_PROF_SLOTS;
-    // the timed launch (segk_profile_*): the 512-row-workgroup launch when there is one, else the 256-row one
-    auto prof_end = [&](int64_t rows) -> int {
+    // the timed interval (segk_profile_*): the 512-row-workgroup launches when there are any, else the 256-row one
+    auto prof_end = [&](int64_t rows, int launches) -> int {
         if (!prof) return SEGK_OK;
         SEGK_CHECK_HIP(hipEventRecord(ctx->prof_ev[slot][1], st));
         ctx->prof_rows[slot] = rows;
         ctx->prof_kind = 1;
+        ctx->prof_launches = launches;
         ctx->prof_n++;
         return SEGK_OK;
     };
-    // a short remainder is only queued: first, so that nothing small sits between the big launch and the
-    // kernels waiting for it
+    const bool overlap = ctx->overlap_req != 0;
+    // Pipeline over chunks of whole rounds (SEGK_PRE_CHUNKS = 2..8; default 1 = off: measured on MI355X it LOSES -- beside
+    // the exact stage a pre-filter chunk takes 88-114 us instead of 67, 1 378 sweeps/s against 1 580, profiles/README.md
+    // r02_c -- the kernels compete for the same CUs and the same power budget): the pre-filter of chunk i + 1 runs on the
+    // caller's stream while the exact stage of chunk i (third stream) and its second stage (second stream) work on the
+    // rows chunk i decided / queued -- matrix-bound beside memory- and latency-bound kernels.  Every chunk has its own
+    // queue counter (header word `ch`) and its own region of the queue (at the chunk's first row: it cannot overflow).
+    int n_chunks = 1;
+    if (overlap && n4 > 0) {
+        const char *ce = getenv("SEGK_PRE_CHUNKS");
+        int want = ce ? atoi(ce) : 1;
+        if (want < 1) want = 1;
+        if (want > 8) want = 8;
+        const int64_t rounds = n4 / round4;
+        n_chunks = (int)(rounds < want ? rounds : want);
+    }
+    // a short remainder is only queued (first chunk's queue): first, so that nothing small sits between the big
+    // launches and the kernels waiting for them
     const int64_t rem = A.n - n4;
     const bool rem_queued = rem > 0 && rem < SEGK_TAIL_QUEUE && n4 > 0;
+    const int64_t rounds_per_chunk = n4 > 0 ? (n4 / round4 + n_chunks - 1) / n_chunks : 0;
+    const int64_t chunk_rows = rounds_per_chunk * round4;
     ScoreArgs T = A;
     T.n = rem;
     T.row0 = A.row0 + n4;
     T.ids = A.ids ? A.ids + n4 : nullptr;
+    T.pre_cap = (int)(n_chunks > 1 ? chunk_rows : cap2);
     if (rem_queued) hipLaunchKernelGGL(k_pre_queue_rows, dim3((unsigned)((rem + 255) / 256)), dim3(256), 0, st, T);
-    if (prof) SEGK_CHECK_HIP(hipEventRecord(ctx->prof_ev[slot][0], st));
-    if (n4 > 0) {
-        ScoreArgs M = A;
-        M.n = n4;
-        hipLaunchKernelGGL((k_kmeans_score_h1<KS, 4>), dim3((unsigned)(n4 / 512)), dim3(256), lds, st, M);
-        if (int rc = prof_end(n4)) return rc;
-    }
-    if (rem > 0 && !rem_queued) {
-        hipLaunchKernelGGL((k_kmeans_score_h1<KS, 2>), dim3((unsigned)((rem + 255) / 256)), dim3(256), lds, st, T);
-        if (n4 == 0)
-            if (int rc = prof_end(rem)) return rc;
-    }
-    // The decided rows' exact stage (this stream) and the undecided rows' second stage + full scan (second
-    // stream, segk_kmeans_score only) touch disjoint rows: side by side, the exact stage leaving LDS for one
-    // second-stage workgroup per CU.  Joined at the end of segk_kmeans_score.
-    const bool overlap = ctx->overlap_req != 0;
-    hipStream_t st2 = st;
+    hipStream_t st2 = st, st3 = st;
     if (overlap) {
         if (!ctx->aux) {
             SEGK_CHECK_HIP(hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking));
             SEGK_CHECK_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
             SEGK_CHECK_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
         }
-        SEGK_CHECK_HIP(hipEventRecord(ctx->ev_fork, st));
-        SEGK_CHECK_HIP(hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
+        if (n_chunks > 1 && !ctx->aux2) {
+            SEGK_CHECK_HIP(hipStreamCreateWithFlags(&ctx->aux2, hipStreamNonBlocking));
+            SEGK_CHECK_HIP(hipEventCreateWithFlags(&ctx->ev_join2, hipEventDisableTiming));
+            for (int i = 0; i < 8; i++) SEGK_CHECK_HIP(hipEventCreateWithFlags(&ctx->ev_chunk[i], hipEventDisableTiming));
+        }
         st2 = ctx->aux;
         ctx->aux_busy = 1;
+        if (n_chunks > 1) {
+            st3 = ctx->aux2;
+            ctx->aux2_busy = 1;
+        }
     }
-    // exact stage of the decided rows
-    {
-        const size_t lds_p = 3 * (size_t)SEGK_PAIR_ROWS * (KS * 16 + 8) * sizeof(float) + 3 * SEGK_PAIR_ROWS * sizeof(uint64_t);
-        const int64_t steps = (A.n + SEGK_PAIR_ROWS - 1) / SEGK_PAIR_ROWS;
+    const char *pv = getenv("SEGK_PAIR_V");
+    const bool pair1 = pv && atoi(pv) == 1;
+    const size_t lds_p = pair1 ? 3 * (size_t)SEGK_PAIR_ROWS * (KS * 16 + 8) * sizeof(float) + 3 * SEGK_PAIR_ROWS * sizeof(uint64_t)
+                               : (size_t)SEGK_PAIR_ROWS * (KS * 16 + 8) * sizeof(float) + SEGK_PAIR_ROWS * sizeof(uint64_t);
+    const char *pw = getenv("SEGK_PAIR_WAVES");
+    // waves per CU: the second form could hold 12 (registers: three per SIMD), but beside the second stage -- the head of
+    // the longer branch -- 6 is the measured optimum (12: 1 555, 8: 1 598, 6: 1 626 sweeps/s; profiles/README.md r02_d)
+    const int max_waves = pw ? atoi(pw) : (pair1 ? 8 : 6);
+    // exact stage of the rows [r0, r0 + nr) of this call on stream `sx`
+    auto launch_pair = [&](int64_t r0, int64_t nr, hipStream_t sx) {
+        ScoreArgs P = A;
+        P.n = nr;
+        P.row0 = A.row0 + r0;
+        P.ids = A.ids ? A.ids + r0 : nullptr;
+        const int64_t steps = (nr + SEGK_PAIR_ROWS - 1) / SEGK_PAIR_ROWS;
         int64_t waves = (int64_t)ctx->n_cu * (int64_t)(((overlap ? 124 : 160) * 1024) / lds_p);
-        if (waves > 8 * (int64_t)ctx->n_cu) waves = 8 * (int64_t)ctx->n_cu;
+        if (waves > max_waves * (int64_t)ctx->n_cu) waves = max_waves * (int64_t)ctx->n_cu;
         if (waves > steps) waves = steps;
-        hipLaunchKernelGGL((k_kmeans_exact_pair<KS>), dim3((unsigned)waves), dim3(64), lds_p, st, A);
-    }
-    // second stage: all three products for the queued rows; the row count is read on the device
-    {
+        if (pair1) hipLaunchKernelGGL((k_kmeans_exact_pair<KS>), dim3((unsigned)waves), dim3(64), lds_p, sx, P);
+        else hipLaunchKernelGGL((k_kmeans_exact_pair2<KS>), dim3((unsigned)waves), dim3(64), lds_p, sx, P);
+    };
+    // second stage (all three products) of the rows queued in region [q0, q0 + cap) under counter `ch`; the row count is read on the device
+    auto launch_second = [&](int64_t q0, int64_t cap, int ch, hipStream_t sx) -> int {
         ScoreArgs B = A;
-        B.ids = A.pre_queue;
+        B.ids = A.pre_queue + q0;
         B.row0 = 0;
-        B.n = cap2;
-        B.n_dev = A.pre_count;
-        if (int rc = segk_launch_sp_second(B, KS, st2)) return rc;
+        B.n = cap;
+        B.n_dev = ctx->pre_queue + ch;
+        return segk_launch_sp_second(B, KS, sx);
+    };
+    if (prof) SEGK_CHECK_HIP(hipEventRecord(ctx->prof_ev[slot][0], st));
+    if (n_chunks > 1) {
+        int launched = 0;
+        for (int ch = 0; ch < n_chunks; ch++) {
+            const int64_t r0 = ch * chunk_rows;
+            const int64_t nr = r0 + chunk_rows <= n4 ? chunk_rows : n4 - r0;
+            if (nr <= 0) break;
+            ScoreArgs M = A;
+            M.n = nr;
+            M.row0 = A.row0 + r0;
+            M.ids = A.ids ? A.ids + r0 : nullptr;
+            M.pre_queue = A.pre_queue + r0;
+            M.pre_count = ctx->pre_queue + ch;
+            M.pre_cap = (int)nr;
+            hipLaunchKernelGGL((k_kmeans_score_h1<KS, 4>), dim3((unsigned)(nr / 512)), dim3(256), lds, st, M);
+            launched++;
+            SEGK_CHECK_HIP(hipEventRecord(ctx->ev_chunk[ch], st));
+            SEGK_CHECK_HIP(hipStreamWaitEvent(st3, ctx->ev_chunk[ch], 0));
+            launch_pair(r0, nr, st3);
+            SEGK_CHECK_HIP(hipStreamWaitEvent(st2, ctx->ev_chunk[ch], 0));
+            if (int rc = launch_second(r0, nr, ch, st2)) return rc;
+        }
+        if (int rc = prof_end(n4, launched)) return rc;
+        if (rem > 0 && !rem_queued) {                          // a long remainder: one more chunk of 256-row workgroups
+            T.pre_queue = A.pre_queue + n4;
+            T.pre_count = ctx->pre_queue + n_chunks;
+            T.pre_cap = (int)rem;
+            hipLaunchKernelGGL((k_kmeans_score_h1<KS, 2>), dim3((unsigned)((rem + 255) / 256)), dim3(256), lds, st, T);
+            SEGK_CHECK_HIP(hipEventRecord(ctx->ev_chunk[n_chunks], st));
+            SEGK_CHECK_HIP(hipStreamWaitEvent(st3, ctx->ev_chunk[n_chunks], 0));
+            launch_pair(n4, rem, st3);
+            SEGK_CHECK_HIP(hipStreamWaitEvent(st2, ctx->ev_chunk[n_chunks], 0));
+            if (int rc = launch_second(n4, rem, n_chunks, st2)) return rc;
+        }
+        SEGK_LAUNCH_CHECK();
+        return SEGK_OK;
     }
+    if (n4 > 0) {
+        ScoreArgs M = A;
+        M.n = n4;
+        hipLaunchKernelGGL((k_kmeans_score_h1<KS, 4>), dim3((unsigned)(n4 / 512)), dim3(256), lds, st, M);
+        if (int rc = prof_end(n4, 1)) return rc;
+    }
+    if (rem > 0 && !rem_queued) {
+        hipLaunchKernelGGL((k_kmeans_score_h1<KS, 2>), dim3((unsigned)((rem + 255) / 256)), dim3(256), lds, st, T);
+        if (n4 == 0)
+            if (int rc = prof_end(rem, 1)) return rc;
+    }
+    // The decided rows' exact stage (this stream) and the undecided rows' second stage + full scan (second
+    // stream, segk_kmeans_score only) touch disjoint rows: side by side, the exact stage leaving LDS for one
+    // second-stage workgroup per CU.  Joined at the end of segk_kmeans_score.
+    if (overlap) {
+        SEGK_CHECK_HIP(hipEventRecord(ctx->ev_fork, st));
+        SEGK_CHECK_HIP(hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
+    }
+    launch_pair(0, A.n, st);
+    if (int rc = launch_second(0, cap2, 0, st2)) return rc;
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;
 }

@@ -46,6 +46,9 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_kmeans_score_sp(ScoreArgs A)
         const int64_t nd = *A.n_dev;
         n = nd < n ? nd : n;
         if ((int64_t)blockIdx.x * WAVES * 32 >= n) return;
+        // this launch is the head of the longer branch of the score stage (second stage -> full scan) and shares its CUs
+        // with the dozen latency-bound waves of the exact pair kernel: its few waves go first at every issue slot
+        if (A.dbg != 64) __builtin_amdgcn_s_setprio(3);
     }
     const float *__restrict__ tiles = A.tiles + 1024;
     const int n_tiles = A.n_tiles, D = A.D;

@@ -155,9 +155,10 @@ __global__ void k_kmeans_segment(segk_corpus c, segk_kmeans m, const int32_t *ut
     const int no = l_cnt[0], nn = l_cnt[1];
     for (int j = lane; j < N; j += 64) gbnd[j] = l_bnd[j];
     for (int j = lane; j < no; j += 64) old_tok[(int64_t)u * c.N_max + j] = l_old[j];
-    for (int j = lane; j < nn; j += 64) {
-        new_tok[(int64_t)u * c.N_max + j] = l_new[j];
-        new_k[(int64_t)u * c.N_max + j] = l_newk[j];
+    // slots beyond the utterance's tokens carry k = -1: the batch statistics scan new_k as it stands
+    for (int j = lane; j < c.N_max; j += 64) {
+        if (j < nn) new_tok[(int64_t)u * c.N_max + j] = l_new[j];
+        new_k[(int64_t)u * c.N_max + j] = j < nn ? l_newk[j] : -1;
     }
 }
 
@@ -331,9 +332,10 @@ __global__ void k_kmeans_segment_w8(segk_corpus c, segk_kmeans m, const int32_t 
     const unsigned long long newb = ((unsigned long long)(unsigned int)l_cnt[3] << 32) | (unsigned int)l_cnt[2];
     if (lane < N) gbnd[lane] = (uint8_t)((newb >> lane) & 1ull);
     for (int j = lane; j < no; j += 64) old_tok[(int64_t)u * c.N_max + j] = l_old[j];
-    for (int j = lane; j < nn; j += 64) {
-        new_tok[(int64_t)u * c.N_max + j] = l_new[j];
-        new_k[(int64_t)u * c.N_max + j] = l_newk[j];
+    // slots beyond the utterance's tokens carry k = -1: the batch statistics scan new_k as it stands
+    for (int j = lane; j < c.N_max; j += 64) {
+        if (j < nn) new_tok[(int64_t)u * c.N_max + j] = l_new[j];
+        new_k[(int64_t)u * c.N_max + j] = j < nn ? l_newk[j] : -1;
     }
 }
 
@@ -505,9 +507,10 @@ __global__ void k_kmeans_segment_w8x2(segk_corpus c, segk_kmeans m, const int32_
     const unsigned long long newb = ((unsigned long long)(unsigned int)l_cnt[3] << 32) | (unsigned int)l_cnt[2];
     if (lane < N) gbnd[lane] = (uint8_t)((newb >> lane) & 1ull);
     for (int j = lane; j < no; j += 32) old_tok[(int64_t)u * c.N_max + j] = l_old[j];
-    for (int j = lane; j < nn; j += 32) {
-        new_tok[(int64_t)u * c.N_max + j] = l_new[j];
-        new_k[(int64_t)u * c.N_max + j] = l_newk[j];
+    // slots beyond the utterance's tokens carry k = -1: the batch statistics scan new_k as it stands
+    for (int j = lane; j < c.N_max; j += 32) {
+        if (j < nn) new_tok[(int64_t)u * c.N_max + j] = l_new[j];
+        new_k[(int64_t)u * c.N_max + j] = j < nn ? l_newk[j] : -1;
     }
 }
 

@@ -174,145 +174,283 @@ __global__ void k_kmeans_update(segk_corpus c, segk_kmeans m, int op, int utt, i
 }
 
 // ======================================================================================
-// A11 batch-synchronous statistics (spec: oracle/np_oracle.py kmeans_batch_sweep)
+// A11 batch-synchronous statistics (spec: oracle/np_oracle.py kmeans_batch_sweep; rank split:
+// oracle/np_dist.py).  Four kernels after the per-utterance kernel:
+//
+//   k_batch_sort       one workgroup per statistics block: stable counting sort of the block's tokens by
+//                      component, straight from the slot arrays new_tok / new_k [U, N_max] (unused slots carry
+//                      k = -1); tokens whose argmax is an INACTIVE row (k >= K: they will found new components)
+//                      are listed instead, per block and in token order, as (slot, k, embedding row) triples.
+//   k_batch_partials   per statistics block and component the sequential fp64 sum of its tokens in token order.
+//   [multi-GPU: ONE all-gather of the packed per-rank record -- partial sums, totals, counts, flag lists]
+//   k_batch_finalize   one workgroup per eight components.  Every workgroup replays, redundantly and from
+//                      the same inputs, the `k > K -> K` clamp over the flagged tokens of all blocks in global
+//                      token order (kmeans_components.py:102-106), the combined counts and the bookkeeping
+//                      of clean_components (:263-266: which original row ends in which final row); then it
+//                      writes ITS final rows -- fixed binary tree over the blocks' partial sums (new
+//                      components: sequential sums of their flagged tokens per block, same tree), means =
+//                      numerators / counts -- and their part of the fp32 MFMA image.
+//   k_batch_post       final labels of the local tokens (remap table), the split-precision image of every tile
+//                      (needs max |m|^2 over ALL rows, complete only now) and the duplicate marking.
+//
+// Packed record of one rank, in 8-byte words (nbl = blocks per rank, FW = flag words per block):
+//   [part_sum nbl*K_max*D double][part_tot nbl double][part_cnt nbl*K_max int64][flags nbl*FW]
+//   flags of a block, as int32: {count, 0, (slot, k, row) x cap}.
 // ======================================================================================
-// (1) one workgroup: (a) exclusive prefix sum of n_new over the local utterances ->
-//     tok_off[u - lo] (tok_off[hi - lo] = number of local tokens); (b) collect, in token order,
-//     the new tokens whose argmax is an inactive row (k >= K; per-utterance counts n_flag come
-//     from the segment kernel): flag_buf[0] = count, then (slot = utt*N_max + t, k) pairs.
-__global__ void k_batch_collect(segk_corpus c, segk_kmeans m, int lo, int hi, const int32_t *new_k,
-                                const int32_t *n_new, const int32_t *n_flag, int32_t *tok_off,
-                                int32_t *flag_buf, int cap)
+static inline __host__ __device__ int64_t segk_flag_words(int cap) { return (2 + 3 * (int64_t)cap + 1) / 2; }
+
+// ======================================================================================
+// (1a) k_batch_sort: ONE workgroup per statistics block.  Stable counting sort of the block's tokens by
+//      component: sorted[p0 + i] = embedding row of the i-th token in (component, token order) order,
+//      koff[b][k] = index of component k's first token (koff[b][K_max] = number of un-flagged tokens), so
+//      that the summing kernel reads every (block, component) list directly -- before, each of the 125
+//      workgroups of a block scanned all of its 25 000 slots for its own eight components.
+//      Waves own contiguous runs of slots: (P1) per-wave histograms in LDS, (P2) per component the waves'
+//      counts turned into running offsets and the totals scanned over the components, (P3) every wave
+//      walks its run again, 64 slots at a time in order; the rank of a token among the same-component tokens
+//      of its 64 is counted explicitly (a dozen iterations: one per valid lane), never left to the order in
+//      which the hardware happens to serve atomics.
+//      Tokens whose argmax is an inactive row (k >= K, flagged) are listed separately in token order; the
+//      block's total is summed in utterance order.  Also zeroes m.mnorm_max and stores K for (2).
+// ======================================================================================
+#define SORT_THREADS 1024
+#define SORT_KEYS_LDS 32768          /* slots of a block whose keys are staged in LDS (int16); larger blocks read them from memory */
+// the lanes of the wave whose key equals this lane's (valid lanes only): one ballot per key bit
+__device__ __forceinline__ unsigned long long dev_match_key(int k, bool ok, int nbits)
 {
-    // every thread owns a run of `per` consecutive utterances: local sums, ONE workgroup scan of the
-    // 1024 run totals (wave scan + 16 wave totals), then the run is walked again with its offsets
-    __shared__ int s_wave[16], s_wave2[16];
-    const int tid = threadIdx.x, nt = blockDim.x;
-    const int lane = tid & 63, wv = tid >> 6, nw = nt >> 6;
-    const int K = *m.K;
-    const int n = hi - lo;
-    const int per = (n + nt - 1) / nt;
-    const int u_lo = lo + tid * per, u_hi = (u_lo + per < hi) ? u_lo + per : hi;
-    int mine = 0, ntok = 0;
-    for (int u = u_lo; u < u_hi; u++) { ntok += n_new[u]; mine += n_flag[u]; }
-    int incl = mine, incl2 = ntok;
-    for (int o = 1; o < 64; o <<= 1) {
-        int v = __shfl_up(incl, o), v2 = __shfl_up(incl2, o);
-        if (lane >= o) { incl += v; incl2 += v2; }
+    unsigned long long mask = __ballot(ok);
+    for (int bit = 0; bit < nbits; bit++) {
+        const unsigned long long bal = __ballot((k >> bit) & 1);
+        mask &= ((k >> bit) & 1) ? bal : ~bal;
     }
-    if (lane == 63) { s_wave[wv] = incl; s_wave2[wv] = incl2; }
+    return mask;
+}
+
+template <int NW>       // waves that own slot runs (NW * K_max int32 counters in LDS: 16 up to K_max 1024, ... 2 up to 8192)
+__device__ __forceinline__ void dev_batch_sort(const segk_corpus &c, const segk_kmeans &m, const int Kb, const int u0, const int u1,
+                                               const int32_t *new_k, int32_t *sorted, int32_t *koff,
+                                               int32_t *cntw /* [NW][K_max] */, int32_t *base /* [K_max + 2] */,
+                                               short *keys /* [SORT_KEYS_LDS] */, int32_t *wtot /* [16] */)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int K_max = m.K_max;
+    const int64_t p0 = (int64_t)u0 * c.N_max;
+    const int S = (u1 - u0) * c.N_max;
+    const bool staged = S <= SORT_KEYS_LDS;
+    const int per = ((S + NW - 1) / NW + 63) & ~63;              // slots per wave, whole chunks of 64
+    int nbits = 1;
+    while ((1 << nbits) < K_max) nbits++;
+    for (int i = tid; i < NW * K_max; i += SORT_THREADS) cntw[i] = 0;
+    // (P0) the block's keys into LDS: every load of a thread in flight together (flagged tokens and unused slots as -1)
+    if (staged) {
+        constexpr int NL = SORT_KEYS_LDS / SORT_THREADS;          // 32 loads per thread at most
+        int v[NL];
+#pragma unroll
+        for (int q = 0; q < NL; q++) {
+            const int s = q * SORT_THREADS + tid;
+            v[q] = new_k[p0 + (s < S ? s : 0)];
+        }
+#pragma unroll
+        for (int q = 0; q < NL; q++) {
+            const int s = q * SORT_THREADS + tid;
+            if (s < S) keys[s] = (short)((v[q] >= 0 && v[q] < Kb) ? v[q] : -1);
+        }
+    }
     __syncthreads();
-    int woff = 0, woff2 = 0, total = 0, total2 = 0;
-    for (int w2 = 0; w2 < nw; w2++) {
-        if (w2 < wv) { woff += s_wave[w2]; woff2 += s_wave2[w2]; }
-        total += s_wave[w2];
-        total2 += s_wave2[w2];
+    auto key_at = [&](int s) -> int {
+        if (staged) return keys[s];
+        const int k = new_k[p0 + s];
+        return (k >= 0 && k < Kb) ? k : -1;
+    };
+    // (P1) histograms
+    if (wv < NW) {
+        int32_t *mine = cntw + wv * K_max;
+        const int s0 = wv * per, s1 = s0 + per < S ? s0 + per : S;
+        for (int s = s0 + lane; s < s1; s += 64) {
+            const int k = key_at(s);
+            if (k >= 0) atomicAdd(&mine[k], 1);
+        }
     }
-    int off2 = woff2 + incl2 - ntok;          // tokens before this run
-    int off = woff + incl - mine;             // flagged tokens before this run
-    for (int u = u_lo; u < u_hi; u++) {
-        const int nt_u = n_new[u];
-        tok_off[u - lo] = off2;
-        off2 += nt_u;
-        if (n_flag[u] > 0)
-            for (int t = 0; t < nt_u; t++) {
-                const int k = new_k[(int64_t)u * c.N_max + t];
-                if (k >= K) {
-                    if (off < cap) {
-                        flag_buf[1 + 2 * off] = u * c.N_max + t;
-                        flag_buf[2 + 2 * off] = k;
-                    }
-                    off++;
-                }
+    __syncthreads();
+    // (P2) per component: the waves' counts -> running offsets; totals -> exclusive scan over the components
+    // (K_max <= 8192: at most 8 slabs of 1024 components, thread t owns component 1024 q + t of slab q)
+    int carry = 0;
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const int k0 = q * SORT_THREADS;
+        if (k0 >= K_max) break;
+        const int k = k0 + tid;
+        int run = 0;
+        if (k < K_max) {
+            int t[NW];
+#pragma unroll
+            for (int w = 0; w < NW; w++) t[w] = cntw[w * K_max + k];
+#pragma unroll
+            for (int w = 0; w < NW; w++) {
+                cntw[w * K_max + k] = run;
+                run += t[w];
             }
+        }
+        int incl = run;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o);
+            if (lane >= o) incl += t;
+        }
+        if (lane == 63) wtot[wv] = incl;
+        __syncthreads();
+        int woff = 0, slab = 0;
+        for (int w = 0; w < SORT_THREADS / 64; w++) {
+            if (w < wv) woff += wtot[w];
+            slab += wtot[w];
+        }
+        if (k < K_max) {
+            const int ex = carry + woff + incl - run;
+            base[k] = ex;
+            koff[k] = ex;
+        }
+        carry += slab;
+        __syncthreads();
     }
-    if (tid == 0) {
-        flag_buf[0] = total;
-        tok_off[n] = total2;
+    if (tid == 0) koff[K_max] = carry;
+    // (P3) placement, stable: `sorted` receives the slot's offset in the block (its embedding row is new_tok[p0 + offset])
+    if (wv < NW) {
+        int32_t *mine = cntw + wv * K_max;
+        const int s0 = wv * per, s1 = s0 + per < S ? s0 + per : S;
+        for (int sb = s0; sb < s1; sb += 64) {
+            const int s = sb + lane;
+            const int k = s < s1 ? key_at(s) : -1;
+            const bool ok = k >= 0;
+            const unsigned long long same = dev_match_key(k, ok, nbits);
+            if (ok) {
+                const int rank = __popcll(same & ((1ull << lane) - 1ull));
+                const int before = mine[k];
+                sorted[p0 + base[k] + before + rank] = s;
+                if (rank == __popcll(same) - 1) mine[k] = before + rank + 1;       // the last of its component in the chunk
+            }
+        }
     }
 }
 
-// (2) replay the `k > K -> K` clamp (kmeans_components.py:103-106) over the flagged tokens of
-//     ALL ranks in rank order; patch the local new_k; set K.  One wave: the (short) lists are
-//     fetched in parallel, lane 0 replays them.
-__global__ void k_batch_resolve(segk_kmeans m, const int32_t *flag_all, int n_ranks, int my_rank, int cap,
-                                int32_t *new_k, int32_t *status)
+// grid = 2 * n_blocks: workgroup b < n_blocks sorts block b; workgroup n_blocks + b lists the block's flagged
+// tokens and sums its totals (a sequential fp64 chain of one thread: beside the sort, not behind it)
+__global__ __launch_bounds__(SORT_THREADS) void k_batch_sort(
+    segk_corpus c, segk_kmeans m, const int32_t *blk_lo, int n_blocks, const int32_t *new_tok, const int32_t *new_k,
+    const int32_t *n_flag, const double *out_total, int32_t *sorted, int32_t *koff_all, double *part_tot, int32_t *flags,
+    int cap, double *out_scalars)
 {
-    __shared__ int32_t l_k[1024], l_slot[1024];
-    const int lane = threadIdx.x;
-    int K = *m.K;
-    for (int r = 0; r < n_ranks; r++) {
-        const int32_t *fb = flag_all + (int64_t)r * (1 + 2 * cap);
-        int cnt = fb[0];
-        if (cnt > cap) { if (lane == 0) atomicOr(status, 4); cnt = cap; }
-        for (int q0 = 0; q0 < cnt; q0 += 1024) {
-            int nq = cnt - q0 < 1024 ? cnt - q0 : 1024;
-            for (int q = lane; q < nq; q += 64) {
-                l_slot[q] = fb[1 + 2 * (q0 + q)];
-                l_k[q] = fb[2 + 2 * (q0 + q)];
-            }
+    extern __shared__ __attribute__((aligned(16))) unsigned char sort_lds[];
+    __shared__ int32_t wtot[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int Kb = *m.K;                          // active components before the sweep: k >= Kb is a flagged token
+    const int K_max = m.K_max;
+    if ((int)blockIdx.x < n_blocks) {
+        const int b = blockIdx.x;
+        const int u0 = blk_lo[b], u1 = blk_lo[b + 1];
+        if (b == 0 && tid == 0) {
+            *(double *)m.mnorm_max = 0.0;         // max |m|^2 of the finalize kernel's prepare
+            out_scalars[3] = (double)Kb;          // the finalize kernel's workgroups read K from here: one of them rewrites *m.K
+        }
+        int32_t *base = reinterpret_cast<int32_t *>(sort_lds);
+        int32_t *cntw = base + K_max + 2;
+        int32_t *koff = koff_all + (int64_t)b * (K_max + 1);
+        if (K_max <= 1024) {
+            short *keys = reinterpret_cast<short *>(cntw + 16 * K_max);
+            dev_batch_sort<16>(c, m, Kb, u0, u1, new_k, sorted, koff, cntw, base, keys, wtot);
+        } else if (K_max <= 2048) {
+            short *keys = reinterpret_cast<short *>(cntw + 8 * K_max);
+            dev_batch_sort<8>(c, m, Kb, u0, u1, new_k, sorted, koff, cntw, base, keys, wtot);
+        } else if (K_max <= 4096) {
+            short *keys = reinterpret_cast<short *>(cntw + 4 * K_max);
+            dev_batch_sort<4>(c, m, Kb, u0, u1, new_k, sorted, koff, cntw, base, keys, wtot);
+        } else {
+            short *keys = reinterpret_cast<short *>(cntw + 2 * K_max);
+            dev_batch_sort<2>(c, m, Kb, u0, u1, new_k, sorted, koff, cntw, base, keys, wtot);
+        }
+        return;
+    }
+    const int b = blockIdx.x - n_blocks;
+    const int u0 = blk_lo[b], u1 = blk_lo[b + 1];
+    double *stage = reinterpret_cast<double *>(sort_lds);           // [2048]
+    // ---- flagged tokens: rare (none once every component is active), so a plain ordered pass
+    int32_t *fl = flags + (int64_t)b * 2 * segk_flag_words(cap);
+    int nf = 0;
+    for (int u = u0 + tid; u < u1; u += SORT_THREADS) nf += n_flag[u];
+    for (int o = 32; o > 0; o >>= 1) nf += __shfl_xor(nf, o);
+    if (lane == 0) wtot[wv] = nf;
+    __syncthreads();
+    nf = 0;
+    for (int w = 0; w < SORT_THREADS / 64; w++) nf += wtot[w];
+    __syncthreads();
+    int written = 0;                               // workgroup-uniform
+    if (nf > 0) {
+        const int64_t p0 = (int64_t)u0 * c.N_max, p1 = (int64_t)u1 * c.N_max;
+        for (int64_t pb = p0; pb < p1; pb += SORT_THREADS) {
+            const int64_t p = pb + tid;
+            const int k = p < p1 ? new_k[p] : -1;
+            const int f = k >= Kb;
+            const unsigned long long bal = __ballot(f);
+            if (lane == 0) wtot[wv] = __popcll(bal);
             __syncthreads();
-            if (lane == 0) {
-                for (int q = 0; q < nq; q++) {
-                    int k = l_k[q];
-                    if (k > K) k = K;
-                    if (k == K) K++;
-                    l_k[q] = k;
-                }
+            int off = written, tot = 0;
+            for (int w = 0; w < SORT_THREADS / 64; w++) {
+                if (w < wv) off += wtot[w];
+                tot += wtot[w];
             }
-            __syncthreads();
-            K = __shfl(K, 0);
-            if (r == my_rank)
-                for (int q = lane; q < nq; q += 64) new_k[l_slot[q]] = l_k[q];
+            off += __popcll(bal & ((1ull << lane) - 1ull));
+            if (f && off < cap) {
+                fl[2 + 3 * off + 0] = (int32_t)p;
+                fl[2 + 3 * off + 1] = k;
+                fl[2 + 3 * off + 2] = new_tok[p];
+            }
+            written += tot;
             __syncthreads();
         }
     }
-    if (lane == 0) *m.K = K;
-}
-
-// (3) compact the local tokens in token order: ctok[tok_off[u-lo] + t] = (embedding, component)
-__global__ void k_batch_compact(segk_corpus c, int lo, int hi, const int32_t *new_tok, const int32_t *new_k,
-                                const int32_t *n_new, const int32_t *tok_off, int32_t *ctok_id, int32_t *ctok_k)
-{
-    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int64_t tot = (int64_t)(hi - lo) * c.N_max;
-    if (idx >= tot) return;
-    int u = lo + (int)(idx / c.N_max), t = (int)(idx % c.N_max);
-    if (t < n_new[u]) {
-        int p = tok_off[u - lo] + t;
-        ctok_id[p] = new_tok[(int64_t)u * c.N_max + t];
-        ctok_k[p] = new_k[(int64_t)u * c.N_max + t];
+    if (tid == 0) { fl[0] = written; fl[1] = 0; }
+    // ---- sequential (utterance order) sum of the block's totals, staged through LDS so that the single summing
+    // thread never waits on global memory
+    double s = 0.0;
+    for (int uc = u0; uc < u1; uc += 2048) {
+        const int nu = u1 - uc < 2048 ? u1 - uc : 2048;
+        __syncthreads();
+        for (int i = tid; i < nu; i += SORT_THREADS) stage[i] = out_total[uc + i];
+        __syncthreads();
+        if (tid == 0) {
+            int i = 0;
+            for (; i + 16 <= nu; i += 16) {       // strictly sequential adds; the LDS reads are issued 16 at a time
+                double v[16];
+#pragma unroll
+                for (int q = 0; q < 16; q++) v[q] = stage[i + q];
+#pragma unroll
+                for (int q = 0; q < 16; q++) s += v[q];
+            }
+            for (; i < nu; i++) s += stage[i];
+        }
     }
+    if (tid == 0) part_tot[b] = s;
 }
 
-// (4) per statistics block and component: sequential fp64 sum over the block's tokens in
-//     token order.  A workgroup = (block, 8 consecutive components), one wave per component;
-//     lanes own dimensions.  The block's token keys are staged in LDS chunk by chunk with
-//     coalesced loads; a wave compacts its matching token ids (token order) into an LDS list and
-//     drains it 16 rows at a time -- the row loads are unconditional (clamped index, select after
-//     the load) so that all 16 are in flight together; the adds stay strictly in order.
-#define PART_CHUNK 8192
-#define PART_MLIST 512
+// (1b) per (block, component) the sequential fp64 sum of its tokens in token order: one wave per pair, lanes own
+//      dimensions; the token rows are fetched 16 at a time (unconditional loads, clamped index, select after the
+//      load: all 16 in flight together) and added strictly in order.
 #define PART_BATCH 16
 template <typename XT>
-__global__ __launch_bounds__(512) void k_batch_partials(
-    segk_corpus c, segk_kmeans m, const int32_t *blk_lo, int n_blocks, int lo, const int32_t *tok_off,
-    const int32_t *ctok_id, const int32_t *ctok_k, const double *out_total, double *part_sum,
-    int64_t *part_cnt, double *part_tot, int dbg)
+__global__ __launch_bounds__(512) void k_batch_partials(segk_corpus c, segk_kmeans m, const int32_t *blk_lo, int n_blocks,
+                                                        const int32_t *new_tok, const int32_t *sorted, const int32_t *koff_all,
+                                                        double *part_sum, int64_t *part_cnt)
 {
-    __shared__ __attribute__((aligned(16))) int32_t keys[PART_CHUNK];
-    __shared__ int32_t mlists[8 * PART_MLIST];
-    __shared__ int32_t wsum[2][8];
     const int groups = (m.K_max + 7) / 8;
     const int b = blockIdx.x / groups, kg = blockIdx.x % groups;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int k = kg * 8 + wv;
-    const bool active = k < m.K_max;
+    if (k >= m.K_max) return;
     const int D = c.D;
     const XT *X = (const XT *)c.X;
-    const int u0 = blk_lo[b], u1 = blk_lo[b + 1];
-    const int p0 = tok_off[u0 - lo], p1 = tok_off[u1 - lo];
-    int32_t *mlist = mlists + wv * PART_MLIST;
+    const int32_t *koff = koff_all + (int64_t)b * (m.K_max + 1);
+    const int q_lo = koff[k], nm = koff[k + 1] - q_lo;
+    const int64_t p0 = (int64_t)blk_lo[b] * c.N_max;
+    const int32_t *list = sorted + p0 + q_lo;           // slot offsets inside the block, (component, token) order
+    const int32_t *tok = new_tok + p0;
     constexpr int MAXR = 2;                       // 128 dims per pass over the tokens
     for (int d0 = 0; d0 < D; d0 += 64 * MAXR) {
         double acc[MAXR];
@@ -323,242 +461,169 @@ __global__ __launch_bounds__(512) void k_batch_partials(
             const int d = d0 + r * 64 + lane;
             dcl[r] = d < D ? d : 0;
         }
-        int64_t cnt = 0;
-        for (int pc = p0; pc < p1; pc += PART_CHUNK) {
-            const int nch = p1 - pc < PART_CHUNK ? p1 - pc : PART_CHUNK;
-            __syncthreads();
-            {   // coalesced staging, 4 independent loads in flight per thread
-                const int nt4 = 4 * blockDim.x;
-                for (int i0 = threadIdx.x; i0 < nch; i0 += nt4) {
-                    int v[4];
+        for (int q0 = 0; q0 < nm; q0 += PART_BATCH) {
+            double xv[PART_BATCH][MAXR];
 #pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        const int i = i0 + q * blockDim.x;
-                        v[q] = ctok_k[pc + (i < nch ? i : 0)];
-                    }
+            for (int q = 0; q < PART_BATCH; q++) {
+                const int e = tok[list[q0 + q < nm ? q0 + q : q0]];  // clamped: always valid
 #pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        const int i = i0 + q * blockDim.x;
-                        if (i < nch) keys[i] = v[q];
-                    }
-                }
+                for (int r = 0; r < MAXR; r++) xv[q][r] = (double)X[(int64_t)e * c.ldx + dcl[r]];
             }
-            __syncthreads();
-            // One cooperative pass of the workgroup over the chunk: the tokens of its EIGHT components, in token
-            // order, compacted in place to the front of keys[] as (position in chunk) * 8 + (component & 7).
-            // Before, every wave scanned every key for its own component -- 8 000 waves x 8 750 compares were
-            // 32 of the kernel's 58 us.  A thread owns four consecutive keys; a sub-chunk of 2048 keys is read
-            // into registers by everybody before anybody writes into its range (the barrier), and the write
-            // cursor never passes the keys already consumed.
-            int wgn = 0;         // workgroup-uniform: compacted entries so far
-            for (int sb = 0, it = 0; sb < nch; sb += 2048, it++) {
-                const int i0 = sb + 4 * threadIdx.x;
-                int4 kv = make_int4(-1, -1, -1, -1);
-                if (i0 + 3 < nch) kv = *reinterpret_cast<const int4 *>(keys + i0);
-                else {
-                    if (i0 < nch) kv.x = keys[i0];
-                    if (i0 + 1 < nch) kv.y = keys[i0 + 1];
-                    if (i0 + 2 < nch) kv.z = keys[i0 + 2];
-                }
-                const int kk[4] = {kv.x, kv.y, kv.z, kv.w};
-                int mine = 0;
 #pragma unroll
-                for (int j = 0; j < 4; j++) mine += (kk[j] >= 0 && (kk[j] >> 3) == kg);
-                int incl = mine;                               // inclusive prefix over the wave's lanes
+            for (int q = 0; q < PART_BATCH; q++) {
+                const bool ok = q0 + q < nm;
 #pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {
-                    const int t = __shfl_up(incl, o);
-                    if (lane >= o) incl += t;
-                }
-                if (lane == 63) wsum[it & 1][wv] = incl;
-                __syncthreads();
-                int wbase = wgn, tot = 0;
-#pragma unroll
-                for (int w = 0; w < 8; w++) {
-                    const int t = wsum[it & 1][w];
-                    if (w < wv) wbase += t;
-                    tot += t;
-                }
-                int pos = wbase + incl - mine;
-#pragma unroll
-                for (int j = 0; j < 4; j++)
-                    if (kk[j] >= 0 && (kk[j] >> 3) == kg) keys[pos++] = ((i0 + j) << 3) | (kk[j] & 7);
-                wgn += tot;
-            }
-            __syncthreads();
-            if (!active || (dbg & 1)) continue;
-            int nm = 0;          // wave-uniform length of the match list
-            for (int pb = 0; pb < wgn; pb += 256) {
-                // four entries per lane per iteration (entries pb + lane + 64 j): token order = j-major
-                int mt[4], ent[4];
-                unsigned long long bal[4];
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const int i = pb + lane + 64 * j;
-                    ent[j] = keys[i < wgn ? i : 0];
-                    mt[j] = (i < wgn) && ((ent[j] & 7) == wv);
-                    bal[j] = __ballot(mt[j]);
-                }
-                if (bal[0] | bal[1] | bal[2] | bal[3]) {
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        if (mt[j])
-                            mlist[nm + __popcll(bal[j] & ((1ull << lane) - 1ull))] = pc + (ent[j] >> 3);   // the token's POSITION: its id is fetched in the drain
-                        nm += __popcll(bal[j]);
-                    }
-                }
-                if (nm > PART_MLIST - 256 || (pb + 256 >= wgn && nm > 0)) {
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    for (int q0 = 0; q0 < nm && !(dbg & 2); q0 += PART_BATCH) {
-                        double xv[PART_BATCH][MAXR];
-#pragma unroll
-                        for (int q = 0; q < PART_BATCH; q++) {
-                            const int e = ctok_id[mlist[q0 + q < nm ? q0 + q : q0]];       // clamped: always valid
-#pragma unroll
-                            for (int r = 0; r < MAXR; r++) xv[q][r] = (double)X[(int64_t)e * c.ldx + dcl[r]];
-                        }
-#pragma unroll
-                        for (int q = 0; q < PART_BATCH; q++) {
-                            const bool ok = q0 + q < nm;
-#pragma unroll
-                            for (int r = 0; r < MAXR; r++) acc[r] += ok ? xv[q][r] : 0.0;
-                        }
-                    }
-                    cnt += nm;
-                    nm = 0;
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                }
+                for (int r = 0; r < MAXR; r++) acc[r] += ok ? xv[q][r] : 0.0;
             }
         }
-        if (active) {
 #pragma unroll
-            for (int r = 0; r < MAXR; r++) {
-                int d = d0 + r * 64 + lane;
-                if (d < D) part_sum[((int64_t)b * m.K_max + k) * D + d] = acc[r];
-            }
-            if (lane == 0 && d0 == 0) part_cnt[(int64_t)b * m.K_max + k] = cnt;
+        for (int r = 0; r < MAXR; r++) {
+            int d = d0 + r * 64 + lane;
+            if (d < D) part_sum[((int64_t)b * m.K_max + k) * D + d] = acc[r];
         }
     }
-    if (kg == 0 && !(dbg & 4)) {
-        // sequential (utterance order) sum of the block's totals, staged through LDS so that the
-        // single summing thread never waits on global memory
-        double *stage = reinterpret_cast<double *>(keys);
-        double s = 0.0;
-        for (int uc = u0; uc < u1; uc += PART_CHUNK / 2) {
-            const int nu = u1 - uc < PART_CHUNK / 2 ? u1 - uc : PART_CHUNK / 2;
-            __syncthreads();
-            for (int i = threadIdx.x; i < nu; i += blockDim.x) stage[i] = out_total[uc + i];
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                // strictly sequential adds; the LDS reads are issued 16 at a time
-                int i = 0;
-                for (; i + 16 <= nu; i += 16) {
-                    double v[16];
-#pragma unroll
-                    for (int q = 0; q < 16; q++) v[q] = stage[i + q];
-#pragma unroll
-                    for (int q = 0; q < 16; q++) s += v[q];
-                }
-                for (; i < nu; i++) s += stage[i];
-            }
-        }
-        if (threadIdx.x == 0) part_tot[b] = s;
-    }
+    if (lane == 0) part_cnt[(int64_t)b * m.K_max + k] = nm;
 }
 
-// Partials of block b live at  base + (b / nbl) * rank_stride + (b % nbl) * blk_stride
-// (units: 8-byte words): `nbl` blocks per rank, packed rank after rank by the all-gather.
-struct PartAddr {
-    int nbl;
-    int64_t rank_stride, blk_stride;
-    __device__ __forceinline__ int64_t operator()(int b) const
+// Record of block b inside the all-gathered buffer: `nbl` blocks per rank, ranks `rank_stride` words apart.
+struct PackAddr {
+    int nbl, K_max, D, cap;
+    int64_t rank_stride;
+    __device__ __forceinline__ int64_t rank_base(int b) const { return (int64_t)(b / nbl) * rank_stride; }
+    __device__ __forceinline__ int64_t sum(int b) const { return rank_base(b) + (int64_t)(b % nbl) * K_max * D; }
+    __device__ __forceinline__ int64_t tot(int b) const { return rank_base(b) + (int64_t)nbl * K_max * D + (b % nbl); }
+    __device__ __forceinline__ int64_t cnt(int b) const
     {
-        return (int64_t)(b / nbl) * rank_stride + (int64_t)(b % nbl) * blk_stride;
+        return rank_base(b) + (int64_t)nbl * K_max * D + nbl + (int64_t)(b % nbl) * K_max;
+    }
+    __device__ __forceinline__ int64_t flg(int b) const
+    {
+        return rank_base(b) + (int64_t)nbl * K_max * D + nbl + (int64_t)nbl * K_max + (int64_t)(b % nbl) * segk_flag_words(cap);
     }
 };
 
 // balanced binary tree over n <= 64 parts, pairing neighbours level by level, odd one carried
-__device__ __forceinline__ double tree_sum_d(const double *p, const PartAddr &pa, int n)
+// (np_oracle.tree_sum); v[] is consumed
+__device__ __forceinline__ double tree_reduce_d(double *v, int n)
 {
-    double buf[64];
-    for (int i = 0; i < n; i++) buf[i] = p[pa(i)];
     while (n > 1) {
         int o = 0;
-        for (int i = 0; i + 1 < n; i += 2) buf[o++] = buf[i] + buf[i + 1];
-        if (n & 1) buf[o++] = buf[n - 1];
+        for (int i = 0; i + 1 < n; i += 2) v[o++] = v[i] + v[i + 1];
+        if (n & 1) v[o++] = v[n - 1];
         n = o;
     }
-    return buf[0];
+    return v[0];
 }
 
-// (5a) combine the partials of all blocks, means = numerators / counts for active rows
-template <typename XT>
-__global__ void k_batch_combine(segk_corpus c, segk_kmeans m, const double *part_sum, const int64_t *part_cnt,
-                                const double *part_tot, int n_blocks, int nbl, int64_t rank_stride,
-                                double *out_scalars)
-{
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int D = c.D;
-    const int K = *m.K;
-    const PartAddr pa_sum{nbl, rank_stride, (int64_t)m.K_max * D};
-    const PartAddr pa_cnt{nbl, rank_stride, (int64_t)m.K_max};
-    const PartAddr pa_tot{nbl, rank_stride, 1};
-    if (idx < (int64_t)m.K_max * D) {
-        int k = (int)(idx / D);
-        double v = tree_sum_d(part_sum + idx, pa_sum, n_blocks);
-        int64_t cnt = 0;
-        for (int b = 0; b < n_blocks; b++) cnt += part_cnt[pa_cnt(b) + k];
-        m.mean_numerators[idx] = v;
-        if (k < K && cnt != 0) ((XT *)m.means)[idx] = (XT)(v / (double)cnt);
-        if (idx % D == 0) m.counts[k] = cnt;
-    }
-    if (idx == 0) out_scalars[0] = tree_sum_d(part_tot, pa_tot, n_blocks);
-}
+#define SEGK_FLAG_LDS 2048        /* flagged tokens of a sweep the finalize kernel can hold (all ranks together) */
+#define FIN_ROWS 8                /* final rows per workgroup */
 
-// (5b) clean_components (kmeans_components.py:263-266) with a relabel table instead of a scan
-//      of `assignments` per deletion.  Single workgroup: the empty rows are found in parallel
-//      (bitmap), then deleted one by one in descending order as the reference does;
-//      remap [K_max]: original label -> final row.  Also n_tokens = sum(counts).
 template <typename XT>
-__global__ void k_batch_clean(segk_corpus c, segk_kmeans m, int32_t *remap, double *out_scalars)
+__global__ __launch_bounds__(256) void k_batch_finalize(
+    segk_corpus c, segk_kmeans m, const double *pack, int n_blocks, int nbl, int64_t rank_stride, int cap, int my_rank,
+    int32_t *new_k, int32_t *remap, double *out_scalars, int32_t *status, unsigned long long *row_hash,
+    unsigned int *sp_zero_slot)
 {
-    // The reference deletes the empty components one at a time in descending order, each time moving
-    // the last active row into the hole (kmeans_components.py:129-151, 263-266).  Because the holes
-    // above the current one are already gone, the row that moves is never empty, every moved row
-    // originates at or above the final K and lands below it -- so the bookkeeping (which original row
-    // ends where) is replayed serially on indices only, and the rows are then moved in parallel.
-    __shared__ int shK, n_holes;
-    __shared__ unsigned int bitmap[256];             // K_max <= 8192
-    __shared__ unsigned short pos2orig[8192];        // position -> original row living there
-    __shared__ unsigned short holes[8192];           // hole positions, descending
-    __shared__ long long red[256];
-    const int tid = threadIdx.x, nt = blockDim.x;
-    const int D = c.D;
-    XT *means = (XT *)m.means;
-    const XT *rnd = (const XT *)m.random_means;
-    const int K0 = *m.K;
-    const int nwords = (K0 + 31) / 32;
-    for (int w = tid; w < nwords; w += nt) bitmap[w] = 0;
-    for (int k = tid; k < m.K_max; k += nt) remap[k] = k;
-    for (int k = tid; k < K0; k += nt) pos2orig[k] = (unsigned short)k;
-    __syncthreads();
+    extern __shared__ __attribute__((aligned(16))) unsigned char fin_lds[];
+    const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wv = tid >> 6;
+    const int K_max = m.K_max, D = c.D;
+    // dynamic LDS: counts [K_max] int32, pos2orig [K_max] u16, holes [K_max] u16, bitmap [K_max/32 + 1] u32, then the
+    // workgroup's rows [FIN_ROWS][D] as doubles (the values of `means`, exactly representable)
+    int32_t *cnt32 = reinterpret_cast<int32_t *>(fin_lds);
+    unsigned short *pos2orig = reinterpret_cast<unsigned short *>(cnt32 + K_max);
+    unsigned short *holes = pos2orig + K_max;
+    unsigned int *bitmap = reinterpret_cast<unsigned int *>(holes + K_max);      // 8 K_max bytes so far: 4-byte aligned
+    double *mrow = reinterpret_cast<double *>(fin_lds + (((size_t)K_max * 8 + ((size_t)K_max / 32 + 2) * 4 + 15) & ~(size_t)15));
+    __shared__ int32_t fl_slot[SEGK_FLAG_LDS], fl_row[SEGK_FLAG_LDS];
+    __shared__ unsigned short fl_k[SEGK_FLAG_LDS], fl_blk[SEGK_FLAG_LDS];
+    __shared__ int shK1, shK, n_holes, n_fl;
+    __shared__ int32_t fl_cnt[64];
+    __shared__ long long red[4];
+    const PackAddr pa{nbl, K_max, D, cap, rank_stride};
+    const int64_t *packi = reinterpret_cast<const int64_t *>(pack);
+    const int Kb = (int)out_scalars[3];            // K before the sweep (k_batch_sort); *m.K is rewritten by workgroup 0
+    const int wg = blockIdx.x;
+    const int j0 = wg * FIN_ROWS;
+
+    // ---- (0a) combined counts of the un-flagged tokens (labels < Kb): every load of a thread issued before the first use
     long long csum = 0;
-    for (int k = tid; k < m.K_max; k += nt) {
-        long long cn = m.counts[k];
-        csum += cn;
-        if (k < K0 && cn == 0) atomicOr(&bitmap[k >> 5], 1u << (k & 31));
+    if (n_blocks == 8) {
+        for (int k0 = 0; k0 < K_max; k0 += 4 * 256) {
+            long long v[4][8];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int k = k0 + u * 256 + tid;
+#pragma unroll
+                for (int b = 0; b < 8; b++) v[u][b] = packi[pa.cnt(b) + (k < K_max ? k : 0)];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int k = k0 + u * 256 + tid;
+                if (k < K_max) {
+                    long long cn = 0;
+#pragma unroll
+                    for (int b = 0; b < 8; b++) cn += v[u][b];
+                    cnt32[k] = (int32_t)cn;
+                    csum += cn;
+                }
+            }
+        }
+    } else {
+        for (int k = tid; k < K_max; k += nt) {
+            long long cn = 0;
+            for (int b = 0; b < n_blocks; b++) cn += packi[pa.cnt(b) + k];
+            cnt32[k] = (int32_t)cn;
+            csum += cn;
+        }
     }
-    red[tid] = csum;
+    // ---- (0b) the flagged tokens of all blocks in global token order: clamp replay by one thread (the blocks'
+    // counts are fetched side by side first: normally they are all zero and the replay is over at once)
+    if (tid < n_blocks) fl_cnt[tid] = reinterpret_cast<const int32_t *>(pack + pa.flg(tid))[0];
+    for (int o = 32; o > 0; o >>= 1) csum += __shfl_xor(csum, o);
+    if (lane == 0) red[wv] = csum;
     __syncthreads();
-    for (int o = nt >> 1; o > 0; o >>= 1) {
-        if (tid < o) red[tid] += red[tid + o];
-        __syncthreads();
-    }
     if (tid == 0) {
-        out_scalars[2] = (double)red[0];
-        int K = K0, nh = 0;
+        int K = Kb, nf = 0, over = 0;
+        for (int b = 0; b < n_blocks; b++) {
+            const int32_t *fl = reinterpret_cast<const int32_t *>(pack + pa.flg(b));
+            int cntb = fl_cnt[b];
+            if (cntb > cap) { over = 1; cntb = cap; }
+            for (int q = 0; q < cntb; q++) {
+                int k = fl[2 + 3 * q + 1];
+                if (k > K) k = K;
+                if (k == K) K++;
+                if (nf < SEGK_FLAG_LDS) {
+                    fl_slot[nf] = fl[2 + 3 * q + 0];
+                    fl_row[nf] = fl[2 + 3 * q + 2];
+                    fl_k[nf] = (unsigned short)k;
+                    fl_blk[nf] = (unsigned short)b;
+                    nf++;
+                } else {
+                    over = 1;
+                }
+            }
+        }
+        if (over && wg == 0) atomicOr(status, 4);
+        shK1 = K;
+        n_fl = nf;
+    }
+    __syncthreads();
+    const int K1 = shK1, nfl = n_fl;
+    for (int q = tid; q < nfl; q += nt) atomicAdd(&cnt32[fl_k[q]], 1);
+    const long long n_tokens = red[0] + red[1] + red[2] + red[3] + nfl;
+    // ---- (0c) clean_components on indices only.  The reference deletes the empty components one at a time
+    // in descending order, each time moving the last active row into the hole (kmeans_components.py:129-151,
+    // 263-266).  Because the holes above the current one are already gone, the row that moves is never empty,
+    // every moved row originates at or above the final K and lands below it.
+    const int nwords = (K1 + 31) / 32;
+    for (int w = tid; w < nwords; w += nt) bitmap[w] = 0;
+    for (int k = tid; k < K1; k += nt) pos2orig[k] = (unsigned short)k;
+    __syncthreads();
+    for (int k = tid; k < K1; k += nt)
+        if (cnt32[k] == 0) atomicOr(&bitmap[k >> 5], 1u << (k & 31));
+    __syncthreads();
+    if (tid == 0) {
+        int K = K1, nh = 0;
         for (int w = nwords - 1; w >= 0; w--) {
             unsigned int bits = bitmap[w];
             while (bits) {
@@ -574,49 +639,178 @@ __global__ void k_batch_clean(segk_corpus c, segk_kmeans m, int32_t *remap, doub
         n_holes = nh;
     }
     __syncthreads();
-    const int K = shK, nh = n_holes;
-    // move: one wave per filled hole below the final K
-    for (int h = tid >> 6; h < nh; h += nt >> 6) {
-        const int k = holes[h];
-        if (k >= K) continue;
-        const int src = pos2orig[k];
-        const double cnt = (double)m.counts[src];
-        for (int d = tid & 63; d < D; d += 64) {
-            const double v = m.mean_numerators[(int64_t)src * D + d];
-            m.mean_numerators[(int64_t)k * D + d] = v;
-            means[(int64_t)k * D + d] = (XT)(v / cnt);
+    const int K = shK;
+
+    // ---- workgroup 0 publishes the scalars, the relabel table and the resolved labels of the local flagged tokens
+    if (wg == 0) {
+        for (int k = tid; k < K_max; k += nt) remap[k] = k;
+        __syncthreads();
+        for (int h = tid; h < n_holes; h += nt) {
+            const int k = holes[h];
+            if (k < K) remap[pos2orig[k]] = k;
         }
-        if ((tid & 63) == 0) {
-            m.counts[k] = m.counts[src];
-            remap[src] = k;
+        for (int q = tid; q < nfl; q += nt)
+            if (fl_blk[q] / nbl == my_rank) new_k[fl_slot[q]] = fl_k[q];
+        if (tid == 0) {
+            double tv[64];
+            for (int b = 0; b < n_blocks; b++) tv[b] = pack[pa.tot(b)];
+            out_scalars[0] = tree_reduce_d(tv, n_blocks);
+            out_scalars[1] = (double)K;
+            out_scalars[2] = (double)n_tokens;
+            *m.K = K;
+            if (sp_zero_slot) *sp_zero_slot = 0u;          // E_m of the fp16 tile image: k_batch_post's atomic maximum
         }
+    }
+
+    // ---- (1) this workgroup's final rows, one element (row, dimension) per thread and step; the loads of four steps
+    // (32 with the default eight blocks) are issued together
+    XT *__restrict__ means = (XT *)m.means;
+    double *__restrict__ numer = m.mean_numerators;
+    const XT *__restrict__ rnd = (const XT *)m.random_means;
+    const XT *__restrict__ X = (const XT *)c.X;
+    const double *__restrict__ rpack = pack;
+    const int nel = FIN_ROWS * D;
+    for (int e0 = 0; e0 < nel; e0 += 4 * 256) {
+        double tv[4][8];
+        int cls[4], src[4];          // 0 nothing, 1 inactive row, 2 eight-block tree from the records, 3 general
+        int el[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int e = e0 + u * 256 + tid;
+            const int r = e / D, d = e - r * D, j = j0 + r;
+            cls[u] = 0;
+            src[u] = 0;
+            el[u] = e;
+            if (e < nel && j < K_max) {
+                if (j >= K) cls[u] = 1;
+                else {
+                    src[u] = pos2orig[j];
+                    cls[u] = (n_blocks == 8 && src[u] < Kb) ? 2 : 3;
+                }
+            }
+            const int64_t off = (int64_t)(cls[u] == 2 ? src[u] : 0) * D + (cls[u] == 2 ? d : 0);
+            if (n_blocks == 8) {
+#pragma unroll
+                for (int b = 0; b < 8; b++) tv[u][b] = rpack[pa.sum(b) + off];         // unconditional: always a valid address
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (cls[u] == 0) continue;
+            const int r = el[u] / D, d = el[u] - r * D;
+            const int64_t at = (int64_t)(j0 + r) * D + d;
+            if (cls[u] == 1) {                                 // inactive row (kmeans_components.py:163-166)
+                const XT rv = rnd[at];
+                numer[at] = 0.0;
+                means[at] = rv;
+                mrow[el[u]] = (double)rv;
+                continue;
+            }
+            double v;
+            if (cls[u] == 2) {
+                v = ((tv[u][0] + tv[u][1]) + (tv[u][2] + tv[u][3])) + ((tv[u][4] + tv[u][5]) + (tv[u][6] + tv[u][7]));
+            } else {
+                double gv[64];
+                if (src[u] < Kb) {
+                    for (int b = 0; b < n_blocks; b++) gv[b] = rpack[pa.sum(b) + (int64_t)src[u] * D + d];
+                } else {                                       // a component founded this sweep: its flagged tokens, block by block
+                    for (int b = 0; b < n_blocks; b++) gv[b] = 0.0;
+                    for (int q = 0; q < nfl; q++)
+                        if (fl_k[q] == src[u]) gv[fl_blk[q]] += (double)X[(int64_t)fl_row[q] * c.ldx + d];
+                }
+                v = tree_reduce_d(gv, n_blocks);
+            }
+            const XT mv = (XT)(v / (double)cnt32[src[u]]);
+            numer[at] = v;
+            means[at] = mv;
+            mrow[el[u]] = (double)mv;
+        }
+    }
+    if (tid < FIN_ROWS) {
+        const int j = j0 + tid;
+        if (j < K_max) m.counts[j] = j < K ? (int64_t)cnt32[pos2orig[j]] : 0;
     }
     __syncthreads();
-    // rows [K, K0) are inactive again
-    for (int64_t j = tid; j < (int64_t)(K0 - K) * D; j += nt) {
-        const int64_t row = K + j / D, d = j % D;
-        m.mean_numerators[row * D + d] = 0.0;
-        means[row * D + d] = rnd[row * D + d];
+    // ---- (2) this workgroup's part of the fp32 MFMA image (layout: segk_internal.h; the padding of the image -- dimensions
+    // beyond D, components beyond K_max -- never changes after segk_kmeans_prepare), |m|^2 maximum, row hashes: the
+    // arithmetic of dev_prepare_tile, 8 lanes per component
+    const int G = segk_gmax(D);
+    float *T = m.tiles + (int64_t)(j0 >> 5) * segk_tile_stride(D);
+    if (tid < FIN_ROWS * 8) {
+        const int r = tid >> 3, sub = tid & 7, comp = j0 + r;
+        double s = 0.0;
+        unsigned long long hh = 0ull;
+        if (comp < K_max)
+            for (int d = sub; d < D; d += 8) {
+                const double v = mrow[r * D + d];
+                s += v * v;
+                hh += segk_elem_hash(v, d);
+            }
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        s += __shfl_xor(s, 4);
+        hh += __shfl_xor(hh, 1);
+        hh += __shfl_xor(hh, 2);
+        hh += __shfl_xor(hh, 4);
+        if (sub == 0 && comp < K_max) {
+            T[G * 128 + (comp & 31)] = (float)(-0.5 * s);
+            atomicMax((unsigned long long *)m.mnorm_max, (unsigned long long)__double_as_longlong(s));
+            if (row_hash) row_hash[comp] = hh | 1ull;        // never 0: the empty key of the hash table
+        }
     }
-    for (int k = K + tid; k < K0; k += nt) m.counts[k] = 0;
-    if (tid == 0) {
-        *m.K = K;
-        out_scalars[1] = (double)K;
+    for (int e = tid; e < nel; e += nt) {
+        const int r = e / D, d = e - r * D, comp = j0 + r;
+        if (comp < K_max) T[(d >> 2) * 128 + ((((d >> 1) & 1) * 32 + (comp & 31)) << 1) + (d & 1)] = (float)mrow[e];
     }
 }
 
-// (5c) final labels of the local tokens
-__global__ void k_batch_relabel(segk_corpus c, int lo, int hi, int32_t *new_k, const int32_t *n_new,
-                                const int32_t *remap, double *zero_me)
+// final labels of the local tokens + (tile workgroups) split-precision image and duplicate marking
+template <typename XT, int P>
+__global__ __launch_bounds__(256) void k_batch_post(segk_corpus c, segk_kmeans m, int lo, int hi, int32_t *new_k, const int32_t *remap,
+                                                    int n_tiles, int stride32, int G, float *tiles_sp, int stride_sp, int sp_const_off,
+                                                    const unsigned long long *row_hash)
 {
-    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx == 0 && zero_me) *zero_me = 0.0;          // max |m|^2 of the prepare that follows on the stream (saves its memset)
-    int64_t tot = (int64_t)(hi - lo) * c.N_max;
-    if (idx >= tot) return;
-    int u = lo + (int)(idx / c.N_max), t = (int)(idx % c.N_max);
-    if (t < n_new[u]) {
-        int64_t p = (int64_t)u * c.N_max + t;
-        new_k[p] = remap[new_k[p]];
+    if ((int)blockIdx.x >= n_tiles) {
+        const int64_t idx = (int64_t)(blockIdx.x - n_tiles) * blockDim.x + threadIdx.x;
+        const int64_t p0 = (int64_t)lo * c.N_max, tot = (int64_t)(hi - lo) * c.N_max;
+        if (idx < tot) {
+            const int k = new_k[p0 + idx];
+            if (k >= 0) new_k[p0 + idx] = remap[k];
+        }
+        return;
+    }
+    const int tile = blockIdx.x;
+    if constexpr (P != 0) {
+        if (tiles_sp)
+            dev_prepare_sp_tile<P>((const float *)m.means, m.K_max, c.D, tiles_sp, m.mnorm_max, (const unsigned char *)c.Xb3,
+                                   (const double *)nullptr, tile);
+    }
+    if (!row_hash) return;
+    // clean_components leaves exact copies behind (the moved rows, the inactive rows): a duplicate with the higher
+    // index can never be np.argmax, but every embedding near the pair is a tie for the full scan -- its accumulator
+    // seed becomes the "absent" constant in both images (k_kmeans_mark_dups, one tile per workgroup here)
+    __shared__ unsigned long long keys[SEGK_DUP_TB];
+    __shared__ int32_t first[SEGK_DUP_TB];
+    dev_dup_table(keys, first, row_hash, m.K_max);            // ends with a barrier: the constants above are written
+    const XT *means = (const XT *)m.means;
+    const int tid = threadIdx.x, sub = tid & 7, D = c.D;
+    const int k = tile * 32 + (tid >> 3);
+    int i = -1;
+    if (k < m.K_max) {
+        i = dev_dup_first(keys, first, row_hash[k]);
+        if (i >= k) i = -1;
+    }
+    int eq = i >= 0;
+    if (i >= 0) {
+#pragma unroll 4
+        for (int d = sub; d < D; d += 8) eq &= means[(int64_t)i * D + d] == means[(int64_t)k * D + d];
+    }
+    eq &= __shfl_xor(eq, 1);
+    eq &= __shfl_xor(eq, 2);
+    eq &= __shfl_xor(eq, 4);
+    if (sub == 0 && i >= 0 && eq) {
+        m.tiles[(int64_t)tile * stride32 + G * 128 + (k & 31)] = -3.0e38f;
+        if (tiles_sp) tiles_sp[1024 + (int64_t)tile * stride_sp + sp_const_off + (k & 31)] = -3.0e38f;
     }
 }
 
@@ -785,89 +979,98 @@ int32_t segk_kmeans_del_component(segk_ctx *ctx, const segk_corpus *c, segk_kmea
     return segk_kmeans_prepare(ctx, c, m, stream);
 }
 
-int32_t segk_kmeans_batch_collect(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m, int32_t utt_lo,
-                                  int32_t utt_hi, const int32_t *new_k, const int32_t *n_new, const int32_t *n_flag,
-                                  int32_t *tok_off, int32_t *flag_buf, int32_t cap, void *stream)
+int64_t segk_kmeans_batch_record_words(int32_t K_max, int32_t D, int32_t n_blocks_local, int32_t flag_cap)
 {
-    (void)ctx;
-    int rc = check_corpus(c);
-    if (rc) return rc;
-    SEGK_REQUIRE(0 <= utt_lo && utt_lo <= utt_hi && utt_hi <= c->n_utt, "utterance range");
-    hipLaunchKernelGGL(k_batch_collect, dim3(1), dim3(1024), 0, (hipStream_t)stream, *c, *m, utt_lo, utt_hi, new_k,
-                       n_new, n_flag, tok_off, flag_buf, cap);
-    SEGK_LAUNCH_CHECK();
-    return SEGK_OK;
-}
-
-int32_t segk_kmeans_batch_assign(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m, int32_t utt_lo,
-                                 int32_t utt_hi, const int32_t *flag_all, int32_t n_ranks, int32_t my_rank,
-                                 int32_t cap, const int32_t *new_tok, int32_t *new_k, const int32_t *n_new,
-                                 const int32_t *tok_off, int32_t *ctok_id, int32_t *ctok_k, int32_t *status,
-                                 void *stream)
-{
-    (void)ctx;
-    int rc = check_corpus(c);
-    if (rc) return rc;
-    hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_batch_resolve, dim3(1), dim3(64), 0, st, *m, flag_all, n_ranks, my_rank, cap, new_k, status);
-    int64_t tot = (int64_t)(utt_hi - utt_lo) * c->N_max;
-    if (tot > 0)
-        hipLaunchKernelGGL(k_batch_compact, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, *c, utt_lo, utt_hi,
-                           new_tok, new_k, n_new, tok_off, ctok_id, ctok_k);
-    SEGK_LAUNCH_CHECK();
-    return SEGK_OK;
+    return (int64_t)n_blocks_local * ((int64_t)K_max * D + 1 + K_max + segk_flag_words(flag_cap));
 }
 
 int32_t segk_kmeans_batch_partials(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m,
-                                   const int32_t *blk_lo, int32_t n_blocks_local, int32_t utt_lo,
-                                   const int32_t *tok_off, const int32_t *ctok_id, const int32_t *ctok_k,
-                                   const double *out_total, double *part_sum, int64_t *part_cnt,
-                                   double *part_tot, void *stream)
+                                   const int32_t *blk_lo, int32_t n_blocks_local,
+                                   const int32_t *new_tok, const int32_t *new_k, const int32_t *n_flag,
+                                   const double *out_total, int32_t *sorted_scratch, int32_t *koff_scratch,
+                                   double *record, int32_t flag_cap, double *out_scalars, void *stream)
 {
     (void)ctx;
     int rc = check_corpus(c);
     if (rc) return rc;
     if (n_blocks_local <= 0) return SEGK_OK;
-    int64_t grid = (int64_t)n_blocks_local * ((m->K_max + 7) / 8);
-    DISPATCH_XT(c, hipLaunchKernelGGL(k_batch_partials<XT>, dim3((unsigned)grid), dim3(512), 0, (hipStream_t)stream,
-                                       *c, *m, blk_lo, n_blocks_local, utt_lo, tok_off, ctok_id, ctok_k, out_total,
-                                       part_sum, part_cnt, part_tot,
-                                       getenv("SEGK_PART_DBG") ? atoi(getenv("SEGK_PART_DBG")) : 0););
+    SEGK_REQUIRE(blk_lo && new_tok && new_k && n_flag && out_total && record && out_scalars && sorted_scratch && koff_scratch,
+                 "batch_partials operands");
+    SEGK_REQUIRE(flag_cap >= 1, "flag_cap");
+    SEGK_REQUIRE(m->K_max <= 8192, "batch mode supports K_max <= 8192");
+    const int64_t nbl = n_blocks_local, KD = (int64_t)m->K_max * c->D;
+    double *part_sum = record;
+    double *part_tot = record + nbl * KD;
+    int64_t *part_cnt = reinterpret_cast<int64_t *>(record + nbl * KD + nbl);
+    int32_t *flags = reinterpret_cast<int32_t *>(record + nbl * KD + nbl + nbl * m->K_max);
+    hipStream_t st = (hipStream_t)stream;
+    const int nw = m->K_max <= 1024 ? 16 : m->K_max <= 2048 ? 8 : m->K_max <= 4096 ? 4 : 2;
+    size_t lds = (size_t)(m->K_max + 2) * 4 + (size_t)nw * m->K_max * 4 + (size_t)SORT_KEYS_LDS * 2;
+    if (lds < 2048 * sizeof(double)) lds = 2048 * sizeof(double);
+    static size_t lds_set = 0;
+    if (lds > 48 * 1024 && lds > lds_set) {
+        SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_batch_sort, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        lds_set = lds;
+    }
+    hipLaunchKernelGGL(k_batch_sort, dim3((unsigned)(2 * nbl)), dim3(SORT_THREADS), lds, st, *c, *m, blk_lo, n_blocks_local, new_tok,
+                       new_k, n_flag, out_total, sorted_scratch, koff_scratch, part_tot, flags, flag_cap, out_scalars);
+    const int64_t grid = nbl * ((m->K_max + 7) / 8);
+    DISPATCH_XT(c, hipLaunchKernelGGL(k_batch_partials<XT>, dim3((unsigned)grid), dim3(512), 0, st, *c, *m, blk_lo,
+                                       n_blocks_local, new_tok, sorted_scratch, koff_scratch, part_sum, part_cnt););
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;
 }
 
 int32_t segk_kmeans_batch_finalize(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m, int32_t utt_lo,
-                                   int32_t utt_hi, const double *part_sum, const int64_t *part_cnt,
-                                   const double *part_tot, int32_t n_blocks_total, int32_t n_blocks_per_rank,
-                                   int64_t rank_stride, int32_t *new_k, const int32_t *n_new,
-                                   int32_t *remap_scratch, double *out_scalars, int32_t *status, void *stream)
+                                   int32_t utt_hi, const double *records, int32_t n_blocks_total,
+                                   int32_t n_blocks_per_rank, int64_t rank_stride, int32_t flag_cap, int32_t my_rank,
+                                   int32_t *new_k, int32_t *remap_scratch, double *out_scalars, int32_t *status,
+                                   void *stream)
 {
-    (void)status;
     int rc = check_corpus(c);
     if (rc) return rc;
     SEGK_REQUIRE(n_blocks_total >= 1 && n_blocks_total <= 64, "1 <= n_blocks_total <= 64");
     SEGK_REQUIRE(n_blocks_per_rank >= 1 && n_blocks_total % n_blocks_per_rank == 0, "blocks per rank");
     SEGK_REQUIRE(m->K_max <= 8192, "batch mode supports K_max <= 8192");
+    SEGK_REQUIRE(records && new_k && remap_scratch && out_scalars && status && m->tiles && m->mnorm_max, "batch_finalize operands");
+    SEGK_REQUIRE(0 <= utt_lo && utt_lo <= utt_hi && utt_hi <= c->n_utt, "utterance range");
     hipStream_t st = (hipStream_t)stream;
-    int64_t tot = (int64_t)m->K_max * c->D;
-    DISPATCH_XT(c, {
-        hipLaunchKernelGGL(k_batch_combine<XT>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, *c, *m,
-                           part_sum, part_cnt, part_tot, n_blocks_total, n_blocks_per_rank, rank_stride, out_scalars);
-        hipLaunchKernelGGL(k_batch_clean<XT>, dim3(1), dim3(256), 0, st, *c, *m, remap_scratch, out_scalars);
-    });
-    int64_t nslot = (int64_t)(utt_hi - utt_lo) * c->N_max;
-    if (nslot > 0)
-        hipLaunchKernelGGL(k_batch_relabel, dim3((unsigned)((nslot + 255) / 256)), dim3(256), 0, st, *c, utt_lo,
-                           utt_hi, new_k, n_new, remap_scratch, (double *)m->mnorm_max);
-    SEGK_LAUNCH_CHECK();
-    rc = segk_kmeans_prepare_impl(ctx, c, m, stream, /* mnorm_max already zero */ nslot > 0);
-    if (rc) return rc;
-    // clean_components leaves exact copies behind (the moved rows, the inactive rows): out of the filters' images,
-    // or every embedding near such a pair is a tie for the full scan.  SEGK_MARK_DUPS=0: leave them in.
+    // value hashes of the rows, for the duplicate marking (context-owned, K_max <= 2048 only; SEGK_MARK_DUPS=0: leave
+    // the duplicates in the filters' images)
     const char *md = getenv("SEGK_MARK_DUPS");
-    if (md && atoi(md) == 0) return SEGK_OK;
-    return segk_kmeans_mark_duplicates(ctx, c, m, nullptr, stream);
+    unsigned long long *row_hash = nullptr;
+    if (ctx && m->K_max <= 2048) {
+        if (!ctx->row_hash) SEGK_CHECK_HIP(hipMalloc((void **)&ctx->row_hash, 2048 * sizeof(unsigned long long)));
+        ctx->row_hash_means = m->means;
+        if (!(md && atoi(md) == 0)) row_hash = ctx->row_hash;
+    }
+    const bool sp = m->tiles_b3 && c->Xb3 && c->x_dtype == SEGK_F32 && c->D >= 8 && c->D <= 128 && (c->sp_pieces == 2 || c->sp_pieces == 3);
+    const int n_tiles = segk_n_tiles(m->K_max);
+    const size_t lds = (((size_t)m->K_max * 8 + ((size_t)m->K_max / 32 + 2) * 4 + 15) & ~(size_t)15) + (size_t)FIN_ROWS * c->D * sizeof(double);
+    DISPATCH_XT(c, {
+        if (lds > 32 * 1024)
+            SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_batch_finalize<XT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_batch_finalize<XT>, dim3((m->K_max + FIN_ROWS - 1) / FIN_ROWS), dim3(256), lds, st, *c, *m, records,
+                           n_blocks_total, n_blocks_per_rank, rank_stride, flag_cap, my_rank, new_k, remap_scratch, out_scalars,
+                           status, ctx && m->K_max <= 2048 ? ctx->row_hash : (unsigned long long *)nullptr,
+                           sp ? (unsigned int *)m->tiles_b3 + 1 : (unsigned int *)nullptr);
+    });
+    const int64_t nslot = (int64_t)(utt_hi - utt_lo) * c->N_max;
+    const unsigned grid = (unsigned)(n_tiles + (nslot + 255) / 256);
+    const int kp = segk_b3_kp(c->D);
+    const int stride32 = segk_tile_stride(c->D), G = segk_gmax(c->D);
+    const int stride_sp = sp ? segk_sp_tile_stride(c->D, c->sp_pieces) : 0, sp_off = sp ? (kp / 16) * c->sp_pieces * 256 : 0;
+    if (sp && c->sp_pieces == 2)
+        hipLaunchKernelGGL((k_batch_post<float, 2>), dim3(grid), dim3(256), 0, st, *c, *m, utt_lo, utt_hi, new_k, remap_scratch,
+                           n_tiles, stride32, G, m->tiles_b3, stride_sp, sp_off, row_hash);
+    else if (sp)
+        hipLaunchKernelGGL((k_batch_post<float, 3>), dim3(grid), dim3(256), 0, st, *c, *m, utt_lo, utt_hi, new_k, remap_scratch,
+                           n_tiles, stride32, G, m->tiles_b3, stride_sp, sp_off, row_hash);
+    else
+        DISPATCH_XT(c, hipLaunchKernelGGL((k_batch_post<XT, 0>), dim3(grid), dim3(256), 0, st, *c, *m, utt_lo, utt_hi, new_k,
+                                           remap_scratch, n_tiles, stride32, G, (float *)nullptr, 0, 0, row_hash););
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
 }
 
 int32_t segk_kmeans_assignments_from_tokens(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m,

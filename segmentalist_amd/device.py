@@ -148,6 +148,10 @@ class DeviceKMeans(object):
                                  queue=self.cand_queue.data_ptr(), count=self.cand_count.data_ptr())
         self.status = torch.zeros(8, dtype=torch.int32, device=dev)
         self.assign_stale = None
+        # multi-rank batch sweeps: the process group of the sweeper (ensure_assignments / ensure_boundaries are
+        # collectives on it) and the boundary buffer whose rows of other ranks' utterances are out of date
+        self.batch_group = None
+        self.bounds_stale = None
         self._L = _abi.lib()
         self._ctx = _abi.ctx()
         check(self._L.segk_kmeans_init_stats(self._ctx, C.byref(c.c), C.byref(self.m), _abi.stream()))
@@ -170,9 +174,6 @@ class DeviceKMeans(object):
         self.utt_arange = torch.arange(nu, dtype=torch.int32, device=dev)
         self.remap = torch.zeros(self.K_max, dtype=torch.int32, device=dev)
         self.out_scalars = torch.zeros(4, dtype=torch.float64, device=dev)
-        self.tok_off = torch.zeros(nu + 1, dtype=torch.int32, device=dev)
-        self.ctok_id = torch.zeros(nu * nm, dtype=torch.int32, device=dev)
-        self.ctok_k = torch.zeros(nu * nm, dtype=torch.int32, device=dev)
         # batch sweeps leave `assignments` untouched: `assign_stale` = (lo, hi, world) of the token
         # lists it must be rebuilt from, or None when it is current
 
@@ -181,9 +182,14 @@ class DeviceKMeans(object):
         return C.byref(self.corpus.c)
 
     def ensure_assignments(self, group=None):
-        """Materialise `assignments` after batch sweeps (they only maintain the token lists)."""
+        """Materialise `assignments` after batch sweeps (they only maintain the token lists).  With more than
+        one rank this is a COLLECTIVE on the sweeper's process group (every rank holds the tokens of its own
+        utterances only): all ranks must call it -- directly or through `components.assignments`,
+        `sum_neg_sqrd_norm()`, `state_dict()` ... -- together."""
         if self.assign_stale is None:
             return
+        if group is None:
+            group = self.batch_group
         lo, hi, world = self.assign_stale
         check(self._L.segk_kmeans_assignments_from_tokens(self._ctx, self._cp(), C.byref(self.m), lo, hi,
                                                           ptr(self.new_tok), ptr(self.new_k), ptr(self.n_new),
@@ -197,6 +203,26 @@ class DeviceKMeans(object):
                 dist.all_reduce(h, op=dist.ReduceOp.MAX, group=group)
                 self.assignments.copy_(h)
         self.assign_stale = None
+
+    def ensure_boundaries(self):
+        """After multi-rank batch sweeps every rank has resegmented its own utterances only: fetch the rows of
+        the others (COLLECTIVE on the sweeper's process group, like ensure_assignments), so that
+        `utterances.boundaries`, transcripts and checkpoints are the same, complete state on every rank."""
+        if self.bounds_stale is None:
+            return
+        bounds, pt = self.bounds_stale
+        torch = _torch()
+        import torch.distributed as dist
+        mine = torch.zeros_like(bounds)
+        mine[pt.utt_lo:pt.utt_hi] = bounds[pt.utt_lo:pt.utt_hi]
+        if dist.get_backend(self.batch_group) == "nccl":
+            dist.all_reduce(mine, op=dist.ReduceOp.MAX, group=self.batch_group)
+            bounds.copy_(mine)
+        else:
+            h = mine.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.MAX, group=self.batch_group)
+            bounds.copy_(h)
+        self.bounds_stale = None
 
     def prepare(self):
         check(self._L.segk_kmeans_prepare(self._ctx, self._cp(), C.byref(self.m), _abi.stream()))
@@ -342,54 +368,126 @@ def all_gather_rows(out, inp, group=None):
 
 
 class KMeansBatchSweeper(object):
-    """One batch-synchronous sweep = score -> segment -> collect -> [all-gather flags] -> assign
-    -> partials -> [all-gather partials] -> finalize, all enqueued on the current stream.
-    With world == 1 there is no collective; with world > 1 the two all-gathers move
-    (1 + 2*flag_cap) int32 and nbl*(K_max*(D+1)+1) 8-byte words per rank over RCCL."""
+    """One batch-synchronous sweep = score -> segment -> partials -> [ONE all-gather] -> finalize, all enqueued
+    on the current stream.  With world == 1 there is no collective; with world > 1 every rank contributes one
+    packed record -- the partial sums, totals and counts of its statistics blocks and, per block, the (normally
+    empty) list of tokens that found new components -- of segk_kmeans_batch_record_words() 8-byte words
+    (nbl * (K_max * (D + 1) + 1 + flag words): 0.8 MB per rank at 8 GPUs on the headline corpus) over RCCL."""
 
     def __init__(self, dk, part, flag_cap=4096, group=None):
         torch = _torch()
         dev = _dev()
         self.dk, self.part, self.cap, self.group = dk, part, int(flag_cap), group
         c = dk.corpus
-        K, D, nbl, W = dk.K_max, c.D, part.nbl, part.world
-        self.rank_stride = nbl * K * D + nbl + nbl * K       # 8-byte words
+        W = part.world
+        self.rank_stride = int(dk._L.segk_kmeans_batch_record_words(dk.K_max, c.D, part.nbl, self.cap))
         self.pack_all = torch.zeros((W, self.rank_stride), dtype=torch.float64, device=dev)
         self.pack = self.pack_all[part.rank]
-        self.flag_all = torch.zeros((W, 1 + 2 * self.cap), dtype=torch.int32, device=dev)
-        self.flag = self.flag_all[part.rank]
         self.blk_lo = to_dev(part.local_bounds, np.int32)
-        base = self.pack.data_ptr()
-        self._p_sum = C.c_void_p(base)
-        self._p_tot = C.c_void_p(base + 8 * (nbl * K * D))
-        self._p_cnt = C.c_void_p(base + 8 * (nbl * K * D + nbl))
-        base0 = self.pack_all.data_ptr()
-        self._a_sum = C.c_void_p(base0)
-        self._a_tot = C.c_void_p(base0 + 8 * (nbl * K * D))
-        self._a_cnt = C.c_void_p(base0 + 8 * (nbl * K * D + nbl))
+        self.sorted = torch.zeros(max(c.n_utt * c.N_max, 1), dtype=torch.int32, device=dev)
+        self.koff = torch.zeros(part.nbl * (dk.K_max + 1), dtype=torch.int32, device=dev)
+        # SEGK_SWEEP_GRAPH=1: the sweep replayed as a hipGraph from its second run on.  Default 0: measured on MI355X
+        # the replay is SLOWER than the plain launches it replaces (full corpus 0.661 vs 0.634 ms per sweep, a
+        # 1 250-utterance shard 0.258 vs 0.216 ms: the launches of sweep i + 1 are enqueued while sweep i runs, so
+        # their host cost is already hidden, and a replay adds ~10 us of its own -- profiles/README.md r02_b)
+        import os
+        self.use_graph = os.environ.get("SEGK_SWEEP_GRAPH", "0") == "1"
+        self._graph, self._graph_args, self._side, self._warm = None, None, None, 0
+        dk.batch_group = group
 
-    def sweep(self, boundaries, n_slices_min, n_slices_max, wip):
+    def _enqueue_front(self, boundaries, n_slices_min, n_slices_max, wip):
         dk, pt = self.dk, self.part
         L, ctx, cp, mp, st = dk._L, dk._ctx, dk._cp(), C.byref(dk.m), _abi.stream()
         dk.score_rows(row0=pt.row_lo, n=pt.row_hi - pt.row_lo)
         dk.segment(boundaries, n_slices_min, n_slices_max, wip, utt0=pt.utt_lo, n_utts=pt.utt_hi - pt.utt_lo)
-        check(L.segk_kmeans_batch_collect(ctx, cp, mp, pt.utt_lo, pt.utt_hi, ptr(dk.new_k), ptr(dk.n_new),
-                                          ptr(dk.n_flag), ptr(dk.tok_off), ptr(self.flag), self.cap, st))
-        if pt.world > 1:
-            all_gather_rows(self.flag_all, self.flag, self.group)
-        check(L.segk_kmeans_batch_assign(ctx, cp, mp, pt.utt_lo, pt.utt_hi, ptr(self.flag_all), pt.world,
-                                         pt.rank, self.cap, ptr(dk.new_tok), ptr(dk.new_k), ptr(dk.n_new),
-                                         ptr(dk.tok_off), ptr(dk.ctok_id), ptr(dk.ctok_k), ptr(dk.status), st))
-        check(L.segk_kmeans_batch_partials(ctx, cp, mp, ptr(self.blk_lo), pt.nbl, pt.utt_lo, ptr(dk.tok_off),
-                                           ptr(dk.ctok_id), ptr(dk.ctok_k), ptr(dk.out_total), self._p_sum,
-                                           self._p_cnt, self._p_tot, st))
-        if pt.world > 1:
-            all_gather_rows(self.pack_all, self.pack, self.group)
-        check(L.segk_kmeans_batch_finalize(ctx, cp, mp, pt.utt_lo, pt.utt_hi, self._a_sum, self._a_cnt,
-                                           self._a_tot, pt.n_blocks, pt.nbl, self.rank_stride,
-                                           ptr(dk.new_k), ptr(dk.n_new), ptr(dk.remap), ptr(dk.out_scalars),
-                                           ptr(dk.status), st))
+        check(L.segk_kmeans_batch_partials(ctx, cp, mp, ptr(self.blk_lo), pt.nbl, ptr(dk.new_tok), ptr(dk.new_k),
+                                           ptr(dk.n_flag), ptr(dk.out_total), ptr(self.sorted), ptr(self.koff),
+                                           ptr(self.pack), self.cap, ptr(dk.out_scalars), st))
+
+    def _enqueue_back(self):
+        dk, pt = self.dk, self.part
+        L, ctx, cp, mp, st = dk._L, dk._ctx, dk._cp(), C.byref(dk.m), _abi.stream()
+        check(L.segk_kmeans_batch_finalize(ctx, cp, mp, pt.utt_lo, pt.utt_hi, ptr(self.pack_all), pt.n_blocks, pt.nbl,
+                                           self.rank_stride, self.cap, pt.rank, ptr(dk.new_k), ptr(dk.remap),
+                                           ptr(dk.out_scalars), ptr(dk.status), st))
+
+    def sweep(self, boundaries, n_slices_min, n_slices_max, wip):
+        dk, pt = self.dk, self.part
+        if self.use_graph:
+            self._sweep_graph(boundaries, n_slices_min, n_slices_max, wip)
+        else:
+            self._enqueue_front(boundaries, n_slices_min, n_slices_max, wip)
+            if pt.world > 1:
+                all_gather_rows(self.pack_all, self.pack, self.group)
+            self._enqueue_back()
         dk.assign_stale = (pt.utt_lo, pt.utt_hi, pt.world)
+        dk.bounds_stale = (boundaries, pt) if pt.world > 1 else None
+
+    # ------------------------------------------------------------------ hipGraph replay
+    def _capture(self, fn):
+        """Run `fn` (library launches only) under stream capture on the sweeper's side stream -> executable graph."""
+        dk = self.dk
+        st = _abi.stream()
+        check(dk._L.segk_graph_begin(dk._ctx, st))
+        try:
+            fn()
+        finally:
+            ex = C.c_void_p()
+            rc = dk._L.segk_graph_end(dk._ctx, st, C.byref(ex))
+        check(rc)
+        return ex
+
+    def _sweep_graph(self, boundaries, n_slices_min, n_slices_max, wip):
+        """The sweep as one hipGraph (two around the all-gather with more than one rank), replayed on a stream of
+        the sweeper's own (a capture cannot run on the legacy default stream); the caller's current stream is
+        ordered before and after it.  The first sweep runs eagerly: it creates what a capture cannot contain
+        (workspaces, the second stream, kernel attributes)."""
+        torch = _torch()
+        dk, pt = self.dk, self.part
+        args = (boundaries.data_ptr(), int(n_slices_min), int(n_slices_max), float(wip))
+        cur = torch.cuda.current_stream()
+        if self._side is None:
+            self._side = torch.cuda.Stream()
+        self._side.wait_stream(cur)
+        with torch.cuda.stream(self._side):
+            if self._warm < 1 or (self._graph is not None and self._graph_args != args):
+                self._drop_graph()
+            if self._warm < 1:
+                self._enqueue_front(boundaries, n_slices_min, n_slices_max, wip)
+                if pt.world > 1:
+                    all_gather_rows(self.pack_all, self.pack, self.group)
+                self._enqueue_back()
+                self._warm += 1
+            else:
+                if self._graph is None:
+                    if pt.world > 1:
+                        front = self._capture(lambda: self._enqueue_front(boundaries, n_slices_min, n_slices_max, wip))
+                        back = self._capture(self._enqueue_back)
+                        self._graph = (front, back)
+                    else:
+                        def whole():
+                            self._enqueue_front(boundaries, n_slices_min, n_slices_max, wip)
+                            self._enqueue_back()
+                        self._graph = (self._capture(whole),)
+                    self._graph_args = args
+                st = _abi.stream()
+                check(dk._L.segk_graph_launch(dk._ctx, self._graph[0], st))
+                if pt.world > 1:
+                    all_gather_rows(self.pack_all, self.pack, self.group)
+                    check(dk._L.segk_graph_launch(dk._ctx, self._graph[1], st))
+        cur.wait_stream(self._side)
+
+    def _drop_graph(self):
+        if self._graph is not None:
+            for ex in self._graph:
+                self.dk._L.segk_graph_destroy(self.dk._ctx, ex)
+        self._graph = None
+
+    def __del__(self):
+        try:
+            self._drop_graph()
+        except Exception:
+            pass
 
 
 class DeviceFbgmm(object):

@@ -90,7 +90,7 @@ class SegmentalKMeansWordseg(object):
         self.acoustic_model = KMeans(embeddings, am_K, assignments, _corpus=self._corpus)
         self._dk = self.acoustic_model.components.dev
         self._dev_bounds = to_dev(u.boundaries.astype(np.uint8))
-        u.bind_device(self._dev_bounds)
+        u.bind_device(self._dev_bounds, refresh=self._dk.ensure_boundaries)
         self._row_start = vec_ids.row_start
 
         # batch mode plumbing (single process unless torch.distributed is initialised)

@@ -68,9 +68,11 @@ class Utterances(object):
                         break
 
     # ---------------------------------------------------------------- device mirroring
-    def bind_device(self, dev_boundaries):
-        """`dev_boundaries`: torch uint8 [D, N_max] owned by the segmenter."""
+    def bind_device(self, dev_boundaries, refresh=None):
+        """`dev_boundaries`: torch uint8 [D, N_max] owned by the segmenter.  `refresh`: called before the device
+        buffer is read back (multi-rank batch mode: fetches the rows other ranks own -- a collective)."""
         self._dev_boundaries = dev_boundaries
+        self._dev_refresh = refresh
 
     def mark_device_dirty(self):
         self._host_stale = True
@@ -78,6 +80,8 @@ class Utterances(object):
     @property
     def boundaries(self):
         if self._host_stale and self._dev_boundaries is not None:
+            if getattr(self, "_dev_refresh", None) is not None:
+                self._dev_refresh()
             self._boundaries = self._dev_boundaries.cpu().numpy().astype(bool)
             self._host_stale = False
         return self._boundaries

@@ -27,23 +27,28 @@ def main():
     np.random.seed(11)
     seg = kaw.SegmentalKMeansWordseg(40, *corpus, n_slices_max=5, init_am_assignments="rand", sync="batch",
                                      n_stat_blocks=8)
+    # optional: --load CKPT resumes from a checkpoint (possibly written under another world size) before sweeping,
+    # --save CKPT writes one after the sweeps (every rank builds it: state_dict() is a collective; rank 0 stores it)
+    extra = sys.argv[4:]
+    load = extra[extra.index("--load") + 1] if "--load" in extra else None
+    save = extra[extra.index("--save") + 1] if "--save" in extra else None
+    if load:
+        import pickle
+        seg.load_state_dict(pickle.load(open(load, "rb")))
     rec = seg.segment(n_sweeps)
     c = seg.acoustic_model.components
     state = dict(assignments=c.assignments, means=c.means, mean_numerators=c.mean_numerators, counts=c.counts,
                  K=np.array(c.K), totals=np.array(rec["sum_neg_len_sqrd_norm"]),
                  n_tokens=np.array(rec["n_tokens"]))
-    # boundaries of the utterances owned by other ranks live on those ranks: gather them
-    b = seg._dev_bounds.cpu()
-    if world > 1:
-        gathered = [torch.empty_like(b) for _ in range(world)]
-        dist.all_gather(gathered, b)
-        part = seg._get_sweeper().part
-        full = b.clone()
-        for r in range(world):
-            lo, hi = int(part.bounds[r * part.nbl]), int(part.bounds[(r + 1) * part.nbl])
-            full[lo:hi] = gathered[r][lo:hi]
-        b = full
-    state["boundaries"] = b.numpy()
+    # the boundaries of the utterances owned by other ranks are fetched by the product (a collective: every rank
+    # reads the attribute)
+    state["boundaries"] = seg.utterances.boundaries.astype(np.uint8)
+    sd = seg.state_dict()
+    assert np.array_equal(sd["boundaries"], seg.utterances.boundaries)
+    assert np.array_equal(sd["km_assignments"], c.assignments)
+    if save and rank == 0:
+        import pickle
+        pickle.dump(sd, open(save, "wb"))
     if rank == 0:
         np.savez(out_path, **state)
     if world > 1:

@@ -34,6 +34,19 @@ def test_batch_mode_is_independent_of_the_number_of_ranks(tmp_path):
             assert np.array_equal(ref[k], got[k]), (world, k)
 
 
+def test_checkpoint_written_under_one_world_size_resumes_under_another(tmp_path):
+    """state_dict() under 2 ranks holds the complete state (boundaries and assignments of every rank's utterances,
+    ADVICE r01): resumed under 1 and under 4 ranks it continues exactly like the uninterrupted single-rank chain."""
+    ref = run(1, str(tmp_path / "c_ref.npz"), 3)
+    ck = str(tmp_path / "ck.pkl")
+    run(2, str(tmp_path / "c_a.npz"), 2, extra=["--save", ck])
+    for world in (1, 4):
+        got = run(world, str(tmp_path / ("c_b%d.npz" % world)), 1, extra=["--load", ck])
+        for k in ("assignments", "means", "mean_numerators", "counts", "K", "boundaries"):
+            assert np.array_equal(ref[k], got[k]), (world, k)
+        assert ref["totals"][-1] == got["totals"][-1]
+
+
 def test_batch_mode_with_the_prefilter_forced_is_independent_of_the_number_of_ranks(tmp_path):
     """The same with SEGK_SCORE_PRE=1: every rank scores its row range (first row > 0 on ranks > 0) through
     the one-product pre-filter, the exact pair kernel and the second stage on the second stream; the result

@@ -95,23 +95,27 @@ def main():
     for name, fn in stages:
         med, mn = timeit(fn, reps=5, warm=1)
         print("%-10s median %.3f ms  min %.3f ms" % (name, med, mn))
-    # batch statistics stages one by one (state left as the last full sweep produced it)
-    def collect():
-        check(L.segk_kmeans_batch_collect(ctx, cp, mp, pt.utt_lo, pt.utt_hi, ptr(dk.new_k), ptr(dk.n_new),
-                                          ptr(dk.n_flag), ptr(dk.tok_off), ptr(sw.flag), sw.cap, st))
-
-    def assign():
-        check(L.segk_kmeans_batch_assign(ctx, cp, mp, pt.utt_lo, pt.utt_hi, ptr(sw.flag_all), pt.world, pt.rank,
-                                         sw.cap, ptr(dk.new_tok), ptr(dk.new_k), ptr(dk.n_new), ptr(dk.tok_off),
-                                         ptr(dk.ctok_id), ptr(dk.ctok_k), ptr(dk.status), st))
-
+    # batch statistics stages one by one (state left as the last full sweep produced it; finalize relabels new_k
+    # in place, so it is timed once on a state its partials call has just prepared)
     def partials():
-        check(L.segk_kmeans_batch_partials(ctx, cp, mp, ptr(sw.blk_lo), pt.nbl, pt.utt_lo, ptr(dk.tok_off),
-                                           ptr(dk.ctok_id), ptr(dk.ctok_k), ptr(dk.out_total), sw._p_sum,
-                                           sw._p_cnt, sw._p_tot, st))
-    for name, fn in [("collect", collect), ("assign", assign), ("partials", partials)]:
-        med, mn = timeit(fn, reps=5, warm=1)
-        print("%-10s median %.3f ms  min %.3f ms" % (name, med, mn))
+        check(L.segk_kmeans_batch_partials(ctx, cp, mp, ptr(sw.blk_lo), pt.nbl, ptr(dk.new_tok), ptr(dk.new_k),
+                                           ptr(dk.n_flag), ptr(dk.out_total), ptr(sw.sorted), ptr(sw.koff),
+                                           ptr(sw.pack), sw.cap, ptr(dk.out_scalars), st))
+
+    def back():
+        dk.score_rows()
+        dk.segment(seg._dev_bounds, 0, 6, 0.0)
+        partials()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        sw._enqueue_back()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1)
+    med, mn = timeit(partials, reps=5, warm=1)
+    print("%-10s median %.3f ms  min %.3f ms" % ("partials", med, mn))
+    ts = sorted(back() for _ in range(5))
+    print("%-10s median %.3f ms  min %.3f ms" % ("finalize+post", ts[2], ts[0]))
     for dbg in (1, 2, 4, 7):       # timing-only ablations inside the partials kernel
         os.environ["SEGK_PART_DBG"] = str(dbg)
         med, mn = timeit(partials, reps=5, warm=1)
