@@ -4,8 +4,9 @@ bench.py -- Gibbs/segmental-k-means sweeps per second on BASELINE.json config 3:
 SegmentalKMeansWordseg, 10 000 utterances x 20 landmarks (n_slices_max = 6 -> 105 candidate
 spans each, 1.05 M embeddings), D = 100, K = 1000, synthetic unit-norm float32 embeddings
 (SURVEY.md 8(d)), batch-synchronous sweeps, sharded over N GPUs (strong scaling:
-the corpus is fixed, each rank owns 1/N of the utterances; two small RCCL all-gathers per
-sweep).
+the corpus is fixed, each rank owns 1/N of the utterances; one small RCCL all-gather per
+sweep).  `--windows` (default 9) back-to-back windows of exactly `--steps` sweeps are timed, each
+bracketed by barrier + synchronize; the line reports the median window and the spread.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -33,6 +34,60 @@ PEAK_FP32_MATRIX_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f3
 PEAK_BF16_MATRIX_TFLOPS = 2516.6    # v_mfma_f32_32x32x16_bf16: 256 CUs x 4 SIMDs x 512 MAC/clk x 2 x 2.4 GHz ("~2.5 PF dense")
 
 
+def cpu_blas_courtesy(corpus, n_utts_total, K, n_slices_max, budget_utts):
+    """NOT the reference: a BLAS-vectorised CPU version of the same batch sweep (one sgemm scores every
+    embedding of the sample against every mean via |x|^2 - 2 x.m + |m|^2, the C oracle's Viterbi per utterance,
+    vectorised statistics), all host cores through the BLAS threads -- the courtesy upper bound BASELINE.md
+    section 4 asks for, so that the GPU number is not only read against a single-threaded Python loop."""
+    from oracle import c_oracle as co
+    emb, vid, dur, lm = corpus
+    keys = sorted(emb)[:budget_utts]
+    X = np.concatenate([emb[k] for k in keys]).astype(np.float32)
+    rs = np.random.RandomState(0)
+    means = X[rs.choice(X.shape[0], K, replace=False)].copy()
+    offs = np.cumsum([0] + [emb[k].shape[0] for k in keys])
+    # per-utterance tables prepared once, as the reference's constructor does (global row of every span, durations)
+    vids = [np.asarray(vid[k]) for k in keys]
+    gids = [np.where(v >= 0, offs[u] + np.maximum(v, 0), 0) for u, v in enumerate(vids)]
+    durs = [np.where(v >= 0, np.asarray(dur[k], dtype=np.float64), 1.0) for v, k in zip(vids, keys)]
+    masks = [v < 0 for v in vids]
+    Ns = [len(lm[k]) for k in keys]
+    from oracle.c_oracle import lib as _olib, _d, _bp
+    L = _olib()
+    t0 = time.perf_counter()
+    for _ in range(2):                                   # two sweeps: scoring, DP, means update
+        xx = np.einsum("ij,ij->i", X, X)
+        mm = np.einsum("ij,ij->i", means, means)
+        sc = X @ means.T
+        sc *= 2.0
+        sc -= mm[None, :]
+        arg = sc.argmax(axis=1)
+        best = (sc[np.arange(sc.shape[0]), arg] - xx).astype(np.float64)
+        tok_rows = []
+        b = np.zeros(max(Ns), np.uint8)
+        g = np.empty(max(Ns), np.float64)
+        for u in range(len(keys)):
+            vec = best[gids[u]] * durs[u]
+            vec[masks[u]] = -np.inf
+            N = Ns[u]
+            L.orc_fb_kmeans_viterbi(_d(vec), N, 0, n_slices_max, b.ctypes.data_as(_bp), _d(g))
+            ends = np.flatnonzero(b[:N]) + 1
+            starts = np.concatenate([[0], ends[:-1]])
+            tok_rows.append(gids[u][ends * (ends - 1) // 2 + starts])
+        rows = np.concatenate(tok_rows)
+        ks = arg[rows]
+        order = np.argsort(ks, kind="stable")
+        cnts = np.bincount(ks, minlength=K)
+        sums = np.add.reduceat(X[rows[order]].astype(np.float64), np.concatenate([[0], np.cumsum(cnts)[:-1]])[cnts > 0], axis=0)
+        nz = cnts > 0
+        means[nz] = (sums / cnts[nz, None]).astype(np.float32)
+    dt = (time.perf_counter() - t0) / 2
+    return {"value": 1.0 / (dt / len(keys) * n_utts_total), "unit": "sweeps/s", "cores": os.cpu_count(),
+            "note": "NOT the reference: BLAS-vectorised CPU batch sweep (sgemm scores + C Viterbi + vectorised statistics), "
+                    "%d utterances, %.3f s per sweep = %.3f ms/utterance, extrapolated linearly; a courtesy upper bound for "
+                    "a CPU, different arithmetic than the reference's" % (len(keys), dt, 1e3 * dt / len(keys))}
+
+
 def cpu_baseline(corpus, n_utts_total, K, n_slices_max, budget_utts):
     """Oracle (port of the reference's per-embedding numpy path) on the first `budget_utts`
     utterances of the same corpus; extrapolated linearly to the whole corpus (the cost per
@@ -51,7 +106,7 @@ def cpu_baseline(corpus, n_utts_total, K, n_slices_max, budget_utts):
         seg.segment_i(i)
     dt = time.perf_counter() - t0
     per_utt = dt / len(keys)
-    return {
+    out = {
         "value": 1.0 / (per_utt * n_utts_total),
         "unit": "sweeps/s",
         "cores": 1,
@@ -62,6 +117,20 @@ def cpu_baseline(corpus, n_utts_total, K, n_slices_max, budget_utts):
                   "host has %d cores, the reference path is single-threaded"
                   % (len(keys), n_utts_total, dt, 1e3 * per_utt, os.cpu_count()),
     }
+    cal = os.path.join(ROOT, "profiles", "cpu_calibration.json")
+    if os.path.exists(cal):
+        cj = json.load(open(cal))
+        out["calibration"] = {
+            "port_over_reference": cj["ratio_port_over_reference"],
+            "note": "ms/utterance of this port / ms/utterance of the py3 translation of the reference itself, same inputs "
+                    "and seeds, identical resulting state, measured in the build container (tools/cpu_calibration.py: "
+                    "%.2f vs %.2f ms/utterance on %d utterances); the reference cannot travel to the GPU box"
+                    % (cj["oracle_port_ms_per_utt"], cj["reference_py3_translation_ms_per_utt"], cj["n_utts"])}
+    try:
+        out["blas_courtesy"] = cpu_blas_courtesy(corpus, n_utts_total, K, n_slices_max, min(4 * budget_utts, n_utts_total))
+    except Exception as e:                               # the courtesy number must never cost the line
+        out["blas_courtesy"] = {"error": repr(e)}
+    return out
 
 
 def main_fbgmm(args):
@@ -206,7 +275,8 @@ def main():
     ap.add_argument("--K", type=int, default=1000)
     ap.add_argument("--landmarks", type=int, default=20)
     ap.add_argument("--n-slices-max", type=int, default=6)
-    ap.add_argument("--cpu-utts", type=int, default=2500, help="utterances timed for cpu_baseline (0 = skip)")
+    ap.add_argument("--windows", type=int, default=9, help="timed windows of --steps sweeps each; the median is reported")
+    ap.add_argument("--cpu-utts", type=int, default=2000, help="utterances timed for cpu_baseline (0 = skip)")
     ap.add_argument("--no-events", action="store_true", help="do not bracket the score kernel with events")
     ap.add_argument("--workload", default="kmeans_c3", choices=["kmeans_c3", "fbgmm_diag_c2", "bigram_c5"],
                     help="kmeans_c3 (default) is the headline of BASELINE.json (configs[2]); fbgmm_diag_c2 = configs[1] "
@@ -259,23 +329,39 @@ def main():
     import ctypes as C
     from segmentalist_amd import _abi
     use_ev = not args.no_events
-    if use_ev:
+    # a hipGraph capture cannot contain the event records: with SEGK_SWEEP_GRAPH=1 the timed windows replay the graph
+    # and the score kernel is timed afterwards over `steps` further sweeps launched plainly
+    ev_after = use_ev and sweeper.use_graph
+    if use_ev and not ev_after:
         _abi.check(_abi.lib().segk_profile_enable(_abi.ctx(), 1))
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        seg.batch_sweep_async()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    # `windows` back-to-back timed windows of EXACTLY `steps` sweeps each, every one bracketed by barrier +
+    # synchronize on both sides and reduced with MAX over the ranks; the line reports the MEDIAN window (a 13 ms
+    # window moves by percent with one clock ramp; the spread is reported beside it)
+    win = []
+    for _ in range(max(1, args.windows)):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            seg.batch_sweep_async()
+        barrier()
+        win.append(time.perf_counter() - t0)
     seg._dk.check_status()
-
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        t = torch.tensor(win, dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        win = [float(v) for v in t.cpu()]
+    elapsed = float(np.median(win))
+    if ev_after:
+        sweeper.use_graph = False
+        _abi.check(_abi.lib().segk_profile_enable(_abi.ctx(), 1))
+        for _ in range(args.steps):
+            seg.batch_sweep_async()
+        barrier()
+        sweeper.use_graph = True
 
     score_ms, score_rows = None, rows_local
     if use_ev:
-        nmax = min(args.steps, 256)
+        nmax = min(args.steps * max(1, args.windows), 256)
         ms = (C.c_float * nmax)()
         rows = (C.c_int64 * nmax)()
         got = _abi.lib().segk_profile_read(_abi.ctx(), ms, rows, nmax)
@@ -294,6 +380,9 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
+            "windows": len(win),
+            "window_ms_per_step": {"min": 1e3 * min(win) / args.steps, "median": 1e3 * elapsed / args.steps,
+                                   "max": 1e3 * max(win) / args.steps},
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
@@ -303,7 +392,10 @@ def main():
                 "workload": "SegmentalKMeansWordseg batch-synchronous sweep (BASELINE.json configs[2])",
                 "utterances": args.utts, "landmarks_per_utt": args.landmarks,
                 "n_slices_max": args.n_slices_max, "embeddings": int(n_emb), "D": args.dim, "K": args.K,
-                "parallelism": "utterance shards x%d, 2 all-gathers/sweep" % world,
+                "parallelism": "utterance shards x%d, ONE all-gather of the packed block statistics per sweep" % world,
+                "collective": ("none (single process)" if world == 1 else
+                               "%s, world size %d as reported by torch.distributed" % (dist.get_backend(), dist.get_world_size())),
+                "sweep_launch": "hipGraph replay" if sweeper.use_graph else "plain launches",
                 "components_after": int(seg.acoustic_model.components.K),
             },
         }
@@ -323,6 +415,7 @@ def main():
             achieved = flops_per_launch / (score_ms * 1e-3) / 1e12
             b3 = getattr(seg._corpus, "Xb3", None) is not None and os.environ.get("SEGK_SCORE_B3", "2") != "0"
             kind = int(_abi.lib().segk_profile_last_kind(_abi.ctx())) if use_ev else -1
+            launches = int(_abi.lib().segk_profile_last_launches(_abi.ctx())) if use_ev else 1
             if b3 and kind == 1:
                 # One-product fp16 pre-filter (k_kmeans_score_h1) in front of the split-precision kernel: the timed
                 # launch scores every row against every component with ONE v_mfma_f32_32x32x16_f16 product per
@@ -347,9 +440,10 @@ def main():
                               "matrix pipe, undecided rows re-scored by k_kmeans_score_sp, results bit-identical to the float32 "
                               "reference)" % (kp // 16, score_rows, rows_local),
                     "achieved": achieved, "peak": PEAK_BF16_MATRIX_TFLOPS, "unit": "TFLOP/s",
-                    "frac": achieved / PEAK_BF16_MATRIX_TFLOPS, "traffic": traffic, "ms_per_launch": score_ms,
-                    "flops_per_launch": flops_per_launch,
-                    "executed_flops_per_launch": executed, "executed_achieved": ex_tf,
+                    "frac": achieved / PEAK_BF16_MATRIX_TFLOPS, "traffic": traffic, "ms_per_launch": score_ms / launches,
+                    "launches_in_interval": launches,
+                    "flops_per_launch": flops_per_launch / launches,
+                    "executed_flops_per_launch": executed / launches, "executed_achieved": ex_tf,
                     "executed_frac": ex_tf / PEAK_BF16_MATRIX_TFLOPS,
                     "achieved_over_fp32_matrix_peak": achieved / PEAK_FP32_MATRIX_TFLOPS,
                 }

@@ -19,7 +19,10 @@ def main():
     ngpu = torch.cuda.device_count()
     torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % max(ngpu, 1))
     if world > 1:
-        dist.init_process_group(backend)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
+        else:
+            dist.init_process_group(backend)
     from segmentalist_amd import kmeans_acoustic_wordseg as kaw
     from segmentalist_amd.synth import make_corpus
     corpus = make_corpus(96, 24, 40, seed=3, ragged=True, n_slices_max=5, N_range=(4, 14))

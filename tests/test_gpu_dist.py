@@ -12,15 +12,15 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run(world, out, n_sweeps=3, worker="dist_worker.py", extra=(), env_extra=None):
+def run(world, out, n_sweeps=3, worker="dist_worker.py", extra=(), env_extra=None, backend="gloo"):
     worker = os.path.join(ROOT, "tests", worker)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     env.update(env_extra or {})
     if world == 1:
-        cmd = [sys.executable, worker, out, "gloo", str(n_sweeps)] + list(extra)
+        cmd = [sys.executable, worker, out, backend, str(n_sweeps)] + list(extra)
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
-               "--master-addr", "127.0.0.1", "--master-port", str(29500 + world), worker, out, "gloo",
+               "--master-addr", "127.0.0.1", "--master-port", str(29500 + world), worker, out, backend,
                str(n_sweeps)] + list(extra)
     subprocess.run(cmd, check=True, env=env, timeout=600, cwd=ROOT)
     return np.load(out)
@@ -32,6 +32,29 @@ def test_batch_mode_is_independent_of_the_number_of_ranks(tmp_path):
         got = run(world, str(tmp_path / ("w%d.npz" % world)))
         for k in ref.files:
             assert np.array_equal(ref[k], got[k]), (world, k)
+
+
+def test_batch_mode_replayed_as_hipgraphs_is_independent_of_the_number_of_ranks(tmp_path):
+    """SEGK_SWEEP_GRAPH=1: the sweep captured as one hipGraph (two around the all-gather with several ranks) and
+    replayed from the second sweep on -- same bits as the plain launches."""
+    ref = run(1, str(tmp_path / "g0.npz"), 4, env_extra={"SEGK_SWEEP_GRAPH": "0"})
+    for world in (1, 2):
+        got = run(world, str(tmp_path / ("g%d.npz" % world)), 4, env_extra={"SEGK_SWEEP_GRAPH": "1"})
+        for k in ref.files:
+            assert np.array_equal(ref[k], got[k]), (world, k)
+
+
+def test_batch_mode_over_rccl_when_the_box_has_two_gpus(tmp_path):
+    """Backend nccl (= RCCL over xGMI): one rank per GPU, the per-sweep all-gather in place on the device buffer
+    (device.all_gather_rows), ensure_assignments / ensure_boundaries as device collectives.  Needs two GPUs: the
+    single-GPU test box skips it, a multi-GPU box exercises the RCCL branch the first time it sees this suite."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("backend nccl needs one GPU per rank; this box has %d" % torch.cuda.device_count())
+    ref = run(1, str(tmp_path / "n1.npz"))
+    got = run(2, str(tmp_path / "n2.npz"), backend="nccl", env_extra={"HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    for k in ref.files:
+        assert np.array_equal(ref[k], got[k]), k
 
 
 def test_checkpoint_written_under_one_world_size_resumes_under_another(tmp_path):

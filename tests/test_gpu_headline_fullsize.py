@@ -52,7 +52,8 @@ def headline(gpu, monkeypatch_module):
     """The headline segmenter after two batch sweeps (default environment)."""
     from segmentalist_amd import kmeans_acoustic_wordseg as kaw
     from segmentalist_amd.synth import make_corpus
-    for v in ("SEGK_SCORE_PRE", "SEGK_SCORE_B3", "SEGK_SCORE_OVERLAP", "SEGK_MARK_DUPS", "SEGK_PRE_NBLK"):
+    for v in ("SEGK_SCORE_PRE", "SEGK_SCORE_B3", "SEGK_SCORE_OVERLAP", "SEGK_MARK_DUPS", "SEGK_PRE_NBLK", "SEGK_PRE_CHUNKS",
+              "SEGK_PAIR_V", "SEGK_PAIR_WAVES", "SEGK_SWEEP_GRAPH"):
         monkeypatch_module.delenv(v, raising=False)
     corpus = make_corpus(N_UTT, D, K, seed=0, N=N_LM, n_slices_max=NMAX)
     random.seed(0)
@@ -120,6 +121,26 @@ def test_a_every_row_matches_the_oracle_argmax_and_score(headline, scored):
     assert bad_s.size == 0, "max differs on %d rows, first %s" % (bad_s.size, bad_s[:8])
     # no pair mark left behind
     assert (scored["cand_k"] >= 0).all() and (scored["cand_k"] < K).all()
+
+
+@pytest.mark.parametrize("env", [{"SEGK_PRE_CHUNKS": "4"}, {"SEGK_PAIR_V": "1"}, {"SEGK_SCORE_OVERLAP": "0"},
+                                 {"SEGK_SCORE_PRE": "0"}],
+                         ids=["chunked_pipeline", "pair_stage_first_form", "one_stream", "no_prefilter"])
+def test_a_optional_launch_plans_give_the_same_bits(gpu, headline, scored, monkeypatch, env):
+    """The opt-in launch plans of the score stage (pre-filter in chunks with the exact stage of chunk i beside the
+    pre-filter of chunk i + 1 on three streams; the LDS-staged form of the exact pair kernel; everything on one stream;
+    the split-precision kernel alone) on the same 1.05 M rows and statistics: cand_k / cand_s identical to the values
+    test_a verified against the oracle."""
+    seg, _ = headline
+    dk = seg._dk
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    dk.cand_k.fill_(-7)
+    dk.cand_s.fill_(float("nan"))
+    dk.score_rows(row0=0, n=dk.corpus.n_emb)
+    gpu.cuda.synchronize()
+    assert np.array_equal(dk.cand_k.cpu().numpy(), scored["cand_k"])
+    assert np.array_equal(dk.cand_s.cpu().numpy(), scored["cand_s"])
 
 
 def test_b_all_boundaries_match_the_oracle_viterbi(headline, scored):
