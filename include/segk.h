@@ -298,6 +298,15 @@ int32_t segk_kmeans_batch_finalize(segk_ctx *ctx, const segk_corpus *c, segk_kme
                                    int64_t rank_stride, int32_t flag_cap, int32_t my_rank,
                                    int32_t *new_k, int32_t *remap_scratch, double *out_scalars,
                                    int32_t *status, void *stream);
+/* Record values of a batch sweep in one place (kmeans_acoustic_wordseg.py:405-420 keeps sum_neg_sqrd_norm,
+ * sum_neg_len_sqrd_norm, components, n_tokens per iteration): after segk_kmeans_batch_finalize, adds
+ * KMeansComponents.sum_neg_sqrd_norm (kmeans_components.py:234-247) of the tokens of utterances [utt_lo, utt_hi)
+ * -- from the token lists, `assignments` is not needed -- to out_scalars[4] (zeroed by the finalize call) and copies
+ * status[0], status[1] to out_scalars[5], [6]: out_scalars [dev] double [8] = {sum of totals, K, n_tokens, K before,
+ * sum_neg_sqrd_norm, status bits, fully scanned rows, -}; one device-to-host copy serves the whole record.        */
+int32_t segk_kmeans_batch_record(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m, int32_t utt_lo,
+                                 int32_t utt_hi, const int32_t *new_tok, const int32_t *new_k,
+                                 const int32_t *status, double *out_scalars, void *stream);
 /* assignments[:] = -1, then assignments[new_tok] = new_k for the tokens of utterances
  * [utt_lo, utt_hi). */
 int32_t segk_kmeans_assignments_from_tokens(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m,
@@ -349,6 +358,19 @@ typedef struct segk_fbgmm {
     double *kconst;            /* [dev] [K_max + 1] derived: x-independent constant of each component's
                                 * predictive; entry K_max = that of the prior predictive        */
 } segk_fbgmm;
+
+/* Record metrics of one sweep on the device: out [dev] double [4] =
+ *   { log_prob_z, log_prob_X_given_z, K, number of assigned rows } of the sequential-mode state in `f`:
+ *   log_prob_z            FBGMM.log_prob_z, fbgmm.py:208-225 (urn = 0: Dirichlet-multinomial with f->alpha), or
+ *                         BigramAcousticWordseg.log_prob_z, bigram_acoustic_wordseg.py:287-305 (urn = 1, urn_a =
+ *                         lm.a: the reference's loop never advances j_prev, so it is the Polya-urn probability of
+ *                         the tokens under the smoothed unigram model -- a function of the counts);
+ *   log_prob_X_given_z    components.log_marg(): gaussian_components_fixedvar.py:261-296 (sums of x and x^2 per
+ *                         component in the dtype of X, rows ascending, as numpy's axis-0 reduction) or
+ *                         gaussian_components_diag.py:271-303.
+ * Values agree with the reference's to ~1e-12 relative (contract for record values: 1e-8); workspace: the context's. */
+int32_t segk_fbgmm_record_metrics(segk_ctx *ctx, const segk_corpus *c, const struct segk_fbgmm *f,
+                                  int32_t urn, double urn_a, double *out, void *stream);
 
 /* Components __init__ from `assignments` (fixedvar:110-120 / diag:114-120): statistics summed in
  * the order of the reference's add_item loop (k ascending, rows ascending), counts, K. */

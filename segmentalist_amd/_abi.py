@@ -99,8 +99,10 @@ SIGNATURES = {
     "segk_kmeans_batch_partials": (_i32, [_P, _CP, _KP, _P, _i32, _P, _P, _P, _P, _P, _P, _P, _i32, _P, _P]),
     "segk_kmeans_batch_finalize": (_i32, [_P, _CP, _KP, _i32, _i32, _P, _i32, _i32, _i64, _i32, _i32, _P, _P, _P, _P,
                                           _P]),
+    "segk_kmeans_batch_record": (_i32, [_P, _CP, _KP, _i32, _i32, _P, _P, _P, _P, _P]),
     "segk_kmeans_assignments_from_tokens": (_i32, [_P, _CP, _KP, _i32, _i32, _P, _P, _P, _P]),
     "segk_kmeans_sum_neg_sqrd_norm": (_i32, [_P, _CP, _KP, _P, _P]),
+    "segk_fbgmm_record_metrics": (_i32, [_P, _CP, _FP, _i32, _f64, _P, _P]),
     "segk_fbgmm_init_stats": (_i32, [_P, _CP, _FP, _P]),
     "segk_fbgmm_update": (_i32, [_P, _CP, _FP, _i32, _i32, _i64, _i32, _P, _P]),
     "segk_fbgmm_score": (_i32, [_P, _CP, _FP, _P, _i64, _i64, _P, _P]),

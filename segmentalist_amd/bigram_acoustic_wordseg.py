@@ -15,6 +15,7 @@ stubs there, bigram_acoustic_wordseg.py:694-695,728-759) and only covariance_typ
 the LM to the components (bigram_fbgmm.py:86-91).
 """
 import logging
+import os
 import math
 import random
 import time
@@ -253,13 +254,19 @@ class BigramAcousticWordseg(object):
                     log_prob += 0. if assignments_only else lps[i_utt]
 
             record_dict["sample_time"].append(time.time() - start_time)
-            record_dict["log_marg"].append(self.log_marg())
+            # the record metrics (bigram_acoustic_wordseg.py:287-305, components.log_marg) in one device call instead of a
+            # Python loop over every token and numpy on host snapshots; SEGK_HOST_METRICS=1 keeps the host expressions
+            if os.environ.get("SEGK_HOST_METRICS", "0") == "1":
+                lpz, lpx, n_comp, n_tok = self.log_prob_z(), am.log_prob_X_given_z(), am.components.K, am.get_n_assigned()
+            else:
+                lpz, lpx, n_comp, n_tok = self._df.record_metrics(urn=True, urn_a=self.lm.a)
+            record_dict["log_marg"].append(lpz + lpx)
             record_dict["log_marg*length"].append(log_prob)
-            record_dict["log_prob_z"].append(self.log_prob_z())
-            record_dict["log_prob_X_given_z"].append(am.log_prob_X_given_z())
+            record_dict["log_prob_z"].append(lpz)
+            record_dict["log_prob_X_given_z"].append(lpx)
             record_dict["anneal_temp"].append(anneal_temp)
-            record_dict["components"].append(am.components.K)
-            record_dict["n_tokens"].append(am.get_n_assigned())
+            record_dict["components"].append(n_comp)
+            record_dict["n_tokens"].append(n_tok)
             info = "iteration: " + str(i_iter)
             for key in sorted(record_dict):
                 info += ", " + key + ": " + str(record_dict[key][-1])

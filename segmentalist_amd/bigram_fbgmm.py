@@ -46,4 +46,6 @@ class BigramFBGMM(object):
         return self.components.log_marg()
 
     def get_n_assigned(self):
-        return int(np.count_nonzero(self.components.assignments != -1))
+        """Number of assigned items (the reference counts `assignments != -1`): the sum of the component counts, read
+        from the device without copying the assignment vector to the host."""
+        return int(self.components.dev.counts.sum().item())

@@ -625,7 +625,8 @@ __global__ void k_fbgmm_gibbs_items(segk_corpus c, segk_fbgmm f, const int32_t *
 // in exactly that order (including the repeated `+= precision`), derived values once at the end.
 // ---------------------------------------------------------------------------------------
 template <typename XT>
-__global__ void k_fbgmm_init_stats(segk_corpus c, segk_fbgmm f)
+__global__ void k_fbgmm_init_stats(segk_corpus c, segk_fbgmm f, const int32_t *blk_lo, int n_blocks, const int32_t *sorted,
+                                   const int32_t *koff)
 {
     const int k = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
@@ -651,20 +652,30 @@ __global__ void k_fbgmm_init_stats(segk_corpus c, segk_fbgmm f)
             else { a = f.k_0 * f.prior_b[d]; b = f.prior_a[d] + f.k_0 * (f.prior_b[d] * f.prior_b[d]); }
         }
         int64_t n = 0;
-        for (int64_t e0 = 0; e0 < c.n_emb; e0 += 64) {
-            int64_t e = e0 + lane;
-            int match = (e < c.n_emb) && (f.assignments[e] == k);
-            unsigned long long bal = __ballot(match);
-            while (bal) {
-                int src = __ffsll((long long)bal) - 1;
-                bal &= bal - 1;
-                int64_t ee = e0 + src;
-                n++;
-                if (d < D) {
-                    const double x = (double)X[ee * c.ldx + d];
-                    if (f.cov_type == 0) { a += f.prior_a[d] * x; b += f.prior_a[d]; }
-                    else { a += x; b += x_sq<XT>(X[ee * c.ldx + d]); }
+        // the component's rows in ascending order, from the bucketed row lists (segk_rows_by_label: before, every
+        // component scanned the whole assignment vector -- K_max x n_emb ballots, 6 ms at a million rows); eight rows
+        // are fetched together, the additions stay one row after the other
+        for (int bb = 0; bb < n_blocks; bb++) {
+            const int32_t *ko = koff + (int64_t)bb * (f.K_max + 1);
+            const int64_t p0 = blk_lo[bb];
+            const int q0 = ko[k], q1 = ko[k + 1];
+            for (int qb = q0; qb < q1; qb += 8) {
+                XT xv[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const int64_t ee = p0 + sorted[p0 + (qb + q < q1 ? qb + q : q0)];       // clamped: always valid
+                    xv[q] = X[ee * c.ldx + (d < D ? d : 0)];
                 }
+#pragma unroll
+                for (int q = 0; q < 8; q++)
+                    if (qb + q < q1) {
+                        n++;
+                        if (d < D) {
+                            const double x = (double)xv[q];
+                            if (f.cov_type == 0) { a += f.prior_a[d] * x; b += f.prior_a[d]; }
+                            else { a += x; b += x_sq<XT>(xv[q]); }
+                        }
+                    }
             }
         }
         cnt = n;
@@ -744,13 +755,18 @@ int32_t segk_fbgmm_update(segk_ctx *ctx, const segk_corpus *c, segk_fbgmm *f, in
 
 int32_t segk_fbgmm_init_stats(segk_ctx *ctx, const segk_corpus *c, segk_fbgmm *f, void *stream)
 {
-    (void)ctx;
+    SEGK_REQUIRE(ctx, "ctx");
     int rc = check_fb(c, f);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     SEGK_CHECK_HIP(hipMemsetAsync(f->K, 0, sizeof(int32_t), st));
+    const int32_t *blk_lo = nullptr, *sorted = nullptr, *koff = nullptr;
+    int n_blocks = 0;
+    rc = segk_rows_by_label(ctx, f->assignments, c->n_emb, f->K_max, &blk_lo, &n_blocks, &sorted, &koff, stream);
+    if (rc) return rc;
     int64_t grid = ((int64_t)f->K_max + 1 + 3) / 4;
-    DISPATCH_XT(c, hipLaunchKernelGGL(k_fbgmm_init_stats<XT>, dim3((unsigned)grid), dim3(256), 0, st, *c, *f););
+    DISPATCH_XT(c, hipLaunchKernelGGL(k_fbgmm_init_stats<XT>, dim3((unsigned)grid), dim3(256), 0, st, *c, *f, blk_lo, n_blocks,
+                                       sorted, koff););
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;
 }

@@ -87,6 +87,10 @@ int32_t segk_destroy(segk_ctx *ctx)
         if (ctx->ws_u64) (void)hipFree(ctx->ws_u64);
         if (ctx->pre_queue) (void)hipFree(ctx->pre_queue);
         if (ctx->row_hash) (void)hipFree(ctx->row_hash);
+        if (ctx->rb_sorted) (void)hipFree(ctx->rb_sorted);
+        if (ctx->rb_koff) (void)hipFree(ctx->rb_koff);
+        if (ctx->rb_misc) (void)hipFree(ctx->rb_misc);
+        if (ctx->rb_term) (void)hipFree(ctx->rb_term);
         if (ctx->aux) (void)hipStreamDestroy(ctx->aux);
         if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
         if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);

@@ -34,6 +34,13 @@ struct segk_ctx {
     // value hashes of the rows of the means most recently prepared (segk_kmeans_mark_duplicates)
     unsigned long long *row_hash;
     const void *row_hash_means;
+    // rows bucketed by label (segk_rows_by_label): sorted row offsets [cap], per-block offsets, block bounds, small scratch
+    int32_t *rb_sorted;
+    int64_t rb_cap;
+    int32_t *rb_koff;            // [64 * (rb_K + 1)]
+    int rb_K;
+    int32_t *rb_misc;            // blk_lo [68], dummy K, flags; then doubles (part_tot, scalars, terms)
+    double *rb_term;             // [rb_K] per-component terms of the record metrics
     // optional timing of the main score launch (segk_profile_*): event pairs used round-robin
     int prof_on, prof_n, prof_kind;
     hipEvent_t prof_ev[SEGK_PROF_SLOTS][2];
@@ -41,6 +48,13 @@ struct segk_ctx {
 };
 
 void segk_set_error(const char *fmt, ...);
+
+// segk_metrics.hip: the rows 0..n-1 bucketed by label (labels[row] in [0, K_max), anything else: not listed), every
+// bucket in ascending row order -- the stable counting sort of the k-means batch statistics run over blocks of rows.
+// Row q of label k inside block b: blk_lo[b] + sorted[blk_lo[b] + koff[b * (K_max + 1) + k] + q].  Buffers are owned
+// by the context (valid until the next call).  K_max <= 8192.
+int segk_rows_by_label(segk_ctx *ctx, const int32_t *labels, int64_t n, int K_max, const int32_t **blk_lo, int *n_blocks,
+                       const int32_t **sorted, const int32_t **koff, void *stream);
 
 #define SEGK_CHECK_HIP(expr)                                                                  \
     do {                                                                                      \
@@ -98,8 +112,9 @@ static inline __host__ __device__ int segk_n_tiles(int K_max) { return (K_max + 
 // Operand images of the split-precision k-means filter (float32 data, 8 <= D <= 128; segk_score_sp.hip, segk_score_h1.hip).
 // P = 3: three bf16 pieces, x = x1 + x2 + x3 exactly.  P = 2: two fp16 pieces of 2^a x (power-of-two
 // scaling), the second one carried at 2^11 times its weight.
-//   rows   [SEGK_SP_HEADER bytes: int32 {P, exponent a, bits of max |x_d|}] then [n_emb][P][KP] 16-bit
-//          pieces, KP = D rounded up to 16 (zero padded, dimensions permuted by segk_b3_dim)
+//   rows   [SEGK_SP_HEADER bytes: int32 {P, exponent a, bits of max |x_d|, 0}, int64 n_emb * KP] then P planes
+//          [n_emb][KP] of 16-bit pieces (piece p of every row together), KP = D rounded up to 16 (zero padded,
+//          dimensions permuted by segk_b3_dim); for P = 2 the float [n_emb] residual norms follow the planes
 //   tiles  [1024 floats header: int32 exponent b at [0]] then per tile of 32 components:
 //          16-bit [s][p][lane 64][8], s < KS = KP/16 (k-step), p < P (piece): piece p of
 //          2^b M[32*tile + (lane & 31)][segk_b3_dim(16 s + 8 (lane >> 5) + i)], i < 8 -- the A operand of

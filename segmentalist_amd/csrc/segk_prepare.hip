@@ -60,16 +60,18 @@ __global__ void k_corpus_split_sp(const float *X, int64_t ldx, int64_t n_emb, in
     int *hdr = (int *)img;
     const int ea = P == 2 ? sp_exponent(__uint_as_float(((unsigned int *)img)[2])) : 0;
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx == 0) { hdr[0] = P; hdr[1] = ea; }
+    if (idx == 0) { hdr[0] = P; hdr[1] = ea; *reinterpret_cast<int64_t *>(img + 16) = n_emb * KP; }
     if (idx >= n_emb * KP) return;
     const int64_t e = idx / KP;
     const int pos = (int)(idx - e * KP), d = segk_b3_dim(pos);
     const float x = d < D ? ldexpf(X[e * ldx + d], ea) : 0.f;
     T pc[P];
     split_sp<P>(x, pc);
-    T *row = (T *)(img + SEGK_SP_HEADER) + e * P * KP;
+    // one PLANE per piece ([P][n_emb][KP]): the one-product pre-filter streams the leading pieces alone, 2 KP contiguous
+    // bytes per row (interleaved, its 224 bytes shared 128-byte lines with the second piece: 369 MB fetched for 235)
+    T *row = (T *)(img + SEGK_SP_HEADER) + e * KP;
 #pragma unroll
-    for (int q = 0; q < P; q++) row[q * KP + pos] = pc[q];
+    for (int q = 0; q < P; q++) row[q * (n_emb * KP) + pos] = pc[q];
 }
 
 __global__ void k_corpus_resid_sp(const float *X, int64_t ldx, int64_t n_emb, int D, unsigned char *img)

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256, 2) void k_kmeans_score_h1(ScoreArgs A)
         r[b] = ((int64_t)blockIdx.x * 4 + wave) * (32 * NBLK) + 32 * b + j;
         rowid[b] = -1;
         if (r[b] < n) rowid[b] = ids ? ids[r[b]] : (int32_t)(row0 + r[b]);
-        const T *xp = (const T *)((const unsigned char *)A.X32 + SEGK_SP_HEADER) + (int64_t)(rowid[b] >= 0 ? rowid[b] : 0) * (P * KP) + 8 * h;
+        const T *xp = (const T *)((const unsigned char *)A.X32 + SEGK_SP_HEADER) + (int64_t)(rowid[b] >= 0 ? rowid[b] : 0) * KP + 8 * h;      // plane 0
 #pragma unroll
         for (int s = 0; s < KS; s++) xb[b][s] = *reinterpret_cast<const V8 *>(xp + 16 * s);
     }

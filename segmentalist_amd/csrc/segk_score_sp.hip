@@ -66,11 +66,12 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_kmeans_score_sp(ScoreArgs A)
     int32_t rowid = -1;
     if (r < n) rowid = ids ? ids[r] : (int32_t)(row0 + r);
     {
-        const T *xp = (const T *)((const unsigned char *)A.X32 + SEGK_SP_HEADER) + (int64_t)(rowid >= 0 ? rowid : 0) * (P * KP) + 8 * h;
+        const int64_t plane = *reinterpret_cast<const int64_t *>((const unsigned char *)A.X32 + 16);      // elements per piece plane
+        const T *xp = (const T *)((const unsigned char *)A.X32 + SEGK_SP_HEADER) + (int64_t)(rowid >= 0 ? rowid : 0) * KP + 8 * h;
 #pragma unroll
         for (int p = 0; p < P; p++)
 #pragma unroll
-            for (int s = 0; s < KS; s++) xb[p][s] = *reinterpret_cast<const V8 *>(xp + p * KP + 16 * s);
+            for (int s = 0; s < KS; s++) xb[p][s] = *reinterpret_cast<const V8 *>(xp + p * plane + 16 * s);
     }
     // MODE 1 (log-sum-exp, base 2, of the UNSCALED accumulator values): m1 / m2 are the running maximum
     // (finite start) and sum, as in k_kmeans_score

@@ -657,6 +657,7 @@ __global__ __launch_bounds__(256) void k_batch_finalize(
             out_scalars[0] = tree_reduce_d(tv, n_blocks);
             out_scalars[1] = (double)K;
             out_scalars[2] = (double)n_tokens;
+            out_scalars[4] = 0.0;                           // accumulator of segk_kmeans_batch_record
             *m.K = K;
             if (sp_zero_slot) *sp_zero_slot = 0u;          // E_m of the fp16 tile image: k_batch_post's atomic maximum
         }
@@ -858,6 +859,38 @@ __global__ void k_kmeans_sum_neg_sqrd_norm(segk_corpus c, segk_kmeans m, double 
     }
 }
 
+// the same metric straight from the token lists of a batch sweep (no `assignments` needed), plus the status word: one
+// small device-to-host copy then carries every record value of the sweep.  out [>= 7]: out[4] += metric (zeroed by
+// k_batch_finalize), out[5] = status[0], out[6] = status[1]
+template <typename XT>
+__global__ void k_kmeans_record_tokens(segk_corpus c, segk_kmeans m, int lo, int hi, const int32_t *new_tok, const int32_t *new_k,
+                                       const int32_t *status, double *out)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int64_t p0 = (int64_t)lo * c.N_max, tot = (int64_t)(hi - lo) * c.N_max;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && status) { out[5] = (double)status[0]; out[6] = (double)status[1]; }
+    double s = 0.0;
+    for (int64_t p = (int64_t)blockIdx.x * nw + wv; p < tot; p += (int64_t)gridDim.x * nw) {
+        const int k = new_k[p0 + p];
+        if (k < 0) continue;
+        const int64_t e = new_tok[p0 + p];
+        const double cnt = (double)m.counts[k];
+        for (int d = lane; d < c.D; d += 64) {
+            const double delta = m.mean_numerators[(int64_t)k * c.D + d] / cnt - (double)((const XT *)c.X)[e * c.ldx + d];
+            s += delta * delta;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    __shared__ double part[16];
+    if (lane == 0) part[wv] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < nw; w++) t += part[w];
+        if (t != 0.0) atomicAdd(out + 4, -t);
+    }
+}
+
 // ======================================================================================
 // KMeansComponents.__init__ (kmeans_components.py:59-81): add_item(i, k) for k ascending and
 // i ascending within k == per component a sequential fp64 sum over its items in ascending
@@ -910,6 +943,26 @@ __global__ void k_kmeans_init_stats(segk_corpus c, segk_kmeans m)
     }
 }
 
+
+// the stable counting sort of (1a), also used by the record metrics of the FBGMM drivers (segk_metrics.hip)
+int segk_launch_batch_sort(const segk_corpus *c, const segk_kmeans *m, const int32_t *blk_lo, int n_blocks, const int32_t *new_tok,
+                           const int32_t *new_k, const int32_t *n_flag, const double *out_total, int32_t *sorted, int32_t *koff,
+                           double *part_tot, int32_t *flags, int cap, double *out_scalars, hipStream_t st)
+{
+    const int nw = m->K_max <= 1024 ? 16 : m->K_max <= 2048 ? 8 : m->K_max <= 4096 ? 4 : 2;
+    size_t lds = (size_t)(m->K_max + 2) * 4 + (size_t)nw * m->K_max * 4 + (size_t)SORT_KEYS_LDS * 2;
+    if (lds < 2048 * sizeof(double)) lds = 2048 * sizeof(double);
+    static size_t lds_set = 0;
+    if (lds > 48 * 1024 && lds > lds_set) {
+        SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_batch_sort, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        lds_set = lds;
+    }
+    // out_total == NULL: the sort alone (no flag lists, no totals: the second half of the grid is not launched)
+    hipLaunchKernelGGL(k_batch_sort, dim3((unsigned)((out_total ? 2 : 1) * n_blocks)), dim3(SORT_THREADS), lds, st, *c, *m, blk_lo,
+                       n_blocks, new_tok, new_k, n_flag, out_total, sorted, koff, part_tot, flags, cap, out_scalars);
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
 
 extern "C" {
 
@@ -1004,16 +1057,9 @@ int32_t segk_kmeans_batch_partials(segk_ctx *ctx, const segk_corpus *c, const se
     int64_t *part_cnt = reinterpret_cast<int64_t *>(record + nbl * KD + nbl);
     int32_t *flags = reinterpret_cast<int32_t *>(record + nbl * KD + nbl + nbl * m->K_max);
     hipStream_t st = (hipStream_t)stream;
-    const int nw = m->K_max <= 1024 ? 16 : m->K_max <= 2048 ? 8 : m->K_max <= 4096 ? 4 : 2;
-    size_t lds = (size_t)(m->K_max + 2) * 4 + (size_t)nw * m->K_max * 4 + (size_t)SORT_KEYS_LDS * 2;
-    if (lds < 2048 * sizeof(double)) lds = 2048 * sizeof(double);
-    static size_t lds_set = 0;
-    if (lds > 48 * 1024 && lds > lds_set) {
-        SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_batch_sort, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        lds_set = lds;
-    }
-    hipLaunchKernelGGL(k_batch_sort, dim3((unsigned)(2 * nbl)), dim3(SORT_THREADS), lds, st, *c, *m, blk_lo, n_blocks_local, new_tok,
-                       new_k, n_flag, out_total, sorted_scratch, koff_scratch, part_tot, flags, flag_cap, out_scalars);
+    if (int rc2 = segk_launch_batch_sort(c, m, blk_lo, n_blocks_local, new_tok, new_k, n_flag, out_total, sorted_scratch, koff_scratch,
+                                         part_tot, flags, flag_cap, out_scalars, st))
+        return rc2;
     const int64_t grid = nbl * ((m->K_max + 7) / 8);
     DISPATCH_XT(c, hipLaunchKernelGGL(k_batch_partials<XT>, dim3((unsigned)grid), dim3(512), 0, st, *c, *m, blk_lo,
                                        n_blocks_local, new_tok, sorted_scratch, koff_scratch, part_sum, part_cnt););
@@ -1069,6 +1115,25 @@ int32_t segk_kmeans_batch_finalize(segk_ctx *ctx, const segk_corpus *c, segk_kme
     else
         DISPATCH_XT(c, hipLaunchKernelGGL((k_batch_post<XT, 0>), dim3(grid), dim3(256), 0, st, *c, *m, utt_lo, utt_hi, new_k,
                                            remap_scratch, n_tiles, stride32, G, (float *)nullptr, 0, 0, row_hash););
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+int32_t segk_kmeans_batch_record(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m, int32_t utt_lo, int32_t utt_hi,
+                                 const int32_t *new_tok, const int32_t *new_k, const int32_t *status, double *out_scalars,
+                                 void *stream)
+{
+    (void)ctx;
+    int rc = check_corpus(c);
+    if (rc) return rc;
+    SEGK_REQUIRE(new_tok && new_k && out_scalars, "batch_record operands");
+    SEGK_REQUIRE(0 <= utt_lo && utt_lo <= utt_hi && utt_hi <= c->n_utt, "utterance range");
+    const int64_t tot = (int64_t)(utt_hi - utt_lo) * c->N_max;
+    int64_t grid = (tot + 31) / 32;
+    if (grid > 2048) grid = 2048;
+    if (grid < 1) grid = 1;
+    DISPATCH_XT(c, hipLaunchKernelGGL(k_kmeans_record_tokens<XT>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, *c, *m,
+                                       utt_lo, utt_hi, new_tok, new_k, status, out_scalars););
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;
 }

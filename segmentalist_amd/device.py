@@ -173,7 +173,7 @@ class DeviceKMeans(object):
         self.out_total = torch.zeros(nu, dtype=torch.float64, device=dev)
         self.utt_arange = torch.arange(nu, dtype=torch.int32, device=dev)
         self.remap = torch.zeros(self.K_max, dtype=torch.int32, device=dev)
-        self.out_scalars = torch.zeros(4, dtype=torch.float64, device=dev)
+        self.out_scalars = torch.zeros(8, dtype=torch.float64, device=dev)
         # batch sweeps leave `assignments` untouched: `assign_stale` = (lo, hi, world) of the token
         # lists it must be rebuilt from, or None when it is current
 
@@ -320,16 +320,28 @@ class DeviceKMeans(object):
                                              ptr(self.new_tok), ptr(self.new_k), ptr(self.n_old),
                                              ptr(self.n_new), ptr(self.status), _abi.stream()))
 
-    def check_status(self):
-        st = self.status.cpu().numpy()
-        if st[0] & 1:
+    def batch_record(self, lo, hi):
+        """The record values of the batch sweep just enqueued, in ONE device-to-host copy (segk_kmeans_batch_record):
+        (sum_neg_len_sqrd_norm, K, n_tokens, sum_neg_sqrd_norm); raises like check_status."""
+        check(self._L.segk_kmeans_batch_record(self._ctx, self._cp(), C.byref(self.m), int(lo), int(hi), ptr(self.new_tok),
+                                               ptr(self.new_k), ptr(self.status), ptr(self.out_scalars), _abi.stream()))
+        o = self.out_scalars.cpu().numpy()
+        self._raise_status(int(o[5]))
+        return float(o[0]), int(o[1]), int(o[2]), float(o[4])
+
+    def _raise_status(self, bits):
+        if bits & 1:
             raise AssertionError("a new segment has no embedding (vec_id == -1): the reference asserts in "
                                  "KMeansComponents.add_item (kmeans_components.py:100)")
-        if st[0] & 2:
+        if bits & 2:
             raise AssertionError("add_item on an item that is already assigned (kmeans_components.py:101)")
-        if st[0] & 4:
-            raise SegkError("batch sweep: more than `flag_cap` new tokens chose an inactive component; "
-                            "raise flag_cap")
+        if bits & 4:
+            raise SegkError("batch sweep: more new tokens chose an inactive component than `flag_cap` per block "
+                            "(2048 per sweep); raise flag_cap")
+
+    def check_status(self):
+        st = self.status.cpu().numpy()
+        self._raise_status(int(st[0]))
         return int(st[1])
 
 
@@ -636,6 +648,17 @@ class DeviceFbgmm(object):
                                   self.ustream.numel(), ptr(self.status), st))
         if self.lm is not None:
             check(L.segk_fbgmm_update(ctx, cp, fp, 6, int(i), 0, 0, ptr(boundaries), st))
+
+    def record_metrics(self, urn=False, urn_a=0.0):
+        """(log_prob_z, log_prob_X_given_z, K, n_assigned) of the sequential-mode state, computed on the device (segk_fbgmm_record_metrics): fbgmm.py:208-225 or, with urn=True,
+        bigram_acoustic_wordseg.py:287-305; gaussian_components_{fixedvar,diag}.py log_marg."""
+        torch = _torch()
+        if getattr(self, "_metric_out", None) is None:
+            self._metric_out = torch.zeros(4, dtype=torch.float64, device=self.K.device)
+        check(self._L.segk_fbgmm_record_metrics(self._ctx, self._cp(), C.byref(self.f), 1 if urn else 0, float(urn_a),
+                                                ptr(self._metric_out), _abi.stream()))
+        o = self._metric_out.cpu().numpy()
+        return float(o[0]), float(o[1]), int(o[2]), int(o[3])
 
     def check_status(self):
         st = int(self.status[0].item())

@@ -160,6 +160,7 @@ class SegmentalKMeansWordseg(object):
         c = self.acoustic_model.components
         for i_iter in range(n_iter):
             start_time = time.time()
+            batch_rec = None
             if self.sync == "sequential":
                 utt_order = list(range(self.utterances.D))
                 rng.shuffle(utt_order)
@@ -175,14 +176,26 @@ class SegmentalKMeansWordseg(object):
                     sum_neg_len_sqrd_norm += totals[i_utt]
             else:
                 self.batch_sweep_async()
-                torch.cuda.synchronize()
-                self._dk.check_status()
-                sum_neg_len_sqrd_norm = float(self._dk.out_scalars[0].item())
+                pt = self._get_sweeper().part
+                if pt.world == 1:
+                    # every record value of the sweep from one device-to-host copy (the metric from the token lists)
+                    sum_neg_len_sqrd_norm, n_comp, n_tok, sum_neg = self._dk.batch_record(pt.utt_lo, pt.utt_hi)
+                    batch_rec = (sum_neg, n_comp, n_tok)
+                else:
+                    torch.cuda.synchronize()
+                    self._dk.check_status()
+                    sum_neg_len_sqrd_norm = float(self._dk.out_scalars[0].item())
             record_dict["sample_time"].append(time.time() - start_time)
-            record_dict["sum_neg_sqrd_norm"].append(c.sum_neg_sqrd_norm())
-            record_dict["sum_neg_len_sqrd_norm"].append(sum_neg_len_sqrd_norm)
-            record_dict["components"].append(c.K)
-            record_dict["n_tokens"].append(self.acoustic_model.get_n_assigned())
+            if batch_rec is not None:
+                record_dict["sum_neg_sqrd_norm"].append(batch_rec[0])
+                record_dict["sum_neg_len_sqrd_norm"].append(sum_neg_len_sqrd_norm)
+                record_dict["components"].append(batch_rec[1])
+                record_dict["n_tokens"].append(batch_rec[2])
+            else:
+                record_dict["sum_neg_sqrd_norm"].append(c.sum_neg_sqrd_norm())
+                record_dict["sum_neg_len_sqrd_norm"].append(sum_neg_len_sqrd_norm)
+                record_dict["components"].append(c.K)
+                record_dict["n_tokens"].append(self.acoustic_model.get_n_assigned())
             info = "iteration: " + str(i_iter)
             for key in sorted(record_dict):
                 info += ", " + key + ": " + str(record_dict[key][-1])

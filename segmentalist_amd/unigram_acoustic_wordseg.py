@@ -10,6 +10,7 @@ that order, and afterwards the host stream is rewound and advanced by the number
 consumed -- so seeded runs stay aligned with the reference draw for draw.
 """
 import logging
+import os
 import math
 import random
 import time
@@ -246,13 +247,19 @@ class UnigramAcousticWordseg(object):
                     log_prob += lps[i_utt]
 
             record_dict["sample_time"].append(time.time() - start_time)
-            record_dict["log_marg"].append(am.log_marg())
+            # the record metrics (fbgmm.py:208-225, components.log_marg) in one device call instead of numpy on host
+            # snapshots of the assignments; SEGK_HOST_METRICS=1 keeps the host expressions (tests compare the two)
+            if os.environ.get("SEGK_HOST_METRICS", "0") == "1":
+                lpz, lpx, n_comp, n_tok = am.log_prob_z(), am.log_prob_X_given_z(), am.components.K, am.get_n_assigned()
+            else:
+                lpz, lpx, n_comp, n_tok = self._df.record_metrics()
+            record_dict["log_marg"].append(lpz + lpx)
             record_dict["log_marg*length"].append(log_prob)
-            record_dict["log_prob_z"].append(am.log_prob_z())
-            record_dict["log_prob_X_given_z"].append(am.log_prob_X_given_z())
+            record_dict["log_prob_z"].append(lpz)
+            record_dict["log_prob_X_given_z"].append(lpx)
             record_dict["anneal_temp"].append(anneal_temp)
-            record_dict["components"].append(am.components.K)
-            record_dict["n_tokens"].append(am.get_n_assigned())
+            record_dict["components"].append(n_comp)
+            record_dict["n_tokens"].append(n_tok)
             info = "iteration: " + str(i_iter)
             for key in sorted(record_dict):
                 info += ", " + key + ": " + str(record_dict[key][-1])
