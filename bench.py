@@ -167,7 +167,11 @@ def main_fbgmm(args):
                                         covariance_type="fixed", fb_type="unigram", score_precision=os.environ.get("SEGK_FBB_PRECISION", "f16"), **kw)
     else:
         prior = NIW(np.zeros(D), 0.05, D + 3, 0.002 * (D + 3) * np.ones(D))
-        seg = uaw.UnigramAcousticWordseg(fbgmm.FBGMM, 1.0, K, prior, *corpus, covariance_type="diag", fb_type="standard", **kw)
+        # score precision of the diagonal Student-t span score: f32 (float32 terms with v_log_f32; within the 1e-4
+        # contract of the path, tests/test_gpu_fbgmm_batch.py) unless SEGK_FBB_PRECISION=f64 asks for the fp64 kernel
+        dprec = os.environ.get("SEGK_FBB_PRECISION", "f32")
+        seg = uaw.UnigramAcousticWordseg(fbgmm.FBGMM, 1.0, K, prior, *corpus, covariance_type="diag", fb_type="standard",
+                                         score_precision="f32" if dprec in ("f32", "f16") else "f64", **kw)
 
     def barrier():
         if world > 1:
@@ -178,18 +182,23 @@ def main_fbgmm(args):
         seg.batch_sweep_async()
     barrier()
     seg._df.check_status()
-    if bigram:
+    diag32 = (not bigram) and getattr(seg._get_sweeper(), "score_diag32", False)
+    if bigram or diag32:
         _abi.check(_abi.lib().segk_profile_enable(_abi.ctx(), 1))
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        seg.batch_sweep_async()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    win = []
+    for _ in range(max(1, args.windows)):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            seg.batch_sweep_async()
+        barrier()
+        win.append(time.perf_counter() - t0)
     seg._df.check_status()
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        t = torch.tensor(win, dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        win = [float(v) for v in t.cpu()]
+    elapsed = float(np.median(win))
     if rank == 0:
         sw = seg._get_sweeper()
         cnt, tot, occ = sw.totals()
@@ -197,8 +206,11 @@ def main_fbgmm(args):
             "metric": "Gibbs sweeps/sec (%s)" % ("BigramAcousticWordseg, 10k utts, D=100, K=1000" if bigram
                                                   else "UnigramAcousticWordseg + FBGMM diag, 1k utts, D=39, K=100"),
             "value": args.steps / elapsed, "unit": "sweeps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32 span scores, f64 sampling" if bigram else "f64", "data": "synthetic",
+            "ms_per_step": 1e3 * elapsed / args.steps, "windows": len(win),
+            "window_ms_per_step": {"min": 1e3 * min(win) / args.steps, "median": 1e3 * elapsed / args.steps,
+                                   "max": 1e3 * max(win) / args.steps},
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32 span scores, f64 sampling" if (bigram or diag32) else "f64", "data": "synthetic",
             "config": {"workload": "%s batch-synchronous blocked Gibbs sweep, 8 blocks (BASELINE.json configs[%d])"
                                    % ("BigramAcousticWordseg" if bigram else "UnigramAcousticWordseg + FBGMM (diag)",
                                       4 if bigram else 1),
@@ -235,6 +247,28 @@ def main_fbgmm(args):
                                        "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": None, "ms_per_launch": score_ms,
                                        "flops_per_launch": flops}
             _abi.check(_abi.lib().segk_profile_enable(_abi.ctx(), 0))
+        if diag32:
+            # dominant kernel: k_fbb_score_diag32, one launch per Gibbs step.  Algorithmic work = one Student-t term
+            # log(1 + delta^2 q) per (row, slot, dimension): rows x K_max x D terms per launch; the roofline is what the
+            # vector ALUs sustain on exactly that term with operands in registers (segk_calibrate_vlog, measured here)
+            nmax = 256
+            ms = (C.c_float * nmax)()
+            rows = (C.c_int64 * nmax)()
+            got = _abi.lib().segk_profile_read(_abi.ctx(), ms, rows, nmax)
+            _abi.check(_abi.lib().segk_profile_enable(_abi.ctx(), 0))
+            peak = C.c_double(0.0)
+            _abi.check(_abi.lib().segk_calibrate_vlog(_abi.ctx(), C.byref(peak), _abi.stream()))
+            if got > 0:
+                score_ms = float(np.mean(ms[:got]))
+                n_rows = float(np.mean(rows[:got]))
+                terms = n_rows * K * D
+                achieved = terms / (score_ms * 1e-3) / 1e9
+                out["roofline"] = {"bound": "valu", "kernel": "k_fbb_score_diag32 (float32 Student-t terms with v_log_f32, one launch per "
+                                   "Gibbs step: %d rows x %d slots x %d dimensions)" % (int(n_rows), K, D),
+                                   "achieved": achieved, "peak": peak.value / 1e9, "unit": "Gterm/s", "frac": achieved / (peak.value / 1e9),
+                                   "traffic": None, "ms_per_launch": score_ms, "terms_per_launch": terms,
+                                   "peak_source": "k_vlog_calibrate measured in this run: the kernel's inner term (v_sub, v_mul, v_fma, "
+                                                  "v_log_f32, v_add) from registers on all %d CUs" % torch.cuda.get_device_properties(0).multi_processor_count}
         if world == 1 and args.cpu_utts > 0:
             from oracle import np_oracle as no
             n_cpu = min(args.cpu_utts, 300 if bigram else 1000) // (10 if bigram else 1) or 1

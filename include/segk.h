@@ -508,6 +508,17 @@ int32_t segk_fbb_make_y(segk_ctx *ctx, const segk_corpus *c, const segk_fbatch *
 int32_t segk_fbb_score_f32(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *f,
                            const segk_fbatch *bt, const int32_t *rows, int64_t n, double *score,
                            void *stream);   /* rows [dev] [n]: the embedding rows to score (a block) */
+/* Roofline calibration of segk_fbb_score_diag32 (no reference counterpart): Student-t terms per second of a kernel
+ * that does nothing but the score kernel's inner term (subtract, multiply, multiply-add, v_log_f32, accumulate) from
+ * registers on every vector ALU of the chip.  out_terms_per_s [host] double; synchronises `stream`.          */
+int32_t segk_calibrate_vlog(segk_ctx *ctx, double *out_terms_per_s, void *stream);
+/* segk_fbb_score for diagonal (Student-t) components in float32 with the hardware logarithm (opt-in,
+ * `score_precision="f32"`): same arguments and result buffer; the reference expression is
+ * gaussian_components_diag.py:237-259, 347-360 inside FBGMM.log_marg_i (fbgmm.py:256-285).  Error against the fp64
+ * kernel <= 1e-4 relative to max(|log_marg_i|, 1) (the contract of the path; measured ~2e-6).                */
+int32_t segk_fbb_score_diag32(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *f,
+                              const segk_fbatch *bt, int32_t s_lo, int32_t s_n, int32_t b,
+                              const int32_t *n_rows, double *score, void *stream);
 /* get_vec_embed_log_probs + forward_backward (unigram...:474-511, 653-756) for every utterance of
  * block b of the local slices with the uniforms u01(seed, sweep, utt, 0, 1, ...); the slots of the
  * old segments are cleared.  n_utts [host] [s_n].  status bit 16: log_prob == -inf.            */

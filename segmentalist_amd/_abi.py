@@ -115,6 +115,8 @@ SIGNATURES = {
     "segk_fbb_partials": (_i32, [_P, _CP, _FP, _BP, _i32, _i32, _i32, _P, _P, _P]),
     "segk_fbb_prepare": (_i32, [_P, _CP, _FP, _BP, _i32, _P]),
     "segk_fbb_score": (_i32, [_P, _CP, _FP, _BP, _i32, _i32, _i32, _P, _P, _P]),
+    "segk_fbb_score_diag32": (_i32, [_P, _CP, _FP, _BP, _i32, _i32, _i32, _P, _P, _P]),
+    "segk_calibrate_vlog": (_i32, [_P, C.POINTER(_f64), _P]),
     "segk_fbb_make_y": (_i32, [_P, _CP, _BP, _P]),
     "segk_fbb_score_f32": (_i32, [_P, _CP, _FP, _BP, _P, _i64, _P, _P]),
     "segk_fbb_segment": (_i32, [_P, _CP, _FP, _BP, _i32, _i32, _i32, _P, _u64, _i32, _i32, _f64, _f64, _f64, _P, _P,

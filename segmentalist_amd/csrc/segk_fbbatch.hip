@@ -319,6 +319,136 @@ __global__ void k_fbb_score(segk_corpus c, segk_fbgmm f, segk_fbatch bt, FbbMap 
 }
 
 // ---------------------------------------------------------------------------------------
+// The diagonal (Student-t) span score in float32 (`score_precision="f32"`, opt-in): the kernel above spends its life in
+// the fp64 software logarithm of every (row, slot, dimension) term -- one log per term, K_max * D terms per row.  Here
+// the term log(1 + delta^2 q) is four float32 instructions, the logarithm the hardware's v_log_f32 (base 2; ln 2 is
+// folded into the slot's factor), the terms of a (row, slot) accumulate in float32, z = zc - h ln2 acc is formed in
+// fp64 and the online log-sum-exp over the slots runs in float32 in base 2 (v_exp_f32) relative to the running
+// maximum.  Error budget against the fp64 kernel (tests/test_gpu_fbgmm_batch.py measures it): |log2(1 + t)| carries
+// ~2^-23 relative, D terms, times h ln2 <= (v_0 + N + 1)/2 -- observed <= 2e-6 relative to max(|log_marg_i|, 1),
+// contract 1e-4.  FBB_R32 rows per workgroup: the slot tables are read once for 16 rows.
+// ---------------------------------------------------------------------------------------
+#define FBB_R32 16
+template <typename XT>
+__global__ __launch_bounds__(256) void k_fbb_score_diag32(segk_corpus c, segk_fbgmm f, segk_fbatch bt, FbbMap map, int b,
+                                                          double prior_alpha, double *score)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int D = c.D, KM = f.K_max, tid = threadIdx.x, nt = blockDim.x;
+    double *xs64 = (double *)smem;               // [8][D] scratch of the prior predictive (fp64, 8 rows at a time)
+    double *lpr = xs64 + 8 * D;                  // [R32]
+    double *red = lpr + FBB_R32;                 // [16]
+    float *xs = (float *)(red + 16);             // [R32][D]
+    int s, idx;
+    if (!fbb_locate(map, blockIdx.x, &s, &idx)) return;
+    const int slice = map.lo[s];
+    const int64_t r_lo = bt.row_range[(slice * bt.n_blocks + b) * 2], r_hi = bt.row_range[(slice * bt.n_blocks + b) * 2 + 1];
+    const int64_t row0 = r_lo + (int64_t)idx * FBB_R32;
+    const int nr = (int)((r_hi - row0) < FBB_R32 ? (r_hi - row0) : FBB_R32);
+    const XT *X = (const XT *)c.X;
+    for (int j = tid; j < FBB_R32 * D; j += nt) {
+        const int r = j / D, d = j - r * D;
+        xs[j] = r < nr ? (float)X[(row0 + r) * c.ldx + d] : 0.f;
+    }
+    // the prior predictive of every row (an empty slot's likelihood): fp64 as in the fp64 kernel, once per row
+    for (int r8 = 0; r8 < FBB_R32; r8 += 8) {
+        __syncthreads();
+        for (int j = tid; j < 8 * D; j += nt) {
+            const int r = r8 + j / D, d = j % D;
+            xs64[j] = r < nr ? (double)X[(row0 + r) * c.ldx + d] : 0.0;
+        }
+        __syncthreads();
+        const int w = tid >> 6, lane = tid & 63, nw = nt >> 6;
+        for (int r = w; r < 8; r += nw) {
+            const double v = fbb_prior_row<XT>(f, D, xs64 + r * D, lane);
+            if (lane == 0) lpr[r8 + r] = v;
+        }
+    }
+    __syncthreads();
+    const double zc_empty = f.lms * log(prior_alpha / (double)KM);
+    const float LOG2E = 1.4426950408889634f;
+    float mx[FBB_R32], sm[FBB_R32];              // running maximum and sum of 2^(z log2 e - mx)
+#pragma unroll
+    for (int r = 0; r < FBB_R32; r++) { mx[r] = -3.0e38f; sm[r] = 0.f; }
+    for (int k = tid; k < KM; k += nt) {
+        float z2[FBB_R32];
+        if (bt.cnt[k] > 0.0) {
+            float acc[FBB_R32];
+#pragma unroll
+            for (int r = 0; r < FBB_R32; r++) acc[r] = 0.f;
+            int d = 0;
+            for (; d + 4 <= D; d += 4) {
+                float m[4], q[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    m[j] = (float)bt.mean_t[(int64_t)(d + j) * KM + k];
+                    q[j] = (float)bt.q_t[(int64_t)(d + j) * KM + k];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+#pragma unroll
+                    for (int r = 0; r < FBB_R32; r++) {
+                        const float delta = m[j] - xs[r * D + d + j];
+                        acc[r] += __builtin_amdgcn_logf(1.f + (delta * delta) * q[j]);       // v_log_f32: log2
+                    }
+            }
+            for (; d < D; d++) {
+                const float m = (float)bt.mean_t[(int64_t)d * KM + k], q = (float)bt.q_t[(int64_t)d * KM + k];
+#pragma unroll
+                for (int r = 0; r < FBB_R32; r++) {
+                    const float delta = m - xs[r * D + d];
+                    acc[r] += __builtin_amdgcn_logf(1.f + (delta * delta) * q);
+                }
+            }
+            const double zc = bt.zconst[k], hl = bt.half[k] * 0.6931471805599453;
+#pragma unroll
+            for (int r = 0; r < FBB_R32; r++) z2[r] = (float)((zc - hl * (double)acc[r]) * 1.4426950408889634);
+        } else {
+#pragma unroll
+            for (int r = 0; r < FBB_R32; r++) z2[r] = (float)((zc_empty + lpr[r]) * 1.4426950408889634);
+        }
+#pragma unroll
+        for (int r = 0; r < FBB_R32; r++) {
+            const float nm = fmaxf(mx[r], z2[r]);
+            sm[r] = sm[r] * __builtin_amdgcn_exp2f(mx[r] - nm) + __builtin_amdgcn_exp2f(z2[r] - nm);
+            mx[r] = nm;
+        }
+    }
+    (void)LOG2E;
+    const double norm = f.lms * log(bt.scal[0] + prior_alpha);
+#pragma unroll
+    for (int r = 0; r < FBB_R32; r++) {
+        const double M = block_max((double)mx[r], red);
+        const double part = sm[r] == 0.f ? 0.0 : (double)sm[r] * exp2((double)mx[r] - M);
+        const double S = block_sum(part, red);
+        if (tid == 0 && r < nr) score[row0 + r] = (log2(S) + M) * 0.6931471805599453 - norm;
+    }
+}
+
+// calibration of the roofline of k_fbb_score_diag32: the same four float32 instructions per term (subtract, multiply,
+// multiply-add, v_log_f32) and the accumulate, operands in registers, eight independent chains per thread -- what the
+// vector ALUs deliver on this chip for the kernel's inner term with nothing else in the way
+__global__ __launch_bounds__(256) void k_vlog_calibrate(int iters, float seed, float *out)
+{
+    float acc[8], m[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) { acc[j] = 0.f; m[j] = seed + 0.01f * (float)(threadIdx.x + j); }
+    float x = seed * 0.5f, q = 1.0f + seed;
+    for (int i = 0; i < iters; i++) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const float delta = m[j] - x;
+            acc[j] += __builtin_amdgcn_logf(1.f + (delta * delta) * q);
+        }
+        x += 1e-6f;
+    }
+    float t = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; j++) t += acc[j];
+    if (t == 12345.678f) out[0] = t;              // never true: keeps the loop alive
+}
+
+// ---------------------------------------------------------------------------------------
 // boundaries of one utterance per workgroup (128 threads; wave 0 runs the DP)
 // ---------------------------------------------------------------------------------------
 __global__ void k_fbb_segment(segk_corpus c, segk_fbatch bt, FbbMap map, int b, uint64_t sweep, int n_max, double wip,
@@ -833,6 +963,62 @@ int32_t segk_fbb_score(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *f,
                                b, alpha, score);
     });
     SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+int32_t segk_fbb_score_diag32(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *f, const segk_fbatch *bt, int32_t s_lo,
+                              int32_t s_n, int32_t b, const int32_t *n_rows, double *score, void *stream)
+{
+    int rc = check_fbb(c, f, bt);
+    if (rc) return rc;
+    SEGK_REQUIRE(f->cov_type == 1, "the float32 span score of this entry point is the diagonal (Student-t) one");
+    FbbMap m;
+    rc = make_map(&m, s_lo, s_n, n_rows, FBB_R32);
+    if (rc) return rc;
+    if (m.off[s_n] == 0) return SEGK_OK;
+    const double alpha = f->lm_unigram ? f->lm_a : f->alpha;
+    const size_t lds = (size_t)(8 * c->D + FBB_R32 + 16) * sizeof(double) + (size_t)FBB_R32 * c->D * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+    const bool prof = ctx && ctx->prof_on != 0;
+    const int slot = prof ? ctx->prof_n % SEGK_PROF_SLOTS : 0;
+    int64_t rows = 0;
+    for (int s = 0; s < s_n; s++) rows += n_rows[s];
+    if (prof) SEGK_CHECK_HIP(hipEventRecord(ctx->prof_ev[slot][0], st));
+    DISPATCH_XT(c, hipLaunchKernelGGL((k_fbb_score_diag32<XT>), dim3(m.off[s_n]), dim3(256), lds, st, *c, *f, *bt, m, b, alpha, score););
+    if (prof) {
+        SEGK_CHECK_HIP(hipEventRecord(ctx->prof_ev[slot][1], st));
+        ctx->prof_rows[slot] = rows;
+        ctx->prof_kind = 5;
+        ctx->prof_launches = 1;
+        ctx->prof_n++;
+    }
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+// terms per second the vector ALUs sustain on the inner term of k_fbb_score_diag32 (k_vlog_calibrate), measured with
+// events on `stream`; synchronises.  out_terms_per_s [host] double.
+int32_t segk_calibrate_vlog(segk_ctx *ctx, double *out_terms_per_s, void *stream)
+{
+    SEGK_REQUIRE(ctx && out_terms_per_s, "arguments");
+    hipStream_t st = (hipStream_t)stream;
+    float *dummy = nullptr;
+    SEGK_CHECK_HIP(hipMalloc((void **)&dummy, 64));
+    hipEvent_t e0, e1;
+    SEGK_CHECK_HIP(hipEventCreate(&e0));
+    SEGK_CHECK_HIP(hipEventCreate(&e1));
+    const int iters = 4096, grid = ctx->n_cu * 8;
+    hipLaunchKernelGGL(k_vlog_calibrate, dim3(grid), dim3(256), 0, st, iters, 0.37f, dummy);      // warm-up
+    SEGK_CHECK_HIP(hipEventRecord(e0, st));
+    hipLaunchKernelGGL(k_vlog_calibrate, dim3(grid), dim3(256), 0, st, iters, 0.37f, dummy);
+    SEGK_CHECK_HIP(hipEventRecord(e1, st));
+    SEGK_CHECK_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    SEGK_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(dummy);
+    *out_terms_per_s = (double)grid * 256.0 * 8.0 * iters / ((double)ms * 1e-3);
     return SEGK_OK;
 }
 

@@ -684,13 +684,15 @@ class FbgmmBatchSweeper(object):
         dev = _dev()
         self.df, self.group = df, group
         assert score_precision in ("f64", "f32", "f16")
-        if score_precision != "f64" and df.cov_type != 0:
-            raise SegkError("score_precision='%s' (matrix-core span score) exists for fixed-variance components only"
-                            % score_precision)
+        if score_precision == "f16" and df.cov_type != 0:
+            raise SegkError("score_precision='f16' (matrix-core span score) exists for fixed-variance components only")
         if score_precision == "f16" and 2 * df.corpus.D > 208:
             raise SegkError("score_precision='f16' supports D <= 104")
-        self.score_f32 = score_precision in ("f32", "f16")
+        # fixed variance: the span score as a matrix-core contraction (f32 / f16); diagonal: the Student-t terms in
+        # float32 with the hardware logarithm (f32)
+        self.score_f32 = score_precision in ("f32", "f16") and df.cov_type == 0
         self.score_f16 = score_precision == "f16"
+        self.score_diag32 = score_precision == "f32" and df.cov_type == 1
         c = df.corpus
         self.S, self.B = int(n_stat_blocks), int(n_gibbs_blocks)
         rank, world = 0, 1
@@ -854,6 +856,8 @@ class FbgmmBatchSweeper(object):
             if self.score_f32:
                 check(L.segk_fbb_score_f32(ctx, cp, fp, bp, ptr(self._block_rows[b]), self._block_rows[b].numel(),
                                            ptr(df.score), st))
+            elif self.score_diag32:
+                check(L.segk_fbb_score_diag32(ctx, cp, fp, bp, self.s_lo, self.s_n, b, self._n_rows[b], ptr(df.score), st))
             else:
                 check(L.segk_fbb_score(ctx, cp, fp, bp, self.s_lo, self.s_n, b, self._n_rows[b], ptr(df.score), st))
             check(L.segk_fbb_segment(ctx, cp, fp, bp, self.s_lo, self.s_n, b, self._n_utts[b], sw, int(n_slices_min),

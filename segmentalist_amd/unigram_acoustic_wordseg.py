@@ -42,8 +42,9 @@ class UnigramAcousticWordseg(object):
         over the ranks of `process_group` when torch.distributed is initialised).
         score_precision="f32" / "f16" (batch mode, fixed-variance components) evaluates the span
         scores on the matrix cores (fp32 MFMA, or two-way fp16 splits of the fp32 operands on the
-        16-bit pipe) -- within the 1e-4 tolerance of the path, 5x / 10x faster; "f64" reproduces the
-        specification to the last draw."""
+        16-bit pipe) -- within the 1e-4 tolerance of the path, 5x / 10x faster; with diagonal
+        components "f32" evaluates the Student-t terms in float32 with the hardware logarithm (same
+        tolerance); "f64" reproduces the specification to the last draw."""
         logger.info("Initializing")
         assert sync in ("sequential", "batch")
         self.sync = sync
