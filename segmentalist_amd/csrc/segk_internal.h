@@ -29,6 +29,8 @@ struct segk_ctx {
     hipStream_t aux2;
     hipEvent_t ev_chunk[8], ev_join2;
     int aux2_busy, prof_launches;
+    int aux_runs_pair;            // the second stream carries the exact pair stage, the full scan stays on the caller's stream
+    int32_t *defer_zero;          // segk_kmeans_score: queue length the chosen filter path still has to clear
     int overlap_req, aux_busy, pre_zeroed;
     int capturing;                // segk_graph_begin .. segk_graph_end
     // value hashes of the rows of the means most recently prepared (segk_kmeans_mark_duplicates)

@@ -2,12 +2,6 @@
 // (one of the translation units of the k-means path; shared helpers: segk_kmeans_dev.h)
 #include "segk_kmeans_dev.h"
 
-__global__ void k_zero_two(int32_t *a, int32_t *b)
-{
-    if (threadIdx.x == 0) *a = 0;
-    if (threadIdx.x < 16) b[threadIdx.x] = 0;        // the pre-filter's queue lengths, one per chunk
-}
-
 extern "C" {
 
 int32_t segk_kmeans_clear_queue(segk_ctx *ctx, const segk_cand *cand, void *stream)
@@ -58,8 +52,10 @@ int32_t segk_kmeans_filter(segk_ctx *ctx, const segk_corpus *c, const segk_kmean
         if (c->sp_pieces == 2 && A.fuse_exact && pre_mode != 0 && (pre_mode == 1 || n > 1024 * (int64_t)ctx->n_cu) &&
             n < (int64_t)1 << 30)
             return segk_dispatch_score_pre(ctx, A, segk_b3_kp(c->D) / 16, st);
+        segk_flush_deferred_zero(ctx, st);
         return segk_dispatch_score_sp(ctx, A, segk_b3_kp(c->D) / 16, c->sp_pieces, st);
     }
+    segk_flush_deferred_zero(ctx, st);
     return segk_dispatch_score_f32(ctx, c, m, A, st);
 }
 
@@ -69,9 +65,9 @@ int32_t segk_kmeans_score(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans
     SEGK_REQUIRE(ctx, "ctx");
     int rc;
     if (ctx->pre_queue && cand && cand->count) {
-        // one tiny kernel instead of two 4-byte memsets: the caller's queue length and the pre-filter's
-        hipLaunchKernelGGL(k_zero_two, dim3(1), dim3(64), 0, (hipStream_t)stream, cand->count, ctx->pre_queue);
-        ctx->pre_zeroed = 1;
+        // the caller's queue length and the pre-filter's are cleared by the first kernel of the path the filter takes
+        // (the pre-filter's own start-up kernel, or one tiny kernel instead of two 4-byte memsets)
+        ctx->defer_zero = cand->count;
         rc = SEGK_OK;
     } else {
         rc = segk_kmeans_clear_queue(ctx, cand, stream);
@@ -83,10 +79,13 @@ int32_t segk_kmeans_score(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans
     rc = segk_kmeans_filter(ctx, c, m, ids, row0, n, cand, stream);
     ctx->overlap_req = 0;
     ctx->pre_zeroed = 0;
+    segk_flush_deferred_zero(ctx, (hipStream_t)stream);        // (an early error return of the filter: nothing was launched)
     if (!ctx->aux_busy) return rc ? rc : segk_resolve_on(ctx, c, m, ids, row0, n, cand, status, stream);
     // the filter forked the second stream: whatever happened after the fork, join it again, so that the
     // next call never finds work of this one still running beside the caller's stream
-    if (!rc) rc = segk_resolve_on(ctx, c, m, ids, row0, n, cand, status, (void *)ctx->aux);
+    const bool pair_on_aux = ctx->aux_runs_pair != 0;
+    ctx->aux_runs_pair = 0;
+    if (!rc) rc = segk_resolve_on(ctx, c, m, ids, row0, n, cand, status, pair_on_aux ? stream : (void *)ctx->aux);
     ctx->aux_busy = 0;
     SEGK_CHECK_HIP(hipEventRecord(ctx->ev_join, ctx->aux));
     SEGK_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, ctx->ev_join, 0));

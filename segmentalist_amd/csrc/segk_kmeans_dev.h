@@ -580,6 +580,21 @@ __device__ __forceinline__ int dev_dup_first(const unsigned long long *keys, con
     return first[slot];
 }
 
+// queue lengths of a score call: the caller's ambiguity queue and the pre-filter's per-chunk counters
+static __global__ void k_zero_two(int32_t *a, int32_t *b)
+{
+    if (threadIdx.x == 0) *a = 0;
+    if (threadIdx.x < 16) b[threadIdx.x] = 0;
+}
+// segk_kmeans_score defers that clearing to the first kernel of the path its filter takes (ctx->defer_zero)
+static inline void segk_flush_deferred_zero(segk_ctx *ctx, hipStream_t st)
+{
+    if (ctx && ctx->defer_zero) {
+        hipLaunchKernelGGL(k_zero_two, dim3(1), dim3(64), 0, st, ctx->defer_zero, ctx->pre_queue);
+        ctx->defer_zero = nullptr;
+    }
+}
+
 // ---- cross-unit entry points (host side; each lives in the unit named) --------------------------------
 // segk_prepare.hip
 int segk_kmeans_prepare_impl(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m, void *stream, bool mnorm_zeroed);

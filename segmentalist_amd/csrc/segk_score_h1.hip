@@ -480,6 +480,26 @@ __global__ __launch_bounds__(64) void k_kmeans_exact_pair2(ScoreArgs A)
     }
 }
 
+// start-up kernel of the pre-filter path, ONE workgroup: the queue lengths of the call cleared (the caller's, when
+// segk_kmeans_score deferred it, and the per-chunk counters), then the rows the big launches do not cover (fewer than
+// SEGK_TAIL_QUEUE) put straight into the first chunk's queue (the order inside the queue is immaterial)
+__global__ __launch_bounds__(1024) void k_pre_begin(ScoreArgs A, int32_t *zero_cnt, int32_t *hdr)
+{
+    if (threadIdx.x == 0 && zero_cnt) *zero_cnt = 0;
+    if (threadIdx.x < 16) hdr[threadIdx.x] = 0;
+    __syncthreads();
+    for (int64_t r = threadIdx.x; r < A.n; r += blockDim.x) {
+        const int32_t id = A.ids ? A.ids[r] : (int32_t)(A.row0 + r);
+        if (id < 0) continue;
+        const int q = atomicAdd(A.pre_count, 1);
+        if (q < A.pre_cap) A.pre_queue[q] = id;
+        else {
+            const int q2 = atomicAdd(A.cand.count, 1);
+            if (q2 < A.amb_cap) A.cand.queue[q2] = id;
+        }
+    }
+}
+
 // rows the pre-filter launch does not cover (fewer than SEGK_TAIL_QUEUE): straight to its second stage
 __global__ void k_pre_queue_rows(ScoreArgs A)
 {
@@ -516,8 +536,12 @@ static int launch_score_pre(segk_ctx *ctx, ScoreArgs A, hipStream_t st)
 #ifdef SEGK_STAMP
     A.stamp = getenv("SEGK_STAMP_PTR") ? (unsigned long long *)strtoull(getenv("SEGK_STAMP_PTR"), nullptr, 0) : nullptr;
 #endif
-    if (ctx->pre_zeroed) ctx->pre_zeroed = 0;          // segk_kmeans_score cleared it together with the caller's queue length
-    else SEGK_CHECK_HIP(hipMemsetAsync(ctx->pre_queue, 0, 16 * sizeof(int32_t), st));
+    // queue lengths: segk_kmeans_score leaves the clearing (its caller's queue length and this path's counters) to the
+    // start-up kernel below; a bare segk_kmeans_filter call clears the counters here
+    int32_t *zero_cnt = ctx->defer_zero;
+    ctx->defer_zero = nullptr;
+    ctx->pre_zeroed = 0;
+    bool zero_pending = true;
 
     constexpr size_t lds = 2 * (size_t)(KS + 1) * 256 * sizeof(float);
     const int64_t slots = 2 * (int64_t)ctx->n_cu;      // two 4-wave workgroups per CU (launch bounds)
@@ -564,7 +588,14 @@ static int launch_score_pre(segk_ctx *ctx, ScoreArgs A, hipStream_t st)
     T.row0 = A.row0 + n4;
     T.ids = A.ids ? A.ids + n4 : nullptr;
     T.pre_cap = (int)(n_chunks > 1 ? chunk_rows : cap2);
-    if (rem_queued) hipLaunchKernelGGL(k_pre_queue_rows, dim3((unsigned)((rem + 255) / 256)), dim3(256), 0, st, T);
+    if (rem_queued) {                                  // one start-up kernel: clear the counters, queue the remainder
+        hipLaunchKernelGGL(k_pre_begin, dim3(1), dim3(1024), 0, st, T, zero_cnt, ctx->pre_queue);
+        zero_pending = false;
+    }
+    if (zero_pending) {
+        if (zero_cnt) hipLaunchKernelGGL(k_zero_two, dim3(1), dim3(64), 0, st, zero_cnt, ctx->pre_queue);
+        else SEGK_CHECK_HIP(hipMemsetAsync(ctx->pre_queue, 0, 16 * sizeof(int32_t), st));
+    }
     hipStream_t st2 = st, st3 = st;
     if (overlap) {
         if (!ctx->aux) {
@@ -664,7 +695,10 @@ static int launch_score_pre(segk_ctx *ctx, ScoreArgs A, hipStream_t st)
     }
     // The decided rows' exact stage (this stream) and the undecided rows' second stage + full scan (second
     // stream, segk_kmeans_score only) touch disjoint rows: side by side, the exact stage leaving LDS for one
-    // second-stage workgroup per CU.  Joined at the end of segk_kmeans_score.
+    // second-stage workgroup per CU.  Joined at the end of segk_kmeans_score.  (The other way round -- the longer
+    // branch on the caller's stream, so that the join finds its event already fired -- was measured SLOWER, 1 503
+    // against 1 622 sweeps/s: the exact stage then starts a cross-stream signal later and both branches are about
+    // equally long.)
     if (overlap) {
         SEGK_CHECK_HIP(hipEventRecord(ctx->ev_fork, st));
         SEGK_CHECK_HIP(hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));

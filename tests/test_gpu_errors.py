@@ -86,7 +86,7 @@ def test_library_refusals(gpu):
     from segmentalist_amd.niw import NIW
     dseg = uaw.UnigramAcousticWordseg(fbgmm.FBGMM, 1.0, 5, NIW(*cases.diag_prior_params(6)), *corpus, covariance_type="diag",
                                       n_slices_max=4, beta_sent_boundary=-1, sync="batch", n_gibbs_blocks=2, n_stat_blocks=2,
-                                      score_precision="f32")
+                                      score_precision="f16")
     with pytest.raises(SegkError, match="fixed-variance"):
         dseg.batch_sweep_async()
 
