@@ -250,6 +250,21 @@ int32_t segk_kmeans_clean_components(segk_ctx *ctx, const segk_corpus *c, segk_k
 int32_t segk_kmeans_del_component(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m, int32_t k,
                                   int32_t *status, void *stream);
 
+/* One sweep of the reference's sequential chain (SegmentalKMeansWordseg.segment's inner loop,
+ * kmeans_acoustic_wordseg.py:393-399): for every utterance of `order` [HOST] int32 [n_order] in turn, segment_i
+ * (:225-332) -- A1 for its spans directly in the reference's arithmetic (one kernel: no filter, no operand images),
+ * segk_kmeans_segment, the update of segk_kmeans_update_utt -- three launches per utterance enqueued by one call;
+ * the operand images are refreshed once at the end.  Same results as calling segk_kmeans_score /
+ * segk_kmeans_segment / segk_kmeans_update_utt per utterance (bit-identical to the reference's chain), about half
+ * the time.  keys_scratch [dev] uint64 [N_max (N_max + 1) / 2 + 2], zeroed by the caller once.  float32 data;
+ * SEGK_ERR_UNSUPPORTED otherwise.                                                                           */
+int32_t segk_kmeans_sequential_sweep(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m,
+                                     const int32_t *order, int32_t n_order, int32_t n_slices_min,
+                                     int32_t n_slices_max, double wip, const segk_cand *cand,
+                                     uint64_t *keys_scratch, uint8_t *boundaries, int32_t *old_tok,
+                                     int32_t *new_tok, int32_t *new_k, int32_t *n_old, int32_t *n_new,
+                                     int32_t *n_flag, double *out_total, int32_t *status, void *stream);
+
 /* A11 batch-synchronous update (DESIGN.md "batch mode"; spec: oracle/np_oracle.py
  * kmeans_batch_sweep, rank split: oracle/np_dist.py).  No reference counterpart: the reference
  * updates its statistics item by item (kmeans_components.py:93-166); the batch sweep rebuilds

@@ -91,6 +91,8 @@ SIGNATURES = {
     "segk_dp_tri": (_i32, [_P, _i32, _P, _P, _P, _i32, _i32, _i32, _f64, _f64, _P, _i64, _P, _i64, _P, _P, _P,
                            _P, _i64, _P]),
     "segk_kmeans_update_utt": (_i32, [_P, _CP, _KP, _i32, _P, _P, _P, _P, _P, _P, _P]),
+    "segk_kmeans_sequential_sweep": (_i32, [_P, _CP, _KP, _P, _i32, _i32, _i32, _f64, _DP, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                                            _P, _P]),
     "segk_kmeans_add_item": (_i32, [_P, _CP, _KP, _i64, _i32, _P, _P]),
     "segk_kmeans_del_item": (_i32, [_P, _CP, _KP, _i64, _P, _P]),
     "segk_kmeans_clean_components": (_i32, [_P, _CP, _KP, _P, _P]),

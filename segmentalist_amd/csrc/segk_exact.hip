@@ -272,6 +272,157 @@ __global__ void k_kmeans_neg_sqrd_norm(segk_corpus c, segk_kmeans m, int64_t row
 
 // ======================================================================================
 
+// ======================================================================================
+// Sequential (reference-chain) mode: A1 for the spans of ONE utterance, directly in the reference's arithmetic -- no
+// filter, no operand images (which the per-utterance updates would have to refresh: two more launches).  The
+// utterance's triangular span table holds <= N (N + 1) / 2 row ids; workgroup g scores them against components
+// 32 g .. 32 g + 31 (their means and, chunk by chunk, the spans' rows in LDS), the 32 lanes of a wave half share a
+// span, the best (score, lowest index) of the 32 goes to the span's 64-bit key by atomic maximum (32 workgroups per
+// address; with 8 components per workgroup and the rows read from memory, lane by lane, the kernel took 32 us) -- key = ordered score bits << 32 | ~index, so that the maximum is
+// np.argmax's first maximum -- and the LAST workgroup to finish unpacks the keys into cand.k / cand.s and clears them
+// for the next utterance.  float32 data (a float64 score does not fit beside its index).
+// keys [dev] uint64 [tri_max + 2]: [0..tri) the spans' keys, [tri_max] the arrival counter.
+// ======================================================================================
+#define SEQ_CPB 32          /* components per workgroup */
+#define SEQ_JCH 128         /* valid spans per LDS chunk */
+#define SEQ_MAXTRI 2048     /* span table entries the kernel compacts in one go (N_max <= 63) */
+__global__ __launch_bounds__(1024) void k_seq_score(segk_corpus c, segk_kmeans m, int utt, int tri_max, segk_cand cand,
+                                                    unsigned long long *keys)
+{
+    extern __shared__ __attribute__((aligned(16))) float s_buf[];        // [SEQ_CPB][D + 1] means, then [SEQ_JCH][LDX] rows
+    __shared__ int s_last, s_nv;
+    __shared__ short s_j[SEQ_MAXTRI];                                     // valid spans: position in the table
+    __shared__ int32_t s_id[SEQ_MAXTRI];                                  // ... and embedding row
+    const int tid = threadIdx.x, D = c.D;
+    const int LDM = D + 1;                                                // odd stride: the 32 lanes of a span read 32 banks
+    const int LDX = (D + 3) & ~3;
+    float *s_means = s_buf, *s_x = s_buf + ((SEQ_CPB * LDM + 3) & ~3);
+    const int N = c.lengths[utt], tri = N * (N + 1) / 2;
+    const int32_t *vid = c.vec_ids + (int64_t)utt * ((int64_t)c.N_max * (c.N_max + 1) / 2);
+    const float *X = (const float *)c.X;
+    const float *means = (const float *)m.means;
+    const int k0 = blockIdx.x * SEQ_CPB;
+    const bool vec4 = (D & 3) == 0 && (c.ldx & 3) == 0;
+    if (tid == 0) s_nv = 0;
+    __syncthreads();
+    // the valid spans of the table, compacted (their order is immaterial); every load of a thread in flight together
+    {
+        int32_t idv[SEQ_MAXTRI / 1024];
+#pragma unroll
+        for (int q = 0; q < SEQ_MAXTRI / 1024; q++) {
+            const int j = q * 1024 + tid;
+            idv[q] = j < tri ? vid[j] : -1;
+        }
+#pragma unroll
+        for (int q = 0; q < SEQ_MAXTRI / 1024; q++)
+            if (idv[q] >= 0) {
+                const int pos = atomicAdd(&s_nv, 1);
+                s_j[pos] = (short)(q * 1024 + tid);
+                s_id[pos] = idv[q];
+            }
+    }
+    // this workgroup's means
+    if (vec4) {
+        const int D4 = D >> 2;
+        for (int q = tid; q < SEQ_CPB * D4; q += blockDim.x) {
+            const int cc = q / D4, d4 = q - cc * D4, kk = k0 + cc;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (kk < m.K_max) v = *reinterpret_cast<const float4 *>(means + (int64_t)kk * D + 4 * d4);
+            float *dst = s_means + cc * LDM + 4 * d4;
+            dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+        }
+    } else {
+        for (int q = tid; q < SEQ_CPB * D; q += blockDim.x) {
+            const int cc = q / D, kk = k0 + cc;
+            s_means[cc * LDM + (q - cc * D)] = kk < m.K_max ? means[(int64_t)kk * D + (q - cc * D)] : 0.f;
+        }
+    }
+    __syncthreads();
+    const int nv = s_nv;
+    for (int v0 = 0; v0 < nv; v0 += SEQ_JCH) {
+        const int nj = nv - v0 < SEQ_JCH ? nv - v0 : SEQ_JCH;
+        if (v0 > 0) __syncthreads();
+        // the chunk's rows into LDS: consecutive threads on consecutive 16 bytes of a row, four loads in flight per thread
+        if (vec4) {
+            const int D4 = D >> 2, tot = nj * D4;
+            for (int q0 = tid; q0 < tot; q0 += 4 * blockDim.x) {
+                float4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int q = q0 + u * blockDim.x, qq = q < tot ? q : 0;
+                    const int jl = qq / D4, d4 = qq - jl * D4;
+                    v[u] = *reinterpret_cast<const float4 *>(X + (int64_t)s_id[v0 + jl] * c.ldx + 4 * d4);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int q = q0 + u * blockDim.x;
+                    if (q < tot) {
+                        const int jl = q / D4, d4 = q - jl * D4;
+                        *reinterpret_cast<float4 *>(s_x + jl * LDX + 4 * d4) = v[u];
+                    }
+                }
+            }
+        } else {
+            for (int q = tid; q < nj * D; q += blockDim.x) {
+                const int jl = q / D, d = q - jl * D;
+                s_x[jl * LDX + d] = X[(int64_t)s_id[v0 + jl] * c.ldx + d];
+            }
+        }
+        __syncthreads();
+        for (int p0 = 0; p0 < nj * SEQ_CPB; p0 += blockDim.x) {
+            const int p = p0 + tid, jl = p / SEQ_CPB, cidx = p % SEQ_CPB, k = k0 + cidx;
+            unsigned long long key = 0ull;
+            if (jl < nj && k < m.K_max) {
+                const float sc = neg_sqd_exact<float>(s_means + cidx * LDM, s_x + jl * LDX, D);
+                const unsigned int bits = __float_as_uint(sc);
+                const unsigned int ord = (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);
+                key = ((unsigned long long)ord << 32) | (unsigned long long)(0xffffffffu - (unsigned int)k);
+            }
+            // the 32 components of a span sit on the 32 lanes of one wave half
+            for (int o = 1; o < SEQ_CPB; o <<= 1) {
+                const unsigned long long other = __shfl_xor(key, o);
+                key = other > key ? other : key;
+            }
+            if (cidx == 0 && jl < nj) atomicMax(&keys[s_j[v0 + jl]], key);
+        }
+    }
+    // last workgroup done: unpack (atomic exchanges read the keys where the atomic maxima were performed, and clear them)
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned long long arrived = atomicAdd(&keys[tri_max], 1ull);
+        s_last = arrived == (unsigned long long)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    for (int v = tid; v < nv; v += blockDim.x) {
+        const unsigned long long key = atomicExch(&keys[s_j[v]], 0ull);
+        const int32_t id = s_id[v];
+        const unsigned int ord = (unsigned int)(key >> 32);
+        const unsigned int bits = (ord & 0x80000000u) ? (ord & 0x7fffffffu) : ~ord;
+        cand.k[id] = (int32_t)(0xffffffffu - (unsigned int)(key & 0xffffffffu));
+        cand.s[id] = (double)__uint_as_float(bits);
+    }
+    if (tid == 0) keys[tri_max] = 0ull;
+}
+
+int segk_launch_seq_score(const segk_corpus *c, const segk_kmeans *m, int utt, const segk_cand *cand, unsigned long long *keys,
+                          hipStream_t st)
+{
+    const int tri_max = c->N_max * (c->N_max + 1) / 2;
+    const size_t lds = ((size_t)((SEQ_CPB * (c->D + 1) + 3) & ~3) + (size_t)SEQ_JCH * ((c->D + 3) & ~3)) * sizeof(float);
+    SEGK_REQUIRE(lds <= 140 * 1024, "D too large for the sequential score kernel");
+    SEGK_REQUIRE(tri_max <= SEQ_MAXTRI, "more than 63 landmarks per utterance: use the per-utterance calls");
+    static size_t lds_set = 0;
+    if (lds > 48 * 1024 && lds > lds_set) {
+        SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_seq_score, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        lds_set = lds;
+    }
+    hipLaunchKernelGGL(k_seq_score, dim3((m->K_max + SEQ_CPB - 1) / SEQ_CPB), dim3(1024), lds, st, *c, *m, utt, tri_max, *cand, keys);
+    return SEGK_OK;
+}
+
 extern "C" {
 
 int32_t segk_kmeans_resolve(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m, const int32_t *ids,

@@ -97,4 +97,36 @@ int32_t segk_kmeans_score(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans
     return rc;
 }
 
+int32_t segk_kmeans_sequential_sweep(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m, const int32_t *order, int32_t n_order,
+                                     int32_t n_slices_min, int32_t n_slices_max, double wip, const segk_cand *cand,
+                                     uint64_t *keys_scratch, uint8_t *boundaries, int32_t *old_tok, int32_t *new_tok,
+                                     int32_t *new_k, int32_t *n_old, int32_t *n_new, int32_t *n_flag, double *out_total,
+                                     int32_t *status, void *stream)
+{
+    SEGK_REQUIRE(ctx, "ctx");
+    int rc = check_corpus(c);
+    if (rc) return rc;
+    SEGK_REQUIRE(order && n_order >= 0 && cand && cand->k && cand->s && keys_scratch, "sequential sweep operands");
+    SEGK_REQUIRE(c->vec_ids && c->lengths && c->n_utt > 0, "corpus without utterances");
+    if (c->x_dtype != SEGK_F32) {
+        segk_set_error("segk_kmeans_sequential_sweep: float32 data only (use the per-utterance calls for float64)");
+        return SEGK_ERR_UNSUPPORTED;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    for (int32_t q = 0; q < n_order; q++) {
+        const int32_t u = order[q];
+        SEGK_REQUIRE(u >= 0 && u < c->n_utt, "utterance index out of range");
+        rc = segk_launch_seq_score(c, m, u, cand, (unsigned long long *)keys_scratch, st);
+        if (rc) return rc;
+        rc = segk_kmeans_segment(ctx, c, m, nullptr, u, 1, n_slices_min, n_slices_max, wip, cand, boundaries, old_tok, new_tok,
+                                 new_k, n_old, n_new, n_flag, out_total, status, stream);
+        if (rc) return rc;
+        rc = segk_launch_update_utt(c, m, u, old_tok, new_tok, new_k, n_old, n_new, status, st);
+        if (rc) return rc;
+    }
+    SEGK_LAUNCH_CHECK();
+    // the operand images of the filters, once per sweep instead of once per utterance
+    return segk_kmeans_prepare(ctx, c, m, stream);
+}
+
 }  // extern "C"

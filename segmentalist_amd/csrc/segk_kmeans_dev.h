@@ -605,6 +605,11 @@ int segk_dispatch_score_sp(segk_ctx *ctx, const ScoreArgs &A, int ks, int pieces
 int segk_launch_sp_second(const ScoreArgs &B, int ks, hipStream_t st);
 // segk_score_h1.hip: one-product pre-filter + exact pair stage + second stage
 int segk_dispatch_score_pre(segk_ctx *ctx, const ScoreArgs &A, int ks, hipStream_t st);
+// segk_exact.hip / segk_stats.hip: the pieces of the sequential (reference-chain) sweep
+int segk_launch_seq_score(const segk_corpus *c, const segk_kmeans *m, int utt, const segk_cand *cand, unsigned long long *keys,
+                          hipStream_t st);
+int segk_launch_update_utt(const segk_corpus *c, segk_kmeans *m, int utt, const int32_t *old_tok, const int32_t *new_tok,
+                           const int32_t *new_k, const int32_t *n_old, const int32_t *n_new, int32_t *status, hipStream_t st);
 // segk_exact.hip: full scan of the ambiguity queue
 int segk_resolve_on(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m, const int32_t *ids, int64_t row0, int64_t n,
                     const segk_cand *cand, int32_t *status, void *stream);

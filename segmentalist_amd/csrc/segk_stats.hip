@@ -976,6 +976,17 @@ static int launch_update(const segk_corpus *c, segk_kmeans *m, int op, int utt, 
     return SEGK_OK;
 }
 
+}  // extern "C"
+
+// the per-utterance update alone (no image refresh): segk_kmeans_sequential_sweep refreshes the images once per sweep
+int segk_launch_update_utt(const segk_corpus *c, segk_kmeans *m, int utt, const int32_t *old_tok, const int32_t *new_tok,
+                           const int32_t *new_k, const int32_t *n_old, const int32_t *n_new, int32_t *status, hipStream_t st)
+{
+    return launch_update(c, m, 0, utt, 0, 0, old_tok, new_tok, new_k, n_old, n_new, status, st);
+}
+
+extern "C" {
+
 int32_t segk_kmeans_update_utt(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m, int32_t utt,
                                const int32_t *old_tok, const int32_t *new_tok, const int32_t *new_k,
                                const int32_t *n_old, const int32_t *n_new, int32_t *status, void *stream)

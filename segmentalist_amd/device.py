@@ -320,6 +320,23 @@ class DeviceKMeans(object):
                                              ptr(self.new_tok), ptr(self.new_k), ptr(self.n_old),
                                              ptr(self.n_new), ptr(self.status), _abi.stream()))
 
+    def sequential_sweep(self, boundaries, order, n_slices_min, n_slices_max, wip):
+        """segment_i for every utterance of `order` in turn, enqueued by ONE library call (three launches per utterance:
+        direct exact score, DP, update; segk_kmeans_sequential_sweep).  Returns False when the library does not
+        support the data (float64): the caller then walks the utterances itself."""
+        if self.corpus.x_dtype != SEGK_F32 or self.corpus.N_max > 63:
+            return False
+        torch = _torch()
+        self.ensure_assignments()
+        if getattr(self, "_seq_keys", None) is None:
+            self._seq_keys = torch.zeros(self.corpus.tri + 2, dtype=torch.int64, device=self.means.device)
+        arr = (C.c_int32 * len(order))(*[int(i) for i in order])
+        check(self._L.segk_kmeans_sequential_sweep(
+            self._ctx, self._cp(), C.byref(self.m), arr, len(order), int(n_slices_min), int(n_slices_max), float(wip),
+            C.byref(self.cand), ptr(self._seq_keys), ptr(boundaries), ptr(self.old_tok), ptr(self.new_tok), ptr(self.new_k),
+            ptr(self.n_old), ptr(self.n_new), ptr(self.n_flag), ptr(self.out_total), ptr(self.status), _abi.stream()))
+        return True
+
     def batch_record(self, lo, hi):
         """The record values of the batch sweep just enqueued, in ONE device-to-host copy (segk_kmeans_batch_record):
         (sum_neg_len_sqrd_norm, K, n_tokens, sum_neg_sqrd_norm); raises like check_status."""

@@ -17,6 +17,7 @@ keys.  Two execution modes:
 """
 import ctypes as C
 import logging
+import os
 import random
 import time
 
@@ -166,8 +167,13 @@ class SegmentalKMeansWordseg(object):
                 rng.shuffle(utt_order)
                 if segment_debug_only:
                     utt_order = [i_debug_monitor]
-                for i_utt in utt_order:
-                    self._segment_i_async(i_utt)
+                # the whole chain of the sweep enqueued by one library call (float32 data); SEGK_SEQ_PER_UTT=1 keeps the
+                # per-utterance calls (score through the filter machinery, DP, update + image refresh)
+                if os.environ.get("SEGK_SEQ_PER_UTT", "0") == "1" or not self._dk.sequential_sweep(
+                        self._dev_bounds, utt_order, self.n_slices_min, self.n_slices_max, self.wip):
+                    for i_utt in utt_order:
+                        self._segment_i_async(i_utt)
+                self.utterances.mark_device_dirty()
                 torch.cuda.synchronize()
                 self._dk.check_status()
                 totals = self._dk.out_total.cpu().numpy()
