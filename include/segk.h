@@ -95,7 +95,13 @@ typedef struct segk_corpus {
                                 (segk_corpus_b3_bytes bytes, written by segk_corpus_prepare_b3); enables the
                                 split-precision k-means filter on the 16-bit matrix pipe (NULL: fp32 MFMA)  */
     int32_t sp_pieces;       /* 2 = fp16x2, 3 = bf16x3: what Xb3 holds                        */
-    int32_t pad_;
+    int32_t band_W;          /* window of the banded span tables below (0: none)              */
+    /* optional banded image of vec_ids / durations (utterances.py:91-105 keeps the triangular tables; the
+     * per-utterance kernels only ever read the band t - s <= n_slices_max): entry (t, w), t = 1..N_max the span's
+     * end, w = 0..band_W-1 its length minus one, at [(utt * N_max + t - 1) * band_W + w] = the triangular entry
+     * t(t-1)/2 + (t-1-w) (-1 / NaN where that span does not exist).  Consecutive lanes read consecutive entries.  */
+    const int32_t *band_ids; /* [dev] [n_utt, N_max, band_W] or NULL                          */
+    const double *band_dur;  /* [dev] [n_utt, N_max, band_W] or NULL                          */
 } segk_corpus;
 
 /* Fill the derived members of a corpus: X32 (when X is float64 or ldx != ld32 the caller

@@ -24,7 +24,8 @@ class Corpus(C.Structure):
         ("X", C.c_void_p), ("X32", C.c_void_p), ("x_dtype", C.c_int32), ("D", C.c_int32),
         ("n_emb", C.c_int64), ("ldx", C.c_int64), ("ld32", C.c_int64), ("xnorm", C.c_void_p),
         ("vec_ids", C.c_void_p), ("durations", C.c_void_p), ("lengths", C.c_void_p),
-        ("n_utt", C.c_int32), ("N_max", C.c_int32), ("Xb3", C.c_void_p), ("sp_pieces", C.c_int32), ("pad_", C.c_int32),
+        ("n_utt", C.c_int32), ("N_max", C.c_int32), ("Xb3", C.c_void_p), ("sp_pieces", C.c_int32), ("band_W", C.c_int32),
+        ("band_ids", C.c_void_p), ("band_dur", C.c_void_p),
     ]
 
 

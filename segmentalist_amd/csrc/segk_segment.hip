@@ -32,6 +32,10 @@ __global__ void k_kmeans_segment(segk_corpus c, segk_kmeans m, const int32_t *ut
     const int64_t triMax = (int64_t)c.N_max * (c.N_max + 1) / 2;
     const int32_t *vid = c.vec_ids + (int64_t)u * triMax;
     const double *dur = c.durations + (int64_t)u * triMax;
+    // banded span tables (segk_corpus.band_ids / band_dur), when they were built for this window
+    const bool band = c.band_ids != nullptr && c.band_W == W && W > 0;
+    const int32_t *bandi = band ? c.band_ids + (int64_t)u * c.N_max * c.band_W : nullptr;
+    const double *bandd = band ? c.band_dur + (int64_t)u * c.N_max * c.band_W : nullptr;
     uint8_t *gbnd = boundaries + (int64_t)u * c.N_max;
 
     char *base = smem + (size_t)wv * wave_bytes;
@@ -52,10 +56,10 @@ __global__ void k_kmeans_segment(segk_corpus c, segk_kmeans m, const int32_t *ut
         int k = -1;
         if (s >= 0) {
             const int j = t * (t - 1) / 2 + s;
-            id = vid[j];
+            id = band ? bandi[i] : vid[j];               // banded image: lane i reads entry i
             if (id >= 0) {
                 k = cand.k[id];
-                const double dd = dur[j];
+                const double dd = band ? bandd[i] : dur[j];
                 v = isnan(dd) ? NEG_INF_D : cand.s[id] * dd;      // :346-349
             }
         }
@@ -185,6 +189,10 @@ __global__ void k_kmeans_segment_w8(segk_corpus c, segk_kmeans m, const int32_t 
     const int64_t triMax = (int64_t)c.N_max * (c.N_max + 1) / 2;
     const int32_t *vid = c.vec_ids + (int64_t)u * triMax;
     const double *dur = c.durations + (int64_t)u * triMax;
+    // banded span tables (segk_corpus.band_ids / band_dur), when they were built for this window
+    const bool band = c.band_ids != nullptr && c.band_W == W && W > 0;
+    const int32_t *bandi = band ? c.band_ids + (int64_t)u * c.N_max * c.band_W : nullptr;
+    const double *bandd = band ? c.band_dur + (int64_t)u * c.N_max * c.band_W : nullptr;
     uint8_t *gbnd = boundaries + (int64_t)u * c.N_max;
 
     char *base = smem + (size_t)wv * wave_bytes;
@@ -204,10 +212,10 @@ __global__ void k_kmeans_segment_w8(segk_corpus c, segk_kmeans m, const int32_t 
         int k = -1;
         if (s >= 0) {
             const int j = t * (t - 1) / 2 + s;
-            id = vid[j];
+            id = band ? bandi[i] : vid[j];               // banded image: lane i reads entry i
             if (id >= 0) {
                 k = cand.k[id];
-                const double dd = dur[j];
+                const double dd = band ? bandd[i] : dur[j];
                 v = isnan(dd) ? NEG_INF_D : cand.s[id] * dd;      // :346-349
             }
         }
@@ -359,6 +367,10 @@ __global__ void k_kmeans_segment_w8x2(segk_corpus c, segk_kmeans m, const int32_
     const int64_t triMax = (int64_t)c.N_max * (c.N_max + 1) / 2;
     const int32_t *vid = c.vec_ids + (int64_t)u * triMax;
     const double *dur = c.durations + (int64_t)u * triMax;
+    // banded span tables (segk_corpus.band_ids / band_dur), when they were built for this window
+    const bool band = c.band_ids != nullptr && c.band_W == W && W > 0;
+    const int32_t *bandi = band ? c.band_ids + (int64_t)u * c.N_max * c.band_W : nullptr;
+    const double *bandd = band ? c.band_dur + (int64_t)u * c.N_max * c.band_W : nullptr;
     uint8_t *gbnd = boundaries + (int64_t)u * c.N_max;
 
     char *base = smem + (size_t)(wv * 2 + half) * wave_bytes;
@@ -378,10 +390,10 @@ __global__ void k_kmeans_segment_w8x2(segk_corpus c, segk_kmeans m, const int32_
         int k = -1;
         if (s >= 0) {
             const int j = t * (t - 1) / 2 + s;
-            id = vid[j];
+            id = band ? bandi[i] : vid[j];               // banded image: lane i reads entry i
             if (id >= 0) {
                 k = cand.k[id];
-                const double dd = dur[j];
+                const double dd = band ? bandd[i] : dur[j];
                 v = isnan(dd) ? NEG_INF_D : cand.s[id] * dd;      // :346-349
             }
         }

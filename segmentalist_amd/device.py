@@ -35,7 +35,7 @@ class DeviceCorpus(object):
     """Device image of the embedding matrix and (optionally) of `Utterances`
     (utterances.py:74-105): vec_ids int32 [n_utt, tri], durations f64, lengths int32."""
 
-    def __init__(self, X, vec_ids=None, durations=None, lengths=None):
+    def __init__(self, X, vec_ids=None, durations=None, lengths=None, band=None):
         torch = _torch()
         X = np.asarray(X)
         if X.dtype not in (np.float32, np.float64):
@@ -74,6 +74,13 @@ class DeviceCorpus(object):
             self.vec_ids = self.durations = self.lengths = None
             self.lengths_np = None
         self.tri = self.N_max * (self.N_max + 1) // 2
+        # banded span tables (ids int32 [n_utt, N_max, W], durations f64): what the per-utterance kernels read
+        self.band_ids = self.band_dur = None
+        self.band_W = 0
+        if band is not None and vec_ids is not None:
+            bi, bd = band
+            assert bi.shape == bd.shape == (self.n_utt, self.N_max, bi.shape[2])
+            self.band_ids, self.band_dur, self.band_W = to_dev(bi, np.int32), to_dev(bd, np.float64), int(bi.shape[2])
         # bf16x3 image of the rows for the k-means filter (float32 data, 8 <= D <= 128); built on demand
         self.Xb3 = None
         self.c = _abi.Corpus(
@@ -82,7 +89,9 @@ class DeviceCorpus(object):
             vec_ids=self.vec_ids.data_ptr() if self.vec_ids is not None else None,
             durations=self.durations.data_ptr() if self.durations is not None else None,
             lengths=self.lengths.data_ptr() if self.lengths is not None else None,
-            n_utt=self.n_utt, N_max=self.N_max)
+            n_utt=self.n_utt, N_max=self.N_max, band_W=self.band_W,
+            band_ids=self.band_ids.data_ptr() if self.band_ids is not None else None,
+            band_dur=self.band_dur.data_ptr() if self.band_dur is not None else None)
         check(_abi.lib().segk_corpus_prepare(_abi.ctx(), C.byref(self.c), ptr(x32_out), ptr(self.xnorm),
                                              _abi.stream()))
 

@@ -87,7 +87,9 @@ class SegmentalKMeansWordseg(object):
 
         # device images
         u = self.utterances
-        self._corpus = DeviceCorpus(embeddings, u.vec_ids, u.durations, u.lengths)
+        # banded span tables for the DP kernels' fast path (windows of at most 8 slices, at most 64 landmarks)
+        band = u.band_tables(n_slices_max) if (1 <= n_slices_max <= 8 and u.N_max <= 64) else None
+        self._corpus = DeviceCorpus(embeddings, u.vec_ids, u.durations, u.lengths, band=band)
         self.acoustic_model = KMeans(embeddings, am_K, assignments, _corpus=self._corpus)
         self._dk = self.acoustic_model.components.dev
         self._dev_bounds = to_dev(u.boundaries.astype(np.uint8))

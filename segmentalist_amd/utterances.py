@@ -25,10 +25,18 @@ class Utterances(object):
         self.landmarks = landmarks
         tri = self.N_max * (self.N_max + 1) // 2
 
-        # vec_ids / durations, padded to the longest utterance (utterances.py:91-102)
-        self.vec_ids = np.full((self.D, tri), -1, dtype=np.int64)
-        self.durations = np.full((self.D, tri), np.nan, dtype=np.float64)
-        for i in range(self.D):
+        # vec_ids / durations, padded to the longest utterance (utterances.py:91-102).  Uniform corpora (every
+        # utterance the same number of landmarks, no duration floor) are stacked in one numpy call instead of the
+        # reference's loop over utterances
+        uniform = (min_duration == 0 and self.D > 0 and all(len(v) == tri for v in vec_ids)
+                   and all(len(d) == tri for d in durations))
+        if uniform:
+            self.vec_ids = np.stack([np.asarray(v) for v in vec_ids]).astype(np.int64)
+            self.durations = np.stack([np.asarray(d, dtype=np.float64) for d in durations])
+        else:
+            self.vec_ids = np.full((self.D, tri), -1, dtype=np.int64)
+            self.durations = np.full((self.D, tri), np.nan, dtype=np.float64)
+        for i in range(0 if uniform else self.D):
             v = np.asarray(vec_ids[i])
             self.vec_ids[i, :len(v)] = v
             dv = durations[i]
@@ -66,6 +74,20 @@ class Utterances(object):
                     spans = [e - s for s, e in self.get_segmented_landmark_indices(i)]
                     if (max(spans) <= n_slices_max and min(spans) >= n_slices_min) or N <= n_slices_min:
                         break
+
+    def band_tables(self, W):
+        """Banded image of `vec_ids` / `durations` for a window of W slices: entry [i, t - 1, w] is the
+        span [t - 1 - w, t) of utterance i, i.e. the triangular entry t(t-1)/2 + (t-1-w); -1 / NaN where the span does not
+        exist.  The per-utterance kernels only ever read this band; built here in one vectorised gather."""
+        N = self.N_max
+        t = np.arange(1, N + 1)[:, None]
+        w = np.arange(W)[None, :]
+        s = t - 1 - w
+        ok = s >= 0
+        j = np.where(ok, t * (t - 1) // 2 + s, 0)
+        ids = np.where(ok[None], self.vec_ids[:, j], -1).astype(np.int32)
+        dur = np.where(ok[None], self.durations[:, j], np.nan)
+        return np.ascontiguousarray(ids), np.ascontiguousarray(dur)
 
     # ---------------------------------------------------------------- device mirroring
     def bind_device(self, dev_boundaries, refresh=None):
@@ -140,12 +162,20 @@ def process_embeddings(embedding_mats, vec_ids_dict):
     mats = [np.asarray(embedding_mats[u]) for u in labels]
     starts = np.concatenate([[0], np.cumsum([len(m) for m in mats])]).astype(np.int64)
     vec_ids = _VecIdList()
-    for n, u in enumerate(labels):
-        src = np.asarray(vec_ids_dict[u])
-        cur = src.copy()
-        ok = (src >= 0) & (src < len(mats[n]))
-        cur[ok] = src[ok] + starts[n]
-        vec_ids.append(cur)
+    srcs = [np.asarray(vec_ids_dict[u]) for u in labels]
+    if srcs and all(v.shape == srcs[0].shape for v in srcs):
+        # every utterance has the same span table shape: one stacked remap instead of the loop
+        V = np.stack(srcs)
+        lens = np.asarray([len(m) for m in mats], dtype=V.dtype)[:, None]
+        ok = (V >= 0) & (V < lens)
+        V = np.where(ok, V + starts[:-1, None].astype(V.dtype), V)
+        vec_ids.extend(list(V))
+    else:
+        for n, src in enumerate(srcs):
+            cur = src.copy()
+            ok = (src >= 0) & (src < len(mats[n]))
+            cur[ok] = src[ok] + starts[n]
+            vec_ids.append(cur)
     vec_ids.row_start = starts
     if len(mats) and all(len(m) for m in mats):
         embeddings = np.concatenate(mats, axis=0)

@@ -39,7 +39,7 @@ def test_library_exports_every_header_symbol(built):
 
 def test_struct_layout_matches_header(built):
     # field order/size of the ctypes mirrors (LP64): segk_corpus 16 fields, segk_kmeans 10
-    assert ctypes.sizeof(built.Corpus) == 8 + 8 + 4 + 4 + 8 * 4 + 8 * 3 + 4 + 4 + 8 + 4 + 4
+    assert ctypes.sizeof(built.Corpus) == 8 + 8 + 4 + 4 + 8 * 4 + 8 * 3 + 4 + 4 + 8 + 4 + 4 + 8 + 8      # + band_ids, band_dur
     assert ctypes.sizeof(built.KMeansDev) == 8 * 6 + 8 + 8 + 8 + 8     # K_max padded to 8
 
 
