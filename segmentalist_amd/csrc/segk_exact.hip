@@ -294,7 +294,10 @@ __global__ __launch_bounds__(1024) void k_seq_score(segk_corpus c, segk_kmeans m
     __shared__ short s_j[SEQ_MAXTRI];                                     // valid spans: position in the table
     __shared__ int32_t s_id[SEQ_MAXTRI];                                  // ... and embedding row
     const int tid = threadIdx.x, D = c.D;
-    const int LDM = D + 1;                                                // odd stride: the 32 lanes of a span read 32 banks
+    const bool vec4 = (D & 3) == 0 && (c.ldx & 3) == 0;
+    // stride of the means in LDS: D itself when rows are read 16 bytes at a time (D / 4 odd or even, the 16 lanes of a span
+    // fall on distinct 16-byte slots as long as D / 4 is odd; D + 4 otherwise), D + 1 for 4-byte reads
+    const int LDM = vec4 ? (((D >> 2) & 1) ? D : D + 4) : D + 1;
     const int LDX = (D + 3) & ~3;
     float *s_means = s_buf, *s_x = s_buf + ((SEQ_CPB * LDM + 3) & ~3);
     const int N = c.lengths[utt], tri = N * (N + 1) / 2;
@@ -302,7 +305,6 @@ __global__ __launch_bounds__(1024) void k_seq_score(segk_corpus c, segk_kmeans m
     const float *X = (const float *)c.X;
     const float *means = (const float *)m.means;
     const int k0 = blockIdx.x * SEQ_CPB;
-    const bool vec4 = (D & 3) == 0 && (c.ldx & 3) == 0;
     if (tid == 0) s_nv = 0;
     __syncthreads();
     // the valid spans of the table, compacted (their order is immaterial); every load of a thread in flight together
@@ -328,8 +330,7 @@ __global__ __launch_bounds__(1024) void k_seq_score(segk_corpus c, segk_kmeans m
             const int cc = q / D4, d4 = q - cc * D4, kk = k0 + cc;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (kk < m.K_max) v = *reinterpret_cast<const float4 *>(means + (int64_t)kk * D + 4 * d4);
-            float *dst = s_means + cc * LDM + 4 * d4;
-            dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+            *reinterpret_cast<float4 *>(s_means + cc * LDM + 4 * d4) = v;
         }
     } else {
         for (int q = tid; q < SEQ_CPB * D; q += blockDim.x) {
@@ -373,12 +374,13 @@ __global__ __launch_bounds__(1024) void k_seq_score(segk_corpus c, segk_kmeans m
             const int p = p0 + tid, jl = p / SEQ_CPB, cidx = p % SEQ_CPB, k = k0 + cidx;
             unsigned long long key = 0ull;
             if (jl < nj && k < m.K_max) {
-                const float sc = neg_sqd_exact<float>(s_means + cidx * LDM, s_x + jl * LDX, D);
+                const float sc = (vec4 && D >= 8 && D <= 128) ? neg_sqd_exact_v4(s_means + cidx * LDM, s_x + jl * LDX, D)
+                                                              : neg_sqd_exact<float>(s_means + cidx * LDM, s_x + jl * LDX, D);
                 const unsigned int bits = __float_as_uint(sc);
                 const unsigned int ord = (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);
                 key = ((unsigned long long)ord << 32) | (unsigned long long)(0xffffffffu - (unsigned int)k);
             }
-            // the 32 components of a span sit on the 32 lanes of one wave half
+            // the components of a span sit on SEQ_CPB adjacent lanes
             for (int o = 1; o < SEQ_CPB; o <<= 1) {
                 const unsigned long long other = __shfl_xor(key, o);
                 key = other > key ? other : key;
@@ -411,7 +413,7 @@ int segk_launch_seq_score(const segk_corpus *c, const segk_kmeans *m, int utt, c
                           hipStream_t st)
 {
     const int tri_max = c->N_max * (c->N_max + 1) / 2;
-    const size_t lds = ((size_t)((SEQ_CPB * (c->D + 1) + 3) & ~3) + (size_t)SEQ_JCH * ((c->D + 3) & ~3)) * sizeof(float);
+    const size_t lds = ((size_t)((SEQ_CPB * (c->D + 4) + 3) & ~3) + (size_t)SEQ_JCH * ((c->D + 3) & ~3)) * sizeof(float);
     SEGK_REQUIRE(lds <= 140 * 1024, "D too large for the sequential score kernel");
     SEGK_REQUIRE(tri_max <= SEQ_MAXTRI, "more than 63 landmarks per utterance: use the per-utterance calls");
     static size_t lds_set = 0;

@@ -90,6 +90,45 @@ __device__ T neg_sqd_exact(const TM &m, const TX *x, int n)
     return -ret;
 }
 
+// pw_base for float rows read 16 bytes at a time (8 <= n <= 128, n % 4 == 0, both pointers 16-byte aligned): the same
+// eight strided accumulators, combine tree and sequential tail as numpy -- only the loads are wider
+__device__ __forceinline__ float neg_sqd_exact_v4(const float *m, const float *x, int n)
+{
+    const int nfull = n & ~7;
+    float r[8];
+    {
+        const float4 m0 = *reinterpret_cast<const float4 *>(m), m1 = *reinterpret_cast<const float4 *>(m + 4);
+        const float4 x0 = *reinterpret_cast<const float4 *>(x), x1 = *reinterpret_cast<const float4 *>(x + 4);
+        const float mv[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w}, xv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const float delta = mv[q] - xv[q];
+            r[q] = delta * delta;
+        }
+    }
+    for (int i = 8; i < nfull; i += 8) {
+        const float4 m0 = *reinterpret_cast<const float4 *>(m + i), m1 = *reinterpret_cast<const float4 *>(m + i + 4);
+        const float4 x0 = *reinterpret_cast<const float4 *>(x + i), x1 = *reinterpret_cast<const float4 *>(x + i + 4);
+        const float mv[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w}, xv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const float delta = mv[q] - xv[q];
+            r[q] += delta * delta;
+        }
+    }
+    float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    if (n & 4) {                                            // the sequential tail: four elements
+        const float4 mt = *reinterpret_cast<const float4 *>(m + nfull), xt = *reinterpret_cast<const float4 *>(x + nfull);
+        const float mv[4] = {mt.x, mt.y, mt.z, mt.w}, xv[4] = {xt.x, xt.y, xt.z, xt.w};
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const float delta = mv[q] - xv[q];
+            res += delta * delta;
+        }
+    }
+    return -res;
+}
+
 // Four rows at once for 8 <= n <= 128 (numpy's single-block case): identical arithmetic per
 // row, interleaved so that 4 x 8 loads are in flight per step.
 template <typename T, typename TM, typename TX>

@@ -27,7 +27,9 @@
 // Reads the two-piece images (segk_internal.h): piece 0 of the rows, the piece-0 blocks and the
 // constants of the tile image -- each a 1 KiB LDS-DMA piece.
 // ======================================================================================
-template <int KS, int NBLK>
+// ABL: timing-only ablations for development (SEGK_H1_ABL; results are wrong): 1 no top-2 drain (one running maximum per
+// block), 2 drain without the pair index, 3 drain without the MFMAs
+template <int KS, int NBLK, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void k_kmeans_score_h1(ScoreArgs A)
 {
     static_assert(NBLK == 2 || NBLK == 4, "an even number of row blocks per wave (static accumulator parity)");
@@ -107,6 +109,17 @@ __global__ __launch_bounds__(256, 2) void k_kmeans_score_h1(ScoreArgs A)
     // values 2 pi, 2 pi + 1 of block O_'s accumulator: components c, c + 1 of this lane half
 #define SEGK_DRAIN2(O_, ACC, pi)                                                      \
     do {                                                                              \
+        if constexpr (ABL == 1) {                                                     \
+            if ((pi) == 0) m1[O_] = vmax_f32(m1[O_], ACC[0]);                         \
+        } else if constexpr (ABL == 2) {                                              \
+            const float tmp_ = __builtin_amdgcn_fmed3f(m1[O_], ACC[2 * (pi)], ACC[2 * (pi) + 1]); \
+            float nm_;                                                                \
+            asm volatile("v_max_f32 %1, %1, %2\n\t"                                   \
+                         "v_max3_f32 %0, %3, %4, %5"                                  \
+                         : "=&v"(nm_), "+v"(m2[O_])                                   \
+                         : "v"(tmp_), "v"(m1[O_]), "v"(ACC[2 * (pi)]), "v"(ACC[2 * (pi) + 1])); \
+            m1[O_] = nm_;                                                             \
+        } else {                                                                      \
         /* the first read of the MFMA results is a compiler-visible instruction: the hazard recogniser */ \
         /* does not look inside inline asm, and these values can be a few cycles old (block b - 1)     */ \
         const float tmp_ = __builtin_amdgcn_fmed3f(m1[O_], ACC[2 * (pi)], ACC[2 * (pi) + 1]);          \
@@ -119,6 +132,7 @@ __global__ __launch_bounds__(256, 2) void k_kmeans_score_h1(ScoreArgs A)
                      : "v"(tmp_), "v"(m1[O_]), "v"(ACC[2 * (pi)]), "v"(ACC[2 * (pi) + 1]), "n"((pi)) \
                      : "vcc");                                                        \
         m1[O_] = nm_;                                                                 \
+        }                                                                             \
     } while (0)
 
     constexpr int PPS = (8 + KS - 1) / KS;
@@ -135,7 +149,7 @@ __global__ __launch_bounds__(256, 2) void k_kmeans_score_h1(ScoreArgs A)
         }                                                                                             \
         const float m1s = m1[O_];                                                                     \
         _Pragma("unroll") for (int s = 0; s < KS; s++) {                                              \
-            acc[(N_) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s], xb[N_][s], acc[(N_) & 1], 0, 0, 0); \
+            if constexpr (ABL != 3) acc[(N_) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s], xb[N_][s], acc[(N_) & 1], 0, 0, 0); \
             _Pragma("unroll") for (int q = 0; q < PPS; q++)                                           \
                 if (s * PPS + q < 8) SEGK_DRAIN2(O_, acc[((N_) & 1) ^ 1], s * PPS + q);               \
         }                                                                                             \
@@ -685,7 +699,12 @@ static int launch_score_pre(segk_ctx *ctx, ScoreArgs A, hipStream_t st)
     if (n4 > 0) {
         ScoreArgs M = A;
         M.n = n4;
-        hipLaunchKernelGGL((k_kmeans_score_h1<KS, 4>), dim3((unsigned)(n4 / 512)), dim3(256), lds, st, M);
+        const char *abl = getenv("SEGK_H1_ABL");
+        const int ab = abl ? atoi(abl) : 0;
+        if (ab == 1) hipLaunchKernelGGL((k_kmeans_score_h1<KS, 4, 1>), dim3((unsigned)(n4 / 512)), dim3(256), lds, st, M);
+        else if (ab == 2) hipLaunchKernelGGL((k_kmeans_score_h1<KS, 4, 2>), dim3((unsigned)(n4 / 512)), dim3(256), lds, st, M);
+        else if (ab == 3) hipLaunchKernelGGL((k_kmeans_score_h1<KS, 4, 3>), dim3((unsigned)(n4 / 512)), dim3(256), lds, st, M);
+        else hipLaunchKernelGGL((k_kmeans_score_h1<KS, 4>), dim3((unsigned)(n4 / 512)), dim3(256), lds, st, M);
         if (int rc = prof_end(n4, 1)) return rc;
     }
     if (rem > 0 && !rem_queued) {

@@ -174,6 +174,175 @@ __global__ void k_kmeans_update(segk_corpus c, segk_kmeans m, int op, int utt, i
 }
 
 // ======================================================================================
+// A11 sequential, one utterance, the touched components staged in LDS (segk_kmeans_sequential_sweep).  k_kmeans_update
+// walks the items one after the other and pays a global-memory round trip or two for every one of them (~20 us for an
+// utterance's ~16 items); here the items' rows, the touched components' numerators and counts are fetched together
+// (three round trips for the whole utterance), the del_item / add_item sequence of the reference (kmeans_components.py:
+// 93-132, the `k > K -> K` clamp included) is applied in LDS in exactly its order -- per component the same float64
+// additions, the same quotient cast to the dtype of X after every item -- and the rows are written back once.
+// clean_components (:263-266) runs afterwards on the global state, and only if a touched component emptied.
+// ======================================================================================
+#define SEQ_MAXOPS 128           /* old + new tokens of an utterance (N_max <= 64) */
+template <typename XT>
+__global__ __launch_bounds__(256) void k_seq_update(segk_corpus c, segk_kmeans m, int utt, const int32_t *old_tok,
+                                                    const int32_t *new_tok, const int32_t *new_k, const int32_t *n_old,
+                                                    const int32_t *n_new, int32_t *status)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char upd_lds[];
+    __shared__ int32_t op_e[SEQ_MAXOPS], op_k[SEQ_MAXOPS], op_ci[SEQ_MAXOPS];      // item, component (-1: no-op), slot of its component
+    __shared__ int32_t op_a[SEQ_MAXOPS];                                            // the item's assignment before this utterance
+    __shared__ int32_t uq_k[SEQ_MAXOPS];                                            // the touched components
+    __shared__ long long uq_cnt[SEQ_MAXOPS], op_cnt[SEQ_MAXOPS];
+    __shared__ int uq_dirty[SEQ_MAXOPS];
+    __shared__ int shK, sh_i, n_uq, any_empty;
+    __shared__ int64_t sh_l;
+    const int tid = threadIdx.x, nt = blockDim.x, D = c.D;
+    const int no = n_old[utt], nn = n_new[utt], nops = no + nn;
+    const XT *X = (const XT *)c.X;
+    XT *means = (XT *)m.means;
+    double *numer = reinterpret_cast<double *>(upd_lds);                            // [n_uq][D]
+    // (1) the items and, for the old ones, their current components -- side by side
+    if (tid < nops) {
+        const bool is_old = tid < no;
+        const int32_t e = is_old ? old_tok[(int64_t)utt * c.N_max + tid] : new_tok[(int64_t)utt * c.N_max + (tid - no)];
+        const int32_t a = m.assignments[e];
+        op_e[tid] = e;
+        op_a[tid] = a;
+        op_k[tid] = is_old ? a : new_k[(int64_t)utt * c.N_max + (tid - no)];
+    }
+    if (tid == 0) shK = *m.K;
+    __syncthreads();
+    // (2) the reference's bookkeeping.  One thread replays the clamp of add_item over the new items in order (:102-106:
+    // labels and K, a dozen register operations); everything that needs a search -- the first item with the same
+    // component (its slot), an earlier item with the same row (the assert of :101), the running count of the component
+    // after every item -- is done by all items side by side, one lane each
+    if (tid == 0) {
+        int K = shK;
+        for (int q = no; q < nops; q++) {
+            int k = op_k[q];
+            if (k > K) k = K;
+            if (k == K) K++;
+            op_k[q] = k;
+        }
+        shK = K;
+        any_empty = 0;
+    }
+    __syncthreads();
+    if (tid < 64) {                                         // nops <= 64 (host: N_max <= 32)
+        const int q = tid;
+        const bool live = q < nops;
+        const int k = live ? op_k[q] : -1, e = live ? op_e[q] : -1;
+        int first = q, prev_same_e = -1;
+        for (int p2 = 0; p2 < nops; p2++) {                 // uniform trip count: every lane reads the same entry (broadcast)
+            const int k2 = op_k[p2], e2 = op_e[p2];
+            if (p2 < q && k2 == k && p2 < first) first = p2;
+            if (p2 < q && e2 == e) prev_same_e = p2;
+        }
+        const bool is_first = live && k >= 0 && first == q;
+        const unsigned long long firsts = __ballot(is_first);
+        const int ci = (live && k >= 0) ? __popcll(firsts & ((1ull << first) - 1ull)) : -1;
+        if (is_first) uq_k[ci] = k;
+        if (live) op_ci[q] = ci;
+        if (q == 0) n_uq = __popcll(firsts);
+        // add_item's assert: the row must be unassigned -- by an earlier item of this utterance, else by the state before it
+        int cur = -1;
+        if (live && q >= no) {
+            cur = prev_same_e >= 0 ? (prev_same_e < no ? -1 : op_k[prev_same_e]) : op_a[q];
+            if (cur != -1) atomicOr(status, 2);
+        }
+    }
+    __syncthreads();
+    const int nu = n_uq;
+    // (3) numerators and counts of the touched components and the rows of all items into LDS
+    const int cap = 2 * c.N_max;                                                    // >= nops >= nu
+    XT *mean_l = reinterpret_cast<XT *>(numer + (size_t)cap * D);                   // [cap][D] latest defined mean
+    XT *xs = mean_l + (size_t)cap * D;                                              // [cap][D] the items' rows
+    // (eight loads of a thread in flight together: a plain loop waits for every load before it issues the next)
+    for (int q0 = tid; q0 < nu * D; q0 += 8 * nt) {
+        double v[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int q = q0 + r * nt, qq = q < nu * D ? q : 0;
+            const int u = qq / D, d = qq - u * D;
+            v[r] = m.mean_numerators[(int64_t)uq_k[u] * D + d];
+        }
+#pragma unroll
+        for (int r = 0; r < 8; r++)
+            if (q0 + r * nt < nu * D) numer[q0 + r * nt] = v[r];
+    }
+    for (int q0 = tid; q0 < nops * D; q0 += 8 * nt) {
+        XT v[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int q = q0 + r * nt, qq = q < nops * D ? q : 0;
+            const int o = qq / D, d = qq - o * D;
+            v[r] = X[(int64_t)op_e[o] * c.ldx + d];
+        }
+#pragma unroll
+        for (int r = 0; r < 8; r++)
+            if (q0 + r * nt < nops * D) xs[q0 + r * nt] = v[r];
+    }
+    if (tid < nu) { uq_cnt[tid] = m.counts[uq_k[tid]]; uq_dirty[tid] = 0; }
+    __syncthreads();
+    // the count of its component after every item (by the items' lanes: items before it on the same component)
+    if (tid < 64 && tid < nops) {
+        const int q = tid, ci = op_ci[q];
+        long long cn = 0;
+        if (ci >= 0) {
+            cn = uq_cnt[ci];
+            for (int p2 = 0; p2 <= q; p2++)
+                if (op_ci[p2] == ci) cn += p2 < no ? -1 : 1;
+        }
+        op_cnt[q] = cn;
+    }
+    __syncthreads();
+    // (4) the items in the reference's order; thread d owns dimension d of every touched component: no barrier needed
+    for (int d = tid; d < D; d += nt)
+        for (int q = 0; q < nops; q++) {
+            const int ci = op_ci[q];
+            if (ci < 0) continue;                           // del_item of an unassigned item: nothing
+            const double x = (double)xs[q * D + d];
+            const double v = q < no ? numer[ci * D + d] - x : numer[ci * D + d] + x;
+            numer[ci * D + d] = v;
+            const long long cnt = op_cnt[q];
+            if (cnt != 0) mean_l[ci * D + d] = (XT)(v / (double)cnt);               // (:110, :128-129)
+        }
+    if (tid < nops && op_ci[tid] >= 0) {
+        if (op_cnt[tid] != 0) uq_dirty[op_ci[tid]] = 1;
+        // the last item of a component leaves its final count
+        bool last = true;
+        for (int p2 = tid + 1; p2 < nops; p2++)
+            if (op_ci[p2] == op_ci[tid]) last = false;
+        if (last) uq_cnt[op_ci[tid]] = op_cnt[tid];
+    }
+    __syncthreads();
+    // (5) write back
+    for (int q = tid; q < nu * D; q += nt) {
+        const int u = q / D, d = q - u * D;
+        m.mean_numerators[(int64_t)uq_k[u] * D + d] = numer[q];
+        if (uq_dirty[u]) means[(int64_t)uq_k[u] * D + d] = mean_l[q];
+    }
+    if (tid < nu) {
+        m.counts[uq_k[tid]] = uq_cnt[tid];
+        if (uq_cnt[tid] == 0 && uq_k[tid] < shK) any_empty = 1;
+    }
+    if (tid < nops) {
+        // final assignment of every item: the last operation on it wins (an item both deleted and added: its new component)
+        bool last = true;
+        for (int p2 = tid + 1; p2 < nops; p2++)
+            if (op_e[p2] == op_e[tid]) last = false;
+        if (last) m.assignments[op_e[tid]] = tid < no ? -1 : op_k[tid];
+    }
+    __threadfence_block();
+    __syncthreads();
+    // (6) clean_components, on the global state, when something emptied
+    if (any_empty) dev_clean_components<XT>(c, m, &shK, &sh_i);
+    (void)sh_l;
+    __syncthreads();
+    if (tid == 0) *m.K = shK;
+}
+
+// ======================================================================================
 // A11 batch-synchronous statistics (spec: oracle/np_oracle.py kmeans_batch_sweep; rank split:
 // oracle/np_dist.py).  Four kernels after the per-utterance kernel:
 //
@@ -982,6 +1151,24 @@ static int launch_update(const segk_corpus *c, segk_kmeans *m, int op, int utt, 
 int segk_launch_update_utt(const segk_corpus *c, segk_kmeans *m, int utt, const int32_t *old_tok, const int32_t *new_tok,
                            const int32_t *new_k, const int32_t *n_old, const int32_t *n_new, int32_t *status, hipStream_t st)
 {
+    // the LDS-staged form for utterances of at most 64 landmarks (SEGK_SEQ_UPDATE=0: the item-by-item kernel)
+    const char *e = getenv("SEGK_SEQ_UPDATE");
+    if (c->N_max <= 32 && !(e && atoi(e) == 0)) {
+        const size_t esz = c->x_dtype == SEGK_F32 ? 4 : 8;
+        const size_t lds = (size_t)2 * c->N_max * c->D * (8 + 2 * esz);
+        if (lds <= 150 * 1024) {
+            DISPATCH_XT(c, {
+                static size_t lds_set = 0;
+                if (lds > 48 * 1024 && lds > lds_set) {
+                    SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_seq_update<XT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    lds_set = lds;
+                }
+                hipLaunchKernelGGL(k_seq_update<XT>, dim3(1), dim3(256), lds, st, *c, *m, utt, old_tok, new_tok, new_k, n_old, n_new, status);
+            });
+            SEGK_LAUNCH_CHECK();
+            return SEGK_OK;
+        }
+    }
     return launch_update(c, m, 0, utt, 0, 0, old_tok, new_tok, new_k, n_old, n_new, status, st);
 }
 
