@@ -21,6 +21,10 @@ struct segk_ctx {
     // rows the one-product pre-filter could not decide: [0] count, [16..] row ids (grown on demand)
     int32_t *pre_queue;
     int64_t pre_cap;
+    // split second stage of the pre-filter: partial candidates [row block][split][128 rows][4] and one ticket per row block
+    float *sp2_part;
+    int32_t *sp2_ticket;
+    int64_t sp2_blocks;
     // second stream of segk_kmeans_score: the pre-filter's second stage and the full scan run on it beside
     // the exact stage of the decided rows (created on first use)
     hipStream_t aux;

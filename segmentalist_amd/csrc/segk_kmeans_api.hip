@@ -73,9 +73,14 @@ int32_t segk_kmeans_score(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans
         rc = segk_kmeans_clear_queue(ctx, cand, stream);
     }
     if (rc) return rc;
-    // SEGK_SCORE_OVERLAP=0: everything on the caller's stream
+    // SEGK_SCORE_OVERLAP=1: the pre-filter's second stage and the full scan on a second stream beside the exact stage.
+    // Default since the exact stage keeps the component table in LDS (k_kmeans_exact_pair4): everything on the caller's
+    // stream.  That stage now runs at what HBM delivers for 400-byte rows (105 us alone), and a kernel that saturates
+    // HBM stretches every latency chain beside it -- the second stage went from 58 to 100-190 us, the full scan from 35
+    // to 75-125 -- so that the two branches side by side were no shorter than one after the other
+    // (profiles/README.md, r02_z).
     const char *ov = getenv("SEGK_SCORE_OVERLAP");
-    ctx->overlap_req = (ov && atoi(ov) == 0) ? 0 : 1;
+    ctx->overlap_req = (ov && atoi(ov) != 0) ? 1 : 0;
     rc = segk_kmeans_filter(ctx, c, m, ids, row0, n, cand, stream);
     ctx->overlap_req = 0;
     ctx->pre_zeroed = 0;

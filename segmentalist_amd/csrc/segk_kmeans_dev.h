@@ -249,6 +249,7 @@ struct ScoreArgs {
     // one-product pre-filter (k_kmeans_score_h1): its undecided rows go to pre_queue (pre_cap entries, then to
     // cand.queue); the split-precision kernel that follows reads its row count from n_dev
     const int32_t *n_dev;
+    int32_t n_dev_off;           /* rows of the queue an earlier launch of the same stage covers */
     int32_t *pre_queue, *pre_count;
     int pre_cap, K_max;
     const float *xerr;           /* pre-filter: |x - x1| per row (k_corpus_resid_sp) */
@@ -641,7 +642,7 @@ int segk_kmeans_prepare_impl(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m
 int segk_dispatch_score_f32(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m, const ScoreArgs &A, hipStream_t st);
 // segk_score_sp.hip: the split-precision filter (pieces = 2 fp16x2, 3 bf16x3) and the pre-filter's second stage
 int segk_dispatch_score_sp(segk_ctx *ctx, const ScoreArgs &A, int ks, int pieces, hipStream_t st);
-int segk_launch_sp_second(const ScoreArgs &B, int ks, hipStream_t st);
+int segk_launch_sp_second(segk_ctx *ctx, const ScoreArgs &B, int ks, hipStream_t st);
 // segk_score_h1.hip: one-product pre-filter + exact pair stage + second stage
 int segk_dispatch_score_pre(segk_ctx *ctx, const ScoreArgs &A, int ks, hipStream_t st);
 // segk_exact.hip / segk_stats.hip: the pieces of the sequential (reference-chain) sweep

@@ -424,29 +424,44 @@ __global__ __launch_bounds__(64) void k_kmeans_exact_pair2(ScoreArgs A)
     const int nfull = D & ~7, nblk = nfull >> 3, rem = D & 7;
     const bool tail = nfull + 4 * h < D;
 
+    // this item's means of one step into registers: the member c + mem, clamped into the table (the result of a member
+    // beyond it is dropped)
+    f32x4_t mreg[2 * KS], mt;
+    auto issue_m = [&](int32_t rid_l, int32_t c_l) {
+        const int32_t rid = __shfl(rid_l, row), c = __shfl(c_l, row);
+        int cm = rid >= 0 ? c + mem : 0;
+        if (cm >= A.K_max) cm = A.K_max - 1;
+        const uintptr_t mp = (uintptr_t)(A.means32 + (int64_t)cm * D + 4 * h);
+#pragma unroll
+        for (int b = 0; b < 2 * KS; b++) mreg[b] = *reinterpret_cast<gptr_t>(mp + 32u * (unsigned)(b < nblk ? b : 0));
+        mt = *reinterpret_cast<gptr_t>(mp + 4u * (unsigned)(tail ? nfull : 0));
+    };
+
+    // Software pipeline, one step deep for everything a step waits on: while step s is summed, the rows AND the means of
+    // step s + 1 are in flight (the candidates of s + 1 were fetched during s - 1, the row numbers of s + 2 during s - 1).
+    // With the means fetched in the step that uses them a step cost two dependent L2 round trips and the stage ran
+    // 2.5x off its HBM floor on six waves per CU.
     int64_t step = blockIdx.x;
     int32_t rid0 = fetch_rid(step);
     int32_t c0 = decode(rid0, fetch_k(rid0));
     issue_x(rid0, step);
+    issue_m(rid0, c0);
     int32_t rid1 = fetch_rid(step + gridDim.x);
     int32_t k1 = fetch_k(rid1);
     int32_t rid2 = fetch_rid(step + 2 * (int64_t)gridDim.x);
     for (; step < n_steps; step += gridDim.x) {
-        // this step's means: the item's member (c + mem, clamped into the table: the result of a member beyond it is dropped)
         const int32_t rid = __shfl(rid0, row), c = __shfl(c0, row);
-        int cm = rid >= 0 ? c + mem : 0;
-        if (cm >= A.K_max) cm = A.K_max - 1;
-        const uintptr_t mp = (uintptr_t)(A.means32 + (int64_t)cm * D + 4 * h);
-        f32x4_t mreg[2 * KS], mt;
+        f32x4_t mc[2 * KS];
 #pragma unroll
-        for (int b = 0; b < 2 * KS; b++) mreg[b] = *reinterpret_cast<gptr_t>(mp + 32u * (unsigned)(b < nblk ? b : 0));
-        mt = *reinterpret_cast<gptr_t>(mp + 4u * (unsigned)(tail ? nfull : 0));
-        // the staged rows of this step into LDS, the next step's row loads into flight
+        for (int b = 0; b < 2 * KS; b++) mc[b] = mreg[b];
+        const f32x4_t mtc = mt;
+        // the staged rows of this step into LDS, the next step's loads into flight
 #pragma unroll
         for (int t = 0; t < NLA; t++)
             if (sub < RPI && RPI * t + sub < R) *reinterpret_cast<f32x4_t *>(lds + (RPI * t + sub) * LD + 4 * c4) = v[t];
         const int32_t c1 = decode(rid1, k1);
         issue_x(rid1, step + gridDim.x);
+        issue_m(rid1, c1);
         rid0 = rid1; c0 = c1;
         rid1 = rid2;
         k1 = fetch_k(rid1);
@@ -461,7 +476,7 @@ __global__ __launch_bounds__(64) void k_kmeans_exact_pair2(ScoreArgs A)
                 const f32x4_t xv = *reinterpret_cast<const f32x4_t *>(xrow + 8 * b);
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
-                    const float delta = mreg[b][q] - xv[q];
+                    const float delta = mc[b][q] - xv[q];
                     const float t2 = delta * delta;
                     r4[q] = b == 0 ? t2 : r4[q] + t2;
                 }
@@ -471,7 +486,7 @@ __global__ __launch_bounds__(64) void k_kmeans_exact_pair2(ScoreArgs A)
             const f32x4_t xt = *reinterpret_cast<const f32x4_t *>(xrow + nfull);
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                const float delta = mt[q] - xt[q];
+                const float delta = mtc[q] - xt[q];
                 tt[q] = delta * delta;
             }
         }
@@ -491,6 +506,302 @@ __global__ __launch_bounds__(64) void k_kmeans_exact_pair2(ScoreArgs A)
             A.cand.k[rid] = second ? c + 1 : c;
             A.cand.s[rid] = (double)(second ? so : sc);
         }
+    }
+}
+
+// Third form of the exact stage.  The second form's per-lane gathers of the means (16 bytes per lane, two lanes per
+// 400-byte row and instruction) touch 32 cache lines per load instruction: 49 M tag lookups in the vector L1 for 1.3 GB,
+// one per clock and CU -- the stage ran at the L1's lookup rate (137 us alone), not at the memory system's
+// (profiles/README.md, r02_t).  Here the member rows are loaded the way the x rows are -- whole rows, RPI per
+// instruction, 7 lines each -- and transposed through LDS: 0.2 M lookups per CU instead of 0.75 M.  Everything a step
+// waits on is one step ahead in flight (rows and means of step s + 1 in registers while step s is summed from LDS).
+// LDS row pitch `ps` 16-byte slots, ps = 2 (mod 4): the 16 lanes of one ds_read_b128 pass fall on 16 distinct slots.
+template <int KS, int V>
+__global__ __launch_bounds__(64) void k_kmeans_exact_pair3(ScoreArgs A)
+{
+    // D = 16 KS - 4 V is a compile-time constant: the block loop has no branches and all of a step's LDS reads are in
+    // flight together (with D at run time every 32-byte block waited for its own two reads: ~2000 cycles of LDS
+    // latency per step)
+    constexpr int D = 16 * KS - 4 * V, D4 = D >> 2;
+    constexpr int ps = D4 + ((2 - D4) & 3);
+    constexpr int R = SEGK_PAIR_ROWS;
+    constexpr int C4 = KS * 4 + 2;                                 // lanes per row in a load instruction
+    constexpr int RPI = 64 / C4;                                   // rows per load instruction
+    constexpr int NLX = (R + RPI - 1) / RPI, NLM = (2 * R + RPI - 1) / RPI;
+    extern __shared__ __attribute__((aligned(16))) float lds[];    // [R][ps * 4] x rows, [2 R][ps * 4] member rows
+    const int lane = threadIdx.x;
+    constexpr int LD = ps * 4;
+    float *xs = lds, *ms = lds + R * LD;
+    const int64_t n_steps = (A.n + R - 1) / R;
+    const int sub = lane / C4, c4 = lane - sub * C4;
+    const int sub_c = sub < RPI ? sub : RPI - 1;
+    const unsigned off = 16u * (unsigned)(c4 < D4 ? c4 : D4 - 1);
+    const bool wr = sub < RPI && c4 < ps;
+    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(1))) f32x4_t *gptr_t;
+
+    auto fetch_rid = [&](int64_t step) -> int32_t {
+        const int64_t r = step * R + lane;
+        int32_t rid = -1;
+        if (step < n_steps && lane < R && r < A.n) rid = A.ids ? A.ids[r] : (int32_t)(A.row0 + r);
+        return rid;
+    };
+    auto fetch_k = [&](int32_t rid) -> int32_t { return rid >= 0 ? A.cand.k[rid] : 0; };
+    auto decode = [&](int32_t &rid, int32_t k) -> int32_t {       // pair base, or -1 (and rid = -1) when not pending
+        if (rid >= 0 && k >= 0 && (k & SEGK_PAIR_PENDING) && (k & ~SEGK_PAIR_PENDING) < A.K_max) return k & ~SEGK_PAIR_PENDING;
+        rid = -1;
+        return -1;
+    };
+    f32x4_t vx[NLX], vm[NLM];
+    // the loads of one step: lane l < R holds the step's row l (rid_l, -1: none) and its pair base c_l
+    auto issue = [&](int32_t rid_l, int32_t c_l, int64_t step_) {
+        int64_t r_any = rid_l;                                  // some valid row for the lanes without one
+        if (rid_l < 0) {
+            r_any = A.ids ? 0 : A.row0 + step_ * R + (lane < R ? lane : 0);
+            if (A.ids || r_any >= A.row0 + A.n) r_any = A.ids ? 0 : A.row0;
+        }
+        // member rows: item i = 2 row + member on lane i, clamped into the table (the result of a member beyond it is dropped)
+        const int32_t c_it = __shfl(c_l, lane >> 1), rid_it = __shfl(rid_l, lane >> 1);
+        int cm = rid_it >= 0 ? c_it + (lane & 1) : 0;
+        if (cm >= A.K_max) cm = A.K_max - 1;
+        // byte offsets worked out once per row, not once per load instruction
+        const unsigned moff = __umul24((unsigned)cm, (unsigned)(D * 4));                 // K_max < 2^24, K_max * D * 4 < 2^32
+        const uintptr_t xaddr = (uintptr_t)(A.xrows32 + r_any * A.ld32);
+        const unsigned xlo = (unsigned)xaddr, xhi = (unsigned)(xaddr >> 32);
+#pragma unroll
+        for (int t = 0; t < NLX; t++) {
+            const int src = (RPI * t + sub_c) & (R - 1);
+            const uintptr_t base = ((uintptr_t)(unsigned)__shfl((int)xhi, src) << 32) | (unsigned)__shfl((int)xlo, src);
+            vx[t] = *reinterpret_cast<gptr_t>(base + off);
+        }
+#pragma unroll
+        for (int t = 0; t < NLM; t++) {
+            const unsigned mo = (unsigned)__shfl((int)moff, (RPI * t + sub_c) & (2 * R - 1));
+            vm[t] = *reinterpret_cast<gptr_t>((uintptr_t)A.means32 + mo + off);
+        }
+    };
+
+    const int item = lane >> 1, h = lane & 1, row = item >> 1;
+    constexpr int nfull = D & ~7, nblk = nfull >> 3, rem = D & 7;
+    const float *xrow = xs + row * LD + 4 * h, *mrow = ms + item * LD + 4 * h;
+
+    int64_t step = blockIdx.x;
+    int32_t rid0 = fetch_rid(step);
+    int32_t c0 = decode(rid0, fetch_k(rid0));
+    issue(rid0, c0, step);
+    int32_t rid1 = fetch_rid(step + gridDim.x);
+    int32_t k1 = fetch_k(rid1);
+    int32_t rid2 = fetch_rid(step + 2 * (int64_t)gridDim.x);
+    for (; step < n_steps; step += gridDim.x) {
+        const int32_t rid = __shfl(rid0, row), c = __shfl(c0, row);
+        // this step's rows into LDS, the next step's into flight
+#pragma unroll
+        for (int t = 0; t < NLX; t++)
+            if (wr && RPI * t + sub < R) *reinterpret_cast<f32x4_t *>(xs + (RPI * t + sub) * LD + 4 * c4) = vx[t];
+#pragma unroll
+        for (int t = 0; t < NLM; t++)
+            if (wr && RPI * t + sub < 2 * R) *reinterpret_cast<f32x4_t *>(ms + (RPI * t + sub) * LD + 4 * c4) = vm[t];
+        const int32_t c1 = decode(rid1, k1);
+        issue(rid1, c1, step + gridDim.x);
+        rid0 = rid1; c0 = c1;
+        rid1 = rid2;
+        k1 = fetch_k(rid1);
+        rid2 = fetch_rid(step + 3 * (int64_t)gridDim.x);
+        // the reference's float32 -(deltas*deltas).sum() in numpy's pairwise order: this lane owns the strided
+        // accumulators r_{4h..4h+3}
+        f32x4_t xv[nblk + 1], mv[nblk + 1];
+#pragma unroll
+        for (int b = 0; b < nblk; b++) {
+            xv[b] = *reinterpret_cast<const f32x4_t *>(xrow + 8 * b);
+            mv[b] = *reinterpret_cast<const f32x4_t *>(mrow + 8 * b);
+        }
+        if (rem) {                                                 // the four tail elements, the same on both lanes of the item
+            xv[nblk] = *reinterpret_cast<const f32x4_t *>(xrow - 4 * h + nfull);
+            mv[nblk] = *reinterpret_cast<const f32x4_t *>(mrow - 4 * h + nfull);
+        }
+        // two elements per instruction (v_pk_add_f32 / v_pk_mul_f32: each half rounded like the scalar operation)
+        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+        auto pk_sub = [](f32x2_t a, f32x2_t b2) -> f32x2_t {       // a - b, both halves in one instruction
+            f32x2_t d;
+            asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b2));
+            return d;
+        };
+        f32x2_t rl = {0.f, 0.f}, rh = {0.f, 0.f};
+        float tt[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int b = 0; b < nblk; b++) {
+            const f32x2_t dl = pk_sub(mv[b].xy, xv[b].xy), dh = pk_sub(mv[b].zw, xv[b].zw);
+            const f32x2_t tl = dl * dl, th = dh * dh;
+            rl = b == 0 ? tl : rl + tl;
+            rh = b == 0 ? th : rh + th;
+        }
+        if (rem) {
+            const f32x2_t dl = pk_sub(mv[nblk].xy, xv[nblk].xy), dh = pk_sub(mv[nblk].zw, xv[nblk].zw);
+            const f32x2_t tl = dl * dl, th = dh * dh;
+            tt[0] = tl.x; tt[1] = tl.y; tt[2] = th.x; tt[3] = th.y;
+        }
+        float res = (rl.x + rl.y) + (rh.x + rh.y);
+        const float ro = __shfl_xor(res, 1);
+        res = (h == 0) ? res + ro : ro + res;                      // ((r0+r1)+(r2+r3)) + ((r4+r5)+(r6+r7))
+        if (rem > 0) res += tt[0];
+        if (rem > 1) res += tt[1];
+        if (rem > 2) res += tt[2];
+        if (rem > 3) res += tt[3];
+        const float sc = -res;
+        const float so = __shfl_xor(sc, 2);
+        if ((lane & 3) == 0 && rid >= 0) {
+            const bool second = c + 1 < A.K_max && so > sc;
+            A.cand.k[rid] = second ? c + 1 : c;
+            A.cand.s[rid] = (double)(second ? so : sc);
+        }
+    }
+}
+
+// Fourth form of the exact stage: the component table in LDS.  Forms two and three move 1.3 GB through the vector L1s
+// (the rows, 0.42 GB from HBM, and two member rows per row, 0.84 GB of L2 hits) and run at what the L1s can have in
+// flight -- ~34 GB/s per CU, 9 TB/s over the chip, 145 us -- whatever the instruction stream looks like (r02_t/u/v in
+// profiles/README.md).  Here the table is split into P ranges of `cpp` components (+1: a pair may straddle), each
+// workgroup keeps ONE range in LDS (pitch ps slots, see the third form) and walks a slice of the rows, taking only those
+// whose pair base lies in its range: the members then cost LDS reads, and what goes through the L1s is the rows
+// themselves plus P reads of cand.k.  One workgroup per CU, four waves; every wave works alone on its own rows: it scans
+// 64 candidates at a time into a small ring (ballot + prefix count), takes 16 rows per step off the ring, and has the
+// 13 loads per lane of the next step in flight while it sums the current one.
+#define SEGK_PAIR4_RING 128
+template <int KS, int V, int NW>
+__global__ __launch_bounds__(64 * NW) void k_kmeans_exact_pair4(ScoreArgs A, int P, int cpp)
+{
+    constexpr int D = 16 * KS - 4 * V, D4 = D >> 2;
+    constexpr int ps = D4 + ((2 - D4) & 3), LD = ps * 4;
+    constexpr int nfull = D & ~7, nblk = nfull >> 3, rem = D & 7;
+    constexpr int NX = nblk + (rem ? 1 : 0);
+    extern __shared__ __attribute__((aligned(16))) float lds[];    // [cpp + 1][LD] member rows, then the waves' rings
+    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    typedef const __attribute__((address_space(1))) f32x4_t *gptr_t;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int part = blockIdx.x % P, chunk = blockIdx.x / P, n_chunk = gridDim.x / P;
+    if (chunk >= n_chunk) return;
+    const int c_lo = part * cpp;
+    int c_n = A.K_max - c_lo;
+    if (c_n > cpp + 1) c_n = cpp + 1;
+    for (int i = tid; i < c_n * D4; i += 64 * NW) {
+        const int r = i / D4, s4 = i - r * D4;
+        *reinterpret_cast<f32x4_t *>(lds + r * LD + 4 * s4) = *reinterpret_cast<const f32x4_t *>(A.means32 + (int64_t)(c_lo + r) * D + 4 * s4);
+    }
+    __syncthreads();
+    if (c_n <= 0) return;
+    volatile int2 *ring = reinterpret_cast<volatile int2 *>(lds + (size_t)(cpp + 1) * LD) + wave * SEGK_PAIR4_RING;
+
+    // this wave's rows: a multiple of 64 per wave
+    const int64_t n_slots = (int64_t)n_chunk * NW;
+    const int64_t per = ((A.n + n_slots - 1) / n_slots + 63) & ~(int64_t)63;
+    int64_t pos = ((int64_t)chunk * NW + wave) * per;
+    const int64_t r_end = pos + per < A.n ? pos + per : A.n;
+
+    auto load_rid = [&](int64_t p_) -> int32_t {
+        const int64_t r = p_ + lane;
+        return r < r_end ? (A.ids ? A.ids[r] : (int32_t)(A.row0 + r)) : -1;
+    };
+    auto pk_sub = [](f32x2_t a, f32x2_t b2) -> f32x2_t {           // a - b, both halves in one instruction
+        f32x2_t d;
+        asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b2));
+        return d;
+    };
+    const int row = lane >> 2, mem = (lane >> 1) & 1, h = lane & 1;
+
+    int32_t rid_n = -1, k_n = 0;
+    if (pos < r_end) {
+        rid_n = load_rid(pos);
+        k_n = rid_n >= 0 ? A.cand.k[rid_n] : 0;
+    }
+    int count = 0, head = 0;
+    bool have_prev = false;
+    f32x4_t xp[NX];
+    int32_t p_rid = -1, p_base = 0;
+    for (;;) {
+        // candidates into the ring until a step's worth is there
+        while (count < SEGK_PAIR_ROWS && pos < r_end) {
+            const int32_t rid = rid_n, k = k_n;
+            pos += 64;
+            if (pos < r_end) {
+                rid_n = load_rid(pos);
+                k_n = rid_n >= 0 ? A.cand.k[rid_n] : 0;
+            }
+            int32_t base = -1;
+            if (rid >= 0 && k >= 0 && (k & SEGK_PAIR_PENDING) && (k & ~SEGK_PAIR_PENDING) < A.K_max) base = (k & ~SEGK_PAIR_PENDING) - c_lo;
+            const bool sel = base >= 0 && base < cpp;
+            const unsigned long long mask = __ballot(sel);
+            const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+            if (sel) {
+                const int at = (head + count + before) & (SEGK_PAIR4_RING - 1);
+                ring[at].x = rid;
+                ring[at].y = base;
+            }
+            count += __popcll(mask);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int n = count < SEGK_PAIR_ROWS ? count : SEGK_PAIR_ROWS;
+        // the next step: its rows off the ring, their loads into flight
+        int32_t n_rid = -1, n_base = 0;
+        if (row < n) {
+            const int at = (head + row) & (SEGK_PAIR4_RING - 1);
+            n_rid = ring[at].x;
+            n_base = ring[at].y;
+        }
+        head = (head + n) & (SEGK_PAIR4_RING - 1);
+        count -= n;
+        f32x4_t xn[NX];
+        {
+            const int64_t r_any = n_rid >= 0 ? (int64_t)n_rid : (A.ids ? 0 : A.row0);
+            const uintptr_t xa = (uintptr_t)(A.xrows32 + r_any * A.ld32);
+#pragma unroll
+            for (int b = 0; b < nblk; b++) xn[b] = *reinterpret_cast<gptr_t>(xa + 16u * h + 32u * b);
+            if (rem) xn[nblk] = *reinterpret_cast<gptr_t>(xa + 4u * nfull);
+        }
+        if (have_prev) {
+            // the reference's float32 -(deltas*deltas).sum() in numpy's pairwise order: this lane owns the strided
+            // accumulators r_{4h..4h+3} of member `mem` of its row
+            int mi = p_base + mem;
+            if (mi >= c_n) mi = c_n - 1;                           // beyond the table: the result is dropped
+            const float *mrow = lds + mi * LD;
+            f32x4_t mv[NX];
+#pragma unroll
+            for (int b = 0; b < nblk; b++) mv[b] = *reinterpret_cast<const f32x4_t *>(mrow + 4 * h + 8 * b);
+            if (rem) mv[nblk] = *reinterpret_cast<const f32x4_t *>(mrow + nfull);
+            f32x2_t rl = {0.f, 0.f}, rh = {0.f, 0.f};
+#pragma unroll
+            for (int b = 0; b < nblk; b++) {
+                const f32x2_t dl = pk_sub(mv[b].xy, xp[b].xy), dh = pk_sub(mv[b].zw, xp[b].zw);
+                const f32x2_t tl = dl * dl, th = dh * dh;
+                rl = b == 0 ? tl : rl + tl;
+                rh = b == 0 ? th : rh + th;
+            }
+            float res = (rl.x + rl.y) + (rh.x + rh.y);
+            const float ro = __shfl_xor(res, 1);
+            res = (h == 0) ? res + ro : ro + res;                  // ((r0+r1)+(r2+r3)) + ((r4+r5)+(r6+r7))
+            if (rem) {
+                const f32x2_t dl = pk_sub(mv[nblk].xy, xp[nblk].xy), dh = pk_sub(mv[nblk].zw, xp[nblk].zw);
+                const f32x2_t tl = dl * dl, th = dh * dh;
+                res += tl.x;
+                if (rem > 1) res += tl.y;
+                if (rem > 2) res += th.x;
+                if (rem > 3) res += th.y;
+            }
+            const float sc = -res;
+            const float so = __shfl_xor(sc, 2);
+            if ((lane & 3) == 0 && p_rid >= 0) {
+                const int c = p_base + c_lo;
+                const bool second = c + 1 < A.K_max && so > sc;
+                A.cand.k[p_rid] = second ? c + 1 : c;
+                A.cand.s[p_rid] = (double)(second ? so : sc);
+            }
+        }
+        if (n == 0) break;
+#pragma unroll
+        for (int b = 0; b < NX; b++) xp[b] = xn[b];
+        p_rid = n_rid;
+        p_base = n_base;
+        have_prev = true;
     }
 }
 
@@ -630,9 +941,23 @@ static int launch_score_pre(segk_ctx *ctx, ScoreArgs A, hipStream_t st)
         }
     }
     const char *pv = getenv("SEGK_PAIR_V");
-    const bool pair1 = pv && atoi(pv) == 1;
+    // 3: whole-row loads transposed through LDS, pipelined (default; its 32-bit offsets into the means want a table < 4 GB)
+    const bool small_table = A.K_max < (1 << 24) && (int64_t)A.K_max * A.D * 4 < ((int64_t)1 << 32);
+    // 4: the table in LDS, split into at most 8 ranges (default)
+    const int pitch4 = ((A.D >> 2) + ((2 - (A.D >> 2)) & 3)) * 16;
+    // SEGK_PAIR4_WAVES: 4 or 8 waves per workgroup (one workgroup per CU)
+    const char *p4w = getenv("SEGK_PAIR4_WAVES");
+    const int nw4 = p4w && atoi(p4w) == 4 ? 4 : 8;
+    const int64_t lds4_budget = (overlap ? 122 : 158) * 1024 - nw4 * SEGK_PAIR4_RING * (int64_t)sizeof(int2);
+    const int64_t cpp_max = lds4_budget / pitch4 - 1;
+    const int parts4 = cpp_max > 0 ? (int)((A.K_max + cpp_max - 1) / cpp_max) : 99;
+    const int cpp4 = parts4 > 0 ? (A.K_max + parts4 - 1) / parts4 : 0;
+    const int pair_v = pv ? atoi(pv) : (parts4 <= 8 && ctx->n_cu >= parts4 ? 4 : small_table ? 3 : 2);
+    const bool pair1 = pair_v == 1;
+    const int d4 = A.D >> 2, pitch_slots = d4 + ((2 - d4) & 3);
     const size_t lds_p = pair1 ? 3 * (size_t)SEGK_PAIR_ROWS * (KS * 16 + 8) * sizeof(float) + 3 * SEGK_PAIR_ROWS * sizeof(uint64_t)
-                               : (size_t)SEGK_PAIR_ROWS * (KS * 16 + 8) * sizeof(float) + SEGK_PAIR_ROWS * sizeof(uint64_t);
+                         : pair_v == 2 ? (size_t)SEGK_PAIR_ROWS * (KS * 16 + 8) * sizeof(float) + SEGK_PAIR_ROWS * sizeof(uint64_t)
+                                       : 3 * (size_t)SEGK_PAIR_ROWS * pitch_slots * 16;
     const char *pw = getenv("SEGK_PAIR_WAVES");
     // waves per CU: the second form could hold 12 (registers: three per SIMD), but beside the second stage -- the head of
     // the longer branch -- 6 is the measured optimum (12: 1 555, 8: 1 598, 6: 1 626 sweeps/s; profiles/README.md r02_d)
@@ -648,7 +973,37 @@ static int launch_score_pre(segk_ctx *ctx, ScoreArgs A, hipStream_t st)
         if (waves > max_waves * (int64_t)ctx->n_cu) waves = max_waves * (int64_t)ctx->n_cu;
         if (waves > steps) waves = steps;
         if (pair1) hipLaunchKernelGGL((k_kmeans_exact_pair<KS>), dim3((unsigned)waves), dim3(64), lds_p, sx, P);
-        else hipLaunchKernelGGL((k_kmeans_exact_pair2<KS>), dim3((unsigned)waves), dim3(64), lds_p, sx, P);
+        else if (pair_v == 2) hipLaunchKernelGGL((k_kmeans_exact_pair2<KS>), dim3((unsigned)waves), dim3(64), lds_p, sx, P);
+        else if (pair_v == 4) {
+            const size_t lds4 = (size_t)(cpp4 + 1) * pitch4 + nw4 * SEGK_PAIR4_RING * sizeof(int2);
+            const unsigned grid4 = (unsigned)((ctx->n_cu / parts4) * parts4);
+#define SEGK_PAIR4_LAUNCH_W(VV, WW)                                                                                               \
+    do {                                                                                                                           \
+        (void)hipFuncSetAttribute((const void *)k_kmeans_exact_pair4<KS, VV, WW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4); \
+        hipLaunchKernelGGL((k_kmeans_exact_pair4<KS, VV, WW>), dim3(grid4), dim3(64 * WW), lds4, sx, P, parts4, cpp4);             \
+    } while (0)
+#define SEGK_PAIR4_LAUNCH(VV)                                                                                                      \
+    do {                                                                                                                           \
+        if (nw4 == 4) SEGK_PAIR4_LAUNCH_W(VV, 4);                                                                                  \
+        else SEGK_PAIR4_LAUNCH_W(VV, 8);                                                                                           \
+    } while (0)
+            switch ((16 * KS - A.D) / 4) {
+                case 0: SEGK_PAIR4_LAUNCH(0); break;
+                case 1: SEGK_PAIR4_LAUNCH(1); break;
+                case 2: SEGK_PAIR4_LAUNCH(2); break;
+                default: SEGK_PAIR4_LAUNCH(3); break;
+            }
+#undef SEGK_PAIR4_LAUNCH_W
+#undef SEGK_PAIR4_LAUNCH
+        } else {
+            if (!small_table) { segk_set_error("exact pair stage: component table of 4 GB or more (SEGK_PAIR_V=2)"); return; }
+            switch ((16 * KS - A.D) / 4) {
+                case 0: hipLaunchKernelGGL((k_kmeans_exact_pair3<KS, 0>), dim3((unsigned)waves), dim3(64), lds_p, sx, P); break;
+                case 1: hipLaunchKernelGGL((k_kmeans_exact_pair3<KS, 1>), dim3((unsigned)waves), dim3(64), lds_p, sx, P); break;
+                case 2: hipLaunchKernelGGL((k_kmeans_exact_pair3<KS, 2>), dim3((unsigned)waves), dim3(64), lds_p, sx, P); break;
+                default: hipLaunchKernelGGL((k_kmeans_exact_pair3<KS, 3>), dim3((unsigned)waves), dim3(64), lds_p, sx, P); break;
+            }
+        }
     };
     // second stage (all three products) of the rows queued in region [q0, q0 + cap) under counter `ch`; the row count is read on the device
     auto launch_second = [&](int64_t q0, int64_t cap, int ch, hipStream_t sx) -> int {
@@ -657,7 +1012,7 @@ static int launch_score_pre(segk_ctx *ctx, ScoreArgs A, hipStream_t st)
         B.row0 = 0;
         B.n = cap;
         B.n_dev = ctx->pre_queue + ch;
-        return segk_launch_sp_second(B, KS, sx);
+        return segk_launch_sp_second(ctx, B, KS, sx);
     };
     if (prof) SEGK_CHECK_HIP(hipEventRecord(ctx->prof_ev[slot][0], st));
     if (n_chunks > 1) {
@@ -718,12 +1073,20 @@ static int launch_score_pre(segk_ctx *ctx, ScoreArgs A, hipStream_t st)
     // branch on the caller's stream, so that the join finds its event already fired -- was measured SLOWER, 1 503
     // against 1 622 sweeps/s: the exact stage then starts a cross-stream signal later and both branches are about
     // equally long.)
+    // SEGK_SCORE_ORDER=1: the second stage first and alone (it is matrix-bound, 580 TFLOP/s on its 49 k rows, and
+    // gains nothing from sharing the chip), then the fork: the exact stage, which saturates HBM, beside the full scan
+    // of the ~1 600 rows left, which is a chain of latencies.
+    const char *oe = getenv("SEGK_SCORE_ORDER");
+    const bool second_first = oe && atoi(oe) == 1;
+    if (second_first)
+        if (int rc = launch_second(0, cap2, 0, st)) return rc;
     if (overlap) {
         SEGK_CHECK_HIP(hipEventRecord(ctx->ev_fork, st));
         SEGK_CHECK_HIP(hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
     }
     launch_pair(0, A.n, st);
-    if (int rc = launch_second(0, cap2, 0, st2)) return rc;
+    if (!second_first)
+        if (int rc = launch_second(0, cap2, 0, st2)) return rc;
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;
 }

@@ -33,7 +33,12 @@
 // (P pieces), component tiles double-buffered in LDS, two accumulator sets so that the top-2 update of
 // tile t-1 drains under the MFMAs of tile t.
 // ======================================================================================
-template <int KS, int WAVES, int P, int MODE = 0>
+// SPLIT = 1 (second stage of the pre-filter only): workgroup b takes row block b / n_chunks and the tile range
+// [(b % n_chunks) * tiles_per_split, ...): the few thousand queued rows then occupy n_chunks times as many CUs for a
+// n_chunks-th of the 32 dependent tile steps (~1.7 us each) a workgroup otherwise walks alone.  Partial candidates go
+// to part_f ([row block][split][row]: top1, top2, component); the workgroup that arrives last at the block's ticket
+// (part_k) merges them and runs the epilogue, and clears the ticket for the next call.
+template <int KS, int WAVES, int P, int MODE = 0, int SPLIT = 0>
 __global__ __launch_bounds__(64 * WAVES, 2) void k_kmeans_score_sp(ScoreArgs A)
 {
     typedef typename SegkPiece<P>::T T;
@@ -42,18 +47,26 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_kmeans_score_sp(ScoreArgs A)
     const int32_t *__restrict__ ids = A.ids;
     const int64_t row0 = A.row0;
     int64_t n = A.n;
+    const int64_t rb_first = SPLIT ? (int64_t)(blockIdx.x / A.n_chunks) : (int64_t)blockIdx.x;
+    // row blocks per workgroup: one (the launch covers the rows), or -- the pre-filter's queue, whose length only the
+    // device knows -- every (grid)th: a launch sized for the queue's capacity spent ~40 us of its 57 dispatching
+    // eight thousand workgroups that found nothing to do
+    const int64_t rb_stride = A.n_dev ? (int64_t)(SPLIT ? gridDim.x / A.n_chunks : gridDim.x) : ((int64_t)1 << 40);
+    const int split = SPLIT ? (int)(blockIdx.x % A.n_chunks) : 0;
+    const int tile0 = SPLIT ? split * A.tiles_per_split : 0;
     if (A.n_dev) {                        // rows queued by the pre-filter: the count lives on the device
-        const int64_t nd = *A.n_dev;
+        const int64_t nd = *A.n_dev - A.n_dev_off;
         n = nd < n ? nd : n;
-        if ((int64_t)blockIdx.x * WAVES * 32 >= n) return;
+        if (rb_first * WAVES * 32 >= n) return;
         // this launch is the head of the longer branch of the score stage (second stage -> full scan) and shares its CUs
         // with the dozen latency-bound waves of the exact pair kernel: its few waves go first at every issue slot
         if (A.dbg != 64) __builtin_amdgcn_s_setprio(3);
     }
-    const float *__restrict__ tiles = A.tiles + 1024;
-    const int n_tiles = A.n_tiles, D = A.D;
     constexpr int KP = KS * 16;
     constexpr int STRIDE = (KS * P * 256 + 32 + 1023) / 1024 * 1024;      // floats per tile image
+    const float *__restrict__ tiles = A.tiles + 1024 + (int64_t)tile0 * STRIDE;
+    const int n_tiles = SPLIT ? (A.n_tiles - tile0 < A.tiles_per_split ? A.n_tiles - tile0 : A.tiles_per_split) : A.n_tiles;
+    const int D = A.D;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
     // scaled domain: accumulators hold 2^(a+b) f (P = 2), unscaled again before anything leaves the kernel
@@ -61,8 +74,9 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_kmeans_score_sp(ScoreArgs A)
     const float unscale = ldexpf(1.f, -e_ab);
     constexpr float LS = P == 2 ? 1.f / 2048.f : 1.f;
 
+    for (int64_t rblock = rb_first; rblock * WAVES * 32 < n; rblock += rb_stride) {
     V8 xb[P][KS];
-    const int64_t r = ((int64_t)blockIdx.x * WAVES + wave) * 32 + j;
+    const int64_t r = (rblock * WAVES + wave) * 32 + j;
     int32_t rowid = -1;
     if (r < n) rowid = ids ? ids[r] : (int32_t)(row0 + r);
     {
@@ -206,21 +220,58 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_kmeans_score_sp(ScoreArgs A)
 #undef SEGK_DRAIN
 #undef SEGK_STAGE
 #undef SEGK_TILE_SYNC
-    if constexpr (MODE == 2) return;
+    if constexpr (MODE == 2) continue;
     if constexpr (MODE == 1) {
         // the two lane halves summed disjoint component subsets of the same row
         const float om = __shfl_xor(m1, 32), os = __shfl_xor(m2, 32);
         const float M = fmaxf(m1, om);
         const float S = m2 * exp2f(m1 - M) + os * exp2f(om - M);
         if (h == 0 && rowid >= 0) A.lse_out[rowid] = (double)(M + log2f(S)) * 0.6931471805599453 - A.lse_norm;
-        return;
+        continue;
     }
-    const int32_t i1 = itile * 32 + 4 * h + (irow & 3) + 8 * (irow >> 2);
+    const int32_t i1 = (itile + tile0) * 32 + 4 * h + (irow & 3) + 8 * (irow >> 2);
     const float o1 = __shfl_xor(m1, 32), o2 = __shfl_xor(m2, 32);
     const int oi = __shfl_xor(i1, 32);
-    const float top1 = fmaxf(m1, o1) * unscale;                    // powers of two: exact
-    const float top2 = fmaxf(fminf(m1, o1), fmaxf(m2, o2)) * unscale;
-    const int idx = (o1 > m1 || (o1 == m1 && oi < i1)) ? oi : i1;
+    float top1 = fmaxf(m1, o1) * unscale;                          // powers of two: exact
+    float top2 = fmaxf(fminf(m1, o1), fmaxf(m2, o2)) * unscale;
+    int idx = (o1 > m1 || (o1 == m1 && oi < i1)) ? oi : i1;
+    if constexpr (SPLIT) {
+        __shared__ int s_last;
+        const int S = A.n_chunks;
+        float *part = A.part_f + ((rblock * S) * (WAVES * 32) + wave * 32 + j) * 4;      // + split * WAVES * 32 * 4
+        if (h == 0) {
+            float *pp = part + (int64_t)split * (WAVES * 32 * 4);
+            __hip_atomic_store(pp + 0, top1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(pp + 1, top2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(pp + 2, __int_as_float(idx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // No __threadfence here: at agent scope it writes back and invalidates the whole L2 of the XCD, and with the exact
+        // stage writing its results beside this kernel every such fence cost ~1 us of everybody's time (634 us for the
+        // stage).  The partials are write-through stores and coherent loads (agent-scope atomics, relaxed), ordered
+        // against the ticket by waiting for the stores' acknowledgements.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) s_last = __hip_atomic_fetch_add(A.part_k + rblock, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == S - 1;
+        __syncthreads();
+        if (!s_last) continue;
+        if (tid == 0) __hip_atomic_store(A.part_k + rblock, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // per row the largest filter value (ties: the lower component) and the second largest over everything else
+        top1 = NEG_INF_F; top2 = NEG_INF_F; idx = 0x7fffffff;
+        for (int sp = 0; sp < S; sp++) {
+            const float *pp = part + (int64_t)sp * (WAVES * 32 * 4);
+            const float f1 = __hip_atomic_load(pp + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float f2 = __hip_atomic_load(pp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int k = __float_as_int(__hip_atomic_load(pp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            if (f1 > top1 || (f1 == top1 && k < idx)) {
+                top2 = fmaxf(top2, top1);
+                top1 = f1;
+                idx = k;
+            } else {
+                top2 = fmaxf(top2, f1);
+            }
+            top2 = fmaxf(top2, f2);
+        }
+    }
     // Fused exact stage for the winner (D a multiple of 4): the reference's float32 -(deltas*deltas).sum()
     // in numpy's pairwise order.  This lane half owns the strided accumulators r_{4h..4h+3} in full
     // (segk_b3_dim); the row and the winner's mean are read as float32 from X32 / `means`.
@@ -239,6 +290,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_kmeans_score_sp(ScoreArgs A)
             if (q < A.amb_cap) A.cand.queue[q] = rowid;
         }
     }
+    }   // row blocks of this workgroup
 }
 
 // split-precision filter: whole rounds (and any larger remainder) to k_kmeans_score_sp, a remainder of
@@ -407,7 +459,7 @@ int segk_dispatch_score_sp(segk_ctx *ctx, const ScoreArgs &A, int ks, int pieces
 // second stage of the one-product pre-filter (segk_score_h1.hip): all three fp16x2 products for the rows it
 // queued; B.n_dev holds the row count on the device, the launch covers B.n rows
 template <int KS>
-static int launch_sp_second(const ScoreArgs &B, hipStream_t st)
+static int launch_sp_second(segk_ctx *ctx, const ScoreArgs &B, hipStream_t st)
 {
     constexpr int STRIDE = (KS * 2 * 256 + 32 + 1023) / 1024 * 1024;
     const size_t lds2 = 2 * (size_t)STRIDE * sizeof(float);
@@ -415,24 +467,55 @@ static int launch_sp_second(const ScoreArgs &B, hipStream_t st)
     if (!attr_set && lds2 > 48 * 1024) {
         SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_kmeans_score_sp<KS, 4, 2>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+        SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_kmeans_score_sp<KS, 4, 2, 0, 1>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_kmeans_score_sp<KS, 4, 2>), dim3((unsigned)((B.n + 127) / 128)), dim3(256), lds2, st, B);
+    // SEGK_SP2_SPLIT: ranges of component tiles per row block (default 1: the plain kernel); SEGK_SP2_GRID: workgroups
+    // (row blocks in flight) of the launch, default two per CU
+    const char *se = getenv("SEGK_SP2_SPLIT"), *ge = getenv("SEGK_SP2_GRID");
+    int n_split = se ? atoi(se) : 1;
+    if (n_split > B.n_tiles) n_split = B.n_tiles;
+    if (n_split > 8) n_split = 8;
+    const int64_t blocks = (B.n + 127) / 128;
+    int64_t grid = ge ? atoi(ge) : 2 * (int64_t)ctx->n_cu;
+    if (grid > blocks) grid = blocks;
+    if (grid < 1) grid = 1;
+    if (n_split <= 1 || ctx->capturing) {
+        hipLaunchKernelGGL((k_kmeans_score_sp<KS, 4, 2>), dim3((unsigned)grid), dim3(256), lds2, st, B);
+        SEGK_LAUNCH_CHECK();
+        return SEGK_OK;
+    }
+    if (ctx->sp2_blocks < blocks) {
+        if (ctx->sp2_part) (void)hipFree(ctx->sp2_part);
+        if (ctx->sp2_ticket) (void)hipFree(ctx->sp2_ticket);
+        ctx->sp2_part = nullptr; ctx->sp2_ticket = nullptr; ctx->sp2_blocks = 0;
+        SEGK_CHECK_HIP(hipMalloc((void **)&ctx->sp2_part, (size_t)blocks * 8 * 128 * 4 * sizeof(float)));
+        SEGK_CHECK_HIP(hipMalloc((void **)&ctx->sp2_ticket, (size_t)blocks * sizeof(int32_t)));
+        SEGK_CHECK_HIP(hipMemsetAsync(ctx->sp2_ticket, 0, (size_t)blocks * sizeof(int32_t), st));
+        ctx->sp2_blocks = blocks;
+    }
+    ScoreArgs S = B;
+    S.tiles_per_split = (B.n_tiles + n_split - 1) / n_split;
+    S.n_chunks = (B.n_tiles + S.tiles_per_split - 1) / S.tiles_per_split;
+    S.part_f = ctx->sp2_part;
+    S.part_k = ctx->sp2_ticket;
+    hipLaunchKernelGGL((k_kmeans_score_sp<KS, 4, 2, 0, 1>), dim3((unsigned)(grid * S.n_chunks)), dim3(256), lds2, st, S);
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;
 }
 
-int segk_launch_sp_second(const ScoreArgs &B, int ks, hipStream_t st)
+int segk_launch_sp_second(segk_ctx *ctx, const ScoreArgs &B, int ks, hipStream_t st)
 {
     switch (ks) {
-        case 1: return launch_sp_second<1>(B, st);
-        case 2: return launch_sp_second<2>(B, st);
-        case 3: return launch_sp_second<3>(B, st);
-        case 4: return launch_sp_second<4>(B, st);
-        case 5: return launch_sp_second<5>(B, st);
-        case 6: return launch_sp_second<6>(B, st);
-        case 7: return launch_sp_second<7>(B, st);
-        case 8: return launch_sp_second<8>(B, st);
+        case 1: return launch_sp_second<1>(ctx, B, st);
+        case 2: return launch_sp_second<2>(ctx, B, st);
+        case 3: return launch_sp_second<3>(ctx, B, st);
+        case 4: return launch_sp_second<4>(ctx, B, st);
+        case 5: return launch_sp_second<5>(ctx, B, st);
+        case 6: return launch_sp_second<6>(ctx, B, st);
+        case 7: return launch_sp_second<7>(ctx, B, st);
+        case 8: return launch_sp_second<8>(ctx, B, st);
         default: break;
     }
     segk_set_error("pre-filter second stage: D out of range");
