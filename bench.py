@@ -405,7 +405,9 @@ def main():
         _abi.check(_abi.lib().segk_profile_enable(_abi.ctx(), 0))
 
     if rank == 0:
-        flops_per_launch = 2.0 * score_rows * args.K * args.dim      # algorithmic: 2 rows K D of the timed launch
+        # algorithmic: 2 rows K D of the timed launch.  K = all K_max slots: those beyond the active components hold
+        # random means and are candidates like any other, as in the reference (kmeans_components.py:149-166, 225-226)
+        flops_per_launch = 2.0 * score_rows * args.K * args.dim
         out = {
             "metric": METRIC,
             "value": args.steps / elapsed,

@@ -125,6 +125,8 @@ __global__ __launch_bounds__(256) void k_kmeans_brute_rows(segk_corpus c, segk_k
     n_groups = (int)gridDim.x / ksplit;
     const int grp0 = blockIdx.x % n_groups, slice = blockIdx.x / n_groups;
     if (slice >= ksplit) return;
+    // all K_max slots: the reference's argmax runs over every row of `means`, and the slots beyond K hold random_means
+    // (kmeans_components.py:149-166, 225-226) -- a token that lands there opens a new component
     const int k_per = (m.K_max + ksplit - 1) / ksplit;
     for (int q0 = grp0 * SEGK_BR; q0 < nq; q0 += n_groups * SEGK_BR) {
         const bool split = ksplit > 1 && q0 + SEGK_BR <= ws_cap;
