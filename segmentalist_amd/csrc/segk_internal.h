@@ -25,6 +25,9 @@ struct segk_ctx {
     float *sp2_part;
     int32_t *sp2_ticket;
     int64_t sp2_blocks;
+    // persistent sequential chain (segk_seq_chain.hip): span maxima, control words, the sweep's utterance order
+    void *chain_buf;
+    size_t chain_bytes;
     // second stream of segk_kmeans_score: the pre-filter's second stage and the full scan run on it beside
     // the exact stage of the decided rows (created on first use)
     hipStream_t aux;

@@ -118,9 +118,18 @@ int32_t segk_kmeans_sequential_sweep(segk_ctx *ctx, const segk_corpus *c, segk_k
         return SEGK_ERR_UNSUPPORTED;
     }
     hipStream_t st = (hipStream_t)stream;
+    for (int32_t q = 0; q < n_order; q++) SEGK_REQUIRE(order[q] >= 0 && order[q] < c->n_utt, "utterance index out of range");
+    // the whole sweep in one persistent kernel (segk_seq_chain.hip) where the configuration allows; SEGK_SEQ_CHAIN=0: three
+    // launches per utterance
+    const char *che = getenv("SEGK_SEQ_CHAIN");
+    if (!(che && atoi(che) == 0) && (n_slices_min == 0 || n_slices_min == 1)) {
+        rc = segk_launch_seq_chain(ctx, c, m, order, n_order, n_slices_max, wip, boundaries, old_tok, new_tok, new_k, n_old, n_new,
+                                   n_flag, out_total, status, st);
+        if (rc == SEGK_OK) return segk_kmeans_prepare(ctx, c, m, stream);
+        if (rc != SEGK_ERR_UNSUPPORTED) return rc;
+    }
     for (int32_t q = 0; q < n_order; q++) {
         const int32_t u = order[q];
-        SEGK_REQUIRE(u >= 0 && u < c->n_utt, "utterance index out of range");
         rc = segk_launch_seq_score(c, m, u, cand, (unsigned long long *)keys_scratch, st);
         if (rc) return rc;
         rc = segk_kmeans_segment(ctx, c, m, nullptr, u, 1, n_slices_min, n_slices_max, wip, cand, boundaries, old_tok, new_tok,

@@ -129,6 +129,44 @@ __device__ __forceinline__ float neg_sqd_exact_v4(const float *m, const float *x
     return -res;
 }
 
+// The same with two elements per instruction (v_pk_add_f32 with the second operand negated, v_pk_mul_f32, v_pk_add_f32: each
+// half is rounded like the scalar operation; -ffp-contract=off keeps multiply and add apart)
+__device__ __forceinline__ float neg_sqd_exact_v4_pk(const float *m, const float *x, int n)
+{
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+    auto pk_sub = [](f32x2_t a, f32x2_t b) -> f32x2_t {
+        f32x2_t d;
+        asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+        return d;
+    };
+    const int nfull = n & ~7;
+    f32x2_t r01, r23, r45, r67;
+    {
+        const f32x4_t m0 = *reinterpret_cast<const f32x4_t *>(m), m1 = *reinterpret_cast<const f32x4_t *>(m + 4);
+        const f32x4_t x0 = *reinterpret_cast<const f32x4_t *>(x), x1 = *reinterpret_cast<const f32x4_t *>(x + 4);
+        const f32x2_t d0 = pk_sub(m0.xy, x0.xy), d1 = pk_sub(m0.zw, x0.zw), d2 = pk_sub(m1.xy, x1.xy), d3 = pk_sub(m1.zw, x1.zw);
+        r01 = d0 * d0; r23 = d1 * d1; r45 = d2 * d2; r67 = d3 * d3;
+    }
+    for (int i = 8; i < nfull; i += 8) {
+        const f32x4_t m0 = *reinterpret_cast<const f32x4_t *>(m + i), m1 = *reinterpret_cast<const f32x4_t *>(m + i + 4);
+        const f32x4_t x0 = *reinterpret_cast<const f32x4_t *>(x + i), x1 = *reinterpret_cast<const f32x4_t *>(x + i + 4);
+        const f32x2_t d0 = pk_sub(m0.xy, x0.xy), d1 = pk_sub(m0.zw, x0.zw), d2 = pk_sub(m1.xy, x1.xy), d3 = pk_sub(m1.zw, x1.zw);
+        r01 += d0 * d0; r23 += d1 * d1; r45 += d2 * d2; r67 += d3 * d3;
+    }
+    float res = ((r01.x + r01.y) + (r23.x + r23.y)) + ((r45.x + r45.y) + (r67.x + r67.y));
+    if (n & 4) {                                            // the sequential tail: four elements
+        const f32x4_t mt = *reinterpret_cast<const f32x4_t *>(m + nfull), xt = *reinterpret_cast<const f32x4_t *>(x + nfull);
+        const f32x2_t d0 = pk_sub(mt.xy, xt.xy), d1 = pk_sub(mt.zw, xt.zw);
+        const f32x2_t t0 = d0 * d0, t1 = d1 * d1;
+        res += t0.x;
+        res += t0.y;
+        res += t1.x;
+        res += t1.y;
+    }
+    return -res;
+}
+
 // Four rows at once for 8 <= n <= 128 (numpy's single-block case): identical arithmetic per
 // row, interleaved so that 4 x 8 loads are in flight per step.
 template <typename T, typename TM, typename TX>
@@ -643,6 +681,10 @@ int segk_dispatch_score_f32(segk_ctx *ctx, const segk_corpus *c, const segk_kmea
 // segk_score_sp.hip: the split-precision filter (pieces = 2 fp16x2, 3 bf16x3) and the pre-filter's second stage
 int segk_dispatch_score_sp(segk_ctx *ctx, const ScoreArgs &A, int ks, int pieces, hipStream_t st);
 int segk_launch_sp_second(segk_ctx *ctx, const ScoreArgs &B, int ks, hipStream_t st);
+int segk_launch_clean(const segk_corpus *c, segk_kmeans *m, int32_t *status, hipStream_t st);
+int segk_launch_seq_chain(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m, const int32_t *order, int n_order, int n_slices_max,
+                          double wip, uint8_t *boundaries, int32_t *old_tok, int32_t *new_tok, int32_t *new_k, int32_t *n_old,
+                          int32_t *n_new, int32_t *n_flag, double *out_total, int32_t *status, hipStream_t st);
 // segk_score_h1.hip: one-product pre-filter + exact pair stage + second stage
 int segk_dispatch_score_pre(segk_ctx *ctx, const ScoreArgs &A, int ks, hipStream_t st);
 // segk_exact.hip / segk_stats.hip: the pieces of the sequential (reference-chain) sweep

@@ -1,6 +1,7 @@
 // segk_segment.hip -- per-utterance kernels: A5 vector + A8 max-plus DP + tokens (band layout), function-level DPs (triangular layout)
 // (one of the translation units of the k-means path; shared helpers: segk_kmeans_dev.h)
 #include "segk_kmeans_dev.h"
+#include "segk_segment_dev.h"
 
 // Per-utterance kernel: A5 (vec from the candidates), A8 (max-plus DP), tokens.
 //   ONE WAVE per utterance, no workgroup barriers: lanes gather the band of candidate spans,
@@ -8,11 +9,6 @@
 //   band layout: entry (t, w), t = 1..N (span end), w = 0..W-1 (span length w+1, start
 //   s = t-1-w) at [(t-1)*W + w]; W = n_slices_max, or N when n_slices_max == 0.
 // ======================================================================================
-#define WAVE_SYNC()                                             \
-    do {                                                        \
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  \
-        __builtin_amdgcn_wave_barrier();                        \
-    } while (0)
 
 __global__ void k_kmeans_segment(segk_corpus c, segk_kmeans m, const int32_t *utts, int utt0, int n_utts,
                                  int n_min, int n_max, double wip, segk_cand cand, uint8_t *boundaries,
@@ -203,7 +199,7 @@ __global__ void k_kmeans_segment_w8(segk_corpus c, segk_kmeans m, const int32_t 
     int32_t *l_old = bid + band_cap;                  // [N_max]
     int32_t *l_new = l_old + c.N_max;                 // [N_max]
     int32_t *l_newk = l_new + c.N_max;                // [N_max]
-    int32_t *l_cnt = l_newk + c.N_max;                // [4]: n_old, n_new, new boundary mask (2 words)
+    int32_t *l_cnt = l_newk + c.N_max;                // [6]: n_old, n_new, new boundary mask (2 words), flagged, bad
 
     for (int i = lane; i < nb; i += 64) {
         const int t = i / W + 1, w = i % W, s = t - 1 - w;
@@ -225,115 +221,15 @@ __global__ void k_kmeans_segment_w8(segk_corpus c, segk_kmeans m, const int32_t 
     }
     const unsigned long long oldb = __ballot(lane < N && gbnd[lane < N ? lane : 0] != 0);
     WAVE_SYNC();
+    double total;
+    seg_w8_wave(bvec, gam, bid, bk, vid, N, W, oldb, *m.K, l_old, l_new, l_newk, l_cnt, &total, lane);
+    WAVE_SYNC();
     if (lane == 0) {
-#define V_(t, s) bvec[((t) - 1) * W + ((t) - 1 - (s))]
-#define ID_(t, s) (((t) - 1 - (s)) < W ? bid[((t) - 1) * W + ((t) - 1 - (s))] : vid[(t) * ((t) - 1) / 2 + (s)])
-        // ---- old tokens (utterances.py:159-174)
-        int no = 0, jp = 0;
-        for (unsigned long long mb = oldb; mb; mb &= mb - 1) {
-            const int j = __ffsll((long long)mb) - 1;
-            const int id = ID_(j + 1, jp);
-            if (id >= 0) l_old[no++] = id;
-            jp = j + 1;
-        }
-        // ---- A8 forward (kmeans_acoustic_wordseg.py:494-506): g[w] = gamma[t - 1 - w]
-        double g[8];
-#pragma unroll
-        for (int w = 0; w < 8; w++) g[w] = NEG_INF_D;
-        g[0] = 0.0;
-        gam[0] = 0.0;
-        for (int t = 1; t < N; t++) {
-            double v[8];
-#pragma unroll
-            for (int w = 0; w < 8; w++) {                  // unconditional loads from a clamped index, then the predicate
-                const bool ok = w < W && t - 1 - w >= 0;
-                v[w] = bvec[ok ? (t - 1) * W + w : 0];
-            }
-            double best = NEG_INF_D;
-#pragma unroll
-            for (int w = 7; w >= 0; w--) {                 // s ascending, as the reference's max() scans
-                const bool ok = w < W && t - 1 - w >= 0;
-                const double x = v[w] + g[w];
-                if (ok && x > best) best = x;
-            }
-            gam[t] = best;
-#pragma unroll
-            for (int w = 7; w > 0; w--) g[w] = g[w - 1];
-            g[0] = best;
-        }
-        unsigned long long newb = 1ull << (N - 1);
-        // candidates of span end tt: are they all -inf; and the reversed np.argmax (shortest span on ties)
-        auto eval = [&](int tt, int &kb) -> bool {
-            double x[8];
-#pragma unroll
-            for (int w = 0; w < 8; w++) {
-                const bool ok = w < W && tt - 1 - w >= 0;
-                x[w] = bvec[ok ? (tt - 1) * W + w : 0] + gam[ok ? tt - 1 - w : 0];
-            }
-            double best = NEG_INF_D;
-            bool first = true, ai = true;
-#pragma unroll
-            for (int w = 0; w < 8; w++) {                  // s = tt - 1 - w descending
-                const bool ok = w < W && tt - 1 - w >= 0;
-                if (ok) {
-                    if (x[w] != NEG_INF_D) ai = false;
-                    if (first || x[w] > best) { best = x[w]; kb = w + 1; first = false; }
-                }
-            }
-            return ai;
-        };
-        // ---- A8 backward (:510-553)
-        int t = N;
-        double total = 0.0;
-        for (;;) {
-            int kb = 1;
-            bool all_inf = eval(t, kb);
-            if (all_inf) {                                 // step back until some candidate is finite (:516-530)
-                while (all_inf) {
-                    t = t - 1;
-                    if (t == 0) break;
-                    all_inf = eval(t, kb);
-                }
-                newb |= 1ull << ((t - 1 + N) % N);
-            }
-            int k = 1;
-            if (t > 0) {
-                k = kb;
-                total += V_(t, t - k);
-            } else {
-                total += V_(N, N - 1);      // python vec[-1]: the last span [N-1, N)
-            }
-            if (t - k - 1 < 0) break;
-            newb |= 1ull << (t - k - 1);
-            t = t - k;
-        }
-        // ---- new tokens + their best components (:312-313)
-        int nn = 0, bad = 0, nf = 0;
-        const int Kact = *m.K;
-        jp = 0;
-        for (unsigned long long mb = newb; mb; mb &= mb - 1) {
-            const int j = __ffsll((long long)mb) - 1;
-            const int tt = j + 1, w = tt - 1 - jp;
-            if (w >= W || bid[(tt - 1) * W + w] < 0) bad = 1;
-            else {
-                l_new[nn] = bid[(tt - 1) * W + w];
-                l_newk[nn] = bk[(tt - 1) * W + w];
-                if (l_newk[nn] >= Kact) nf++;
-                nn++;
-            }
-            jp = j + 1;
-        }
         out_total[u] = total;
-        n_old[u] = no;
-        n_new[u] = nn;
-        if (n_flag) n_flag[u] = nf;
-        l_cnt[0] = no;
-        l_cnt[1] = nn;
-        l_cnt[2] = (int32_t)(newb & 0xffffffffull);
-        l_cnt[3] = (int32_t)(newb >> 32);
-        if (bad) atomicOr(status, 1);
-#undef V_
-#undef ID_
+        n_old[u] = l_cnt[0];
+        n_new[u] = l_cnt[1];
+        if (n_flag) n_flag[u] = l_cnt[4];
+        if (l_cnt[5]) atomicOr(status, 1);
     }
     WAVE_SYNC();
     const int no = l_cnt[0], nn = l_cnt[1];
@@ -381,7 +277,7 @@ __global__ void k_kmeans_segment_w8x2(segk_corpus c, segk_kmeans m, const int32_
     int32_t *l_old = bid + band_cap;                  // [N_max]
     int32_t *l_new = l_old + c.N_max;                 // [N_max]
     int32_t *l_newk = l_new + c.N_max;                // [N_max]
-    int32_t *l_cnt = l_newk + c.N_max;                // [4]: n_old, n_new, new boundary mask (2 words)
+    int32_t *l_cnt = l_newk + c.N_max;                // [6]: n_old, n_new, new boundary mask (2 words), flagged, bad
 
     for (int i = lane; i < nb; i += 32) {
         const int t = i / W + 1, w = i % W, s = t - 1 - w;
@@ -676,7 +572,7 @@ int32_t segk_kmeans_segment(segk_ctx *ctx, const segk_corpus *c, const segk_kmea
     const int W = (n_slices_max > 0 && n_slices_max < c->N_max) ? n_slices_max : c->N_max;
     const int band_cap = c->N_max * W;
     size_t wave_bytes = (size_t)(band_cap + c->N_max + 1) * sizeof(double)
-                        + (size_t)(2 * band_cap + 3 * c->N_max + 4) * sizeof(int32_t) + (size_t)c->N_max;
+                        + (size_t)(2 * band_cap + 3 * c->N_max + 8) * sizeof(int32_t) + (size_t)c->N_max;
     wave_bytes = (wave_bytes + 15) & ~(size_t)15;
     int waves = 4;
     while (waves > 1 && waves * wave_bytes > 64 * 1024) waves >>= 1;
@@ -690,11 +586,12 @@ int32_t segk_kmeans_segment(segk_ctx *ctx, const segk_corpus *c, const segk_kmea
         SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_kmeans_segment, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)lds));
     const bool w8_ok = n_slices_max >= 1 && n_slices_max <= 8 && c->N_max <= 64 && !(getenv("SEGK_SEGMENT_GENERIC") && atoi(getenv("SEGK_SEGMENT_GENERIC")));
-    // two utterances per wave once one-per-wave would not fit the chip in a single round (8 waves per SIMD);
-    // SEGK_SEGMENT_X2=0 / 1: never / always
+    // SEGK_SEGMENT_X2=1: two utterances per wave, their serial DPs on lanes 0 and 32 in lockstep -- the default for launches
+    // over more than one round of resident waves until the DP of the one-per-wave kernel was spread over the wave
+    // (seg_w8_wave: 10 000 utterances 40 -> 29 us)
     const char *x2e = getenv("SEGK_SEGMENT_X2");
     const int n_cu_ = ctx ? ctx->n_cu : 256;
-    if (w8_ok && c->N_max <= 32 && 2 * waves * wave_bytes <= 48 * 1024 && (x2e ? atoi(x2e) != 0 : n_utts > 28 * n_cu_)) {
+    if (w8_ok && c->N_max <= 32 && 2 * waves * wave_bytes <= 48 * 1024 && (x2e ? atoi(x2e) != 0 : false)) {
         const int per_block = 2 * waves;
         hipLaunchKernelGGL(k_kmeans_segment_w8x2, dim3((n_utts + per_block - 1) / per_block), dim3(64 * waves), 2 * lds, st, *c, *m, utts,
                            utt0, n_utts, n_slices_max, wip, *cand, boundaries, old_tok, new_tok, new_k, n_old, n_new, n_flag,

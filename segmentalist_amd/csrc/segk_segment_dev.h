@@ -1,0 +1,268 @@
+// segk_segment_dev.h -- device code shared by the per-utterance segmenter (segk_segment.hip) and the persistent
+// sequential chain (segk_seq_chain.hip)
+#pragma once
+#include "segk_kmeans_dev.h"
+
+#define WAVE_SYNC()                                             \
+    do {                                                        \
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  \
+        __builtin_amdgcn_wave_barrier();                        \
+    } while (0)
+
+// The serial part of the window-of-eight segmenter, run by ONE lane on wave-private LDS arrays (k_kmeans_segment_w8 and the
+// persistent sequential chain, segk_seq_chain.hip): old tokens from the old boundary mask, A8 forward and backward, the new
+// tokens and their components.  bvec / bid / bk hold the band (entry (t, w) at [(t - 1) * W + w]); results: l_old, l_new,
+// l_newk and l_cnt = {n_old, n_new, new boundary mask (2 words), tokens on inactive components, bad}.
+__device__ __forceinline__ void seg_w8_serial(const double *bvec, double *gam, const int32_t *bid, const int32_t *bk, const int32_t *vid,
+                                              int N, int W, unsigned long long oldb, int Kact, int32_t *l_old, int32_t *l_new,
+                                              int32_t *l_newk, int32_t *l_cnt, double *total_out)
+{
+#define V_(t, s) bvec[((t) - 1) * W + ((t) - 1 - (s))]
+#define ID_(t, s) (((t) - 1 - (s)) < W ? bid[((t) - 1) * W + ((t) - 1 - (s))] : vid[(t) * ((t) - 1) / 2 + (s)])
+    // ---- old tokens (utterances.py:159-174)
+    int no = 0, jp = 0;
+    for (unsigned long long mb = oldb; mb; mb &= mb - 1) {
+        const int j = __ffsll((long long)mb) - 1;
+        const int id = ID_(j + 1, jp);
+        if (id >= 0) l_old[no++] = id;
+        jp = j + 1;
+    }
+    // ---- A8 forward (kmeans_acoustic_wordseg.py:494-506): g[w] = gamma[t - 1 - w]
+    double g[8];
+#pragma unroll
+    for (int w = 0; w < 8; w++) g[w] = NEG_INF_D;
+    g[0] = 0.0;
+    gam[0] = 0.0;
+    for (int t = 1; t < N; t++) {
+        double v[8];
+#pragma unroll
+        for (int w = 0; w < 8; w++) {                  // unconditional loads from a clamped index, then the predicate
+            const bool ok = w < W && t - 1 - w >= 0;
+            v[w] = bvec[ok ? (t - 1) * W + w : 0];
+        }
+        double best = NEG_INF_D;
+#pragma unroll
+        for (int w = 7; w >= 0; w--) {                 // s ascending, as the reference's max() scans
+            const bool ok = w < W && t - 1 - w >= 0;
+            const double x = v[w] + g[w];
+            if (ok && x > best) best = x;
+        }
+        gam[t] = best;
+#pragma unroll
+        for (int w = 7; w > 0; w--) g[w] = g[w - 1];
+        g[0] = best;
+    }
+    unsigned long long newb = 1ull << (N - 1);
+    // candidates of span end tt: are they all -inf; and the reversed np.argmax (shortest span on ties)
+    auto eval = [&](int tt, int &kb) -> bool {
+        double x[8];
+#pragma unroll
+        for (int w = 0; w < 8; w++) {
+            const bool ok = w < W && tt - 1 - w >= 0;
+            x[w] = bvec[ok ? (tt - 1) * W + w : 0] + gam[ok ? tt - 1 - w : 0];
+        }
+        double best = NEG_INF_D;
+        bool first = true, ai = true;
+#pragma unroll
+        for (int w = 0; w < 8; w++) {                  // s = tt - 1 - w descending
+            const bool ok = w < W && tt - 1 - w >= 0;
+            if (ok) {
+                if (x[w] != NEG_INF_D) ai = false;
+                if (first || x[w] > best) { best = x[w]; kb = w + 1; first = false; }
+            }
+        }
+        return ai;
+    };
+    // ---- A8 backward (:510-553)
+    int t = N;
+    double total = 0.0;
+    for (;;) {
+        int kb = 1;
+        bool all_inf = eval(t, kb);
+        if (all_inf) {                                 // step back until some candidate is finite (:516-530)
+            while (all_inf) {
+                t = t - 1;
+                if (t == 0) break;
+                all_inf = eval(t, kb);
+            }
+            newb |= 1ull << ((t - 1 + N) % N);
+        }
+        int k = 1;
+        if (t > 0) {
+            k = kb;
+            total += V_(t, t - k);
+        } else {
+            total += V_(N, N - 1);      // python vec[-1]: the last span [N-1, N)
+        }
+        if (t - k - 1 < 0) break;
+        newb |= 1ull << (t - k - 1);
+        t = t - k;
+    }
+    // ---- new tokens + their best components (:312-313)
+    int nn = 0, bad = 0, nf = 0;
+    jp = 0;
+    for (unsigned long long mb = newb; mb; mb &= mb - 1) {
+        const int j = __ffsll((long long)mb) - 1;
+        const int tt = j + 1, w = tt - 1 - jp;
+        if (w >= W || bid[(tt - 1) * W + w] < 0) bad = 1;
+        else {
+            l_new[nn] = bid[(tt - 1) * W + w];
+            l_newk[nn] = bk[(tt - 1) * W + w];
+            if (l_newk[nn] >= Kact) nf++;
+            nn++;
+        }
+        jp = j + 1;
+    }
+    l_cnt[0] = no;
+    l_cnt[1] = nn;
+    l_cnt[2] = (int32_t)(newb & 0xffffffffull);
+    l_cnt[3] = (int32_t)(newb >> 32);
+    l_cnt[4] = nf;
+    l_cnt[5] = bad;
+    *total_out = total;
+#undef V_
+#undef ID_
+}
+
+// ---- the same, by a whole wave --------------------------------------------------------------------------------------------
+// seg_w8_serial costs 14 us of dependent fp64 operations and LDS round trips on one lane (measured inside the persistent
+// chain).  Here lane w < 8 owns candidate w of a DP step -- one add, a three-step DPP maximum over the eight lanes, a DPP
+// shift of the gammas -- and the token lists are built by the lanes of the set boundary bits side by side (rank = prefix
+// popcount of a ballot).  Same values and the same decisions: the forward pass needs the maximum's VALUE only; the backward
+// pass takes the first maximum in w order (the reference's reversed np.argmax: the shortest span on ties).  Control flow
+// is wave-uniform.  All 64 lanes of the wave must call it.
+template <int CTRL>
+__device__ __forceinline__ double seg_dpp_f64(double v)
+{
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int lo2 = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+    const int hi2 = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi2, lo2);
+}
+template <int CTRL>
+__device__ __forceinline__ int seg_dpp_i32(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false); }
+#define SEG_DPP_XOR1 0xB1          /* quad_perm [1,0,3,2] */
+#define SEG_DPP_XOR2 0x4E          /* quad_perm [2,3,0,1] */
+#define SEG_DPP_HMIRROR 0x141      /* row_half_mirror: lane i <-> 7 - i inside every group of eight */
+#define SEG_DPP_SHR1 0x111         /* row_shr:1: lane i reads lane i - 1 (lane 0 of a row keeps its own) */
+
+// the tokens of a boundary mask, by a whole wave: the lane of a set bit j looks up its own span [jp, j + 1) (band entry, or the
+// triangular table for a span longer than the window); spans without an embedding are skipped.  Returns their number.
+__device__ __forceinline__ int seg_old_tokens_wave(const int32_t *bid, const int32_t *vid, int N, int W, unsigned long long oldb,
+                                                   int32_t *l_old, int lane)
+{
+    const bool bit = lane < N && ((oldb >> lane) & 1ull);
+    const unsigned long long below = oldb & ((1ull << lane) - 1ull);
+    const int jp = below ? 64 - __clzll((long long)below) : 0;
+    int id = -1;
+    if (bit) {
+        const int t = lane + 1, w = lane - jp;
+        id = w < W ? bid[(t - 1) * W + w] : vid[t * (t - 1) / 2 + jp];
+    }
+    const unsigned long long keep = __ballot(bit && id >= 0);
+    if (bit && id >= 0) l_old[__popcll(keep & ((1ull << lane) - 1ull))] = id;
+    return __popcll(keep);
+}
+
+__device__ __forceinline__ void seg_w8_wave(const double *bvec, double *gam, const int32_t *bid, const int32_t *bk, const int32_t *vid,
+                                            int N, int W, unsigned long long oldb, int Kact, int32_t *l_old, int32_t *l_new,
+                                            int32_t *l_newk, int32_t *l_cnt, double *total_out, int lane)
+{
+    // ---- old tokens (utterances.py:159-174)
+    {
+        const int no = seg_old_tokens_wave(bid, vid, N, W, oldb, l_old, lane);
+        if (lane == 0) l_cnt[0] = no;
+    }
+    // ---- A8 forward (kmeans_acoustic_wordseg.py:494-506): lane w holds g = gamma[t - 1 - w]
+    double g = lane == 0 ? 0.0 : NEG_INF_D;
+    if (lane == 0) gam[0] = 0.0;
+    double vn = bvec[0];                                           // step 1 has one candidate, entry (1, 0); the entries of step t + 1 are fetched during step t
+    for (int t = 1; t < N; t++) {
+        const bool ok = lane < W && t - 1 - lane >= 0;
+        const double v = vn;
+        {
+            const bool okn = lane < W && t - lane >= 0 && t + 1 < N;
+            vn = bvec[okn ? t * W + lane : 0];
+        }
+        double x = ok ? v + g : NEG_INF_D;
+        x = fmax(x, seg_dpp_f64<SEG_DPP_XOR1>(x));
+        x = fmax(x, seg_dpp_f64<SEG_DPP_XOR2>(x));
+        x = fmax(x, seg_dpp_f64<SEG_DPP_HMIRROR>(x));                // lanes 0..7 hold the maximum
+        if (lane == 0) gam[t] = x;
+        g = seg_dpp_f64<SEG_DPP_SHR1>(g);
+        if (lane == 0) g = x;
+    }
+    WAVE_SYNC();
+    unsigned long long newb = 1ull << (N - 1);
+    // candidates of span end tt: are they all -inf; and the reversed np.argmax (shortest span on ties)
+    auto eval = [&](int tt, int &kb) -> bool {
+        const bool ok = lane < W && tt - 1 - lane >= 0;
+        double x = ok ? bvec[(tt - 1) * W + lane] + gam[tt - 1 - lane] : NEG_INF_D;
+        const unsigned long long fin = __ballot(ok && x != NEG_INF_D);
+        int w = ok ? lane : 99;
+#define SEG_ARGMAX_STEP(CTRL)                                                    \
+        do {                                                                     \
+            const double xo_ = seg_dpp_f64<CTRL>(x);                             \
+            const int wo_ = seg_dpp_i32<CTRL>(w);                                \
+            if (xo_ > x || (xo_ == x && wo_ < w)) { x = xo_; w = wo_; }          \
+        } while (0)
+        SEG_ARGMAX_STEP(SEG_DPP_XOR1);
+        SEG_ARGMAX_STEP(SEG_DPP_XOR2);
+        SEG_ARGMAX_STEP(SEG_DPP_HMIRROR);
+#undef SEG_ARGMAX_STEP
+        kb = __builtin_amdgcn_readfirstlane(w) + 1;
+        return (fin & 0xFFull) == 0ull;
+    };
+    // ---- A8 backward (:510-553)
+    int t = N;
+    double total = 0.0;
+    for (;;) {
+        int kb = 1;
+        bool all_inf = eval(t, kb);
+        if (all_inf) {                                 // step back until some candidate is finite (:516-530)
+            while (all_inf) {
+                t = t - 1;
+                if (t == 0) break;
+                all_inf = eval(t, kb);
+            }
+            newb |= 1ull << ((t - 1 + N) % N);
+        }
+        int k = 1;
+        if (t > 0) {
+            k = kb;
+            total += bvec[(t - 1) * W + (k - 1)];
+        } else {
+            total += bvec[(N - 1) * W];                // python vec[-1]: the last span [N-1, N)
+        }
+        if (t - k - 1 < 0) break;
+        newb |= 1ull << (t - k - 1);
+        t = t - k;
+    }
+    // ---- new tokens + their best components (:312-313)
+    {
+        const bool bit = lane < N && ((newb >> lane) & 1ull);
+        const unsigned long long below = newb & ((1ull << lane) - 1ull);
+        const int jp = below ? 64 - __clzll((long long)below) : 0;
+        const int w = lane - jp;
+        int id = -1, kk = -1;
+        if (bit && w < W) {
+            id = bid[lane * W + w];
+            kk = bk[lane * W + w];
+        }
+        const bool valid = bit && id >= 0;
+        const unsigned long long keep = __ballot(valid), badm = __ballot(bit && !valid), fl = __ballot(valid && kk >= Kact);
+        if (valid) {
+            const int r = __popcll(keep & ((1ull << lane) - 1ull));
+            l_new[r] = id;
+            l_newk[r] = kk;
+        }
+        if (lane == 0) {
+            l_cnt[1] = __popcll(keep);
+            l_cnt[2] = (int32_t)(newb & 0xffffffffull);
+            l_cnt[3] = (int32_t)(newb >> 32);
+            l_cnt[4] = __popcll(fl);
+            l_cnt[5] = badm != 0ull;
+        }
+    }
+    *total_out = total;
+}

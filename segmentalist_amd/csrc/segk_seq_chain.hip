@@ -1,0 +1,590 @@
+// segk_seq_chain.hip -- the reference's sequential k-means chain (segment_i for one utterance after the other,
+// kmeans_acoustic_wordseg.py:225-332, 393-399) as ONE persistent kernel
+// (one of the translation units of the k-means path; shared helpers: segk_kmeans_dev.h, segk_segment_dev.h)
+//
+// The three-launch form (k_seq_score -> k_kmeans_segment_w8 -> k_seq_update per utterance) costs 52 us per utterance:
+// three kernel boundaries and a dozen dependent memory round trips, every one of them paid 10 000 times per sweep because
+// utterance i + 1 needs the means utterance i leaves behind.  Here G workgroups stay resident for the whole sweep and meet
+// at ONE grid barrier per utterance:
+//
+//   * owner computes: workgroup g owns the components [g * cpw, (g + 1) * cpw) -- their means, numerators and counts live
+//     in its LDS for the whole sweep (written through to memory, never read back);
+//   * phase A: every workgroup stages the utterance's candidate rows (banded table) and scores them against ITS components
+//     in the reference's arithmetic (neg_sqd_exact), one 64-bit atomic maximum of (score, ~component) per span;
+//   * grid barrier (an atomic counter; spins are bounded and end in an error, never in a hang);
+//   * phase B, replicated: EVERY workgroup reads the spans' maxima and runs the same DP (seg_w8_serial) on the same
+//     inputs, so every workgroup knows the utterance's old and new tokens without another exchange; each applies the
+//     del_item / add_item sequence (kmeans_components.py:93-132, the `k > K -> K` clamp included) to the components it owns,
+//     in the reference's order, from the rows it staged in phase A.  Labels and boundaries are written by every workgroup
+//     (the same values: whichever L2 a later read hits holds them).
+//
+// Nothing but atomics crosses workgroups inside the kernel (maxima, barrier counter, stop flag), so no cache maintenance is
+// needed between the XCDs' L2s.  clean_components (:263-266) moves rows between owners and relabels the whole assignment
+// vector: when a component empties, its owner raises the stop flag, every workgroup leaves after the utterance, the host
+// runs the ordinary clean kernel and relaunches from the next utterance (a handful of times per sweep once the model has
+// settled; 124 times in the first sweep of the bench corpus).
+#include "segk_kmeans_dev.h"
+#include "segk_segment_dev.h"
+
+#define CH_THREADS 1024
+#define CH_MAXOPS 64              /* old + new tokens of an utterance (N_max <= 32) */
+#define CH_SPIN_LIMIT (1 << 22)
+
+struct ChainArgs {
+    segk_corpus c;
+    segk_kmeans m;
+    const int32_t *order;         // [dev] utterances of the sweep
+    int q0, q1;                   // this launch walks order[q0 .. q1)
+    int n_max;                    // n_slices_max (1..8)
+    double wip;
+    unsigned long long *keys;     // [2][G][nb_cap] the workgroups' span maxima (score, ~component), by utterance parity
+    int32_t *ctl;                 // [0] barrier counter, [1] stop flag, [2] utterances completed, [3] error
+    uint8_t *boundaries;
+    int32_t *old_tok, *new_tok, *new_k, *n_old, *n_new, *n_flag;
+    double *out_total;
+    int32_t *status;
+    int cpw;                      // components per workgroup
+    int nb_cap;                   // N_max * W: band entries per utterance
+    int ldm;                      // floats per staged component row
+    unsigned long long *stamp;    // development (SEGK_CHAIN_STAMP=1): wall_clock64 at the phase boundaries of workgroup 0, 8 per utterance
+};
+#define CH_STAMP(slot)                                                                                   \
+    do {                                                                                                 \
+        if (A.stamp && blockIdx.x == 0 && tid == 0 && q - A.q0 < 256) A.stamp[(q - A.q0) * 8 + (slot)] = wall_clock64(); \
+    } while (0)
+
+// Grid barrier number `phase` (1, 2, ...): false when the spin limit was hit or another workgroup reported an error.  One
+// word carries the arrivals (low 30 bits) and the stop flag (bit 30), so that a workgroup learns both from one atomic: the
+// last one to arrive from its own fetch-add, the others from the value they poll.  (Separate words cost every workgroup
+// three dependent device-scope round trips per utterance: 5.9 us measured for the LAST arriver.)
+#define CH_STOP_BIT (1 << 30)
+__device__ __forceinline__ bool chain_barrier(int32_t *ctl, int phase, int *sh_flag)
+{
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // this wave's stores have been performed
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int target = phase * (int)gridDim.x;
+        int seen = __hip_atomic_fetch_add(&ctl[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+        int spins = 0, ok = 1;
+        while ((seen & (CH_STOP_BIT - 1)) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            seen = __hip_atomic_load(&ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (++spins > CH_SPIN_LIMIT || ((spins & 1023) == 0 && __hip_atomic_load(&ctl[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                __hip_atomic_fetch_or(&ctl[3], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = 0;
+                break;
+            }
+        }
+        // bit 0: passed; bit 1: a component emptied during the previous utterance
+        *sh_flag = ok | ((seen & CH_STOP_BIT) ? 2 : 0);
+    }
+    __syncthreads();
+    return (*sh_flag & 1) != 0;
+}
+
+// what phase A needs of one utterance, staged ahead (two sets: the next utterance's is filled while wave 0 runs the DP)
+struct ChainSet {
+    float *xs, *xo;                                   // [NBC][LDX] candidate rows by band entry, [NM][LDX] rows of the old tokens
+    double *bdur;                                     // [NBC]
+    int32_t *bid, *basg, *o_e, *o_a;                  // [NBC] row of the entry, its label before the utterance (workgroup 0); [NM] old tokens, their labels
+    int32_t *meta;                                    // [8]: u, N, W, nb, old mask (2 words), number of old tokens, band flag
+};
+
+__global__ __launch_bounds__(CH_THREADS) void k_seq_chain(ChainArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char ch_lds[];
+    const segk_corpus &c = A.c;
+    const segk_kmeans &m = A.m;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int D = c.D, D4 = D >> 2, LDM = A.ldm, LDX = D, NBC = A.nb_cap, CPW = A.cpw, NM = c.N_max;
+    const int k0 = blockIdx.x * CPW;
+    const int kn = k0 + CPW <= m.K_max ? CPW : (m.K_max > k0 ? m.K_max - k0 : 0);      // components this workgroup owns
+    const float *X = (const float *)c.X;
+    float *means_g = (float *)m.means;
+    const int64_t triMax = (int64_t)NM * (NM + 1) / 2;
+
+    // ---- LDS (the size is worked out in the same order by segk_launch_seq_chain)
+    unsigned char *lp = ch_lds;
+    auto take = [&](size_t bytes) { unsigned char *r = lp; lp += (bytes + 15) & ~(size_t)15; return r; };
+    double *numer_l = reinterpret_cast<double *>(take((size_t)CPW * D * 8));            // [CPW][D]
+    double *bvec = reinterpret_cast<double *>(take((size_t)NBC * 8));                   // [NBC]
+    double *gam = reinterpret_cast<double *>(take((size_t)(NM + 1) * 8));               // [NM + 1]
+    long long *cnt_l = reinterpret_cast<long long *>(take((size_t)CPW * 8));            // [CPW]
+    long long *op_cnt = reinterpret_cast<long long *>(take((size_t)CH_MAXOPS * 8));     // [CH_MAXOPS] count of its component after the item
+    float *means_l = reinterpret_cast<float *>(take((size_t)CPW * LDM * 4));            // [CPW][LDM]
+    int32_t *bk = reinterpret_cast<int32_t *>(take((size_t)NBC * 4));                   // [NBC]
+    int32_t *l_old = reinterpret_cast<int32_t *>(take((size_t)NM * 4));                 // [NM]
+    int32_t *l_new = reinterpret_cast<int32_t *>(take((size_t)NM * 4));                 // [NM]
+    int32_t *l_newk = reinterpret_cast<int32_t *>(take((size_t)NM * 4));                // [NM]
+    int32_t *l_cnt = reinterpret_cast<int32_t *>(take(8 * 4));                          // [8]
+    int32_t *op_e = reinterpret_cast<int32_t *>(take(CH_MAXOPS * 4));                   // [CH_MAXOPS] item
+    int32_t *op_k = reinterpret_cast<int32_t *>(take(CH_MAXOPS * 4));                   // [CH_MAXOPS] component (-1: nothing to do)
+    int32_t *op_x = reinterpret_cast<int32_t *>(take(CH_MAXOPS * 4));                   // [CH_MAXOPS] its row: xo index (old), band entry (new)
+    unsigned long long *kred = reinterpret_cast<unsigned long long *>(take(8 * 128 * 8));    // [8][128] partial maxima of a pass
+    unsigned long long *kfin = reinterpret_cast<unsigned long long *>(take((size_t)NBC * 8)); // [NBC] the spans' maxima
+    ChainSet S[2];
+    for (int z = 0; z < 2; z++) {
+        S[z].xs = reinterpret_cast<float *>(take((size_t)NBC * LDX * 4));
+        S[z].xo = reinterpret_cast<float *>(take((size_t)NM * LDX * 4));
+        S[z].bdur = reinterpret_cast<double *>(take((size_t)NBC * 8));
+        S[z].bid = reinterpret_cast<int32_t *>(take((size_t)NBC * 4));
+        S[z].basg = reinterpret_cast<int32_t *>(take((size_t)NBC * 4));
+        S[z].o_e = reinterpret_cast<int32_t *>(take((size_t)NM * 4));
+        S[z].o_a = reinterpret_cast<int32_t *>(take((size_t)NM * 4));
+        S[z].meta = reinterpret_cast<int32_t *>(take(8 * 4));
+    }
+    __shared__ int sh_flag, sh_K, sh_empty;
+
+    // Everything phase A needs of utterance order[qn] into set `st` -- none of it depends on the utterances before it.
+    // Wave `w_old` (all its 64 lanes) lists the old tokens; the threads t0 <= tid < t0 + nth fetch the candidates.  No
+    // barrier inside: every thread works from global memory alone (the band table is read again for the rows).
+    auto stage = [&](int u, int N, const ChainSet &st, int w_old, int t0, int nth) {
+        const int W = (A.n_max > 0 && A.n_max < N) ? A.n_max : N;            // <= 8
+        const int nb = N * W;
+        const int32_t *vid = c.vec_ids + (int64_t)u * triMax;
+        const double *dur = c.durations + (int64_t)u * triMax;
+        const bool band = c.band_ids != nullptr && c.band_W == W && W > 0;
+        const int32_t *bandi = band ? c.band_ids + (int64_t)u * NM * c.band_W : nullptr;
+        const double *bandd = band ? c.band_dur + (int64_t)u * NM * c.band_W : nullptr;
+        auto entry_id = [&](int i) -> int {
+            const int t = i / W + 1, w = i % W, s0 = t - 1 - w;
+            if (s0 < 0) return -1;
+            return band ? bandi[i] : vid[t * (t - 1) / 2 + s0];
+        };
+        if (wv == w_old) {
+            const uint8_t *gbnd = A.boundaries + (int64_t)u * NM;
+            // the lane of a set bit j looks up its own span [jp, j + 1) (utterances.py:159-174); the W entries of its row
+            // are fetched beside the boundary flags, not after them
+            int ent[8];
+#pragma unroll
+            for (int w = 0; w < 8; w++) ent[w] = (lane < N && w < W) ? entry_id(lane * W + w) : -1;
+            const unsigned long long oldb = __ballot(lane < N && gbnd[lane < N ? lane : 0] != 0);
+            const bool bit = lane < N && ((oldb >> lane) & 1ull);
+            const unsigned long long below = oldb & ((1ull << lane) - 1ull);
+            const int jp = below ? 64 - __clzll((long long)below) : 0;
+            int id = -1;
+            if (bit) {
+                const int t = lane + 1, w = lane - jp;
+                if (w < W) {
+#pragma unroll
+                    for (int z = 0; z < 8; z++)
+                        if (z == w) id = ent[z];
+                } else {
+                    id = vid[t * (t - 1) / 2 + jp];
+                }
+            }
+            const unsigned long long keep = __ballot(bit && id >= 0);
+            const int no = __popcll(keep), r = __popcll(keep & ((1ull << lane) - 1ull));
+            if (bit && id >= 0) {
+                st.o_e[r] = id;
+                st.o_a[r] = m.assignments[id];
+            }
+            WAVE_SYNC();
+            // their rows, 16 bytes per lane and step
+            for (int p = lane; p < no * D4; p += 64) {
+                const int i = p / D4, d4 = p - i * D4;
+                *reinterpret_cast<float4 *>(st.xo + i * LDX + 4 * d4) = *reinterpret_cast<const float4 *>(X + (int64_t)st.o_e[i] * c.ldx + 4 * d4);
+            }
+            if (lane == 0) {
+                st.meta[0] = u; st.meta[1] = N; st.meta[2] = W; st.meta[3] = nb;
+                st.meta[4] = (int32_t)(oldb & 0xffffffffull); st.meta[5] = (int32_t)(oldb >> 32);
+                st.meta[6] = no; st.meta[7] = band ? 1 : 0;
+            }
+        }
+        const int tt = tid - t0;
+        if (tt < 0 || tt >= nth) return;
+        for (int i = tt; i < nb; i += nth) {
+            const int id = entry_id(i);
+            double dd = __builtin_nan("");
+            if (id >= 0) {
+                const int t = i / W + 1, w = i % W;
+                dd = band ? bandd[i] : dur[t * (t - 1) / 2 + (t - 1 - w)];
+            }
+            st.bid[i] = id;
+            st.bdur[i] = dd;
+            // add_item's assert (:101) wants the row's label BEFORE this utterance: read ahead of the barrier -- once the
+            // first workgroup is through its phase B the labels in memory are the new ones
+            if (blockIdx.x == 0) st.basg[i] = id >= 0 ? m.assignments[id] : -1;
+        }
+        // the candidate rows, by band entry: consecutive threads on consecutive 16 bytes, four loads in flight per thread
+        const int tot = nb * D4;
+        for (int p0 = tt; p0 < tot; p0 += 4 * nth) {
+            int ids[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int p = p0 + r * nth;
+                ids[r] = entry_id((p < tot ? p : 0) / D4);
+            }
+            float4 v[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int p = p0 + r * nth, pp = p < tot ? p : 0;
+                const int d4 = pp % D4;
+                v[r] = *reinterpret_cast<const float4 *>(X + (int64_t)(ids[r] >= 0 ? ids[r] : 0) * c.ldx + 4 * d4);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int p = p0 + r * nth;
+                if (p < tot) *reinterpret_cast<float4 *>(st.xs + (p / D4) * LDX + 4 * (p % D4)) = v[r];
+            }
+        }
+    };
+
+    // ---- this workgroup's components: float32 means (the score operand), float64 numerators, counts
+    for (int q = tid; q < kn * D4; q += CH_THREADS) {
+        const int ci = q / D4, d4 = q - ci * D4;
+        *reinterpret_cast<float4 *>(means_l + ci * LDM + 4 * d4) = *reinterpret_cast<const float4 *>(means_g + (int64_t)(k0 + ci) * D + 4 * d4);
+    }
+    for (int q = tid; q < kn * D; q += CH_THREADS) numer_l[q] = m.mean_numerators[(int64_t)k0 * D + q];
+    if (tid < kn) cnt_l[tid] = m.counts[k0 + tid];
+    if (tid == 0) sh_K = *m.K;
+    // the utterance numbers and lengths run two and one utterance ahead of the staging, so that it starts with the tables
+    int u1 = -1, u2 = -1, N1 = 0;
+    if (A.q0 < A.q1) {
+        const int u0 = A.order[A.q0];
+        stage(u0, c.lengths[u0], S[0], 0, 0, CH_THREADS);
+        if (A.q0 + 1 < A.q1) u1 = A.order[A.q0 + 1];
+    }
+    __syncthreads();
+
+    int phase = 0;
+    int q = A.q0;
+    for (; q < A.q1; q++) {
+        if (q + 2 < A.q1) u2 = A.order[q + 2];
+        if (q + 1 < A.q1) N1 = c.lengths[u1];
+        const ChainSet &C = S[(q - A.q0) & 1];
+        const int u = C.meta[0], N = C.meta[1], W = C.meta[2], nb = C.meta[3];
+        const unsigned long long oldb = ((unsigned long long)(unsigned int)C.meta[5] << 32) | (unsigned int)C.meta[4];
+        const int32_t *vid = c.vec_ids + (int64_t)u * triMax;
+        const int32_t *bid = C.bid;
+        const float *xs = C.xs, *xo = C.xo;
+        uint8_t *gbnd = A.boundaries + (int64_t)u * NM;
+        unsigned long long *keys_all = A.keys + (size_t)(q & 1) * gridDim.x * NBC;      // [G][NBC]
+        unsigned long long *keys = keys_all + (size_t)blockIdx.x * NBC;
+        CH_STAMP(0);
+        CH_STAMP(1);
+
+        // ================================ phase A: this workgroup's share of the scores, the components of a span on CPW
+        // adjacent lanes
+        for (int p0 = 0; p0 < nb * CPW; p0 += CH_THREADS) {
+            const int p = p0 + tid, i = p / CPW, ci = p - i * CPW;
+            unsigned long long key = 0ull;
+            if (i < nb && ci < kn && bid[i] >= 0) {
+                const float sc = neg_sqd_exact_v4_pk(means_l + ci * LDM, xs + i * LDX, D);
+                const unsigned int bits = __float_as_uint(sc);
+                const unsigned int ord = (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);
+                key = ((unsigned long long)ord << 32) | (unsigned long long)(0xffffffffu - (unsigned int)(k0 + ci));
+            }
+            for (int o = 1; o < CPW; o <<= 1) {
+                const unsigned long long other = __shfl_xor(key, o);
+                key = other > key ? other : key;
+            }
+            // one write-through store per span and workgroup (an atomic maximum per span instead -- 13 000 of them on seven
+            // cache lines per utterance -- kept every workgroup ~6 us at the barrier waiting for its own atomics)
+            if (ci == 0 && i < nb) __hip_atomic_store(&keys[i], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        CH_STAMP(2);
+        if (A.stamp && tid == 0 && q - A.q0 >= 100 && q - A.q0 < 104) A.stamp[2048 + (q - A.q0 - 100) * 256 + blockIdx.x] = wall_clock64();
+        phase++;
+        if (!chain_barrier(A.ctl, phase, &sh_flag)) return;
+        CH_STAMP(3);
+        if (sh_flag & 2) break;            // a component emptied during the previous utterance: clean_components on the host's side
+        // every workgroup reduces the G partial maxima of every span: 128 spans x 8 groups of workgroups per pass
+        for (int i0 = 0; i0 < nb; i0 += 128) {
+            const int i = i0 + (tid & 127), grp = tid >> 7;
+            unsigned long long key = 0ull;
+            if (i < nb && bid[i] >= 0) {
+                for (int g0 = grp; g0 < (int)gridDim.x; g0 += 32) {
+                    unsigned long long kv[4];
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int g = g0 + 8 * r;
+                        kv[r] = g < (int)gridDim.x ? __hip_atomic_load(&keys_all[(size_t)g * NBC + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; r++) key = kv[r] > key ? kv[r] : key;
+                }
+            }
+            kred[grp * 128 + (tid & 127)] = key;
+            __syncthreads();
+            if (tid < 128 && i0 + tid < nb) {
+                unsigned long long kk = kred[tid];
+#pragma unroll
+                for (int r = 1; r < 8; r++) kk = kred[r * 128 + tid] > kk ? kred[r * 128 + tid] : kk;
+                kfin[i0 + tid] = kk;
+            }
+            __syncthreads();
+        }
+        // ================================ phase B, the same in every workgroup: wave 0 runs the DP, the other waves fetch the
+        // next utterance
+        if (wv == 0) {
+            for (int i = lane; i < nb; i += 64) {
+                double v = NEG_INF_D;
+                int k = -1;
+                if (bid[i] >= 0) {
+                    const unsigned long long key = kfin[i];
+                    const unsigned int ord = (unsigned int)(key >> 32);
+                    const unsigned int bits = (ord & 0x80000000u) ? (ord & 0x7fffffffu) : ~ord;
+                    k = (int32_t)(0xffffffffu - (unsigned int)(key & 0xffffffffu));
+                    const double dd = C.bdur[i];
+                    v = isnan(dd) ? NEG_INF_D : (double)__uint_as_float(bits) * dd;       // :346-349
+                }
+                bk[i] = k;
+                bvec[i] = v + A.wip;                                                   // :351
+            }
+            WAVE_SYNC();
+            CH_STAMP(4);
+            double total;
+            seg_w8_wave(bvec, gam, bid, bk, vid, N, W, oldb, sh_K, l_old, l_new, l_newk, l_cnt, &total, lane);
+            WAVE_SYNC();
+            if (A.stamp && blockIdx.x == 0 && lane == 0 && q - A.q0 < 256) A.stamp[(q - A.q0) * 8 + 7] = wall_clock64();
+            // the operations of the utterance in the reference's order: del_item of the old tokens, add_item of the new ones;
+            // lane 0 replays the clamp of add_item (:102-106) on K
+            const int no = l_cnt[0], nn = l_cnt[1];
+            if (lane < no) { op_e[lane] = l_old[lane]; op_k[lane] = C.o_a[lane]; op_x[lane] = lane; }
+            {
+                const unsigned long long newb = ((unsigned long long)(unsigned int)l_cnt[3] << 32) | (unsigned int)l_cnt[2];
+                const bool bit = lane < N && ((newb >> lane) & 1ull);
+                const unsigned long long below = newb & ((1ull << lane) - 1ull);
+                const int jp = below ? 64 - __clzll((long long)below) : 0;
+                const int w = lane - jp;
+                const bool valid = bit && w < W && bid[lane * W + (w < W ? w : 0)] >= 0;
+                const unsigned long long keep = __ballot(valid);
+                if (valid) {
+                    const int r = __popcll(keep & ((1ull << lane) - 1ull));
+                    op_e[no + r] = l_new[r];
+                    op_x[no + r] = lane * W + w;
+                }
+            }
+            if (lane == 0) {
+                if (blockIdx.x == 0) {
+                    A.out_total[u] = total;
+                    A.n_old[u] = no;
+                    A.n_new[u] = nn;
+                    if (A.n_flag) A.n_flag[u] = l_cnt[4];
+                    if (l_cnt[5]) atomicOr(A.status, 1);
+                }
+                int K = sh_K;
+                for (int t2 = 0; t2 < nn; t2++) {
+                    int k = l_newk[t2];
+                    if (k > K) k = K;
+                    if (k == K) K++;
+                    op_k[no + t2] = k;
+                    l_newk[t2] = k;
+                }
+                sh_K = K;
+                sh_empty = 0;
+            }
+        } else if (q + 1 < A.q1) {
+            stage(u1, N1, S[(q + 1 - A.q0) & 1], 1, 128, CH_THREADS - 128);
+        }
+        u1 = u2;
+        __syncthreads();
+        CH_STAMP(5);
+        const int no = l_cnt[0], nn = l_cnt[1], nops = no + nn;
+        // add_item's assert (:101): the row must be unassigned -- by an earlier item of this utterance, else by the state before it
+        if (blockIdx.x == 0 && tid >= no && tid < nops) {
+            int prev = -1;
+            for (int p2 = 0; p2 < tid; p2++)
+                if (op_e[p2] == op_e[tid]) prev = p2;
+            const int cur = prev >= 0 ? (prev < no ? -1 : op_k[prev]) : C.basg[op_x[tid]];
+            if (cur != -1) atomicOr(A.status, 2);
+        }
+        // the count of its component after every item, for the components this workgroup owns
+        if (tid < nops) {
+            const int k = op_k[tid], ci = k - k0;
+            long long cn = 0;
+            if (k >= 0 && ci >= 0 && ci < kn) {
+                cn = cnt_l[ci];
+                for (int p2 = 0; p2 <= tid; p2++)
+                    if (op_k[p2] == k) cn += p2 < no ? -1 : 1;
+            }
+            op_cnt[tid] = cn;
+        }
+        __syncthreads();
+        // the items in the reference's order; thread d owns dimension d of every component of this workgroup (:110, :128-129)
+        for (int d = tid; d < D; d += CH_THREADS)
+            for (int o = 0; o < nops; o++) {
+                const int k = op_k[o], ci = k - k0;
+                if (k < 0 || ci < 0 || ci >= kn) continue;
+                const double x = (double)(o < no ? xo[op_x[o] * LDX + d] : xs[op_x[o] * LDX + d]);
+                const double v = o < no ? numer_l[ci * D + d] - x : numer_l[ci * D + d] + x;
+                numer_l[ci * D + d] = v;
+                const long long cnt = op_cnt[o];
+                if (cnt != 0) means_l[ci * LDM + d] = (float)(v / (double)cnt);
+            }
+        __syncthreads();
+        // write through: the touched rows of this workgroup (the last item of a component writes them), labels, boundaries
+        if (tid < nops) {
+            const int k = op_k[tid], ci = k - k0;
+            bool last_k = k >= 0 && ci >= 0 && ci < kn, last_e = true;
+            for (int p2 = tid + 1; p2 < nops; p2++) {
+                if (op_k[p2] == k) last_k = false;
+                if (op_e[p2] == op_e[tid]) last_e = false;
+            }
+            if (last_k) {
+                cnt_l[ci] = op_cnt[tid];
+                m.counts[k] = op_cnt[tid];
+                if (op_cnt[tid] == 0 && k < sh_K) sh_empty = 1;
+            }
+            op_x[tid] = last_k ? ci : -1;                                        // (op_x is not needed any more)
+            if (last_e) m.assignments[op_e[tid]] = tid < no ? -1 : op_k[tid];
+        }
+        if (tid < N) {
+            const unsigned long long newb = ((unsigned long long)(unsigned int)l_cnt[3] << 32) | (unsigned int)l_cnt[2];
+            gbnd[tid] = (uint8_t)((newb >> tid) & 1ull);
+        }
+        if (blockIdx.x == 0) {
+            for (int j = tid; j < no; j += CH_THREADS) A.old_tok[(int64_t)u * NM + j] = l_old[j];
+            for (int j = tid; j < NM; j += CH_THREADS) {
+                if (j < nn) A.new_tok[(int64_t)u * NM + j] = l_new[j];
+                A.new_k[(int64_t)u * NM + j] = j < nn ? l_newk[j] : -1;
+            }
+        }
+        __syncthreads();
+        for (int o = 0; o < nops; o++) {
+            const int ci = op_x[o];
+            if (ci < 0) continue;
+            const int k = k0 + ci;
+            for (int d = tid; d < D; d += CH_THREADS) {
+                m.mean_numerators[(int64_t)k * D + d] = numer_l[ci * D + d];
+                means_g[(int64_t)k * D + d] = means_l[ci * LDM + d];             // (unchanged when every count on the way was 0)
+            }
+        }
+        if (tid == 0 && sh_empty) {
+            __hip_atomic_fetch_or(&A.ctl[0], CH_STOP_BIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&A.ctl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // for the host
+        }
+        __syncthreads();
+        CH_STAMP(6);
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+        A.ctl[2] = q;                    // utterances order[q0 .. q) are done
+        *m.K = sh_K;
+    }
+}
+
+// One sweep over order[0 .. n_order) (host array): launches of the persistent kernel, a clean_components launch whenever one
+// of them stopped because a component emptied.  Returns SEGK_ERR_UNSUPPORTED (nothing enqueued) when the configuration is
+// outside the kernel's reach.
+int segk_launch_seq_chain(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m, const int32_t *order, int n_order, int n_slices_max,
+                          double wip, uint8_t *boundaries, int32_t *old_tok, int32_t *new_tok, int32_t *new_k, int32_t *n_old,
+                          int32_t *n_new, int32_t *n_flag, double *out_total, int32_t *status, hipStream_t st)
+{
+    if (c->x_dtype != SEGK_F32 || (c->D & 3) || c->D < 8 || c->D > 128 || (c->ldx & 3) || c->N_max > 32 || n_slices_max < 1 ||
+        n_slices_max > 8 || m->K_max < 1 || c->N_max < 1)
+        return SEGK_ERR_UNSUPPORTED;
+    const int W = n_slices_max < c->N_max ? n_slices_max : c->N_max;
+    const int nbc = c->N_max * W;
+    // components per workgroup: 8 from K_max = 512 on (125 workgroups for the headline model: measured 22.1 us per utterance
+    // against 23.9 with 16 and 27.6 with 32 -- the score phase is bound by LDS bandwidth, 800 bytes per (span, component))
+    int G = ctx->n_cu / 2;
+    if (G < 1) G = 1;
+    int cpw = (m->K_max + G - 1) / G;
+    int cp2 = 1;
+    while (cp2 < cpw) cp2 <<= 1;                            // the components of a span sit on a power-of-two group of lanes
+    cpw = cp2 < 8 ? 8 : cp2;
+    if (const char *ce = getenv("SEGK_CHAIN_CPW")) {        // development: 4, 8, 16, 32 components per workgroup
+        const int v = atoi(ce);
+        if (v == 4 || v == 8 || v == 16 || v == 32 || v == 64) cpw = v;
+    }
+    if (cpw > 64) return SEGK_ERR_UNSUPPORTED;
+    G = (m->K_max + cpw - 1) / cpw;
+    const int D = c->D, ldm = ((D >> 2) & 1) ? D : D + 4;
+    auto al = [](size_t b) { return (b + 15) & ~(size_t)15; };
+    const size_t NM = (size_t)c->N_max;
+    const size_t set_bytes = al((size_t)nbc * D * 4) + al(NM * D * 4) + al((size_t)nbc * 8) + 2 * al((size_t)nbc * 4) + 2 * al(NM * 4) + al(8 * 4);
+    const size_t lds = al((size_t)cpw * D * 8) + al((size_t)nbc * 8) + al((NM + 1) * 8) + al((size_t)cpw * 8) + al(CH_MAXOPS * 8) +
+                       al((size_t)cpw * ldm * 4) + al((size_t)nbc * 4) + 3 * al(NM * 4) + al(8 * 4) + 3 * al(CH_MAXOPS * 4) + al(8 * 128 * 8) +
+                       al((size_t)nbc * 8) + 2 * set_bytes;
+    if (lds > 158 * 1024) return SEGK_ERR_UNSUPPORTED;
+    static size_t lds_set = 0;
+    if (lds > 48 * 1024 && lds > lds_set) {
+        SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_seq_chain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        lds_set = lds;
+    }
+    // all workgroups must be resident together: one per CU at most
+    if (G > ctx->n_cu || (int64_t)G * (n_order + 1) >= CH_STOP_BIT) return SEGK_ERR_UNSUPPORTED;
+
+    const size_t key_bytes = 2 * (size_t)G * nbc * sizeof(unsigned long long), ctl_bytes = 8 * sizeof(int32_t);
+    const size_t need = key_bytes + ctl_bytes + (size_t)n_order * sizeof(int32_t);
+    if (ctx->chain_bytes < need) {
+        if (ctx->chain_buf) (void)hipFree(ctx->chain_buf);
+        ctx->chain_buf = nullptr;
+        ctx->chain_bytes = 0;
+        SEGK_CHECK_HIP(hipMalloc(&ctx->chain_buf, need));
+        ctx->chain_bytes = need;
+    }
+    unsigned char *buf = (unsigned char *)ctx->chain_buf;
+    ChainArgs A{};
+    A.c = *c; A.m = *m;
+    A.keys = (unsigned long long *)buf;
+    A.ctl = (int32_t *)(buf + key_bytes);
+    A.order = (const int32_t *)(buf + key_bytes + ctl_bytes);
+    A.n_max = n_slices_max; A.wip = wip;
+    A.boundaries = boundaries; A.old_tok = old_tok; A.new_tok = new_tok; A.new_k = new_k; A.n_old = n_old; A.n_new = n_new;
+    A.n_flag = n_flag; A.out_total = out_total; A.status = status;
+    A.cpw = cpw; A.nb_cap = nbc; A.ldm = ldm;
+    SEGK_CHECK_HIP(hipMemcpyAsync((void *)A.order, order, (size_t)n_order * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    const bool stamping = getenv("SEGK_CHAIN_STAMP") && atoi(getenv("SEGK_CHAIN_STAMP"));
+    static unsigned long long *stamp_dev = nullptr;
+    if (stamping && !stamp_dev) SEGK_CHECK_HIP(hipMalloc((void **)&stamp_dev, (256 * 8 + 4 * 256) * sizeof(unsigned long long)));
+    A.stamp = stamping ? stamp_dev : nullptr;
+    int q = 0;
+    while (q < n_order) {
+        SEGK_CHECK_HIP(hipMemsetAsync(buf + key_bytes, 0, ctl_bytes, st));
+        A.q0 = q; A.q1 = n_order;
+        hipLaunchKernelGGL(k_seq_chain, dim3(G), dim3(CH_THREADS), lds, st, A);
+        SEGK_LAUNCH_CHECK();
+        int32_t ctl[8];
+        SEGK_CHECK_HIP(hipMemcpyAsync(ctl, A.ctl, sizeof(ctl), hipMemcpyDeviceToHost, st));
+        SEGK_CHECK_HIP(hipStreamSynchronize(st));
+        if (ctl[3] != 0) {
+            segk_set_error("sequential chain: grid barrier timed out (%d workgroups were not resident together?)", G);
+            return SEGK_ERR_HIP;
+        }
+        if (ctl[2] <= q && ctl[1] == 0) {
+            segk_set_error("sequential chain: no progress at utterance %d", q);
+            return SEGK_ERR_HIP;
+        }
+        if (stamping && ctl[2] - q >= 200) {          // a long launch: mean time between the stamps, in 10 ns ticks of the 100 MHz clock
+            static unsigned long long hs[256 * 8];
+            SEGK_CHECK_HIP(hipMemcpy(hs, stamp_dev, sizeof(hs), hipMemcpyDeviceToHost));
+            {
+                static unsigned long long ar[4 * 256];
+                SEGK_CHECK_HIP(hipMemcpy(ar, stamp_dev + 2048, sizeof(ar), hipMemcpyDeviceToHost));
+                for (int z = 0; z < 4; z++) {
+                    unsigned long long mn = ~0ull, mx = 0;
+                    int imx = 0;
+                    for (int g = 0; g < G; g++) {
+                        if (ar[z * 256 + g] < mn) mn = ar[z * 256 + g];
+                        if (ar[z * 256 + g] > mx) { mx = ar[z * 256 + g]; imx = g; }
+                    }
+                    int late = 0;
+                    for (int g = 0; g < G; g++) late += (ar[z * 256 + g] - mn) > 200;
+                    fprintf(stderr, "  arrivals at barrier %d: spread %.2f us, workgroup 0 at +%.2f, last is workgroup %d, %d of %d later than +2 us\n",
+                            100 + z, (double)(mx - mn) / 100, (double)(ar[z * 256] - mn) / 100, imx, late, G);
+                }
+            }
+            double acc[7] = {0, 0, 0, 0, 0, 0, 0};
+            for (int i = 20; i < 199; i++) {
+                for (int j = 0; j < 6; j++) acc[j] += (double)(hs[i * 8 + j + 1] - hs[i * 8 + j]);
+                acc[6] += (double)(hs[(i + 1) * 8] - hs[i * 8]);
+            }
+            {
+                double dpw = 0;
+                for (int i = 20; i < 199; i++) dpw += (double)(hs[i * 8 + 7] - hs[i * 8 + 4]);
+                fprintf(stderr, "  of dp: seg_w8_wave %.2f us\n", dpw / 179 / 100);
+            }
+            fprintf(stderr, "chain stamps (us): score %.2f  barrier %.2f  keys %.2f  dp %.2f  update %.2f  | per utterance %.2f\n",
+                    (acc[0] + acc[1]) / 179 / 100, acc[2] / 179 / 100, acc[3] / 179 / 100, acc[4] / 179 / 100, acc[5] / 179 / 100,
+                    acc[6] / 179 / 100);
+        }
+        q = ctl[2];
+        if (ctl[1] != 0) {               // a component emptied: clean_components, then on with the next utterance
+            int rc = segk_launch_clean(c, m, status, st);
+            if (rc) return rc;
+        }
+    }
+    return SEGK_OK;
+}

@@ -1381,3 +1381,9 @@ int32_t segk_kmeans_init_stats(segk_ctx *ctx, const segk_corpus *c, segk_kmeans 
 }
 
 }  // extern "C"
+
+// clean_components (kmeans_components.py:263-266) alone, no image refresh: the persistent sequential chain calls it between launches
+int segk_launch_clean(const segk_corpus *c, segk_kmeans *m, int32_t *status, hipStream_t st)
+{
+    return launch_update(c, m, 3, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, status, st);
+}

@@ -573,3 +573,34 @@ def test_duplicate_means_are_taken_out_of_the_filters(gpu, monkeypatch, pre):
     assert np.array_equal(am, want_am) and np.array_equal(mx, want_mx)
     assert not np.isin(am, list(dup_of)).any()            # a duplicate never wins
     assert nbrute_after <= nbrute_before // 2
+
+
+@pytest.mark.parametrize("n_utt,D,K,N,nmax,ragged", [(300, 100, 1000, 20, 6, False), (200, 40, 130, 0, 5, True),
+                                                      (150, 16, 9, 12, 8, False), (120, 8, 300, 0, 3, True)])
+def test_persistent_sequential_chain_equals_the_three_launch_form(gpu, monkeypatch, n_utt, D, K, N, nmax, ragged):
+    """segk_seq_chain.hip (one persistent kernel per sweep: owner-computes components, one grid barrier per utterance, the DP
+    replicated in every workgroup) against the three launches per utterance it replaces (SEGK_SEQ_CHAIN=0), which
+    test_sequential_chain_bit_exact_vs_reference pins to the reference's captured chains: boundaries, labels, means,
+    numerators, counts and the record values after every sweep, bit for bit -- headline shape, ragged utterances shorter than
+    the window (no banded table), a window of eight, many components emptying (the stop / clean / relaunch path)."""
+    from segmentalist_amd import kmeans_acoustic_wordseg as kaw
+    corpus = cases.chain_corpus(n_utt, D, K, 7 * n_utt + D, ragged, N, nmax, "float32")
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("SEGK_SEQ_CHAIN", mode)
+        random.seed(5)
+        np.random.seed(5)
+        seg = kaw.SegmentalKMeansWordseg(K, *corpus, n_slices_min=0, n_slices_max=nmax, p_boundary_init=0.5,
+                                         init_am_assignments="rand", wip=-0.1)
+        c = seg.acoustic_model.components
+        states = []
+        for it in range(3):
+            rec = seg.segment(1)
+            states.append((seg.utterances.boundaries.copy(), c.assignments.copy(), c.means.copy(), c.mean_numerators.copy(),
+                           c.counts.copy(), c.K, rec["sum_neg_len_sqrd_norm"][0], rec["n_tokens"][0]))
+        out[mode] = states
+    for it in range(3):
+        a, b = out["0"][it], out["1"][it]
+        for x, y in zip(a[:5], b[:5]):
+            assert np.array_equal(x, y), it
+        assert a[5:] == b[5:], it
