@@ -29,6 +29,8 @@
 #define CH_THREADS 1024
 #define CH_MAXOPS 64              /* old + new tokens of an utterance (N_max <= 32) */
 #define CH_SPIN_LIMIT (1 << 22)
+#define CH_KEY_PITCH 16           /* 8-byte words between two spans' maxima: one 128-byte line each */
+#define CH_FLAGS 16               /* release words of the barrier, one 128-byte line each */
 
 struct ChainArgs {
     segk_corpus c;
@@ -37,7 +39,7 @@ struct ChainArgs {
     int q0, q1;                   // this launch walks order[q0 .. q1)
     int n_max;                    // n_slices_max (1..8)
     double wip;
-    unsigned long long *keys;     // [2][G][nb_cap] the workgroups' span maxima (score, ~component), by utterance parity
+    unsigned long long *keys;     // [3][nb_cap][16] span maxima (score, ~component), one 128-byte line per span, zero between uses
     int32_t *ctl;                 // [0] barrier counter, [1] stop flag, [2] utterances completed, [3] error
     uint8_t *boundaries;
     int32_t *old_tok, *new_tok, *new_k, *n_old, *n_new, *n_flag;
@@ -53,30 +55,43 @@ struct ChainArgs {
         if (A.stamp && blockIdx.x == 0 && tid == 0 && q - A.q0 < 256) A.stamp[(q - A.q0) * 8 + (slot)] = wall_clock64(); \
     } while (0)
 
-// Grid barrier number `phase` (1, 2, ...): false when the spin limit was hit or another workgroup reported an error.  One
-// word carries the arrivals (low 30 bits) and the stop flag (bit 30), so that a workgroup learns both from one atomic: the
-// last one to arrive from its own fetch-add, the others from the value they poll.  (Separate words cost every workgroup
-// three dependent device-scope round trips per utterance: 5.9 us measured for the LAST arriver.)
+// Grid barrier number `phase` (1, 2, ...): false when the spin limit was hit or another workgroup reported an error.  The
+// arrivals go to ONE counter (low 30 bits; bit 30: a component emptied, stop after this utterance); the workgroup whose add
+// came last learns it from the value the add returned and releases the others through CH_FLAGS words on cache lines of
+// their own (one store instruction, one lane per word), each polled by G / CH_FLAGS workgroups: with every workgroup
+// polling the counter itself the last arriver's own add queued behind 124 pollers (5.9 us per barrier for the LAST one).
+// ctl: [0] counter, [1] stop (for the host), [2] utterances completed, [3] error, [32 * (1 + f)] release word f.
 #define CH_STOP_BIT (1 << 30)
 __device__ __forceinline__ bool chain_barrier(int32_t *ctl, int phase, int *sh_flag)
 {
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // this wave's stores have been performed
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // this wave's atomics and stores have been performed
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
         const int target = phase * (int)gridDim.x;
-        int seen = __hip_atomic_fetch_add(&ctl[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
-        int spins = 0, ok = 1;
-        while ((seen & (CH_STOP_BIT - 1)) < target) {
-            __builtin_amdgcn_s_sleep(1);
-            seen = __hip_atomic_load(&ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (++spins > CH_SPIN_LIMIT || ((spins & 1023) == 0 && __hip_atomic_load(&ctl[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-                __hip_atomic_fetch_or(&ctl[3], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ok = 0;
-                break;
+        int seen = 0;
+        if (lane == 0) seen = __hip_atomic_fetch_add(&ctl[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+        seen = __shfl(seen, 0);
+        int ok = 1, word;
+        if ((seen & (CH_STOP_BIT - 1)) >= target) {                 // the last one in: release the others
+            word = (seen & CH_STOP_BIT) | phase;
+            if (lane < CH_FLAGS) __hip_atomic_store(&ctl[32 * (1 + lane)], word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            int *flag = &ctl[32 * (1 + (int)(blockIdx.x % CH_FLAGS))];
+            int spins = 0;
+            for (;;) {
+                word = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((word & (CH_STOP_BIT - 1)) >= phase) break;
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > CH_SPIN_LIMIT || ((spins & 1023) == 0 && __hip_atomic_load(&ctl[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                    __hip_atomic_fetch_or(&ctl[3], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = 0;
+                    break;
+                }
             }
         }
         // bit 0: passed; bit 1: a component emptied during the previous utterance
-        *sh_flag = ok | ((seen & CH_STOP_BIT) ? 2 : 0);
+        if (lane == 0) *sh_flag = ok | ((word & CH_STOP_BIT) ? 2 : 0);
     }
     __syncthreads();
     return (*sh_flag & 1) != 0;
@@ -120,8 +135,6 @@ __global__ __launch_bounds__(CH_THREADS) void k_seq_chain(ChainArgs A)
     int32_t *op_e = reinterpret_cast<int32_t *>(take(CH_MAXOPS * 4));                   // [CH_MAXOPS] item
     int32_t *op_k = reinterpret_cast<int32_t *>(take(CH_MAXOPS * 4));                   // [CH_MAXOPS] component (-1: nothing to do)
     int32_t *op_x = reinterpret_cast<int32_t *>(take(CH_MAXOPS * 4));                   // [CH_MAXOPS] its row: xo index (old), band entry (new)
-    unsigned long long *kred = reinterpret_cast<unsigned long long *>(take(8 * 128 * 8));    // [8][128] partial maxima of a pass
-    unsigned long long *kfin = reinterpret_cast<unsigned long long *>(take((size_t)NBC * 8)); // [NBC] the spans' maxima
     ChainSet S[2];
     for (int z = 0; z < 2; z++) {
         S[z].xs = reinterpret_cast<float *>(take((size_t)NBC * LDX * 4));
@@ -259,8 +272,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_seq_chain(ChainArgs A)
         const int32_t *bid = C.bid;
         const float *xs = C.xs, *xo = C.xo;
         uint8_t *gbnd = A.boundaries + (int64_t)u * NM;
-        unsigned long long *keys_all = A.keys + (size_t)(q & 1) * gridDim.x * NBC;      // [G][NBC]
-        unsigned long long *keys = keys_all + (size_t)blockIdx.x * NBC;
+        unsigned long long *keys = A.keys + (size_t)(q % 3) * NBC * CH_KEY_PITCH;
         CH_STAMP(0);
         CH_STAMP(1);
 
@@ -279,9 +291,9 @@ __global__ __launch_bounds__(CH_THREADS) void k_seq_chain(ChainArgs A)
                 const unsigned long long other = __shfl_xor(key, o);
                 key = other > key ? other : key;
             }
-            // one write-through store per span and workgroup (an atomic maximum per span instead -- 13 000 of them on seven
-            // cache lines per utterance -- kept every workgroup ~6 us at the barrier waiting for its own atomics)
-            if (ci == 0 && i < nb) __hip_atomic_store(&keys[i], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // one atomic maximum per span and workgroup; every span's word on a 128-byte line of its own, so that the
+            // 125 x 105 atomics of an utterance spread over the L2 channels
+            if (ci == 0 && i < nb && key != 0ull) atomicMax(&keys[(size_t)i * CH_KEY_PITCH], key);
         }
         CH_STAMP(2);
         if (A.stamp && tid == 0 && q - A.q0 >= 100 && q - A.q0 < 104) A.stamp[2048 + (q - A.q0 - 100) * 256 + blockIdx.x] = wall_clock64();
@@ -289,32 +301,12 @@ __global__ __launch_bounds__(CH_THREADS) void k_seq_chain(ChainArgs A)
         if (!chain_barrier(A.ctl, phase, &sh_flag)) return;
         CH_STAMP(3);
         if (sh_flag & 2) break;            // a component emptied during the previous utterance: clean_components on the host's side
-        // every workgroup reduces the G partial maxima of every span: 128 spans x 8 groups of workgroups per pass
-        for (int i0 = 0; i0 < nb; i0 += 128) {
-            const int i = i0 + (tid & 127), grp = tid >> 7;
-            unsigned long long key = 0ull;
-            if (i < nb && bid[i] >= 0) {
-                for (int g0 = grp; g0 < (int)gridDim.x; g0 += 32) {
-                    unsigned long long kv[4];
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const int g = g0 + 8 * r;
-                        kv[r] = g < (int)gridDim.x ? __hip_atomic_load(&keys_all[(size_t)g * NBC + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; r++) key = kv[r] > key ? kv[r] : key;
-                }
-            }
-            kred[grp * 128 + (tid & 127)] = key;
-            __syncthreads();
-            if (tid < 128 && i0 + tid < nb) {
-                unsigned long long kk = kred[tid];
-#pragma unroll
-                for (int r = 1; r < 8; r++) kk = kred[r * 128 + tid] > kk ? kred[r * 128 + tid] : kk;
-                kfin[i0 + tid] = kk;
-            }
-            __syncthreads();
-        }
+        // the maxima of the utterance before the previous one: every workgroup has read them (it passed this barrier after
+        // its phase B), nobody writes them before the next barrier
+        if (blockIdx.x == 0)
+            for (int i = tid; i < NBC; i += CH_THREADS)
+                __hip_atomic_store(&A.keys[((size_t)((q + 2) % 3) * NBC + i) * CH_KEY_PITCH], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
         // ================================ phase B, the same in every workgroup: wave 0 runs the DP, the other waves fetch the
         // next utterance
         if (wv == 0) {
@@ -322,7 +314,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_seq_chain(ChainArgs A)
                 double v = NEG_INF_D;
                 int k = -1;
                 if (bid[i] >= 0) {
-                    const unsigned long long key = kfin[i];
+                    const unsigned long long key = __hip_atomic_load(&keys[(size_t)i * CH_KEY_PITCH], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     const unsigned int ord = (unsigned int)(key >> 32);
                     const unsigned int bits = (ord & 0x80000000u) ? (ord & 0x7fffffffu) : ~ord;
                     k = (int32_t)(0xffffffffu - (unsigned int)(key & 0xffffffffu));
@@ -495,8 +487,7 @@ int segk_launch_seq_chain(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m, c
     const size_t NM = (size_t)c->N_max;
     const size_t set_bytes = al((size_t)nbc * D * 4) + al(NM * D * 4) + al((size_t)nbc * 8) + 2 * al((size_t)nbc * 4) + 2 * al(NM * 4) + al(8 * 4);
     const size_t lds = al((size_t)cpw * D * 8) + al((size_t)nbc * 8) + al((NM + 1) * 8) + al((size_t)cpw * 8) + al(CH_MAXOPS * 8) +
-                       al((size_t)cpw * ldm * 4) + al((size_t)nbc * 4) + 3 * al(NM * 4) + al(8 * 4) + 3 * al(CH_MAXOPS * 4) + al(8 * 128 * 8) +
-                       al((size_t)nbc * 8) + 2 * set_bytes;
+                       al((size_t)cpw * ldm * 4) + al((size_t)nbc * 4) + 3 * al(NM * 4) + al(8 * 4) + 3 * al(CH_MAXOPS * 4) + 2 * set_bytes;
     if (lds > 158 * 1024) return SEGK_ERR_UNSUPPORTED;
     static size_t lds_set = 0;
     if (lds > 48 * 1024 && lds > lds_set) {
@@ -506,7 +497,7 @@ int segk_launch_seq_chain(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m, c
     // all workgroups must be resident together: one per CU at most
     if (G > ctx->n_cu || (int64_t)G * (n_order + 1) >= CH_STOP_BIT) return SEGK_ERR_UNSUPPORTED;
 
-    const size_t key_bytes = 2 * (size_t)G * nbc * sizeof(unsigned long long), ctl_bytes = 8 * sizeof(int32_t);
+    const size_t key_bytes = 3 * (size_t)nbc * CH_KEY_PITCH * sizeof(unsigned long long), ctl_bytes = (8 + 32 * (CH_FLAGS + 1)) * sizeof(int32_t);
     const size_t need = key_bytes + ctl_bytes + (size_t)n_order * sizeof(int32_t);
     if (ctx->chain_bytes < need) {
         if (ctx->chain_buf) (void)hipFree(ctx->chain_buf);
@@ -532,7 +523,7 @@ int segk_launch_seq_chain(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m, c
     A.stamp = stamping ? stamp_dev : nullptr;
     int q = 0;
     while (q < n_order) {
-        SEGK_CHECK_HIP(hipMemsetAsync(buf + key_bytes, 0, ctl_bytes, st));
+        SEGK_CHECK_HIP(hipMemsetAsync(buf, 0, key_bytes + ctl_bytes, st));
         A.q0 = q; A.q1 = n_order;
         hipLaunchKernelGGL(k_seq_chain, dim3(G), dim3(CH_THREADS), lds, st, A);
         SEGK_LAUNCH_CHECK();
