@@ -199,18 +199,14 @@ __device__ __forceinline__ void seg_w8_wave(const double *bvec, double *gam, con
         const bool ok = lane < W && tt - 1 - lane >= 0;
         double x = ok ? bvec[(tt - 1) * W + lane] + gam[tt - 1 - lane] : NEG_INF_D;
         const unsigned long long fin = __ballot(ok && x != NEG_INF_D);
-        int w = ok ? lane : 99;
-#define SEG_ARGMAX_STEP(CTRL)                                                    \
-        do {                                                                     \
-            const double xo_ = seg_dpp_f64<CTRL>(x);                             \
-            const int wo_ = seg_dpp_i32<CTRL>(w);                                \
-            if (xo_ > x || (xo_ == x && wo_ < w)) { x = xo_; w = wo_; }          \
-        } while (0)
-        SEG_ARGMAX_STEP(SEG_DPP_XOR1);
-        SEG_ARGMAX_STEP(SEG_DPP_XOR2);
-        SEG_ARGMAX_STEP(SEG_DPP_HMIRROR);
-#undef SEG_ARGMAX_STEP
-        kb = __builtin_amdgcn_readfirstlane(w) + 1;
+        // the maximum's value over the eight lanes, then the first lane that holds it
+        double mx = x;
+        mx = fmax(mx, seg_dpp_f64<SEG_DPP_XOR1>(mx));
+        mx = fmax(mx, seg_dpp_f64<SEG_DPP_XOR2>(mx));
+        mx = fmax(mx, seg_dpp_f64<SEG_DPP_HMIRROR>(mx));
+        const unsigned long long at = __ballot(ok && x == mx) & 0xFFull;
+        const int w = at ? __ffsll((long long)at) - 1 : 0;
+        kb = w + 1;
         return (fin & 0xFFull) == 0ull;
     };
     // ---- A8 backward (:510-553)

@@ -135,6 +135,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_seq_chain(ChainArgs A)
     int32_t *op_e = reinterpret_cast<int32_t *>(take(CH_MAXOPS * 4));                   // [CH_MAXOPS] item
     int32_t *op_k = reinterpret_cast<int32_t *>(take(CH_MAXOPS * 4));                   // [CH_MAXOPS] component (-1: nothing to do)
     int32_t *op_x = reinterpret_cast<int32_t *>(take(CH_MAXOPS * 4));                   // [CH_MAXOPS] its row: xo index (old), band entry (new)
+    int32_t *op_w = reinterpret_cast<int32_t *>(take(CH_MAXOPS * 4));                   // [CH_MAXOPS] low half: own slot when it is the last item of its component (else -1); bit 16: last item of its row
     ChainSet S[2];
     for (int z = 0; z < 2; z++) {
         S[z].xs = reinterpret_cast<float *>(take((size_t)NBC * LDX * 4));
@@ -374,26 +375,40 @@ __global__ __launch_bounds__(CH_THREADS) void k_seq_chain(ChainArgs A)
         __syncthreads();
         CH_STAMP(5);
         const int no = l_cnt[0], nn = l_cnt[1], nops = no + nn;
-        // add_item's assert (:101): the row must be unassigned -- by an earlier item of this utterance, else by the state before it
-        if (blockIdx.x == 0 && tid >= no && tid < nops) {
-            int prev = -1;
-            for (int p2 = 0; p2 < tid; p2++)
-                if (op_e[p2] == op_e[tid]) prev = p2;
-            const int cur = prev >= 0 ? (prev < no ? -1 : op_k[prev]) : C.basg[op_x[tid]];
-            if (cur != -1) atomicOr(A.status, 2);
-        }
-        // the count of its component after every item, for the components this workgroup owns
         if (tid < nops) {
-            const int k = op_k[tid], ci = k - k0;
-            long long cn = 0;
-            if (k >= 0 && ci >= 0 && ci < kn) {
-                cn = cnt_l[ci];
-                for (int p2 = 0; p2 <= tid; p2++)
-                    if (op_k[p2] == k) cn += p2 < no ? -1 : 1;
+            // the count of its component after every item, for the components this workgroup owns; whether the item is the
+            // last one on its component / on its row
+            const int k = op_k[tid], ci = k - k0, e = op_e[tid];
+            const bool own = k >= 0 && ci >= 0 && ci < kn;
+            long long cn = own ? cnt_l[ci] : 0;
+            bool last_k = own, last_e = true;
+            int prev = -1;
+            for (int p2 = 0; p2 < nops; p2++) {
+                const int k2 = op_k[p2], e2 = op_e[p2];
+                if (own && k2 == k && p2 <= tid) cn += p2 < no ? -1 : 1;
+                if (p2 > tid && k2 == k) last_k = false;
+                if (p2 > tid && e2 == e) last_e = false;
+                if (p2 < tid && e2 == e) prev = p2;
             }
             op_cnt[tid] = cn;
+            op_w[tid] = ((last_k ? ci : 0xffff) & 0xffff) | (last_e ? 0x10000 : 0);
+            // add_item's assert (:101): the row must be unassigned -- by an earlier item of this utterance, else by the state
+            // before it
+            if (blockIdx.x == 0 && tid >= no) {
+                const int cur = prev >= 0 ? (prev < no ? -1 : op_k[prev]) : C.basg[op_x[tid]];
+                if (cur != -1) atomicOr(A.status, 2);
+            }
         }
         __syncthreads();
+        if (tid < nops) {
+            const int w = op_w[tid], ci = (int)(short)(w & 0xffff);
+            if (ci >= 0) {                                               // the last item of a component leaves its count
+                cnt_l[ci] = op_cnt[tid];
+                m.counts[k0 + ci] = op_cnt[tid];
+                if (op_cnt[tid] == 0 && k0 + ci < sh_K) sh_empty = 1;
+            }
+            if (w & 0x10000) m.assignments[op_e[tid]] = tid < no ? -1 : op_k[tid];
+        }
         // the items in the reference's order; thread d owns dimension d of every component of this workgroup (:110, :128-129)
         for (int d = tid; d < D; d += CH_THREADS)
             for (int o = 0; o < nops; o++) {
@@ -405,37 +420,23 @@ __global__ __launch_bounds__(CH_THREADS) void k_seq_chain(ChainArgs A)
                 const long long cnt = op_cnt[o];
                 if (cnt != 0) means_l[ci * LDM + d] = (float)(v / (double)cnt);
             }
-        __syncthreads();
-        // write through: the touched rows of this workgroup (the last item of a component writes them), labels, boundaries
-        if (tid < nops) {
-            const int k = op_k[tid], ci = k - k0;
-            bool last_k = k >= 0 && ci >= 0 && ci < kn, last_e = true;
-            for (int p2 = tid + 1; p2 < nops; p2++) {
-                if (op_k[p2] == k) last_k = false;
-                if (op_e[p2] == op_e[tid]) last_e = false;
-            }
-            if (last_k) {
-                cnt_l[ci] = op_cnt[tid];
-                m.counts[k] = op_cnt[tid];
-                if (op_cnt[tid] == 0 && k < sh_K) sh_empty = 1;
-            }
-            op_x[tid] = last_k ? ci : -1;                                        // (op_x is not needed any more)
-            if (last_e) m.assignments[op_e[tid]] = tid < no ? -1 : op_k[tid];
-        }
-        if (tid < N) {
+        // boundaries (every workgroup: the same values) and the utterance's outputs, by the threads the loop above leaves idle
+        if (tid >= 512 && tid - 512 < N) {
             const unsigned long long newb = ((unsigned long long)(unsigned int)l_cnt[3] << 32) | (unsigned int)l_cnt[2];
-            gbnd[tid] = (uint8_t)((newb >> tid) & 1ull);
+            gbnd[tid - 512] = (uint8_t)((newb >> (tid - 512)) & 1ull);
         }
-        if (blockIdx.x == 0) {
-            for (int j = tid; j < no; j += CH_THREADS) A.old_tok[(int64_t)u * NM + j] = l_old[j];
-            for (int j = tid; j < NM; j += CH_THREADS) {
+        if (blockIdx.x == 0 && tid >= 576) {
+            const int j = tid - 576;
+            if (j < no) A.old_tok[(int64_t)u * NM + j] = l_old[j];
+            if (j < NM) {
                 if (j < nn) A.new_tok[(int64_t)u * NM + j] = l_new[j];
                 A.new_k[(int64_t)u * NM + j] = j < nn ? l_newk[j] : -1;
             }
         }
         __syncthreads();
+        // write through the touched rows of this workgroup
         for (int o = 0; o < nops; o++) {
-            const int ci = op_x[o];
+            const int ci = (int)(short)(op_w[o] & 0xffff);
             if (ci < 0) continue;
             const int k = k0 + ci;
             for (int d = tid; d < D; d += CH_THREADS) {
@@ -447,7 +448,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_seq_chain(ChainArgs A)
             __hip_atomic_fetch_or(&A.ctl[0], CH_STOP_BIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&A.ctl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // for the host
         }
-        __syncthreads();
+        // (no barrier here: the next one is the grid barrier's, and until then nothing below is written again)
         CH_STAMP(6);
     }
     if (blockIdx.x == 0 && tid == 0) {
@@ -487,7 +488,7 @@ int segk_launch_seq_chain(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m, c
     const size_t NM = (size_t)c->N_max;
     const size_t set_bytes = al((size_t)nbc * D * 4) + al(NM * D * 4) + al((size_t)nbc * 8) + 2 * al((size_t)nbc * 4) + 2 * al(NM * 4) + al(8 * 4);
     const size_t lds = al((size_t)cpw * D * 8) + al((size_t)nbc * 8) + al((NM + 1) * 8) + al((size_t)cpw * 8) + al(CH_MAXOPS * 8) +
-                       al((size_t)cpw * ldm * 4) + al((size_t)nbc * 4) + 3 * al(NM * 4) + al(8 * 4) + 3 * al(CH_MAXOPS * 4) + 2 * set_bytes;
+                       al((size_t)cpw * ldm * 4) + al((size_t)nbc * 4) + 3 * al(NM * 4) + al(8 * 4) + 4 * al(CH_MAXOPS * 4) + 2 * set_bytes;
     if (lds > 158 * 1024) return SEGK_ERR_UNSUPPORTED;
     static size_t lds_set = 0;
     if (lds > 48 * 1024 && lds > lds_set) {
