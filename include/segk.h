@@ -258,12 +258,15 @@ int32_t segk_kmeans_del_component(segk_ctx *ctx, const segk_corpus *c, segk_kmea
 
 /* One sweep of the reference's sequential chain (SegmentalKMeansWordseg.segment's inner loop,
  * kmeans_acoustic_wordseg.py:393-399): for every utterance of `order` [HOST] int32 [n_order] in turn, segment_i
- * (:225-332) -- A1 for its spans directly in the reference's arithmetic (one kernel: no filter, no operand images),
- * segk_kmeans_segment, the update of segk_kmeans_update_utt -- three launches per utterance enqueued by one call;
- * the operand images are refreshed once at the end.  Same results as calling segk_kmeans_score /
- * segk_kmeans_segment / segk_kmeans_update_utt per utterance (bit-identical to the reference's chain), about half
- * the time.  keys_scratch [dev] uint64 [N_max (N_max + 1) / 2 + 2], zeroed by the caller once.  float32 data;
- * SEGK_ERR_UNSUPPORTED otherwise.                                                                           */
+ * (:225-332) -- A1 for its spans directly in the reference's arithmetic (no filter, no operand images), the DP,
+ * the del_item / add_item updates, clean_components; the operand images are refreshed once at the end.  Same
+ * results as calling segk_kmeans_score / segk_kmeans_segment / segk_kmeans_update_utt per utterance (bit-identical
+ * to the reference's chain).  Where the configuration allows (D % 4 = 0, 8 <= D <= 128, at most 32 landmarks per
+ * utterance, 1 <= n_slices_max <= 8) the sweep runs as ONE persistent kernel (segk_seq_chain.hip: ~19 us per
+ * utterance on the headline corpus); the call then synchronises `stream` after every launch of it (one launch per
+ * stretch of utterances between two emptied components).  Otherwise, and with SEGK_SEQ_CHAIN=0: three launches
+ * per utterance, all enqueued (~44 us per utterance).  keys_scratch [dev] uint64 [N_max (N_max + 1) / 2 + 2],
+ * zeroed by the caller once.  float32 data; SEGK_ERR_UNSUPPORTED otherwise.                                   */
 int32_t segk_kmeans_sequential_sweep(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m,
                                      const int32_t *order, int32_t n_order, int32_t n_slices_min,
                                      int32_t n_slices_max, double wip, const segk_cand *cand,
