@@ -230,6 +230,39 @@ static __device__ __forceinline__ void fbb_accumulate(const segk_fbatch &bt, int
     }
 }
 
+// the same for NR rows starting at xs (a row group of k_fbb_assign): per (row, slot) the identical sequence of operations
+template <int COV, int NR>
+static __device__ __forceinline__ void fbb_accumulate_rows(const segk_fbatch &bt, int KM, int k, int D, const double *xs, double *acc)
+{
+    int d = 0;
+    for (; d + 4 <= D; d += 4) {
+        double m[4], q[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            m[j] = bt.mean_t[(int64_t)(d + j) * KM + k];
+            q[j] = bt.q_t[(int64_t)(d + j) * KM + k];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+#pragma unroll
+            for (int r = 0; r < NR; r++) {
+                const double delta = m[j] - xs[r * D + d + j];
+                if (COV == 0) acc[r] += (delta * delta) * q[j];
+                else acc[r] += log(1. + (delta * delta) * q[j]);
+            }
+        }
+    }
+    for (; d < D; d++) {
+        const double m = bt.mean_t[(int64_t)d * KM + k], q = bt.q_t[(int64_t)d * KM + k];
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            const double delta = m - xs[r * D + d];
+            if (COV == 0) acc[r] += (delta * delta) * q;
+            else acc[r] += log(1. + (delta * delta) * q);
+        }
+    }
+}
+
 // x-dependent part of the prior predictive of one row, by one wave (lanes over d); result in all lanes
 template <typename XT>
 static __device__ double fbb_prior_row(const segk_fbgmm &f, int D, const double *x, int lane)
@@ -554,6 +587,23 @@ __global__ void k_fbb_assign(segk_corpus c, segk_fbgmm f, segk_fbatch bt, FbbMap
             }
         }
         __syncthreads();
+        if (nt >= 4 * 128 && KM <= 128) {
+            // few slots: four groups of threads take two rows each (the per-(row, slot) arithmetic is unchanged; with one
+            // thread per slot 100 of 256 threads each walked D x 8 software logarithms)
+            const int k = tid & 127, r0 = 2 * (tid >> 7);
+            if (k < KM && r0 < nr) {
+                if (bt.cnt[k] > 0.0) {
+                    double acc[2] = {0.0, 0.0};
+                    fbb_accumulate_rows<COV, 2>(bt, KM, k, (dbg & 1) ? 1 : D, xs + r0 * D, acc);
+                    const double lc = bt.lconst[k], h = bt.half[k];
+                    ll[(int64_t)r0 * KM + k] = lc - h * acc[0];
+                    if (r0 + 1 < nr) ll[(int64_t)(r0 + 1) * KM + k] = lc - h * acc[1];
+                } else {
+                    ll[(int64_t)r0 * KM + k] = lpr[r0];
+                    if (r0 + 1 < nr) ll[(int64_t)(r0 + 1) * KM + k] = lpr[r0 + 1];
+                }
+            }
+        } else
         for (int k = tid; k < KM; k += nt) {
             if (bt.cnt[k] > 0.0) {
                 double acc[FBB_R];
@@ -572,6 +622,57 @@ __global__ void k_fbb_assign(segk_corpus c, segk_fbgmm f, segk_fbatch bt, FbbMap
         }
         }
         __syncthreads();
+        if (!f.lm_unigram) {
+            // Without a language model a token's draw does not depend on the token before it: one WAVE per token, maxima
+            // and sums by shuffles.  The sums keep the association of the block-wide form below at 256 threads (per wave
+            // of 64 consecutive slots a butterfly, the waves' results added in order), so the probabilities -- and the
+            // draws -- are the same bits.
+            const int w = tid >> 6, lane = tid & 63, nw = nt >> 6;
+            for (int r = w; r < ((dbg & 2) ? 1 : nr); r += nw) {
+                const int64_t e = new_tok[(int64_t)utt * c.N_max + t0 + r];
+                double *zr = ll + (int64_t)r * KM;
+                double mx = NEG_INF_D;
+                for (int k = lane; k < KM; k += 64) {
+                    const double n = bt.cnt[k];
+                    const double v = (n > 0.0 ? f.lms * log(prior_alpha / (double)KM + n) : zc_empty) + zr[k];      // fbgmm.py:436-440
+                    zr[k] = v;
+                    mx = v > mx ? v : mx;
+                }
+                for (int o = 32; o > 0; o >>= 1) {
+                    const double other = __shfl_xor(mx, o);
+                    mx = other > mx ? other : mx;
+                }
+                auto sum_exp = [&](double shift) -> double {       // sum_k exp(zr[k] - shift) in the order of block_sum at 256 threads
+                    double tot = 0.0;
+                    for (int cw = 0; cw < 4 && cw * 64 < KM; cw++) {
+                        double sv = 0.0;
+                        for (int k = cw * 64 + lane; k < KM; k += 256) sv += exp(zr[k] - shift);
+                        for (int o = 32; o > 0; o >>= 1) sv += __shfl_xor(sv, o);
+                        tot = cw == 0 ? sv : tot + sv;
+                    }
+                    return tot;
+                };
+                double lse = log(sum_exp(mx)) + mx;
+                if (anneal_temp != 1.0) {                           // fbgmm.py:446-449
+                    double mx2 = NEG_INF_D;
+                    for (int k = lane; k < KM; k += 64) {
+                        const double v = (1. / anneal_temp) * (zr[k] - lse);
+                        zr[k] = v;
+                        mx2 = v > mx2 ? v : mx2;
+                    }
+                    for (int o = 32; o > 0; o >>= 1) {
+                        const double other = __shfl_xor(mx2, o);
+                        mx2 = other > mx2 ? other : mx2;
+                    }
+                    lse = log(sum_exp(mx2)) + mx2;
+                }
+                for (int k = lane; k < KM; k += 64) zr[k] = exp(zr[k] - lse);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const int k = (dbg & 4) ? 0 : fb_draw_chunked(zr, KM, segk_u01(bt.seed, sweep, (uint64_t)utt, (uint64_t)(c.N_max + t0 + r)), lane);
+                if (lane == 0) bt.slot[e] = k;
+            }
+        } else
         for (int r = 0; r < ((dbg & 2) ? 1 : nr); r++) {
             const int64_t e = new_tok[(int64_t)utt * c.N_max + t0 + r];
             for (int k = tid; k < KM; k += nt) {
@@ -1079,18 +1180,21 @@ int32_t segk_fbb_assign(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *f
     while (rcap > 1 && fixed_b + (size_t)rcap * f->K_max * sizeof(double) > 80 * 1024) rcap >>= 1;
     const size_t lds = fixed_b + (size_t)rcap * f->K_max * sizeof(double);
     SEGK_REQUIRE(lds <= 160 * 1024, "K_max too large for the LDS logits buffer");
+    // 512 threads where the slots alone would leave most of 256 idle and the tokens' draws are independent (no language
+    // model): four row groups in the likelihood phase, a wave per token in the draw phase
+    const int nt_assign = (f->K_max <= 128 && !f->lm_unigram && rcap == FBB_R) ? 512 : 256;
     DISPATCH_XT(c, {
         if (f->cov_type == 0) {
             if (lds > 48 * 1024)
                 SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_fbb_assign<XT, 0>,
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL((k_fbb_assign<XT, 0>), dim3(m.off[s_n]), dim3(256), lds, (hipStream_t)stream, *c, *f, *bt, m,
+            hipLaunchKernelGGL((k_fbb_assign<XT, 0>), dim3(m.off[s_n]), dim3(nt_assign), lds, (hipStream_t)stream, *c, *f, *bt, m,
                                b, sweep, alpha, anneal_temp, new_tok, n_new, rcap, dbg, ll_mat, ll_ld);
         } else {
             if (lds > 48 * 1024)
                 SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_fbb_assign<XT, 1>,
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL((k_fbb_assign<XT, 1>), dim3(m.off[s_n]), dim3(256), lds, (hipStream_t)stream, *c, *f, *bt, m,
+            hipLaunchKernelGGL((k_fbb_assign<XT, 1>), dim3(m.off[s_n]), dim3(nt_assign), lds, (hipStream_t)stream, *c, *f, *bt, m,
                                b, sweep, alpha, anneal_temp, new_tok, n_new, rcap, dbg, ll_mat, ll_ld);
         }
     });

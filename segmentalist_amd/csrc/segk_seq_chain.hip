@@ -220,7 +220,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_seq_chain(ChainArgs A)
             st.bdur[i] = dd;
             // add_item's assert (:101) wants the row's label BEFORE this utterance: read ahead of the barrier -- once the
             // first workgroup is through its phase B the labels in memory are the new ones
-            if (blockIdx.x == 0) st.basg[i] = id >= 0 ? m.assignments[id] : -1;
+            if (blockIdx.x == gridDim.x - 1) st.basg[i] = id >= 0 ? m.assignments[id] : -1;
         }
         // the candidate rows, by band entry: consecutive threads on consecutive 16 bytes, four loads in flight per thread
         const int tot = nb * D4;
@@ -306,8 +306,9 @@ __global__ __launch_bounds__(CH_THREADS) void k_seq_chain(ChainArgs A)
         if (sh_flag & 2) break;            // a component emptied during the previous utterance: clean_components on the host's side
         // the maxima of the utterance before the previous one: every workgroup has read them (it passed this barrier after
         // its phase B), nobody writes them before the next barrier
-        if (blockIdx.x == 0)
-            for (int i = tid; i < NBC; i += CH_THREADS)
+        // (one word per workgroup: 120 write-through stores by ONE workgroup made it 2 us late at every barrier)
+        if (tid == 0)
+            for (int i = blockIdx.x; i < NBC; i += gridDim.x)
                 __hip_atomic_store(&A.keys[((size_t)((q + 2) % 3) * NBC + i) * CH_KEY_PITCH], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
         // ================================ phase B, the same in every workgroup: wave 0 runs the DP, the other waves fetch the
@@ -393,10 +394,10 @@ __global__ __launch_bounds__(CH_THREADS) void k_seq_chain(ChainArgs A)
                 if (p2 < tid && e2 == e) prev = p2;
             }
             op_cnt[tid] = cn;
-            op_w[tid] = ((last_k ? ci : 0xffff) & 0xffff) | (last_e ? 0x10000 : 0);
+            op_w[tid] = ((last_k ? ci : 0xffff) & 0xffff) | (last_e ? 0x10000 : 0) | (own ? 0x20000 : 0);
             // add_item's assert (:101): the row must be unassigned -- by an earlier item of this utterance, else by the state
             // before it
-            if (blockIdx.x == 0 && tid >= no) {
+            if (blockIdx.x == gridDim.x - 1 && tid >= no) {          // (the last workgroup checks, workgroup 0 writes the outputs)
                 const int cur = prev >= 0 ? (prev < no ? -1 : op_k[prev]) : C.basg[op_x[tid]];
                 if (cur != -1) atomicOr(A.status, 2);
             }
@@ -414,8 +415,8 @@ __global__ __launch_bounds__(CH_THREADS) void k_seq_chain(ChainArgs A)
         // the items in the reference's order; thread d owns dimension d of every component of this workgroup (:110, :128-129)
         for (int d = tid; d < D; d += CH_THREADS)
             for (int o = 0; o < nops; o++) {
-                const int k = op_k[o], ci = k - k0;
-                if (k < 0 || ci < 0 || ci >= kn) continue;
+                if (!(op_w[o] & 0x20000)) continue;                       // not a component of this workgroup
+                const int ci = op_k[o] - k0;
                 const double x = (double)(o < no ? xo[op_x[o] * LDX + d] : xs[op_x[o] * LDX + d]);
                 const double v = o < no ? numer_l[ci * D + d] - x : numer_l[ci * D + d] + x;
                 numer_l[ci * D + d] = v;
