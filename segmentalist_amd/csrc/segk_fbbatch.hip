@@ -362,16 +362,24 @@ __global__ void k_fbb_score(segk_corpus c, segk_fbgmm f, segk_fbatch bt, FbbMap 
 // contract 1e-4.  FBB_R32 rows per workgroup: the slot tables are read once for 16 rows.
 // ---------------------------------------------------------------------------------------
 #define FBB_R32 16
-template <typename XT>
+// RPG rows per thread (16: one thread group over the slots; 8: two groups when K_max <= 128 would leave most of the 256
+// threads idle).  TLDS: the slot tables (mean, q) as float32 in LDS, staged once per workgroup with coalesced loads -- read
+// from memory inside the term loop (TLDS = false, tables beyond the LDS budget) every four dimensions cost a dependent
+// round trip, which is where the first version of this kernel spent its time (9 % of what the ALUs sustain on the term).
+template <typename XT, int RPG, bool TLDS>
 __global__ __launch_bounds__(256) void k_fbb_score_diag32(segk_corpus c, segk_fbgmm f, segk_fbatch bt, FbbMap map, int b,
                                                           double prior_alpha, double *score)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NG = FBB_R32 / RPG;            // thread groups
     const int D = c.D, KM = f.K_max, tid = threadIdx.x, nt = blockDim.x;
     double *xs64 = (double *)smem;               // [8][D] scratch of the prior predictive (fp64, 8 rows at a time)
     double *lpr = xs64 + 8 * D;                  // [R32]
-    double *red = lpr + FBB_R32;                 // [16]
-    float *xs = (float *)(red + 16);             // [R32][D]
+    float *wm = (float *)(lpr + FBB_R32);        // [4 waves][R32] the waves' maxima
+    float *ws = wm + 4 * FBB_R32;                // [4 waves][R32] and sums
+    float *xs = ws + 4 * FBB_R32;                // [R32][D]
+    float *tm = xs + FBB_R32 * D;                // [D][KM] (TLDS)
+    float *tq = tm + (TLDS ? D * KM : 0);        // [D][KM]
     int s, idx;
     if (!fbb_locate(map, blockIdx.x, &s, &idx)) return;
     const int slice = map.lo[s];
@@ -383,6 +391,11 @@ __global__ __launch_bounds__(256) void k_fbb_score_diag32(segk_corpus c, segk_fb
         const int r = j / D, d = j - r * D;
         xs[j] = r < nr ? (float)X[(row0 + r) * c.ldx + d] : 0.f;
     }
+    if (TLDS)
+        for (int j = tid; j < D * KM; j += nt) {
+            tm[j] = (float)bt.mean_t[j];
+            tq[j] = (float)bt.q_t[j];
+        }
     // the prior predictive of every row (an empty slot's likelihood): fp64 as in the fp64 kernel, once per row
     for (int r8 = 0; r8 < FBB_R32; r8 += 8) {
         __syncthreads();
@@ -399,62 +412,82 @@ __global__ __launch_bounds__(256) void k_fbb_score_diag32(segk_corpus c, segk_fb
     }
     __syncthreads();
     const double zc_empty = f.lms * log(prior_alpha / (double)KM);
-    const float LOG2E = 1.4426950408889634f;
-    float mx[FBB_R32], sm[FBB_R32];              // running maximum and sum of 2^(z log2 e - mx)
+    const int gsz = nt / NG, kk = tid % gsz, r0 = (tid / gsz) * RPG;       // this thread's slots kk, kk + gsz, ...; rows r0 .. r0 + RPG
+    const float *xg = xs + r0 * D;
+    float mx[RPG], sm[RPG];                      // running maximum and sum of 2^(z log2 e - mx)
 #pragma unroll
-    for (int r = 0; r < FBB_R32; r++) { mx[r] = -3.0e38f; sm[r] = 0.f; }
-    for (int k = tid; k < KM; k += nt) {
-        float z2[FBB_R32];
+    for (int r = 0; r < RPG; r++) { mx[r] = -3.0e38f; sm[r] = 0.f; }
+    for (int k = kk; k < KM; k += gsz) {
+        float z2[RPG];
         if (bt.cnt[k] > 0.0) {
-            float acc[FBB_R32];
+            float acc[RPG];
 #pragma unroll
-            for (int r = 0; r < FBB_R32; r++) acc[r] = 0.f;
+            for (int r = 0; r < RPG; r++) acc[r] = 0.f;
             int d = 0;
             for (; d + 4 <= D; d += 4) {
                 float m[4], q[4];
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    m[j] = (float)bt.mean_t[(int64_t)(d + j) * KM + k];
-                    q[j] = (float)bt.q_t[(int64_t)(d + j) * KM + k];
+                    m[j] = TLDS ? tm[(d + j) * KM + k] : (float)bt.mean_t[(int64_t)(d + j) * KM + k];
+                    q[j] = TLDS ? tq[(d + j) * KM + k] : (float)bt.q_t[(int64_t)(d + j) * KM + k];
                 }
 #pragma unroll
                 for (int j = 0; j < 4; j++)
 #pragma unroll
-                    for (int r = 0; r < FBB_R32; r++) {
-                        const float delta = m[j] - xs[r * D + d + j];
+                    for (int r = 0; r < RPG; r++) {
+                        const float delta = m[j] - xg[r * D + d + j];
                         acc[r] += __builtin_amdgcn_logf(1.f + (delta * delta) * q[j]);       // v_log_f32: log2
                     }
             }
             for (; d < D; d++) {
-                const float m = (float)bt.mean_t[(int64_t)d * KM + k], q = (float)bt.q_t[(int64_t)d * KM + k];
+                const float m = TLDS ? tm[d * KM + k] : (float)bt.mean_t[(int64_t)d * KM + k];
+                const float q = TLDS ? tq[d * KM + k] : (float)bt.q_t[(int64_t)d * KM + k];
 #pragma unroll
-                for (int r = 0; r < FBB_R32; r++) {
-                    const float delta = m - xs[r * D + d];
+                for (int r = 0; r < RPG; r++) {
+                    const float delta = m - xg[r * D + d];
                     acc[r] += __builtin_amdgcn_logf(1.f + (delta * delta) * q);
                 }
             }
             const double zc = bt.zconst[k], hl = bt.half[k] * 0.6931471805599453;
 #pragma unroll
-            for (int r = 0; r < FBB_R32; r++) z2[r] = (float)((zc - hl * (double)acc[r]) * 1.4426950408889634);
+            for (int r = 0; r < RPG; r++) z2[r] = (float)((zc - hl * (double)acc[r]) * 1.4426950408889634);
         } else {
 #pragma unroll
-            for (int r = 0; r < FBB_R32; r++) z2[r] = (float)((zc_empty + lpr[r]) * 1.4426950408889634);
+            for (int r = 0; r < RPG; r++) z2[r] = (float)((zc_empty + lpr[r0 + r]) * 1.4426950408889634);
         }
 #pragma unroll
-        for (int r = 0; r < FBB_R32; r++) {
+        for (int r = 0; r < RPG; r++) {
             const float nm = fmaxf(mx[r], z2[r]);
             sm[r] = sm[r] * __builtin_amdgcn_exp2f(mx[r] - nm) + __builtin_amdgcn_exp2f(z2[r] - nm);
             mx[r] = nm;
         }
     }
-    (void)LOG2E;
-    const double norm = f.lms * log(bt.scal[0] + prior_alpha);
+    // per row: the waves' (maximum, sum) by shuffles, then the four waves' by the row's thread -- one barrier for all rows
+    // (a block-wide maximum and a block-wide sum per row were 32 double barriers)
+    {
+        const int w = tid >> 6, lane = tid & 63;
 #pragma unroll
-    for (int r = 0; r < FBB_R32; r++) {
-        const double M = block_max((double)mx[r], red);
-        const double part = sm[r] == 0.f ? 0.0 : (double)sm[r] * exp2((double)mx[r] - M);
-        const double S = block_sum(part, red);
-        if (tid == 0 && r < nr) score[row0 + r] = (log2(S) + M) * 0.6931471805599453 - norm;
+        for (int r = 0; r < RPG; r++) {
+            float M = mx[r];
+            for (int o = 32; o > 0; o >>= 1) M = fmaxf(M, __shfl_xor(M, o));
+            float S = sm[r] == 0.f ? 0.f : sm[r] * __builtin_amdgcn_exp2f(mx[r] - M);
+            for (int o = 32; o > 0; o >>= 1) S += __shfl_xor(S, o);
+            // (with two thread groups a wave lies inside one group: 128 threads each)
+            if (lane == 0) { wm[w * FBB_R32 + r0 + r] = M; ws[w * FBB_R32 + r0 + r] = S; }
+        }
+        if (NG > 1) {                              // the rows of the other groups: neutral
+            for (int r = lane; r < FBB_R32; r += 64)
+                if (r < r0 || r >= r0 + RPG) { wm[w * FBB_R32 + r] = -3.0e38f; ws[w * FBB_R32 + r] = 0.f; }
+        }
+    }
+    __syncthreads();
+    if (tid < nr) {
+        const double norm = f.lms * log(bt.scal[0] + prior_alpha);
+        float M = wm[tid];
+        for (int w = 1; w < 4; w++) M = fmaxf(M, wm[w * FBB_R32 + tid]);
+        double S = 0.0;
+        for (int w = 0; w < 4; w++) S += ws[w * FBB_R32 + tid] == 0.f ? 0.0 : (double)ws[w * FBB_R32 + tid] * exp2((double)wm[w * FBB_R32 + tid] - (double)M);
+        score[row0 + tid] = (log2(S) + (double)M) * 0.6931471805599453 - norm;
     }
 }
 
@@ -1078,14 +1111,27 @@ int32_t segk_fbb_score_diag32(segk_ctx *ctx, const segk_corpus *c, const segk_fb
     if (rc) return rc;
     if (m.off[s_n] == 0) return SEGK_OK;
     const double alpha = f->lm_unigram ? f->lm_a : f->alpha;
-    const size_t lds = (size_t)(8 * c->D + FBB_R32 + 16) * sizeof(double) + (size_t)FBB_R32 * c->D * sizeof(float);
+    const size_t lds0 = (size_t)(8 * c->D + FBB_R32) * sizeof(double) + (size_t)(8 * FBB_R32 + FBB_R32 * c->D) * sizeof(float);
+    const size_t tbl = 2 * (size_t)c->D * f->K_max * sizeof(float);
+    const bool tlds = lds0 + tbl <= 60 * 1024;                // two workgroups per CU keep their tables
+    const bool two_groups = f->K_max <= 128;
+    const size_t lds = lds0 + (tlds ? tbl : 0);
     hipStream_t st = (hipStream_t)stream;
     const bool prof = ctx && ctx->prof_on != 0;
     const int slot = prof ? ctx->prof_n % SEGK_PROF_SLOTS : 0;
     int64_t rows = 0;
     for (int s = 0; s < s_n; s++) rows += n_rows[s];
     if (prof) SEGK_CHECK_HIP(hipEventRecord(ctx->prof_ev[slot][0], st));
-    DISPATCH_XT(c, hipLaunchKernelGGL((k_fbb_score_diag32<XT>), dim3(m.off[s_n]), dim3(256), lds, st, *c, *f, *bt, m, b, alpha, score););
+    DISPATCH_XT(c, {
+        if (lds > 48 * 1024) {
+            SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_fbb_score_diag32<XT, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_fbb_score_diag32<XT, 16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        }
+        if (tlds && two_groups) hipLaunchKernelGGL((k_fbb_score_diag32<XT, 8, true>), dim3(m.off[s_n]), dim3(256), lds, st, *c, *f, *bt, m, b, alpha, score);
+        else if (tlds) hipLaunchKernelGGL((k_fbb_score_diag32<XT, 16, true>), dim3(m.off[s_n]), dim3(256), lds, st, *c, *f, *bt, m, b, alpha, score);
+        else if (two_groups) hipLaunchKernelGGL((k_fbb_score_diag32<XT, 8, false>), dim3(m.off[s_n]), dim3(256), lds, st, *c, *f, *bt, m, b, alpha, score);
+        else hipLaunchKernelGGL((k_fbb_score_diag32<XT, 16, false>), dim3(m.off[s_n]), dim3(256), lds, st, *c, *f, *bt, m, b, alpha, score);
+    });
     if (prof) {
         SEGK_CHECK_HIP(hipEventRecord(ctx->prof_ev[slot][1], st));
         ctx->prof_rows[slot] = rows;
