@@ -132,13 +132,25 @@ __global__ void k_fbb_prepare(segk_fbgmm f, segk_fbatch bt, int D, int b, double
     const int S = bt.n_slices, B = bt.n_blocks, KM = f.K_max;
     const int64_t rec = fbb_rec(f, D);
     double (*my)[64] = scr[w];
-    // counts
-    for (int s = 0; s < S; s++) {
+    // sum over the blocks bp != b of partials[(bp * S + s) * rec + off], in block order; eight loads in flight at a time
+    // (one load per loop iteration made this kernel three dozen dependent round trips: 36 us)
+    auto sum_blocks = [&](int s, int64_t off) -> double {
         double a = 0.0;
-        for (int bp = 0; bp < B; bp++)
-            if (bp != b) a += bt.partials[((int64_t)bp * S + s) * rec + k];
-        my[s][lane] = a;
-    }
+        for (int bp0 = 0; bp0 < B; bp0 += 8) {
+            double v[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int bp = bp0 + j < B ? bp0 + j : B - 1;
+                v[j] = bt.partials[((int64_t)bp * S + s) * rec + off];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                if (bp0 + j < B && bp0 + j != b) a += v[j];
+        }
+        return a;
+    };
+    // counts
+    for (int s = 0; s < S; s++) my[s][lane] = sum_blocks(s, k);
     const double n = fbb_tree(&my[0][lane], S, 64);
     double lsum = 0.0;
     const double k_N = f.k_0 + n, v_N = f.v_0 + n;
@@ -146,20 +158,10 @@ __global__ void k_fbb_prepare(segk_fbgmm f, segk_fbatch bt, int D, int b, double
         const int d = d0 + lane;
         double sx = 0.0, sxx = 0.0;
         if (d < D) {
-            for (int s = 0; s < S; s++) {
-                double a = 0.0;
-                for (int bp = 0; bp < B; bp++)
-                    if (bp != b) a += bt.partials[((int64_t)bp * S + s) * rec + KM + (int64_t)k * D + d];
-                my[s][lane] = a;
-            }
+            for (int s = 0; s < S; s++) my[s][lane] = sum_blocks(s, KM + (int64_t)k * D + d);
             sx = fbb_tree(&my[0][lane], S, 64);
             if (f.cov_type == 1) {
-                for (int s = 0; s < S; s++) {
-                    double a = 0.0;
-                    for (int bp = 0; bp < B; bp++)
-                        if (bp != b) a += bt.partials[((int64_t)bp * S + s) * rec + KM + (int64_t)KM * D + (int64_t)k * D + d];
-                    my[s][lane] = a;
-                }
+                for (int s = 0; s < S; s++) my[s][lane] = sum_blocks(s, KM + (int64_t)KM * D + (int64_t)k * D + d);
                 sxx = fbb_tree(&my[0][lane], S, 64);
             }
             double mean, q, lt;
