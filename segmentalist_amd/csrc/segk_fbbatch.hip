@@ -759,6 +759,93 @@ __global__ void k_fbb_assign(segk_corpus c, segk_fbgmm f, segk_fbatch bt, FbbMap
 }
 
 // ---------------------------------------------------------------------------------------
+// The same with a language model and the token likelihoods from the matrix-core contraction: ONE WAVE per utterance.
+// The draws of an utterance are a chain (each needs the slot of the token before), and the block-wide form above
+// pays seven workgroup barriers per token for it; a wave needs none, and four times as many utterances are in flight.
+// Per token the same expressions in the same order; the sums keep the association of the block-wide form at 256 threads
+// (virtual thread v = 64 cw + lane sums the slots v, v + 256, ...; a butterfly per cw; the four results added in order),
+// so the probabilities and the draws are the same bits.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_fbb_assign_lm_wave(segk_corpus c, segk_fbgmm f, segk_fbatch bt, FbbMap map, int b, uint64_t sweep,
+                                                            double prior_alpha, double anneal_temp, const int32_t *new_tok,
+                                                            const int32_t *n_new, const float *llmat, int64_t ll_ld, int n_items)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int KM = f.K_max, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int item = blockIdx.x * 4 + w;
+    if (item >= n_items) return;
+    double *z = (double *)smem + (int64_t)w * KM;      // [K_max], this wave's
+    int s, idx;
+    if (!fbb_locate(map, item, &s, &idx)) return;
+    const int slice = map.lo[s];
+    const int utt = bt.utt_range[(slice * bt.n_blocks + b) * 2] + idx;
+    const int nn = n_new[utt];
+    const double LN2 = 0.6931471805599453;
+    const double zc_empty = f.lms * log(prior_alpha / (double)KM);
+    const double tot = bt.scal[0];
+    const double norm = f.lms * log(tot + prior_alpha);
+    const double n_empty = (double)KM - bt.scal[1];
+    auto sum_exp = [&](double shift) -> double {           // sum_k exp(z[k] - shift) in the order of block_sum at 256 threads
+        double acc = 0.0;
+        for (int cw = 0; cw < 4 && cw * 64 < KM; cw++) {
+            double sv = 0.0;
+            for (int k = cw * 64 + lane; k < KM; k += 256) sv += exp(z[k] - shift);
+            for (int o = 32; o > 0; o >>= 1) sv += __shfl_xor(sv, o);
+            acc = cw == 0 ? sv : acc + sv;
+        }
+        return acc;
+    };
+    int j_prev = -1;
+    for (int t = 0; t < nn; t++) {
+        const int64_t e = new_tok[(int64_t)utt * c.N_max + t];
+        const float *mrow = llmat + ((int64_t)item * c.N_max + t) * ll_ld;
+        double mx = NEG_INF_D;
+        for (int k = lane; k < KM; k += 64) {
+            const double n = bt.cnt[k];
+            const double llv = n > 0.0 ? (double)mrow[k] * LN2 - (bt.zconst[k] - bt.lconst[k]) + norm
+                                       : (double)mrow[KM] * LN2 - zc_empty - log(n_empty) + norm;
+            double pz;
+            if (j_prev < 0) pz = (log(n + f.lm_a / (double)KM) - log(tot + f.lm_a)) * f.lms;                       // bigram_lms.py:64-69
+            else {                                                                                              // bigram_lms.py:84-91
+                const double pi = (n + f.lm_a / (double)KM) / (tot + f.lm_a);
+                const double pij = (1. - f.lm_lambda) * ((double)f.lm_bigram[(int64_t)j_prev * KM + k] + f.lm_b / (double)KM)
+                                   / (bt.cnt[j_prev] + f.lm_b);
+                pz = log(f.lm_lambda * pi + pij) * f.lms;
+            }
+            const double v = pz + llv;
+            z[k] = v;
+            mx = v > mx ? v : mx;
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const double other = __shfl_xor(mx, o);
+            mx = other > mx ? other : mx;
+        }
+        double lse = log(sum_exp(mx)) + mx;
+        if (anneal_temp != 1.0) {                               // fbgmm.py:446-449
+            double mx2 = NEG_INF_D;
+            for (int k = lane; k < KM; k += 64) {
+                const double v = (1. / anneal_temp) * (z[k] - lse);
+                z[k] = v;
+                mx2 = v > mx2 ? v : mx2;
+            }
+            for (int o = 32; o > 0; o >>= 1) {
+                const double other = __shfl_xor(mx2, o);
+                mx2 = other > mx2 ? other : mx2;
+            }
+            lse = log(sum_exp(mx2)) + mx2;
+        }
+        for (int k = lane; k < KM; k += 64) z[k] = exp(z[k] - lse);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int kd = fb_draw_chunked(z, KM, segk_u01(bt.seed, sweep, (uint64_t)utt, (uint64_t)(c.N_max + t)), lane);
+        if (lane == 0) bt.slot[e] = kd;
+        j_prev = __shfl(kd, 0);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // language-model tables (integers): transcripts of block b, all slices, +/-; and the fill of the
 // replicated transcript store from the local slices' new tokens.
 //   lm_tok [B][S][U_max][N_max] int32 slots, -1 padded
@@ -1231,6 +1318,21 @@ int32_t segk_fbb_assign(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *f
     // 512 threads where the slots alone would leave most of 256 idle and the tokens' draws are independent (no language
     // model): four row groups in the likelihood phase, a wave per token in the draw phase
     const int nt_assign = (f->K_max <= 128 && !f->lm_unigram && rcap == FBB_R) ? 512 : 256;
+    // language model + matrix-core likelihoods: one wave per utterance (SEGK_FBB_ASSIGN_WAVE=0: the block-wide form)
+    const char *awe = getenv("SEGK_FBB_ASSIGN_WAVE");
+    if (f->lm_unigram && ll_mat && dbg == 0 && !(awe && atoi(awe) == 0) && 4 * (size_t)f->K_max * sizeof(double) <= 150 * 1024) {
+        const size_t ldsw = 4 * (size_t)f->K_max * sizeof(double);
+        static size_t ldsw_set = 0;
+        if (ldsw > 48 * 1024 && ldsw > ldsw_set) {
+            SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_fbb_assign_lm_wave, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw));
+            ldsw_set = ldsw;
+        }
+        const int n_items = m.off[s_n];
+        hipLaunchKernelGGL(k_fbb_assign_lm_wave, dim3((n_items + 3) / 4), dim3(256), ldsw, (hipStream_t)stream, *c, *f, *bt, m, b, sweep,
+                           alpha, anneal_temp, new_tok, n_new, ll_mat, ll_ld, n_items);
+        SEGK_LAUNCH_CHECK();
+        return SEGK_OK;
+    }
     DISPATCH_XT(c, {
         if (f->cov_type == 0) {
             if (lds > 48 * 1024)
