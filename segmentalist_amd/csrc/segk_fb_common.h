@@ -189,18 +189,39 @@ static __device__ double fb_dp_sample(const double *vec, double *a, double *w, d
     for (int t = 1; t < N; t++) {
         int lo = (n_max == 0 || t - n_max < 0) ? 0 : t - n_max;
         int n = t - lo;
-        bool all_inf = true;
-        double best = NEG_INF_D;
-        for (int s = lo; s < t; s++) {
-            double v = vec[i + s] + a[s];
-            if (lane == 0) w[s - lo] = v;
-            if (v != NEG_INF_D) all_inf = false;
-            if (v > best) best = v;
-        }
-        __builtin_amdgcn_wave_barrier();
         double at;
-        if (viterbi) at = best;
-        else at = all_inf ? NEG_INF_D : fb_logsumexp_wave(w, n, lane) + log_p_continue;
+        if (n <= 64) {
+            // one candidate per lane: the same maximum, the same exponentials and the same left-to-right sum as
+            // fb_logsumexp_wave, without the trip of the candidates through LDS (a serial loop of n dependent reads and
+            // stores per step)
+            const double v = lane < n ? vec[i + lo + lane] + a[lo + lane] : NEG_INF_D;
+            const bool all_inf = __ballot(lane < n && v != NEG_INF_D) == 0ull;
+            double mx = v;
+            for (int o = 32; o > 0; o >>= 1) {
+                const double other = __shfl_xor(mx, o);
+                mx = other > mx ? other : mx;
+            }
+            if (viterbi) at = mx;
+            else if (all_inf) at = NEG_INF_D;
+            else {
+                const double ej = lane < n ? exp(v - mx) : 0.0;
+                double sm = 0.0;
+                for (int q = 0; q < n; q++) sm += fb_readlane(ej, q);
+                at = log(sm) + mx + log_p_continue;
+            }
+        } else {
+            bool all_inf = true;
+            double best = NEG_INF_D;
+            for (int s = lo; s < t; s++) {
+                double v = vec[i + s] + a[s];
+                if (lane == 0) w[s - lo] = v;
+                if (v != NEG_INF_D) all_inf = false;
+                if (v > best) best = v;
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (viterbi) at = best;
+            else at = all_inf ? NEG_INF_D : fb_logsumexp_wave(w, n, lane) + log_p_continue;
+        }
         if (lane == 0) a[t] = at;
         __builtin_amdgcn_wave_barrier();
         i += t;

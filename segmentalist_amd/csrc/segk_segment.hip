@@ -590,7 +590,7 @@ int32_t segk_kmeans_segment(segk_ctx *ctx, const segk_corpus *c, const segk_kmea
     // over more than one round of resident waves until the DP of the one-per-wave kernel was spread over the wave
     // (seg_w8_wave: 10 000 utterances 40 -> 29 us)
     const char *x2e = getenv("SEGK_SEGMENT_X2");
-    const int n_cu_ = ctx ? ctx->n_cu : 256;
+    (void)ctx;
     if (w8_ok && c->N_max <= 32 && 2 * waves * wave_bytes <= 48 * 1024 && (x2e ? atoi(x2e) != 0 : false)) {
         const int per_block = 2 * waves;
         hipLaunchKernelGGL(k_kmeans_segment_w8x2, dim3((n_utts + per_block - 1) / per_block), dim3(64 * waves), 2 * lds, st, *c, *m, utts,
