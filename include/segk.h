@@ -561,6 +561,14 @@ int32_t segk_fbb_assign(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *f
                         const int32_t *n_utts, uint64_t sweep, double anneal_temp,
                         const int32_t *new_tok, const int32_t *n_new, const float *ll_mat,
                         int64_t ll_ld, void *stream);
+/* The same with the token likelihoods of diagonal (Student-t) components in float32 -- v_log_f32 terms as in
+ * segk_fbb_score_diag32, z and the draws in fp64 as above (`score_precision="f32"`: log-likelihoods within 1e-4
+ * relative of the fp64 form; the fp64 software logarithm of K_max * D terms per token is otherwise most of the
+ * assignment step).                                                                                        */
+int32_t segk_fbb_assign_diag32(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *f,
+                               const segk_fbatch *bt, int32_t s_lo, int32_t s_n, int32_t b,
+                               const int32_t *n_utts, uint64_t sweep, double anneal_temp,
+                               const int32_t *new_tok, const int32_t *n_new, void *stream);
 /* ll_mat of segk_fbb_assign (optional; fixed-variance components with the fp16x2 images): the token
  * likelihoods come from the matrix-core contraction instead of the fp64 VALU loop.  Row j*N_max + t of
  * ll_mat [n, ll_ld] belongs to segment t of the j-th utterance of the block (local slices in order);

@@ -125,6 +125,7 @@ SIGNATURES = {
     "segk_fbb_segment": (_i32, [_P, _CP, _FP, _BP, _i32, _i32, _i32, _P, _u64, _i32, _i32, _f64, _f64, _f64, _P, _P,
                                 _P, _P, _P, _P, _P]),
     "segk_fbb_assign": (_i32, [_P, _CP, _FP, _BP, _i32, _i32, _i32, _P, _u64, _f64, _P, _P, _P, _i64, _P]),
+    "segk_fbb_assign_diag32": (_i32, [_P, _CP, _FP, _BP, _i32, _i32, _i32, _P, _u64, _f64, _P, _P, _P]),
     "segk_fbb_token_scores": (_i32, [_P, _CP, _FP, _BP, _P, _i64, _P, _i64, _P]),
     "segk_fbb_lm_apply": (_i32, [_P, _CP, _FP, _BP, _i32, _i32, _P]),
     "segk_fbb_lm_fill": (_i32, [_P, _CP, _FP, _BP, _i32, _i32, _i32, _P, _P, _P, _P]),

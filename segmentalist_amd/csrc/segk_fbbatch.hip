@@ -265,6 +265,38 @@ static __device__ __forceinline__ void fbb_accumulate_rows(const segk_fbatch &bt
     }
 }
 
+// the diagonal (Student-t) terms of NR rows in float32 with the hardware logarithm (log2; the caller multiplies by ln 2):
+// the arithmetic of k_fbb_score_diag32, for the token likelihoods of the assignment step (`score_precision="f32"`)
+template <int NR>
+static __device__ __forceinline__ void fbb_accumulate_rows32(const segk_fbatch &bt, int KM, int k, int D, const double *xs, float *acc)
+{
+    int d = 0;
+    for (; d + 4 <= D; d += 4) {
+        float m[4], q[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            m[j] = (float)bt.mean_t[(int64_t)(d + j) * KM + k];
+            q[j] = (float)bt.q_t[(int64_t)(d + j) * KM + k];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+#pragma unroll
+            for (int r = 0; r < NR; r++) {
+                const float delta = m[j] - (float)xs[r * D + d + j];
+                acc[r] += __builtin_amdgcn_logf(1.f + (delta * delta) * q[j]);
+            }
+        }
+    }
+    for (; d < D; d++) {
+        const float m = (float)bt.mean_t[(int64_t)d * KM + k], q = (float)bt.q_t[(int64_t)d * KM + k];
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            const float delta = m - (float)xs[r * D + d];
+            acc[r] += __builtin_amdgcn_logf(1.f + (delta * delta) * q);
+        }
+    }
+}
+
 // x-dependent part of the prior predictive of one row, by one wave (lanes over d); result in all lanes
 template <typename XT>
 static __device__ double fbb_prior_row(const segk_fbgmm &f, int D, const double *x, int lane)
@@ -567,7 +599,7 @@ __global__ void k_fbb_segment(segk_corpus c, segk_fbatch bt, FbbMap map, int b, 
 // ---------------------------------------------------------------------------------------
 // slots of the new tokens of one utterance per workgroup
 // ---------------------------------------------------------------------------------------
-template <typename XT, int COV>
+template <typename XT, int COV, int F32 = 0>
 __global__ void k_fbb_assign(segk_corpus c, segk_fbgmm f, segk_fbatch bt, FbbMap map, int b, uint64_t sweep,
                              double prior_alpha, double anneal_temp, const int32_t *new_tok, const int32_t *n_new,
                              int rcap, int dbg, const float *llmat, int64_t ll_ld)
@@ -629,6 +661,12 @@ __global__ void k_fbb_assign(segk_corpus c, segk_fbgmm f, segk_fbatch bt, FbbMap
             if (k < KM && r0 < nr) {
                 if (bt.cnt[k] > 0.0) {
                     double acc[2] = {0.0, 0.0};
+                    if (F32) {
+                        float a32[2] = {0.f, 0.f};
+                        fbb_accumulate_rows32<2>(bt, KM, k, (dbg & 1) ? 1 : D, xs + r0 * D, a32);
+                        acc[0] = 0.6931471805599453 * (double)a32[0];
+                        acc[1] = 0.6931471805599453 * (double)a32[1];
+                    } else
                     fbb_accumulate_rows<COV, 2>(bt, KM, k, (dbg & 1) ? 1 : D, xs + r0 * D, acc);
                     const double lc = bt.lconst[k], h = bt.half[k];
                     ll[(int64_t)r0 * KM + k] = lc - h * acc[0];
@@ -644,6 +682,14 @@ __global__ void k_fbb_assign(segk_corpus c, segk_fbgmm f, segk_fbatch bt, FbbMap
                 double acc[FBB_R];
 #pragma unroll
                 for (int r = 0; r < FBB_R; r++) acc[r] = 0.0;
+                if (F32) {
+                    float a32[FBB_R];
+#pragma unroll
+                    for (int r = 0; r < FBB_R; r++) a32[r] = 0.f;
+                    fbb_accumulate_rows32<FBB_R>(bt, KM, k, (dbg & 1) ? 1 : D, xs, a32);
+#pragma unroll
+                    for (int r = 0; r < FBB_R; r++) acc[r] = 0.6931471805599453 * (double)a32[r];
+                } else
                 fbb_accumulate<COV>(bt, KM, k, (dbg & 1) ? 1 : D, xs, acc);
                 const double lc = bt.lconst[k], h = bt.half[k];
 #pragma unroll
@@ -1294,9 +1340,10 @@ int32_t segk_fbb_token_scores(segk_ctx *ctx, const segk_corpus *c, const segk_fb
                                     stream);
 }
 
-int32_t segk_fbb_assign(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *f, const segk_fbatch *bt, int32_t s_lo,
-                        int32_t s_n, int32_t b, const int32_t *n_utts, uint64_t sweep, double anneal_temp,
-                        const int32_t *new_tok, const int32_t *n_new, const float *ll_mat, int64_t ll_ld, void *stream)
+static int32_t fbb_assign_impl(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *f, const segk_fbatch *bt, int32_t s_lo,
+                               int32_t s_n, int32_t b, const int32_t *n_utts, uint64_t sweep, double anneal_temp,
+                               const int32_t *new_tok, const int32_t *n_new, const float *ll_mat, int64_t ll_ld, int f32,
+                               void *stream)
 {
     (void)ctx;
     int rc = check_fbb(c, f, bt);
@@ -1344,12 +1391,34 @@ int32_t segk_fbb_assign(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *f
             if (lds > 48 * 1024)
                 SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_fbb_assign<XT, 1>,
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            if (f32) {
+                if (lds > 48 * 1024)
+                    SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_fbb_assign<XT, 1, 1>,
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL((k_fbb_assign<XT, 1, 1>), dim3(m.off[s_n]), dim3(nt_assign), lds, (hipStream_t)stream, *c, *f, *bt, m,
+                                   b, sweep, alpha, anneal_temp, new_tok, n_new, rcap, dbg, ll_mat, ll_ld);
+            } else
             hipLaunchKernelGGL((k_fbb_assign<XT, 1>), dim3(m.off[s_n]), dim3(nt_assign), lds, (hipStream_t)stream, *c, *f, *bt, m,
                                b, sweep, alpha, anneal_temp, new_tok, n_new, rcap, dbg, ll_mat, ll_ld);
         }
     });
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;
+}
+
+int32_t segk_fbb_assign(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *f, const segk_fbatch *bt, int32_t s_lo,
+                        int32_t s_n, int32_t b, const int32_t *n_utts, uint64_t sweep, double anneal_temp,
+                        const int32_t *new_tok, const int32_t *n_new, const float *ll_mat, int64_t ll_ld, void *stream)
+{
+    return fbb_assign_impl(ctx, c, f, bt, s_lo, s_n, b, n_utts, sweep, anneal_temp, new_tok, n_new, ll_mat, ll_ld, 0, stream);
+}
+
+int32_t segk_fbb_assign_diag32(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *f, const segk_fbatch *bt, int32_t s_lo,
+                               int32_t s_n, int32_t b, const int32_t *n_utts, uint64_t sweep, double anneal_temp,
+                               const int32_t *new_tok, const int32_t *n_new, void *stream)
+{
+    SEGK_REQUIRE(f && f->cov_type == 1, "the float32 token likelihoods of this entry point are the diagonal (Student-t) ones");
+    return fbb_assign_impl(ctx, c, f, bt, s_lo, s_n, b, n_utts, sweep, anneal_temp, new_tok, n_new, nullptr, 0, 1, stream);
 }
 
 int32_t segk_fbb_lm_apply(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *f, const segk_fbatch *bt, int32_t b,

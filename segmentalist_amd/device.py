@@ -897,6 +897,9 @@ class FbgmmBatchSweeper(object):
                 check(L.segk_fbb_token_scores(ctx, cp, fp, bp, ptr(rows), tm.numel(), ptr(self.ll_mat), self.ll_ld, st))
                 check(L.segk_fbb_assign(ctx, cp, fp, bp, self.s_lo, self.s_n, b, self._n_utts[b], sw, float(anneal_temp_am),
                                         ptr(df.new_tok), ptr(df.n_new), ptr(self.ll_mat), self.ll_ld, st))
+            elif self.score_diag32:
+                check(L.segk_fbb_assign_diag32(ctx, cp, fp, bp, self.s_lo, self.s_n, b, self._n_utts[b], sw,
+                                               float(anneal_temp_am), ptr(df.new_tok), ptr(df.n_new), st))
             else:
                 check(L.segk_fbb_assign(ctx, cp, fp, bp, self.s_lo, self.s_n, b, self._n_utts[b], sw, float(anneal_temp_am),
                                         ptr(df.new_tok), ptr(df.n_new), None, 0, st))

@@ -199,9 +199,10 @@ def test_matrix_core_span_scores_within_tolerance(gpu, kind, n_utt, D, K, nmax, 
     assert worst < 1e-4, (worst, worst_abs)
 
 
-@pytest.mark.parametrize("kind,prec", [("fixed", "f32"), ("fixed", "f16"), ("bigram", "f16")])
+@pytest.mark.parametrize("kind,prec", [("fixed", "f32"), ("fixed", "f16"), ("bigram", "f16"), ("diag", "f32")])
 def test_matrix_core_mode_samples_a_valid_chain(gpu, kind, prec):
-    """Full sweeps with matrix-core scores (f16: also the token likelihoods of the assignment step): the
+    """Full sweeps with matrix-core scores (f16: also the token likelihoods of the assignment step; diagonal components
+    in f32: span scores AND token likelihoods from float32 Student-t terms, segk_fbb_assign_diag32): the
     chain stays close to the f64 chain (equal boundaries and slots for the vast majority of utterances
     after one sweep -- a draw only flips when a uniform falls within ~1e-5 of a cumulative boundary) and
     the state invariants hold."""
