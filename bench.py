@@ -210,7 +210,8 @@ def main_fbgmm(args):
             "window_ms_per_step": {"min": 1e3 * min(win) / args.steps, "median": 1e3 * elapsed / args.steps,
                                    "max": 1e3 * max(win) / args.steps},
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32 span scores, f64 sampling" if (bigram or diag32) else "f64", "data": "synthetic",
+            "dtype": ("f32 span scores and token likelihoods, f64 sampling" if diag32 else
+                      "f32 span scores, f64 sampling" if bigram else "f64"), "data": "synthetic",
             "config": {"workload": "%s batch-synchronous blocked Gibbs sweep, 8 blocks (BASELINE.json configs[%d])"
                                    % ("BigramAcousticWordseg" if bigram else "UnigramAcousticWordseg + FBGMM (diag)",
                                       4 if bigram else 1),
