@@ -812,6 +812,7 @@ __global__ void k_fbb_assign(segk_corpus c, segk_fbgmm f, segk_fbatch bt, FbbMap
 // (virtual thread v = 64 cw + lane sums the slots v, v + 256, ...; a butterfly per cw; the four results added in order),
 // so the probabilities and the draws are the same bits.
 // ---------------------------------------------------------------------------------------
+template <int F32>
 __global__ __launch_bounds__(256) void k_fbb_assign_lm_wave(segk_corpus c, segk_fbgmm f, segk_fbatch bt, FbbMap map, int b, uint64_t sweep,
                                                             double prior_alpha, double anneal_temp, const int32_t *new_tok,
                                                             const int32_t *n_new, const float *llmat, int64_t ll_ld, int n_items)
@@ -842,6 +843,69 @@ __global__ __launch_bounds__(256) void k_fbb_assign_lm_wave(segk_corpus c, segk_
         return acc;
     };
     int j_prev = -1;
+    if (F32) {
+        // The matrix-core modes (`score_precision` f32 / f16: log-likelihoods within 1e-4 relative) take the token
+        // likelihoods as float32 already; here the softmax follows: K_max hardware logarithms and 2 K_max hardware
+        // exponentials per token (v_log_f32 / v_exp_f32 on differences that were formed in fp64) instead of 3 K_max fp64
+        // software ones -- the step was bound by them (290 us per Gibbs step of bigram_c5).  Probabilities carry ~3e-6
+        // relative error; a draw changes when the uniform falls that close to a cumulative boundary.
+        const float LOG2E = 1.4426950408889634f;
+        const double le = log(n_empty), ltot = log(tot + f.lm_a), inv_tot = 1. / (tot + f.lm_a), aK = f.lm_a / (double)KM, bK = f.lm_b / (double)KM;
+        for (int t = 0; t < nn; t++) {
+            const int64_t e = new_tok[(int64_t)utt * c.N_max + t];
+            const float *mrow = llmat + ((int64_t)item * c.N_max + t) * ll_ld;
+            const double inv_prev = j_prev >= 0 ? (1. - f.lm_lambda) / (bt.cnt[j_prev] + f.lm_b) : 0.0;
+            const double empty_ll = (double)mrow[KM] * LN2 - zc_empty - le + norm;
+            double mx = NEG_INF_D;
+            for (int k = lane; k < KM; k += 64) {
+                const double n = bt.cnt[k];
+                const double llv = n > 0.0 ? (double)mrow[k] * LN2 - (bt.zconst[k] - bt.lconst[k]) + norm : empty_ll;
+                double pz;
+                if (j_prev < 0) pz = ((double)(__builtin_amdgcn_logf((float)(n + aK)) * 0.6931471805599453f) - ltot) * f.lms;      // bigram_lms.py:64-69
+                else {                                                                                                          // bigram_lms.py:84-91
+                    const double pi = (n + aK) * inv_tot;
+                    const double pij = ((double)f.lm_bigram[(int64_t)j_prev * KM + k] + bK) * inv_prev;
+                    pz = (double)(__builtin_amdgcn_logf((float)(f.lm_lambda * pi + pij)) * 0.6931471805599453f) * f.lms;
+                }
+                const double v = pz + llv;
+                z[k] = v;
+                mx = v > mx ? v : mx;
+            }
+            for (int o = 32; o > 0; o >>= 1) {
+                const double other = __shfl_xor(mx, o);
+                mx = other > mx ? other : mx;
+            }
+            auto sum_exp32 = [&](double shift) -> double {
+                double sv = 0.0;
+                for (int k = lane; k < KM; k += 64) sv += (double)__builtin_amdgcn_exp2f((float)(z[k] - shift) * LOG2E);
+                for (int o = 32; o > 0; o >>= 1) sv += __shfl_xor(sv, o);
+                return sv;
+            };
+            double lse = log(sum_exp32(mx)) + mx;
+            if (anneal_temp != 1.0) {                               // fbgmm.py:446-449
+                double mx2 = NEG_INF_D;
+                for (int k = lane; k < KM; k += 64) {
+                    const double v = (1. / anneal_temp) * (z[k] - lse);
+                    z[k] = v;
+                    mx2 = v > mx2 ? v : mx2;
+                }
+                for (int o = 32; o > 0; o >>= 1) {
+                    const double other = __shfl_xor(mx2, o);
+                    mx2 = other > mx2 ? other : mx2;
+                }
+                lse = log(sum_exp32(mx2)) + mx2;
+            }
+            for (int k = lane; k < KM; k += 64) z[k] = (double)__builtin_amdgcn_exp2f((float)(z[k] - lse) * LOG2E);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int kd = fb_draw_chunked(z, KM, segk_u01(bt.seed, sweep, (uint64_t)utt, (uint64_t)(c.N_max + t)), lane);
+            if (lane == 0) bt.slot[e] = kd;
+            j_prev = __shfl(kd, 0);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        return;
+    }
     for (int t = 0; t < nn; t++) {
         const int64_t e = new_tok[(int64_t)utt * c.N_max + t];
         const float *mrow = llmat + ((int64_t)item * c.N_max + t) * ll_ld;
@@ -1371,12 +1435,18 @@ static int32_t fbb_assign_impl(segk_ctx *ctx, const segk_corpus *c, const segk_f
         const size_t ldsw = 4 * (size_t)f->K_max * sizeof(double);
         static size_t ldsw_set = 0;
         if (ldsw > 48 * 1024 && ldsw > ldsw_set) {
-            SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_fbb_assign_lm_wave, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw));
+            SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_fbb_assign_lm_wave<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw));
+            SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_fbb_assign_lm_wave<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw));
             ldsw_set = ldsw;
         }
         const int n_items = m.off[s_n];
-        hipLaunchKernelGGL(k_fbb_assign_lm_wave, dim3((n_items + 3) / 4), dim3(256), ldsw, (hipStream_t)stream, *c, *f, *bt, m, b, sweep,
-                           alpha, anneal_temp, new_tok, n_new, ll_mat, ll_ld, n_items);
+        // SEGK_FBB_ASSIGN_WAVE=2: the softmax with the fp64 library functions (the bits of the block-wide form)
+        if (awe && atoi(awe) == 2)
+            hipLaunchKernelGGL(k_fbb_assign_lm_wave<0>, dim3((n_items + 3) / 4), dim3(256), ldsw, (hipStream_t)stream, *c, *f, *bt, m, b,
+                               sweep, alpha, anneal_temp, new_tok, n_new, ll_mat, ll_ld, n_items);
+        else
+            hipLaunchKernelGGL(k_fbb_assign_lm_wave<1>, dim3((n_items + 3) / 4), dim3(256), ldsw, (hipStream_t)stream, *c, *f, *bt, m, b,
+                               sweep, alpha, anneal_temp, new_tok, n_new, ll_mat, ll_ld, n_items);
         SEGK_LAUNCH_CHECK();
         return SEGK_OK;
     }
