@@ -851,6 +851,80 @@ __global__ __launch_bounds__(256) void k_fbb_assign_lm_wave(segk_corpus c, segk_
         // relative error; a draw changes when the uniform falls that close to a cumulative boundary.
         const float LOG2E = 1.4426950408889634f;
         const double le = log(n_empty), ltot = log(tot + f.lm_a), inv_tot = 1. / (tot + f.lm_a), aK = f.lm_a / (double)KM, bK = f.lm_b / (double)KM;
+        if (KM <= 64 * 16) {
+            // up to 16 slots per lane: what does not change from token to token (counts, constants) stays in registers for
+            // the utterance, and a token's loads (likelihood row, bigram row) are all issued before the first is used --
+            // a plain loop over the slots waited for five loads per slot, sixteen times per token
+            constexpr int KPL = 16;
+            double cn[KPL], zl[KPL];
+#pragma unroll
+            for (int j = 0; j < KPL; j++) {
+                const int k = lane + 64 * j, kc = k < KM ? k : KM - 1;
+                cn[j] = bt.cnt[kc];
+                zl[j] = bt.zconst[kc] - bt.lconst[kc];
+            }
+            for (int t = 0; t < nn; t++) {
+                const int64_t e = new_tok[(int64_t)utt * c.N_max + t];
+                const float *mrow = llmat + ((int64_t)item * c.N_max + t) * ll_ld;
+                const double inv_prev = j_prev >= 0 ? (1. - f.lm_lambda) / (bt.cnt[j_prev] + f.lm_b) : 0.0;
+                const double empty_ll = (double)mrow[KM] * LN2 - zc_empty - le + norm;
+                float mr[KPL];
+                long long bg[KPL];
+#pragma unroll
+                for (int j = 0; j < KPL; j++) {
+                    const int k = lane + 64 * j, kc = k < KM ? k : KM - 1;
+                    mr[j] = mrow[kc];
+                    bg[j] = j_prev >= 0 ? f.lm_bigram[(int64_t)j_prev * KM + kc] : 0;
+                }
+                double zv[KPL], mx = NEG_INF_D;
+#pragma unroll
+                for (int j = 0; j < KPL; j++) {
+                    const double n = cn[j];
+                    const double llv = n > 0.0 ? (double)mr[j] * LN2 - zl[j] + norm : empty_ll;
+                    double pz;
+                    if (j_prev < 0) pz = ((double)(__builtin_amdgcn_logf((float)(n + aK)) * 0.6931471805599453f) - ltot) * f.lms;
+                    else pz = (double)(__builtin_amdgcn_logf((float)(f.lm_lambda * ((n + aK) * inv_tot) + ((double)bg[j] + bK) * inv_prev)) * 0.6931471805599453f) * f.lms;
+                    zv[j] = lane + 64 * j < KM ? pz + llv : NEG_INF_D;
+                    mx = zv[j] > mx ? zv[j] : mx;
+                }
+                for (int o = 32; o > 0; o >>= 1) {
+                    const double other = __shfl_xor(mx, o);
+                    mx = other > mx ? other : mx;
+                }
+                auto sum_reg = [&](double shift) -> double {
+                    double sv = 0.0;
+#pragma unroll
+                    for (int j = 0; j < KPL; j++) sv += (double)__builtin_amdgcn_exp2f((float)(zv[j] - shift) * LOG2E);      // 2^-inf = 0 for the slots beyond K_max
+                    for (int o = 32; o > 0; o >>= 1) sv += __shfl_xor(sv, o);
+                    return sv;
+                };
+                double lse = log(sum_reg(mx)) + mx;
+                if (anneal_temp != 1.0) {                               // fbgmm.py:446-449
+                    double mx2 = NEG_INF_D;
+#pragma unroll
+                    for (int j = 0; j < KPL; j++) {
+                        zv[j] = (1. / anneal_temp) * (zv[j] - lse);
+                        mx2 = zv[j] > mx2 ? zv[j] : mx2;
+                    }
+                    for (int o = 32; o > 0; o >>= 1) {
+                        const double other = __shfl_xor(mx2, o);
+                        mx2 = other > mx2 ? other : mx2;
+                    }
+                    lse = log(sum_reg(mx2)) + mx2;
+                }
+#pragma unroll
+                for (int j = 0; j < KPL; j++)
+                    if (lane + 64 * j < KM) z[lane + 64 * j] = (double)__builtin_amdgcn_exp2f((float)(zv[j] - lse) * LOG2E);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const int kd = fb_draw_chunked(z, KM, segk_u01(bt.seed, sweep, (uint64_t)utt, (uint64_t)(c.N_max + t)), lane);
+                if (lane == 0) bt.slot[e] = kd;
+                j_prev = __shfl(kd, 0);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+            return;
+        }
         for (int t = 0; t < nn; t++) {
             const int64_t e = new_tok[(int64_t)utt * c.N_max + t];
             const float *mrow = llmat + ((int64_t)item * c.N_max + t) * ll_ld;
