@@ -107,6 +107,143 @@ __global__ void k_fbb_partials(segk_corpus c, segk_fbgmm f, segk_fbatch bt, int 
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// The same in two steps for banks of many slots.  Above, every (slice, slot) wave walks ALL utterances of the block --
+// two dependent loads per utterance, 1 250 utterances, 1 000 waves: 115 us per Gibbs step of bigram_c5.  Here one
+// workgroup per slice first buckets the block's tokens by slot -- a stable counting sort: per-wave histograms in LDS, the
+// waves own contiguous runs of token positions, the rank of a token among the equal keys of its 64 comes from ballots --
+// and the (slice, slot) waves then sum their own lists, in token order as before: the same additions in the same order.
+// ---------------------------------------------------------------------------------------
+#define FBS_THREADS 1024
+#define FBS_WAVES 16
+__global__ __launch_bounds__(FBS_THREADS) void k_fbb_sort(segk_corpus c, segk_fbgmm f, segk_fbatch bt, int s_lo, int b,
+                                                        const int32_t *new_tok, const int32_t *n_new, int32_t *sorted,
+                                                        int64_t sorted_stride, int32_t *koff)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int KM = f.K_max, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int32_t *cntw = (int32_t *)smem;                 // [FBS_WAVES][KM]
+    int32_t *wsum = cntw + FBS_WAVES * KM;           // [FBS_WAVES + 1]
+    const int s = s_lo + blockIdx.x;
+    const int u0 = bt.utt_range[(s * bt.n_blocks + b) * 2], u1 = bt.utt_range[(s * bt.n_blocks + b) * 2 + 1];
+    const int S = (u1 - u0) * c.N_max;               // token positions (utterance-major), most of them unused
+    const int per = ((S + FBS_WAVES - 1) / FBS_WAVES + 63) & ~63;
+    int32_t *out = sorted + (int64_t)blockIdx.x * sorted_stride;
+    int32_t *ko = koff + (int64_t)blockIdx.x * (KM + 1);
+    int nbits = 1;
+    while ((1 << nbits) < KM) nbits++;
+    for (int i = tid; i < FBS_WAVES * KM; i += FBS_THREADS) cntw[i] = 0;
+    __syncthreads();
+    auto key_of = [&](int p, int32_t *id_out) -> int {
+        int key = -1;
+        *id_out = -1;
+        if (p < S) {
+            const int u = u0 + p / c.N_max, j = p % c.N_max;
+            if (j < n_new[u]) {
+                const int32_t id = new_tok[(int64_t)u * c.N_max + j];
+                *id_out = id;
+                key = bt.slot[id];
+            }
+        }
+        return key;
+    };
+    const int p_lo = wv * per, p_hi = p_lo + per < S ? p_lo + per : S;
+    for (int p0 = p_lo; p0 < p_hi; p0 += 64) {
+        int32_t id;
+        const int key = key_of(p0 + lane < p_hi ? p0 + lane : S, &id);
+        if (key >= 0) atomicAdd(&cntw[wv * KM + key], 1);
+    }
+    __syncthreads();
+    // per slot: the waves' counts -> running offsets inside the slot; the slots' totals -> an exclusive scan over the slots
+    int tot = 0;
+    if (tid < KM)
+        for (int w = 0; w < FBS_WAVES; w++) {
+            const int v = cntw[w * KM + tid];
+            cntw[w * KM + tid] = tot;
+            tot += v;
+        }
+    int incl = tot;                                 // inclusive scan over the threads (slots tid = 0 .. KM - 1; KM <= 1024)
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int w = 0; w < FBS_WAVES; w++) { const int v = wsum[w]; wsum[w] = run; run += v; }
+        wsum[FBS_WAVES] = run;
+    }
+    __syncthreads();
+    const int base = wsum[wv] + incl - tot;         // first position of slot tid
+    if (tid < KM) {
+        ko[tid] = base;
+        for (int w = 0; w < FBS_WAVES; w++) cntw[w * KM + tid] += base;
+    }
+    if (tid == 0) ko[KM] = wsum[FBS_WAVES];
+    __syncthreads();
+    // placement: every wave walks its run again, 64 positions at a time in order
+    for (int p0 = p_lo; p0 < p_hi; p0 += 64) {
+        int32_t id;
+        const int key = key_of(p0 + lane < p_hi ? p0 + lane : S, &id);
+        const bool ok = key >= 0;
+        unsigned long long mask = __ballot(ok);
+        for (int bit = 0; bit < nbits; bit++) {
+            const unsigned long long bal = __ballot((key >> bit) & 1);
+            mask &= ((key >> bit) & 1) ? bal : ~bal;
+        }
+        if (ok) {
+            const int rank = __popcll(mask & ((1ull << lane) - 1ull));
+            const int o = cntw[wv * KM + key];
+            out[o + rank] = id;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (ok && (mask & ((1ull << lane) - 1ull)) == 0ull) cntw[wv * KM + key] += __popcll(mask);      // the first lane of every key
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <typename XT>
+__global__ void k_fbb_partials_sorted(segk_corpus c, segk_fbgmm f, segk_fbatch bt, int s_lo, int s_n, int b,
+                                      const int32_t *sorted, int64_t sorted_stride, const int32_t *koff)
+{
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (wave >= s_n * f.K_max) return;
+    const int si = wave / f.K_max, s = s_lo + si, k = wave % f.K_max;
+    const int D = c.D;
+    const XT *X = (const XT *)c.X;
+    const int32_t *list = sorted + (int64_t)si * sorted_stride;
+    const int q0 = koff[(int64_t)si * (f.K_max + 1) + k], q1 = koff[(int64_t)si * (f.K_max + 1) + k + 1];
+    double ax[FBB_MAXCH], axx[FBB_MAXCH];
+#pragma unroll
+    for (int q = 0; q < FBB_MAXCH; q++) { ax[q] = 0.0; axx[q] = 0.0; }
+    for (int t = q0; t < q1; t++) {                     // token order
+        const int64_t e = list[t];
+#pragma unroll
+        for (int q = 0; q < FBB_MAXCH; q++) {
+            const int d = q * 64 + lane;
+            if (d < D) {
+                const XT x = X[e * c.ldx + d];
+                ax[q] += (double)x;
+                axx[q] += fbb_sq<XT>(x);
+            }
+        }
+    }
+    double *rec = bt.partials + ((int64_t)b * bt.n_slices + s) * fbb_rec(f, D);
+    if (lane == 0) rec[k] = (double)(q1 - q0);
+#pragma unroll
+    for (int q = 0; q < FBB_MAXCH; q++) {
+        const int d = q * 64 + lane;
+        if (d < D) {
+            rec[f.K_max + (int64_t)k * D + d] = ax[q];
+            rec[f.K_max + (int64_t)f.K_max * D + (int64_t)k * D + d] = axx[q];
+        }
+    }
+}
+
 // the pairing of oracle tree_sum: [(0+1), (2+3), ...], odd element carried
 static __device__ __forceinline__ double fbb_tree(double *p, int n, int stride)
 {
@@ -1283,11 +1420,37 @@ int32_t segk_fbb_partials(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm 
                           int32_t s_lo, int32_t s_n, int32_t b, const int32_t *new_tok, const int32_t *n_new,
                           void *stream)
 {
-    (void)ctx;
     int rc = check_fbb(c, f, bt);
     if (rc) return rc;
     SEGK_REQUIRE(s_lo >= 0 && s_n >= 1 && s_lo + s_n <= bt->n_slices && b >= 0 && b < bt->n_blocks, "slice / block range");
     const int64_t waves = (int64_t)s_n * f->K_max;
+    // many slots: bucket the tokens by slot first (k_fbb_sort), then every slot sums its own list; SEGK_FBB_SORT=0: the
+    // one-step kernel.  LDS of the sort: 16 waves x K_max counters.
+    const char *se = getenv("SEGK_FBB_SORT");
+    const size_t lds_sort = ((size_t)FBS_WAVES * f->K_max + FBS_WAVES + 1) * sizeof(int32_t);
+    if (ctx && f->K_max >= 256 && f->K_max <= 1024 && lds_sort <= 150 * 1024 && !(se && atoi(se) == 0)) {
+        const int64_t stride = (int64_t)c->n_utt * c->N_max;             // more than any (slice, block) can hold
+        const size_t need = ((size_t)s_n * stride + (size_t)s_n * (f->K_max + 1)) * sizeof(int32_t);
+        if (ctx->fbs_bytes < need) {
+            if (ctx->fbs_buf) (void)hipFree(ctx->fbs_buf);
+            ctx->fbs_buf = nullptr;
+            ctx->fbs_bytes = 0;
+            SEGK_CHECK_HIP(hipMalloc((void **)&ctx->fbs_buf, need));
+            ctx->fbs_bytes = need;
+        }
+        int32_t *sorted = ctx->fbs_buf, *koff = ctx->fbs_buf + (size_t)s_n * stride;
+        static size_t lds_set = 0;
+        if (lds_sort > 48 * 1024 && lds_sort > lds_set) {
+            SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_fbb_sort, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sort));
+            lds_set = lds_sort;
+        }
+        hipLaunchKernelGGL(k_fbb_sort, dim3(s_n), dim3(FBS_THREADS), lds_sort, (hipStream_t)stream, *c, *f, *bt, s_lo, b, new_tok, n_new,
+                           sorted, stride, koff);
+        DISPATCH_XT(c, hipLaunchKernelGGL(k_fbb_partials_sorted<XT>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0,
+                                           (hipStream_t)stream, *c, *f, *bt, s_lo, s_n, b, sorted, stride, koff););
+        SEGK_LAUNCH_CHECK();
+        return SEGK_OK;
+    }
     DISPATCH_XT(c, hipLaunchKernelGGL(k_fbb_partials<XT>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0,
                                        (hipStream_t)stream, *c, *f, *bt, s_lo, s_n, b, new_tok, n_new););
     SEGK_LAUNCH_CHECK();

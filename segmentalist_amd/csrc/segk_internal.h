@@ -28,6 +28,9 @@ struct segk_ctx {
     // persistent sequential chain (segk_seq_chain.hip): span maxima, control words, the sweep's utterance order
     void *chain_buf;
     size_t chain_bytes;
+    // batch sampler: the block's tokens bucketed by slot (k_fbb_sort) + offsets
+    int32_t *fbs_buf;
+    size_t fbs_bytes;
     // second stream of segk_kmeans_score: the pre-filter's second stage and the full scan run on it beside
     // the exact stage of the decided rows (created on first use)
     hipStream_t aux;

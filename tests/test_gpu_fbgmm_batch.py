@@ -284,3 +284,22 @@ def test_diag_float32_span_scores_within_the_contract(gpu, n_utt, D, K, nmax, sc
 def _abi_ptr(t):
     from segmentalist_amd._abi import ptr
     return ptr(t)
+
+
+@pytest.mark.parametrize("kind", ["fixed", "bigram"])
+def test_sorted_partial_sums_are_the_same_bits(gpu, monkeypatch, kind):
+    """Banks of 256 slots and more bucket a block's tokens by slot (k_fbb_sort: stable counting sort) before the partial
+    sums; SEGK_FBB_SORT=0 keeps the one-step kernel that walks every utterance per slot.  Same additions in the same order:
+    the sampler's whole state after three sweeps is identical."""
+    states = []
+    for mode in ("0", "1"):
+        monkeypatch.setenv("SEGK_FBB_SORT", mode)
+        _, _, seg = _pair(kind, 50, 12, 300, 99, 6, 3, 4)
+        for _ in range(3):
+            seg.batch_sweep_async()
+        gpu.cuda.synchronize()
+        seg._df.check_status()
+        sw = seg._get_sweeper()
+        states.append((sw.partials.cpu().numpy().copy(), sw.slot.cpu().numpy().copy(), seg.utterances.boundaries.copy()))
+    for a, b in zip(*states):
+        assert np.array_equal(a, b)
