@@ -476,7 +476,8 @@ int32_t segk_fbgmm_gibbs_items(segk_ctx *ctx, const segk_corpus *c, segk_fbgmm *
 typedef struct {
     int32_t n_slices, n_blocks;   /* S (<= 16), B (>= 2)                                          */
     int32_t u_max;                /* max utterances of a (slice, block); 0 without an LM store    */
-    int32_t pad_;
+    int32_t fast_dp;              /* boundary sampler of the batch steps: 0 = fp64 library exp / log (bit-exact against the
+                                   * specification), 1 = hardware v_exp_f32 / v_log_f32 (tolerance modes f32 / f16)  */
     const int32_t *utt_range;     /* [dev] [S, B, 2] utterances [lo, hi) of (slice, block)        */
     const int32_t *row_range;     /* [dev] [S, B, 2] embedding rows [lo, hi) of (slice, block)    */
     double *partials;             /* [dev] [B, S, K_max*(2D+1)]: counts [K_max] (as doubles), sum x

@@ -39,7 +39,7 @@ class KMeansDev(C.Structure):
 
 class FbatchDev(C.Structure):
     _fields_ = [
-        ("n_slices", C.c_int32), ("n_blocks", C.c_int32), ("u_max", C.c_int32), ("pad_", C.c_int32),
+        ("n_slices", C.c_int32), ("n_blocks", C.c_int32), ("u_max", C.c_int32), ("fast_dp", C.c_int32),
         ("utt_range", C.c_void_p), ("row_range", C.c_void_p), ("partials", C.c_void_p), ("cnt", C.c_void_p),
         ("mean_t", C.c_void_p), ("q_t", C.c_void_p), ("lconst", C.c_void_p), ("zconst", C.c_void_p),
         ("half", C.c_void_p), ("scal", C.c_void_p), ("slot", C.c_void_p), ("lm_tok", C.c_void_p),

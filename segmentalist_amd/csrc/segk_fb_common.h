@@ -68,6 +68,33 @@ static __device__ double fb_logsumexp_wave(const double *a, int n, int lane)
     return log(s) + mx;
 }
 
+// The same with the hardware exponential and logarithm (v_exp_f32 / v_log_f32) on differences formed in fp64: ~3e-6
+// relative in the sum, for the batch sampler's tolerance modes (`score_precision` f32 / f16; segk_fbatch.fast_dp).
+static __device__ __forceinline__ double fb_exp_fast(double d)      // exp(d), d <= ~0
+{
+    return (double)__builtin_amdgcn_exp2f((float)d * 1.4426950408889634f);
+}
+static __device__ __forceinline__ double fb_log_fast(double x)      // log(x), x of order 1
+{
+    return (double)(__builtin_amdgcn_logf((float)x) * 0.6931471805599453f);
+}
+static __device__ double fb_logsumexp_wave_fast(const double *a, int n, int lane)
+{
+    double mx = NEG_INF_D;
+    for (int j = lane; j < n; j += 64) mx = a[j] > mx ? a[j] : mx;
+    for (int o = 32; o > 0; o >>= 1) {
+        double other = __shfl_xor(mx, o);
+        mx = other > mx ? other : mx;
+    }
+    double s = 0.0;
+    for (int j0 = 0; j0 < n; j0 += 64) {
+        const double ej = (j0 + lane < n) ? fb_exp_fast(a[j0 + lane] - mx) : 0.0;
+        const int cnt = n - j0 < 64 ? n - j0 : 64;
+        for (int q = 0; q < cnt; q++) s += fb_readlane(ej, q);
+    }
+    return fb_log_fast(s) + mx;
+}
+
 // embedding ids of the segments the boundaries of one utterance select, -1 (no embedding) skipped
 // (unigram_acoustic_wordseg.py:340-342)
 static __device__ int fb_collect_tokens(const int32_t *vid, const uint8_t *bnd, int N, int32_t *tok)
@@ -179,7 +206,7 @@ struct CounterUniforms {       // the batch sampler's counter-based stream
 template <typename USRC>
 static __device__ double fb_dp_sample(const double *vec, double *a, double *w, double *pr, int N, int tri, int n_max,
                                       int viterbi, double log_p_continue, double anneal_temp, uint8_t *bnd, int lane,
-                                      USRC &usrc)
+                                      USRC &usrc, int fast = 0)
 {
     for (int j = lane; j < N; j += 64) { a[j] = 1.0; bnd[j] = (j == N - 1) ? 1 : 0; }
     __builtin_amdgcn_wave_barrier();
@@ -204,10 +231,10 @@ static __device__ double fb_dp_sample(const double *vec, double *a, double *w, d
             if (viterbi) at = mx;
             else if (all_inf) at = NEG_INF_D;
             else {
-                const double ej = lane < n ? exp(v - mx) : 0.0;
+                const double ej = lane < n ? (fast ? fb_exp_fast(v - mx) : exp(v - mx)) : 0.0;
                 double sm = 0.0;
                 for (int q = 0; q < n; q++) sm += fb_readlane(ej, q);
-                at = log(sm) + mx + log_p_continue;
+                at = (fast ? fb_log_fast(sm) : log(sm)) + mx + log_p_continue;
             }
         } else {
             bool all_inf = true;
@@ -254,7 +281,7 @@ static __device__ double fb_dp_sample(const double *vec, double *a, double *w, d
             if (lane == 0) w[0] = NEG_INF_D;
         }
         __builtin_amdgcn_wave_barrier();
-        const double lse = fb_logsumexp_wave(w, n, lane);
+        const double lse = fast ? fb_logsumexp_wave_fast(w, n, lane) : fb_logsumexp_wave(w, n, lane);
         if (viterbi) {
             if (t > 0) {
                 for (int j = lane; j < n; j += 64) pr[j] = exp(w[j] - lse);
@@ -273,10 +300,10 @@ static __device__ double fb_dp_sample(const double *vec, double *a, double *w, d
                 __builtin_amdgcn_wave_barrier();
                 for (int j = lane; j < n; j += 64) w[j] = inv * pr[j];
                 __builtin_amdgcn_wave_barrier();
-                const double lse2 = fb_logsumexp_wave(w, n, lane);
-                for (int j = lane; j < n; j += 64) pr[j] = exp(w[j] - lse2);
+                const double lse2 = fast ? fb_logsumexp_wave_fast(w, n, lane) : fb_logsumexp_wave(w, n, lane);
+                for (int j = lane; j < n; j += 64) pr[j] = fast ? fb_exp_fast(w[j] - lse2) : exp(w[j] - lse2);
             } else {
-                for (int j = lane; j < n; j += 64) pr[j] = exp(w[n - 1 - j] - lse);
+                for (int j = lane; j < n; j += 64) pr[j] = fast ? fb_exp_fast(w[n - 1 - j] - lse) : exp(w[n - 1 - j] - lse);
             }
             __builtin_amdgcn_wave_barrier();
             double uu = usrc.next(lane);

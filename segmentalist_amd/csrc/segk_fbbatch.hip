@@ -725,7 +725,7 @@ __global__ void k_fbb_segment(segk_corpus c, segk_fbatch bt, FbbMap map, int b, 
     n_old = __shfl(n_old, 0);
     __builtin_amdgcn_wave_barrier();
     CounterUniforms usrc = {bt.seed, sweep, (uint64_t)utt, 0};
-    const double total = fb_dp_sample(vec, a, w, pr, N, tri, n_max, 0, 0.0, anneal_temp, bnd, lane, usrc);
+    const double total = fb_dp_sample(vec, a, w, pr, N, tri, n_max, 0, 0.0, anneal_temp, bnd, lane, usrc, bt.fast_dp);
     for (int j = lane; j < n_old; j += 64) bt.slot[old[j]] = -1;
     if (lane != 0) return;
     if (total == NEG_INF_D) atomicOr(status, 16);

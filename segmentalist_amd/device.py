@@ -789,7 +789,7 @@ class FbgmmBatchSweeper(object):
             consts16=self.consts16.data_ptr() if self.consts16 is not None else None,
             y=self.y.data_ptr() if self.y is not None else None, ldy=ldy,
             tiles32=self.tiles32.data_ptr() if self.tiles32 is not None else None,
-            n_slices=self.S, n_blocks=self.B, u_max=self.u_max if df.lm is not None else 0, pad_=0,
+            n_slices=self.S, n_blocks=self.B, u_max=self.u_max if df.lm is not None else 0, fast_dp=1 if score_precision != "f64" else 0,
             utt_range=self.utt_range.data_ptr(), row_range=self.row_range.data_ptr(),
             partials=self.partials.data_ptr(), cnt=self.cnt.data_ptr(), mean_t=self.mean_t.data_ptr(),
             q_t=self.q_t.data_ptr(), lconst=self.lconst.data_ptr(), zconst=self.zconst.data_ptr(),
