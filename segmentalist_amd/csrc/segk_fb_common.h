@@ -109,6 +109,25 @@ static __device__ int fb_collect_tokens(const int32_t *vid, const uint8_t *bnd, 
     return nn;
 }
 
+// The same by a whole wave (N <= 64): one load of the boundary flags, the lane of every set flag looks up its own segment
+// [jp, j + 1), the kept ids are compacted in order by a prefix count.  All 64 lanes must call it; returns the count in every
+// lane.  (The one-lane loop above is N dependent global loads: 5-10 us per call in the boundary kernels.)
+static __device__ int fb_collect_tokens_wave(const int32_t *vid, const uint8_t *bnd, int N, int32_t *tok, int lane)
+{
+    // the flags may have been written a moment ago by other lanes of this wave: wait for those stores and read past the L1
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const uint8_t flag = lane < N ? __hip_atomic_load(&bnd[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (uint8_t)0;
+    const unsigned long long mask = __ballot(flag != 0);
+    const bool bit = lane < N && ((mask >> lane) & 1ull);
+    const unsigned long long below = mask & ((1ull << lane) - 1ull);
+    const int jp = below ? 64 - __clzll((long long)below) : 0;
+    int id = -1;
+    if (bit) id = vid[(lane + 1) * lane / 2 + jp];
+    const unsigned long long keep = __ballot(bit && id >= 0);
+    if (bit && id >= 0) tok[__popcll(keep & ((1ull << lane) - 1ull))] = id;
+    return __popcll(keep);
+}
+
 
 // utils.draw (utils.py:10-21): the first q with u - p[0] - ... - p[q] < 0, subtractions in index
 // order (else n - 1).  Executed redundantly by every calling lane (uniform LDS addresses are

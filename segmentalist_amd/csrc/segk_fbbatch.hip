@@ -720,17 +720,21 @@ __global__ void k_fbb_segment(segk_corpus c, segk_fbatch bt, FbbMap map, int b, 
     if (threadIdx.x >= 64) return;
     const int lane = threadIdx.x;
     uint8_t *bnd = boundaries + (int64_t)utt * c.N_max;
-    int n_old = 0;
-    if (lane == 0) n_old = fb_collect_tokens(vid, bnd, N, old);
-    n_old = __shfl(n_old, 0);
+    const int n_old = N <= 64 ? fb_collect_tokens_wave(vid, bnd, N, old, lane)
+                              : __shfl(lane == 0 ? fb_collect_tokens(vid, bnd, N, old) : 0, 0);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     CounterUniforms usrc = {bt.seed, sweep, (uint64_t)utt, 0};
     const double total = fb_dp_sample(vec, a, w, pr, N, tri, n_max, 0, 0.0, anneal_temp, bnd, lane, usrc, bt.fast_dp);
     for (int j = lane; j < n_old; j += 64) bt.slot[old[j]] = -1;
+    // (the boundary flags were written by lane 0 of this wave)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int nn = N <= 64 ? fb_collect_tokens_wave(vid, bnd, N, new_tok + (int64_t)utt * c.N_max, lane) : -1;
     if (lane != 0) return;
     if (total == NEG_INF_D) atomicOr(status, 16);
     out_logprob[utt] = total;
-    n_new[utt] = fb_collect_tokens(vid, bnd, N, new_tok + (int64_t)utt * c.N_max);
+    n_new[utt] = nn >= 0 ? nn : fb_collect_tokens(vid, bnd, N, new_tok + (int64_t)utt * c.N_max);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -457,11 +457,12 @@ __global__ void k_unigram_segment(segk_corpus c, int utt, int viterbi, int n_min
     StreamUniforms usrc = {ustream, *ucursor, ucap, status};
     const double total = fb_dp_sample(vec, a, w, pr, N, tri, n_max, viterbi, log_p_continue, anneal_temp, bnd, lane, usrc);
     const int64_t cur = usrc.cur;
+    const int nn = N <= 64 ? fb_collect_tokens_wave(vid, bnd, N, new_tok + (int64_t)utt * c.N_max, lane) : -1;
     if (lane != 0) return;
     if (!viterbi && total == NEG_INF_D) atomicOr(status, 16);      // unigram_acoustic_wordseg.py:753
     *ucursor = cur;
     out_logprob[utt] = total;
-    n_new[utt] = fb_collect_tokens(vid, bnd, N, new_tok + (int64_t)utt * c.N_max);
+    n_new[utt] = nn >= 0 ? nn : fb_collect_tokens(vid, bnd, N, new_tok + (int64_t)utt * c.N_max);
 }
 
 // softmax of the logits in z (scipy logsumexp order: max-shift, sum, log), optional annealing
