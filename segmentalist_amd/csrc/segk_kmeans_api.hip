@@ -49,7 +49,10 @@ int32_t segk_kmeans_filter(segk_ctx *ctx, const segk_corpus *c, const segk_kmean
         // SEGK_SCORE_PRE=0 disables it, =1 forces it at every size (tests).
         const char *pre_env = getenv("SEGK_SCORE_PRE");
         const int pre_mode = pre_env ? atoi(pre_env) : -1;
-        if (c->sp_pieces == 2 && A.fuse_exact && pre_mode != 0 && (pre_mode == 1 || n > 1024 * (int64_t)ctx->n_cu) &&
+        // (round 2: from 384 rows per CU on -- 98 304 -- with the second stage split over component ranges for small
+        // queues: a 1 250-utterance shard 5 636 against 5 329 sweeps/s, 2 500 utterances 4 493 against 4 278; at 625
+        // utterances the split-precision kernel alone still wins, 7 154 against 6 273)
+        if (c->sp_pieces == 2 && A.fuse_exact && pre_mode != 0 && (pre_mode == 1 || n > 384 * (int64_t)ctx->n_cu) &&
             n < (int64_t)1 << 30)
             return segk_dispatch_score_pre(ctx, A, segk_b3_kp(c->D) / 16, st);
         segk_flush_deferred_zero(ctx, st);
