@@ -148,39 +148,51 @@ __global__ __launch_bounds__(256) void k_kmeans_brute_rows(segk_corpus c, segk_k
         for (int r = 0; r < SEGK_BR; r++) { best[r] = NEG_INF_F; bk[r] = 0x7fffffff; }
         for (int k = k_lo + tid; k < k_hi; k += nt) {
             const TileRow mr = tile_row(m.tiles, tstride, k);
-            float acc[SEGK_BR][8];
-            float mv[8];
+            // two elements per instruction (v_pk_add_f32 with the second operand negated, v_pk_mul_f32, v_pk_add_f32: every
+            // half rounded like the scalar operation): the scan is bound by the vector ALU
+            typedef float f32x2_t __attribute__((ext_vector_type(2)));
+            auto pk_sub = [](f32x2_t a, f32x2_t b2) -> f32x2_t {
+                f32x2_t d;
+                asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b2));
+                return d;
+            };
+            // the eight elements of block i as four adjacent pairs of the tile image (TileRow: pairs (d, d + 1), d even)
+            auto load_m = [&](int i, f32x2_t *mp) {
+                const float *b = mr.base + (i >> 2) * 128;
 #pragma unroll
-            for (int j = 0; j < 8; j++) mv[j] = mr[j];
+                for (int q = 0; q < 4; q++) mp[q] = *reinterpret_cast<const f32x2_t *>(b + (q >> 1) * 128 + (q & 1) * 64);
+            };
+            f32x2_t acc[SEGK_BR][4];
+            f32x2_t mp[4];
+            load_m(0, mp);
 #pragma unroll
             for (int r = 0; r < SEGK_BR; r++) {
                 const float4 x0 = *reinterpret_cast<const float4 *>(xs + r * DP), x1 = *reinterpret_cast<const float4 *>(xs + r * DP + 4);
-                const float xv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+                const f32x2_t xp[4] = {{x0.x, x0.y}, {x0.z, x0.w}, {x1.x, x1.y}, {x1.z, x1.w}};
 #pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const float delta = mv[j] - xv[j];
-                    acc[r][j] = delta * delta;
+                for (int q = 0; q < 4; q++) {
+                    const f32x2_t d = pk_sub(mp[q], xp[q]);
+                    acc[r][q] = d * d;
                 }
             }
             int i;
             for (i = 8; i < nfull; i += 8) {
-#pragma unroll
-                for (int j = 0; j < 8; j++) mv[j] = mr[i + j];
+                load_m(i, mp);
 #pragma unroll
                 for (int r = 0; r < SEGK_BR; r++) {
                     const float4 x0 = *reinterpret_cast<const float4 *>(xs + r * DP + i), x1 = *reinterpret_cast<const float4 *>(xs + r * DP + i + 4);
-                    const float xv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+                    const f32x2_t xp[4] = {{x0.x, x0.y}, {x0.z, x0.w}, {x1.x, x1.y}, {x1.z, x1.w}};
 #pragma unroll
-                    for (int j = 0; j < 8; j++) {
-                        const float delta = mv[j] - xv[j];
-                        acc[r][j] += delta * delta;
+                    for (int q = 0; q < 4; q++) {
+                        const f32x2_t d = pk_sub(mp[q], xp[q]);
+                        acc[r][q] += d * d;
                     }
                 }
             }
             float res[SEGK_BR];
 #pragma unroll
             for (int r = 0; r < SEGK_BR; r++)
-                res[r] = ((acc[r][0] + acc[r][1]) + (acc[r][2] + acc[r][3])) + ((acc[r][4] + acc[r][5]) + (acc[r][6] + acc[r][7]));
+                res[r] = ((acc[r][0].x + acc[r][0].y) + (acc[r][1].x + acc[r][1].y)) + ((acc[r][2].x + acc[r][2].y) + (acc[r][3].x + acc[r][3].y));
             for (; i < D; i++) {
                 const float mvi = mr[i];
 #pragma unroll
