@@ -604,3 +604,32 @@ def test_persistent_sequential_chain_equals_the_three_launch_form(gpu, monkeypat
         for x, y in zip(a[:5], b[:5]):
             assert np.array_equal(x, y), it
         assert a[5:] == b[5:], it
+
+
+@pytest.mark.parametrize("n_utt,D,K,N,nmax,ragged", [(400, 16, 40, 20, 6, False), (300, 8, 25, 0, 8, True), (200, 12, 30, 0, 3, True)])
+def test_segment_kernels_agree(gpu, monkeypatch, n_utt, D, K, N, nmax, ragged):
+    """The per-utterance DP by the whole wave (seg_w8_wave: eight lanes per step, DPP maxima, token lists from ballots; the
+    default), by one lane with two utterances per wave (SEGK_SEGMENT_X2=1: seg_w8_serial's arithmetic) and the generic kernel
+    (SEGK_SEGMENT_GENERIC=1): identical boundaries, labels and statistics after three batch sweeps -- uniform utterances,
+    ragged ones shorter than the window, a window of eight."""
+    from segmentalist_amd import kmeans_acoustic_wordseg as kaw
+    corpus = cases.chain_corpus(n_utt, D, K, 31 * n_utt + D, ragged, N, nmax, "float32")
+    out = []
+    for env in ({}, {"SEGK_SEGMENT_X2": "1"}, {"SEGK_SEGMENT_GENERIC": "1"}):
+        for k in ("SEGK_SEGMENT_X2", "SEGK_SEGMENT_GENERIC"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        random.seed(9)
+        np.random.seed(9)
+        seg = kaw.SegmentalKMeansWordseg(K, *corpus, n_slices_min=0, n_slices_max=nmax, p_boundary_init=0.5,
+                                         init_am_assignments="rand", wip=-0.2, sync="batch")
+        recs = []
+        for _ in range(3):
+            recs.append(seg.segment(1)["sum_neg_len_sqrd_norm"][0])
+        c = seg.acoustic_model.components
+        out.append((seg.utterances.boundaries.copy(), c.assignments.copy(), c.means.copy(), c.counts.copy(), recs))
+    for other in out[1:]:
+        for a, b in zip(out[0][:4], other[:4]):
+            assert np.array_equal(a, b)
+        assert out[0][4] == other[4]
