@@ -418,12 +418,14 @@ def test_split_precision_filter_wide_dynamic_range(gpu, monkeypatch, pieces):
 
 # ------------------------------------------------------------------ one-product pre-filter
 @pytest.mark.parametrize("D,K,n,scale", [(100, 1000, 4096, 1.0), (128, 513, 3000, 1.0), (40, 257, 2500, 30.0),
-                                         (16, 64, 1500, 1e-3), (8, 31, 700, 1.0), (64, 33, 5000, 7e3)])
+                                         (16, 64, 1500, 1e-3), (8, 31, 700, 1.0), (64, 33, 5000, 7e3),
+                                         (108, 130, 3000, 1.0), (12, 40, 2000, 1.0), (28, 70, 2500, 0.1)])
 def test_prefilter_decisions_are_the_references(gpu, monkeypatch, D, K, n, scale):
     """SEGK_SCORE_PRE=1 forces the one-product fp16 pre-filter (normally used above one round of the
     chip) in front of the split-precision kernel: max / argmax after the exact stage stay the
     reference's bit for bit -- clustered rows, an exact tie, a duplicated mean inside one PAIR of
-    components (the pre-filter tracks pairs and lets the exact stage pick the member)."""
+    components (the pre-filter tracks pairs and lets the exact stage pick the member).  The shapes cover the four
+    compile-time layouts of the exact stage (D = 16 KS - 4 V, V = 0..3) and tables of one and several LDS ranges."""
     from oracle import c_oracle as co
     monkeypatch.setenv("SEGK_SCORE_PRE", "1")
     rs = np.random.RandomState(D * 1000 + K + 1)
