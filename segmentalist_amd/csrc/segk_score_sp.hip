@@ -139,7 +139,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_kmeans_score_sp(ScoreArgs A)
         if constexpr (MODE == 2) {      /* store the unscaled values: row-major [row][component] */ \
             st4[(vi) & 3] = v_ * unscale;                                             \
             if ((((vi) & 3) == 3) && dtile >= 0 && r < n)                             \
-                *reinterpret_cast<float4 *>(A.mat_out + r * A.mat_ld + dtile * 32 + 4 * h + 8 * ((vi) >> 2)) = \
+                *reinterpret_cast<float4 *>(A.mat_out + r * A.mat_ld + (dtile + tile0) * 32 + 4 * h + 8 * ((vi) >> 2)) = \
                     make_float4(st4[0], st4[1], st4[2], st4[3]);                      \
         } else if constexpr (MODE == 1) {                                                    \
             v_ = fmaxf(v_ * unscale, -3.0e38f);                                       \
@@ -397,7 +397,27 @@ static int launch_score_mat_sp(const ScoreArgs &A, hipStream_t st)
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_kmeans_score_sp<KS, 4, 2, 2>), dim3((unsigned)((A.n + 127) / 128)), dim3(256), lds, st, A);
+    // few rows (the new tokens of one Gibbs block: ~10 k): the tiles of a row block over several workgroups -- every
+    // workgroup writes its own columns of the matrix, nothing to merge (78 workgroups walking 32 tiles each: 54 us)
+    const int64_t blocks = (A.n + 127) / 128;
+    int n_split = blocks > 0 ? (int)(512 / blocks) : 1;
+    if (n_split > 8) n_split = 8;
+    if (n_split > A.n_tiles) n_split = A.n_tiles;
+    if (n_split >= 2) {
+        static bool attr_set2 = false;
+        if (!attr_set2 && lds > 48 * 1024) {
+            SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_kmeans_score_sp<KS, 4, 2, 2, 1>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set2 = true;
+        }
+        ScoreArgs S = A;
+        S.tiles_per_split = (A.n_tiles + n_split - 1) / n_split;
+        S.n_chunks = (A.n_tiles + S.tiles_per_split - 1) / S.tiles_per_split;
+        hipLaunchKernelGGL((k_kmeans_score_sp<KS, 4, 2, 2, 1>), dim3((unsigned)(blocks * S.n_chunks)), dim3(256), lds, st, S);
+        SEGK_LAUNCH_CHECK();
+        return SEGK_OK;
+    }
+    hipLaunchKernelGGL((k_kmeans_score_sp<KS, 4, 2, 2>), dim3((unsigned)blocks), dim3(256), lds, st, A);
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;
 }
