@@ -300,6 +300,40 @@ def main_fbgmm(args):
         dist.destroy_process_group()
 
 
+def main_sequential(args):
+    """The reference's sequential chain (every utterance sees the means the previous one left; bit-identical to the
+    reference, tests/test_gpu_kmeans.py) on the headline corpus: sweeps per second on ONE GPU -- the chain does not shard."""
+    import torch
+    assert args.gpus == 1, "the sequential chain is one Markov chain: one GPU"
+    torch.cuda.set_device(0)
+    from segmentalist_amd import kmeans_acoustic_wordseg as kaw
+    from segmentalist_amd.synth import make_corpus
+    steps = args.steps if args.steps != 50 else 3
+    warmup = args.warmup if args.warmup != 5 else 1
+    corpus = make_corpus(args.utts, args.dim, args.K, seed=0, N=args.landmarks, n_slices_max=args.n_slices_max)
+    random.seed(0)
+    np.random.seed(0)
+    seg = kaw.SegmentalKMeansWordseg(args.K, *corpus, n_slices_max=args.n_slices_max, init_am_assignments="spread")
+    for _ in range(warmup):
+        seg.segment(1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    rec = seg.segment(steps)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    print(json.dumps({
+        "metric": "Gibbs sweeps/sec (sequential reference chain, 10k utts, D=100, K=1000)",
+        "value": steps / elapsed, "unit": "sweeps/s", "n_gpus": 1, "steps": steps, "warmup": warmup,
+        "ms_per_step": 1e3 * elapsed / steps, "us_per_utterance": 1e6 * elapsed / steps / args.utts,
+        "higher_is_better": True, "scaling": "none (one chain)", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "SegmentalKMeansWordseg sync='sequential' (the reference's chain, bit-identical state), "
+                               "one persistent kernel per stretch of utterances between two emptied components",
+                   "utterances": args.utts, "landmarks_per_utt": args.landmarks, "n_slices_max": args.n_slices_max,
+                   "D": args.dim, "K": args.K, "components_after": int(seg.acoustic_model.components.K),
+                   "sweep_seconds_including_record_keeping": [float(t) for t in rec["sample_time"]]},
+    }))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -313,11 +347,15 @@ def main():
     ap.add_argument("--windows", type=int, default=9, help="timed windows of --steps sweeps each; the median is reported")
     ap.add_argument("--cpu-utts", type=int, default=2000, help="utterances timed for cpu_baseline (0 = skip)")
     ap.add_argument("--no-events", action="store_true", help="do not bracket the score kernel with events")
-    ap.add_argument("--workload", default="kmeans_c3", choices=["kmeans_c3", "fbgmm_diag_c2", "bigram_c5"],
+    ap.add_argument("--workload", default="kmeans_c3", choices=["kmeans_c3", "fbgmm_diag_c2", "bigram_c5", "kmeans_c3_sequential"],
                     help="kmeans_c3 (default) is the headline of BASELINE.json (configs[2]); fbgmm_diag_c2 = configs[1] "
                          "(UnigramAcousticWordseg + FBGMM diag, 1k utterances, D=39, K=100), bigram_c5 = configs[4] "
-                         "(BigramAcousticWordseg, 10k utterances, D=100, K=1000): the batch (blocked Gibbs) sampler")
+                         "(BigramAcousticWordseg, 10k utterances, D=100, K=1000): the batch (blocked Gibbs) sampler; "
+                         "kmeans_c3_sequential = the headline corpus through the reference's own sequential chain "
+                         "(sync='sequential', the API default; one GPU; --steps sweeps after --warmup, default 3 after 1)")
     args = ap.parse_args()
+    if args.workload == "kmeans_c3_sequential":
+        return main_sequential(args)
     if args.workload != "kmeans_c3":
         return main_fbgmm(args)
 
