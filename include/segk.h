@@ -42,7 +42,11 @@ typedef struct segk_ctx segk_ctx;
 int32_t segk_create(int32_t device_id, segk_ctx **out_ctx);
 int32_t segk_destroy(segk_ctx *ctx);
 const char *segk_last_error(void);
-/* ABI version, bumped on any signature change. */
+/* ABI version, bumped on any change of a signature or of a structure below (SEGK_ABI_VERSION is the version this
+ * header describes; a binding must refuse a library that reports another one: segmentalist_amd/_abi.py does).
+ *   1 rounds 1-2 | 2 round 2: segk_corpus gained band_W / band_ids / band_dur (the bump was forgotten then)
+ *   3 round 3: segk_fbb_set_probe; this check                                                            */
+#define SEGK_ABI_VERSION 3
 int32_t segk_abi_version(void);
 
 /* Timing of the MAIN launch of the MFMA score kernel (k_kmeans_score<..., 0>) with HIP events
@@ -577,6 +581,17 @@ int32_t segk_fbb_assign_diag32(segk_ctx *ctx, const segk_corpus *c, const segk_f
 int32_t segk_fbb_token_scores(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *f,
                               const segk_fbatch *bt, const int32_t *tok_rows, int64_t n,
                               float *ll_mat, int64_t ll_ld, void *stream);
+/* Diagnostic probes of the tolerance modes (no reference counterpart; used by the parity tests to hold the float32 /
+ * fp16 token likelihoods and the hardware-exp/log forward filter to the 1e-4 contract directly, not through the draws
+ * they feed).  While set, on this context:
+ *   segk_fbb_segment also writes the forward filter's alpha[t] (unigram_acoustic_wordseg.py:691-703), t < N, of every
+ *     utterance it samples to alpha_out[utt * N_max + t]                     (alpha_out [dev] double [n_utt, N_max]);
+ *   segk_fbb_assign / segk_fbb_assign_diag32 also write, for token t of utterance utt and every slot k < K_max, the
+ *     log predictive density of the token under slot k that enters its logits (posterior predictive of an occupied
+ *     slot, prior predictive of an empty one: oracle/np_fbgmm_batch.py `loglik`) to
+ *     ll_out[(utt * N_max + t) * ll_ld + k]                                 (ll_out [dev] double [n_utt * N_max, ll_ld]).
+ * NULL pointers (the default) switch a probe off.                                                                  */
+int32_t segk_fbb_set_probe(segk_ctx *ctx, double *alpha_out, double *ll_out, int64_t ll_ld);
 /* bigram table += sign * (transcripts of block b, all slices) from bt->lm_tok                  */
 int32_t segk_fbb_lm_apply(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *f,
                           const segk_fbatch *bt, int32_t b, int32_t sign, void *stream);

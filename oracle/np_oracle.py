@@ -328,6 +328,18 @@ def forward_backward_kmeans_viterbi(vec, N, n_slices_min=0, n_slices_max=0, i_ut
     return total, boundaries
 
 
+def forward_alphas(vec, log_p_continue, N, n_slices_max=0):
+    """The forward filter of forward_backward alone (unigram_acoustic_wordseg.py:684-703): alphas[t], t < N."""
+    a = np.ones(N)
+    a[0] = 0.0
+    i = 0
+    for t in range(1, N):
+        q = _win(vec, t, i, n_slices_max) + (a[:t][-n_slices_max:] if n_slices_max else a[:t])
+        a[t] = -np.inf if np.all(q == -np.inf) else logsumexp(q) + log_p_continue
+        i += t
+    return a
+
+
 def forward_backward(vec, log_p_continue, N, n_slices_min=0, n_slices_max=0, i_utt=None,
                      anneal_temp=1, uniforms=None):
     """unigram_acoustic_wordseg.py:653-756.  `uniforms` (iterator) replaces random.random()."""

@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsegk.so")
 
 SEGK_F32, SEGK_F64 = 0, 1
+ABI_VERSION = 3          # SEGK_ABI_VERSION of include/segk.h this binding was written against
 
 
 class SegkError(RuntimeError):
@@ -127,6 +128,7 @@ SIGNATURES = {
     "segk_fbb_assign": (_i32, [_P, _CP, _FP, _BP, _i32, _i32, _i32, _P, _u64, _f64, _P, _P, _P, _i64, _P]),
     "segk_fbb_assign_diag32": (_i32, [_P, _CP, _FP, _BP, _i32, _i32, _i32, _P, _u64, _f64, _P, _P, _P]),
     "segk_fbb_token_scores": (_i32, [_P, _CP, _FP, _BP, _P, _i64, _P, _i64, _P]),
+    "segk_fbb_set_probe": (_i32, [_P, _P, _P, _i64]),
     "segk_fbb_lm_apply": (_i32, [_P, _CP, _FP, _BP, _i32, _i32, _P]),
     "segk_fbb_lm_fill": (_i32, [_P, _CP, _FP, _BP, _i32, _i32, _i32, _P, _P, _P, _P]),
     "segk_fbb_canonical": (_i32, [_P, _CP, _FP, _BP, _P, _P]),
@@ -177,6 +179,10 @@ def lib():
                 raise SegkError("libsegk.so does not export %s (stale build?)" % name)
             fn.restype = res
             fn.argtypes = args
+        got = int(L.segk_abi_version())
+        if got != ABI_VERSION:
+            raise SegkError("libsegk.so reports ABI version %d, this binding is written against %d (include/segk.h "
+                            "SEGK_ABI_VERSION): rebuild the library (`make -C segmentalist_amd/csrc`)" % (got, ABI_VERSION))
         _lib = L
     return _lib
 

@@ -690,7 +690,7 @@ __global__ __launch_bounds__(256) void k_vlog_calibrate(int iters, float seed, f
 // ---------------------------------------------------------------------------------------
 __global__ void k_fbb_segment(segk_corpus c, segk_fbatch bt, FbbMap map, int b, uint64_t sweep, int n_max, double wip,
                               double time_power_term, double anneal_temp, const double *score, uint8_t *boundaries,
-                              int32_t *new_tok, int32_t *n_new, double *out_logprob, int32_t *status)
+                              int32_t *new_tok, int32_t *n_new, double *out_logprob, int32_t *status, double *probe_alpha)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int s, idx;
@@ -726,6 +726,8 @@ __global__ void k_fbb_segment(segk_corpus c, segk_fbatch bt, FbbMap map, int b, 
     __builtin_amdgcn_wave_barrier();
     CounterUniforms usrc = {bt.seed, sweep, (uint64_t)utt, 0};
     const double total = fb_dp_sample(vec, a, w, pr, N, tri, n_max, 0, 0.0, anneal_temp, bnd, lane, usrc, bt.fast_dp);
+    if (probe_alpha)            // segk_fbb_set_probe: the forward filter's values (the backward pass only reads them)
+        for (int j = lane; j < N; j += 64) probe_alpha[(int64_t)utt * c.N_max + j] = a[j];
     for (int j = lane; j < n_old; j += 64) bt.slot[old[j]] = -1;
     // (the boundary flags were written by lane 0 of this wave)
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -743,7 +745,7 @@ __global__ void k_fbb_segment(segk_corpus c, segk_fbatch bt, FbbMap map, int b, 
 template <typename XT, int COV, int F32 = 0>
 __global__ void k_fbb_assign(segk_corpus c, segk_fbgmm f, segk_fbatch bt, FbbMap map, int b, uint64_t sweep,
                              double prior_alpha, double anneal_temp, const int32_t *new_tok, const int32_t *n_new,
-                             int rcap, int dbg, const float *llmat, int64_t ll_ld)
+                             int rcap, int dbg, const float *llmat, int64_t ll_ld, double *probe_ll, int64_t probe_ld)
 {
     // The likelihood part of the logits does not depend on the previous segment's slot, so it is
     // evaluated for up to `rcap` (<= FBB_R) tokens of the utterance at once -- the component
@@ -844,6 +846,13 @@ __global__ void k_fbb_assign(segk_corpus c, segk_fbgmm f, segk_fbatch bt, FbbMap
         }
         }
         __syncthreads();
+        if (probe_ll) {         // segk_fbb_set_probe: the likelihood part of the logits, as the draws below use it
+            for (int j = tid; j < nr * KM; j += nt) {
+                const int r = j / KM, k = j - r * KM;
+                probe_ll[((int64_t)utt * c.N_max + t0 + r) * probe_ld + k] = ll[(int64_t)r * KM + k];
+            }
+            __syncthreads();
+        }
         if (!f.lm_unigram) {
             // Without a language model a token's draw does not depend on the token before it: one WAVE per token, maxima
             // and sums by shuffles.  The sums keep the association of the block-wide form below at 256 threads (per wave
@@ -956,7 +965,8 @@ __global__ void k_fbb_assign(segk_corpus c, segk_fbgmm f, segk_fbatch bt, FbbMap
 template <int F32>
 __global__ __launch_bounds__(256) void k_fbb_assign_lm_wave(segk_corpus c, segk_fbgmm f, segk_fbatch bt, FbbMap map, int b, uint64_t sweep,
                                                             double prior_alpha, double anneal_temp, const int32_t *new_tok,
-                                                            const int32_t *n_new, const float *llmat, int64_t ll_ld, int n_items)
+                                                            const int32_t *n_new, const float *llmat, int64_t ll_ld, int n_items,
+                                                            double *probe_ll, int64_t probe_ld)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int KM = f.K_max, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -1022,6 +1032,7 @@ __global__ __launch_bounds__(256) void k_fbb_assign_lm_wave(segk_corpus c, segk_
                 for (int j = 0; j < KPL; j++) {
                     const double n = cn[j];
                     const double llv = n > 0.0 ? (double)mr[j] * LN2 - zl[j] + norm : empty_ll;
+                    if (probe_ll && lane + 64 * j < KM) probe_ll[((int64_t)utt * c.N_max + t) * probe_ld + lane + 64 * j] = llv;
                     double pz;
                     if (j_prev < 0) pz = ((double)(__builtin_amdgcn_logf((float)(n + aK)) * 0.6931471805599453f) - ltot) * f.lms;
                     else pz = (double)(__builtin_amdgcn_logf((float)(f.lm_lambda * ((n + aK) * inv_tot) + ((double)bg[j] + bK) * inv_prev)) * 0.6931471805599453f) * f.lms;
@@ -1075,6 +1086,7 @@ __global__ __launch_bounds__(256) void k_fbb_assign_lm_wave(segk_corpus c, segk_
             for (int k = lane; k < KM; k += 64) {
                 const double n = bt.cnt[k];
                 const double llv = n > 0.0 ? (double)mrow[k] * LN2 - (bt.zconst[k] - bt.lconst[k]) + norm : empty_ll;
+                if (probe_ll) probe_ll[((int64_t)utt * c.N_max + t) * probe_ld + k] = llv;
                 double pz;
                 if (j_prev < 0) pz = ((double)(__builtin_amdgcn_logf((float)(n + aK)) * 0.6931471805599453f) - ltot) * f.lms;      // bigram_lms.py:64-69
                 else {                                                                                                          // bigram_lms.py:84-91
@@ -1129,6 +1141,7 @@ __global__ __launch_bounds__(256) void k_fbb_assign_lm_wave(segk_corpus c, segk_
             const double n = bt.cnt[k];
             const double llv = n > 0.0 ? (double)mrow[k] * LN2 - (bt.zconst[k] - bt.lconst[k]) + norm
                                        : (double)mrow[KM] * LN2 - zc_empty - log(n_empty) + norm;
+            if (probe_ll) probe_ll[((int64_t)utt * c.N_max + t) * probe_ld + k] = llv;
             double pz;
             if (j_prev < 0) pz = (log(n + f.lm_a / (double)KM) - log(tot + f.lm_a)) * f.lms;                       // bigram_lms.py:64-69
             else {                                                                                              // bigram_lms.py:84-91
@@ -1615,7 +1628,7 @@ int32_t segk_fbb_segment(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *
                          const double *score, uint8_t *boundaries, int32_t *new_tok, int32_t *n_new,
                          double *out_logprob, int32_t *status, void *stream)
 {
-    (void)ctx;
+    SEGK_REQUIRE(ctx, "context");
     int rc = check_fbb(c, f, bt);
     if (rc) return rc;
     SEGK_REQUIRE(n_slices_min == 0 || n_slices_min == 1, "n_slices_min must be 0 or 1");
@@ -1628,7 +1641,7 @@ int32_t segk_fbb_segment(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *
     SEGK_REQUIRE(lds <= 64 * 1024, "N_max too large for the LDS score vector");
     hipLaunchKernelGGL(k_fbb_segment, dim3(m.off[s_n]), dim3(128), lds, (hipStream_t)stream, *c, *bt, m, b, sweep,
                        n_slices_max, wip, time_power_term, anneal_temp, score, boundaries, new_tok, n_new, out_logprob,
-                       status);
+                       status, ctx->probe_alpha);
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;
 }
@@ -1650,7 +1663,8 @@ static int32_t fbb_assign_impl(segk_ctx *ctx, const segk_corpus *c, const segk_f
                                const int32_t *new_tok, const int32_t *n_new, const float *ll_mat, int64_t ll_ld, int f32,
                                void *stream)
 {
-    (void)ctx;
+    SEGK_REQUIRE(ctx, "context");
+    SEGK_REQUIRE(!ctx->probe_ll || ctx->probe_ll_ld >= f->K_max, "probe leading dimension");
     int rc = check_fbb(c, f, bt);
     if (rc) return rc;
     FbbMap m;
@@ -1684,10 +1698,10 @@ static int32_t fbb_assign_impl(segk_ctx *ctx, const segk_corpus *c, const segk_f
         // SEGK_FBB_ASSIGN_WAVE=2: the softmax with the fp64 library functions (the bits of the block-wide form)
         if (awe && atoi(awe) == 2)
             hipLaunchKernelGGL(k_fbb_assign_lm_wave<0>, dim3((n_items + 3) / 4), dim3(256), ldsw, (hipStream_t)stream, *c, *f, *bt, m, b,
-                               sweep, alpha, anneal_temp, new_tok, n_new, ll_mat, ll_ld, n_items);
+                               sweep, alpha, anneal_temp, new_tok, n_new, ll_mat, ll_ld, n_items, ctx->probe_ll, ctx->probe_ll_ld);
         else
             hipLaunchKernelGGL(k_fbb_assign_lm_wave<1>, dim3((n_items + 3) / 4), dim3(256), ldsw, (hipStream_t)stream, *c, *f, *bt, m, b,
-                               sweep, alpha, anneal_temp, new_tok, n_new, ll_mat, ll_ld, n_items);
+                               sweep, alpha, anneal_temp, new_tok, n_new, ll_mat, ll_ld, n_items, ctx->probe_ll, ctx->probe_ll_ld);
         SEGK_LAUNCH_CHECK();
         return SEGK_OK;
     }
@@ -1697,7 +1711,7 @@ static int32_t fbb_assign_impl(segk_ctx *ctx, const segk_corpus *c, const segk_f
                 SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_fbb_assign<XT, 0>,
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL((k_fbb_assign<XT, 0>), dim3(m.off[s_n]), dim3(nt_assign), lds, (hipStream_t)stream, *c, *f, *bt, m,
-                               b, sweep, alpha, anneal_temp, new_tok, n_new, rcap, dbg, ll_mat, ll_ld);
+                               b, sweep, alpha, anneal_temp, new_tok, n_new, rcap, dbg, ll_mat, ll_ld, ctx->probe_ll, ctx->probe_ll_ld);
         } else {
             if (lds > 48 * 1024)
                 SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_fbb_assign<XT, 1>,
@@ -1707,10 +1721,10 @@ static int32_t fbb_assign_impl(segk_ctx *ctx, const segk_corpus *c, const segk_f
                     SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_fbb_assign<XT, 1, 1>,
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 hipLaunchKernelGGL((k_fbb_assign<XT, 1, 1>), dim3(m.off[s_n]), dim3(nt_assign), lds, (hipStream_t)stream, *c, *f, *bt, m,
-                                   b, sweep, alpha, anneal_temp, new_tok, n_new, rcap, dbg, ll_mat, ll_ld);
+                                   b, sweep, alpha, anneal_temp, new_tok, n_new, rcap, dbg, ll_mat, ll_ld, ctx->probe_ll, ctx->probe_ll_ld);
             } else
             hipLaunchKernelGGL((k_fbb_assign<XT, 1>), dim3(m.off[s_n]), dim3(nt_assign), lds, (hipStream_t)stream, *c, *f, *bt, m,
-                               b, sweep, alpha, anneal_temp, new_tok, n_new, rcap, dbg, ll_mat, ll_ld);
+                               b, sweep, alpha, anneal_temp, new_tok, n_new, rcap, dbg, ll_mat, ll_ld, ctx->probe_ll, ctx->probe_ll_ld);
         }
     });
     SEGK_LAUNCH_CHECK();
@@ -1730,6 +1744,16 @@ int32_t segk_fbb_assign_diag32(segk_ctx *ctx, const segk_corpus *c, const segk_f
 {
     SEGK_REQUIRE(f && f->cov_type == 1, "the float32 token likelihoods of this entry point are the diagonal (Student-t) ones");
     return fbb_assign_impl(ctx, c, f, bt, s_lo, s_n, b, n_utts, sweep, anneal_temp, new_tok, n_new, nullptr, 0, 1, stream);
+}
+
+int32_t segk_fbb_set_probe(segk_ctx *ctx, double *alpha_out, double *ll_out, int64_t ll_ld)
+{
+    SEGK_REQUIRE(ctx, "context");
+    SEGK_REQUIRE(!ll_out || ll_ld > 0, "leading dimension of the likelihood probe");
+    ctx->probe_alpha = alpha_out;
+    ctx->probe_ll = ll_out;
+    ctx->probe_ll_ld = ll_out ? ll_ld : 0;
+    return SEGK_OK;
 }
 
 int32_t segk_fbb_lm_apply(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *f, const segk_fbatch *bt, int32_t b,

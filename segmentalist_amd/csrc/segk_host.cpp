@@ -19,7 +19,7 @@ extern "C" {
 
 const char *segk_last_error(void) { return g_err; }
 
-int32_t segk_abi_version(void) { return 1; }
+int32_t segk_abi_version(void) { return SEGK_ABI_VERSION; }
 
 int32_t segk_destroy(segk_ctx *ctx);
 

@@ -53,6 +53,9 @@ struct segk_ctx {
     int rb_K;
     int32_t *rb_misc;            // blk_lo [68], dummy K, flags; then doubles (part_tot, scalars, terms)
     double *rb_term;             // [rb_K] per-component terms of the record metrics
+    // diagnostic probes of the batch sampler's tolerance modes (segk_fbb_set_probe); NULL = off
+    double *probe_alpha, *probe_ll;
+    int64_t probe_ll_ld;
     // optional timing of the main score launch (segk_profile_*): event pairs used round-robin
     int prof_on, prof_n, prof_kind;
     hipEvent_t prof_ev[SEGK_PROF_SLOTS][2];
