@@ -311,7 +311,9 @@ int32_t segk_kmeans_sequential_sweep(segk_ctx *ctx, const segk_corpus *c, segk_k
  *      (as segk_kmeans_prepare + segk_kmeans_mark_duplicates).
  *      out_scalars [dev] double [4] = {sum of totals, K, n_tokens, K before the sweep}.
  *  status bits: 1 new segment without embedding, 2 add_item on an assigned item
- *  (kmeans_components.py:101 assert), 4 more flagged tokens than flag_cap per block / 2048 per sweep.
+ *  (kmeans_components.py:101 assert), 4 more flagged tokens in one block than flag_cap (the record has room for
+ *  flag_cap per block; the tokens beyond were dropped and the statistics of this sweep are NOT usable: restore a
+ *  checkpoint or rebuild the state, and sweep again with a larger flag_cap.  There is no per-sweep limit).
  */
 int64_t segk_kmeans_batch_record_words(int32_t K_max, int32_t D, int32_t n_blocks_local, int32_t flag_cap);
 int32_t segk_kmeans_batch_partials(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m,

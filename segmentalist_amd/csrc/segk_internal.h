@@ -53,6 +53,9 @@ struct segk_ctx {
     int rb_K;
     int32_t *rb_misc;            // blk_lo [68], dummy K, flags; then doubles (part_tot, scalars, terms)
     double *rb_term;             // [rb_K] per-component terms of the record metrics
+    // k-means batch finalize: the flagged tokens of a sweep beyond the kernel's LDS list, [4][flag_ovf_cap] int32
+    int32_t *flag_ovf;
+    int64_t flag_ovf_cap;
     // diagnostic probes of the batch sampler's tolerance modes (segk_fbb_set_probe); NULL = off
     double *probe_alpha, *probe_ll;
     int64_t probe_ll_ld;

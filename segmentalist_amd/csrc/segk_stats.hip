@@ -684,14 +684,16 @@ __device__ __forceinline__ double tree_reduce_d(double *v, int n)
     return v[0];
 }
 
-#define SEGK_FLAG_LDS 2048        /* flagged tokens of a sweep the finalize kernel can hold (all ranks together) */
+#define SEGK_FLAG_LDS 2048        /* flagged tokens of a sweep (all ranks together) the finalize kernel keeps in LDS; the ones
+                                     beyond go through the context's overflow arrays in global memory (identical values
+                                     written by every workgroup) -- the only limit left is flag_cap per block              */
 #define FIN_ROWS 8                /* final rows per workgroup */
 
 template <typename XT>
 __global__ __launch_bounds__(256) void k_batch_finalize(
     segk_corpus c, segk_kmeans m, const double *pack, int n_blocks, int nbl, int64_t rank_stride, int cap, int my_rank,
     int32_t *new_k, int32_t *remap, double *out_scalars, int32_t *status, unsigned long long *row_hash,
-    unsigned int *sp_zero_slot)
+    unsigned int *sp_zero_slot, int32_t *ovf, int ovf_cap)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char fin_lds[];
     const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wv = tid >> 6;
@@ -709,6 +711,11 @@ __global__ __launch_bounds__(256) void k_batch_finalize(
     __shared__ int32_t fl_cnt[64];
     __shared__ long long red[4];
     const PackAddr pa{nbl, K_max, D, cap, rank_stride};
+    // flagged token q of the sweep: the first SEGK_FLAG_LDS in LDS, the others in ovf [4][ovf_cap] (slot, row, k, block)
+    auto FL_SLOT = [&](int q) -> int { return q < SEGK_FLAG_LDS ? fl_slot[q] : ovf[q - SEGK_FLAG_LDS]; };
+    auto FL_ROW = [&](int q) -> int { return q < SEGK_FLAG_LDS ? fl_row[q] : ovf[(int64_t)ovf_cap + q - SEGK_FLAG_LDS]; };
+    auto FL_K = [&](int q) -> int { return q < SEGK_FLAG_LDS ? (int)fl_k[q] : ovf[2 * (int64_t)ovf_cap + q - SEGK_FLAG_LDS]; };
+    auto FL_BLK = [&](int q) -> int { return q < SEGK_FLAG_LDS ? (int)fl_blk[q] : ovf[3 * (int64_t)ovf_cap + q - SEGK_FLAG_LDS]; };
     const int64_t *packi = reinterpret_cast<const int64_t *>(pack);
     const int Kb = (int)out_scalars[3];            // K before the sweep (k_batch_sort); *m.K is rewritten by workgroup 0
     const int wg = blockIdx.x;
@@ -767,6 +774,13 @@ __global__ __launch_bounds__(256) void k_batch_finalize(
                     fl_k[nf] = (unsigned short)k;
                     fl_blk[nf] = (unsigned short)b;
                     nf++;
+                } else if (ovf && nf - SEGK_FLAG_LDS < ovf_cap) {
+                    const int o = nf - SEGK_FLAG_LDS;
+                    ovf[o] = fl[2 + 3 * q + 0];
+                    ovf[(int64_t)ovf_cap + o] = fl[2 + 3 * q + 2];
+                    ovf[2 * (int64_t)ovf_cap + o] = k;
+                    ovf[3 * (int64_t)ovf_cap + o] = b;
+                    nf++;
                 } else {
                     over = 1;
                 }
@@ -775,10 +789,11 @@ __global__ __launch_bounds__(256) void k_batch_finalize(
         if (over && wg == 0) atomicOr(status, 4);
         shK1 = K;
         n_fl = nf;
+        if (nf > SEGK_FLAG_LDS) __threadfence();      // the overflow entries are read back by the other threads below
     }
     __syncthreads();
     const int K1 = shK1, nfl = n_fl;
-    for (int q = tid; q < nfl; q += nt) atomicAdd(&cnt32[fl_k[q]], 1);
+    for (int q = tid; q < nfl; q += nt) atomicAdd(&cnt32[FL_K(q)], 1);
     const long long n_tokens = red[0] + red[1] + red[2] + red[3] + nfl;
     // ---- (0c) clean_components on indices only.  The reference deletes the empty components one at a time
     // in descending order, each time moving the last active row into the hole (kmeans_components.py:129-151,
@@ -819,7 +834,7 @@ __global__ __launch_bounds__(256) void k_batch_finalize(
             if (k < K) remap[pos2orig[k]] = k;
         }
         for (int q = tid; q < nfl; q += nt)
-            if (fl_blk[q] / nbl == my_rank) new_k[fl_slot[q]] = fl_k[q];
+            if (FL_BLK(q) / nbl == my_rank) new_k[FL_SLOT(q)] = FL_K(q);
         if (tid == 0) {
             double tv[64];
             for (int b = 0; b < n_blocks; b++) tv[b] = pack[pa.tot(b)];
@@ -886,7 +901,7 @@ __global__ __launch_bounds__(256) void k_batch_finalize(
                 } else {                                       // a component founded this sweep: its flagged tokens, block by block
                     for (int b = 0; b < n_blocks; b++) gv[b] = 0.0;
                     for (int q = 0; q < nfl; q++)
-                        if (fl_k[q] == src[u]) gv[fl_blk[q]] += (double)X[(int64_t)fl_row[q] * c.ldx + d];
+                        if (FL_K(q) == src[u]) gv[FL_BLK(q)] += (double)X[(int64_t)FL_ROW(q) * c.ldx + d];
                 }
                 v = tree_reduce_d(gv, n_blocks);
             }
@@ -1288,6 +1303,26 @@ int32_t segk_kmeans_batch_finalize(segk_ctx *ctx, const segk_corpus *c, segk_kme
         ctx->row_hash_means = m->means;
         if (!(md && atoi(md) == 0)) row_hash = ctx->row_hash;
     }
+    // overflow arrays of the clamp replay: the flagged tokens of a sweep beyond the SEGK_FLAG_LDS the kernel keeps in LDS
+    // (a first sweep with K << K_max: the inactive rows are data points, every token near one founds a component)
+    int32_t *ovf = nullptr;
+    int ovf_cap = 0;
+    const int64_t flag_max = (int64_t)n_blocks_total * flag_cap;
+    if (ctx && flag_max > SEGK_FLAG_LDS) {
+        const int64_t need = flag_max - SEGK_FLAG_LDS;
+        SEGK_REQUIRE(need < (1ll << 28), "n_blocks_total * flag_cap");
+        if (ctx->flag_ovf_cap < need) {
+            SEGK_REQUIRE(!ctx->capturing, "the overflow arrays of the clamp replay must exist before a graph capture (run one sweep first)");
+            SEGK_CHECK_HIP(hipStreamSynchronize(st));
+            if (ctx->flag_ovf) (void)hipFree(ctx->flag_ovf);
+            ctx->flag_ovf = nullptr;
+            ctx->flag_ovf_cap = 0;
+            SEGK_CHECK_HIP(hipMalloc((void **)&ctx->flag_ovf, (size_t)need * 4 * sizeof(int32_t)));
+            ctx->flag_ovf_cap = need;
+        }
+        ovf = ctx->flag_ovf;
+        ovf_cap = (int)ctx->flag_ovf_cap;
+    }
     const bool sp = m->tiles_b3 && c->Xb3 && c->x_dtype == SEGK_F32 && c->D >= 8 && c->D <= 128 && (c->sp_pieces == 2 || c->sp_pieces == 3);
     const int n_tiles = segk_n_tiles(m->K_max);
     const size_t lds = (((size_t)m->K_max * 8 + ((size_t)m->K_max / 32 + 2) * 4 + 15) & ~(size_t)15) + (size_t)FIN_ROWS * c->D * sizeof(double);
@@ -1297,7 +1332,7 @@ int32_t segk_kmeans_batch_finalize(segk_ctx *ctx, const segk_corpus *c, segk_kme
         hipLaunchKernelGGL(k_batch_finalize<XT>, dim3((m->K_max + FIN_ROWS - 1) / FIN_ROWS), dim3(256), lds, st, *c, *m, records,
                            n_blocks_total, n_blocks_per_rank, rank_stride, flag_cap, my_rank, new_k, remap_scratch, out_scalars,
                            status, ctx && m->K_max <= 2048 ? ctx->row_hash : (unsigned long long *)nullptr,
-                           sp ? (unsigned int *)m->tiles_b3 + 1 : (unsigned int *)nullptr);
+                           sp ? (unsigned int *)m->tiles_b3 + 1 : (unsigned int *)nullptr, ovf, ovf_cap);
     });
     const int64_t nslot = (int64_t)(utt_hi - utt_lo) * c->N_max;
     const unsigned grid = (unsigned)(n_tiles + (nslot + 255) / 256);

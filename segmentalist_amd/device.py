@@ -10,6 +10,7 @@ import numpy as np
 
 from . import _abi
 from ._abi import SEGK_F32, SEGK_F64, SegkError, check, ptr
+from .comm import SingleComm, get_comm
 
 
 def _torch():
@@ -157,9 +158,9 @@ class DeviceKMeans(object):
                                  queue=self.cand_queue.data_ptr(), count=self.cand_count.data_ptr())
         self.status = torch.zeros(8, dtype=torch.int32, device=dev)
         self.assign_stale = None
-        # multi-rank batch sweeps: the process group of the sweeper (ensure_assignments / ensure_boundaries are
+        # multi-rank batch sweeps: the communicator of the sweeper (ensure_assignments / ensure_boundaries are
         # collectives on it) and the boundary buffer whose rows of other ranks' utterances are out of date
-        self.batch_group = None
+        self.batch_comm = SingleComm()
         self.bounds_stale = None
         self._L = _abi.lib()
         self._ctx = _abi.ctx()
@@ -192,46 +193,38 @@ class DeviceKMeans(object):
 
     def ensure_assignments(self, group=None):
         """Materialise `assignments` after batch sweeps (they only maintain the token lists).  With more than
-        one rank this is a COLLECTIVE on the sweeper's process group (every rank holds the tokens of its own
+        one rank this is a COLLECTIVE on the sweeper's communicator (every rank holds the tokens of its own
         utterances only): all ranks must call it -- directly or through `components.assignments`,
         `sum_neg_sqrd_norm()`, `state_dict()` ... -- together."""
         if self.assign_stale is None:
             return
-        if group is None:
-            group = self.batch_group
         lo, hi, world = self.assign_stale
         check(self._L.segk_kmeans_assignments_from_tokens(self._ctx, self._cp(), C.byref(self.m), lo, hi,
                                                           ptr(self.new_tok), ptr(self.new_k), ptr(self.n_new),
                                                           _abi.stream()))
         if world > 1:
-            import torch.distributed as dist
-            if dist.get_backend(group) == "nccl":
-                dist.all_reduce(self.assignments, op=dist.ReduceOp.MAX, group=group)
-            else:
-                h = self.assignments.cpu()
-                dist.all_reduce(h, op=dist.ReduceOp.MAX, group=group)
-                self.assignments.copy_(h)
+            (self.batch_comm if group is None else get_comm(group)).all_reduce_max(self.assignments)
         self.assign_stale = None
 
     def ensure_boundaries(self):
         """After multi-rank batch sweeps every rank has resegmented its own utterances only: fetch the rows of
-        the others (COLLECTIVE on the sweeper's process group, like ensure_assignments), so that
+        the others (COLLECTIVE on the sweeper's communicator, like ensure_assignments), so that
         `utterances.boundaries`, transcripts and checkpoints are the same, complete state on every rank."""
         if self.bounds_stale is None:
             return
         bounds, pt = self.bounds_stale
         torch = _torch()
-        import torch.distributed as dist
         mine = torch.zeros_like(bounds)
         mine[pt.utt_lo:pt.utt_hi] = bounds[pt.utt_lo:pt.utt_hi]
-        if dist.get_backend(self.batch_group) == "nccl":
-            dist.all_reduce(mine, op=dist.ReduceOp.MAX, group=self.batch_group)
-            bounds.copy_(mine)
-        else:
-            h = mine.cpu()
-            dist.all_reduce(h, op=dist.ReduceOp.MAX, group=self.batch_group)
-            bounds.copy_(h)
+        self.batch_comm.all_reduce_max(mine)
+        bounds.copy_(mine)
         self.bounds_stale = None
+
+    def ensure_state(self):
+        """Both of the above: what the sequential-mode entry points need after multi-rank batch sweeps (they read the
+        old boundaries and labels of utterances other ranks own).  A collective when anything is stale."""
+        self.ensure_assignments()
+        self.ensure_boundaries()
 
     def prepare(self):
         check(self._L.segk_kmeans_prepare(self._ctx, self._cp(), C.byref(self.m), _abi.stream()))
@@ -320,7 +313,7 @@ class DeviceKMeans(object):
         """The whole of segment_i (kmeans_acoustic_wordseg.py:225-332) for utterance i, enqueued
         asynchronously: score its spans, DP, del/add/clean in the reference's order."""
         c = self.corpus
-        self.ensure_assignments()
+        self.ensure_state()
         N = int(c.lengths_np[i])
         tri_i = N * (N + 1) // 2
         self.score_ptr(c.vec_ids.data_ptr() + 4 * i * c.tri, tri_i)
@@ -336,7 +329,7 @@ class DeviceKMeans(object):
         if self.corpus.x_dtype != SEGK_F32 or self.corpus.N_max > 63:
             return False
         torch = _torch()
-        self.ensure_assignments()
+        self.ensure_state()
         if getattr(self, "_seq_keys", None) is None:
             self._seq_keys = torch.zeros(self.corpus.tri + 2, dtype=torch.int64, device=self.means.device)
         arr = (C.c_int32 * len(order))(*[int(i) for i in order])
@@ -362,8 +355,9 @@ class DeviceKMeans(object):
         if bits & 2:
             raise AssertionError("add_item on an item that is already assigned (kmeans_components.py:101)")
         if bits & 4:
-            raise SegkError("batch sweep: more new tokens chose an inactive component than `flag_cap` per block "
-                            "(2048 per sweep); raise flag_cap")
+            raise SegkError("batch sweep: in one statistics block more new tokens chose an inactive component than "
+                            "`flag_cap`; the tokens beyond were dropped, so the statistics of this sweep are not usable: "
+                            "rebuild the segmenter (or load a checkpoint) with a larger flag_cap")
 
     def check_status(self):
         st = self.status.cpu().numpy()
@@ -390,21 +384,6 @@ class Partition(object):
         self.local_bounds = self.bounds[rank * self.nbl:(rank + 1) * self.nbl + 1].copy()
 
 
-def all_gather_rows(out, inp, group=None):
-    """out[r] <- inp of rank r.  `inp` is out[rank] (in-place all-gather).  RCCL directly on the
-    device buffers; under the gloo backend (CPU tests, several ranks sharing one GPU) the rows
-    are staged through host memory."""
-    import torch
-    import torch.distributed as dist
-    if dist.get_backend(group) == "nccl":
-        dist.all_gather_into_tensor(out.view(-1), inp, group=group)
-    else:
-        host = [torch.empty(inp.shape, dtype=inp.dtype) for _ in range(dist.get_world_size(group))]
-        dist.all_gather(host, inp.cpu(), group=group)
-        for r, h in enumerate(host):
-            out[r].copy_(h)
-
-
 class KMeansBatchSweeper(object):
     """One batch-synchronous sweep = score -> segment -> partials -> [ONE all-gather] -> finalize, all enqueued
     on the current stream.  With world == 1 there is no collective; with world > 1 every rank contributes one
@@ -415,7 +394,8 @@ class KMeansBatchSweeper(object):
     def __init__(self, dk, part, flag_cap=4096, group=None):
         torch = _torch()
         dev = _dev()
-        self.dk, self.part, self.cap, self.group = dk, part, int(flag_cap), group
+        self.dk, self.part, self.cap, self.comm = dk, part, int(flag_cap), get_comm(group)
+        assert self.comm.world == part.world and self.comm.rank == part.rank
         c = dk.corpus
         W = part.world
         self.rank_stride = int(dk._L.segk_kmeans_batch_record_words(dk.K_max, c.D, part.nbl, self.cap))
@@ -431,7 +411,7 @@ class KMeansBatchSweeper(object):
         import os
         self.use_graph = os.environ.get("SEGK_SWEEP_GRAPH", "0") == "1"
         self._graph, self._graph_args, self._side, self._warm = None, None, None, 0
-        dk.batch_group = group
+        dk.batch_comm = self.comm
 
     def _enqueue_front(self, boundaries, n_slices_min, n_slices_max, wip):
         dk, pt = self.dk, self.part
@@ -456,7 +436,7 @@ class KMeansBatchSweeper(object):
         else:
             self._enqueue_front(boundaries, n_slices_min, n_slices_max, wip)
             if pt.world > 1:
-                all_gather_rows(self.pack_all, self.pack, self.group)
+                self.comm.all_gather_rows(self.pack_all, self.pack)
             self._enqueue_back()
         dk.assign_stale = (pt.utt_lo, pt.utt_hi, pt.world)
         dk.bounds_stale = (boundaries, pt) if pt.world > 1 else None
@@ -493,7 +473,7 @@ class KMeansBatchSweeper(object):
             if self._warm < 1:
                 self._enqueue_front(boundaries, n_slices_min, n_slices_max, wip)
                 if pt.world > 1:
-                    all_gather_rows(self.pack_all, self.pack, self.group)
+                    self.comm.all_gather_rows(self.pack_all, self.pack)
                 self._enqueue_back()
                 self._warm += 1
             else:
@@ -511,7 +491,7 @@ class KMeansBatchSweeper(object):
                 st = _abi.stream()
                 check(dk._L.segk_graph_launch(dk._ctx, self._graph[0], st))
                 if pt.world > 1:
-                    all_gather_rows(self.pack_all, self.pack, self.group)
+                    self.comm.all_gather_rows(self.pack_all, self.pack)
                     check(dk._L.segk_graph_launch(dk._ctx, self._graph[1], st))
         cur.wait_stream(self._side)
 
@@ -708,7 +688,7 @@ class FbgmmBatchSweeper(object):
     def __init__(self, df, row_start, n_gibbs_blocks=8, n_stat_blocks=8, seed=0, group=None, score_precision="f64"):
         torch = _torch()
         dev = _dev()
-        self.df, self.group = df, group
+        self.df, self.comm = df, get_comm(group)
         assert score_precision in ("f64", "f32", "f16")
         if score_precision == "f16" and df.cov_type != 0:
             raise SegkError("score_precision='f16' (matrix-core span score) exists for fixed-variance components only")
@@ -721,13 +701,7 @@ class FbgmmBatchSweeper(object):
         self.score_diag32 = score_precision == "f32" and df.cov_type == 1
         c = df.corpus
         self.S, self.B = int(n_stat_blocks), int(n_gibbs_blocks)
-        rank, world = 0, 1
-        try:
-            import torch.distributed as dist
-            if dist.is_available() and dist.is_initialized():
-                rank, world = dist.get_rank(group), dist.get_world_size(group)
-        except ImportError:
-            pass
+        rank, world = self.comm.rank, self.comm.world
         if self.S % world != 0:
             raise SegkError("the number of statistics slices (%d) must be a multiple of the number of ranks (%d)"
                             % (self.S, world))
@@ -832,7 +806,7 @@ class FbgmmBatchSweeper(object):
         if self.world == 1:
             return
         out = full[b].view(self.world, -1)
-        all_gather_rows(out, out[self.rank], self.group)
+        self.comm.all_gather_rows(out, out[self.rank])
 
     def enter(self, boundaries):
         """Build the batch state (slots, token lists, all partial sums, transcripts) from the
@@ -916,12 +890,9 @@ class FbgmmBatchSweeper(object):
         """numpy copy of a per-utterance device vector with every rank's own utterances filled in."""
         v = t.cpu().numpy().copy()
         if self.world > 1:
-            import torch.distributed as dist
             lo = int(self.utt_range_np[self.s_lo, 0, 0])
             hi = int(self.utt_range_np[self.s_lo + self.s_n - 1, -1, 1])
-            parts = [None] * self.world
-            dist.all_gather_object(parts, (lo, hi, v[lo:hi]), group=self.group)
-            for plo, phi, x in parts:
+            for plo, phi, x in self.comm.all_gather_object((lo, hi, v[lo:hi])):
                 v[plo:phi] = x
         return v
 
@@ -950,16 +921,12 @@ class FbgmmBatchSweeper(object):
         if self.world > 1:
             # every rank holds the slots of its own rows only
             lo, hi = int(self.row_range_np[self.s_lo, 0, 0]), int(self.row_range_np[self.s_lo + self.s_n - 1, -1, 1])
-            import torch.distributed as dist
-            parts = [None] * self.world
-            dist.all_gather_object(parts, (lo, hi, df.assignments[lo:hi].cpu()), group=self.group)
-            for plo, phi, t in parts:
+            for plo, phi, t in self.comm.all_gather_object((lo, hi, df.assignments[lo:hi].cpu())):
                 df.assignments[plo:phi] = t.to(df.assignments.device)
             if boundaries is not None:          # the boundaries of the other ranks' utterances
                 ulo = int(self.utt_range_np[self.s_lo, 0, 0])
                 uhi = int(self.utt_range_np[self.s_lo + self.s_n - 1, -1, 1])
-                dist.all_gather_object(parts, (ulo, uhi, boundaries[ulo:uhi].cpu()), group=self.group)
-                for plo, phi, t in parts:
+                for plo, phi, t in self.comm.all_gather_object((ulo, uhi, boundaries[ulo:uhi].cpu())):
                     boundaries[plo:phi] = t.to(boundaries.device)
         if df.lm is not None:
             occ = torch.nonzero(self.remap >= 0).flatten()

@@ -24,6 +24,7 @@ import time
 import numpy as np
 
 from . import _abi, rng
+from .comm import get_comm
 from .device import DeviceCorpus, KMeansBatchSweeper, Partition, to_dev
 from .kmeans import KMeans, _consecutive
 from .utterances import Utterances, process_embeddings
@@ -137,15 +138,9 @@ class SegmentalKMeansWordseg(object):
     def _get_sweeper(self):
         if self._sweeper is None:
             n_blocks, cap, group = self._batch_args
-            rank, world = 0, 1
-            try:
-                import torch.distributed as dist
-                if dist.is_available() and dist.is_initialized():
-                    rank, world = dist.get_rank(group), dist.get_world_size(group)
-            except ImportError:
-                pass
-            part = Partition(self.utterances.D, self._row_start, n_blocks, rank, world)
-            self._sweeper = KMeansBatchSweeper(self._dk, part, cap, group)
+            comm = get_comm(group)
+            part = Partition(self.utterances.D, self._row_start, n_blocks, comm.rank, comm.world)
+            self._sweeper = KMeansBatchSweeper(self._dk, part, cap, comm)
         return self._sweeper
 
     def batch_sweep_async(self):

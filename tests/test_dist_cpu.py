@@ -29,7 +29,7 @@ def _worker(rank, world, port, out_dir):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from oracle import np_dist, np_oracle as no
-    from segmentalist_amd.device import all_gather_rows
+    from segmentalist_amd.comm import TorchComm, get_comm
 
     def ago(obj):
         out = [None] * world
@@ -55,11 +55,18 @@ def _worker(rank, world, port, out_dir):
     full = b.clone()
     for r in range(world):
         full[bb[r * nbl]:bb[(r + 1) * nbl]] = gathered[r][bb[r * nbl]:bb[(r + 1) * nbl]]
-    # the product's exchange helper on CPU tensors (gloo branch)
+    # the product's communicator on CPU tensors (gloo branch of segmentalist_amd/comm.py)
     rows = torch.zeros((world, 5), dtype=torch.float64)
     rows[rank] = torch.arange(5, dtype=torch.float64) + 10 * rank
-    all_gather_rows(rows, rows[rank])
+    comm = get_comm()
+    assert isinstance(comm, TorchComm) and (comm.rank, comm.world, comm.backend) == (rank, world, "gloo")
+    comm.all_gather_rows(rows, rows[rank])
     assert all(torch.equal(rows[r], torch.arange(5, dtype=torch.float64) + 10 * r) for r in range(world))
+    mx = torch.full((4,), -1, dtype=torch.int32)
+    mx[rank] = 7 + rank
+    comm.all_reduce_max(mx)
+    assert mx.tolist() == [7 + r if r < world else -1 for r in range(4)]
+    assert comm.all_gather_object(("r", rank)) == [("r", r) for r in range(world)]
     if rank == 0:
         np.savez(os.path.join(out_dir, "dist.npz"), assignments=a.numpy(), boundaries=full.numpy(),
                  means=c.means, mean_numerators=c.mean_numerators, counts=c.counts, K=np.array(c.K),

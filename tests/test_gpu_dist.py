@@ -46,7 +46,7 @@ def test_batch_mode_replayed_as_hipgraphs_is_independent_of_the_number_of_ranks(
 
 def test_batch_mode_over_rccl_when_the_box_has_two_gpus(tmp_path):
     """Backend nccl (= RCCL over xGMI): one rank per GPU, the per-sweep all-gather in place on the device buffer
-    (device.all_gather_rows), ensure_assignments / ensure_boundaries as device collectives.  Needs two GPUs: the
+    (comm.TorchComm.all_gather_rows), ensure_assignments / ensure_boundaries as device collectives.  Needs two GPUs: the
     single-GPU test box skips it, a multi-GPU box exercises the RCCL branch the first time it sees this suite."""
     import torch
     if torch.cuda.device_count() < 2:

@@ -99,3 +99,42 @@ def test_edge_cases_kmeans_batch_vs_specification(gpu, case):
         assert np.array_equal(c.assignments, rc.assignments), sw
         assert np.array_equal(c.means, rc.means), sw
         assert rec["sum_neg_len_sqrd_norm"][0] == tot
+
+
+def test_batch_sweep_with_thousands_of_new_components_in_one_sweep(gpu):
+    """a first sweep with K << K_max.  The inactive rows of `means` are data points
+    (kmeans_components.py:75-76, 149-166), so nearly every new token of the first batch sweep has an inactive row as its
+    argmax and founds a component through add_item's `k > K -> K` clamp (:102-106): several thousand flagged tokens in one
+    sweep, far beyond the 2048 the finalize kernel keeps in LDS (the rest goes through the context's overflow arrays).
+    Bit-exact against the specification sweep; a per-block cap that is too small raises instead of corrupting silently."""
+    from segmentalist_amd import _abi, kmeans_acoustic_wordseg as kaw
+    from segmentalist_amd.synth import make_corpus
+    n_utt, D, K_max = 1500, 8, 4000
+    # utterances longer than the window have no embedding for their single initial span: very few initial tokens
+    corpus = make_corpus(n_utt, D, 200, seed=77, ragged=True, n_slices_max=6, N_range=(5, 12))
+    kw = dict(n_slices_min=0, n_slices_max=6, p_boundary_init=0.0, init_am_assignments="rand", wip=0)
+    random.seed(2); np.random.seed(2)
+    ref = no.SegmentalKMeansWordseg(K_max, *corpus, **kw)
+    random.seed(2); np.random.seed(2)
+    seg = kaw.SegmentalKMeansWordseg(K_max, *corpus, sync="batch", n_stat_blocks=8, **kw)
+    cr, cd = ref.acoustic_model.components, seg.acoustic_model.components
+    assert cr.K < K_max // 8                       # at most one token per utterance at the start: most rows are inactive
+    K0 = cr.K
+    for it in range(2):
+        want = no.kmeans_batch_sweep(ref, n_blocks=8)
+        rec = seg.segment(1)
+        if it == 0:
+            assert cr.K - K0 > 2048, (K0, cr.K)    # more components founded in ONE sweep than the LDS list holds
+            assert int(seg._dk.n_flag.sum().item()) > 3000
+        assert np.array_equal(seg.utterances.boundaries, ref.utterances.boundaries), it
+        assert np.array_equal(cd.assignments, cr.assignments), it
+        assert cd.K == cr.K
+        assert np.array_equal(cd.counts, cr.counts)
+        assert np.array_equal(cd.mean_numerators, cr.mean_numerators), it
+        assert np.array_equal(cd.means, cr.means), it
+        assert rec["sum_neg_len_sqrd_norm"][0] == want
+    # the per-block cap is the one limit left, and exceeding it is loud
+    random.seed(2); np.random.seed(2)
+    small = kaw.SegmentalKMeansWordseg(K_max, *corpus, sync="batch", n_stat_blocks=8, flag_cap=64, **kw)
+    with pytest.raises(_abi.SegkError, match="flag_cap"):
+        small.segment(1)

@@ -89,3 +89,34 @@ def test_partition_covers_everything_once():
             assert len(p.local_bounds) == 8 // world + 1
         assert lo == 1000
     assert list(Partition(1000, row_start, 8, 0, 1).bounds) == no.block_bounds(1000, 8)
+
+
+def test_virtual_ranks_communicator_behaves_like_a_process_group():
+    """tests/virtual_ranks.py (eight ranks in one process for the one-GPU box): the three collectives of
+    segmentalist_amd/comm.py on CPU tensors, and a rank that skips a collective fails the run instead of passing."""
+    import pytest
+    import torch
+    from tests.virtual_ranks import VirtualWorld
+
+    def fn(comm):
+        rows = torch.zeros((comm.world, 3), dtype=torch.float64)
+        rows[comm.rank] = torch.arange(3, dtype=torch.float64) + 10 * comm.rank
+        comm.all_gather_rows(rows, rows[comm.rank])
+        mx = torch.full((comm.world,), -1, dtype=torch.int32)
+        mx[comm.rank] = comm.rank
+        comm.all_reduce_max(mx)
+        objs = comm.all_gather_object({"rank": comm.rank})
+        return rows, mx, objs
+
+    for rows, mx, objs in VirtualWorld(8).run(fn):
+        assert all(torch.equal(rows[r], torch.arange(3, dtype=torch.float64) + 10 * r) for r in range(8))
+        assert mx.tolist() == list(range(8))
+        assert [o["rank"] for o in objs] == list(range(8))
+
+    def skips(comm):
+        if comm.rank != 3:
+            comm.all_gather_object(comm.rank)
+        return comm.rank
+
+    with pytest.raises(RuntimeError, match="never entered"):
+        VirtualWorld(4, timeout=2).run(skips)
