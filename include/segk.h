@@ -45,7 +45,7 @@ const char *segk_last_error(void);
 /* ABI version, bumped on any change of a signature or of a structure below (SEGK_ABI_VERSION is the version this
  * header describes; a binding must refuse a library that reports another one: segmentalist_amd/_abi.py does).
  *   1 rounds 1-2 | 2 round 2: segk_corpus gained band_W / band_ids / band_dur (the bump was forgotten then)
- *   3 round 3: segk_fbb_set_probe; this check                                                            */
+ *   3 round 3: segk_fbb_set_probe, segk_kmeans_score_hinted; this check                                                           */
 #define SEGK_ABI_VERSION 3
 int32_t segk_abi_version(void);
 
@@ -57,7 +57,8 @@ int32_t segk_profile_enable(segk_ctx *ctx, int32_t on);
 int32_t segk_profile_read(segk_ctx *ctx, float *ms_out, int64_t *rows_out, int32_t max);
 /* Which kernel the most recent recorded launch was: 0 the fp32-MFMA filter, 2 / 3 the split-precision
  * filter (fp16x2 / bf16x3), 1 the one-product fp16 pre-filter (k_kmeans_score_h1: rows above ~260 k,
- * D % 4 == 0), 4 the log-sum-exp kernels of the FBGMM batch sampler; -1 none recorded.               */
+ * D % 4 == 0), 4 the log-sum-exp kernels of the FBGMM batch sampler, 5 the range-stationary one-product
+ * top-2 kernel of segk_kmeans_score_hinted (k_kmeans_top2_rs); -1 none recorded.                      */
 int32_t segk_profile_last_kind(segk_ctx *ctx);
 /* Number of back-to-back launches of that kernel the most recent recorded interval spans (the one-product
  * pre-filter runs as up to four launches of one round each, so that the exact stage of one chunk overlaps the
@@ -186,6 +187,21 @@ typedef struct segk_cand {
 int32_t segk_kmeans_score(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m,
                           const int32_t *ids, int64_t row0, int64_t n, const segk_cand *cand,
                           int32_t *status, void *stream);
+
+/* segk_kmeans_score with a HINT per row (no reference counterpart; the reference recomputes every argmax from nothing,
+ * kmeans_components.py:225-232): on entry cand->k[e] of every row to be processed names the component the caller expects to
+ * win -- normally what the previous call left there, the row's argmax under the previous statistics -- as a label of the
+ * numbering `hint_remap` translates into the current one (hint_remap [dev] int32 [K_max], e.g. the relabel table
+ * segk_kmeans_batch_finalize leaves in remap_scratch; NULL = identity; values outside [0, K_max) = no hint).  The library
+ * still evaluates every (row, component) product on the matrix cores, but only VERIFIES the hint against them (the two
+ * largest filter values and the hinted component's reference-arithmetic score; proof in segk_score_hint.hip) instead of
+ * tracking which component won; rows whose hint cannot be verified take the stages of segk_kmeans_score.  On return cand->k /
+ * cand->s are bit-identical to segk_kmeans_score's whatever the hints were: a wrong hint costs time, never correctness.
+ * Applies to float32 data with the fp16x2 row image (c->Xb3, sp_pieces 2), D % 4 == 0, launches of more than 384 rows per
+ * CU; everything else is forwarded to segk_kmeans_score.                                                               */
+int32_t segk_kmeans_score_hinted(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m,
+                                 const int32_t *ids, int64_t row0, int64_t n, const segk_cand *cand,
+                                 const int32_t *hint_remap, int32_t *status, void *stream);
 
 /* The three steps of segk_kmeans_score as separate calls (same arguments), for callers that
  * want to time or overlap them: clear_queue (cand->count = 0), filter (kernel 1), resolve

@@ -82,6 +82,7 @@ SIGNATURES = {
     "segk_kmeans_mark_duplicates": (_i32, [_P, _CP, _KP, _P, _P]),
     "segk_kmeans_init_stats": (_i32, [_P, _CP, _KP, _P]),
     "segk_kmeans_score": (_i32, [_P, _CP, _KP, _P, _i64, _i64, _DP, _P, _P]),
+    "segk_kmeans_score_hinted": (_i32, [_P, _CP, _KP, _P, _i64, _i64, _DP, _P, _P, _P]),
     "segk_kmeans_clear_queue": (_i32, [_P, _DP, _P]),
     "segk_kmeans_filter": (_i32, [_P, _CP, _KP, _P, _i64, _i64, _DP, _P]),
     "segk_kmeans_resolve": (_i32, [_P, _CP, _KP, _P, _i64, _i64, _DP, _P, _P]),

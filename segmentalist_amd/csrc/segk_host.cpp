@@ -89,6 +89,8 @@ int32_t segk_destroy(segk_ctx *ctx)
         if (ctx->chain_buf) (void)hipFree(ctx->chain_buf);
         if (ctx->fbs_buf) (void)hipFree(ctx->fbs_buf);
         if (ctx->flag_ovf) (void)hipFree(ctx->flag_ovf);
+        if (ctx->hint_part) (void)hipFree(ctx->hint_part);
+        if (ctx->hint_map) (void)hipFree(ctx->hint_map);
         if (ctx->ws_u64) (void)hipFree(ctx->ws_u64);
         if (ctx->pre_queue) (void)hipFree(ctx->pre_queue);
         if (ctx->row_hash) (void)hipFree(ctx->row_hash);

@@ -53,6 +53,11 @@ struct segk_ctx {
     int rb_K;
     int32_t *rb_misc;            // blk_lo [68], dummy K, flags; then doubles (part_tot, scalars, terms)
     double *rb_term;             // [rb_K] per-component terms of the record metrics
+    // hinted score path (segk_score_hint.hip): the filter's partial top-2 per (range, row), the hint map [K_max]
+    void *hint_part;
+    size_t hint_part_bytes;
+    int32_t *hint_map;
+    int hint_map_k;
     // k-means batch finalize: the flagged tokens of a sweep beyond the kernel's LDS list, [4][flag_ovf_cap] int32
     int32_t *flag_ovf;
     int64_t flag_ovf_cap;

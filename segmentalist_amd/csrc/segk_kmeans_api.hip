@@ -12,14 +12,11 @@ int32_t segk_kmeans_clear_queue(segk_ctx *ctx, const segk_cand *cand, void *stre
     return SEGK_OK;
 }
 
-int32_t segk_kmeans_filter(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m, const int32_t *ids,
-                           int64_t row0, int64_t n, const segk_cand *cand, void *stream)
+// launch arguments of the filter stage for rows ids[0..n) / row0..row0+n-1 (the split-precision members are filled when
+// the fp16x2 / bf16x3 images are in use: segk_use_b3)
+static ScoreArgs make_score_args(const segk_corpus *c, const segk_kmeans *m, const int32_t *ids, int64_t row0, int64_t n,
+                                 const segk_cand *cand, bool b3)
 {
-    SEGK_REQUIRE(ctx, "ctx");
-    int rc = score_checks(c, m, ids, row0, n, cand);
-    if (rc) return rc;
-    if (n <= 0) return SEGK_OK;
-    hipStream_t st = (hipStream_t)stream;
     ScoreArgs A{};
     A.X32 = c->X32; A.ld32 = c->ld32; A.ids = ids; A.row0 = row0; A.n = n;
     A.tiles = m->tiles; A.n_tiles = segk_n_tiles(m->K_max); A.tile_stride = segk_tile_stride(c->D);
@@ -29,11 +26,7 @@ int32_t segk_kmeans_filter(segk_ctx *ctx, const segk_corpus *c, const segk_kmean
     A.dbg = getenv("SEGK_SCORE_DBG") ? atoi(getenv("SEGK_SCORE_DBG")) : 0;
     A.xnorm = c->xnorm; A.mnorm2 = m->mnorm_max; A.cand = *cand; A.amb_cap = (int)c->n_emb;
     A.n_chunks = 0; A.tiles_per_split = 0; A.part_k = nullptr; A.part_f = nullptr;
-    // 4-wave workgroups, two per CU: the two waves sharing a SIMD belong to DIFFERENT workgroups
-    // and drift apart, covering each other's barrier/staging gaps.  (Measured: an 8-wave
-    // workgroup, one barrier for all eight waves, locks the SIMD partners in step and is 15 %
-    // slower although it halves the staging instructions per wave.)
-    if (segk_use_b3(c, m)) {
+    if (b3) {
         A.xrows32 = c->X32;
         A.X32 = (const float *)c->Xb3;
         A.tiles = m->tiles_b3;
@@ -42,6 +35,24 @@ int32_t segk_kmeans_filter(segk_ctx *ctx, const segk_corpus *c, const segk_kmean
         A.fuse_exact = (c->D % 4 == 0) ? 1 : 0;
         A.K_max = m->K_max;
         A.xerr = (const float *)((const unsigned char *)c->Xb3 + SEGK_SP_HEADER + c->n_emb * 2 * (int64_t)segk_b3_kp(c->D) * 2);
+    }
+    return A;
+}
+
+int32_t segk_kmeans_filter(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m, const int32_t *ids,
+                           int64_t row0, int64_t n, const segk_cand *cand, void *stream)
+{
+    SEGK_REQUIRE(ctx, "ctx");
+    int rc = score_checks(c, m, ids, row0, n, cand);
+    if (rc) return rc;
+    if (n <= 0) return SEGK_OK;
+    hipStream_t st = (hipStream_t)stream;
+    // 4-wave workgroups, two per CU: the two waves sharing a SIMD belong to DIFFERENT workgroups
+    // and drift apart, covering each other's barrier/staging gaps.  (Measured: an 8-wave
+    // workgroup, one barrier for all eight waves, locks the SIMD partners in step and is 15 %
+    // slower although it halves the staging instructions per wave.)
+    if (segk_use_b3(c, m)) {
+        const ScoreArgs A = make_score_args(c, m, ids, row0, n, cand, true);
         // one-product pre-filter in front (two-piece images, D % 4 == 0).  Its three extra launches -- and the
         // second stage's fixed cost, one workgroup's pass over every tile with all three products (~45 us)
         // -- pay once the split-precision kernel alone would need more than four rounds of the chip
@@ -58,8 +69,41 @@ int32_t segk_kmeans_filter(segk_ctx *ctx, const segk_corpus *c, const segk_kmean
         segk_flush_deferred_zero(ctx, st);
         return segk_dispatch_score_sp(ctx, A, segk_b3_kp(c->D) / 16, c->sp_pieces, st);
     }
+    const ScoreArgs A = make_score_args(c, m, ids, row0, n, cand, false);
     segk_flush_deferred_zero(ctx, st);
     return segk_dispatch_score_f32(ctx, c, m, A, st);
+}
+
+// Where the hinted path (segk_score_hint.hip) applies: float32 data with the fp16x2 images, D % 4 == 0, enough rows to
+// fill the chip (the threshold of the pre-filter path), SEGK_SCORE_HINT not 0 (=1: at every size, tests)
+static bool hinted_path_applies(const segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m, int64_t n)
+{
+    const char *he = getenv("SEGK_SCORE_HINT");
+    const int mode = he ? atoi(he) : -1;
+    if (mode == 0 || ctx->capturing) return false;
+    if (!segk_use_b3(c, m) || c->sp_pieces != 2 || c->D % 4 != 0) return false;
+    if (n >= (int64_t)1 << 30) return false;
+    // K1 keeps at most four LDS ranges of tile images, K2's table ranges must not outnumber the CUs
+    if (segk_n_tiles(m->K_max) > 4 * (int)((160 * 1024) / (((segk_b3_kp(c->D) / 16) * 256 + 32) * sizeof(float)))) return false;
+    return mode == 1 || n > 384 * (int64_t)ctx->n_cu;
+}
+
+int32_t segk_kmeans_score_hinted(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m, const int32_t *ids,
+                                 int64_t row0, int64_t n, const segk_cand *cand, const int32_t *hint_remap,
+                                 int32_t *status, void *stream)
+{
+    SEGK_REQUIRE(ctx, "ctx");
+    int rc = score_checks(c, m, ids, row0, n, cand);
+    if (rc) return rc;
+    if (n <= 0) return SEGK_OK;
+    if (!hinted_path_applies(ctx, c, m, n)) return segk_kmeans_score(ctx, c, m, ids, row0, n, cand, status, stream);
+    hipStream_t st = (hipStream_t)stream;
+    ctx->defer_zero = cand->count;                     // cleared by the path's first kernel, with its own queue length
+    const ScoreArgs A = make_score_args(c, m, ids, row0, n, cand, true);
+    rc = segk_dispatch_score_hint(ctx, A, hint_remap, segk_b3_kp(c->D) / 16, st);
+    segk_flush_deferred_zero(ctx, st);                 // (an early error return: nothing was launched)
+    if (rc) return rc;
+    return segk_resolve_on(ctx, c, m, ids, row0, n, cand, status, stream);
 }
 
 int32_t segk_kmeans_score(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m, const int32_t *ids,

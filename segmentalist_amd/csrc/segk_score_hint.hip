@@ -1,0 +1,603 @@
+// segk_score_hint.hip -- A1 with a HINT per row (round 3): the dense one-product fp16 contraction with a value-only top-2
+// drain, and an exact stage that verifies the hinted component against it.
+// (one of the translation units of the k-means path; shared helpers: segk_kmeans_dev.h)
+//
+// KMeansComponents.argmax_neg_sqrd_norm_i (kmeans_components.py:225-232) is evaluated for every row in every sweep, and from
+// one sweep to the next almost every row keeps its component (measured on the headline corpus: 6-17 % of the rows change
+// in sweeps 2-10, 0.1 % once the chain has settled; tools/diag_hint_stability.py).  The one-product pre-filter
+// (segk_score_h1.hip) spends as many vector-ALU issue cycles on its running top-2 -- five operations per two values, two
+// of them only to remember WHICH pair won -- as its matrix pipe spends on the products, and pays a staging barrier per
+// tile: 41 % matrix-pipe occupancy.  With a hint the index does not have to be tracked at all:
+//
+//   K1  k_kmeans_top2_rs   every (row, component) product on the matrix cores exactly as before (all K_max slots, nothing
+//       skipped), but the drain keeps only the two largest VALUES per row: m1' = max3(m1, a, b), m2' = max(m2, med3(m1, a, b))
+//       -- three operations per two values.  Range-stationary: a workgroup (8 waves, one per CU) copies the fp16 tile
+//       images of ONE range of components into LDS once (16 tiles = 114 KB for the headline model) and its waves stream
+//       row blocks past them without a single barrier; the constants -|m|^2/2 enter as the C operand of each block's
+//       first MFMA.  Output: (m1, m2) per (row, range).
+//   K2  k_kmeans_hint_exact   the component table in LDS as float32 (ranges, like k_kmeans_exact_pair4): for each row the
+//       hinted component h is scored in the reference's arithmetic, s = -|x - m_h|^2, together with |x|^2 in the same
+//       summation order, so that f_h = (s + |x|^2) / 2 = x.m_h - |m_h|^2/2 is known to within the reference's own
+//       rounding.  With F the filter values (|F_k - f_k| <= E for every k), top1 >= top2 their two largest and
+//       tau >= 2 E + E2 the pre-filter's margin (filter_tau_h1):
+//           top1 - top2 > tau            =>  the filter's argmax k1 is the reference's argmax      (as in the pre-filter)
+//           f_h >= top1 - tau + E + dl   =>  h = k1: any other k has F_k <= top2, so f_k <= top2 + E < top1 - tau + E
+//       (dl bounds the error of the computed f_h).  Both hold -> cand.k = h, cand.s = s: the reference's bits.  Otherwise
+//       the row is queued for the existing second stage (k_kmeans_score_sp, all three products) and, from there, the full
+//       scan -- exactly the rows the pre-filter would have queued plus the rows whose hint was wrong.  A hint that names a
+//       component the filters' images carry as "absent" (an exact duplicate of a lower row, segk_kmeans_mark_duplicates)
+//       is no hint: its F is not a bound on anything.
+//
+// Results are those of segk_kmeans_score whatever the hints are (a wrong hint costs time, never correctness); the
+// full-size parity tests run this path against the C oracle row by row.
+#include "segk_kmeans_dev.h"
+
+// cand.k between K1 and K2: (label | SEGK_HINT_BIT) = a usable hint, already mapped to the current labelling; -1 = no usable
+// hint.  K2's workgroups (one table range each) all scan every row: the mark tells a row that still waits for its range's
+// workgroup from one that workgroup has already given its final label.
+#define SEGK_HINT_BIT 0x20000000
+
+struct HintArgs {
+    const unsigned char *ximg;      // fp16x2 row image (segk_corpus.Xb3): header, then plane 0 [n_emb][KP]
+    const int32_t *ids;
+    int64_t row0, n;
+    const float *tiles;             // first tile of the fp16x2 tile image (tiles_b3 + 1024)
+    int n_tiles, tpr, n_ranges;     // tiles per range, ranges
+    float2 *part;                   // [n_ranges][n] (m1, m2) in the scaled domain of the images
+    int32_t *cand_k;                // hints in (labels of the previous call), marks out -- written by range 0's workgroups
+    const int32_t *map;             // [K_max] k_hint_map
+    int K_max;
+};
+
+// single instructions on MFMA outputs (fmaxf() would add a canonicalising v_max per operand)
+#define SEGK_TOP2_PAIR(M1, M2, A_, B_)                                                     \
+    do {                                                                                   \
+        /* the first read of the MFMA results is a compiler-visible instruction (hazard recogniser) */ \
+        const float t_ = __builtin_amdgcn_fmed3f(M1, A_, B_);                              \
+        asm volatile("v_max_f32 %1, %1, %2\n\tv_max3_f32 %0, %0, %3, %4" : "+v"(M1), "+v"(M2) : "v"(t_), "v"(A_), "v"(B_)); \
+    } while (0)
+
+template <int KS>
+__global__ __launch_bounds__(512, 2) void k_kmeans_top2_rs(HintArgs H)
+{
+    typedef _Float16 T;
+    typedef SegkPiece<2>::V8 V8;
+    constexpr int P = 2, KP = KS * 16, NBLK = 4;
+    constexpr int STRIDE = (KS * P * 256 + 32 + 1023) / 1024 * 1024;      // floats per tile of the global image
+    constexpr int TL = KS * 256 + 32;                                     // floats per tile in LDS: KS piece-0 blocks + constants
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int R = H.n_ranges;
+    // workgroup -> (range, slot).  Workgroups b and b + 8 share an XCD (round-robin placement, speed only): the R
+    // workgroups that stream the same rows sit on one XCD when the grid allows, so that the rows cross HBM once
+    int range, wgr, n_wgr;
+    if ((gridDim.x & 7) == 0 && ((gridDim.x >> 3) % R) == 0) {
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        range = idx % R;
+        wgr = (idx / R) * 8 + xcd;
+        n_wgr = gridDim.x / R;
+    } else {
+        n_wgr = gridDim.x / R;
+        range = blockIdx.x % R;
+        wgr = blockIdx.x / R;
+        if (wgr >= n_wgr) return;
+    }
+    const int t_lo = range * H.tpr;
+    int nt = H.n_tiles - t_lo;
+    if (nt > H.tpr) nt = H.tpr;
+    if (nt <= 0) return;
+    // ---- the range's tile images into LDS, once
+    for (int i = tid; i < nt * (KS * 64 + 8); i += 512) {
+        const int t = i / (KS * 64 + 8), q = i - t * (KS * 64 + 8);
+        const float *src = H.tiles + (int64_t)(t_lo + t) * STRIDE;
+        float4 v;
+        if (q < KS * 64) v = *reinterpret_cast<const float4 *>(src + ((q >> 6) * P) * 256 + (q & 63) * 4);      // piece 0 of k-step q >> 6
+        else v = *reinterpret_cast<const float4 *>(src + KS * P * 256 + (q - KS * 64) * 4);                    // the 32 constants
+        *reinterpret_cast<float4 *>(lds + t * TL + q * 4) = v;
+    }
+    __syncthreads();
+
+    const T *plane0 = (const T *)(H.ximg + SEGK_SP_HEADER);
+    const int64_t n_groups = (H.n + 32 * NBLK - 1) / (32 * NBLK);
+    const int64_t n_slots = (int64_t)n_wgr * 8;
+    for (int64_t g = (int64_t)wgr * 8 + wave; g < n_groups; g += n_slots) {
+        V8 xb[NBLK][KS];
+        int32_t hrow[NBLK], hk[NBLK];                                  // range 0, lane half 0: the row whose hint this lane marks
+#pragma unroll
+        for (int b = 0; b < NBLK; b++) {
+            const int64_t r = g * (32 * NBLK) + 32 * b + j;
+            int64_t rowid = -1;
+            if (r < H.n) rowid = H.ids ? (int64_t)H.ids[r] : H.row0 + r;
+            hrow[b] = (range == 0 && h == 0) ? (int32_t)rowid : -1;
+            if (rowid < 0) rowid = 0;                                  // a skipped entry of the id list: some valid row, result unused
+            const T *xp = plane0 + rowid * KP + 8 * h;
+#pragma unroll
+            for (int s = 0; s < KS; s++) xb[b][s] = *reinterpret_cast<const V8 *>(xp + 16 * s);
+        }
+#pragma unroll
+        for (int b = 0; b < NBLK; b++) hk[b] = hrow[b] >= 0 ? H.cand_k[hrow[b]] : -1;      // used after the tile loop
+        float m1[NBLK], m2[NBLK];
+#pragma unroll
+        for (int b = 0; b < NBLK; b++) { m1[b] = NEG_INF_F; m2[b] = NEG_INF_F; }
+
+        // operands of tile 0: A fragments (one ds_read_b128 per k-step) and the 16 constants of this lane half
+        V8 a[KS];
+        f32x16 cs;
+        auto load_a = [&](int t, int s) { a[s] = *reinterpret_cast<const V8 *>((const T *)(lds + t * TL) + (s * 64 + lane) * 8); };
+        auto load_cs = [&](int t) {
+            const float *cv = lds + t * TL + KS * 256 + 4 * h;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const float4 c4 = *reinterpret_cast<const float4 *>(cv + 8 * q);
+                cs[4 * q + 0] = c4.x; cs[4 * q + 1] = c4.y; cs[4 * q + 2] = c4.z; cs[4 * q + 3] = c4.w;
+            }
+        };
+#pragma unroll
+        for (int s = 0; s < KS; s++) load_a(0, s);
+        load_cs(0);
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int q = 0; q < 16; q++) acc1[q] = NEG_INF_F;              // "block 3 of tile -1": drains to nothing
+
+        // MFMAs of block N_ (accumulator AN) over the drain of block O_'s values (accumulator AO).  The eight pairs of the
+        // drain are spread over the MFMAs 1 .. KS-1: block O_'s last MFMA was issued just before this unit's first one, and a
+        // drain behind that one would wait out the matrix pipe's latency (the compiler pads it with s_nop 11).
+#define SEGK_RS_UNIT(N_, AN, O_, AO, REFILL)                                                                         \
+    do {                                                                                                              \
+        _Pragma("unroll") for (int s = 0; s < KS; s++) {                                                              \
+            /* The MFMA intrinsic has no side effects, so neither volatile asm nor sched_barrier orders it: instruction   */ \
+            /* selection sinks it towards its use, behind the drain.  Two empty asm statements pin it by DATA dependence: */ \
+            /* its A operand passes through the first, its result through the second.                                    */ \
+            asm volatile("" : "+v"(a[s]));                                                                            \
+            AN = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s], xb[N_][s], s == 0 ? cs : AN, 0, 0, 0);                  \
+            asm volatile("" : "+v"(AN));                                                                              \
+            if (REFILL) {                      /* this tile is done with a[s] (and, after its first MFMA, with cs) */ \
+                load_a(tn, s);                                                                                        \
+                if (s == 0) load_cs(tn);                                                                              \
+            }                                                                                                         \
+            __builtin_amdgcn_sched_barrier(0);         /* the MFMA first, then its share of the drain */               \
+            constexpr int SL = KS > 1 ? KS - 1 : 1;                                                                   \
+            const int p_lo = KS > 1 ? ((s - 1) * 8) / SL : 0, p_hi = KS > 1 ? (s * 8) / SL : 8;                       \
+            _Pragma("unroll") for (int pi = 0; pi < 8; pi++)                                                          \
+                if ((KS == 1 || s >= 1) && pi >= p_lo && pi < p_hi) SEGK_TOP2_PAIR(m1[O_], m2[O_], AO[2 * pi], AO[2 * pi + 1]); \
+            /* keep the order: one MFMA, then its share of the other block's drain (left alone, the scheduler issues */ \
+            /* the four blocks' MFMAs of a k-step together and the drains in one burst behind them)                  */ \
+            __builtin_amdgcn_sched_barrier(0);                                                                        \
+        }                                                                                                             \
+    } while (0)
+
+        // (two tiles per trip: with one, the accumulator of block 3 and the constants of the next tile change registers
+        // across the back edge -- 24 moves and an s_nop 11 per tile)
+#define SEGK_RS_TILE(t_)                                            \
+    do {                                                            \
+        const int tn = (t_) + 1 < nt ? (t_) + 1 : (t_);             \
+        SEGK_RS_UNIT(0, acc0, 3, acc1, false);                      \
+        SEGK_RS_UNIT(1, acc1, 0, acc0, false);                      \
+        SEGK_RS_UNIT(2, acc0, 1, acc1, false);                      \
+        SEGK_RS_UNIT(3, acc1, 2, acc0, true);                       \
+    } while (0)
+        int t = 0;
+        for (; t + 1 < nt; t += 2) {
+            SEGK_RS_TILE(t);
+            SEGK_RS_TILE(t + 1);
+        }
+        if (t < nt) SEGK_RS_TILE(t);
+#undef SEGK_RS_TILE
+#undef SEGK_RS_UNIT
+#pragma unroll
+        for (int pi = 0; pi < 8; pi++) SEGK_TOP2_PAIR(m1[3], m2[3], acc1[2 * pi], acc1[2 * pi + 1]);
+
+        // the two lane halves of a row hold 16 components of every tile each: merge, lane half 0 stores
+#pragma unroll
+        for (int b = 0; b < NBLK; b++) {
+            const float o1 = __shfl_xor(m1[b], 32), o2 = __shfl_xor(m2[b], 32);
+            const float top1 = fmaxf(m1[b], o1);
+            const float top2 = fmaxf(fminf(m1[b], o1), fmaxf(m2[b], o2));
+            const int64_t r = g * (32 * NBLK) + 32 * b + j;
+            if (h == 0 && r < H.n) H.part[(int64_t)range * H.n + r] = make_float2(top1, top2);
+            // the row's hint for K2: the previous label through the map, marked; -1 when there is none
+            if (hrow[b] >= 0) {
+                const int32_t hv = (hk[b] >= 0 && hk[b] < H.K_max) ? H.map[hk[b]] : -1;
+                H.cand_k[hrow[b]] = hv >= 0 ? (hv | SEGK_HINT_BIT) : -1;
+            }
+        }
+    }
+}
+#undef SEGK_TOP2_PAIR
+
+// map[k] = the label a hint k of the previous call stands for now (remap, identity when NULL), or -1 when that component
+// is carried as "absent" by the filters' images (seed constant <= -1e37: a marked duplicate) -- such a hint proves nothing
+__global__ void k_hint_map(const int32_t *remap, const float *tiles_sp /* first tile */, int K_max, int stride, int const_off, int32_t *map)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K_max) return;
+    int v = remap ? remap[k] : k;
+    if (v < 0 || v >= K_max) v = -1;
+    else if (tiles_sp[(int64_t)(v >> 5) * stride + const_off + (v & 31)] < -1.0e37f) v = -1;
+    map[k] = v;
+}
+
+struct HintExactArgs {
+    const float2 *part;             // K1's output
+    int n_ranges;
+    const float *tiles_hdr;         // tiles_b3: [0] exponent b, [1] E_m
+    const unsigned char *ximg;      // row image header: [1] exponent a
+};
+
+#define SEGK_HINT_ROWS 16       /* rows per step of a wave: four lanes per row */
+#define SEGK_HINT_RING 128
+#define SEGK_HINT_UBUF 192
+// K2: see the head of the file.  Skeleton of k_kmeans_exact_pair4 (the table split into P ranges of cpp components, one range
+// per workgroup in LDS; a wave walks its slice of the rows, keeps those whose hint lies in its range in a ring, takes 16 rows
+// per step off the ring and has the next step's loads in flight while it sums the current one).  Four lanes per row:
+// (member, half) -- member 0 is the hinted component, member 1 the zero vector, so that |x|^2 comes out of the same
+// pairwise summation; the four lanes of a row also fetch its (m1, m2) of up to four ranges, its norm bound and its residual.
+template <int KS, int V, int NW>
+__global__ __launch_bounds__(64 * NW) void k_kmeans_hint_exact(ScoreArgs A, HintExactArgs H, int P, int cpp)
+{
+    constexpr int D = 16 * KS - 4 * V, D4 = D >> 2;
+    constexpr int ps = D4 + ((2 - D4) & 3), LD = ps * 4;
+    constexpr int nfull = D & ~7, nblk = nfull >> 3, rem = D & 7;
+    constexpr int NX = nblk + (rem ? 1 : 0);
+    extern __shared__ __attribute__((aligned(16))) float lds[];    // [cpp][LD] member rows, then per wave: ring, undecided rows
+    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    typedef const __attribute__((address_space(1))) f32x4_t *gptr_t;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int part = blockIdx.x % P, chunk = blockIdx.x / P, n_chunk = gridDim.x / P;
+    if (chunk >= n_chunk) return;
+    const int c_lo = part * cpp;
+    int c_n = A.K_max - c_lo;
+    if (c_n > cpp) c_n = cpp;
+    for (int i = tid; i < c_n * D4; i += 64 * NW) {
+        const int r = i / D4, s4 = i - r * D4;
+        *reinterpret_cast<f32x4_t *>(lds + r * LD + 4 * s4) = *reinterpret_cast<const f32x4_t *>(A.means32 + (int64_t)(c_lo + r) * D + 4 * s4);
+    }
+    __syncthreads();
+    if (c_n <= 0 && part != 0) return;
+    int32_t *wbase = reinterpret_cast<int32_t *>(lds + (size_t)cpp * LD) + wave * (3 * SEGK_HINT_RING + SEGK_HINT_UBUF);
+    volatile int32_t *ring = wbase;                                 // [3][RING]: row id, local component, position in the launch
+    volatile int32_t *ubuf = wbase + 3 * SEGK_HINT_RING;            // undecided rows waiting for a queue reservation
+    int ucnt = 0;
+
+    const int e_ab = ((const int *)H.ximg)[1] + ((const int *)H.tiles_hdr)[0];
+    const float unscale = ldexpf(1.f, -e_ab);
+    const float M = (float)(sqrt(*A.mnorm2) * (1.0 + 1e-6)) + 1e-30f;
+    const float Em = H.tiles_hdr[1];
+
+    // this wave's rows: a multiple of 64 per wave
+    const int64_t n_slots = (int64_t)n_chunk * NW;
+    const int64_t per = ((A.n + n_slots - 1) / n_slots + 63) & ~(int64_t)63;
+    int64_t pos = ((int64_t)chunk * NW + wave) * per;
+    const int64_t r_end = pos + per < A.n ? pos + per : A.n;
+
+    auto load_rid = [&](int64_t p_) -> int32_t {
+        const int64_t r = p_ + lane;
+        return r < r_end ? (A.ids ? A.ids[r] : (int32_t)(A.row0 + r)) : -1;
+    };
+    auto pk_sub = [](f32x2_t a, f32x2_t b2) -> f32x2_t {           // a - b, both halves in one instruction
+        f32x2_t d;
+        asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b2));
+        return d;
+    };
+    // 64 undecided rows of the buffer to the second stage's queue (one reservation), the rest moves to the front
+    auto flush = [&](int nflush) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(A.pre_count, nflush);
+        base = __shfl(base, 0);
+        if (lane < nflush) {
+            const int q = base + lane;
+            const int32_t rid = ubuf[lane];
+            if (q < A.pre_cap) A.pre_queue[q] = rid;
+            else {                                                 // beyond the second stage's launch: full scan
+                const int q2 = atomicAdd(A.cand.count, 1);
+                if (q2 < A.amb_cap) A.cand.queue[q2] = rid;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int left = ucnt - nflush;
+        int32_t mv = 0;
+        if (lane < left) mv = ubuf[nflush + lane];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane < left) ubuf[lane] = mv;
+        int32_t mv2 = 0;
+        if (lane + 64 < left) mv2 = ubuf[nflush + 64 + lane];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane + 64 < left) ubuf[64 + lane] = mv2;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        ucnt = left;
+    };
+    auto push_undecided = [&](bool und, int32_t rid) {             // wave-wide: lanes with `und` append their row
+        const unsigned long long mask = __ballot(und);
+        if (mask == 0ull) return;
+        const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+        if (und) ubuf[ucnt + before] = rid;
+        ucnt += __popcll(mask);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        while (ucnt >= 64) flush(64);
+    };
+    const int row = lane >> 2, q4 = lane & 3, mem = (lane >> 1) & 1, h = lane & 1;
+
+    int32_t rid_n = -1, k_n = 0;
+    if (pos < r_end) {
+        rid_n = load_rid(pos);
+        k_n = rid_n >= 0 ? A.cand.k[rid_n] : -1;
+    }
+    int count = 0, head = 0;
+    bool have_prev = false;
+    f32x4_t xp[NX];
+    int32_t p_rid = -1, p_base = 0;
+    float p_aux = 0.f, p_m1 = NEG_INF_F, p_m2 = NEG_INF_F;
+    for (;;) {
+        // candidates into the ring until a step's worth is there
+        while (count < SEGK_HINT_ROWS && pos < r_end) {
+            const int32_t rid = rid_n, k = k_n;
+            const int64_t p_here = pos + lane;
+            pos += 64;
+            if (pos < r_end) {
+                rid_n = load_rid(pos);
+                k_n = rid_n >= 0 ? A.cand.k[rid_n] : -1;
+            }
+            // marked by K1: (label | SEGK_HINT_BIT) a hint, -1 none; anything else: already finished by its range's workgroup
+            int32_t hint = -1;
+            if (rid >= 0 && k >= 0 && (k & SEGK_HINT_BIT) && (k & ~SEGK_HINT_BIT) < A.K_max) hint = k & ~SEGK_HINT_BIT;
+            const int32_t base = hint - c_lo;
+            const bool sel = hint >= 0 && base >= 0 && base < c_n;
+            // a row without a usable hint belongs to nobody's range: range 0 sends it on
+            push_undecided(part == 0 && rid >= 0 && k == -1, rid);
+            const unsigned long long mask = __ballot(sel);
+            const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+            if (sel) {
+                const int at = (head + count + before) & (SEGK_HINT_RING - 1);
+                ring[at] = rid;
+                ring[SEGK_HINT_RING + at] = base;
+                ring[2 * SEGK_HINT_RING + at] = (int32_t)p_here;
+            }
+            count += __popcll(mask);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int n = count < SEGK_HINT_ROWS ? count : SEGK_HINT_ROWS;
+        // the next step: its rows off the ring, their loads into flight
+        int32_t n_rid = -1, n_base = 0, n_pos = 0;
+        if (row < n) {
+            const int at = (head + row) & (SEGK_HINT_RING - 1);
+            n_rid = ring[at];
+            n_base = ring[SEGK_HINT_RING + at];
+            n_pos = ring[2 * SEGK_HINT_RING + at];
+        }
+        head = (head + n) & (SEGK_HINT_RING - 1);
+        count -= n;
+        f32x4_t xn[NX];
+        float n_aux = 0.f, n_m1 = NEG_INF_F, n_m2 = NEG_INF_F;
+        {
+            const int64_t r_any = n_rid >= 0 ? (int64_t)n_rid : (A.ids ? 0 : A.row0);
+            const uintptr_t xa = (uintptr_t)(A.xrows32 + r_any * A.ld32);
+#pragma unroll
+            for (int b = 0; b < nblk; b++) xn[b] = *reinterpret_cast<gptr_t>(xa + 16u * h + 32u * b);
+            if constexpr (rem != 0) xn[nblk] = *reinterpret_cast<gptr_t>(xa + 4u * nfull);
+            // lane q of the row: the filter's (m1, m2) of range q; lane 0 also the norm bound, lane 1 the residual
+            if (n_rid >= 0) {
+                if (q4 < H.n_ranges) {
+                    const float2 pv = H.part[(int64_t)q4 * A.n + n_pos];
+                    n_m1 = pv.x;
+                    n_m2 = pv.y;
+                }
+                n_aux = q4 == 0 ? A.xnorm[n_rid] : q4 == 1 ? A.xerr[n_rid] : 0.f;
+            }
+        }
+        if (have_prev) {
+            // the reference's float32 -(deltas*deltas).sum() in numpy's pairwise order: this lane owns the strided
+            // accumulators r_{4h..4h+3}; member 0 = the hinted component, member 1 = 0 (gives -|x|^2)
+            const float *mrow = lds + p_base * LD;
+            f32x4_t mv[NX];
+#pragma unroll
+            for (int b = 0; b < nblk; b++) mv[b] = *reinterpret_cast<const f32x4_t *>(mrow + 4 * h + 8 * b);
+            if constexpr (rem != 0) mv[nblk] = *reinterpret_cast<const f32x4_t *>(mrow + nfull);
+            if (mem) {
+#pragma unroll
+                for (int b = 0; b < NX; b++) mv[b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            }
+            f32x2_t rl = {0.f, 0.f}, rh = {0.f, 0.f};
+#pragma unroll
+            for (int b = 0; b < nblk; b++) {
+                const f32x2_t dl = pk_sub(mv[b].xy, xp[b].xy), dh = pk_sub(mv[b].zw, xp[b].zw);
+                const f32x2_t tl = dl * dl, th = dh * dh;
+                rl = b == 0 ? tl : rl + tl;
+                rh = b == 0 ? th : rh + th;
+            }
+            float res = (rl.x + rl.y) + (rh.x + rh.y);
+            const float ro = __shfl_xor(res, 1);
+            res = (h == 0) ? res + ro : ro + res;                  // ((r0+r1)+(r2+r3)) + ((r4+r5)+(r6+r7))
+            if constexpr (rem != 0) {
+                const f32x2_t dl = pk_sub(mv[nblk].xy, xp[nblk].xy), dh = pk_sub(mv[nblk].zw, xp[nblk].zw);
+                const f32x2_t tl = dl * dl, th = dh * dh;
+                res += tl.x;
+                if (rem > 1) res += tl.y;
+                if (rem > 2) res += th.x;
+                if (rem > 3) res += th.y;
+            }
+            const float sc = -res;                                 // lanes 0, 1 of the row: -|x - m_h|^2; lanes 2, 3: -|x|^2
+            const float so = __shfl_xor(sc, 2);
+            // the filter's top-2 over the ranges: (a1, a2) + (b1, b2) = (max(a1, b1), max(min(a1, b1), max(a2, b2)))
+            float t1 = p_m1, t2 = p_m2;
+#pragma unroll
+            for (int o = 1; o <= 2; o <<= 1) {
+                const float u1 = __shfl_xor(t1, o), u2 = __shfl_xor(t2, o);
+                const float n1 = fmaxf(t1, u1);
+                t2 = fmaxf(fminf(t1, u1), fmaxf(t2, u2));
+                t1 = n1;
+            }
+            const float xnb = __shfl(p_aux, lane & ~3), xer = __shfl(p_aux, (lane & ~3) | 1);
+            bool und = false;
+            if (q4 == 0 && p_rid >= 0) {
+                const float top1 = t1 * unscale, top2 = t2 * unscale;          // powers of two: exact
+                const float u = 5.9604645e-8f;
+                const float tau = filter_tau_h1(xnb, M, D, xer, Em);
+                // E: bound of |F_k - f_k| (accumulation + operand rounding, the terms of tau); dl: of the computed f_h
+                const float e1 = (1.02f * (float)(KS * 16 + 16) + 16.f) * u * (xnb * M + 0.5f * M * M);
+                const float rnd = 1.00001f * fminf((xnb + xer) * Em + xer * M, 1.01f * 9.765625e-4f * xnb * M);
+                const float s2 = xnb + M;
+                const float dl = ((float)(D / 8 + 13) + 4.f) * u * s2 * s2;
+                const float fh = 0.5f * (sc - so);                             // x.m_h - |m_h|^2/2
+                const bool ok = (top1 - top2 > tau) && (fh >= top1 - tau + (e1 + rnd + dl) * 1.0001f);
+                if (ok) {
+                    A.cand.k[p_rid] = p_base + c_lo;
+                    A.cand.s[p_rid] = (double)sc;
+                    A.cand.f[2 * (int64_t)p_rid + 0] = top1;
+                    A.cand.f[2 * (int64_t)p_rid + 1] = top2;
+                } else {
+                    und = true;
+                }
+            }
+            push_undecided(und, p_rid);
+        }
+        if (n == 0) break;
+#pragma unroll
+        for (int b = 0; b < NX; b++) xp[b] = xn[b];
+        p_rid = n_rid;
+        p_base = n_base;
+        p_aux = n_aux;
+        p_m1 = n_m1;
+        p_m2 = n_m2;
+        have_prev = true;
+    }
+    if (ucnt > 0) flush(ucnt);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+template <int KS>
+static int launch_score_hint(segk_ctx *ctx, ScoreArgs A, const int32_t *remap, hipStream_t st)
+{
+    const int n_cu = ctx->n_cu;
+    // ---- workspaces: the second stage's queue (as the pre-filter path), K1's partial top-2, the hint map
+    if (ctx->pre_cap < A.n) {
+        SEGK_REQUIRE(!ctx->capturing, "workspaces must exist before a graph capture (run the sequence once first)");
+        if (ctx->pre_queue) SEGK_CHECK_HIP(hipFree(ctx->pre_queue));
+        ctx->pre_queue = nullptr;
+        ctx->pre_cap = 0;
+        SEGK_CHECK_HIP(hipMalloc((void **)&ctx->pre_queue, sizeof(int32_t) * (size_t)(A.n + 16)));
+        ctx->pre_cap = A.n;
+    }
+    A.pre_queue = ctx->pre_queue + 16;
+    A.pre_count = ctx->pre_queue;
+    A.pre_cap = (int)A.n;
+    // K1's ranges: as many tiles as fit in LDS beside nothing else (one workgroup per CU)
+    constexpr int TL = KS * 256 + 32;
+    const int max_tiles = (int)((160 * 1024) / (TL * sizeof(float)));
+    int n_ranges = (A.n_tiles + max_tiles - 1) / max_tiles;
+    // two ranges at least when that halves the LDS fill per workgroup without starving the grid (the fill is per workgroup)
+    if (n_ranges < 1) n_ranges = 1;
+    const int tpr = (A.n_tiles + n_ranges - 1) / n_ranges;
+    SEGK_REQUIRE(n_ranges <= 4, "hinted score path: K_max too large (more than four LDS ranges of tile images)");
+    const size_t need_part = (size_t)n_ranges * (size_t)A.n * sizeof(float2);
+    if (ctx->hint_part_bytes < need_part || !ctx->hint_map || ctx->hint_map_k < A.K_max) {
+        SEGK_REQUIRE(!ctx->capturing, "workspaces must exist before a graph capture (run the sequence once first)");
+        SEGK_CHECK_HIP(hipStreamSynchronize(st));
+        if (ctx->hint_part_bytes < need_part) {
+            if (ctx->hint_part) (void)hipFree(ctx->hint_part);
+            ctx->hint_part = nullptr;
+            ctx->hint_part_bytes = 0;
+            SEGK_CHECK_HIP(hipMalloc((void **)&ctx->hint_part, need_part));
+            ctx->hint_part_bytes = need_part;
+        }
+        if (!ctx->hint_map || ctx->hint_map_k < A.K_max) {
+            if (ctx->hint_map) (void)hipFree(ctx->hint_map);
+            ctx->hint_map = nullptr;
+            SEGK_CHECK_HIP(hipMalloc((void **)&ctx->hint_map, sizeof(int32_t) * (size_t)A.K_max));
+            ctx->hint_map_k = A.K_max;
+        }
+    }
+    // queue lengths of the call (the caller's ambiguity queue, deferred by segk_kmeans_score, and the second stage's)
+    int32_t *zero_cnt = ctx->defer_zero;
+    ctx->defer_zero = nullptr;
+    if (zero_cnt) hipLaunchKernelGGL(k_zero_two, dim3(1), dim3(64), 0, st, zero_cnt, ctx->pre_queue);
+    else SEGK_CHECK_HIP(hipMemsetAsync(ctx->pre_queue, 0, 16 * sizeof(int32_t), st));
+    const int stride_sp = segk_sp_tile_stride(A.D, 2);
+    hipLaunchKernelGGL(k_hint_map, dim3((A.K_max + 255) / 256), dim3(256), 0, st, remap, A.tiles + 1024, A.K_max, stride_sp,
+                       KS * 2 * 256, ctx->hint_map);
+
+    // ---- K1
+    HintArgs H{};
+    H.ximg = (const unsigned char *)A.X32;
+    H.ids = A.ids; H.row0 = A.row0; H.n = A.n;
+    H.tiles = A.tiles + 1024;
+    H.n_tiles = A.n_tiles; H.tpr = tpr; H.n_ranges = n_ranges;
+    H.part = (float2 *)ctx->hint_part;
+    H.cand_k = A.cand.k;
+    H.map = ctx->hint_map;
+    H.K_max = A.K_max;
+    const size_t lds1 = (size_t)tpr * TL * sizeof(float);
+    int grid1 = (n_cu / n_ranges) * n_ranges;
+    {   // no more workgroups than there are 1024-row steps per range (each of the 8 waves takes 128 rows at a time)
+        const int64_t steps = (A.n + 1023) / 1024;
+        if ((int64_t)grid1 / n_ranges > steps) grid1 = (int)steps * n_ranges;
+    }
+    SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_kmeans_top2_rs<KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+    const bool prof = ctx->prof_on != 0;
+    const int slot = ctx->prof_n % SEGK_PROF_SLOTS;
+    if (prof) SEGK_CHECK_HIP(hipEventRecord(ctx->prof_ev[slot][0], st));
+    hipLaunchKernelGGL((k_kmeans_top2_rs<KS>), dim3((unsigned)grid1), dim3(512), lds1, st, H);
+    if (prof) {
+        SEGK_CHECK_HIP(hipEventRecord(ctx->prof_ev[slot][1], st));
+        ctx->prof_rows[slot] = A.n;
+        ctx->prof_kind = 5;
+        ctx->prof_launches = 1;
+        ctx->prof_n++;
+    }
+
+    // ---- K2: the float32 table in LDS, split into P ranges
+    HintExactArgs E{};
+    E.part = (const float2 *)ctx->hint_part;
+    E.n_ranges = n_ranges;
+    E.tiles_hdr = A.tiles;
+    E.ximg = (const unsigned char *)A.X32;
+    const int pitch4 = ((A.D >> 2) + ((2 - (A.D >> 2)) & 3)) * 16;
+    constexpr int NW = 8;
+    const int64_t fixed_b = (int64_t)NW * (3 * SEGK_HINT_RING + SEGK_HINT_UBUF) * 4;
+    const int64_t cpp_max = (160 * 1024 - fixed_b) / pitch4;
+    SEGK_REQUIRE(cpp_max > 0, "hinted score path: no room for the component table");
+    const int parts = (int)((A.K_max + cpp_max - 1) / cpp_max);
+    SEGK_REQUIRE(parts <= n_cu, "hinted score path: more table ranges than CUs");
+    const int cpp = (A.K_max + parts - 1) / parts;
+    const size_t lds2 = (size_t)cpp * pitch4 + (size_t)fixed_b;
+    const unsigned grid2 = (unsigned)((n_cu / parts) * parts);
+#define SEGK_HINT_LAUNCH(VV)                                                                                                       \
+    do {                                                                                                                            \
+        SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_kmeans_hint_exact<KS, VV, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2)); \
+        hipLaunchKernelGGL((k_kmeans_hint_exact<KS, VV, NW>), dim3(grid2), dim3(64 * NW), lds2, st, A, E, parts, cpp);              \
+    } while (0)
+    switch ((16 * KS - A.D) / 4) {
+        case 0: SEGK_HINT_LAUNCH(0); break;
+        case 1: SEGK_HINT_LAUNCH(1); break;
+        case 2: SEGK_HINT_LAUNCH(2); break;
+        default: SEGK_HINT_LAUNCH(3); break;
+    }
+#undef SEGK_HINT_LAUNCH
+    // ---- the rows K2 queued: all three products (the pre-filter's second stage); its own undecided rows go to cand.queue
+    ScoreArgs B = A;
+    B.ids = A.pre_queue;
+    B.row0 = 0;
+    B.n = A.n;
+    B.n_dev = ctx->pre_queue;
+    if (int rc = segk_launch_sp_second(ctx, B, KS, st)) return rc;
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+int segk_dispatch_score_hint(segk_ctx *ctx, const ScoreArgs &A, const int32_t *remap, int ks, hipStream_t st)
+{
+    switch (ks) {
+        case 1: return launch_score_hint<1>(ctx, A, remap, st);
+        case 2: return launch_score_hint<2>(ctx, A, remap, st);
+        case 3: return launch_score_hint<3>(ctx, A, remap, st);
+        case 4: return launch_score_hint<4>(ctx, A, remap, st);
+        case 5: return launch_score_hint<5>(ctx, A, remap, st);
+        case 6: return launch_score_hint<6>(ctx, A, remap, st);
+        case 7: return launch_score_hint<7>(ctx, A, remap, st);
+        case 8: return launch_score_hint<8>(ctx, A, remap, st);
+        default: break;
+    }
+    segk_set_error("hinted score path: D out of range");
+    return SEGK_ERR_UNSUPPORTED;
+}

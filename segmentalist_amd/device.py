@@ -229,15 +229,22 @@ class DeviceKMeans(object):
     def prepare(self):
         check(self._L.segk_kmeans_prepare(self._ctx, self._cp(), C.byref(self.m), _abi.stream()))
 
-    def score_rows(self, ids=None, row0=0, n=None):
+    def score_rows(self, ids=None, row0=0, n=None, hint_remap=None):
         """A1 over rows (device int32 tensor `ids`, or the range row0..row0+n): afterwards
-        cand_k / cand_s hold np.argmax / np.max of neg_sqrd_norm for those rows."""
+        cand_k / cand_s hold np.argmax / np.max of neg_sqrd_norm for those rows.
+        hint_remap (device int32 [K_max]): cand_k of these rows holds what the previous call left there, in the labelling
+        that table translates into the current one -- the library then verifies those hints against the dense filter values
+        instead of tracking the winner's index (segk_kmeans_score_hinted); the results are the same bits either way."""
         if ids is not None:
             n = ids.numel()
             p = ptr(ids)
         else:
             p = None
             n = self.corpus.n_emb - row0 if n is None else n
+        if hint_remap is not None:
+            check(self._L.segk_kmeans_score_hinted(self._ctx, self._cp(), C.byref(self.m), p, int(row0), int(n),
+                                                   C.byref(self.cand), ptr(hint_remap), ptr(self.status), _abi.stream()))
+            return
         check(self._L.segk_kmeans_score(self._ctx, self._cp(), C.byref(self.m), p, int(row0), int(n),
                                         C.byref(self.cand), ptr(self.status), _abi.stream()))
 
@@ -411,12 +418,15 @@ class KMeansBatchSweeper(object):
         import os
         self.use_graph = os.environ.get("SEGK_SWEEP_GRAPH", "0") == "1"
         self._graph, self._graph_args, self._side, self._warm = None, None, None, 0
+        self._hints = False          # no sweep of this sweeper has filled cand_k / remap yet
         dk.batch_comm = self.comm
 
     def _enqueue_front(self, boundaries, n_slices_min, n_slices_max, wip):
         dk, pt = self.dk, self.part
         L, ctx, cp, mp, st = dk._L, dk._ctx, dk._cp(), C.byref(dk.m), _abi.stream()
-        dk.score_rows(row0=pt.row_lo, n=pt.row_hi - pt.row_lo)
+        # from the second sweep on cand_k holds every row's argmax of the previous sweep and dk.remap the relabelling of
+        # that sweep's finalize: hints for the score stage (same results)
+        dk.score_rows(row0=pt.row_lo, n=pt.row_hi - pt.row_lo, hint_remap=dk.remap if self._hints else None)
         dk.segment(boundaries, n_slices_min, n_slices_max, wip, utt0=pt.utt_lo, n_utts=pt.utt_hi - pt.utt_lo)
         check(L.segk_kmeans_batch_partials(ctx, cp, mp, ptr(self.blk_lo), pt.nbl, ptr(dk.new_tok), ptr(dk.new_k),
                                            ptr(dk.n_flag), ptr(dk.out_total), ptr(self.sorted), ptr(self.koff),
@@ -440,6 +450,7 @@ class KMeansBatchSweeper(object):
             self._enqueue_back()
         dk.assign_stale = (pt.utt_lo, pt.utt_hi, pt.world)
         dk.bounds_stale = (boundaries, pt) if pt.world > 1 else None
+        self._hints = True
 
     # ------------------------------------------------------------------ hipGraph replay
     def _capture(self, fn):

@@ -84,6 +84,75 @@ def test_a1_max_argmax_vs_oracle_random(gpu, monkeypatch, D, K, n, dtype, b3):
     assert 1 <= nbrute < n             # the tie takes the full scan; the filter decides most rows
 
 
+
+@pytest.mark.parametrize("D,K,n", [(100, 1000, 6000), (8, 33, 3000), (40, 257, 5000), (128, 2300, 4000), (12, 64, 2000),
+                                    (64, 700, 9000)])
+def test_a1_hinted_path_vs_oracle_random(gpu, monkeypatch, D, K, n):
+    """segk_kmeans_score_hinted forced at small sizes (SEGK_SCORE_HINT=1) on random data with engineered exact ties: hints
+    that are right, wrong, garbage and duplicates of the winner; row ranges and id lists (with -1 entries and an offset);
+    one, two and four LDS ranges of tile images (K = 2300: 72 tiles).  cand_k / cand_s == the C oracle, bit for bit."""
+    import torch
+    from oracle import c_oracle as co
+    monkeypatch.setenv("SEGK_SCORE_HINT", "1")
+    rs = np.random.RandomState(D * 7 + K)
+    K_true = max(2, K // 2)
+    mu = rs.randn(K_true, D)
+    X = mu[rs.randint(0, K_true, n)] + 0.3 * rs.randn(n, D)
+    X /= np.linalg.norm(X, axis=1, keepdims=True)
+    X = X.astype(np.float32)
+    means = mu[rs.randint(0, K_true, K)] + 0.05 * rs.randn(K, D)
+    means /= np.linalg.norm(means, axis=1, keepdims=True)
+    means = means.astype(np.float32)
+    means[K // 2] = means[1]          # exact duplicate of row 1 ...
+    X[5] = means[1]                   # ... and a data point sitting on it
+    c = _components(X, means)
+    from segmentalist_amd import _abi
+    from segmentalist_amd._abi import ptr
+    import ctypes as C
+    _abi.check(_abi.lib().segk_kmeans_mark_duplicates(c.dev._ctx, c.dev._cp(), C.byref(c.dev.m), None, _abi.stream()))
+    want_s, want_k = co.kmeans_max_argmax(means, X)
+    ident = torch.arange(K, dtype=torch.int32, device="cuda")
+
+    def run(hints, ids=None, row0=0, nrows=None, remap=ident):
+        c.dev.cand_k.copy_(torch.from_numpy(hints.astype(np.int32)).cuda())
+        c.dev.cand_s.fill_(float("nan"))
+        _abi.check(_abi.lib().segk_profile_enable(c.dev._ctx, 1))
+        if ids is None:
+            c.dev.score_rows(row0=row0, n=nrows, hint_remap=remap)
+        else:
+            c.dev.score_rows(ids=torch.from_numpy(ids.astype(np.int32)).cuda(), hint_remap=remap)
+        torch.cuda.synchronize()
+        kind = int(_abi.lib().segk_profile_last_kind(c.dev._ctx))
+        _abi.check(_abi.lib().segk_profile_enable(c.dev._ctx, 0))
+        assert kind == 5, kind
+        return c.dev.cand_k.cpu().numpy(), c.dev.cand_s.cpu().numpy()
+
+    # right hints, whole range
+    k, s = run(want_k)
+    assert np.array_equal(k, want_k) and np.array_equal(s, want_s.astype(np.float64))
+    assert k[5] == 1
+    # hint = the duplicate of the winner
+    adv = want_k.copy()
+    adv[want_k == 1] = K // 2
+    k, s = run(adv)
+    assert np.array_equal(k, want_k) and np.array_equal(s, want_s.astype(np.float64))
+    # wrong / garbage hints on a sub-range with an offset
+    junk = rs.choice(np.array([-1, -5, K, 2 ** 29 | 1, 2 ** 30 | 2, 2 ** 31 - 1], dtype=np.int64), n)
+    hints = np.where(rs.rand(n) < 0.3, want_k, np.where(rs.rand(n) < 0.5, rs.randint(0, K, n), junk))
+    r0, nr = 37, n - 100
+    k, s = run(hints, row0=r0, nrows=nr)
+    assert np.array_equal(k[r0:r0 + nr], want_k[r0:r0 + nr]) and np.array_equal(s[r0:r0 + nr], want_s[r0:r0 + nr].astype(np.float64))
+    assert np.array_equal(k[:r0], hints[:r0].astype(np.int32)) and np.isnan(s[:r0]).all()       # rows outside the call untouched
+    # an id list with skipped entries, through a relabel table
+    perm = rs.permutation(K).astype(np.int32)
+    inv = np.argsort(perm)
+    ids = rs.permutation(n)[: n // 2].astype(np.int64)
+    ids[::17] = -1
+    k, s = run(inv[want_k], ids=ids, remap=torch.from_numpy(perm).cuda())
+    live = ids[ids >= 0]
+    assert np.array_equal(k[live], want_k[live]) and np.array_equal(s[live], want_s[live].astype(np.float64))
+
+
 def test_a1_filter_candidate_is_within_margin(gpu):
     """The fp32 MFMA filter's winner must be the true argmax or inside the proven margin."""
     import torch
