@@ -308,8 +308,7 @@ def main_sequential(args):
     torch.cuda.set_device(0)
     from segmentalist_amd import kmeans_acoustic_wordseg as kaw
     from segmentalist_amd.synth import make_corpus
-    steps = args.steps if args.steps != 50 else 3
-    warmup = args.warmup if args.warmup != 5 else 1
+    steps, warmup = args.steps, args.warmup
     corpus = make_corpus(args.utts, args.dim, args.K, seed=0, N=args.landmarks, n_slices_max=args.n_slices_max)
     random.seed(0)
     np.random.seed(0)
@@ -331,20 +330,25 @@ def main_sequential(args):
                    "utterances": args.utts, "landmarks_per_utt": args.landmarks, "n_slices_max": args.n_slices_max,
                    "D": args.dim, "K": args.K, "components_after": int(seg.acoustic_model.components.K),
                    "sweep_seconds_including_record_keeping": [float(t) for t in rec["sample_time"]]},
+        "note": "`value` is wall time over the whole segment() call, record keeping of every sweep included; "
+                "record['sample_time'] (the reference's own bracket: the per-utterance loop only) is listed in config",
     }))
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=None, help="timed sweeps per window (default 50; kmeans_c3_sequential: 3)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed sweeps first (default 5; kmeans_c3_sequential: 1)")
     ap.add_argument("--utts", type=int, default=10000)
     ap.add_argument("--dim", type=int, default=100)
     ap.add_argument("--K", type=int, default=1000)
     ap.add_argument("--landmarks", type=int, default=20)
     ap.add_argument("--n-slices-max", type=int, default=6)
-    ap.add_argument("--windows", type=int, default=9, help="timed windows of --steps sweeps each; the median is reported")
+    ap.add_argument("--windows", type=int, default=9, help="timed windows of --steps sweeps each (at least; more are added "
+                    "until --min-seconds of timed sweeps have run); the median window is reported")
+    ap.add_argument("--min-seconds", type=float, default=2.0, help="lower bound of the total timed region")
+    ap.add_argument("--no-seq-chain", action="store_true", help="skip the sequential_chain extra key (N = 1)")
     ap.add_argument("--cpu-utts", type=int, default=2000, help="utterances timed for cpu_baseline (0 = skip)")
     ap.add_argument("--no-events", action="store_true", help="do not bracket the score kernel with events")
     ap.add_argument("--workload", default="kmeans_c3", choices=["kmeans_c3", "fbgmm_diag_c2", "bigram_c5", "kmeans_c3_sequential"],
@@ -354,7 +358,12 @@ def main():
                          "kmeans_c3_sequential = the headline corpus through the reference's own sequential chain "
                          "(sync='sequential', the API default; one GPU; --steps sweeps after --warmup, default 3 after 1)")
     args = ap.parse_args()
-    if args.workload == "kmeans_c3_sequential":
+    seq = args.workload == "kmeans_c3_sequential"
+    if args.steps is None:
+        args.steps = 3 if seq else 50
+    if args.warmup is None:
+        args.warmup = 1 if seq else 5
+    if seq:
         return main_sequential(args)
     if args.workload != "kmeans_c3":
         return main_fbgmm(args)
@@ -411,13 +420,23 @@ def main():
     # synchronize on both sides and reduced with MAX over the ranks; the line reports the MEDIAN window (a 13 ms
     # window moves by percent with one clock ramp; the spread is reported beside it)
     win = []
-    for _ in range(max(1, args.windows)):
+    n_windows = max(1, args.windows)
+    w = 0
+    while w < n_windows:
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             seg.batch_sweep_async()
         barrier()
         win.append(time.perf_counter() - t0)
+        w += 1
+        if w == 1 and args.min_seconds > 0:
+            # as many windows as it takes for the timed region to last --min-seconds (the driver's independent busy
+            # sampling must be able to see the run); every rank derives the same count from the slowest rank's first window
+            t1 = torch.tensor([win[0]], dtype=torch.float64, device="cuda" if (world > 1 and dist.get_backend() == "nccl") else "cpu")
+            if world > 1:
+                dist.all_reduce(t1, op=dist.ReduceOp.MAX)
+            n_windows = int(min(4000, max(n_windows, np.ceil(args.min_seconds / max(float(t1.item()), 1e-6)))))
     seg._dk.check_status()
     if world > 1:
         t = torch.tensor(win, dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
@@ -434,7 +453,7 @@ def main():
 
     score_ms, score_rows = None, rows_local
     if use_ev:
-        nmax = min(args.steps * max(1, args.windows), 256)
+        nmax = min(args.steps * len(win), 256)
         ms = (C.c_float * nmax)()
         rows = (C.c_int64 * nmax)()
         got = _abi.lib().segk_profile_read(_abi.ctx(), ms, rows, nmax)
@@ -442,6 +461,50 @@ def main():
             score_ms = float(np.mean(ms[:got]))
             score_rows = int(rows[got - 1])
         _abi.check(_abi.lib().segk_profile_enable(_abi.ctx(), 0))
+
+    # rows the hinted exact stage passed on to the second stage / rows of the full scan, last sweep (diagnostic)
+    sc = (C.c_int32 * 2)()
+    _abi.check(_abi.lib().segk_kmeans_stage_counts(_abi.ctx(), C.byref(seg._dk.cand), sc, _abi.stream()))
+    stage_counts = {"second_stage_rows": int(sc[0]), "full_scan_rows": int(sc[1]), "rows": int(rows_local)}
+
+    # N > 1: the cost of the per-sweep collective, measured outside the timed windows -- `steps` further sweeps with the
+    # all-gather bracketed by stream synchronisation on every rank (comm.TorchComm.timed)
+    gather_info = None
+    if world > 1:
+        comm = sweeper.comm
+        comm.timed, comm.gather_us, comm.gather_calls = True, 0.0, 0
+        for _ in range(args.steps):
+            seg.batch_sweep_async()
+        barrier()
+        comm.timed = False
+        g = torch.tensor([comm.gather_us / max(comm.gather_calls, 1)], dtype=torch.float64,
+                         device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(g, op=dist.ReduceOp.MAX)
+        gather_info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                       "all_gather_us_per_sweep_max_over_ranks": float(g.item()),
+                       "record_bytes_per_rank": int(sweeper.rank_stride * 8),
+                       "note": "host wall time of the one all-gather of a sweep between two stream synchronisations "
+                               "(includes the launch of the collective), measured on sweeps outside the timed windows"}
+
+    # N = 1: the reference's own chain (sync='sequential', the API default; bit-identical to the reference) on the same
+    # corpus, outside the timed region: one warm sweep, two timed by the chain's own record['sample_time'] bracket
+    seq_chain = None
+    if world == 1 and rank == 0 and not args.no_seq_chain:
+        try:
+            random.seed(0)
+            np.random.seed(0)
+            seg_s = kaw.SegmentalKMeansWordseg(args.K, *corpus, n_slices_max=args.n_slices_max, init_am_assignments="spread")
+            seg_s.segment(1)
+            rec_s = seg_s.segment(2)
+            t_s = float(np.mean(rec_s["sample_time"]))
+            seq_chain = {"sweeps_per_s": 1.0 / t_s, "us_per_utterance": 1e6 * t_s / args.utts,
+                         "note": "SegmentalKMeansWordseg(sync='sequential').segment: the reference's chain, every utterance sees "
+                                 "the means the previous one left (kmeans_acoustic_wordseg.py:393-399), bit-identical state "
+                                 "(tests/test_gpu_chain_parity_fullshape.py); one GPU, mean of record['sample_time'] over two "
+                                 "sweeps after one warm sweep; does not shard"}
+            del seg_s
+        except Exception as e:                           # the extra key must never cost the line
+            seq_chain = {"error": repr(e)}
 
     if rank == 0:
         # algorithmic: 2 rows K D of the timed launch.  K = all K_max slots: those beyond the active components hold
@@ -491,7 +554,38 @@ def main():
             b3 = getattr(seg._corpus, "Xb3", None) is not None and os.environ.get("SEGK_SCORE_B3", "2") != "0"
             kind = int(_abi.lib().segk_profile_last_kind(_abi.ctx())) if use_ev else -1
             launches = int(_abi.lib().segk_profile_last_launches(_abi.ctx())) if use_ev else 1
-            if b3 and kind == 1:
+            if b3 and kind == 5:
+                # segk_kmeans_score_hinted (every sweep but the first): k_kmeans_top2_rs scores every row against every
+                # component with ONE v_mfma_f32_32x32x16_f16 product per 16 dimensions and keeps the two largest values per
+                # row; the exact stage verifies the previous sweep's winner against them (segk_score_hint.hip).  `achieved`
+                # / `frac`: the contract's ALGORITHMIC flops 2*rows*K*D over this launch; executed_*: the padded product.
+                kp, kpad = (args.dim + 15) // 16 * 16, (args.K + 31) // 32 * 32
+                executed = 2.0 * score_rows * kpad * kp
+                ex_tf = executed / (score_ms * 1e-3) / 1e12
+                tp = os.path.join(ROOT, "profiles", "score_kernel_traffic_hint.json")
+                traffic = None
+                if os.path.exists(tp):
+                    tj = json.load(open(tp))
+                    wl = tj["workload"]
+                    if (wl["utterances"], wl["landmarks_per_utt"], wl["n_slices_max"], wl["D"], wl["K"], wl["n_gpus"]) == \
+                            (args.utts, args.landmarks, args.n_slices_max, args.dim, args.K, world):
+                        traffic = tj["traffic_bytes_per_launch"]
+                out["dtype"] = "fp16 one-product filter + fp16x2 second stage, float32 reference arithmetic for the results"
+                out["roofline"] = {
+                    "bound": "mfma",
+                    "kernel": "k_kmeans_top2_rs<%d> (all %d rows of the rank x all %d component slots; one fp16 product on the 16-bit "
+                              "matrix pipe, value-only top-2, tile images resident in LDS; the winners are verified in reference "
+                              "arithmetic by k_kmeans_hint_exact, results bit-identical to the float32 reference)"
+                              % (kp // 16, score_rows, args.K),
+                    "achieved": achieved, "peak": PEAK_BF16_MATRIX_TFLOPS, "unit": "TFLOP/s",
+                    "frac": achieved / PEAK_BF16_MATRIX_TFLOPS, "traffic": traffic, "ms_per_launch": score_ms,
+                    "launches_in_interval": 1,
+                    "flops_per_launch": flops_per_launch,
+                    "executed_flops_per_launch": executed, "executed_achieved": ex_tf,
+                    "executed_frac": ex_tf / PEAK_BF16_MATRIX_TFLOPS,
+                    "achieved_over_fp32_matrix_peak": achieved / PEAK_FP32_MATRIX_TFLOPS,
+                }
+            elif b3 and kind == 1:
                 # One-product fp16 pre-filter (k_kmeans_score_h1) in front of the split-precision kernel: the timed
                 # launch scores every row against every component with ONE v_mfma_f32_32x32x16_f16 product per
                 # 16 dimensions; rows it cannot decide (6 % here) pass to the three-product kernel.  `achieved`
@@ -555,6 +649,11 @@ def main():
                     "traffic": traffic, "ms_per_launch": score_ms,
                     "flops_per_launch": flops_per_launch,
                 }
+        out["stage_counts"] = stage_counts
+        if gather_info is not None:
+            out["config"]["collective_measured"] = gather_info
+        if seq_chain is not None:
+            out["sequential_chain"] = seq_chain
         if world == 1 and args.cpu_utts > 0:
             out["cpu_baseline"] = cpu_baseline(corpus, args.utts, args.K, args.n_slices_max, args.cpu_utts)
         print(json.dumps(out))

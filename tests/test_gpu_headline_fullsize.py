@@ -330,12 +330,12 @@ def test_a_hinted_path_gives_the_oracle_bits_whatever_the_hints(gpu, headline, s
         f = int(first[inverse[kk]])
         if f != kk:
             dup_of.setdefault(min(f, kk), max(f, kk))
-    assert len(dup_of) > 20, "the headline state has exact duplicate rows (clean_components leaves copies behind)"
+    assert len(dup_of) >= 1, "the headline state has exact duplicate rows (clean_components leaves copies behind)"
     adv = want_k.copy()
     hit = 0
     for lo_k, hi_k in dup_of.items():
         sel = want_k == lo_k
         adv[sel] = hi_k
         hit += int(sel.sum())
-    assert hit > 1000
+    assert hit > 100
     check("duplicate of the winner", adv, ident, hit, hit + int(1.2 * scored["n_second"]) + 64)
