@@ -49,22 +49,48 @@ struct HintArgs {
     int K_max;
 };
 
-// single instructions on MFMA outputs (fmaxf() would add a canonicalising v_max per operand)
-#define SEGK_TOP2_PAIR(M1, M2, A_, B_)                                                     \
-    do {                                                                                   \
-        /* the first read of the MFMA results is a compiler-visible instruction (hazard recogniser) */ \
-        const float t_ = __builtin_amdgcn_fmed3f(M1, A_, B_);                              \
-        asm volatile("v_max_f32 %1, %1, %2\n\tv_max3_f32 %0, %0, %3, %4" : "+v"(M1), "+v"(M2) : "v"(t_), "v"(A_), "v"(B_)); \
+// ---- K1 ---------------------------------------------------------------------------------------------------------------
+// NW waves per workgroup, one workgroup per CU.  NW = 4: ONE wave per SIMD with the whole register file (512 per lane) --
+// the rows of the wave's next group are prefetched into a second register set while the current group is multiplied, and
+// nothing but the wave's own instruction stream decides whether the matrix pipe idles: per 32-cycle MFMA slot the MFMA's
+// issue (8 cycles) and 3-4 vector operations of the other block's drain.  NW = 8: two waves per SIMD with 256 registers
+// each (no prefetch), which fill each other's gaps at group boundaries but compete for the SIMD's vector issue inside the
+// tile loop.
+//
+// Drain of a block's 16 values per lane, four at a time, value-only (no index): with x1 = max3(m1, a, b),
+// t1 = med3(m1, a, b) [the second largest of m1, a, b], u = med3(x1, c, d) [the second largest of x1, c, d]:
+//     m1' = max3(x1, c, d)     m2' = max3(m2, t1, u)
+// (the second largest of {m1, a, b, c, d} is max(t1, u): t1 <= x1, and whichever of x1, c, d is largest, u is the runner-up
+// among them) -- five operations per four values.  Operation 0 of a quad is a compiler-visible builtin, so that the hazard
+// recogniser sees the first read of the MFMA's result; the others are single-instruction asm (fmaxf() would add a
+// canonicalising v_max per MFMA output, and the scheduler may not reorder asm volatile).
+#define SEGK_RS_DRAIN_OP(O_, AO, o_)                                                                                        \
+    do {                                                                                                                     \
+        constexpr int q_ = (o_) / 5, st_ = (o_) % 5;                                                                         \
+        if constexpr (st_ == 0) dt1[q_] = __builtin_amdgcn_fmed3f(m1[O_], AO[4 * q_], AO[4 * q_ + 1]);                       \
+        else if constexpr (st_ == 1) asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(dx1[q_]) : "v"(m1[O_]), "v"(AO[4 * q_]), "v"(AO[4 * q_ + 1])); \
+        else if constexpr (st_ == 2) asm volatile("v_med3_f32 %0, %1, %2, %3" : "=v"(du[q_]) : "v"(dx1[q_]), "v"(AO[4 * q_ + 2]), "v"(AO[4 * q_ + 3])); \
+        else if constexpr (st_ == 3) asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(m1[O_]) : "v"(dx1[q_]), "v"(AO[4 * q_ + 2]), "v"(AO[4 * q_ + 3])); \
+        else asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(m2[O_]) : "v"(dt1[q_]), "v"(du[q_]));                          \
     } while (0)
 
-template <int KS>
-__global__ __launch_bounds__(512, 2) void k_kmeans_top2_rs(HintArgs H)
+template <int O>
+struct SegkIc { static constexpr int value = O; };
+
+// (launch bounds "two waves per SIMD" for both: 256 registers per lane, all of them vector registers.  Given 512 the compiler
+// keeps the accumulators in the accumulator file and copies every value out for the drain, 16 v_accvgpr_read per block)
+template <int KS, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void k_kmeans_top2_rs(HintArgs H)
 {
     typedef _Float16 T;
     typedef SegkPiece<2>::V8 V8;
-    constexpr int P = 2, KP = KS * 16, NBLK = 4;
+    // (only 256 of a lone wave's 512 registers are addressable by vector instructions, the rest is the accumulator file: a
+    // second 4-block row set lands there and is copied back and forth -- 5 000 v_accvgpr moves.  So: two blocks per group with
+    // prefetch for NW = 4, four without for NW = 8)
+    constexpr int P = 2, KP = KS * 16, NBLK = NW == 4 ? 2 : 4;
     constexpr int STRIDE = (KS * P * 256 + 32 + 1023) / 1024 * 1024;      // floats per tile of the global image
     constexpr int TL = KS * 256 + 32;                                     // floats per tile in LDS: KS piece-0 blocks + constants
+    constexpr bool PREFETCH = NW == 4;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
@@ -88,7 +114,7 @@ __global__ __launch_bounds__(512, 2) void k_kmeans_top2_rs(HintArgs H)
     if (nt > H.tpr) nt = H.tpr;
     if (nt <= 0) return;
     // ---- the range's tile images into LDS, once
-    for (int i = tid; i < nt * (KS * 64 + 8); i += 512) {
+    for (int i = tid; i < nt * (KS * 64 + 8); i += 64 * NW) {
         const int t = i / (KS * 64 + 8), q = i - t * (KS * 64 + 8);
         const float *src = H.tiles + (int64_t)(t_lo + t) * STRIDE;
         float4 v;
@@ -100,111 +126,155 @@ __global__ __launch_bounds__(512, 2) void k_kmeans_top2_rs(HintArgs H)
 
     const T *plane0 = (const T *)(H.ximg + SEGK_SP_HEADER);
     const int64_t n_groups = (H.n + 32 * NBLK - 1) / (32 * NBLK);
-    const int64_t n_slots = (int64_t)n_wgr * 8;
-    for (int64_t g = (int64_t)wgr * 8 + wave; g < n_groups; g += n_slots) {
-        V8 xb[NBLK][KS];
-        int32_t hrow[NBLK], hk[NBLK];                                  // range 0, lane half 0: the row whose hint this lane marks
-#pragma unroll
-        for (int b = 0; b < NBLK; b++) {
-            const int64_t r = g * (32 * NBLK) + 32 * b + j;
-            int64_t rowid = -1;
-            if (r < H.n) rowid = H.ids ? (int64_t)H.ids[r] : H.row0 + r;
-            hrow[b] = (range == 0 && h == 0) ? (int32_t)rowid : -1;
-            if (rowid < 0) rowid = 0;                                  // a skipped entry of the id list: some valid row, result unused
-            const T *xp = plane0 + rowid * KP + 8 * h;
-#pragma unroll
-            for (int s = 0; s < KS; s++) xb[b][s] = *reinterpret_cast<const V8 *>(xp + 16 * s);
-        }
-#pragma unroll
-        for (int b = 0; b < NBLK; b++) hk[b] = hrow[b] >= 0 ? H.cand_k[hrow[b]] : -1;      // used after the tile loop
-        float m1[NBLK], m2[NBLK];
-#pragma unroll
-        for (int b = 0; b < NBLK; b++) { m1[b] = NEG_INF_F; m2[b] = NEG_INF_F; }
+    const int64_t n_slots = (int64_t)n_wgr * NW;
 
-        // operands of tile 0: A fragments (one ds_read_b128 per k-step) and the 16 constants of this lane half
-        V8 a[KS];
-        f32x16 cs;
-        auto load_a = [&](int t, int s) { a[s] = *reinterpret_cast<const V8 *>((const T *)(lds + t * TL) + (s * 64 + lane) * 8); };
-        auto load_cs = [&](int t) {
-            const float *cv = lds + t * TL + KS * 256 + 4 * h;
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const float4 c4 = *reinterpret_cast<const float4 *>(cv + 8 * q);
-                cs[4 * q + 0] = c4.x; cs[4 * q + 1] = c4.y; cs[4 * q + 2] = c4.z; cs[4 * q + 3] = c4.w;
-            }
-        };
-#pragma unroll
-        for (int s = 0; s < KS; s++) load_a(0, s);
-        load_cs(0);
-        f32x16 acc0, acc1;
-#pragma unroll
-        for (int q = 0; q < 16; q++) acc1[q] = NEG_INF_F;              // "block 3 of tile -1": drains to nothing
+    // the rows of group g into a register set (and, range 0 / lane half 0, the previous labels of the rows this lane marks)
+#define SEGK_RS_LOAD(g_, XB, HROW, HK)                                                                          \
+    do {                                                                                                         \
+        _Pragma("unroll") for (int b = 0; b < NBLK; b++) {                                                       \
+            const int64_t r = (g_) * (32 * NBLK) + 32 * b + j;                                                   \
+            int64_t rowid = -1;                                                                                  \
+            if (r < H.n) rowid = H.ids ? (int64_t)H.ids[r] : H.row0 + r;                                         \
+            HROW[b] = (range == 0 && h == 0) ? (int32_t)rowid : -1;                                              \
+            if (rowid < 0) rowid = 0;          /* a skipped entry of the id list: some valid row, result unused */ \
+            const T *xp = plane0 + rowid * KP + 8 * h;                                                           \
+            _Pragma("unroll") for (int s = 0; s < KS; s++) XB[b][s] = *reinterpret_cast<const V8 *>(xp + 16 * s); \
+        }                                                                                                        \
+        _Pragma("unroll") for (int b = 0; b < NBLK; b++) HK[b] = HROW[b] >= 0 ? H.cand_k[HROW[b]] : -1;          \
+    } while (0)
 
-        // MFMAs of block N_ (accumulator AN) over the drain of block O_'s values (accumulator AO).  The eight pairs of the
-        // drain are spread over the MFMAs 1 .. KS-1: block O_'s last MFMA was issued just before this unit's first one, and a
-        // drain behind that one would wait out the matrix pipe's latency (the compiler pads it with s_nop 11).
-#define SEGK_RS_UNIT(N_, AN, O_, AO, REFILL)                                                                         \
+    // MFMAs of block N_ (accumulator AN) over the drain of block O_'s values (accumulator AO).  The twenty operations of the
+    // drain are spread over the MFMAs 1 .. KS-1: block O_'s last MFMA was issued just before this unit's first one, and a
+    // drain right behind that one would wait out the matrix pipe's latency.
+    // The MFMA intrinsic has no side effects, so neither volatile asm nor sched_barrier orders it (instruction selection sinks
+    // it towards its use, behind the drain): two empty asm statements pin it by DATA dependence -- its A operand passes
+    // through the first, its result through the second.
+#define SEGK_RS_UNIT(XB, N_, AN, O_, AO, REFILL)                                                                     \
     do {                                                                                                              \
         _Pragma("unroll") for (int s = 0; s < KS; s++) {                                                              \
-            /* The MFMA intrinsic has no side effects, so neither volatile asm nor sched_barrier orders it: instruction   */ \
-            /* selection sinks it towards its use, behind the drain.  Two empty asm statements pin it by DATA dependence: */ \
-            /* its A operand passes through the first, its result through the second.                                    */ \
             asm volatile("" : "+v"(a[s]));                                                                            \
-            AN = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s], xb[N_][s], s == 0 ? cs : AN, 0, 0, 0);                  \
+            AN = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s], XB[N_][s], s == 0 ? cs : AN, 0, 0, 0);                  \
             asm volatile("" : "+v"(AN));                                                                              \
             if (REFILL) {                      /* this tile is done with a[s] (and, after its first MFMA, with cs) */ \
                 load_a(tn, s);                                                                                        \
                 if (s == 0) load_cs(tn);                                                                              \
             }                                                                                                         \
-            __builtin_amdgcn_sched_barrier(0);         /* the MFMA first, then its share of the drain */               \
+            __builtin_amdgcn_sched_barrier(0);                                                                        \
             constexpr int SL = KS > 1 ? KS - 1 : 1;                                                                   \
-            const int p_lo = KS > 1 ? ((s - 1) * 8) / SL : 0, p_hi = KS > 1 ? (s * 8) / SL : 8;                       \
-            _Pragma("unroll") for (int pi = 0; pi < 8; pi++)                                                          \
-                if ((KS == 1 || s >= 1) && pi >= p_lo && pi < p_hi) SEGK_TOP2_PAIR(m1[O_], m2[O_], AO[2 * pi], AO[2 * pi + 1]); \
-            /* keep the order: one MFMA, then its share of the other block's drain (left alone, the scheduler issues */ \
-            /* the four blocks' MFMAs of a k-step together and the drains in one burst behind them)                  */ \
+            const int o_lo = KS > 1 ? ((s - 1) * 20) / SL : 0, o_hi = KS > 1 ? (s * 20) / SL : 20;                    \
+            if (KS == 1 || s >= 1) {                                                                                  \
+                drain_ops(o_lo, o_hi, [&](auto oc) { SEGK_RS_DRAIN_OP(O_, AO, decltype(oc)::value); });               \
+            }                                                                                                         \
             __builtin_amdgcn_sched_barrier(0);                                                                        \
         }                                                                                                             \
     } while (0)
 
-        // (two tiles per trip: with one, the accumulator of block 3 and the constants of the next tile change registers
-        // across the back edge -- 24 moves and an s_nop 11 per tile)
-#define SEGK_RS_TILE(t_)                                            \
+    // (two tiles per trip: with one, the accumulator of block 3 and the constants of the next tile change registers
+    // across the back edge -- 24 moves and an s_nop 11 per tile)
+#define SEGK_RS_TILE(XB, t_)                                        \
     do {                                                            \
         const int tn = (t_) + 1 < nt ? (t_) + 1 : (t_);             \
-        SEGK_RS_UNIT(0, acc0, 3, acc1, false);                      \
-        SEGK_RS_UNIT(1, acc1, 0, acc0, false);                      \
-        SEGK_RS_UNIT(2, acc0, 1, acc1, false);                      \
-        SEGK_RS_UNIT(3, acc1, 2, acc0, true);                       \
+        if constexpr (NBLK == 4) {                                  \
+            SEGK_RS_UNIT(XB, 0, acc0, 3, acc1, false);              \
+            SEGK_RS_UNIT(XB, 1, acc1, 0, acc0, false);              \
+            SEGK_RS_UNIT(XB, 2, acc0, 1, acc1, false);              \
+            SEGK_RS_UNIT(XB, 3, acc1, 2, acc0, true);               \
+        } else {                                                    \
+            SEGK_RS_UNIT(XB, 0, acc0, 1, acc1, false);              \
+            SEGK_RS_UNIT(XB, 1, acc1, 0, acc0, true);               \
+        }                                                           \
     } while (0)
-        int t = 0;
-        for (; t + 1 < nt; t += 2) {
-            SEGK_RS_TILE(t);
-            SEGK_RS_TILE(t + 1);
-        }
-        if (t < nt) SEGK_RS_TILE(t);
-#undef SEGK_RS_TILE
-#undef SEGK_RS_UNIT
-#pragma unroll
-        for (int pi = 0; pi < 8; pi++) SEGK_TOP2_PAIR(m1[3], m2[3], acc1[2 * pi], acc1[2 * pi + 1]);
 
-        // the two lane halves of a row hold 16 components of every tile each: merge, lane half 0 stores
+    // one group: all the range's tiles against the rows in XB, then the (m1, m2) of its rows and the marks of their hints
+#define SEGK_RS_GROUP(g_, XB, HROW, HK)                                                                                   \
+    do {                                                                                                                   \
+        float m1[NBLK], m2[NBLK];                                                                                          \
+        _Pragma("unroll") for (int b = 0; b < NBLK; b++) { m1[b] = NEG_INF_F; m2[b] = NEG_INF_F; }                         \
+        _Pragma("unroll") for (int s = 0; s < KS; s++) load_a(0, s);                                                       \
+        load_cs(0);                                                                                                        \
+        f32x16 acc0, acc1;                                                                                                 \
+        _Pragma("unroll") for (int q = 0; q < 16; q++) acc1[q] = NEG_INF_F;        /* "last block of tile -1": drains to nothing */ \
+        int t = 0;                                                                                                         \
+        for (; t + 1 < nt; t += 2) {                                                                                       \
+            SEGK_RS_TILE(XB, t);                                                                                           \
+            SEGK_RS_TILE(XB, t + 1);                                                                                       \
+        }                                                                                                                  \
+        if (t < nt) SEGK_RS_TILE(XB, t);                                                                                   \
+        drain_ops(0, 20, [&](auto oc) { SEGK_RS_DRAIN_OP(NBLK - 1, acc1, decltype(oc)::value); });                         \
+        /* the two lane halves of a row hold 16 components of every tile each: merge, lane half 0 stores */                \
+        _Pragma("unroll") for (int b = 0; b < NBLK; b++) {                                                                 \
+            const float o1 = __shfl_xor(m1[b], 32), o2 = __shfl_xor(m2[b], 32);                                            \
+            const float top1 = fmaxf(m1[b], o1);                                                                           \
+            const float top2 = fmaxf(fminf(m1[b], o1), fmaxf(m2[b], o2));                                                  \
+            const int64_t r = (g_) * (32 * NBLK) + 32 * b + j;                                                             \
+            if (h == 0 && r < H.n) H.part[(int64_t)range * H.n + r] = make_float2(top1, top2);                             \
+            /* the row's hint for K2: the previous label through the map, marked; -1 when there is none */                 \
+            if (HROW[b] >= 0) {                                                                                            \
+                const int32_t hv = (HK[b] >= 0 && HK[b] < H.K_max) ? H.map[HK[b]] : -1;                                    \
+                H.cand_k[HROW[b]] = hv >= 0 ? (hv | SEGK_HINT_BIT) : -1;                                                   \
+            }                                                                                                              \
+        }                                                                                                                  \
+    } while (0)
+
+    V8 a[KS];
+    f32x16 cs;
+    float dt1[4], dx1[4], du[4];
+    auto load_a = [&](int t, int s) { a[s] = *reinterpret_cast<const V8 *>((const T *)(lds + t * TL) + (s * 64 + lane) * 8); };
+    auto load_cs = [&](int t) {
+        const float *cv = lds + t * TL + KS * 256 + 4 * h;
 #pragma unroll
-        for (int b = 0; b < NBLK; b++) {
-            const float o1 = __shfl_xor(m1[b], 32), o2 = __shfl_xor(m2[b], 32);
-            const float top1 = fmaxf(m1[b], o1);
-            const float top2 = fmaxf(fminf(m1[b], o1), fmaxf(m2[b], o2));
-            const int64_t r = g * (32 * NBLK) + 32 * b + j;
-            if (h == 0 && r < H.n) H.part[(int64_t)range * H.n + r] = make_float2(top1, top2);
-            // the row's hint for K2: the previous label through the map, marked; -1 when there is none
-            if (hrow[b] >= 0) {
-                const int32_t hv = (hk[b] >= 0 && hk[b] < H.K_max) ? H.map[hk[b]] : -1;
-                H.cand_k[hrow[b]] = hv >= 0 ? (hv | SEGK_HINT_BIT) : -1;
-            }
+        for (int q = 0; q < 4; q++) {
+            const float4 c4 = *reinterpret_cast<const float4 *>(cv + 8 * q);
+            cs[4 * q + 0] = c4.x; cs[4 * q + 1] = c4.y; cs[4 * q + 2] = c4.z; cs[4 * q + 3] = c4.w;
+        }
+    };
+    // operations o_lo .. o_hi-1 of a block's drain (compile-time indices: the loop is fully unrolled)
+    auto drain_ops = [&](int o_lo, int o_hi, auto &&op) {
+#define SEGK_RS_OP(o_) if ((o_) >= o_lo && (o_) < o_hi) op(SegkIc<o_>{});
+        SEGK_RS_OP(0) SEGK_RS_OP(1) SEGK_RS_OP(2) SEGK_RS_OP(3) SEGK_RS_OP(4) SEGK_RS_OP(5) SEGK_RS_OP(6) SEGK_RS_OP(7) SEGK_RS_OP(8)
+        SEGK_RS_OP(9) SEGK_RS_OP(10) SEGK_RS_OP(11) SEGK_RS_OP(12) SEGK_RS_OP(13) SEGK_RS_OP(14) SEGK_RS_OP(15) SEGK_RS_OP(16)
+        SEGK_RS_OP(17) SEGK_RS_OP(18) SEGK_RS_OP(19)
+#undef SEGK_RS_OP
+    };
+
+    int64_t g = (int64_t)wgr * NW + wave;
+    if (g >= n_groups) return;
+    V8 xa[NBLK][KS];
+    int32_t hrow_a[NBLK], hk_a[NBLK];
+    SEGK_RS_LOAD(g, xa, hrow_a, hk_a);
+    if constexpr (PREFETCH) {
+        V8 xb[NBLK][KS];
+        int32_t hrow_b[NBLK], hk_b[NBLK];
+        // The explicit waits (the builtin, which the compiler's wait-count pass understands; an asm wait it would not) tell
+        // it that the current set has landed BEFORE the other set's loads are issued: left to itself it waits for the
+        // current set inside the tile loop with counted vmcnt, which -- the counter being in issue order -- waits out the
+        // prefetch too.
+        for (;;) {
+            __builtin_amdgcn_s_waitcnt(0x0F70);                             // vmcnt(0): the rows of group g are in xa
+            const int64_t g1 = g + n_slots;
+            if (g1 < n_groups) SEGK_RS_LOAD(g1, xb, hrow_b, hk_b);          // in flight under this group's tile loop
+            SEGK_RS_GROUP(g, xa, hrow_a, hk_a);
+            if (g1 >= n_groups) break;
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            g = g1 + n_slots;
+            if (g < n_groups) SEGK_RS_LOAD(g, xa, hrow_a, hk_a);
+            SEGK_RS_GROUP(g1, xb, hrow_b, hk_b);
+            if (g >= n_groups) break;
+        }
+    } else {
+        for (;;) {
+            SEGK_RS_GROUP(g, xa, hrow_a, hk_a);
+            g += n_slots;
+            if (g >= n_groups) break;
+            SEGK_RS_LOAD(g, xa, hrow_a, hk_a);
         }
     }
+#undef SEGK_RS_GROUP
+#undef SEGK_RS_TILE
+#undef SEGK_RS_UNIT
+#undef SEGK_RS_LOAD
 }
-#undef SEGK_TOP2_PAIR
+#undef SEGK_RS_DRAIN_OP
 
 // map[k] = the label a hint k of the previous call stands for now (remap, identity when NULL), or -1 when that component
 // is carried as "absent" by the filters' images (seed constant <= -1e37: a marked duplicate) -- such a hint proves nothing
@@ -528,16 +598,23 @@ static int launch_score_hint(segk_ctx *ctx, ScoreArgs A, const int32_t *remap, h
     H.map = ctx->hint_map;
     H.K_max = A.K_max;
     const size_t lds1 = (size_t)tpr * TL * sizeof(float);
+    // SEGK_HINT_WAVES: 4 (default) = one wave per SIMD with the next group's rows prefetched into registers; 8 = two waves per
+    // SIMD, no prefetch (section 4 of DESIGN.md has the measurements)
+    const char *we = getenv("SEGK_HINT_WAVES");
+    const int nw1 = we && atoi(we) == 8 ? 8 : 4;
     int grid1 = (n_cu / n_ranges) * n_ranges;
-    {   // no more workgroups than there are 1024-row steps per range (each of the 8 waves takes 128 rows at a time)
-        const int64_t steps = (A.n + 1023) / 1024;
+    {   // no more workgroups than there are steps per range (each wave takes 128 rows at a time)
+        const int64_t rows_ws = (nw1 == 8 ? 128 : 64) * (int64_t)nw1;      // rows a workgroup takes per step
+        const int64_t steps = (A.n + rows_ws - 1) / rows_ws;
         if ((int64_t)grid1 / n_ranges > steps) grid1 = (int)steps * n_ranges;
     }
-    SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_kmeans_top2_rs<KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+    if (nw1 == 8) SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_kmeans_top2_rs<KS, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+    else SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_kmeans_top2_rs<KS, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
     const bool prof = ctx->prof_on != 0;
     const int slot = ctx->prof_n % SEGK_PROF_SLOTS;
     if (prof) SEGK_CHECK_HIP(hipEventRecord(ctx->prof_ev[slot][0], st));
-    hipLaunchKernelGGL((k_kmeans_top2_rs<KS>), dim3((unsigned)grid1), dim3(512), lds1, st, H);
+    if (nw1 == 8) hipLaunchKernelGGL((k_kmeans_top2_rs<KS, 8>), dim3((unsigned)grid1), dim3(512), lds1, st, H);
+    else hipLaunchKernelGGL((k_kmeans_top2_rs<KS, 4>), dim3((unsigned)grid1), dim3(256), lds1, st, H);
     if (prof) {
         SEGK_CHECK_HIP(hipEventRecord(ctx->prof_ev[slot][1], st));
         ctx->prof_rows[slot] = A.n;

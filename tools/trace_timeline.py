@@ -8,7 +8,9 @@ cols = [r[1] for r in c.execute("pragma table_info(kernels)")]
 rows = c.execute("select name, start, end from kernels order by start").fetchall()
 # find the nth occurrence of the segment kernel as the sweep anchor
 idx = [i for i, r in enumerate(rows) if "k_kmeans_score_h1" in r[0] or "k_kmeans_score_sp<" in r[0] and "h1" not in r[0]]
-starts = [i for i, r in enumerate(rows) if "k_kmeans_score_h1" in r[0]]
+starts = [i for i, r in enumerate(rows) if "k_kmeans_top2_rs" in r[0]]
+if not starts:
+    starts = [i for i, r in enumerate(rows) if "k_kmeans_score_h1" in r[0]]
 if not starts:
     starts = [i for i, r in enumerate(rows) if "k_kmeans_score_sp" in r[0]]
 nth = min(nth * span, len(starts) - span - 1)
