@@ -32,9 +32,9 @@
 // full-size parity tests run this path against the C oracle row by row.
 #include "segk_kmeans_dev.h"
 
-// cand.k between K1 and K2: (label | SEGK_HINT_BIT) = a usable hint, already mapped to the current labelling; -1 = no usable
-// hint.  K2's workgroups (one table range each) all scan every row: the mark tells a row that still waits for its range's
-// workgroup from one that workgroup has already given its final label.
+// cand.k between K1 and K2: (previous label | SEGK_HINT_BIT) = a hint to be translated by K2's map; -1 = no hint.  K2's
+// workgroups (one table range each) all scan every row: the mark tells a row that still waits for its range's workgroup from
+// one that workgroup has already given its final label.
 #define SEGK_HINT_BIT 0x20000000
 
 struct HintArgs {
@@ -45,7 +45,6 @@ struct HintArgs {
     int n_tiles, tpr, n_ranges;     // tiles per range, ranges
     float2 *part;                   // [n_ranges][n] (m1, m2) in the scaled domain of the images
     int32_t *cand_k;                // hints in (labels of the previous call), marks out -- written by range 0's workgroups
-    const int32_t *map;             // [K_max] k_hint_map
     int K_max;
 };
 
@@ -201,17 +200,28 @@ __global__ __launch_bounds__(64 * NW, 2) void k_kmeans_top2_rs(HintArgs H)
         }                                                                                                                  \
         if (t < nt) SEGK_RS_TILE(XB, t);                                                                                   \
         drain_ops(0, 20, [&](auto oc) { SEGK_RS_DRAIN_OP(NBLK - 1, acc1, decltype(oc)::value); });                         \
-        /* the two lane halves of a row hold 16 components of every tile each: merge, lane half 0 stores */                \
+        /* the two lane halves of a row hold 16 components of every tile each: merge; stored at the start of the next */   \
+        /* group (SEGK_RS_STORE), behind that group's prefetch: a store issued here would sit in front of the loads in */  \
+        /* the in-order vmcnt queue and every wait for rows would wait out its write acknowledge as well              */  \
         _Pragma("unroll") for (int b = 0; b < NBLK; b++) {                                                                 \
             const float o1 = __shfl_xor(m1[b], 32), o2 = __shfl_xor(m2[b], 32);                                            \
-            const float top1 = fmaxf(m1[b], o1);                                                                           \
-            const float top2 = fmaxf(fminf(m1[b], o1), fmaxf(m2[b], o2));                                                  \
-            const int64_t r = (g_) * (32 * NBLK) + 32 * b + j;                                                             \
-            if (h == 0 && r < H.n) H.part[(int64_t)range * H.n + r] = make_float2(top1, top2);                             \
-            /* the row's hint for K2: the previous label through the map, marked; -1 when there is none */                 \
-            if (HROW[b] >= 0) {                                                                                            \
-                const int32_t hv = (HK[b] >= 0 && HK[b] < H.K_max) ? H.map[HK[b]] : -1;                                    \
-                H.cand_k[HROW[b]] = hv >= 0 ? (hv | SEGK_HINT_BIT) : -1;                                                   \
+            pend1[b] = fmaxf(m1[b], o1);                                                                                   \
+            pend2[b] = fmaxf(fminf(m1[b], o1), fmaxf(m2[b], o2));                                                          \
+            pend_row[b] = HROW[b];                                                                                         \
+            pend_k[b] = HK[b];                                                                                             \
+        }                                                                                                                  \
+        pend_g = (g_);                                                                                                     \
+    } while (0)
+
+    // results of the group before: (m1, m2) of its rows (lane half 0), and -- range 0 -- the rows' hints marked for K2:
+    // (previous label | SEGK_HINT_BIT), or -1 when that label is no component index
+#define SEGK_RS_STORE()                                                                                                    \
+    do {                                                                                                                   \
+        if (pend_g >= 0) {                                                                                                 \
+            _Pragma("unroll") for (int b = 0; b < NBLK; b++) {                                                             \
+                const int64_t r = pend_g * (32 * NBLK) + 32 * b + j;                                                       \
+                if (h == 0 && r < H.n) H.part[(int64_t)range * H.n + r] = make_float2(pend1[b], pend2[b]);                 \
+                if (pend_row[b] >= 0) H.cand_k[pend_row[b]] = (pend_k[b] >= 0 && pend_k[b] < H.K_max) ? (pend_k[b] | SEGK_HINT_BIT) : -1; \
             }                                                                                                              \
         }                                                                                                                  \
     } while (0)
@@ -239,6 +249,9 @@ __global__ __launch_bounds__(64 * NW, 2) void k_kmeans_top2_rs(HintArgs H)
 
     int64_t g = (int64_t)wgr * NW + wave;
     if (g >= n_groups) return;
+    float pend1[NBLK], pend2[NBLK];
+    int32_t pend_row[NBLK], pend_k[NBLK];
+    int64_t pend_g = -1;
     V8 xa[NBLK][KS];
     int32_t hrow_a[NBLK], hk_a[NBLK];
     SEGK_RS_LOAD(g, xa, hrow_a, hk_a);
@@ -248,27 +261,36 @@ __global__ __launch_bounds__(64 * NW, 2) void k_kmeans_top2_rs(HintArgs H)
         // The explicit waits (the builtin, which the compiler's wait-count pass understands; an asm wait it would not) tell
         // it that the current set has landed BEFORE the other set's loads are issued: left to itself it waits for the
         // current set inside the tile loop with counted vmcnt, which -- the counter being in issue order -- waits out the
-        // prefetch too.
+        // prefetch too.  What is outstanding at such a wait was issued a whole group earlier (the rows, the stores of the
+        // group before).
         for (;;) {
             __builtin_amdgcn_s_waitcnt(0x0F70);                             // vmcnt(0): the rows of group g are in xa
             const int64_t g1 = g + n_slots;
             if (g1 < n_groups) SEGK_RS_LOAD(g1, xb, hrow_b, hk_b);          // in flight under this group's tile loop
+            SEGK_RS_STORE();
             SEGK_RS_GROUP(g, xa, hrow_a, hk_a);
             if (g1 >= n_groups) break;
             __builtin_amdgcn_s_waitcnt(0x0F70);
             g = g1 + n_slots;
             if (g < n_groups) SEGK_RS_LOAD(g, xa, hrow_a, hk_a);
+            SEGK_RS_STORE();
             SEGK_RS_GROUP(g1, xb, hrow_b, hk_b);
             if (g >= n_groups) break;
         }
     } else {
         for (;;) {
             SEGK_RS_GROUP(g, xa, hrow_a, hk_a);
+            const int64_t gp = pend_g;
             g += n_slots;
+            if (g < n_groups) SEGK_RS_LOAD(g, xa, hrow_a, hk_a);            // the next rows first, the stores behind them
+            pend_g = gp;
+            SEGK_RS_STORE();
+            pend_g = -1;
             if (g >= n_groups) break;
-            SEGK_RS_LOAD(g, xa, hrow_a, hk_a);
         }
     }
+    SEGK_RS_STORE();
+#undef SEGK_RS_STORE
 #undef SEGK_RS_GROUP
 #undef SEGK_RS_TILE
 #undef SEGK_RS_UNIT
@@ -291,6 +313,7 @@ __global__ void k_hint_map(const int32_t *remap, const float *tiles_sp /* first 
 struct HintExactArgs {
     const float2 *part;             // K1's output
     int n_ranges;
+    const int32_t *map;             // [K_max] k_hint_map
     const float *tiles_hdr;         // tiles_b3: [0] exponent b, [1] E_m
     const unsigned char *ximg;      // row image header: [1] exponent a
 };
@@ -310,7 +333,7 @@ __global__ __launch_bounds__(64 * NW) void k_kmeans_hint_exact(ScoreArgs A, Hint
     constexpr int ps = D4 + ((2 - D4) & 3), LD = ps * 4;
     constexpr int nfull = D & ~7, nblk = nfull >> 3, rem = D & 7;
     constexpr int NX = nblk + (rem ? 1 : 0);
-    extern __shared__ __attribute__((aligned(16))) float lds[];    // [cpp][LD] member rows, then per wave: ring, undecided rows
+    extern __shared__ __attribute__((aligned(16))) float lds[];    // [cpp][LD] member rows, map [K_max], then per wave: ring, undecided rows
     typedef float f32x4_t __attribute__((ext_vector_type(4)));
     typedef float f32x2_t __attribute__((ext_vector_type(2)));
     typedef const __attribute__((address_space(1))) f32x4_t *gptr_t;
@@ -324,9 +347,12 @@ __global__ __launch_bounds__(64 * NW) void k_kmeans_hint_exact(ScoreArgs A, Hint
         const int r = i / D4, s4 = i - r * D4;
         *reinterpret_cast<f32x4_t *>(lds + r * LD + 4 * s4) = *reinterpret_cast<const f32x4_t *>(A.means32 + (int64_t)(c_lo + r) * D + 4 * s4);
     }
+    // label of the previous call -> current label, or -1 (k_hint_map)
+    int32_t *map = reinterpret_cast<int32_t *>(lds + (size_t)cpp * LD);
+    for (int k = tid; k < A.K_max; k += 64 * NW) map[k] = H.map[k];
     __syncthreads();
     if (c_n <= 0 && part != 0) return;
-    int32_t *wbase = reinterpret_cast<int32_t *>(lds + (size_t)cpp * LD) + wave * (3 * SEGK_HINT_RING + SEGK_HINT_UBUF);
+    int32_t *wbase = map + ((A.K_max + 3) & ~3) + wave * (3 * SEGK_HINT_RING + SEGK_HINT_UBUF);
     volatile int32_t *ring = wbase;                                 // [3][RING]: row id, local component, position in the launch
     volatile int32_t *ubuf = wbase + 3 * SEGK_HINT_RING;            // undecided rows waiting for a queue reservation
     int ucnt = 0;
@@ -409,13 +435,14 @@ __global__ __launch_bounds__(64 * NW) void k_kmeans_hint_exact(ScoreArgs A, Hint
                 rid_n = load_rid(pos);
                 k_n = rid_n >= 0 ? A.cand.k[rid_n] : -1;
             }
-            // marked by K1: (label | SEGK_HINT_BIT) a hint, -1 none; anything else: already finished by its range's workgroup
-            int32_t hint = -1;
-            if (rid >= 0 && k >= 0 && (k & SEGK_HINT_BIT) && (k & ~SEGK_HINT_BIT) < A.K_max) hint = k & ~SEGK_HINT_BIT;
+            // marked by K1: (previous label | SEGK_HINT_BIT) a hint, -1 none; anything else: already finished by its range's
+            // workgroup.  The label goes through the map: -1 there = the component is carried as absent, no hint either
+            const bool marked = rid >= 0 && k >= 0 && (k & SEGK_HINT_BIT) && (k & ~SEGK_HINT_BIT) < A.K_max;
+            const int32_t hint = marked ? map[k & ~SEGK_HINT_BIT] : -1;
             const int32_t base = hint - c_lo;
             const bool sel = hint >= 0 && base >= 0 && base < c_n;
             // a row without a usable hint belongs to nobody's range: range 0 sends it on
-            push_undecided(part == 0 && rid >= 0 && k == -1, rid);
+            push_undecided(part == 0 && rid >= 0 && (k == -1 || (marked && hint < 0)), rid);
             const unsigned long long mask = __ballot(sel);
             const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
             if (sel) {
@@ -595,7 +622,6 @@ static int launch_score_hint(segk_ctx *ctx, ScoreArgs A, const int32_t *remap, h
     H.n_tiles = A.n_tiles; H.tpr = tpr; H.n_ranges = n_ranges;
     H.part = (float2 *)ctx->hint_part;
     H.cand_k = A.cand.k;
-    H.map = ctx->hint_map;
     H.K_max = A.K_max;
     const size_t lds1 = (size_t)tpr * TL * sizeof(float);
     // SEGK_HINT_WAVES: 4 (default) = one wave per SIMD with the next group's rows prefetched into registers; 8 = two waves per
@@ -627,11 +653,12 @@ static int launch_score_hint(segk_ctx *ctx, ScoreArgs A, const int32_t *remap, h
     HintExactArgs E{};
     E.part = (const float2 *)ctx->hint_part;
     E.n_ranges = n_ranges;
+    E.map = ctx->hint_map;
     E.tiles_hdr = A.tiles;
     E.ximg = (const unsigned char *)A.X32;
     const int pitch4 = ((A.D >> 2) + ((2 - (A.D >> 2)) & 3)) * 16;
     constexpr int NW = 8;
-    const int64_t fixed_b = (int64_t)NW * (3 * SEGK_HINT_RING + SEGK_HINT_UBUF) * 4;
+    const int64_t fixed_b = (int64_t)((A.K_max + 3) & ~3) * 4 + (int64_t)NW * (3 * SEGK_HINT_RING + SEGK_HINT_UBUF) * 4;
     const int64_t cpp_max = (160 * 1024 - fixed_b) / pitch4;
     SEGK_REQUIRE(cpp_max > 0, "hinted score path: no room for the component table");
     const int parts = (int)((A.K_max + cpp_max - 1) / cpp_max);
