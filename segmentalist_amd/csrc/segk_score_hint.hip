@@ -32,7 +32,7 @@
 // full-size parity tests run this path against the C oracle row by row.
 #include "segk_kmeans_dev.h"
 
-// cand.k between K1 and K2: (previous label | SEGK_HINT_BIT) = a hint to be translated by K2's map; -1 = no hint.  K2's
+// cand.k in K2 (marked by k_hint_map): (previous label | SEGK_HINT_BIT) = a hint to be translated by the map; -1 = none.  K2's
 // workgroups (one table range each) all scan every row: the mark tells a row that still waits for its range's workgroup from
 // one that workgroup has already given its final label.
 #define SEGK_HINT_BIT 0x20000000
@@ -44,8 +44,9 @@ struct HintArgs {
     const float *tiles;             // first tile of the fp16x2 tile image (tiles_b3 + 1024)
     int n_tiles, tpr, n_ranges;     // tiles per range, ranges
     float2 *part;                   // [n_ranges][n] (m1, m2) in the scaled domain of the images
-    int32_t *cand_k;                // hints in (labels of the previous call), marks out -- written by range 0's workgroups
     int K_max;
+    int dbg;                        // development (SEGK_HINT_DBG, results wrong): 1 no result stores, 2 no hint loads / marks
+    unsigned long long *stamp;      // development (-DSEGK_STAMP builds): per wave {cycles in the row waits, in the tile loops, total, groups}
 };
 
 // ---- K1 ---------------------------------------------------------------------------------------------------------------
@@ -112,14 +113,28 @@ __global__ __launch_bounds__(64 * NW, 2) void k_kmeans_top2_rs(HintArgs H)
     int nt = H.n_tiles - t_lo;
     if (nt > H.tpr) nt = H.tpr;
     if (nt <= 0) return;
-    // ---- the range's tile images into LDS, once
-    for (int i = tid; i < nt * (KS * 64 + 8); i += 64 * NW) {
-        const int t = i / (KS * 64 + 8), q = i - t * (KS * 64 + 8);
-        const float *src = H.tiles + (int64_t)(t_lo + t) * STRIDE;
-        float4 v;
-        if (q < KS * 64) v = *reinterpret_cast<const float4 *>(src + ((q >> 6) * P) * 256 + (q & 63) * 4);      // piece 0 of k-step q >> 6
-        else v = *reinterpret_cast<const float4 *>(src + KS * P * 256 + (q - KS * 64) * 4);                    // the 32 constants
-        *reinterpret_cast<float4 *>(lds + t * TL + q * 4) = v;
+    // ---- the range's tile images into LDS, once: eight 16-byte loads per thread in flight (one at a time, the fill of
+    // 114 KB by 256 threads is 29 dependent round trips: ~40 us of a 220 us kernel)
+    {
+        constexpr int PER_TILE = KS * 64 + 8, NT = 64 * NW, UF = 8;
+        const int total = nt * PER_TILE;
+        for (int i0 = tid; i0 < total; i0 += NT * UF) {
+            float4 v[UF];
+#pragma unroll
+            for (int u = 0; u < UF; u++) {
+                int i = i0 + u * NT;
+                if (i >= total) i = total - 1;                          // clamped, unconditional load
+                const int t = i / PER_TILE, q = i - t * PER_TILE;
+                const float *src = H.tiles + (int64_t)(t_lo + t) * STRIDE;
+                v[u] = q < KS * 64 ? *reinterpret_cast<const float4 *>(src + ((q >> 6) * P) * 256 + (q & 63) * 4)     // piece 0 of k-step q >> 6
+                                   : *reinterpret_cast<const float4 *>(src + KS * P * 256 + (q - KS * 64) * 4);       // the 32 constants
+            }
+#pragma unroll
+            for (int u = 0; u < UF; u++) {
+                const int i = i0 + u * NT;
+                if (i < total) *reinterpret_cast<float4 *>(lds + (i / PER_TILE) * TL + (i % PER_TILE) * 4) = v[u];
+            }
+        }
     }
     __syncthreads();
 
@@ -127,19 +142,19 @@ __global__ __launch_bounds__(64 * NW, 2) void k_kmeans_top2_rs(HintArgs H)
     const int64_t n_groups = (H.n + 32 * NBLK - 1) / (32 * NBLK);
     const int64_t n_slots = (int64_t)n_wgr * NW;
 
-    // the rows of group g into a register set (and, range 0 / lane half 0, the previous labels of the rows this lane marks)
+    // the rows of group g into a register set
 #define SEGK_RS_LOAD(g_, XB, HROW, HK)                                                                          \
     do {                                                                                                         \
         _Pragma("unroll") for (int b = 0; b < NBLK; b++) {                                                       \
             const int64_t r = (g_) * (32 * NBLK) + 32 * b + j;                                                   \
             int64_t rowid = -1;                                                                                  \
             if (r < H.n) rowid = H.ids ? (int64_t)H.ids[r] : H.row0 + r;                                         \
-            HROW[b] = (range == 0 && h == 0) ? (int32_t)rowid : -1;                                              \
+            HROW[b] = -1;                                                                                        \
             if (rowid < 0) rowid = 0;          /* a skipped entry of the id list: some valid row, result unused */ \
             const T *xp = plane0 + rowid * KP + 8 * h;                                                           \
             _Pragma("unroll") for (int s = 0; s < KS; s++) XB[b][s] = *reinterpret_cast<const V8 *>(xp + 16 * s); \
         }                                                                                                        \
-        _Pragma("unroll") for (int b = 0; b < NBLK; b++) HK[b] = HROW[b] >= 0 ? H.cand_k[HROW[b]] : -1;          \
+        _Pragma("unroll") for (int b = 0; b < NBLK; b++) HK[b] = -1;                                             \
     } while (0)
 
     // MFMAs of block N_ (accumulator AN) over the drain of block O_'s values (accumulator AO).  The twenty operations of the
@@ -172,7 +187,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_kmeans_top2_rs(HintArgs H)
     // across the back edge -- 24 moves and an s_nop 11 per tile)
 #define SEGK_RS_TILE(XB, t_)                                        \
     do {                                                            \
-        const int tn = (t_) + 1 < nt ? (t_) + 1 : (t_);             \
+        const int tn = (t_) + 1 < nt ? (t_) + 1 : 0;     /* the last tile refills tile 0's operands: the next group's */ \
         if constexpr (NBLK == 4) {                                  \
             SEGK_RS_UNIT(XB, 0, acc0, 3, acc1, false);              \
             SEGK_RS_UNIT(XB, 1, acc1, 0, acc0, false);              \
@@ -189,8 +204,6 @@ __global__ __launch_bounds__(64 * NW, 2) void k_kmeans_top2_rs(HintArgs H)
     do {                                                                                                                   \
         float m1[NBLK], m2[NBLK];                                                                                          \
         _Pragma("unroll") for (int b = 0; b < NBLK; b++) { m1[b] = NEG_INF_F; m2[b] = NEG_INF_F; }                         \
-        _Pragma("unroll") for (int s = 0; s < KS; s++) load_a(0, s);                                                       \
-        load_cs(0);                                                                                                        \
         f32x16 acc0, acc1;                                                                                                 \
         _Pragma("unroll") for (int q = 0; q < 16; q++) acc1[q] = NEG_INF_F;        /* "last block of tile -1": drains to nothing */ \
         int t = 0;                                                                                                         \
@@ -213,15 +226,14 @@ __global__ __launch_bounds__(64 * NW, 2) void k_kmeans_top2_rs(HintArgs H)
         pend_g = (g_);                                                                                                     \
     } while (0)
 
-    // results of the group before: (m1, m2) of its rows (lane half 0), and -- range 0 -- the rows' hints marked for K2:
-    // (previous label | SEGK_HINT_BIT), or -1 when that label is no component index
+    // results of the group before: (m1, m2) of its rows (lane half 0)
 #define SEGK_RS_STORE()                                                                                                    \
     do {                                                                                                                   \
         if (pend_g >= 0) {                                                                                                 \
             _Pragma("unroll") for (int b = 0; b < NBLK; b++) {                                                             \
                 const int64_t r = pend_g * (32 * NBLK) + 32 * b + j;                                                       \
-                if (h == 0 && r < H.n) H.part[(int64_t)range * H.n + r] = make_float2(pend1[b], pend2[b]);                 \
-                if (pend_row[b] >= 0) H.cand_k[pend_row[b]] = (pend_k[b] >= 0 && pend_k[b] < H.K_max) ? (pend_k[b] | SEGK_HINT_BIT) : -1; \
+                if (h == 0 && r < H.n && !(H.dbg & 1)) H.part[(int64_t)range * H.n + r] = make_float2(pend1[b], pend2[b]); \
+                (void)pend_row[b]; (void)pend_k[b];                                                                        \
             }                                                                                                              \
         }                                                                                                                  \
     } while (0)
@@ -249,6 +261,9 @@ __global__ __launch_bounds__(64 * NW, 2) void k_kmeans_top2_rs(HintArgs H)
 
     int64_t g = (int64_t)wgr * NW + wave;
     if (g >= n_groups) return;
+#pragma unroll
+    for (int s = 0; s < KS; s++) load_a(0, s);          // tile 0's operands for the first group; every group's last tile reloads them
+    load_cs(0);
     float pend1[NBLK], pend2[NBLK];
     int32_t pend_row[NBLK], pend_k[NBLK];
     int64_t pend_g = -1;
@@ -263,20 +278,48 @@ __global__ __launch_bounds__(64 * NW, 2) void k_kmeans_top2_rs(HintArgs H)
         // current set inside the tile loop with counted vmcnt, which -- the counter being in issue order -- waits out the
         // prefetch too.  What is outstanding at such a wait was issued a whole group earlier (the rows, the stores of the
         // group before).
+#ifdef SEGK_STAMP
+        unsigned long long st_wait = 0, st_loop = 0, st_groups = 0;
+        const unsigned long long st_begin = __builtin_amdgcn_s_memtime();
+#define SEGK_ST(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#else
+#define SEGK_ST(var) do { } while (0)
+#endif
         for (;;) {
+            SEGK_ST(s0);
             __builtin_amdgcn_s_waitcnt(0x0F70);                             // vmcnt(0): the rows of group g are in xa
+            SEGK_ST(s1);
             const int64_t g1 = g + n_slots;
             if (g1 < n_groups) SEGK_RS_LOAD(g1, xb, hrow_b, hk_b);          // in flight under this group's tile loop
             SEGK_RS_STORE();
+            SEGK_ST(s2);
             SEGK_RS_GROUP(g, xa, hrow_a, hk_a);
+            SEGK_ST(s3);
+#ifdef SEGK_STAMP
+            st_wait += s1 - s0; st_loop += s3 - s2; st_groups++;
+#endif
             if (g1 >= n_groups) break;
+            SEGK_ST(s4);
             __builtin_amdgcn_s_waitcnt(0x0F70);
+            SEGK_ST(s5);
             g = g1 + n_slots;
             if (g < n_groups) SEGK_RS_LOAD(g, xa, hrow_a, hk_a);
             SEGK_RS_STORE();
+            SEGK_ST(s6);
             SEGK_RS_GROUP(g1, xb, hrow_b, hk_b);
+            SEGK_ST(s7);
+#ifdef SEGK_STAMP
+            st_wait += s5 - s4; st_loop += s7 - s6; st_groups++;
+#endif
             if (g >= n_groups) break;
         }
+#ifdef SEGK_STAMP
+        if (H.stamp && lane == 0) {
+            unsigned long long *o = H.stamp + ((int64_t)blockIdx.x * NW + wave) * 4;
+            o[0] = st_wait; o[1] = st_loop; o[2] = __builtin_amdgcn_s_memtime() - st_begin; o[3] = st_groups;
+        }
+#endif
+#undef SEGK_ST
     } else {
         for (;;) {
             SEGK_RS_GROUP(g, xa, hrow_a, hk_a);
@@ -298,16 +341,28 @@ __global__ __launch_bounds__(64 * NW, 2) void k_kmeans_top2_rs(HintArgs H)
 }
 #undef SEGK_RS_DRAIN_OP
 
-// map[k] = the label a hint k of the previous call stands for now (remap, identity when NULL), or -1 when that component
-// is carried as "absent" by the filters' images (seed constant <= -1e37: a marked duplicate) -- such a hint proves nothing
-__global__ void k_hint_map(const int32_t *remap, const float *tiles_sp /* first tile */, int K_max, int stride, int const_off, int32_t *map)
+// One small launch in front of K1:
+//   map[k] = the label a hint k of the previous call stands for now (remap, identity when NULL), or -1 when that component
+//            is carried as "absent" by the filters' images (seed constant <= -1e37: a marked duplicate) -- such a hint
+//            proves nothing;
+//   cand.k of every row of the call: (previous label | SEGK_HINT_BIT) when that label is a component index, -1 otherwise.
+__global__ void k_hint_map(const int32_t *remap, const float *tiles_sp /* first tile */, int K_max, int stride, int const_off, int32_t *map,
+                           const int32_t *ids, int64_t row0, int64_t n, int32_t *cand_k)
 {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= K_max) return;
-    int v = remap ? remap[k] : k;
-    if (v < 0 || v >= K_max) v = -1;
-    else if (tiles_sp[(int64_t)(v >> 5) * stride + const_off + (v & 31)] < -1.0e37f) v = -1;
-    map[k] = v;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < K_max) {
+        int v = remap ? remap[i] : (int)i;
+        if (v < 0 || v >= K_max) v = -1;
+        else if (tiles_sp[(int64_t)(v >> 5) * stride + const_off + (v & 31)] < -1.0e37f) v = -1;
+        map[i] = v;
+    }
+    if (i < n) {
+        const int64_t rid = ids ? (int64_t)ids[i] : row0 + i;
+        if (rid >= 0) {
+            const int32_t k = cand_k[rid];
+            cand_k[rid] = (k >= 0 && k < K_max) ? (k | SEGK_HINT_BIT) : -1;
+        }
+    }
 }
 
 struct HintExactArgs {
@@ -611,8 +666,11 @@ static int launch_score_hint(segk_ctx *ctx, ScoreArgs A, const int32_t *remap, h
     if (zero_cnt) hipLaunchKernelGGL(k_zero_two, dim3(1), dim3(64), 0, st, zero_cnt, ctx->pre_queue);
     else SEGK_CHECK_HIP(hipMemsetAsync(ctx->pre_queue, 0, 16 * sizeof(int32_t), st));
     const int stride_sp = segk_sp_tile_stride(A.D, 2);
-    hipLaunchKernelGGL(k_hint_map, dim3((A.K_max + 255) / 256), dim3(256), 0, st, remap, A.tiles + 1024, A.K_max, stride_sp,
-                       KS * 2 * 256, ctx->hint_map);
+    {
+        const int64_t nthr = A.n > A.K_max ? A.n : A.K_max;
+        hipLaunchKernelGGL(k_hint_map, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, remap, A.tiles + 1024, A.K_max, stride_sp,
+                           KS * 2 * 256, ctx->hint_map, A.ids, A.row0, A.n, A.cand.k);
+    }
 
     // ---- K1
     HintArgs H{};
@@ -621,8 +679,11 @@ static int launch_score_hint(segk_ctx *ctx, ScoreArgs A, const int32_t *remap, h
     H.tiles = A.tiles + 1024;
     H.n_tiles = A.n_tiles; H.tpr = tpr; H.n_ranges = n_ranges;
     H.part = (float2 *)ctx->hint_part;
-    H.cand_k = A.cand.k;
     H.K_max = A.K_max;
+    H.dbg = getenv("SEGK_HINT_DBG") ? atoi(getenv("SEGK_HINT_DBG")) : 0;
+#ifdef SEGK_STAMP
+    H.stamp = getenv("SEGK_STAMP_PTR") ? (unsigned long long *)strtoull(getenv("SEGK_STAMP_PTR"), nullptr, 0) : nullptr;
+#endif
     const size_t lds1 = (size_t)tpr * TL * sizeof(float);
     // SEGK_HINT_WAVES: 4 (default) = one wave per SIMD with the next group's rows prefetched into registers; 8 = two waves per
     // SIMD, no prefetch (section 4 of DESIGN.md has the measurements)

@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Development (library built with -DSEGK_STAMP: `make -C segmentalist_amd/csrc clean; make ... HIPFLAGS+=-DSEGK_STAMP`):
+where a wave of k_kmeans_top2_rs spends its cycles -- waiting for the prefetched rows, inside the tile loops, in all."""
+import ctypes as C, os, random, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+from segmentalist_amd import _abi, kmeans_acoustic_wordseg as kaw
+from segmentalist_amd.synth import make_corpus
+corpus = make_corpus(10000, 100, 1000, seed=0, N=20, n_slices_max=6)
+random.seed(0); np.random.seed(0)
+seg = kaw.SegmentalKMeansWordseg(1000, *corpus, n_slices_max=6, init_am_assignments="spread", sync="batch")
+for _ in range(6): seg.batch_sweep_async()
+torch.cuda.synchronize()
+dk = seg._dk
+st = torch.zeros(256 * 8 * 4, dtype=torch.int64, device="cuda")
+os.environ["SEGK_STAMP_PTR"] = hex(st.data_ptr())
+for _ in range(3):
+    dk.score_rows(row0=0, n=dk.corpus.n_emb, hint_remap=dk.remap)
+torch.cuda.synchronize()
+v = st.cpu().numpy().reshape(-1, 4)
+v = v[v[:, 3] > 0]
+print("waves %d  groups/wave %.1f" % (len(v), v[:, 3].mean()))
+print("cycles per wave: total %.0f  tile loops %.0f (%.1f %%)  row waits %.0f (%.1f %%)" % (
+    v[:, 2].mean(), v[:, 1].mean(), 100 * v[:, 1].sum() / v[:, 2].sum(), v[:, 0].mean(), 100 * v[:, 0].sum() / v[:, 2].sum()))
+print("tile loop cycles per group: mean %.0f  (16 tiles x 14 MFMAs x 32 = 7168 at full rate) -> %.1f cycles per MFMA" % (
+    (v[:, 1] / v[:, 3]).mean(), (v[:, 1] / v[:, 3]).mean() / 224))
+print("row wait cycles per group: mean %.0f  max wave %.0f" % ((v[:, 0] / v[:, 3]).mean(), (v[:, 0] / v[:, 3]).max()))
