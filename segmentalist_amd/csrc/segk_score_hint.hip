@@ -64,18 +64,32 @@ struct HintArgs {
 // among them) -- five operations per four values.  Operation 0 of a quad is a compiler-visible builtin, so that the hazard
 // recogniser sees the first read of the MFMA's result; the others are single-instruction asm (fmaxf() would add a
 // canonicalising v_max per MFMA output, and the scheduler may not reorder asm volatile).
-#define SEGK_RS_DRAIN_OP(O_, AO, o_)                                                                                        \
+// One quad = one asm block (the compiler pads every asm statement that a vector instruction of its own follows with an
+// s_nop 0, four cycles of issue each: with one statement per operation the nops were a fifth of the loop's issue slots, and a
+// lone wave has none to spare).  FIRST: the quad that opens a block's drain -- its first operation, the first read of the
+// MFMA's result, stays a compiler-visible builtin so that the hazard recogniser places the wait states the matrix pipe needs.
+#define SEGK_RS_DRAIN_QUAD(O_, AO, q_, FIRST)                                                                               \
     do {                                                                                                                     \
-        constexpr int q_ = (o_) / 5, st_ = (o_) % 5;                                                                         \
-        if constexpr (st_ == 0) dt1[q_] = __builtin_amdgcn_fmed3f(m1[O_], AO[4 * q_], AO[4 * q_ + 1]);                       \
-        else if constexpr (st_ == 1) asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(dx1[q_]) : "v"(m1[O_]), "v"(AO[4 * q_]), "v"(AO[4 * q_ + 1])); \
-        else if constexpr (st_ == 2) asm volatile("v_med3_f32 %0, %1, %2, %3" : "=v"(du[q_]) : "v"(dx1[q_]), "v"(AO[4 * q_ + 2]), "v"(AO[4 * q_ + 3])); \
-        else if constexpr (st_ == 3) asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(m1[O_]) : "v"(dx1[q_]), "v"(AO[4 * q_ + 2]), "v"(AO[4 * q_ + 3])); \
-        else asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(m2[O_]) : "v"(dt1[q_]), "v"(du[q_]));                          \
+        float x1_, u_;                                                                                                       \
+        if (FIRST) {                                                                                                         \
+            const float t1_ = __builtin_amdgcn_fmed3f(m1[O_], AO[4 * (q_)], AO[4 * (q_) + 1]);                              \
+            asm volatile("v_max3_f32 %2, %0, %4, %5\n\t"                                                                     \
+                         "v_med3_f32 %3, %2, %6, %7\n\t"                                                                     \
+                         "v_max3_f32 %0, %2, %6, %7\n\t"                                                                     \
+                         "v_max3_f32 %1, %1, %8, %3"                                                                          \
+                         : "+v"(m1[O_]), "+v"(m2[O_]), "=&v"(x1_), "=&v"(u_)                                                 \
+                         : "v"(AO[4 * (q_)]), "v"(AO[4 * (q_) + 1]), "v"(AO[4 * (q_) + 2]), "v"(AO[4 * (q_) + 3]), "v"(t1_)); \
+        } else {                                                                                                             \
+            float t1_;                                                                                                       \
+            asm volatile("v_med3_f32 %4, %0, %5, %6\n\t"                                                                     \
+                         "v_max3_f32 %2, %0, %5, %6\n\t"                                                                     \
+                         "v_med3_f32 %3, %2, %7, %8\n\t"                                                                     \
+                         "v_max3_f32 %0, %2, %7, %8\n\t"                                                                     \
+                         "v_max3_f32 %1, %1, %4, %3"                                                                          \
+                         : "+v"(m1[O_]), "+v"(m2[O_]), "=&v"(x1_), "=&v"(u_), "=&v"(t1_)                                     \
+                         : "v"(AO[4 * (q_)]), "v"(AO[4 * (q_) + 1]), "v"(AO[4 * (q_) + 2]), "v"(AO[4 * (q_) + 3]));         \
+        }                                                                                                                    \
     } while (0)
-
-template <int O>
-struct SegkIc { static constexpr int value = O; };
 
 // (launch bounds "two waves per SIMD" for both: 256 registers per lane, all of them vector registers.  Given 512 the compiler
 // keeps the accumulators in the accumulator file and copies every value out for the drain, 16 v_accvgpr_read per block)
@@ -95,6 +109,9 @@ __global__ __launch_bounds__(64 * NW, 2) void k_kmeans_top2_rs(HintArgs H)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
     const int R = H.n_ranges;
+#ifdef SEGK_STAMP
+    const unsigned long long st_k0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     // workgroup -> (range, slot).  Workgroups b and b + 8 share an XCD (round-robin placement, speed only): the R
     // workgroups that stream the same rows sit on one XCD when the grid allows, so that the rows cross HBM once
     int range, wgr, n_wgr;
@@ -174,10 +191,14 @@ __global__ __launch_bounds__(64 * NW, 2) void k_kmeans_top2_rs(HintArgs H)
                 if (s == 0) load_cs(tn);                                                                              \
             }                                                                                                         \
             __builtin_amdgcn_sched_barrier(0);                                                                        \
+            /* quads q_lo .. q_hi-1 of block O_ behind this MFMA: the four quads over the slots 1 .. KS-1 */          \
             constexpr int SL = KS > 1 ? KS - 1 : 1;                                                                   \
-            const int o_lo = KS > 1 ? ((s - 1) * 20) / SL : 0, o_hi = KS > 1 ? (s * 20) / SL : 20;                    \
+            const int q_lo = KS > 1 ? ((s - 1) * 4 + SL - 1) / SL : 0, q_hi = KS > 1 ? (s * 4 + SL - 1) / SL : 4;     \
             if (KS == 1 || s >= 1) {                                                                                  \
-                drain_ops(o_lo, o_hi, [&](auto oc) { SEGK_RS_DRAIN_OP(O_, AO, decltype(oc)::value); });               \
+                if (0 >= q_lo && 0 < q_hi) SEGK_RS_DRAIN_QUAD(O_, AO, 0, true);                                       \
+                if (1 >= q_lo && 1 < q_hi) SEGK_RS_DRAIN_QUAD(O_, AO, 1, false);                                      \
+                if (2 >= q_lo && 2 < q_hi) SEGK_RS_DRAIN_QUAD(O_, AO, 2, false);                                      \
+                if (3 >= q_lo && 3 < q_hi) SEGK_RS_DRAIN_QUAD(O_, AO, 3, false);                                      \
             }                                                                                                         \
             __builtin_amdgcn_sched_barrier(0);                                                                        \
         }                                                                                                             \
@@ -212,7 +233,10 @@ __global__ __launch_bounds__(64 * NW, 2) void k_kmeans_top2_rs(HintArgs H)
             SEGK_RS_TILE(XB, t + 1);                                                                                       \
         }                                                                                                                  \
         if (t < nt) SEGK_RS_TILE(XB, t);                                                                                   \
-        drain_ops(0, 20, [&](auto oc) { SEGK_RS_DRAIN_OP(NBLK - 1, acc1, decltype(oc)::value); });                         \
+        SEGK_RS_DRAIN_QUAD(NBLK - 1, acc1, 0, true);                                                                       \
+        SEGK_RS_DRAIN_QUAD(NBLK - 1, acc1, 1, false);                                                                      \
+        SEGK_RS_DRAIN_QUAD(NBLK - 1, acc1, 2, false);                                                                      \
+        SEGK_RS_DRAIN_QUAD(NBLK - 1, acc1, 3, false);                                                                      \
         /* the two lane halves of a row hold 16 components of every tile each: merge; stored at the start of the next */   \
         /* group (SEGK_RS_STORE), behind that group's prefetch: a store issued here would sit in front of the loads in */  \
         /* the in-order vmcnt queue and every wait for rows would wait out its write acknowledge as well              */  \
@@ -240,7 +264,6 @@ __global__ __launch_bounds__(64 * NW, 2) void k_kmeans_top2_rs(HintArgs H)
 
     V8 a[KS];
     f32x16 cs;
-    float dt1[4], dx1[4], du[4];
     auto load_a = [&](int t, int s) { a[s] = *reinterpret_cast<const V8 *>((const T *)(lds + t * TL) + (s * 64 + lane) * 8); };
     auto load_cs = [&](int t) {
         const float *cv = lds + t * TL + KS * 256 + 4 * h;
@@ -250,15 +273,6 @@ __global__ __launch_bounds__(64 * NW, 2) void k_kmeans_top2_rs(HintArgs H)
             cs[4 * q + 0] = c4.x; cs[4 * q + 1] = c4.y; cs[4 * q + 2] = c4.z; cs[4 * q + 3] = c4.w;
         }
     };
-    // operations o_lo .. o_hi-1 of a block's drain (compile-time indices: the loop is fully unrolled)
-    auto drain_ops = [&](int o_lo, int o_hi, auto &&op) {
-#define SEGK_RS_OP(o_) if ((o_) >= o_lo && (o_) < o_hi) op(SegkIc<o_>{});
-        SEGK_RS_OP(0) SEGK_RS_OP(1) SEGK_RS_OP(2) SEGK_RS_OP(3) SEGK_RS_OP(4) SEGK_RS_OP(5) SEGK_RS_OP(6) SEGK_RS_OP(7) SEGK_RS_OP(8)
-        SEGK_RS_OP(9) SEGK_RS_OP(10) SEGK_RS_OP(11) SEGK_RS_OP(12) SEGK_RS_OP(13) SEGK_RS_OP(14) SEGK_RS_OP(15) SEGK_RS_OP(16)
-        SEGK_RS_OP(17) SEGK_RS_OP(18) SEGK_RS_OP(19)
-#undef SEGK_RS_OP
-    };
-
     int64_t g = (int64_t)wgr * NW + wave;
     if (g >= n_groups) return;
 #pragma unroll
@@ -315,8 +329,9 @@ __global__ __launch_bounds__(64 * NW, 2) void k_kmeans_top2_rs(HintArgs H)
         }
 #ifdef SEGK_STAMP
         if (H.stamp && lane == 0) {
-            unsigned long long *o = H.stamp + ((int64_t)blockIdx.x * NW + wave) * 4;
+            unsigned long long *o = H.stamp + ((int64_t)blockIdx.x * NW + wave) * 8;
             o[0] = st_wait; o[1] = st_loop; o[2] = __builtin_amdgcn_s_memtime() - st_begin; o[3] = st_groups;
+            o[4] = st_begin - st_k0; o[5] = st_r0; o[6] = __builtin_amdgcn_s_memrealtime();
         }
 #endif
 #undef SEGK_ST
@@ -339,7 +354,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_kmeans_top2_rs(HintArgs H)
 #undef SEGK_RS_UNIT
 #undef SEGK_RS_LOAD
 }
-#undef SEGK_RS_DRAIN_OP
+#undef SEGK_RS_DRAIN_QUAD
 
 // One small launch in front of K1:
 //   map[k] = the label a hint k of the previous call stands for now (remap, identity when NULL), or -1 when that component

@@ -13,12 +13,12 @@ seg = kaw.SegmentalKMeansWordseg(1000, *corpus, n_slices_max=6, init_am_assignme
 for _ in range(6): seg.batch_sweep_async()
 torch.cuda.synchronize()
 dk = seg._dk
-st = torch.zeros(256 * 8 * 4, dtype=torch.int64, device="cuda")
+st = torch.zeros(256 * 8 * 8, dtype=torch.int64, device="cuda")
 os.environ["SEGK_STAMP_PTR"] = hex(st.data_ptr())
 for _ in range(3):
     dk.score_rows(row0=0, n=dk.corpus.n_emb, hint_remap=dk.remap)
 torch.cuda.synchronize()
-v = st.cpu().numpy().reshape(-1, 4)
+v = st.cpu().numpy().reshape(-1, 8)
 v = v[v[:, 3] > 0]
 print("waves %d  groups/wave %.1f" % (len(v), v[:, 3].mean()))
 print("cycles per wave: total %.0f  tile loops %.0f (%.1f %%)  row waits %.0f (%.1f %%)" % (
@@ -26,3 +26,8 @@ print("cycles per wave: total %.0f  tile loops %.0f (%.1f %%)  row waits %.0f (%
 print("tile loop cycles per group: mean %.0f  (16 tiles x 14 MFMAs x 32 = 7168 at full rate) -> %.1f cycles per MFMA" % (
     (v[:, 1] / v[:, 3]).mean(), (v[:, 1] / v[:, 3]).mean() / 224))
 print("row wait cycles per group: mean %.0f  max wave %.0f" % ((v[:, 0] / v[:, 3]).mean(), (v[:, 0] / v[:, 3]).max()))
+print("fill + start-up cycles per wave: mean %.0f" % v[:, 4].mean())
+r0, r1 = v[:, 5].min(), v[:, 6].max()
+print("realtime (100 MHz): kernel span %.1f us; wave starts spread %.1f us; wave ends spread %.1f us; mean wave life %.1f us -> clock %.2f GHz" % (
+    (r1 - r0) / 100.0, (v[:, 5].max() - r0) / 100.0, (r1 - v[:, 6].min()) / 100.0, ((v[:, 6] - v[:, 5]).mean()) / 100.0,
+    (v[:, 2] + v[:, 4]).mean() / ((v[:, 6] - v[:, 5]).mean() / 100.0) / 1e3))
