@@ -116,7 +116,8 @@ int32_t segk_corpus_prepare(segk_ctx *ctx, const segk_corpus *c, float *X32_out,
 /* Xb3_out [dev] segk_corpus_b3_bytes(n_emb, D) bytes (the size of three piece planes whatever `pieces` is).
  * pieces = 3: x = x1 + x2 + x3 exactly in bf16; pieces = 2: 2^a x = x1 + 2^-11 x2 (+ two dropped bits) in
  * fp16, a chosen from max |x|, followed -- in the room of the third plane -- by float [n_emb]
- * |x - x1| per row, which the one-product pre-filter's margin uses.                                     */
+ * |x - x1| per row, which the one-product pre-filter's margin uses, and float [n_emb] -|x|^2 in the reference's
+ * float32 summation order, which segk_kmeans_score_hinted uses.                                          */
 int64_t segk_corpus_b3_bytes(int64_t n_emb, int32_t D);
 int32_t segk_corpus_prepare_b3(segk_ctx *ctx, const segk_corpus *c, void *Xb3_out, int32_t pieces,
                                void *stream);

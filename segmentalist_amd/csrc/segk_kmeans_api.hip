@@ -100,7 +100,7 @@ int32_t segk_kmeans_score_hinted(segk_ctx *ctx, const segk_corpus *c, const segk
     hipStream_t st = (hipStream_t)stream;
     ctx->defer_zero = cand->count;                     // cleared by the path's first kernel, with its own queue length
     const ScoreArgs A = make_score_args(c, m, ids, row0, n, cand, true);
-    rc = segk_dispatch_score_hint(ctx, A, hint_remap, segk_b3_kp(c->D) / 16, st);
+    rc = segk_dispatch_score_hint(ctx, A, hint_remap, c->n_emb, segk_b3_kp(c->D) / 16, st);
     segk_flush_deferred_zero(ctx, st);                 // (an early error return: nothing was launched)
     if (rc) return rc;
     return segk_resolve_on(ctx, c, m, ids, row0, n, cand, status, stream);

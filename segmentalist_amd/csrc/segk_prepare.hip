@@ -74,16 +74,28 @@ __global__ void k_corpus_split_sp(const float *X, int64_t ldx, int64_t n_emb, in
     for (int q = 0; q < P; q++) row[q * (n_emb * KP) + pos] = pc[q];
 }
 
+// the zero vector as a "mean": neg_sqd_exact against it is -|x|^2 in the reference's own float32 summation order
+struct ZeroRow {
+    __device__ __forceinline__ float operator[](int) const { return 0.f; }
+    __device__ __forceinline__ ZeroRow operator+(int) const { return ZeroRow{}; }
+};
+
+// per row, behind the two piece planes (the image is sized for three): float [n_emb] |x - x1| (the residual norm of the
+// pre-filter's margin), then float [n_emb] -|x|^2 summed exactly like the reference's -(deltas * deltas).sum() with a zero
+// mean (kmeans_components.py:225-226) -- the hinted exact stage turns a reference-arithmetic score s = -|x - m|^2 into
+// the filter's quantity x.m - |m|^2/2 = (s + |x|^2) / 2 with it (segk_score_hint.hip)
 __global__ void k_corpus_resid_sp(const float *X, int64_t ldx, int64_t n_emb, int D, unsigned char *img)
 {
     const int ea = ((const int *)img)[1];
     const int KP = segk_b3_kp(D);
     float *xerr = (float *)(img + SEGK_SP_HEADER + n_emb * 2 * (int64_t)KP * 2);
+    float *nxx = xerr + n_emb;
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_emb) return;
     double s = 0.0;
     for (int d = 0; d < D; d++) s += sp_resid2(ldexpf(X[e * ldx + d], ea));
     xerr[e] = (float)(ldexp(sqrt(s), -ea) * (1.0 + 1e-6)) + 1e-37f;
+    nxx[e] = neg_sqd_exact<float>(ZeroRow{}, X + e * ldx, D);
 }
 
 template <int P>

@@ -37,6 +37,11 @@
 // one that workgroup has already given its final label.
 #define SEGK_HINT_BIT 0x20000000
 
+// development, timing only (-DSEGK_K1_ABL=n, results wrong): 1 no drain in the tile loop, 2 no operand refill from LDS
+#ifndef SEGK_K1_ABL
+#define SEGK_K1_ABL 0
+#endif
+
 struct HintArgs {
     const unsigned char *ximg;      // fp16x2 row image (segk_corpus.Xb3): header, then plane 0 [n_emb][KP]
     const int32_t *ids;
@@ -130,31 +135,6 @@ __global__ __launch_bounds__(64 * NW, 2) void k_kmeans_top2_rs(HintArgs H)
     int nt = H.n_tiles - t_lo;
     if (nt > H.tpr) nt = H.tpr;
     if (nt <= 0) return;
-    // ---- the range's tile images into LDS, once: eight 16-byte loads per thread in flight (one at a time, the fill of
-    // 114 KB by 256 threads is 29 dependent round trips: ~40 us of a 220 us kernel)
-    {
-        constexpr int PER_TILE = KS * 64 + 8, NT = 64 * NW, UF = 8;
-        const int total = nt * PER_TILE;
-        for (int i0 = tid; i0 < total; i0 += NT * UF) {
-            float4 v[UF];
-#pragma unroll
-            for (int u = 0; u < UF; u++) {
-                int i = i0 + u * NT;
-                if (i >= total) i = total - 1;                          // clamped, unconditional load
-                const int t = i / PER_TILE, q = i - t * PER_TILE;
-                const float *src = H.tiles + (int64_t)(t_lo + t) * STRIDE;
-                v[u] = q < KS * 64 ? *reinterpret_cast<const float4 *>(src + ((q >> 6) * P) * 256 + (q & 63) * 4)     // piece 0 of k-step q >> 6
-                                   : *reinterpret_cast<const float4 *>(src + KS * P * 256 + (q - KS * 64) * 4);       // the 32 constants
-            }
-#pragma unroll
-            for (int u = 0; u < UF; u++) {
-                const int i = i0 + u * NT;
-                if (i < total) *reinterpret_cast<float4 *>(lds + (i / PER_TILE) * TL + (i % PER_TILE) * 4) = v[u];
-            }
-        }
-    }
-    __syncthreads();
-
     const T *plane0 = (const T *)(H.ximg + SEGK_SP_HEADER);
     const int64_t n_groups = (H.n + 32 * NBLK - 1) / (32 * NBLK);
     const int64_t n_slots = (int64_t)n_wgr * NW;
@@ -186,7 +166,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_kmeans_top2_rs(HintArgs H)
             asm volatile("" : "+v"(a[s]));                                                                            \
             AN = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s], XB[N_][s], s == 0 ? cs : AN, 0, 0, 0);                  \
             asm volatile("" : "+v"(AN));                                                                              \
-            if (REFILL) {                      /* this tile is done with a[s] (and, after its first MFMA, with cs) */ \
+            if (REFILL && !(SEGK_K1_ABL & 2)) {   /* this tile is done with a[s] (and, after its first MFMA, with cs) */ \
                 load_a(tn, s);                                                                                        \
                 if (s == 0) load_cs(tn);                                                                              \
             }                                                                                                         \
@@ -194,7 +174,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_kmeans_top2_rs(HintArgs H)
             /* quads q_lo .. q_hi-1 of block O_ behind this MFMA: the four quads over the slots 1 .. KS-1 */          \
             constexpr int SL = KS > 1 ? KS - 1 : 1;                                                                   \
             const int q_lo = KS > 1 ? ((s - 1) * 4 + SL - 1) / SL : 0, q_hi = KS > 1 ? (s * 4 + SL - 1) / SL : 4;     \
-            if (KS == 1 || s >= 1) {                                                                                  \
+            if ((KS == 1 || s >= 1) && !(SEGK_K1_ABL & 1)) {                                                          \
                 if (0 >= q_lo && 0 < q_hi) SEGK_RS_DRAIN_QUAD(O_, AO, 0, true);                                       \
                 if (1 >= q_lo && 1 < q_hi) SEGK_RS_DRAIN_QUAD(O_, AO, 1, false);                                      \
                 if (2 >= q_lo && 2 < q_hi) SEGK_RS_DRAIN_QUAD(O_, AO, 2, false);                                      \
@@ -274,16 +254,41 @@ __global__ __launch_bounds__(64 * NW, 2) void k_kmeans_top2_rs(HintArgs H)
         }
     };
     int64_t g = (int64_t)wgr * NW + wave;
-    if (g >= n_groups) return;
-#pragma unroll
-    for (int s = 0; s < KS; s++) load_a(0, s);          // tile 0's operands for the first group; every group's last tile reloads them
-    load_cs(0);
     float pend1[NBLK], pend2[NBLK];
     int32_t pend_row[NBLK], pend_k[NBLK];
     int64_t pend_g = -1;
     V8 xa[NBLK][KS];
     int32_t hrow_a[NBLK], hk_a[NBLK];
-    SEGK_RS_LOAD(g, xa, hrow_a, hk_a);
+    if (g < n_groups) SEGK_RS_LOAD(g, xa, hrow_a, hk_a);          // the first rows travel while the tile images are copied
+    // ---- the range's tile images into LDS, once: sixteen 16-byte loads per thread in flight (one at a time, the fill of
+    // 114 KB by 256 threads is 29 dependent round trips: ~40 us of a 220 us kernel)
+    {
+        constexpr int PER_TILE = KS * 64 + 8, NT = 64 * NW, UF = 16;
+        const int total = nt * PER_TILE;
+        for (int i0 = tid; i0 < total; i0 += NT * UF) {
+            float4 v[UF];
+#pragma unroll
+            for (int u = 0; u < UF; u++) {
+                int i = i0 + u * NT;
+                if (i >= total) i = total - 1;                          // clamped, unconditional load
+                const int t = i / PER_TILE, q = i - t * PER_TILE;
+                const float *src = H.tiles + (int64_t)(t_lo + t) * STRIDE;
+                v[u] = q < KS * 64 ? *reinterpret_cast<const float4 *>(src + ((q >> 6) * P) * 256 + (q & 63) * 4)     // piece 0 of k-step q >> 6
+                                   : *reinterpret_cast<const float4 *>(src + KS * P * 256 + (q - KS * 64) * 4);       // the 32 constants
+            }
+#pragma unroll
+            for (int u = 0; u < UF; u++) {
+                const int i = i0 + u * NT;
+                if (i < total) *reinterpret_cast<float4 *>(lds + (i / PER_TILE) * TL + (i % PER_TILE) * 4) = v[u];
+            }
+        }
+    }
+    __syncthreads();
+
+    if (g >= n_groups) return;
+#pragma unroll
+    for (int s = 0; s < KS; s++) load_a(0, s);          // tile 0's operands for the first group; every group's last tile reloads them
+    load_cs(0);
     if constexpr (PREFETCH) {
         V8 xb[NBLK][KS];
         int32_t hrow_b[NBLK], hk_b[NBLK];
@@ -384,18 +389,20 @@ struct HintExactArgs {
     const float2 *part;             // K1's output
     int n_ranges;
     const int32_t *map;             // [K_max] k_hint_map
+    int64_t n_emb;                  // rows of the corpus (the per-row arrays behind the piece planes)
     const float *tiles_hdr;         // tiles_b3: [0] exponent b, [1] E_m
     const unsigned char *ximg;      // row image header: [1] exponent a
 };
 
-#define SEGK_HINT_ROWS 16       /* rows per step of a wave: four lanes per row */
+#define SEGK_HINT_ROWS 32       /* rows per step of a wave: two lanes per row */
 #define SEGK_HINT_RING 128
 #define SEGK_HINT_UBUF 192
 // K2: see the head of the file.  Skeleton of k_kmeans_exact_pair4 (the table split into P ranges of cpp components, one range
-// per workgroup in LDS; a wave walks its slice of the rows, keeps those whose hint lies in its range in a ring, takes 16 rows
-// per step off the ring and has the next step's loads in flight while it sums the current one).  Four lanes per row:
-// (member, half) -- member 0 is the hinted component, member 1 the zero vector, so that |x|^2 comes out of the same
-// pairwise summation; the four lanes of a row also fetch its (m1, m2) of up to four ranges, its norm bound and its residual.
+// per workgroup in LDS; a wave walks its slice of the rows, keeps those whose hint lies in its range in a ring, takes a step's
+// worth of rows off the ring and has the next step's loads in flight while it sums the current one).  TWO lanes per row
+// (h = 0, 1: the lane halves of numpy's eight strided accumulators), 32 rows = 12.8 KB of rows in flight per wave and step --
+// the stage is bound by the bytes a CU keeps in flight.  -|x|^2 comes precomputed with the row image (k_corpus_resid_sp);
+// the two lanes of a row also fetch its (m1, m2) of up to four ranges, its norm bound and its residual.
 template <int KS, int V, int NW>
 __global__ __launch_bounds__(64 * NW) void k_kmeans_hint_exact(ScoreArgs A, HintExactArgs H, int P, int cpp)
 {
@@ -431,6 +438,7 @@ __global__ __launch_bounds__(64 * NW) void k_kmeans_hint_exact(ScoreArgs A, Hint
     const float unscale = ldexpf(1.f, -e_ab);
     const float M = (float)(sqrt(*A.mnorm2) * (1.0 + 1e-6)) + 1e-30f;
     const float Em = H.tiles_hdr[1];
+    const float *nxx = A.xerr + H.n_emb;                            // -|x|^2 per row, behind the residual norms
 
     // this wave's rows: a multiple of 64 per wave
     const int64_t n_slots = (int64_t)n_chunk * NW;
@@ -483,18 +491,19 @@ __global__ __launch_bounds__(64 * NW) void k_kmeans_hint_exact(ScoreArgs A, Hint
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         while (ucnt >= 64) flush(64);
     };
-    const int row = lane >> 2, q4 = lane & 3, mem = (lane >> 1) & 1, h = lane & 1;
+    const int row = lane >> 1, h = lane & 1;
 
     int32_t rid_n = -1, k_n = 0;
     if (pos < r_end) {
         rid_n = load_rid(pos);
-        k_n = rid_n >= 0 ? A.cand.k[rid_n] : -1;
+        k_n = rid_n >= 0 ? A.cand.k[rid_n] : -2;
     }
     int count = 0, head = 0;
     bool have_prev = false;
     f32x4_t xp[NX];
     int32_t p_rid = -1, p_base = 0;
-    float p_aux = 0.f, p_m1 = NEG_INF_F, p_m2 = NEG_INF_F;
+    // per row, by lane half: h = 0: norm bound, (m1, m2) of ranges 0 and 2; h = 1: residual, -|x|^2, ranges 1 and 3
+    float p_a0 = 0.f, p_a1 = 0.f, p_m1 = NEG_INF_F, p_m2 = NEG_INF_F, p_n1 = NEG_INF_F, p_n2 = NEG_INF_F;
     for (;;) {
         // candidates into the ring until a step's worth is there
         while (count < SEGK_HINT_ROWS && pos < r_end) {
@@ -503,10 +512,10 @@ __global__ __launch_bounds__(64 * NW) void k_kmeans_hint_exact(ScoreArgs A, Hint
             pos += 64;
             if (pos < r_end) {
                 rid_n = load_rid(pos);
-                k_n = rid_n >= 0 ? A.cand.k[rid_n] : -1;
+                k_n = rid_n >= 0 ? A.cand.k[rid_n] : -2;
             }
-            // marked by K1: (previous label | SEGK_HINT_BIT) a hint, -1 none; anything else: already finished by its range's
-            // workgroup.  The label goes through the map: -1 there = the component is carried as absent, no hint either
+            // marked by k_hint_map: (previous label | SEGK_HINT_BIT) a hint, -1 none; anything else: already finished by its
+            // range's workgroup.  The label goes through the map: -1 there = the component is carried as absent, no hint either
             const bool marked = rid >= 0 && k >= 0 && (k & SEGK_HINT_BIT) && (k & ~SEGK_HINT_BIT) < A.K_max;
             const int32_t hint = marked ? map[k & ~SEGK_HINT_BIT] : -1;
             const int32_t base = hint - c_lo;
@@ -536,35 +545,36 @@ __global__ __launch_bounds__(64 * NW) void k_kmeans_hint_exact(ScoreArgs A, Hint
         head = (head + n) & (SEGK_HINT_RING - 1);
         count -= n;
         f32x4_t xn[NX];
-        float n_aux = 0.f, n_m1 = NEG_INF_F, n_m2 = NEG_INF_F;
+        float n_a0 = 0.f, n_a1 = 0.f, n_m1 = NEG_INF_F, n_m2 = NEG_INF_F, n_n1 = NEG_INF_F, n_n2 = NEG_INF_F;
         {
             const int64_t r_any = n_rid >= 0 ? (int64_t)n_rid : (A.ids ? 0 : A.row0);
             const uintptr_t xa = (uintptr_t)(A.xrows32 + r_any * A.ld32);
 #pragma unroll
             for (int b = 0; b < nblk; b++) xn[b] = *reinterpret_cast<gptr_t>(xa + 16u * h + 32u * b);
             if constexpr (rem != 0) xn[nblk] = *reinterpret_cast<gptr_t>(xa + 4u * nfull);
-            // lane q of the row: the filter's (m1, m2) of range q; lane 0 also the norm bound, lane 1 the residual
             if (n_rid >= 0) {
-                if (q4 < H.n_ranges) {
-                    const float2 pv = H.part[(int64_t)q4 * A.n + n_pos];
+                n_a0 = h == 0 ? A.xnorm[n_rid] : A.xerr[n_rid];
+                if (h == 1) n_a1 = nxx[n_rid];
+                if (h < H.n_ranges) {
+                    const float2 pv = H.part[(int64_t)h * A.n + n_pos];
                     n_m1 = pv.x;
                     n_m2 = pv.y;
                 }
-                n_aux = q4 == 0 ? A.xnorm[n_rid] : q4 == 1 ? A.xerr[n_rid] : 0.f;
+                if (h + 2 < H.n_ranges) {
+                    const float2 pv = H.part[(int64_t)(h + 2) * A.n + n_pos];
+                    n_n1 = pv.x;
+                    n_n2 = pv.y;
+                }
             }
         }
         if (have_prev) {
             // the reference's float32 -(deltas*deltas).sum() in numpy's pairwise order: this lane owns the strided
-            // accumulators r_{4h..4h+3}; member 0 = the hinted component, member 1 = 0 (gives -|x|^2)
+            // accumulators r_{4h..4h+3} of the hinted component
             const float *mrow = lds + p_base * LD;
             f32x4_t mv[NX];
 #pragma unroll
             for (int b = 0; b < nblk; b++) mv[b] = *reinterpret_cast<const f32x4_t *>(mrow + 4 * h + 8 * b);
             if constexpr (rem != 0) mv[nblk] = *reinterpret_cast<const f32x4_t *>(mrow + nfull);
-            if (mem) {
-#pragma unroll
-                for (int b = 0; b < NX; b++) mv[b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-            }
             f32x2_t rl = {0.f, 0.f}, rh = {0.f, 0.f};
 #pragma unroll
             for (int b = 0; b < nblk; b++) {
@@ -584,20 +594,19 @@ __global__ __launch_bounds__(64 * NW) void k_kmeans_hint_exact(ScoreArgs A, Hint
                 if (rem > 2) res += th.x;
                 if (rem > 3) res += th.y;
             }
-            const float sc = -res;                                 // lanes 0, 1 of the row: -|x - m_h|^2; lanes 2, 3: -|x|^2
-            const float so = __shfl_xor(sc, 2);
+            const float sc = -res;                                 // -|x - m_h|^2, both lanes of the row
             // the filter's top-2 over the ranges: (a1, a2) + (b1, b2) = (max(a1, b1), max(min(a1, b1), max(a2, b2)))
-            float t1 = p_m1, t2 = p_m2;
-#pragma unroll
-            for (int o = 1; o <= 2; o <<= 1) {
-                const float u1 = __shfl_xor(t1, o), u2 = __shfl_xor(t2, o);
+            float t1 = fmaxf(p_m1, p_n1), t2 = fmaxf(fminf(p_m1, p_n1), fmaxf(p_m2, p_n2));
+            {
+                const float u1 = __shfl_xor(t1, 1), u2 = __shfl_xor(t2, 1);
                 const float n1 = fmaxf(t1, u1);
                 t2 = fmaxf(fminf(t1, u1), fmaxf(t2, u2));
                 t1 = n1;
             }
-            const float xnb = __shfl(p_aux, lane & ~3), xer = __shfl(p_aux, (lane & ~3) | 1);
+            const float xer = __shfl_xor(p_a0, 1), so = __shfl_xor(p_a1, 1);      // lane half 0 reads its partner's
             bool und = false;
-            if (q4 == 0 && p_rid >= 0) {
+            if (h == 0 && p_rid >= 0) {
+                const float xnb = p_a0;
                 const float top1 = t1 * unscale, top2 = t2 * unscale;          // powers of two: exact
                 const float u = 5.9604645e-8f;
                 const float tau = filter_tau_h1(xnb, M, D, xer, Em);
@@ -611,8 +620,6 @@ __global__ __launch_bounds__(64 * NW) void k_kmeans_hint_exact(ScoreArgs A, Hint
                 if (ok) {
                     A.cand.k[p_rid] = p_base + c_lo;
                     A.cand.s[p_rid] = (double)sc;
-                    A.cand.f[2 * (int64_t)p_rid + 0] = top1;
-                    A.cand.f[2 * (int64_t)p_rid + 1] = top2;
                 } else {
                     und = true;
                 }
@@ -624,9 +631,8 @@ __global__ __launch_bounds__(64 * NW) void k_kmeans_hint_exact(ScoreArgs A, Hint
         for (int b = 0; b < NX; b++) xp[b] = xn[b];
         p_rid = n_rid;
         p_base = n_base;
-        p_aux = n_aux;
-        p_m1 = n_m1;
-        p_m2 = n_m2;
+        p_a0 = n_a0; p_a1 = n_a1;
+        p_m1 = n_m1; p_m2 = n_m2; p_n1 = n_n1; p_n2 = n_n2;
         have_prev = true;
     }
     if (ucnt > 0) flush(ucnt);
@@ -634,7 +640,7 @@ __global__ __launch_bounds__(64 * NW) void k_kmeans_hint_exact(ScoreArgs A, Hint
 
 // ---------------------------------------------------------------------------------------------------------------------
 template <int KS>
-static int launch_score_hint(segk_ctx *ctx, ScoreArgs A, const int32_t *remap, hipStream_t st)
+static int launch_score_hint(segk_ctx *ctx, ScoreArgs A, const int32_t *remap, int64_t n_emb, hipStream_t st)
 {
     const int n_cu = ctx->n_cu;
     // ---- workspaces: the second stage's queue (as the pre-filter path), K1's partial top-2, the hint map
@@ -730,6 +736,7 @@ static int launch_score_hint(segk_ctx *ctx, ScoreArgs A, const int32_t *remap, h
     E.part = (const float2 *)ctx->hint_part;
     E.n_ranges = n_ranges;
     E.map = ctx->hint_map;
+    E.n_emb = n_emb;
     E.tiles_hdr = A.tiles;
     E.ximg = (const unsigned char *)A.X32;
     const int pitch4 = ((A.D >> 2) + ((2 - (A.D >> 2)) & 3)) * 16;
@@ -765,17 +772,17 @@ static int launch_score_hint(segk_ctx *ctx, ScoreArgs A, const int32_t *remap, h
     return SEGK_OK;
 }
 
-int segk_dispatch_score_hint(segk_ctx *ctx, const ScoreArgs &A, const int32_t *remap, int ks, hipStream_t st)
+int segk_dispatch_score_hint(segk_ctx *ctx, const ScoreArgs &A, const int32_t *remap, int64_t n_emb, int ks, hipStream_t st)
 {
     switch (ks) {
-        case 1: return launch_score_hint<1>(ctx, A, remap, st);
-        case 2: return launch_score_hint<2>(ctx, A, remap, st);
-        case 3: return launch_score_hint<3>(ctx, A, remap, st);
-        case 4: return launch_score_hint<4>(ctx, A, remap, st);
-        case 5: return launch_score_hint<5>(ctx, A, remap, st);
-        case 6: return launch_score_hint<6>(ctx, A, remap, st);
-        case 7: return launch_score_hint<7>(ctx, A, remap, st);
-        case 8: return launch_score_hint<8>(ctx, A, remap, st);
+        case 1: return launch_score_hint<1>(ctx, A, remap, n_emb, st);
+        case 2: return launch_score_hint<2>(ctx, A, remap, n_emb, st);
+        case 3: return launch_score_hint<3>(ctx, A, remap, n_emb, st);
+        case 4: return launch_score_hint<4>(ctx, A, remap, n_emb, st);
+        case 5: return launch_score_hint<5>(ctx, A, remap, n_emb, st);
+        case 6: return launch_score_hint<6>(ctx, A, remap, n_emb, st);
+        case 7: return launch_score_hint<7>(ctx, A, remap, n_emb, st);
+        case 8: return launch_score_hint<8>(ctx, A, remap, n_emb, st);
         default: break;
     }
     segk_set_error("hinted score path: D out of range");

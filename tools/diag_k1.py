@@ -19,6 +19,9 @@ for env in sys.argv[2:] or [""]:
         if "=" in kv:
             k, v = kv.split("=")
             os.environ[k] = v
+    if "ZERO=1" in env:          # clock check: the same instruction stream on all-zero operands (results meaningless)
+        dk.corpus.Xb3[64:].zero_()
+        dk.tiles_b3.view(torch.uint8)[4096:].zero_()
     _abi.check(L.segk_profile_enable(ctx, 1))
     for _ in range(14):
         dk.score_rows(row0=0, n=dk.corpus.n_emb, hint_remap=dk.remap)

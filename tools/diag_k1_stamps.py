@@ -15,7 +15,10 @@ torch.cuda.synchronize()
 dk = seg._dk
 st = torch.zeros(256 * 8 * 8, dtype=torch.int64, device="cuda")
 os.environ["SEGK_STAMP_PTR"] = hex(st.data_ptr())
-for _ in range(3):
+if os.environ.get("ZERO") == "1":          # clock check: the same instruction stream on all-zero operands
+    dk.corpus.Xb3[64:].zero_()
+    dk.tiles_b3.view(torch.uint8)[4096:].zero_()
+for _ in range(12):
     dk.score_rows(row0=0, n=dk.corpus.n_emb, hint_remap=dk.remap)
 torch.cuda.synchronize()
 v = st.cpu().numpy().reshape(-1, 8)
