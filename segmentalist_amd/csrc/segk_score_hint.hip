@@ -366,10 +366,16 @@ __global__ __launch_bounds__(64 * NW, 2) void k_kmeans_top2_rs(HintArgs H)
 //            is carried as "absent" by the filters' images (seed constant <= -1e37: a marked duplicate) -- such a hint
 //            proves nothing;
 //   cand.k of every row of the call: (previous label | SEGK_HINT_BIT) when that label is a component index, -1 otherwise.
+//   and the queue lengths of the call cleared: the caller's ambiguity queue (when segk_kmeans_score_hinted deferred it) and
+//   the second stage's counters.
 __global__ void k_hint_map(const int32_t *remap, const float *tiles_sp /* first tile */, int K_max, int stride, int const_off, int32_t *map,
-                           const int32_t *ids, int64_t row0, int64_t n, int32_t *cand_k)
+                           const int32_t *ids, int64_t row0, int64_t n, int32_t *cand_k, int32_t *zero_cnt, int32_t *pre_hdr)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (blockIdx.x == 0) {
+        if (threadIdx.x == 0 && zero_cnt) *zero_cnt = 0;
+        if (threadIdx.x < 16) pre_hdr[threadIdx.x] = 0;
+    }
     if (i < K_max) {
         int v = remap ? remap[i] : (int)i;
         if (v < 0 || v >= K_max) v = -1;
@@ -684,13 +690,11 @@ static int launch_score_hint(segk_ctx *ctx, ScoreArgs A, const int32_t *remap, i
     // queue lengths of the call (the caller's ambiguity queue, deferred by segk_kmeans_score, and the second stage's)
     int32_t *zero_cnt = ctx->defer_zero;
     ctx->defer_zero = nullptr;
-    if (zero_cnt) hipLaunchKernelGGL(k_zero_two, dim3(1), dim3(64), 0, st, zero_cnt, ctx->pre_queue);
-    else SEGK_CHECK_HIP(hipMemsetAsync(ctx->pre_queue, 0, 16 * sizeof(int32_t), st));
     const int stride_sp = segk_sp_tile_stride(A.D, 2);
     {
         const int64_t nthr = A.n > A.K_max ? A.n : A.K_max;
         hipLaunchKernelGGL(k_hint_map, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, remap, A.tiles + 1024, A.K_max, stride_sp,
-                           KS * 2 * 256, ctx->hint_map, A.ids, A.row0, A.n, A.cand.k);
+                           KS * 2 * 256, ctx->hint_map, A.ids, A.row0, A.n, A.cand.k, zero_cnt, ctx->pre_queue);
     }
 
     // ---- K1
