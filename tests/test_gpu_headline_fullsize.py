@@ -148,6 +148,87 @@ def test_a_optional_launch_plans_give_the_same_bits(gpu, headline, scored, monke
     assert np.array_equal(dk.cand_s.cpu().numpy(), scored["cand_s"])
 
 
+# ------------------------------------------------------------------ the hinted score path (segk_kmeans_score_hinted)
+def _hinted(gpu, dk, hints, remap):
+    """One hinted score call over the whole corpus -> (cand_k, cand_s, rows sent to the second stage, rows of the full scan,
+    kind of the timed kernel)."""
+    import ctypes as C
+    import torch
+    from segmentalist_amd import _abi
+    L, ctx = _abi.lib(), _abi.ctx()
+    dk.cand_k.copy_(torch.from_numpy(np.ascontiguousarray(hints.astype(np.int32))).to(dk.cand_k.device))
+    dk.cand_s.fill_(float("nan"))
+    _abi.check(L.segk_profile_enable(ctx, 1))
+    dk.score_rows(row0=0, n=dk.corpus.n_emb, hint_remap=remap)
+    counts = (C.c_int32 * 2)()
+    _abi.check(L.segk_kmeans_stage_counts(ctx, C.byref(dk.cand), counts, _abi.stream()))
+    kind = int(L.segk_profile_last_kind(ctx))
+    _abi.check(L.segk_profile_enable(ctx, 0))
+    gpu.cuda.synchronize()
+    return dk.cand_k.cpu().numpy(), dk.cand_s.cpu().numpy(), int(counts[0]), int(counts[1]), kind
+
+
+def test_a_hinted_path_gives_the_oracle_bits_whatever_the_hints(gpu, headline, scored, monkeypatch):
+    """segk_kmeans_score_hinted on the 1.05 M rows and the statistics of test_a (whose cand_k / cand_s are the C oracle's):
+    the value-only top-2 on the matrix cores (k_kmeans_top2_rs) + the exact stage that verifies a hint per row
+    (k_kmeans_hint_exact) must return the same bits for ANY hints -- the true winners (the steady state of a chain), the
+    winners under another labelling through the relabel table, every hint wrong, garbage, and the adversarial one: a hint
+    that names an exact duplicate (higher row) of the true winner, which the dense filter values alone cannot tell from the
+    winner (np.argmax takes the first; the library carries marked duplicates as absent, so such a hint proves nothing)."""
+    import torch
+    monkeypatch.delenv("SEGK_SCORE_HINT", raising=False)
+    seg, _ = headline
+    dk = seg._dk
+    n_emb = dk.corpus.n_emb
+    want_k, want_s = scored["cand_k"], scored["cand_s"]
+    ident = torch.arange(K, dtype=torch.int32, device="cuda")
+    rs = np.random.RandomState(5)
+
+    def check(tag, hints, remap, lo, hi):
+        k, s, n_second, n_scan, kind = _hinted(gpu, dk, hints, remap)
+        assert kind == 5, "%s: the hinted path did not run (kind %d)" % (tag, kind)
+        bad = np.flatnonzero(k != want_k)
+        assert bad.size == 0, "%s: argmax differs on %d rows, first %s" % (tag, bad.size, bad[:8])
+        assert np.array_equal(s, want_s), tag
+        assert lo <= n_second <= hi, "%s: %d rows went to the second stage, expected %d..%d" % (tag, n_second, lo, hi)
+        return n_second
+
+    # (1) the true winners: only the rows whose margin the one-product filter cannot certify go on (the pre-filter's count)
+    n1 = check("true winners", want_k, ident, 1, int(1.2 * scored["n_second"]) + 64)
+    assert n1 >= int(0.8 * scored["n_second"])
+    # (2) the same under a permuted labelling, translated by the relabel table
+    perm = rs.permutation(K).astype(np.int32)                     # new label of old label k
+    inv = np.argsort(perm).astype(np.int32)
+    n2 = check("relabelled", inv[want_k], torch.from_numpy(perm).cuda(), 1, int(1.2 * scored["n_second"]) + 64)
+    assert n2 == n1
+    # (3) every hint wrong: everything goes to the second stage
+    wrong = (want_k + 1 + rs.randint(0, K - 1, n_emb)) % K
+    assert not (wrong == want_k).any()
+    check("all wrong", wrong, ident, n_emb - 64, n_emb)
+    # (4) garbage: negative, out of range, stale marks of either kind
+    junk = rs.choice(np.array([-1, -7, K, K + 5, 2 ** 30, 2 ** 29, 2 ** 29 | 3, 2 ** 30 | 17, 2 ** 31 - 1], dtype=np.int64), n_emb)
+    mix = np.where(rs.rand(n_emb) < 0.5, want_k, junk)
+    check("garbage", mix, ident, int(0.4 * n_emb), int(0.6 * n_emb) + scored["n_second"])
+    # (5) exact duplicates: hint = a LATER row with the same mean as the true winner
+    means = scored["means"]
+    _, first, inverse = np.unique(means, axis=0, return_index=True, return_inverse=True)
+    inverse = inverse.reshape(-1)
+    dup_of = {}
+    for kk in range(K):
+        f = int(first[inverse[kk]])
+        if f != kk:
+            dup_of.setdefault(min(f, kk), max(f, kk))
+    assert len(dup_of) >= 1, "the headline state has exact duplicate rows (clean_components leaves copies behind)"
+    adv = want_k.copy()
+    hit = 0
+    for lo_k, hi_k in dup_of.items():
+        sel = want_k == lo_k
+        adv[sel] = hi_k
+        hit += int(sel.sum())
+    assert hit >= 1
+    check("duplicate of the winner", adv, ident, hit, hit + int(1.2 * scored["n_second"]) + 64)
+
+
 def test_b_all_boundaries_match_the_oracle_viterbi(headline, scored):
     from oracle import c_oracle as co
     seg, _ = headline
@@ -259,83 +340,3 @@ def test_c_statistics_equal_a_host_recount_in_the_specified_order(gpu, headline,
     rows = np.concatenate([new_tok[i, :n_new[i]] for i in range(N_UTT)])
     assert np.array_equal(a[rows], np.concatenate([new_k[i, :n_new[i]] for i in range(N_UTT)]))
 
-
-# ------------------------------------------------------------------ the hinted score path (segk_kmeans_score_hinted)
-def _hinted(gpu, dk, hints, remap):
-    """One hinted score call over the whole corpus -> (cand_k, cand_s, rows sent to the second stage, rows of the full scan,
-    kind of the timed kernel)."""
-    import ctypes as C
-    import torch
-    from segmentalist_amd import _abi
-    L, ctx = _abi.lib(), _abi.ctx()
-    dk.cand_k.copy_(torch.from_numpy(np.ascontiguousarray(hints.astype(np.int32))).to(dk.cand_k.device))
-    dk.cand_s.fill_(float("nan"))
-    _abi.check(L.segk_profile_enable(ctx, 1))
-    dk.score_rows(row0=0, n=dk.corpus.n_emb, hint_remap=remap)
-    counts = (C.c_int32 * 2)()
-    _abi.check(L.segk_kmeans_stage_counts(ctx, C.byref(dk.cand), counts, _abi.stream()))
-    kind = int(L.segk_profile_last_kind(ctx))
-    _abi.check(L.segk_profile_enable(ctx, 0))
-    gpu.cuda.synchronize()
-    return dk.cand_k.cpu().numpy(), dk.cand_s.cpu().numpy(), int(counts[0]), int(counts[1]), kind
-
-
-def test_a_hinted_path_gives_the_oracle_bits_whatever_the_hints(gpu, headline, scored, monkeypatch):
-    """segk_kmeans_score_hinted on the 1.05 M rows and the statistics of test_a (whose cand_k / cand_s are the C oracle's):
-    the value-only top-2 on the matrix cores (k_kmeans_top2_rs) + the exact stage that verifies a hint per row
-    (k_kmeans_hint_exact) must return the same bits for ANY hints -- the true winners (the steady state of a chain), the
-    winners under another labelling through the relabel table, every hint wrong, garbage, and the adversarial one: a hint
-    that names an exact duplicate (higher row) of the true winner, which the dense filter values alone cannot tell from the
-    winner (np.argmax takes the first; the library carries marked duplicates as absent, so such a hint proves nothing)."""
-    import torch
-    monkeypatch.delenv("SEGK_SCORE_HINT", raising=False)
-    seg, _ = headline
-    dk = seg._dk
-    n_emb = dk.corpus.n_emb
-    want_k, want_s = scored["cand_k"], scored["cand_s"]
-    ident = torch.arange(K, dtype=torch.int32, device="cuda")
-    rs = np.random.RandomState(5)
-
-    def check(tag, hints, remap, lo, hi):
-        k, s, n_second, n_scan, kind = _hinted(gpu, dk, hints, remap)
-        assert kind == 5, "%s: the hinted path did not run (kind %d)" % (tag, kind)
-        bad = np.flatnonzero(k != want_k)
-        assert bad.size == 0, "%s: argmax differs on %d rows, first %s" % (tag, bad.size, bad[:8])
-        assert np.array_equal(s, want_s), tag
-        assert lo <= n_second <= hi, "%s: %d rows went to the second stage, expected %d..%d" % (tag, n_second, lo, hi)
-        return n_second
-
-    # (1) the true winners: only the rows whose margin the one-product filter cannot certify go on (the pre-filter's count)
-    n1 = check("true winners", want_k, ident, 1, int(1.2 * scored["n_second"]) + 64)
-    assert n1 >= int(0.8 * scored["n_second"])
-    # (2) the same under a permuted labelling, translated by the relabel table
-    perm = rs.permutation(K).astype(np.int32)                     # new label of old label k
-    inv = np.argsort(perm).astype(np.int32)
-    n2 = check("relabelled", inv[want_k], torch.from_numpy(perm).cuda(), 1, int(1.2 * scored["n_second"]) + 64)
-    assert n2 == n1
-    # (3) every hint wrong: everything goes to the second stage
-    wrong = (want_k + 1 + rs.randint(0, K - 1, n_emb)) % K
-    assert not (wrong == want_k).any()
-    check("all wrong", wrong, ident, n_emb - 64, n_emb)
-    # (4) garbage: negative, out of range, stale marks of either kind
-    junk = rs.choice(np.array([-1, -7, K, K + 5, 2 ** 30, 2 ** 29, 2 ** 29 | 3, 2 ** 30 | 17, 2 ** 31 - 1], dtype=np.int64), n_emb)
-    mix = np.where(rs.rand(n_emb) < 0.5, want_k, junk)
-    check("garbage", mix, ident, int(0.4 * n_emb), int(0.6 * n_emb) + scored["n_second"])
-    # (5) exact duplicates: hint = a LATER row with the same mean as the true winner
-    means = scored["means"]
-    _, first, inverse = np.unique(means, axis=0, return_index=True, return_inverse=True)
-    inverse = inverse.reshape(-1)
-    dup_of = {}
-    for kk in range(K):
-        f = int(first[inverse[kk]])
-        if f != kk:
-            dup_of.setdefault(min(f, kk), max(f, kk))
-    assert len(dup_of) >= 1, "the headline state has exact duplicate rows (clean_components leaves copies behind)"
-    adv = want_k.copy()
-    hit = 0
-    for lo_k, hi_k in dup_of.items():
-        sel = want_k == lo_k
-        adv[sel] = hi_k
-        hit += int(sel.sum())
-    assert hit >= 1
-    check("duplicate of the winner", adv, ident, hit, hit + int(1.2 * scored["n_second"]) + 64)
