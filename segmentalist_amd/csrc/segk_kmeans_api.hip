@@ -84,7 +84,11 @@ static bool hinted_path_applies(const segk_ctx *ctx, const segk_corpus *c, const
     if (!segk_use_b3(c, m) || c->sp_pieces != 2 || c->D % 4 != 0) return false;
     if (n >= (int64_t)1 << 30) return false;
     // K1 keeps at most four LDS ranges of tile images, K2's table ranges must not outnumber the CUs
-    if (segk_n_tiles(m->K_max) > 4 * (int)((160 * 1024) / (((segk_b3_kp(c->D) / 16) * 256 + 32) * sizeof(float)))) return false;
+    {
+        int max_tiles = (int)((160 * 1024) / (((segk_b3_kp(c->D) / 16) * 256 + 32) * sizeof(float)));
+        if (max_tiles > 32) max_tiles = 32;              // SEGK_HINT_MAX_TPR
+        if (segk_n_tiles(m->K_max) > 4 * max_tiles) return false;
+    }
     return mode == 1 || n > 384 * (int64_t)ctx->n_cu;
 }
 

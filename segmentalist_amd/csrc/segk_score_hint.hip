@@ -36,6 +36,7 @@
 // workgroups (one table range each) all scan every row: the mark tells a row that still waits for its range's workgroup from
 // one that workgroup has already given its final label.
 #define SEGK_HINT_BIT 0x20000000
+#define SEGK_HINT_MAX_TPR 32         /* tiles per LDS range of K1 at most (its fill: one thread per float4 of the constants) */
 
 // development, timing only (-DSEGK_K1_ABL=n, results wrong): 1 no drain in the tile loop, 2 no operand refill from LDS
 #ifndef SEGK_K1_ABL
@@ -259,33 +260,55 @@ __global__ __launch_bounds__(64 * NW, 2) void k_kmeans_top2_rs(HintArgs H)
     int64_t pend_g = -1;
     V8 xa[NBLK][KS];
     int32_t hrow_a[NBLK], hk_a[NBLK];
-    if (g < n_groups) SEGK_RS_LOAD(g, xa, hrow_a, hk_a);          // the first rows travel while the tile images are copied
-    // ---- the range's tile images into LDS, once: sixteen 16-byte loads per thread in flight (one at a time, the fill of
-    // 114 KB by 256 threads is 29 dependent round trips: ~40 us of a 220 us kernel)
+    if (g < n_groups && !(H.dbg & 4)) SEGK_RS_LOAD(g, xa, hrow_a, hk_a);      // the first rows travel while the tile images are copied
+#ifdef SEGK_STAMP
+    const unsigned long long st_k1 = __builtin_amdgcn_s_memtime();
+#endif
+    // ---- the range's tile images into LDS, once.  The unit of the copy is one 1 KiB piece-0 block (a k-step of a tile:
+    // 64 lanes x 16 bytes, contiguous in both images): wave w takes the blocks w, w + NW, ...; source and destination of a
+    // block are wave-uniform (scalar arithmetic), and ALL of a wave's loads -- 28 for the headline model -- are in flight
+    // together: one round trip for the 114 KB.  (Element-wise with a division per 16 bytes and 16 loads in flight per thread
+    // the fill took 21 700 cycles, 12 us of a 200 us kernel -- and a third of a 1 250-utterance shard's.)
     {
-        constexpr int PER_TILE = KS * 64 + 8, NT = 64 * NW, UF = 16;
-        const int total = nt * PER_TILE;
-        for (int i0 = tid; i0 < total; i0 += NT * UF) {
-            float4 v[UF];
+        constexpr int MAXT = (160 * 1024 / (TL * 4)) < SEGK_HINT_MAX_TPR ? (160 * 1024 / (TL * 4)) : SEGK_HINT_MAX_TPR;
+        constexpr int MAXB = MAXT * KS;                                 // blocks of the largest range (LDS, SEGK_HINT_MAX_TPR)
+        constexpr int PER_W = (MAXB + NW - 1) / NW;
+        const int n_blk = nt * KS;
+        // every workgroup of a range copies the same bytes at the same moment: started at the same block they all queue on
+        // the same L2 channel (5.8 bytes per cycle and CU measured).  Each starts somewhere else in the range instead.
+        const int rot = (int)(((unsigned)wgr * 2654435761u) >> 8) % n_blk;
+        float4 v[PER_W];
 #pragma unroll
-            for (int u = 0; u < UF; u++) {
-                int i = i0 + u * NT;
-                if (i >= total) i = total - 1;                          // clamped, unconditional load
-                const int t = i / PER_TILE, q = i - t * PER_TILE;
-                const float *src = H.tiles + (int64_t)(t_lo + t) * STRIDE;
-                v[u] = q < KS * 64 ? *reinterpret_cast<const float4 *>(src + ((q >> 6) * P) * 256 + (q & 63) * 4)     // piece 0 of k-step q >> 6
-                                   : *reinterpret_cast<const float4 *>(src + KS * P * 256 + (q - KS * 64) * 4);       // the 32 constants
-            }
+        for (int u = 0; u < PER_W; u++) {
+            int c = wave + u * NW;
+            if (c >= n_blk) c = n_blk - 1;                              // clamped, unconditional load
+            c += rot;
+            if (c >= n_blk) c -= n_blk;
+            const int t = c / KS, ks = c - t * KS;
+            v[u] = *reinterpret_cast<const float4 *>(H.tiles + (int64_t)(t_lo + t) * STRIDE + ks * (P * 256) + lane * 4);
+        }
+        float4 cv4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        const bool has_c = tid < nt * 8;                                // the 32 constants of every tile: one float4 per thread
+        if (has_c) cv4 = *reinterpret_cast<const float4 *>(H.tiles + (int64_t)(t_lo + (tid >> 3)) * STRIDE + KS * P * 256 + (tid & 7) * 4);
 #pragma unroll
-            for (int u = 0; u < UF; u++) {
-                const int i = i0 + u * NT;
-                if (i < total) *reinterpret_cast<float4 *>(lds + (i / PER_TILE) * TL + (i % PER_TILE) * 4) = v[u];
+        for (int u = 0; u < PER_W; u++) {
+            int c = wave + u * NW;
+            if (c < n_blk) {
+                c += rot;
+                if (c >= n_blk) c -= n_blk;
+                const int t = c / KS, ks = c - t * KS;
+                *reinterpret_cast<float4 *>(lds + t * TL + ks * 256 + lane * 4) = v[u];
             }
         }
+        if (has_c) *reinterpret_cast<float4 *>(lds + (tid >> 3) * TL + KS * 256 + (tid & 7) * 4) = cv4;
+        static_assert(64 * NW >= MAXT * 8, "one thread per float4 of the constants");
     }
     __syncthreads();
-
+#ifdef SEGK_STAMP
+    const unsigned long long st_k2 = __builtin_amdgcn_s_memtime();
+#endif
     if (g >= n_groups) return;
+    if (H.dbg & 4) SEGK_RS_LOAD(g, xa, hrow_a, hk_a);
 #pragma unroll
     for (int s = 0; s < KS; s++) load_a(0, s);          // tile 0's operands for the first group; every group's last tile reloads them
     load_cs(0);
@@ -336,7 +359,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_kmeans_top2_rs(HintArgs H)
         if (H.stamp && lane == 0) {
             unsigned long long *o = H.stamp + ((int64_t)blockIdx.x * NW + wave) * 8;
             o[0] = st_wait; o[1] = st_loop; o[2] = __builtin_amdgcn_s_memtime() - st_begin; o[3] = st_groups;
-            o[4] = st_begin - st_k0; o[5] = st_r0; o[6] = __builtin_amdgcn_s_memrealtime();
+            o[4] = st_begin - st_k0; o[5] = st_r0; o[6] = __builtin_amdgcn_s_memrealtime(); o[7] = ((st_k1 - st_k0) << 32) | (st_k2 - st_k1);
         }
 #endif
 #undef SEGK_ST
@@ -663,7 +686,8 @@ static int launch_score_hint(segk_ctx *ctx, ScoreArgs A, const int32_t *remap, i
     A.pre_cap = (int)A.n;
     // K1's ranges: as many tiles as fit in LDS beside nothing else (one workgroup per CU)
     constexpr int TL = KS * 256 + 32;
-    const int max_tiles = (int)((160 * 1024) / (TL * sizeof(float)));
+    int max_tiles = (int)((160 * 1024) / (TL * sizeof(float)));
+    if (max_tiles > SEGK_HINT_MAX_TPR) max_tiles = SEGK_HINT_MAX_TPR;
     int n_ranges = (A.n_tiles + max_tiles - 1) / max_tiles;
     // two ranges at least when that halves the LDS fill per workgroup without starving the grid (the fill is per workgroup)
     if (n_ranges < 1) n_ranges = 1;

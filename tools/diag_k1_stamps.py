@@ -34,3 +34,4 @@ r0, r1 = v[:, 5].min(), v[:, 6].max()
 print("realtime (100 MHz): kernel span %.1f us; wave starts spread %.1f us; wave ends spread %.1f us; mean wave life %.1f us -> clock %.2f GHz" % (
     (r1 - r0) / 100.0, (v[:, 5].max() - r0) / 100.0, (r1 - v[:, 6].min()) / 100.0, ((v[:, 6] - v[:, 5]).mean()) / 100.0,
     (v[:, 2] + v[:, 4]).mean() / ((v[:, 6] - v[:, 5]).mean() / 100.0) / 1e3))
+print("start-up: entry -> first rows issued %.0f cycles, LDS fill (loads + writes + barrier) %.0f cycles" % ((v[:, 7] >> 32).mean(), (v[:, 7] & 0xffffffff).mean()))
