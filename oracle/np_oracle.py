@@ -596,6 +596,87 @@ def kmeans_batch_sweep(seg, n_blocks=8):
     return tree_sum(blk)
 
 
+def minibatch_ranges(n_utt, n_blocks, n_batches):
+    """Utterance ranges [lo, hi) of (statistics block b, mini-batch j): every block is cut into n_batches contiguous runs."""
+    bb = block_bounds(n_utt, n_blocks)
+    out = []
+    for b in range(n_blocks):
+        sub = block_bounds(bb[b + 1] - bb[b], n_batches)
+        out.append([(bb[b] + sub[j], bb[b] + sub[j + 1]) for j in range(n_batches)])
+    return out
+
+
+def kmeans_minibatch_sweep(seg, n_blocks=8, n_batches=1, totals=None):
+    """SPEC of the mini-batch form of the batch-synchronous sweep ("or per mini-batch of B utterances for
+    fresher stats"; the reference itself refreshes the means after EVERY utterance, kmeans_acoustic_wordseg.py:314-320,
+    393-399).  The sweep is n_batches steps; step j resegments, against the means as they stand at the start of the step,
+    the utterances of run j of EVERY statistics block (so that every GPU has an equal share of every step), then rebuilds
+    counts / mean_numerators from scratch over the CURRENT tokens of ALL utterances -- resegmented ones and not yet
+    resegmented ones alike -- in the fixed order of kmeans_batch_sweep, and cleans the components.  n_batches = 1 is
+    kmeans_batch_sweep.  `totals` (float64 [n_utt], kept by the caller across sweeps; default: a fresh array) holds every
+    utterance's objective from the step that resegmented it; the return value is their block-sequential, tree-combined sum.
+    Results do not depend on the number of GPUs."""
+    u, c = seg.utterances, seg.acoustic_model.components
+    D = u.D
+    if totals is None:
+        totals = np.zeros(D)
+    bb = block_bounds(D, n_blocks)
+    ranges = minibatch_ranges(D, n_blocks, n_batches)
+    for j in range(n_batches):
+        step = [i for b in range(n_blocks) for i in range(*ranges[b][j])]          # utterance-index order
+        new_tokens = {}
+        for i in step:
+            N = u.lengths[i]
+            tri = (N * N + N) // 2
+            vec = seg.get_vec_embed_neg_len_sqrd_norms(u.vec_ids[i, :tri], u.durations[i, :tri])
+            totals[i], bnd = forward_backward_kmeans_viterbi(vec, N, seg.n_slices_min, seg.n_slices_max, i)
+            old = u.get_segmented_embeds_i(i)
+            u.boundaries[i, :N] = bnd
+            new = u.get_segmented_embeds_i(i)
+            assert -1 not in new
+            new_tokens[i] = (old, new, c.get_max_assignments(new))
+        for i in step:                                   # delete the old items of the step's utterances ...
+            for e in new_tokens[i][0]:
+                if e != -1:
+                    c.assignments[e] = -1
+        K = c.K
+        for i in step:                                   # ... add the new ones in utterance order, add_item's clamp replayed
+            for e, k in zip(new_tokens[i][1], new_tokens[i][2]):
+                if k > K:
+                    k = K
+                if k == K:
+                    K += 1
+                c.assignments[e] = k
+        c.K = K
+        # statistics from scratch over ALL utterances' current tokens, in the fixed order
+        part_sum, part_cnt = [], []
+        for b in range(n_blocks):
+            s = np.zeros((c.K_max, c.D), np.float64)
+            n = np.zeros(c.K_max, np.int64)
+            for i in range(bb[b], bb[b + 1]):
+                for e in u.get_segmented_embeds_i(i):    # token order: utterance, then segment
+                    if e == -1:                          # a segment of the initial segmentation without an embedding
+                        continue
+                    k = c.assignments[e]
+                    s[k] += c.X[e]
+                    n[k] += 1
+            part_sum.append(s)
+            part_cnt.append(n)
+        c.mean_numerators = tree_sum(part_sum)
+        c.counts = tree_sum(part_cnt)
+        for k in range(c.K):
+            if c.counts[k] != 0:
+                c.means[k] = c.mean_numerators[k] / c.counts[k]
+        c.clean_components()
+    blk = []
+    for b in range(n_blocks):
+        acc = np.float64(0.)
+        for i in range(bb[b], bb[b + 1]):
+            acc += totals[i]
+        blk.append(acc)
+    return tree_sum(blk)
+
+
 # --------------------------------------------------------------------------- #
 # A3/A11  GaussianComponentsFixedVar (gaussian_components_fixedvar.py:20-338)
 # --------------------------------------------------------------------------- #

@@ -389,6 +389,24 @@ class Partition(object):
         self.row_lo = int(utt_row_start[self.utt_lo])
         self.row_hi = int(utt_row_start[self.utt_hi])
         self.local_bounds = self.bounds[rank * self.nbl:(rank + 1) * self.nbl + 1].copy()
+        self._row_start = utt_row_start
+
+    def minibatch(self, n_batches):
+        """Step j of a mini-batch sweep resegments run j of EVERY statistics block (oracle/np_oracle.py minibatch_ranges):
+        for this rank's blocks -> per step (utterance ids int32, embedding rows int32, contiguous?) as numpy arrays."""
+        steps = []
+        for j in range(n_batches):
+            utts, rows = [], []
+            for b in range(self.rank * self.nbl, (self.rank + 1) * self.nbl):
+                lo_b, hi_b = int(self.bounds[b]), int(self.bounds[b + 1])
+                lo = lo_b + (j * (hi_b - lo_b)) // n_batches
+                hi = lo_b + ((j + 1) * (hi_b - lo_b)) // n_batches
+                utts.append(np.arange(lo, hi, dtype=np.int32))
+                rows.append(np.arange(int(self._row_start[lo]), int(self._row_start[hi]), dtype=np.int32))
+            u, r = np.concatenate(utts), np.concatenate(rows)
+            contiguous = self.nbl == 1 or (len(u) and u[-1] - u[0] + 1 == len(u))
+            steps.append((u, r, bool(contiguous)))
+        return steps
 
 
 class KMeansBatchSweeper(object):
@@ -419,7 +437,61 @@ class KMeansBatchSweeper(object):
         self.use_graph = os.environ.get("SEGK_SWEEP_GRAPH", "0") == "1"
         self._graph, self._graph_args, self._side, self._warm = None, None, None, 0
         self._hints = False          # no sweep of this sweeper has filled cand_k / remap yet
+        self._mb = None              # (n_batches, per-step launch tables) of sweep_minibatch
         dk.batch_comm = self.comm
+
+    # ------------------------------------------------------------------ mini-batch sweeps
+    def _minibatch_tables(self, n_batches):
+        if self._mb is None or self._mb[0] != n_batches:
+            steps = []
+            for u, r, contiguous in self.part.minibatch(n_batches):
+                if contiguous:
+                    steps.append((int(u[0]) if len(u) else 0, len(u), int(r[0]) if len(r) else 0, len(r), None, None))
+                else:
+                    steps.append((0, len(u), 0, len(r), to_dev(u, np.int32), to_dev(r, np.int32)))
+            self._mb = (n_batches, steps)
+        return self._mb[1]
+
+    def _tokens_from_state(self, boundaries):
+        """Token lists of ALL utterances from the boundaries and `assignments` (the state a fresh segmenter or the
+        sequential mode leaves): what a mini-batch step needs for the utterances it does not resegment."""
+        torch = _torch()
+        dk, c = self.dk, self.dk.corpus
+        check(dk._L.segk_fbb_collect(dk._ctx, dk._cp(), ptr(boundaries), ptr(dk.new_tok), ptr(dk.n_new), _abi.stream()))
+        live = torch.arange(c.N_max, device=dk.n_new.device, dtype=torch.int32)[None, :] < dk.n_new[:, None]
+        lab = dk.assignments[dk.new_tok.clamp(min=0).long()]
+        dk.new_k.copy_(torch.where(live, lab, torch.full_like(lab, -1)))
+        dk.n_flag.zero_()
+
+    def sweep_minibatch(self, boundaries, n_slices_min, n_slices_max, wip, n_batches):
+        """One sweep as n_batches steps (specification: oracle/np_oracle.py kmeans_minibatch_sweep): step j scores and
+        resegments run j of every local statistics block against the current means, then the statistics are rebuilt from the
+        current tokens of ALL utterances exactly as in a whole-sweep batch step (sort, partial sums, ONE all-gather,
+        finalize) -- n_batches all-gathers per sweep, n_batches times fresher statistics."""
+        dk, pt = self.dk, self.part
+        L, ctx, cp, mp, st = dk._L, dk._ctx, dk._cp(), C.byref(dk.m), _abi.stream()
+        if dk.assign_stale is None:
+            dk.ensure_boundaries()
+            self._tokens_from_state(boundaries)
+        for (utt0, n_utts, row0, n_rows, utts, rows) in self._minibatch_tables(n_batches):
+            remap = dk.remap if self._hints else None
+            if rows is None:
+                dk.score_rows(row0=row0, n=n_rows, hint_remap=remap)
+                dk.segment(boundaries, n_slices_min, n_slices_max, wip, utt0=utt0, n_utts=n_utts)
+            else:
+                dk.score_rows(ids=rows, hint_remap=remap)
+                check(L.segk_kmeans_segment(ctx, cp, mp, ptr(utts), 0, n_utts, int(n_slices_min), int(n_slices_max), float(wip),
+                                            C.byref(dk.cand), ptr(boundaries), ptr(dk.old_tok), ptr(dk.new_tok), ptr(dk.new_k),
+                                            ptr(dk.n_old), ptr(dk.n_new), ptr(dk.n_flag), ptr(dk.out_total), ptr(dk.status), st))
+            check(L.segk_kmeans_batch_partials(ctx, cp, mp, ptr(self.blk_lo), pt.nbl, ptr(dk.new_tok), ptr(dk.new_k),
+                                               ptr(dk.n_flag), ptr(dk.out_total), ptr(self.sorted), ptr(self.koff),
+                                               ptr(self.pack), self.cap, ptr(dk.out_scalars), st))
+            if pt.world > 1:
+                self.comm.all_gather_rows(self.pack_all, self.pack)
+            self._enqueue_back()
+            self._hints = True
+        dk.assign_stale = (pt.utt_lo, pt.utt_hi, pt.world)
+        dk.bounds_stale = (boundaries, pt) if pt.world > 1 else None
 
     def _enqueue_front(self, boundaries, n_slices_min, n_slices_max, wip):
         dk, pt = self.dk, self.part

@@ -14,6 +14,9 @@ keys.  Two execution modes:
         summation order; utterances shard over the ranks of a torch.distributed job.  A
         different (AD-LDA style) chain; bit-identical for 1/2/4/8 GPUs and to the CPU
         restatement of the same specification (oracle/np_oracle.py kmeans_batch_sweep).
+        n_batches > 1: the sweep runs as that many steps, each resegmenting 1/n_batches of every
+        statistics block against the means the previous step left (kmeans_minibatch_sweep):
+        between the whole-sweep batch chain and the reference's per-utterance refresh.
 """
 import ctypes as C
 import logging
@@ -38,10 +41,12 @@ class SegmentalKMeansWordseg(object):
     def __init__(self, am_K, embedding_mats, vec_ids_dict, durations_dict, landmarks_dict,
                  seed_boundaries_dict=None, seed_assignments_dict=None, n_slices_min=0,
                  n_slices_max=20, min_duration=0, p_boundary_init=0.5, init_am_assignments="rand",
-                 wip=0, sync="sequential", n_stat_blocks=8, flag_cap=4096, process_group=None):
+                 wip=0, sync="sequential", n_stat_blocks=8, flag_cap=4096, process_group=None, n_batches=1):
         logger.info("Initializing")
         assert seed_assignments_dict is None or seed_boundaries_dict is not None
         assert sync in ("sequential", "batch")
+        assert n_batches >= 1
+        self.n_batches = int(n_batches)      # batch mode: statistics refreshed n_batches times per sweep (mini-batches)
         self.n_slices_min = n_slices_min
         self.n_slices_max = n_slices_max
         self.wip = wip
@@ -145,7 +150,10 @@ class SegmentalKMeansWordseg(object):
 
     def batch_sweep_async(self):
         """Enqueue one batch-synchronous sweep; results stay on the device."""
-        self._get_sweeper().sweep(self._dev_bounds, self.n_slices_min, self.n_slices_max, self.wip)
+        if self.n_batches > 1:
+            self._get_sweeper().sweep_minibatch(self._dev_bounds, self.n_slices_min, self.n_slices_max, self.wip, self.n_batches)
+        else:
+            self._get_sweeper().sweep(self._dev_bounds, self.n_slices_min, self.n_slices_max, self.wip)
         self.utterances.mark_device_dirty()
 
     # ------------------------------------------------------------------ driver

@@ -30,12 +30,13 @@ def gpu():
     return torch
 
 
-def _kmeans_run(corpus, K, n_sweeps, comm, counts=None):
+def _kmeans_run(corpus, K, n_sweeps, comm, counts=None, n_batches=1):
     from segmentalist_amd import kmeans_acoustic_wordseg as kaw
     random.seed(11)
     np.random.seed(11)
     seg = kaw.SegmentalKMeansWordseg(K, *corpus, n_slices_min=0, n_slices_max=6, p_boundary_init=0.5,
-                                     init_am_assignments="spread", wip=0, sync="batch", n_stat_blocks=8, process_group=comm)
+                                     init_am_assignments="spread", wip=0, sync="batch", n_stat_blocks=8, process_group=comm,
+                                     n_batches=n_batches)
     rec = seg.segment(n_sweeps)
     c = seg.acoustic_model.components
     if counts is not None:           # which stages of the score path this rank's launches went through
@@ -77,6 +78,20 @@ def test_headline_corpus_on_eight_ranks_equals_one_rank(gpu):
     # whole-corpus one and not the split-precision filter alone
     assert sorted(c[0] for c in counts) == list(range(8))
     assert all(c[1] > 0 for c in counts), counts
+
+
+def test_minibatch_sweeps_on_eight_ranks_equal_one_rank(gpu):
+    """n_batches = 4 (four all-gathers per sweep, every rank resegmenting a quarter of its block per step) at a size where the
+    hinted score path runs per step on one rank (2 000 utterances: 52 500 rows per step) and the small-launch paths on eight."""
+    from segmentalist_amd.comm import SingleComm
+    from segmentalist_amd.synth import make_corpus
+    corpus = make_corpus(2000, 100, 1000, seed=1, N=20, n_slices_max=6)
+    one = _kmeans_run(corpus, 1000, 3, SingleComm(), n_batches=4)
+    eight = VirtualWorld(8).run(lambda comm: _kmeans_run(corpus, 1000, 3, comm, n_batches=4))
+    for r in range(8):
+        _same(one, eight[r])
+    whole = _kmeans_run(corpus, 1000, 3, SingleComm(), n_batches=1)
+    assert whole["totals"] != one["totals"]                  # a different chain than the whole-sweep batch mode
 
 
 @pytest.mark.parametrize("kind,prec", [("diag", "f64"), ("bigram", "f64"), ("bigram", "f16"), ("diag", "f32")])

@@ -362,6 +362,42 @@ def test_batch_sweep_bit_exact_vs_spec(gpu, n_utt, D, K, nmax, dtype, n_blocks):
             assert rec["n_tokens"][0] == ref.acoustic_model.get_n_assigned()
 
 
+@pytest.mark.parametrize("n_utt,D,K,nmax,n_blocks,n_batches", [(40, 16, 12, 6, 4, 2), (64, 8, 9, 5, 8, 4), (33, 12, 30, 4, 2, 8),
+                                                             (24, 5, 4, 5, 1, 3), (300, 100, 130, 6, 8, 2)])
+def test_minibatch_sweep_bit_exact_vs_spec(gpu, n_utt, D, K, nmax, n_blocks, n_batches):
+    """sync="batch", n_batches > 1 ("or per mini-batch of B utterances for fresher stats") against the executable
+    specification oracle/np_oracle.py kmeans_minibatch_sweep: after every sweep boundaries, assignments, K, counts, numerators,
+    means and the record total, bit for bit -- from a fresh segmenter (whose token lists are first derived from the initial
+    segmentation), with more mini-batches than some blocks have utterances, with one block, and with an interleaved step of
+    the sequential chain (the token lists are then rebuilt from the state it leaves)."""
+    from oracle import np_oracle as no
+    from segmentalist_amd import kmeans_acoustic_wordseg as kaw
+    corpus = cases.chain_corpus(n_utt, D, K, 2000 + n_utt, True, 0, nmax, "float32")
+    for init in ("spread", "rand"):
+        random.seed(5); np.random.seed(5)
+        ref = no.SegmentalKMeansWordseg(K, *corpus, n_slices_max=nmax, init_am_assignments=init)
+        random.seed(5); np.random.seed(5)
+        seg = kaw.SegmentalKMeansWordseg(K, *corpus, n_slices_max=nmax, init_am_assignments=init, sync="batch",
+                                         n_stat_blocks=n_blocks, n_batches=n_batches)
+        cr, cd = ref.acoustic_model.components, seg.acoustic_model.components
+        totals = np.zeros(ref.utterances.D)
+        for it in range(4):
+            if it == 2:                                  # one utterance through the reference's sequential step on both sides
+                want_i = ref.segment_i(3)
+                assert seg.segment_i(3) == want_i
+                totals[3] = want_i
+            want = no.kmeans_minibatch_sweep(ref, n_blocks, n_batches, totals)
+            rec = seg.segment(1)
+            assert np.array_equal(seg.utterances.boundaries, ref.utterances.boundaries), it
+            assert np.array_equal(cd.assignments, cr.assignments), it
+            assert cd.K == cr.K
+            assert np.array_equal(cd.counts, cr.counts)
+            assert np.array_equal(cd.mean_numerators, cr.mean_numerators), it
+            assert np.array_equal(cd.means, cr.means), it
+            assert rec["sum_neg_len_sqrd_norm"][0] == want, it
+            assert rec["n_tokens"][0] == ref.acoustic_model.get_n_assigned()
+
+
 def test_batch_sweep_headline_shape_properties(gpu):
     """BASELINE config 3 shape (D=100, K=1000, 20 landmarks, n_slices_max=6) at 1500 utterances:
     size-independent properties + spot parity against the C oracle."""

@@ -42,7 +42,15 @@ def test_kmeans_batch_objective_tracks_the_sequential_chain(gpu):
     batch chain keeps fewer components (772 against 950: with every token moving at once more components empty in the
     first sweep and clean_components removes them for good)."""
     import batch_vs_sequential as bvs
-    r = bvs.kmeans_curves(2000, 10)
+    r = bvs.kmeans_curves(2000, 10, minibatches=(8,))
+    # mini-batches (n_batches = 8: the statistics refreshed eight times per sweep) move the batch chain towards the
+    # sequential one: more components survive the first sweeps, the objective ends closer (VERDICT r02 item 6)
+    km, ks_ = r["minibatch_8"]["components"][-1], r["sequential"]["components"][-1]
+    assert abs(km - ks_) <= 0.10 * ks_, (km, ks_)
+    rel8 = _rel(r["minibatch_8"]["sum_neg_len_sqrd_norm"], r["sequential"]["sum_neg_len_sqrd_norm"])
+    assert abs(rel8[-1]) < 0.01, rel8
+    assert abs(rel8[-1]) <= abs(_rel(r["batch"]["sum_neg_len_sqrd_norm"], r["sequential"]["sum_neg_len_sqrd_norm"])[-1])
+    assert r["minibatch_8"]["components"][-1] >= r["batch"]["components"][-1]
     rel = _rel(r["batch"]["sum_neg_len_sqrd_norm"], r["sequential"]["sum_neg_len_sqrd_norm"])
     assert (np.abs(rel[2:]) < 0.12).all(), rel
     assert abs(rel[-1]) < 0.04, rel

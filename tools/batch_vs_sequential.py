@@ -11,16 +11,19 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 
 
-def kmeans_curves(n_utt, n_sweeps, D=100, K=1000):
+def kmeans_curves(n_utt, n_sweeps, D=100, K=1000, minibatches=()):
+    """sequential, batch (whole-sweep statistics) and, for every B in `minibatches`, "minibatch_B" (n_batches = B)."""
     from segmentalist_amd import kmeans_acoustic_wordseg as kaw
     from segmentalist_amd.synth import make_corpus
     corpus = make_corpus(n_utt, D, K, seed=0, N=20, n_slices_max=6)
     out = {}
-    for sync in ("sequential", "batch"):
+    for name, kw in [("sequential", dict(sync="sequential")), ("batch", dict(sync="batch"))] + \
+            [("minibatch_%d" % b, dict(sync="batch", n_batches=b)) for b in minibatches]:
         random.seed(0); np.random.seed(0)
-        seg = kaw.SegmentalKMeansWordseg(K, *corpus, n_slices_max=6, init_am_assignments="spread", sync=sync)
+        seg = kaw.SegmentalKMeansWordseg(K, *corpus, n_slices_max=6, init_am_assignments="spread", **kw)
         rec = seg.segment(n_sweeps)
-        out[sync] = {k: [float(v) for v in rec[k]] for k in ("sum_neg_len_sqrd_norm", "sum_neg_sqrd_norm", "components", "n_tokens")}
+        out[name] = {k: [float(v) for v in rec[k]] for k in ("sum_neg_len_sqrd_norm", "sum_neg_sqrd_norm", "components", "n_tokens")}
+        out[name]["sample_time"] = [float(v) for v in rec["sample_time"]]
     return out
 
 
@@ -53,7 +56,7 @@ def main():
     ap.add_argument("--sweeps", type=int, default=10)
     ap.add_argument("--out", default="")
     a = ap.parse_args()
-    res = {"kmeans_c3_shape": dict(utterances=a.utts, D=100, K=1000, **kmeans_curves(a.utts, a.sweeps)),
+    res = {"kmeans_c3_shape": dict(utterances=a.utts, D=100, K=1000, **kmeans_curves(a.utts, a.sweeps, minibatches=(2, 4, 8))),
            "fbgmm_diag_c2": dict(utterances=1000, D=39, K=100, **fbgmm_curves("diag", 1000, a.sweeps, 39, 100)),
            "bigram_fixed": dict(utterances=500, D=39, K=100, **fbgmm_curves("bigram", 500, a.sweeps, 39, 100))}
     txt = json.dumps(res, indent=1)
@@ -66,6 +69,10 @@ def main():
             print("  sweep %2d  sequential %14.4f  batch %14.4f  rel diff %+.4f   K %4d / %4d   tokens %6d / %6d"
                   % (i, s, b, (b - s) / abs(s), r["sequential"]["components"][i], r["batch"]["components"][i],
                      r["sequential"]["n_tokens"][i], r["batch"]["n_tokens"][i]))
+        for mb in sorted(k for k in r if k.startswith("minibatch_")):
+            print("  %-12s last sweep %14.4f  rel diff to sequential %+.4f   K %4d   tokens %6d   %.2f ms per sweep"
+                  % (mb, r[mb][key][-1], (r[mb][key][-1] - r["sequential"][key][-1]) / abs(r["sequential"][key][-1]),
+                     r[mb]["components"][-1], r[mb]["n_tokens"][-1], 1e3 * float(np.median(r[mb]["sample_time"][1:]))))
 
 
 if __name__ == "__main__":
