@@ -34,7 +34,38 @@ def test_library_exports_every_header_symbol(built):
     for s in syms:
         assert hasattr(lib, s), s
     assert set(syms) == set(built.SIGNATURES), set(syms) ^ set(built.SIGNATURES)
-    assert built.lib().segk_abi_version() == 1
+    # the version the header describes == the one the library reports == the one the binding was written against
+    # (built.lib() itself refuses a library that reports another one)
+    hdr = int(re.search(r"#define\s+SEGK_ABI_VERSION\s+(\d+)", open(os.path.join(ROOT, "include", "segk.h")).read()).group(1))
+    assert lib.segk_abi_version() == hdr == built.ABI_VERSION
+
+
+def test_binding_refuses_a_library_of_another_abi_version(built, monkeypatch):
+    monkeypatch.setattr(built, "_lib", None)
+    monkeypatch.setattr(built, "ABI_VERSION", built.ABI_VERSION + 1)
+    with pytest.raises(built.SegkError, match="ABI version"):
+        built.lib()
+    monkeypatch.setattr(built, "_lib", None)
+
+
+def test_integration_stub_structs_match_the_binding(built):
+    """INTEGRATION.md shows the ctypes stub a maintainer of the reference would add; its structures are passed to the
+    library BY VALUE inside the calls, so a stub that lags behind include/segk.h makes the library read past its end
+    (VERDICT r02).  The structures of the document are executed here and compared with the binding's field by field."""
+    txt = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", txt, flags=re.S)
+    stub = [b for b in blocks if "class Corpus(C.Structure)" in b]
+    assert len(stub) == 1
+    src = stub[0]
+    # only the structure definitions: everything up to the first function
+    src = src[:src.index("def check(rc)")]
+    src = "\n".join(l for l in src.splitlines() if not l.startswith(("import ", "lib = ", "# ", "assert lib.")))
+    ns = {"C": ctypes}
+    exec(src, ns)
+    for name, mine in (("Corpus", built.Corpus), ("KMeansDev", built.KMeansDev), ("Cand", built.CandDev)):
+        doc = ns[name]
+        assert ctypes.sizeof(doc) == ctypes.sizeof(mine), name
+        assert [(f[0], f[1]) for f in doc._fields_] == [(f[0], f[1]) for f in mine._fields_], name
 
 
 def test_struct_layout_matches_header(built):
