@@ -51,7 +51,6 @@ struct HintArgs {
     int n_tiles, tpr, n_ranges;     // tiles per range, ranges
     float2 *part;                   // [n_ranges][n] (m1, m2) in the scaled domain of the images
     int K_max;
-    int32_t *ctr;                   // [n_ranges] dynamic group counters (zeroed by k_hint_map)
     int dbg;                        // development (SEGK_HINT_DBG, results wrong): 1 no result stores, 2 no hint loads / marks
     unsigned long long *stamp;      // development (-DSEGK_STAMP builds): per wave {cycles in the row waits, in the tile loops, total, groups}
 };
@@ -328,49 +327,33 @@ __global__ __launch_bounds__(64 * NW, 2) void k_kmeans_top2_rs(HintArgs H)
 #else
 #define SEGK_ST(var) do { } while (0)
 #endif
-        // Groups are handed out dynamically after the first two per wave: one counter per range, fetched (a returning
-        // atomic by lane 0) a whole group before the index is needed, right behind a wait and in front of the loads it
-        // must not queue behind.  With a static split the waves of the slower CUs ended 17-25 us after the first ones.
-        auto fetch_issue = [&]() -> int32_t {
-            int32_t v = 0;
-            if (lane == 0) v = __hip_atomic_fetch_add(H.ctr + range, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return v;
-        };
-        int64_t g_cur = g, g_nxt = g + n_slots, g_nn;
-        int32_t f_v = fetch_issue();
         for (;;) {
             SEGK_ST(s0);
-            __builtin_amdgcn_s_waitcnt(0x0F70);                             // vmcnt(0): the rows of group g_cur are in xa
+            __builtin_amdgcn_s_waitcnt(0x0F70);                             // vmcnt(0): the rows of group g are in xa
             SEGK_ST(s1);
-            g_nn = 2 * n_slots + __builtin_amdgcn_readfirstlane(f_v);
-            f_v = fetch_issue();
-            if (g_nxt < n_groups) SEGK_RS_LOAD(g_nxt, xb, hrow_b, hk_b);    // in flight under this group's tile loop
+            const int64_t g1 = g + n_slots;
+            if (g1 < n_groups) SEGK_RS_LOAD(g1, xb, hrow_b, hk_b);          // in flight under this group's tile loop
             SEGK_RS_STORE();
             SEGK_ST(s2);
-            SEGK_RS_GROUP(g_cur, xa, hrow_a, hk_a);
+            SEGK_RS_GROUP(g, xa, hrow_a, hk_a);
             SEGK_ST(s3);
 #ifdef SEGK_STAMP
             st_wait += s1 - s0; st_loop += s3 - s2; st_groups++;
 #endif
-            if (g_nxt >= n_groups) break;
-            g_cur = g_nxt;
-            g_nxt = g_nn;
+            if (g1 >= n_groups) break;
             SEGK_ST(s4);
             __builtin_amdgcn_s_waitcnt(0x0F70);
             SEGK_ST(s5);
-            g_nn = 2 * n_slots + __builtin_amdgcn_readfirstlane(f_v);
-            f_v = fetch_issue();
-            if (g_nxt < n_groups) SEGK_RS_LOAD(g_nxt, xa, hrow_a, hk_a);
+            g = g1 + n_slots;
+            if (g < n_groups) SEGK_RS_LOAD(g, xa, hrow_a, hk_a);
             SEGK_RS_STORE();
             SEGK_ST(s6);
-            SEGK_RS_GROUP(g_cur, xb, hrow_b, hk_b);
+            SEGK_RS_GROUP(g1, xb, hrow_b, hk_b);
             SEGK_ST(s7);
 #ifdef SEGK_STAMP
             st_wait += s5 - s4; st_loop += s7 - s6; st_groups++;
 #endif
-            if (g_nxt >= n_groups) break;
-            g_cur = g_nxt;
-            g_nxt = g_nn;
+            if (g >= n_groups) break;
         }
 #ifdef SEGK_STAMP
         if (H.stamp && lane == 0) {
@@ -414,7 +397,7 @@ __global__ void k_hint_map(const int32_t *remap, const float *tiles_sp /* first 
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (blockIdx.x == 0) {
         if (threadIdx.x == 0 && zero_cnt) *zero_cnt = 0;
-        if (threadIdx.x < 16) pre_hdr[threadIdx.x] = 0;          // [0..3] queue counters, [8..11] K1's group counters
+        if (threadIdx.x < 16) pre_hdr[threadIdx.x] = 0;
     }
     if (i < K_max) {
         int v = remap ? remap[i] : (int)i;
@@ -746,7 +729,6 @@ static int launch_score_hint(segk_ctx *ctx, ScoreArgs A, const int32_t *remap, i
     H.n_tiles = A.n_tiles; H.tpr = tpr; H.n_ranges = n_ranges;
     H.part = (float2 *)ctx->hint_part;
     H.K_max = A.K_max;
-    H.ctr = ctx->pre_queue + 8;
     H.dbg = getenv("SEGK_HINT_DBG") ? atoi(getenv("SEGK_HINT_DBG")) : 0;
 #ifdef SEGK_STAMP
     H.stamp = getenv("SEGK_STAMP_PTR") ? (unsigned long long *)strtoull(getenv("SEGK_STAMP_PTR"), nullptr, 0) : nullptr;
