@@ -962,7 +962,9 @@ __global__ void k_fbb_assign(segk_corpus c, segk_fbgmm f, segk_fbatch bt, FbbMap
 // (virtual thread v = 64 cw + lane sums the slots v, v + 256, ...; a butterfly per cw; the four results added in order),
 // so the probabilities and the draws are the same bits.
 // ---------------------------------------------------------------------------------------
-template <int F32>
+// PROBE: the variant the library launches while segk_fbb_set_probe is in force -- the same statements plus the stores of
+// the token likelihoods (a test of a null pointer per slot inside the token loop cost the production kernel ~9 %)
+template <int F32, bool PROBE = false>
 __global__ __launch_bounds__(256) void k_fbb_assign_lm_wave(segk_corpus c, segk_fbgmm f, segk_fbatch bt, FbbMap map, int b, uint64_t sweep,
                                                             double prior_alpha, double anneal_temp, const int32_t *new_tok,
                                                             const int32_t *n_new, const float *llmat, int64_t ll_ld, int n_items,
@@ -1032,7 +1034,8 @@ __global__ __launch_bounds__(256) void k_fbb_assign_lm_wave(segk_corpus c, segk_
                 for (int j = 0; j < KPL; j++) {
                     const double n = cn[j];
                     const double llv = n > 0.0 ? (double)mr[j] * LN2 - zl[j] + norm : empty_ll;
-                    if (probe_ll && lane + 64 * j < KM) probe_ll[((int64_t)utt * c.N_max + t) * probe_ld + lane + 64 * j] = llv;
+                    if constexpr (PROBE)
+                        if (lane + 64 * j < KM) probe_ll[((int64_t)utt * c.N_max + t) * probe_ld + lane + 64 * j] = llv;
                     double pz;
                     if (j_prev < 0) pz = ((double)(__builtin_amdgcn_logf((float)(n + aK)) * 0.6931471805599453f) - ltot) * f.lms;
                     else pz = (double)(__builtin_amdgcn_logf((float)(f.lm_lambda * ((n + aK) * inv_tot) + ((double)bg[j] + bK) * inv_prev)) * 0.6931471805599453f) * f.lms;
@@ -1086,7 +1089,7 @@ __global__ __launch_bounds__(256) void k_fbb_assign_lm_wave(segk_corpus c, segk_
             for (int k = lane; k < KM; k += 64) {
                 const double n = bt.cnt[k];
                 const double llv = n > 0.0 ? (double)mrow[k] * LN2 - (bt.zconst[k] - bt.lconst[k]) + norm : empty_ll;
-                if (probe_ll) probe_ll[((int64_t)utt * c.N_max + t) * probe_ld + k] = llv;
+                if constexpr (PROBE) probe_ll[((int64_t)utt * c.N_max + t) * probe_ld + k] = llv;
                 double pz;
                 if (j_prev < 0) pz = ((double)(__builtin_amdgcn_logf((float)(n + aK)) * 0.6931471805599453f) - ltot) * f.lms;      // bigram_lms.py:64-69
                 else {                                                                                                          // bigram_lms.py:84-91
@@ -1141,7 +1144,7 @@ __global__ __launch_bounds__(256) void k_fbb_assign_lm_wave(segk_corpus c, segk_
             const double n = bt.cnt[k];
             const double llv = n > 0.0 ? (double)mrow[k] * LN2 - (bt.zconst[k] - bt.lconst[k]) + norm
                                        : (double)mrow[KM] * LN2 - zc_empty - log(n_empty) + norm;
-            if (probe_ll) probe_ll[((int64_t)utt * c.N_max + t) * probe_ld + k] = llv;
+            if constexpr (PROBE) probe_ll[((int64_t)utt * c.N_max + t) * probe_ld + k] = llv;
             double pz;
             if (j_prev < 0) pz = (log(n + f.lm_a / (double)KM) - log(tot + f.lm_a)) * f.lms;                       // bigram_lms.py:64-69
             else {                                                                                              // bigram_lms.py:84-91
@@ -1688,20 +1691,24 @@ static int32_t fbb_assign_impl(segk_ctx *ctx, const segk_corpus *c, const segk_f
     const char *awe = getenv("SEGK_FBB_ASSIGN_WAVE");
     if (f->lm_unigram && ll_mat && dbg == 0 && !(awe && atoi(awe) == 0) && 4 * (size_t)f->K_max * sizeof(double) <= 150 * 1024) {
         const size_t ldsw = 4 * (size_t)f->K_max * sizeof(double);
-        static size_t ldsw_set = 0;
-        if (ldsw > 48 * 1024 && ldsw > ldsw_set) {
-            SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_fbb_assign_lm_wave<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw));
-            SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_fbb_assign_lm_wave<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw));
-            ldsw_set = ldsw;
-        }
         const int n_items = m.off[s_n];
         // SEGK_FBB_ASSIGN_WAVE=2: the softmax with the fp64 library functions (the bits of the block-wide form)
-        if (awe && atoi(awe) == 2)
-            hipLaunchKernelGGL(k_fbb_assign_lm_wave<0>, dim3((n_items + 3) / 4), dim3(256), ldsw, (hipStream_t)stream, *c, *f, *bt, m, b,
-                               sweep, alpha, anneal_temp, new_tok, n_new, ll_mat, ll_ld, n_items, ctx->probe_ll, ctx->probe_ll_ld);
-        else
-            hipLaunchKernelGGL(k_fbb_assign_lm_wave<1>, dim3((n_items + 3) / 4), dim3(256), ldsw, (hipStream_t)stream, *c, *f, *bt, m, b,
-                               sweep, alpha, anneal_temp, new_tok, n_new, ll_mat, ll_ld, n_items, ctx->probe_ll, ctx->probe_ll_ld);
+        const bool lib64 = awe && atoi(awe) == 2;
+#define SEGK_LM_WAVE(FF, PP)                                                                                                    \
+    do {                                                                                                                        \
+        if (ldsw > 48 * 1024)                                                                                                   \
+            SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_fbb_assign_lm_wave<FF, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw)); \
+        hipLaunchKernelGGL((k_fbb_assign_lm_wave<FF, PP>), dim3((n_items + 3) / 4), dim3(256), ldsw, (hipStream_t)stream, *c, *f, *bt, m, b, \
+                           sweep, alpha, anneal_temp, new_tok, n_new, ll_mat, ll_ld, n_items, ctx->probe_ll, ctx->probe_ll_ld);  \
+    } while (0)
+        if (ctx->probe_ll) {
+            if (lib64) SEGK_LM_WAVE(0, true);
+            else SEGK_LM_WAVE(1, true);
+        } else {
+            if (lib64) SEGK_LM_WAVE(0, false);
+            else SEGK_LM_WAVE(1, false);
+        }
+#undef SEGK_LM_WAVE
         SEGK_LAUNCH_CHECK();
         return SEGK_OK;
     }

@@ -9,6 +9,7 @@
 #     shards    bench.py --utts 5000 / 2500 / 1250 (the per-rank share at 2 / 4 / 8 GPUs, no collective)
 #     variants  the other filters (SEGK_SCORE_HINT=0, SEGK_SCORE_PRE=0, SEGK_SCORE_B3=0)
 #     workloads bench.py --workload bigram_c5 / fbgmm_diag_c2 / kmeans_c3_sequential
+#     clean     delete the rocpd databases of this session (after stats / timeline / pmc have been summarised)
 # Copy what is to be judged from gpurun_out/TAG/ into profiles/ (named rNN_TAG_*).
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
@@ -30,6 +31,7 @@ stats)
     python tools/rocpd_summary.py stats $(find $O/stats -name "*.db" | head -1) $O/kernel_stats.csv
     head -16 $O/kernel_stats.csv | cut -c1-150 ;;
 timeline) python tools/trace_timeline.py $(find $O/stats -name "*.db" | head -1) 15 1 > $O/timeline.txt; cat $O/timeline.txt ;;
+clean) find $O -name "*.db" -delete ;;      # the rocpd databases are tens of MB each: gpurun_out/ travels back only under 64 MiB
 pmc)
     for C in FETCH_SIZE WRITE_SIZE; do
         (cd /tmp && export TMPDIR=/tmp && timeout -k 10 500 rocprofv3 --kernel-trace --pmc $C -d $O/pmc_$C -o pmc -- python3 $R/bench.py --steps 5 --warmup 2 --windows 1 --cpu-utts 0 > /dev/null 2> $O/pmc_$C.err)
@@ -37,6 +39,7 @@ pmc)
     done
     (cd /tmp && export TMPDIR=/tmp && timeout -k 10 500 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d $O/pmc_sq -o pmc -- python3 $R/bench.py --steps 5 --warmup 2 --windows 1 --cpu-utts 0 > /dev/null 2> $O/pmc_sq.err)
     python tools/rocpd_summary.py pmc $(find $O/pmc_sq -name "*.db" | head -1) $O/pmc_sq.csv
+    find $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_sq -name "*.db" -delete
     grep -E "top2_rs|hint_exact|score_h1|exact_pair4" $O/pmc_fetch_size.csv $O/pmc_write_size.csv $O/pmc_sq.csv | cut -c1-230 ;;
 shards) for u in 5000 2500 1250; do timeout -k 10 300 python bench.py --cpu-utts 0 --utts $u > $O/bench_$u.json 2> /dev/null; v "utts=$u" $O/bench_$u.json; done ;;
 variants)
