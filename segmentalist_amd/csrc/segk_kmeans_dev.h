@@ -294,6 +294,31 @@ struct ScoreArgs {
     unsigned long long *stamp;   /* -DSEGK_STAMP development builds: s_memtime at phase boundaries, 8 per workgroup */
 };
 
+// development (-DSEGK_STAMP builds only): wall-clock stamps (s_memrealtime, 100 MHz) of the phases of the sweep's tail kernels,
+// [kernel][workgroup % 1024][8] in a device buffer whose address comes through the environment (tools/diag_tail_stamps.py)
+#ifdef SEGK_STAMP
+static __device__ unsigned long long segk_tstamp_buf;           // the address as an integer: stores go through a global (address_space(1)) pointer
+#define SEGK_TSTAMP_AT(kern, ph) ((__attribute__((address_space(1))) unsigned long long *)segk_tstamp_buf + (((kern) * 1024 + (blockIdx.x & 1023)) * 8) + (ph))
+#define SEGK_TSTAMP(kern, ph)                                                                           \
+    do {                                                                                                \
+        if (segk_tstamp_buf && threadIdx.x == 0) *SEGK_TSTAMP_AT(kern, ph) = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#define SEGK_TSTAMP_MAX(kern, ph)                                                                       \
+    do {                                                                                                \
+        if (segk_tstamp_buf && (threadIdx.x & 63) == 0) *SEGK_TSTAMP_AT(kern, ph) = __builtin_amdgcn_s_memrealtime(); /* the last wave to finish writes last */ \
+    } while (0)
+static inline void segk_tstamp_bind()
+{
+    const char *e = getenv("SEGK_TSTAMP_PTR");
+    unsigned long long p = e ? strtoull(e, nullptr, 0) : 0ull;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(segk_tstamp_buf), &p, sizeof(p));
+}
+#else
+#define SEGK_TSTAMP(kern, ph) do { } while (0)
+#define SEGK_TSTAMP_MAX(kern, ph) do { } while (0)
+static inline void segk_tstamp_bind() {}
+#endif
+
 template <int P> struct SegkPiece;
 template <> struct SegkPiece<3> {
     typedef __bf16 T;

@@ -177,6 +177,7 @@ __global__ void k_kmeans_segment_w8(segk_corpus c, segk_kmeans m, const int32_t 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int slot = blockIdx.x * (blockDim.x >> 6) + wv;
+    SEGK_TSTAMP(0, 0);
     if (slot >= n_utts) return;
     const int u = utts ? utts[slot] : utt0 + slot;
     const int N = c.lengths[u];
@@ -221,9 +222,11 @@ __global__ void k_kmeans_segment_w8(segk_corpus c, segk_kmeans m, const int32_t 
     }
     const unsigned long long oldb = __ballot(lane < N && gbnd[lane < N ? lane : 0] != 0);
     WAVE_SYNC();
+    SEGK_TSTAMP(0, 1);
     double total;
     seg_w8_wave(bvec, gam, bid, bk, vid, N, W, oldb, *m.K, l_old, l_new, l_newk, l_cnt, &total, lane);
     WAVE_SYNC();
+    SEGK_TSTAMP(0, 2);
     if (lane == 0) {
         out_total[u] = total;
         n_old[u] = l_cnt[0];
@@ -241,6 +244,7 @@ __global__ void k_kmeans_segment_w8(segk_corpus c, segk_kmeans m, const int32_t 
         if (j < nn) new_tok[(int64_t)u * c.N_max + j] = l_new[j];
         new_k[(int64_t)u * c.N_max + j] = j < nn ? l_newk[j] : -1;
     }
+    SEGK_TSTAMP_MAX(0, 3);
 }
 
 // The same with TWO utterances per wave (utterances of at most 32 landmarks): a launch over 10 000 utterances
@@ -599,6 +603,7 @@ int32_t segk_kmeans_segment(segk_ctx *ctx, const segk_corpus *c, const segk_kmea
         SEGK_LAUNCH_CHECK();
         return SEGK_OK;
     }
+    segk_tstamp_bind();
     if (n_slices_max >= 1 && n_slices_max <= 8 && c->N_max <= 64 && !(getenv("SEGK_SEGMENT_GENERIC") && atoi(getenv("SEGK_SEGMENT_GENERIC")))) {
         hipLaunchKernelGGL(k_kmeans_segment_w8, dim3((n_utts + waves - 1) / waves), dim3(64 * waves), lds, st, *c, *m, utts, utt0,
                            n_utts, n_slices_max, wip, *cand, boundaries, old_tok, new_tok, new_k, n_old, n_new, n_flag,

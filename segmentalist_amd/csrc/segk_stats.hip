@@ -409,6 +409,7 @@ __device__ __forceinline__ void dev_batch_sort(const segk_corpus &c, const segk_
     const int per = ((S + NW - 1) / NW + 63) & ~63;              // slots per wave, whole chunks of 64
     int nbits = 1;
     while ((1 << nbits) < K_max) nbits++;
+    SEGK_TSTAMP(1, 0);
     for (int i = tid; i < NW * K_max; i += SORT_THREADS) cntw[i] = 0;
     // (P0) the block's keys into LDS: every load of a thread in flight together (flagged tokens and unused slots as -1)
     if (staged) {
@@ -426,6 +427,7 @@ __device__ __forceinline__ void dev_batch_sort(const segk_corpus &c, const segk_
         }
     }
     __syncthreads();
+    SEGK_TSTAMP(1, 1);
     auto key_at = [&](int s) -> int {
         if (staged) return keys[s];
         const int k = new_k[p0 + s];
@@ -441,6 +443,7 @@ __device__ __forceinline__ void dev_batch_sort(const segk_corpus &c, const segk_
         }
     }
     __syncthreads();
+    SEGK_TSTAMP(1, 2);
     // (P2) per component: the waves' counts -> running offsets; totals -> exclusive scan over the components
     // (K_max <= 8192: at most 8 slabs of 1024 components, thread t owns component 1024 q + t of slab q)
     int carry = 0;
@@ -481,6 +484,7 @@ __device__ __forceinline__ void dev_batch_sort(const segk_corpus &c, const segk_
         __syncthreads();
     }
     if (tid == 0) koff[K_max] = carry;
+    SEGK_TSTAMP(1, 3);
     // (P3) placement, stable: `sorted` receives the slot's offset in the block (its embedding row is new_tok[p0 + offset])
     if (wv < NW) {
         int32_t *mine = cntw + wv * K_max;
@@ -498,6 +502,7 @@ __device__ __forceinline__ void dev_batch_sort(const segk_corpus &c, const segk_
             }
         }
     }
+    SEGK_TSTAMP_MAX(1, 4);
 }
 
 // grid = 2 * n_blocks: workgroup b < n_blocks sorts block b; workgroup n_blocks + b lists the block's flagged
@@ -540,6 +545,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_batch_sort(
     const int b = blockIdx.x - n_blocks;
     const int u0 = blk_lo[b], u1 = blk_lo[b + 1];
     double *stage = reinterpret_cast<double *>(sort_lds);           // [2048]
+    SEGK_TSTAMP(1, 0);
     // ---- flagged tokens: rare (none once every component is active), so a plain ordered pass
     int32_t *fl = flags + (int64_t)b * 2 * segk_flag_words(cap);
     int nf = 0;
@@ -576,6 +582,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_batch_sort(
         }
     }
     if (tid == 0) { fl[0] = written; fl[1] = 0; }
+    SEGK_TSTAMP(1, 1);
     // ---- sequential (utterance order) sum of the block's totals, staged through LDS so that the single summing
     // thread never waits on global memory
     double s = 0.0;
@@ -597,6 +604,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_batch_sort(
         }
     }
     if (tid == 0) part_tot[b] = s;
+    SEGK_TSTAMP(1, 4);
 }
 
 // (1b) per (block, component) the sequential fp64 sum of its tokens in token order: one wave per pair, lanes own
@@ -612,11 +620,15 @@ __global__ __launch_bounds__(512) void k_batch_partials(segk_corpus c, segk_kmea
     const int b = blockIdx.x / groups, kg = blockIdx.x % groups;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int k = kg * 8 + wv;
+    SEGK_TSTAMP(2, 0);
     if (k >= m.K_max) return;
     const int D = c.D;
     const XT *X = (const XT *)c.X;
     const int32_t *koff = koff_all + (int64_t)b * (m.K_max + 1);
     const int q_lo = koff[k], nm = koff[k + 1] - q_lo;
+#ifdef SEGK_STAMP
+    if (segk_tstamp_buf && lane == 0 && (unsigned long long)nm > *SEGK_TSTAMP_AT(2, 2)) *SEGK_TSTAMP_AT(2, 2) = (unsigned long long)nm;
+#endif
     const int64_t p0 = (int64_t)blk_lo[b] * c.N_max;
     const int32_t *list = sorted + p0 + q_lo;           // slot offsets inside the block, (component, token) order
     const int32_t *tok = new_tok + p0;
@@ -652,6 +664,7 @@ __global__ __launch_bounds__(512) void k_batch_partials(segk_corpus c, segk_kmea
         }
     }
     if (lane == 0) part_cnt[(int64_t)b * m.K_max + k] = nm;
+    SEGK_TSTAMP_MAX(2, 1);
 }
 
 // Record of block b inside the all-gathered buffer: `nbl` blocks per rank, ranks `rank_stride` words apart.
@@ -720,6 +733,7 @@ __global__ __launch_bounds__(256) void k_batch_finalize(
     const int Kb = (int)out_scalars[3];            // K before the sweep (k_batch_sort); *m.K is rewritten by workgroup 0
     const int wg = blockIdx.x;
     const int j0 = wg * FIN_ROWS;
+    SEGK_TSTAMP(3, 0);          // (a second stamp in this kernel and the compiler dies: "Illegal instruction detected")
 
     // ---- (0a) combined counts of the un-flagged tokens (labels < Kb): every load of a thread issued before the first use
     long long csum = 0;
@@ -962,14 +976,17 @@ __global__ __launch_bounds__(256) void k_batch_post(segk_corpus c, segk_kmeans m
             const int k = new_k[p0 + idx];
             if (k >= 0) new_k[p0 + idx] = remap[k];
         }
+        SEGK_TSTAMP_MAX(4, 4);
         return;
     }
     const int tile = blockIdx.x;
+    SEGK_TSTAMP(4, 0);
     if constexpr (P != 0) {
         if (tiles_sp)
             dev_prepare_sp_tile<P>((const float *)m.means, m.K_max, c.D, tiles_sp, m.mnorm_max, (const unsigned char *)c.Xb3,
                                    (const double *)nullptr, tile);
     }
+    SEGK_TSTAMP(4, 1);
     if (!row_hash) return;
     // clean_components leaves exact copies behind (the moved rows, the inactive rows): a duplicate with the higher
     // index can never be np.argmax, but every embedding near the pair is a tie for the full scan -- its accumulator
@@ -977,6 +994,7 @@ __global__ __launch_bounds__(256) void k_batch_post(segk_corpus c, segk_kmeans m
     __shared__ unsigned long long keys[SEGK_DUP_TB];
     __shared__ int32_t first[SEGK_DUP_TB];
     dev_dup_table(keys, first, row_hash, m.K_max);            // ends with a barrier: the constants above are written
+    SEGK_TSTAMP(4, 2);
     const XT *means = (const XT *)m.means;
     const int tid = threadIdx.x, sub = tid & 7, D = c.D;
     const int k = tile * 32 + (tid >> 3);
@@ -997,6 +1015,7 @@ __global__ __launch_bounds__(256) void k_batch_post(segk_corpus c, segk_kmeans m
         m.tiles[(int64_t)tile * stride32 + G * 128 + (k & 31)] = -3.0e38f;
         if (tiles_sp) tiles_sp[1024 + (int64_t)tile * stride_sp + sp_const_off + (k & 31)] = -3.0e38f;
     }
+    SEGK_TSTAMP_MAX(4, 3);
 }
 
 // `assignments` from the token lists of utterances [lo, hi) (everything else unassigned):
@@ -1141,6 +1160,7 @@ int segk_launch_batch_sort(const segk_corpus *c, const segk_kmeans *m, const int
         SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_batch_sort, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         lds_set = lds;
     }
+    segk_tstamp_bind();
     // out_total == NULL: the sort alone (no flag lists, no totals: the second half of the grid is not launched)
     hipLaunchKernelGGL(k_batch_sort, dim3((unsigned)((out_total ? 2 : 1) * n_blocks)), dim3(SORT_THREADS), lds, st, *c, *m, blk_lo,
                        n_blocks, new_tok, new_k, n_flag, out_total, sorted, koff, part_tot, flags, cap, out_scalars);
