@@ -46,7 +46,7 @@ const char *segk_last_error(void);
  * header describes; a binding must refuse a library that reports another one: segmentalist_amd/_abi.py does).
  *   1 rounds 1-2 | 2 round 2: segk_corpus gained band_W / band_ids / band_dur (the bump was forgotten then)
  *   3 round 3: segk_fbb_set_probe, segk_kmeans_score_hinted; this check                                                           */
-#define SEGK_ABI_VERSION 3
+#define SEGK_ABI_VERSION 4
 int32_t segk_abi_version(void);
 
 /* Timing of the MAIN launch of the MFMA score kernel (k_kmeans_score<..., 0>) with HIP events
@@ -313,8 +313,9 @@ int32_t segk_kmeans_sequential_sweep(segk_ctx *ctx, const segk_corpus *c, segk_k
  *      blk_lo [dev] int32 [n_blocks_local + 1]) the sequential fp64 sum of its tokens per component, in
  *      token order (utterance, segment), read from the slot arrays new_tok / new_k [dev] int32
  *      [n_utt, N_max] as segk_kmeans_segment leaves them (unused slots: k = -1): a stable counting sort
- *      of the block's tokens by component (sorted_scratch [dev] int32 [n_utt * N_max], koff_scratch
- *      [dev] int32 [n_blocks_local * (K_max + 1)]), then one sequential sum per (block, component);
+ *      of the block's tokens by component (sorted_scratch [dev] int32 [n_utt * N_max * ceil(K_max / 128)]: one region per
+ *      (block, range of 128 components); koff_scratch [dev] int32 [n_blocks_local * K_max * 2]: {offset, length} of every
+ *      (block, component) list -- ABI version 4), then one sequential sum per (block, component);
  *      part_tot = sum of out_total in utterance order.  Tokens whose argmax is an inactive row (k >= K;
  *      n_flag [dev] int32 [n_utt] counts them per utterance) are listed instead, in token order.
  *      Writes out_scalars[3] = K (before the sweep) and zeroes m->mnorm_max for (2).

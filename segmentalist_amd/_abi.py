@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsegk.so")
 
 SEGK_F32, SEGK_F64 = 0, 1
-ABI_VERSION = 3          # SEGK_ABI_VERSION of include/segk.h this binding was written against
+ABI_VERSION = 4          # SEGK_ABI_VERSION of include/segk.h this binding was written against
 
 
 class SegkError(RuntimeError):

@@ -309,9 +309,11 @@ static __device__ unsigned long long segk_tstamp_buf;           // the address a
     } while (0)
 static inline void segk_tstamp_bind()
 {
+    static unsigned long long bound = ~0ull;       // (hipMemcpyToSymbol synchronises: only when the address changes)
     const char *e = getenv("SEGK_TSTAMP_PTR");
     unsigned long long p = e ? strtoull(e, nullptr, 0) : 0ull;
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(segk_tstamp_buf), &p, sizeof(p));
+    if (p != bound) (void)hipMemcpyToSymbol(HIP_SYMBOL(segk_tstamp_buf), &p, sizeof(p));
+    bound = p;
 }
 #else
 #define SEGK_TSTAMP(kern, ph) do { } while (0)
@@ -608,13 +610,29 @@ __device__ __forceinline__ void dev_prepare_sp_tile(const float *means, int K_ma
     float *Tt = tiles + 1024 + (int64_t)tile * stride;
     T *Tb = (T *)Tt;
     __shared__ double nrm[32];
+    // the tile's 32 rows (contiguous in `means`) into LDS first: coalesced loads, all in flight -- read in place, the image
+    // loop below fetched one element per lane from 32 different rows per instruction, 14 dependent rounds (8 of the post
+    // kernel's 14 us)
+    constexpr int PITCH = 129;                                       // odd pitch: the 32 rows of a lane group on 32 banks
+    __shared__ float rowsl[32 * PITCH];
+    const bool staged = D <= 128;                                    // (wider rows -- the FBGMM span-score images -- are read in place)
+    const float *src = means + (int64_t)tile * 32 * D;
+    if (staged) {
+        const int nrow = K_max - tile * 32 < 32 ? K_max - tile * 32 : 32;
+        for (int idx = threadIdx.x; idx < 32 * D; idx += blockDim.x) {
+            const int ci = idx / D, d = idx - ci * D;
+            rowsl[ci * PITCH + d] = ci < nrow ? src[idx] : 0.f;
+        }
+    }
+    __syncthreads();
+    auto elem = [&](int ci, int d) -> float { return staged ? rowsl[ci * PITCH + d] : src[(int64_t)ci * D + d]; };   // live rows only
     {
         const int ci = threadIdx.x >> 3, sub = threadIdx.x & 7;      // 256 threads = 32 x 8
         const int comp = tile * 32 + ci;
         double s = 0.0, rs = 0.0;
         if (comp < K_max)
             for (int d = sub; d < D; d += 8) {
-                const float mv = means[(int64_t)comp * D + d];
+                const float mv = elem(ci, d);
                 double v = (double)mv;
                 s += v * v;
                 if (P == 2) rs += sp_resid2(ldexpf(mv, eb));
@@ -632,15 +650,23 @@ __device__ __forceinline__ void dev_prepare_sp_tile(const float *means, int K_ma
         }
     }
     __syncthreads();
-    for (int idx = threadIdx.x; idx < KS * 64 * 8; idx += blockDim.x) {
-        const int sidx = idx >> 9, lane = (idx >> 3) & 63, i = idx & 7;
-        const int comp = tile * 32 + (lane & 31);
-        const int d = segk_b3_dim(16 * sidx + 8 * (lane >> 5) + i);
-        const float v = (comp < K_max && d < D) ? ldexpf(means[(int64_t)comp * D + d], eb) : 0.f;
-        T pc[P];
-        split_sp<P>(v, pc);
+    // one (k-step, lane) fragment per thread and trip: its eight elements split into pieces, one 16-byte store per piece
+    for (int pr = threadIdx.x; pr < KS * 64; pr += blockDim.x) {
+        const int sidx = pr >> 6, lane = pr & 63;
+        const int ci = lane & 31;
+        const bool live = tile * 32 + ci < K_max;
+        typename SegkPiece<P>::V8 out[P];
 #pragma unroll
-        for (int q = 0; q < P; q++) Tb[((sidx * P + q) * 64 + lane) * 8 + i] = pc[q];
+        for (int i = 0; i < 8; i++) {
+            const int d = segk_b3_dim(16 * sidx + 8 * (lane >> 5) + i);
+            const float v = (live && d < D) ? ldexpf(elem(ci, d), eb) : 0.f;
+            T pc[P];
+            split_sp<P>(v, pc);
+#pragma unroll
+            for (int q = 0; q < P; q++) out[q][i] = pc[q];
+        }
+#pragma unroll
+        for (int q = 0; q < P; q++) *reinterpret_cast<typename SegkPiece<P>::V8 *>(Tb + ((sidx * P + q) * 64 + lane) * 8) = out[q];
     }
     for (int idx = threadIdx.x; idx < stride - KS * P * 256; idx += blockDim.x) {
         float v = 0.f;

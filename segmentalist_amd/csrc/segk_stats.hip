@@ -607,14 +607,224 @@ __global__ __launch_bounds__(SORT_THREADS) void k_batch_sort(
     SEGK_TSTAMP(1, 4);
 }
 
+// ======================================================================================
+// (1a') k_batch_sort_ranges (round 3): the same stable counting sort, spread over the chip.  The one-workgroup-per-block form
+//      spends 20 of its 29 us in the placement pass -- sixteen waves on one CU, every chunk of 64 slots a ten-ballot key
+//      match -- while 248 CUs idle.  Here a block is sorted by NR + 2 workgroups: workgroup (b, r < NR) owns the
+//      components [128 r, 128 r + 128) and a region of its own in `sorted` (S_b entries: whatever the split of the tokens
+//      over the ranges, a region cannot overflow), so nothing crosses workgroups: every wave compacts the in-range tokens of
+//      its run of slots into LDS (ballot + prefix count, order kept), counts them per component, and the placement pass
+//      walks the compacted list -- an eighth of the tokens, seven key bits.  Workgroup (b, NR) lists the flagged tokens
+//      (argmax on an inactive row) in token order with the same compaction; workgroup (b, NR + 1) sums the block's totals.
+//      koff2[b][k] = {offset of component k's list inside its range's region, length}.
+// ======================================================================================
+#define SORT_RS 128                  /* components per range */
+#define SORT_CL 2048                 /* compacted entries per wave kept in LDS: blocks of up to 16 * 2048 slots; larger ones
+                                        walk all their slots again in the placement pass                                   */
+static inline __host__ __device__ int segk_sort_ranges(int K_max) { return (K_max + SORT_RS - 1) / SORT_RS; }
+
+__global__ __launch_bounds__(SORT_THREADS) void k_batch_sort_ranges(
+    segk_corpus c, segk_kmeans m, const int32_t *blk_lo, int n_blocks, const int32_t *new_tok, const int32_t *new_k,
+    const double *out_total, int32_t *sorted, int32_t *koff2, double *part_tot, int32_t *flags, int cap, double *out_scalars, int NR)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char sort_lds[];
+    __shared__ int32_t wcount[16], wscan[2];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int Kb = *m.K;                          // active components before the sweep: k >= Kb is a flagged token
+    const int K_max = m.K_max;
+    const int b = blockIdx.x / (NR + 2), r = blockIdx.x % (NR + 2);
+    const int u0 = blk_lo[b], u1 = blk_lo[b + 1];
+    SEGK_TSTAMP(1, 0);
+    if (r == NR + 1) {
+        if (b == 0 && tid == 0) {
+            *(double *)m.mnorm_max = 0.0;         // max |m|^2 of the finalize kernel's prepare
+            out_scalars[3] = (double)Kb;          // the finalize kernel's workgroups read K from here: one of them rewrites *m.K
+        }
+        // ---- sequential (utterance order) sum of the block's totals, staged through LDS so that the single summing
+        // thread never waits on global memory
+        double *stage = reinterpret_cast<double *>(sort_lds);           // [2048]
+        double s = 0.0;
+        for (int uc = u0; uc < u1; uc += 2048) {
+            const int nu = u1 - uc < 2048 ? u1 - uc : 2048;
+            __syncthreads();
+            for (int i = tid; i < nu; i += SORT_THREADS) stage[i] = out_total[uc + i];
+            __syncthreads();
+            if (tid == 0) {
+                int i = 0;
+                for (; i + 16 <= nu; i += 16) {       // strictly sequential adds; the LDS reads are issued 16 at a time
+                    double v[16];
+#pragma unroll
+                    for (int q = 0; q < 16; q++) v[q] = stage[i + q];
+#pragma unroll
+                    for (int q = 0; q < 16; q++) s += v[q];
+                }
+                for (; i < nu; i++) s += stage[i];
+            }
+        }
+        if (tid == 0) part_tot[b] = s;
+        SEGK_TSTAMP(1, 4);
+        return;
+    }
+    const bool flg = r == NR;
+    const int64_t p0 = (int64_t)u0 * c.N_max;
+    const int S = (u1 - u0) * c.N_max;
+    const int per = ((S + 15) / 16 + 63) & ~63;                  // slots per wave, whole chunks of 64
+    const bool compact = per <= SORT_CL;
+    int32_t *cntw = reinterpret_cast<int32_t *>(sort_lds);       // [16][SORT_RS]
+    int32_t *base = cntw + 16 * SORT_RS;                         // [SORT_RS]
+    uint32_t *cl = reinterpret_cast<uint32_t *>(base + SORT_RS) + (size_t)wv * SORT_CL;      // this wave's compacted entries
+    const int32_t *keys = new_k + (S > 0 ? p0 : 0);            // (an empty block at the end of the corpus: nothing is read)
+    const int s0 = wv * per < S ? wv * per : S, s1 = s0 + per < S ? s0 + per : S;
+    auto in_range = [&](int k) -> bool { return flg ? k >= Kb : (k >= 0 && k < Kb && (k >> 7) == r); };
+    for (int i = tid; i < 16 * SORT_RS; i += SORT_THREADS) cntw[i] = 0;
+    int n_mine = 0;                                              // wave-uniform: in-range tokens of this wave's run
+    if (compact) {
+        // (P1) every key of the run fetched up front (unconditional loads, clamped index), then compacted in order
+        constexpr int NC = SORT_CL / 64;
+        int v[NC];
+#pragma unroll
+        for (int q = 0; q < NC; q++) {
+            const int sidx = s0 + q * 64 + lane;
+            v[q] = keys[sidx < s1 ? sidx : (S > 0 ? S - 1 : 0)];
+        }
+        __syncthreads();                                         // the zeroed counters
+#pragma unroll
+        for (int q = 0; q < NC; q++) {
+            const int sidx = s0 + q * 64 + lane;
+            const int k = sidx < s1 ? v[q] : -1;
+            const bool in = sidx < s1 && in_range(k);
+            const unsigned long long bal = __ballot(in);
+            if (in) {
+                cl[n_mine + __popcll(bal & ((1ull << lane) - 1ull))] = ((unsigned int)sidx << 7) | (unsigned int)(k & (SORT_RS - 1));
+                if (!flg) atomicAdd(&cntw[wv * SORT_RS + (k & (SORT_RS - 1))], 1);
+            }
+            n_mine += __popcll(bal);
+        }
+    } else {
+        __syncthreads();
+        for (int sb = s0; sb < s1; sb += 64) {
+            const int sidx = sb + lane;
+            const int k = sidx < s1 ? keys[sidx] : -1;
+            const bool in = sidx < s1 && in_range(k);
+            if (in && !flg) atomicAdd(&cntw[wv * SORT_RS + (k & (SORT_RS - 1))], 1);
+            n_mine += __popcll(__ballot(in));
+        }
+    }
+    if (lane == 0) wcount[wv] = n_mine;
+    __syncthreads();
+    SEGK_TSTAMP(1, 2);
+    // item i of this wave's in-range tokens, in order: from the compacted list, or (large blocks) by walking the run again
+    if (flg) {
+        // ---- the flagged tokens, in token order: {count, 0, (slot, k, row) x cap}
+        int32_t *fl = flags + (int64_t)b * 2 * segk_flag_words(cap);
+        int off = 0, tot = 0;
+        for (int w = 0; w < 16; w++) {
+            if (w < wv) off += wcount[w];
+            tot += wcount[w];
+        }
+        if (tid == 0) { fl[0] = tot; fl[1] = 0; }
+        if (compact) {
+            for (int i = lane; i < n_mine; i += 64) {
+                const int sidx = (int)(cl[i] >> 7);
+                if (off + i < cap) {
+                    fl[2 + 3 * (off + i) + 0] = (int32_t)(p0 + sidx);
+                    fl[2 + 3 * (off + i) + 1] = keys[sidx];
+                    fl[2 + 3 * (off + i) + 2] = new_tok[p0 + sidx];
+                }
+            }
+        } else {
+            int done = 0;
+            for (int sb = s0; sb < s1 && done < n_mine; sb += 64) {
+                const int sidx = sb + lane;
+                const int k = sidx < s1 ? keys[sidx] : -1;
+                const bool in = sidx < s1 && k >= Kb;
+                const unsigned long long bal = __ballot(in);
+                const int at = off + done + __popcll(bal & ((1ull << lane) - 1ull));
+                if (in && at < cap) {
+                    fl[2 + 3 * at + 0] = (int32_t)(p0 + sidx);
+                    fl[2 + 3 * at + 1] = k;
+                    fl[2 + 3 * at + 2] = new_tok[p0 + sidx];
+                }
+                done += __popcll(bal);
+            }
+        }
+        SEGK_TSTAMP_MAX(1, 4);
+        return;
+    }
+    // (P2) per component of the range: the waves' counts -> running offsets; totals -> exclusive scan over the range
+    int run = 0, incl = 0;
+    if (tid < SORT_RS) {
+        int t[16];
+#pragma unroll
+        for (int w = 0; w < 16; w++) t[w] = cntw[w * SORT_RS + tid];
+#pragma unroll
+        for (int w = 0; w < 16; w++) {
+            cntw[w * SORT_RS + tid] = run;
+            run += t[w];
+        }
+        incl = run;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t2 = __shfl_up(incl, o);
+            if (lane >= o) incl += t2;
+        }
+        if (lane == 63) wscan[wv] = incl;
+    }
+    __syncthreads();
+    if (tid < SORT_RS) {
+        const int ex = (wv == 1 ? wscan[0] : 0) + incl - run;
+        base[tid] = ex;
+        const int k = r * SORT_RS + tid;
+        if (k < K_max) {
+            koff2[((int64_t)b * K_max + k) * 2 + 0] = ex;
+            koff2[((int64_t)b * K_max + k) * 2 + 1] = run;
+        }
+    }
+    __syncthreads();
+    SEGK_TSTAMP(1, 3);
+    // (P3) placement, stable: `sorted` receives the slot's offset in the block (its embedding row is new_tok[p0 + offset])
+    int32_t *region = sorted + p0 * NR + (int64_t)r * S;
+    int32_t *mine = cntw + wv * SORT_RS;
+    if (compact) {
+        for (int ib = 0; ib < n_mine; ib += 64) {
+            const int i = ib + lane;
+            const bool ok = i < n_mine;
+            const unsigned int e = ok ? cl[i] : 0u;
+            const int kk = (int)(e & (SORT_RS - 1));
+            const unsigned long long same = dev_match_key(kk, ok, 7);
+            if (ok) {
+                const int rank = __popcll(same & ((1ull << lane) - 1ull));
+                const int before = mine[kk];
+                region[base[kk] + before + rank] = (int32_t)(e >> 7);
+                if (rank == __popcll(same) - 1) mine[kk] = before + rank + 1;       // the last of its component in the chunk
+            }
+        }
+    } else {
+        for (int sb = s0; sb < s1; sb += 64) {
+            const int sidx = sb + lane;
+            const int k = sidx < s1 ? keys[sidx] : -1;
+            const bool ok = sidx < s1 && in_range(k);
+            if (__ballot(ok) == 0ull) continue;
+            const int kk = k & (SORT_RS - 1);
+            const unsigned long long same = dev_match_key(kk, ok, 7);
+            if (ok) {
+                const int rank = __popcll(same & ((1ull << lane) - 1ull));
+                const int before = mine[kk];
+                region[base[kk] + before + rank] = sidx;
+                if (rank == __popcll(same) - 1) mine[kk] = before + rank + 1;
+            }
+        }
+    }
+    SEGK_TSTAMP_MAX(1, 4);
+}
+
 // (1b) per (block, component) the sequential fp64 sum of its tokens in token order: one wave per pair, lanes own
 //      dimensions; the token rows are fetched 16 at a time (unconditional loads, clamped index, select after the
 //      load: all 16 in flight together) and added strictly in order.
 #define PART_BATCH 16
 template <typename XT>
 __global__ __launch_bounds__(512) void k_batch_partials(segk_corpus c, segk_kmeans m, const int32_t *blk_lo, int n_blocks,
-                                                        const int32_t *new_tok, const int32_t *sorted, const int32_t *koff_all,
-                                                        double *part_sum, int64_t *part_cnt)
+                                                        const int32_t *new_tok, const int32_t *sorted, const int32_t *koff2,
+                                                        double *part_sum, int64_t *part_cnt, int NR)
 {
     const int groups = (m.K_max + 7) / 8;
     const int b = blockIdx.x / groups, kg = blockIdx.x % groups;
@@ -624,13 +834,14 @@ __global__ __launch_bounds__(512) void k_batch_partials(segk_corpus c, segk_kmea
     if (k >= m.K_max) return;
     const int D = c.D;
     const XT *X = (const XT *)c.X;
-    const int32_t *koff = koff_all + (int64_t)b * (m.K_max + 1);
-    const int q_lo = koff[k], nm = koff[k + 1] - q_lo;
+    const int2 on = *reinterpret_cast<const int2 *>(koff2 + ((int64_t)b * m.K_max + k) * 2);
+    const int nm = on.y;
 #ifdef SEGK_STAMP
     if (segk_tstamp_buf && lane == 0 && (unsigned long long)nm > *SEGK_TSTAMP_AT(2, 2)) *SEGK_TSTAMP_AT(2, 2) = (unsigned long long)nm;
 #endif
     const int64_t p0 = (int64_t)blk_lo[b] * c.N_max;
-    const int32_t *list = sorted + p0 + q_lo;           // slot offsets inside the block, (component, token) order
+    const int S = (blk_lo[b + 1] - blk_lo[b]) * c.N_max;
+    const int32_t *list = sorted + p0 * NR + (int64_t)(k >> 7) * S + on.x;      // slot offsets inside the block, token order
     const int32_t *tok = new_tok + p0;
     constexpr int MAXR = 2;                       // 128 dims per pass over the tokens
     for (int d0 = 0; d0 < D; d0 += 64 * MAXR) {
@@ -642,19 +853,34 @@ __global__ __launch_bounds__(512) void k_batch_partials(segk_corpus c, segk_kmea
             const int d = d0 + r * 64 + lane;
             dcl[r] = d < D ? d : 0;
         }
-        for (int q0 = 0; q0 < nm; q0 += PART_BATCH) {
-            double xv[PART_BATCH][MAXR];
+        // 64 tokens at a time: lane q fetches the row index of token c0 + q (two dependent loads for all 64 together); the
+        // rows are then fetched 16 at a time, the next 16 in flight while the current 16 are added strictly in order
+        for (int c0 = 0; c0 < nm; c0 += 64) {
+            const int mine = c0 + lane < nm ? tok[list[c0 + lane]] : 0;
+            const int nb = nm - c0 < 64 ? nm - c0 : 64;
+            XT xv[2][PART_BATCH][MAXR];
+            auto fetch = [&](int buf, int q0) {
 #pragma unroll
-            for (int q = 0; q < PART_BATCH; q++) {
-                const int e = tok[list[q0 + q < nm ? q0 + q : q0]];  // clamped: always valid
+                for (int q = 0; q < PART_BATCH; q++) {
+                    const int e = __shfl(mine, q0 + q < nb ? q0 + q : 0);      // clamped: always a valid row
 #pragma unroll
-                for (int r = 0; r < MAXR; r++) xv[q][r] = (double)X[(int64_t)e * c.ldx + dcl[r]];
-            }
+                    for (int r = 0; r < MAXR; r++) xv[buf][q][r] = X[(int64_t)e * c.ldx + dcl[r]];
+                }
+            };
+            auto add = [&](int buf, int q0) {
 #pragma unroll
-            for (int q = 0; q < PART_BATCH; q++) {
-                const bool ok = q0 + q < nm;
+                for (int q = 0; q < PART_BATCH; q++) {
+                    const bool ok = q0 + q < nb;
 #pragma unroll
-                for (int r = 0; r < MAXR; r++) acc[r] += ok ? xv[q][r] : 0.0;
+                    for (int r = 0; r < MAXR; r++) acc[r] += ok ? (double)xv[buf][q][r] : 0.0;
+                }
+            };
+            fetch(0, 0);
+            for (int q0 = 0; q0 < nb; q0 += 2 * PART_BATCH) {
+                if (q0 + PART_BATCH < nb) fetch(1, q0 + PART_BATCH);
+                add(0, q0);
+                if (q0 + 2 * PART_BATCH < nb) fetch(0, q0 + 2 * PART_BATCH);
+                if (q0 + PART_BATCH < nb) add(1, q0 + PART_BATCH);
             }
         }
 #pragma unroll
@@ -725,15 +951,19 @@ __global__ __launch_bounds__(256) void k_batch_finalize(
     __shared__ long long red[4];
     const PackAddr pa{nbl, K_max, D, cap, rank_stride};
     // flagged token q of the sweep: the first SEGK_FLAG_LDS in LDS, the others in ovf [4][ovf_cap] (slot, row, k, block)
-    auto FL_SLOT = [&](int q) -> int { return q < SEGK_FLAG_LDS ? fl_slot[q] : ovf[q - SEGK_FLAG_LDS]; };
-    auto FL_ROW = [&](int q) -> int { return q < SEGK_FLAG_LDS ? fl_row[q] : ovf[(int64_t)ovf_cap + q - SEGK_FLAG_LDS]; };
-    auto FL_K = [&](int q) -> int { return q < SEGK_FLAG_LDS ? (int)fl_k[q] : ovf[2 * (int64_t)ovf_cap + q - SEGK_FLAG_LDS]; };
-    auto FL_BLK = [&](int q) -> int { return q < SEGK_FLAG_LDS ? (int)fl_blk[q] : ovf[3 * (int64_t)ovf_cap + q - SEGK_FLAG_LDS]; };
+    // (the overflow arrays through an explicitly global pointer: left generic, the compiler merges the two sources of an accessor
+    // into one flat pointer, and the LDS-aperture test it then needs does not always survive instruction selection)
+    typedef __attribute__((address_space(1))) int32_t gi32;
+    gi32 *ovg = (gi32 *)(uintptr_t)ovf;
+    auto FL_SLOT = [&](int q) -> int { return q < SEGK_FLAG_LDS ? fl_slot[q] : ovg[q - SEGK_FLAG_LDS]; };
+    auto FL_ROW = [&](int q) -> int { return q < SEGK_FLAG_LDS ? fl_row[q] : ovg[(int64_t)ovf_cap + q - SEGK_FLAG_LDS]; };
+    auto FL_K = [&](int q) -> int { return q < SEGK_FLAG_LDS ? (int)fl_k[q] : ovg[2 * (int64_t)ovf_cap + q - SEGK_FLAG_LDS]; };
+    auto FL_BLK = [&](int q) -> int { return q < SEGK_FLAG_LDS ? (int)fl_blk[q] : ovg[3 * (int64_t)ovf_cap + q - SEGK_FLAG_LDS]; };
     const int64_t *packi = reinterpret_cast<const int64_t *>(pack);
     const int Kb = (int)out_scalars[3];            // K before the sweep (k_batch_sort); *m.K is rewritten by workgroup 0
     const int wg = blockIdx.x;
     const int j0 = wg * FIN_ROWS;
-    SEGK_TSTAMP(3, 0);          // (a second stamp in this kernel and the compiler dies: "Illegal instruction detected")
+    SEGK_TSTAMP(3, 0);
 
     // ---- (0a) combined counts of the un-flagged tokens (labels < Kb): every load of a thread issued before the first use
     long long csum = 0;
@@ -772,6 +1002,7 @@ __global__ __launch_bounds__(256) void k_batch_finalize(
     for (int o = 32; o > 0; o >>= 1) csum += __shfl_xor(csum, o);
     if (lane == 0) red[wv] = csum;
     __syncthreads();
+    SEGK_TSTAMP(3, 1);
     if (tid == 0) {
         int K = Kb, nf = 0, over = 0;
         for (int b = 0; b < n_blocks; b++) {
@@ -790,10 +1021,10 @@ __global__ __launch_bounds__(256) void k_batch_finalize(
                     nf++;
                 } else if (ovf && nf - SEGK_FLAG_LDS < ovf_cap) {
                     const int o = nf - SEGK_FLAG_LDS;
-                    ovf[o] = fl[2 + 3 * q + 0];
-                    ovf[(int64_t)ovf_cap + o] = fl[2 + 3 * q + 2];
-                    ovf[2 * (int64_t)ovf_cap + o] = k;
-                    ovf[3 * (int64_t)ovf_cap + o] = b;
+                    ovg[o] = fl[2 + 3 * q + 0];
+                    ovg[(int64_t)ovf_cap + o] = fl[2 + 3 * q + 2];
+                    ovg[2 * (int64_t)ovf_cap + o] = k;
+                    ovg[3 * (int64_t)ovf_cap + o] = b;
                     nf++;
                 } else {
                     over = 1;
@@ -806,6 +1037,7 @@ __global__ __launch_bounds__(256) void k_batch_finalize(
         if (nf > SEGK_FLAG_LDS) __threadfence();      // the overflow entries are read back by the other threads below
     }
     __syncthreads();
+    SEGK_TSTAMP(3, 2);
     const int K1 = shK1, nfl = n_fl;
     for (int q = tid; q < nfl; q += nt) atomicAdd(&cnt32[FL_K(q)], 1);
     const long long n_tokens = red[0] + red[1] + red[2] + red[3] + nfl;
@@ -837,10 +1069,12 @@ __global__ __launch_bounds__(256) void k_batch_finalize(
         n_holes = nh;
     }
     __syncthreads();
+    SEGK_TSTAMP(3, 3);
     const int K = shK;
 
-    // ---- workgroup 0 publishes the scalars, the relabel table and the resolved labels of the local flagged tokens
-    if (wg == 0) {
+    // ---- the LAST workgroup (it has no rows of its own: as part of workgroup 0 this was 4 us on the kernel's critical path)
+    // publishes the scalars, the relabel table and the resolved labels of the local flagged tokens
+    if (wg == (int)gridDim.x - 1) {
         for (int k = tid; k < K_max; k += nt) remap[k] = k;
         __syncthreads();
         for (int h = tid; h < n_holes; h += nt) {
@@ -859,10 +1093,12 @@ __global__ __launch_bounds__(256) void k_batch_finalize(
             *m.K = K;
             if (sp_zero_slot) *sp_zero_slot = 0u;          // E_m of the fp16 tile image: k_batch_post's atomic maximum
         }
+        return;
     }
 
     // ---- (1) this workgroup's final rows, one element (row, dimension) per thread and step; the loads of four steps
     // (32 with the default eight blocks) are issued together
+    SEGK_TSTAMP(3, 4);
     XT *__restrict__ means = (XT *)m.means;
     double *__restrict__ numer = m.mean_numerators;
     const XT *__restrict__ rnd = (const XT *)m.random_means;
@@ -930,6 +1166,7 @@ __global__ __launch_bounds__(256) void k_batch_finalize(
         if (j < K_max) m.counts[j] = j < K ? (int64_t)cnt32[pos2orig[j]] : 0;
     }
     __syncthreads();
+    SEGK_TSTAMP(3, 5);
     // ---- (2) this workgroup's part of the fp32 MFMA image (layout: segk_internal.h; the padding of the image -- dimensions
     // beyond D, components beyond K_max -- never changes after segk_kmeans_prepare), |m|^2 maximum, row hashes: the
     // arithmetic of dev_prepare_tile, 8 lanes per component
@@ -961,6 +1198,7 @@ __global__ __launch_bounds__(256) void k_batch_finalize(
         const int r = e / D, d = e - r * D, comp = j0 + r;
         if (comp < K_max) T[(d >> 2) * 128 + ((((d >> 1) & 1) * 32 + (comp & 31)) << 1) + (d & 1)] = (float)mrow[e];
     }
+    SEGK_TSTAMP(3, 6);
 }
 
 // final labels of the local tokens + (tile workgroups) split-precision image and duplicate marking
@@ -1290,12 +1528,22 @@ int32_t segk_kmeans_batch_partials(segk_ctx *ctx, const segk_corpus *c, const se
     int64_t *part_cnt = reinterpret_cast<int64_t *>(record + nbl * KD + nbl);
     int32_t *flags = reinterpret_cast<int32_t *>(record + nbl * KD + nbl + nbl * m->K_max);
     hipStream_t st = (hipStream_t)stream;
-    if (int rc2 = segk_launch_batch_sort(c, m, blk_lo, n_blocks_local, new_tok, new_k, n_flag, out_total, sorted_scratch, koff_scratch,
-                                         part_tot, flags, flag_cap, out_scalars, st))
-        return rc2;
+    (void)n_flag;
+    segk_tstamp_bind();
+    const int NR = segk_sort_ranges(m->K_max);
+    {
+        const size_t lds = (size_t)(16 * SORT_RS + SORT_RS) * 4 + (size_t)16 * SORT_CL * 4;
+        static bool lds_set = false;
+        if (!lds_set) SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_batch_sort_ranges, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        lds_set = true;
+        hipLaunchKernelGGL(k_batch_sort_ranges, dim3((unsigned)(nbl * (NR + 2))), dim3(SORT_THREADS), lds, st, *c, *m, blk_lo,
+                           n_blocks_local, new_tok, new_k, out_total, sorted_scratch, koff_scratch, part_tot, flags, flag_cap,
+                           out_scalars, NR);
+        SEGK_LAUNCH_CHECK();
+    }
     const int64_t grid = nbl * ((m->K_max + 7) / 8);
     DISPATCH_XT(c, hipLaunchKernelGGL(k_batch_partials<XT>, dim3((unsigned)grid), dim3(512), 0, st, *c, *m, blk_lo,
-                                       n_blocks_local, new_tok, sorted_scratch, koff_scratch, part_sum, part_cnt););
+                                       n_blocks_local, new_tok, sorted_scratch, koff_scratch, part_sum, part_cnt, NR););
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;
 }
@@ -1349,7 +1597,7 @@ int32_t segk_kmeans_batch_finalize(segk_ctx *ctx, const segk_corpus *c, segk_kme
     DISPATCH_XT(c, {
         if (lds > 32 * 1024)
             SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_batch_finalize<XT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_batch_finalize<XT>, dim3((m->K_max + FIN_ROWS - 1) / FIN_ROWS), dim3(256), lds, st, *c, *m, records,
+        hipLaunchKernelGGL(k_batch_finalize<XT>, dim3((m->K_max + FIN_ROWS - 1) / FIN_ROWS + 1), dim3(256), lds, st, *c, *m, records,
                            n_blocks_total, n_blocks_per_rank, rank_stride, flag_cap, my_rank, new_k, remap_scratch, out_scalars,
                            status, ctx && m->K_max <= 2048 ? ctx->row_hash : (unsigned long long *)nullptr,
                            sp ? (unsigned int *)m->tiles_b3 + 1 : (unsigned int *)nullptr, ovf, ovf_cap);
