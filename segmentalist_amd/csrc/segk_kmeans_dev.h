@@ -625,6 +625,7 @@ __device__ __forceinline__ void dev_prepare_sp_tile(const float *means, int K_ma
         }
     }
     __syncthreads();
+    SEGK_TSTAMP(4, 5);
     auto elem = [&](int ci, int d) -> float { return staged ? rowsl[ci * PITCH + d] : src[(int64_t)ci * D + d]; };   // live rows only
     {
         const int ci = threadIdx.x >> 3, sub = threadIdx.x & 7;      // 256 threads = 32 x 8
@@ -650,6 +651,7 @@ __device__ __forceinline__ void dev_prepare_sp_tile(const float *means, int K_ma
         }
     }
     __syncthreads();
+    SEGK_TSTAMP(4, 6);
     // one (k-step, lane) fragment per thread and trip: its eight elements split into pieces, one 16-byte store per piece
     for (int pr = threadIdx.x; pr < KS * 64; pr += blockDim.x) {
         const int sidx = pr >> 6, lane = pr & 63;

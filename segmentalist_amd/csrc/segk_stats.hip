@@ -781,7 +781,8 @@ __global__ __launch_bounds__(SORT_THREADS) void k_batch_sort_ranges(
     }
     __syncthreads();
     SEGK_TSTAMP(1, 3);
-    // (P3) placement, stable: `sorted` receives the slot's offset in the block (its embedding row is new_tok[p0 + offset])
+    // (P3) placement, stable: `sorted` receives the token's embedding row (new_tok of its slot), so that the summing kernel
+    // has one dependent load less per list
     int32_t *region = sorted + p0 * NR + (int64_t)r * S;
     int32_t *mine = cntw + wv * SORT_RS;
     if (compact) {
@@ -790,11 +791,12 @@ __global__ __launch_bounds__(SORT_THREADS) void k_batch_sort_ranges(
             const bool ok = i < n_mine;
             const unsigned int e = ok ? cl[i] : 0u;
             const int kk = (int)(e & (SORT_RS - 1));
+            const int row = new_tok[p0 + (ok ? (int)(e >> 7) : 0)];         // (issued before the key match: off its critical path)
             const unsigned long long same = dev_match_key(kk, ok, 7);
             if (ok) {
                 const int rank = __popcll(same & ((1ull << lane) - 1ull));
                 const int before = mine[kk];
-                region[base[kk] + before + rank] = (int32_t)(e >> 7);
+                region[base[kk] + before + rank] = row;
                 if (rank == __popcll(same) - 1) mine[kk] = before + rank + 1;       // the last of its component in the chunk
             }
         }
@@ -809,7 +811,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_batch_sort_ranges(
             if (ok) {
                 const int rank = __popcll(same & ((1ull << lane) - 1ull));
                 const int before = mine[kk];
-                region[base[kk] + before + rank] = sidx;
+                region[base[kk] + before + rank] = new_tok[p0 + sidx];
                 if (rank == __popcll(same) - 1) mine[kk] = before + rank + 1;
             }
         }
@@ -820,16 +822,22 @@ __global__ __launch_bounds__(SORT_THREADS) void k_batch_sort_ranges(
 // (1b) per (block, component) the sequential fp64 sum of its tokens in token order: one wave per pair, lanes own
 //      dimensions; the token rows are fetched 16 at a time (unconditional loads, clamped index, select after the
 //      load: all 16 in flight together) and added strictly in order.
-#define PART_BATCH 16
+// Lists are short on average (a dozen tokens) and a wave's time is a chain of dependent round trips (~1.5 us each under this
+// kernel's load): {offset, length} -> the list's rows (64 at a time, one per lane) -> the rows' elements, PART_BATCH rows in
+// flight together.  The longest list of the launch (~100 tokens) sets the kernel's duration: PART_BATCH = 32 makes that
+// four round trips (sixteen with double buffering took seven).  Float32 rows of even D <= 128 are fetched as float2 (lane l
+// owns dimensions 2l, 2l + 1: one load instruction per row).
+#define PART_BATCH 32
+#define PART_WAVES 4
 template <typename XT>
-__global__ __launch_bounds__(512) void k_batch_partials(segk_corpus c, segk_kmeans m, const int32_t *blk_lo, int n_blocks,
-                                                        const int32_t *new_tok, const int32_t *sorted, const int32_t *koff2,
-                                                        double *part_sum, int64_t *part_cnt, int NR)
+__global__ __launch_bounds__(64 * PART_WAVES) void k_batch_partials(segk_corpus c, segk_kmeans m, const int32_t *blk_lo, int n_blocks,
+                                                                   const int32_t *sorted, const int32_t *koff2,
+                                                                   double *part_sum, int64_t *part_cnt, int NR)
 {
-    const int groups = (m.K_max + 7) / 8;
+    const int groups = (m.K_max + PART_WAVES - 1) / PART_WAVES;
     const int b = blockIdx.x / groups, kg = blockIdx.x % groups;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int k = kg * 8 + wv;
+    const int k = kg * PART_WAVES + wv;
     SEGK_TSTAMP(2, 0);
     if (k >= m.K_max) return;
     const int D = c.D;
@@ -841,8 +849,35 @@ __global__ __launch_bounds__(512) void k_batch_partials(segk_corpus c, segk_kmea
 #endif
     const int64_t p0 = (int64_t)blk_lo[b] * c.N_max;
     const int S = (blk_lo[b + 1] - blk_lo[b]) * c.N_max;
-    const int32_t *list = sorted + p0 * NR + (int64_t)(k >> 7) * S + on.x;      // slot offsets inside the block, token order
-    const int32_t *tok = new_tok + p0;
+    const int32_t *list = sorted + p0 * NR + (int64_t)(k >> 7) * S + on.x;      // embedding rows of the list's tokens, token order
+    double *out = part_sum + ((int64_t)b * m.K_max + k) * D;
+    if (lane == 0) part_cnt[(int64_t)b * m.K_max + k] = nm;
+    if (sizeof(XT) == 4 && D <= 128 && (D & 1) == 0 && (c.ldx & 1) == 0) {
+        const float *Xf = (const float *)c.X;
+        const int dl = 2 * lane < D ? 2 * lane : 0;                              // clamped: always a valid address
+        double a0 = 0.0, a1 = 0.0;
+        for (int c0 = 0; c0 < nm; c0 += 64) {
+            const int mine = list[c0 + lane < nm ? c0 + lane : c0];
+            const int nb = nm - c0 < 64 ? nm - c0 : 64;
+            for (int q0 = 0; q0 < nb; q0 += PART_BATCH) {
+                float2 xv[PART_BATCH];
+#pragma unroll
+                for (int q = 0; q < PART_BATCH; q++) {
+                    const int e = __shfl(mine, q0 + q < nb ? q0 + q : 0);
+                    xv[q] = *reinterpret_cast<const float2 *>(Xf + (int64_t)e * c.ldx + dl);
+                }
+#pragma unroll
+                for (int q = 0; q < PART_BATCH; q++) {
+                    const bool ok = q0 + q < nb;
+                    a0 += ok ? (double)xv[q].x : 0.0;
+                    a1 += ok ? (double)xv[q].y : 0.0;
+                }
+            }
+        }
+        if (2 * lane < D) *reinterpret_cast<double2 *>(out + 2 * lane) = make_double2(a0, a1);
+        SEGK_TSTAMP_MAX(2, 1);
+        return;
+    }
     constexpr int MAXR = 2;                       // 128 dims per pass over the tokens
     for (int d0 = 0; d0 < D; d0 += 64 * MAXR) {
         double acc[MAXR];
@@ -853,43 +888,31 @@ __global__ __launch_bounds__(512) void k_batch_partials(segk_corpus c, segk_kmea
             const int d = d0 + r * 64 + lane;
             dcl[r] = d < D ? d : 0;
         }
-        // 64 tokens at a time: lane q fetches the row index of token c0 + q (two dependent loads for all 64 together); the
-        // rows are then fetched 16 at a time, the next 16 in flight while the current 16 are added strictly in order
         for (int c0 = 0; c0 < nm; c0 += 64) {
-            const int mine = c0 + lane < nm ? tok[list[c0 + lane]] : 0;
+            const int mine = list[c0 + lane < nm ? c0 + lane : c0];
             const int nb = nm - c0 < 64 ? nm - c0 : 64;
-            XT xv[2][PART_BATCH][MAXR];
-            auto fetch = [&](int buf, int q0) {
+            for (int q0 = 0; q0 < nb; q0 += 16) {
+                XT xv[16][MAXR];
 #pragma unroll
-                for (int q = 0; q < PART_BATCH; q++) {
+                for (int q = 0; q < 16; q++) {
                     const int e = __shfl(mine, q0 + q < nb ? q0 + q : 0);      // clamped: always a valid row
 #pragma unroll
-                    for (int r = 0; r < MAXR; r++) xv[buf][q][r] = X[(int64_t)e * c.ldx + dcl[r]];
+                    for (int r = 0; r < MAXR; r++) xv[q][r] = X[(int64_t)e * c.ldx + dcl[r]];
                 }
-            };
-            auto add = [&](int buf, int q0) {
 #pragma unroll
-                for (int q = 0; q < PART_BATCH; q++) {
+                for (int q = 0; q < 16; q++) {
                     const bool ok = q0 + q < nb;
 #pragma unroll
-                    for (int r = 0; r < MAXR; r++) acc[r] += ok ? (double)xv[buf][q][r] : 0.0;
+                    for (int r = 0; r < MAXR; r++) acc[r] += ok ? (double)xv[q][r] : 0.0;
                 }
-            };
-            fetch(0, 0);
-            for (int q0 = 0; q0 < nb; q0 += 2 * PART_BATCH) {
-                if (q0 + PART_BATCH < nb) fetch(1, q0 + PART_BATCH);
-                add(0, q0);
-                if (q0 + 2 * PART_BATCH < nb) fetch(0, q0 + 2 * PART_BATCH);
-                if (q0 + PART_BATCH < nb) add(1, q0 + PART_BATCH);
             }
         }
 #pragma unroll
         for (int r = 0; r < MAXR; r++) {
             int d = d0 + r * 64 + lane;
-            if (d < D) part_sum[((int64_t)b * m.K_max + k) * D + d] = acc[r];
+            if (d < D) out[d] = acc[r];
         }
     }
-    if (lane == 0) part_cnt[(int64_t)b * m.K_max + k] = nm;
     SEGK_TSTAMP_MAX(2, 1);
 }
 
@@ -927,6 +950,7 @@ __device__ __forceinline__ double tree_reduce_d(double *v, int n)
                                      beyond go through the context's overflow arrays in global memory (identical values
                                      written by every workgroup) -- the only limit left is flag_cap per block              */
 #define FIN_ROWS 8                /* final rows per workgroup */
+#define FIN_ML 32                 /* flagged tokens of a new component listed per row (more: the general loop) */
 
 template <typename XT>
 __global__ __launch_bounds__(256) void k_batch_finalize(
@@ -949,6 +973,8 @@ __global__ __launch_bounds__(256) void k_batch_finalize(
     __shared__ int shK1, shK, n_holes, n_fl;
     __shared__ int32_t fl_cnt[64];
     __shared__ long long red[4];
+    __shared__ int32_t ml[FIN_ROWS][FIN_ML];
+    __shared__ int ml_cnt[FIN_ROWS];
     const PackAddr pa{nbl, K_max, D, cap, rank_stride};
     // flagged token q of the sweep: the first SEGK_FLAG_LDS in LDS, the others in ovf [4][ovf_cap] (slot, row, k, block)
     // (the overflow arrays through an explicitly global pointer: left generic, the compiler merges the two sources of an accessor
@@ -1003,33 +1029,60 @@ __global__ __launch_bounds__(256) void k_batch_finalize(
     if (lane == 0) red[wv] = csum;
     __syncthreads();
     SEGK_TSTAMP(3, 1);
+    // the entries of all blocks are staged side by side first (raw labels; one round trip: thread t fetches entry t % 32 of
+    // block t / 32, whatever is beyond that in a plain loop), then one thread replays the clamp over the staged labels --
+    // fetched inside the replay loop, every flagged token cost that thread a dependent round trip
+    {
+        auto put = [&](int at, int b, int slot, int kraw, int row) {
+            if (at < SEGK_FLAG_LDS) {
+                fl_slot[at] = slot;
+                fl_row[at] = row;
+                fl_k[at] = (unsigned short)kraw;
+                fl_blk[at] = (unsigned short)b;
+            } else if (ovf && at - SEGK_FLAG_LDS < ovf_cap) {
+                const int o = at - SEGK_FLAG_LDS;
+                ovg[o] = slot;
+                ovg[(int64_t)ovf_cap + o] = row;
+                ovg[2 * (int64_t)ovf_cap + o] = kraw;
+                ovg[3 * (int64_t)ovf_cap + o] = b;
+            }
+        };
+        const int pb = tid >> 5, pq = tid & 31;
+        int at0 = 0, mycnt = 0;                                  // start of block pb's entries in the global order, their number
+        for (int b = 0; b < n_blocks; b++) {
+            const int cb = fl_cnt[b] < cap ? fl_cnt[b] : cap;
+            if (b < pb) at0 += cb;
+            if (b == pb) mycnt = cb;
+        }
+        if (pb < n_blocks && pq < mycnt) {
+            const int32_t *fl = reinterpret_cast<const int32_t *>(pack + pa.flg(pb));
+            const int sl = fl[2 + 3 * pq + 0], kr = fl[2 + 3 * pq + 1], rw = fl[2 + 3 * pq + 2];
+            put(at0 + pq, pb, sl, kr, rw);
+        }
+        int at = 0;
+        for (int b = 0; b < n_blocks; b++) {                     // (rare) entries 32.. of a block, blocks 8..
+            const int cb = fl_cnt[b] < cap ? fl_cnt[b] : cap;
+            const int32_t *fl = reinterpret_cast<const int32_t *>(pack + pa.flg(b));
+            for (int q = (b < nt / 32 ? 32 : 0) + tid; q < cb; q += nt) put(at + q, b, fl[2 + 3 * q + 0], fl[2 + 3 * q + 1], fl[2 + 3 * q + 2]);
+            at += cb;
+        }
+        if (at > SEGK_FLAG_LDS) __threadfence();                  // overflow entries: written by many threads, read by others below
+    }
+    __syncthreads();
     if (tid == 0) {
         int K = Kb, nf = 0, over = 0;
         for (int b = 0; b < n_blocks; b++) {
-            const int32_t *fl = reinterpret_cast<const int32_t *>(pack + pa.flg(b));
-            int cntb = fl_cnt[b];
-            if (cntb > cap) { over = 1; cntb = cap; }
-            for (int q = 0; q < cntb; q++) {
-                int k = fl[2 + 3 * q + 1];
-                if (k > K) k = K;
-                if (k == K) K++;
-                if (nf < SEGK_FLAG_LDS) {
-                    fl_slot[nf] = fl[2 + 3 * q + 0];
-                    fl_row[nf] = fl[2 + 3 * q + 2];
-                    fl_k[nf] = (unsigned short)k;
-                    fl_blk[nf] = (unsigned short)b;
-                    nf++;
-                } else if (ovf && nf - SEGK_FLAG_LDS < ovf_cap) {
-                    const int o = nf - SEGK_FLAG_LDS;
-                    ovg[o] = fl[2 + 3 * q + 0];
-                    ovg[(int64_t)ovf_cap + o] = fl[2 + 3 * q + 2];
-                    ovg[2 * (int64_t)ovf_cap + o] = k;
-                    ovg[3 * (int64_t)ovf_cap + o] = b;
-                    nf++;
-                } else {
-                    over = 1;
-                }
-            }
+            if (fl_cnt[b] > cap) over = 1;
+            nf += fl_cnt[b] < cap ? fl_cnt[b] : cap;
+        }
+        const int room = SEGK_FLAG_LDS + (ovf ? ovf_cap : 0);
+        if (nf > room) { over = 1; nf = room; }
+        for (int q = 0; q < nf; q++) {
+            int k = q < SEGK_FLAG_LDS ? (int)fl_k[q] : ovg[2 * (int64_t)ovf_cap + q - SEGK_FLAG_LDS];
+            if (k > K) k = K;
+            if (k == K) K++;
+            if (q < SEGK_FLAG_LDS) fl_k[q] = (unsigned short)k;
+            else ovg[2 * (int64_t)ovf_cap + q - SEGK_FLAG_LDS] = k;
         }
         if (over && wg == 0) atomicOr(status, 4);
         shK1 = K;
@@ -1052,7 +1105,13 @@ __global__ __launch_bounds__(256) void k_batch_finalize(
     for (int k = tid; k < K1; k += nt)
         if (cnt32[k] == 0) atomicOr(&bitmap[k >> 5], 1u << (k & 31));
     __syncthreads();
-    if (tid == 0) {
+    // (no component emptied -- the usual case once the chain has settled: nothing moves)
+    int any_hole = 0;
+    for (int w = tid; w < nwords; w += nt) any_hole |= bitmap[w] != 0u;
+    any_hole = __syncthreads_or(any_hole);
+    if (!any_hole) {
+        if (tid == 0) { shK = K1; n_holes = 0; }
+    } else if (tid == 0) {
         int K = K1, nh = 0;
         for (int w = nwords - 1; w >= 0; w--) {
             unsigned int bits = bitmap[w];
@@ -1098,6 +1157,21 @@ __global__ __launch_bounds__(256) void k_batch_finalize(
 
     // ---- (1) this workgroup's final rows, one element (row, dimension) per thread and step; the loads of four steps
     // (32 with the default eight blocks) are issued together
+    // match lists of this workgroup's rows that hold a component founded in this sweep (its tokens are flagged ones only)
+    if (tid < FIN_ROWS) {
+        const int j = j0 + tid;
+        int n = 0;
+        if (j < K && j < K_max && pos2orig[j] >= Kb) {
+            const int sc = pos2orig[j];
+            for (int q = 0; q < nfl; q++)
+                if (FL_K(q) == sc) {
+                    if (n < FIN_ML) ml[tid][n] = q;
+                    n++;
+                }
+        }
+        ml_cnt[tid] = n;
+    }
+    __syncthreads();
     SEGK_TSTAMP(3, 4);
     XT *__restrict__ means = (XT *)m.means;
     double *__restrict__ numer = m.mean_numerators;
@@ -1148,7 +1222,32 @@ __global__ __launch_bounds__(256) void k_batch_finalize(
                 double gv[64];
                 if (src[u] < Kb) {
                     for (int b = 0; b < n_blocks; b++) gv[b] = rpack[pa.sum(b) + (int64_t)src[u] * D + d];
-                } else {                                       // a component founded this sweep: its flagged tokens, block by block
+                } else if (n_blocks == 8 && ml_cnt[r] <= FIN_ML) {
+                    // a component founded this sweep: its flagged tokens, block by block -- the row's match list (LDS), four
+                    // rows in flight, the block's accumulator chosen by predicate (a dynamically indexed array lives in scratch)
+                    double g8[8];
+#pragma unroll
+                    for (int b = 0; b < 8; b++) g8[b] = 0.0;
+                    const int nmr = ml_cnt[r];
+                    for (int i0 = 0; i0 < nmr; i0 += 4) {
+                        XT xq[4];
+                        int bq[4];
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            const int qq = ml[r][i0 + i < nmr ? i0 + i : nmr - 1];
+                            bq[i] = FL_BLK(qq);
+                            xq[i] = X[(int64_t)FL_ROW(qq) * c.ldx + d];
+                        }
+#pragma unroll
+                        for (int i = 0; i < 4; i++)
+                            if (i0 + i < nmr) {
+#pragma unroll
+                                for (int b = 0; b < 8; b++) g8[b] = bq[i] == b ? g8[b] + (double)xq[i] : g8[b];
+                            }
+                    }
+#pragma unroll
+                    for (int b = 0; b < 8; b++) gv[b] = g8[b];
+                } else {                                       // (general: any number of blocks, long lists)
                     for (int b = 0; b < n_blocks; b++) gv[b] = 0.0;
                     for (int q = 0; q < nfl; q++)
                         if (FL_K(q) == src[u]) gv[FL_BLK(q)] += (double)X[(int64_t)FL_ROW(q) * c.ldx + d];
@@ -1541,9 +1640,9 @@ int32_t segk_kmeans_batch_partials(segk_ctx *ctx, const segk_corpus *c, const se
                            out_scalars, NR);
         SEGK_LAUNCH_CHECK();
     }
-    const int64_t grid = nbl * ((m->K_max + 7) / 8);
-    DISPATCH_XT(c, hipLaunchKernelGGL(k_batch_partials<XT>, dim3((unsigned)grid), dim3(512), 0, st, *c, *m, blk_lo,
-                                       n_blocks_local, new_tok, sorted_scratch, koff_scratch, part_sum, part_cnt, NR););
+    const int64_t grid = nbl * ((m->K_max + PART_WAVES - 1) / PART_WAVES);
+    DISPATCH_XT(c, hipLaunchKernelGGL(k_batch_partials<XT>, dim3((unsigned)grid), dim3(64 * PART_WAVES), 0, st, *c, *m, blk_lo,
+                                       n_blocks_local, sorted_scratch, koff_scratch, part_sum, part_cnt, NR););
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;
 }

@@ -46,7 +46,7 @@ for k, nm in enumerate(names):
         live = live[rows[:, 0] > 0]
         print("  workgroup life: mean %.2f  p50 %.2f  p90 %.2f  max %.2f" % (live.mean(), np.percentile(live, 50), np.percentile(live, 90), live.max()))
         continue
-    for ph in range(7):
+    for ph in range(8):
         if (rows[:, ph] > 0).any():
             print("  phase %d: %8.2f %8.2f %8.2f" % ((ph,) + rel(rows[:, ph])))
     if k == 0:
