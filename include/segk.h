@@ -313,9 +313,10 @@ int32_t segk_kmeans_sequential_sweep(segk_ctx *ctx, const segk_corpus *c, segk_k
  *      blk_lo [dev] int32 [n_blocks_local + 1]) the sequential fp64 sum of its tokens per component, in
  *      token order (utterance, segment), read from the slot arrays new_tok / new_k [dev] int32
  *      [n_utt, N_max] as segk_kmeans_segment leaves them (unused slots: k = -1): a stable counting sort
- *      of the block's tokens by component (sorted_scratch [dev] int32 [n_utt * N_max * ceil(K_max / 128)]: one region per
- *      (block, range of 128 components); koff_scratch [dev] int32 [n_blocks_local * K_max * 2]: {offset, length} of every
- *      (block, component) list -- ABI version 4), then one sequential sum per (block, component);
+ *      of the block's tokens by component (sorted_scratch: one region per (block, range of components);
+ *      koff_scratch: {offset, length} of every (block, component) list; both [dev] int32, their sizes in words from
+ *      segk_kmeans_batch_scratch_words with n_slots = n_utt * N_max -- ABI version 4), then one sequential sum per
+ *      (block, component);
  *      part_tot = sum of out_total in utterance order.  Tokens whose argmax is an inactive row (k >= K;
  *      n_flag [dev] int32 [n_utt] counts them per utterance) are listed instead, in token order.
  *      Writes out_scalars[3] = K (before the sweep) and zeroes m->mnorm_max for (2).
@@ -334,6 +335,8 @@ int32_t segk_kmeans_sequential_sweep(segk_ctx *ctx, const segk_corpus *c, segk_k
  *  checkpoint or rebuild the state, and sweep again with a larger flag_cap.  There is no per-sweep limit).
  */
 int64_t segk_kmeans_batch_record_words(int32_t K_max, int32_t D, int32_t n_blocks_local, int32_t flag_cap);
+int32_t segk_kmeans_batch_scratch_words(int32_t K_max, int64_t n_slots, int32_t n_blocks_local, int64_t *sorted_words,
+                                        int64_t *koff_words);
 int32_t segk_kmeans_batch_partials(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m,
                                    const int32_t *blk_lo, int32_t n_blocks_local,
                                    const int32_t *new_tok, const int32_t *new_k, const int32_t *n_flag,

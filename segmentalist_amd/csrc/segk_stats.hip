@@ -608,30 +608,48 @@ __global__ __launch_bounds__(SORT_THREADS) void k_batch_sort(
 }
 
 // ======================================================================================
-// (1a') k_batch_sort_ranges (round 3): the same stable counting sort, spread over the chip.  The one-workgroup-per-block form
-//      spends 20 of its 29 us in the placement pass -- sixteen waves on one CU, every chunk of 64 slots a ten-ballot key
-//      match -- while 248 CUs idle.  Here a block is sorted by NR + 2 workgroups: workgroup (b, r < NR) owns the
-//      components [128 r, 128 r + 128) and a region of its own in `sorted` (S_b entries: whatever the split of the tokens
-//      over the ranges, a region cannot overflow), so nothing crosses workgroups: every wave compacts the in-range tokens of
-//      its run of slots into LDS (ballot + prefix count, order kept), counts them per component, and the placement pass
-//      walks the compacted list -- an eighth of the tokens, seven key bits.  Workgroup (b, NR) lists the flagged tokens
-//      (argmax on an inactive row) in token order with the same compaction; workgroup (b, NR + 1) sums the block's totals.
-//      koff2[b][k] = {offset of component k's list inside its range's region, length}.
+// (1a') k_batch_sort_sum (round 3): the same stable counting sort AND the partial sums, spread over the chip.  The
+//      one-workgroup-per-block sort spent 20 of its 29 us in the placement pass -- sixteen waves on one CU, every chunk of 64
+//      slots a ten-ballot key match -- while 248 CUs idled, and the summing kernel behind it (one wave per (block, component))
+//      25 us on workgroup dispatch and three dependent round trips per wave for a dozen tokens.  Here a block is handled by
+//      NR + 2 workgroups: workgroup (b, r < NR) owns the components k = r mod NR (at most RS = 32 of them up to K_max 2048: 32 ranges x
+//      8 blocks fill the 256 CUs -- a CU takes in ~25 GB/s, so the 32 MB of token rows must be gathered by all of them) and a
+//      region of its own in `sorted` (S_b entries: whatever the split of the tokens over the ranges, a region cannot
+//      overflow), so nothing crosses workgroups:
+//      (P1) every wave compacts the in-range tokens of its run of slots into LDS (ballot + prefix count, order kept) and
+//           counts them per component; (P2) offsets; (P3) the placement pass walks the compacted list -- a thirty-second of
+//           the tokens, five key bits -- and writes the tokens' embedding rows into the region;
+//      (S)  the range's tokens now lie contiguous in the region, component after component: wave w takes the components
+//           whose lists START in the w-th sixteenth of them and streams their rows 32 at a time, whatever the component
+//           boundaries -- the sums stay strictly sequential per component; an accumulator is written out when its list ends.
+//      Workgroup (b, NR) lists the flagged tokens (argmax on an inactive row) in token order with the same compaction;
+//      workgroup (b, NR + 1) sums the block's totals.  koff2[b][k] = {offset of component k's list in its region, length}.
 // ======================================================================================
-#define SORT_RS 128                  /* components per range */
-#define SORT_CL 2048                 /* compacted entries per wave kept in LDS: blocks of up to 16 * 2048 slots; larger ones
-                                        walk all their slots again in the placement pass                                   */
-static inline __host__ __device__ int segk_sort_ranges(int K_max) { return (K_max + SORT_RS - 1) / SORT_RS; }
+#define SORT_CL 512                  /* compacted entries per wave kept in LDS; a wave with more in-range tokens (or a block of
+                                        more than 16 * 2048 slots): the placement pass walks all slots again                */
+static inline __host__ __device__ int segk_sort_rsh(int K_max) { return K_max <= 2048 ? 5 : 7; }       // log2 of components per range (at most)
+// log2 of the number of ranges (a power of two): component k belongs to range k & (NR - 1) as its member k >> nsh -- strided,
+// so that the active components (the low indices: K of K_max) and the inactive ones spread evenly over the ranges' workgroups
+static inline __host__ __device__ int segk_sort_nsh(int K_max)
+{
+    const int need = (K_max + (1 << segk_sort_rsh(K_max)) - 1) >> segk_sort_rsh(K_max);
+    int nsh = 0;
+    while ((1 << nsh) < need) nsh++;
+    return nsh;
+}
+static inline __host__ __device__ int segk_sort_ranges(int K_max) { return 1 << segk_sort_nsh(K_max); }
 
-__global__ __launch_bounds__(SORT_THREADS) void k_batch_sort_ranges(
+__global__ __launch_bounds__(SORT_THREADS) void k_batch_sort_sum(
     segk_corpus c, segk_kmeans m, const int32_t *blk_lo, int n_blocks, const int32_t *new_tok, const int32_t *new_k,
-    const double *out_total, int32_t *sorted, int32_t *koff2, double *part_tot, int32_t *flags, int cap, double *out_scalars, int NR)
+    const double *out_total, int32_t *sorted, int32_t *koff2, double *part_tot, int32_t *flags, int cap, double *out_scalars, int NR,
+    int rsh, int nsh, double *part_sum, int64_t *part_cnt, int fuse_sum)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char sort_lds[];
     __shared__ int32_t wcount[16], wscan[2];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int Kb = *m.K;                          // active components before the sweep: k >= Kb is a flagged token
     const int K_max = m.K_max;
+    const int RS = 1 << rsh, kmask = RS - 1;
     const int b = blockIdx.x / (NR + 2), r = blockIdx.x % (NR + 2);
     const int u0 = blk_lo[b], u1 = blk_lo[b + 1];
     SEGK_TSTAMP(1, 0);
@@ -669,18 +687,19 @@ __global__ __launch_bounds__(SORT_THREADS) void k_batch_sort_ranges(
     const int64_t p0 = (int64_t)u0 * c.N_max;
     const int S = (u1 - u0) * c.N_max;
     const int per = ((S + 15) / 16 + 63) & ~63;                  // slots per wave, whole chunks of 64
-    const bool compact = per <= SORT_CL;
-    int32_t *cntw = reinterpret_cast<int32_t *>(sort_lds);       // [16][SORT_RS]
-    int32_t *base = cntw + 16 * SORT_RS;                         // [SORT_RS]
-    uint32_t *cl = reinterpret_cast<uint32_t *>(base + SORT_RS) + (size_t)wv * SORT_CL;      // this wave's compacted entries
+    const bool preload = per <= 2048;
+    int32_t *cntw = reinterpret_cast<int32_t *>(sort_lds);       // [16][RS]
+    int32_t *base = cntw + 16 * RS;                              // [RS]
+    int32_t *cnts = base + RS;                                   // [RS]
+    uint32_t *cl = reinterpret_cast<uint32_t *>(cnts + RS) + (size_t)wv * SORT_CL;      // this wave's compacted entries
     const int32_t *keys = new_k + (S > 0 ? p0 : 0);            // (an empty block at the end of the corpus: nothing is read)
     const int s0 = wv * per < S ? wv * per : S, s1 = s0 + per < S ? s0 + per : S;
-    auto in_range = [&](int k) -> bool { return flg ? k >= Kb : (k >= 0 && k < Kb && (k >> 7) == r); };
-    for (int i = tid; i < 16 * SORT_RS; i += SORT_THREADS) cntw[i] = 0;
+    auto in_range = [&](int k) -> bool { return flg ? k >= Kb : (k >= 0 && k < Kb && (k & (NR - 1)) == r); };
+    for (int i = tid; i < 16 * RS; i += SORT_THREADS) cntw[i] = 0;
     int n_mine = 0;                                              // wave-uniform: in-range tokens of this wave's run
-    if (compact) {
+    if (preload) {
         // (P1) every key of the run fetched up front (unconditional loads, clamped index), then compacted in order
-        constexpr int NC = SORT_CL / 64;
+        constexpr int NC = 2048 / 64;
         int v[NC];
 #pragma unroll
         for (int q = 0; q < NC; q++) {
@@ -695,8 +714,9 @@ __global__ __launch_bounds__(SORT_THREADS) void k_batch_sort_ranges(
             const bool in = sidx < s1 && in_range(k);
             const unsigned long long bal = __ballot(in);
             if (in) {
-                cl[n_mine + __popcll(bal & ((1ull << lane) - 1ull))] = ((unsigned int)sidx << 7) | (unsigned int)(k & (SORT_RS - 1));
-                if (!flg) atomicAdd(&cntw[wv * SORT_RS + (k & (SORT_RS - 1))], 1);
+                const int at = n_mine + __popcll(bal & ((1ull << lane) - 1ull));
+                if (at < SORT_CL) cl[at] = ((unsigned int)sidx << rsh) | (unsigned int)((k >> nsh) & kmask);
+                if (!flg) atomicAdd(&cntw[wv * RS + ((k >> nsh) & kmask)], 1);
             }
             n_mine += __popcll(bal);
         }
@@ -706,14 +726,13 @@ __global__ __launch_bounds__(SORT_THREADS) void k_batch_sort_ranges(
             const int sidx = sb + lane;
             const int k = sidx < s1 ? keys[sidx] : -1;
             const bool in = sidx < s1 && in_range(k);
-            if (in && !flg) atomicAdd(&cntw[wv * SORT_RS + (k & (SORT_RS - 1))], 1);
+            if (in && !flg) atomicAdd(&cntw[wv * RS + ((k >> nsh) & kmask)], 1);
             n_mine += __popcll(__ballot(in));
         }
     }
     if (lane == 0) wcount[wv] = n_mine;
-    __syncthreads();
+    const bool compact = !__syncthreads_or(!preload || n_mine > SORT_CL);      // workgroup-uniform (and the barrier after P1)
     SEGK_TSTAMP(1, 2);
-    // item i of this wave's in-range tokens, in order: from the compacted list, or (large blocks) by walking the run again
     if (flg) {
         // ---- the flagged tokens, in token order: {count, 0, (slot, k, row) x cap}
         int32_t *fl = flags + (int64_t)b * 2 * segk_flag_words(cap);
@@ -725,7 +744,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_batch_sort_ranges(
         if (tid == 0) { fl[0] = tot; fl[1] = 0; }
         if (compact) {
             for (int i = lane; i < n_mine; i += 64) {
-                const int sidx = (int)(cl[i] >> 7);
+                const int sidx = (int)(cl[i] >> rsh);
                 if (off + i < cap) {
                     fl[2 + 3 * (off + i) + 0] = (int32_t)(p0 + sidx);
                     fl[2 + 3 * (off + i) + 1] = keys[sidx];
@@ -753,13 +772,13 @@ __global__ __launch_bounds__(SORT_THREADS) void k_batch_sort_ranges(
     }
     // (P2) per component of the range: the waves' counts -> running offsets; totals -> exclusive scan over the range
     int run = 0, incl = 0;
-    if (tid < SORT_RS) {
+    if (tid < RS) {
         int t[16];
 #pragma unroll
-        for (int w = 0; w < 16; w++) t[w] = cntw[w * SORT_RS + tid];
+        for (int w = 0; w < 16; w++) t[w] = cntw[w * RS + tid];
 #pragma unroll
         for (int w = 0; w < 16; w++) {
-            cntw[w * SORT_RS + tid] = run;
+            cntw[w * RS + tid] = run;
             run += t[w];
         }
         incl = run;
@@ -767,13 +786,14 @@ __global__ __launch_bounds__(SORT_THREADS) void k_batch_sort_ranges(
             const int t2 = __shfl_up(incl, o);
             if (lane >= o) incl += t2;
         }
-        if (lane == 63) wscan[wv] = incl;
+        if (lane == 63) wscan[wv] = incl;                        // (RS = 128: two waves)
     }
     __syncthreads();
-    if (tid < SORT_RS) {
+    if (tid < RS) {
         const int ex = (wv == 1 ? wscan[0] : 0) + incl - run;
         base[tid] = ex;
-        const int k = r * SORT_RS + tid;
+        cnts[tid] = run;
+        const int k = (tid << nsh) + r;
         if (k < K_max) {
             koff2[((int64_t)b * K_max + k) * 2 + 0] = ex;
             koff2[((int64_t)b * K_max + k) * 2 + 1] = run;
@@ -781,18 +801,17 @@ __global__ __launch_bounds__(SORT_THREADS) void k_batch_sort_ranges(
     }
     __syncthreads();
     SEGK_TSTAMP(1, 3);
-    // (P3) placement, stable: `sorted` receives the token's embedding row (new_tok of its slot), so that the summing kernel
-    // has one dependent load less per list
+    // (P3) placement, stable: `sorted` receives the token's embedding row (new_tok of its slot)
     int32_t *region = sorted + p0 * NR + (int64_t)r * S;
-    int32_t *mine = cntw + wv * SORT_RS;
+    int32_t *mine = cntw + wv * RS;
     if (compact) {
         for (int ib = 0; ib < n_mine; ib += 64) {
             const int i = ib + lane;
             const bool ok = i < n_mine;
             const unsigned int e = ok ? cl[i] : 0u;
-            const int kk = (int)(e & (SORT_RS - 1));
-            const int row = new_tok[p0 + (ok ? (int)(e >> 7) : 0)];         // (issued before the key match: off its critical path)
-            const unsigned long long same = dev_match_key(kk, ok, 7);
+            const int kk = (int)(e & (unsigned int)kmask);
+            const int row = new_tok[p0 + (ok ? (int)(e >> rsh) : 0)];         // (issued before the key match: off its critical path)
+            const unsigned long long same = dev_match_key(kk, ok, rsh);
             if (ok) {
                 const int rank = __popcll(same & ((1ull << lane) - 1ull));
                 const int before = mine[kk];
@@ -806,8 +825,8 @@ __global__ __launch_bounds__(SORT_THREADS) void k_batch_sort_ranges(
             const int k = sidx < s1 ? keys[sidx] : -1;
             const bool ok = sidx < s1 && in_range(k);
             if (__ballot(ok) == 0ull) continue;
-            const int kk = k & (SORT_RS - 1);
-            const unsigned long long same = dev_match_key(kk, ok, 7);
+            const int kk = (k >> nsh) & kmask;
+            const unsigned long long same = dev_match_key(kk, ok, rsh);
             if (ok) {
                 const int rank = __popcll(same & ((1ull << lane) - 1ull));
                 const int before = mine[kk];
@@ -817,6 +836,68 @@ __global__ __launch_bounds__(SORT_THREADS) void k_batch_sort_ranges(
         }
     }
     SEGK_TSTAMP_MAX(1, 4);
+    if (!fuse_sum) return;
+    // (S) float32 rows of even D <= 128; everything else: k_batch_partials
+    // (the barrier orders this workgroup's stores to `region` before its own loads of them: workgroup scope is all that is
+    // needed -- one CU, one vector L1 that has never held these lines.  An agent-scope __threadfence() here writes back and
+    // invalidates the XCD's L2 per workgroup: +77 us on the sweep)
+    __syncthreads();
+    {
+        const int T = base[RS - 1] + cnts[RS - 1];
+        auto owner = [&](int kk) -> int {
+            const int o = T > 0 ? (int)(((long long)base[kk] * 16) / T) : 0;
+            return o < 15 ? o : 15;
+        };
+        // the wave's components [ka, kb): owner() is monotone in kk
+        const unsigned long long m0 = __ballot(lane < RS && owner(lane < RS ? lane : 0) == wv),
+                                 m1 = __ballot(64 + lane < RS && owner(64 + lane < RS ? 64 + lane : 0) == wv);
+        if ((m0 | m1) == 0ull) return;
+        const int ka = m0 ? __ffsll((long long)m0) - 1 : 64 + __ffsll((long long)m1) - 1;
+        const int kb = m1 ? 128 - __clzll((long long)m1) : 64 - __clzll((long long)m0);
+        const int D = c.D;
+        const float *Xf = (const float *)c.X;
+        const int dl = 2 * lane < D ? 2 * lane : 0;              // clamped: always a valid address
+        const int t_lo = base[ka], t_hi = base[kb - 1] + cnts[kb - 1];
+        double a0 = 0.0, a1 = 0.0;
+        int kk = ka, rem = cnts[ka];
+        auto flush = [&]() {                                     // component kk is complete (rem == 0): write it out, move on
+            for (;;) {
+                const int k = (kk << nsh) + r;
+                if (k < K_max) {
+                    if (2 * lane < D) *reinterpret_cast<double2 *>(part_sum + ((int64_t)b * K_max + k) * D + 2 * lane) = make_double2(a0, a1);
+                    if (lane == 0) part_cnt[(int64_t)b * K_max + k] = cnts[kk];
+                }
+                a0 = 0.0;
+                a1 = 0.0;
+                kk++;
+                if (kk >= kb) { rem = 0x7fffffff; return; }
+                rem = cnts[kk];
+                if (rem > 0) return;
+            }
+        };
+        if (rem == 0) flush();
+        for (int c0 = t_lo; c0 < t_hi; c0 += 64) {
+            const int nb = t_hi - c0 < 64 ? t_hi - c0 : 64;
+            const int mine_row = region[c0 + (lane < nb ? lane : 0)];
+            for (int q0 = 0; q0 < nb; q0 += 32) {
+                float2 xv[32];
+#pragma unroll
+                for (int q = 0; q < 32; q++) {
+                    const int e = __shfl(mine_row, q0 + q < nb ? q0 + q : 0);       // clamped: always a valid row
+                    xv[q] = *reinterpret_cast<const float2 *>(Xf + (int64_t)e * c.ldx + dl);
+                }
+#pragma unroll
+                for (int q = 0; q < 32; q++) {
+                    if (q0 + q < nb) {                                               // wave-uniform
+                        a0 += (double)xv[q].x;
+                        a1 += (double)xv[q].y;
+                        if (--rem == 0) flush();
+                    }
+                }
+            }
+        }
+        SEGK_TSTAMP_MAX(1, 5);
+    }
 }
 
 // (1b) per (block, component) the sequential fp64 sum of its tokens in token order: one wave per pair, lanes own
@@ -849,7 +930,7 @@ __global__ __launch_bounds__(64 * PART_WAVES) void k_batch_partials(segk_corpus 
 #endif
     const int64_t p0 = (int64_t)blk_lo[b] * c.N_max;
     const int S = (blk_lo[b + 1] - blk_lo[b]) * c.N_max;
-    const int32_t *list = sorted + p0 * NR + (int64_t)(k >> 7) * S + on.x;      // embedding rows of the list's tokens, token order
+    const int32_t *list = sorted + p0 * NR + (int64_t)(k & (NR - 1)) * S + on.x;    // embedding rows of the list's tokens, token order
     double *out = part_sum + ((int64_t)b * m.K_max + k) * D;
     if (lane == 0) part_cnt[(int64_t)b * m.K_max + k] = nm;
     if (sizeof(XT) == 4 && D <= 128 && (D & 1) == 0 && (c.ldx & 1) == 0) {
@@ -1602,6 +1683,15 @@ int32_t segk_kmeans_del_component(segk_ctx *ctx, const segk_corpus *c, segk_kmea
     return segk_kmeans_prepare(ctx, c, m, stream);
 }
 
+int32_t segk_kmeans_batch_scratch_words(int32_t K_max, int64_t n_slots, int32_t n_blocks_local, int64_t *sorted_words,
+                                        int64_t *koff_words)
+{
+    SEGK_REQUIRE(K_max >= 1 && n_slots >= 0 && n_blocks_local >= 0 && sorted_words && koff_words, "batch_scratch_words operands");
+    *sorted_words = (n_slots > 0 ? n_slots : 1) * segk_sort_ranges(K_max);
+    *koff_words = (int64_t)(n_blocks_local > 0 ? n_blocks_local : 1) * K_max * 2;
+    return SEGK_OK;
+}
+
 int64_t segk_kmeans_batch_record_words(int32_t K_max, int32_t D, int32_t n_blocks_local, int32_t flag_cap)
 {
     return (int64_t)n_blocks_local * ((int64_t)K_max * D + 1 + K_max + segk_flag_words(flag_cap));
@@ -1629,17 +1719,18 @@ int32_t segk_kmeans_batch_partials(segk_ctx *ctx, const segk_corpus *c, const se
     hipStream_t st = (hipStream_t)stream;
     (void)n_flag;
     segk_tstamp_bind();
-    const int NR = segk_sort_ranges(m->K_max);
+    const int NR = segk_sort_ranges(m->K_max), rsh = segk_sort_rsh(m->K_max), nsh = segk_sort_nsh(m->K_max);
+    const bool fuse = c->x_dtype == SEGK_F32 && c->D <= 128 && (c->D & 1) == 0 && (c->ldx & 1) == 0 &&
+                      !(getenv("SEGK_PARTIALS_FUSED") && atoi(getenv("SEGK_PARTIALS_FUSED")) == 0);
     {
-        const size_t lds = (size_t)(16 * SORT_RS + SORT_RS) * 4 + (size_t)16 * SORT_CL * 4;
-        static bool lds_set = false;
-        if (!lds_set) SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_batch_sort_ranges, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        lds_set = true;
-        hipLaunchKernelGGL(k_batch_sort_ranges, dim3((unsigned)(nbl * (NR + 2))), dim3(SORT_THREADS), lds, st, *c, *m, blk_lo,
+        size_t lds = (size_t)(16 + 2) * (1 << rsh) * 4 + (size_t)16 * SORT_CL * 4;
+        if (lds < 2048 * sizeof(double)) lds = 2048 * sizeof(double);
+        hipLaunchKernelGGL(k_batch_sort_sum, dim3((unsigned)(nbl * (NR + 2))), dim3(SORT_THREADS), lds, st, *c, *m, blk_lo,
                            n_blocks_local, new_tok, new_k, out_total, sorted_scratch, koff_scratch, part_tot, flags, flag_cap,
-                           out_scalars, NR);
+                           out_scalars, NR, rsh, nsh, part_sum, part_cnt, fuse ? 1 : 0);
         SEGK_LAUNCH_CHECK();
     }
+    if (fuse) return SEGK_OK;
     const int64_t grid = nbl * ((m->K_max + PART_WAVES - 1) / PART_WAVES);
     DISPATCH_XT(c, hipLaunchKernelGGL(k_batch_partials<XT>, dim3((unsigned)grid), dim3(64 * PART_WAVES), 0, st, *c, *m, blk_lo,
                                        n_blocks_local, sorted_scratch, koff_scratch, part_sum, part_cnt, NR););

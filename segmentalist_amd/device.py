@@ -427,8 +427,10 @@ class KMeansBatchSweeper(object):
         self.pack_all = torch.zeros((W, self.rank_stride), dtype=torch.float64, device=dev)
         self.pack = self.pack_all[part.rank]
         self.blk_lo = to_dev(part.local_bounds, np.int32)
-        self.sorted = torch.zeros(max(c.n_utt * c.N_max, 1) * ((dk.K_max + 127) // 128), dtype=torch.int32, device=dev)
-        self.koff = torch.zeros(part.nbl * dk.K_max * 2, dtype=torch.int32, device=dev)
+        ws, wk = C.c_int64(), C.c_int64()
+        check(dk._L.segk_kmeans_batch_scratch_words(dk.K_max, c.n_utt * c.N_max, part.nbl, C.byref(ws), C.byref(wk)))
+        self.sorted = torch.zeros(ws.value, dtype=torch.int32, device=dev)
+        self.koff = torch.zeros(wk.value, dtype=torch.int32, device=dev)
         # SEGK_SWEEP_GRAPH=1: the sweep replayed as a hipGraph from its second run on.  Default 0: measured on MI355X
         # the replay is SLOWER than the plain launches it replaces (full corpus 0.661 vs 0.634 ms per sweep, a
         # 1 250-utterance shard 0.258 vs 0.216 ms: the launches of sweep i + 1 are enqueued while sweep i runs, so

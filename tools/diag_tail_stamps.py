@@ -36,10 +36,13 @@ for k, nm in enumerate(names):
         nb = 8
         for lab, sl in (("sort workgroups", slice(0, nb)), ("flags + totals workgroups", slice(nb, 2 * nb))):
             print("  %s" % lab)
-            for ph in range(5):
+            for ph in range(6):
                 print("    phase %d: %8.2f %8.2f %8.2f" % ((ph,) + rel(rows[sl, ph])))
         continue
     if k == 2:
+        if not (rows[:, 0] > 0).any():
+            print("  (fused into the sort kernel)")
+            continue
         print("  entry: %8.2f %8.2f %8.2f   last wave exit: %8.2f %8.2f %8.2f   longest list of a wave (tokens): max %d mean %.1f" % (
             rel(rows[:, 0]) + rel(rows[:, 1]) + (int(st.cpu().numpy().reshape(8, 1024, 8)[2][:, 2].max()), st.cpu().numpy().reshape(8, 1024, 8)[2][:, 2].mean())))
         live = rows[:, 1] - rows[:, 0]
