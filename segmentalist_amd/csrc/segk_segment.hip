@@ -247,6 +247,222 @@ __global__ void k_kmeans_segment_w8(segk_corpus c, segk_kmeans m, const int32_t 
     SEGK_TSTAMP_MAX(0, 3);
 }
 
+// EIGHT utterances per wave (round 3; launches over many utterances): lanes 8g..8g+7 run utterance g's DP -- the DPP steps of
+// seg_w8_wave act inside groups of eight lanes already, so the eight DPs advance in lockstep in one instruction stream, and a
+// launch over 10 000 utterances is 1 250 waves instead of 10 000.  (One utterance per wave took 29 us: 2 500 workgroups to
+// dispatch, 14 us of life each -- gathers 5.7, DP 7.9 under that load.)  Token lists by the group's eight lanes, eight
+// boundary bits per step; the backward pass as a state machine with one candidate evaluation per trip, so that groups in
+// different phases share the loop.  Same values and decisions as seg_w8_serial.
+__global__ __launch_bounds__(256) void k_kmeans_segment_oct(segk_corpus c, segk_kmeans m, const int32_t *utts, int utt0, int n_utts,
+                                                            int n_max, double wip, segk_cand cand, uint8_t *boundaries, int32_t *old_tok,
+                                                            int32_t *new_tok, int32_t *new_k, int32_t *n_old, int32_t *n_new, int32_t *n_flag,
+                                                            double *out_total, int32_t *status, int band_cap, int utt_bytes)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane >> 3, w8 = lane & 7;
+    const int slot = (blockIdx.x * (blockDim.x >> 6) + wv) * 8 + g;
+    SEGK_TSTAMP(0, 0);
+    const bool valid = slot < n_utts;
+    const int u = valid ? (utts ? utts[slot] : utt0 + slot) : (utts ? utts[0] : utt0);
+    const int N = valid ? c.lengths[u] : 0;
+    const int W = (n_max > 0 && n_max < N) ? n_max : N;          // <= 8 (host checks n_max <= 8)
+    const int nb = N * W;
+    const int64_t triMax = (int64_t)c.N_max * (c.N_max + 1) / 2;
+    const int32_t *vid = c.vec_ids + (int64_t)u * triMax;
+    const double *dur = c.durations + (int64_t)u * triMax;
+    const bool band = c.band_ids != nullptr && c.band_W == W && W > 0;
+    const int32_t *bandi = band ? c.band_ids + (int64_t)u * c.N_max * c.band_W : nullptr;
+    const double *bandd = band ? c.band_dur + (int64_t)u * c.N_max * c.band_W : nullptr;
+    uint8_t *gbnd = boundaries + (int64_t)u * c.N_max;
+    const int Kact = *m.K;
+    const int gsh = 8 * g;                                          // this group's byte of a ballot
+    const unsigned long long lt8 = (1ull << w8) - 1ull;
+
+    char *base = smem + (size_t)((wv * 8 + g)) * utt_bytes;
+    double *bvec = (double *)base;                    // [band_cap]
+    double *gam = bvec + band_cap;                    // [N_max + 1]
+    int32_t *bk = (int32_t *)(gam + c.N_max + 1);     // [band_cap]
+    int32_t *bid = bk + band_cap;                     // [band_cap]
+    int32_t *l_old = bid + band_cap;                  // [N_max]
+    int32_t *l_new = l_old + c.N_max;                 // [N_max]
+    int32_t *l_newk = l_new + c.N_max;                // [N_max]
+
+    // ---- the band (A5, kmeans_acoustic_wordseg.py:334-351): eight entries of each utterance per step, sixteen steps (128
+    // entries) at a time: every span id first, then every gather -- two round trips for the whole band
+    int nb_wave = nb;
+    nb_wave = max(nb_wave, __shfl_xor(nb_wave, 8));
+    nb_wave = max(nb_wave, __shfl_xor(nb_wave, 16));
+    nb_wave = max(nb_wave, __shfl_xor(nb_wave, 32));
+    for (int i0 = 0; i0 < nb_wave; i0 += 128) {
+        constexpr int NQ = 16;
+        int id[NQ], kq[NQ];
+        double dd[NQ], sc[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            const int i = i0 + q * 8 + w8;
+            id[q] = -1;
+            if (i < nb) {
+                const int t = i / W + 1, w = i % W, s = t - 1 - w;
+                if (s >= 0) id[q] = band ? bandi[i] : vid[t * (t - 1) / 2 + s];      // banded image: consecutive lanes, consecutive entries
+                dd[q] = s >= 0 ? (band ? bandd[i] : dur[t * (t - 1) / 2 + s]) : 0.0;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            kq[q] = -1;
+            sc[q] = 0.0;
+            if (id[q] >= 0) {
+                kq[q] = cand.k[id[q]];
+                sc[q] = cand.s[id[q]];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            const int i = i0 + q * 8 + w8;
+            if (i < nb) {
+                double v = NEG_INF_D;
+                if (id[q] >= 0) v = isnan(dd[q]) ? NEG_INF_D : sc[q] * dd[q];           // :346-349
+                bid[i] = id[q];
+                bk[i] = kq[q];
+                bvec[i] = v + wip;                                                    // :351
+            }
+        }
+    }
+    // ---- old boundary mask, eight bits per step
+    int N_wave = N;
+    N_wave = max(N_wave, __shfl_xor(N_wave, 8));
+    N_wave = max(N_wave, __shfl_xor(N_wave, 16));
+    N_wave = max(N_wave, __shfl_xor(N_wave, 32));
+    unsigned long long oldb = 0ull;
+    for (int jj = 0; jj < N_wave; jj += 8) {
+        const int j = jj + w8;
+        const unsigned long long bal = __ballot(j < N && gbnd[j < N ? j : 0] != 0);
+        oldb |= ((bal >> gsh) & 0xFFull) << jj;
+    }
+    WAVE_SYNC();
+    // the tokens of a boundary mask: the lane of bit j looks up its span [jp, j + 1)
+    auto tokens = [&](unsigned long long mask, int32_t *out_id, int32_t *out_k, int &n_out, int &n_fl, int &bad, bool is_new) {
+        int n = 0, nf = 0, bd = 0;
+        for (int jj = 0; jj < N_wave; jj += 8) {
+            const int j = jj + w8;
+            const bool bit = j < N && ((mask >> j) & 1ull);
+            const unsigned long long below = mask & ((1ull << j) - 1ull);
+            const int jp = below ? 64 - __clzll((long long)below) : 0;
+            const int w = j - jp;
+            int id = -1, kk = -1;
+            if (bit) {
+                if (w < W) {
+                    id = bid[j * W + w];
+                    kk = bk[j * W + w];
+                } else if (!is_new) {
+                    id = vid[(j + 1) * j / 2 + jp];              // an old span longer than the window: the triangular table
+                }
+            }
+            const bool ok = bit && id >= 0;
+            const unsigned long long keep = (__ballot(ok) >> gsh) & 0xFFull;
+            const unsigned long long badm = (__ballot(bit && !ok) >> gsh) & 0xFFull;
+            const unsigned long long flm = (__ballot(ok && kk >= Kact) >> gsh) & 0xFFull;
+            if (ok) {
+                const int rk = n + __popcll(keep & lt8);
+                out_id[rk] = id;
+                if (out_k) out_k[rk] = kk;
+            }
+            n += __popcll(keep);
+            nf += __popcll(flm);
+            bd |= badm != 0ull;
+        }
+        n_out = n;
+        n_fl = nf;
+        bad = bd;
+    };
+    SEGK_TSTAMP(0, 1);
+    int no, dummy1, dummy2;
+    tokens(oldb, l_old, nullptr, no, dummy1, dummy2, false);
+    // ---- A8 forward (kmeans_acoustic_wordseg.py:494-506): lane w of a group holds gamma[t - 1 - w].  The candidates of span
+    // end t are the ones the backward pass would evaluate again (:510-553), so the step also records its decision: kbarr[t] =
+    // length of the best span ending at t (first maximum in w order: the shortest span on ties), 0 when every candidate is -inf
+    uint8_t *kbarr = (uint8_t *)(l_newk + c.N_max);                  // [N_max + 1] (the one-per-wave kernel's counters + tail)
+    double gw = w8 == 0 ? 0.0 : NEG_INF_D;
+    if (w8 == 0 && N > 0) gam[0] = 0.0;
+    double vn = nb > 0 ? bvec[0] : NEG_INF_D;
+    for (int t = 1; t <= N_wave; t++) {
+        const bool act = t <= N;
+        const bool ok = act && w8 < W && t - 1 - w8 >= 0;
+        const double v = vn;
+        {
+            const bool okn = w8 < W && t - w8 >= 0 && t + 1 <= N;
+            vn = bvec[okn ? t * W + w8 : 0];
+        }
+        const double x = ok ? v + gw : NEG_INF_D;
+        const unsigned long long fin = (__ballot(ok && x != NEG_INF_D) >> gsh) & 0xFFull;
+        double mx = x;
+        mx = fmax(mx, seg_dpp_f64<SEG_DPP_XOR1>(mx));
+        mx = fmax(mx, seg_dpp_f64<SEG_DPP_XOR2>(mx));
+        mx = fmax(mx, seg_dpp_f64<SEG_DPP_HMIRROR>(mx));               // the group's eight lanes hold the maximum
+        const unsigned long long at = (__ballot(ok && x == mx) >> gsh) & 0xFFull;
+        if (w8 == 0 && act) {
+            if (t < N) gam[t] = mx;
+            kbarr[t] = (uint8_t)(fin ? __ffsll((long long)at) : 0);
+        }
+        const double gs = seg_dpp_f64<SEG_DPP_SHR1>(gw);            // lane 0 of a group reads its neighbour group's lane 7: overwritten below
+        if (act) gw = w8 == 0 ? mx : gs;
+    }
+    WAVE_SYNC();
+    // ---- A8 backward (:510-553): a walk over the recorded decisions; state = (t, searching)
+    unsigned long long newb = N > 0 ? 1ull << (N - 1) : 0ull;
+    int t = N;
+    bool searching = false, done = N <= 0;
+    double total = 0.0;
+    while (__ballot(!done) != 0ull) {
+        const int kb = done ? 1 : (int)kbarr[t];
+        if (!done) {
+            if (kb == 0) {                                           // every candidate -inf: step back (:516-530)
+                t = t - 1;
+                if (t == 0) {
+                    newb |= 1ull << (N - 1);
+                    total += bvec[(N - 1) * W];                      // python vec[-1]: the last span [N-1, N)
+                    done = true;
+                } else {
+                    searching = true;
+                }
+            } else {
+                if (searching) {
+                    newb |= 1ull << (t - 1);
+                    searching = false;
+                }
+                total += bvec[(t - 1) * W + (kb - 1)];
+                if (t - kb - 1 < 0) done = true;
+                else {
+                    newb |= 1ull << (t - kb - 1);
+                    t = t - kb;
+                }
+            }
+        }
+    }
+    // ---- new tokens + their best components (:312-313)
+    int nn, nfl, bad;
+    tokens(newb, l_new, l_newk, nn, nfl, bad, true);
+    WAVE_SYNC();
+    SEGK_TSTAMP(0, 2);
+    if (valid) {
+        if (w8 == 0) {
+            out_total[u] = total;
+            n_old[u] = no;
+            n_new[u] = nn;
+            if (n_flag) n_flag[u] = nfl;
+            if (bad) atomicOr(status, 1);
+        }
+        for (int j = w8; j < N; j += 8) gbnd[j] = (uint8_t)((newb >> j) & 1ull);
+        for (int j = w8; j < no; j += 8) old_tok[(int64_t)u * c.N_max + j] = l_old[j];
+        // slots beyond the utterance's tokens carry k = -1: the batch statistics scan new_k as it stands
+        for (int j = w8; j < c.N_max; j += 8) {
+            if (j < nn) new_tok[(int64_t)u * c.N_max + j] = l_new[j];
+            new_k[(int64_t)u * c.N_max + j] = j < nn ? l_newk[j] : -1;
+        }
+    }
+    SEGK_TSTAMP_MAX(0, 3);
+}
+
 // The same with TWO utterances per wave (utterances of at most 32 landmarks): a launch over 10 000 utterances
 // is two rounds of resident waves with one utterance each (7 waves per SIMD), and each round costs a wave's
 // whole latency chain (dependent gathers, the serial DP); with two per wave it is one round.
@@ -604,6 +820,17 @@ int32_t segk_kmeans_segment(segk_ctx *ctx, const segk_corpus *c, const segk_kmea
         return SEGK_OK;
     }
     segk_tstamp_bind();
+    // many utterances: eight per wave (SEGK_SEGMENT_OCT=0: one per wave)
+    if (w8_ok && n_utts >= 512 && 8 * wave_bytes <= 64 * 1024 && !(getenv("SEGK_SEGMENT_OCT") && atoi(getenv("SEGK_SEGMENT_OCT")) == 0)) {
+        int ow = 4;
+        while (ow > 1 && (size_t)ow * 8 * wave_bytes > 64 * 1024) ow >>= 1;
+        const int per_block = 8 * ow;
+        hipLaunchKernelGGL(k_kmeans_segment_oct, dim3((n_utts + per_block - 1) / per_block), dim3(64 * ow), (size_t)ow * 8 * wave_bytes, st,
+                           *c, *m, utts, utt0, n_utts, n_slices_max, wip, *cand, boundaries, old_tok, new_tok, new_k, n_old, n_new,
+                           n_flag, out_total, status, band_cap, (int)wave_bytes);
+        SEGK_LAUNCH_CHECK();
+        return SEGK_OK;
+    }
     if (n_slices_max >= 1 && n_slices_max <= 8 && c->N_max <= 64 && !(getenv("SEGK_SEGMENT_GENERIC") && atoi(getenv("SEGK_SEGMENT_GENERIC")))) {
         hipLaunchKernelGGL(k_kmeans_segment_w8, dim3((n_utts + waves - 1) / waves), dim3(64 * waves), lds, st, *c, *m, utts, utt0,
                            n_utts, n_slices_max, wip, *cand, boundaries, old_tok, new_tok, new_k, n_old, n_new, n_flag,
