@@ -98,13 +98,6 @@ int32_t segk_destroy(segk_ctx *ctx)
         if (ctx->rb_koff) (void)hipFree(ctx->rb_koff);
         if (ctx->rb_misc) (void)hipFree(ctx->rb_misc);
         if (ctx->rb_term) (void)hipFree(ctx->rb_term);
-        if (ctx->aux) (void)hipStreamDestroy(ctx->aux);
-        if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
-        if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
-        if (ctx->aux2) (void)hipStreamDestroy(ctx->aux2);
-        if (ctx->ev_join2) (void)hipEventDestroy(ctx->ev_join2);
-        for (int i = 0; i < 8; i++)
-            if (ctx->ev_chunk[i]) (void)hipEventDestroy(ctx->ev_chunk[i]);
         for (int i = 0; i < SEGK_PROF_SLOTS; i++)
             for (int j = 0; j < 2; j++)
                 if (ctx->prof_ev[i][j]) (void)hipEventDestroy(ctx->prof_ev[i][j]);

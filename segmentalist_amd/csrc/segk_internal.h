@@ -31,17 +31,9 @@ struct segk_ctx {
     // batch sampler: the block's tokens bucketed by slot (k_fbb_sort) + offsets
     int32_t *fbs_buf;
     size_t fbs_bytes;
-    // second stream of segk_kmeans_score: the pre-filter's second stage and the full scan run on it beside
-    // the exact stage of the decided rows (created on first use)
-    hipStream_t aux;
-    hipEvent_t ev_fork, ev_join;
-    // chunked pre-filter pipeline: the exact stage of chunk i runs on a third stream beside the pre-filter of chunk i + 1
-    hipStream_t aux2;
-    hipEvent_t ev_chunk[8], ev_join2;
-    int aux2_busy, prof_launches;
-    int aux_runs_pair;            // the second stream carries the exact pair stage, the full scan stays on the caller's stream
+    int prof_launches;
     int32_t *defer_zero;          // segk_kmeans_score: queue length the chosen filter path still has to clear
-    int overlap_req, aux_busy, pre_zeroed;
+    int pre_zeroed;
     int capturing;                // segk_graph_begin .. segk_graph_end
     // value hashes of the rows of the means most recently prepared (segk_kmeans_mark_duplicates)
     unsigned long long *row_hash;

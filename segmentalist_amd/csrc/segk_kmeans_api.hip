@@ -63,7 +63,8 @@ int32_t segk_kmeans_filter(segk_ctx *ctx, const segk_corpus *c, const segk_kmean
         // (round 2: from 384 rows per CU on -- 98 304 -- with the second stage split over component ranges for small
         // queues: a 1 250-utterance shard 5 636 against 5 329 sweeps/s, 2 500 utterances 4 493 against 4 278; at 625
         // utterances the split-precision kernel alone still wins, 7 154 against 6 273)
-        if (c->sp_pieces == 2 && A.fuse_exact && pre_mode != 0 && (pre_mode == 1 || n > 384 * (int64_t)ctx->n_cu) &&
+        const bool small_table = m->K_max < (1 << 24) && (int64_t)m->K_max * c->D * 4 < ((int64_t)1 << 32);      // the exact stage's 32-bit offsets
+        if (c->sp_pieces == 2 && A.fuse_exact && small_table && pre_mode != 0 && (pre_mode == 1 || n > 384 * (int64_t)ctx->n_cu) &&
             n < (int64_t)1 << 30)
             return segk_dispatch_score_pre(ctx, A, segk_b3_kp(c->D) / 16, st);
         segk_flush_deferred_zero(ctx, st);
@@ -124,33 +125,10 @@ int32_t segk_kmeans_score(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans
         rc = segk_kmeans_clear_queue(ctx, cand, stream);
     }
     if (rc) return rc;
-    // SEGK_SCORE_OVERLAP=1: the pre-filter's second stage and the full scan on a second stream beside the exact stage.
-    // Default since the exact stage keeps the component table in LDS (k_kmeans_exact_pair4): everything on the caller's
-    // stream.  That stage now runs at what HBM delivers for 400-byte rows (105 us alone), and a kernel that saturates
-    // HBM stretches every latency chain beside it -- the second stage went from 58 to 100-190 us, the full scan from 35
-    // to 75-125 -- so that the two branches side by side were no shorter than one after the other
-    // (profiles/README.md, r02_z).
-    const char *ov = getenv("SEGK_SCORE_OVERLAP");
-    ctx->overlap_req = (ov && atoi(ov) != 0) ? 1 : 0;
     rc = segk_kmeans_filter(ctx, c, m, ids, row0, n, cand, stream);
-    ctx->overlap_req = 0;
     ctx->pre_zeroed = 0;
     segk_flush_deferred_zero(ctx, (hipStream_t)stream);        // (an early error return of the filter: nothing was launched)
-    if (!ctx->aux_busy) return rc ? rc : segk_resolve_on(ctx, c, m, ids, row0, n, cand, status, stream);
-    // the filter forked the second stream: whatever happened after the fork, join it again, so that the
-    // next call never finds work of this one still running beside the caller's stream
-    const bool pair_on_aux = ctx->aux_runs_pair != 0;
-    ctx->aux_runs_pair = 0;
-    if (!rc) rc = segk_resolve_on(ctx, c, m, ids, row0, n, cand, status, pair_on_aux ? stream : (void *)ctx->aux);
-    ctx->aux_busy = 0;
-    SEGK_CHECK_HIP(hipEventRecord(ctx->ev_join, ctx->aux));
-    SEGK_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, ctx->ev_join, 0));
-    if (ctx->aux2_busy) {                                  // the exact stages of the pre-filter's chunks
-        ctx->aux2_busy = 0;
-        SEGK_CHECK_HIP(hipEventRecord(ctx->ev_join2, ctx->aux2));
-        SEGK_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, ctx->ev_join2, 0));
-    }
-    return rc;
+    return rc ? rc : segk_resolve_on(ctx, c, m, ids, row0, n, cand, status, stream);
 }
 
 int32_t segk_kmeans_sequential_sweep(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m, const int32_t *order, int32_t n_order,

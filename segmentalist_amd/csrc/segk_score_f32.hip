@@ -474,12 +474,10 @@ int segk_dispatch_score_f32(segk_ctx *ctx, const segk_corpus *c, const segk_kmea
 {
     // Rows per wave: one 32-row MFMA column block per wave (108 VGPRs, four workgroups per CU) beat
     // two blocks sharing every LDS tile fetch (194 VGPRs, two per CU) at every row count measured
-    // (D = 100: 77 % vs 73 % of the fp32 matrix peak); SEGK_SCORE_NB=2 selects the latter.
-    const char *nb_env = getenv("SEGK_SCORE_NB");
-    const bool one_block = nb_env ? atoi(nb_env) == 1 : true;   // measured faster at every size for D = 100
+    // (D = 100: 77 % vs 73 % of the fp32 matrix peak): the two-block instantiations were retired in round 3.
     switch (segk_gmax(c->D)) {
 #define SEGK_CASE(g, nb) \
-    case g: return (nb == 2 && !one_block) ? launch_score<g, nb, 4>(ctx, c, m, A, st) : launch_score<g, 1, 4>(ctx, c, m, A, st);
+    case g: return launch_score<g, 1, 4>(ctx, c, m, A, st);
         SEGK_CASE(1, 2) SEGK_CASE(2, 2) SEGK_CASE(4, 2) SEGK_CASE(6, 2) SEGK_CASE(8, 2) SEGK_CASE(10, 2)
         SEGK_CASE(13, 2) SEGK_CASE(16, 2) SEGK_CASE(20, 2) SEGK_CASE(25, 2) SEGK_CASE(26, 2) SEGK_CASE(28, 2)
         SEGK_CASE(32, 2) SEGK_CASE(33, 2) SEGK_CASE(34, 2) SEGK_CASE(40, 1) SEGK_CASE(50, 1) SEGK_CASE(64, 1)

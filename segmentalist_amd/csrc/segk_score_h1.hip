@@ -245,272 +245,12 @@ __global__ __launch_bounds__(256, 2) void k_kmeans_score_h1(ScoreArgs A)
 // reads -- 16 bytes per lane from 64 different rows per instruction, eight waves per CU, one row block
 // after the other -- took 60 % of a workgroup's lifetime (s_memtime stamps, profiles/README.md r01_h).
 // The arithmetic wants a lane to own whole strided accumulators of one (row, member), the memory system
-// wants whole lines: rows and pairs of means (a row is 4 D contiguous bytes, a pair 8 D) are read with
-// consecutive lanes on consecutive 16 bytes, written to LDS and scored from there.  One wave per
-// workgroup, 16 rows per step, private LDS (no barrier); the loads of step i + 1 are in flight while
-// step i is scored.  (Copying by LDS-DMA instead was measured at ~500 cycles per 1 KiB piece with 13
-// waves per CU -- the copy engine, not latency, set the pace: 324 us.)  Row stride KS*16 + 8 floats: the
-// float4 reads of 8 items x 2 lanes fall on distinct banks.
+// wants whole lines.  Two forms are left (the first two -- members staged through LDS lane by lane, members
+// gathered into registers -- were retired in round 3; DESIGN.md section 2 and `git log` have them):
 #define SEGK_PAIR_ROWS 16
-template <int KS>
-__global__ __launch_bounds__(64) void k_kmeans_exact_pair(ScoreArgs A)
-{
-    constexpr int R = SEGK_PAIR_ROWS;
-    constexpr int C4 = KS * 4;                                     // 16-byte slots read per row (>= D / 4)
-    constexpr int LD = KS * 16 + 8;                                // floats per staged row
-    constexpr int RPI = 64 / C4;                                   // rows per load instruction (2 for KS 5..8)
-    constexpr int NLA = (R + RPI - 1) / RPI;                       // load instructions per array
-    extern __shared__ __attribute__((aligned(16))) float lds[];    // [3][R][LD]: x rows, member 0, member 1
-    const int lane = threadIdx.x, D = A.D, D4 = D >> 2;
-    const int64_t n_steps = (A.n + R - 1) / R;
-    const int sub = lane / C4, c4 = lane - sub * C4;               // this lane's row within an instruction, its slot
 
-    // Row ids and pair bases of a step live on lanes 0..R-1.  They are fetched ahead of use and nothing
-    // tests them in the iteration that issues the fetch (a test would wait for every older load as well):
-    //   rid2 (step i + 2): issued in iteration i;  k1 = cand.k[rid1] (step i + 1): issued in iteration i,
-    //   decoded in iteration i + 1 right before that step's loads.
-    auto fetch_rid = [&](int64_t step) -> int32_t {
-        const int64_t r = step * R + lane;
-        int32_t rid = -1;
-        if (step < n_steps && lane < R && r < A.n) rid = A.ids ? A.ids[r] : (int32_t)(A.row0 + r);
-        return rid;
-    };
-    auto fetch_k = [&](int32_t rid) -> int32_t { return rid >= 0 ? A.cand.k[rid] : 0; };
-    float4 v[3 * NLA];
-    // rows 2t, 2t + 1 (RPI = 2) of array arr per instruction: consecutive lanes on consecutive 16 bytes
-    uint64_t *rowp = reinterpret_cast<uint64_t *>(lds + 3 * R * LD);     // [3][R] row addresses of the step being loaded
-    auto issue_loads = [&](int32_t rid, int32_t c, int64_t step_) {
-        // 64-bit row addresses once per step, by the rows' own lanes, through LDS: the load instructions
-        // below cost a ds_read_b64 and an add each -- no multiply, no lane exchange.  Every load is
-        // unconditional (a branch around each of the 24 cost more than the loads): a row that is skipped
-        // reads its own float32 row and the first means (never used), a lane without a slot re-reads its
-        // neighbour's last 16 bytes (same cache line).
-        if (lane < R) {
-            const bool live = rid >= 0;
-            int64_t r_any = rid;
-            if (!live) {                                       // some valid row: this step's own when the rows are a range
-                r_any = A.ids ? 0 : A.row0 + step_ * R + lane;
-                if (r_any >= A.row0 + A.n || A.ids) r_any = A.ids ? 0 : A.row0;
-            }
-            const uint64_t xp = (uint64_t)(uintptr_t)(A.xrows32 + r_any * A.ld32);
-            const uint64_t mp0 = (uint64_t)(uintptr_t)(A.means32 + (int64_t)(live ? c : 0) * D);
-            rowp[lane] = xp;
-            rowp[R + lane] = mp0;
-            rowp[2 * R + lane] = (live && c + 1 < A.K_max) ? mp0 + (uint64_t)D * 4 : mp0;
-        }
-        const int sub_c = sub < RPI ? sub : RPI - 1;
-        const unsigned off = 16u * (unsigned)(c4 < D4 ? c4 : D4 - 1);
-        uint64_t base[3 * NLA];
-#pragma unroll
-        for (int arr = 0; arr < 3; arr++)
-#pragma unroll
-            for (int t = 0; t < NLA; t++)
-                base[arr * NLA + t] = rowp[arr * R + ((RPI * t + sub_c) & (R - 1))];
-#pragma unroll
-        for (int i = 0; i < 3 * NLA; i++) {
-            // an integer turned pointer is a FLAT pointer to the compiler (flat loads, and the staging array in
-            // scratch: 900 us); say that it is global memory
-            typedef float f32x4_t __attribute__((ext_vector_type(4)));
-            typedef const __attribute__((address_space(1))) f32x4_t *gptr_t;
-            const f32x4_t t_ = *reinterpret_cast<gptr_t>((uintptr_t)(base[i] + off));
-            v[i] = make_float4(t_.x, t_.y, t_.z, t_.w);
-        }
-    };
-    auto decode = [&](int32_t &rid, int32_t k) -> int32_t {       // pair base, or -1 (and rid = -1) when not pending
-        // (a valid mark only: non-negative, pair base inside the component range -- whatever else the caller's
-        // candidate buffer holds for a row the pre-filter did not decide is left alone)
-        if (rid >= 0 && k >= 0 && (k & SEGK_PAIR_PENDING) && (k & ~SEGK_PAIR_PENDING) < A.K_max) return k & ~SEGK_PAIR_PENDING;
-        rid = -1;
-        return -1;
-    };
-
-    int64_t step = blockIdx.x;
-    int32_t rid0 = fetch_rid(step);
-    int32_t c0 = decode(rid0, fetch_k(rid0));
-    issue_loads(rid0, c0, step);
-    int32_t rid1 = fetch_rid(step + gridDim.x);
-    int32_t k1 = fetch_k(rid1);
-    int32_t rid2 = fetch_rid(step + 2 * (int64_t)gridDim.x);
-#ifdef SEGK_STAMP
-#define SEGK_STAMP_P(i) do { if (A.stamp && lane == 0 && it_ == 3) A.stamp[65536 + (int64_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define SEGK_STAMP_P(i) do { } while (0)
-#endif
-    int it_ = 0;
-    for (; step < n_steps; step += gridDim.x, it_++) {
-        SEGK_STAMP_P(0);
-#pragma unroll
-        for (int arr = 0; arr < 3; arr++)
-#pragma unroll
-            for (int t = 0; t < NLA; t++)
-                if (sub < RPI && RPI * t + sub < R)
-                    *reinterpret_cast<float4 *>(lds + (arr * R + RPI * t + sub) * LD + 4 * c4) = v[arr * NLA + t];
-        SEGK_STAMP_P(1);
-        const int32_t ridc = rid0, cc0 = c0;
-        const int32_t c1 = decode(rid1, k1);
-        issue_loads(rid1, c1, step + gridDim.x);                   // the next step's rows: in flight under this step's arithmetic
-        rid0 = rid1; c0 = c1;
-        rid1 = rid2;
-        k1 = fetch_k(rid1);
-        rid2 = fetch_rid(step + 3 * (int64_t)gridDim.x);
-        SEGK_STAMP_P(2);
-        // lanes 4 r + {0, 1}: member 0 of row r; lanes 4 r + {2, 3}: member 1 (LDS operations of one wave
-        // complete in order: the reads below see the writes above)
-        const int item = lane >> 1, h = lane & 1, row = item >> 1, mem = item & 1;
-        const float sc = sp_exact_score_x<KS, 1>(lds + ((1 + mem) * R + row) * LD, lds + row * LD, D, h);
-        const float so = __shfl_xor(sc, 2);
-        const int32_t rid = __shfl(ridc, row), c = __shfl(cc0, row);
-        if ((lane & 3) == 0 && rid >= 0) {
-            const bool second = c + 1 < A.K_max && so > sc;
-            A.cand.k[rid] = second ? c + 1 : c;
-            A.cand.s[rid] = (double)(second ? so : sc);
-        }
-        SEGK_STAMP_P(3);
-    }
-#undef SEGK_STAMP_P
-}
-
-// Second form of the exact pair stage (default; SEGK_PAIR_V=1 selects the first): only the float32 ROWS go through LDS.
-// The two means of an item are read by the item's own two lanes straight into registers -- 16 bytes per lane at the
-// offsets sp_exact_score_x wants (8 b + 4 h), 2 KS + 1 loads per lane, all in flight together.  The 400 KB of `means`
-// live in L2 (and partly in L1), so that what the first form staged and re-read through LDS (two thirds of its LDS
-// traffic, 16 of its 24 staging loads per step, 15 of its 23 KB of LDS per wave) becomes L2 hits into registers:
-// 8 KB of LDS per wave, twice the waves per CU.
-template <int KS>
-__global__ __launch_bounds__(64) void k_kmeans_exact_pair2(ScoreArgs A)
-{
-    constexpr int R = SEGK_PAIR_ROWS;
-    constexpr int C4 = KS * 4;                                     // 16-byte slots read per row (>= D / 4)
-    constexpr int LD = KS * 16 + 8;                                // floats per staged row
-    constexpr int RPI = 64 / C4;                                   // rows per load instruction (2 for KS 5..8)
-    constexpr int NLA = (R + RPI - 1) / RPI;                       // load instructions per step
-    extern __shared__ __attribute__((aligned(16))) float lds[];    // [R][LD] x rows, then [R] row addresses
-    const int lane = threadIdx.x, D = A.D, D4 = D >> 2;
-    const int64_t n_steps = (A.n + R - 1) / R;
-    const int sub = lane / C4, c4 = lane - sub * C4;               // this lane's row within an instruction, its slot
-    typedef float f32x4_t __attribute__((ext_vector_type(4)));
-    typedef const __attribute__((address_space(1))) f32x4_t *gptr_t;
-
-    auto fetch_rid = [&](int64_t step) -> int32_t {
-        const int64_t r = step * R + lane;
-        int32_t rid = -1;
-        if (step < n_steps && lane < R && r < A.n) rid = A.ids ? A.ids[r] : (int32_t)(A.row0 + r);
-        return rid;
-    };
-    auto fetch_k = [&](int32_t rid) -> int32_t { return rid >= 0 ? A.cand.k[rid] : 0; };
-    f32x4_t v[NLA];
-    uint64_t *rowp = reinterpret_cast<uint64_t *>(lds + R * LD);
-    auto issue_x = [&](int32_t rid, int64_t step_) {
-        if (lane < R) {
-            int64_t r_any = rid;
-            if (rid < 0) {                                     // some valid row: this step's own when the rows are a range
-                r_any = A.ids ? 0 : A.row0 + step_ * R + lane;
-                if (r_any >= A.row0 + A.n || A.ids) r_any = A.ids ? 0 : A.row0;
-            }
-            rowp[lane] = (uint64_t)(uintptr_t)(A.xrows32 + r_any * A.ld32);
-        }
-        const int sub_c = sub < RPI ? sub : RPI - 1;
-        const unsigned off = 16u * (unsigned)(c4 < D4 ? c4 : D4 - 1);
-#pragma unroll
-        for (int t = 0; t < NLA; t++) v[t] = *reinterpret_cast<gptr_t>((uintptr_t)(rowp[(RPI * t + sub_c) & (R - 1)] + off));
-    };
-    auto decode = [&](int32_t &rid, int32_t k) -> int32_t {       // pair base, or -1 (and rid = -1) when not pending
-        if (rid >= 0 && k >= 0 && (k & SEGK_PAIR_PENDING) && (k & ~SEGK_PAIR_PENDING) < A.K_max) return k & ~SEGK_PAIR_PENDING;
-        rid = -1;
-        return -1;
-    };
-
-    const int item = lane >> 1, h = lane & 1, row = item >> 1, mem = item & 1;
-    const int nfull = D & ~7, nblk = nfull >> 3, rem = D & 7;
-    const bool tail = nfull + 4 * h < D;
-
-    // this item's means of one step into registers: the member c + mem, clamped into the table (the result of a member
-    // beyond it is dropped)
-    f32x4_t mreg[2 * KS], mt;
-    auto issue_m = [&](int32_t rid_l, int32_t c_l) {
-        const int32_t rid = __shfl(rid_l, row), c = __shfl(c_l, row);
-        int cm = rid >= 0 ? c + mem : 0;
-        if (cm >= A.K_max) cm = A.K_max - 1;
-        const uintptr_t mp = (uintptr_t)(A.means32 + (int64_t)cm * D + 4 * h);
-#pragma unroll
-        for (int b = 0; b < 2 * KS; b++) mreg[b] = *reinterpret_cast<gptr_t>(mp + 32u * (unsigned)(b < nblk ? b : 0));
-        mt = *reinterpret_cast<gptr_t>(mp + 4u * (unsigned)(tail ? nfull : 0));
-    };
-
-    // Software pipeline, one step deep for everything a step waits on: while step s is summed, the rows AND the means of
-    // step s + 1 are in flight (the candidates of s + 1 were fetched during s - 1, the row numbers of s + 2 during s - 1).
-    // With the means fetched in the step that uses them a step cost two dependent L2 round trips and the stage ran
-    // 2.5x off its HBM floor on six waves per CU.
-    int64_t step = blockIdx.x;
-    int32_t rid0 = fetch_rid(step);
-    int32_t c0 = decode(rid0, fetch_k(rid0));
-    issue_x(rid0, step);
-    issue_m(rid0, c0);
-    int32_t rid1 = fetch_rid(step + gridDim.x);
-    int32_t k1 = fetch_k(rid1);
-    int32_t rid2 = fetch_rid(step + 2 * (int64_t)gridDim.x);
-    for (; step < n_steps; step += gridDim.x) {
-        const int32_t rid = __shfl(rid0, row), c = __shfl(c0, row);
-        f32x4_t mc[2 * KS];
-#pragma unroll
-        for (int b = 0; b < 2 * KS; b++) mc[b] = mreg[b];
-        const f32x4_t mtc = mt;
-        // the staged rows of this step into LDS, the next step's loads into flight
-#pragma unroll
-        for (int t = 0; t < NLA; t++)
-            if (sub < RPI && RPI * t + sub < R) *reinterpret_cast<f32x4_t *>(lds + (RPI * t + sub) * LD + 4 * c4) = v[t];
-        const int32_t c1 = decode(rid1, k1);
-        issue_x(rid1, step + gridDim.x);
-        issue_m(rid1, c1);
-        rid0 = rid1; c0 = c1;
-        rid1 = rid2;
-        k1 = fetch_k(rid1);
-        rid2 = fetch_rid(step + 3 * (int64_t)gridDim.x);
-        // the reference's float32 -(deltas*deltas).sum() in numpy's pairwise order (sp_exact_score_x with the mean in
-        // registers): this lane owns the strided accumulators r_{4h..4h+3}
-        const float *xrow = lds + row * LD + 4 * h;
-        float r4[4] = {0.f, 0.f, 0.f, 0.f}, tt[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int b = 0; b < 2 * KS; b++) {
-            if (b < nblk) {
-                const f32x4_t xv = *reinterpret_cast<const f32x4_t *>(xrow + 8 * b);
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const float delta = mc[b][q] - xv[q];
-                    const float t2 = delta * delta;
-                    r4[q] = b == 0 ? t2 : r4[q] + t2;
-                }
-            }
-        }
-        if (tail) {
-            const f32x4_t xt = *reinterpret_cast<const f32x4_t *>(xrow + nfull);
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const float delta = mtc[q] - xt[q];
-                tt[q] = delta * delta;
-            }
-        }
-        float res = (r4[0] + r4[1]) + (r4[2] + r4[3]);
-        const float ro = __shfl_xor(res, 1);
-        res = (h == 0) ? res + ro : ro + res;                      // ((r0+r1)+(r2+r3)) + ((r4+r5)+(r6+r7))
-        const float u0 = __shfl_xor(tt[0], 1), u1 = __shfl_xor(tt[1], 1), u2 = __shfl_xor(tt[2], 1), u3 = __shfl_xor(tt[3], 1);
-        const float t0 = h == 0 ? tt[0] : u0, t1 = h == 0 ? tt[1] : u1, t2 = h == 0 ? tt[2] : u2, t3 = h == 0 ? tt[3] : u3;
-        if (rem > 0) res += t0;
-        if (rem > 1) res += t1;
-        if (rem > 2) res += t2;
-        if (rem > 3) res += t3;
-        const float sc = -res;
-        const float so = __shfl_xor(sc, 2);
-        if ((lane & 3) == 0 && rid >= 0) {
-            const bool second = c + 1 < A.K_max && so > sc;
-            A.cand.k[rid] = second ? c + 1 : c;
-            A.cand.s[rid] = (double)(second ? so : sc);
-        }
-    }
-}
-
-// Third form of the exact stage.  The second form's per-lane gathers of the means (16 bytes per lane, two lanes per
-// 400-byte row and instruction) touch 32 cache lines per load instruction: 49 M tag lookups in the vector L1 for 1.3 GB,
+// k_kmeans_exact_pair3 (tables that need more than eight LDS ranges).  Per-lane gathers of the means (16 bytes per lane, two
+// lanes per 400-byte row and instruction) touch 32 cache lines per load instruction: 49 M tag lookups in the vector L1 for 1.3 GB,
 // one per clock and CU -- the stage ran at the L1's lookup rate (137 us alone), not at the memory system's
 // (profiles/README.md, r02_t).  Here the member rows are loaded the way the x rows are -- whole rows, RPI per
 // instruction, 7 lines each -- and transposed through LDS: 0.2 M lookups per CU instead of 0.75 M.  Everything a step
@@ -872,11 +612,10 @@ static int launch_score_pre(segk_ctx *ctx, ScoreArgs A, hipStream_t st)
     const int64_t slots = 2 * (int64_t)ctx->n_cu;      // two 4-wave workgroups per CU (launch bounds)
     // whole rounds of 512-row workgroups (four row blocks per wave), the remainder in 256-row workgroups
     const int64_t round4 = slots * 512;
-    int64_t n4 = (A.n / round4) * round4;
-    if (getenv("SEGK_PRE_NBLK") && atoi(getenv("SEGK_PRE_NBLK")) == 2) n4 = 0;      // development: 256-row workgroups only
+    const int64_t n4 = (A.n / round4) * round4;
     const bool prof = ctx->prof_on != 0;
     const int slot = ctx->prof_n % SEGK_PROF_SLOTS;
-    // the timed interval (segk_profile_*): the 512-row-workgroup launches when there are any, else the 256-row one
+    // the timed interval (segk_profile_*): the 512-row-workgroup launch when there is one, else the 256-row one
     auto prof_end = [&](int64_t rows, int launches) -> int {
         if (!prof) return SEGK_OK;
         SEGK_CHECK_HIP(hipEventRecord(ctx->prof_ev[slot][1], st));
@@ -886,33 +625,19 @@ static int launch_score_pre(segk_ctx *ctx, ScoreArgs A, hipStream_t st)
         ctx->prof_n++;
         return SEGK_OK;
     };
-    const bool overlap = ctx->overlap_req != 0;
-    // Pipeline over chunks of whole rounds (SEGK_PRE_CHUNKS = 2..8; default 1 = off: measured on MI355X it LOSES -- beside
-    // the exact stage a pre-filter chunk takes 88-114 us instead of 67, 1 378 sweeps/s against 1 580, profiles/README.md
-    // r02_c -- the kernels compete for the same CUs and the same power budget): the pre-filter of chunk i + 1 runs on the
-    // caller's stream while the exact stage of chunk i (third stream) and its second stage (second stream) work on the
-    // rows chunk i decided / queued -- matrix-bound beside memory- and latency-bound kernels.  Every chunk has its own
-    // queue counter (header word `ch`) and its own region of the queue (at the chunk's first row: it cannot overflow).
-    int n_chunks = 1;
-    if (overlap && n4 > 0) {
-        const char *ce = getenv("SEGK_PRE_CHUNKS");
-        int want = ce ? atoi(ce) : 1;
-        if (want < 1) want = 1;
-        if (want > 8) want = 8;
-        const int64_t rounds = n4 / round4;
-        n_chunks = (int)(rounds < want ? rounds : want);
-    }
-    // a short remainder is only queued (first chunk's queue): first, so that nothing small sits between the big
-    // launches and the kernels waiting for them
+    // Everything on the caller's stream, one launch per stage.  Retired in round 3 after losing on MI355X
+    // (profiles/README.md r02_c, r02_z; `git log` has the code): a pipeline over chunks of rounds with the exact stage and
+    // the second stage of chunk i on two more streams beside the pre-filter of chunk i + 1 (-13 %: the kernels compete
+    // for the same CUs and the same power budget), and the second stage + full scan on a second stream beside the exact
+    // stage (no gain once that stage ran at HBM speed: it stretches every latency chain beside it).
+    // a short remainder is only queued: first, so that nothing small sits between the big launches
     const int64_t rem = A.n - n4;
     const bool rem_queued = rem > 0 && rem < SEGK_TAIL_QUEUE && n4 > 0;
-    const int64_t rounds_per_chunk = n4 > 0 ? (n4 / round4 + n_chunks - 1) / n_chunks : 0;
-    const int64_t chunk_rows = rounds_per_chunk * round4;
     ScoreArgs T = A;
     T.n = rem;
     T.row0 = A.row0 + n4;
     T.ids = A.ids ? A.ids + n4 : nullptr;
-    T.pre_cap = (int)(n_chunks > 1 ? chunk_rows : cap2);
+    T.pre_cap = (int)cap2;
     if (rem_queued) {                                  // one start-up kernel: clear the counters, queue the remainder
         hipLaunchKernelGGL(k_pre_begin, dim3(1), dim3(1024), 0, st, T, zero_cnt, ctx->pre_queue);
         zero_pending = false;
@@ -921,71 +646,32 @@ static int launch_score_pre(segk_ctx *ctx, ScoreArgs A, hipStream_t st)
         if (zero_cnt) hipLaunchKernelGGL(k_zero_two, dim3(1), dim3(64), 0, st, zero_cnt, ctx->pre_queue);
         else SEGK_CHECK_HIP(hipMemsetAsync(ctx->pre_queue, 0, 16 * sizeof(int32_t), st));
     }
-    hipStream_t st2 = st, st3 = st;
-    if (overlap) {
-        if (!ctx->aux) {
-            SEGK_CHECK_HIP(hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking));
-            SEGK_CHECK_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-            SEGK_CHECK_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
-        }
-        if (n_chunks > 1 && !ctx->aux2) {
-            SEGK_CHECK_HIP(hipStreamCreateWithFlags(&ctx->aux2, hipStreamNonBlocking));
-            SEGK_CHECK_HIP(hipEventCreateWithFlags(&ctx->ev_join2, hipEventDisableTiming));
-            for (int i = 0; i < 8; i++) SEGK_CHECK_HIP(hipEventCreateWithFlags(&ctx->ev_chunk[i], hipEventDisableTiming));
-        }
-        st2 = ctx->aux;
-        ctx->aux_busy = 1;
-        if (n_chunks > 1) {
-            st3 = ctx->aux2;
-            ctx->aux2_busy = 1;
-        }
-    }
-    const char *pv = getenv("SEGK_PAIR_V");
-    // 3: whole-row loads transposed through LDS, pipelined (default; its 32-bit offsets into the means want a table < 4 GB)
-    const bool small_table = A.K_max < (1 << 24) && (int64_t)A.K_max * A.D * 4 < ((int64_t)1 << 32);
-    // 4: the table in LDS, split into at most 8 ranges (default)
+    // The exact stage: the component table in LDS, split into at most 8 ranges, eight waves, one workgroup per CU
+    // (k_kmeans_exact_pair4); larger tables: whole-row loads transposed through LDS, pipelined (k_kmeans_exact_pair3; 32-bit
+    // offsets into the means: segk_kmeans_filter takes this path for tables under 4 GB only)
     const int pitch4 = ((A.D >> 2) + ((2 - (A.D >> 2)) & 3)) * 16;
-    // SEGK_PAIR4_WAVES: 4 or 8 waves per workgroup (one workgroup per CU)
-    const char *p4w = getenv("SEGK_PAIR4_WAVES");
-    const int nw4 = p4w && atoi(p4w) == 4 ? 4 : 8;
-    const int64_t lds4_budget = (overlap ? 122 : 158) * 1024 - nw4 * SEGK_PAIR4_RING * (int64_t)sizeof(int2);
+    constexpr int nw4 = 8;
+    const int64_t lds4_budget = 158 * 1024 - nw4 * SEGK_PAIR4_RING * (int64_t)sizeof(int2);
     const int64_t cpp_max = lds4_budget / pitch4 - 1;
     const int parts4 = cpp_max > 0 ? (int)((A.K_max + cpp_max - 1) / cpp_max) : 99;
     const int cpp4 = parts4 > 0 ? (A.K_max + parts4 - 1) / parts4 : 0;
-    const int pair_v = pv ? atoi(pv) : (parts4 <= 8 && ctx->n_cu >= parts4 ? 4 : small_table ? 3 : 2);
-    const bool pair1 = pair_v == 1;
+    const int pair_v = (parts4 <= 8 && ctx->n_cu >= parts4) ? 4 : 3;
     const int d4 = A.D >> 2, pitch_slots = d4 + ((2 - d4) & 3);
-    const size_t lds_p = pair1 ? 3 * (size_t)SEGK_PAIR_ROWS * (KS * 16 + 8) * sizeof(float) + 3 * SEGK_PAIR_ROWS * sizeof(uint64_t)
-                         : pair_v == 2 ? (size_t)SEGK_PAIR_ROWS * (KS * 16 + 8) * sizeof(float) + SEGK_PAIR_ROWS * sizeof(uint64_t)
-                                       : 3 * (size_t)SEGK_PAIR_ROWS * pitch_slots * 16;
-    const char *pw = getenv("SEGK_PAIR_WAVES");
-    // waves per CU: the second form could hold 12 (registers: three per SIMD), but beside the second stage -- the head of
-    // the longer branch -- 6 is the measured optimum (12: 1 555, 8: 1 598, 6: 1 626 sweeps/s; profiles/README.md r02_d)
-    const int max_waves = pw ? atoi(pw) : (pair1 ? 8 : 6);
-    // exact stage of the rows [r0, r0 + nr) of this call on stream `sx`
-    auto launch_pair = [&](int64_t r0, int64_t nr, hipStream_t sx) {
-        ScoreArgs P = A;
-        P.n = nr;
-        P.row0 = A.row0 + r0;
-        P.ids = A.ids ? A.ids + r0 : nullptr;
-        const int64_t steps = (nr + SEGK_PAIR_ROWS - 1) / SEGK_PAIR_ROWS;
-        int64_t waves = (int64_t)ctx->n_cu * (int64_t)(((overlap ? 124 : 160) * 1024) / lds_p);
+    const size_t lds_p = 3 * (size_t)SEGK_PAIR_ROWS * pitch_slots * 16;
+    const int max_waves = 6;                           // pair3: waves per CU (12: 1 555, 8: 1 598, 6: 1 626 sweeps/s; r02_d)
+    auto launch_pair = [&]() {
+        const ScoreArgs &P = A;
+        const int64_t steps = (A.n + SEGK_PAIR_ROWS - 1) / SEGK_PAIR_ROWS;
+        int64_t waves = (int64_t)ctx->n_cu * (int64_t)((160 * 1024) / lds_p);
         if (waves > max_waves * (int64_t)ctx->n_cu) waves = max_waves * (int64_t)ctx->n_cu;
         if (waves > steps) waves = steps;
-        if (pair1) hipLaunchKernelGGL((k_kmeans_exact_pair<KS>), dim3((unsigned)waves), dim3(64), lds_p, sx, P);
-        else if (pair_v == 2) hipLaunchKernelGGL((k_kmeans_exact_pair2<KS>), dim3((unsigned)waves), dim3(64), lds_p, sx, P);
-        else if (pair_v == 4) {
+        if (pair_v == 4) {
             const size_t lds4 = (size_t)(cpp4 + 1) * pitch4 + nw4 * SEGK_PAIR4_RING * sizeof(int2);
             const unsigned grid4 = (unsigned)((ctx->n_cu / parts4) * parts4);
-#define SEGK_PAIR4_LAUNCH_W(VV, WW)                                                                                               \
-    do {                                                                                                                           \
-        (void)hipFuncSetAttribute((const void *)k_kmeans_exact_pair4<KS, VV, WW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4); \
-        hipLaunchKernelGGL((k_kmeans_exact_pair4<KS, VV, WW>), dim3(grid4), dim3(64 * WW), lds4, sx, P, parts4, cpp4);             \
-    } while (0)
 #define SEGK_PAIR4_LAUNCH(VV)                                                                                                      \
     do {                                                                                                                           \
-        if (nw4 == 4) SEGK_PAIR4_LAUNCH_W(VV, 4);                                                                                  \
-        else SEGK_PAIR4_LAUNCH_W(VV, 8);                                                                                           \
+        (void)hipFuncSetAttribute((const void *)k_kmeans_exact_pair4<KS, VV, nw4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4); \
+        hipLaunchKernelGGL((k_kmeans_exact_pair4<KS, VV, nw4>), dim3(grid4), dim3(64 * nw4), lds4, st, P, parts4, cpp4);            \
     } while (0)
             switch ((16 * KS - A.D) / 4) {
                 case 0: SEGK_PAIR4_LAUNCH(0); break;
@@ -993,68 +679,21 @@ static int launch_score_pre(segk_ctx *ctx, ScoreArgs A, hipStream_t st)
                 case 2: SEGK_PAIR4_LAUNCH(2); break;
                 default: SEGK_PAIR4_LAUNCH(3); break;
             }
-#undef SEGK_PAIR4_LAUNCH_W
 #undef SEGK_PAIR4_LAUNCH
         } else {
-            if (!small_table) { segk_set_error("exact pair stage: component table of 4 GB or more (SEGK_PAIR_V=2)"); return; }
             switch ((16 * KS - A.D) / 4) {
-                case 0: hipLaunchKernelGGL((k_kmeans_exact_pair3<KS, 0>), dim3((unsigned)waves), dim3(64), lds_p, sx, P); break;
-                case 1: hipLaunchKernelGGL((k_kmeans_exact_pair3<KS, 1>), dim3((unsigned)waves), dim3(64), lds_p, sx, P); break;
-                case 2: hipLaunchKernelGGL((k_kmeans_exact_pair3<KS, 2>), dim3((unsigned)waves), dim3(64), lds_p, sx, P); break;
-                default: hipLaunchKernelGGL((k_kmeans_exact_pair3<KS, 3>), dim3((unsigned)waves), dim3(64), lds_p, sx, P); break;
+                case 0: hipLaunchKernelGGL((k_kmeans_exact_pair3<KS, 0>), dim3((unsigned)waves), dim3(64), lds_p, st, P); break;
+                case 1: hipLaunchKernelGGL((k_kmeans_exact_pair3<KS, 1>), dim3((unsigned)waves), dim3(64), lds_p, st, P); break;
+                case 2: hipLaunchKernelGGL((k_kmeans_exact_pair3<KS, 2>), dim3((unsigned)waves), dim3(64), lds_p, st, P); break;
+                default: hipLaunchKernelGGL((k_kmeans_exact_pair3<KS, 3>), dim3((unsigned)waves), dim3(64), lds_p, st, P); break;
             }
         }
     };
-    // second stage (all three products) of the rows queued in region [q0, q0 + cap) under counter `ch`; the row count is read on the device
-    auto launch_second = [&](int64_t q0, int64_t cap, int ch, hipStream_t sx) -> int {
-        ScoreArgs B = A;
-        B.ids = A.pre_queue + q0;
-        B.row0 = 0;
-        B.n = cap;
-        B.n_dev = ctx->pre_queue + ch;
-        return segk_launch_sp_second(ctx, B, KS, sx);
-    };
     if (prof) SEGK_CHECK_HIP(hipEventRecord(ctx->prof_ev[slot][0], st));
-    if (n_chunks > 1) {
-        int launched = 0;
-        for (int ch = 0; ch < n_chunks; ch++) {
-            const int64_t r0 = ch * chunk_rows;
-            const int64_t nr = r0 + chunk_rows <= n4 ? chunk_rows : n4 - r0;
-            if (nr <= 0) break;
-            ScoreArgs M = A;
-            M.n = nr;
-            M.row0 = A.row0 + r0;
-            M.ids = A.ids ? A.ids + r0 : nullptr;
-            M.pre_queue = A.pre_queue + r0;
-            M.pre_count = ctx->pre_queue + ch;
-            M.pre_cap = (int)nr;
-            hipLaunchKernelGGL((k_kmeans_score_h1<KS, 4>), dim3((unsigned)(nr / 512)), dim3(256), lds, st, M);
-            launched++;
-            SEGK_CHECK_HIP(hipEventRecord(ctx->ev_chunk[ch], st));
-            SEGK_CHECK_HIP(hipStreamWaitEvent(st3, ctx->ev_chunk[ch], 0));
-            launch_pair(r0, nr, st3);
-            SEGK_CHECK_HIP(hipStreamWaitEvent(st2, ctx->ev_chunk[ch], 0));
-            if (int rc = launch_second(r0, nr, ch, st2)) return rc;
-        }
-        if (int rc = prof_end(n4, launched)) return rc;
-        if (rem > 0 && !rem_queued) {                          // a long remainder: one more chunk of 256-row workgroups
-            T.pre_queue = A.pre_queue + n4;
-            T.pre_count = ctx->pre_queue + n_chunks;
-            T.pre_cap = (int)rem;
-            hipLaunchKernelGGL((k_kmeans_score_h1<KS, 2>), dim3((unsigned)((rem + 255) / 256)), dim3(256), lds, st, T);
-            SEGK_CHECK_HIP(hipEventRecord(ctx->ev_chunk[n_chunks], st));
-            SEGK_CHECK_HIP(hipStreamWaitEvent(st3, ctx->ev_chunk[n_chunks], 0));
-            launch_pair(n4, rem, st3);
-            SEGK_CHECK_HIP(hipStreamWaitEvent(st2, ctx->ev_chunk[n_chunks], 0));
-            if (int rc = launch_second(n4, rem, n_chunks, st2)) return rc;
-        }
-        SEGK_LAUNCH_CHECK();
-        return SEGK_OK;
-    }
     if (n4 > 0) {
         ScoreArgs M = A;
         M.n = n4;
-        const char *abl = getenv("SEGK_H1_ABL");
+        const char *abl = getenv("SEGK_H1_ABL");                     // development, timing only
         const int ab = abl ? atoi(abl) : 0;
         if (ab == 1) hipLaunchKernelGGL((k_kmeans_score_h1<KS, 4, 1>), dim3((unsigned)(n4 / 512)), dim3(256), lds, st, M);
         else if (ab == 2) hipLaunchKernelGGL((k_kmeans_score_h1<KS, 4, 2>), dim3((unsigned)(n4 / 512)), dim3(256), lds, st, M);
@@ -1067,26 +706,17 @@ static int launch_score_pre(segk_ctx *ctx, ScoreArgs A, hipStream_t st)
         if (n4 == 0)
             if (int rc = prof_end(rem, 1)) return rc;
     }
-    // The decided rows' exact stage (this stream) and the undecided rows' second stage + full scan (second
-    // stream, segk_kmeans_score only) touch disjoint rows: side by side, the exact stage leaving LDS for one
-    // second-stage workgroup per CU.  Joined at the end of segk_kmeans_score.  (The other way round -- the longer
-    // branch on the caller's stream, so that the join finds its event already fired -- was measured SLOWER, 1 503
-    // against 1 622 sweeps/s: the exact stage then starts a cross-stream signal later and both branches are about
-    // equally long.)
-    // SEGK_SCORE_ORDER=1: the second stage first and alone (it is matrix-bound, 580 TFLOP/s on its 49 k rows, and
-    // gains nothing from sharing the chip), then the fork: the exact stage, which saturates HBM, beside the full scan
-    // of the ~1 600 rows left, which is a chain of latencies.
-    const char *oe = getenv("SEGK_SCORE_ORDER");
-    const bool second_first = oe && atoi(oe) == 1;
-    if (second_first)
-        if (int rc = launch_second(0, cap2, 0, st)) return rc;
-    if (overlap) {
-        SEGK_CHECK_HIP(hipEventRecord(ctx->ev_fork, st));
-        SEGK_CHECK_HIP(hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
+    // the decided rows' exact stage, then the undecided rows' second stage (all three products; its row count is read on
+    // the device); the full scan of what that leaves follows in segk_kmeans_score
+    launch_pair();
+    {
+        ScoreArgs B = A;
+        B.ids = A.pre_queue;
+        B.row0 = 0;
+        B.n = cap2;
+        B.n_dev = ctx->pre_queue;
+        if (int rc = segk_launch_sp_second(ctx, B, KS, st)) return rc;
     }
-    launch_pair(0, A.n, st);
-    if (!second_first)
-        if (int rc = launch_second(0, cap2, 0, st2)) return rc;
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;
 }

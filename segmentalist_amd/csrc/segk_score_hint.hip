@@ -734,23 +734,20 @@ static int launch_score_hint(segk_ctx *ctx, ScoreArgs A, const int32_t *remap, i
     H.stamp = getenv("SEGK_STAMP_PTR") ? (unsigned long long *)strtoull(getenv("SEGK_STAMP_PTR"), nullptr, 0) : nullptr;
 #endif
     const size_t lds1 = (size_t)tpr * TL * sizeof(float);
-    // SEGK_HINT_WAVES: 4 (default) = one wave per SIMD with the next group's rows prefetched into registers; 8 = two waves per
-    // SIMD, no prefetch (section 4 of DESIGN.md has the measurements)
-    const char *we = getenv("SEGK_HINT_WAVES");
-    const int nw1 = we && atoi(we) == 8 ? 8 : 4;
+    // four waves per workgroup: one per SIMD with the next group's rows prefetched into registers (the eight-wave
+    // instantiation -- two per SIMD, no prefetch: +6 % -- is still in the kernel's template, no longer launched)
+    constexpr int nw1 = 4;
     int grid1 = (n_cu / n_ranges) * n_ranges;
-    {   // no more workgroups than there are steps per range (each wave takes 128 rows at a time)
-        const int64_t rows_ws = (nw1 == 8 ? 128 : 64) * (int64_t)nw1;      // rows a workgroup takes per step
+    {   // no more workgroups than there are steps per range (each wave takes 64 rows at a time)
+        const int64_t rows_ws = 64 * (int64_t)nw1;                          // rows a workgroup takes per step
         const int64_t steps = (A.n + rows_ws - 1) / rows_ws;
         if ((int64_t)grid1 / n_ranges > steps) grid1 = (int)steps * n_ranges;
     }
-    if (nw1 == 8) SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_kmeans_top2_rs<KS, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
-    else SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_kmeans_top2_rs<KS, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+    SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_kmeans_top2_rs<KS, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
     const bool prof = ctx->prof_on != 0;
     const int slot = ctx->prof_n % SEGK_PROF_SLOTS;
     if (prof) SEGK_CHECK_HIP(hipEventRecord(ctx->prof_ev[slot][0], st));
-    if (nw1 == 8) hipLaunchKernelGGL((k_kmeans_top2_rs<KS, 8>), dim3((unsigned)grid1), dim3(512), lds1, st, H);
-    else hipLaunchKernelGGL((k_kmeans_top2_rs<KS, 4>), dim3((unsigned)grid1), dim3(256), lds1, st, H);
+    hipLaunchKernelGGL((k_kmeans_top2_rs<KS, 4>), dim3((unsigned)grid1), dim3(256), lds1, st, H);
     if (prof) {
         SEGK_CHECK_HIP(hipEventRecord(ctx->prof_ev[slot][1], st));
         ctx->prof_rows[slot] = A.n;

@@ -491,18 +491,16 @@ static int launch_sp_second(segk_ctx *ctx, const ScoreArgs &B, hipStream_t st)
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
         attr_set = true;
     }
-    // SEGK_SP2_SPLIT: ranges of component tiles per row block (1: the plain kernel); SEGK_SP2_GRID: workgroups (row blocks in
-    // flight) of the launch, default two per CU
-    // default by the size of the launch: a workgroup walks the 32 tiles of its row block in ~55 us however few blocks
-    // there are, so that short queues (a multi-GPU shard) gain from the split although the stage is matrix-bound on the
-    // whole corpus (1.05 M rows: 1 588 unsplit against 1 500 split)
-    const char *se = getenv("SEGK_SP2_SPLIT"), *ge = getenv("SEGK_SP2_GRID");
+    // ranges of component tiles per row block (1: the plain kernel), by the size of the launch: a workgroup walks the 32 tiles
+    // of its row block in ~55 us however few blocks there are, so that short queues (a multi-GPU shard) gain from the split
+    // although the stage is matrix-bound on the whole corpus (1.05 M rows: 1 588 unsplit against 1 500 split); two workgroups
+    // (row blocks in flight) per CU
     const int64_t per_cu = ctx->n_cu > 0 ? B.n / ctx->n_cu : B.n;
-    int n_split = se ? atoi(se) : (per_cu <= 1536 ? 4 : per_cu <= 3072 ? 2 : 1);
+    int n_split = per_cu <= 1536 ? 4 : per_cu <= 3072 ? 2 : 1;
     if (n_split > B.n_tiles) n_split = B.n_tiles;
     if (n_split > 8) n_split = 8;
     const int64_t blocks = (B.n + 127) / 128;
-    int64_t grid = ge ? atoi(ge) : 2 * (int64_t)ctx->n_cu;
+    int64_t grid = 2 * (int64_t)ctx->n_cu;
     if (grid > blocks) grid = blocks;
     if (grid < 1) grid = 1;
     if (n_split <= 1 || ctx->capturing) {

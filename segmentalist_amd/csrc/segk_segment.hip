@@ -252,7 +252,7 @@ __global__ void k_kmeans_segment_w8(segk_corpus c, segk_kmeans m, const int32_t 
 // launch over 10 000 utterances is 1 250 waves instead of 10 000.  (One utterance per wave took 29 us: 2 500 workgroups to
 // dispatch, 14 us of life each -- gathers 5.7, DP 7.9 under that load.)  Token lists by the group's eight lanes, eight
 // boundary bits per step; the backward pass as a state machine with one candidate evaluation per trip, so that groups in
-// different phases share the loop.  Same values and decisions as seg_w8_serial.
+// different phases share the loop.  Same values and decisions as seg_w8_wave.
 __global__ __launch_bounds__(256) void k_kmeans_segment_oct(segk_corpus c, segk_kmeans m, const int32_t *utts, int utt0, int n_utts,
                                                             int n_max, double wip, segk_cand cand, uint8_t *boundaries, int32_t *old_tok,
                                                             int32_t *new_tok, int32_t *new_k, int32_t *n_old, int32_t *n_new, int32_t *n_flag,
@@ -463,185 +463,6 @@ __global__ __launch_bounds__(256) void k_kmeans_segment_oct(segk_corpus c, segk_
     SEGK_TSTAMP_MAX(0, 3);
 }
 
-// The same with TWO utterances per wave (utterances of at most 32 landmarks): a launch over 10 000 utterances
-// is two rounds of resident waves with one utterance each (7 waves per SIMD), and each round costs a wave's
-// whole latency chain (dependent gathers, the serial DP); with two per wave it is one round.
-__global__ void k_kmeans_segment_w8x2(segk_corpus c, segk_kmeans m, const int32_t *utts, int utt0, int n_utts,
-                                    int n_max, double wip, segk_cand cand, uint8_t *boundaries, int32_t *old_tok,
-                                    int32_t *new_tok, int32_t *new_k, int32_t *n_old, int32_t *n_new, int32_t *n_flag,
-                                    double *out_total, int32_t *status, int band_cap, int wave_bytes)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    // two utterances per wave: lanes 0..31 and 32..63 (N <= 32), the two DPs on lanes 0 and 32 in lockstep
-    const int half = (threadIdx.x >> 5) & 1, lane = threadIdx.x & 31, wv = threadIdx.x >> 6;
-    const int slot = (blockIdx.x * (blockDim.x >> 6) + wv) * 2 + half;
-    const bool valid = slot < n_utts;
-    const int u = valid ? (utts ? utts[slot] : utt0 + slot) : (utts ? utts[0] : utt0);
-    const int N = valid ? c.lengths[u] : 0;
-    const int W = (n_max > 0 && n_max < N) ? n_max : N;          // <= 8 (host checks n_max <= 8)
-    const int nb = N * W;
-    const int64_t triMax = (int64_t)c.N_max * (c.N_max + 1) / 2;
-    const int32_t *vid = c.vec_ids + (int64_t)u * triMax;
-    const double *dur = c.durations + (int64_t)u * triMax;
-    // banded span tables (segk_corpus.band_ids / band_dur), when they were built for this window
-    const bool band = c.band_ids != nullptr && c.band_W == W && W > 0;
-    const int32_t *bandi = band ? c.band_ids + (int64_t)u * c.N_max * c.band_W : nullptr;
-    const double *bandd = band ? c.band_dur + (int64_t)u * c.N_max * c.band_W : nullptr;
-    uint8_t *gbnd = boundaries + (int64_t)u * c.N_max;
-
-    char *base = smem + (size_t)(wv * 2 + half) * wave_bytes;
-    double *bvec = (double *)base;                    // [band_cap]
-    double *gam = bvec + band_cap;                    // [N_max + 1]
-    int32_t *bk = (int32_t *)(gam + c.N_max + 1);     // [band_cap]
-    int32_t *bid = bk + band_cap;                     // [band_cap]
-    int32_t *l_old = bid + band_cap;                  // [N_max]
-    int32_t *l_new = l_old + c.N_max;                 // [N_max]
-    int32_t *l_newk = l_new + c.N_max;                // [N_max]
-    int32_t *l_cnt = l_newk + c.N_max;                // [6]: n_old, n_new, new boundary mask (2 words), flagged, bad
-
-    for (int i = lane; i < nb; i += 32) {
-        const int t = i / W + 1, w = i % W, s = t - 1 - w;
-        int id = -1;
-        double v = NEG_INF_D;
-        int k = -1;
-        if (s >= 0) {
-            const int j = t * (t - 1) / 2 + s;
-            id = band ? bandi[i] : vid[j];               // banded image: lane i reads entry i
-            if (id >= 0) {
-                k = cand.k[id];
-                const double dd = band ? bandd[i] : dur[j];
-                v = isnan(dd) ? NEG_INF_D : cand.s[id] * dd;      // :346-349
-            }
-        }
-        bid[i] = id;
-        bk[i] = k;
-        bvec[i] = v + wip;                                       // :351
-    }
-    const unsigned long long oldb = (__ballot(lane < N && gbnd[lane < N ? lane : 0] != 0) >> (32 * half)) & 0xffffffffull;
-    WAVE_SYNC();
-    if (lane == 0 && valid) {
-#define V_(t, s) bvec[((t) - 1) * W + ((t) - 1 - (s))]
-#define ID_(t, s) (((t) - 1 - (s)) < W ? bid[((t) - 1) * W + ((t) - 1 - (s))] : vid[(t) * ((t) - 1) / 2 + (s)])
-        // ---- old tokens (utterances.py:159-174)
-        int no = 0, jp = 0;
-        for (unsigned long long mb = oldb; mb; mb &= mb - 1) {
-            const int j = __ffsll((long long)mb) - 1;
-            const int id = ID_(j + 1, jp);
-            if (id >= 0) l_old[no++] = id;
-            jp = j + 1;
-        }
-        // ---- A8 forward (kmeans_acoustic_wordseg.py:494-506): g[w] = gamma[t - 1 - w]
-        double g[8];
-#pragma unroll
-        for (int w = 0; w < 8; w++) g[w] = NEG_INF_D;
-        g[0] = 0.0;
-        gam[0] = 0.0;
-        for (int t = 1; t < N; t++) {
-            double v[8];
-#pragma unroll
-            for (int w = 0; w < 8; w++) {                  // unconditional loads from a clamped index, then the predicate
-                const bool ok = w < W && t - 1 - w >= 0;
-                v[w] = bvec[ok ? (t - 1) * W + w : 0];
-            }
-            double best = NEG_INF_D;
-#pragma unroll
-            for (int w = 7; w >= 0; w--) {                 // s ascending, as the reference's max() scans
-                const bool ok = w < W && t - 1 - w >= 0;
-                const double x = v[w] + g[w];
-                if (ok && x > best) best = x;
-            }
-            gam[t] = best;
-#pragma unroll
-            for (int w = 7; w > 0; w--) g[w] = g[w - 1];
-            g[0] = best;
-        }
-        unsigned long long newb = 1ull << (N - 1);
-        // candidates of span end tt: are they all -inf; and the reversed np.argmax (shortest span on ties)
-        auto eval = [&](int tt, int &kb) -> bool {
-            double x[8];
-#pragma unroll
-            for (int w = 0; w < 8; w++) {
-                const bool ok = w < W && tt - 1 - w >= 0;
-                x[w] = bvec[ok ? (tt - 1) * W + w : 0] + gam[ok ? tt - 1 - w : 0];
-            }
-            double best = NEG_INF_D;
-            bool first = true, ai = true;
-#pragma unroll
-            for (int w = 0; w < 8; w++) {                  // s = tt - 1 - w descending
-                const bool ok = w < W && tt - 1 - w >= 0;
-                if (ok) {
-                    if (x[w] != NEG_INF_D) ai = false;
-                    if (first || x[w] > best) { best = x[w]; kb = w + 1; first = false; }
-                }
-            }
-            return ai;
-        };
-        // ---- A8 backward (:510-553)
-        int t = N;
-        double total = 0.0;
-        for (;;) {
-            int kb = 1;
-            bool all_inf = eval(t, kb);
-            if (all_inf) {                                 // step back until some candidate is finite (:516-530)
-                while (all_inf) {
-                    t = t - 1;
-                    if (t == 0) break;
-                    all_inf = eval(t, kb);
-                }
-                newb |= 1ull << ((t - 1 + N) % N);
-            }
-            int k = 1;
-            if (t > 0) {
-                k = kb;
-                total += V_(t, t - k);
-            } else {
-                total += V_(N, N - 1);      // python vec[-1]: the last span [N-1, N)
-            }
-            if (t - k - 1 < 0) break;
-            newb |= 1ull << (t - k - 1);
-            t = t - k;
-        }
-        // ---- new tokens + their best components (:312-313)
-        int nn = 0, bad = 0, nf = 0;
-        const int Kact = *m.K;
-        jp = 0;
-        for (unsigned long long mb = newb; mb; mb &= mb - 1) {
-            const int j = __ffsll((long long)mb) - 1;
-            const int tt = j + 1, w = tt - 1 - jp;
-            if (w >= W || bid[(tt - 1) * W + w] < 0) bad = 1;
-            else {
-                l_new[nn] = bid[(tt - 1) * W + w];
-                l_newk[nn] = bk[(tt - 1) * W + w];
-                if (l_newk[nn] >= Kact) nf++;
-                nn++;
-            }
-            jp = j + 1;
-        }
-        out_total[u] = total;
-        n_old[u] = no;
-        n_new[u] = nn;
-        if (n_flag) n_flag[u] = nf;
-        l_cnt[0] = no;
-        l_cnt[1] = nn;
-        l_cnt[2] = (int32_t)(newb & 0xffffffffull);
-        l_cnt[3] = (int32_t)(newb >> 32);
-        if (bad) atomicOr(status, 1);
-#undef V_
-#undef ID_
-    }
-    WAVE_SYNC();
-    if (!valid) return;
-    const int no = l_cnt[0], nn = l_cnt[1];
-    const unsigned long long newb = ((unsigned long long)(unsigned int)l_cnt[3] << 32) | (unsigned int)l_cnt[2];
-    if (lane < N) gbnd[lane] = (uint8_t)((newb >> lane) & 1ull);
-    for (int j = lane; j < no; j += 32) old_tok[(int64_t)u * c.N_max + j] = l_old[j];
-    // slots beyond the utterance's tokens carry k = -1: the batch statistics scan new_k as it stands
-    for (int j = lane; j < c.N_max; j += 32) {
-        if (j < nn) new_tok[(int64_t)u * c.N_max + j] = l_new[j];
-        new_k[(int64_t)u * c.N_max + j] = j < nn ? l_newk[j] : -1;
-    }
-}
-
 // ======================================================================================
 // Function-level DPs on caller-supplied vectors (drop-in for the module functions
 // forward_backward_kmeans_viterbi / forward_backward / forward_backward_viterbi):
@@ -806,23 +627,13 @@ int32_t segk_kmeans_segment(segk_ctx *ctx, const segk_corpus *c, const segk_kmea
         SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_kmeans_segment, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)lds));
     const bool w8_ok = n_slices_max >= 1 && n_slices_max <= 8 && c->N_max <= 64 && !(getenv("SEGK_SEGMENT_GENERIC") && atoi(getenv("SEGK_SEGMENT_GENERIC")));
-    // SEGK_SEGMENT_X2=1: two utterances per wave, their serial DPs on lanes 0 and 32 in lockstep -- the default for launches
-    // over more than one round of resident waves until the DP of the one-per-wave kernel was spread over the wave
-    // (seg_w8_wave: 10 000 utterances 40 -> 29 us)
-    const char *x2e = getenv("SEGK_SEGMENT_X2");
     (void)ctx;
-    if (w8_ok && c->N_max <= 32 && 2 * waves * wave_bytes <= 48 * 1024 && (x2e ? atoi(x2e) != 0 : false)) {
-        const int per_block = 2 * waves;
-        hipLaunchKernelGGL(k_kmeans_segment_w8x2, dim3((n_utts + per_block - 1) / per_block), dim3(64 * waves), 2 * lds, st, *c, *m, utts,
-                           utt0, n_utts, n_slices_max, wip, *cand, boundaries, old_tok, new_tok, new_k, n_old, n_new, n_flag,
-                           out_total, status, band_cap, (int)wave_bytes);
-        SEGK_LAUNCH_CHECK();
-        return SEGK_OK;
-    }
     segk_tstamp_bind();
     // many utterances: eight per wave (SEGK_SEGMENT_OCT=0: one per wave).  Both forms are latency chains; at 1 250 utterances
     // the one-per-wave form is the shorter one (12 against 16 us), at 10 000 this one (21 against 30)
-    if (w8_ok && n_utts >= 4096 && 8 * wave_bytes <= 64 * 1024 && !(getenv("SEGK_SEGMENT_OCT") && atoi(getenv("SEGK_SEGMENT_OCT")) == 0)) {
+    const char *oce = getenv("SEGK_SEGMENT_OCT");           // 0: never, 1: at every size (tests)
+    const int oct_mode = oce ? atoi(oce) : -1;
+    if (w8_ok && oct_mode != 0 && (oct_mode == 1 || n_utts >= 4096) && 8 * wave_bytes <= 64 * 1024) {
         int ow = 4;
         while (ow > 1 && (size_t)ow * 8 * wave_bytes > 64 * 1024) ow >>= 1;
         const int per_block = 8 * ow;

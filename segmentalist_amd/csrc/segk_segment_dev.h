@@ -9,124 +9,14 @@
         __builtin_amdgcn_wave_barrier();                        \
     } while (0)
 
-// The serial part of the window-of-eight segmenter, run by ONE lane on wave-private LDS arrays (k_kmeans_segment_w8 and the
+// The window-of-eight segmenter of ONE utterance by a whole wave, on wave-private LDS arrays (k_kmeans_segment_w8 and the
 // persistent sequential chain, segk_seq_chain.hip): old tokens from the old boundary mask, A8 forward and backward, the new
 // tokens and their components.  bvec / bid / bk hold the band (entry (t, w) at [(t - 1) * W + w]); results: l_old, l_new,
 // l_newk and l_cnt = {n_old, n_new, new boundary mask (2 words), tokens on inactive components, bad}.
-__device__ __forceinline__ void seg_w8_serial(const double *bvec, double *gam, const int32_t *bid, const int32_t *bk, const int32_t *vid,
-                                              int N, int W, unsigned long long oldb, int Kact, int32_t *l_old, int32_t *l_new,
-                                              int32_t *l_newk, int32_t *l_cnt, double *total_out)
-{
-#define V_(t, s) bvec[((t) - 1) * W + ((t) - 1 - (s))]
-#define ID_(t, s) (((t) - 1 - (s)) < W ? bid[((t) - 1) * W + ((t) - 1 - (s))] : vid[(t) * ((t) - 1) / 2 + (s)])
-    // ---- old tokens (utterances.py:159-174)
-    int no = 0, jp = 0;
-    for (unsigned long long mb = oldb; mb; mb &= mb - 1) {
-        const int j = __ffsll((long long)mb) - 1;
-        const int id = ID_(j + 1, jp);
-        if (id >= 0) l_old[no++] = id;
-        jp = j + 1;
-    }
-    // ---- A8 forward (kmeans_acoustic_wordseg.py:494-506): g[w] = gamma[t - 1 - w]
-    double g[8];
-#pragma unroll
-    for (int w = 0; w < 8; w++) g[w] = NEG_INF_D;
-    g[0] = 0.0;
-    gam[0] = 0.0;
-    for (int t = 1; t < N; t++) {
-        double v[8];
-#pragma unroll
-        for (int w = 0; w < 8; w++) {                  // unconditional loads from a clamped index, then the predicate
-            const bool ok = w < W && t - 1 - w >= 0;
-            v[w] = bvec[ok ? (t - 1) * W + w : 0];
-        }
-        double best = NEG_INF_D;
-#pragma unroll
-        for (int w = 7; w >= 0; w--) {                 // s ascending, as the reference's max() scans
-            const bool ok = w < W && t - 1 - w >= 0;
-            const double x = v[w] + g[w];
-            if (ok && x > best) best = x;
-        }
-        gam[t] = best;
-#pragma unroll
-        for (int w = 7; w > 0; w--) g[w] = g[w - 1];
-        g[0] = best;
-    }
-    unsigned long long newb = 1ull << (N - 1);
-    // candidates of span end tt: are they all -inf; and the reversed np.argmax (shortest span on ties)
-    auto eval = [&](int tt, int &kb) -> bool {
-        double x[8];
-#pragma unroll
-        for (int w = 0; w < 8; w++) {
-            const bool ok = w < W && tt - 1 - w >= 0;
-            x[w] = bvec[ok ? (tt - 1) * W + w : 0] + gam[ok ? tt - 1 - w : 0];
-        }
-        double best = NEG_INF_D;
-        bool first = true, ai = true;
-#pragma unroll
-        for (int w = 0; w < 8; w++) {                  // s = tt - 1 - w descending
-            const bool ok = w < W && tt - 1 - w >= 0;
-            if (ok) {
-                if (x[w] != NEG_INF_D) ai = false;
-                if (first || x[w] > best) { best = x[w]; kb = w + 1; first = false; }
-            }
-        }
-        return ai;
-    };
-    // ---- A8 backward (:510-553)
-    int t = N;
-    double total = 0.0;
-    for (;;) {
-        int kb = 1;
-        bool all_inf = eval(t, kb);
-        if (all_inf) {                                 // step back until some candidate is finite (:516-530)
-            while (all_inf) {
-                t = t - 1;
-                if (t == 0) break;
-                all_inf = eval(t, kb);
-            }
-            newb |= 1ull << ((t - 1 + N) % N);
-        }
-        int k = 1;
-        if (t > 0) {
-            k = kb;
-            total += V_(t, t - k);
-        } else {
-            total += V_(N, N - 1);      // python vec[-1]: the last span [N-1, N)
-        }
-        if (t - k - 1 < 0) break;
-        newb |= 1ull << (t - k - 1);
-        t = t - k;
-    }
-    // ---- new tokens + their best components (:312-313)
-    int nn = 0, bad = 0, nf = 0;
-    jp = 0;
-    for (unsigned long long mb = newb; mb; mb &= mb - 1) {
-        const int j = __ffsll((long long)mb) - 1;
-        const int tt = j + 1, w = tt - 1 - jp;
-        if (w >= W || bid[(tt - 1) * W + w] < 0) bad = 1;
-        else {
-            l_new[nn] = bid[(tt - 1) * W + w];
-            l_newk[nn] = bk[(tt - 1) * W + w];
-            if (l_newk[nn] >= Kact) nf++;
-            nn++;
-        }
-        jp = j + 1;
-    }
-    l_cnt[0] = no;
-    l_cnt[1] = nn;
-    l_cnt[2] = (int32_t)(newb & 0xffffffffull);
-    l_cnt[3] = (int32_t)(newb >> 32);
-    l_cnt[4] = nf;
-    l_cnt[5] = bad;
-    *total_out = total;
-#undef V_
-#undef ID_
-}
-
+// A one-lane form of the same (14 us of dependent fp64 operations and LDS round trips per utterance, measured inside the
+// persistent chain) was retired in round 3.
 // ---- the same, by a whole wave --------------------------------------------------------------------------------------------
-// seg_w8_serial costs 14 us of dependent fp64 operations and LDS round trips on one lane (measured inside the persistent
-// chain).  Here lane w < 8 owns candidate w of a DP step -- one add, a three-step DPP maximum over the eight lanes, a DPP
+// Lane w < 8 owns candidate w of a DP step -- one add, a three-step DPP maximum over the eight lanes, a DPP
 // shift of the gammas -- and the token lists are built by the lanes of the set boundary bits side by side (rank = prefix
 // popcount of a ballot).  Same values and the same decisions: the forward pass needs the maximum's VALUE only; the backward
 // pass takes the first maximum in w order (the reference's reversed np.argmax: the shortest span on ties).  Control flow

@@ -480,10 +480,6 @@ int segk_launch_seq_chain(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m, c
     int cp2 = 1;
     while (cp2 < cpw) cp2 <<= 1;                            // the components of a span sit on a power-of-two group of lanes
     cpw = cp2 < 8 ? 8 : cp2;
-    if (const char *ce = getenv("SEGK_CHAIN_CPW")) {        // development: 4, 8, 16, 32 components per workgroup
-        const int v = atoi(ce);
-        if (v == 4 || v == 8 || v == 16 || v == 32 || v == 64) cpw = v;
-    }
     if (cpw > 64) return SEGK_ERR_UNSUPPORTED;
     G = (m->K_max + cpw - 1) / cpw;
     const int D = c->D, ldm = ((D >> 2) & 1) ? D : D + 4;

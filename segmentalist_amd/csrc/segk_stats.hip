@@ -1720,8 +1720,7 @@ int32_t segk_kmeans_batch_partials(segk_ctx *ctx, const segk_corpus *c, const se
     (void)n_flag;
     segk_tstamp_bind();
     const int NR = segk_sort_ranges(m->K_max), rsh = segk_sort_rsh(m->K_max), nsh = segk_sort_nsh(m->K_max);
-    const bool fuse = c->x_dtype == SEGK_F32 && c->D <= 128 && (c->D & 1) == 0 && (c->ldx & 1) == 0 &&
-                      !(getenv("SEGK_PARTIALS_FUSED") && atoi(getenv("SEGK_PARTIALS_FUSED")) == 0);
+    const bool fuse = c->x_dtype == SEGK_F32 && c->D <= 128 && (c->D & 1) == 0 && (c->ldx & 1) == 0;
     {
         size_t lds = (size_t)(16 + 2) * (1 << rsh) * 4 + (size_t)16 * SORT_CL * 4;
         if (lds < 2048 * sizeof(double)) lds = 2048 * sizeof(double);

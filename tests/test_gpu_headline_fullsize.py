@@ -52,9 +52,7 @@ def headline(gpu, monkeypatch_module):
     """The headline segmenter after two batch sweeps (default environment)."""
     from segmentalist_amd import kmeans_acoustic_wordseg as kaw
     from segmentalist_amd.synth import make_corpus
-    for v in ("SEGK_SCORE_PRE", "SEGK_SCORE_B3", "SEGK_SCORE_OVERLAP", "SEGK_MARK_DUPS", "SEGK_PRE_NBLK", "SEGK_PRE_CHUNKS",
-              "SEGK_PAIR_V", "SEGK_PAIR_WAVES", "SEGK_PAIR4_WAVES", "SEGK_SCORE_ORDER", "SEGK_SP2_SPLIT", "SEGK_SP2_GRID",
-              "SEGK_SWEEP_GRAPH"):
+    for v in ("SEGK_SCORE_PRE", "SEGK_SCORE_B3", "SEGK_SCORE_HINT", "SEGK_MARK_DUPS", "SEGK_SEGMENT_OCT", "SEGK_SWEEP_GRAPH"):
         monkeypatch_module.delenv(v, raising=False)
     corpus = make_corpus(N_UTT, D, K, seed=0, N=N_LM, n_slices_max=NMAX)
     random.seed(0)
@@ -124,18 +122,12 @@ def test_a_every_row_matches_the_oracle_argmax_and_score(headline, scored):
     assert (scored["cand_k"] >= 0).all() and (scored["cand_k"] < K).all()
 
 
-@pytest.mark.parametrize("env", [{"SEGK_PRE_CHUNKS": "4", "SEGK_SCORE_OVERLAP": "1"}, {"SEGK_PAIR_V": "1"}, {"SEGK_PAIR_V": "2"},
-                                 {"SEGK_PAIR_V": "3"}, {"SEGK_SCORE_OVERLAP": "1", "SEGK_PAIR4_WAVES": "4"},
-                                 {"SEGK_SCORE_OVERLAP": "1", "SEGK_SCORE_ORDER": "1"}, {"SEGK_SP2_SPLIT": "4"},
-                                 {"SEGK_SCORE_PRE": "0"}],
-                         ids=["chunked_pipeline", "pair_stage_first_form", "pair_stage_second_form", "pair_stage_third_form",
-                              "two_streams", "two_streams_second_stage_first", "split_second_stage", "no_prefilter"])
+@pytest.mark.parametrize("env", [{"SEGK_SCORE_PRE": "0"}, {"SEGK_SCORE_B3": "0"}], ids=["no_prefilter", "fp32_matrix_filter"])
 def test_a_optional_launch_plans_give_the_same_bits(gpu, headline, scored, monkeypatch, env):
-    """The opt-in launch plans of the score stage (pre-filter in chunks with the exact stage of chunk i beside the
-    pre-filter of chunk i + 1 on three streams; the three earlier forms of the exact pair kernel; second stage and full
-    scan on a second stream beside the exact stage, in either order; the second stage split over component ranges; the
-    split-precision kernel alone) on the same 1.05 M rows and statistics: cand_k / cand_s identical to the values test_a
-    verified against the oracle."""
+    """The other filters in front of the exact stages (the split-precision kernel alone; the fp32-MFMA filter of float64 data
+    and unusual D) on the same 1.05 M rows and statistics: cand_k / cand_s identical to the values test_a verified against
+    the oracle.  (The launch plans round 2 also tested here -- chunked pipeline, second stream, earlier forms of the exact
+    stage -- lost on this hardware and were retired in round 3.)"""
     seg, _ = headline
     dk = seg._dk
     for k, v in env.items():

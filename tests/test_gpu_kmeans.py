@@ -524,13 +524,14 @@ def test_split_precision_filter_wide_dynamic_range(gpu, monkeypatch, pieces):
 # ------------------------------------------------------------------ one-product pre-filter
 @pytest.mark.parametrize("D,K,n,scale", [(100, 1000, 4096, 1.0), (128, 513, 3000, 1.0), (40, 257, 2500, 30.0),
                                          (16, 64, 1500, 1e-3), (8, 31, 700, 1.0), (64, 33, 5000, 7e3),
-                                         (108, 130, 3000, 1.0), (12, 40, 2000, 1.0), (28, 70, 2500, 0.1)])
+                                         (108, 130, 3000, 1.0), (12, 40, 2000, 1.0), (28, 70, 2500, 0.1), (100, 3100, 3000, 1.0)])
 def test_prefilter_decisions_are_the_references(gpu, monkeypatch, D, K, n, scale):
     """SEGK_SCORE_PRE=1 forces the one-product fp16 pre-filter (normally used above one round of the
     chip) in front of the split-precision kernel: max / argmax after the exact stage stay the
     reference's bit for bit -- clustered rows, an exact tie, a duplicated mean inside one PAIR of
     components (the pre-filter tracks pairs and lets the exact stage pick the member).  The shapes cover the four
-    compile-time layouts of the exact stage (D = 16 KS - 4 V, V = 0..3) and tables of one and several LDS ranges."""
+    compile-time layouts of the exact stage (D = 16 KS - 4 V, V = 0..3), tables of one and several LDS ranges, and one that
+    needs more than eight (K = 3100: the exact stage that transposes whole rows through LDS, k_kmeans_exact_pair3)."""
     from oracle import c_oracle as co
     monkeypatch.setenv("SEGK_SCORE_PRE", "1")
     rs = np.random.RandomState(D * 1000 + K + 1)
@@ -716,14 +717,14 @@ def test_persistent_sequential_chain_equals_the_three_launch_form(gpu, monkeypat
 @pytest.mark.parametrize("n_utt,D,K,N,nmax,ragged", [(400, 16, 40, 20, 6, False), (300, 8, 25, 0, 8, True), (200, 12, 30, 0, 3, True)])
 def test_segment_kernels_agree(gpu, monkeypatch, n_utt, D, K, N, nmax, ragged):
     """The per-utterance DP by the whole wave (seg_w8_wave: eight lanes per step, DPP maxima, token lists from ballots; the
-    default), by one lane with two utterances per wave (SEGK_SEGMENT_X2=1: seg_w8_serial's arithmetic) and the generic kernel
-    (SEGK_SEGMENT_GENERIC=1): identical boundaries, labels and statistics after three batch sweeps -- uniform utterances,
-    ragged ones shorter than the window, a window of eight."""
+    default below 4 096 utterances), with eight utterances per wave (k_kmeans_segment_oct, the default above; forced here with
+    SEGK_SEGMENT_OCT=1) and the generic kernel (SEGK_SEGMENT_GENERIC=1): identical boundaries, labels and statistics after
+    three batch sweeps -- uniform utterances, ragged ones shorter than the window, a window of eight."""
     from segmentalist_amd import kmeans_acoustic_wordseg as kaw
     corpus = cases.chain_corpus(n_utt, D, K, 31 * n_utt + D, ragged, N, nmax, "float32")
     out = []
-    for env in ({}, {"SEGK_SEGMENT_X2": "1"}, {"SEGK_SEGMENT_GENERIC": "1"}):
-        for k in ("SEGK_SEGMENT_X2", "SEGK_SEGMENT_GENERIC"):
+    for env in ({"SEGK_SEGMENT_OCT": "0"}, {"SEGK_SEGMENT_OCT": "1"}, {"SEGK_SEGMENT_GENERIC": "1"}):
+        for k in ("SEGK_SEGMENT_OCT", "SEGK_SEGMENT_GENERIC"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
