@@ -362,6 +362,40 @@ def test_batch_sweep_bit_exact_vs_spec(gpu, n_utt, D, K, nmax, dtype, n_blocks):
             assert rec["n_tokens"][0] == ref.acoustic_model.get_n_assigned()
 
 
+@pytest.mark.parametrize("n_utt,D,K,N,nmax,n_blocks,sweeps,p_b", [(150, 16, 2500, 0, 6, 8, 3, 0.5), (1700, 8, 12, 20, 4, 1, 2, 0.7),
+                                                                (1000, 8, 2, 20, 1, 1, 2, 1.0), (900, 12, 70, 20, 2, 2, 2, 0.8)],
+                         ids=["ranges_of_128_components", "block_beyond_the_preloaded_keys", "compaction_overflow",
+                              "two_large_blocks"])
+def test_batch_statistics_kernel_fallbacks_vs_spec(gpu, n_utt, D, K, N, nmax, n_blocks, sweeps, p_b):
+    """k_batch_sort_sum (csrc/segk_stats.hip) beyond the headline shape, against oracle/np_oracle.py kmeans_batch_sweep bit for bit:
+    K_max > 2048 (ranges of 128 components instead of 32); a statistics block of more than 32 768 slots (its keys are not
+    preloaded, the placement pass walks all slots again); more than 512 in-range tokens per wave (a window of one slice makes
+    every landmark a token, two components share one range: the compacted list overflows and the workgroup falls back to the
+    walk); two blocks of 9 000 slots with long per-component lists (several 32-row batches per list, component boundaries
+    inside a batch)."""
+    from oracle import np_oracle as no
+    from segmentalist_amd import kmeans_acoustic_wordseg as kaw
+    from segmentalist_amd.synth import make_corpus
+    corpus = make_corpus(n_utt, D, K, seed=4000 + n_utt, N=N, ragged=(N == 0), n_slices_max=nmax, N_range=(3, 9))
+    random.seed(5); np.random.seed(5)
+    ref = no.SegmentalKMeansWordseg(K, *corpus, n_slices_max=nmax, init_am_assignments="spread", p_boundary_init=p_b)
+    random.seed(5); np.random.seed(5)
+    seg = kaw.SegmentalKMeansWordseg(K, *corpus, n_slices_max=nmax, init_am_assignments="spread", p_boundary_init=p_b, sync="batch",
+                                     n_stat_blocks=n_blocks, flag_cap=40000)       # (one block: every token near an inactive row is on its list)
+    cr, cd = ref.acoustic_model.components, seg.acoustic_model.components
+    for it in range(sweeps):
+        want = no.kmeans_batch_sweep(ref, n_blocks=n_blocks)
+        rec = seg.segment(1)
+        assert np.array_equal(seg.utterances.boundaries, ref.utterances.boundaries), it
+        assert np.array_equal(cd.assignments, cr.assignments), it
+        assert cd.K == cr.K
+        assert np.array_equal(cd.counts, cr.counts)
+        assert np.array_equal(cd.mean_numerators, cr.mean_numerators), it
+        assert np.array_equal(cd.means, cr.means), it
+        assert rec["sum_neg_len_sqrd_norm"][0] == want
+        assert rec["n_tokens"][0] == ref.acoustic_model.get_n_assigned()
+
+
 @pytest.mark.parametrize("n_utt,D,K,nmax,n_blocks,n_batches", [(40, 16, 12, 6, 4, 2), (64, 8, 9, 5, 8, 4), (33, 12, 30, 4, 2, 8),
                                                              (24, 5, 4, 5, 1, 3), (300, 100, 130, 6, 8, 2)])
 def test_minibatch_sweep_bit_exact_vs_spec(gpu, n_utt, D, K, nmax, n_blocks, n_batches):
