@@ -285,7 +285,8 @@ int32_t segk_kmeans_del_component(segk_ctx *ctx, const segk_corpus *c, segk_kmea
  * to the reference's chain).  Where the configuration allows (D % 4 = 0, 8 <= D <= 128, at most 32 landmarks per
  * utterance, 1 <= n_slices_max <= 8) the sweep runs as ONE persistent kernel (segk_seq_chain.hip: ~19 us per
  * utterance on the headline corpus); the call then synchronises `stream` after every launch of it (one launch per
- * stretch of utterances between two emptied components).  Otherwise, and with SEGK_SEQ_CHAIN=0: three launches
+ * stretch of utterances between two emptied components; not inside a graph capture).  Otherwise -- also when an
+ * utterance occurs twice in `order`, which the persistent kernel's prefetch could not handle -- and with SEGK_SEQ_CHAIN=0: three launches
  * per utterance, all enqueued (~44 us per utterance).  keys_scratch [dev] uint64 [N_max (N_max + 1) / 2 + 2],
  * zeroed by the caller once.  float32 data; SEGK_ERR_UNSUPPORTED otherwise.                                   */
 int32_t segk_kmeans_sequential_sweep(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m,

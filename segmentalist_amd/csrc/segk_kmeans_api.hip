@@ -1,5 +1,6 @@
-// segk_kmeans_api.hip -- C ABI of the score stage: filter selection (pre-filter / split precision / fp32 MFMA), two-stream join
+// segk_kmeans_api.hip -- C ABI of the score stage: filter selection (hinted / pre-filter / split precision / fp32 MFMA) and the sequential sweep
 // (one of the translation units of the k-means path; shared helpers: segk_kmeans_dev.h)
+#include <vector>
 #include "segk_kmeans_dev.h"
 
 extern "C" {
@@ -148,10 +149,21 @@ int32_t segk_kmeans_sequential_sweep(segk_ctx *ctx, const segk_corpus *c, segk_k
     }
     hipStream_t st = (hipStream_t)stream;
     for (int32_t q = 0; q < n_order; q++) SEGK_REQUIRE(order[q] >= 0 && order[q] < c->n_utt, "utterance index out of range");
+    // an utterance listed twice: the persistent kernel stages utterance order[q + 1] while order[q] is still being updated
+    // (old boundary mask, old tokens' labels), so a repeat would read the state from before its earlier visit -- those
+    // orders take the three launches per utterance, which see every update
+    bool repeats = false;
+    {
+        std::vector<uint8_t> seen((size_t)c->n_utt, 0);
+        for (int32_t q = 0; q < n_order && !repeats; q++) {
+            repeats = seen[order[q]] != 0;
+            seen[order[q]] = 1;
+        }
+    }
     // the whole sweep in one persistent kernel (segk_seq_chain.hip) where the configuration allows; SEGK_SEQ_CHAIN=0: three
     // launches per utterance
     const char *che = getenv("SEGK_SEQ_CHAIN");
-    if (!(che && atoi(che) == 0) && (n_slices_min == 0 || n_slices_min == 1)) {
+    if (!(che && atoi(che) == 0) && !repeats && !ctx->capturing && (n_slices_min == 0 || n_slices_min == 1)) {
         rc = segk_launch_seq_chain(ctx, c, m, order, n_order, n_slices_max, wip, boundaries, old_tok, new_tok, new_k, n_old, n_new,
                                    n_flag, out_total, status, st);
         if (rc == SEGK_OK) return segk_kmeans_prepare(ctx, c, m, stream);

@@ -330,9 +330,11 @@ class DeviceKMeans(object):
                                              ptr(self.n_new), ptr(self.status), _abi.stream()))
 
     def sequential_sweep(self, boundaries, order, n_slices_min, n_slices_max, wip):
-        """segment_i for every utterance of `order` in turn, enqueued by ONE library call (three launches per utterance:
-        direct exact score, DP, update; segk_kmeans_sequential_sweep).  Returns False when the library does not
-        support the data (float64): the caller then walks the utterances itself."""
+        """segment_i for every utterance of `order` in turn by ONE library call (segk_kmeans_sequential_sweep): where the
+        configuration allows, one persistent kernel per stretch of utterances between two emptied components -- the call
+        then SYNCHRONISES the stream after every such launch --, otherwise three launches per utterance (direct exact score,
+        DP, update), all enqueued.  Returns False when the library does not support the data (float64): the caller then
+        walks the utterances itself."""
         if self.corpus.x_dtype != SEGK_F32 or self.corpus.N_max > 63:
             return False
         torch = _torch()

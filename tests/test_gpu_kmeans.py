@@ -748,6 +748,39 @@ def test_persistent_sequential_chain_equals_the_three_launch_form(gpu, monkeypat
         assert a[5:] == b[5:], it
 
 
+def test_sequential_sweep_with_a_repeated_utterance(gpu, monkeypatch):
+    """segk_kmeans_sequential_sweep with an utterance listed twice in `order` (adjacent and apart): the persistent kernel
+    prefetches utterance order[q + 1] while order[q] is being updated, so such an order is routed to the launches per
+    utterance -- same state as SEGK_SEQ_CHAIN=0, and as visiting the utterances one call at a time."""
+    from segmentalist_amd import kmeans_acoustic_wordseg as kaw
+    corpus = cases.chain_corpus(60, 16, 12, 977, False, 12, 6, "float32")
+    order = [5, 5, 9, 3, 17, 9, 40, 41, 5, 2]
+    out = []
+    for mode in ("default", "0", "one_by_one"):
+        monkeypatch.delenv("SEGK_SEQ_CHAIN", raising=False)
+        if mode == "0":
+            monkeypatch.setenv("SEGK_SEQ_CHAIN", "0")
+        random.seed(5)
+        np.random.seed(5)
+        seg = kaw.SegmentalKMeansWordseg(12, *corpus, n_slices_min=0, n_slices_max=6, p_boundary_init=0.5,
+                                         init_am_assignments="rand", wip=-0.1)
+        c = seg.acoustic_model.components
+        if mode == "one_by_one":
+            for i in order:
+                seg.segment_i(i)
+        else:
+            assert seg._dk.sequential_sweep(seg._dev_bounds, order, 0, 6, -0.1)
+            seg.utterances.mark_device_dirty()
+            gpu.cuda.synchronize()
+            seg._dk.check_status()
+        out.append((seg.utterances.boundaries.copy(), c.assignments.copy(), c.means.copy(), c.mean_numerators.copy(),
+                    c.counts.copy(), c.K))
+    for other in out[1:]:
+        for x, y in zip(out[0][:5], other[:5]):
+            assert np.array_equal(x, y)
+        assert out[0][5] == other[5]
+
+
 @pytest.mark.parametrize("n_utt,D,K,N,nmax,ragged", [(400, 16, 40, 20, 6, False), (300, 8, 25, 0, 8, True), (200, 12, 30, 0, 3, True)])
 def test_segment_kernels_agree(gpu, monkeypatch, n_utt, D, K, N, nmax, ragged):
     """The per-utterance DP by the whole wave (seg_w8_wave: eight lanes per step, DPP maxima, token lists from ballots; the
