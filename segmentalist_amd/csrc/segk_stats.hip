@@ -900,15 +900,10 @@ __global__ __launch_bounds__(SORT_THREADS) void k_batch_sort_sum(
     }
 }
 
-// (1b) per (block, component) the sequential fp64 sum of its tokens in token order: one wave per pair, lanes own
-//      dimensions; the token rows are fetched 16 at a time (unconditional loads, clamped index, select after the
-//      load: all 16 in flight together) and added strictly in order.
-// Lists are short on average (a dozen tokens) and a wave's time is a chain of dependent round trips (~1.5 us each under this
-// kernel's load): {offset, length} -> the list's rows (64 at a time, one per lane) -> the rows' elements, PART_BATCH rows in
-// flight together.  The longest list of the launch (~100 tokens) sets the kernel's duration: PART_BATCH = 32 makes that
-// four round trips (sixteen with double buffering took seven).  Float32 rows of even D <= 128 are fetched as float2 (lane l
-// owns dimensions 2l, 2l + 1: one load instruction per row).
-#define PART_BATCH 32
+// (1b) k_batch_partials: what k_batch_sort_sum's summing phase does not cover (float64 data, odd D, D > 128).  Per (block,
+//      component) the sequential fp64 sum of its tokens in token order: one wave per pair, lanes own dimensions; the list's rows
+//      are fetched 64 at a time (one per lane), their elements 16 rows at a time (unconditional loads, clamped index, select
+//      after the load: all 16 in flight together) and added strictly in order.
 #define PART_WAVES 4
 template <typename XT>
 __global__ __launch_bounds__(64 * PART_WAVES) void k_batch_partials(segk_corpus c, segk_kmeans m, const int32_t *blk_lo, int n_blocks,
@@ -933,32 +928,6 @@ __global__ __launch_bounds__(64 * PART_WAVES) void k_batch_partials(segk_corpus 
     const int32_t *list = sorted + p0 * NR + (int64_t)(k & (NR - 1)) * S + on.x;    // embedding rows of the list's tokens, token order
     double *out = part_sum + ((int64_t)b * m.K_max + k) * D;
     if (lane == 0) part_cnt[(int64_t)b * m.K_max + k] = nm;
-    if (sizeof(XT) == 4 && D <= 128 && (D & 1) == 0 && (c.ldx & 1) == 0) {
-        const float *Xf = (const float *)c.X;
-        const int dl = 2 * lane < D ? 2 * lane : 0;                              // clamped: always a valid address
-        double a0 = 0.0, a1 = 0.0;
-        for (int c0 = 0; c0 < nm; c0 += 64) {
-            const int mine = list[c0 + lane < nm ? c0 + lane : c0];
-            const int nb = nm - c0 < 64 ? nm - c0 : 64;
-            for (int q0 = 0; q0 < nb; q0 += PART_BATCH) {
-                float2 xv[PART_BATCH];
-#pragma unroll
-                for (int q = 0; q < PART_BATCH; q++) {
-                    const int e = __shfl(mine, q0 + q < nb ? q0 + q : 0);
-                    xv[q] = *reinterpret_cast<const float2 *>(Xf + (int64_t)e * c.ldx + dl);
-                }
-#pragma unroll
-                for (int q = 0; q < PART_BATCH; q++) {
-                    const bool ok = q0 + q < nb;
-                    a0 += ok ? (double)xv[q].x : 0.0;
-                    a1 += ok ? (double)xv[q].y : 0.0;
-                }
-            }
-        }
-        if (2 * lane < D) *reinterpret_cast<double2 *>(out + 2 * lane) = make_double2(a0, a1);
-        SEGK_TSTAMP_MAX(2, 1);
-        return;
-    }
     constexpr int MAXR = 2;                       // 128 dims per pass over the tokens
     for (int d0 = 0; d0 < D; d0 += 64 * MAXR) {
         double acc[MAXR];
@@ -1037,7 +1006,7 @@ template <typename XT>
 __global__ __launch_bounds__(256) void k_batch_finalize(
     segk_corpus c, segk_kmeans m, const double *pack, int n_blocks, int nbl, int64_t rank_stride, int cap, int my_rank,
     int32_t *new_k, int32_t *remap, double *out_scalars, int32_t *status, unsigned long long *row_hash,
-    unsigned int *sp_zero_slot, int32_t *ovf, int ovf_cap)
+    unsigned int *sp_zero_slot, int32_t *ovf, int ovf_cap, int sp_spec)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char fin_lds[];
     const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wv = tid >> 6;
@@ -1179,45 +1148,49 @@ __global__ __launch_bounds__(256) void k_batch_finalize(
     // in descending order, each time moving the last active row into the hole (kmeans_components.py:129-151,
     // 263-266).  Because the holes above the current one are already gone, the row that moves is never empty,
     // every moved row originates at or above the final K and lands below it.
-    const int nwords = (K1 + 31) / 32;
-    for (int w = tid; w < nwords; w += nt) bitmap[w] = 0;
-    for (int k = tid; k < K1; k += nt) pos2orig[k] = (unsigned short)k;
-    __syncthreads();
-    for (int k = tid; k < K1; k += nt)
-        if (cnt32[k] == 0) atomicOr(&bitmap[k >> 5], 1u << (k & 31));
-    __syncthreads();
-    // (no component emptied -- the usual case once the chain has settled: nothing moves)
-    int any_hole = 0;
-    for (int w = tid; w < nwords; w += nt) any_hole |= bitmap[w] != 0u;
-    any_hole = __syncthreads_or(any_hole);
-    if (!any_hole) {
-        if (tid == 0) { shK = K1; n_holes = 0; }
-    } else if (tid == 0) {
-        int K = K1, nh = 0;
-        for (int w = nwords - 1; w >= 0; w--) {
-            unsigned int bits = bitmap[w];
-            while (bits) {
-                const int bit = 31 - __clz((int)bits);
-                bits &= ~(1u << bit);
-                const int k = w * 32 + bit;
-                K--;
-                if (k != K) pos2orig[k] = pos2orig[K];
-                holes[nh++] = (unsigned short)k;
+    // Usually no component emptied (once the chain has settled): one pass over the counts and ONE barrier say so, nothing
+    // moves, and final row j holds component j -- no table is built (four barriers and 4 us less than the general path).
+    __syncthreads();                                             // the flagged tokens' increments
+    int hole_here = 0;
+    for (int k = tid; k < K1; k += nt) hole_here |= cnt32[k] == 0;
+    const int any_hole = __syncthreads_or(hole_here);
+    if (any_hole) {
+        const int nwords = (K1 + 31) / 32;
+        for (int w = tid; w < nwords; w += nt) bitmap[w] = 0;
+        for (int k = tid; k < K1; k += nt) pos2orig[k] = (unsigned short)k;
+        __syncthreads();
+        for (int k = tid; k < K1; k += nt)
+            if (cnt32[k] == 0) atomicOr(&bitmap[k >> 5], 1u << (k & 31));
+        __syncthreads();
+        if (tid == 0) {
+            int K = K1, nh = 0;
+            for (int w = nwords - 1; w >= 0; w--) {
+                unsigned int bits = bitmap[w];
+                while (bits) {
+                    const int bit = 31 - __clz((int)bits);
+                    bits &= ~(1u << bit);
+                    const int k = w * 32 + bit;
+                    K--;
+                    if (k != K) pos2orig[k] = pos2orig[K];
+                    holes[nh++] = (unsigned short)k;
+                }
             }
+            shK = K;
+            n_holes = nh;
         }
-        shK = K;
-        n_holes = nh;
+        __syncthreads();
     }
-    __syncthreads();
     SEGK_TSTAMP(3, 3);
-    const int K = shK;
+    const int K = any_hole ? shK : K1;
+    const int nholes = any_hole ? n_holes : 0;
+    auto orig = [&](int j) -> int { return any_hole ? (int)pos2orig[j] : j; };        // the component final row j < K holds
 
     // ---- the LAST workgroup (it has no rows of its own: as part of workgroup 0 this was 4 us on the kernel's critical path)
     // publishes the scalars, the relabel table and the resolved labels of the local flagged tokens
     if (wg == (int)gridDim.x - 1) {
         for (int k = tid; k < K_max; k += nt) remap[k] = k;
         __syncthreads();
-        for (int h = tid; h < n_holes; h += nt) {
+        for (int h = tid; h < nholes; h += nt) {
             const int k = holes[h];
             if (k < K) remap[pos2orig[k]] = k;
         }
@@ -1242,8 +1215,8 @@ __global__ __launch_bounds__(256) void k_batch_finalize(
     if (tid < FIN_ROWS) {
         const int j = j0 + tid;
         int n = 0;
-        if (j < K && j < K_max && pos2orig[j] >= Kb) {
-            const int sc = pos2orig[j];
+        if (j < K && j < K_max && orig(j) >= Kb) {
+            const int sc = orig(j);
             for (int q = 0; q < nfl; q++)
                 if (FL_K(q) == sc) {
                     if (n < FIN_ML) ml[tid][n] = q;
@@ -1274,7 +1247,7 @@ __global__ __launch_bounds__(256) void k_batch_finalize(
             if (e < nel && j < K_max) {
                 if (j >= K) cls[u] = 1;
                 else {
-                    src[u] = pos2orig[j];
+                    src[u] = orig(j);
                     cls[u] = (n_blocks == 8 && src[u] < Kb) ? 2 : 3;
                 }
             }
@@ -1299,36 +1272,37 @@ __global__ __launch_bounds__(256) void k_batch_finalize(
             double v;
             if (cls[u] == 2) {
                 v = ((tv[u][0] + tv[u][1]) + (tv[u][2] + tv[u][3])) + ((tv[u][4] + tv[u][5]) + (tv[u][6] + tv[u][7]));
-            } else {
+            } else if (n_blocks == 8 && src[u] >= Kb && ml_cnt[r] <= FIN_ML) {
+                // a component founded this sweep: its flagged tokens, block by block -- the row's match list (LDS), four
+                // rows in flight, the block's accumulator chosen by predicate (a dynamically indexed array lives in scratch)
+                double g8[8];
+#pragma unroll
+                for (int b = 0; b < 8; b++) g8[b] = 0.0;
+                const int nmr = ml_cnt[r];
+                for (int i0 = 0; i0 < nmr; i0 += 4) {
+                    XT xq[4];
+                    int bq[4];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const int qq = ml[r][i0 + i < nmr ? i0 + i : nmr - 1];
+                        bq[i] = FL_BLK(qq);
+                        xq[i] = X[(int64_t)FL_ROW(qq) * c.ldx + d];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                        if (i0 + i < nmr) {
+#pragma unroll
+                            for (int b = 0; b < 8; b++) g8[b] = bq[i] == b ? g8[b] + (double)xq[i] : g8[b];
+                        }
+                }
+                // (registers and the fixed tree: the general path's array lives in scratch, and its tree walks it through memory --
+                // seven dependent round trips, 6 us for the workgroup that holds a new component)
+                v = ((g8[0] + g8[1]) + (g8[2] + g8[3])) + ((g8[4] + g8[5]) + (g8[6] + g8[7]));
+            } else {                                           // (general: any number of blocks, long lists)
                 double gv[64];
                 if (src[u] < Kb) {
                     for (int b = 0; b < n_blocks; b++) gv[b] = rpack[pa.sum(b) + (int64_t)src[u] * D + d];
-                } else if (n_blocks == 8 && ml_cnt[r] <= FIN_ML) {
-                    // a component founded this sweep: its flagged tokens, block by block -- the row's match list (LDS), four
-                    // rows in flight, the block's accumulator chosen by predicate (a dynamically indexed array lives in scratch)
-                    double g8[8];
-#pragma unroll
-                    for (int b = 0; b < 8; b++) g8[b] = 0.0;
-                    const int nmr = ml_cnt[r];
-                    for (int i0 = 0; i0 < nmr; i0 += 4) {
-                        XT xq[4];
-                        int bq[4];
-#pragma unroll
-                        for (int i = 0; i < 4; i++) {
-                            const int qq = ml[r][i0 + i < nmr ? i0 + i : nmr - 1];
-                            bq[i] = FL_BLK(qq);
-                            xq[i] = X[(int64_t)FL_ROW(qq) * c.ldx + d];
-                        }
-#pragma unroll
-                        for (int i = 0; i < 4; i++)
-                            if (i0 + i < nmr) {
-#pragma unroll
-                                for (int b = 0; b < 8; b++) g8[b] = bq[i] == b ? g8[b] + (double)xq[i] : g8[b];
-                            }
-                    }
-#pragma unroll
-                    for (int b = 0; b < 8; b++) gv[b] = g8[b];
-                } else {                                       // (general: any number of blocks, long lists)
+                } else {
                     for (int b = 0; b < n_blocks; b++) gv[b] = 0.0;
                     for (int q = 0; q < nfl; q++)
                         if (FL_K(q) == src[u]) gv[FL_BLK(q)] += (double)X[(int64_t)FL_ROW(q) * c.ldx + d];
@@ -1343,35 +1317,91 @@ __global__ __launch_bounds__(256) void k_batch_finalize(
     }
     if (tid < FIN_ROWS) {
         const int j = j0 + tid;
-        if (j < K_max) m.counts[j] = j < K ? (int64_t)cnt32[pos2orig[j]] : 0;
+        if (j < K_max) m.counts[j] = j < K ? (int64_t)cnt32[orig(j)] : 0;
     }
     __syncthreads();
     SEGK_TSTAMP(3, 5);
     // ---- (2) this workgroup's part of the fp32 MFMA image (layout: segk_internal.h; the padding of the image -- dimensions
     // beyond D, components beyond K_max -- never changes after segk_kmeans_prepare), |m|^2 maximum, row hashes: the
     // arithmetic of dev_prepare_tile, 8 lanes per component
+    // (2') sp_spec: ALSO this workgroup's part of the fp16x2 image, with the exponent the image has NOW (header word 0).
+    // The exponent follows max |m|^2 over all rows, which is complete only when this kernel ends -- the reason the image is
+    // the post kernel's job -- but from one sweep to the next it almost never moves: the post kernel compares, and rebuilds
+    // the image only when it did (same arithmetic as dev_prepare_sp_tile: the two ways give the same bits).  The residual
+    // maximum E_m of these rows goes to header word 2; the post kernel moves it to word 1.
     const int G = segk_gmax(D);
     float *T = m.tiles + (int64_t)(j0 >> 5) * segk_tile_stride(D);
-    if (tid < FIN_ROWS * 8) {
-        const int r = tid >> 3, sub = tid & 7, comp = j0 + r;
-        double s = 0.0;
-        unsigned long long hh = 0ull;
-        if (comp < K_max)
-            for (int d = sub; d < D; d += 8) {
-                const double v = mrow[r * D + d];
-                s += v * v;
-                hh += segk_elem_hash(v, d);
+    const int KSsp = segk_b3_kp(D) / 16;
+    const int eb_prev = sp_spec ? ((const int *)m.tiles_b3)[0] : 0;
+    const int ea_sp = sp_spec ? ((const int *)c.Xb3)[1] : 0;
+    float *Tsp = sp_spec ? m.tiles_b3 + 1024 + (int64_t)(j0 >> 5) * segk_sp_tile_stride(D, 2) : nullptr;
+    {
+        // three independent reductions over a row's elements, one per wave (8 lanes per component, the summation pattern of
+        // dev_prepare_tile / dev_prepare_sp_tile): wave 0 |m|^2, wave 1 the fp16 residual, wave 2 the value hash
+        const int what = tid >> 6, t64 = tid & 63;
+        const int r = t64 >> 3, sub = t64 & 7, comp = j0 + r;
+        const bool live = comp < K_max;
+        if (what == 0) {
+            double s = 0.0;
+            if (live)
+                for (int d = sub; d < D; d += 8) {
+                    const double v = mrow[r * D + d];
+                    s += v * v;
+                }
+            s += __shfl_xor(s, 1);
+            s += __shfl_xor(s, 2);
+            s += __shfl_xor(s, 4);
+            if (sub == 0 && live) {
+                T[G * 128 + (comp & 31)] = (float)(-0.5 * s);
+                atomicMax((unsigned long long *)m.mnorm_max, (unsigned long long)__double_as_longlong(s));
+                if (sp_spec) Tsp[KSsp * 2 * 256 + (comp & 31)] = (float)ldexp(-0.5 * s, ea_sp + eb_prev);      // accumulator seed, scaled domain
             }
-        s += __shfl_xor(s, 1);
-        s += __shfl_xor(s, 2);
-        s += __shfl_xor(s, 4);
-        hh += __shfl_xor(hh, 1);
-        hh += __shfl_xor(hh, 2);
-        hh += __shfl_xor(hh, 4);
-        if (sub == 0 && comp < K_max) {
-            T[G * 128 + (comp & 31)] = (float)(-0.5 * s);
-            atomicMax((unsigned long long *)m.mnorm_max, (unsigned long long)__double_as_longlong(s));
-            if (row_hash) row_hash[comp] = hh | 1ull;        // never 0: the empty key of the hash table
+        } else if (what == 1) {
+            if (sp_spec) {
+                double rs = 0.0;
+                if (live)
+                    for (int d = sub; d < D; d += 8) rs += sp_resid2(ldexpf((float)mrow[r * D + d], eb_prev));
+                rs += __shfl_xor(rs, 1);
+                rs += __shfl_xor(rs, 2);
+                rs += __shfl_xor(rs, 4);
+                if (sub == 0 && live) {
+                    const float em = (float)(ldexp(sqrt(rs), -eb_prev) * (1.0 + 1e-6));
+                    atomicMax((unsigned int *)m.tiles_b3 + 2, __float_as_uint(em));
+                }
+            }
+        } else if (what == 2) {
+            if (row_hash) {
+                unsigned long long hh = 0ull;
+                if (live)
+                    for (int d = sub; d < D; d += 8) hh += segk_elem_hash(mrow[r * D + d], d);
+                hh += __shfl_xor(hh, 1);
+                hh += __shfl_xor(hh, 2);
+                hh += __shfl_xor(hh, 4);
+                if (sub == 0 && live) row_hash[comp] = hh | 1ull;        // never 0: the empty key of the hash table
+            }
+        }
+    }
+    if (sp_spec) {
+        typedef SegkPiece<2>::T T16;
+        typedef SegkPiece<2>::V8 V8;
+        T16 *Tb = (T16 *)Tsp;
+        for (int it = tid; it < FIN_ROWS * KSsp * 2; it += nt) {
+            const int r = it / (KSsp * 2), rem = it - r * (KSsp * 2), sidx = rem >> 1, h = rem & 1;
+            const int comp = j0 + r;
+            if (comp >= K_max) continue;
+            const int ln = (comp & 31) + 32 * h;
+            V8 out[2];
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int d = segk_b3_dim(16 * sidx + 8 * h + i);
+                const float v = d < D ? ldexpf((float)mrow[r * D + d], eb_prev) : 0.f;
+                T16 pc[2];
+                split_sp<2>(v, pc);
+                out[0][i] = pc[0];
+                out[1][i] = pc[1];
+            }
+#pragma unroll
+            for (int q = 0; q < 2; q++) *reinterpret_cast<V8 *>(Tb + ((sidx * 2 + q) * 64 + ln) * 8) = out[q];
         }
     }
     for (int e = tid; e < nel; e += nt) {
@@ -1385,7 +1415,7 @@ __global__ __launch_bounds__(256) void k_batch_finalize(
 template <typename XT, int P>
 __global__ __launch_bounds__(256) void k_batch_post(segk_corpus c, segk_kmeans m, int lo, int hi, int32_t *new_k, const int32_t *remap,
                                                     int n_tiles, int stride32, int G, float *tiles_sp, int stride_sp, int sp_const_off,
-                                                    const unsigned long long *row_hash)
+                                                    const unsigned long long *row_hash, int sp_spec)
 {
     if ((int)blockIdx.x >= n_tiles) {
         const int64_t idx = (int64_t)(blockIdx.x - n_tiles) * blockDim.x + threadIdx.x;
@@ -1400,9 +1430,22 @@ __global__ __launch_bounds__(256) void k_batch_post(segk_corpus c, segk_kmeans m
     const int tile = blockIdx.x;
     SEGK_TSTAMP(4, 0);
     if constexpr (P != 0) {
-        if (tiles_sp)
-            dev_prepare_sp_tile<P>((const float *)m.means, m.K_max, c.D, tiles_sp, m.mnorm_max, (const unsigned char *)c.Xb3,
-                                   (const double *)nullptr, tile);
+        if (tiles_sp) {
+            // P = 2: the finalize kernel has written the image with the exponent of the previous one (its sp_spec path); when
+            // the exponent of the new means is the same there is nothing to build (workgroup-uniform)
+            bool built = false;
+            if (P == 2 && sp_spec) {
+                const int eb_new = sp_exponent((float)(sqrt(*m.mnorm_max) * (1.0 + 1e-6)));
+                built = eb_new == ((const int *)tiles_sp)[0];
+            }
+            if (!built)
+                dev_prepare_sp_tile<P>((const float *)m.means, m.K_max, c.D, tiles_sp, m.mnorm_max, (const unsigned char *)c.Xb3,
+                                       (const double *)nullptr, tile);
+            if (P == 2 && sp_spec && tile == 0 && threadIdx.x == 0) {
+                if (built) ((unsigned int *)tiles_sp)[1] = ((const unsigned int *)tiles_sp)[2];      // E_m of the rows
+                ((unsigned int *)tiles_sp)[2] = 0u;
+            }
+        }
     }
     SEGK_TSTAMP(4, 1);
     if (!row_hash) return;
@@ -1781,6 +1824,7 @@ int32_t segk_kmeans_batch_finalize(segk_ctx *ctx, const segk_corpus *c, segk_kme
         ovf_cap = (int)ctx->flag_ovf_cap;
     }
     const bool sp = m->tiles_b3 && c->Xb3 && c->x_dtype == SEGK_F32 && c->D >= 8 && c->D <= 128 && (c->sp_pieces == 2 || c->sp_pieces == 3);
+    const int sp_spec = sp && c->sp_pieces == 2 ? 1 : 0;      // fp16x2 image by the finalize kernel, checked by the post kernel
     const int n_tiles = segk_n_tiles(m->K_max);
     const size_t lds = (((size_t)m->K_max * 8 + ((size_t)m->K_max / 32 + 2) * 4 + 15) & ~(size_t)15) + (size_t)FIN_ROWS * c->D * sizeof(double);
     DISPATCH_XT(c, {
@@ -1789,7 +1833,7 @@ int32_t segk_kmeans_batch_finalize(segk_ctx *ctx, const segk_corpus *c, segk_kme
         hipLaunchKernelGGL(k_batch_finalize<XT>, dim3((m->K_max + FIN_ROWS - 1) / FIN_ROWS + 1), dim3(256), lds, st, *c, *m, records,
                            n_blocks_total, n_blocks_per_rank, rank_stride, flag_cap, my_rank, new_k, remap_scratch, out_scalars,
                            status, ctx && m->K_max <= 2048 ? ctx->row_hash : (unsigned long long *)nullptr,
-                           sp ? (unsigned int *)m->tiles_b3 + 1 : (unsigned int *)nullptr, ovf, ovf_cap);
+                           sp ? (unsigned int *)m->tiles_b3 + 1 : (unsigned int *)nullptr, ovf, ovf_cap, sp_spec);
     });
     const int64_t nslot = (int64_t)(utt_hi - utt_lo) * c->N_max;
     const unsigned grid = (unsigned)(n_tiles + (nslot + 255) / 256);
@@ -1798,13 +1842,13 @@ int32_t segk_kmeans_batch_finalize(segk_ctx *ctx, const segk_corpus *c, segk_kme
     const int stride_sp = sp ? segk_sp_tile_stride(c->D, c->sp_pieces) : 0, sp_off = sp ? (kp / 16) * c->sp_pieces * 256 : 0;
     if (sp && c->sp_pieces == 2)
         hipLaunchKernelGGL((k_batch_post<float, 2>), dim3(grid), dim3(256), 0, st, *c, *m, utt_lo, utt_hi, new_k, remap_scratch,
-                           n_tiles, stride32, G, m->tiles_b3, stride_sp, sp_off, row_hash);
+                           n_tiles, stride32, G, m->tiles_b3, stride_sp, sp_off, row_hash, sp_spec);
     else if (sp)
         hipLaunchKernelGGL((k_batch_post<float, 3>), dim3(grid), dim3(256), 0, st, *c, *m, utt_lo, utt_hi, new_k, remap_scratch,
-                           n_tiles, stride32, G, m->tiles_b3, stride_sp, sp_off, row_hash);
+                           n_tiles, stride32, G, m->tiles_b3, stride_sp, sp_off, row_hash, 0);
     else
         DISPATCH_XT(c, hipLaunchKernelGGL((k_batch_post<XT, 0>), dim3(grid), dim3(256), 0, st, *c, *m, utt_lo, utt_hi, new_k,
-                                           remap_scratch, n_tiles, stride32, G, (float *)nullptr, 0, 0, row_hash););
+                                           remap_scratch, n_tiles, stride32, G, (float *)nullptr, 0, 0, row_hash, 0););
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;
 }

@@ -362,6 +362,35 @@ def test_batch_sweep_bit_exact_vs_spec(gpu, n_utt, D, K, nmax, dtype, n_blocks):
             assert rec["n_tokens"][0] == ref.acoustic_model.get_n_assigned()
 
 
+@pytest.mark.parametrize("n_utt,D,K,scale", [(600, 100, 130, 1.0), (300, 16, 40, 1.0), (300, 16, 40, 37.0)])
+def test_operand_images_after_a_batch_sweep_equal_a_fresh_prepare(gpu, n_utt, D, K, scale):
+    """The finalize kernel writes its rows' part of the fp16x2 image with the exponent the image had (the post kernel rebuilds
+    it only when the exponent of the new means differs): after every sweep both operand images are, bit for bit, what
+    segk_kmeans_prepare + segk_kmeans_mark_duplicates build from the same means -- also when the scale of the data moves the
+    exponent between the initial means and the first sweep's."""
+    import ctypes as C
+    from segmentalist_amd import _abi, kmeans_acoustic_wordseg as kaw
+    from segmentalist_amd.synth import make_corpus
+    corpus = list(make_corpus(n_utt, D, K, seed=77, N=12, n_slices_max=5))
+    corpus[0] = {k: (v * scale).astype(np.float32) for k, v in corpus[0].items()}
+    random.seed(3); np.random.seed(3)
+    seg = kaw.SegmentalKMeansWordseg(K, *corpus, n_slices_max=5, init_am_assignments="spread", sync="batch")
+    dk = seg._dk
+    L, ctx = _abi.lib(), _abi.ctx()
+    for it in range(4):
+        seg.batch_sweep_async()
+        gpu.cuda.synchronize()
+        dk.check_status()
+        got32, got16 = dk.tiles.clone(), dk.tiles_b3.clone()
+        dk.prepare()
+        _abi.check(L.segk_kmeans_mark_duplicates(ctx, dk._cp(), C.byref(dk.m), None, _abi.stream()))
+        gpu.cuda.synchronize()
+        assert gpu.equal(got32.view(gpu.int32), dk.tiles.view(gpu.int32)), it
+        a, b = got16.view(gpu.int32), dk.tiles_b3.view(gpu.int32)
+        assert gpu.equal(a[:2], b[:2]), (it, a[:4].tolist(), b[:4].tolist())          # exponent, E_m
+        assert gpu.equal(a[1024:], b[1024:]), it
+
+
 @pytest.mark.parametrize("n_utt,D,K,N,nmax,n_blocks,sweeps,p_b", [(150, 16, 2500, 0, 6, 8, 3, 0.5), (1700, 8, 12, 20, 4, 1, 2, 0.7),
                                                                 (1000, 8, 2, 20, 1, 1, 2, 1.0), (900, 12, 70, 20, 2, 2, 2, 0.8)],
                          ids=["ranges_of_128_components", "block_beyond_the_preloaded_keys", "compaction_overflow",
