@@ -92,6 +92,7 @@ int32_t segk_destroy(segk_ctx *ctx)
         if (ctx->hint_part) (void)hipFree(ctx->hint_part);
         if (ctx->hint_map) (void)hipFree(ctx->hint_map);
         if (ctx->ws_u64) (void)hipFree(ctx->ws_u64);
+        if (ctx->hint_fb) (void)hipFree(ctx->hint_fb);
         if (ctx->pre_queue) (void)hipFree(ctx->pre_queue);
         if (ctx->row_hash) (void)hipFree(ctx->row_hash);
         if (ctx->rb_sorted) (void)hipFree(ctx->rb_sorted);

@@ -50,6 +50,8 @@ struct segk_ctx {
     size_t hint_part_bytes;
     int32_t *hint_map;
     int hint_map_k;
+    void *hint_fb;               // per-XCD shares and wave lifetimes of the matrix kernel's last launches, [3][8] floats + [3][8] uint32
+    unsigned int hint_fb_launch;
     // k-means batch finalize: the flagged tokens of a sweep beyond the kernel's LDS list, [4][flag_ovf_cap] int32
     int32_t *flag_ovf;
     int64_t flag_ovf_cap;

@@ -53,6 +53,10 @@ struct HintArgs {
     int K_max;
     int dbg;                        // development (SEGK_HINT_DBG, results wrong): 1 no result stores, 2 no hint loads / marks
     unsigned long long *stamp;      // development (-DSEGK_STAMP builds): per wave {cycles in the row waits, in the tile loops, total, groups}
+    float *fb_w;                    // [3][8] share of the row groups each XCD took in the launches L - 1, L, L + 1 (slot = launch % 3)
+    unsigned int *fb_t;             // [3][8] how long its waves lived (s_memrealtime ticks, maximum); NULL: equal shares
+    int fb_cur;                     // this launch's slot
+    const int64_t *fb_split;        // [9] this launch's first group per XCD (k_hint_map)
 };
 
 // ---- K1 ---------------------------------------------------------------------------------------------------------------
@@ -121,7 +125,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_kmeans_top2_rs(HintArgs H)
     // workgroup -> (range, slot).  Workgroups b and b + 8 share an XCD (round-robin placement, speed only): the R
     // workgroups that stream the same rows sit on one XCD when the grid allows, so that the rows cross HBM once
     int range, wgr, n_wgr;
-    if ((gridDim.x & 7) == 0 && ((gridDim.x >> 3) % R) == 0) {
+    const bool xcd_aware = (gridDim.x & 7) == 0 && ((gridDim.x >> 3) % R) == 0;
+    if (xcd_aware) {
         const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
         range = idx % R;
         wgr = (idx / R) * 8 + xcd;
@@ -137,8 +142,23 @@ __global__ __launch_bounds__(64 * NW, 2) void k_kmeans_top2_rs(HintArgs H)
     if (nt > H.tpr) nt = H.tpr;
     if (nt <= 0) return;
     const T *plane0 = (const T *)(H.ximg + SEGK_SP_HEADER);
-    const int64_t n_groups = (H.n + 32 * NBLK - 1) / (32 * NBLK);
-    const int64_t n_slots = (int64_t)n_wgr * NW;
+    // this wave's row groups: g_first, g_first + n_slots, ... below n_groups
+    const int64_t total_groups = (H.n + 32 * NBLK - 1) / (32 * NBLK);
+    int64_t n_groups = total_groups, n_slots = (int64_t)n_wgr * NW, g_first = (int64_t)wgr * NW + wave;
+    // Under this kernel the chip runs into its power limit, and the eight XCDs then hold DIFFERENT clocks (1.65-1.77 GHz
+    // measured, the same XCDs slow launch after launch): with equal shares the fast ones idle for the last 10-20 us of 200.
+    // So an XCD takes a contiguous share of the groups in proportion to the rate it showed in the previous launch (its share
+    // then / the lifetime of its waves, half-way blended; k_hint_map, the small launch in front, does the arithmetic): nothing is
+    // exchanged during the launch, and the results do not depend on who computes which rows.
+    const unsigned long long fb_t0 = __builtin_amdgcn_s_memrealtime();
+    const bool fb = xcd_aware && H.fb_t != nullptr;
+    if (fb) {
+        const int xcd = blockIdx.x & 7;
+        const int64_t lo = H.fb_split[xcd], hi = H.fb_split[xcd + 1];
+        n_slots = (int64_t)(n_wgr >> 3) * NW;
+        g_first = lo + (int64_t)(wgr >> 3) * NW + wave;
+        n_groups = hi;
+    }
 
     // the rows of group g into a register set
 #define SEGK_RS_LOAD(g_, XB, HROW, HK)                                                                          \
@@ -254,7 +274,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_kmeans_top2_rs(HintArgs H)
             cs[4 * q + 0] = c4.x; cs[4 * q + 1] = c4.y; cs[4 * q + 2] = c4.z; cs[4 * q + 3] = c4.w;
         }
     };
-    int64_t g = (int64_t)wgr * NW + wave;
+    int64_t g = g_first;
     float pend1[NBLK], pend2[NBLK];
     int32_t pend_row[NBLK], pend_k[NBLK];
     int64_t pend_g = -1;
@@ -376,6 +396,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_kmeans_top2_rs(HintArgs H)
         }
     }
     SEGK_RS_STORE();
+    if (fb && lane == 0) atomicMax(&H.fb_t[H.fb_cur * 8 + (blockIdx.x & 7)], (unsigned int)(__builtin_amdgcn_s_memrealtime() - fb_t0));
 #undef SEGK_RS_STORE
 #undef SEGK_RS_GROUP
 #undef SEGK_RS_TILE
@@ -392,12 +413,42 @@ __global__ __launch_bounds__(64 * NW, 2) void k_kmeans_top2_rs(HintArgs H)
 //   and the queue lengths of the call cleared: the caller's ambiguity queue (when segk_kmeans_score_hinted deferred it) and
 //   the second stage's counters.
 __global__ void k_hint_map(const int32_t *remap, const float *tiles_sp /* first tile */, int K_max, int stride, int const_off, int32_t *map,
-                           const int32_t *ids, int64_t row0, int64_t n, int32_t *cand_k, int32_t *zero_cnt, int32_t *pre_hdr)
+                           const int32_t *ids, int64_t row0, int64_t n, int32_t *cand_k, int32_t *zero_cnt, int32_t *pre_hdr,
+                           float *fb_w, unsigned int *fb_t, int fb_cur, int64_t *fb_split, int64_t total_groups)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (blockIdx.x == 0) {
         if (threadIdx.x == 0 && zero_cnt) *zero_cnt = 0;
         if (threadIdx.x < 16) pre_hdr[threadIdx.x] = 0;
+        // the XCDs' shares of the matrix kernel's row groups for the launch behind this one (see k_kmeans_top2_rs): share of
+        // the previous launch / lifetime of its waves = the rate an XCD showed; new share = half the old one, half the rate's
+        if (threadIdx.x == 0 && fb_split) {
+            const int cur = fb_cur, prev = (cur + 2) % 3, next = (cur + 1) % 3;
+            float wp[8], w[8], rate[8];
+            bool ok = fb_t != nullptr;
+            float rsum = 0.f, wsum = 0.f;
+            for (int x = 0; x < 8; x++) {
+                wp[x] = fb_w[prev * 8 + x];
+                const unsigned int tp = fb_t ? fb_t[prev * 8 + x] : 0u;
+                ok = ok && tp > 0u && wp[x] > 0.f;
+                rate[x] = ok ? wp[x] / (float)tp : 0.f;
+                rsum += rate[x];
+            }
+            for (int x = 0; x < 8; x++) {
+                w[x] = !(wp[x] > 0.f) ? 0.125f : ok ? 0.5f * wp[x] + 0.5f * (rate[x] / rsum) : wp[x];
+                w[x] = fminf(fmaxf(w[x], 0.0625f), 0.25f);
+                wsum += w[x];
+            }
+            const double per = (double)total_groups / (double)wsum;
+            double cum = 0.0;
+            for (int x = 0; x < 8; x++) {
+                fb_split[x] = (int64_t)(cum * per);
+                cum += (double)w[x];
+                fb_w[cur * 8 + x] = w[x] / wsum;
+                if (fb_t) fb_t[next * 8 + x] = 0u;
+            }
+            fb_split[8] = total_groups;
+        }
     }
     if (i < K_max) {
         int v = remap ? remap[i] : (int)i;
@@ -715,10 +766,27 @@ static int launch_score_hint(segk_ctx *ctx, ScoreArgs A, const int32_t *remap, i
     int32_t *zero_cnt = ctx->defer_zero;
     ctx->defer_zero = nullptr;
     const int stride_sp = segk_sp_tile_stride(A.D, 2);
+    // per-XCD shares of the row groups (see the kernel): three slots of (shares, lifetimes), owned by the context
+    if (!ctx->hint_fb) {
+        SEGK_CHECK_HIP(hipMalloc(&ctx->hint_fb, 3 * 8 * (sizeof(float) + sizeof(unsigned int)) + 16 * sizeof(int64_t)));
+        float init[3 * 8 + 3 * 8];
+        for (int i = 0; i < 24; i++) init[i] = 0.125f;
+        memset(init + 24, 0, 24 * sizeof(unsigned int));
+        SEGK_CHECK_HIP(hipMemcpyAsync(ctx->hint_fb, init, sizeof(init), hipMemcpyHostToDevice, st));
+        SEGK_CHECK_HIP(hipStreamSynchronize(st));                            // (`init` lives on this stack frame)
+        ctx->hint_fb_launch = 0;
+    }
+    const bool fb_off = getenv("SEGK_HINT_BALANCE") && atoi(getenv("SEGK_HINT_BALANCE")) == 0;
+    float *fb_w = (float *)ctx->hint_fb;
+    unsigned int *fb_t = fb_off ? nullptr : (unsigned int *)(fb_w + 24);
+    int64_t *fb_split = (int64_t *)(fb_w + 48);                  // [9] (+ padding), rewritten by every launch of k_hint_map
+    const int fb_cur = (int)(ctx->hint_fb_launch++ % 3u);
+    const int64_t total_groups = (A.n + 63) / 64;                // k_kmeans_top2_rs<KS, 4>: two blocks of 32 rows per group
     {
         const int64_t nthr = A.n > A.K_max ? A.n : A.K_max;
         hipLaunchKernelGGL(k_hint_map, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, remap, A.tiles + 1024, A.K_max, stride_sp,
-                           KS * 2 * 256, ctx->hint_map, A.ids, A.row0, A.n, A.cand.k, zero_cnt, ctx->pre_queue);
+                           KS * 2 * 256, ctx->hint_map, A.ids, A.row0, A.n, A.cand.k, zero_cnt, ctx->pre_queue, fb_w, fb_t, fb_cur,
+                           fb_split, total_groups);
     }
 
     // ---- K1
@@ -733,6 +801,10 @@ static int launch_score_hint(segk_ctx *ctx, ScoreArgs A, const int32_t *remap, i
 #ifdef SEGK_STAMP
     H.stamp = getenv("SEGK_STAMP_PTR") ? (unsigned long long *)strtoull(getenv("SEGK_STAMP_PTR"), nullptr, 0) : nullptr;
 #endif
+    H.fb_w = fb_w;
+    H.fb_t = fb_t;
+    H.fb_cur = fb_cur;
+    H.fb_split = fb_split;
     const size_t lds1 = (size_t)tpr * TL * sizeof(float);
     // four waves per workgroup: one per SIMD with the next group's rows prefetched into registers (the eight-wave
     // instantiation -- two per SIMD, no prefetch: +6 % -- is still in the kernel's template, no longer launched)

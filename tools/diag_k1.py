@@ -5,6 +5,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from segmentalist_amd import _abi, kmeans_acoustic_wordseg as kaw
+if os.environ.get("SEGK_LIB_PATH"):          # a -DSEGK_STAMP build kept beside the product build (build_stamp/libsegk_stamp.so)
+    _abi.LIB_PATH = os.environ["SEGK_LIB_PATH"]
 from segmentalist_amd.synth import make_corpus
 n_utt = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 corpus = make_corpus(n_utt, 100, 1000, seed=0, N=20, n_slices_max=6)

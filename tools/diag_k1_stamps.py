@@ -6,6 +6,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from segmentalist_amd import _abi, kmeans_acoustic_wordseg as kaw
+if os.environ.get("SEGK_LIB_PATH"):          # a -DSEGK_STAMP build kept beside the product build (build_stamp/libsegk_stamp.so)
+    _abi.LIB_PATH = os.environ["SEGK_LIB_PATH"]
 from segmentalist_amd.synth import make_corpus
 corpus = make_corpus(10000, 100, 1000, seed=0, N=20, n_slices_max=6)
 random.seed(0); np.random.seed(0)
@@ -35,3 +37,12 @@ print("realtime (100 MHz): kernel span %.1f us; wave starts spread %.1f us; wave
     (r1 - r0) / 100.0, (v[:, 5].max() - r0) / 100.0, (r1 - v[:, 6].min()) / 100.0, ((v[:, 6] - v[:, 5]).mean()) / 100.0,
     (v[:, 2] + v[:, 4]).mean() / ((v[:, 6] - v[:, 5]).mean() / 100.0) / 1e3))
 print("start-up: entry -> first rows issued %.0f cycles, LDS fill (loads + writes + barrier) %.0f cycles" % ((v[:, 7] >> 32).mean(), (v[:, 7] & 0xffffffff).mean()))
+# wave ends by XCD (workgroup i runs on XCD i % 8) and by position inside the XCD: is the end spread systematic?
+wg = np.arange(len(v)) // 4
+end = (v[:, 6] - r0) / 100.0
+cyc = v[:, 2] + v[:, 4]
+print("per XCD: mean / min / max wave end (us) and mean cycles per wave")
+for x in range(8):
+    sel = (wg % 8) == x
+    print("  XCD %d: %.1f / %.1f / %.1f   cycles %.0f   clock %.3f GHz" % (x, end[sel].mean(), end[sel].min(), end[sel].max(), cyc[sel].mean(),
+          cyc[sel].mean() / ((v[sel, 6] - v[sel, 5]).mean() / 100.0) / 1e3))
