@@ -422,32 +422,36 @@ __global__ void k_hint_map(const int32_t *remap, const float *tiles_sp /* first 
         if (threadIdx.x < 16) pre_hdr[threadIdx.x] = 0;
         // the XCDs' shares of the matrix kernel's row groups for the launch behind this one (see k_kmeans_top2_rs): share of
         // the previous launch / lifetime of its waves = the rate an XCD showed; new share = half the old one, half the rate's
-        if (threadIdx.x == 0 && fb_split) {
+        if (threadIdx.x < 64 && fb_split) {                     // lane x < 8 = XCD x (one load round trip, sums and prefix by shuffles)
+            const int x = threadIdx.x & 7;
+            const bool mine = threadIdx.x < 8;
             const int cur = fb_cur, prev = (cur + 2) % 3, next = (cur + 1) % 3;
-            float wp[8], w[8], rate[8];
-            bool ok = fb_t != nullptr;
-            float rsum = 0.f, wsum = 0.f;
-            for (int x = 0; x < 8; x++) {
-                wp[x] = fb_w[prev * 8 + x];
-                const unsigned int tp = fb_t ? fb_t[prev * 8 + x] : 0u;
-                ok = ok && tp > 0u && wp[x] > 0.f;
-                rate[x] = ok ? wp[x] / (float)tp : 0.f;
-                rsum += rate[x];
-            }
-            for (int x = 0; x < 8; x++) {
-                w[x] = !(wp[x] > 0.f) ? 0.125f : ok ? 0.5f * wp[x] + 0.5f * (rate[x] / rsum) : wp[x];
-                w[x] = fminf(fmaxf(w[x], 0.0625f), 0.25f);
-                wsum += w[x];
-            }
-            const double per = (double)total_groups / (double)wsum;
+            const float wp = fb_w[prev * 8 + x];
+            const unsigned int tp = fb_t ? fb_t[prev * 8 + x] : 0u;
+            const bool ok = __all(tp > 0u && wp > 0.f);           // (lanes 8.. repeat lanes 0..7)
+            const float rate = ok ? wp / (float)tp : 0.f;
+            float rsum = rate;
+            rsum += __shfl_xor(rsum, 1);
+            rsum += __shfl_xor(rsum, 2);
+            rsum += __shfl_xor(rsum, 4);
+            float w = !(wp > 0.f) ? 0.125f : ok ? 0.5f * wp + 0.5f * (rate / rsum) : wp;
+            w = fminf(fmaxf(w, 0.0625f), 0.25f);
+            float wsum = w;
+            wsum += __shfl_xor(wsum, 1);
+            wsum += __shfl_xor(wsum, 2);
+            wsum += __shfl_xor(wsum, 4);
+            // exclusive prefix over the eight lanes, added in XCD order (every lane the same sequence of additions)
             double cum = 0.0;
-            for (int x = 0; x < 8; x++) {
-                fb_split[x] = (int64_t)(cum * per);
-                cum += (double)w[x];
-                fb_w[cur * 8 + x] = w[x] / wsum;
-                if (fb_t) fb_t[next * 8 + x] = 0u;
+            for (int y = 0; y < 8; y++) {
+                const float wy = __shfl(w, y);
+                if (y < x) cum += (double)wy;
             }
-            fb_split[8] = total_groups;
+            if (mine) {
+                fb_split[x] = (int64_t)(cum * ((double)total_groups / (double)wsum));
+                fb_w[cur * 8 + x] = w / wsum;
+                if (fb_t) fb_t[next * 8 + x] = 0u;
+                if (x == 0) fb_split[8] = total_groups;
+            }
         }
     }
     if (i < K_max) {
