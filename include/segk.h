@@ -45,14 +45,17 @@ const char *segk_last_error(void);
 /* ABI version, bumped on any change of a signature or of a structure below (SEGK_ABI_VERSION is the version this
  * header describes; a binding must refuse a library that reports another one: segmentalist_amd/_abi.py does).
  *   1 rounds 1-2 | 2 round 2: segk_corpus gained band_W / band_ids / band_dur (the bump was forgotten then)
- *   3 round 3: segk_fbb_set_probe, segk_kmeans_score_hinted; this check                                                           */
+ *   3 round 3: segk_fbb_set_probe, segk_kmeans_score_hinted; this check
+ *   4 round 3: scratch sizes of segk_kmeans_batch_partials from segk_kmeans_batch_scratch_words; segk_profile_enable(N)          */
 #define SEGK_ABI_VERSION 4
 int32_t segk_abi_version(void);
 
 /* Timing of the MAIN launch of the MFMA score kernel (k_kmeans_score<..., 0>) with HIP events
  * recorded on its launch stream inside segk_kmeans_filter (and of its log-sum-exp twin inside
  * segk_fbb_score_f32) -- what bench.py's roofline.achieved is computed from.  segk_profile_read synchronises and returns, oldest first, the duration (ms) and
- * the row count of the most recent recorded launches (at most `max`, at most 256 kept).          */
+ * the row count of the most recent recorded launches (at most `max`, at most 256 kept).
+ * on = 0: off; on = N >= 1: every Nth timed launch records its event pair (an event record between two kernels costs the
+ * stream a few microseconds of bubble: bench.py samples every 8th sweep of its timed region).                            */
 int32_t segk_profile_enable(segk_ctx *ctx, int32_t on);
 int32_t segk_profile_read(segk_ctx *ctx, float *ms_out, int64_t *rows_out, int32_t max);
 /* Which kernel the most recent recorded launch was: 0 the fp32-MFMA filter, 2 / 3 the split-precision

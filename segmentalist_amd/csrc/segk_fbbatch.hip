@@ -1573,7 +1573,7 @@ int32_t segk_fbb_score_diag32(segk_ctx *ctx, const segk_corpus *c, const segk_fb
     const bool two_groups = f->K_max <= 128;
     const size_t lds = lds0 + (tlds ? tbl : 0);
     hipStream_t st = (hipStream_t)stream;
-    const bool prof = ctx && ctx->prof_on != 0;
+    const bool prof = ctx && segk_prof_now(ctx);
     const int slot = prof ? ctx->prof_n % SEGK_PROF_SLOTS : 0;
     int64_t rows = 0;
     for (int s = 0; s < s_n; s++) rows += n_rows[s];

@@ -108,7 +108,7 @@ int32_t segk_destroy(segk_ctx *ctx)
 }
 
 // Timing of the main launch of the MFMA score kernel with HIP events recorded on its launch stream
-// (bench.py: roofline.achieved).  While enabled every segk_kmeans_filter call records one pair.
+// (bench.py: roofline.achieved).  While enabled every `on`-th timed launch records one pair.
 int32_t segk_profile_enable(segk_ctx *ctx, int32_t on)
 {
     SEGK_REQUIRE(ctx, "ctx");
@@ -116,7 +116,8 @@ int32_t segk_profile_enable(segk_ctx *ctx, int32_t on)
         for (int i = 0; i < SEGK_PROF_SLOTS; i++)
             for (int j = 0; j < 2; j++)
                 if (!ctx->prof_ev[i][j]) SEGK_CHECK_HIP(hipEventCreate(&ctx->prof_ev[i][j]));
-    ctx->prof_on = on ? 1 : 0;
+    ctx->prof_on = on > 0 ? on : 0;
+    ctx->prof_calls = 0;
     ctx->prof_n = 0;
     if (on) ctx->prof_kind = -1;
     return SEGK_OK;

@@ -59,10 +59,20 @@ struct segk_ctx {
     double *probe_alpha, *probe_ll;
     int64_t probe_ll_ld;
     // optional timing of the main score launch (segk_profile_*): event pairs used round-robin
-    int prof_on, prof_n, prof_kind;
+    int prof_on, prof_n, prof_kind;      // prof_on: 0 off, N: every Nth timed launch records its event pair
+    unsigned int prof_calls;
     hipEvent_t prof_ev[SEGK_PROF_SLOTS][2];
     int64_t prof_rows[SEGK_PROF_SLOTS];
 };
+
+// does THIS launch record its event pair?  (segk_profile_enable(ctx, N): every Nth -- an event record between two kernels costs
+// the stream ~3 us of bubble, 6.5 us per sweep around the headline kernel with N = 1)
+static inline bool segk_prof_now(segk_ctx *ctx)
+{
+    if (!ctx->prof_on) return false;
+    return (ctx->prof_calls++ % (unsigned int)ctx->prof_on) == 0u;
+}
+
 
 void segk_set_error(const char *fmt, ...);
 

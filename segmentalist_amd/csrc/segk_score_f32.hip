@@ -381,7 +381,7 @@ static int launch_score(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *
     if (main_chunks > 0) {
         ScoreArgs M = A;
         M.n = n_main;
-        const bool prof = ctx->prof_on != 0;
+        const bool prof = segk_prof_now(ctx);
         const int slot = ctx->prof_n % SEGK_PROF_SLOTS;
         if (prof) SEGK_CHECK_HIP(hipEventRecord(ctx->prof_ev[slot][0], st));
         hipLaunchKernelGGL((k_kmeans_score<GMAX, NB, WAVES, 0>), dim3((unsigned)main_chunks), dim3(64 * WAVES), lds, st, M);
@@ -430,7 +430,7 @@ static int launch_score_lse(segk_ctx *ctx, const ScoreArgs &A, hipStream_t st)
         attr_set = true;
     }
     const int64_t chunks = (A.n + 127) / 128;
-    const bool prof = ctx && ctx->prof_on != 0;
+    const bool prof = ctx && segk_prof_now(ctx);
     const int slot = prof ? ctx->prof_n % SEGK_PROF_SLOTS : 0;
     if (prof) SEGK_CHECK_HIP(hipEventRecord(ctx->prof_ev[slot][0], st));
     hipLaunchKernelGGL((k_kmeans_score<GMAX, 1, 4, 0, 1>), dim3((unsigned)chunks), dim3(256), lds, st, A);

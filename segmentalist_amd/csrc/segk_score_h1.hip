@@ -613,7 +613,7 @@ static int launch_score_pre(segk_ctx *ctx, ScoreArgs A, hipStream_t st)
     // whole rounds of 512-row workgroups (four row blocks per wave), the remainder in 256-row workgroups
     const int64_t round4 = slots * 512;
     const int64_t n4 = (A.n / round4) * round4;
-    const bool prof = ctx->prof_on != 0;
+    const bool prof = segk_prof_now(ctx);
     const int slot = ctx->prof_n % SEGK_PROF_SLOTS;
     // the timed interval (segk_profile_*): the 512-row-workgroup launch when there is one, else the 256-row one
     auto prof_end = [&](int64_t rows, int launches) -> int {

@@ -820,7 +820,7 @@ static int launch_score_hint(segk_ctx *ctx, ScoreArgs A, const int32_t *remap, i
         if ((int64_t)grid1 / n_ranges > steps) grid1 = (int)steps * n_ranges;
     }
     SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_kmeans_top2_rs<KS, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
-    const bool prof = ctx->prof_on != 0;
+    const bool prof = segk_prof_now(ctx);
     const int slot = ctx->prof_n % SEGK_PROF_SLOTS;
     if (prof) SEGK_CHECK_HIP(hipEventRecord(ctx->prof_ev[slot][0], st));
     hipLaunchKernelGGL((k_kmeans_top2_rs<KS, 4>), dim3((unsigned)grid1), dim3(256), lds1, st, H);

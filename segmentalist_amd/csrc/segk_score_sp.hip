@@ -320,7 +320,7 @@ static int launch_score_sp(segk_ctx *ctx, ScoreArgs A, hipStream_t st)
     if (main_chunks > 0) {
         ScoreArgs M = A;
         M.n = n_main;
-        const bool prof = ctx->prof_on != 0;
+        const bool prof = segk_prof_now(ctx);
         const int slot = ctx->prof_n % SEGK_PROF_SLOTS;
         if (prof) SEGK_CHECK_HIP(hipEventRecord(ctx->prof_ev[slot][0], st));
         hipLaunchKernelGGL((k_kmeans_score_sp<KS, 4, P>), dim3((unsigned)main_chunks), dim3(256), lds, st, M);
@@ -372,7 +372,7 @@ static int launch_score_lse_sp(segk_ctx *ctx, const ScoreArgs &A, hipStream_t st
         attr_set = true;
     }
     const int64_t chunks = (A.n + 127) / 128;
-    const bool prof = ctx && ctx->prof_on != 0;
+    const bool prof = ctx && segk_prof_now(ctx);
     const int slot = prof ? ctx->prof_n % SEGK_PROF_SLOTS : 0;
     if (prof) SEGK_CHECK_HIP(hipEventRecord(ctx->prof_ev[slot][0], st));
     hipLaunchKernelGGL((k_kmeans_score_sp<KS, 4, 2, 1>), dim3((unsigned)chunks), dim3(256), lds, st, A);
