@@ -782,7 +782,10 @@ static int launch_score_hint(segk_ctx *ctx, ScoreArgs A, const int32_t *remap, i
     }
     const bool fb_off = getenv("SEGK_HINT_BALANCE") && atoi(getenv("SEGK_HINT_BALANCE")) == 0;
     float *fb_w = (float *)ctx->hint_fb;
-    unsigned int *fb_t = fb_off ? nullptr : (unsigned int *)(fb_w + 24);
+    // (only where a wave has a few dozen groups to shift: at shard sizes -- 4 to 8 groups of 5 us per wave -- shares other
+    // than equal ones only make the last round ragged: 1 250 utterances 5 960 against 6 215 sweeps/s, 2 500: 4 878 against 4 948)
+    const bool fb_big = (A.n + 63) / 64 >= 192 * 64;
+    unsigned int *fb_t = (fb_off || !fb_big) ? nullptr : (unsigned int *)(fb_w + 24);
     int64_t *fb_split = (int64_t *)(fb_w + 48);                  // [9] (+ padding), rewritten by every launch of k_hint_map
     const int fb_cur = (int)(ctx->hint_fb_launch++ % 3u);
     const int64_t total_groups = (A.n + 63) / 64;                // k_kmeans_top2_rs<KS, 4>: two blocks of 32 rows per group
