@@ -57,6 +57,7 @@ struct HintArgs {
     unsigned int *fb_t;             // [3][8] how long its waves lived (s_memrealtime ticks, maximum); NULL: equal shares
     int fb_cur;                     // this launch's slot
     const int64_t *fb_split;        // [9] this launch's first group per XCD (k_hint_map)
+    int64_t k1_groups;              // groups this kernel multiplies (the few behind the last whole round of all waves go to the second stage)
 };
 
 // ---- K1 ---------------------------------------------------------------------------------------------------------------
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_kmeans_top2_rs(HintArgs H)
     const T *plane0 = (const T *)(H.ximg + SEGK_SP_HEADER);
     // this wave's row groups: g_first, g_first + n_slots, ... below n_groups
     const int64_t total_groups = (H.n + 32 * NBLK - 1) / (32 * NBLK);
-    int64_t n_groups = total_groups, n_slots = (int64_t)n_wgr * NW, g_first = (int64_t)wgr * NW + wave;
+    int64_t n_groups = H.k1_groups < total_groups ? H.k1_groups : total_groups, n_slots = (int64_t)n_wgr * NW, g_first = (int64_t)wgr * NW + wave;
     // Under this kernel the chip runs into its power limit, and the eight XCDs then hold DIFFERENT clocks (1.65-1.77 GHz
     // measured, the same XCDs slow launch after launch): with equal shares the fast ones idle for the last 10-20 us of 200.
     // So an XCD takes a contiguous share of the groups in proportion to the rate it showed in the previous launch (its share
@@ -414,7 +415,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_kmeans_top2_rs(HintArgs H)
 //   the second stage's counters.
 __global__ void k_hint_map(const int32_t *remap, const float *tiles_sp /* first tile */, int K_max, int stride, int const_off, int32_t *map,
                            const int32_t *ids, int64_t row0, int64_t n, int32_t *cand_k, int32_t *zero_cnt, int32_t *pre_hdr,
-                           float *fb_w, unsigned int *fb_t, int fb_cur, int64_t *fb_split, int64_t total_groups)
+                           float *fb_w, unsigned int *fb_t, int fb_cur, int64_t *fb_split, int64_t total_groups, int64_t first_skipped,
+                           float2 *part, int n_ranges)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (blockIdx.x == 0) {
@@ -454,6 +456,10 @@ __global__ void k_hint_map(const int32_t *remap, const float *tiles_sp /* first 
             }
         }
     }
+    // rows the matrix kernel leaves out (the groups behind the last whole round of all its waves, when they are few): (m1, m2) =
+    // (0, 0) in every range reads as "undecided" to the exact stage, which queues them for the second stage
+    if (i >= first_skipped && i < n)
+        for (int rg = 0; rg < n_ranges; rg++) part[(int64_t)rg * n + i] = make_float2(0.f, 0.f);
     if (i < K_max) {
         int v = remap ? remap[i] : (int)i;
         if (v < 0 || v >= K_max) v = -1;
@@ -789,11 +795,29 @@ static int launch_score_hint(segk_ctx *ctx, ScoreArgs A, const int32_t *remap, i
     int64_t *fb_split = (int64_t *)(fb_w + 48);                  // [9] (+ padding), rewritten by every launch of k_hint_map
     const int fb_cur = (int)(ctx->hint_fb_launch++ % 3u);
     const int64_t total_groups = (A.n + 63) / 64;                // k_kmeans_top2_rs<KS, 4>: two blocks of 32 rows per group
+    // K1's grid: four waves per workgroup (one per SIMD with the next group's rows prefetched into registers; the eight-wave
+    // instantiation -- two per SIMD, no prefetch: +6 % -- is still in the kernel's template, no longer launched)
+    constexpr int nw1 = 4;
+    int grid1 = (n_cu / n_ranges) * n_ranges;
+    {   // no more workgroups than there are steps per range (each wave takes 64 rows at a time)
+        const int64_t rows_ws = 64 * (int64_t)nw1;                          // rows a workgroup takes per step
+        const int64_t steps = (A.n + rows_ws - 1) / rows_ws;
+        if ((int64_t)grid1 / n_ranges > steps) grid1 = (int)steps * n_ranges;
+    }
+    // With equal shares every wave walks the groups slot, slot + slots, ...: when a handful of groups is left behind the last
+    // whole round (a 1 250-utterance shard: 2 051 groups = 4 x 512 + 3) three waves would take a fifth group, 5 us, for all
+    // the others to wait on.  Those few rows skip the filter: marked undecided (k_hint_map), they take the second stage.
+    int64_t k1_groups = total_groups;
+    if (!fb_t) {
+        const int64_t slots = (int64_t)(grid1 / n_ranges) * nw1;
+        const int64_t whole = slots > 0 ? (total_groups / slots) * slots : 0;
+        if (whole > 0 && total_groups - whole <= 32) k1_groups = whole;
+    }
     {
         const int64_t nthr = A.n > A.K_max ? A.n : A.K_max;
         hipLaunchKernelGGL(k_hint_map, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, remap, A.tiles + 1024, A.K_max, stride_sp,
                            KS * 2 * 256, ctx->hint_map, A.ids, A.row0, A.n, A.cand.k, zero_cnt, ctx->pre_queue, fb_w, fb_t, fb_cur,
-                           fb_split, total_groups);
+                           fb_split, total_groups, k1_groups * 64, (float2 *)ctx->hint_part, n_ranges);
     }
 
     // ---- K1
@@ -812,16 +836,8 @@ static int launch_score_hint(segk_ctx *ctx, ScoreArgs A, const int32_t *remap, i
     H.fb_t = fb_t;
     H.fb_cur = fb_cur;
     H.fb_split = fb_split;
+    H.k1_groups = k1_groups;
     const size_t lds1 = (size_t)tpr * TL * sizeof(float);
-    // four waves per workgroup: one per SIMD with the next group's rows prefetched into registers (the eight-wave
-    // instantiation -- two per SIMD, no prefetch: +6 % -- is still in the kernel's template, no longer launched)
-    constexpr int nw1 = 4;
-    int grid1 = (n_cu / n_ranges) * n_ranges;
-    {   // no more workgroups than there are steps per range (each wave takes 64 rows at a time)
-        const int64_t rows_ws = 64 * (int64_t)nw1;                          // rows a workgroup takes per step
-        const int64_t steps = (A.n + rows_ws - 1) / rows_ws;
-        if ((int64_t)grid1 / n_ranges > steps) grid1 = (int)steps * n_ranges;
-    }
     SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_kmeans_top2_rs<KS, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
     const bool prof = segk_prof_now(ctx);
     const int slot = ctx->prof_n % SEGK_PROF_SLOTS;
