@@ -9,7 +9,7 @@ from segmentalist_amd import _abi, kmeans_acoustic_wordseg as kaw
 if os.environ.get("SEGK_LIB_PATH"):          # a -DSEGK_STAMP build kept beside the product build (build_stamp/libsegk_stamp.so)
     _abi.LIB_PATH = os.environ["SEGK_LIB_PATH"]
 from segmentalist_amd.synth import make_corpus
-corpus = make_corpus(10000, 100, 1000, seed=0, N=20, n_slices_max=6)
+corpus = make_corpus(int(sys.argv[1]) if len(sys.argv) > 1 else 10000, 100, 1000, seed=0, N=20, n_slices_max=6)
 random.seed(0); np.random.seed(0)
 seg = kaw.SegmentalKMeansWordseg(1000, *corpus, n_slices_max=6, init_am_assignments="spread", sync="batch")
 for _ in range(6): seg.batch_sweep_async()
