@@ -62,6 +62,9 @@ __global__ void k_fbb_partials(segk_corpus c, segk_fbgmm f, segk_fbatch bt, int 
 {
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
+    // (the step's totals -- read by its score and assignment kernels, rebuilt with atomics by the next k_fbb_prepare -- are
+    // cleared here: a memset of 16 bytes in front of every prepare was a 4.5 us launch)
+    if (wave == 0 && lane < 2) bt.scal[lane] = 0.0;
     if (wave >= s_n * f.K_max) return;
     const int s = s_lo + wave / f.K_max, k = wave % f.K_max;
     const int D = c.D;
@@ -211,6 +214,9 @@ __global__ void k_fbb_partials_sorted(segk_corpus c, segk_fbgmm f, segk_fbatch b
 {
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
+    // (the step's totals -- read by its score and assignment kernels, rebuilt with atomics by the next k_fbb_prepare -- are
+    // cleared here: a memset of 16 bytes in front of every prepare was a 4.5 us launch)
+    if (wave == 0 && lane < 2) bt.scal[lane] = 0.0;
     if (wave >= s_n * f.K_max) return;
     const int si = wave / f.K_max, s = s_lo + si, k = wave % f.K_max;
     const int D = c.D;
@@ -1469,23 +1475,25 @@ int32_t segk_fbb_partials(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm 
         DISPATCH_XT(c, hipLaunchKernelGGL(k_fbb_partials_sorted<XT>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0,
                                            (hipStream_t)stream, *c, *f, *bt, s_lo, s_n, b, sorted, stride, koff););
         SEGK_LAUNCH_CHECK();
+        ctx->fbb_scal_zeroed = (const void *)bt->scal;             // (the kernel cleared the totals for the next segk_fbb_prepare)
         return SEGK_OK;
     }
     DISPATCH_XT(c, hipLaunchKernelGGL(k_fbb_partials<XT>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0,
                                        (hipStream_t)stream, *c, *f, *bt, s_lo, s_n, b, new_tok, n_new););
     SEGK_LAUNCH_CHECK();
+    if (ctx) ctx->fbb_scal_zeroed = (const void *)bt->scal;
     return SEGK_OK;
 }
 
 int32_t segk_fbb_prepare(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *f, const segk_fbatch *bt, int32_t b,
                          void *stream)
 {
-    (void)ctx;
     int rc = check_fbb(c, f, bt);
     if (rc) return rc;
     SEGK_REQUIRE(b >= -1 && b < bt->n_blocks, "block");
     hipStream_t st = (hipStream_t)stream;
-    SEGK_CHECK_HIP(hipMemsetAsync(bt->scal, 0, 2 * sizeof(double), st));
+    if (!ctx || ctx->fbb_scal_zeroed != (const void *)bt->scal) SEGK_CHECK_HIP(hipMemsetAsync(bt->scal, 0, 2 * sizeof(double), st));
+    if (ctx) ctx->fbb_scal_zeroed = nullptr;
     const double alpha = f->lm_unigram ? f->lm_a : f->alpha;
     hipLaunchKernelGGL(k_fbb_prepare, dim3((f->K_max + 3) / 4), dim3(256), 0, st, *f, *bt, c->D, b, alpha);
     if (bt->tiles16 && bt->y16 && f->cov_type == 0) {

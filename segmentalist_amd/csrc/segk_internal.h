@@ -31,6 +31,7 @@ struct segk_ctx {
     // batch sampler: the block's tokens bucketed by slot (k_fbb_sort) + offsets
     int32_t *fbs_buf;
     size_t fbs_bytes;
+    const void *fbb_scal_zeroed;  // segk_fbb_partials cleared these totals on the stream: the next segk_fbb_prepare need not
     int prof_launches;
     int32_t *defer_zero;          // segk_kmeans_score: queue length the chosen filter path still has to clear
     int pre_zeroed;
