@@ -810,12 +810,14 @@ def test_sequential_sweep_with_a_repeated_utterance(gpu, monkeypatch):
         assert out[0][5] == other[5]
 
 
-@pytest.mark.parametrize("n_utt,D,K,N,nmax,ragged", [(400, 16, 40, 20, 6, False), (300, 8, 25, 0, 8, True), (200, 12, 30, 0, 3, True)])
+@pytest.mark.parametrize("n_utt,D,K,N,nmax,ragged", [(400, 16, 40, 20, 6, False), (300, 8, 25, 0, 8, True), (200, 12, 30, 0, 3, True),
+                                                     (150, 8, 20, 44, 8, False), (120, 8, 20, 64, 5, False)])
 def test_segment_kernels_agree(gpu, monkeypatch, n_utt, D, K, N, nmax, ragged):
     """The per-utterance DP by the whole wave (seg_w8_wave: eight lanes per step, DPP maxima, token lists from ballots; the
     default below 4 096 utterances), with eight utterances per wave (k_kmeans_segment_oct, the default above; forced here with
     SEGK_SEGMENT_OCT=1) and the generic kernel (SEGK_SEGMENT_GENERIC=1): identical boundaries, labels and statistics after
-    three batch sweeps -- uniform utterances, ragged ones shorter than the window, a window of eight."""
+    three batch sweeps -- uniform utterances, ragged ones shorter than the window, a window of eight, 44 and 64 landmarks
+    (boundary masks beyond 32 bits, several steps of eight bits in the token lists)."""
     from segmentalist_amd import kmeans_acoustic_wordseg as kaw
     corpus = cases.chain_corpus(n_utt, D, K, 31 * n_utt + D, ragged, N, nmax, "float32")
     out = []
