@@ -10,7 +10,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsegk.so")
+LIB_PATH = os.environ.get("SEGK_LIB_PATH") or os.path.join(_HERE, "libsegk.so")      # (SEGK_LIB_PATH: a development build kept beside the product build)
 
 SEGK_F32, SEGK_F64 = 0, 1
 ABI_VERSION = 4          # SEGK_ABI_VERSION of include/segk.h this binding was written against
