@@ -245,6 +245,167 @@ __global__ __launch_bounds__(256) void k_kmeans_brute_rows(segk_corpus c, segk_k
     }
 }
 
+// The full scan with the COMPONENTS resident in LDS (round 3; float32 data, 8 <= D <= 128).  k_kmeans_brute_rows gives
+// every group of four queued rows a workgroup of its own, which reads the whole table of means for them: 1 600 rows = 160 MB
+// through the L2s and a thousand workgroups to dispatch.  Here a workgroup keeps a slice of BLS_TPS tiles (128 components:
+// 51 KB as float32, the layout of the tile image) and walks a CHUNK of the queue with it, 32 rows at a time: the ids of the
+// chunk are fetched once, the next 32 rows are in flight while the current 32 are scored.  Thread = (component of the slice,
+// four of the 32 rows), sixteen waves (with four -- one per SIMD -- every dependent LDS read and packed operation was
+// exposed); arithmetic and first-maximum rule as in k_kmeans_brute_rows (neg_sqd_exact's order, packed pairs); the slices of
+// a row meet in ws[] by a 64-bit atomic maximum of (orderable score bits, ~component), one per wave, unpacked by
+// k_brute_finish_ls.
+#define BLS_TPS 4
+#define BLS_THREADS 1024
+#define BLS_ROWS (BLS_THREADS / 128 * 4)      /* rows per batch */
+#define BLS_IDS 256
+__global__ __launch_bounds__(BLS_THREADS) void k_kmeans_brute_ls(segk_corpus c, segk_kmeans m, segk_cand cand, int cap, int32_t *n_brute,
+                                                                int n_slices, int n_chunks, unsigned long long *ws)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, D = c.D;
+    const int DP = (D + 3) & ~3;                             // row pitch: float4 reads of the staged rows
+    const int TP = segk_G(D) * 128;                          // floats of a tile that hold means
+    const int tstride = segk_tile_stride(D);
+    float *ts = (float *)smem;                               // [BLS_TPS][TP]
+    float *xs = ts + BLS_TPS * TP;                           // [BLS_ROWS][DP]
+    __shared__ int32_t ids[BLS_IDS];
+    const float *X = (const float *)c.X;
+    int nq = *cand.count;
+    if (nq > cap) nq = cap;
+    if (blockIdx.x == 0 && tid == 0 && n_brute && nq > 0) atomicAdd(n_brute, nq);
+    const int slice = blockIdx.x % n_slices, chunk = blockIdx.x / n_slices;
+    const int per = ((nq + n_chunks - 1) / n_chunks + BLS_ROWS - 1) & ~(BLS_ROWS - 1);
+    const int q_lo = chunk * per, q_hi = q_lo + per < nq ? q_lo + per : nq;
+    if (q_lo >= q_hi) return;
+    // ---- the slice's tiles (all K_max slots: the reference's argmax runs over every row of `means`)
+    const int n_tiles = segk_n_tiles(m.K_max);
+    const int tile0 = slice * BLS_TPS;
+    const int nth = n_tiles - tile0 < BLS_TPS ? n_tiles - tile0 : BLS_TPS;
+    for (int i = tid; i < nth * (TP / 4); i += BLS_THREADS) {
+        const int t = i / (TP / 4), o = i - t * (TP / 4);
+        reinterpret_cast<float4 *>(ts + t * TP)[o] = reinterpret_cast<const float4 *>(m.tiles + (int64_t)(tile0 + t) * tstride)[o];
+    }
+    const int comp_l = tid & 127, rh = tid >> 7;
+    const int k = tile0 * 32 + comp_l;
+    const bool live = comp_l < nth * 32 && k < m.K_max;
+    const TileRow mr{ts + (live ? (comp_l >> 5) * TP + 2 * (comp_l & 31) : 0)};
+    const int nfull = D - (D % 8);
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    auto pk_sub = [](f32x2_t a, f32x2_t b2) -> f32x2_t {
+        f32x2_t d;
+        asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b2));
+        return d;
+    };
+    auto load_m = [&](int i, f32x2_t *mp) {                  // the eight elements of block i as four adjacent pairs
+        const float *b = mr.base + (i >> 2) * 128;
+#pragma unroll
+        for (int q = 0; q < 4; q++) mp[q] = *reinterpret_cast<const f32x2_t *>(b + (q >> 1) * 128 + (q & 1) * 64);
+    };
+    // elements of a batch of rows this thread moves: j = tid + BLS_THREADS e -> (row j / D, dimension j % D)
+    constexpr int NPF = 4;                                   // BLS_ROWS rows x D <= 128 floats / BLS_THREADS threads
+    float pf[NPF];
+    auto fetch = [&](int qb, int ib) {                       // rows qb .. of the queue (ids at ids[ib ..])
+#pragma unroll
+        for (int e = 0; e < NPF; e++) {
+            const int j = tid + BLS_THREADS * e;
+            const int r = j / D, d = j - r * D;
+            const bool ok = r < BLS_ROWS && qb + r < q_hi;
+            pf[e] = ok ? X[(int64_t)ids[ib + r] * c.ldx + d] : 0.f;
+        }
+    };
+    for (int s0 = q_lo; s0 < q_hi; s0 += BLS_IDS) {
+        const int ns = q_hi - s0 < BLS_IDS ? q_hi - s0 : BLS_IDS;
+        __syncthreads();                                     // the previous super-chunk's ids are no longer read
+        if (tid < ns) ids[tid] = cand.queue[s0 + tid];
+        __syncthreads();
+        fetch(s0, 0);
+        for (int b0 = 0; b0 < ns; b0 += BLS_ROWS) {
+            const int q0 = s0 + b0;
+            const int nr = q_hi - q0 < BLS_ROWS ? q_hi - q0 : BLS_ROWS;
+            __syncthreads();                                 // the previous batch's rows are no longer read (first trip: the tiles are staged)
+#pragma unroll
+            for (int e = 0; e < NPF; e++) {
+                const int j = tid + BLS_THREADS * e;
+                const int r = j / D, d = j - r * D;
+                if (r < BLS_ROWS) xs[r * DP + d] = pf[e];
+            }
+            __syncthreads();
+            if (b0 + BLS_ROWS < ns) fetch(q0 + BLS_ROWS, b0 + BLS_ROWS);        // in flight under the arithmetic
+            const float *xr = xs + rh * 4 * DP;
+            f32x2_t acc[4][4];
+            f32x2_t mp[4];
+            load_m(0, mp);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const float4 x0 = *reinterpret_cast<const float4 *>(xr + r * DP), x1 = *reinterpret_cast<const float4 *>(xr + r * DP + 4);
+                const f32x2_t xp[4] = {{x0.x, x0.y}, {x0.z, x0.w}, {x1.x, x1.y}, {x1.z, x1.w}};
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const f32x2_t d = pk_sub(mp[q], xp[q]);
+                    acc[r][q] = d * d;
+                }
+            }
+            int i;
+            for (i = 8; i < nfull; i += 8) {
+                load_m(i, mp);
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const float4 x0 = *reinterpret_cast<const float4 *>(xr + r * DP + i), x1 = *reinterpret_cast<const float4 *>(xr + r * DP + i + 4);
+                    const f32x2_t xp[4] = {{x0.x, x0.y}, {x0.z, x0.w}, {x1.x, x1.y}, {x1.z, x1.w}};
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const f32x2_t d = pk_sub(mp[q], xp[q]);
+                        acc[r][q] += d * d;
+                    }
+                }
+            }
+            float res[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                res[r] = ((acc[r][0].x + acc[r][0].y) + (acc[r][1].x + acc[r][1].y)) + ((acc[r][2].x + acc[r][2].y) + (acc[r][3].x + acc[r][3].y));
+            for (; i < D; i++) {
+                const float mvi = mr[i];
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const float delta = mvi - xr[r * DP + i];
+                    res[r] += delta * delta;
+                }
+            }
+            // (orderable score bits, ~component): the largest score, the lowest component on ties; maximum over the wave's 64
+            // components by butterfly, one atomic per wave and row
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                unsigned long long key = 0ull;
+                if (live) {
+                    const unsigned int bits = __float_as_uint(-res[r]);
+                    const unsigned int ord = (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);
+                    key = ((unsigned long long)ord << 32) | (unsigned long long)(0xffffffffu - (unsigned)k);
+                }
+                for (int o = 32; o > 0; o >>= 1) {
+                    const unsigned long long other = __shfl_xor(key, o);
+                    key = other > key ? other : key;
+                }
+                if (lane == 0 && rh * 4 + r < nr && key != 0ull) atomicMax(&ws[q0 + rh * 4 + r], key);
+            }
+        }
+    }
+}
+
+__global__ void k_brute_finish_ls(segk_cand cand, int cap, unsigned long long *ws)
+{
+    int nq = *cand.count;
+    if (nq > cap) nq = cap;
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += gridDim.x * blockDim.x) {
+        const unsigned long long pk = ws[q];
+        ws[q] = 0ull;
+        const unsigned int ord = (unsigned int)(pk >> 32);
+        const unsigned int bits = (ord & 0x80000000u) ? (ord & 0x7fffffffu) : ~ord;
+        const int32_t id = cand.queue[q];
+        cand.k[id] = (int32_t)(0xffffffffu - (unsigned int)(pk & 0xffffffffu));
+        cand.s[id] = (double)__uint_as_float(bits);
+    }
+}
+
 // unpack the split scan's (score, component) pairs into the candidates and clear the workspace
 __global__ void k_brute_finish(segk_cand cand, int cap, unsigned long long *ws, int ws_cap, int scan_grid, int max_split)
 {
@@ -462,6 +623,34 @@ int segk_resolve_on(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m, c
         DISPATCH_XT(c, hipLaunchKernelGGL(k_kmeans_exact_fill<XT>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
                                            *c, *m, ids, row0, n, *cand););
     const int nt = 256;
+    // components in LDS, a chunk of the queue per workgroup (SEGK_BRUTE_LS=0: one workgroup per four rows)
+    if (fused && !ctx->capturing && !(getenv("SEGK_BRUTE_LS") && atoi(getenv("SEGK_BRUTE_LS")) == 0)) {
+        if (ctx->brute_ws_cap < n) {
+            SEGK_CHECK_HIP(hipStreamSynchronize(st));
+            if (ctx->brute_ws) (void)hipFree(ctx->brute_ws);
+            ctx->brute_ws = nullptr;
+            ctx->brute_ws_cap = 0;
+            SEGK_CHECK_HIP(hipMalloc((void **)&ctx->brute_ws, sizeof(unsigned long long) * (size_t)n));
+            SEGK_CHECK_HIP(hipMemset(ctx->brute_ws, 0, sizeof(unsigned long long) * (size_t)n));
+            ctx->brute_ws_cap = n;
+        }
+        const int n_slices = (segk_n_tiles(m->K_max) + BLS_TPS - 1) / BLS_TPS;
+        int n_chunks = 256 / n_slices;
+        if (n_chunks < 1) n_chunks = 1;
+        const int64_t max_chunks = (n + BLS_ROWS - 1) / BLS_ROWS;
+        if (n_chunks > max_chunks) n_chunks = (int)max_chunks;
+        const size_t lds = ((size_t)BLS_TPS * segk_G(c->D) * 128 + (size_t)BLS_ROWS * ((c->D + 3) & ~3)) * sizeof(float);
+        static size_t lds_set = 0;
+        if (lds > 48 * 1024 && lds > lds_set) {
+            SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_kmeans_brute_ls, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            lds_set = lds;
+        }
+        hipLaunchKernelGGL(k_kmeans_brute_ls, dim3((unsigned)(n_slices * n_chunks)), dim3(BLS_THREADS), lds, st, *c, *m, *cand, (int)c->n_emb,
+                           status ? status + 1 : nullptr, n_slices, n_chunks, ctx->brute_ws);
+        hipLaunchKernelGGL(k_brute_finish_ls, dim3(32), dim3(256), 0, st, *cand, (int)c->n_emb, ctx->brute_ws);
+        SEGK_LAUNCH_CHECK();
+        return SEGK_OK;
+    }
     if (fused) {         // float32 data, 8 <= D <= 128: SEGK_BR queued rows per workgroup, components in slices
         const size_t lds = (size_t)SEGK_BR * ((c->D + 3) & ~3) * sizeof(float) + nt * (sizeof(float) + sizeof(int32_t));
         // grid for the worst case the host can see (every row queued), capped; the kernel reads the queue

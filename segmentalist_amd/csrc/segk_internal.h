@@ -53,6 +53,9 @@ struct segk_ctx {
     int hint_map_k;
     void *hint_fb;               // per-XCD shares and wave lifetimes of the matrix kernel's last launches, [3][8] floats + [3][8] uint32
     unsigned int hint_fb_launch;
+    // full scan with the components in LDS (k_kmeans_brute_ls): (score, component) per queue entry, zero between uses
+    unsigned long long *brute_ws;
+    int64_t brute_ws_cap;
     // k-means batch finalize: the flagged tokens of a sweep beyond the kernel's LDS list, [4][flag_ovf_cap] int32
     int32_t *flag_ovf;
     int64_t flag_ovf_cap;
