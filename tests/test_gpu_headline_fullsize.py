@@ -52,7 +52,7 @@ def headline(gpu, monkeypatch_module):
     """The headline segmenter after two batch sweeps (default environment)."""
     from segmentalist_amd import kmeans_acoustic_wordseg as kaw
     from segmentalist_amd.synth import make_corpus
-    for v in ("SEGK_SCORE_PRE", "SEGK_SCORE_B3", "SEGK_SCORE_HINT", "SEGK_MARK_DUPS", "SEGK_SEGMENT_OCT", "SEGK_SWEEP_GRAPH"):
+    for v in ("SEGK_SCORE_PRE", "SEGK_SCORE_B3", "SEGK_SCORE_HINT", "SEGK_MARK_DUPS", "SEGK_SEGMENT_OCT", "SEGK_SWEEP_GRAPH", "SEGK_BRUTE_LS"):
         monkeypatch_module.delenv(v, raising=False)
     corpus = make_corpus(N_UTT, D, K, seed=0, N=N_LM, n_slices_max=NMAX)
     random.seed(0)
@@ -122,10 +122,11 @@ def test_a_every_row_matches_the_oracle_argmax_and_score(headline, scored):
     assert (scored["cand_k"] >= 0).all() and (scored["cand_k"] < K).all()
 
 
-@pytest.mark.parametrize("env", [{"SEGK_SCORE_PRE": "0"}, {"SEGK_SCORE_B3": "0"}], ids=["no_prefilter", "fp32_matrix_filter"])
+@pytest.mark.parametrize("env", [{"SEGK_SCORE_PRE": "0"}, {"SEGK_SCORE_B3": "0"}, {"SEGK_BRUTE_LS": "0"}],
+                         ids=["no_prefilter", "fp32_matrix_filter", "full_scan_one_workgroup_per_four_rows"])
 def test_a_optional_launch_plans_give_the_same_bits(gpu, headline, scored, monkeypatch, env):
     """The other filters in front of the exact stages (the split-precision kernel alone; the fp32-MFMA filter of float64 data
-    and unusual D) on the same 1.05 M rows and statistics: cand_k / cand_s identical to the values test_a verified against
+    and unusual D; the full scan's earlier form) on the same 1.05 M rows and statistics: cand_k / cand_s identical to the values test_a verified against
     the oracle.  (The launch plans round 2 also tested here -- chunked pipeline, second stream, earlier forms of the exact
     stage -- lost on this hardware and were retired in round 3.)"""
     seg, _ = headline
