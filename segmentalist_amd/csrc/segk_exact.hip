@@ -631,7 +631,8 @@ int segk_resolve_on(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m, c
             ctx->brute_ws = nullptr;
             ctx->brute_ws_cap = 0;
             SEGK_CHECK_HIP(hipMalloc((void **)&ctx->brute_ws, sizeof(unsigned long long) * (size_t)n));
-            SEGK_CHECK_HIP(hipMemset(ctx->brute_ws, 0, sizeof(unsigned long long) * (size_t)n));
+            SEGK_CHECK_HIP(hipMemsetAsync(ctx->brute_ws, 0, sizeof(unsigned long long) * (size_t)n, st));      // (on the launch stream: a plain
+                                                                        // hipMemset is not ordered before kernels of another stream)
             ctx->brute_ws_cap = n;
         }
         const int n_slices = (segk_n_tiles(m->K_max) + BLS_TPS - 1) / BLS_TPS;

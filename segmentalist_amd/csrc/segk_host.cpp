@@ -66,6 +66,8 @@ int32_t segk_create(int32_t device_id, segk_ctx **out_ctx)
     if (err == hipSuccess) { what = "hipMalloc(ws_f)"; err = hipMalloc((void **)&c->ws_f, sizeof(float) * 2 * SEGK_WS_ENTRIES); }
     if (err == hipSuccess) { what = "hipMalloc(ws_u64)"; err = hipMalloc((void **)&c->ws_u64, sizeof(unsigned long long) * SEGK_WS_ENTRIES); }
     if (err == hipSuccess) { what = "hipMemset(ws_u64)"; err = hipMemset(c->ws_u64, 0, sizeof(unsigned long long) * SEGK_WS_ENTRIES); }
+    // (a device memset is not ordered before kernels of the caller's non-blocking streams: the workspace must read zero at its first use)
+    if (err == hipSuccess) { what = "hipDeviceSynchronize"; err = hipDeviceSynchronize(); }
     if (prev >= 0) {
         const hipError_t back = hipSetDevice(prev);
         if (err == hipSuccess && back != hipSuccess) { what = "hipSetDevice(previous)"; err = back; }
