@@ -63,14 +63,12 @@ int32_t segk_profile_read(segk_ctx *ctx, float *ms_out, int64_t *rows_out, int32
  * D % 4 == 0), 4 the log-sum-exp kernels of the FBGMM batch sampler, 5 the range-stationary one-product
  * top-2 kernel of segk_kmeans_score_hinted (k_kmeans_top2_rs); -1 none recorded.                      */
 int32_t segk_profile_last_kind(segk_ctx *ctx);
-/* Number of back-to-back launches of that kernel the most recent recorded interval spans (the one-product
- * pre-filter runs as up to four launches of one round each, so that the exact stage of one chunk overlaps the
- * pre-filter of the next); the recorded duration and row count cover all of them.                        */
+/* Number of back-to-back launches of that kernel the most recent recorded interval spans (1 since round 3 retired the
+ * chunked pre-filter pipeline); the recorded duration and row count cover all of them.                            */
 int32_t segk_profile_last_launches(segk_ctx *ctx);
 
 /* hipGraph capture of a launch sequence (no reference counterpart: the reference has no device).  Every
- * kernel the library enqueues on `stream` between begin and end -- including the work segk_kmeans_score
- * forks onto the context's second stream -- becomes one executable graph; segk_graph_launch replays it
+ * kernel the library enqueues on `stream` between begin and end becomes one executable graph; segk_graph_launch replays it
  * with a single host call.  Run the sequence once before capturing it (workspaces, streams, events and
  * kernel attributes are created on first use, which a capture cannot contain); `stream` must not be the
  * legacy default stream; pointers and scalar arguments are frozen into the graph.                    */

@@ -84,7 +84,7 @@ __global__ void k_kmeans_brute(segk_corpus c, segk_kmeans m, segk_cand cand, int
 // from L2-bandwidth bound (one pass over the tile image per row) to latency/compute bound.  Per
 // (row, component) the arithmetic is neg_sqd_exact's: eight strided accumulators, the fixed combine
 // tree, the sequential tail; first maximum per row.
-// BR = 4 (was 8: 234 VGPRs): in the pre-filter path the scan runs on the second stream beside the exact pair
+// BR = 4 (was 8: 234 VGPRs): when round 1 ran the scan on a second stream beside the exact pair
 // kernel, whose waves hold 144 VGPRs each -- with 8 rows its workgroups could not be placed until those
 // waves ended (121 us in the trace against 65 alone); with 4 the sweep gains 4 %.
 #define SEGK_BR 4

@@ -153,9 +153,8 @@ int32_t segk_profile_last_launches(segk_ctx *ctx)
 }
 
 // ----------------------------------------------------------------------------------------
-// hipGraph capture of a launch sequence (a whole batch sweep: ~12 kernels on two streams with their
-// fork / join events).  Everything the library enqueues between begin and end on `stream` -- and on the
-// context's second stream, which joins the capture through the fork event -- becomes one executable graph;
+// hipGraph capture of a launch sequence (a whole batch sweep: a dozen kernels).  Everything the library enqueues between
+// begin and end on `stream` becomes one executable graph;
 // replaying it costs one host call instead of a dozen launches.  Lazy initialisation (workspace growth,
 // stream / event creation, function attributes) must have happened before: run the sequence once, then
 // capture the second run.  The stream must not be the legacy default stream.

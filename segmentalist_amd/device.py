@@ -546,7 +546,7 @@ class KMeansBatchSweeper(object):
         """The sweep as one hipGraph (two around the all-gather with more than one rank), replayed on a stream of
         the sweeper's own (a capture cannot run on the legacy default stream); the caller's current stream is
         ordered before and after it.  The first sweep runs eagerly: it creates what a capture cannot contain
-        (workspaces, the second stream, kernel attributes)."""
+        (workspaces, kernel attributes)."""
         torch = _torch()
         dk, pt = self.dk, self.part
         args = (boundaries.data_ptr(), int(n_slices_min), int(n_slices_max), float(wip))

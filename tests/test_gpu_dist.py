@@ -72,7 +72,7 @@ def test_checkpoint_written_under_one_world_size_resumes_under_another(tmp_path)
 
 def test_batch_mode_with_the_prefilter_forced_is_independent_of_the_number_of_ranks(tmp_path):
     """The same with SEGK_SCORE_PRE=1: every rank scores its row range (first row > 0 on ranks > 0) through
-    the one-product pre-filter, the exact pair kernel and the second stage on the second stream; the result
+    the one-product pre-filter, the exact pair kernel, the second stage and the full scan; the result
     must still be the single-rank, un-prefiltered one bit for bit."""
     ref = run(1, str(tmp_path / "p0.npz"), env_extra={"SEGK_SCORE_PRE": "0"})
     for world in (1, 2, 4):
