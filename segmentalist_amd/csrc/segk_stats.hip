@@ -709,6 +709,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_batch_sort_sum(
         __syncthreads();                                         // the zeroed counters
 #pragma unroll
         for (int q = 0; q < NC; q++) {
+            if (s0 + q * 64 >= s1) break;                        // (wave-uniform: the run's last chunk is behind)
             const int sidx = s0 + q * 64 + lane;
             const int k = sidx < s1 ? v[q] : -1;
             const bool in = sidx < s1 && in_range(k);
