@@ -14,7 +14,7 @@
 //     (neg_sqd_exact), one 64-bit atomic maximum of (score, ~component) per span, every span's word on its own cache line;
 //   * grid barrier: arrivals on one counter, the last arriver releases the others through separate flag words; spins are
 //     bounded and end in an error, never in a hang;
-//   * phase B, replicated: EVERY workgroup reads the spans' maxima and runs the same DP (seg_w8_wave) on the same inputs,
+//   * phase B, replicated: EVERY workgroup reads the spans' maxima and runs the same DP (seg_w8_uniform) on the same inputs,
 //     so every workgroup knows the utterance's old and new tokens without another exchange; each applies the del_item /
 //     add_item sequence (kmeans_components.py:93-132, the `k > K -> K` clamp included) to the components it owns, in the
 //     reference's order, from the rows it staged.  Labels and boundaries are written by every workgroup (the same values:
@@ -29,7 +29,7 @@
 #include "segk_segment_dev.h"
 
 #define CH_THREADS 1024
-#define CH_MAXOPS 64              /* old + new tokens of an utterance (N_max <= 32) */
+#define CH_MAXOPS 64              /* old tokens [0, 32) + new tokens [32, 64) of an utterance, by span end (N_max <= 32) */
 #define CH_SPIN_LIMIT (1 << 22)
 #define CH_KEY_PITCH 16           /* 8-byte words between two spans' maxima: one 128-byte line each */
 #define CH_FLAGS 16               /* release words of the barrier, one 128-byte line each */
@@ -104,7 +104,7 @@ struct ChainSet {
     float *xs, *xo;                                   // [NBC][LDX] candidate rows by band entry, [NM][LDX] rows of the old tokens
     double *bdur;                                     // [NBC]
     int32_t *bid, *basg, *o_e, *o_a;                  // [NBC] row of the entry, its label before the utterance (workgroup 0); [NM] old tokens, their labels
-    int32_t *meta;                                    // [8]: u, N, W, nb, old mask (2 words), number of old tokens, band flag
+    int32_t *meta;                                    // [12]: u, N, W, nb, old mask (2 words), number of old tokens, band flag, mask of the old tokens with a row (2 words)
 };
 
 __global__ __launch_bounds__(CH_THREADS) void k_seq_chain(ChainArgs A)
@@ -124,20 +124,17 @@ __global__ __launch_bounds__(CH_THREADS) void k_seq_chain(ChainArgs A)
     unsigned char *lp = ch_lds;
     auto take = [&](size_t bytes) { unsigned char *r = lp; lp += (bytes + 15) & ~(size_t)15; return r; };
     double *numer_l = reinterpret_cast<double *>(take((size_t)CPW * D * 8));            // [CPW][D]
-    double *bvec = reinterpret_cast<double *>(take((size_t)NBC * 8));                   // [NBC]
-    double *gam = reinterpret_cast<double *>(take((size_t)(NM + 1) * 8));               // [NM + 1]
+    double *bvec = reinterpret_cast<double *>(take((size_t)NM * 8 * 8));                // [NM][8] the DP's candidates, pitch 8 (seg_w8_uniform)
+    double *gam = reinterpret_cast<double *>(take((size_t)(NM + 9) * 8));               // [8 + NM + 1]
     long long *cnt_l = reinterpret_cast<long long *>(take((size_t)CPW * 8));            // [CPW]
     long long *op_cnt = reinterpret_cast<long long *>(take((size_t)CH_MAXOPS * 8));     // [CH_MAXOPS] count of its component after the item
     float *means_l = reinterpret_cast<float *>(take((size_t)CPW * LDM * 4));            // [CPW][LDM]
     int32_t *bk = reinterpret_cast<int32_t *>(take((size_t)NBC * 4));                   // [NBC]
-    int32_t *l_old = reinterpret_cast<int32_t *>(take((size_t)NM * 4));                 // [NM]
     int32_t *l_new = reinterpret_cast<int32_t *>(take((size_t)NM * 4));                 // [NM]
     int32_t *l_newk = reinterpret_cast<int32_t *>(take((size_t)NM * 4));                // [NM]
     int32_t *l_cnt = reinterpret_cast<int32_t *>(take(8 * 4));                          // [8]
-    int32_t *op_e = reinterpret_cast<int32_t *>(take(CH_MAXOPS * 4));                   // [CH_MAXOPS] item
-    int32_t *op_k = reinterpret_cast<int32_t *>(take(CH_MAXOPS * 4));                   // [CH_MAXOPS] component (-1: nothing to do)
+    int32_t *op_k = reinterpret_cast<int32_t *>(take(CH_MAXOPS * 4));                   // [CH_MAXOPS] own items only: slot of the component; [j] old token of span end j + 1, [32 + j] new token
     int32_t *op_x = reinterpret_cast<int32_t *>(take(CH_MAXOPS * 4));                   // [CH_MAXOPS] its row: xo index (old), band entry (new)
-    int32_t *op_w = reinterpret_cast<int32_t *>(take(CH_MAXOPS * 4));                   // [CH_MAXOPS] low half: own slot when it is the last item of its component (else -1); bit 16: last item of its row
     ChainSet S[2];
     for (int z = 0; z < 2; z++) {
         S[z].xs = reinterpret_cast<float *>(take((size_t)NBC * LDX * 4));
@@ -147,9 +144,10 @@ __global__ __launch_bounds__(CH_THREADS) void k_seq_chain(ChainArgs A)
         S[z].basg = reinterpret_cast<int32_t *>(take((size_t)NBC * 4));
         S[z].o_e = reinterpret_cast<int32_t *>(take((size_t)NM * 4));
         S[z].o_a = reinterpret_cast<int32_t *>(take((size_t)NM * 4));
-        S[z].meta = reinterpret_cast<int32_t *>(take(8 * 4));
+        S[z].meta = reinterpret_cast<int32_t *>(take(12 * 4));
     }
     __shared__ int sh_flag, sh_K, sh_empty;
+    __shared__ unsigned long long sh_own[2];           // the old / new tokens (by span end) on components this workgroup owns
 
     // Everything phase A needs of utterance order[qn] into set `st` -- none of it depends on the utterances before it.
     // Wave `w_old` (all its 64 lanes) lists the old tokens; the threads t0 <= tid < t0 + nth fetch the candidates.  No
@@ -205,6 +203,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_seq_chain(ChainArgs A)
                 st.meta[0] = u; st.meta[1] = N; st.meta[2] = W; st.meta[3] = nb;
                 st.meta[4] = (int32_t)(oldb & 0xffffffffull); st.meta[5] = (int32_t)(oldb >> 32);
                 st.meta[6] = no; st.meta[7] = band ? 1 : 0;
+                st.meta[8] = (int32_t)(keep & 0xffffffffull); st.meta[9] = (int32_t)(keep >> 32);
             }
         }
         const int tt = tid - t0;
@@ -270,8 +269,6 @@ __global__ __launch_bounds__(CH_THREADS) void k_seq_chain(ChainArgs A)
         if (q + 1 < A.q1) N1 = c.lengths[u1];
         const ChainSet &C = S[(q - A.q0) & 1];
         const int u = C.meta[0], N = C.meta[1], W = C.meta[2], nb = C.meta[3];
-        const unsigned long long oldb = ((unsigned long long)(unsigned int)C.meta[5] << 32) | (unsigned int)C.meta[4];
-        const int32_t *vid = c.vec_ids + (int64_t)u * triMax;
         const int32_t *bid = C.bid;
         const float *xs = C.xs, *xo = C.xo;
         uint8_t *gbnd = A.boundaries + (int64_t)u * NM;
@@ -326,33 +323,84 @@ __global__ __launch_bounds__(CH_THREADS) void k_seq_chain(ChainArgs A)
                     v = isnan(dd) ? NEG_INF_D : (double)__uint_as_float(bits) * dd;       // :346-349
                 }
                 bk[i] = k;
-                bvec[i] = v + A.wip;                                                   // :351
+                bvec[(i / W) * 8 + i % W] = v + A.wip;                                 // :351
             }
+            if (W < 8)
+                for (int i = lane; i < N * 8; i += 64)
+                    if ((i & 7) >= W) bvec[i] = NEG_INF_D;
             WAVE_SYNC();
             CH_STAMP(4);
             double total;
-            seg_w8_wave(bvec, gam, bid, bk, vid, N, W, oldb, sh_K, l_old, l_new, l_newk, l_cnt, &total, lane);
+            seg_w8_uniform(bvec, gam, bid, bk, N, W, sh_K, l_new, l_newk, l_cnt, &total, lane,
+                           (A.stamp && blockIdx.x == 0 && q - A.q0 < 256) ? A.stamp + 3072 + (q - A.q0) * 8 : nullptr);
             WAVE_SYNC();
             if (A.stamp && blockIdx.x == 0 && lane == 0 && q - A.q0 < 256) A.stamp[(q - A.q0) * 8 + 7] = wall_clock64();
-            // the operations of the utterance in the reference's order: del_item of the old tokens, add_item of the new ones;
-            // lane 0 replays the clamp of add_item (:102-106) on K
-            const int no = l_cnt[0], nn = l_cnt[1];
-            if (lane < no) { op_e[lane] = l_old[lane]; op_k[lane] = C.o_a[lane]; op_x[lane] = lane; }
+            // ---- the operations of the utterance in the reference's order: del_item of the old tokens, add_item of the new ones
+            // (kmeans_components.py:93-132), both in span-end order.  The lane of span end j + 1 holds the old token and the new
+            // token that end there; a span that is deleted and added again sits on ONE lane (rows are per span).
+            const int no = C.meta[6], nn = l_cnt[1];
+            if (l_cnt[4] != 0) {                                        // tokens on inactive components: add_item's clamp (:102-106), in order
+                if (lane == 0) {
+                    int K = sh_K;
+                    for (int t2 = 0; t2 < nn; t2++) {
+                        int k = l_newk[t2];
+                        if (k > K) k = K;
+                        if (k == K) K++;
+                        l_newk[t2] = k;
+                    }
+                    sh_K = K;
+                }
+                WAVE_SYNC();
+            }
+            const unsigned long long keepO = ((unsigned long long)(unsigned int)C.meta[9] << 32) | (unsigned int)C.meta[8];
+            const unsigned long long newb = ((unsigned long long)(unsigned int)l_cnt[3] << 32) | (unsigned int)l_cnt[2];
+            const unsigned long long lt = (1ull << lane) - 1ull;
+            const bool vO = (keepO >> lane) & 1ull;
+            const int rO = __popcll(keepO & lt);
+            int eO = -1, kO = -1;
+            if (vO) { eO = C.o_e[rO]; kO = C.o_a[rO]; }
+            int eN = -1, kN = -1, xN = 0;
             {
-                const unsigned long long newb = ((unsigned long long)(unsigned int)l_cnt[3] << 32) | (unsigned int)l_cnt[2];
                 const bool bit = lane < N && ((newb >> lane) & 1ull);
-                const unsigned long long below = newb & ((1ull << lane) - 1ull);
+                const unsigned long long below = newb & lt;
                 const int jp = below ? 64 - __clzll((long long)below) : 0;
                 const int w = lane - jp;
-                const bool valid = bit && w < W && bid[lane * W + (w < W ? w : 0)] >= 0;
-                const unsigned long long keep = __ballot(valid);
-                if (valid) {
-                    const int r = __popcll(keep & ((1ull << lane) - 1ull));
-                    op_e[no + r] = l_new[r];
-                    op_x[no + r] = lane * W + w;
+                if (bit && w < W) {
+                    xN = lane * W + w;
+                    eN = bid[xN];
                 }
             }
+            const bool vN = eN >= 0;
+            const unsigned long long keepN = __ballot(vN);
+            if (vN) kN = l_newk[__popcll(keepN & lt)];
+            // labels (every workgroup: the same values, whichever L2 a later read hits holds them)
+            if (vN) m.assignments[eN] = kN;
+            if (vO && eO != eN) m.assignments[eO] = -1;
+            // add_item's assert (:101): the row must be unassigned -- by this utterance's own del_item, else by the state before it
+            // (the last workgroup checks, workgroup 0 writes the outputs)
+            if (blockIdx.x == gridDim.x - 1 && vN && !(vO && eO == eN) && C.basg[xN] != -1) atomicOr(A.status, 2);
+            // the items on the components this workgroup owns; the count of its component after every one of them
+            const bool ownO = vO && kO >= k0 && kO < k0 + kn, ownN = vN && kN >= k0 && kN < k0 + kn;
+            const unsigned long long mO = __ballot(ownO), mN = __ballot(ownN);
+            if (ownO) { op_k[lane] = kO - k0; op_x[lane] = rO; }
+            if (ownN) { op_k[32 + lane] = kN - k0; op_x[32 + lane] = xN; }
+            WAVE_SYNC();
             if (lane == 0) {
+                for (unsigned long long mm = mO; mm; mm &= mm - 1ull) {
+                    const int j = __ffsll((long long)mm) - 1, ci = op_k[j];
+                    const long long cn = cnt_l[ci] - 1;
+                    cnt_l[ci] = cn;
+                    op_cnt[j] = cn;
+                }
+                for (unsigned long long mm = mN; mm; mm &= mm - 1ull) {
+                    const int j = __ffsll((long long)mm) - 1, ci = op_k[32 + j];
+                    const long long cn = cnt_l[ci] + 1;
+                    cnt_l[ci] = cn;
+                    op_cnt[32 + j] = cn;
+                }
+                sh_own[0] = mO;
+                sh_own[1] = mN;
+                sh_empty = 0;
                 if (blockIdx.x == 0) {
                     A.out_total[u] = total;
                     A.n_old[u] = no;
@@ -360,16 +408,15 @@ __global__ __launch_bounds__(CH_THREADS) void k_seq_chain(ChainArgs A)
                     if (A.n_flag) A.n_flag[u] = l_cnt[4];
                     if (l_cnt[5]) atomicOr(A.status, 1);
                 }
-                int K = sh_K;
-                for (int t2 = 0; t2 < nn; t2++) {
-                    int k = l_newk[t2];
-                    if (k > K) k = K;
-                    if (k == K) K++;
-                    op_k[no + t2] = k;
-                    l_newk[t2] = k;
-                }
-                sh_K = K;
-                sh_empty = 0;
+            }
+            WAVE_SYNC();
+            if (ownO || ownN) {
+                // (a lane that owns both writes the same final count twice)
+                const int ciO = ownO ? kO - k0 : kN - k0, ciN = ownN ? kN - k0 : kO - k0;
+                const long long cO = cnt_l[ciO], cNn = cnt_l[ciN];
+                m.counts[k0 + ciO] = cO;
+                m.counts[k0 + ciN] = cNn;
+                if ((cO == 0 && k0 + ciO < sh_K) || (cNn == 0 && k0 + ciN < sh_K)) sh_empty = 1;
             }
         } else if (q + 1 < A.q1) {
             stage(u1, N1, S[(q + 1 - A.q0) & 1], 1, 128, CH_THREADS - 128);
@@ -377,76 +424,40 @@ __global__ __launch_bounds__(CH_THREADS) void k_seq_chain(ChainArgs A)
         u1 = u2;
         __syncthreads();
         CH_STAMP(5);
-        const int no = l_cnt[0], nn = l_cnt[1], nops = no + nn;
-        if (tid < nops) {
-            // the count of its component after every item, for the components this workgroup owns; whether the item is the
-            // last one on its component / on its row
-            const int k = op_k[tid], ci = k - k0, e = op_e[tid];
-            const bool own = k >= 0 && ci >= 0 && ci < kn;
-            long long cn = own ? cnt_l[ci] : 0;
-            bool last_k = own, last_e = true;
-            int prev = -1;
-            for (int p2 = 0; p2 < nops; p2++) {
-                const int k2 = op_k[p2], e2 = op_e[p2];
-                if (own && k2 == k && p2 <= tid) cn += p2 < no ? -1 : 1;
-                if (p2 > tid && k2 == k) last_k = false;
-                if (p2 > tid && e2 == e) last_e = false;
-                if (p2 < tid && e2 == e) prev = p2;
-            }
-            op_cnt[tid] = cn;
-            op_w[tid] = ((last_k ? ci : 0xffff) & 0xffff) | (last_e ? 0x10000 : 0) | (own ? 0x20000 : 0);
-            // add_item's assert (:101): the row must be unassigned -- by an earlier item of this utterance, else by the state
-            // before it
-            if (blockIdx.x == gridDim.x - 1 && tid >= no) {          // (the last workgroup checks, workgroup 0 writes the outputs)
-                const int cur = prev >= 0 ? (prev < no ? -1 : op_k[prev]) : C.basg[op_x[tid]];
-                if (cur != -1) atomicOr(A.status, 2);
-            }
+        // the items in the reference's order; thread d owns dimension d of every component of this workgroup (:110, :128-129), and
+        // writes the rows through as it goes
+        if (tid < D) {
+            const int d = tid;
+            for (int ph = 0; ph < 2; ph++)
+                for (unsigned long long mm = sh_own[ph]; mm; mm &= mm - 1ull) {
+                    const int o = 32 * ph + __ffsll((long long)mm) - 1;
+                    const int ci = op_k[o];
+                    const double x = (double)(ph == 0 ? xo[op_x[o] * LDX + d] : xs[op_x[o] * LDX + d]);
+                    const double v = ph == 0 ? numer_l[ci * D + d] - x : numer_l[ci * D + d] + x;
+                    numer_l[ci * D + d] = v;
+                    m.mean_numerators[(int64_t)(k0 + ci) * D + d] = v;
+                    const long long cnt = op_cnt[o];
+                    if (cnt != 0) {
+                        const float mu = (float)(v / (double)cnt);
+                        means_l[ci * LDM + d] = mu;
+                        means_g[(int64_t)(k0 + ci) * D + d] = mu;
+                    }
+                }
         }
-        __syncthreads();
-        if (tid < nops) {
-            const int w = op_w[tid], ci = (int)(short)(w & 0xffff);
-            if (ci >= 0) {                                               // the last item of a component leaves its count
-                cnt_l[ci] = op_cnt[tid];
-                m.counts[k0 + ci] = op_cnt[tid];
-                if (op_cnt[tid] == 0 && k0 + ci < sh_K) sh_empty = 1;
-            }
-            if (w & 0x10000) m.assignments[op_e[tid]] = tid < no ? -1 : op_k[tid];
-        }
-        // the items in the reference's order; thread d owns dimension d of every component of this workgroup (:110, :128-129)
-        for (int d = tid; d < D; d += CH_THREADS)
-            for (int o = 0; o < nops; o++) {
-                if (!(op_w[o] & 0x20000)) continue;                       // not a component of this workgroup
-                const int ci = op_k[o] - k0;
-                const double x = (double)(o < no ? xo[op_x[o] * LDX + d] : xs[op_x[o] * LDX + d]);
-                const double v = o < no ? numer_l[ci * D + d] - x : numer_l[ci * D + d] + x;
-                numer_l[ci * D + d] = v;
-                const long long cnt = op_cnt[o];
-                if (cnt != 0) means_l[ci * LDM + d] = (float)(v / (double)cnt);
-            }
-        // boundaries (every workgroup: the same values) and the utterance's outputs, by the threads the loop above leaves idle
+        // boundaries (every workgroup: the same values) and the utterance's outputs, by threads the loop above leaves idle
         if (tid >= 512 && tid - 512 < N) {
             const unsigned long long newb = ((unsigned long long)(unsigned int)l_cnt[3] << 32) | (unsigned int)l_cnt[2];
             gbnd[tid - 512] = (uint8_t)((newb >> (tid - 512)) & 1ull);
         }
         if (blockIdx.x == 0 && tid >= 576) {
-            const int j = tid - 576;
-            if (j < no) A.old_tok[(int64_t)u * NM + j] = l_old[j];
+            const int j = tid - 576, no = C.meta[6], nn = l_cnt[1];
+            if (j < no) A.old_tok[(int64_t)u * NM + j] = C.o_e[j];
             if (j < NM) {
                 if (j < nn) A.new_tok[(int64_t)u * NM + j] = l_new[j];
                 A.new_k[(int64_t)u * NM + j] = j < nn ? l_newk[j] : -1;
             }
         }
         __syncthreads();
-        // write through the touched rows of this workgroup
-        for (int o = 0; o < nops; o++) {
-            const int ci = (int)(short)(op_w[o] & 0xffff);
-            if (ci < 0) continue;
-            const int k = k0 + ci;
-            for (int d = tid; d < D; d += CH_THREADS) {
-                m.mean_numerators[(int64_t)k * D + d] = numer_l[ci * D + d];
-                means_g[(int64_t)k * D + d] = means_l[ci * LDM + d];             // (unchanged when every count on the way was 0)
-            }
-        }
         if (tid == 0 && sh_empty) {
             __hip_atomic_fetch_or(&A.ctl[0], CH_STOP_BIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&A.ctl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // for the host
@@ -485,9 +496,9 @@ int segk_launch_seq_chain(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m, c
     const int D = c->D, ldm = ((D >> 2) & 1) ? D : D + 4;
     auto al = [](size_t b) { return (b + 15) & ~(size_t)15; };
     const size_t NM = (size_t)c->N_max;
-    const size_t set_bytes = al((size_t)nbc * D * 4) + al(NM * D * 4) + al((size_t)nbc * 8) + 2 * al((size_t)nbc * 4) + 2 * al(NM * 4) + al(8 * 4);
-    const size_t lds = al((size_t)cpw * D * 8) + al((size_t)nbc * 8) + al((NM + 1) * 8) + al((size_t)cpw * 8) + al(CH_MAXOPS * 8) +
-                       al((size_t)cpw * ldm * 4) + al((size_t)nbc * 4) + 3 * al(NM * 4) + al(8 * 4) + 4 * al(CH_MAXOPS * 4) + 2 * set_bytes;
+    const size_t set_bytes = al((size_t)nbc * D * 4) + al(NM * D * 4) + al((size_t)nbc * 8) + 2 * al((size_t)nbc * 4) + 2 * al(NM * 4) + al(12 * 4);
+    const size_t lds = al((size_t)cpw * D * 8) + al(NM * 8 * 8) + al((NM + 9) * 8) + al((size_t)cpw * 8) + al(CH_MAXOPS * 8) +
+                       al((size_t)cpw * ldm * 4) + al((size_t)nbc * 4) + 2 * al(NM * 4) + al(8 * 4) + 2 * al(CH_MAXOPS * 4) + 2 * set_bytes;
     if (lds > 158 * 1024) return SEGK_ERR_UNSUPPORTED;
     static size_t lds_set = 0;
     if (lds > 48 * 1024 && lds > lds_set) {
@@ -519,7 +530,7 @@ int segk_launch_seq_chain(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m, c
     SEGK_CHECK_HIP(hipMemcpyAsync((void *)A.order, order, (size_t)n_order * sizeof(int32_t), hipMemcpyHostToDevice, st));
     const bool stamping = getenv("SEGK_CHAIN_STAMP") && atoi(getenv("SEGK_CHAIN_STAMP"));
     static unsigned long long *stamp_dev = nullptr;
-    if (stamping && !stamp_dev) SEGK_CHECK_HIP(hipMalloc((void **)&stamp_dev, (256 * 8 + 4 * 256) * sizeof(unsigned long long)));
+    if (stamping && !stamp_dev) SEGK_CHECK_HIP(hipMalloc((void **)&stamp_dev, (256 * 8 + 4 * 256 + 256 * 8) * sizeof(unsigned long long)));
     A.stamp = stamping ? stamp_dev : nullptr;
     int q = 0;
     while (q < n_order) {
@@ -565,7 +576,16 @@ int segk_launch_seq_chain(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m, c
             {
                 double dpw = 0;
                 for (int i = 20; i < 199; i++) dpw += (double)(hs[i * 8 + 7] - hs[i * 8 + 4]);
-                fprintf(stderr, "  of dp: seg_w8_wave %.2f us\n", dpw / 179 / 100);
+                fprintf(stderr, "  of dp: seg_w8_uniform %.2f us\n", dpw / 179 / 100);
+                static unsigned long long us[256 * 8];
+                SEGK_CHECK_HIP(hipMemcpy(us, stamp_dev + 3072, sizeof(us), hipMemcpyDeviceToHost));
+                double ph[5] = {0, 0, 0, 0, 0};
+                for (int i = 20; i < 199; i++) {
+                    ph[0] += (double)(us[i * 8] - hs[i * 8 + 4]);
+                    for (int j = 1; j < 5; j++) ph[j] += (double)(us[i * 8 + j] - us[i * 8 + j - 1]);
+                }
+                fprintf(stderr, "    (entry) %.2f  forward %.2f  decisions %.2f  walk %.2f  new tokens %.2f\n", ph[0] / 179 / 100,
+                        ph[1] / 179 / 100, ph[2] / 179 / 100, ph[3] / 179 / 100, ph[4] / 179 / 100);
             }
             fprintf(stderr, "chain stamps (us): score %.2f  barrier %.2f  keys %.2f  dp %.2f  update %.2f  | per utterance %.2f\n",
                     (acc[0] + acc[1]) / 179 / 100, acc[2] / 179 / 100, acc[3] / 179 / 100, acc[4] / 179 / 100, acc[5] / 179 / 100,
