@@ -64,9 +64,10 @@ __device__ __forceinline__ int seg_old_tokens_wave(const int32_t *bid, const int
 // candidate equals gamma[t]; 0 when gamma[t] is -inf), and the backward pass is a walk over lanes with v_readlane -- no
 // candidate is evaluated twice, nothing on the walk touches LDS.
 //   bvec8: [N][8]   candidate (t, w) at [(t - 1) * 8 + w]; -inf beyond the window (w >= W) and before the utterance's start
-//   gamp:  [8 + N + 1]   gamp[8 + t] = gamma[t]; gamp[0..7] = -inf (written here)
+//   gamp:  [8 + N + 4]   gamp[8 + t] = gamma[t]; gamp[0..7] = -inf (written here); three more entries of slack
 // bid / bk keep the pitch W of the band.  The old tokens are not listed here (the chain's staging lists them ahead of time);
-// otherwise the values, decisions and outputs of seg_w8_wave (N <= 64): l_new, l_newk, l_cnt[1..5].
+// otherwise the values, decisions and outputs of seg_w8_wave (N <= 64): l_new, l_newk, l_cnt[1..5], and the lane of span end
+// j + 1 gets its own new token back in registers.
 __device__ __forceinline__ double seg_readlane_f64(double v, int l)
 {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
@@ -91,11 +92,16 @@ __device__ __forceinline__ void seg_forward_uniform(const double *bvec8, double 
         }
     };
     fetch(va, 0);
+    // four steps at a time without a test in between (a test per step kept the compiler from hoisting the next step's reads over
+    // this step's arithmetic): up to three steps past N compute gammas nobody reads -- gamp has room for them
     for (int t0 = 1; t0 <= N; t0 += 8) {
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const int t = t0 + j;                                       // t % 8 == (1 + j) % 8
-            if (t <= N) {
+        for (int half = 0; half < 2; half++) {
+            if (half == 1 && t0 + 4 > N) break;
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++) {
+                const int j = 4 * half + jj;
+                const int t = t0 + j;                                   // t % 8 == (1 + j) % 8
                 double (&v)[WW] = (j & 1) ? vb : va;
                 fetch((j & 1) ? va : vb, t < N ? t : N - 1);
                 double x[WW];
@@ -113,7 +119,8 @@ __device__ __forceinline__ void seg_forward_uniform(const double *bvec8, double 
 }
 __device__ __forceinline__ void seg_w8_uniform(const double *bvec8, double *gamp, const int32_t *bid, const int32_t *bk, int N, int W,
                                                int Kact, int32_t *l_new, int32_t *l_newk, int32_t *l_cnt, double *total_out, int lane,
-                                               unsigned long long *tstamp = nullptr)
+                                               unsigned long long &newb_out, unsigned long long &keep_out, int &id_out, int &k_out,
+                                               int &entry_out, int &n_flag_out, unsigned long long *tstamp = nullptr)
 {
 #define SEG_U_STAMP(i) do { if (tstamp && lane == 0) tstamp[i] = wall_clock64(); } while (0)
     N = __builtin_amdgcn_readfirstlane(N);             // wave-uniform by contract: keep the loops below on the scalar unit
@@ -158,26 +165,39 @@ __device__ __forceinline__ void seg_w8_uniform(const double *bvec8, double *gamp
     unsigned long long newb = 1ull << (N - 1);
     int t = N;
     double total = 0.0;
-    for (;;) {
-        int kb = __builtin_amdgcn_readlane(kbv, t - 1);
-        if (kb == 0) {                                 // every candidate -inf: step back until one is finite (:516-530)
-            do {
-                t = t - 1;
-                if (t == 0) break;
-                kb = __builtin_amdgcn_readlane(kbv, t - 1);
-            } while (kb == 0);
-            if (t == 0) {                              // python vec[-1]: the last span [N-1, N)
-                newb |= 1ull << (N - 1);
-                total += bvec8[(size_t)(N - 1) * 8];
-                break;
-            }
-            newb |= 1ull << (t - 1);
+    bool blocked = false;
+    for (;;) {                                         // the walk as long as every span end on it has a finite candidate
+        const int kb = __builtin_amdgcn_readlane(kbv, t - 1);
+        if (kb == 0) {
+            blocked = true;
+            break;
         }
         total += seg_readlane_f64(cv, t - 1);
         t = t - kb;
         if (t < 1) break;
         newb |= 1ull << (t - 1);
     }
+    if (blocked)
+        for (;;) {                                     // ... and from the first span end whose candidates are all -inf on (:516-530)
+            int kb = __builtin_amdgcn_readlane(kbv, t - 1);
+            if (kb == 0) {
+                do {
+                    t = t - 1;
+                    if (t == 0) break;
+                    kb = __builtin_amdgcn_readlane(kbv, t - 1);
+                } while (kb == 0);
+                if (t == 0) {                          // python vec[-1]: the last span [N-1, N)
+                    newb |= 1ull << (N - 1);
+                    total += bvec8[(size_t)(N - 1) * 8];
+                    break;
+                }
+                newb |= 1ull << (t - 1);
+            }
+            total += seg_readlane_f64(cv, t - 1);
+            t = t - kb;
+            if (t < 1) break;
+            newb |= 1ull << (t - 1);
+        }
     SEG_U_STAMP(3);
     // ---- new tokens + their best components (:312-313)
     {
@@ -204,6 +224,13 @@ __device__ __forceinline__ void seg_w8_uniform(const double *bvec8, double *gamp
             l_cnt[4] = __popcll(fl);
             l_cnt[5] = badm != 0ull;
         }
+        // the same for the caller's wave, in registers: this lane's new token (row, component, band entry), if any
+        newb_out = newb;
+        keep_out = keep;
+        id_out = valid ? id : -1;
+        k_out = kk;
+        entry_out = lane * W + (w < W ? w : 0);
+        n_flag_out = __popcll(fl);
     }
     *total_out = total;
     SEG_U_STAMP(4);

@@ -125,7 +125,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_seq_chain(ChainArgs A)
     auto take = [&](size_t bytes) { unsigned char *r = lp; lp += (bytes + 15) & ~(size_t)15; return r; };
     double *numer_l = reinterpret_cast<double *>(take((size_t)CPW * D * 8));            // [CPW][D]
     double *bvec = reinterpret_cast<double *>(take((size_t)NM * 8 * 8));                // [NM][8] the DP's candidates, pitch 8 (seg_w8_uniform)
-    double *gam = reinterpret_cast<double *>(take((size_t)(NM + 9) * 8));               // [8 + NM + 1]
+    double *gam = reinterpret_cast<double *>(take((size_t)(NM + 12) * 8));              // [8 + NM + 4]
     long long *cnt_l = reinterpret_cast<long long *>(take((size_t)CPW * 8));            // [CPW]
     long long *op_cnt = reinterpret_cast<long long *>(take((size_t)CH_MAXOPS * 8));     // [CH_MAXOPS] count of its component after the item
     float *means_l = reinterpret_cast<float *>(take((size_t)CPW * LDM * 4));            // [CPW][LDM]
@@ -311,35 +311,55 @@ __global__ __launch_bounds__(CH_THREADS) void k_seq_chain(ChainArgs A)
         // ================================ phase B, the same in every workgroup: wave 0 runs the DP, the other waves fetch the
         // next utterance
         if (wv == 0) {
-            for (int i = lane; i < nb; i += 64) {
-                double v = NEG_INF_D;
-                int k = -1;
-                if (bid[i] >= 0) {
-                    const unsigned long long key = __hip_atomic_load(&keys[(size_t)i * CH_KEY_PITCH], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const unsigned int ord = (unsigned int)(key >> 32);
-                    const unsigned int bits = (ord & 0x80000000u) ? (ord & 0x7fffffffu) : ~ord;
-                    k = (int32_t)(0xffffffffu - (unsigned int)(key & 0xffffffffu));
-                    const double dd = C.bdur[i];
-                    v = isnan(dd) ? NEG_INF_D : (double)__uint_as_float(bits) * dd;       // :346-349
+            // the spans' maxima, eight span ends per step: lane (r, w) takes entry (r + 1, w) -- every load first, then the
+            // conversions (:346-351); the DP's image of the band has pitch 8, -inf beyond the window
+            {
+                const int w = lane & 7;
+                unsigned long long key[4];
+                int idv[4];
+#pragma unroll
+                for (int z = 0; z < 4; z++) {
+                    const int r = 8 * z + (lane >> 3);
+                    key[z] = 0ull;
+                    idv[z] = (r < N && w < W) ? bid[r * W + w] : -1;
                 }
-                bk[i] = k;
-                bvec[(i / W) * 8 + i % W] = v + A.wip;                                 // :351
+#pragma unroll
+                for (int z = 0; z < 4; z++) {
+                    const int r = 8 * z + (lane >> 3);
+                    if (idv[z] >= 0)
+                        key[z] = __hip_atomic_load(&keys[(size_t)(r * W + w) * CH_KEY_PITCH], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+#pragma unroll
+                for (int z = 0; z < 4; z++) {
+                    const int r = 8 * z + (lane >> 3);
+                    if (r < N) {
+                        double v = NEG_INF_D;
+                        if (idv[z] >= 0) {
+                            const unsigned int ord = (unsigned int)(key[z] >> 32);
+                            const unsigned int bits = (ord & 0x80000000u) ? (ord & 0x7fffffffu) : ~ord;
+                            const double dd = C.bdur[r * W + w];
+                            v = isnan(dd) ? NEG_INF_D : (double)__uint_as_float(bits) * dd;
+                        }
+                        if (w < W) bk[r * W + w] = idv[z] >= 0 ? (int32_t)(0xffffffffu - (unsigned int)(key[z] & 0xffffffffu)) : -1;
+                        bvec[r * 8 + w] = v + A.wip;
+                    }
+                }
             }
-            if (W < 8)
-                for (int i = lane; i < N * 8; i += 64)
-                    if ((i & 7) >= W) bvec[i] = NEG_INF_D;
             WAVE_SYNC();
             CH_STAMP(4);
             double total;
-            seg_w8_uniform(bvec, gam, bid, bk, N, W, sh_K, l_new, l_newk, l_cnt, &total, lane,
+            unsigned long long newb, keepN;
+            int eN, kN, xN, n_flagged;
+            seg_w8_uniform(bvec, gam, bid, bk, N, W, sh_K, l_new, l_newk, l_cnt, &total, lane, newb, keepN, eN, kN, xN, n_flagged,
                            (A.stamp && blockIdx.x == 0 && q - A.q0 < 256) ? A.stamp + 3072 + (q - A.q0) * 8 : nullptr);
-            WAVE_SYNC();
             if (A.stamp && blockIdx.x == 0 && lane == 0 && q - A.q0 < 256) A.stamp[(q - A.q0) * 8 + 7] = wall_clock64();
             // ---- the operations of the utterance in the reference's order: del_item of the old tokens, add_item of the new ones
             // (kmeans_components.py:93-132), both in span-end order.  The lane of span end j + 1 holds the old token and the new
             // token that end there; a span that is deleted and added again sits on ONE lane (rows are per span).
-            const int no = C.meta[6], nn = l_cnt[1];
-            if (l_cnt[4] != 0) {                                        // tokens on inactive components: add_item's clamp (:102-106), in order
+            const int no = C.meta[6], nn = __popcll(keepN);
+            const unsigned long long lt = (1ull << lane) - 1ull;
+            if (n_flagged != 0) {                                       // tokens on inactive components: add_item's clamp (:102-106), in order
+                WAVE_SYNC();
                 if (lane == 0) {
                     int K = sh_K;
                     for (int t2 = 0; t2 < nn; t2++) {
@@ -351,28 +371,14 @@ __global__ __launch_bounds__(CH_THREADS) void k_seq_chain(ChainArgs A)
                     sh_K = K;
                 }
                 WAVE_SYNC();
+                if (eN >= 0) kN = l_newk[__popcll(keepN & lt)];
             }
             const unsigned long long keepO = ((unsigned long long)(unsigned int)C.meta[9] << 32) | (unsigned int)C.meta[8];
-            const unsigned long long newb = ((unsigned long long)(unsigned int)l_cnt[3] << 32) | (unsigned int)l_cnt[2];
-            const unsigned long long lt = (1ull << lane) - 1ull;
             const bool vO = (keepO >> lane) & 1ull;
             const int rO = __popcll(keepO & lt);
             int eO = -1, kO = -1;
             if (vO) { eO = C.o_e[rO]; kO = C.o_a[rO]; }
-            int eN = -1, kN = -1, xN = 0;
-            {
-                const bool bit = lane < N && ((newb >> lane) & 1ull);
-                const unsigned long long below = newb & lt;
-                const int jp = below ? 64 - __clzll((long long)below) : 0;
-                const int w = lane - jp;
-                if (bit && w < W) {
-                    xN = lane * W + w;
-                    eN = bid[xN];
-                }
-            }
             const bool vN = eN >= 0;
-            const unsigned long long keepN = __ballot(vN);
-            if (vN) kN = l_newk[__popcll(keepN & lt)];
             // labels (every workgroup: the same values, whichever L2 a later read hits holds them)
             if (vN) m.assignments[eN] = kN;
             if (vO && eO != eN) m.assignments[eO] = -1;
@@ -405,7 +411,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_seq_chain(ChainArgs A)
                     A.out_total[u] = total;
                     A.n_old[u] = no;
                     A.n_new[u] = nn;
-                    if (A.n_flag) A.n_flag[u] = l_cnt[4];
+                    if (A.n_flag) A.n_flag[u] = n_flagged;
                     if (l_cnt[5]) atomicOr(A.status, 1);
                 }
             }
@@ -497,7 +503,7 @@ int segk_launch_seq_chain(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m, c
     auto al = [](size_t b) { return (b + 15) & ~(size_t)15; };
     const size_t NM = (size_t)c->N_max;
     const size_t set_bytes = al((size_t)nbc * D * 4) + al(NM * D * 4) + al((size_t)nbc * 8) + 2 * al((size_t)nbc * 4) + 2 * al(NM * 4) + al(12 * 4);
-    const size_t lds = al((size_t)cpw * D * 8) + al(NM * 8 * 8) + al((NM + 9) * 8) + al((size_t)cpw * 8) + al(CH_MAXOPS * 8) +
+    const size_t lds = al((size_t)cpw * D * 8) + al(NM * 8 * 8) + al((NM + 12) * 8) + al((size_t)cpw * 8) + al(CH_MAXOPS * 8) +
                        al((size_t)cpw * ldm * 4) + al((size_t)nbc * 4) + 2 * al(NM * 4) + al(8 * 4) + 2 * al(CH_MAXOPS * 4) + 2 * set_bytes;
     if (lds > 158 * 1024) return SEGK_ERR_UNSUPPORTED;
     static size_t lds_set = 0;
