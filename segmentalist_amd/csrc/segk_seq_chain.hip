@@ -64,10 +64,11 @@ struct ChainArgs {
 // polling the counter itself the last arriver's own add queued behind 124 pollers (5.9 us per barrier for the LAST one).
 // ctl: [0] counter, [1] stop (for the host), [2] utterances completed, [3] error, [32 * (1 + f)] release word f.
 #define CH_STOP_BIT (1 << 30)
-__device__ __forceinline__ bool chain_barrier(int32_t *ctl, int phase, int *sh_flag)
+__device__ __forceinline__ bool chain_barrier(int32_t *ctl, int phase, int *sh_flag, unsigned long long *dbg = nullptr)
 {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // this wave's atomics and stores have been performed
     __syncthreads();
+    if (dbg && threadIdx.x == 0) *dbg = wall_clock64();
     if (threadIdx.x < 64) {
         const int lane = threadIdx.x;
         const int target = phase * (int)gridDim.x;
@@ -298,7 +299,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_seq_chain(ChainArgs A)
         CH_STAMP(2);
         if (A.stamp && tid == 0 && q - A.q0 >= 100 && q - A.q0 < 104) A.stamp[2048 + (q - A.q0 - 100) * 256 + blockIdx.x] = wall_clock64();
         phase++;
-        if (!chain_barrier(A.ctl, phase, &sh_flag)) return;
+        if (!chain_barrier(A.ctl, phase, &sh_flag, (A.stamp && blockIdx.x == 0 && q - A.q0 < 256) ? A.stamp + 3072 + (q - A.q0) * 8 + 5 : nullptr)) return;
         CH_STAMP(3);
         if (sh_flag & 2) break;            // a component emptied during the previous utterance: clean_components on the host's side
         // the maxima of the utterance before the previous one: every workgroup has read them (it passed this barrier after
@@ -590,6 +591,9 @@ int segk_launch_seq_chain(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m, c
                     ph[0] += (double)(us[i * 8] - hs[i * 8 + 4]);
                     for (int j = 1; j < 5; j++) ph[j] += (double)(us[i * 8 + j] - us[i * 8 + j - 1]);
                 }
+                double aw = 0;
+                for (int i = 20; i < 199; i++) aw += (double)(us[i * 8 + 5] - hs[i * 8 + 2]);
+                fprintf(stderr, "    of barrier: the wait for the atomics + workgroup barrier %.2f us\n", aw / 179 / 100);
                 fprintf(stderr, "    (entry) %.2f  forward %.2f  decisions %.2f  walk %.2f  new tokens %.2f\n", ph[0] / 179 / 100,
                         ph[1] / 179 / 100, ph[2] / 179 / 100, ph[3] / 179 / 100, ph[4] / 179 / 100);
             }
