@@ -167,6 +167,51 @@ __device__ __forceinline__ float neg_sqd_exact_v4_pk(const float *m, const float
     return -res;
 }
 
+// Two components against one row: the row's elements are read once (the persistent sequential chain's score phase is bound by
+// LDS instructions: three per pair and eight elements instead of four).  Per pair the arithmetic of neg_sqd_exact_v4_pk.
+__device__ __forceinline__ void neg_sqd_exact_v4_pk2(const float *ma, const float *mb, const float *x, int n, float *out_a, float *out_b)
+{
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+    auto pk_sub = [](f32x2_t a, f32x2_t b) -> f32x2_t {
+        f32x2_t d;
+        asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+        return d;
+    };
+    const int nfull = n & ~7;
+    f32x2_t a01, a23, a45, a67, b01, b23, b45, b67;
+    {
+        const f32x4_t x0 = *reinterpret_cast<const f32x4_t *>(x), x1 = *reinterpret_cast<const f32x4_t *>(x + 4);
+        const f32x4_t p0 = *reinterpret_cast<const f32x4_t *>(ma), p1 = *reinterpret_cast<const f32x4_t *>(ma + 4);
+        const f32x4_t q0 = *reinterpret_cast<const f32x4_t *>(mb), q1 = *reinterpret_cast<const f32x4_t *>(mb + 4);
+        const f32x2_t d0 = pk_sub(p0.xy, x0.xy), d1 = pk_sub(p0.zw, x0.zw), d2 = pk_sub(p1.xy, x1.xy), d3 = pk_sub(p1.zw, x1.zw);
+        const f32x2_t e0 = pk_sub(q0.xy, x0.xy), e1 = pk_sub(q0.zw, x0.zw), e2 = pk_sub(q1.xy, x1.xy), e3 = pk_sub(q1.zw, x1.zw);
+        a01 = d0 * d0; a23 = d1 * d1; a45 = d2 * d2; a67 = d3 * d3;
+        b01 = e0 * e0; b23 = e1 * e1; b45 = e2 * e2; b67 = e3 * e3;
+    }
+    for (int i = 8; i < nfull; i += 8) {
+        const f32x4_t x0 = *reinterpret_cast<const f32x4_t *>(x + i), x1 = *reinterpret_cast<const f32x4_t *>(x + i + 4);
+        const f32x4_t p0 = *reinterpret_cast<const f32x4_t *>(ma + i), p1 = *reinterpret_cast<const f32x4_t *>(ma + i + 4);
+        const f32x4_t q0 = *reinterpret_cast<const f32x4_t *>(mb + i), q1 = *reinterpret_cast<const f32x4_t *>(mb + i + 4);
+        const f32x2_t d0 = pk_sub(p0.xy, x0.xy), d1 = pk_sub(p0.zw, x0.zw), d2 = pk_sub(p1.xy, x1.xy), d3 = pk_sub(p1.zw, x1.zw);
+        const f32x2_t e0 = pk_sub(q0.xy, x0.xy), e1 = pk_sub(q0.zw, x0.zw), e2 = pk_sub(q1.xy, x1.xy), e3 = pk_sub(q1.zw, x1.zw);
+        a01 += d0 * d0; a23 += d1 * d1; a45 += d2 * d2; a67 += d3 * d3;
+        b01 += e0 * e0; b23 += e1 * e1; b45 += e2 * e2; b67 += e3 * e3;
+    }
+    float ra = ((a01.x + a01.y) + (a23.x + a23.y)) + ((a45.x + a45.y) + (a67.x + a67.y));
+    float rb = ((b01.x + b01.y) + (b23.x + b23.y)) + ((b45.x + b45.y) + (b67.x + b67.y));
+    if (n & 4) {                                            // the sequential tail: four elements
+        const f32x4_t xt = *reinterpret_cast<const f32x4_t *>(x + nfull);
+        const f32x4_t pt = *reinterpret_cast<const f32x4_t *>(ma + nfull), qt = *reinterpret_cast<const f32x4_t *>(mb + nfull);
+        const f32x2_t d0 = pk_sub(pt.xy, xt.xy), d1 = pk_sub(pt.zw, xt.zw), e0 = pk_sub(qt.xy, xt.xy), e1 = pk_sub(qt.zw, xt.zw);
+        const f32x2_t t0 = d0 * d0, t1 = d1 * d1, s0 = e0 * e0, s1 = e1 * e1;
+        ra += t0.x; ra += t0.y; ra += t1.x; ra += t1.y;
+        rb += s0.x; rb += s0.y; rb += s1.x; rb += s1.y;
+    }
+    *out_a = -ra;
+    *out_b = -rb;
+}
+
 // Four rows at once for 8 <= n <= 128 (numpy's single-block case): identical arithmetic per
 // row, interleaved so that 4 x 8 loads are in flight per step.
 template <typename T, typename TM, typename TX>

@@ -279,16 +279,27 @@ __global__ __launch_bounds__(CH_THREADS) void k_seq_chain(ChainArgs A)
 
         // ================================ phase A: this workgroup's share of the scores, the components of a span on CPW
         // adjacent lanes
-        for (int p0 = 0; p0 < nb * CPW; p0 += CH_THREADS) {
-            const int p = p0 + tid, i = p / CPW, ci = p - i * CPW;
+        // two components per thread (ci and ci + CPW / 2 of one span): the span's row is read once for both
+        const int HW = CPW >> 1;
+        for (int p0 = 0; p0 < nb * HW; p0 += CH_THREADS) {
+            const int p = p0 + tid, i = p / HW, ci = p - i * HW;
             unsigned long long key = 0ull;
             if (i < nb && ci < kn && bid[i] >= 0) {
-                const float sc = neg_sqd_exact_v4_pk(means_l + ci * LDM, xs + i * LDX, D);
-                const unsigned int bits = __float_as_uint(sc);
-                const unsigned int ord = (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);
-                key = ((unsigned long long)ord << 32) | (unsigned long long)(0xffffffffu - (unsigned int)(k0 + ci));
+                const bool two = ci + HW < kn;
+                float sa, sb;
+                neg_sqd_exact_v4_pk2(means_l + ci * LDM, means_l + (two ? ci + HW : ci) * LDM, xs + i * LDX, D, &sa, &sb);
+                auto pack = [&](float sc, int cc) -> unsigned long long {
+                    const unsigned int bits = __float_as_uint(sc);
+                    const unsigned int ord = (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);
+                    return ((unsigned long long)ord << 32) | (unsigned long long)(0xffffffffu - (unsigned int)(k0 + cc));
+                };
+                key = pack(sa, ci);
+                if (two) {
+                    const unsigned long long kb2 = pack(sb, ci + HW);
+                    key = kb2 > key ? kb2 : key;
+                }
             }
-            for (int o = 1; o < CPW; o <<= 1) {
+            for (int o = 1; o < HW; o <<= 1) {
                 const unsigned long long other = __shfl_xor(key, o);
                 key = other > key ? other : key;
             }
