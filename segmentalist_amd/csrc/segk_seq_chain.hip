@@ -5,20 +5,23 @@
 // The three-launch form (k_seq_score -> k_kmeans_segment_w8 -> k_seq_update per utterance) costs 44-52 us per utterance:
 // three kernel boundaries and a dozen dependent memory round trips, every one of them paid 10 000 times per sweep because
 // utterance i + 1 needs the means utterance i leaves behind.  Here G workgroups stay resident for the whole sweep and meet
-// at ONE grid barrier per utterance (19 us per utterance on the headline corpus):
+// at ONE grid barrier per utterance (12.3 us per utterance on the headline corpus; 19 at the end of round 2):
 //
 //   * owner computes: workgroup g owns the components [g * cpw, (g + 1) * cpw) -- their means, numerators and counts live
 //     in its LDS for the whole sweep (written through to memory, never read back);
 //   * phase A: every workgroup scores the utterance's candidate rows (staged by band entry; the NEXT utterance's are
 //     fetched by the otherwise idle waves during phase B) against ITS components in the reference's arithmetic
-//     (neg_sqd_exact), one 64-bit atomic maximum of (score, ~component) per span, every span's word on its own cache line;
+//     (neg_sqd_exact; two components per thread, so that a row's elements leave LDS once for both: the phase is bound by
+//     LDS instructions), one 64-bit atomic maximum of (score, ~component) per span, every span's word on its own cache line;
 //   * grid barrier: arrivals on one counter, the last arriver releases the others through separate flag words; spins are
 //     bounded and end in an error, never in a hang;
 //   * phase B, replicated: EVERY workgroup reads the spans' maxima and runs the same DP (seg_w8_uniform) on the same inputs,
 //     so every workgroup knows the utterance's old and new tokens without another exchange; each applies the del_item /
 //     add_item sequence (kmeans_components.py:93-132, the `k > K -> K` clamp included) to the components it owns, in the
 //     reference's order, from the rows it staged.  Labels and boundaries are written by every workgroup (the same values:
-//     whichever L2 a later read hits holds them).
+//     whichever L2 a later read hits holds them).  The items are kept by span end, one lane per span end holding the old
+//     and the new token that end there; a workgroup walks only the items on ITS components (two 64-bit masks), so the
+//     hundred-odd workgroups an utterance does not touch do nothing after the DP.
 //
 // Nothing but atomics crosses workgroups inside the kernel (maxima, barrier counter and release words), so no cache
 // maintenance is needed between the XCDs' L2s.  clean_components (:263-266) moves rows between owners and relabels the
