@@ -746,14 +746,17 @@ def test_duplicate_means_are_taken_out_of_the_filters(gpu, monkeypatch, pre):
     assert nbrute_after <= nbrute_before // 2
 
 
-@pytest.mark.parametrize("n_utt,D,K,N,nmax,ragged", [(300, 100, 1000, 20, 6, False), (200, 40, 130, 0, 5, True),
-                                                      (150, 16, 9, 12, 8, False), (120, 8, 300, 0, 3, True)])
-def test_persistent_sequential_chain_equals_the_three_launch_form(gpu, monkeypatch, n_utt, D, K, N, nmax, ragged):
+@pytest.mark.parametrize("n_utt,D,K,N,nmax,ragged,mindur", [(300, 100, 1000, 20, 6, False, 0), (200, 40, 130, 0, 5, True, 0),
+                                                             (150, 16, 9, 12, 8, False, 0), (120, 8, 300, 0, 3, True, 0),
+                                                             (150, 8, 20, 0, 4, True, 9), (100, 12, 40, 0, 6, True, 14)])
+def test_persistent_sequential_chain_equals_the_three_launch_form(gpu, monkeypatch, n_utt, D, K, N, nmax, ragged, mindur):
     """segk_seq_chain.hip (one persistent kernel per sweep: owner-computes components, one grid barrier per utterance, the DP
     replicated in every workgroup) against the three launches per utterance it replaces (SEGK_SEQ_CHAIN=0), which
     test_sequential_chain_bit_exact_vs_reference pins to the reference's captured chains: boundaries, labels, means,
     numerators, counts and the record values after every sweep, bit for bit -- headline shape, ragged utterances shorter than
-    the window (no banded table), a window of eight, many components emptying (the stop / clean / relaunch path)."""
+    the window (no banded table), a window of eight, many components emptying (the stop / clean / relaunch path), spans
+    shorter than min_duration (NaN durations, utterances.py:96-101: span ends whose candidates are all -inf, the backward
+    pass's step-back branch, kmeans_acoustic_wordseg.py:516-530)."""
     from segmentalist_amd import kmeans_acoustic_wordseg as kaw
     corpus = cases.chain_corpus(n_utt, D, K, 7 * n_utt + D, ragged, N, nmax, "float32")
     out = {}
@@ -762,7 +765,11 @@ def test_persistent_sequential_chain_equals_the_three_launch_form(gpu, monkeypat
         random.seed(5)
         np.random.seed(5)
         seg = kaw.SegmentalKMeansWordseg(K, *corpus, n_slices_min=0, n_slices_max=nmax, p_boundary_init=0.5,
-                                         init_am_assignments="rand", wip=-0.1)
+                                         init_am_assignments="rand", wip=-0.1, min_duration=mindur)
+        if mindur:
+            # the case is here for spans that HAVE an embedding and a NaN duration
+            ut = seg.utterances
+            assert (np.isnan(ut.durations) & (ut.vec_ids >= 0)).any()
         c = seg.acoustic_model.components
         states = []
         for it in range(3):
