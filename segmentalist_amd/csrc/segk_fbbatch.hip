@@ -264,75 +264,103 @@ static __device__ __forceinline__ double fbb_tree(double *p, int n, int stride)
 
 // ---------------------------------------------------------------------------------------
 // statistics without block b (b = -1: all) and the per-slot predictive parameters.
-// One wave per slot; lanes over the dimensions.  Shared scratch: [waves][16 slices][64 lanes].
+// One workgroup of three waves per slot: wave 0 sums the counts, wave 1 the sums, wave 2 the sums of squares (their loads
+// are one memory round trip side by side; as one wave per slot they were three in a row -- the kernel is K_max workgroups of
+// pure latency: 36 us with a load per loop iteration, 28 with eight in flight, 21 with a quantity's 64 in flight), lanes over
+// the dimensions; wave 0 then forms the parameters.  Shared scratch: [waves][16 slices][64 lanes].
 // ---------------------------------------------------------------------------------------
-__global__ void k_fbb_prepare(segk_fbgmm f, segk_fbatch bt, int D, int b, double prior_alpha)
+__global__ __launch_bounds__(192) void k_fbb_prepare(segk_fbgmm f, segk_fbatch bt, int D, int b, double prior_alpha)
 {
-    __shared__ double scr[4][16][64];
+    __shared__ double scr[3][16][64];
+    __shared__ double res[3][64];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int k = blockIdx.x * 4 + w;
-    if (k >= f.K_max) return;
+    const int k = blockIdx.x;
     const int S = bt.n_slices, B = bt.n_blocks, KM = f.K_max;
     const int64_t rec = fbb_rec(f, D);
     double (*my)[64] = scr[w];
-    // sum over the blocks bp != b of partials[(bp * S + s) * rec + off], in block order; eight loads in flight at a time
-    // (one load per loop iteration made this kernel three dozen dependent round trips: 36 us)
-    auto sum_blocks = [&](int s, int64_t off) -> double {
-        double a = 0.0;
-        for (int bp0 = 0; bp0 < B; bp0 += 8) {
-            double v[8];
+    // my[s][lane] = sum over the blocks bp != b of partials[(bp * S + s) * rec + off], in block order, for every slice s: the
+    // loads of eight slices x eight blocks are in flight together
+    auto sum_slices = [&](int64_t off) {
+        for (int s0 = 0; s0 < S; s0 += 8) {
+            double a[8];
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const int bp = bp0 + j < B ? bp0 + j : B - 1;
-                v[j] = bt.partials[((int64_t)bp * S + s) * rec + off];
+            for (int i = 0; i < 8; i++) a[i] = 0.0;
+            for (int bp0 = 0; bp0 < B; bp0 += 8) {
+                double v[8][8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const int sidx = s0 + i < S ? s0 + i : S - 1;
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        const int bp = bp0 + j < B ? bp0 + j : B - 1;
+                        v[i][j] = bt.partials[((int64_t)bp * S + sidx) * rec + off];
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 8; i++)
+#pragma unroll
+                    for (int j = 0; j < 8; j++)
+                        if (bp0 + j < B && bp0 + j != b) a[i] += v[i][j];
             }
 #pragma unroll
-            for (int j = 0; j < 8; j++)
-                if (bp0 + j < B && bp0 + j != b) a += v[j];
+            for (int i = 0; i < 8; i++)
+                if (s0 + i < S) my[s0 + i][lane] = a[i];
         }
-        return a;
     };
-    // counts
-    for (int s = 0; s < S; s++) my[s][lane] = sum_blocks(s, k);
-    const double n = fbb_tree(&my[0][lane], S, 64);
-    double lsum = 0.0;
-    const double k_N = f.k_0 + n, v_N = f.v_0 + n;
+    double lsum = 0.0, n = 0.0, k_N = 0.0, v_N = 0.0;
     for (int d0 = 0; d0 < D; d0 += 64) {
         const int d = d0 + lane;
-        double sx = 0.0, sxx = 0.0;
-        if (d < D) {
-            for (int s = 0; s < S; s++) my[s][lane] = sum_blocks(s, KM + (int64_t)k * D + d);
-            sx = fbb_tree(&my[0][lane], S, 64);
-            if (f.cov_type == 1) {
-                for (int s = 0; s < S; s++) my[s][lane] = sum_blocks(s, KM + (int64_t)KM * D + (int64_t)k * D + d);
-                sxx = fbb_tree(&my[0][lane], S, 64);
+        if (w == 0) {
+            if (d0 == 0) {
+                sum_slices(k);
+                res[0][lane] = fbb_tree(&my[0][lane], S, 64);
             }
-            double mean, q, lt;
-            if (f.cov_type == 0) {          // fixedvar:153-170, 317-325
-                const double pN = f.prior_c[d] + n * f.prior_a[d];
-                mean = (f.prior_c[d] * f.prior_b[d] + f.prior_a[d] * sx) / pN;
-                q = pN * f.prior_a[d] / (pN + f.prior_a[d]);
-                lt = log(q);
-            } else {                        // diag:162-177, 332-345
-                mean = (f.k_0 * f.prior_b[d] + sx) / k_N;
-                const double var = (k_N + 1.) / (k_N * v_N)
-                                   * (f.prior_a[d] + f.k_0 * (f.prior_b[d] * f.prior_b[d]) + sxx - k_N * (mean * mean));
-                q = 1. / var * (1. / v_N);
-                lt = log(var);
-            }
-            bt.mean_t[(int64_t)d * KM + k] = mean;
-            bt.q_t[(int64_t)d * KM + k] = q;
-            lsum += lt;
+        } else if (d < D && (w == 1 || f.cov_type == 1)) {
+            sum_slices(w == 1 ? KM + (int64_t)k * D + d : KM + (int64_t)KM * D + (int64_t)k * D + d);
+            res[w][lane] = fbb_tree(&my[0][lane], S, 64);
         }
+        __syncthreads();
+        if (w == 0) {
+            if (d0 == 0) {
+                n = res[0][lane];
+                k_N = f.k_0 + n;
+                v_N = f.v_0 + n;
+            }
+            if (d < D) {
+                const double sx = res[1][lane], sxx = f.cov_type == 1 ? res[2][lane] : 0.0;
+                double mean, q, lt;
+                if (f.cov_type == 0) {          // fixedvar:153-170, 317-325
+                    const double pN = f.prior_c[d] + n * f.prior_a[d];
+                    mean = (f.prior_c[d] * f.prior_b[d] + f.prior_a[d] * sx) / pN;
+                    q = pN * f.prior_a[d] / (pN + f.prior_a[d]);
+                    lt = log(q);
+                } else {                        // diag:162-177, 332-345
+                    mean = (f.k_0 * f.prior_b[d] + sx) / k_N;
+                    const double var = (k_N + 1.) / (k_N * v_N)
+                                       * (f.prior_a[d] + f.k_0 * (f.prior_b[d] * f.prior_b[d]) + sxx - k_N * (mean * mean));
+                    q = 1. / var * (1. / v_N);
+                    lt = log(var);
+                }
+                bt.mean_t[(int64_t)d * KM + k] = mean;
+                bt.q_t[(int64_t)d * KM + k] = q;
+                lsum += lt;
+            }
+        }
+        if (d0 + 64 < D) __syncthreads();           // (res is written again)
     }
+    if (w != 0) return;
     for (int o = 32; o > 0; o >>= 1) lsum += __shfl_xor(lsum, o);
+    // the slot's scalars: the two log-gammas side by side on lanes 0 and 1, the two logarithms likewise
+    const double lg = f.cov_type == 0 ? 0.0 : lgamma(lane == 0 ? (v_N + 1.) / 2. : v_N / 2.);
+    const double lv = log(lane == 0 ? v_N : prior_alpha / (double)KM + n);
+    const double lg1 = __shfl(lg, 1), lv1 = __shfl(lv, 1);
     if (lane == 0) {
         double lconst;
         if (f.cov_type == 0) lconst = -0.5 * (double)D * 1.8378770664093453 + 0.5 * lsum;
-        else lconst = (double)D * (lgamma((v_N + 1.) / 2.) - lgamma(v_N / 2.) - 0.5 * log(v_N) - 0.5 * 1.1447298858494002) - 0.5 * lsum;
+        else lconst = (double)D * (lg - lg1 - 0.5 * lv - 0.5 * 1.1447298858494002) - 0.5 * lsum;
         bt.cnt[k] = n;
         bt.lconst[k] = lconst;
-        bt.zconst[k] = f.lms * log(prior_alpha / (double)KM + n) + (n > 0.0 ? lconst : 0.0);
+        bt.zconst[k] = f.lms * lv1 + (n > 0.0 ? lconst : 0.0);
         bt.half[k] = f.cov_type == 0 ? 0.5 : (v_N + 1.) / 2.;
         atomicAdd(&bt.scal[0], n);                       // integer valued: exact in any order
         if (n > 0.0) atomicAdd(&bt.scal[1], 1.0);
@@ -1495,7 +1523,7 @@ int32_t segk_fbb_prepare(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *
     if (!ctx || ctx->fbb_scal_zeroed != (const void *)bt->scal) SEGK_CHECK_HIP(hipMemsetAsync(bt->scal, 0, 2 * sizeof(double), st));
     if (ctx) ctx->fbb_scal_zeroed = nullptr;
     const double alpha = f->lm_unigram ? f->lm_a : f->alpha;
-    hipLaunchKernelGGL(k_fbb_prepare, dim3((f->K_max + 3) / 4), dim3(256), 0, st, *f, *bt, c->D, b, alpha);
+    hipLaunchKernelGGL(k_fbb_prepare, dim3(f->K_max), dim3(192), 0, st, *f, *bt, c->D, b, alpha);
     if (bt->tiles16 && bt->y16 && f->cov_type == 0) {
         SEGK_REQUIRE(bt->rows32 && bt->consts16, "rows32 / consts16 scratch missing");
         SEGK_CHECK_HIP(hipMemsetAsync(bt->consts16 + f->K_max + 1, 0, sizeof(double), st));
