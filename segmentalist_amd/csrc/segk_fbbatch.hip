@@ -442,6 +442,24 @@ template <int NR>
 static __device__ __forceinline__ void fbb_accumulate_rows32(const segk_fbatch &bt, int KM, int k, int D, const double *xs, float *acc)
 {
     int d = 0;
+    // sixteen dimensions' parameters in flight (four at a time were ten dependent round trips for D = 39); the terms in the
+    // same order
+    for (; d + 16 <= D; d += 16) {
+        float m[16], q[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            m[j] = (float)bt.mean_t[(int64_t)(d + j) * KM + k];
+            q[j] = (float)bt.q_t[(int64_t)(d + j) * KM + k];
+        }
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+#pragma unroll
+            for (int r = 0; r < NR; r++) {
+                const float delta = m[j] - (float)xs[r * D + d + j];
+                acc[r] += __builtin_amdgcn_logf(1.f + (delta * delta) * q[j]);
+            }
+        }
+    }
     for (; d + 4 <= D; d += 4) {
         float m[4], q[4];
 #pragma unroll
@@ -490,7 +508,7 @@ static __device__ double fbb_prior_row(const segk_fbgmm &f, int D, const double 
 // merged across the workgroup at the end.
 // ---------------------------------------------------------------------------------------
 template <typename XT, int COV>
-__global__ void k_fbb_score(segk_corpus c, segk_fbgmm f, segk_fbatch bt, FbbMap map, int b, double prior_alpha,
+__global__ __launch_bounds__(256) void k_fbb_score(segk_corpus c, segk_fbgmm f, segk_fbatch bt, FbbMap map, int b, double prior_alpha,
                             double *score)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -722,7 +740,7 @@ __global__ __launch_bounds__(256) void k_vlog_calibrate(int iters, float seed, f
 // ---------------------------------------------------------------------------------------
 // boundaries of one utterance per workgroup (128 threads; wave 0 runs the DP)
 // ---------------------------------------------------------------------------------------
-__global__ void k_fbb_segment(segk_corpus c, segk_fbatch bt, FbbMap map, int b, uint64_t sweep, int n_max, double wip,
+__global__ __launch_bounds__(128) void k_fbb_segment(segk_corpus c, segk_fbatch bt, FbbMap map, int b, uint64_t sweep, int n_max, double wip,
                               double time_power_term, double anneal_temp, const double *score, uint8_t *boundaries,
                               int32_t *new_tok, int32_t *n_new, double *out_logprob, int32_t *status, double *probe_alpha)
 {
@@ -777,7 +795,7 @@ __global__ void k_fbb_segment(segk_corpus c, segk_fbatch bt, FbbMap map, int b, 
 // slots of the new tokens of one utterance per workgroup
 // ---------------------------------------------------------------------------------------
 template <typename XT, int COV, int F32 = 0>
-__global__ void k_fbb_assign(segk_corpus c, segk_fbgmm f, segk_fbatch bt, FbbMap map, int b, uint64_t sweep,
+__global__ __launch_bounds__(512) void k_fbb_assign(segk_corpus c, segk_fbgmm f, segk_fbatch bt, FbbMap map, int b, uint64_t sweep,
                              double prior_alpha, double anneal_temp, const int32_t *new_tok, const int32_t *n_new,
                              int rcap, int dbg, const float *llmat, int64_t ll_ld, double *probe_ll, int64_t probe_ld)
 {
