@@ -217,6 +217,31 @@ struct CounterUniforms {       // the batch sampler's counter-based stream
     __device__ double next(int) { return segk_u01(seed, sweep, utt, j++); }
 };
 
+// Cross-lane moves inside a row of sixteen lanes (DPP: a few clocks; __shfl_xor on a double is two ds_bpermute round trips, and
+// a lone wave -- the DP is one wave per utterance -- waits out every one of them)
+template <int CTRL>
+static __device__ __forceinline__ double fb_dpp_f64(double v)
+{
+    union { double d; int i[2]; } u, r;
+    u.d = v;
+    r.i[0] = __builtin_amdgcn_update_dpp(u.i[0], u.i[0], CTRL, 0xF, 0xF, false);
+    r.i[1] = __builtin_amdgcn_update_dpp(u.i[1], u.i[1], CTRL, 0xF, 0xF, false);
+    return r.d;
+}
+// maximum over the lanes 0..15 of a row, in all of them (quad xor 1, xor 2, half-row mirror, row mirror)
+static __device__ __forceinline__ double fb_row16_max(double v)
+{
+    double o = fb_dpp_f64<0xB1>(v);
+    v = o > v ? o : v;
+    o = fb_dpp_f64<0x4E>(v);
+    v = o > v ? o : v;
+    o = fb_dpp_f64<0x141>(v);
+    v = o > v ? o : v;
+    o = fb_dpp_f64<0x140>(v);
+    v = o > v ? o : v;
+    return v;
+}
+
 // A6 / A7 by one full wave (unigram_acoustic_wordseg.py:653-864): forward filtering, then backward
 // sampling (or Viterbi back-tracking) writing the boundaries; returns the summed score of the chosen
 // segments.  Control flow and values are wave-uniform; the exponentials of each logsumexp /
@@ -232,11 +257,32 @@ static __device__ double fb_dp_sample(const double *vec, double *a, double *w, d
     a[0] = 0.0;
     __builtin_amdgcn_wave_barrier();
     int i = 0;
+    // A window of at most sixteen slices (the models' n_slices_max): lane w holds candidate s = t - 1 - w and alpha[s] in a
+    // register -- a delay line shifted by one lane per step, the new alpha entering at lane 0 --, the maximum by DPP inside the
+    // row; the exponentials one per lane and their sum in the order of s, as below.  Same values: maxima do not depend on the
+    // order, everything else is the same operation on the same operands.
+    const bool lanes16 = n_max > 0 && n_max <= 16;
+    double g = 0.0;                                                  // alpha[t - 1 - lane]; alpha[0] = 0
     for (int t = 1; t < N; t++) {
         int lo = (n_max == 0 || t - n_max < 0) ? 0 : t - n_max;
         int n = t - lo;
         double at;
-        if (n <= 64) {
+        if (lanes16) {
+            const double v = lane < n ? vec[i + t - 1 - lane] + g : NEG_INF_D;
+            const bool all_inf = __ballot(lane < n && v != NEG_INF_D) == 0ull;
+            const double mx = fb_row16_max(lane < 16 ? v : NEG_INF_D);
+            if (viterbi) at = fb_readlane(mx, 0);
+            else if (all_inf) at = NEG_INF_D;
+            else {
+                const double m0 = fb_readlane(mx, 0);
+                const double ej = lane < n ? (fast ? fb_exp_fast(v - m0) : exp(v - m0)) : 0.0;
+                double sm = 0.0;
+                for (int q = n - 1; q >= 0; q--) sm += fb_readlane(ej, q);       // s = lo .. t - 1
+                at = (fast ? fb_log_fast(sm) : log(sm)) + m0 + log_p_continue;
+            }
+            const double gs = fb_dpp_f64<0x111>(g);                  // row_shr:1: lane w takes lane w - 1's
+            g = lane == 0 ? at : gs;
+        } else if (n <= 64) {
             // one candidate per lane: the same maximum, the same exponentials and the same left-to-right sum as
             // fb_logsumexp_wave, without the trip of the candidates through LDS (a serial loop of n dependent reads and
             // stores per step)
@@ -278,6 +324,11 @@ static __device__ double fb_dp_sample(const double *vec, double *a, double *w, d
         i = (t - 1) * t / 2;
         lo = (n_max == 0 || t - n_max < 0) ? 0 : t - n_max;
         bool all_inf = true;
+        double xw = NEG_INF_D;                                       // lanes16: candidate lo + lane of span end t
+        if (lanes16) {
+            xw = lane < t - lo ? vec[i + lo + lane] + a[lo + lane] : NEG_INF_D;
+            all_inf = __ballot(lane < t - lo && xw != NEG_INF_D) == 0ull;
+        } else
         for (int s = lo; s < t; s++)
             if (vec[i + s] + a[s] != NEG_INF_D) { all_inf = false; break; }
         if (all_inf) {
@@ -287,12 +338,41 @@ static __device__ double fb_dp_sample(const double *vec, double *a, double *w, d
                 i = (t - 1) * t / 2;
                 lo = (n_max == 0 || t - n_max < 0) ? 0 : t - n_max;
                 all_inf = true;
+                if (lanes16) {
+                    xw = lane < t - lo ? vec[i + lo + lane] + a[lo + lane] : NEG_INF_D;
+                    all_inf = __ballot(lane < t - lo && xw != NEG_INF_D) == 0ull;
+                } else
                 for (int s = lo; s < t; s++)
                     if (vec[i + s] + a[s] != NEG_INF_D) { all_inf = false; break; }
             }
             if (lane == 0) bnd[(t - 1 + N) % N] = 1;
         }
         int k = 1, n = 1;
+        if (lanes16 && !viterbi && anneal_temp == 1.0 && t > 0) {
+            // the step in registers: lane j holds w[j]; maximum by DPP, the exponentials one per lane, their sum in index
+            // order, the draw walking pr[j] = exp(w[n - 1 - j] - lse) -- the arithmetic of the general form below
+            n = t - lo;
+            const double m0 = fb_readlane(fb_row16_max(lane < 16 ? xw : NEG_INF_D), 0);
+            const double ej = lane < n ? (fast ? fb_exp_fast(xw - m0) : exp(xw - m0)) : 0.0;
+            double sm = 0.0;
+            for (int q = 0; q < n; q++) sm += fb_readlane(ej, q);
+            const double lse = (fast ? fb_log_fast(sm) : log(sm)) + m0;
+            const double pl = lane < n ? (fast ? fb_exp_fast(xw - lse) : exp(xw - lse)) : 0.0;
+            double uu = usrc.next(lane);
+            int kk = n - 1;
+            for (int j = 0; j < n; j++) {
+                uu = uu - fb_readlane(pl, n - 1 - j);
+                if (uu < 0) { kk = j; break; }
+            }
+            k = kk + 1;
+            int idx = i + t - k;
+            if (idx < 0) idx += tri;
+            total += vec[idx];
+            if (t - k - 1 < 0) break;
+            if (lane == 0) bnd[t - k - 1] = 1;
+            t = t - k;
+            continue;
+        }
         if (t > 0) {
             n = t - lo;
             for (int j = lane; j < n; j += 64) w[j] = vec[i + lo + j] + a[lo + j];
