@@ -195,7 +195,7 @@ __device__ void fb_del_item(const segk_corpus &c, const segk_fbgmm &f, int64_t e
 // op 0: delete the OLD segments of utterance `utt` (listed from the boundaries + vec_ids)
 // op 1: add_item(item, k_item)   op 2: del_item(item)   op 4: del_component(k_item)
 template <typename XT>
-__global__ void k_fbgmm_update(segk_corpus c, segk_fbgmm f, int op, int utt, int64_t item, int k_item,
+__global__ __launch_bounds__(256) void k_fbgmm_update(segk_corpus c, segk_fbgmm f, int op, int utt, int64_t item, int k_item,
                                const uint8_t *boundaries)
 {
     __shared__ int shK, sh_i;
@@ -262,20 +262,50 @@ __global__ void k_fbgmm_update(segk_corpus c, segk_fbgmm f, int op, int utt, int
 template <typename XT>
 __device__ __forceinline__ double fb_pred_sum(const segk_fbgmm &f, int D, int k, const XT *x, int d0, int dstep)
 {
+    // the statistics of eight of the lane's dimensions are fetched together (a load pair per loop iteration was a dependent
+    // round trip per dimension: ten of them per token and lane at D = 39 with four lanes per component); the terms and
+    // their order are unchanged
     double s = 0.0;
+    const double *sa = f.stat_a + (int64_t)k * D, *sb = f.stat_b + (int64_t)k * D, *pp = f.pred + (int64_t)k * D;
     if (f.cov_type == 0) {      // gaussian_components_fixedvar.py:242-253
-        for (int d = d0; d < D; d += dstep) {
-            double mu = f.stat_a[(int64_t)k * D + d] / f.stat_b[(int64_t)k * D + d];
-            double delta = mu - (double)x[d];
-            s += (delta * delta) * f.pred[(int64_t)k * D + d];
+        for (int dd = d0; dd < D; dd += 8 * dstep) {
+            double a[8], b[8], p[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int d = dd + j * dstep;
+                a[j] = b[j] = p[j] = 1.0;
+                if (d < D) { a[j] = sa[d]; b[j] = sb[d]; p[j] = pp[d]; }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int d = dd + j * dstep;
+                if (d < D) {
+                    double mu = a[j] / b[j];
+                    double delta = mu - (double)x[d];
+                    s += (delta * delta) * p[j];
+                }
+            }
         }
     } else {                    // gaussian_components_diag.py:237-259
         const double cnt = (double)f.counts[k];
         const double k_N = f.k_0 + cnt, v_N = f.v_0 + cnt;
-        for (int d = d0; d < D; d += dstep) {
-            double m = f.stat_a[(int64_t)k * D + d] / k_N;
-            double delta = m - (double)x[d];
-            s += log(1. + (delta * delta) * f.pred[(int64_t)k * D + d] * (1. / v_N));
+        for (int dd = d0; dd < D; dd += 8 * dstep) {
+            double a[8], p[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int d = dd + j * dstep;
+                a[j] = p[j] = 0.0;
+                if (d < D) { a[j] = sa[d]; p[j] = pp[d]; }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int d = dd + j * dstep;
+                if (d < D) {
+                    double m = a[j] / k_N;
+                    double delta = m - (double)x[d];
+                    s += log(1. + (delta * delta) * p[j] * (1. / v_N));
+                }
+            }
         }
     }
     return s;
@@ -379,7 +409,7 @@ __device__ void fb_logits(const segk_corpus &c, const segk_fbgmm &f, int64_t e, 
 
 // A4: out[ids[r]] = log_marg_i(ids[r]) for r < n (entries -1 skipped).  One workgroup per row.
 template <typename XT>
-__global__ void k_fbgmm_score(segk_corpus c, segk_fbgmm f, const int32_t *ids, int64_t row0, double *out)
+__global__ __launch_bounds__(512) void k_fbgmm_score(segk_corpus c, segk_fbgmm f, const int32_t *ids, int64_t row0, double *out)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *z = (double *)smem;                      // [K_max]
@@ -415,7 +445,7 @@ __global__ void k_fbgmm_pred_vector(segk_corpus c, segk_fbgmm f, int64_t row, do
 // Single thread does the DP (N <= N_max landmarks, fp64, reference order); uniforms are taken
 // from ustream[*ucursor ...] and the cursor advanced (one per backward-sampling step).
 // ---------------------------------------------------------------------------------------
-__global__ void k_unigram_segment(segk_corpus c, int utt, int viterbi, int n_min, int n_max, double wip,
+__global__ __launch_bounds__(128) void k_unigram_segment(segk_corpus c, int utt, int viterbi, int n_min, int n_max, double wip,
                                   double time_power_term, double log_p_continue, double anneal_temp,
                                   const double *score, const double *ustream, int64_t *ucursor, int64_t ucap,
                                   uint8_t *boundaries, int32_t *new_tok, int32_t *n_new, double *out_logprob,
@@ -523,7 +553,7 @@ __device__ void fb_draw_component(const segk_fbgmm &f, double *z, double *red, i
 // A10 for the new segments of one utterance, in order (fbgmm.py:422-494).  One workgroup.
 // ---------------------------------------------------------------------------------------
 template <typename XT>
-__global__ void k_fbgmm_assign(segk_corpus c, segk_fbgmm f, int utt, int map_assign, int j_prev0, double anneal_temp,
+__global__ __launch_bounds__(512) void k_fbgmm_assign(segk_corpus c, segk_fbgmm f, int utt, int map_assign, int j_prev0, double anneal_temp,
                                const int32_t *new_tok, const int32_t *n_new, const double *ustream,
                                int64_t *ucursor, int64_t ucap, int32_t *status)
 {
@@ -560,7 +590,7 @@ __global__ void k_fbgmm_assign(segk_corpus c, segk_fbgmm f, int utt, int map_ass
 // restore the cached statistics (same component, no component deleted) or add_item.
 // ---------------------------------------------------------------------------------------
 template <typename XT>
-__global__ void k_fbgmm_gibbs_items(segk_corpus c, segk_fbgmm f, const int32_t *ids, int64_t n,
+__global__ __launch_bounds__(512) void k_fbgmm_gibbs_items(segk_corpus c, segk_fbgmm f, const int32_t *ids, int64_t n,
                                     int consider_unassigned, double anneal_temp, const double *ustream,
                                     int64_t *ucursor, int64_t ucap, int32_t *status)
 {

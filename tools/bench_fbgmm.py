@@ -76,7 +76,9 @@ def main():
         print("%-6s init %.2f s; sweep times %s s -> %.2f sweeps/s (%.1f us/utterance); K=%d"
               % (which, t_init, ["%.3f" % x for x in st], 1.0 / min(st), 1e6 * min(st) / args.utts,
                  rec["components"][-1]), flush=True)
-        # oracle on a bounded sample
+        # oracle on a bounded sample (--cpu-utts 0: device timings only)
+        if not keys:
+            continue
         random.seed(0)
         np.random.seed(0)
         if which == "diag":
