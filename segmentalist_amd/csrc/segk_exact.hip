@@ -591,11 +591,7 @@ int segk_launch_seq_score(const segk_corpus *c, const segk_kmeans *m, int utt, c
     const size_t lds = ((size_t)((SEQ_CPB * (c->D + 4) + 3) & ~3) + (size_t)SEQ_JCH * ((c->D + 3) & ~3)) * sizeof(float);
     SEGK_REQUIRE(lds <= 140 * 1024, "D too large for the sequential score kernel");
     SEGK_REQUIRE(tri_max <= SEQ_MAXTRI, "more than 63 landmarks per utterance: use the per-utterance calls");
-    static size_t lds_set = 0;
-    if (lds > 48 * 1024 && lds > lds_set) {
-        SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_seq_score, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        lds_set = lds;
-    }
+    SEGK_CHECK_HIP(segk_dyn_lds((const void *)k_seq_score, lds));
     hipLaunchKernelGGL(k_seq_score, dim3((m->K_max + SEQ_CPB - 1) / SEQ_CPB), dim3(1024), lds, st, *c, *m, utt, tri_max, *cand, keys);
     return SEGK_OK;
 }
@@ -641,11 +637,7 @@ int segk_resolve_on(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m, c
         const int64_t max_chunks = (n + BLS_ROWS - 1) / BLS_ROWS;
         if (n_chunks > max_chunks) n_chunks = (int)max_chunks;
         const size_t lds = ((size_t)BLS_TPS * segk_G(c->D) * 128 + (size_t)BLS_ROWS * ((c->D + 3) & ~3)) * sizeof(float);
-        static size_t lds_set = 0;
-        if (lds > 48 * 1024 && lds > lds_set) {
-            SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_kmeans_brute_ls, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            lds_set = lds;
-        }
+        SEGK_CHECK_HIP(segk_dyn_lds((const void *)k_kmeans_brute_ls, lds));
         hipLaunchKernelGGL(k_kmeans_brute_ls, dim3((unsigned)(n_slices * n_chunks)), dim3(BLS_THREADS), lds, st, *c, *m, *cand, (int)c->n_emb,
                            status ? status + 1 : nullptr, n_slices, n_chunks, ctx->brute_ws);
         hipLaunchKernelGGL(k_brute_finish_ls, dim3(32), dim3(256), 0, st, *cand, (int)c->n_emb, ctx->brute_ws);

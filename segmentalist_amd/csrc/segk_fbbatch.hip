@@ -1511,11 +1511,7 @@ int32_t segk_fbb_partials(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm 
             ctx->fbs_bytes = need;
         }
         int32_t *sorted = ctx->fbs_buf, *koff = ctx->fbs_buf + (size_t)s_n * stride;
-        static size_t lds_set = 0;
-        if (lds_sort > 48 * 1024 && lds_sort > lds_set) {
-            SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_fbb_sort, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sort));
-            lds_set = lds_sort;
-        }
+        SEGK_CHECK_HIP(segk_dyn_lds((const void *)k_fbb_sort, lds_sort));
         hipLaunchKernelGGL(k_fbb_sort, dim3(s_n), dim3(FBS_THREADS), lds_sort, (hipStream_t)stream, *c, *f, *bt, s_lo, b, new_tok, n_new,
                            sorted, stride, koff);
         DISPATCH_XT(c, hipLaunchKernelGGL(k_fbb_partials_sorted<XT>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0,

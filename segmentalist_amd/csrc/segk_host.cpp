@@ -2,6 +2,9 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdlib.h>
+#include <map>
+#include <mutex>
+#include <tuple>
 
 #include "segk_internal.h"
 
@@ -272,3 +275,47 @@ double segk_sum_square_a_times_b(const double *a, const double *b, int64_t n)   
 }
 
 }  // extern "C"
+
+
+// ---- per-device launch attributes (segk_internal.h)
+static std::mutex g_attr_mu;
+static std::map<std::pair<int, const void *>, size_t> g_dyn_lds;
+static std::map<std::tuple<int, const void *, int, size_t>, int> g_occupancy;
+
+hipError_t segk_dyn_lds(const void *fn, size_t lds)
+{
+    if (lds <= 48 * 1024) return hipSuccess;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(g_attr_mu);
+    size_t &have = g_dyn_lds[std::make_pair(dev, fn)];
+    if (have >= lds) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) have = lds;
+    return e;
+}
+
+hipError_t segk_occupancy(const void *fn, int threads, size_t lds, int *wg_per_cu)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    {
+        std::lock_guard<std::mutex> lock(g_attr_mu);
+        auto it = g_occupancy.find(std::make_tuple(dev, fn, threads, lds));
+        if (it != g_occupancy.end()) {
+            *wg_per_cu = it->second;
+            return hipSuccess;
+        }
+    }
+    e = segk_dyn_lds(fn, lds);
+    if (e != hipSuccess) return e;
+    int occ = 0;
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, threads, lds);
+    if (e != hipSuccess) return e;
+    *wg_per_cu = occ > 0 ? occ : 1;
+    std::lock_guard<std::mutex> lock(g_attr_mu);
+    g_occupancy[std::make_tuple(dev, fn, threads, lds)] = *wg_per_cu;
+    return hipSuccess;
+}

@@ -106,6 +106,13 @@ int segk_rows_by_label(segk_ctx *ctx, const int32_t *labels, int64_t n, int K_ma
 
 #define SEGK_LAUNCH_CHECK() SEGK_CHECK_HIP(hipGetLastError())
 
+// hipFuncAttributeMaxDynamicSharedMemorySize for `fn` on the CURRENT device, raised when `lds` exceeds 48 KB and what has been set
+// there before.  The attribute is per device: a function-local static flag (rounds 1-2) skipped it for a second context on
+// another GPU of the same process.  segk_occupancy: hipOccupancyMaxActiveBlocksPerMultiprocessor, cached per (device, function,
+// threads, lds) the same way.
+hipError_t segk_dyn_lds(const void *fn, size_t lds);
+hipError_t segk_occupancy(const void *fn, int threads, size_t lds, int *wg_per_cu);
+
 // ---------------------------------------------------------------------------------------
 // Layout of the MFMA operand image of the k-means means ("tiles"), shared by the prepare
 // and score kernels.  One tile = 32 components:

@@ -350,19 +350,9 @@ static int launch_score(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *
 {
     const size_t lds = 2 * (size_t)A.tile_stride * sizeof(float);
     const int rows_per_wg = WAVES * 32 * NB;
-    static int wg_per_cu = 0;
-    if (!wg_per_cu) {
-        if (lds > 48 * 1024) {
-            SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_kmeans_score<GMAX, NB, WAVES, 0>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_kmeans_score<GMAX, NB, WAVES, 1>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        }
-        int occ = 0;
-        SEGK_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)k_kmeans_score<GMAX, NB, WAVES, 0>,
-                                                                    64 * WAVES, lds));
-        wg_per_cu = occ > 0 ? occ : 1;
-    }
+    int wg_per_cu = 1;
+    SEGK_CHECK_HIP(segk_dyn_lds((const void *)k_kmeans_score<GMAX, NB, WAVES, 1>, lds));
+    SEGK_CHECK_HIP(segk_occupancy((const void *)k_kmeans_score<GMAX, NB, WAVES, 0>, 64 * WAVES, lds, &wg_per_cu));
     const int64_t slots = (int64_t)wg_per_cu * ctx->n_cu;
     const int64_t chunks = (A.n + rows_per_wg - 1) / rows_per_wg;
     int64_t main_chunks = (chunks / slots) * slots, tail_chunks = chunks - main_chunks;
@@ -423,12 +413,7 @@ template <int GMAX>
 static int launch_score_lse(segk_ctx *ctx, const ScoreArgs &A, hipStream_t st)
 {
     const size_t lds = 2 * (size_t)A.tile_stride * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set && lds > 48 * 1024) {
-        SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_kmeans_score<GMAX, 1, 4, 0, 1>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    SEGK_CHECK_HIP(segk_dyn_lds((const void *)k_kmeans_score<GMAX, 1, 4, 0, 1>, lds));
     const int64_t chunks = (A.n + 127) / 128;
     const bool prof = ctx && segk_prof_now(ctx);
     const int slot = prof ? ctx->prof_n % SEGK_PROF_SLOTS : 0;

@@ -300,15 +300,8 @@ static int launch_score_sp(segk_ctx *ctx, ScoreArgs A, hipStream_t st)
 {
     constexpr int STRIDE = (KS * P * 256 + 32 + 1023) / 1024 * 1024;
     const size_t lds = 2 * (size_t)STRIDE * sizeof(float);
-    static int wg_per_cu = 0;
-    if (!wg_per_cu) {
-        if (lds > 48 * 1024)
-            SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_kmeans_score_sp<KS, 4, P>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        int occ = 0;
-        SEGK_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)k_kmeans_score_sp<KS, 4, P>, 256, lds));
-        wg_per_cu = occ > 0 ? occ : 1;
-    }
+    int wg_per_cu = 1;
+    SEGK_CHECK_HIP(segk_occupancy((const void *)k_kmeans_score_sp<KS, 4, P>, 256, lds, &wg_per_cu));
     const int64_t slots = (int64_t)wg_per_cu * ctx->n_cu;
     const int64_t chunks = (A.n + 127) / 128;
     int64_t main_chunks = (chunks / slots) * slots;
@@ -365,12 +358,7 @@ static int launch_score_lse_sp(segk_ctx *ctx, const ScoreArgs &A, hipStream_t st
 {
     constexpr int STRIDE = (KS * 2 * 256 + 32 + 1023) / 1024 * 1024;
     const size_t lds = 2 * (size_t)STRIDE * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set && lds > 48 * 1024) {
-        SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_kmeans_score_sp<KS, 4, 2, 1>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    SEGK_CHECK_HIP(segk_dyn_lds((const void *)k_kmeans_score_sp<KS, 4, 2, 1>, lds));
     const int64_t chunks = (A.n + 127) / 128;
     const bool prof = ctx && segk_prof_now(ctx);
     const int slot = prof ? ctx->prof_n % SEGK_PROF_SLOTS : 0;
@@ -391,12 +379,7 @@ static int launch_score_mat_sp(const ScoreArgs &A, hipStream_t st)
 {
     constexpr int STRIDE = (KS * 2 * 256 + 32 + 1023) / 1024 * 1024;
     const size_t lds = 2 * (size_t)STRIDE * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set && lds > 48 * 1024) {
-        SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_kmeans_score_sp<KS, 4, 2, 2>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    SEGK_CHECK_HIP(segk_dyn_lds((const void *)k_kmeans_score_sp<KS, 4, 2, 2>, lds));
     // few rows (the new tokens of one Gibbs block: ~10 k): the tiles of a row block over several workgroups -- every
     // workgroup writes its own columns of the matrix, nothing to merge (78 workgroups walking 32 tiles each: 54 us)
     const int64_t blocks = (A.n + 127) / 128;
@@ -404,12 +387,7 @@ static int launch_score_mat_sp(const ScoreArgs &A, hipStream_t st)
     if (n_split > 8) n_split = 8;
     if (n_split > A.n_tiles) n_split = A.n_tiles;
     if (n_split >= 2) {
-        static bool attr_set2 = false;
-        if (!attr_set2 && lds > 48 * 1024) {
-            SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_kmeans_score_sp<KS, 4, 2, 2, 1>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_set2 = true;
-        }
+        SEGK_CHECK_HIP(segk_dyn_lds((const void *)k_kmeans_score_sp<KS, 4, 2, 2, 1>, lds));
         ScoreArgs S = A;
         S.tiles_per_split = (A.n_tiles + n_split - 1) / n_split;
         S.n_chunks = (A.n_tiles + S.tiles_per_split - 1) / S.tiles_per_split;
@@ -483,14 +461,8 @@ static int launch_sp_second(segk_ctx *ctx, const ScoreArgs &B, hipStream_t st)
 {
     constexpr int STRIDE = (KS * 2 * 256 + 32 + 1023) / 1024 * 1024;
     const size_t lds2 = 2 * (size_t)STRIDE * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set && lds2 > 48 * 1024) {
-        SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_kmeans_score_sp<KS, 4, 2>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-        SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_kmeans_score_sp<KS, 4, 2, 0, 1>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-        attr_set = true;
-    }
+    SEGK_CHECK_HIP(segk_dyn_lds((const void *)k_kmeans_score_sp<KS, 4, 2>, lds2));
+    SEGK_CHECK_HIP(segk_dyn_lds((const void *)k_kmeans_score_sp<KS, 4, 2, 0, 1>, lds2));
     // ranges of component tiles per row block (1: the plain kernel), by the size of the launch: a workgroup walks the 32 tiles
     // of its row block in ~55 us however few blocks there are, so that short queues (a multi-GPU shard) gain from the split
     // although the stage is matrix-bound on the whole corpus (1.05 M rows: 1 588 unsplit against 1 500 split); two workgroups

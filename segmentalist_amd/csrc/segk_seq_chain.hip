@@ -521,11 +521,7 @@ int segk_launch_seq_chain(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m, c
     const size_t lds = al((size_t)cpw * D * 8) + al(NM * 8 * 8) + al((NM + 12) * 8) + al((size_t)cpw * 8) + al(CH_MAXOPS * 8) +
                        al((size_t)cpw * ldm * 4) + al((size_t)nbc * 4) + 2 * al(NM * 4) + al(8 * 4) + 2 * al(CH_MAXOPS * 4) + 2 * set_bytes;
     if (lds > 158 * 1024) return SEGK_ERR_UNSUPPORTED;
-    static size_t lds_set = 0;
-    if (lds > 48 * 1024 && lds > lds_set) {
-        SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_seq_chain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        lds_set = lds;
-    }
+    SEGK_CHECK_HIP(segk_dyn_lds((const void *)k_seq_chain, lds));
     // all workgroups must be resident together: one per CU at most
     if (G > ctx->n_cu || (int64_t)G * (n_order + 1) >= CH_STOP_BIT) return SEGK_ERR_UNSUPPORTED;
 

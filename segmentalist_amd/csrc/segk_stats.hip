@@ -1617,11 +1617,7 @@ int segk_launch_batch_sort(const segk_corpus *c, const segk_kmeans *m, const int
     const int nw = m->K_max <= 1024 ? 16 : m->K_max <= 2048 ? 8 : m->K_max <= 4096 ? 4 : 2;
     size_t lds = (size_t)(m->K_max + 2) * 4 + (size_t)nw * m->K_max * 4 + (size_t)SORT_KEYS_LDS * 2;
     if (lds < 2048 * sizeof(double)) lds = 2048 * sizeof(double);
-    static size_t lds_set = 0;
-    if (lds > 48 * 1024 && lds > lds_set) {
-        SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_batch_sort, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        lds_set = lds;
-    }
+    SEGK_CHECK_HIP(segk_dyn_lds((const void *)k_batch_sort, lds));
     segk_tstamp_bind();
     // out_total == NULL: the sort alone (no flag lists, no totals: the second half of the grid is not launched)
     hipLaunchKernelGGL(k_batch_sort, dim3((unsigned)((out_total ? 2 : 1) * n_blocks)), dim3(SORT_THREADS), lds, st, *c, *m, blk_lo,
@@ -1655,11 +1651,7 @@ int segk_launch_update_utt(const segk_corpus *c, segk_kmeans *m, int utt, const 
         const size_t lds = (size_t)2 * c->N_max * c->D * (8 + 2 * esz);
         if (lds <= 150 * 1024) {
             DISPATCH_XT(c, {
-                static size_t lds_set = 0;
-                if (lds > 48 * 1024 && lds > lds_set) {
-                    SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_seq_update<XT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                    lds_set = lds;
-                }
+                SEGK_CHECK_HIP(segk_dyn_lds((const void *)k_seq_update<XT>, lds));
                 hipLaunchKernelGGL(k_seq_update<XT>, dim3(1), dim3(256), lds, st, *c, *m, utt, old_tok, new_tok, new_k, n_old, n_new, status);
             });
             SEGK_LAUNCH_CHECK();
