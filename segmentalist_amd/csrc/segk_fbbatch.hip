@@ -21,9 +21,11 @@
 // fixed-variance score -- left for a later round.
 #include <stdlib.h>
 
+#include <type_traits>
 #include "segk_fb_common.h"
 
 #define FBB_R 8            // rows per workgroup of the score kernel
+#define FBA_R 16           // token rows of the assignment kernel's LDS image (chunks of 16 tokens with four row groups, else <= FBB_R)
 #define FBB_MAXCH 4        // dimension chunks of 64 lanes held in registers (D <= 256)
 
 static __device__ __forceinline__ int64_t fbb_rec(const segk_fbgmm &f, int D) { return (int64_t)f.K_max * (2 * D + 1); }
@@ -807,9 +809,9 @@ __global__ __launch_bounds__(512) void k_fbb_assign(segk_corpus c, segk_fbgmm f,
     const int D = c.D, KM = f.K_max, tid = threadIdx.x, nt = blockDim.x;
     double *z = (double *)smem;                  // [K_max]
     double *ll = z + KM;                         // [rcap][K_max]
-    double *xs = ll + (int64_t)rcap * KM;        // [FBB_R][D]
-    double *lpr = xs + FBB_R * D;                // [FBB_R]
-    double *red = lpr + FBB_R;                   // [16]
+    double *xs = ll + (int64_t)rcap * KM;        // [FBA_R][D]
+    double *lpr = xs + FBA_R * D;                // [FBA_R]
+    double *red = lpr + FBA_R;                   // [16]
     __shared__ int sh_k;
     int s, idx;
     if (!fbb_locate(map, blockIdx.x, &s, &idx)) return;
@@ -836,7 +838,7 @@ __global__ __launch_bounds__(512) void k_fbb_assign(segk_corpus c, segk_fbgmm f,
                                                                : (double)mrow[KM] * LN2 - zc_empty - log(n_empty) + norm;
             }
         } else {
-        for (int j = tid; j < FBB_R * D; j += nt) {
+        for (int j = tid; j < (rcap > FBB_R ? rcap : FBB_R) * D; j += nt) {
             const int r = j / D, d = j - r * D;
             xs[j] = r < nr ? (double)X[(int64_t)new_tok[(int64_t)utt * c.N_max + t0 + r] * c.ldx + d] : 0.0;
         }
@@ -851,26 +853,38 @@ __global__ __launch_bounds__(512) void k_fbb_assign(segk_corpus c, segk_fbgmm f,
         __syncthreads();
         if (nt >= 4 * 128 && KM <= 128) {
             // few slots: four groups of threads take two rows each (the per-(row, slot) arithmetic is unchanged; with one
-            // thread per slot 100 of 256 threads each walked D x 8 software logarithms)
-            const int k = tid & 127, r0 = 2 * (tid >> 7);
-            if (k < KM && r0 < nr) {
-                if (bt.cnt[k] > 0.0) {
-                    double acc[2] = {0.0, 0.0};
-                    if (F32) {
-                        float a32[2] = {0.f, 0.f};
-                        fbb_accumulate_rows32<2>(bt, KM, k, (dbg & 1) ? 1 : D, xs + r0 * D, a32);
-                        acc[0] = 0.6931471805599453 * (double)a32[0];
-                        acc[1] = 0.6931471805599453 * (double)a32[1];
-                    } else
-                    fbb_accumulate_rows<COV, 2>(bt, KM, k, (dbg & 1) ? 1 : D, xs + r0 * D, acc);
-                    const double lc = bt.lconst[k], h = bt.half[k];
-                    ll[(int64_t)r0 * KM + k] = lc - h * acc[0];
-                    if (r0 + 1 < nr) ll[(int64_t)(r0 + 1) * KM + k] = lc - h * acc[1];
-                } else {
-                    ll[(int64_t)r0 * KM + k] = lpr[r0];
-                    if (r0 + 1 < nr) ll[(int64_t)(r0 + 1) * KM + k] = lpr[r0 + 1];
+            // thread per slot 100 of 256 threads each walked D x 8 software logarithms) -- four rows each when the chunk
+            // holds sixteen tokens (an utterance with nine tokens paid the whole chunk twice)
+            auto rows_of_group = [&](auto NRC) {
+                constexpr int NR = decltype(NRC)::value;
+                const int k = tid & 127, r0 = NR * (tid >> 7);
+                if (k < KM && r0 < nr) {
+                    if (bt.cnt[k] > 0.0) {
+                        double acc[NR];
+#pragma unroll
+                        for (int r = 0; r < NR; r++) acc[r] = 0.0;
+                        if (F32) {
+                            float a32[NR];
+#pragma unroll
+                            for (int r = 0; r < NR; r++) a32[r] = 0.f;
+                            fbb_accumulate_rows32<NR>(bt, KM, k, (dbg & 1) ? 1 : D, xs + r0 * D, a32);
+#pragma unroll
+                            for (int r = 0; r < NR; r++) acc[r] = 0.6931471805599453 * (double)a32[r];
+                        } else
+                        fbb_accumulate_rows<COV, NR>(bt, KM, k, (dbg & 1) ? 1 : D, xs + r0 * D, acc);
+                        const double lc = bt.lconst[k], h = bt.half[k];
+#pragma unroll
+                        for (int r = 0; r < NR; r++)
+                            if (r0 + r < nr) ll[(int64_t)(r0 + r) * KM + k] = lc - h * acc[r];
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < NR; r++)
+                            if (r0 + r < nr) ll[(int64_t)(r0 + r) * KM + k] = lpr[r0 + r];
+                    }
                 }
-            }
+            };
+            if (rcap > FBB_R) rows_of_group(std::integral_constant<int, 4>());
+            else rows_of_group(std::integral_constant<int, 2>());
         } else
         for (int k = tid; k < KM; k += nt) {
             if (bt.cnt[k] > 0.0) {
@@ -1730,13 +1744,14 @@ static int32_t fbb_assign_impl(segk_ctx *ctx, const segk_corpus *c, const segk_f
     const int dbg = dbg_s ? atoi(dbg_s) : 0;
     // tokens per chunk: as many likelihood rows as fit beside the logits (two workgroups per CU)
     int rcap = FBB_R;
-    const size_t fixed_b = (size_t)(f->K_max + FBB_R * c->D + FBB_R + 16) * sizeof(double);
+    const size_t fixed_b = (size_t)(f->K_max + FBA_R * c->D + FBA_R + 16) * sizeof(double);
     while (rcap > 1 && fixed_b + (size_t)rcap * f->K_max * sizeof(double) > 80 * 1024) rcap >>= 1;
+    // 512 threads where the slots alone would leave most of 256 idle and the tokens' draws are independent (no language
+    // model): four row groups in the likelihood phase, a wave per token in the draw phase -- and chunks of sixteen tokens
+    const int nt_assign = (f->K_max <= 128 && !f->lm_unigram && rcap == FBB_R) ? 512 : 256;
+    if (nt_assign == 512 && fixed_b + (size_t)FBA_R * f->K_max * sizeof(double) <= 80 * 1024) rcap = FBA_R;
     const size_t lds = fixed_b + (size_t)rcap * f->K_max * sizeof(double);
     SEGK_REQUIRE(lds <= 160 * 1024, "K_max too large for the LDS logits buffer");
-    // 512 threads where the slots alone would leave most of 256 idle and the tokens' draws are independent (no language
-    // model): four row groups in the likelihood phase, a wave per token in the draw phase
-    const int nt_assign = (f->K_max <= 128 && !f->lm_unigram && rcap == FBB_R) ? 512 : 256;
     // language model + matrix-core likelihoods: one wave per utterance (SEGK_FBB_ASSIGN_WAVE=0: the block-wide form)
     const char *awe = getenv("SEGK_FBB_ASSIGN_WAVE");
     if (f->lm_unigram && ll_mat && dbg == 0 && !(awe && atoi(awe) == 0) && 4 * (size_t)f->K_max * sizeof(double) <= 150 * 1024) {
