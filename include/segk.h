@@ -46,8 +46,9 @@ const char *segk_last_error(void);
  * header describes; a binding must refuse a library that reports another one: segmentalist_amd/_abi.py does).
  *   1 rounds 1-2 | 2 round 2: segk_corpus gained band_W / band_ids / band_dur (the bump was forgotten then)
  *   3 round 3: segk_fbb_set_probe, segk_kmeans_score_hinted; this check
- *   4 round 3: scratch sizes of segk_kmeans_batch_partials from segk_kmeans_batch_scratch_words; segk_profile_enable(N)          */
-#define SEGK_ABI_VERSION 4
+ *   4 round 3: scratch sizes of segk_kmeans_batch_partials from segk_kmeans_batch_scratch_words; segk_profile_enable(N)
+ *   5 round 3: segk_fbatch.prior_rows, segk_fbb_prior_rows                                                                      */
+#define SEGK_ABI_VERSION 5
 int32_t segk_abi_version(void);
 
 /* Timing of the MAIN launch of the MFMA score kernel (k_kmeans_score<..., 0>) with HIP events
@@ -531,6 +532,10 @@ typedef struct {
     float *tiles16;               /* [dev] segk_kmeans_tiles_b3_floats(K_max + 1, 2D) floats        */
     float *rows32;                /* [dev] [(K_max + 1), 2D] scratch: the per-slot rows in float32   */
     double *consts16;             /* [dev] [K_max + 2] scratch: per-slot constants; [K_max + 1] = max |row|^2 */
+    /* optional: the prior predictive of every embedding row (an empty slot's likelihood) -- a constant of corpus and prior, so
+     * the score and assignment kernels of every Gibbs step need not evaluate its D logarithms per row again
+     * (segk_fbb_prior_rows once; NULL: evaluated in the kernels; the values are the same either way)                           */
+    const double *prior_rows;     /* [dev] [n_emb] or NULL                                         */
 } segk_fbatch;
 
 /* token lists of all utterances from the boundaries: new_tok [n_utt, N_max], n_new [n_utt]     */
@@ -559,6 +564,10 @@ int32_t segk_fbb_score(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *f,
  * = their number); log-sum-exp accumulated online in the MFMA kernel's epilogue.  Needs bt->y
  * (segk_fbb_make_y once) and bt->tiles32 (filled by segk_fbb_prepare).                            */
 int32_t segk_fbb_make_y(segk_ctx *ctx, const segk_corpus *c, const segk_fbatch *bt, void *stream);
+/* out[row] = log prior predictive of X[row] (gaussian_components_fixedvar.py:224-231 / gaussian_components_diag.py:215-222), the
+ * value the score / assignment kernels use for an empty slot: for segk_fbatch.prior_rows.  Valid while X and the prior of `f`
+ * stay what they are.                                                                                                          */
+int32_t segk_fbb_prior_rows(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *f, double *out, void *stream);
 int32_t segk_fbb_score_f32(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *f,
                            const segk_fbatch *bt, const int32_t *rows, int64_t n, double *score,
                            void *stream);   /* rows [dev] [n]: the embedding rows to score (a block) */

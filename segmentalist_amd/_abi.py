@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SEGK_LIB_PATH") or os.path.join(_HERE, "libsegk.so")      # (SEGK_LIB_PATH: a development build kept beside the product build)
 
 SEGK_F32, SEGK_F64 = 0, 1
-ABI_VERSION = 4          # SEGK_ABI_VERSION of include/segk.h this binding was written against
+ABI_VERSION = 5          # SEGK_ABI_VERSION of include/segk.h this binding was written against
 
 
 class SegkError(RuntimeError):
@@ -46,6 +46,7 @@ class FbatchDev(C.Structure):
         ("half", C.c_void_p), ("scal", C.c_void_p), ("slot", C.c_void_p), ("lm_tok", C.c_void_p),
         ("seed", C.c_uint64), ("y", C.c_void_p), ("ldy", C.c_int64), ("tiles32", C.c_void_p),
         ("y16", C.c_void_p), ("tiles16", C.c_void_p), ("rows32", C.c_void_p), ("consts16", C.c_void_p),
+        ("prior_rows", C.c_void_p),
     ]
 
 
@@ -124,6 +125,7 @@ SIGNATURES = {
     "segk_fbb_score_diag32": (_i32, [_P, _CP, _FP, _BP, _i32, _i32, _i32, _P, _P, _P]),
     "segk_calibrate_vlog": (_i32, [_P, C.POINTER(_f64), _P]),
     "segk_fbb_make_y": (_i32, [_P, _CP, _BP, _P]),
+    "segk_fbb_prior_rows": (_i32, [_P, _CP, _FP, _P, _P]),
     "segk_fbb_score_f32": (_i32, [_P, _CP, _FP, _BP, _P, _i64, _P, _P]),
     "segk_fbb_segment": (_i32, [_P, _CP, _FP, _BP, _i32, _i32, _i32, _P, _u64, _i32, _i32, _f64, _f64, _f64, _P, _P,
                                 _P, _P, _P, _P, _P]),

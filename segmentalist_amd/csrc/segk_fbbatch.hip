@@ -505,7 +505,47 @@ static __device__ double fbb_prior_row(const segk_fbgmm &f, int D, const double 
     return f.cov_type == 0 ? f.kconst[f.K_max] - 0.5 * s : f.kconst[f.K_max] - (f.v_0 + 1.) / 2. * s;
 }
 
+// the same for a row in memory in the dtype of X (k_fbb_prior_rows, D > 256)
+template <typename XT>
+static __device__ double fbb_prior_row_mem(const segk_fbgmm &f, int D, const XT *x, int lane)
+{
+    double s = 0.0;
+    for (int d = lane; d < D; d += 64) {
+        const double delta = (double)x[d] - f.prior_b[d];
+        if (f.cov_type == 0) s += delta * delta * f.prior_c[d];
+        else {
+            const double var = (f.k_0 + 1.) / (f.k_0 * f.v_0) * f.prior_a[d];
+            s += log(1. + 1. / f.v_0 * (delta * delta) * (1. / var));
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    return f.cov_type == 0 ? f.kconst[f.K_max] - 0.5 * s : f.kconst[f.K_max] - (f.v_0 + 1.) / 2. * s;
+}
+
 // ---------------------------------------------------------------------------------------
+// the prior predictive of every embedding row, one wave per row (segk_fbb_prior_rows): the value the kernels below compute
+// for themselves when segk_fbatch.prior_rows is NULL -- same function, same lanes, same order
+template <typename XT>
+__global__ __launch_bounds__(256) void k_fbb_prior_rows(segk_corpus c, segk_fbgmm f, double *out)
+{
+    __shared__ double xs[4][256];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, D = c.D;
+    const int64_t row = (int64_t)blockIdx.x * 4 + w;
+    if (row >= c.n_emb) return;
+    const XT *X = (const XT *)c.X;
+    // (rows of more than 256 dimensions: straight from memory -- fbb_prior_row reads x[d] for d = lane, lane + 64, ...)
+    double v;
+    if (D <= 256) {
+        for (int d = lane; d < D; d += 64) xs[w][d] = (double)X[row * c.ldx + d];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        v = fbb_prior_row<XT>(f, D, xs[w], lane);
+    } else {
+        v = fbb_prior_row_mem<XT>(f, D, X + row * c.ldx, lane);
+    }
+    if (lane == 0) out[row] = v;
+}
+
 // score of FBB_R rows against all slots per workgroup; online logsumexp per row and thread,
 // merged across the workgroup at the end.
 // ---------------------------------------------------------------------------------------
@@ -533,7 +573,7 @@ __global__ __launch_bounds__(256) void k_fbb_score(segk_corpus c, segk_fbgmm f, 
     {
         const int w = tid >> 6, lane = tid & 63, nw = nt >> 6;
         for (int r = w; r < FBB_R; r += nw) {
-            const double v = fbb_prior_row<XT>(f, D, xs + r * D, lane);
+            const double v = (bt.prior_rows && r < nr) ? bt.prior_rows[row0 + r] : fbb_prior_row<XT>(f, D, xs + r * D, lane);
             if (lane == 0) lpr[r] = v;
         }
     }
@@ -621,7 +661,12 @@ __global__ __launch_bounds__(256) void k_fbb_score_diag32(segk_corpus c, segk_fb
             tm[j] = (float)bt.mean_t[j];
             tq[j] = (float)bt.q_t[j];
         }
-    // the prior predictive of every row (an empty slot's likelihood): fp64 as in the fp64 kernel, once per row
+    // the prior predictive of every row (an empty slot's likelihood): fp64 as in the fp64 kernel, once per row -- from
+    // segk_fbb_prior_rows' table when the caller keeps one (the values are constants of the corpus: 16 x D software
+    // logarithms and four barriers per workgroup and Gibbs step otherwise)
+    if (bt.prior_rows) {
+        for (int r = tid; r < FBB_R32; r += nt) lpr[r] = r < nr ? bt.prior_rows[row0 + r] : 0.0;
+    } else
     for (int r8 = 0; r8 < FBB_R32; r8 += 8) {
         __syncthreads();
         for (int j = tid; j < 8 * D; j += nt) {
@@ -846,7 +891,8 @@ __global__ __launch_bounds__(512) void k_fbb_assign(segk_corpus c, segk_fbgmm f,
         {
             const int w = tid >> 6, lane = tid & 63, nw = nt >> 6;
             for (int r = w; r < nr; r += nw) {
-                const double v = fbb_prior_row<XT>(f, D, xs + r * D, lane);
+                const double v = bt.prior_rows ? bt.prior_rows[new_tok[(int64_t)utt * c.N_max + t0 + r]]
+                                               : fbb_prior_row<XT>(f, D, xs + r * D, lane);
                 if (lane == 0) lpr[r] = v;
             }
         }
@@ -1562,6 +1608,18 @@ int32_t segk_fbb_prepare(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *
     }
     if (bt->tiles32 && f->cov_type == 0)
         hipLaunchKernelGGL(k_fbb_tiles32, dim3(segk_n_tiles(f->K_max + 1)), dim3(256), 0, st, *f, *bt, c->D, alpha);
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+int32_t segk_fbb_prior_rows(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *f, double *out, void *stream)
+{
+    (void)ctx;
+    SEGK_REQUIRE(c && f && out, "null argument");
+    SEGK_REQUIRE(c->x_dtype == SEGK_F32 || c->x_dtype == SEGK_F64, "unsupported dtype");
+    if (c->n_emb == 0) return SEGK_OK;
+    const unsigned grid = (unsigned)((c->n_emb + 3) / 4);
+    DISPATCH_XT(c, { hipLaunchKernelGGL(k_fbb_prior_rows<XT>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *c, *f, out); });
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;
 }

@@ -843,7 +843,12 @@ class FbgmmBatchSweeper(object):
             self.tiles16 = torch.zeros(int(L.segk_kmeans_tiles_b3_floats(K + 1, 2 * D)), dtype=torch.float32, device=dev)
             self.rows32 = torch.zeros((K + 1, 2 * D), dtype=torch.float32, device=dev)
             self.consts16 = torch.zeros(K + 2, dtype=f64, device=dev)
+        # the prior predictive of every row (an empty slot's likelihood): a constant of corpus and prior, evaluated once
+        # instead of in the score and assignment kernels of every Gibbs step (same values)
+        self.prior_rows = torch.zeros(c.n_emb, dtype=f64, device=dev)
+        check(df._L.segk_fbb_prior_rows(df._ctx, df._cp(), C.byref(self.f), self.prior_rows.data_ptr(), _abi.stream()))
         self.bt = _abi.FbatchDev(
+            prior_rows=self.prior_rows.data_ptr(),
             y16=self.y16.data_ptr() if self.y16 is not None else None,
             tiles16=self.tiles16.data_ptr() if self.tiles16 is not None else None,
             rows32=self.rows32.data_ptr() if self.rows32 is not None else None,
