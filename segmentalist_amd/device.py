@@ -341,9 +341,9 @@ class DeviceKMeans(object):
         self.ensure_state()
         if getattr(self, "_seq_keys", None) is None:
             self._seq_keys = torch.zeros(self.corpus.tri + 2, dtype=torch.int64, device=self.means.device)
-        arr = (C.c_int32 * len(order))(*[int(i) for i in order])
+        arr = np.ascontiguousarray(order, dtype=np.int32)       # (a ctypes array built element by element: 2 ms of a 135 ms sweep)
         check(self._L.segk_kmeans_sequential_sweep(
-            self._ctx, self._cp(), C.byref(self.m), arr, len(order), int(n_slices_min), int(n_slices_max), float(wip),
+            self._ctx, self._cp(), C.byref(self.m), arr.ctypes.data, len(order), int(n_slices_min), int(n_slices_max), float(wip),
             C.byref(self.cand), ptr(self._seq_keys), ptr(boundaries), ptr(self.old_tok), ptr(self.new_tok), ptr(self.new_k),
             ptr(self.n_old), ptr(self.n_new), ptr(self.n_flag), ptr(self.out_total), ptr(self.status), _abi.stream()))
         return True

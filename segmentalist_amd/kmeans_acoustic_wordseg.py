@@ -182,9 +182,9 @@ class SegmentalKMeansWordseg(object):
                 torch.cuda.synchronize()
                 self._dk.check_status()
                 totals = self._dk.out_total.cpu().numpy()
-                sum_neg_len_sqrd_norm = 0
-                for i_utt in utt_order:                  # same summation order as the reference
-                    sum_neg_len_sqrd_norm += totals[i_utt]
+                # the reference's `sum += ...` over the utterances in visiting order: a running sum is that sequence of
+                # additions (np.cumsum accumulates left to right; the Python loop over 10 000 numpy scalars took 2 ms)
+                sum_neg_len_sqrd_norm = np.cumsum(totals[np.asarray(utt_order, dtype=np.int64)])[-1] if len(utt_order) else 0
             else:
                 self.batch_sweep_async()
                 pt = self._get_sweeper().part
