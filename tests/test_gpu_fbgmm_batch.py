@@ -93,6 +93,27 @@ def test_batch_sweeps_match_specification(gpu, kind, n_utt, D, K, cseed, nmax, B
         assert np.array_equal(c.counts[:Kc], cnt[cnt > 0])
 
 
+@pytest.mark.parametrize("kind", ["fixed", "diag"])
+def test_batch_sweeps_without_the_prior_row_table(gpu, kind):
+    """segk_fbatch.prior_rows = NULL: the score and assignment kernels evaluate the rows' prior predictive themselves (the
+    table of segk_fbb_prior_rows is the default and is what the tests above run) -- the same chain, and the table holds the
+    values the kernels would compute."""
+    ref, spec, seg = _pair(kind, 24, 8, 30, 91, 5, 3, 4)          # K_max > the number of tokens' components: empty slots
+    sweeper = seg._get_sweeper()
+    assert sweeper.bt.prior_rows, "the sweeper keeps the table by default"
+    table = sweeper.prior_rows.cpu().numpy()
+    want = np.array([ref.acoustic_model.components.log_prior(i) for i in range(len(table))])
+    npt.assert_allclose(table, want, rtol=1e-12)
+    sweeper.bt.prior_rows = None
+    for sw in range(2):
+        spec.sweep(sw)
+        seg.batch_sweep_async()
+        gpu.cuda.synchronize()
+        seg._df.check_status()
+        assert np.array_equal(seg.utterances.boundaries, ref.utterances.boundaries), sw
+        assert np.array_equal(sweeper.slot.cpu().numpy(), spec.slot), sw
+
+
 def test_batch_statistics_and_scores_match_specification(gpu):
     """The prepared statistics and the span scores of one step, value by value."""
     ref, spec, seg = _pair("diag", 24, 8, 10, 78, 5, 3, 4)
