@@ -67,6 +67,7 @@ CASES = [
     ("fixed", 40, 12, 30, 79, 6, 4, 8, dict(lms=0.7, wip=-0.2, time_power_term=1.2)),
     ("diag", 33, 70, 12, 80, 4, 2, 2, {}),          # D > 64: two dimension chunks
     ("fixed", 19, 6, 300, 81, 5, 5, 1, {}),         # K_max > workgroup width
+    ("diag", 130, 8, 10, 82, 5, 9, 12, {}),         # more than eight blocks and more than eight slices: k_fbb_prepare's second load rounds
 ]
 
 
