@@ -242,6 +242,20 @@ static __device__ __forceinline__ double fb_row16_max(double v)
     return v;
 }
 
+// maximum over all 64 lanes, wave-uniform: the rows' maxima by DPP, the four rows' by v_readlane (one row when `one_row`)
+static __device__ __forceinline__ double fb_wave_max(double v, bool one_row)
+{
+    v = fb_row16_max(v);
+    double m = fb_readlane(v, 0);
+    if (!one_row) {
+        const double m1 = fb_readlane(v, 16), m2 = fb_readlane(v, 32), m3 = fb_readlane(v, 48);
+        m = m1 > m ? m1 : m;
+        const double m23 = m3 > m2 ? m3 : m2;
+        m = m23 > m ? m23 : m;
+    }
+    return m;
+}
+
 // A6 / A7 by one full wave (unigram_acoustic_wordseg.py:653-864): forward filtering, then backward
 // sampling (or Viterbi back-tracking) writing the boundaries; returns the summed score of the chosen
 // segments.  Control flow and values are wave-uniform; the exponentials of each logsumexp /
@@ -257,11 +271,13 @@ static __device__ double fb_dp_sample(const double *vec, double *a, double *w, d
     a[0] = 0.0;
     __builtin_amdgcn_wave_barrier();
     int i = 0;
-    // A window of at most sixteen slices (the models' n_slices_max): lane w holds candidate s = t - 1 - w and alpha[s] in a
-    // register -- a delay line shifted by one lane per step, the new alpha entering at lane 0 --, the maximum by DPP inside the
-    // row; the exponentials one per lane and their sum in the order of s, as below.  Same values: maxima do not depend on the
-    // order, everything else is the same operation on the same operands.
-    const bool lanes16 = n_max > 0 && n_max <= 16;
+    // A window of at most 64 slices (n_slices_max, or the whole utterance when it is unbounded and N <= 64): lane w holds
+    // candidate s = t - 1 - w and alpha[s] in a register -- a delay line shifted by one lane per step (DPP wave_shr:1), the
+    // new alpha entering at lane 0 --, the maximum by DPP inside the rows (and v_readlane across them when the window is
+    // wider than sixteen); the exponentials one per lane and their sum in the order of s, as below.  Same values: maxima do
+    // not depend on the order, everything else is the same operation on the same operands.
+    const bool lanes16 = (n_max > 0 && n_max <= 64) || (n_max == 0 && N <= 64);
+    const bool one_row = n_max > 0 && n_max <= 16;
     double g = 0.0;                                                  // alpha[t - 1 - lane]; alpha[0] = 0
     for (int t = 1; t < N; t++) {
         int lo = (n_max == 0 || t - n_max < 0) ? 0 : t - n_max;
@@ -270,17 +286,16 @@ static __device__ double fb_dp_sample(const double *vec, double *a, double *w, d
         if (lanes16) {
             const double v = lane < n ? vec[i + t - 1 - lane] + g : NEG_INF_D;
             const bool all_inf = __ballot(lane < n && v != NEG_INF_D) == 0ull;
-            const double mx = fb_row16_max(lane < 16 ? v : NEG_INF_D);
-            if (viterbi) at = fb_readlane(mx, 0);
+            const double m0 = fb_wave_max(v, one_row);
+            if (viterbi) at = m0;
             else if (all_inf) at = NEG_INF_D;
             else {
-                const double m0 = fb_readlane(mx, 0);
                 const double ej = lane < n ? (fast ? fb_exp_fast(v - m0) : exp(v - m0)) : 0.0;
                 double sm = 0.0;
                 for (int q = n - 1; q >= 0; q--) sm += fb_readlane(ej, q);       // s = lo .. t - 1
                 at = (fast ? fb_log_fast(sm) : log(sm)) + m0 + log_p_continue;
             }
-            const double gs = fb_dpp_f64<0x111>(g);                  // row_shr:1: lane w takes lane w - 1's
+            const double gs = fb_dpp_f64<0x138>(g);                  // wave_shr:1: lane w takes lane w - 1's
             g = lane == 0 ? at : gs;
         } else if (n <= 64) {
             // one candidate per lane: the same maximum, the same exponentials and the same left-to-right sum as
@@ -324,7 +339,7 @@ static __device__ double fb_dp_sample(const double *vec, double *a, double *w, d
         i = (t - 1) * t / 2;
         lo = (n_max == 0 || t - n_max < 0) ? 0 : t - n_max;
         bool all_inf = true;
-        double xw = NEG_INF_D;                                       // lanes16: candidate lo + lane of span end t
+        double xw = NEG_INF_D;                                       // (register path) candidate lo + lane of span end t
         if (lanes16) {
             xw = lane < t - lo ? vec[i + lo + lane] + a[lo + lane] : NEG_INF_D;
             all_inf = __ballot(lane < t - lo && xw != NEG_INF_D) == 0ull;
@@ -352,7 +367,7 @@ static __device__ double fb_dp_sample(const double *vec, double *a, double *w, d
             // the step in registers: lane j holds w[j]; maximum by DPP, the exponentials one per lane, their sum in index
             // order, the draw walking pr[j] = exp(w[n - 1 - j] - lse) -- the arithmetic of the general form below
             n = t - lo;
-            const double m0 = fb_readlane(fb_row16_max(lane < 16 ? xw : NEG_INF_D), 0);
+            const double m0 = fb_wave_max(xw, one_row);
             const double ej = lane < n ? (fast ? fb_exp_fast(xw - m0) : exp(xw - m0)) : 0.0;
             double sm = 0.0;
             for (int q = 0; q < n; q++) sm += fb_readlane(ej, q);

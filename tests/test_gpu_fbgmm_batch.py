@@ -25,12 +25,13 @@ def gpu():
     return torch
 
 
-def _pair(kind, n_utt, D, K, cseed, nmax, B, S, seed=5, dtype="float32", score_precision="f64", **kw):
-    """(oracle segmenter + batch state, product segmenter) from identical initial states."""
+def _pair(kind, n_utt, D, K, cseed, nmax, B, S, seed=5, dtype="float32", score_precision="f64", n_landmarks=0, **kw):
+    """(oracle segmenter + batch state, product segmenter) from identical initial states.  n_landmarks > 0: every utterance
+    that long (default: ragged, 3 to 9 landmarks)."""
     from segmentalist_amd import bigram_acoustic_wordseg as baw, fbgmm, unigram_acoustic_wordseg as uaw
     from segmentalist_amd.gaussian_components_fixedvar import FixedVarPrior
     from segmentalist_amd.niw import NIW
-    corpus = cases.chain_corpus(n_utt, D, K, cseed, True, 0, nmax, dtype)
+    corpus = cases.chain_corpus(n_utt, D, K, cseed, n_landmarks == 0, n_landmarks, nmax, dtype)
     args = dict(n_slices_min=0, n_slices_max=nmax, p_boundary_init=0.5, beta_sent_boundary=-1, lms=1.0, wip=0.0,
                 init_am_assignments="rand", time_power_term=1.0)
     args.update(kw)
@@ -92,6 +93,22 @@ def test_batch_sweeps_match_specification(gpu, kind, n_utt, D, K, cseed, nmax, B
         assert np.array_equal(c.assignments, a)
         cnt = spec.stats_excluding(-1)[0]
         assert np.array_equal(c.counts[:Kc], cnt[cnt > 0])
+
+
+@pytest.mark.parametrize("kind,nmax", [("fixed", 20), ("diag", 20), ("fixed", 12)])
+def test_batch_sweeps_with_a_wide_window(gpu, kind, nmax):
+    """Utterances of 24 landmarks and windows of 20 and 12 slices: the boundary sampler's register path beyond one row of
+    sixteen lanes (fb_dp_sample: delay line by wave_shr, maxima across rows) and inside it with more than eight candidates."""
+    ref, spec, seg = _pair(kind, 8, 8, 10, 93, nmax, 2, 2, n_landmarks=24)
+    assert int(np.max(seg.utterances.lengths)) == 24
+    for sw in range(2):
+        lp = spec.sweep(sw)
+        seg.batch_sweep_async()
+        gpu.cuda.synchronize()
+        seg._df.check_status()
+        assert np.array_equal(seg.utterances.boundaries, ref.utterances.boundaries), sw
+        assert np.array_equal(seg._get_sweeper().slot.cpu().numpy(), spec.slot), sw
+        npt.assert_allclose(seg._df.out_logprob.cpu().numpy(), lp, rtol=1e-9)
 
 
 @pytest.mark.parametrize("kind", ["fixed", "diag"])
