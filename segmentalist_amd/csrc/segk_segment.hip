@@ -169,7 +169,7 @@ __global__ void k_kmeans_segment(segk_corpus c, segk_kmeans m, const int32_t *ut
 // boundary flags with a branch on each); here the last eight gammas live in registers, the eight
 // candidates of a step are fetched together (predicated, fully unrolled), and the boundary vectors
 // are 64-bit masks.
-__global__ void k_kmeans_segment_w8(segk_corpus c, segk_kmeans m, const int32_t *utts, int utt0, int n_utts,
+__global__ __launch_bounds__(256) void k_kmeans_segment_w8(segk_corpus c, segk_kmeans m, const int32_t *utts, int utt0, int n_utts,
                                     int n_max, double wip, segk_cand cand, uint8_t *boundaries, int32_t *old_tok,
                                     int32_t *new_tok, int32_t *new_k, int32_t *n_old, int32_t *n_new, int32_t *n_flag,
                                     double *out_total, int32_t *status, int band_cap, int wave_bytes)
@@ -182,7 +182,6 @@ __global__ void k_kmeans_segment_w8(segk_corpus c, segk_kmeans m, const int32_t 
     const int u = utts ? utts[slot] : utt0 + slot;
     const int N = c.lengths[u];
     const int W = (n_max > 0 && n_max < N) ? n_max : N;          // <= 8 (host checks n_max <= 8)
-    const int nb = N * W;
     const int64_t triMax = (int64_t)c.N_max * (c.N_max + 1) / 2;
     const int32_t *vid = c.vec_ids + (int64_t)u * triMax;
     const double *dur = c.durations + (int64_t)u * triMax;
@@ -193,38 +192,71 @@ __global__ void k_kmeans_segment_w8(segk_corpus c, segk_kmeans m, const int32_t 
     uint8_t *gbnd = boundaries + (int64_t)u * c.N_max;
 
     char *base = smem + (size_t)wv * wave_bytes;
-    double *bvec = (double *)base;                    // [band_cap]
-    double *gam = bvec + band_cap;                    // [N_max + 1]
-    int32_t *bk = (int32_t *)(gam + c.N_max + 1);     // [band_cap]
+    double *bvec = (double *)base;                    // [N_max][8]: the DP's candidates, pitch 8, -inf beyond the window (seg_w8_uniform)
+    double *gam = bvec + c.N_max * 8;                 // [8 + N_max + 4]
+    int32_t *bk = (int32_t *)(gam + c.N_max + 12);    // [band_cap]
     int32_t *bid = bk + band_cap;                     // [band_cap]
     int32_t *l_old = bid + band_cap;                  // [N_max]
     int32_t *l_new = l_old + c.N_max;                 // [N_max]
     int32_t *l_newk = l_new + c.N_max;                // [N_max]
     int32_t *l_cnt = l_newk + c.N_max;                // [6]: n_old, n_new, new boundary mask (2 words), flagged, bad
 
-    for (int i = lane; i < nb; i += 64) {
-        const int t = i / W + 1, w = i % W, s = t - 1 - w;
-        int id = -1;
-        double v = NEG_INF_D;
-        int k = -1;
-        if (s >= 0) {
-            const int j = t * (t - 1) / 2 + s;
-            id = band ? bandi[i] : vid[j];               // banded image: lane i reads entry i
-            if (id >= 0) {
-                k = cand.k[id];
-                const double dd = band ? bandd[i] : dur[j];
-                v = isnan(dd) ? NEG_INF_D : cand.s[id] * dd;      // :346-349
+    // the band (A5, kmeans_acoustic_wordseg.py:334-351): lane (r, w) takes entry (r + 1, w), 32 span ends per batch: every span id
+    // first, then every gather -- two round trips per batch (a loop over the entries with id, label and score in turn was three
+    // per 64 entries)
+    {
+        const int w = lane & 7;
+        for (int z0 = 0; z0 < N; z0 += 32) {
+            int id[4], kq[4];
+            double dd[4], sc[4];
+#pragma unroll
+            for (int z = 0; z < 4; z++) {
+                const int r = z0 + 8 * z + (lane >> 3), t = r + 1, sp = t - 1 - w;
+                id[z] = -1;
+                dd[z] = 0.0;
+                if (r < N && w < W && sp >= 0) {
+                    const int j = t * (t - 1) / 2 + sp;
+                    id[z] = band ? bandi[r * W + w] : vid[j];
+                    dd[z] = band ? bandd[r * W + w] : dur[j];
+                }
+            }
+#pragma unroll
+            for (int z = 0; z < 4; z++) {
+                kq[z] = -1;
+                sc[z] = 0.0;
+                if (id[z] >= 0) {
+                    kq[z] = cand.k[id[z]];
+                    sc[z] = cand.s[id[z]];
+                }
+            }
+#pragma unroll
+            for (int z = 0; z < 4; z++) {
+                const int r = z0 + 8 * z + (lane >> 3);
+                if (r < N) {
+                    double v = NEG_INF_D;
+                    if (id[z] >= 0) v = isnan(dd[z]) ? NEG_INF_D : sc[z] * dd[z];      // :346-349
+                    if (w < W) {
+                        bid[r * W + w] = id[z];
+                        bk[r * W + w] = kq[z];
+                    }
+                    bvec[r * 8 + w] = v + wip;                                          // :351
+                }
             }
         }
-        bid[i] = id;
-        bk[i] = k;
-        bvec[i] = v + wip;                                       // :351
     }
     const unsigned long long oldb = __ballot(lane < N && gbnd[lane < N ? lane : 0] != 0);
     WAVE_SYNC();
     SEGK_TSTAMP(0, 1);
+    {
+        const int no_ = seg_old_tokens_wave(bid, vid, N, W, oldb, l_old, lane);
+        if (lane == 0) l_cnt[0] = no_;
+    }
     double total;
-    seg_w8_wave(bvec, gam, bid, bk, vid, N, W, oldb, *m.K, l_old, l_new, l_newk, l_cnt, &total, lane);
+    {
+        unsigned long long newb_, keep_;
+        int e_, k_, x_, f_;
+        seg_w8_uniform(bvec, gam, bid, bk, N, W, *m.K, l_new, l_newk, l_cnt, &total, lane, newb_, keep_, e_, k_, x_, f_);
+    }
     WAVE_SYNC();
     SEGK_TSTAMP(0, 2);
     if (lane == 0) {
@@ -615,6 +647,10 @@ int32_t segk_kmeans_segment(segk_ctx *ctx, const segk_corpus *c, const segk_kmea
     size_t wave_bytes = (size_t)(band_cap + c->N_max + 1) * sizeof(double)
                         + (size_t)(2 * band_cap + 3 * c->N_max + 8) * sizeof(int32_t) + (size_t)c->N_max;
     wave_bytes = (wave_bytes + 15) & ~(size_t)15;
+    // the one-utterance-per-wave kernel keeps the DP's candidates with pitch 8 and the gammas with eleven words of slack
+    size_t w8_bytes = (size_t)(c->N_max * 8 + c->N_max + 12) * sizeof(double)
+                      + (size_t)(2 * band_cap + 3 * c->N_max + 8) * sizeof(int32_t) + (size_t)c->N_max;
+    w8_bytes = (w8_bytes + 15) & ~(size_t)15;
     int waves = 4;
     while (waves > 1 && waves * wave_bytes > 64 * 1024) waves >>= 1;
     size_t lds = waves * wave_bytes;
@@ -644,9 +680,11 @@ int32_t segk_kmeans_segment(segk_ctx *ctx, const segk_corpus *c, const segk_kmea
         return SEGK_OK;
     }
     if (n_slices_max >= 1 && n_slices_max <= 8 && c->N_max <= 64 && !(getenv("SEGK_SEGMENT_GENERIC") && atoi(getenv("SEGK_SEGMENT_GENERIC")))) {
-        hipLaunchKernelGGL(k_kmeans_segment_w8, dim3((n_utts + waves - 1) / waves), dim3(64 * waves), lds, st, *c, *m, utts, utt0,
+        int w8w = 4;
+        while (w8w > 1 && w8w * w8_bytes > 64 * 1024) w8w >>= 1;
+        hipLaunchKernelGGL(k_kmeans_segment_w8, dim3((n_utts + w8w - 1) / w8w), dim3(64 * w8w), w8w * w8_bytes, st, *c, *m, utts, utt0,
                            n_utts, n_slices_max, wip, *cand, boundaries, old_tok, new_tok, new_k, n_old, n_new, n_flag,
-                           out_total, status, band_cap, (int)wave_bytes);
+                           out_total, status, band_cap, (int)w8_bytes);
         SEGK_LAUNCH_CHECK();
         return SEGK_OK;
     }
