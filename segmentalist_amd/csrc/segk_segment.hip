@@ -665,11 +665,13 @@ int32_t segk_kmeans_segment(segk_ctx *ctx, const segk_corpus *c, const segk_kmea
     const bool w8_ok = n_slices_max >= 1 && n_slices_max <= 8 && c->N_max <= 64 && !(getenv("SEGK_SEGMENT_GENERIC") && atoi(getenv("SEGK_SEGMENT_GENERIC")));
     (void)ctx;
     segk_tstamp_bind();
-    // many utterances: eight per wave (SEGK_SEGMENT_OCT=0: one per wave).  Both forms are latency chains; at 1 250 utterances
-    // the one-per-wave form is the shorter one (12 against 16 us), at 10 000 this one (21 against 30)
-    const char *oce = getenv("SEGK_SEGMENT_OCT");           // 0: never, 1: at every size (tests)
+    // eight utterances per wave: SEGK_SEGMENT_OCT=1 only.  It was the shorter form from 4 096 utterances on (21 against 30 us
+    // at 10 000) until the one-per-wave kernel got the chain's uniform DP and the batched band fetch: interleaved on one box the
+    // one-per-wave form is now ahead at every size (10 000 utterances: 1 916 / 1 923 against 1 906 / 1 906 sweeps/s; 5 000:
+    // 3 365 / 3 367 against 3 272 / 3 268)
+    const char *oce = getenv("SEGK_SEGMENT_OCT");           // 1: eight utterances per wave (tests keep it covered)
     const int oct_mode = oce ? atoi(oce) : -1;
-    if (w8_ok && oct_mode != 0 && (oct_mode == 1 || n_utts >= 4096) && 8 * wave_bytes <= 64 * 1024) {
+    if (w8_ok && oct_mode == 1 && 8 * wave_bytes <= 64 * 1024) {
         int ow = 4;
         while (ow > 1 && (size_t)ow * 8 * wave_bytes > 64 * 1024) ow >>= 1;
         const int per_block = 8 * ow;
