@@ -280,11 +280,11 @@ __global__ __launch_bounds__(256) void k_kmeans_segment_w8(segk_corpus c, segk_k
 }
 
 // EIGHT utterances per wave (round 3; launches over many utterances): lanes 8g..8g+7 run utterance g's DP -- the DPP steps of
-// seg_w8_wave act inside groups of eight lanes already, so the eight DPs advance in lockstep in one instruction stream, and a
+// round 2's eight-lane DP act inside groups of eight lanes already, so the eight DPs advance in lockstep in one instruction stream, and a
 // launch over 10 000 utterances is 1 250 waves instead of 10 000.  (One utterance per wave took 29 us: 2 500 workgroups to
 // dispatch, 14 us of life each -- gathers 5.7, DP 7.9 under that load.)  Token lists by the group's eight lanes, eight
 // boundary bits per step; the backward pass as a state machine with one candidate evaluation per trip, so that groups in
-// different phases share the loop.  Same values and decisions as seg_w8_wave.
+// different phases share the loop.  Same values and decisions as seg_w8_uniform.
 __global__ __launch_bounds__(256) void k_kmeans_segment_oct(segk_corpus c, segk_kmeans m, const int32_t *utts, int utt0, int n_utts,
                                                             int n_max, double wip, segk_cand cand, uint8_t *boundaries, int32_t *old_tok,
                                                             int32_t *new_tok, int32_t *new_k, int32_t *n_old, int32_t *n_new, int32_t *n_flag,

@@ -10,17 +10,11 @@
     } while (0)
 
 // The window-of-eight segmenter of ONE utterance by a whole wave, on wave-private LDS arrays (k_kmeans_segment_w8 and the
-// persistent sequential chain, segk_seq_chain.hip): old tokens from the old boundary mask, A8 forward and backward, the new
-// tokens and their components.  bvec / bid / bk hold the band (entry (t, w) at [(t - 1) * W + w]); results: l_old, l_new,
-// l_newk and l_cnt = {n_old, n_new, new boundary mask (2 words), tokens on inactive components, bad}.
-// A one-lane form of the same (14 us of dependent fp64 operations and LDS round trips per utterance, measured inside the
-// persistent chain) was retired in round 3.
-// ---- the same, by a whole wave --------------------------------------------------------------------------------------------
-// Lane w < 8 owns candidate w of a DP step -- one add, a three-step DPP maximum over the eight lanes, a DPP
-// shift of the gammas -- and the token lists are built by the lanes of the set boundary bits side by side (rank = prefix
-// popcount of a ballot).  Same values and the same decisions: the forward pass needs the maximum's VALUE only; the backward
-// pass takes the first maximum in w order (the reference's reversed np.argmax: the shortest span on ties).  Control flow
-// is wave-uniform.  All 64 lanes of the wave must call it.
+// persistent sequential chain, segk_seq_chain.hip): A8 forward and backward, the new tokens and their components --
+// seg_w8_uniform below.  (Round 2's form, seg_w8_wave, spread a step's eight candidates over eight lanes: one add, a three-step
+// DPP maximum, a DPP shift of the gammas -- 230 clocks per step for a lone wave, 180 per backward token; k_kmeans_segment_oct
+// still advances eight utterances that way in one wave.  A one-lane form before it: 14 us per utterance.)
+// The DPP helpers:
 template <int CTRL>
 __device__ __forceinline__ double seg_dpp_f64(double v)
 {
@@ -66,7 +60,7 @@ __device__ __forceinline__ int seg_old_tokens_wave(const int32_t *bid, const int
 //   bvec8: [N][8]   candidate (t, w) at [(t - 1) * 8 + w]; -inf beyond the window (w >= W) and before the utterance's start
 //   gamp:  [8 + N + 4]   gamp[8 + t] = gamma[t]; gamp[0..7] = -inf (written here); three more entries of slack
 // bid / bk keep the pitch W of the band.  The old tokens are not listed here (the chain's staging lists them ahead of time);
-// otherwise the values, decisions and outputs of seg_w8_wave (N <= 64): l_new, l_newk, l_cnt[1..5], and the lane of span end
+// otherwise the values, decisions and outputs of round 2's seg_w8_wave (N <= 64): l_new, l_newk, l_cnt[1..5], and the lane of span end
 // j + 1 gets its own new token back in registers.
 __device__ __forceinline__ double seg_readlane_f64(double v, int l)
 {
@@ -237,101 +231,3 @@ __device__ __forceinline__ void seg_w8_uniform(const double *bvec8, double *gamp
 #undef SEG_U_STAMP
 }
 
-__device__ __forceinline__ void seg_w8_wave(const double *bvec, double *gam, const int32_t *bid, const int32_t *bk, const int32_t *vid,
-                                            int N, int W, unsigned long long oldb, int Kact, int32_t *l_old, int32_t *l_new,
-                                            int32_t *l_newk, int32_t *l_cnt, double *total_out, int lane)
-{
-    // ---- old tokens (utterances.py:159-174)
-    {
-        const int no = seg_old_tokens_wave(bid, vid, N, W, oldb, l_old, lane);
-        if (lane == 0) l_cnt[0] = no;
-    }
-    // ---- A8 forward (kmeans_acoustic_wordseg.py:494-506): lane w holds g = gamma[t - 1 - w]
-    double g = lane == 0 ? 0.0 : NEG_INF_D;
-    if (lane == 0) gam[0] = 0.0;
-    double vn = bvec[0];                                           // step 1 has one candidate, entry (1, 0); the entries of step t + 1 are fetched during step t
-    for (int t = 1; t < N; t++) {
-        const bool ok = lane < W && t - 1 - lane >= 0;
-        const double v = vn;
-        {
-            const bool okn = lane < W && t - lane >= 0 && t + 1 < N;
-            vn = bvec[okn ? t * W + lane : 0];
-        }
-        double x = ok ? v + g : NEG_INF_D;
-        x = fmax(x, seg_dpp_f64<SEG_DPP_XOR1>(x));
-        x = fmax(x, seg_dpp_f64<SEG_DPP_XOR2>(x));
-        x = fmax(x, seg_dpp_f64<SEG_DPP_HMIRROR>(x));                // lanes 0..7 hold the maximum
-        if (lane == 0) gam[t] = x;
-        g = seg_dpp_f64<SEG_DPP_SHR1>(g);
-        if (lane == 0) g = x;
-    }
-    WAVE_SYNC();
-    unsigned long long newb = 1ull << (N - 1);
-    // candidates of span end tt: are they all -inf; and the reversed np.argmax (shortest span on ties)
-    auto eval = [&](int tt, int &kb) -> bool {
-        const bool ok = lane < W && tt - 1 - lane >= 0;
-        double x = ok ? bvec[(tt - 1) * W + lane] + gam[tt - 1 - lane] : NEG_INF_D;
-        const unsigned long long fin = __ballot(ok && x != NEG_INF_D);
-        // the maximum's value over the eight lanes, then the first lane that holds it
-        double mx = x;
-        mx = fmax(mx, seg_dpp_f64<SEG_DPP_XOR1>(mx));
-        mx = fmax(mx, seg_dpp_f64<SEG_DPP_XOR2>(mx));
-        mx = fmax(mx, seg_dpp_f64<SEG_DPP_HMIRROR>(mx));
-        const unsigned long long at = __ballot(ok && x == mx) & 0xFFull;
-        const int w = at ? __ffsll((long long)at) - 1 : 0;
-        kb = w + 1;
-        return (fin & 0xFFull) == 0ull;
-    };
-    // ---- A8 backward (:510-553)
-    int t = N;
-    double total = 0.0;
-    for (;;) {
-        int kb = 1;
-        bool all_inf = eval(t, kb);
-        if (all_inf) {                                 // step back until some candidate is finite (:516-530)
-            while (all_inf) {
-                t = t - 1;
-                if (t == 0) break;
-                all_inf = eval(t, kb);
-            }
-            newb |= 1ull << ((t - 1 + N) % N);
-        }
-        int k = 1;
-        if (t > 0) {
-            k = kb;
-            total += bvec[(t - 1) * W + (k - 1)];
-        } else {
-            total += bvec[(N - 1) * W];                // python vec[-1]: the last span [N-1, N)
-        }
-        if (t - k - 1 < 0) break;
-        newb |= 1ull << (t - k - 1);
-        t = t - k;
-    }
-    // ---- new tokens + their best components (:312-313)
-    {
-        const bool bit = lane < N && ((newb >> lane) & 1ull);
-        const unsigned long long below = newb & ((1ull << lane) - 1ull);
-        const int jp = below ? 64 - __clzll((long long)below) : 0;
-        const int w = lane - jp;
-        int id = -1, kk = -1;
-        if (bit && w < W) {
-            id = bid[lane * W + w];
-            kk = bk[lane * W + w];
-        }
-        const bool valid = bit && id >= 0;
-        const unsigned long long keep = __ballot(valid), badm = __ballot(bit && !valid), fl = __ballot(valid && kk >= Kact);
-        if (valid) {
-            const int r = __popcll(keep & ((1ull << lane) - 1ull));
-            l_new[r] = id;
-            l_newk[r] = kk;
-        }
-        if (lane == 0) {
-            l_cnt[1] = __popcll(keep);
-            l_cnt[2] = (int32_t)(newb & 0xffffffffull);
-            l_cnt[3] = (int32_t)(newb >> 32);
-            l_cnt[4] = __popcll(fl);
-            l_cnt[5] = badm != 0ull;
-        }
-    }
-    *total_out = total;
-}
