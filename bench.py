@@ -133,6 +133,104 @@ def cpu_baseline(corpus, n_utts_total, K, n_slices_max, budget_utts):
     return out
 
 
+def self_launch(gpus):
+    """`python bench.py --gpus N` without a launcher (no WORLD_SIZE in the environment): start the N ranks as a CHILD
+    `python -m torch.distributed.run` job BEFORE this process touches a GPU (never an exec after GPU initialisation), relay
+    the ranks' output -- rank 0 prints the one JSON line -- and leave with the child's exit code.  The torchrun form the
+    driver uses for N > 1 sets WORLD_SIZE and never comes here.  Backend: RCCL ("nccl") when the box has a GPU per rank;
+    with fewer GPUs than ranks (a rehearsal on a one-GPU box) gloo with the ranks sharing the cards, unless
+    SEGK_BENCH_BACKEND says otherwise."""
+    import socket
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if "SEGK_BENCH_BACKEND" not in env:
+        import torch                                   # device_count() does not initialise the GPU
+        if torch.cuda.device_count() < gpus:
+            env["SEGK_BENCH_BACKEND"] = "gloo"
+    with socket.socket() as so:                        # a free rendezvous port
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    sys.exit(proc.wait())
+
+
+def early_sweeps(kaw, corpus, args, n_sweeps=10):
+    """Sweeps 1..n_sweeps of a FRESH chain (the sweeps in which a k-means run does its work: 57 % of the rows change their
+    component in sweep 1, 16 % in sweep 2, 6-10 % in sweeps 3-10), each timed with HIP events on the launch stream, once on
+    the default (hinted) score path and once with SEGK_SCORE_HINT=0 (the library reads the switch at every call); outside the
+    main timed region.  second_stage_rows / full_scan_rows: what the score stages of that sweep passed on."""
+    import ctypes as C
+    import torch
+    from segmentalist_amd import _abi
+    out = {}
+    saved = os.environ.get("SEGK_SCORE_HINT")
+    try:
+        for label, env in (("hinted", None), ("unhinted", "0")):
+            if env is None:
+                os.environ.pop("SEGK_SCORE_HINT", None)
+                if saved is not None:
+                    os.environ["SEGK_SCORE_HINT"] = saved
+            else:
+                os.environ["SEGK_SCORE_HINT"] = env
+            random.seed(0)
+            np.random.seed(0)
+            seg = kaw.SegmentalKMeansWordseg(args.K, *corpus, n_slices_max=args.n_slices_max,
+                                             init_am_assignments="spread", sync="batch")
+            ms, second, full, comps = [], [], [], []
+            sc = (C.c_int32 * 2)()
+            for _ in range(n_sweeps):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize()
+                e0.record()
+                seg.batch_sweep_async()
+                e1.record()
+                torch.cuda.synchronize()
+                ms.append(float(e0.elapsed_time(e1)))
+                _abi.check(_abi.lib().segk_kmeans_stage_counts(_abi.ctx(), C.byref(seg._dk.cand), sc, _abi.stream()))
+                second.append(int(sc[0]))
+                full.append(int(sc[1]))
+                comps.append(int(seg._dk.K.item()))
+            seg._dk.check_status()
+            out[label] = {"ms": ms, "second_stage_rows": second, "full_scan_rows": full, "components": comps}
+            del seg
+    finally:
+        if saved is None:
+            os.environ.pop("SEGK_SCORE_HINT", None)
+        else:
+            os.environ["SEGK_SCORE_HINT"] = saved
+    out["note"] = ("sweeps 1..%d of a fresh chain (spread initialisation), one HIP-event pair around each whole sweep with the "
+                   "stream drained in between (so ~10 us of launch latency per sweep that back-to-back sweeps hide); sweep 1 has "
+                   "no hints on either path" % n_sweeps)
+    return out
+
+
+def minibatch_rate(kaw, corpus, args, n_batches, n_sweeps):
+    """sweeps/s of the mini-batch form (n_batches statistics refreshes per sweep) on the same corpus:
+    5 warm sweeps, then n_sweeps timed between two synchronisations; outside the main timed region."""
+    import torch
+    random.seed(0)
+    np.random.seed(0)
+    seg = kaw.SegmentalKMeansWordseg(args.K, *corpus, n_slices_max=args.n_slices_max, init_am_assignments="spread",
+                                     sync="batch", n_batches=n_batches)
+    for _ in range(5):
+        seg.batch_sweep_async()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n_sweeps):
+        seg.batch_sweep_async()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    seg._dk.check_status()
+    return {"n_batches": n_batches, "sweeps_per_s": n_sweeps / dt, "ms_per_sweep": 1e3 * dt / n_sweeps,
+            "components_after": int(seg._dk.K.item()), "sweeps": 5 + n_sweeps}
+
+
 def main_fbgmm(args):
     """Secondary workloads (BASELINE.json configs[1] and configs[4]): sweeps/s of the batch-synchronous
     blocked Gibbs sampler of the FBGMM / bigram drivers, same JSON contract."""
@@ -349,6 +447,7 @@ def main():
                     "until --min-seconds of timed sweeps have run); the median window is reported")
     ap.add_argument("--min-seconds", type=float, default=2.0, help="lower bound of the total timed region")
     ap.add_argument("--no-seq-chain", action="store_true", help="skip the sequential_chain extra key (N = 1)")
+    ap.add_argument("--no-early", action="store_true", help="skip the early_sweeps and minibatch extra keys (N = 1)")
     ap.add_argument("--cpu-utts", type=int, default=2000, help="utterances timed for cpu_baseline (0 = skip)")
     ap.add_argument("--no-events", action="store_true", help="do not bracket the score kernel with events")
     ap.add_argument("--event-period", type=int, default=8,
@@ -365,6 +464,8 @@ def main():
         args.steps = 3 if seq else 50
     if args.warmup is None:
         args.warmup = 1 if seq else 5
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not seq:
+        self_launch(args.gpus)                           # does not return
     if seq:
         return main_sequential(args)
     if args.workload != "kmeans_c3":
@@ -510,6 +611,18 @@ def main():
         except Exception as e:                           # the extra key must never cost the line
             seq_chain = {"error": repr(e)}
 
+    # N = 1: sweeps 1-10 of a fresh chain on both score paths, and the mini-batch form beside `value` (outside the timed region)
+    early, mb = None, None
+    if world == 1 and rank == 0 and not args.no_early:
+        try:
+            early = early_sweeps(kaw, corpus, args)
+        except Exception as e:                           # the extra keys must never cost the line
+            early = {"error": repr(e)}
+        try:
+            mb = minibatch_rate(kaw, corpus, args, 8, 20)
+        except Exception as e:
+            mb = {"error": repr(e)}
+
     if rank == 0:
         # algorithmic: 2 rows K D of the timed launch.  K = all K_max slots: those beyond the active components hold
         # random means and are candidates like any other, as in the reference (kmeans_components.py:149-166, 225-226)
@@ -582,7 +695,11 @@ def main():
                               "arithmetic by k_kmeans_hint_exact, results bit-identical to the float32 reference)"
                               % (kp // 16, score_rows, args.K),
                     "achieved": achieved, "peak": PEAK_BF16_MATRIX_TFLOPS, "unit": "TFLOP/s",
-                    "frac": achieved / PEAK_BF16_MATRIX_TFLOPS, "traffic": traffic, "ms_per_launch": score_ms,
+                    "frac": achieved / PEAK_BF16_MATRIX_TFLOPS, "traffic": traffic,
+                    "traffic_source": ("profiles/score_kernel_traffic_hint.json (static: separate rocprofv3 --pmc passes of this "
+                                       "command on this workload, FETCH_SIZE x2 + WRITE_SIZE, committed; not measured in this run)"
+                                       if traffic is not None else None),
+                    "ms_per_launch": score_ms,
                     "launches_in_interval": 1,
                     "timed_launches": "HIP events around the kernel in every %d-th sweep of the timed region" % max(1, args.event_period),
                     "flops_per_launch": flops_per_launch,
@@ -659,6 +776,15 @@ def main():
             out["config"]["collective_measured"] = gather_info
         if seq_chain is not None:
             out["sequential_chain"] = seq_chain
+        if early is not None:
+            out["early_sweeps"] = early
+        if mb is not None:
+            out["batch_forms"] = {"n_batches_1": {"n_batches": 1, "sweeps_per_s": args.steps / elapsed,
+                                                  "components_after": int(seg.acoustic_model.components.K)},
+                                  "n_batches_8": mb,
+                                  "note": "`value` is n_batches = 1 (statistics frozen for a whole sweep); n_batches = 8 refreshes them "
+                                          "eight times per sweep (closer to the reference's per-utterance refresh: more components "
+                                          "survive) at the cost of eight statistics passes per sweep"}
         if world == 1 and args.cpu_utts > 0:
             out["cpu_baseline"] = cpu_baseline(corpus, args.utts, args.K, args.n_slices_max, args.cpu_utts)
         print(json.dumps(out))

@@ -1799,8 +1799,7 @@ static int32_t fbb_assign_impl(segk_ctx *ctx, const segk_corpus *c, const segk_f
     if (m.off[s_n] == 0) return SEGK_OK;
     const double alpha = f->lm_unigram ? f->lm_a : f->alpha;
     // timing-only ablation knob (development): 1 = one dimension, 2 = one token, 4 = no draw
-    const char *dbg_s = getenv("SEGK_FBB_DBG");
-    const int dbg = dbg_s ? atoi(dbg_s) : 0;
+    const int dbg = segk_dev_env("SEGK_FBB_DBG");       // -DSEGK_DEV builds only
     // tokens per chunk: as many likelihood rows as fit beside the logits (two workgroups per CU)
     int rcap = FBB_R;
     const size_t fixed_b = (size_t)(f->K_max + FBA_R * c->D + FBA_R + 16) * sizeof(double);

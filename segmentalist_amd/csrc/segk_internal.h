@@ -80,6 +80,16 @@ static inline bool segk_prof_now(segk_ctx *ctx)
 
 void segk_set_error(const char *fmt, ...);
 
+// Development switches that ALTER RESULTS (timing ablations, debug modes) or hand raw pointers to kernels exist only in builds
+// with -DSEGK_DEV: the shipped library cannot be told through the environment to compute wrong answers.  (The launch-plan
+// switches that remain -- SEGK_SCORE_HINT, SEGK_SCORE_PRE, SEGK_SCORE_B3, ... -- choose between paths with identical results.)
+#ifdef SEGK_DEV
+#include <stdlib.h>
+static inline int segk_dev_env(const char *name) { const char *e = getenv(name); return e ? atoi(e) : 0; }
+#else
+static inline int segk_dev_env(const char *) { return 0; }
+#endif
+
 // segk_metrics.hip: the rows 0..n-1 bucketed by label (labels[row] in [0, K_max), anything else: not listed), every
 // bucket in ascending row order -- the stable counting sort of the k-means batch statistics run over blocks of rows.
 // Row q of label k inside block b: blk_lo[b] + sorted[blk_lo[b] + koff[b * (K_max + 1) + k] + q].  Buffers are owned

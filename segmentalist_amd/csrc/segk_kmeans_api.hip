@@ -24,7 +24,7 @@ static ScoreArgs make_score_args(const segk_corpus *c, const segk_kmeans *m, con
     A.G = segk_G(c->D); A.D = c->D;
     A.fuse_exact = (c->x_dtype == SEGK_F32 && c->D >= 8 && c->D <= 128) ? 1 : 0;
     A.is_f64 = c->x_dtype == SEGK_F64;
-    A.dbg = getenv("SEGK_SCORE_DBG") ? atoi(getenv("SEGK_SCORE_DBG")) : 0;
+    A.dbg = segk_dev_env("SEGK_SCORE_DBG");
     A.xnorm = c->xnorm; A.mnorm2 = m->mnorm_max; A.cand = *cand; A.amb_cap = (int)c->n_emb;
     A.n_chunks = 0; A.tiles_per_split = 0; A.part_k = nullptr; A.part_f = nullptr;
     if (b3) {

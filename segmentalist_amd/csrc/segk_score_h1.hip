@@ -693,8 +693,7 @@ static int launch_score_pre(segk_ctx *ctx, ScoreArgs A, hipStream_t st)
     if (n4 > 0) {
         ScoreArgs M = A;
         M.n = n4;
-        const char *abl = getenv("SEGK_H1_ABL");                     // development, timing only
-        const int ab = abl ? atoi(abl) : 0;
+        const int ab = segk_dev_env("SEGK_H1_ABL");                  // development (-DSEGK_DEV builds), timing only
         if (ab == 1) hipLaunchKernelGGL((k_kmeans_score_h1<KS, 4, 1>), dim3((unsigned)(n4 / 512)), dim3(256), lds, st, M);
         else if (ab == 2) hipLaunchKernelGGL((k_kmeans_score_h1<KS, 4, 2>), dim3((unsigned)(n4 / 512)), dim3(256), lds, st, M);
         else if (ab == 3) hipLaunchKernelGGL((k_kmeans_score_h1<KS, 4, 3>), dim3((unsigned)(n4 / 512)), dim3(256), lds, st, M);

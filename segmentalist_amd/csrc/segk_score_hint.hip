@@ -828,7 +828,7 @@ static int launch_score_hint(segk_ctx *ctx, ScoreArgs A, const int32_t *remap, i
     H.n_tiles = A.n_tiles; H.tpr = tpr; H.n_ranges = n_ranges;
     H.part = (float2 *)ctx->hint_part;
     H.K_max = A.K_max;
-    H.dbg = getenv("SEGK_HINT_DBG") ? atoi(getenv("SEGK_HINT_DBG")) : 0;
+    H.dbg = segk_dev_env("SEGK_HINT_DBG");
 #ifdef SEGK_STAMP
     H.stamp = getenv("SEGK_STAMP_PTR") ? (unsigned long long *)strtoull(getenv("SEGK_STAMP_PTR"), nullptr, 0) : nullptr;
 #endif

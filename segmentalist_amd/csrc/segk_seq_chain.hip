@@ -545,7 +545,7 @@ int segk_launch_seq_chain(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m, c
     A.n_flag = n_flag; A.out_total = out_total; A.status = status;
     A.cpw = cpw; A.nb_cap = nbc; A.ldm = ldm;
     SEGK_CHECK_HIP(hipMemcpyAsync((void *)A.order, order, (size_t)n_order * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    const bool stamping = getenv("SEGK_CHAIN_STAMP") && atoi(getenv("SEGK_CHAIN_STAMP"));
+    const bool stamping = segk_dev_env("SEGK_CHAIN_STAMP") != 0;      // -DSEGK_DEV builds only
     static unsigned long long *stamp_dev = nullptr;
     if (stamping && !stamp_dev) SEGK_CHECK_HIP(hipMalloc((void **)&stamp_dev, (256 * 8 + 4 * 256 + 256 * 8) * sizeof(unsigned long long)));
     A.stamp = stamping ? stamp_dev : nullptr;

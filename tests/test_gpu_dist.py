@@ -100,3 +100,24 @@ def test_bigram_batch_matrix_core_mode_is_independent_of_the_number_of_ranks(tmp
         got = run(world, str(tmp_path / ("h%d.npz" % world)), 2, "dist_worker_fbgmm.py", ["bigram", "f16"])
         for k in ref.files:
             assert np.array_equal(ref[k], got[k]), (world, k)
+
+
+def test_bench_self_launches_its_ranks_and_reports_the_measured_collective(tmp_path):
+    """`python bench.py --gpus 2` WITHOUT a launcher (the form the driver uses for N = 1): bench.py starts the two ranks as a
+    child torchrun job before touching the GPU, the ranks share the card over gloo (one GPU here), rank 0's JSON line comes
+    back through the parent and carries the measured per-sweep all-gather."""
+    import json
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--windows", "1",
+           "--min-seconds", "0", "--cpu-utts", "0", "--utts", "400", "--K", "64", "--dim", "16"]
+    res = subprocess.run(cmd, check=True, env=env, timeout=600, cwd=ROOT, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["value"] > 0
+    cm = out["config"]["collective_measured"]
+    assert cm["world_size"] == 2 and cm["all_gather_us_per_sweep_max_over_ranks"] > 0
+    import torch
+    assert cm["backend"] == ("nccl" if torch.cuda.device_count() >= 2 else "gloo")

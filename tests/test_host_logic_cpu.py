@@ -120,3 +120,39 @@ def test_virtual_ranks_communicator_behaves_like_a_process_group():
 
     with pytest.raises(RuntimeError, match="never entered"):
         VirtualWorld(4, timeout=2).run(skips)
+
+
+def test_bench_starts_its_own_ranks_when_no_launcher_did(monkeypatch):
+    """`python bench.py --gpus N` without WORLD_SIZE must not die on an assertion: it starts `python -m torch.distributed.run
+    --nproc-per-node N ... bench.py <same arguments>` as a CHILD process (never an exec) with a 127.0.0.1 rendezvous and relays
+    its output; with fewer GPUs than ranks (here: none) the child is told to use gloo."""
+    import io
+    import os
+    import subprocess
+    import sys
+    import pytest
+    import bench
+    seen = {}
+
+    class FakeProc(object):
+        stdout = io.StringIO('{"metric": "x"}\n')
+
+        def wait(self):
+            return 0
+
+    def fake_popen(cmd, env=None, stdout=None, text=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return FakeProc()
+
+    monkeypatch.setattr(subprocess, "Popen", fake_popen)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.delenv("SEGK_BENCH_BACKEND", raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert os.path.basename(cmd[cmd.index("--master-port") + 2]) == "bench.py" and cmd[-4:] == ["--gpus", "4", "--steps", "3"]
+    assert seen["env"]["SEGK_BENCH_BACKEND"] == "gloo" and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
