@@ -145,8 +145,13 @@ def self_launch(gpus):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if "SEGK_BENCH_BACKEND" not in env:
-        import torch                                   # device_count() does not initialise the GPU
-        if torch.cuda.device_count() < gpus:
+        # GPUs of the box counted by a short-lived child that is gone before the ranks start: this process never opens the GPU
+        try:
+            n_dev = int(subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], env=env,
+                                       stdout=subprocess.PIPE, text=True, timeout=300).stdout.strip().splitlines()[-1])
+        except Exception:
+            n_dev = gpus
+        if n_dev < gpus:
             env["SEGK_BENCH_BACKEND"] = "gloo"
     with socket.socket() as so:                        # a free rendezvous port
         so.bind(("127.0.0.1", 0))
@@ -154,9 +159,10 @@ def self_launch(gpus):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
-    for line in proc.stdout:
-        sys.stdout.write(line)
-        sys.stdout.flush()
+    for line in proc.stdout:                           # rank 0's JSON line to stdout; anything else the ranks print (gloo's
+        dst = sys.stdout if line.startswith("{") else sys.stderr      # connection chatter) to stderr
+        dst.write(line)
+        dst.flush()
     sys.exit(proc.wait())
 
 

@@ -85,9 +85,11 @@ static bool hinted_path_applies(const segk_ctx *ctx, const segk_corpus *c, const
     if (mode == 0 || ctx->capturing) return false;
     if (!segk_use_b3(c, m) || c->sp_pieces != 2 || c->D % 4 != 0) return false;
     if (n >= (int64_t)1 << 30) return false;
-    // K1 keeps at most four LDS ranges of tile images, K2's table ranges must not outnumber the CUs
+    // K1 keeps at most four LDS ranges of tile images
     {
-        int max_tiles = (int)((160 * 1024) / (((segk_b3_kp(c->D) / 16) * 256 + 32) * sizeof(float)));
+        const int64_t map_bytes = (int64_t)((m->K_max + 3) & ~3) * 4;        // the hint waves' label map shares K1's LDS
+        if (map_bytes + ((segk_b3_kp(c->D) / 16) * 256 + 32) * 4 > 160 * 1024) return false;
+        int max_tiles = (int)((160 * 1024 - map_bytes) / (((segk_b3_kp(c->D) / 16) * 256 + 32) * sizeof(float)));
         if (max_tiles > 32) max_tiles = 32;              // SEGK_HINT_MAX_TPR
         if (segk_n_tiles(m->K_max) > 4 * max_tiles) return false;
     }

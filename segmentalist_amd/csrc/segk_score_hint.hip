@@ -58,6 +58,14 @@ struct HintArgs {
     int fb_cur;                     // this launch's slot
     const int64_t *fb_split;        // [9] this launch's first group per XCD (k_hint_map)
     int64_t k1_groups;              // groups this kernel multiplies (the few behind the last whole round of all waves go to the second stage)
+    // the hint waves (waves NW .. 2 NW - 1 of every workgroup): the hinted component of every row scored in reference arithmetic
+    const float *xrows32;           // float32 rows [n_emb][ld32]
+    int64_t ld32;
+    const float *means32;           // float32 `means` [K_max][D]
+    const int32_t *cand_k;          // per row: the label the previous call left (the hint, in that call's labelling)
+    const int32_t *map;             // [K_max] previous label -> current label, or -1 (k_hint_map)
+    const float *nxx;               // -|x|^2 per row in the reference's summation order (k_corpus_resid_sp)
+    float4 *hint_out;               // [n] by position in the launch: {s = -|x - m_h|^2, f_h = x.m_h - |m_h|^2/2, bits of h (-1: no hint), 0}
 };
 
 // ---- K1 ---------------------------------------------------------------------------------------------------------------
@@ -102,11 +110,99 @@ struct HintArgs {
         }                                                                                                                    \
     } while (0)
 
+// ---- the hint waves of K1 -----------------------------------------------------------------------------------------------
+// K1's four matrix waves leave the chip's memory system nearly idle (224 bytes per row and 200 us: 1.2 TB/s) and every SIMD a
+// second wave slot.  Four more waves per workgroup use both: they stream the float32 rows ONCE, contiguously (whole 128-byte
+// lines: a step is 32 consecutive rows), fetch each row's hinted component from the float32 table (400 KB: L2-resident) and
+// evaluate the reference's -|x - m_h|^2 in numpy's pairwise order -- TWO lanes per row (h = 0, 1: the lane halves of the eight
+// strided accumulators), packed fp32 arithmetic with every half rounded like the scalar operation.  Nothing here depends on the
+// matrix waves' results: the certificate (top-2 of ALL ranges against f_h) is taken afterwards by k_hint_merge, one pass over
+// 48 bytes per row.  Round 3 did this as a kernel of its own behind K1 (k_kmeans_hint_exact: 129 us, 572 MB fetched because
+// its range workgroups picked scattered rows); fused, the float32 corpus crosses HBM once per sweep, under the matrix work.
+template <int KS, int V>
+__device__ __forceinline__ void hint_wave_rows(const HintArgs &H, const int32_t *map /* LDS */, int64_t w, int64_t n_w)
+{
+    constexpr int D = 16 * KS - 4 * V;
+    constexpr int nfull = D & ~7, nblk = nfull >> 3, rem = D & 7;
+    constexpr int NX = nblk + (rem ? 1 : 0);
+    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    typedef const __attribute__((address_space(1))) f32x4_t *gptr_t;
+    const int lane = threadIdx.x & 63, row = lane >> 1, h = lane & 1;
+    auto pk_sub = [](f32x2_t a, f32x2_t b2) -> f32x2_t {           // a - b, both halves in one instruction
+        f32x2_t d;
+        asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b2));
+        return d;
+    };
+    const int64_t n_steps = (H.n + 31) >> 5;
+    auto rid_of = [&](int64_t s_) -> int32_t {
+        const int64_t p_ = s_ * 32 + row;
+        return p_ < H.n ? (H.ids ? H.ids[p_] : (int32_t)(H.row0 + p_)) : -1;
+    };
+    int64_t s = w;
+    // row ids two steps ahead, previous labels one step ahead: no load of a step waits for another load of the same step
+    int32_t rid = -1, rid_n = -1, kprev = -1;
+    if (s < n_steps) {
+        rid = rid_of(s);
+        if (s + n_w < n_steps) rid_n = rid_of(s + n_w);
+        kprev = rid >= 0 ? H.cand_k[rid] : -1;
+    }
+    for (; s < n_steps; s += n_w) {
+        const int32_t hint = (rid >= 0 && kprev >= 0 && kprev < H.K_max) ? map[kprev] : -1;
+        const int32_t rid_c = rid;
+        f32x4_t xv[NX], mv[NX];
+        {
+            const int64_t r_any = rid_c >= 0 ? (int64_t)rid_c : (H.ids ? 0 : H.row0);
+            const uintptr_t xa = (uintptr_t)(H.xrows32 + r_any * H.ld32);
+            const uintptr_t ma = (uintptr_t)(H.means32 + (int64_t)(hint >= 0 ? hint : 0) * D);
+#pragma unroll
+            for (int b = 0; b < nblk; b++) xv[b] = *reinterpret_cast<gptr_t>(xa + 16u * h + 32u * b);
+            if constexpr (rem != 0) xv[nblk] = *reinterpret_cast<gptr_t>(xa + 4u * nfull);
+#pragma unroll
+            for (int b = 0; b < nblk; b++) mv[b] = *reinterpret_cast<gptr_t>(ma + 16u * h + 32u * b);
+            if constexpr (rem != 0) mv[nblk] = *reinterpret_cast<gptr_t>(ma + 4u * nfull);
+        }
+        const float nx = rid_c >= 0 ? H.nxx[rid_c] : 0.f;
+        // the next step's previous labels and the row ids of the step after it travel under this step's arithmetic
+        {
+            rid = rid_n;
+            kprev = rid >= 0 ? H.cand_k[rid] : -1;
+            const int64_t s2 = s + 2 * n_w;
+            rid_n = s2 < n_steps ? rid_of(s2) : -1;
+        }
+        // the reference's float32 -(deltas*deltas).sum() in numpy's pairwise order: this lane owns the strided accumulators
+        // r_{4h..4h+3}
+        f32x2_t rl = {0.f, 0.f}, rh = {0.f, 0.f};
+#pragma unroll
+        for (int b = 0; b < nblk; b++) {
+            const f32x2_t dl = pk_sub(mv[b].xy, xv[b].xy), dh = pk_sub(mv[b].zw, xv[b].zw);
+            const f32x2_t tl = dl * dl, th = dh * dh;
+            rl = b == 0 ? tl : rl + tl;
+            rh = b == 0 ? th : rh + th;
+        }
+        float res = (rl.x + rl.y) + (rh.x + rh.y);
+        const float ro = __shfl_xor(res, 1);
+        res = (h == 0) ? res + ro : ro + res;                      // ((r0+r1)+(r2+r3)) + ((r4+r5)+(r6+r7))
+        if constexpr (rem != 0) {
+            const f32x2_t dl = pk_sub(mv[nblk].xy, xv[nblk].xy), dh = pk_sub(mv[nblk].zw, xv[nblk].zw);
+            const f32x2_t tl = dl * dl, th = dh * dh;
+            res += tl.x;
+            if (rem > 1) res += tl.y;
+            if (rem > 2) res += th.x;
+            if (rem > 3) res += th.y;
+        }
+        const float sc = -res;                                     // -|x - m_h|^2
+        const int64_t p = s * 32 + row;
+        if (h == 0 && p < H.n) H.hint_out[p] = make_float4(sc, 0.5f * (sc - nx), __int_as_float(rid_c >= 0 ? hint : -1), 0.f);
+    }
+}
+
 // (launch bounds "two waves per SIMD" for both: 256 registers per lane, all of them vector registers.  Given 512 the compiler
 // keeps the accumulators in the accumulator file and copies every value out for the drain, 16 v_accvgpr_read per block)
-template <int KS, int NW>
-__global__ __launch_bounds__(64 * NW, 2) void k_kmeans_top2_rs(HintArgs H)
+template <int KS, int V, int NW>
+__global__ __launch_bounds__(128 * NW, 1) void k_kmeans_top2_rs(HintArgs H)
 {
+    static_assert(NW == 4, "four matrix waves (one per SIMD, rows prefetched) + four hint waves per workgroup");
     typedef _Float16 T;
     typedef SegkPiece<2>::V8 V8;
     // (only 256 of a lone wave's 512 registers are addressable by vector instructions, the rest is the accumulator file: a
@@ -120,6 +216,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_kmeans_top2_rs(HintArgs H)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
     const int R = H.n_ranges;
+    const bool is_hint = wave >= NW;                // waves NW .. 2 NW - 1: hint_wave_rows
+    if (!is_hint) __builtin_amdgcn_s_setprio(2);    // the matrix waves first wherever the two kinds meet at an issue port
 #ifdef SEGK_STAMP
     const unsigned long long st_k0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -136,12 +234,13 @@ __global__ __launch_bounds__(64 * NW, 2) void k_kmeans_top2_rs(HintArgs H)
         n_wgr = gridDim.x / R;
         range = blockIdx.x % R;
         wgr = blockIdx.x / R;
-        if (wgr >= n_wgr) return;
     }
     const int t_lo = range * H.tpr;
     int nt = H.n_tiles - t_lo;
     if (nt > H.tpr) nt = H.tpr;
-    if (nt <= 0) return;
+    // (a workgroup without matrix work -- beyond the last whole set of ranges, or a range without tiles -- still runs its hint waves)
+    const bool mm_on = wgr < n_wgr && nt > 0;
+    if (nt < 1) nt = 1;
     const T *plane0 = (const T *)(H.ximg + SEGK_SP_HEADER);
     // this wave's row groups: g_first, g_first + n_slots, ... below n_groups
     const int64_t total_groups = (H.n + 32 * NBLK - 1) / (32 * NBLK);
@@ -281,7 +380,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_kmeans_top2_rs(HintArgs H)
     int64_t pend_g = -1;
     V8 xa[NBLK][KS];
     int32_t hrow_a[NBLK], hk_a[NBLK];
-    if (g < n_groups && !(H.dbg & 4)) SEGK_RS_LOAD(g, xa, hrow_a, hk_a);      // the first rows travel while the tile images are copied
+    if (!is_hint && mm_on && g < n_groups && !(H.dbg & 4)) SEGK_RS_LOAD(g, xa, hrow_a, hk_a);      // the first rows travel while the tile images are copied
 #ifdef SEGK_STAMP
     const unsigned long long st_k1 = __builtin_amdgcn_s_memtime();
 #endif
@@ -293,28 +392,33 @@ __global__ __launch_bounds__(64 * NW, 2) void k_kmeans_top2_rs(HintArgs H)
     {
         constexpr int MAXT = (160 * 1024 / (TL * 4)) < SEGK_HINT_MAX_TPR ? (160 * 1024 / (TL * 4)) : SEGK_HINT_MAX_TPR;
         constexpr int MAXB = MAXT * KS;                                 // blocks of the largest range (LDS, SEGK_HINT_MAX_TPR)
-        constexpr int PER_W = (MAXB + NW - 1) / NW;
-        const int n_blk = nt * KS;
+        constexpr int NWF = 2 * NW;                                     // all eight waves copy
+        constexpr int PER_W = (MAXB + NWF - 1) / NWF;
+        const int n_blk = nt * KS;                                      // (without matrix work: tile 0's blocks are loaded and dropped)
+        const int t_ld = mm_on ? t_lo : 0;
         // every workgroup of a range copies the same bytes at the same moment: started at the same block they all queue on
         // the same L2 channel (5.8 bytes per cycle and CU measured).  Each starts somewhere else in the range instead.
         const int rot = (int)(((unsigned)wgr * 2654435761u) >> 8) % n_blk;
         float4 v[PER_W];
 #pragma unroll
         for (int u = 0; u < PER_W; u++) {
-            int c = wave + u * NW;
+            int c = wave + u * NWF;
             if (c >= n_blk) c = n_blk - 1;                              // clamped, unconditional load
             c += rot;
             if (c >= n_blk) c -= n_blk;
             const int t = c / KS, ks = c - t * KS;
-            v[u] = *reinterpret_cast<const float4 *>(H.tiles + (int64_t)(t_lo + t) * STRIDE + ks * (P * 256) + lane * 4);
+            v[u] = *reinterpret_cast<const float4 *>(H.tiles + (int64_t)(t_ld + t) * STRIDE + ks * (P * 256) + lane * 4);
         }
         float4 cv4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        const bool has_c = tid < nt * 8;                                // the 32 constants of every tile: one float4 per thread
+        const bool has_c = mm_on && tid < nt * 8;                       // the 32 constants of every tile: one float4 per thread
         if (has_c) cv4 = *reinterpret_cast<const float4 *>(H.tiles + (int64_t)(t_lo + (tid >> 3)) * STRIDE + KS * P * 256 + (tid & 7) * 4);
+        // the label map of the hint waves behind the tile images
+        int32_t *map_l = reinterpret_cast<int32_t *>(lds + H.tpr * TL);
+        for (int k = tid; k < H.K_max; k += 128 * NW) map_l[k] = H.map[k];
 #pragma unroll
         for (int u = 0; u < PER_W; u++) {
-            int c = wave + u * NW;
-            if (c < n_blk) {
+            int c = wave + u * NWF;
+            if (mm_on && c < n_blk) {
                 c += rot;
                 if (c >= n_blk) c -= n_blk;
                 const int t = c / KS, ks = c - t * KS;
@@ -322,13 +426,19 @@ __global__ __launch_bounds__(64 * NW, 2) void k_kmeans_top2_rs(HintArgs H)
             }
         }
         if (has_c) *reinterpret_cast<float4 *>(lds + (tid >> 3) * TL + KS * 256 + (tid & 7) * 4) = cv4;
-        static_assert(64 * NW >= MAXT * 8, "one thread per float4 of the constants");
+        static_assert(128 * NW >= MAXT * 8, "one thread per float4 of the constants");
     }
     __syncthreads();
+    if (is_hint) {
+        // every workgroup's hint waves take steps of 32 rows, strided over the whole grid: the chip walks the corpus front to back
+        hint_wave_rows<KS, V>(H, reinterpret_cast<const int32_t *>(lds + H.tpr * TL), (int64_t)blockIdx.x * NW + (wave - NW),
+                              (int64_t)gridDim.x * NW);
+        return;
+    }
 #ifdef SEGK_STAMP
     const unsigned long long st_k2 = __builtin_amdgcn_s_memtime();
 #endif
-    if (g >= n_groups) return;
+    if (!mm_on || g >= n_groups) return;
     if (H.dbg & 4) SEGK_RS_LOAD(g, xa, hrow_a, hk_a);
 #pragma unroll
     for (int s = 0; s < KS; s++) load_a(0, s);          // tile 0's operands for the first group; every group's last tile reloads them
@@ -410,11 +520,10 @@ __global__ __launch_bounds__(64 * NW, 2) void k_kmeans_top2_rs(HintArgs H)
 //   map[k] = the label a hint k of the previous call stands for now (remap, identity when NULL), or -1 when that component
 //            is carried as "absent" by the filters' images (seed constant <= -1e37: a marked duplicate) -- such a hint
 //            proves nothing;
-//   cand.k of every row of the call: (previous label | SEGK_HINT_BIT) when that label is a component index, -1 otherwise.
-//   and the queue lengths of the call cleared: the caller's ambiguity queue (when segk_kmeans_score_hinted deferred it) and
-//   the second stage's counters.
+//   the queue lengths of the call cleared: the caller's ambiguity queue (when segk_kmeans_score_hinted deferred it) and the
+//   second stage's counters; the XCDs' shares of K1's row groups; (m1, m2) = (0, 0) for the rows K1 leaves out.
 __global__ void k_hint_map(const int32_t *remap, const float *tiles_sp /* first tile */, int K_max, int stride, int const_off, int32_t *map,
-                           const int32_t *ids, int64_t row0, int64_t n, int32_t *cand_k, int32_t *zero_cnt, int32_t *pre_hdr,
+                           int64_t n, int32_t *zero_cnt, int32_t *pre_hdr,
                            float *fb_w, unsigned int *fb_t, int fb_cur, int64_t *fb_split, int64_t total_groups, int64_t first_skipped,
                            float2 *part, int n_ranges)
 {
@@ -457,275 +566,124 @@ __global__ void k_hint_map(const int32_t *remap, const float *tiles_sp /* first 
         }
     }
     // rows the matrix kernel leaves out (the groups behind the last whole round of all its waves, when they are few): (m1, m2) =
-    // (0, 0) in every range reads as "undecided" to the exact stage, which queues them for the second stage
-    if (i >= first_skipped && i < n)
-        for (int rg = 0; rg < n_ranges; rg++) part[(int64_t)rg * n + i] = make_float2(0.f, 0.f);
+    // (0, 0) in every range reads as "undecided" to the merge, which queues them for the second stage
+    if (first_skipped + i < n)
+        for (int rg = 0; rg < n_ranges; rg++) part[(int64_t)rg * n + first_skipped + i] = make_float2(0.f, 0.f);
     if (i < K_max) {
         int v = remap ? remap[i] : (int)i;
         if (v < 0 || v >= K_max) v = -1;
         else if (tiles_sp[(int64_t)(v >> 5) * stride + const_off + (v & 31)] < -1.0e37f) v = -1;
         map[i] = v;
     }
-    if (i < n) {
-        const int64_t rid = ids ? (int64_t)ids[i] : row0 + i;
-        if (rid >= 0) {
-            const int32_t k = cand_k[rid];
-            cand_k[rid] = (k >= 0 && k < K_max) ? (k | SEGK_HINT_BIT) : -1;
-        }
-    }
 }
 
-struct HintExactArgs {
-    const float2 *part;             // K1's output
+struct HintMergeArgs {
+    const float2 *part;             // K1's matrix waves: (m1, m2) per (range, position)
+    const float4 *hint_out;         // K1's hint waves: {s, f_h, bits of h, 0} per position
     int n_ranges;
-    const int32_t *map;             // [K_max] k_hint_map
-    int64_t n_emb;                  // rows of the corpus (the per-row arrays behind the piece planes)
     const float *tiles_hdr;         // tiles_b3: [0] exponent b, [1] E_m
     const unsigned char *ximg;      // row image header: [1] exponent a
 };
 
-#define SEGK_HINT_ROWS 32       /* rows per step of a wave: two lanes per row */
-#define SEGK_HINT_RING 128
-#define SEGK_HINT_UBUF 192
-// K2: see the head of the file.  Skeleton of k_kmeans_exact_pair4 (the table split into P ranges of cpp components, one range
-// per workgroup in LDS; a wave walks its slice of the rows, keeps those whose hint lies in its range in a ring, takes a step's
-// worth of rows off the ring and has the next step's loads in flight while it sums the current one).  TWO lanes per row
-// (h = 0, 1: the lane halves of numpy's eight strided accumulators), 32 rows = 12.8 KB of rows in flight per wave and step --
-// the stage is bound by the bytes a CU keeps in flight.  -|x|^2 comes precomputed with the row image (k_corpus_resid_sp);
-// the two lanes of a row also fetch its (m1, m2) of up to four ranges, its norm bound and its residual.
-template <int KS, int V, int NW>
-__global__ __launch_bounds__(64 * NW) void k_kmeans_hint_exact(ScoreArgs A, HintExactArgs H, int P, int cpp)
+// K2 (round 4): the certificate.  Per row the filter's top-2 merged over the ranges, the hinted component's exact score s and its
+// filter-domain value f_h (see the head of the file):
+//     top1 - top2 > tau   and   f_h >= top1 - tau + E + dl      =>   cand.k = h, cand.s = s  (the reference's bits)
+// anything else -- no hint, a wrong hint, a near-tie -- is queued for the second stage (one reservation per wave).  One thread
+// per row, 48 bytes read and 12 written: the whole exact stage of round 3 (k_kmeans_hint_exact, 129 us) shrunk to this pass,
+// its arithmetic moved under K1's matrix work.
+#define SEGK_MERGE_ROWS 4096        /* rows per workgroup at most (its list of undecided rows in LDS) */
+__global__ __launch_bounds__(256) void k_hint_merge(ScoreArgs A, HintMergeArgs H, int KP, int64_t per)
 {
-    constexpr int D = 16 * KS - 4 * V, D4 = D >> 2;
-    constexpr int ps = D4 + ((2 - D4) & 3), LD = ps * 4;
-    constexpr int nfull = D & ~7, nblk = nfull >> 3, rem = D & 7;
-    constexpr int NX = nblk + (rem ? 1 : 0);
-    extern __shared__ __attribute__((aligned(16))) float lds[];    // [cpp][LD] member rows, map [K_max], then per wave: ring, undecided rows
-    typedef float f32x4_t __attribute__((ext_vector_type(4)));
-    typedef float f32x2_t __attribute__((ext_vector_type(2)));
-    typedef const __attribute__((address_space(1))) f32x4_t *gptr_t;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int part = blockIdx.x % P, chunk = blockIdx.x / P, n_chunk = gridDim.x / P;
-    if (chunk >= n_chunk) return;
-    const int c_lo = part * cpp;
-    int c_n = A.K_max - c_lo;
-    if (c_n > cpp) c_n = cpp;
-    for (int i = tid; i < c_n * D4; i += 64 * NW) {
-        const int r = i / D4, s4 = i - r * D4;
-        *reinterpret_cast<f32x4_t *>(lds + r * LD + 4 * s4) = *reinterpret_cast<const f32x4_t *>(A.means32 + (int64_t)(c_lo + r) * D + 4 * s4);
-    }
-    // label of the previous call -> current label, or -1 (k_hint_map)
-    int32_t *map = reinterpret_cast<int32_t *>(lds + (size_t)cpp * LD);
-    for (int k = tid; k < A.K_max; k += 64 * NW) map[k] = H.map[k];
+    // ONE queue reservation per workgroup: returning atomics on one address are served one after the other (a first version
+    // with one per wave -- 15 600 of them -- took 185 us for 55 MB of traffic); the workgroup's undecided rows wait in LDS
+    __shared__ int32_t ulist[SEGK_MERGE_ROWS];
+    __shared__ int32_t ucnt, ubase;
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (tid == 0) ucnt = 0;
     __syncthreads();
-    if (c_n <= 0 && part != 0) return;
-    int32_t *wbase = map + ((A.K_max + 3) & ~3) + wave * (3 * SEGK_HINT_RING + SEGK_HINT_UBUF);
-    volatile int32_t *ring = wbase;                                 // [3][RING]: row id, local component, position in the launch
-    volatile int32_t *ubuf = wbase + 3 * SEGK_HINT_RING;            // undecided rows waiting for a queue reservation
-    int ucnt = 0;
-
+    const int64_t p_lo = (int64_t)blockIdx.x * per, p_hi = p_lo + per < A.n ? p_lo + per : A.n;
     const int e_ab = ((const int *)H.ximg)[1] + ((const int *)H.tiles_hdr)[0];
     const float unscale = ldexpf(1.f, -e_ab);
     const float M = (float)(sqrt(*A.mnorm2) * (1.0 + 1e-6)) + 1e-30f;
     const float Em = H.tiles_hdr[1];
-    const float *nxx = A.xerr + H.n_emb;                            // -|x|^2 per row, behind the residual norms
-
-    // this wave's rows: a multiple of 64 per wave
-    const int64_t n_slots = (int64_t)n_chunk * NW;
-    const int64_t per = ((A.n + n_slots - 1) / n_slots + 63) & ~(int64_t)63;
-    int64_t pos = ((int64_t)chunk * NW + wave) * per;
-    const int64_t r_end = pos + per < A.n ? pos + per : A.n;
-
-    auto load_rid = [&](int64_t p_) -> int32_t {
-        const int64_t r = p_ + lane;
-        return r < r_end ? (A.ids ? A.ids[r] : (int32_t)(A.row0 + r)) : -1;
-    };
-    auto pk_sub = [](f32x2_t a, f32x2_t b2) -> f32x2_t {           // a - b, both halves in one instruction
-        f32x2_t d;
-        asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b2));
-        return d;
-    };
-    // 64 undecided rows of the buffer to the second stage's queue (one reservation), the rest moves to the front
-    auto flush = [&](int nflush) {
-        int base = 0;
-        if (lane == 0) base = atomicAdd(A.pre_count, nflush);
-        base = __shfl(base, 0);
-        if (lane < nflush) {
-            const int q = base + lane;
-            const int32_t rid = ubuf[lane];
-            if (q < A.pre_cap) A.pre_queue[q] = rid;
-            else {                                                 // beyond the second stage's launch: full scan
-                const int q2 = atomicAdd(A.cand.count, 1);
-                if (q2 < A.amb_cap) A.cand.queue[q2] = rid;
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const int left = ucnt - nflush;
-        int32_t mv = 0;
-        if (lane < left) mv = ubuf[nflush + lane];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (lane < left) ubuf[lane] = mv;
-        int32_t mv2 = 0;
-        if (lane + 64 < left) mv2 = ubuf[nflush + 64 + lane];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (lane + 64 < left) ubuf[64 + lane] = mv2;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        ucnt = left;
-    };
-    auto push_undecided = [&](bool und, int32_t rid) {             // wave-wide: lanes with `und` append their row
-        const unsigned long long mask = __ballot(und);
-        if (mask == 0ull) return;
-        const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
-        if (und) ubuf[ucnt + before] = rid;
-        ucnt += __popcll(mask);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        while (ucnt >= 64) flush(64);
-    };
-    const int row = lane >> 1, h = lane & 1;
-
-    int32_t rid_n = -1, k_n = 0;
-    if (pos < r_end) {
-        rid_n = load_rid(pos);
-        k_n = rid_n >= 0 ? A.cand.k[rid_n] : -2;
-    }
-    int count = 0, head = 0;
-    bool have_prev = false;
-    f32x4_t xp[NX];
-    int32_t p_rid = -1, p_base = 0;
-    // per row, by lane half: h = 0: norm bound, (m1, m2) of ranges 0 and 2; h = 1: residual, -|x|^2, ranges 1 and 3
-    float p_a0 = 0.f, p_a1 = 0.f, p_m1 = NEG_INF_F, p_m2 = NEG_INF_F, p_n1 = NEG_INF_F, p_n2 = NEG_INF_F;
-    for (;;) {
-        // candidates into the ring until a step's worth is there
-        while (count < SEGK_HINT_ROWS && pos < r_end) {
-            const int32_t rid = rid_n, k = k_n;
-            const int64_t p_here = pos + lane;
-            pos += 64;
-            if (pos < r_end) {
-                rid_n = load_rid(pos);
-                k_n = rid_n >= 0 ? A.cand.k[rid_n] : -2;
-            }
-            // marked by k_hint_map: (previous label | SEGK_HINT_BIT) a hint, -1 none; anything else: already finished by its
-            // range's workgroup.  The label goes through the map: -1 there = the component is carried as absent, no hint either
-            const bool marked = rid >= 0 && k >= 0 && (k & SEGK_HINT_BIT) && (k & ~SEGK_HINT_BIT) < A.K_max;
-            const int32_t hint = marked ? map[k & ~SEGK_HINT_BIT] : -1;
-            const int32_t base = hint - c_lo;
-            const bool sel = hint >= 0 && base >= 0 && base < c_n;
-            // a row without a usable hint belongs to nobody's range: range 0 sends it on
-            push_undecided(part == 0 && rid >= 0 && (k == -1 || (marked && hint < 0)), rid);
-            const unsigned long long mask = __ballot(sel);
-            const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
-            if (sel) {
-                const int at = (head + count + before) & (SEGK_HINT_RING - 1);
-                ring[at] = rid;
-                ring[SEGK_HINT_RING + at] = base;
-                ring[2 * SEGK_HINT_RING + at] = (int32_t)p_here;
-            }
-            count += __popcll(mask);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const int n = count < SEGK_HINT_ROWS ? count : SEGK_HINT_ROWS;
-        // the next step: its rows off the ring, their loads into flight
-        int32_t n_rid = -1, n_base = 0, n_pos = 0;
-        if (row < n) {
-            const int at = (head + row) & (SEGK_HINT_RING - 1);
-            n_rid = ring[at];
-            n_base = ring[SEGK_HINT_RING + at];
-            n_pos = ring[2 * SEGK_HINT_RING + at];
-        }
-        head = (head + n) & (SEGK_HINT_RING - 1);
-        count -= n;
-        f32x4_t xn[NX];
-        float n_a0 = 0.f, n_a1 = 0.f, n_m1 = NEG_INF_F, n_m2 = NEG_INF_F, n_n1 = NEG_INF_F, n_n2 = NEG_INF_F;
-        {
-            const int64_t r_any = n_rid >= 0 ? (int64_t)n_rid : (A.ids ? 0 : A.row0);
-            const uintptr_t xa = (uintptr_t)(A.xrows32 + r_any * A.ld32);
+    // four rows per thread and trip, their loads in flight together (one row per trip was four dependent round trips per
+    // workgroup: 25 us for 55 MB)
+    constexpr int U = 4;
+    for (int64_t p0 = p_lo; p0 < p_hi; p0 += 256 * U) {
+        int32_t rid[U];
+        float4 ho[U];
+        float t1[U], t2[U], xnb[U], xer[U];
 #pragma unroll
-            for (int b = 0; b < nblk; b++) xn[b] = *reinterpret_cast<gptr_t>(xa + 16u * h + 32u * b);
-            if constexpr (rem != 0) xn[nblk] = *reinterpret_cast<gptr_t>(xa + 4u * nfull);
-            if (n_rid >= 0) {
-                n_a0 = h == 0 ? A.xnorm[n_rid] : A.xerr[n_rid];
-                if (h == 1) n_a1 = nxx[n_rid];
-                if (h < H.n_ranges) {
-                    const float2 pv = H.part[(int64_t)h * A.n + n_pos];
-                    n_m1 = pv.x;
-                    n_m2 = pv.y;
+        for (int j = 0; j < U; j++) {
+            const int64_t p = p0 + j * 256 + tid;
+            rid[j] = -1;
+            if (p < p_hi) rid[j] = A.ids ? A.ids[p] : (int32_t)(A.row0 + p);
+        }
+#pragma unroll
+        for (int j = 0; j < U; j++) {
+            const int64_t p = p0 + j * 256 + tid;
+            ho[j] = make_float4(0.f, 0.f, __int_as_float(-1), 0.f);
+            t1[j] = NEG_INF_F; t2[j] = NEG_INF_F; xnb[j] = 0.f; xer[j] = 0.f;
+            if (rid[j] >= 0) {
+                ho[j] = H.hint_out[p];
+                for (int r = 0; r < H.n_ranges; r++) {
+                    const float2 pv = H.part[(int64_t)r * A.n + p];
+                    const float n1 = fmaxf(t1[j], pv.x);
+                    t2[j] = fmaxf(fminf(t1[j], pv.x), fmaxf(t2[j], pv.y));
+                    t1[j] = n1;
                 }
-                if (h + 2 < H.n_ranges) {
-                    const float2 pv = H.part[(int64_t)(h + 2) * A.n + n_pos];
-                    n_n1 = pv.x;
-                    n_n2 = pv.y;
-                }
+                xnb[j] = A.xnorm[rid[j]];
+                xer[j] = A.xerr[rid[j]];
             }
         }
-        if (have_prev) {
-            // the reference's float32 -(deltas*deltas).sum() in numpy's pairwise order: this lane owns the strided
-            // accumulators r_{4h..4h+3} of the hinted component
-            const float *mrow = lds + p_base * LD;
-            f32x4_t mv[NX];
 #pragma unroll
-            for (int b = 0; b < nblk; b++) mv[b] = *reinterpret_cast<const f32x4_t *>(mrow + 4 * h + 8 * b);
-            if constexpr (rem != 0) mv[nblk] = *reinterpret_cast<const f32x4_t *>(mrow + nfull);
-            f32x2_t rl = {0.f, 0.f}, rh = {0.f, 0.f};
-#pragma unroll
-            for (int b = 0; b < nblk; b++) {
-                const f32x2_t dl = pk_sub(mv[b].xy, xp[b].xy), dh = pk_sub(mv[b].zw, xp[b].zw);
-                const f32x2_t tl = dl * dl, th = dh * dh;
-                rl = b == 0 ? tl : rl + tl;
-                rh = b == 0 ? th : rh + th;
-            }
-            float res = (rl.x + rl.y) + (rh.x + rh.y);
-            const float ro = __shfl_xor(res, 1);
-            res = (h == 0) ? res + ro : ro + res;                  // ((r0+r1)+(r2+r3)) + ((r4+r5)+(r6+r7))
-            if constexpr (rem != 0) {
-                const f32x2_t dl = pk_sub(mv[nblk].xy, xp[nblk].xy), dh = pk_sub(mv[nblk].zw, xp[nblk].zw);
-                const f32x2_t tl = dl * dl, th = dh * dh;
-                res += tl.x;
-                if (rem > 1) res += tl.y;
-                if (rem > 2) res += th.x;
-                if (rem > 3) res += th.y;
-            }
-            const float sc = -res;                                 // -|x - m_h|^2, both lanes of the row
-            // the filter's top-2 over the ranges: (a1, a2) + (b1, b2) = (max(a1, b1), max(min(a1, b1), max(a2, b2)))
-            float t1 = fmaxf(p_m1, p_n1), t2 = fmaxf(fminf(p_m1, p_n1), fmaxf(p_m2, p_n2));
-            {
-                const float u1 = __shfl_xor(t1, 1), u2 = __shfl_xor(t2, 1);
-                const float n1 = fmaxf(t1, u1);
-                t2 = fmaxf(fminf(t1, u1), fmaxf(t2, u2));
-                t1 = n1;
-            }
-            const float xer = __shfl_xor(p_a0, 1), so = __shfl_xor(p_a1, 1);      // lane half 0 reads its partner's
+        for (int j = 0; j < U; j++) {
             bool und = false;
-            if (h == 0 && p_rid >= 0) {
-                const float xnb = p_a0;
-                const float top1 = t1 * unscale, top2 = t2 * unscale;          // powers of two: exact
-                const float u = 5.9604645e-8f;
-                const float tau = filter_tau_h1(xnb, M, D, xer, Em);
-                // E: bound of |F_k - f_k| (accumulation + operand rounding, the terms of tau); dl: of the computed f_h
-                const float e1 = (1.02f * (float)(KS * 16 + 16) + 16.f) * u * (xnb * M + 0.5f * M * M);
-                const float rnd = 1.00001f * fminf((xnb + xer) * Em + xer * M, 1.01f * 9.765625e-4f * xnb * M);
-                const float s2 = xnb + M;
-                const float dl = ((float)(D / 8 + 13) + 4.f) * u * s2 * s2;
-                const float fh = 0.5f * (sc - so);                             // x.m_h - |m_h|^2/2
-                const bool ok = (top1 - top2 > tau) && (fh >= top1 - tau + (e1 + rnd + dl) * 1.0001f);
-                if (ok) {
-                    A.cand.k[p_rid] = p_base + c_lo;
-                    A.cand.s[p_rid] = (double)sc;
-                } else {
-                    und = true;
+            if (rid[j] >= 0) {
+                const int32_t hint = __float_as_int(ho[j].z);
+                und = true;
+                if (hint >= 0) {
+                    const float top1 = t1[j] * unscale, top2 = t2[j] * unscale;          // powers of two: exact
+                    const float u = 5.9604645e-8f;
+                    const float tau = filter_tau_h1(xnb[j], M, A.D, xer[j], Em);
+                    // E: bound of |F_k - f_k| (accumulation + operand rounding, the terms of tau); dl: of the computed f_h
+                    const float e1 = (1.02f * (float)(KP + 16) + 16.f) * u * (xnb[j] * M + 0.5f * M * M);
+                    const float rnd = 1.00001f * fminf((xnb[j] + xer[j]) * Em + xer[j] * M, 1.01f * 9.765625e-4f * xnb[j] * M);
+                    const float s2 = xnb[j] + M;
+                    const float dl = ((float)(A.D / 8 + 13) + 4.f) * u * s2 * s2;
+                    const bool ok = (top1 - top2 > tau) && (ho[j].y >= top1 - tau + (e1 + rnd + dl) * 1.0001f);
+                    if (ok) {
+                        A.cand.k[rid[j]] = hint;
+                        A.cand.s[rid[j]] = (double)ho[j].x;
+                        und = false;
+                    }
                 }
             }
-            push_undecided(und, p_rid);
+            const unsigned long long mask = __ballot(und);
+            if (mask != 0ull) {
+                const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&ucnt, __popcll(mask));           // LDS
+                base = __shfl(base, 0);
+                if (und) ulist[base + before] = rid[j];
+            }
         }
-        if (n == 0) break;
-#pragma unroll
-        for (int b = 0; b < NX; b++) xp[b] = xn[b];
-        p_rid = n_rid;
-        p_base = n_base;
-        p_a0 = n_a0; p_a1 = n_a1;
-        p_m1 = n_m1; p_m2 = n_m2; p_n1 = n_n1; p_n2 = n_n2;
-        have_prev = true;
     }
-    if (ucnt > 0) flush(ucnt);
+    __syncthreads();
+    const int cnt = ucnt;
+    if (cnt == 0) return;
+    if (tid == 0) ubase = atomicAdd(A.pre_count, cnt);
+    __syncthreads();
+    const int base = ubase;
+    for (int i = tid; i < cnt; i += 256) {
+        const int q = base + i;
+        const int32_t rid = ulist[i];
+        if (q < A.pre_cap) A.pre_queue[q] = rid;
+        else {                                                 // beyond the second stage's launch: full scan
+            const int q2 = atomicAdd(A.cand.count, 1);
+            if (q2 < A.amb_cap) A.cand.queue[q2] = rid;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -747,14 +705,18 @@ static int launch_score_hint(segk_ctx *ctx, ScoreArgs A, const int32_t *remap, i
     A.pre_cap = (int)A.n;
     // K1's ranges: as many tiles as fit in LDS beside nothing else (one workgroup per CU)
     constexpr int TL = KS * 256 + 32;
-    int max_tiles = (int)((160 * 1024) / (TL * sizeof(float)));
+    const size_t map_bytes = (size_t)((A.K_max + 3) & ~3) * sizeof(int32_t);          // the hint waves' label map behind the images
+    SEGK_REQUIRE(map_bytes + TL * sizeof(float) <= 160 * 1024, "hinted score path: K_max too large for the label map in LDS");
+    int max_tiles = (int)((160 * 1024 - map_bytes) / (TL * sizeof(float)));
     if (max_tiles > SEGK_HINT_MAX_TPR) max_tiles = SEGK_HINT_MAX_TPR;
     int n_ranges = (A.n_tiles + max_tiles - 1) / max_tiles;
     // two ranges at least when that halves the LDS fill per workgroup without starving the grid (the fill is per workgroup)
     if (n_ranges < 1) n_ranges = 1;
     const int tpr = (A.n_tiles + n_ranges - 1) / n_ranges;
     SEGK_REQUIRE(n_ranges <= 4, "hinted score path: K_max too large (more than four LDS ranges of tile images)");
-    const size_t need_part = (size_t)n_ranges * (size_t)A.n * sizeof(float2);
+    // [n_ranges][n] (m1, m2) of the matrix waves, then [n] {s, f_h, h, 0} of the hint waves
+    const size_t part_bytes = ((size_t)n_ranges * (size_t)A.n * sizeof(float2) + 255) & ~(size_t)255;
+    const size_t need_part = part_bytes + (size_t)A.n * sizeof(float4);
     if (ctx->hint_part_bytes < need_part || !ctx->hint_map || ctx->hint_map_k < A.K_max) {
         SEGK_REQUIRE(!ctx->capturing, "workspaces must exist before a graph capture (run the sequence once first)");
         SEGK_CHECK_HIP(hipStreamSynchronize(st));
@@ -814,13 +776,14 @@ static int launch_score_hint(segk_ctx *ctx, ScoreArgs A, const int32_t *remap, i
         if (whole > 0 && total_groups - whole <= 32) k1_groups = whole;
     }
     {
-        const int64_t nthr = A.n > A.K_max ? A.n : A.K_max;
+        const int64_t skipped = A.n - k1_groups * 64 > 0 ? A.n - k1_groups * 64 : 0;
+        const int64_t nthr = skipped > A.K_max ? skipped : A.K_max;
         hipLaunchKernelGGL(k_hint_map, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, remap, A.tiles + 1024, A.K_max, stride_sp,
-                           KS * 2 * 256, ctx->hint_map, A.ids, A.row0, A.n, A.cand.k, zero_cnt, ctx->pre_queue, fb_w, fb_t, fb_cur,
+                           KS * 2 * 256, ctx->hint_map, A.n, zero_cnt, ctx->pre_queue, fb_w, fb_t, fb_cur,
                            fb_split, total_groups, k1_groups * 64, (float2 *)ctx->hint_part, n_ranges);
     }
 
-    // ---- K1
+    // ---- K1: matrix waves (top-2 values per row and range) + hint waves (the hinted component in reference arithmetic)
     HintArgs H{};
     H.ximg = (const unsigned char *)A.X32;
     H.ids = A.ids; H.row0 = A.row0; H.n = A.n;
@@ -837,12 +800,29 @@ static int launch_score_hint(segk_ctx *ctx, ScoreArgs A, const int32_t *remap, i
     H.fb_cur = fb_cur;
     H.fb_split = fb_split;
     H.k1_groups = k1_groups;
-    const size_t lds1 = (size_t)tpr * TL * sizeof(float);
-    SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_kmeans_top2_rs<KS, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+    H.xrows32 = A.xrows32;
+    H.ld32 = A.ld32;
+    H.means32 = A.means32;
+    H.cand_k = A.cand.k;
+    H.map = ctx->hint_map;
+    H.nxx = A.xerr + n_emb;                                      // -|x|^2 per row, behind the residual norms
+    H.hint_out = (float4 *)((unsigned char *)ctx->hint_part + part_bytes);
+    const size_t lds1 = (size_t)tpr * TL * sizeof(float) + map_bytes;
     const bool prof = segk_prof_now(ctx);
     const int slot = ctx->prof_n % SEGK_PROF_SLOTS;
-    if (prof) SEGK_CHECK_HIP(hipEventRecord(ctx->prof_ev[slot][0], st));
-    hipLaunchKernelGGL((k_kmeans_top2_rs<KS, 4>), dim3((unsigned)grid1), dim3(256), lds1, st, H);
+#define SEGK_K1_LAUNCH(VV)                                                                                                  \
+    do {                                                                                                                     \
+        SEGK_CHECK_HIP(segk_dyn_lds((const void *)k_kmeans_top2_rs<KS, VV, 4>, lds1));                                       \
+        if (prof) SEGK_CHECK_HIP(hipEventRecord(ctx->prof_ev[slot][0], st));                                                 \
+        hipLaunchKernelGGL((k_kmeans_top2_rs<KS, VV, 4>), dim3((unsigned)grid1), dim3(512), lds1, st, H);                    \
+    } while (0)
+    switch ((16 * KS - A.D) / 4) {
+        case 0: SEGK_K1_LAUNCH(0); break;
+        case 1: SEGK_K1_LAUNCH(1); break;
+        case 2: SEGK_K1_LAUNCH(2); break;
+        default: SEGK_K1_LAUNCH(3); break;
+    }
+#undef SEGK_K1_LAUNCH
     if (prof) {
         SEGK_CHECK_HIP(hipEventRecord(ctx->prof_ev[slot][1], st));
         ctx->prof_rows[slot] = A.n;
@@ -851,36 +831,21 @@ static int launch_score_hint(segk_ctx *ctx, ScoreArgs A, const int32_t *remap, i
         ctx->prof_n++;
     }
 
-    // ---- K2: the float32 table in LDS, split into P ranges
-    HintExactArgs E{};
+    // ---- K2: the certificate, one thread per row
+    HintMergeArgs E{};
     E.part = (const float2 *)ctx->hint_part;
+    E.hint_out = H.hint_out;
     E.n_ranges = n_ranges;
-    E.map = ctx->hint_map;
-    E.n_emb = n_emb;
     E.tiles_hdr = A.tiles;
     E.ximg = (const unsigned char *)A.X32;
-    const int pitch4 = ((A.D >> 2) + ((2 - (A.D >> 2)) & 3)) * 16;
-    constexpr int NW = 8;
-    const int64_t fixed_b = (int64_t)((A.K_max + 3) & ~3) * 4 + (int64_t)NW * (3 * SEGK_HINT_RING + SEGK_HINT_UBUF) * 4;
-    const int64_t cpp_max = (160 * 1024 - fixed_b) / pitch4;
-    SEGK_REQUIRE(cpp_max > 0, "hinted score path: no room for the component table");
-    const int parts = (int)((A.K_max + cpp_max - 1) / cpp_max);
-    SEGK_REQUIRE(parts <= n_cu, "hinted score path: more table ranges than CUs");
-    const int cpp = (A.K_max + parts - 1) / parts;
-    const size_t lds2 = (size_t)cpp * pitch4 + (size_t)fixed_b;
-    const unsigned grid2 = (unsigned)((n_cu / parts) * parts);
-#define SEGK_HINT_LAUNCH(VV)                                                                                                       \
-    do {                                                                                                                            \
-        SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_kmeans_hint_exact<KS, VV, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2)); \
-        hipLaunchKernelGGL((k_kmeans_hint_exact<KS, VV, NW>), dim3(grid2), dim3(64 * NW), lds2, st, A, E, parts, cpp);              \
-    } while (0)
-    switch ((16 * KS - A.D) / 4) {
-        case 0: SEGK_HINT_LAUNCH(0); break;
-        case 1: SEGK_HINT_LAUNCH(1); break;
-        case 2: SEGK_HINT_LAUNCH(2); break;
-        default: SEGK_HINT_LAUNCH(3); break;
+    {
+        // four workgroups per CU, each a contiguous run of at most SEGK_MERGE_ROWS rows
+        int64_t grid2 = 4 * (int64_t)n_cu;
+        if (grid2 * 256 > A.n) grid2 = (A.n + 255) / 256;
+        if (grid2 * SEGK_MERGE_ROWS < A.n) grid2 = (A.n + SEGK_MERGE_ROWS - 1) / SEGK_MERGE_ROWS;
+        const int64_t per = (A.n + grid2 - 1) / grid2;
+        hipLaunchKernelGGL(k_hint_merge, dim3((unsigned)grid2), dim3(256), 0, st, A, E, KS * 16, per);
     }
-#undef SEGK_HINT_LAUNCH
     // ---- the rows K2 queued: all three products (the pre-filter's second stage); its own undecided rows go to cand.queue
     ScoreArgs B = A;
     B.ids = A.pre_queue;

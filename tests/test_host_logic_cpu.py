@@ -144,7 +144,11 @@ def test_bench_starts_its_own_ranks_when_no_launcher_did(monkeypatch):
         seen["cmd"], seen["env"] = cmd, env
         return FakeProc()
 
+    class FakeRun(object):
+        stdout = "0\n"
+
     monkeypatch.setattr(subprocess, "Popen", fake_popen)
+    monkeypatch.setattr(subprocess, "run", lambda *a, **k: FakeRun())
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3"])
     monkeypatch.delenv("WORLD_SIZE", raising=False)
     monkeypatch.delenv("SEGK_BENCH_BACKEND", raising=False)

@@ -9,7 +9,7 @@
 #     shards    bench.py --utts 5000 / 2500 / 1250 (the per-rank share at 2 / 4 / 8 GPUs, no collective)
 #     variants  the other filters (SEGK_SCORE_HINT=0, SEGK_SCORE_PRE=0, SEGK_SCORE_B3=0)
 #     workloads bench.py --workload bigram_c5 / fbgmm_diag_c2 / kmeans_c3_sequential
-#     rehearse  bench.py --gpus 2 / 4 / 6 self-launched, gloo, all ranks on the one card (plumbing of the multi-GPU run)
+#     rehearse  bench.py --gpus 2 / 4 self-launched (4 ranks + launcher + parent: the box admits six processes), gloo, all ranks on the one card (plumbing of the multi-GPU run)
 #     clean     delete the rocpd databases of this session (after stats / timeline / pmc have been summarised)
 # Copy what is to be judged from gpurun_out/TAG/ into profiles/ (named rNN_TAG_*).
 set -o pipefail
@@ -52,7 +52,7 @@ workloads)
     timeout -k 10 400 python bench.py --workload fbgmm_diag_c2 > $O/bench_fbgmm_diag_c2.json 2> /dev/null; cut -c1-200 $O/bench_fbgmm_diag_c2.json
     timeout -k 10 400 python bench.py --workload kmeans_c3_sequential > $O/bench_kmeans_c3_sequential.json 2> /dev/null; cut -c1-200 $O/bench_kmeans_c3_sequential.json ;;
 rehearse)   # the N > 1 launcher and transport on ONE card: `python bench.py --gpus N` starts its own torchrun child, gloo backend
-    for n in 2 4 6; do timeout -k 10 500 python bench.py --gpus $n --cpu-utts 0 --steps 20 --warmup 5 > $O/bench_gpus${n}_gloo.json 2> $O/bench_gpus${n}_gloo.err || { tail -20 $O/bench_gpus${n}_gloo.err; exit 1; }; v "gpus=$n" $O/bench_gpus${n}_gloo.json; done ;;
+    for n in 2 4; do timeout -k 10 500 python bench.py --gpus $n --cpu-utts 0 --steps 20 --warmup 5 > $O/bench_gpus${n}_gloo.json 2> $O/bench_gpus${n}_gloo.err || { tail -20 $O/bench_gpus${n}_gloo.err; exit 1; }; v "gpus=$n" $O/bench_gpus${n}_gloo.json; done ;;
 *) echo "unknown step $S"; exit 2 ;;
 esac
 done
