@@ -98,6 +98,8 @@ int32_t segk_destroy(segk_ctx *ctx)
         if (ctx->hint_map) (void)hipFree(ctx->hint_map);
         if (ctx->ws_u64) (void)hipFree(ctx->ws_u64);
         if (ctx->hint_fb) (void)hipFree(ctx->hint_fb);
+        if (ctx->pre_thr) (void)hipFree(ctx->pre_thr);
+        if (ctx->band_mask) (void)hipFree(ctx->band_mask);
         if (ctx->brute_ws) (void)hipFree(ctx->brute_ws);
         if (ctx->pre_queue) (void)hipFree(ctx->pre_queue);
         if (ctx->row_hash) (void)hipFree(ctx->row_hash);

@@ -51,6 +51,10 @@ struct segk_ctx {
     size_t hint_part_bytes;
     int32_t *hint_map;
     int hint_map_k;
+    float *pre_thr;              // band stage (segk_score_band.hip): threshold per entry of pre_queue
+    int64_t pre_thr_cap;
+    void *band_mask;             // its candidate masks, [ranges][queue capacity][2] x 16 bytes
+    size_t band_mask_bytes;
     void *hint_fb;               // per-XCD shares and wave lifetimes of the matrix kernel's last launches, [3][8] floats + [3][8] uint32
     unsigned int hint_fb_launch;
     // full scan with the components in LDS (k_kmeans_brute_ls): (score, component) per queue entry, zero between uses

@@ -591,37 +591,40 @@ struct HintMergeArgs {
 // anything else -- no hint, a wrong hint, a near-tie -- is queued for the second stage (one reservation per wave).  One thread
 // per row, 48 bytes read and 12 written: the whole exact stage of round 3 (k_kmeans_hint_exact, 129 us) shrunk to this pass,
 // its arithmetic moved under K1's matrix work.
-#define SEGK_MERGE_ROWS 4096        /* rows per workgroup at most (its list of undecided rows in LDS) */
-__global__ __launch_bounds__(256) void k_hint_merge(ScoreArgs A, HintMergeArgs H, int KP, int64_t per)
+#define SEGK_MERGE_ROWS 6144        /* rows per workgroup at most (its list of undecided rows in LDS) */
+#define SEGK_MERGE_THREADS 1024
+__global__ __launch_bounds__(SEGK_MERGE_THREADS) void k_hint_merge(ScoreArgs A, HintMergeArgs H, int KP, int64_t per, float *pre_thr, int64_t first_skipped)
 {
-    // ONE queue reservation per workgroup: returning atomics on one address are served one after the other (a first version
-    // with one per wave -- 15 600 of them -- took 185 us for 55 MB of traffic); the workgroup's undecided rows wait in LDS
+    // ONE queue reservation per workgroup, one workgroup per CU: returning atomics on one address are served one after the other,
+    // ~11 ns each (a first version with one per wave -- 15 600 of them -- took 185 us for 55 MB of traffic, 1 024 workgroups
+    // still 25 us); the workgroup's undecided rows wait in LDS
     __shared__ int32_t ulist[SEGK_MERGE_ROWS];
+    __shared__ float uthr[SEGK_MERGE_ROWS];         // per undecided row: top1 - tau in the scaled domain (the band stage's threshold)
     __shared__ int32_t ucnt, ubase;
     const int tid = threadIdx.x, lane = tid & 63;
     if (tid == 0) ucnt = 0;
     __syncthreads();
     const int64_t p_lo = (int64_t)blockIdx.x * per, p_hi = p_lo + per < A.n ? p_lo + per : A.n;
     const int e_ab = ((const int *)H.ximg)[1] + ((const int *)H.tiles_hdr)[0];
-    const float unscale = ldexpf(1.f, -e_ab);
+    const float unscale = ldexpf(1.f, -e_ab), scale = ldexpf(1.f, e_ab);
     const float M = (float)(sqrt(*A.mnorm2) * (1.0 + 1e-6)) + 1e-30f;
     const float Em = H.tiles_hdr[1];
     // four rows per thread and trip, their loads in flight together (one row per trip was four dependent round trips per
     // workgroup: 25 us for 55 MB)
     constexpr int U = 4;
-    for (int64_t p0 = p_lo; p0 < p_hi; p0 += 256 * U) {
+    for (int64_t p0 = p_lo; p0 < p_hi; p0 += SEGK_MERGE_THREADS * U) {
         int32_t rid[U];
         float4 ho[U];
         float t1[U], t2[U], xnb[U], xer[U];
 #pragma unroll
         for (int j = 0; j < U; j++) {
-            const int64_t p = p0 + j * 256 + tid;
+            const int64_t p = p0 + j * SEGK_MERGE_THREADS + tid;
             rid[j] = -1;
             if (p < p_hi) rid[j] = A.ids ? A.ids[p] : (int32_t)(A.row0 + p);
         }
 #pragma unroll
         for (int j = 0; j < U; j++) {
-            const int64_t p = p0 + j * 256 + tid;
+            const int64_t p = p0 + j * SEGK_MERGE_THREADS + tid;
             ho[j] = make_float4(0.f, 0.f, __int_as_float(-1), 0.f);
             t1[j] = NEG_INF_F; t2[j] = NEG_INF_F; xnb[j] = 0.f; xer[j] = 0.f;
             if (rid[j] >= 0) {
@@ -639,13 +642,22 @@ __global__ __launch_bounds__(256) void k_hint_merge(ScoreArgs A, HintMergeArgs H
 #pragma unroll
         for (int j = 0; j < U; j++) {
             bool und = false;
-            if (rid[j] >= 0) {
+            float thr = 0.f;
+            if (rid[j] >= 0 && p0 + j * SEGK_MERGE_THREADS + tid >= first_skipped) {
+                // a row K1 left out (the few groups behind the last whole round of its waves): no filter values, full scan
+                const int q2 = atomicAdd(A.cand.count, 1);
+                if (q2 < A.amb_cap) A.cand.queue[q2] = rid[j];
+            } else if (rid[j] >= 0) {
                 const int32_t hint = __float_as_int(ho[j].z);
                 und = true;
+                const float tau = filter_tau_h1(xnb[j], M, A.D, xer[j], Em);
+                // the band the reference's argmax lies in: F >= top1 - tau (scaled domain; the subtraction's own rounding and a
+                // little more taken off)
+                thr = t1[j] - tau * scale * 1.000001f;
+                thr -= 4e-7f * fabsf(t1[j]);
                 if (hint >= 0) {
                     const float top1 = t1[j] * unscale, top2 = t2[j] * unscale;          // powers of two: exact
                     const float u = 5.9604645e-8f;
-                    const float tau = filter_tau_h1(xnb[j], M, A.D, xer[j], Em);
                     // E: bound of |F_k - f_k| (accumulation + operand rounding, the terms of tau); dl: of the computed f_h
                     const float e1 = (1.02f * (float)(KP + 16) + 16.f) * u * (xnb[j] * M + 0.5f * M * M);
                     const float rnd = 1.00001f * fminf((xnb[j] + xer[j]) * Em + xer[j] * M, 1.01f * 9.765625e-4f * xnb[j] * M);
@@ -665,7 +677,10 @@ __global__ __launch_bounds__(256) void k_hint_merge(ScoreArgs A, HintMergeArgs H
                 int base = 0;
                 if (lane == 0) base = atomicAdd(&ucnt, __popcll(mask));           // LDS
                 base = __shfl(base, 0);
-                if (und) ulist[base + before] = rid[j];
+                if (und) {
+                    ulist[base + before] = rid[j];
+                    uthr[base + before] = thr;
+                }
             }
         }
     }
@@ -675,11 +690,13 @@ __global__ __launch_bounds__(256) void k_hint_merge(ScoreArgs A, HintMergeArgs H
     if (tid == 0) ubase = atomicAdd(A.pre_count, cnt);
     __syncthreads();
     const int base = ubase;
-    for (int i = tid; i < cnt; i += 256) {
+    for (int i = tid; i < cnt; i += SEGK_MERGE_THREADS) {
         const int q = base + i;
         const int32_t rid = ulist[i];
-        if (q < A.pre_cap) A.pre_queue[q] = rid;
-        else {                                                 // beyond the second stage's launch: full scan
+        if (q < A.pre_cap) {
+            A.pre_queue[q] = rid;
+            if (pre_thr) pre_thr[q] = uthr[i];
+        } else {                                               // beyond the second stage's launch: full scan
             const int q2 = atomicAdd(A.cand.count, 1);
             if (q2 < A.amb_cap) A.cand.queue[q2] = rid;
         }
@@ -703,6 +720,16 @@ static int launch_score_hint(segk_ctx *ctx, ScoreArgs A, const int32_t *remap, i
     A.pre_queue = ctx->pre_queue + 16;
     A.pre_count = ctx->pre_queue;
     A.pre_cap = (int)A.n;
+    const bool band = segk_band_applies(A);
+    if (band && ctx->pre_thr_cap < A.n) {
+        SEGK_REQUIRE(!ctx->capturing, "workspaces must exist before a graph capture (run the sequence once first)");
+        SEGK_CHECK_HIP(hipStreamSynchronize(st));
+        if (ctx->pre_thr) (void)hipFree(ctx->pre_thr);
+        ctx->pre_thr = nullptr;
+        ctx->pre_thr_cap = 0;
+        SEGK_CHECK_HIP(hipMalloc((void **)&ctx->pre_thr, sizeof(float) * (size_t)A.n));
+        ctx->pre_thr_cap = A.n;
+    }
     // K1's ranges: as many tiles as fit in LDS beside nothing else (one workgroup per CU)
     constexpr int TL = KS * 256 + 32;
     const size_t map_bytes = (size_t)((A.K_max + 3) & ~3) * sizeof(int32_t);          // the hint waves' label map behind the images
@@ -839,12 +866,19 @@ static int launch_score_hint(segk_ctx *ctx, ScoreArgs A, const int32_t *remap, i
     E.tiles_hdr = A.tiles;
     E.ximg = (const unsigned char *)A.X32;
     {
-        // four workgroups per CU, each a contiguous run of at most SEGK_MERGE_ROWS rows
-        int64_t grid2 = 4 * (int64_t)n_cu;
-        if (grid2 * 256 > A.n) grid2 = (A.n + 255) / 256;
+        // one workgroup per CU, each a contiguous run of at most SEGK_MERGE_ROWS rows
+        int64_t grid2 = (int64_t)n_cu;
+        if (grid2 * SEGK_MERGE_THREADS > A.n) grid2 = (A.n + SEGK_MERGE_THREADS - 1) / SEGK_MERGE_THREADS;
         if (grid2 * SEGK_MERGE_ROWS < A.n) grid2 = (A.n + SEGK_MERGE_ROWS - 1) / SEGK_MERGE_ROWS;
         const int64_t per = (A.n + grid2 - 1) / grid2;
-        hipLaunchKernelGGL(k_hint_merge, dim3((unsigned)grid2), dim3(256), 0, st, A, E, KS * 16, per);
+        hipLaunchKernelGGL(k_hint_merge, dim3((unsigned)grid2), dim3(SEGK_MERGE_THREADS), 0, st, A, E, KS * 16, per, band ? ctx->pre_thr : nullptr,
+                           k1_groups * 64);
+    }
+    // ---- the rows the certificate could not decide: candidates inside the band of the filter's maximum, scored in the
+    // reference's arithmetic (segk_score_band.hip); tables beyond its reach keep round 3's three-product second stage
+    if (band) {
+        if (int rc = segk_launch_band(ctx, A, ctx->pre_thr, KS, st)) return rc;
+        return SEGK_OK;
     }
     // ---- the rows K2 queued: all three products (the pre-filter's second stage); its own undecided rows go to cand.queue
     ScoreArgs B = A;
