@@ -47,8 +47,9 @@ const char *segk_last_error(void);
  *   1 rounds 1-2 | 2 round 2: segk_corpus gained band_W / band_ids / band_dur (the bump was forgotten then)
  *   3 round 3: segk_fbb_set_probe, segk_kmeans_score_hinted; this check
  *   4 round 3: scratch sizes of segk_kmeans_batch_partials from segk_kmeans_batch_scratch_words; segk_profile_enable(N)
- *   5 round 3: segk_fbatch.prior_rows, segk_fbb_prior_rows                                                                      */
-#define SEGK_ABI_VERSION 5
+ *   5 round 3: segk_fbatch.prior_rows, segk_fbb_prior_rows
+ *   6 round 4: segk_kmeans_hint_feedback                                                                                        */
+#define SEGK_ABI_VERSION 6
 int32_t segk_abi_version(void);
 
 /* Timing of the MAIN launch of the MFMA score kernel (k_kmeans_score<..., 0>) with HIP events
@@ -198,8 +199,11 @@ int32_t segk_kmeans_score(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans
  * segk_kmeans_batch_finalize leaves in remap_scratch; NULL = identity; values outside [0, K_max) = no hint).  The library
  * still evaluates every (row, component) product on the matrix cores, but only VERIFIES the hint against them (the two
  * largest filter values and the hinted component's reference-arithmetic score; proof in segk_score_hint.hip) instead of
- * tracking which component won; rows whose hint cannot be verified take the stages of segk_kmeans_score.  On return cand->k /
+ * tracking which component won; rows whose hint cannot be verified are settled among the components inside the band of the
+ * filter's maximum (segk_score_band.hip; tables of more than 2048 slots: the second stage of segk_kmeans_score), what is left
+ * takes the full scan.  On return cand->k /
  * cand->s are bit-identical to segk_kmeans_score's whatever the hints were: a wrong hint costs time, never correctness.
+ * A segk_ctx serves one stream at a time: the path's workspaces and the per-XCD shares of its matrix kernel are the context's.
  * Applies to float32 data with the fp16x2 row image (c->Xb3, sp_pieces 2), D % 4 == 0, launches of more than 384 rows per
  * CU; everything else is forwarded to segk_kmeans_score.                                                               */
 int32_t segk_kmeans_score_hinted(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m,
@@ -223,6 +227,15 @@ int32_t segk_kmeans_resolve(segk_ctx *ctx, const segk_corpus *c, const segk_kmea
  * rows in the ambiguity queue `cand->queue` (full reference-arithmetic scan).  out [host] int32 [2];
  * synchronises `stream`.                                                                          */
 int32_t segk_kmeans_stage_counts(segk_ctx *ctx, const segk_cand *cand, int32_t *out, void *stream);
+
+/* How well the hints of segk_kmeans_score_hinted are doing, WITHOUT touching any stream (no reference counterpart): hinted
+ * calls on a context are numbered 1, 2, ...; *launched = number of the last one enqueued, *seen = number of the latest one
+ * whose figure has reached the host (0: none yet; the device writes it into pinned host memory while the call runs),
+ * *permille = thousandths of that call's rows the certificate could not decide (wrong or missing hints + near-ties).  A
+ * driver that enqueues sweeps asynchronously uses it to leave the hints out (segk_kmeans_score) while most of them are
+ * wrong -- the first sweeps of a chain --, where the hinted path would be the slower one; results do not depend on it.
+ * launched, seen [host] uint32, permille [host] int32.                                                                  */
+int32_t segk_kmeans_hint_feedback(segk_ctx *ctx, uint32_t *launched, uint32_t *seen, int32_t *permille);
 
 /* Gather of the A1 results for rows ids[0..n) (0..n-1 when NULL): out_max[r] (double, widened
  * from the dtype of X) and out_arg[r] = np.max / np.argmax of neg_sqrd_norm(ids[r])

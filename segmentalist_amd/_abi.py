@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SEGK_LIB_PATH") or os.path.join(_HERE, "libsegk.so")      # (SEGK_LIB_PATH: a development build kept beside the product build)
 
 SEGK_F32, SEGK_F64 = 0, 1
-ABI_VERSION = 5          # SEGK_ABI_VERSION of include/segk.h this binding was written against
+ABI_VERSION = 6          # SEGK_ABI_VERSION of include/segk.h this binding was written against
 
 
 class SegkError(RuntimeError):
@@ -88,6 +88,7 @@ SIGNATURES = {
     "segk_kmeans_filter": (_i32, [_P, _CP, _KP, _P, _i64, _i64, _DP, _P]),
     "segk_kmeans_resolve": (_i32, [_P, _CP, _KP, _P, _i64, _i64, _DP, _P, _P]),
     "segk_kmeans_stage_counts": (_i32, [_P, _DP, C.POINTER(_i32), _P]),
+    "segk_kmeans_hint_feedback": (_i32, [_P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(_i32)]),
     "segk_kmeans_exact_max": (_i32, [_P, _CP, _KP, _P, _i64, _DP, _P, _P, _P]),
     "segk_kmeans_neg_sqrd_norm": (_i32, [_P, _CP, _KP, _i64, _P, _P]),
     "segk_kmeans_segment": (_i32, [_P, _CP, _KP, _P, _i32, _i32, _i32, _i32, _f64, _DP, _P, _P, _P, _P, _P, _P,

@@ -71,6 +71,21 @@ int32_t segk_create(int32_t device_id, segk_ctx **out_ctx)
     if (err == hipSuccess) { what = "hipMemset(ws_u64)"; err = hipMemset(c->ws_u64, 0, sizeof(unsigned long long) * SEGK_WS_ENTRIES); }
     // (a device memset is not ordered before kernels of the caller's non-blocking streams: the workspace must read zero at its first use)
     if (err == hipSuccess) { what = "hipDeviceSynchronize"; err = hipDeviceSynchronize(); }
+    if (err == hipSuccess) {
+        // the feedback word of the hinted score path: pinned host memory the device writes directly (optional: without it
+        // segk_kmeans_hint_feedback reports that nothing has arrived)
+        void *hp = nullptr, *dp = nullptr;
+        if (hipHostMalloc(&hp, 64, hipHostMallocMapped) == hipSuccess) {
+            memset(hp, 0, 64);
+            if (hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess) {
+                c->miss_host = (volatile unsigned long long *)hp;
+                c->miss_dev = (unsigned long long *)dp;
+            } else {
+                (void)hipHostFree(hp);
+            }
+        }
+        (void)hipGetLastError();
+    }
     if (prev >= 0) {
         const hipError_t back = hipSetDevice(prev);
         if (err == hipSuccess && back != hipSuccess) { what = "hipSetDevice(previous)"; err = back; }
@@ -100,6 +115,7 @@ int32_t segk_destroy(segk_ctx *ctx)
         if (ctx->hint_fb) (void)hipFree(ctx->hint_fb);
         if (ctx->pre_thr) (void)hipFree(ctx->pre_thr);
         if (ctx->band_mask) (void)hipFree(ctx->band_mask);
+        if (ctx->miss_host) (void)hipHostFree((void *)ctx->miss_host);
         if (ctx->brute_ws) (void)hipFree(ctx->brute_ws);
         if (ctx->pre_queue) (void)hipFree(ctx->pre_queue);
         if (ctx->row_hash) (void)hipFree(ctx->row_hash);
@@ -223,6 +239,25 @@ int32_t segk_kmeans_stage_counts(segk_ctx *ctx, const segk_cand *cand, int32_t *
     if (ctx->pre_queue) {
         out[0] = 0;
         for (int i = 0; i < 16; i++) out[0] += hdr[i];
+    }
+    return SEGK_OK;
+}
+
+// How many rows the hinted score path's certificate left undecided, WITHOUT touching the stream: the band kernel of call number
+// q writes (q << 32) | permille into pinned host memory; *launched = number of the last hinted call enqueued on this context,
+// *seen = number of the latest call whose figure has arrived (0: none yet), *permille = that figure.  Lets a driver that
+// enqueues sweeps asynchronously stop passing hints while most of them are wrong (early sweeps of a chain) -- results are the
+// same either way, only the time differs.
+int32_t segk_kmeans_hint_feedback(segk_ctx *ctx, uint32_t *launched, uint32_t *seen, int32_t *permille)
+{
+    SEGK_REQUIRE(ctx && launched && seen && permille, "arguments");
+    *launched = ctx->miss_seq;
+    *seen = 0;
+    *permille = 0;
+    if (ctx->miss_host) {
+        const unsigned long long w = *ctx->miss_host;
+        *seen = (uint32_t)(w >> 32);
+        *permille = (int32_t)(w & 0xffffffffull);
     }
     return SEGK_OK;
 }

@@ -55,6 +55,11 @@ struct segk_ctx {
     int64_t pre_thr_cap;
     void *band_mask;             // its candidate masks, [ranges][queue capacity][2] x 16 bytes
     size_t band_mask_bytes;
+    // hinted path feedback (segk_kmeans_hint_feedback): host-mapped word the band kernel writes, (call number << 32) | permille
+    // of the call's rows the certificate could not decide; no stream command, no synchronisation
+    volatile unsigned long long *miss_host;
+    unsigned long long *miss_dev;
+    unsigned int miss_seq;
     void *hint_fb;               // per-XCD shares and wave lifetimes of the matrix kernel's last launches, [3][8] floats + [3][8] uint32
     unsigned int hint_fb_launch;
     // full scan with the components in LDS (k_kmeans_brute_ls): (score, component) per queue entry, zero between uses

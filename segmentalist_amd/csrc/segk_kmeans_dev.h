@@ -789,7 +789,7 @@ int segk_dispatch_score_pre(segk_ctx *ctx, const ScoreArgs &A, int ks, hipStream
 int segk_dispatch_score_hint(segk_ctx *ctx, const ScoreArgs &A, const int32_t *remap, int64_t n_emb, int ks, hipStream_t st);
 // segk_score_band.hip: the hinted path's undecided rows -- candidates inside the band of the filter's maximum, exact scores
 bool segk_band_applies(const ScoreArgs &A);
-int segk_launch_band(segk_ctx *ctx, const ScoreArgs &A, const float *thr, int ks, hipStream_t st);
+int segk_launch_band(segk_ctx *ctx, const ScoreArgs &A, const float *thr, int64_t call_rows, int ks, hipStream_t st);
 // segk_exact.hip / segk_stats.hip: the pieces of the sequential (reference-chain) sweep
 int segk_launch_seq_score(const segk_corpus *c, const segk_kmeans *m, int utt, const segk_cand *cand, unsigned long long *keys,
                           hipStream_t st);

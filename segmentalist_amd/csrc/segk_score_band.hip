@@ -39,6 +39,9 @@ struct BandArgs {
     const float *tiles;             // first tile of the fp16x2 tile image (tiles_b3 + 1024)
     int n_tiles, n_ranges;
     int4 *mask;                     // [n_ranges][cap][2 lane halves] four words each
+    unsigned long long *fb;         // host-mapped feedback word (NULL: none): (fb_seq << 32) | permille of fb_rows that were queued
+    unsigned int fb_seq;
+    int64_t fb_rows;
 };
 
 // four values: bit = (value >= thr), shifted in from the right (value q of a tile ends at bit 15 - q of its half word)
@@ -77,6 +80,10 @@ __global__ __launch_bounds__(256, 2) void k_kmeans_band_rs(BandArgs B)
     int count = *B.n_dev;
     if (count > B.cap) count = B.cap;
     const int64_t n_groups = ((int64_t)count + 32 * NBLK - 1) / (32 * NBLK);
+    if (B.fb && blockIdx.x == 0 && tid == 0) {
+        const unsigned long long pm = B.fb_rows > 0 ? (unsigned long long)((int64_t)count * 1000 / B.fb_rows) : 0ull;
+        __hip_atomic_store(B.fb, ((unsigned long long)B.fb_seq << 32) | pm, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     // workgroup -> (range, slot); the R workgroups that stream the same queue entries share an XCD when the grid allows
     int range, wgr, n_wgr;
     if ((gridDim.x & 7) == 0 && ((gridDim.x >> 3) % R) == 0) {
@@ -397,7 +404,7 @@ __global__ __launch_bounds__(256) void k_band_exact(BandExactArgs E)
 
 // ---------------------------------------------------------------------------------------------------------------------
 template <int KS>
-static int launch_band(segk_ctx *ctx, const ScoreArgs &A, const float *thr, hipStream_t st)
+static int launch_band(segk_ctx *ctx, const ScoreArgs &A, const float *thr, int64_t call_rows, hipStream_t st)
 {
     const int n_cu = ctx->n_cu;
     const int n_ranges = (A.n_tiles + SEGK_BAND_TPR - 1) / SEGK_BAND_TPR;
@@ -423,6 +430,9 @@ static int launch_band(segk_ctx *ctx, const ScoreArgs &A, const float *thr, hipS
     B.n_tiles = A.n_tiles;
     B.n_ranges = n_ranges;
     B.mask = (int4 *)ctx->band_mask;
+    B.fb = ctx->miss_dev;
+    B.fb_seq = ++ctx->miss_seq;
+    B.fb_rows = call_rows;
     constexpr int TL = KS * 256 + 32;
     const size_t lds = (size_t)SEGK_BAND_TPR * TL * sizeof(float);
     // two workgroups per CU (58 KB of LDS and 4 x 256 registers each): a (range, slot) pair per workgroup
@@ -468,17 +478,17 @@ bool segk_band_applies(const ScoreArgs &A)
     return n_ranges >= 1 && n_ranges <= SEGK_BAND_MAX_RANGES && A.D % 4 == 0 && A.D >= 8 && A.D <= 128;
 }
 
-int segk_launch_band(segk_ctx *ctx, const ScoreArgs &A, const float *thr, int ks, hipStream_t st)
+int segk_launch_band(segk_ctx *ctx, const ScoreArgs &A, const float *thr, int64_t call_rows, int ks, hipStream_t st)
 {
     switch (ks) {
-        case 1: return launch_band<1>(ctx, A, thr, st);
-        case 2: return launch_band<2>(ctx, A, thr, st);
-        case 3: return launch_band<3>(ctx, A, thr, st);
-        case 4: return launch_band<4>(ctx, A, thr, st);
-        case 5: return launch_band<5>(ctx, A, thr, st);
-        case 6: return launch_band<6>(ctx, A, thr, st);
-        case 7: return launch_band<7>(ctx, A, thr, st);
-        case 8: return launch_band<8>(ctx, A, thr, st);
+        case 1: return launch_band<1>(ctx, A, thr, call_rows, st);
+        case 2: return launch_band<2>(ctx, A, thr, call_rows, st);
+        case 3: return launch_band<3>(ctx, A, thr, call_rows, st);
+        case 4: return launch_band<4>(ctx, A, thr, call_rows, st);
+        case 5: return launch_band<5>(ctx, A, thr, call_rows, st);
+        case 6: return launch_band<6>(ctx, A, thr, call_rows, st);
+        case 7: return launch_band<7>(ctx, A, thr, call_rows, st);
+        case 8: return launch_band<8>(ctx, A, thr, call_rows, st);
         default: break;
     }
     segk_set_error("band stage: D out of range");

@@ -877,7 +877,7 @@ static int launch_score_hint(segk_ctx *ctx, ScoreArgs A, const int32_t *remap, i
     // ---- the rows the certificate could not decide: candidates inside the band of the filter's maximum, scored in the
     // reference's arithmetic (segk_score_band.hip); tables beyond its reach keep round 3's three-product second stage
     if (band) {
-        if (int rc = segk_launch_band(ctx, A, ctx->pre_thr, KS, st)) return rc;
+        if (int rc = segk_launch_band(ctx, A, ctx->pre_thr, A.n, KS, st)) return rc;
         return SEGK_OK;
     }
     // ---- the rows K2 queued: all three products (the pre-filter's second stage); its own undecided rows go to cand.queue

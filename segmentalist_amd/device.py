@@ -440,9 +440,31 @@ class KMeansBatchSweeper(object):
         import os
         self.use_graph = os.environ.get("SEGK_SWEEP_GRAPH", "0") == "1"
         self._graph, self._graph_args, self._side, self._warm = None, None, None, 0
-        self._hints = False          # no sweep of this sweeper has filled cand_k / remap yet
+        # Hints for the score stage (segk_kmeans_score_hinted): every row's argmax of the previous sweep + the relabelling of that
+        # sweep's finalize.  They are passed from the THIRD sweep of a chain on (the first sweep has none; the second would hint
+        # with labels found against the initial means -- on a fresh chain more than half of them are wrong, and verifying a wrong
+        # hint costs more than not hinting), and left out for one sweep whenever the library reports that the certificate of a
+        # recent hinted sweep failed on more than HINT_MISS_PERMILLE of the rows (segk_kmeans_hint_feedback: no synchronisation).
+        # Results are identical either way.
+        self._sweeps_done = 0
+        _l, _s, _p = C.c_uint32(0), C.c_uint32(0), C.c_int32(0)
+        check(dk._L.segk_kmeans_hint_feedback(dk._ctx, C.byref(_l), C.byref(_s), C.byref(_p)))
+        self._fb_seen = _l.value     # figures of hinted calls enqueued before this sweeper existed are not its business
         self._mb = None              # (n_batches, per-step launch tables) of sweep_minibatch
         dk.batch_comm = self.comm
+
+    HINT_MISS_PERMILLE = 450
+
+    def _use_hints(self):
+        if self._sweeps_done < 2:
+            return False
+        launched, seen, permille = C.c_uint32(0), C.c_uint32(0), C.c_int32(0)
+        check(self.dk._L.segk_kmeans_hint_feedback(self.dk._ctx, C.byref(launched), C.byref(seen), C.byref(permille)))
+        if seen.value > self._fb_seen:
+            self._fb_seen = seen.value
+            if permille.value > self.HINT_MISS_PERMILLE:
+                return False
+        return True
 
     # ------------------------------------------------------------------ mini-batch sweeps
     def _minibatch_tables(self, n_batches):
@@ -477,8 +499,12 @@ class KMeansBatchSweeper(object):
         if dk.assign_stale is None:
             dk.ensure_boundaries()
             self._tokens_from_state(boundaries)
+        # (the rows of step j carry the labels of step j of the PREVIOUS sweep, n_batches finalizes old, of which only the last
+        # one's relabelling is in dk.remap: while components are still being removed some hints are stale -- they are verified
+        # like any other and cost one pass of the band stage, never a wrong result)
+        hints = self._use_hints()
         for (utt0, n_utts, row0, n_rows, utts, rows) in self._minibatch_tables(n_batches):
-            remap = dk.remap if self._hints else None
+            remap = dk.remap if hints else None
             if rows is None:
                 dk.score_rows(row0=row0, n=n_rows, hint_remap=remap)
                 dk.segment(boundaries, n_slices_min, n_slices_max, wip, utt0=utt0, n_utts=n_utts)
@@ -493,7 +519,7 @@ class KMeansBatchSweeper(object):
             if pt.world > 1:
                 self.comm.all_gather_rows(self.pack_all, self.pack)
             self._enqueue_back()
-            self._hints = True
+        self._sweeps_done += 1
         dk.assign_stale = (pt.utt_lo, pt.utt_hi, pt.world)
         dk.bounds_stale = (boundaries, pt) if pt.world > 1 else None
 
@@ -502,7 +528,7 @@ class KMeansBatchSweeper(object):
         L, ctx, cp, mp, st = dk._L, dk._ctx, dk._cp(), C.byref(dk.m), _abi.stream()
         # from the second sweep on cand_k holds every row's argmax of the previous sweep and dk.remap the relabelling of
         # that sweep's finalize: hints for the score stage (same results)
-        dk.score_rows(row0=pt.row_lo, n=pt.row_hi - pt.row_lo, hint_remap=dk.remap if self._hints else None)
+        dk.score_rows(row0=pt.row_lo, n=pt.row_hi - pt.row_lo, hint_remap=dk.remap if self._use_hints() else None)
         dk.segment(boundaries, n_slices_min, n_slices_max, wip, utt0=pt.utt_lo, n_utts=pt.utt_hi - pt.utt_lo)
         check(L.segk_kmeans_batch_partials(ctx, cp, mp, ptr(self.blk_lo), pt.nbl, ptr(dk.new_tok), ptr(dk.new_k),
                                            ptr(dk.n_flag), ptr(dk.out_total), ptr(self.sorted), ptr(self.koff),
@@ -526,7 +552,7 @@ class KMeansBatchSweeper(object):
             self._enqueue_back()
         dk.assign_stale = (pt.utt_lo, pt.utt_hi, pt.world)
         dk.bounds_stale = (boundaries, pt) if pt.world > 1 else None
-        self._hints = True
+        self._sweeps_done += 1
 
     # ------------------------------------------------------------------ hipGraph replay
     def _capture(self, fn):

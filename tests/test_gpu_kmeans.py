@@ -153,6 +153,40 @@ def test_a1_hinted_path_vs_oracle_random(gpu, monkeypatch, D, K, n):
     assert np.array_equal(k[live], want_k[live]) and np.array_equal(s[live], want_s[live].astype(np.float64))
 
 
+@pytest.mark.parametrize("K,spread", [(40, 3e-4), (200, 1e-7), (1000, 2e-4)], ids=["tens_of_candidates", "band_overflow", "four_ranges"])
+def test_band_stage_with_crowded_bands(gpu, monkeypatch, K, spread):
+    """The band stage of the hinted path (segk_score_band.hip) where MANY components lie inside the band of a row's largest
+    filter value: the means are tiny perturbations of three base vectors, so every row has its base's whole family as
+    candidates -- a dozen per row (several passes of the candidate list), hundreds (more than a wave's list holds: those rows
+    take the full scan), and the same on four LDS ranges.  Hints right, wrong and absent: cand_k / cand_s == the C oracle."""
+    import torch
+    from oracle import c_oracle as co
+    from segmentalist_amd import _abi
+    monkeypatch.setenv("SEGK_SCORE_HINT", "1")
+    rs = np.random.RandomState(K)
+    D, n = 16, 3000
+    base = rs.randn(3, D)
+    base /= np.linalg.norm(base, axis=1, keepdims=True)
+    means = (base[rs.randint(0, 3, K)] * (1.0 + spread * rs.randn(K, 1)) + spread * rs.randn(K, D)).astype(np.float32)
+    X = base[rs.randint(0, 3, n)] + 0.2 * rs.randn(n, D)
+    X /= np.linalg.norm(X, axis=1, keepdims=True)
+    X = X.astype(np.float32)
+    c = _components(X, means)
+    want_s, want_k = co.kmeans_max_argmax(means, X)
+    ident = torch.arange(K, dtype=torch.int32, device="cuda")
+    for hints in (want_k, rs.randint(0, K, n), np.full(n, -1)):
+        c.dev.cand_k.copy_(torch.from_numpy(np.asarray(hints, dtype=np.int32)).cuda())
+        c.dev.cand_s.fill_(float("nan"))
+        _abi.check(_abi.lib().segk_profile_enable(c.dev._ctx, 1))
+        c.dev.score_rows(hint_remap=ident)
+        torch.cuda.synchronize()
+        assert int(_abi.lib().segk_profile_last_kind(c.dev._ctx)) == 5
+        _abi.check(_abi.lib().segk_profile_enable(c.dev._ctx, 0))
+        assert np.array_equal(c.dev.cand_k.cpu().numpy(), want_k)
+        assert np.array_equal(c.dev.cand_s.cpu().numpy(), want_s.astype(np.float64))
+    c.dev.check_status()
+
+
 def test_a1_filter_candidate_is_within_margin(gpu):
     """The fp32 MFMA filter's winner must be the true argmax or inside the proven margin."""
     import torch
@@ -459,6 +493,50 @@ def test_minibatch_sweep_bit_exact_vs_spec(gpu, n_utt, D, K, nmax, n_blocks, n_b
             assert np.array_equal(cd.means, cr.means), it
             assert rec["sum_neg_len_sqrd_norm"][0] == want, it
             assert rec["n_tokens"][0] == ref.acoustic_model.get_n_assigned()
+
+
+def test_hint_policy_of_the_batch_sweeper(gpu, monkeypatch):
+    """The batch sweeper's use of hints (device.KMeansBatchSweeper._use_hints) at a size where the hinted path applies
+    (3 000 utterances of the headline shape, whole sweeps and two mini-batches per sweep): no hints in the first two sweeps,
+    hints afterwards -- the hinted kernels run (profile kind 5) and the rows the certificate leaves undecided stay a minority
+    (a hint-miss regression -- stale or unmapped hints -- would show here) --, and the state after six sweeps is bit-identical
+    to the same chain with SEGK_SCORE_HINT=0."""
+    import ctypes as C
+    import torch
+    from segmentalist_amd import _abi, kmeans_acoustic_wordseg as kaw
+    from segmentalist_amd.synth import make_corpus
+    corpus = make_corpus(3000, 100, 1000, seed=0, N=20, n_slices_max=6)
+    L, ctx = _abi.lib(), _abi.ctx()
+    for n_batches in (1, 2):
+        states = {}
+        for mode in ("default", "0"):
+            if mode == "0":
+                monkeypatch.setenv("SEGK_SCORE_HINT", "0")
+            else:
+                monkeypatch.delenv("SEGK_SCORE_HINT", raising=False)
+            random.seed(0); np.random.seed(0)
+            seg = kaw.SegmentalKMeansWordseg(1000, *corpus, n_slices_max=6, init_am_assignments="spread", sync="batch",
+                                             n_batches=n_batches)
+            n_rows = seg._corpus.n_emb // n_batches
+            for it in range(6):
+                _abi.check(L.segk_profile_enable(ctx, 1))
+                seg.batch_sweep_async()
+                torch.cuda.synchronize()
+                kind = int(L.segk_profile_last_kind(ctx))
+                _abi.check(L.segk_profile_enable(ctx, 0))
+                sc = (C.c_int32 * 2)()
+                _abi.check(L.segk_kmeans_stage_counts(ctx, C.byref(seg._dk.cand), sc, _abi.stream()))
+                if mode == "default":
+                    assert (kind == 5) == (it >= 2), (n_batches, it, kind)
+                    if it >= 3:
+                        assert 0 < sc[0] < 0.35 * n_rows, (n_batches, it, sc[0], n_rows)
+                else:
+                    assert kind != 5
+            seg._dk.check_status()
+            c = seg.acoustic_model.components
+            states[mode] = (c.assignments.copy(), c.means.copy(), c.counts.copy(), seg.utterances.boundaries.copy())
+        for a, b in zip(states["default"], states["0"]):
+            assert np.array_equal(a, b), n_batches
 
 
 def test_batch_sweep_headline_shape_properties(gpu):
