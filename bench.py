@@ -502,7 +502,7 @@ def main():
     seg = kaw.SegmentalKMeansWordseg(args.K, *corpus, n_slices_max=args.n_slices_max,
                                      init_am_assignments="spread", sync="batch")
     sweeper = seg._get_sweeper()
-    n_emb = seg._corpus.n_emb
+    n_emb = seg.acoustic_model.components.N          # (seg._corpus holds this rank's shard of the rows when world > 1)
     rows_local = sweeper.part.row_hi - sweeper.part.row_lo
 
     def barrier():
@@ -657,6 +657,9 @@ def main():
                 "collective": ("none (single process)" if world == 1 else
                                "%s, world size %d as reported by torch.distributed" % (dist.get_backend(), dist.get_world_size())),
                 "sweep_launch": "hipGraph replay" if sweeper.use_graph else "plain launches",
+                "corpus": ("rows sharded over the ranks: %d of %d on rank 0 (float32 matrix, fp16 planes, per-row work arrays); "
+                           "component statistics replicated" % (seg._corpus.n_emb, n_emb)) if world > 1 else "one device holds all rows",
+                "device_memory_allocated_bytes_rank0": int(torch.cuda.max_memory_allocated()),
                 "components_after": int(seg.acoustic_model.components.K),
             },
         }

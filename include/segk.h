@@ -48,7 +48,7 @@ const char *segk_last_error(void);
  *   3 round 3: segk_fbb_set_probe, segk_kmeans_score_hinted; this check
  *   4 round 3: scratch sizes of segk_kmeans_batch_partials from segk_kmeans_batch_scratch_words; segk_profile_enable(N)
  *   5 round 3: segk_fbatch.prior_rows, segk_fbb_prior_rows
- *   6 round 4: segk_kmeans_hint_feedback                                                                                        */
+ *   6 round 4: segk_kmeans_hint_feedback; flag_rows / flag_row_bytes of the batch statistics (sharded corpus)     */
 #define SEGK_ABI_VERSION 6
 int32_t segk_abi_version(void);
 
@@ -323,7 +323,11 @@ int32_t segk_kmeans_sequential_sweep(segk_ctx *ctx, const segk_corpus *c, segk_k
  * Record of one rank, in 8-byte words (nbl = n_blocks_local, FW = (2 + 3*flag_cap + 1) / 2):
  *   [part_sum nbl*K_max*D double][part_tot nbl double][part_cnt nbl*K_max int64][flags nbl*FW]
  *   flags of a block, as int32: {count, 0, (slot = utt*N_max + t, k, embedding row) x flag_cap};
- *   segk_kmeans_batch_record_words() returns its length.
+ *   with flag_rows (ABI 6: a rank that holds only a SHARD of the corpus -- its own utterances' rows, numbered from 0 -- cannot
+ *   read the rows of other ranks' tokens from X) followed by [rows nbl*RW], RW = (flag_cap * D * sizeof(dtype of X) + 7) / 8:
+ *   the embedding rows of the block's flagged tokens themselves, in list order, which segk_kmeans_batch_finalize then reads
+ *   instead of X (same values, same sums).  segk_kmeans_batch_record_words() returns the record's length
+ *   (flag_row_bytes = D * sizeof(dtype of X) with flag_rows, else 0).
  *
  *  (1) segk_kmeans_batch_partials: per statistics block b (utterances [blk_lo[b], blk_lo[b+1]),
  *      blk_lo [dev] int32 [n_blocks_local + 1]) the sequential fp64 sum of its tokens per component, in
@@ -350,19 +354,20 @@ int32_t segk_kmeans_sequential_sweep(segk_ctx *ctx, const segk_corpus *c, segk_k
  *  flag_cap per block; the tokens beyond were dropped and the statistics of this sweep are NOT usable: restore a
  *  checkpoint or rebuild the state, and sweep again with a larger flag_cap.  There is no per-sweep limit).
  */
-int64_t segk_kmeans_batch_record_words(int32_t K_max, int32_t D, int32_t n_blocks_local, int32_t flag_cap);
+int64_t segk_kmeans_batch_record_words(int32_t K_max, int32_t D, int32_t n_blocks_local, int32_t flag_cap,
+                                       int32_t flag_row_bytes);
 int32_t segk_kmeans_batch_scratch_words(int32_t K_max, int64_t n_slots, int32_t n_blocks_local, int64_t *sorted_words,
                                         int64_t *koff_words);
 int32_t segk_kmeans_batch_partials(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m,
                                    const int32_t *blk_lo, int32_t n_blocks_local,
                                    const int32_t *new_tok, const int32_t *new_k, const int32_t *n_flag,
                                    const double *out_total, int32_t *sorted_scratch,
-                                   int32_t *koff_scratch, double *record, int32_t flag_cap,
+                                   int32_t *koff_scratch, double *record, int32_t flag_cap, int32_t flag_rows,
                                    double *out_scalars, void *stream);
 int32_t segk_kmeans_batch_finalize(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m,
                                    int32_t utt_lo, int32_t utt_hi, const double *records,
                                    int32_t n_blocks_total, int32_t n_blocks_per_rank,
-                                   int64_t rank_stride, int32_t flag_cap, int32_t my_rank,
+                                   int64_t rank_stride, int32_t flag_cap, int32_t flag_rows, int32_t my_rank,
                                    int32_t *new_k, int32_t *remap_scratch, double *out_scalars,
                                    int32_t *status, void *stream);
 /* Record values of a batch sweep in one place (kmeans_acoustic_wordseg.py:405-420 keeps sum_neg_sqrd_norm,

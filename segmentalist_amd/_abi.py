@@ -102,10 +102,10 @@ SIGNATURES = {
     "segk_kmeans_del_item": (_i32, [_P, _CP, _KP, _i64, _P, _P]),
     "segk_kmeans_clean_components": (_i32, [_P, _CP, _KP, _P, _P]),
     "segk_kmeans_del_component": (_i32, [_P, _CP, _KP, _i32, _P, _P]),
-    "segk_kmeans_batch_record_words": (_i64, [_i32, _i32, _i32, _i32]),
+    "segk_kmeans_batch_record_words": (_i64, [_i32, _i32, _i32, _i32, _i32]),
     "segk_kmeans_batch_scratch_words": (_i32, [_i32, _i64, _i32, C.POINTER(_i64), C.POINTER(_i64)]),
-    "segk_kmeans_batch_partials": (_i32, [_P, _CP, _KP, _P, _i32, _P, _P, _P, _P, _P, _P, _P, _i32, _P, _P]),
-    "segk_kmeans_batch_finalize": (_i32, [_P, _CP, _KP, _i32, _i32, _P, _i32, _i32, _i64, _i32, _i32, _P, _P, _P, _P,
+    "segk_kmeans_batch_partials": (_i32, [_P, _CP, _KP, _P, _i32, _P, _P, _P, _P, _P, _P, _P, _i32, _i32, _P, _P]),
+    "segk_kmeans_batch_finalize": (_i32, [_P, _CP, _KP, _i32, _i32, _P, _i32, _i32, _i64, _i32, _i32, _i32, _P, _P, _P, _P,
                                           _P]),
     "segk_kmeans_batch_record": (_i32, [_P, _CP, _KP, _i32, _i32, _P, _P, _P, _P, _P]),
     "segk_kmeans_assignments_from_tokens": (_i32, [_P, _CP, _KP, _i32, _i32, _P, _P, _P, _P]),

@@ -30,9 +30,10 @@ def state_dict(seg):
           "py_random": random.getstate(), "np_random": np.random.get_state()}
     if hasattr(seg, "_dk"):                              # SegmentalKMeansWordseg
         dk = seg._dk
-        dk.ensure_assignments()      # (multi-rank batch mode: a collective, like the boundaries above)
+        # (multi-rank batch mode: a collective, like the boundaries above; a sharded corpus: every rank's rows assembled)
+        assign = dk.global_assignments()
         for name in _KMEANS_FIELDS:
-            sd["km_" + name] = _np(getattr(dk, name))
+            sd["km_" + name] = assign.copy() if name == "assignments" else _np(getattr(dk, name))
     else:                                                # Unigram / Bigram drivers
         sw = seg._sweeper
         if sw is not None and sw.in_batch_state:
@@ -55,7 +56,10 @@ def load_state_dict(seg, sd):
     if hasattr(seg, "_dk"):
         dk = seg._dk
         for name in _KMEANS_FIELDS:
-            _put(getattr(dk, name), sd["km_" + name])
+            if name == "assignments":
+                dk.set_global_assignments(sd["km_" + name])
+            else:
+                _put(getattr(dk, name), sd["km_" + name])
         dk.assign_stale = None
         dk.bounds_stale = None
         dk.prepare()                                     # the MFMA operand image of the means

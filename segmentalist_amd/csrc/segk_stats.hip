@@ -971,6 +971,7 @@ __global__ __launch_bounds__(64 * PART_WAVES) void k_batch_partials(segk_corpus 
 struct PackAddr {
     int nbl, K_max, D, cap;
     int64_t rank_stride;
+    int64_t row_words;      // words per block of the flagged tokens' rows carried in the record (0: the rows are read from X)
     __device__ __forceinline__ int64_t rank_base(int b) const { return (int64_t)(b / nbl) * rank_stride; }
     __device__ __forceinline__ int64_t sum(int b) const { return rank_base(b) + (int64_t)(b % nbl) * K_max * D; }
     __device__ __forceinline__ int64_t tot(int b) const { return rank_base(b) + (int64_t)nbl * K_max * D + (b % nbl); }
@@ -982,7 +983,32 @@ struct PackAddr {
     {
         return rank_base(b) + (int64_t)nbl * K_max * D + nbl + (int64_t)nbl * K_max + (int64_t)(b % nbl) * segk_flag_words(cap);
     }
+    __device__ __forceinline__ int64_t rows(int b) const       // behind the flag lists of all the rank's blocks
+    {
+        return rank_base(b) + (int64_t)nbl * K_max * D + nbl + (int64_t)nbl * K_max + (int64_t)nbl * segk_flag_words(cap) + (int64_t)(b % nbl) * row_words;
+    }
 };
+
+// words of a block's row area when the flagged tokens' embedding rows travel in the record (a rank that holds a shard of the
+// corpus cannot read the rows of other ranks' tokens from X): cap rows of D elements
+static inline __host__ __device__ int64_t segk_flag_row_words(int cap, int D, int elem) { return ((int64_t)cap * D * elem + 7) / 8; }
+
+// the rows of a block's flagged tokens into the record (only with flag_rows; one workgroup per local block, behind the kernel
+// that wrote the flag lists)
+template <typename XT>
+__global__ __launch_bounds__(256) void k_batch_flag_rows(segk_corpus c, const int32_t *flags, int cap, XT *rows, int64_t row_words)
+{
+    const int b = blockIdx.x, D = c.D;
+    const int32_t *fl = flags + (int64_t)b * 2 * segk_flag_words(cap);
+    int n = fl[0];
+    if (n > cap) n = cap;
+    XT *out = reinterpret_cast<XT *>(reinterpret_cast<double *>(rows) + (int64_t)b * row_words);
+    const XT *X = (const XT *)c.X;
+    for (int64_t idx = threadIdx.x; idx < (int64_t)n * D; idx += blockDim.x) {
+        const int i = (int)(idx / D), d = (int)(idx - (int64_t)i * D);
+        out[idx] = X[(int64_t)fl[2 + 3 * i + 2] * c.ldx + d];
+    }
+}
 
 // balanced binary tree over n <= 64 parts, pairing neighbours level by level, odd one carried
 // (np_oracle.tree_sum); v[] is consumed
@@ -1007,7 +1033,7 @@ template <typename XT>
 __global__ __launch_bounds__(256) void k_batch_finalize(
     segk_corpus c, segk_kmeans m, const double *pack, int n_blocks, int nbl, int64_t rank_stride, int cap, int my_rank,
     int32_t *new_k, int32_t *remap, double *out_scalars, int32_t *status, unsigned long long *row_hash,
-    unsigned int *sp_zero_slot, int32_t *ovf, int ovf_cap, int sp_spec)
+    unsigned int *sp_zero_slot, int32_t *ovf, int ovf_cap, int sp_spec, int64_t row_words)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char fin_lds[];
     const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wv = tid >> 6;
@@ -1026,7 +1052,7 @@ __global__ __launch_bounds__(256) void k_batch_finalize(
     __shared__ long long red[4];
     __shared__ int32_t ml[FIN_ROWS][FIN_ML];
     __shared__ int ml_cnt[FIN_ROWS];
-    const PackAddr pa{nbl, K_max, D, cap, rank_stride};
+    const PackAddr pa{nbl, K_max, D, cap, rank_stride, row_words};
     // flagged token q of the sweep: the first SEGK_FLAG_LDS in LDS, the others in ovf [4][ovf_cap] (slot, row, k, block)
     // (the overflow arrays through an explicitly global pointer: left generic, the compiler merges the two sources of an accessor
     // into one flat pointer, and the LDS-aperture test it then needs does not always survive instruction selection)
@@ -1036,6 +1062,12 @@ __global__ __launch_bounds__(256) void k_batch_finalize(
     auto FL_ROW = [&](int q) -> int { return q < SEGK_FLAG_LDS ? fl_row[q] : ovg[(int64_t)ovf_cap + q - SEGK_FLAG_LDS]; };
     auto FL_K = [&](int q) -> int { return q < SEGK_FLAG_LDS ? (int)fl_k[q] : ovg[2 * (int64_t)ovf_cap + q - SEGK_FLAG_LDS]; };
     auto FL_BLK = [&](int q) -> int { return q < SEGK_FLAG_LDS ? (int)fl_blk[q] : ovg[3 * (int64_t)ovf_cap + q - SEGK_FLAG_LDS]; };
+    // element d of flagged token q's embedding row: from X, or -- a sharded corpus -- from the rows the token's rank put into
+    // its record (FL_ROW is then the token's place in its block's list)
+    auto FLX = [&](int q, int d) -> XT {
+        if (row_words) return reinterpret_cast<const XT *>(pack + pa.rows(FL_BLK(q)))[(int64_t)FL_ROW(q) * D + d];
+        return ((const XT *)c.X)[(int64_t)FL_ROW(q) * c.ldx + d];
+    };
     const int64_t *packi = reinterpret_cast<const int64_t *>(pack);
     const int Kb = (int)out_scalars[3];            // K before the sweep (k_batch_sort); *m.K is rewritten by workgroup 0
     const int wg = blockIdx.x;
@@ -1107,14 +1139,15 @@ __global__ __launch_bounds__(256) void k_batch_finalize(
         }
         if (pb < n_blocks && pq < mycnt) {
             const int32_t *fl = reinterpret_cast<const int32_t *>(pack + pa.flg(pb));
-            const int sl = fl[2 + 3 * pq + 0], kr = fl[2 + 3 * pq + 1], rw = fl[2 + 3 * pq + 2];
+            // (row_words: the token's row travels in the record -- its place there, not its row of X, is what is kept)
+            const int sl = fl[2 + 3 * pq + 0], kr = fl[2 + 3 * pq + 1], rw = row_words ? pq : fl[2 + 3 * pq + 2];
             put(at0 + pq, pb, sl, kr, rw);
         }
         int at = 0;
         for (int b = 0; b < n_blocks; b++) {                     // (rare) entries 32.. of a block, blocks 8..
             const int cb = fl_cnt[b] < cap ? fl_cnt[b] : cap;
             const int32_t *fl = reinterpret_cast<const int32_t *>(pack + pa.flg(b));
-            for (int q = (b < nt / 32 ? 32 : 0) + tid; q < cb; q += nt) put(at + q, b, fl[2 + 3 * q + 0], fl[2 + 3 * q + 1], fl[2 + 3 * q + 2]);
+            for (int q = (b < nt / 32 ? 32 : 0) + tid; q < cb; q += nt) put(at + q, b, fl[2 + 3 * q + 0], fl[2 + 3 * q + 1], row_words ? q : fl[2 + 3 * q + 2]);
             at += cb;
         }
         if (at > SEGK_FLAG_LDS) __threadfence();                  // overflow entries: written by many threads, read by others below
@@ -1231,7 +1264,7 @@ __global__ __launch_bounds__(256) void k_batch_finalize(
     XT *__restrict__ means = (XT *)m.means;
     double *__restrict__ numer = m.mean_numerators;
     const XT *__restrict__ rnd = (const XT *)m.random_means;
-    const XT *__restrict__ X = (const XT *)c.X;
+    (void)0;   // (the rows of X are read through FLX: from X, or from the record when the corpus is sharded)
     const double *__restrict__ rpack = pack;
     const int nel = FIN_ROWS * D;
     for (int e0 = 0; e0 < nel; e0 += 4 * 256) {
@@ -1287,7 +1320,7 @@ __global__ __launch_bounds__(256) void k_batch_finalize(
                     for (int i = 0; i < 4; i++) {
                         const int qq = ml[r][i0 + i < nmr ? i0 + i : nmr - 1];
                         bq[i] = FL_BLK(qq);
-                        xq[i] = X[(int64_t)FL_ROW(qq) * c.ldx + d];
+                        xq[i] = FLX(qq, d);
                     }
 #pragma unroll
                     for (int i = 0; i < 4; i++)
@@ -1306,7 +1339,7 @@ __global__ __launch_bounds__(256) void k_batch_finalize(
                 } else {
                     for (int b = 0; b < n_blocks; b++) gv[b] = 0.0;
                     for (int q = 0; q < nfl; q++)
-                        if (FL_K(q) == src[u]) gv[FL_BLK(q)] += (double)X[(int64_t)FL_ROW(q) * c.ldx + d];
+                        if (FL_K(q) == src[u]) gv[FL_BLK(q)] += (double)FLX(q, d);
                 }
                 v = tree_reduce_d(gv, n_blocks);
             }
@@ -1728,16 +1761,17 @@ int32_t segk_kmeans_batch_scratch_words(int32_t K_max, int64_t n_slots, int32_t 
     return SEGK_OK;
 }
 
-int64_t segk_kmeans_batch_record_words(int32_t K_max, int32_t D, int32_t n_blocks_local, int32_t flag_cap)
+int64_t segk_kmeans_batch_record_words(int32_t K_max, int32_t D, int32_t n_blocks_local, int32_t flag_cap, int32_t flag_row_bytes)
 {
-    return (int64_t)n_blocks_local * ((int64_t)K_max * D + 1 + K_max + segk_flag_words(flag_cap));
+    const int64_t rw = flag_row_bytes > 0 ? ((int64_t)flag_cap * flag_row_bytes + 7) / 8 : 0;
+    return (int64_t)n_blocks_local * ((int64_t)K_max * D + 1 + K_max + segk_flag_words(flag_cap) + rw);
 }
 
 int32_t segk_kmeans_batch_partials(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m,
                                    const int32_t *blk_lo, int32_t n_blocks_local,
                                    const int32_t *new_tok, const int32_t *new_k, const int32_t *n_flag,
                                    const double *out_total, int32_t *sorted_scratch, int32_t *koff_scratch,
-                                   double *record, int32_t flag_cap, double *out_scalars, void *stream)
+                                   double *record, int32_t flag_cap, int32_t flag_rows, double *out_scalars, void *stream)
 {
     (void)ctx;
     int rc = check_corpus(c);
@@ -1765,6 +1799,14 @@ int32_t segk_kmeans_batch_partials(segk_ctx *ctx, const segk_corpus *c, const se
                            out_scalars, NR, rsh, nsh, part_sum, part_cnt, fuse ? 1 : 0);
         SEGK_LAUNCH_CHECK();
     }
+    if (flag_rows) {
+        // a shard of the corpus: the embedding rows of the flagged tokens into the record, behind the flag lists
+        const int elem = c->x_dtype == SEGK_F32 ? 4 : 8;
+        const int64_t rw = segk_flag_row_words(flag_cap, c->D, elem);
+        double *rows = record + nbl * KD + nbl + nbl * m->K_max + nbl * segk_flag_words(flag_cap);
+        DISPATCH_XT(c, hipLaunchKernelGGL(k_batch_flag_rows<XT>, dim3((unsigned)nbl), dim3(256), 0, st, *c, flags, flag_cap, (XT *)rows, rw););
+        SEGK_LAUNCH_CHECK();
+    }
     if (fuse) return SEGK_OK;
     const int64_t grid = nbl * ((m->K_max + PART_WAVES - 1) / PART_WAVES);
     DISPATCH_XT(c, hipLaunchKernelGGL(k_batch_partials<XT>, dim3((unsigned)grid), dim3(64 * PART_WAVES), 0, st, *c, *m, blk_lo,
@@ -1775,8 +1817,8 @@ int32_t segk_kmeans_batch_partials(segk_ctx *ctx, const segk_corpus *c, const se
 
 int32_t segk_kmeans_batch_finalize(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m, int32_t utt_lo,
                                    int32_t utt_hi, const double *records, int32_t n_blocks_total,
-                                   int32_t n_blocks_per_rank, int64_t rank_stride, int32_t flag_cap, int32_t my_rank,
-                                   int32_t *new_k, int32_t *remap_scratch, double *out_scalars, int32_t *status,
+                                   int32_t n_blocks_per_rank, int64_t rank_stride, int32_t flag_cap, int32_t flag_rows,
+                                   int32_t my_rank, int32_t *new_k, int32_t *remap_scratch, double *out_scalars, int32_t *status,
                                    void *stream)
 {
     int rc = check_corpus(c);
@@ -1826,7 +1868,8 @@ int32_t segk_kmeans_batch_finalize(segk_ctx *ctx, const segk_corpus *c, segk_kme
         hipLaunchKernelGGL(k_batch_finalize<XT>, dim3((m->K_max + FIN_ROWS - 1) / FIN_ROWS + 1), dim3(256), lds, st, *c, *m, records,
                            n_blocks_total, n_blocks_per_rank, rank_stride, flag_cap, my_rank, new_k, remap_scratch, out_scalars,
                            status, ctx && m->K_max <= 2048 ? ctx->row_hash : (unsigned long long *)nullptr,
-                           sp ? (unsigned int *)m->tiles_b3 + 1 : (unsigned int *)nullptr, ovf, ovf_cap, sp_spec);
+                           sp ? (unsigned int *)m->tiles_b3 + 1 : (unsigned int *)nullptr, ovf, ovf_cap, sp_spec,
+                           flag_rows ? segk_flag_row_words(flag_cap, c->D, c->x_dtype == SEGK_F32 ? 4 : 8) : (int64_t)0);
     });
     const int64_t nslot = (int64_t)(utt_hi - utt_lo) * c->N_max;
     const unsigned grid = (unsigned)(n_tiles + (nslot + 255) / 256);

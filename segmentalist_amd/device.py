@@ -32,6 +32,29 @@ def to_dev(a, dtype=None):
     return torch.from_numpy(a).to(_dev())
 
 
+def _host_init_stats(X, assignments, K_max, random_means):
+    """KMeansComponents.__init__'s statistics (kmeans_components.py:79-81: add_item for k ascending, i ascending within k) on
+    the host, exactly as k_kmeans_init_stats computes them on the device -- float64 sums of a component's rows in ascending row
+    order, means = the float64 quotient rounded to the dtype of X, empty slots = the random means --, for the ranks of a
+    sharded corpus, none of which holds every row on its device."""
+    X = np.asarray(X)
+    a = np.asarray(assignments, dtype=np.int64)
+    D = X.shape[1]
+    numer = np.zeros((K_max, D), dtype=np.float64)
+    counts = np.zeros(K_max, dtype=np.int64)
+    means = np.array(random_means, dtype=X.dtype, copy=True)
+    rows = np.flatnonzero((a >= 0) & (a < K_max))
+    order = rows[np.argsort(a[rows], kind="stable")]          # by component, ascending rows inside a component
+    ks, starts = np.unique(a[order], return_index=True)
+    ends = np.append(starts[1:], len(order))
+    for k, s, e in zip(ks, starts, ends):
+        numer[k] = np.cumsum(X[order[s:e]].astype(np.float64), axis=0)[-1]      # cumsum: strictly sequential additions
+        counts[k] = e - s
+        means[k] = (numer[k] / float(e - s)).astype(X.dtype)
+    K = int(ks.max()) + 1 if len(ks) else 0
+    return means, numer, counts, K
+
+
 class DeviceCorpus(object):
     """Device image of the embedding matrix and (optionally) of `Utterances`
     (utterances.py:74-105): vec_ids int32 [n_utt, tri], durations f64, lengths int32."""
@@ -122,12 +145,25 @@ class DeviceKMeans(object):
     """Device image of `KMeansComponents` (kmeans_components.py:18-91) plus the derived MFMA
     operands and the per-sweep work buffers."""
 
-    def __init__(self, corpus, K_max, assignments, random_means):
+    def __init__(self, corpus, K_max, assignments, random_means, shard=None):
         torch = _torch()
         dev = _dev()
         self.corpus = corpus
         c = corpus
         self.K_max = int(K_max)
+        # shard = (row_lo, row_hi, X_host): `corpus` holds the rows [row_lo, row_hi) of the embedding matrix, numbered from 0
+        # (multi-rank batch mode, SURVEY 8(e): "each GPU keeps its shard's X rows").  Everything row-indexed on the device --
+        # the span tables' ids, token lists, candidates, `assignments` -- is then in that LOCAL numbering; the host-facing
+        # views (components.assignments, checkpoints) are assembled from all ranks.  Component statistics are replicated.
+        self.row_base, self.n_rows_global, self.shard = 0, c.n_emb, None
+        assignments = np.asarray(assignments)
+        init = None
+        if shard is not None:
+            lo, hi, X_host = shard
+            assert hi - lo == c.n_emb and len(assignments) == X_host.shape[0]
+            self.row_base, self.n_rows_global, self.shard = lo, len(assignments), (lo, hi)
+            init = _host_init_stats(X_host, assignments, self.K_max, np.asarray(random_means, dtype=c.x_np_dtype))
+            assignments = assignments[lo:hi]
         xd = c.torch_xdtype
         self.means = torch.empty((self.K_max, c.D), dtype=xd, device=dev)
         self.mean_numerators = torch.zeros((self.K_max, c.D), dtype=torch.float64, device=dev)
@@ -164,7 +200,15 @@ class DeviceKMeans(object):
         self.bounds_stale = None
         self._L = _abi.lib()
         self._ctx = _abi.ctx()
-        check(self._L.segk_kmeans_init_stats(self._ctx, C.byref(c.c), C.byref(self.m), _abi.stream()))
+        if init is None:
+            check(self._L.segk_kmeans_init_stats(self._ctx, C.byref(c.c), C.byref(self.m), _abi.stream()))
+        else:
+            means, numer, counts, K = init
+            self.means.copy_(torch.from_numpy(means))
+            self.mean_numerators.copy_(torch.from_numpy(numer))
+            self.counts.copy_(torch.from_numpy(counts))
+            self.K.fill_(int(K))
+            self.prepare()
         if c.n_utt:
             self._alloc_utt_buffers()
 
@@ -191,6 +235,32 @@ class DeviceKMeans(object):
     def _cp(self):
         return C.byref(self.corpus.c)
 
+    def require_whole_corpus(self, what):
+        if self.shard is not None:
+            raise SegkError("%s needs every row of the embedding matrix on this device, but the segmenter holds a shard (rows "
+                            "%d..%d of %d): construct it with shard_corpus=False" % (what, self.shard[0], self.shard[1],
+                                                                                     self.n_rows_global))
+
+    def global_assignments(self):
+        """`assignments` of ALL rows as a numpy array (a collective on the sweeper's communicator when anything is stale or
+        the corpus is sharded: every rank contributes the labels of its own rows)."""
+        self.ensure_assignments()
+        a = self.assignments.cpu().numpy()
+        if self.shard is None:
+            return a
+        out = np.full(self.n_rows_global, -1, dtype=a.dtype)
+        for lo, hi, part in self.batch_comm.all_gather_object((self.shard[0], self.shard[1], a)):
+            out[lo:hi] = part
+        return out
+
+    def set_global_assignments(self, a):
+        """Upload `assignments` given for all rows (checkpoint resume)."""
+        torch = _torch()
+        a = np.asarray(a)
+        if self.shard is not None:
+            a = a[self.shard[0]:self.shard[1]]
+        self.assignments.copy_(torch.from_numpy(np.ascontiguousarray(a)).to(self.assignments.dtype))
+
     def ensure_assignments(self, group=None):
         """Materialise `assignments` after batch sweeps (they only maintain the token lists).  With more than
         one rank this is a COLLECTIVE on the sweeper's communicator (every rank holds the tokens of its own
@@ -202,7 +272,7 @@ class DeviceKMeans(object):
         check(self._L.segk_kmeans_assignments_from_tokens(self._ctx, self._cp(), C.byref(self.m), lo, hi,
                                                           ptr(self.new_tok), ptr(self.new_k), ptr(self.n_new),
                                                           _abi.stream()))
-        if world > 1:
+        if world > 1 and self.shard is None:
             (self.batch_comm if group is None else get_comm(group)).all_reduce_max(self.assignments)
         self.assign_stale = None
 
@@ -256,7 +326,7 @@ class DeviceKMeans(object):
         """np.max / np.argmax of neg_sqrd_norm for rows `ids` (host ints) ->
         (float64[n], int32[n], number of rows that needed the full scan)."""
         torch = _torch()
-        ids_t = to_dev(ids, np.int32)
+        ids_t = to_dev(self._local_rows(ids), np.int32)
         n = ids_t.numel()
         out_max = torch.empty(n, dtype=torch.float64, device=ids_t.device)
         out_arg = torch.empty(n, dtype=torch.int32, device=ids_t.device)
@@ -265,29 +335,43 @@ class DeviceKMeans(object):
                                             C.byref(self.cand), ptr(out_max), ptr(out_arg), _abi.stream()))
         return out_max.cpu().numpy(), out_arg.cpu().numpy(), int(self.cand_count.item())
 
+    def _local_rows(self, ids):
+        """Global row ids -> the device's numbering (identity unless the corpus is sharded: then they must lie in the shard)."""
+        if self.shard is None:
+            return ids
+        a = np.asarray(ids, dtype=np.int64)
+        if a.size and (a.min() < self.shard[0] or a.max() >= self.shard[1]):
+            self.require_whole_corpus("scoring rows outside this rank's shard")
+        return a - self.shard[0]
+
     def neg_sqrd_norm(self, row):
         torch = _torch()
+        row = int(self._local_rows([row])[0])
         out = torch.empty(self.K_max, dtype=self.corpus.torch_xdtype, device=self.means.device)
         check(self._L.segk_kmeans_neg_sqrd_norm(self._ctx, self._cp(), C.byref(self.m), int(row), ptr(out),
                                                 _abi.stream()))
         return out.cpu().numpy()
 
     def add_item(self, i, k):
+        self.require_whole_corpus("add_item")
         self.ensure_assignments()
         check(self._L.segk_kmeans_add_item(self._ctx, self._cp(), C.byref(self.m), int(i), int(k),
                                            ptr(self.status), _abi.stream()))
 
     def del_item(self, i):
+        self.require_whole_corpus("del_item")
         self.ensure_assignments()
         check(self._L.segk_kmeans_del_item(self._ctx, self._cp(), C.byref(self.m), int(i), ptr(self.status),
                                            _abi.stream()))
 
     def del_component(self, k):
+        self.require_whole_corpus("del_component")
         self.ensure_assignments()
         check(self._L.segk_kmeans_del_component(self._ctx, self._cp(), C.byref(self.m), int(k),
                                                 ptr(self.status), _abi.stream()))
 
     def clean_components(self):
+        self.require_whole_corpus("clean_components")
         self.ensure_assignments()
         check(self._L.segk_kmeans_clean_components(self._ctx, self._cp(), C.byref(self.m), ptr(self.status),
                                                    _abi.stream()))
@@ -298,6 +382,8 @@ class DeviceKMeans(object):
         out = torch.zeros(1, dtype=torch.float64, device=self.means.device)
         check(self._L.segk_kmeans_sum_neg_sqrd_norm(self._ctx, self._cp(), C.byref(self.m), ptr(out),
                                                     _abi.stream()))
+        if self.shard is not None:      # every rank's rows, added in rank order (a record metric: tolerance-level parity)
+            return float(sum(self.batch_comm.all_gather_object(float(out.item()))))
         return float(out.item())
 
     # ------------------------------------------------------------------ segmentation
@@ -320,6 +406,7 @@ class DeviceKMeans(object):
         """The whole of segment_i (kmeans_acoustic_wordseg.py:225-332) for utterance i, enqueued
         asynchronously: score its spans, DP, del/add/clean in the reference's order."""
         c = self.corpus
+        self.require_whole_corpus("the sequential chain (segment_i)")
         self.ensure_state()
         N = int(c.lengths_np[i])
         tri_i = N * (N + 1) // 2
@@ -338,6 +425,7 @@ class DeviceKMeans(object):
         if self.corpus.x_dtype != SEGK_F32 or self.corpus.N_max > 63:
             return False
         torch = _torch()
+        self.require_whole_corpus("the sequential chain (segment)")
         self.ensure_state()
         if getattr(self, "_seq_keys", None) is None:
             self._seq_keys = torch.zeros(self.corpus.tri + 2, dtype=torch.int64, device=self.means.device)
@@ -425,7 +513,11 @@ class KMeansBatchSweeper(object):
         assert self.comm.world == part.world and self.comm.rank == part.rank
         c = dk.corpus
         W = part.world
-        self.rank_stride = int(dk._L.segk_kmeans_batch_record_words(dk.K_max, c.D, part.nbl, self.cap))
+        # a sharded corpus: the embedding rows of the tokens that found new components travel in the record (the other ranks
+        # cannot read them from their own X)
+        self.flag_rows = 1 if dk.shard is not None else 0
+        self.rank_stride = int(dk._L.segk_kmeans_batch_record_words(
+            dk.K_max, c.D, part.nbl, self.cap, c.D * (4 if c.x_dtype == SEGK_F32 else 8) if self.flag_rows else 0))
         self.pack_all = torch.zeros((W, self.rank_stride), dtype=torch.float64, device=dev)
         self.pack = self.pack_all[part.rank]
         self.blk_lo = to_dev(part.local_bounds, np.int32)
@@ -471,6 +563,7 @@ class KMeansBatchSweeper(object):
         if self._mb is None or self._mb[0] != n_batches:
             steps = []
             for u, r, contiguous in self.part.minibatch(n_batches):
+                r = r - self.dk.row_base                 # rows in the device's numbering (a shard starts at 0)
                 if contiguous:
                     steps.append((int(u[0]) if len(u) else 0, len(u), int(r[0]) if len(r) else 0, len(r), None, None))
                 else:
@@ -515,7 +608,7 @@ class KMeansBatchSweeper(object):
                                             ptr(dk.n_old), ptr(dk.n_new), ptr(dk.n_flag), ptr(dk.out_total), ptr(dk.status), st))
             check(L.segk_kmeans_batch_partials(ctx, cp, mp, ptr(self.blk_lo), pt.nbl, ptr(dk.new_tok), ptr(dk.new_k),
                                                ptr(dk.n_flag), ptr(dk.out_total), ptr(self.sorted), ptr(self.koff),
-                                               ptr(self.pack), self.cap, ptr(dk.out_scalars), st))
+                                               ptr(self.pack), self.cap, self.flag_rows, ptr(dk.out_scalars), st))
             if pt.world > 1:
                 self.comm.all_gather_rows(self.pack_all, self.pack)
             self._enqueue_back()
@@ -528,17 +621,17 @@ class KMeansBatchSweeper(object):
         L, ctx, cp, mp, st = dk._L, dk._ctx, dk._cp(), C.byref(dk.m), _abi.stream()
         # from the second sweep on cand_k holds every row's argmax of the previous sweep and dk.remap the relabelling of
         # that sweep's finalize: hints for the score stage (same results)
-        dk.score_rows(row0=pt.row_lo, n=pt.row_hi - pt.row_lo, hint_remap=dk.remap if self._use_hints() else None)
+        dk.score_rows(row0=pt.row_lo - dk.row_base, n=pt.row_hi - pt.row_lo, hint_remap=dk.remap if self._use_hints() else None)
         dk.segment(boundaries, n_slices_min, n_slices_max, wip, utt0=pt.utt_lo, n_utts=pt.utt_hi - pt.utt_lo)
         check(L.segk_kmeans_batch_partials(ctx, cp, mp, ptr(self.blk_lo), pt.nbl, ptr(dk.new_tok), ptr(dk.new_k),
                                            ptr(dk.n_flag), ptr(dk.out_total), ptr(self.sorted), ptr(self.koff),
-                                           ptr(self.pack), self.cap, ptr(dk.out_scalars), st))
+                                           ptr(self.pack), self.cap, self.flag_rows, ptr(dk.out_scalars), st))
 
     def _enqueue_back(self):
         dk, pt = self.dk, self.part
         L, ctx, cp, mp, st = dk._L, dk._ctx, dk._cp(), C.byref(dk.m), _abi.stream()
         check(L.segk_kmeans_batch_finalize(ctx, cp, mp, pt.utt_lo, pt.utt_hi, ptr(self.pack_all), pt.n_blocks, pt.nbl,
-                                           self.rank_stride, self.cap, pt.rank, ptr(dk.new_k), ptr(dk.remap),
+                                           self.rank_stride, self.cap, self.flag_rows, pt.rank, ptr(dk.new_k), ptr(dk.remap),
                                            ptr(dk.out_scalars), ptr(dk.status), st))
 
     def sweep(self, boundaries, n_slices_min, n_slices_max, wip):

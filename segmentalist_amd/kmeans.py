@@ -23,8 +23,9 @@ def _consecutive(assignments):
 
 
 class KMeans(object):
-    def __init__(self, X, K, assignments="rand", _corpus=None):
+    def __init__(self, X, K, assignments="rand", _corpus=None, _shard=None):
         self._corpus = _corpus
+        self._shard = _shard         # (row_lo, row_hi): the device holds a shard of X (multi-rank batch mode)
         self.setup_components(K, assignments, X)
 
     def setup_components(self, K, assignments="rand", X=None):
@@ -42,7 +43,7 @@ class KMeans(object):
             rng.shuffle(spread)
             assignments = np.array(spread)
         assignments = _consecutive(np.asarray(assignments))
-        self.components = KMeansComponents(X, assignments, K, _corpus=self._corpus)
+        self.components = KMeansComponents(X, assignments, K, _corpus=self._corpus, _shard=getattr(self, "_shard", None))
 
     def fit(self, n_iter, consider_unassigned=True, no_empty=True):
         """
@@ -52,6 +53,7 @@ class KMeans(object):
         """
         c = self.components
         dk = c.dev
+        dk.require_whole_corpus("KMeans.fit")
         record_dict = {"sum_neg_sqrd_norm": [], "components": [], "n_mean_updates": [], "sample_time": []}
         start_time = time.time()
         for i_iter in range(n_iter):

@@ -41,7 +41,8 @@ class SegmentalKMeansWordseg(object):
     def __init__(self, am_K, embedding_mats, vec_ids_dict, durations_dict, landmarks_dict,
                  seed_boundaries_dict=None, seed_assignments_dict=None, n_slices_min=0,
                  n_slices_max=20, min_duration=0, p_boundary_init=0.5, init_am_assignments="rand",
-                 wip=0, sync="sequential", n_stat_blocks=8, flag_cap=4096, process_group=None, n_batches=1):
+                 wip=0, sync="sequential", n_stat_blocks=8, flag_cap=None, process_group=None, n_batches=1,
+                 shard_corpus=None):
         logger.info("Initializing")
         assert seed_assignments_dict is None or seed_boundaries_dict is not None
         assert sync in ("sequential", "batch")
@@ -95,8 +96,30 @@ class SegmentalKMeansWordseg(object):
         u = self.utterances
         # banded span tables for the DP kernels' fast path (windows of at most 8 slices, at most 64 landmarks)
         band = u.band_tables(n_slices_max) if (1 <= n_slices_max <= 8 and u.N_max <= 64) else None
-        self._corpus = DeviceCorpus(embeddings, u.vec_ids, u.durations, u.lengths, band=band)
-        self.acoustic_model = KMeans(embeddings, am_K, assignments, _corpus=self._corpus)
+        # Multi-rank batch mode ("each GPU keeps its shard's X rows"): this rank's device holds only the rows of
+        # its own utterances -- the float32 matrix, both fp16 planes, the per-row work arrays -- numbered from 0; the span
+        # tables name them by those local numbers.  shard_corpus=False keeps every row on every rank (needed to mix in
+        # sequential-mode calls or KMeans.fit, which walk the whole matrix).
+        comm = get_comm(process_group)
+        if shard_corpus is None:
+            shard_corpus = sync == "batch" and comm.world > 1
+        shard = None
+        if shard_corpus and comm.world > 1:
+            assert sync == "batch", "a sharded corpus exists in batch mode only (the sequential chain does not shard)"
+            pt = Partition(u.D, vec_ids.row_start, n_stat_blocks, comm.rank, comm.world)
+            shard = (pt.row_lo, pt.row_hi)
+            vi = np.full(np.asarray(u.vec_ids).shape, -1, dtype=np.int32)
+            own = np.asarray(u.vec_ids)[pt.utt_lo:pt.utt_hi]
+            vi[pt.utt_lo:pt.utt_hi] = np.where(own >= 0, own - pt.row_lo, -1)
+            if band is not None:
+                bi = np.full(band[0].shape, -1, dtype=np.int32)
+                bown = band[0][pt.utt_lo:pt.utt_hi]
+                bi[pt.utt_lo:pt.utt_hi] = np.where(bown >= 0, bown - pt.row_lo, -1)
+                band = (bi, band[1])
+            self._corpus = DeviceCorpus(embeddings[pt.row_lo:pt.row_hi], vi, u.durations, u.lengths, band=band)
+        else:
+            self._corpus = DeviceCorpus(embeddings, u.vec_ids, u.durations, u.lengths, band=band)
+        self.acoustic_model = KMeans(embeddings, am_K, assignments, _corpus=self._corpus, _shard=shard)
         self._dk = self.acoustic_model.components.dev
         self._dev_bounds = to_dev(u.boundaries.astype(np.uint8))
         u.bind_device(self._dev_bounds, refresh=self._dk.ensure_boundaries)
@@ -104,7 +127,11 @@ class SegmentalKMeansWordseg(object):
 
         # batch mode plumbing (single process unless torch.distributed is initialised)
         self._sweeper = None
-        self._batch_args = (n_stat_blocks, flag_cap, process_group)
+        # flag_cap: tokens per statistics block and sweep that may found new components (more: an error, never a wrong result).
+        # Default 4 096; 1 024 with a sharded corpus, whose records carry flag_cap embedding rows per block over the wire.
+        if flag_cap is None:
+            flag_cap = 1024 if shard is not None else 4096
+        self._batch_args = (n_stat_blocks, flag_cap, comm)
 
     # ------------------------------------------------------------------ sequential mode
     def segment_i(self, i):

@@ -20,7 +20,7 @@ logger = logging.getLogger(__name__)
 
 
 class KMeansComponents(object):
-    def __init__(self, X, assignments, K_max, _corpus=None):
+    def __init__(self, X, assignments, K_max, _corpus=None, _shard=None):
         self.X = X
         self.N, self.D = X.shape
         self.K_max = K_max
@@ -34,7 +34,10 @@ class KMeansComponents(object):
         corpus = _corpus if _corpus is not None else DeviceCorpus(X)
         # device: counts / mean_numerators / means / K from the assignments, summed in the order
         # of the reference's add_item loop (:79-81)
-        self.dev = DeviceKMeans(corpus, K_max, assignments, self.random_means)
+        # _shard = (row_lo, row_hi): `corpus` holds only those rows of X (numbered from 0); the initial statistics then come
+        # from the host, which has all of X
+        self.dev = DeviceKMeans(corpus, K_max, assignments, self.random_means,
+                                shard=None if _shard is None else (int(_shard[0]), int(_shard[1]), X))
 
     def setup_random_means(self):
         # kmeans_components.py:90-91 (consumes np.random exactly like the reference)
@@ -59,8 +62,7 @@ class KMeansComponents(object):
 
     @property
     def assignments(self):
-        self.dev.ensure_assignments()
-        return self.dev.assignments.cpu().numpy().astype(np.int64)
+        return self.dev.global_assignments().astype(np.int64)
 
     # ---------------------------------------------------------------- mutators (A11)
     def add_item(self, i, k):

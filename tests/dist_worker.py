@@ -28,8 +28,13 @@ def main():
     corpus = make_corpus(96, 24, 40, seed=3, ragged=True, n_slices_max=5, N_range=(4, 14))
     random.seed(11)
     np.random.seed(11)
+    # (world > 1: every rank's device holds the rows of its own utterances only, unless --no-shard)
     seg = kaw.SegmentalKMeansWordseg(40, *corpus, n_slices_max=5, init_am_assignments="rand", sync="batch",
-                                     n_stat_blocks=8)
+                                     n_stat_blocks=8, shard_corpus=False if "--no-shard" in sys.argv else None)
+    if world > 1:
+        assert (seg._dk.shard is None) == ("--no-shard" in sys.argv)
+        if seg._dk.shard is not None:
+            assert seg._corpus.n_emb == seg._dk.shard[1] - seg._dk.shard[0] < seg.acoustic_model.components.N
     # optional: --load CKPT resumes from a checkpoint (possibly written under another world size) before sweeping,
     # --save CKPT writes one after the sweeps (every rank builds it: state_dict() is a collective; rank 0 stores it)
     extra = sys.argv[4:]

@@ -34,6 +34,15 @@ def test_batch_mode_is_independent_of_the_number_of_ranks(tmp_path):
             assert np.array_equal(ref[k], got[k]), (world, k)
 
 
+def test_batch_mode_with_the_corpus_replicated_on_every_rank(tmp_path):
+    """shard_corpus=False (every rank keeps all rows on its device, as rounds 1-3 did; needed to mix sequential-mode calls
+    into a multi-rank run): the same bits as one rank and as the sharded default."""
+    ref = run(1, str(tmp_path / "r1.npz"))
+    got = run(2, str(tmp_path / "r2.npz"), extra=["--no-shard"])
+    for k in ref.files:
+        assert np.array_equal(ref[k], got[k]), k
+
+
 def test_batch_mode_replayed_as_hipgraphs_is_independent_of_the_number_of_ranks(tmp_path):
     """SEGK_SWEEP_GRAPH=1: the sweep captured as one hipGraph (two around the all-gather with several ranks) and
     replayed from the second sweep on -- same bits as the plain launches."""

@@ -160,3 +160,25 @@ def test_bench_starts_its_own_ranks_when_no_launcher_did(monkeypatch):
     assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
     assert os.path.basename(cmd[cmd.index("--master-port") + 2]) == "bench.py" and cmd[-4:] == ["--gpus", "4", "--steps", "3"]
     assert seen["env"]["SEGK_BENCH_BACKEND"] == "gloo" and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_host_init_stats_of_a_sharded_corpus_equal_the_reference_constructor():
+    """device._host_init_stats (what the ranks of a sharded corpus upload instead of running k_kmeans_init_stats, which needs
+    every row on the device) against the oracle's KMeansComponents.__init__ (kmeans_components.py:79-81: add_item for k
+    ascending, i ascending): means, numerators, counts and K bit for bit, float32 and float64, with unassigned rows, an
+    empty slot in the middle of the labels' range excluded by construction (labels are consecutive) and empty trailing slots."""
+    from segmentalist_amd.device import _host_init_stats
+    for dtype in (np.float32, np.float64):
+        rs = np.random.RandomState(3)
+        n, D, K_max = 700, 13, 40
+        X = rs.randn(n, D).astype(dtype)
+        a = rs.randint(0, 31, n)
+        a[rs.rand(n) < 0.2] = -1
+        a[:31] = np.arange(31)                       # every label 0..30 occurs: consecutive, slots 31..39 stay empty
+        np.random.seed(11)
+        ref = no.KMeansComponents(X, a.copy(), K_max)
+        means, numer, counts, K = _host_init_stats(X, a, K_max, ref.random_means)
+        assert K == ref.K == 31
+        assert means.dtype == ref.means.dtype and np.array_equal(means, ref.means)
+        assert np.array_equal(numer, ref.mean_numerators)
+        assert np.array_equal(counts, ref.counts)
