@@ -253,13 +253,13 @@ __global__ __launch_bounds__(256) void k_kmeans_brute_rows(segk_corpus c, segk_k
 // four of the 32 rows), sixteen waves (with four -- one per SIMD -- every dependent LDS read and packed operation was
 // exposed); arithmetic and first-maximum rule as in k_kmeans_brute_rows (neg_sqd_exact's order, packed pairs); the slices of
 // a row meet in ws[] by a 64-bit atomic maximum of (orderable score bits, ~component), one per wave, unpacked by
-// k_brute_finish_ls.
+// the workgroup that finishes last.
 #define BLS_TPS 4
 #define BLS_THREADS 1024
 #define BLS_ROWS (BLS_THREADS / 128 * 4)      /* rows per batch */
 #define BLS_IDS 256
 __global__ __launch_bounds__(BLS_THREADS) void k_kmeans_brute_ls(segk_corpus c, segk_kmeans m, segk_cand cand, int cap, int32_t *n_brute,
-                                                                int n_slices, int n_chunks, unsigned long long *ws)
+                                                                int n_slices, int n_chunks, unsigned long long *ws, unsigned int *ticket)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, D = c.D;
@@ -276,12 +276,13 @@ __global__ __launch_bounds__(BLS_THREADS) void k_kmeans_brute_ls(segk_corpus c, 
     const int slice = blockIdx.x % n_slices, chunk = blockIdx.x / n_slices;
     const int per = ((nq + n_chunks - 1) / n_chunks + BLS_ROWS - 1) & ~(BLS_ROWS - 1);
     const int q_lo = chunk * per, q_hi = q_lo + per < nq ? q_lo + per : nq;
-    if (q_lo >= q_hi) return;
+    if (nq <= 0) return;                                     // (every workgroup alike) nothing queued: nothing to unpack either
+    const bool has = q_lo < q_hi;                            // a workgroup without rows still takes its ticket below
     // ---- the slice's tiles (all K_max slots: the reference's argmax runs over every row of `means`)
     const int n_tiles = segk_n_tiles(m.K_max);
     const int tile0 = slice * BLS_TPS;
     const int nth = n_tiles - tile0 < BLS_TPS ? n_tiles - tile0 : BLS_TPS;
-    for (int i = tid; i < nth * (TP / 4); i += BLS_THREADS) {
+    for (int i = tid; has && i < nth * (TP / 4); i += BLS_THREADS) {
         const int t = i / (TP / 4), o = i - t * (TP / 4);
         reinterpret_cast<float4 *>(ts + t * TP)[o] = reinterpret_cast<const float4 *>(m.tiles + (int64_t)(tile0 + t) * tstride)[o];
     }
@@ -389,20 +390,26 @@ __global__ __launch_bounds__(BLS_THREADS) void k_kmeans_brute_ls(segk_corpus c, 
             }
         }
     }
-}
-
-__global__ void k_brute_finish_ls(segk_cand cand, int cap, unsigned long long *ws)
-{
-    int nq = *cand.count;
-    if (nq > cap) nq = cap;
-    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += gridDim.x * blockDim.x) {
-        const unsigned long long pk = ws[q];
-        ws[q] = 0ull;
-        const unsigned int ord = (unsigned int)(pk >> 32);
-        const unsigned int bits = (ord & 0x80000000u) ? (ord & 0x7fffffffu) : ~ord;
-        const int32_t id = cand.queue[q];
-        cand.k[id] = (int32_t)(0xffffffffu - (unsigned int)(pk & 0xffffffffu));
-        cand.s[id] = (double)__uint_as_float(bits);
+    // ---- the workgroup that finishes last unpacks the (score, component) pairs into the candidates and clears the workspace
+    // (round 3 launched k_brute_finish_ls for this: one more kernel boundary, ~5 us of a sweep even when the queue is empty)
+    __shared__ int last;
+    __syncthreads();
+    if (tid == 0) {
+        __threadfence();
+        last = atomicAdd(ticket, 1u) == gridDim.x - 1u;
+    }
+    __syncthreads();
+    if (last) {
+        __threadfence();
+        for (int q = tid; q < nq; q += BLS_THREADS) {
+            const unsigned long long pk = atomicExch(&ws[q], 0ull);      // (device scope: the maxima were formed by atomics of every XCD)
+            const unsigned int ord = (unsigned int)(pk >> 32);
+            const unsigned int bits = (ord & 0x80000000u) ? (ord & 0x7fffffffu) : ~ord;
+            const int32_t id = cand.queue[q];
+            cand.k[id] = (int32_t)(0xffffffffu - (unsigned int)(pk & 0xffffffffu));
+            cand.s[id] = (double)__uint_as_float(bits);
+        }
+        if (tid == 0) atomicExch(ticket, 0u);
     }
 }
 
@@ -626,8 +633,8 @@ int segk_resolve_on(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m, c
             if (ctx->brute_ws) (void)hipFree(ctx->brute_ws);
             ctx->brute_ws = nullptr;
             ctx->brute_ws_cap = 0;
-            SEGK_CHECK_HIP(hipMalloc((void **)&ctx->brute_ws, sizeof(unsigned long long) * (size_t)n));
-            SEGK_CHECK_HIP(hipMemsetAsync(ctx->brute_ws, 0, sizeof(unsigned long long) * (size_t)n, st));      // (on the launch stream: a plain
+            SEGK_CHECK_HIP(hipMalloc((void **)&ctx->brute_ws, sizeof(unsigned long long) * (size_t)(n + 1)));      // + the ticket
+            SEGK_CHECK_HIP(hipMemsetAsync(ctx->brute_ws, 0, sizeof(unsigned long long) * (size_t)(n + 1), st));      // (on the launch stream: a plain
                                                                         // hipMemset is not ordered before kernels of another stream)
             ctx->brute_ws_cap = n;
         }
@@ -639,8 +646,7 @@ int segk_resolve_on(segk_ctx *ctx, const segk_corpus *c, const segk_kmeans *m, c
         const size_t lds = ((size_t)BLS_TPS * segk_G(c->D) * 128 + (size_t)BLS_ROWS * ((c->D + 3) & ~3)) * sizeof(float);
         SEGK_CHECK_HIP(segk_dyn_lds((const void *)k_kmeans_brute_ls, lds));
         hipLaunchKernelGGL(k_kmeans_brute_ls, dim3((unsigned)(n_slices * n_chunks)), dim3(BLS_THREADS), lds, st, *c, *m, *cand, (int)c->n_emb,
-                           status ? status + 1 : nullptr, n_slices, n_chunks, ctx->brute_ws);
-        hipLaunchKernelGGL(k_brute_finish_ls, dim3(32), dim3(256), 0, st, *cand, (int)c->n_emb, ctx->brute_ws);
+                           status ? status + 1 : nullptr, n_slices, n_chunks, ctx->brute_ws, (unsigned int *)(ctx->brute_ws + ctx->brute_ws_cap));
         SEGK_LAUNCH_CHECK();
         return SEGK_OK;
     }

@@ -56,7 +56,13 @@ struct HintArgs {
     float *fb_w;                    // [3][8] share of the row groups each XCD took in the launches L - 1, L, L + 1 (slot = launch % 3)
     unsigned int *fb_t;             // [3][8] how long its waves lived (s_memrealtime ticks, maximum); NULL: equal shares
     int fb_cur;                     // this launch's slot
-    const int64_t *fb_split;        // [9] this launch's first group per XCD (k_hint_map)
+    const int64_t *fb_split;        // [9] this launch's first group per XCD (k_hint_map; unused with `own`)
+    // own != 0: the kernel does k_hint_map's work itself (the label map straight into LDS, the XCDs' shares by every wave, the
+    // queue counters by its first thread): one launch and one kernel boundary (~5 us) less per score call
+    int own;
+    const int32_t *remap;           // previous label -> current label (NULL: identity)
+    int32_t *zero_cnt, *pre_hdr;    // the caller's ambiguity-queue length (may be NULL) and the undecided-row queue's header [16]
+    int64_t total_groups;
     int64_t k1_groups;              // groups this kernel multiplies (the few behind the last whole round of all waves go to the second stage)
     // the hint waves (waves NW .. 2 NW - 1 of every workgroup): the hinted component of every row scored in reference arithmetic
     const float *xrows32;           // float32 rows [n_emb][ld32]
@@ -252,9 +258,49 @@ __global__ __launch_bounds__(128 * NW, 1) void k_kmeans_top2_rs(HintArgs H)
     // exchanged during the launch, and the results do not depend on who computes which rows.
     const unsigned long long fb_t0 = __builtin_amdgcn_s_memrealtime();
     const bool fb = xcd_aware && H.fb_t != nullptr;
+    int64_t own_lo = 0, own_hi = 0;
+    if (H.own) {
+        if (blockIdx.x == 0 && tid == 0) {
+            if (H.zero_cnt) *H.zero_cnt = 0;
+#pragma unroll
+            for (int i = 0; i < 16; i++) H.pre_hdr[i] = 0;
+        }
+        // the XCDs' shares for this launch (k_hint_map's arithmetic, by every wave: one load round trip, sums and prefix by
+        // shuffles; lane x & 7 = XCD x): share of the previous launch / lifetime of its waves = the rate an XCD showed; new
+        // share = half the old one, half the rate's
+        const int x = lane & 7;
+        const int cur = H.fb_cur, prev = (cur + 2) % 3, next = (cur + 1) % 3;
+        const float wp = H.fb_w[prev * 8 + x];
+        const unsigned int tp = H.fb_t ? H.fb_t[prev * 8 + x] : 0u;
+        const bool ok = __all(tp > 0u && wp > 0.f);
+        const float rate = ok ? wp / (float)tp : 0.f;
+        float rsum = rate;
+        rsum += __shfl_xor(rsum, 1);
+        rsum += __shfl_xor(rsum, 2);
+        rsum += __shfl_xor(rsum, 4);
+        float w = !(wp > 0.f) ? 0.125f : ok ? 0.5f * wp + 0.5f * (rate / rsum) : wp;
+        w = fminf(fmaxf(w, 0.0625f), 0.25f);
+        float wsum = w;
+        wsum += __shfl_xor(wsum, 1);
+        wsum += __shfl_xor(wsum, 2);
+        wsum += __shfl_xor(wsum, 4);
+        double cum = 0.0;                                        // exclusive prefix in XCD order, every lane the same additions
+        for (int y = 0; y < 8; y++) {
+            const float wy = __shfl(w, y);
+            if (y < x) cum += (double)wy;
+        }
+        const int64_t split = (int64_t)(cum * ((double)H.total_groups / (double)wsum));
+        const int xcd = blockIdx.x & 7;
+        own_lo = __shfl(split, xcd);
+        own_hi = xcd == 7 ? H.total_groups : __shfl(split, (xcd + 1) & 7);
+        if (blockIdx.x == 0 && wave == 0 && lane < 8) {
+            H.fb_w[cur * 8 + x] = w / wsum;
+            if (H.fb_t) H.fb_t[next * 8 + x] = 0u;
+        }
+    }
     if (fb) {
         const int xcd = blockIdx.x & 7;
-        const int64_t lo = H.fb_split[xcd], hi = H.fb_split[xcd + 1];
+        const int64_t lo = H.own ? own_lo : H.fb_split[xcd], hi = H.own ? own_hi : H.fb_split[xcd + 1];
         n_slots = (int64_t)(n_wgr >> 3) * NW;
         g_first = lo + (int64_t)(wgr >> 3) * NW + wave;
         n_groups = hi;
@@ -414,7 +460,18 @@ __global__ __launch_bounds__(128 * NW, 1) void k_kmeans_top2_rs(HintArgs H)
         if (has_c) cv4 = *reinterpret_cast<const float4 *>(H.tiles + (int64_t)(t_lo + (tid >> 3)) * STRIDE + KS * P * 256 + (tid & 7) * 4);
         // the label map of the hint waves behind the tile images
         int32_t *map_l = reinterpret_cast<int32_t *>(lds + H.tpr * TL);
-        for (int k = tid; k < H.K_max; k += 128 * NW) map_l[k] = H.map[k];
+        if (H.own) {
+            // the label a hint of the previous call stands for now (the relabelling of clean_components), or -1 when the
+            // filters' images carry that component as absent (a marked duplicate: such a hint proves nothing)
+            for (int k = tid; k < H.K_max; k += 128 * NW) {
+                int v = H.remap ? H.remap[k] : k;
+                if (v < 0 || v >= H.K_max) v = -1;
+                else if (H.tiles[(int64_t)(v >> 5) * STRIDE + KS * P * 256 + (v & 31)] < -1.0e37f) v = -1;
+                map_l[k] = v;
+            }
+        } else {
+            for (int k = tid; k < H.K_max; k += 128 * NW) map_l[k] = H.map[k];
+        }
 #pragma unroll
         for (int u = 0; u < PER_W; u++) {
             int c = wave + u * NWF;
@@ -796,13 +853,16 @@ static int launch_score_hint(segk_ctx *ctx, ScoreArgs A, const int32_t *remap, i
     // With equal shares every wave walks the groups slot, slot + slots, ...: when a handful of groups is left behind the last
     // whole round (a 1 250-utterance shard: 2 051 groups = 4 x 512 + 3) three waves would take a fifth group, 5 us, for all
     // the others to wait on.  Those few rows skip the filter: marked undecided (k_hint_map), they take the second stage.
+    // (with the band stage the rows K1 leaves out would take the full scan, 9 us for a shard's 192 rows: no skipping then)
     int64_t k1_groups = total_groups;
-    if (!fb_t) {
+    if (!fb_t && !band) {
         const int64_t slots = (int64_t)(grid1 / n_ranges) * nw1;
         const int64_t whole = slots > 0 ? (total_groups / slots) * slots : 0;
         if (whole > 0 && total_groups - whole <= 32) k1_groups = whole;
     }
-    {
+    // k_hint_map's work is K1's own (H.own) unless rows are left out (their (m1, m2) must be initialised in front of K1)
+    const bool own = k1_groups == total_groups;
+    if (!own) {
         const int64_t skipped = A.n - k1_groups * 64 > 0 ? A.n - k1_groups * 64 : 0;
         const int64_t nthr = skipped > A.K_max ? skipped : A.K_max;
         hipLaunchKernelGGL(k_hint_map, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, remap, A.tiles + 1024, A.K_max, stride_sp,
@@ -832,6 +892,11 @@ static int launch_score_hint(segk_ctx *ctx, ScoreArgs A, const int32_t *remap, i
     H.means32 = A.means32;
     H.cand_k = A.cand.k;
     H.map = ctx->hint_map;
+    H.own = own ? 1 : 0;
+    H.remap = remap;
+    H.zero_cnt = zero_cnt;
+    H.pre_hdr = ctx->pre_queue;
+    H.total_groups = total_groups;
     H.nxx = A.xerr + n_emb;                                      // -|x|^2 per row, behind the residual norms
     H.hint_out = (float4 *)((unsigned char *)ctx->hint_part + part_bytes);
     const size_t lds1 = (size_t)tpr * TL * sizeof(float) + map_bytes;
