@@ -48,7 +48,8 @@ const char *segk_last_error(void);
  *   3 round 3: segk_fbb_set_probe, segk_kmeans_score_hinted; this check
  *   4 round 3: scratch sizes of segk_kmeans_batch_partials from segk_kmeans_batch_scratch_words; segk_profile_enable(N)
  *   5 round 3: segk_fbatch.prior_rows, segk_fbb_prior_rows
- *   6 round 4: segk_kmeans_hint_feedback; flag_rows / flag_row_bytes of the batch statistics (sharded corpus)     */
+ *   6 round 4: segk_kmeans_hint_feedback; flag_rows / flag_row_bytes of the batch statistics (sharded corpus);
+ *              segk_fbgmm_sequential_sweep                                                                                     */
 #define SEGK_ABI_VERSION 6
 int32_t segk_abi_version(void);
 
@@ -500,6 +501,23 @@ int32_t segk_fbgmm_assign(segk_ctx *ctx, const segk_corpus *c, segk_fbgmm *f, in
                           int32_t map_assign, int32_t j_prev, double anneal_temp, const int32_t *new_tok,
                           const int32_t *n_new, const double *ustream, int64_t *ucursor,
                           int64_t ucap, int32_t *status, void *stream);
+
+/* A12: UnigramAcousticWordseg.gibbs_sample_i (unigram_acoustic_wordseg.py:252-360) for every utterance of order[0 .. n_order)
+ * [host] in turn -- remove its segments, score its spans (segk_fbgmm_score), sample or maximise its boundaries
+ * (segk_unigram_segment with viterbi 0 / 1), assign the new segments (segk_fbgmm_assign, map_assign) -- by ONE persistent
+ * kernel per stretch of utterances between two emptied components (ABI 6): every workgroup keeps the whole model in LDS and
+ * replays every update, only the span scores are shared out, one grid barrier per utterance.  Same device functions, same
+ * order of operations, same uniforms (ustream / ucursor as in the per-utterance calls): the same bits as the four calls per
+ * utterance.  row_start [dev] int32 [n_utt + 1]: first row of every utterance (an utterance's rows are contiguous);
+ * score [dev] double [n_emb] scratch.  Returns SEGK_ERR_UNSUPPORTED, with nothing enqueued, where the kernel does not apply
+ * (a language model attached, more than 64 landmarks, 3 K_max D doubles beyond a workgroup's LDS, an utterance listed twice,
+ * SEGK_FB_CHAIN=0): the caller then makes the four calls per utterance.  SYNCHRONISES the stream after every launch.       */
+int32_t segk_fbgmm_sequential_sweep(segk_ctx *ctx, const segk_corpus *c, segk_fbgmm *f, const int32_t *order, int32_t n_order,
+                                    const int32_t *row_start, int32_t viterbi, int32_t map_assign, int32_t n_slices_min,
+                                    int32_t n_slices_max, double wip, double time_power_term, double log_p_continue,
+                                    double anneal_temp_fb, double anneal_temp_am, double *score, const double *ustream,
+                                    int64_t *ucursor, int64_t ucap, uint8_t *boundaries, int32_t *new_tok, int32_t *n_new,
+                                    double *out_logprob, int32_t *status, void *stream);
 
 /* Inner loop of FBGMM.gibbs_sample (fbgmm.py:352-405) over the rows ids[0..n) (ids == NULL: rows
  * 0..n-1) in order: cache_component_stats, del_item, logits (:364-372), annealing, utils.draw with

@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SEGK_LIB_PATH") or os.path.join(_HERE, "libsegk.so")      # (SEGK_LIB_PATH: a development build kept beside the product build)
 
 SEGK_F32, SEGK_F64 = 0, 1
+SEGK_ERR_UNSUPPORTED = -4          # include/segk.h
 ABI_VERSION = 6          # SEGK_ABI_VERSION of include/segk.h this binding was written against
 
 
@@ -119,6 +120,8 @@ SIGNATURES = {
                                     _P, _P, _P, _P, _P]),
     "segk_fbgmm_assign": (_i32, [_P, _CP, _FP, _i32, _i32, _i32, _f64, _P, _P, _P, _P, _i64, _P, _P]),
     "segk_fbgmm_gibbs_items": (_i32, [_P, _CP, _FP, _P, _i64, _i32, _f64, _P, _P, _i64, _P, _P]),
+    "segk_fbgmm_sequential_sweep": (_i32, [_P, _CP, _FP, _P, _i32, _P, _i32, _i32, _i32, _i32, _f64, _f64, _f64, _f64, _f64,
+                                           _P, _P, _P, _i64, _P, _P, _P, _P, _P, _P]),
     "segk_fbb_collect": (_i32, [_P, _CP, _P, _P, _P, _P]),
     "segk_fbb_partials": (_i32, [_P, _CP, _FP, _BP, _i32, _i32, _i32, _P, _P, _P]),
     "segk_fbb_prepare": (_i32, [_P, _CP, _FP, _BP, _i32, _P]),

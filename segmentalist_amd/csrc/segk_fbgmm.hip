@@ -12,9 +12,25 @@
 // Tolerance contract (BASELINE north_star): log-likelihoods within 1e-4 relative of the
 // reference; everything here is fp64 with device libm, which lands at ~1e-15.
 #include <stdlib.h>
+#include <vector>
 
 #include "segk_internal.h"
 #include "segk_fb_common.h"
+#include "segk_chain_barrier.h"
+
+// The persistent chain (k_fb_chain) keeps the labels of ONE utterance's rows in LDS (f.assignments then addresses that
+// staging array as if it began at row 0): a component that empties is relabelled in those rows at once, the rows of all
+// other utterances are relabelled between two launches (nobody reads them before), from this log.
+struct FbLocal {
+    int32_t *asg;          // the staged labels (LDS), entry i = row row0 + i
+    int64_t row0;
+    int nrows;
+    int32_t *relog;        // [2 * FB_RELOG] pairs (from, to), in order
+    int *n_relog;
+    const double *ktab;    // fb_diag_const(count), count < ktab_n (diagonal components), or NULL
+    int64_t ktab_n;
+};
+#define FB_RELOG 16
 
 // ---------------------------------------------------------------------------------------
 // derived statistics of component k (all threads of the block cooperate over D)
@@ -31,7 +47,7 @@ __device__ double fb_diag_const(const segk_fbgmm &f, int D, double cnt)
     return (double)D * (lgamma((v_N + 1.) / 2.) - lgamma(v_N / 2.) - 0.5 * log(v_N) - 0.5 * LOG_PI);
 }
 
-__device__ void fb_update_derived(const segk_fbgmm &f, int D, int k, double *red)
+__device__ void fb_update_derived(const segk_fbgmm &f, int D, int k, double *red, const FbLocal *loc = nullptr)
 {
     const int tid = threadIdx.x, nt = blockDim.x;
     double part = 0.0;
@@ -55,25 +71,40 @@ __device__ void fb_update_derived(const segk_fbgmm &f, int D, int k, double *red
     double tot = block_sum(part, red);
     if (tid == 0) {
         f.log_prod[k] = tot;
-        f.kconst[k] = f.cov_type == 0 ? -0.5 * (double)D * LOG_2PI : fb_diag_const(f, D, (double)f.counts[k]);
+        if (f.cov_type == 0) f.kconst[k] = -0.5 * (double)D * LOG_2PI;
+        // (k_fb_chain: fb_diag_const by count from a table the same function filled once -- two lgamma calls by one thread
+        // were 2-4 us of every add_item / del_item; the reference reads its lgamma values from tables indexed by the count
+        // too, gaussian_components_diag.py:128-131)
+        else if (loc && loc->ktab && f.counts[k] >= 0 && f.counts[k] < loc->ktab_n) f.kconst[k] = loc->ktab[f.counts[k]];
+        else f.kconst[k] = fb_diag_const(f, D, (double)f.counts[k]);
     }
     __syncthreads();
 }
 
 template <typename XT>
-__device__ void fb_del_component(const segk_corpus &c, const segk_fbgmm &f, int k, int *shK)
+__device__ void fb_del_component(const segk_corpus &c, const segk_fbgmm &f, int k, int *shK, const FbLocal *loc = nullptr)
 {
     // *shK already decremented
     const int tid = threadIdx.x, nt = blockDim.x, D = c.D;
     const int K = *shK;
+    if (loc && tid == 0) {                       // (k == K too: the log also tells the launcher that a component went)
+        const int n = *loc->n_relog;
+        if (n < FB_RELOG) { loc->relog[2 * n] = K; loc->relog[2 * n + 1] = k; }
+        *loc->n_relog = n + 1;
+    }
     if (k != K) {
         for (int d = tid; d < D; d += nt) {
             f.stat_a[(int64_t)k * D + d] = f.stat_a[(int64_t)K * D + d];
             f.stat_b[(int64_t)k * D + d] = f.stat_b[(int64_t)K * D + d];
             f.pred[(int64_t)k * D + d] = f.pred[(int64_t)K * D + d];
         }
-        for (int64_t e = tid; e < c.n_emb; e += nt)
-            if (f.assignments[e] == K) f.assignments[e] = k;
+        if (loc) {
+            for (int i = tid; i < loc->nrows; i += nt)
+                if (loc->asg[i] == K) loc->asg[i] = k;
+        } else {
+            for (int64_t e = tid; e < c.n_emb; e += nt)
+                if (f.assignments[e] == K) f.assignments[e] = k;
+        }
     }
     __syncthreads();
     for (int d = tid; d < D; d += nt) {
@@ -120,7 +151,7 @@ __device__ __forceinline__ double x_sq(XT x)
 
 template <typename XT>
 __device__ void fb_add_item(const segk_corpus &c, const segk_fbgmm &f, int64_t e, int k_in, int *shK, int *sh_i,
-                            double *red)
+                            double *red, const FbLocal *loc = nullptr)
 {
     const int tid = threadIdx.x, nt = blockDim.x, D = c.D;
     const XT *X = (const XT *)c.X;
@@ -151,11 +182,12 @@ __device__ void fb_add_item(const segk_corpus &c, const segk_fbgmm &f, int64_t e
         f.assignments[e] = k;
     }
     __syncthreads();
-    fb_update_derived(f, D, k, red);
+    fb_update_derived(f, D, k, red, loc);
 }
 
 template <typename XT>
-__device__ void fb_del_item(const segk_corpus &c, const segk_fbgmm &f, int64_t e, int *shK, int *sh_i, double *red)
+__device__ void fb_del_item(const segk_corpus &c, const segk_fbgmm &f, int64_t e, int *shK, int *sh_i, double *red,
+                            const FbLocal *loc = nullptr)
 {
     const int tid = threadIdx.x, nt = blockDim.x, D = c.D;
     const XT *X = (const XT *)c.X;
@@ -175,7 +207,7 @@ __device__ void fb_del_item(const segk_corpus &c, const segk_fbgmm &f, int64_t e
     if (sh_cnt0) {
         if (tid == 0) *shK = *shK - 1;
         __syncthreads();
-        fb_del_component<XT>(c, f, k, shK);
+        fb_del_component<XT>(c, f, k, shK, loc);
     } else {
         for (int d = tid; d < D; d += nt) {
             const double x = (double)X[e * c.ldx + d];
@@ -188,7 +220,7 @@ __device__ void fb_del_item(const segk_corpus &c, const segk_fbgmm &f, int64_t e
             }
         }
         __syncthreads();
-        fb_update_derived(f, D, k, red);
+        fb_update_derived(f, D, k, red, loc);
     }
 }
 
@@ -377,8 +409,13 @@ __device__ void fb_logits(const segk_corpus &c, const segk_fbgmm &f, int64_t e, 
     for (int d = tid; d < D; d += nt) xrow[d] = X[e * c.ldx + d];
     double csum = 0.0;
     const int64_t *cnts = (mode >= 3) ? f.lm_unigram : f.counts;
-    for (int k = tid; k < KM; k += nt) csum += (double)cnts[k];
-    const double total = block_sum(csum, red);          // exact: integer-valued (also publishes xrow)
+    double total = 0.0;
+    if (mode == 1 || mode == 2) {
+        __syncthreads();                                // (the assignment priors of these modes do not use the total) publishes xrow
+    } else {
+        for (int k = tid; k < KM; k += nt) csum += (double)cnts[k];
+        total = block_sum(csum, red);                   // exact: integer-valued (also publishes xrow)
+    }
     double lprior = 0.0;
     if (K < KM) lprior = fb_prior_finish(f, block_sum(fb_prior_sum<XT>(f, D, xrow, tid, nt), red));
     int G = 1;
@@ -583,6 +620,245 @@ __global__ __launch_bounds__(512) void k_fbgmm_assign(segk_corpus c, segk_fbgmm 
     }
     __syncthreads();
     if (threadIdx.x == 0) *f.K = shK;
+}
+
+
+// ---------------------------------------------------------------------------------------
+// The reference's serial Gibbs chain (gibbs_sample_i for one utterance after the other,
+// unigram_acoustic_wordseg.py:252-360, 437-457) as ONE persistent kernel (round 4).
+//
+// The four launches per utterance (remove, score, sample boundaries, assign) cost 212 us per utterance at
+// configs[1] (D = 39, K = 100): four kernel boundaries and, in the assignment kernel, a dozen dependent round trips
+// through statistics in global memory per token, every one of them paid for every utterance because utterance
+// i + 1 needs the statistics utterance i leaves behind.  Here G workgroups stay resident for a whole sweep:
+//
+//   * EVERY workgroup holds the whole model in LDS (statistics, derived terms, counts, K: 3 K_max D + 3 K_max
+//     doubles; the kernel applies where that fits) and applies every update itself -- replicated arithmetic on
+//     identical inputs, the same device functions as the launches, so nothing about the model ever crosses
+//     workgroups and the results are the launches' bits;
+//   * the one thing that is shared out is the span scores (log_marg_i of every candidate span: K_max x D terms
+//     each, 105 spans per utterance at 20 landmarks): workgroup g scores the spans g, g + G, ... and publishes them
+//     with atomics; ONE grid barrier per utterance; then every workgroup reads all of them and runs the same
+//     forward filtering / backward sampling on the same uniforms (the stream's cursor is replicated too) and the
+//     same sequence of assignments;
+//   * workgroup 0 alone writes what leaves the kernel (labels, boundaries, token lists, totals; at the end the model).
+//
+// Labels: the utterance's rows are contiguous in X; their labels are staged in LDS (f.assignments addresses the
+// staging array as if it began at row 0) and written back by workgroup 0 after the utterance.  A component that
+// empties moves the last component into its slot (gaussian_components_*.py del_component): the utterance's own
+// rows are relabelled in LDS at once, all workgroups leave after the utterance, the launcher relabels the other
+// rows (k_fb_relabel) and starts the kernel again at the next utterance.
+// ---------------------------------------------------------------------------------------
+struct FbChainArgs {
+    segk_corpus c;
+    segk_fbgmm f;
+    const int32_t *order;           // [dev] utterances of the sweep
+    int q0, q1;                     // this launch walks order[q0 .. q1)
+    const int32_t *row_start;       // [dev] [n_utt + 1] first row of every utterance
+    int max_rows;                   // rows of an utterance at most
+    int viterbi, map_assign, n_max;
+    double wip, time_power_term, log_p_continue, anneal_fb, anneal_am;
+    unsigned long long *score;      // [dev] [n_emb] span scores as bit patterns (the exchange between the workgroups)
+    const double *ustream;
+    int64_t *ucursor;
+    int64_t ucap;
+    uint8_t *boundaries;
+    int32_t *new_tok, *n_new;
+    double *out_logprob;
+    int32_t *status;
+    int32_t *ctl;                   // [0] barrier counter, [2] utterances completed, [3] error, [4] relabels logged, [5] utterance of
+                                    // the relabels, [8 ..] the pairs, [32 (1 + f)] release words
+    unsigned long long *stamp;      // development (make DEV=1, SEGK_CHAIN_STAMP=1): wall_clock64 of workgroup 0 at the phase boundaries
+    const double *ktab;             // fb_diag_const by count (diagonal components), [ktab_n], or NULL
+    int64_t ktab_n;
+};
+#define FBC_STAMP(slot)                                                                                                   \
+    do {                                                                                                                   \
+        if (A.stamp && blockIdx.x == 0 && tid == 0 && q - A.q0 < 256) A.stamp[(q - A.q0) * 8 + (slot)] = wall_clock64();  \
+    } while (0)
+#define FBC_THREADS 512
+
+template <typename XT>
+__global__ __launch_bounds__(FBC_THREADS) void k_fb_chain(FbChainArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char fbc_lds[];
+    const segk_corpus &c = A.c;
+    const int tid = threadIdx.x, lane = tid & 63, nt = FBC_THREADS;
+    const int D = c.D, KM = A.f.K_max, NM = c.N_max;
+    const int64_t KD = (int64_t)KM * D, triMax = (int64_t)NM * (NM + 1) / 2;
+    // ---- LDS: the model, then the per-utterance buffers
+    double *sa = reinterpret_cast<double *>(fbc_lds), *sb = sa + KD, *pp = sb + KD;
+    double *lp = pp + KD, *kc = lp + KM;                                  // [K_max], [K_max + 1]
+    int64_t *cn = reinterpret_cast<int64_t *>(kc + KM + 1);               // [K_max]
+    double *z = reinterpret_cast<double *>(cn + KM);                      // [K_max]
+    double *red = z + KM;                                                 // [nt]
+    double *vec = red + nt;                                               // [triMax]
+    double *al = vec + triMax, *ww = al + NM, *pr = ww + NM + 1;          // [N_max], [N_max + 1], [N_max + 1]
+    XT *xrow = reinterpret_cast<XT *>(pr + NM + 1);                       // [D] (rounded to 8 bytes)
+    int32_t *vid_l = reinterpret_cast<int32_t *>(reinterpret_cast<unsigned char *>(xrow) + (((size_t)D * sizeof(XT) + 7) & ~(size_t)7));   // [triMax]
+    int32_t *spans = vid_l + triMax;                                      // [triMax] the valid entries of vid_l, in order
+    int32_t *asg_l = spans + triMax;                                      // [max_rows]
+    int32_t *tok_l = asg_l + A.max_rows;                                  // [N_max]
+    uint8_t *bnd_l = reinterpret_cast<uint8_t *>(tok_l + NM);             // [N_max] (rounded to 16 bytes)
+    XT *xs_l = reinterpret_cast<XT *>(bnd_l + ((NM + 15) & ~15));         // [max_rows][D] the utterance's rows of X
+    __shared__ int shK, ldsK, sh_i, sh_k, sh_flag, sh_nn, sh_nspan, n_relog;
+    __shared__ int32_t relog[2 * FB_RELOG];
+    __shared__ long long sh_cur;
+    __shared__ double sh_total;
+    for (int64_t i = tid; i < KD; i += nt) { sa[i] = A.f.stat_a[i]; sb[i] = A.f.stat_b[i]; pp[i] = A.f.pred[i]; }
+    for (int i = tid; i < KM; i += nt) { lp[i] = A.f.log_prod[i]; kc[i] = A.f.kconst[i]; cn[i] = A.f.counts[i]; }
+    if (tid == 0) { kc[KM] = A.f.kconst[KM]; shK = *A.f.K; ldsK = shK; sh_cur = *A.ucursor; }
+    segk_fbgmm fl = A.f;
+    fl.stat_a = sa; fl.stat_b = sb; fl.pred = pp; fl.log_prod = lp; fl.kconst = kc; fl.counts = cn; fl.K = &ldsK;
+    __syncthreads();
+    int phase = 0;
+    for (int q = A.q0; q < A.q1; q++) {
+        const int u = A.order[q];
+        const int N = c.lengths[u], tri = N * (N + 1) / 2;
+        const int64_t row0 = A.row_start[u];
+        const int nrows = A.row_start[u + 1] - (int)row0;
+        const int32_t *vid = c.vec_ids + (int64_t)u * triMax;
+        const double *dur = c.durations + (int64_t)u * triMax;
+        // ---- (A) stage the utterance: labels of its rows, span table, old boundaries
+        FBC_STAMP(0);
+        for (int i = tid; i < nrows; i += nt) asg_l[i] = A.f.assignments[row0 + i];
+        // (the rows themselves: every add_item / del_item / logits call read its row from global memory, a dependent round
+        // trip each, two dozen per utterance)
+        for (int i = tid; i < nrows * D; i += nt) {
+            const int r = i / D, d = i - r * D;
+            xs_l[i] = ((const XT *)c.X)[(row0 + r) * c.ldx + d];
+        }
+        for (int j = tid; j < tri; j += nt) vid_l[j] = vid[j];
+        for (int j = tid; j < N; j += nt) bnd_l[j] = A.boundaries[(int64_t)u * NM + j];
+        if (tid == 0) n_relog = 0;
+        __syncthreads();
+        fl.assignments = asg_l - row0;                   // (only the utterance's rows are ever named)
+        segk_corpus cl = c;                              // X as the device functions index it, backed by the staged rows
+        cl.X = xs_l - row0 * D;
+        cl.ldx = D;
+        const FbLocal loc{asg_l, row0, nrows, relog, &n_relog, A.ktab, A.ktab_n};
+        if (tid < 64) {                                  // the valid spans, in table order (one wave: ballot + prefix count)
+            int n = 0;
+            for (int j0 = 0; j0 < tri; j0 += 64) {
+                const int j = j0 + lane;
+                const bool ok = j < tri && vid_l[j] >= 0;
+                const unsigned long long m = __ballot(ok);
+                if (ok) spans[n + __popcll(m & ((1ull << lane) - 1ull))] = j;
+                n += __popcll(m);
+            }
+            if (lane == 0) sh_nspan = n;
+        }
+        // ---- (B) remove the utterance's old segments (unigram_acoustic_wordseg.py:270-273), replicated
+        FBC_STAMP(1);
+        {
+            int jp = 0;
+            for (int j = 0; j < N; j++) {
+                if (bnd_l[j]) {
+                    const int id = vid_l[(j + 1) * j / 2 + jp];
+                    jp = j + 1;
+                    if (id >= 0) fb_del_item<XT>(cl, fl, id, &shK, &sh_i, red, &loc);
+                }
+            }
+        }
+        __syncthreads();
+        if (tid == 0) ldsK = shK;
+        __syncthreads();
+        // ---- (C) this workgroup's share of the span scores: log_marg_i (fbgmm.py:256-285)
+        FBC_STAMP(2);
+        const int nspan = sh_nspan;
+        for (int s = blockIdx.x; s < nspan; s += gridDim.x) {
+            const int64_t e = vid_l[spans[s]];
+            fb_logits<XT>(cl, fl, e, 0, -1, xrow, z, red);
+            double mx = NEG_INF_D;
+            for (int k = tid; k < KM; k += nt) mx = z[k] > mx ? z[k] : mx;
+            mx = block_max(mx, red);
+            double sm = 0.0;
+            for (int k = tid; k < KM; k += nt) sm += exp(z[k] - mx);
+            sm = block_sum(sm, red);
+            if (tid == 0) atomicExch(&A.score[e], (unsigned long long)__double_as_longlong(log(sm) + mx));
+        }
+        FBC_STAMP(3);
+        if (!chain_barrier(A.ctl, ++phase, &sh_flag)) return;
+        FBC_STAMP(4);
+        // ---- (D) vec (unigram_acoustic_wordseg.py:474-511) from everybody's scores, the DP by wave 0 (replicated)
+        for (int j = tid; j < tri; j += nt) {
+            const int id = vid_l[j];
+            double v = NEG_INF_D;
+            if (id >= 0) {
+                const double dd = dur[j];
+                const double sc = __longlong_as_double((long long)__hip_atomic_load(&A.score[id], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                v = isnan(dd) ? NEG_INF_D : sc * (A.time_power_term == 1.0 ? dd : pow(dd, A.time_power_term));
+            }
+            vec[j] = v + A.wip;
+        }
+        __syncthreads();
+        if (tid < 64) {
+            StreamUniforms usrc = {A.ustream, (int64_t)sh_cur, A.ucap, A.status};
+            const double total = fb_dp_sample(vec, al, ww, pr, N, tri, A.n_max, A.viterbi, A.log_p_continue, A.anneal_fb, bnd_l, lane, usrc);
+            const int nn = fb_collect_tokens_wave(vid_l, bnd_l, N, tok_l, lane);
+            if (lane == 0) {
+                if (!A.viterbi && total == NEG_INF_D) atomicOr(A.status, 16);      // unigram_acoustic_wordseg.py:753
+                sh_cur = usrc.cur;
+                sh_total = total;
+                sh_nn = nn;
+            }
+        }
+        __syncthreads();
+        // ---- (E) the new segments, in order (fbgmm.py:422-494), replicated
+        FBC_STAMP(5);
+        const int nn = sh_nn;
+        for (int t = 0; t < nn; t++) {
+            const int64_t e = tok_l[t];
+            if (tid == 0) ldsK = shK;
+            __syncthreads();
+            fb_logits<XT>(cl, fl, e, A.map_assign ? 2 : 1, -1, xrow, z, red);
+            fb_draw_component(fl, z, red, A.map_assign, A.anneal_am, A.ustream, (int64_t *)&sh_cur, A.ucap, A.status, shK, &sh_k);
+            __syncthreads();
+            fb_add_item<XT>(cl, fl, e, sh_k, &shK, &sh_i, red, &loc);
+            __syncthreads();
+        }
+        // ---- (F) what leaves the kernel, by workgroup 0
+        FBC_STAMP(6);
+        bool stop = false;
+        for (int i = 0; i < n_relog && i < FB_RELOG; i++) stop = stop || relog[2 * i] != relog[2 * i + 1];
+        stop = stop || n_relog > FB_RELOG;
+        if (blockIdx.x == 0) {
+            for (int i = tid; i < nrows; i += nt) A.f.assignments[row0 + i] = asg_l[i];
+            for (int j = tid; j < N; j += nt) A.boundaries[(int64_t)u * NM + j] = bnd_l[j];
+            for (int t = tid; t < nn; t += nt) A.new_tok[(int64_t)u * NM + t] = tok_l[t];
+            if (tid == 0) {
+                A.n_new[u] = nn;
+                A.out_logprob[u] = sh_total;
+                A.ctl[2] = q + 1;
+                if (stop) {
+                    A.ctl[4] = n_relog;
+                    A.ctl[5] = u;
+                    for (int i = 0; i < 2 * FB_RELOG; i++) A.ctl[8 + i] = relog[i];
+                }
+            }
+        }
+        __syncthreads();
+        if (stop) break;
+    }
+    // ---- the model and the stream's cursor back to memory
+    if (blockIdx.x == 0) {
+        for (int64_t i = tid; i < KD; i += nt) { A.f.stat_a[i] = sa[i]; A.f.stat_b[i] = sb[i]; A.f.pred[i] = pp[i]; }
+        for (int i = tid; i < KM; i += nt) { A.f.log_prod[i] = lp[i]; A.f.kconst[i] = kc[i]; A.f.counts[i] = cn[i]; }
+        if (tid == 0) { *A.f.K = shK; *A.ucursor = (int64_t)sh_cur; }
+    }
+}
+
+__global__ void k_fb_kconst_tab(segk_fbgmm f, int D, int64_t n, double *out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = fb_diag_const(f, D, (double)i);
+}
+
+// the rows of every utterance but `skip_lo .. skip_hi` relabelled from -> to (a component moved into an emptied slot)
+__global__ void k_fb_relabel(int32_t *assignments, int64_t n, int64_t skip_lo, int64_t skip_hi, int from, int to)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n && (e < skip_lo || e >= skip_hi) && assignments[e] == from) assignments[e] = to;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -877,6 +1153,159 @@ int32_t segk_fbgmm_assign(segk_ctx *ctx, const segk_corpus *c, segk_fbgmm *f, in
                            j_prev, anneal_temp, new_tok, n_new, ustream, ucursor, ucap, status);
     });
     SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+// gibbs_sample_i (unigram_acoustic_wordseg.py:252-360) for every utterance of `order` in turn by the persistent kernel
+// k_fb_chain.  SEGK_ERR_UNSUPPORTED (nothing enqueued) where it does not apply: a language model, a model that does
+// not fit a workgroup's LDS, more than 64 landmarks, an utterance listed twice, assignments_only.  The call SYNCHRONISES the
+// stream after every launch (it reads how far the kernel got: a launch ends early when a component empties).
+int32_t segk_fbgmm_sequential_sweep(segk_ctx *ctx, const segk_corpus *c, segk_fbgmm *f, const int32_t *order, int32_t n_order,
+                                    const int32_t *row_start, int32_t viterbi, int32_t map_assign, int32_t n_slices_min,
+                                    int32_t n_slices_max, double wip, double time_power_term, double log_p_continue,
+                                    double anneal_temp_fb, double anneal_temp_am, double *score, const double *ustream,
+                                    int64_t *ucursor, int64_t ucap, uint8_t *boundaries, int32_t *new_tok, int32_t *n_new,
+                                    double *out_logprob, int32_t *status, void *stream)
+{
+    SEGK_REQUIRE(ctx, "ctx");
+    int rc = check_fb(c, f);
+    if (rc) return rc;
+    SEGK_REQUIRE(order && n_order >= 0 && row_start && score && ustream && ucursor && boundaries && new_tok && n_new && out_logprob && status,
+                 "sequential sweep operands");
+    SEGK_REQUIRE(c->vec_ids && c->durations && c->lengths && c->n_utt > 0, "corpus without utterances");
+    SEGK_REQUIRE(n_slices_min == 0 || n_slices_min == 1, "n_slices_min must be 0 or 1");
+    SEGK_REQUIRE(viterbi == 0 || viterbi == 1, "viterbi");
+    if (n_order == 0) return SEGK_OK;
+    const char *env = getenv("SEGK_FB_CHAIN");
+    if (env && atoi(env) == 0) { segk_set_error("segk_fbgmm_sequential_sweep: disabled (SEGK_FB_CHAIN=0)"); return SEGK_ERR_UNSUPPORTED; }
+    if (f->lm_unigram || c->N_max > 64 || ctx->capturing) {
+        segk_set_error("segk_fbgmm_sequential_sweep: no language-model variant, at most 64 landmarks");
+        return SEGK_ERR_UNSUPPORTED;
+    }
+    // rows of an utterance (host copy of row_start: the caller passes the device array; the extent comes from the order's
+    // utterances, read back once per corpus would do -- it is 4 (n_utt + 1) bytes)
+    std::vector<int32_t> rs((size_t)c->n_utt + 1);
+    hipStream_t st = (hipStream_t)stream;
+    SEGK_CHECK_HIP(hipMemcpyAsync(rs.data(), row_start, rs.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    SEGK_CHECK_HIP(hipStreamSynchronize(st));
+    int max_rows = 1;
+    {
+        std::vector<uint8_t> seen((size_t)c->n_utt, 0);
+        for (int32_t q = 0; q < n_order; q++) {
+            SEGK_REQUIRE(order[q] >= 0 && order[q] < c->n_utt, "utterance index out of range");
+            if (seen[order[q]]) { segk_set_error("segk_fbgmm_sequential_sweep: an utterance is listed twice"); return SEGK_ERR_UNSUPPORTED; }
+            seen[order[q]] = 1;
+            const int nr = rs[order[q] + 1] - rs[order[q]];
+            SEGK_REQUIRE(nr >= 0 && rs[order[q] + 1] <= c->n_emb, "row_start");
+            if (nr > max_rows) max_rows = nr;
+        }
+    }
+    const int KM = f->K_max, D = c->D, NM = c->N_max;
+    const int64_t KD = (int64_t)KM * D, triMax = (int64_t)NM * (NM + 1) / 2;
+    const size_t xb = ((size_t)D * (c->x_dtype == SEGK_F32 ? 4 : 8) + 7) & ~(size_t)7;
+    const size_t lds = (size_t)(3 * KD + 3 * KM + 1 + KM + FBC_THREADS + triMax + 3 * NM + 2) * sizeof(double) + xb +
+                       (size_t)(2 * triMax + max_rows + NM) * sizeof(int32_t) + (size_t)((NM + 15) & ~15) +
+                       (size_t)max_rows * D * (c->x_dtype == SEGK_F32 ? 4 : 8) + 16;
+    if (lds > 150 * 1024) {
+        segk_set_error("segk_fbgmm_sequential_sweep: the model (%d components x %d dimensions) does not fit a workgroup's LDS", KM, D);
+        return SEGK_ERR_UNSUPPORTED;
+    }
+    // control words + the order, owned by the context
+    const size_t ctl_bytes = 32 * (1 + CH_FLAGS) * sizeof(int32_t), need = ctl_bytes + (size_t)n_order * sizeof(int32_t);
+    if (ctx->fbchain_bytes < need) {
+        if (ctx->fbchain_buf) (void)hipFree(ctx->fbchain_buf);
+        ctx->fbchain_buf = nullptr;
+        ctx->fbchain_bytes = 0;
+        SEGK_CHECK_HIP(hipMalloc(&ctx->fbchain_buf, need));
+        ctx->fbchain_bytes = need;
+    }
+    unsigned char *buf = (unsigned char *)ctx->fbchain_buf;
+    FbChainArgs A{};
+    A.c = *c; A.f = *f;
+    A.ctl = (int32_t *)buf;
+    A.order = (const int32_t *)(buf + ctl_bytes);
+    A.row_start = row_start; A.max_rows = max_rows;
+    A.viterbi = viterbi; A.map_assign = map_assign; A.n_max = n_slices_max;
+    A.wip = wip; A.time_power_term = time_power_term; A.log_p_continue = log_p_continue;
+    A.anneal_fb = anneal_temp_fb; A.anneal_am = anneal_temp_am;
+    A.score = (unsigned long long *)score;
+    A.ustream = ustream; A.ucursor = ucursor; A.ucap = ucap;
+    A.boundaries = boundaries; A.new_tok = new_tok; A.n_new = n_new; A.out_logprob = out_logprob; A.status = status;
+    SEGK_CHECK_HIP(hipMemcpyAsync((void *)A.order, order, (size_t)n_order * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    const bool stamping = segk_dev_env("SEGK_CHAIN_STAMP") != 0;      // make DEV=1 builds only
+    static unsigned long long *stamp_dev = nullptr;
+    if (stamping && !stamp_dev) SEGK_CHECK_HIP(hipMalloc((void **)&stamp_dev, 257 * 8 * sizeof(unsigned long long)));
+    A.stamp = stamping ? stamp_dev : nullptr;
+    // diagonal components: fb_diag_const by count, once per (prior, corpus size)
+    A.ktab = nullptr;
+    A.ktab_n = 0;
+    if (f->cov_type == 1) {
+        const int64_t n = c->n_emb + 2;
+        if (!ctx->fb_ktab || ctx->fb_ktab_n < n || ctx->fb_ktab_v0 != f->v_0 || ctx->fb_ktab_D != D) {
+            if (ctx->fb_ktab) (void)hipFree(ctx->fb_ktab);
+            ctx->fb_ktab = nullptr;
+            SEGK_CHECK_HIP(hipMalloc((void **)&ctx->fb_ktab, (size_t)n * sizeof(double)));
+            hipLaunchKernelGGL(k_fb_kconst_tab, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, *f, D, n, ctx->fb_ktab);
+            ctx->fb_ktab_n = n;
+            ctx->fb_ktab_v0 = f->v_0;
+            ctx->fb_ktab_D = D;
+        }
+        A.ktab = ctx->fb_ktab;
+        A.ktab_n = ctx->fb_ktab_n;
+    }
+    // one workgroup per span of an utterance at most (105 at 20 landmarks and a window of six), never more than fit together
+    int G = ctx->n_cu < 128 ? ctx->n_cu : 128;
+    {
+        const int64_t spans = (int64_t)max_rows < triMax ? max_rows : triMax;
+        if (spans < G) G = (int)(spans > 0 ? spans : 1);
+    }
+    int q = 0;
+    while (q < n_order) {
+        SEGK_CHECK_HIP(hipMemsetAsync(buf, 0, ctl_bytes, st));
+        A.q0 = q; A.q1 = n_order;
+        DISPATCH_XT(c, {
+            SEGK_CHECK_HIP(segk_dyn_lds((const void *)k_fb_chain<XT>, lds));
+            hipLaunchKernelGGL(k_fb_chain<XT>, dim3(G), dim3(FBC_THREADS), lds, st, A);
+        });
+        SEGK_LAUNCH_CHECK();
+        int32_t ctl[8 + 2 * FB_RELOG];
+        SEGK_CHECK_HIP(hipMemcpyAsync(ctl, A.ctl, sizeof(ctl), hipMemcpyDeviceToHost, st));
+        SEGK_CHECK_HIP(hipStreamSynchronize(st));
+        if (ctl[3] != 0) {
+            segk_set_error("FBGMM chain: grid barrier timed out (%d workgroups were not resident together?)", G);
+            return SEGK_ERR_HIP;
+        }
+        if (ctl[2] <= q) {
+            segk_set_error("FBGMM chain: no progress at utterance %d", q);
+            return SEGK_ERR_HIP;
+        }
+        if (stamping && ctl[2] - q >= 120) {       // a long launch: mean time of the phases, in 10 ns ticks of the 100 MHz clock
+            static unsigned long long hs[257 * 8];
+            SEGK_CHECK_HIP(hipMemcpy(hs, stamp_dev, sizeof(hs), hipMemcpyDeviceToHost));
+            double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            const int n0 = 10, n1 = 110;
+            for (int i = n0; i < n1; i++) {
+                for (int j = 0; j < 6; j++) acc[j] += (double)(hs[i * 8 + j + 1] - hs[i * 8 + j]);
+                acc[6] += (double)(hs[(i + 1) * 8] - hs[i * 8 + 6]);
+                acc[7] += (double)(hs[(i + 1) * 8] - hs[i * 8]);
+            }
+            const double dn = 100.0 * (n1 - n0);
+            fprintf(stderr, "fb chain stamps (us): stage %.2f  remove %.2f  scores %.2f  barrier %.2f  vec+dp %.2f  assign %.2f  write %.2f | per utterance %.2f\n",
+                    acc[0] / dn, acc[1] / dn, acc[2] / dn, acc[3] / dn, acc[4] / dn, acc[5] / dn, acc[6] / dn, acc[7] / dn);
+        }
+        q = ctl[2];
+        if (ctl[4] > 0) {                 // components emptied during utterance ctl[5]: the other utterances' rows follow
+            SEGK_REQUIRE(ctl[4] <= FB_RELOG, "FBGMM chain: more components emptied within one utterance than the log holds");
+            const int u = ctl[5];
+            for (int i = 0; i < ctl[4]; i++) {
+                const int from = ctl[8 + 2 * i], to = ctl[8 + 2 * i + 1];
+                if (from != to)
+                    hipLaunchKernelGGL(k_fb_relabel, dim3((unsigned)((c->n_emb + 255) / 256)), dim3(256), 0, st, f->assignments,
+                                       c->n_emb, (int64_t)rs[u], (int64_t)rs[u + 1], from, to);
+            }
+            SEGK_LAUNCH_CHECK();
+        }
+    }
     return SEGK_OK;
 }
 

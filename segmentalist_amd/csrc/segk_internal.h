@@ -28,6 +28,12 @@ struct segk_ctx {
     // persistent sequential chain (segk_seq_chain.hip): span maxima, control words, the sweep's utterance order
     void *chain_buf;
     size_t chain_bytes;
+    double *fb_ktab;              // persistent FBGMM chain: fb_diag_const by count (diagonal components)
+    int64_t fb_ktab_n;
+    double fb_ktab_v0;
+    int fb_ktab_D;
+    void *fbchain_buf;            // persistent FBGMM chain (segk_fbgmm.hip k_fb_chain): control words, the sweep's utterance order
+    size_t fbchain_bytes;
     // batch sampler: the block's tokens bucketed by slot (k_fbb_sort) + offsets
     int32_t *fbs_buf;
     size_t fbs_bytes;

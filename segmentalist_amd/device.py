@@ -861,6 +861,30 @@ class DeviceFbgmm(object):
         if self.lm is not None:
             check(L.segk_fbgmm_update(ctx, cp, fp, 6, int(i), 0, 0, ptr(boundaries), st))
 
+    def sequential_sweep(self, boundaries, order, row_start, viterbi, n_slices_min, n_slices_max, wip, time_power_term,
+                         log_p_continue, anneal_temp_fb, anneal_temp_am, map_assign=None):
+        """gibbs_utt for every utterance of `order` in turn by ONE library call (segk_fbgmm_sequential_sweep: a persistent
+        kernel per stretch of utterances between two emptied components; the call synchronises the stream).  Returns False,
+        with nothing enqueued, where the kernel does not apply (a language model, a model too large for a workgroup's LDS,
+        ...): the caller then walks the utterances itself."""
+        if self.lm is not None or self.corpus.N_max > 64:
+            return False
+        if getattr(self, "_row_start_dev", None) is None:
+            self._row_start_dev = to_dev(np.asarray(row_start, dtype=np.int32))
+        arr = np.ascontiguousarray(order, dtype=np.int32)
+        if map_assign is None:
+            map_assign = viterbi
+        rc = self._L.segk_fbgmm_sequential_sweep(
+            self._ctx, self._cp(), C.byref(self.f), arr.ctypes.data, len(arr), ptr(self._row_start_dev), 1 if viterbi else 0,
+            1 if map_assign else 0, int(n_slices_min), int(n_slices_max), float(wip), float(time_power_term),
+            float(log_p_continue), float(anneal_temp_fb), float(anneal_temp_am), ptr(self.score), ptr(self.ustream),
+            ptr(self.ucursor), self.ustream.numel(), ptr(boundaries), ptr(self.new_tok), ptr(self.n_new),
+            ptr(self.out_logprob), ptr(self.status), _abi.stream())
+        if rc == _abi.SEGK_ERR_UNSUPPORTED:
+            return False
+        check(rc)
+        return True
+
     def record_metrics(self, urn=False, urn_a=0.0):
         """(log_prob_z, log_prob_X_given_z, K, n_assigned) of the sequential-mode state, computed on the device (segk_fbgmm_record_metrics): fbgmm.py:208-225 or, with urn=True,
         bigram_acoustic_wordseg.py:287-305; gaussian_components_{fixedvar,diag}.py log_marg."""

@@ -237,8 +237,17 @@ class UnigramAcousticWordseg(object):
                 if debug_gibbs_only:
                     utt_order = [i_debug_monitor]
                 self._open_stream(utt_order)
-                for i_utt in utt_order:
-                    self._gibbs_i_async(i_utt, anneal_temp, anneal_gibbs_am)
+                # the whole chain of the sweep by one library call (a persistent kernel per stretch of utterances between two
+                # emptied components) where it applies; SEGK_SEQ_PER_UTT=1 / SEGK_FB_CHAIN=0 keep the four launches per utterance
+                whole = os.environ.get("SEGK_SEQ_PER_UTT", "0") != "1" and not debug_gibbs_only and self._df.sequential_sweep(
+                    self._dev_bounds, utt_order, self._row_start, self.fb_type == "viterbi", self.n_slices_min, self.n_slices_max,
+                    self.wip, self.time_power_term, math.log(self.calc_p_continue()), anneal_temp,
+                    anneal_temp if anneal_gibbs_am else 1.0)
+                if whole:
+                    self.utterances.mark_device_dirty()
+                else:
+                    for i_utt in utt_order:
+                        self._gibbs_i_async(i_utt, anneal_temp, anneal_gibbs_am)
                 torch.cuda.synchronize()
                 self._close_stream()
                 self._df.check_status()

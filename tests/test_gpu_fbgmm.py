@@ -258,3 +258,41 @@ def test_unigram_chain_with_am_iterations_vs_reference(gpu, golden, chain):
     npt.assert_allclose(rec["log_marg"], g[tag + "_rec_log_marg"], rtol=1e-8)
     assert list(rec["components"]) == list(g[tag + "_rec_components"])
     assert list(rec["n_tokens"]) == list(g[tag + "_rec_n_tokens"])
+
+
+@pytest.mark.parametrize("cov", ["diag", "fixed"])
+@pytest.mark.parametrize("fb_type", ["standard", "viterbi"])
+def test_persistent_chain_equals_the_four_launches_per_utterance(gpu, monkeypatch, cov, fb_type):
+    """segk_fbgmm_sequential_sweep (one persistent kernel per stretch of utterances between two emptied components: every
+    workgroup replays every update on a model held in LDS, only the span scores are shared out) against the four launches
+    per utterance (SEGK_FB_CHAIN=0) from identical states: boundaries, assignments, every statistic, K, the record values and
+    the position of the RNG stream bit for bit, over sweeps in which components empty (ragged utterances, more components
+    than the data support)."""
+    from segmentalist_amd import fbgmm, unigram_acoustic_wordseg as uaw
+    from segmentalist_amd.gaussian_components_fixedvar import FixedVarPrior
+    from segmentalist_amd.niw import NIW
+    from segmentalist_amd.synth import make_corpus
+    D, K = 12, 30
+    corpus = make_corpus(60, D, K, seed=4, ragged=True, n_slices_max=5, N_range=(3, 14))
+    prior = (FixedVarPrior(0.002 * np.ones(D), np.zeros(D), 0.002 / 0.05 * np.ones(D)) if cov == "fixed"
+             else NIW(np.zeros(D), 0.05, D + 3, 0.002 * (D + 3) * np.ones(D)))
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SEGK_FB_CHAIN", mode)
+        random.seed(3)
+        np.random.seed(3)
+        seg = uaw.UnigramAcousticWordseg(fbgmm.FBGMM, 1.0, K, prior, *corpus, covariance_type=cov, fb_type=fb_type,
+                                         n_slices_min=0, n_slices_max=5, p_boundary_init=0.5, beta_sent_boundary=-1, lms=1.0,
+                                         wip=0.0, init_am_assignments="rand", time_power_term=1.0)
+        rec = seg.gibbs_sample(4, anneal_schedule="linear", anneal_gibbs_am=True)
+        df = seg._df
+        out[mode] = dict(b=seg.utterances.boundaries.copy(), a=seg.acoustic_model.components.assignments.copy(),
+                         sa=df.stat_a.cpu().numpy(), sb=df.stat_b.cpu().numpy(), pr=df.pred.cpu().numpy(),
+                         lp=df.log_prod.cpu().numpy(), kc=df.kconst.cpu().numpy(), cn=df.counts.cpu().numpy(),
+                         K=int(df.K.item()), rec={k: list(v) for k, v in rec.items() if k != "sample_time"}, rnd=random.random())
+    assert min(out["1"]["rec"]["components"]) < K, "no component emptied: the test does not cover the relaunches"
+    for k in out["1"]:
+        if isinstance(out["1"][k], np.ndarray):
+            assert np.array_equal(out["1"][k], out["0"][k]), k
+        else:
+            assert out["1"][k] == out["0"][k], k
