@@ -8,38 +8,6 @@
 #define LOG_2PI 1.8378770664093453
 #define LOG_PI 1.1447298858494002
 
-// ---------------------------------------------------------------------------------------
-// block-wide helpers (blockDim.x a multiple of 64, <= 1024; `red` has >= 16 doubles)
-// ---------------------------------------------------------------------------------------
-// Butterfly inside each wave, then the per-wave partials (<= 16) are added in wave order by every
-// thread: two barriers per reduction and a fixed, launch-independent order.
-static __device__ double block_sum(double v, double *red)
-{
-    const int tid = threadIdx.x, nw = blockDim.x >> 6;
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    __syncthreads();                      // `red` may still be read from a previous reduction
-    if ((tid & 63) == 0) red[tid >> 6] = v;
-    __syncthreads();
-    double r = red[0];
-    for (int w = 1; w < nw; w++) r += red[w];
-    return r;
-}
-
-static __device__ double block_max(double v, double *red)
-{
-    const int tid = threadIdx.x, nw = blockDim.x >> 6;
-    for (int o = 32; o > 0; o >>= 1) {
-        const double other = __shfl_xor(v, o);
-        v = other > v ? other : v;
-    }
-    __syncthreads();
-    if ((tid & 63) == 0) red[tid >> 6] = v;
-    __syncthreads();
-    double r = red[0];
-    for (int w = 1; w < nw; w++) r = red[w] > r ? red[w] : r;
-    return r;
-}
-
 static __device__ __forceinline__ double fb_readlane(double v, int l)       // l wave-uniform
 {
     union { double d; int i[2]; } u;
@@ -51,6 +19,88 @@ static __device__ __forceinline__ double fb_readlane(double v, int l)       // l
 
 // _cython_utils.pyx:13-25 (max, then the sum of exp(a[j] - max) in index order, then log) by one
 // full wave: the exponentials are evaluated one per lane, the additions stay sequential.
+// Cross-lane moves inside a row of sixteen lanes (DPP: a few clocks; __shfl_xor on a double is two ds_bpermute round trips, and
+// a lone wave -- the DP is one wave per utterance -- waits out every one of them)
+template <int CTRL>
+static __device__ __forceinline__ double fb_dpp_f64(double v)
+{
+    union { double d; int i[2]; } u, r;
+    u.d = v;
+    r.i[0] = __builtin_amdgcn_update_dpp(u.i[0], u.i[0], CTRL, 0xF, 0xF, false);
+    r.i[1] = __builtin_amdgcn_update_dpp(u.i[1], u.i[1], CTRL, 0xF, 0xF, false);
+    return r.d;
+}
+// maximum over the lanes 0..15 of a row, in all of them (quad xor 1, xor 2, half-row mirror, row mirror)
+static __device__ __forceinline__ double fb_row16_max(double v)
+{
+    double o = fb_dpp_f64<0xB1>(v);
+    v = o > v ? o : v;
+    o = fb_dpp_f64<0x4E>(v);
+    v = o > v ? o : v;
+    o = fb_dpp_f64<0x141>(v);
+    v = o > v ? o : v;
+    o = fb_dpp_f64<0x140>(v);
+    v = o > v ? o : v;
+    return v;
+}
+
+// maximum over all 64 lanes, wave-uniform: the rows' maxima by DPP, the four rows' by v_readlane (one row when `one_row`)
+static __device__ __forceinline__ double fb_wave_max(double v, bool one_row)
+{
+    v = fb_row16_max(v);
+    double m = fb_readlane(v, 0);
+    if (!one_row) {
+        const double m1 = fb_readlane(v, 16), m2 = fb_readlane(v, 32), m3 = fb_readlane(v, 48);
+        m = m1 > m ? m1 : m;
+        const double m23 = m3 > m2 ? m3 : m2;
+        m = m23 > m ? m23 : m;
+    }
+    return m;
+}
+
+// sum over all 64 lanes, in every lane, in a fixed order: inside the rows of sixteen by DPP (quad xor 1, xor 2, half-row mirror,
+// row mirror: at every step the partners hold the totals of disjoint groups), the four rows' totals by v_readlane as
+// (r0 + r1) + (r2 + r3).  (__shfl_xor on a double is two ds_bpermute round trips per step: six steps were ~0.5 us of every
+// block-wide reduction, and the serial chains do a dozen of those per token.)
+static __device__ __forceinline__ double fb_wave_sum(double v)
+{
+    v += fb_dpp_f64<0xB1>(v);
+    v += fb_dpp_f64<0x4E>(v);
+    v += fb_dpp_f64<0x141>(v);
+    v += fb_dpp_f64<0x140>(v);
+    const double r0 = fb_readlane(v, 0), r1 = fb_readlane(v, 16), r2 = fb_readlane(v, 32), r3 = fb_readlane(v, 48);
+    return (r0 + r1) + (r2 + r3);
+}
+
+// ---------------------------------------------------------------------------------------
+// block-wide helpers (blockDim.x a multiple of 64, <= 1024; `red` has >= 16 doubles)
+// ---------------------------------------------------------------------------------------
+// The wave's total by DPP + v_readlane (fb_wave_sum), then the per-wave partials (<= 16) are added in wave order by every
+// thread: two barriers per reduction and a fixed, launch-independent order.
+static __device__ double block_sum(double v, double *red)
+{
+    const int tid = threadIdx.x, nw = blockDim.x >> 6;
+    v = fb_wave_sum(v);
+    __syncthreads();                      // `red` may still be read from a previous reduction
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    double r = red[0];
+    for (int w = 1; w < nw; w++) r += red[w];
+    return r;
+}
+
+static __device__ double block_max(double v, double *red)
+{
+    const int tid = threadIdx.x, nw = blockDim.x >> 6;
+    v = fb_wave_max(v, false);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    double r = red[0];
+    for (int w = 1; w < nw; w++) r = red[w] > r ? red[w] : r;
+    return r;
+}
+
 static __device__ double fb_logsumexp_wave(const double *a, int n, int lane)
 {
     double mx = NEG_INF_D;
@@ -216,45 +266,6 @@ struct CounterUniforms {       // the batch sampler's counter-based stream
     uint64_t seed, sweep, utt, j;
     __device__ double next(int) { return segk_u01(seed, sweep, utt, j++); }
 };
-
-// Cross-lane moves inside a row of sixteen lanes (DPP: a few clocks; __shfl_xor on a double is two ds_bpermute round trips, and
-// a lone wave -- the DP is one wave per utterance -- waits out every one of them)
-template <int CTRL>
-static __device__ __forceinline__ double fb_dpp_f64(double v)
-{
-    union { double d; int i[2]; } u, r;
-    u.d = v;
-    r.i[0] = __builtin_amdgcn_update_dpp(u.i[0], u.i[0], CTRL, 0xF, 0xF, false);
-    r.i[1] = __builtin_amdgcn_update_dpp(u.i[1], u.i[1], CTRL, 0xF, 0xF, false);
-    return r.d;
-}
-// maximum over the lanes 0..15 of a row, in all of them (quad xor 1, xor 2, half-row mirror, row mirror)
-static __device__ __forceinline__ double fb_row16_max(double v)
-{
-    double o = fb_dpp_f64<0xB1>(v);
-    v = o > v ? o : v;
-    o = fb_dpp_f64<0x4E>(v);
-    v = o > v ? o : v;
-    o = fb_dpp_f64<0x141>(v);
-    v = o > v ? o : v;
-    o = fb_dpp_f64<0x140>(v);
-    v = o > v ? o : v;
-    return v;
-}
-
-// maximum over all 64 lanes, wave-uniform: the rows' maxima by DPP, the four rows' by v_readlane (one row when `one_row`)
-static __device__ __forceinline__ double fb_wave_max(double v, bool one_row)
-{
-    v = fb_row16_max(v);
-    double m = fb_readlane(v, 0);
-    if (!one_row) {
-        const double m1 = fb_readlane(v, 16), m2 = fb_readlane(v, 32), m3 = fb_readlane(v, 48);
-        m = m1 > m ? m1 : m;
-        const double m23 = m3 > m2 ? m3 : m2;
-        m = m23 > m ? m23 : m;
-    }
-    return m;
-}
 
 // A6 / A7 by one full wave (unigram_acoustic_wordseg.py:653-864): forward filtering, then backward
 // sampling (or Viterbi back-tracking) writing the boundaries; returns the summed score of the chosen

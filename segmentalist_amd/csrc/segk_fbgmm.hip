@@ -399,7 +399,7 @@ __device__ double fb_log_prior(const segk_fbgmm &f, int D, const XT *x)
 // component and strides over the dimensions; partial sums are combined by a butterfly.
 template <typename XT>
 __device__ void fb_logits(const segk_corpus &c, const segk_fbgmm &f, int64_t e, int mode, int j_prev, XT *xrow,
-                          double *z, double *red)
+                          double *z, double *red, const double *lprior_tab = nullptr)
 {
     const int tid = threadIdx.x, nt = blockDim.x, D = c.D;
     const XT *X = (const XT *)c.X;
@@ -416,8 +416,10 @@ __device__ void fb_logits(const segk_corpus &c, const segk_fbgmm &f, int64_t e, 
         for (int k = tid; k < KM; k += nt) csum += (double)cnts[k];
         total = block_sum(csum, red);                   // exact: integer-valued (also publishes xrow)
     }
+    // (lprior_tab: this very expression evaluated once per row by k_fb_prior_tab with the same number of threads -- it depends
+    // on the row and the prior only; the persistent chain passes it)
     double lprior = 0.0;
-    if (K < KM) lprior = fb_prior_finish(f, block_sum(fb_prior_sum<XT>(f, D, xrow, tid, nt), red));
+    if (K < KM) lprior = lprior_tab ? lprior_tab[e] : fb_prior_finish(f, block_sum(fb_prior_sum<XT>(f, D, xrow, tid, nt), red));
     int G = 1;
     while (G < 64 && KM * (G * 2) <= nt) G *= 2;
     const int g = tid & (G - 1), kk0 = tid / G, kstep = nt / G;
@@ -425,7 +427,10 @@ __device__ void fb_logits(const segk_corpus &c, const segk_fbgmm &f, int64_t e, 
         const int k = kb + kk0;
         double s = 0.0;
         if (k < K) s = fb_pred_sum<XT>(f, D, k, xrow, g, G);
-        for (int o = G >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        // (the same xor butterfly, o = G/2 ... 1; the steps inside a quad by DPP instead of two ds_bpermute round trips)
+        for (int o = G >> 1; o > 2; o >>= 1) s += __shfl_xor(s, o);
+        if (G >= 4) s += fb_dpp_f64<0x4E>(s);            // xor 2
+        if (G >= 2) s += fb_dpp_f64<0xB1>(s);            // xor 1
         if (g == 0 && k < KM) {
             double v;
             if (mode == 0) v = f.lms * (log(f.alpha / (double)KM + (double)f.counts[k]) - log(total + f.alpha));
@@ -671,19 +676,20 @@ struct FbChainArgs {
     unsigned long long *stamp;      // development (make DEV=1, SEGK_CHAIN_STAMP=1): wall_clock64 of workgroup 0 at the phase boundaries
     const double *ktab;             // fb_diag_const by count (diagonal components), [ktab_n], or NULL
     int64_t ktab_n;
+    const double *lprior_tab;       // [n_emb] log prior predictive of every row (k_fb_prior_tab), or NULL
 };
 #define FBC_STAMP(slot)                                                                                                   \
     do {                                                                                                                   \
         if (A.stamp && blockIdx.x == 0 && tid == 0 && q - A.q0 < 256) A.stamp[(q - A.q0) * 8 + (slot)] = wall_clock64();  \
     } while (0)
-#define FBC_THREADS 512
 
 template <typename XT>
-__global__ __launch_bounds__(FBC_THREADS) void k_fb_chain(FbChainArgs A)
+__global__ __launch_bounds__(512) void k_fb_chain(FbChainArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char fbc_lds[];
     const segk_corpus &c = A.c;
-    const int tid = threadIdx.x, lane = tid & 63, nt = FBC_THREADS;
+    const int tid = threadIdx.x, lane = tid & 63, nt = blockDim.x;      // (nt = fb_nt(f): the launches' number of threads -- the
+                                                                        // order of every block-wide sum depends on it)
     const int D = c.D, KM = A.f.K_max, NM = c.N_max;
     const int64_t KD = (int64_t)KM * D, triMax = (int64_t)NM * (NM + 1) / 2;
     // ---- LDS: the model, then the per-utterance buffers
@@ -700,7 +706,8 @@ __global__ __launch_bounds__(FBC_THREADS) void k_fb_chain(FbChainArgs A)
     int32_t *asg_l = spans + triMax;                                      // [max_rows]
     int32_t *tok_l = asg_l + A.max_rows;                                  // [N_max]
     uint8_t *bnd_l = reinterpret_cast<uint8_t *>(tok_l + NM);             // [N_max] (rounded to 16 bytes)
-    XT *xs_l = reinterpret_cast<XT *>(bnd_l + ((NM + 15) & ~15));         // [max_rows][D] the utterance's rows of X
+    double *pri_l = reinterpret_cast<double *>(bnd_l + ((NM + 15) & ~15));    // [3][D] the prior's vectors
+    XT *xs_l = reinterpret_cast<XT *>(pri_l + 3 * D);                     // [max_rows][D] the utterance's rows of X
     __shared__ int shK, ldsK, sh_i, sh_k, sh_flag, sh_nn, sh_nspan, n_relog;
     __shared__ int32_t relog[2 * FB_RELOG];
     __shared__ long long sh_cur;
@@ -708,8 +715,10 @@ __global__ __launch_bounds__(FBC_THREADS) void k_fb_chain(FbChainArgs A)
     for (int64_t i = tid; i < KD; i += nt) { sa[i] = A.f.stat_a[i]; sb[i] = A.f.stat_b[i]; pp[i] = A.f.pred[i]; }
     for (int i = tid; i < KM; i += nt) { lp[i] = A.f.log_prod[i]; kc[i] = A.f.kconst[i]; cn[i] = A.f.counts[i]; }
     if (tid == 0) { kc[KM] = A.f.kconst[KM]; shK = *A.f.K; ldsK = shK; sh_cur = *A.ucursor; }
+    for (int d = tid; d < D; d += nt) { pri_l[d] = A.f.prior_a[d]; pri_l[D + d] = A.f.prior_b[d]; pri_l[2 * D + d] = A.f.prior_c[d]; }
     segk_fbgmm fl = A.f;
     fl.stat_a = sa; fl.stat_b = sb; fl.pred = pp; fl.log_prod = lp; fl.kconst = kc; fl.counts = cn; fl.K = &ldsK;
+    fl.prior_a = pri_l; fl.prior_b = pri_l + D; fl.prior_c = pri_l + 2 * D;
     __syncthreads();
     int phase = 0;
     for (int q = A.q0; q < A.q1; q++) {
@@ -768,7 +777,7 @@ __global__ __launch_bounds__(FBC_THREADS) void k_fb_chain(FbChainArgs A)
         const int nspan = sh_nspan;
         for (int s = blockIdx.x; s < nspan; s += gridDim.x) {
             const int64_t e = vid_l[spans[s]];
-            fb_logits<XT>(cl, fl, e, 0, -1, xrow, z, red);
+            fb_logits<XT>(cl, fl, e, 0, -1, xrow, z, red, A.lprior_tab);
             double mx = NEG_INF_D;
             for (int k = tid; k < KM; k += nt) mx = z[k] > mx ? z[k] : mx;
             mx = block_max(mx, red);
@@ -811,7 +820,7 @@ __global__ __launch_bounds__(FBC_THREADS) void k_fb_chain(FbChainArgs A)
             const int64_t e = tok_l[t];
             if (tid == 0) ldsK = shK;
             __syncthreads();
-            fb_logits<XT>(cl, fl, e, A.map_assign ? 2 : 1, -1, xrow, z, red);
+            fb_logits<XT>(cl, fl, e, A.map_assign ? 2 : 1, -1, xrow, z, red, A.lprior_tab);
             fb_draw_component(fl, z, red, A.map_assign, A.anneal_am, A.ustream, (int64_t *)&sh_cur, A.ucap, A.status, shK, &sh_k);
             __syncthreads();
             fb_add_item<XT>(cl, fl, e, sh_k, &shK, &sh_i, red, &loc);
@@ -846,6 +855,20 @@ __global__ __launch_bounds__(FBC_THREADS) void k_fb_chain(FbChainArgs A)
         for (int i = tid; i < KM; i += nt) { A.f.log_prod[i] = lp[i]; A.f.kconst[i] = kc[i]; A.f.counts[i] = cn[i]; }
         if (tid == 0) { *A.f.K = shK; *A.ucursor = (int64_t)sh_cur; }
     }
+}
+
+// out[e] = log prior predictive of row e, by the expression (and the number of threads) fb_logits uses: one workgroup per row
+template <typename XT>
+__global__ __launch_bounds__(512) void k_fb_prior_tab(segk_corpus c, segk_fbgmm f, double *out)
+{
+    __shared__ double red[16];
+    __shared__ XT xrow[512];
+    const int64_t e = blockIdx.x;
+    const int tid = threadIdx.x, nt = blockDim.x, D = c.D;
+    for (int d = tid; d < D; d += nt) xrow[d] = ((const XT *)c.X)[e * c.ldx + d];
+    __syncthreads();
+    const double v = fb_prior_finish(f, block_sum(fb_prior_sum<XT>(f, D, xrow, tid, nt), red));
+    if (tid == 0) out[e] = v;
 }
 
 __global__ void k_fb_kconst_tab(segk_fbgmm f, int D, int64_t n, double *out)
@@ -1203,7 +1226,8 @@ int32_t segk_fbgmm_sequential_sweep(segk_ctx *ctx, const segk_corpus *c, segk_fb
     const int KM = f->K_max, D = c->D, NM = c->N_max;
     const int64_t KD = (int64_t)KM * D, triMax = (int64_t)NM * (NM + 1) / 2;
     const size_t xb = ((size_t)D * (c->x_dtype == SEGK_F32 ? 4 : 8) + 7) & ~(size_t)7;
-    const size_t lds = (size_t)(3 * KD + 3 * KM + 1 + KM + FBC_THREADS + triMax + 3 * NM + 2) * sizeof(double) + xb +
+    const int nt = fb_nt(f);
+    const size_t lds = (size_t)(3 * KD + 3 * KM + 1 + KM + nt + triMax + 3 * NM + 2 + 3 * D) * sizeof(double) + xb +
                        (size_t)(2 * triMax + max_rows + NM) * sizeof(int32_t) + (size_t)((NM + 15) & ~15) +
                        (size_t)max_rows * D * (c->x_dtype == SEGK_F32 ? 4 : 8) + 16;
     if (lds > 150 * 1024) {
@@ -1253,6 +1277,25 @@ int32_t segk_fbgmm_sequential_sweep(segk_ctx *ctx, const segk_corpus *c, segk_fb
         A.ktab = ctx->fb_ktab;
         A.ktab_n = ctx->fb_ktab_n;
     }
+    // the rows' log prior predictive, once per (corpus, prior, number of threads)
+    A.lprior_tab = nullptr;
+    if (D <= 512) {
+        if (!ctx->fb_ptab || ctx->fb_ptab_n < c->n_emb || ctx->fb_ptab_X != c->X || ctx->fb_ptab_prior != (const void *)f->prior_a ||
+            ctx->fb_ptab_nt != nt || ctx->fb_ptab_cov != f->cov_type || ctx->fb_ptab_k0 != f->k_0 || ctx->fb_ptab_v0 != f->v_0) {
+            if (ctx->fb_ptab_n < c->n_emb) {
+                if (ctx->fb_ptab) (void)hipFree(ctx->fb_ptab);
+                ctx->fb_ptab = nullptr;
+                ctx->fb_ptab_n = 0;
+                SEGK_CHECK_HIP(hipMalloc((void **)&ctx->fb_ptab, (size_t)c->n_emb * sizeof(double)));
+                ctx->fb_ptab_n = c->n_emb;
+            }
+            DISPATCH_XT(c, hipLaunchKernelGGL(k_fb_prior_tab<XT>, dim3((unsigned)c->n_emb), dim3(nt), 0, st, *c, *f, ctx->fb_ptab););
+            SEGK_LAUNCH_CHECK();
+            ctx->fb_ptab_X = c->X; ctx->fb_ptab_prior = (const void *)f->prior_a; ctx->fb_ptab_nt = nt; ctx->fb_ptab_cov = f->cov_type;
+            ctx->fb_ptab_k0 = f->k_0; ctx->fb_ptab_v0 = f->v_0;
+        }
+        A.lprior_tab = ctx->fb_ptab;
+    }
     // one workgroup per span of an utterance at most (105 at 20 landmarks and a window of six), never more than fit together
     int G = ctx->n_cu < 128 ? ctx->n_cu : 128;
     {
@@ -1265,7 +1308,7 @@ int32_t segk_fbgmm_sequential_sweep(segk_ctx *ctx, const segk_corpus *c, segk_fb
         A.q0 = q; A.q1 = n_order;
         DISPATCH_XT(c, {
             SEGK_CHECK_HIP(segk_dyn_lds((const void *)k_fb_chain<XT>, lds));
-            hipLaunchKernelGGL(k_fb_chain<XT>, dim3(G), dim3(FBC_THREADS), lds, st, A);
+            hipLaunchKernelGGL(k_fb_chain<XT>, dim3(G), dim3(nt), lds, st, A);
         });
         SEGK_LAUNCH_CHECK();
         int32_t ctl[8 + 2 * FB_RELOG];

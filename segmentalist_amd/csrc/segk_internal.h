@@ -32,6 +32,11 @@ struct segk_ctx {
     int64_t fb_ktab_n;
     double fb_ktab_v0;
     int fb_ktab_D;
+    double *fb_ptab;              // persistent FBGMM chain: log prior predictive of every row, and what it was computed from
+    int64_t fb_ptab_n;
+    const void *fb_ptab_X, *fb_ptab_prior;
+    int fb_ptab_nt, fb_ptab_cov;
+    double fb_ptab_k0, fb_ptab_v0;
     void *fbchain_buf;            // persistent FBGMM chain (segk_fbgmm.hip k_fb_chain): control words, the sweep's utterance order
     size_t fbchain_bytes;
     // batch sampler: the block's tokens bucketed by slot (k_fbb_sort) + offsets
