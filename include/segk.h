@@ -336,7 +336,10 @@ int32_t segk_kmeans_sequential_sweep(segk_ctx *ctx, const segk_corpus *c, segk_k
  *      [n_utt, N_max] as segk_kmeans_segment leaves them (unused slots: k = -1): a stable counting sort
  *      of the block's tokens by component (sorted_scratch: one region per (block, range of components);
  *      koff_scratch: {offset, length} of every (block, component) list; both [dev] int32, their sizes in words from
- *      segk_kmeans_batch_scratch_words with n_slots = n_utt * N_max -- ABI version 4), then one sequential sum per
+ *      segk_kmeans_batch_scratch_words -- ABI version 4; a block's regions sit at sorted_scratch + blk_lo[b] * N_max * NR
+ *      words (NR = sorted_words / n_slots), so n_slots = n_utt * N_max covers any blocks, and a rank whose blocks begin at
+ *      utterance u0 > 0 may allocate for n_slots = (its utterances) * N_max and pass the address of its buffer MINUS
+ *      u0 * N_max * NR words: only the regions of the blocks named are touched), then one sequential sum per
  *      (block, component);
  *      part_tot = sum of out_total in utterance order.  Tokens whose argmax is an inactive row (k >= K;
  *      n_flag [dev] int32 [n_utt] counts them per utterance) are listed instead, in token order.
@@ -579,7 +582,10 @@ int32_t segk_fbb_collect(segk_ctx *ctx, const segk_corpus *c, const uint8_t *bou
                          int32_t *new_tok, int32_t *n_new, void *stream);
 /* partials[b][s] for the slices s_lo .. s_lo+s_n-1 from their token lists and bt->slot: per slot
  * sequential in token order (utterance, then segment); x^2 is the square in the dtype of X
- * (gaussian_components_diag.py:125).                                                            */
+ * (gaussian_components_diag.py:125).  SIDE EFFECT: bt->scal (the totals segk_fbb_prepare accumulates into) is left
+ * zeroed, so that a segk_fbb_prepare enqueued next on the same stream need not clear it; the totals are therefore only
+ * valid between a segk_fbb_prepare and the next segk_fbb_partials -- call segk_fbb_prepare before reading them (or before
+ * segk_fbb_score / _assign / _token_scores) after any segk_fbb_partials.                                              */
 int32_t segk_fbb_partials(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *f,
                           const segk_fbatch *bt, int32_t s_lo, int32_t s_n, int32_t b,
                           const int32_t *new_tok, const int32_t *n_new, void *stream);

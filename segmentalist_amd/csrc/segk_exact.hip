@@ -392,12 +392,12 @@ __global__ __launch_bounds__(BLS_THREADS) void k_kmeans_brute_ls(segk_corpus c, 
     }
     // ---- the workgroup that finishes last unpacks the (score, component) pairs into the candidates and clears the workspace
     // (round 3 launched k_brute_finish_ls for this: one more kernel boundary, ~5 us of a sweep even when the queue is empty)
+    // (EVERY thread's atomics must have been performed before the workgroup's ticket is taken: a fence by thread 0 alone orders
+    // only its own -- the last workgroup then read maxima that were still in flight, an intermittent wrong argmax)
     __shared__ int last;
+    __threadfence();
     __syncthreads();
-    if (tid == 0) {
-        __threadfence();
-        last = atomicAdd(ticket, 1u) == gridDim.x - 1u;
-    }
+    if (tid == 0) last = atomicAdd(ticket, 1u) == gridDim.x - 1u;
     __syncthreads();
     if (last) {
         __threadfence();

@@ -1578,13 +1578,14 @@ int32_t segk_fbb_partials(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm 
         DISPATCH_XT(c, hipLaunchKernelGGL(k_fbb_partials_sorted<XT>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0,
                                            (hipStream_t)stream, *c, *f, *bt, s_lo, s_n, b, sorted, stride, koff););
         SEGK_LAUNCH_CHECK();
-        ctx->fbb_scal_zeroed = (const void *)bt->scal;             // (the kernel cleared the totals for the next segk_fbb_prepare)
+        ctx->fbb_scal_zeroed = (const void *)bt->scal;             // (the kernel cleared the totals for the next segk_fbb_prepare
+        ctx->fbb_scal_stream = stream;                             //  enqueued on THIS stream)
         return SEGK_OK;
     }
     DISPATCH_XT(c, hipLaunchKernelGGL(k_fbb_partials<XT>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0,
                                        (hipStream_t)stream, *c, *f, *bt, s_lo, s_n, b, new_tok, n_new););
     SEGK_LAUNCH_CHECK();
-    if (ctx) ctx->fbb_scal_zeroed = (const void *)bt->scal;
+    if (ctx) { ctx->fbb_scal_zeroed = (const void *)bt->scal; ctx->fbb_scal_stream = stream; }
     return SEGK_OK;
 }
 
@@ -1595,8 +1596,10 @@ int32_t segk_fbb_prepare(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *
     if (rc) return rc;
     SEGK_REQUIRE(b >= -1 && b < bt->n_blocks, "block");
     hipStream_t st = (hipStream_t)stream;
-    if (!ctx || ctx->fbb_scal_zeroed != (const void *)bt->scal) SEGK_CHECK_HIP(hipMemsetAsync(bt->scal, 0, 2 * sizeof(double), st));
-    if (ctx) ctx->fbb_scal_zeroed = nullptr;
+    // (the totals are zero already when the last thing enqueued for them was segk_fbb_partials on this very stream)
+    if (!ctx || ctx->fbb_scal_zeroed != (const void *)bt->scal || ctx->fbb_scal_stream != stream)
+        SEGK_CHECK_HIP(hipMemsetAsync(bt->scal, 0, 2 * sizeof(double), st));
+    if (ctx) { ctx->fbb_scal_zeroed = nullptr; ctx->fbb_scal_stream = nullptr; }
     const double alpha = f->lm_unigram ? f->lm_a : f->alpha;
     hipLaunchKernelGGL(k_fbb_prepare, dim3(f->K_max), dim3(192), 0, st, *f, *bt, c->D, b, alpha);
     if (bt->tiles16 && bt->y16 && f->cov_type == 0) {

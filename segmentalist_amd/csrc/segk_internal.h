@@ -43,6 +43,7 @@ struct segk_ctx {
     int32_t *fbs_buf;
     size_t fbs_bytes;
     const void *fbb_scal_zeroed;  // segk_fbb_partials cleared these totals on the stream: the next segk_fbb_prepare need not
+    const void *fbb_scal_stream;  // ... provided it is enqueued on the same stream
     int prof_launches;
     int32_t *defer_zero;          // segk_kmeans_score: queue length the chosen filter path still has to clear
     int pre_zeroed;

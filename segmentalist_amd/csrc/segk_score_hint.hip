@@ -141,6 +141,7 @@ __device__ __forceinline__ void hint_wave_rows(const HintArgs &H, const int32_t 
         return d;
     };
     const int64_t n_steps = (H.n + 31) >> 5;
+    if (H.dbg & 8) return;                                         // development (make DEV=1): timing without the hint waves' work
     auto rid_of = [&](int64_t s_) -> int32_t {
         const int64_t p_ = s_ * 32 + row;
         return p_ < H.n ? (H.ids ? H.ids[p_] : (int32_t)(H.row0 + p_)) : -1;
@@ -169,6 +170,7 @@ __device__ __forceinline__ void hint_wave_rows(const HintArgs &H, const int32_t 
             if constexpr (rem != 0) mv[nblk] = *reinterpret_cast<gptr_t>(ma + 4u * nfull);
         }
         const float nx = rid_c >= 0 ? H.nxx[rid_c] : 0.f;
+        if (H.dbg & 64) __builtin_amdgcn_s_sleep(64);               // development: paced hint waves
         // the next step's previous labels and the row ids of the step after it travel under this step's arithmetic
         {
             rid = rid_n;
@@ -495,7 +497,7 @@ __global__ __launch_bounds__(128 * NW, 1) void k_kmeans_top2_rs(HintArgs H)
 #ifdef SEGK_STAMP
     const unsigned long long st_k2 = __builtin_amdgcn_s_memtime();
 #endif
-    if (!mm_on || g >= n_groups) return;
+    if (!mm_on || g >= n_groups || (H.dbg & 128)) return;       // (dbg 128, make DEV=1: timing of the hint waves alone)
     if (H.dbg & 4) SEGK_RS_LOAD(g, xa, hrow_a, hk_a);
 #pragma unroll
     for (int s = 0; s < KS; s++) load_a(0, s);          // tile 0's operands for the first group; every group's last tile reloads them

@@ -521,9 +521,15 @@ class KMeansBatchSweeper(object):
         self.pack_all = torch.zeros((W, self.rank_stride), dtype=torch.float64, device=dev)
         self.pack = self.pack_all[part.rank]
         self.blk_lo = to_dev(part.local_bounds, np.int32)
+        # sort scratch: one region per (local block, component range), addressed by the kernels as sorted + p0 * NR with p0 the
+        # block's first GLOBAL token slot (utterance * N_max): only this rank's slots are backed by memory -- the pointer
+        # handed to the library is the address slot 0 would have (the kernels touch the regions of the local blocks only)
         ws, wk = C.c_int64(), C.c_int64()
-        check(dk._L.segk_kmeans_batch_scratch_words(dk.K_max, c.n_utt * c.N_max, part.nbl, C.byref(ws), C.byref(wk)))
+        n_loc = (part.utt_hi - part.utt_lo) * c.N_max
+        check(dk._L.segk_kmeans_batch_scratch_words(dk.K_max, n_loc, part.nbl, C.byref(ws), C.byref(wk)))
         self.sorted = torch.zeros(ws.value, dtype=torch.int32, device=dev)
+        nr = ws.value // max(n_loc, 1)
+        self._sorted_ptr = C.c_void_p(self.sorted.data_ptr() - 4 * part.utt_lo * c.N_max * nr)
         self.koff = torch.zeros(wk.value, dtype=torch.int32, device=dev)
         # SEGK_SWEEP_GRAPH=1: the sweep replayed as a hipGraph from its second run on.  Default 0: measured on MI355X
         # the replay is SLOWER than the plain launches it replaces (full corpus 0.661 vs 0.634 ms per sweep, a
@@ -607,7 +613,7 @@ class KMeansBatchSweeper(object):
                                             C.byref(dk.cand), ptr(boundaries), ptr(dk.old_tok), ptr(dk.new_tok), ptr(dk.new_k),
                                             ptr(dk.n_old), ptr(dk.n_new), ptr(dk.n_flag), ptr(dk.out_total), ptr(dk.status), st))
             check(L.segk_kmeans_batch_partials(ctx, cp, mp, ptr(self.blk_lo), pt.nbl, ptr(dk.new_tok), ptr(dk.new_k),
-                                               ptr(dk.n_flag), ptr(dk.out_total), ptr(self.sorted), ptr(self.koff),
+                                               ptr(dk.n_flag), ptr(dk.out_total), self._sorted_ptr, ptr(self.koff),
                                                ptr(self.pack), self.cap, self.flag_rows, ptr(dk.out_scalars), st))
             if pt.world > 1:
                 self.comm.all_gather_rows(self.pack_all, self.pack)
@@ -624,7 +630,7 @@ class KMeansBatchSweeper(object):
         dk.score_rows(row0=pt.row_lo - dk.row_base, n=pt.row_hi - pt.row_lo, hint_remap=dk.remap if self._use_hints() else None)
         dk.segment(boundaries, n_slices_min, n_slices_max, wip, utt0=pt.utt_lo, n_utts=pt.utt_hi - pt.utt_lo)
         check(L.segk_kmeans_batch_partials(ctx, cp, mp, ptr(self.blk_lo), pt.nbl, ptr(dk.new_tok), ptr(dk.new_k),
-                                           ptr(dk.n_flag), ptr(dk.out_total), ptr(self.sorted), ptr(self.koff),
+                                           ptr(dk.n_flag), ptr(dk.out_total), self._sorted_ptr, ptr(self.koff),
                                            ptr(self.pack), self.cap, self.flag_rows, ptr(dk.out_scalars), st))
 
     def _enqueue_back(self):
