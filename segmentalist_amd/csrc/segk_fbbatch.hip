@@ -351,7 +351,7 @@ __global__ __launch_bounds__(192) void k_fbb_prepare(segk_fbgmm f, segk_fbatch b
         if (d0 + 64 < D) __syncthreads();           // (res is written again)
     }
     if (w != 0) return;
-    for (int o = 32; o > 0; o >>= 1) lsum += __shfl_xor(lsum, o);
+    lsum = fb_wave_sum(lsum);
     // the slot's scalars: the two log-gammas side by side on lanes 0 and 1, the two logarithms likewise
     const double lg = f.cov_type == 0 ? 0.0 : lgamma(lane == 0 ? (v_N + 1.) / 2. : v_N / 2.);
     const double lv = log(lane == 0 ? v_N : prior_alpha / (double)KM + n);
@@ -501,7 +501,7 @@ static __device__ double fbb_prior_row(const segk_fbgmm &f, int D, const double 
             s += log(1. + 1. / f.v_0 * (delta * delta) * (1. / var));
         }
     }
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    s = fb_wave_sum(s);
     return f.cov_type == 0 ? f.kconst[f.K_max] - 0.5 * s : f.kconst[f.K_max] - (f.v_0 + 1.) / 2. * s;
 }
 
@@ -518,7 +518,7 @@ static __device__ double fbb_prior_row_mem(const segk_fbgmm &f, int D, const XT 
             s += log(1. + 1. / f.v_0 * (delta * delta) * (1. / var));
         }
     }
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    s = fb_wave_sum(s);
     return f.cov_type == 0 ? f.kconst[f.K_max] - 0.5 * s : f.kconst[f.K_max] - (f.v_0 + 1.) / 2. * s;
 }
 
@@ -982,16 +982,13 @@ __global__ __launch_bounds__(512) void k_fbb_assign(segk_corpus c, segk_fbgmm f,
                     zr[k] = v;
                     mx = v > mx ? v : mx;
                 }
-                for (int o = 32; o > 0; o >>= 1) {
-                    const double other = __shfl_xor(mx, o);
-                    mx = other > mx ? other : mx;
-                }
+                mx = fb_wave_max(mx, false);
                 auto sum_exp = [&](double shift) -> double {       // sum_k exp(zr[k] - shift) in the order of block_sum at 256 threads
                     double tot = 0.0;
                     for (int cw = 0; cw < 4 && cw * 64 < KM; cw++) {
                         double sv = 0.0;
                         for (int k = cw * 64 + lane; k < KM; k += 256) sv += exp(zr[k] - shift);
-                        for (int o = 32; o > 0; o >>= 1) sv += __shfl_xor(sv, o);
+                        sv = fb_wave_sum(sv);
                         tot = cw == 0 ? sv : tot + sv;
                     }
                     return tot;
@@ -1004,10 +1001,7 @@ __global__ __launch_bounds__(512) void k_fbb_assign(segk_corpus c, segk_fbgmm f,
                         zr[k] = v;
                         mx2 = v > mx2 ? v : mx2;
                     }
-                    for (int o = 32; o > 0; o >>= 1) {
-                        const double other = __shfl_xor(mx2, o);
-                        mx2 = other > mx2 ? other : mx2;
-                    }
+                    mx2 = fb_wave_max(mx2, false);
                     lse = log(sum_exp(mx2)) + mx2;
                 }
                 for (int k = lane; k < KM; k += 64) zr[k] = exp(zr[k] - lse);
@@ -1103,7 +1097,7 @@ __global__ __launch_bounds__(256) void k_fbb_assign_lm_wave(segk_corpus c, segk_
         for (int cw = 0; cw < 4 && cw * 64 < KM; cw++) {
             double sv = 0.0;
             for (int k = cw * 64 + lane; k < KM; k += 256) sv += exp(z[k] - shift);
-            for (int o = 32; o > 0; o >>= 1) sv += __shfl_xor(sv, o);
+            sv = fb_wave_sum(sv);
             acc = cw == 0 ? sv : acc + sv;
         }
         return acc;
@@ -1155,15 +1149,12 @@ __global__ __launch_bounds__(256) void k_fbb_assign_lm_wave(segk_corpus c, segk_
                     zv[j] = lane + 64 * j < KM ? pz + llv : NEG_INF_D;
                     mx = zv[j] > mx ? zv[j] : mx;
                 }
-                for (int o = 32; o > 0; o >>= 1) {
-                    const double other = __shfl_xor(mx, o);
-                    mx = other > mx ? other : mx;
-                }
+                mx = fb_wave_max(mx, false);
                 auto sum_reg = [&](double shift) -> double {
                     double sv = 0.0;
 #pragma unroll
                     for (int j = 0; j < KPL; j++) sv += (double)__builtin_amdgcn_exp2f((float)(zv[j] - shift) * LOG2E);      // 2^-inf = 0 for the slots beyond K_max
-                    for (int o = 32; o > 0; o >>= 1) sv += __shfl_xor(sv, o);
+                    sv = fb_wave_sum(sv);
                     return sv;
                 };
                 double lse = log(sum_reg(mx)) + mx;
@@ -1174,10 +1165,7 @@ __global__ __launch_bounds__(256) void k_fbb_assign_lm_wave(segk_corpus c, segk_
                         zv[j] = (1. / anneal_temp) * (zv[j] - lse);
                         mx2 = zv[j] > mx2 ? zv[j] : mx2;
                     }
-                    for (int o = 32; o > 0; o >>= 1) {
-                        const double other = __shfl_xor(mx2, o);
-                        mx2 = other > mx2 ? other : mx2;
-                    }
+                    mx2 = fb_wave_max(mx2, false);
                     lse = log(sum_reg(mx2)) + mx2;
                 }
 #pragma unroll
@@ -1214,14 +1202,11 @@ __global__ __launch_bounds__(256) void k_fbb_assign_lm_wave(segk_corpus c, segk_
                 z[k] = v;
                 mx = v > mx ? v : mx;
             }
-            for (int o = 32; o > 0; o >>= 1) {
-                const double other = __shfl_xor(mx, o);
-                mx = other > mx ? other : mx;
-            }
+            mx = fb_wave_max(mx, false);
             auto sum_exp32 = [&](double shift) -> double {
                 double sv = 0.0;
                 for (int k = lane; k < KM; k += 64) sv += (double)__builtin_amdgcn_exp2f((float)(z[k] - shift) * LOG2E);
-                for (int o = 32; o > 0; o >>= 1) sv += __shfl_xor(sv, o);
+                sv = fb_wave_sum(sv);
                 return sv;
             };
             double lse = log(sum_exp32(mx)) + mx;
@@ -1232,10 +1217,7 @@ __global__ __launch_bounds__(256) void k_fbb_assign_lm_wave(segk_corpus c, segk_
                     z[k] = v;
                     mx2 = v > mx2 ? v : mx2;
                 }
-                for (int o = 32; o > 0; o >>= 1) {
-                    const double other = __shfl_xor(mx2, o);
-                    mx2 = other > mx2 ? other : mx2;
-                }
+                mx2 = fb_wave_max(mx2, false);
                 lse = log(sum_exp32(mx2)) + mx2;
             }
             for (int k = lane; k < KM; k += 64) z[k] = (double)__builtin_amdgcn_exp2f((float)(z[k] - lse) * LOG2E);
@@ -1270,10 +1252,7 @@ __global__ __launch_bounds__(256) void k_fbb_assign_lm_wave(segk_corpus c, segk_
             z[k] = v;
             mx = v > mx ? v : mx;
         }
-        for (int o = 32; o > 0; o >>= 1) {
-            const double other = __shfl_xor(mx, o);
-            mx = other > mx ? other : mx;
-        }
+        mx = fb_wave_max(mx, false);
         double lse = log(sum_exp(mx)) + mx;
         if (anneal_temp != 1.0) {                               // fbgmm.py:446-449
             double mx2 = NEG_INF_D;
@@ -1282,10 +1261,7 @@ __global__ __launch_bounds__(256) void k_fbb_assign_lm_wave(segk_corpus c, segk_
                 z[k] = v;
                 mx2 = v > mx2 ? v : mx2;
             }
-            for (int o = 32; o > 0; o >>= 1) {
-                const double other = __shfl_xor(mx2, o);
-                mx2 = other > mx2 ? other : mx2;
-            }
+            mx2 = fb_wave_max(mx2, false);
             lse = log(sum_exp(mx2)) + mx2;
         }
         for (int k = lane; k < KM; k += 64) z[k] = exp(z[k] - lse);
@@ -1483,7 +1459,8 @@ __global__ void k_fbb_rows16(segk_fbgmm f, segk_fbatch bt, int D, double prior_a
         bt.rows32[(int64_t)k * D2 + 2 * d + 1] = r1;
         n2 += (double)r0 * r0 + (double)r1 * r1;
     }
-    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); n2 += __shfl_xor(n2, o); }
+    s = fb_wave_sum(s);
+    n2 = fb_wave_sum(n2);
     if (lane == 0) {
         const double norm = f.lms * log(bt.scal[0] + prior_alpha);
         double v = -3.0e38;
