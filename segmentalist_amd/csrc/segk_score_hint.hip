@@ -159,7 +159,8 @@ __device__ __forceinline__ void hint_wave_rows(const HintArgs &H, const int32_t 
         const int32_t rid_c = rid;
         f32x4_t xv[NX], mv[NX];
         {
-            const int64_t r_any = rid_c >= 0 ? (int64_t)rid_c : (H.ids ? 0 : H.row0);
+            int64_t r_any = rid_c >= 0 ? (int64_t)rid_c : (H.ids ? 0 : H.row0);
+            if (H.dbg & 16) r_any &= 1023;                          // development: the rows from a cache-resident corner (timing)
             const uintptr_t xa = (uintptr_t)(H.xrows32 + r_any * H.ld32);
             const uintptr_t ma = (uintptr_t)(H.means32 + (int64_t)(hint >= 0 ? hint : 0) * D);
 #pragma unroll
@@ -182,7 +183,7 @@ __device__ __forceinline__ void hint_wave_rows(const HintArgs &H, const int32_t 
         // r_{4h..4h+3}
         f32x2_t rl = {0.f, 0.f}, rh = {0.f, 0.f};
 #pragma unroll
-        for (int b = 0; b < nblk; b++) {
+        for (int b = 0; b < ((H.dbg & 32) ? 1 : nblk); b++) {      // (dbg 32, development: one block of the arithmetic only)
             const f32x2_t dl = pk_sub(mv[b].xy, xv[b].xy), dh = pk_sub(mv[b].zw, xv[b].zw);
             const f32x2_t tl = dl * dl, th = dh * dh;
             rl = b == 0 ? tl : rl + tl;
