@@ -570,7 +570,8 @@ typedef struct {
     void *y16;                    /* [dev] segk_corpus_b3_bytes(n_emb, 2D) bytes (segk_fbb_make_y)  */
     float *tiles16;               /* [dev] segk_kmeans_tiles_b3_floats(K_max + 1, 2D) floats        */
     float *rows32;                /* [dev] [(K_max + 1), 2D] scratch: the per-slot rows in float32   */
-    double *consts16;             /* [dev] [K_max + 2] scratch: per-slot constants; [K_max + 1] = max |row|^2 */
+    double *consts16;             /* [dev] [2 (K_max + 2) + 32] scratch: per-column constants; [K_max + 1] = max |row|^2; behind
+                                     them the int32 column maps of the packed image (segk_fbb_prepare writes, the score calls read) */
     /* optional: the prior predictive of every embedding row (an empty slot's likelihood) -- a constant of corpus and prior, so
      * the score and assignment kernels of every Gibbs step need not evaluate its D logarithms per row again
      * (segk_fbb_prior_rows once; NULL: evaluated in the kernels; the values are the same either way)                           */
@@ -653,7 +654,9 @@ int32_t segk_fbb_assign_diag32(segk_ctx *ctx, const segk_corpus *c, const segk_f
 /* ll_mat of segk_fbb_assign (optional; fixed-variance components with the fp16x2 images): the token
  * likelihoods come from the matrix-core contraction instead of the fp64 VALU loop.  Row j*N_max + t of
  * ll_mat [n, ll_ld] belongs to segment t of the j-th utterance of the block (local slices in order);
- * segk_fbb_token_scores fills it for the row list tok_rows[j*N_max + t] = new_tok[utt_j][t].        */
+ * segk_fbb_token_scores fills it for the row list tok_rows[j*N_max + t] = new_tok[utt_j][t].  The columns
+ * are those of the packed operand image of the step's segk_fbb_prepare (occupied slots in slot order, then the
+ * pseudo-component of the empty ones), which segk_fbb_assign of the same step resolves; not a per-slot table. */
 int32_t segk_fbb_token_scores(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *f,
                               const segk_fbatch *bt, const int32_t *tok_rows, int64_t n,
                               float *ll_mat, int64_t ll_ld, void *stream);

@@ -44,6 +44,13 @@ struct FbbMap {
     int off[17];
 };
 
+// Column maps of the packed fp16x2 image (k_fbb_compact), behind the constants: [K_max] column of slot k (-1: empty), [K_max] the
+// pseudo-component's, [K_max + 1] tiles in use.  The token-likelihood matrix has the image's columns.
+static __host__ __device__ __forceinline__ int32_t *fbb_cmap(const segk_fbatch *bt, int KM)
+{
+    return reinterpret_cast<int32_t *>(bt->consts16 + KM + 2);
+}
+
 static __device__ __forceinline__ bool fbb_locate(const FbbMap &m, int wg, int *slice, int *idx)
 {
     for (int s = 0; s < m.n; s++)
@@ -877,11 +884,15 @@ __global__ __launch_bounds__(512) void k_fbb_assign(segk_corpus c, segk_fbgmm f,
             const double LN2 = 0.6931471805599453;
             const double norm = f.lms * log(tot + prior_alpha);
             const double n_empty = (double)KM - bt.scal[1];
+            const int32_t *cm = fbb_cmap(&bt, KM);
+            const int pc = cm[KM];
             for (int r = 0; r < nr; r++) {
                 const float *mrow = llmat + ((int64_t)blockIdx.x * c.N_max + t0 + r) * ll_ld;
-                for (int k = tid; k < KM; k += nt)
-                    ll[(int64_t)r * KM + k] = bt.cnt[k] > 0.0 ? (double)mrow[k] * LN2 - (bt.zconst[k] - bt.lconst[k]) + norm
-                                                               : (double)mrow[KM] * LN2 - zc_empty - log(n_empty) + norm;
+                for (int k = tid; k < KM; k += nt) {
+                    const int ck = cm[k];
+                    ll[(int64_t)r * KM + k] = bt.cnt[k] > 0.0 && ck >= 0 ? (double)mrow[ck] * LN2 - (bt.zconst[k] - bt.lconst[k]) + norm
+                                                                         : (double)mrow[pc] * LN2 - zc_empty - log(n_empty) + norm;
+                }
             }
         } else {
         for (int j = tid; j < (rcap > FBB_R ? rcap : FBB_R) * D; j += nt) {
@@ -1082,6 +1093,19 @@ __global__ __launch_bounds__(256) void k_fbb_assign_lm_wave(segk_corpus c, segk_
     const int item = blockIdx.x * 4 + w;
     if (item >= n_items) return;
     double *z = (double *)smem + (int64_t)w * KM;      // [K_max], this wave's
+    // column of the token-likelihood matrix per slot (an empty slot: the pseudo-component's).  The table is the workgroup's, every
+    // wave writes all of it (the same values) and waits for its own stores only -- waves leave early, no workgroup barrier here
+    int *cm = (int *)((double *)smem + 4 * (int64_t)KM);   // [K_max + 1]
+    {
+        const int32_t *g = fbb_cmap(&bt, KM);
+        const int pcol = g[KM];
+        for (int k = lane; k <= KM; k += 64) {
+            const int ck = g[k];
+            cm[k] = ck >= 0 ? ck : pcol;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
     int s, idx;
     if (!fbb_locate(map, item, &s, &idx)) return;
     const int slice = map.lo[s];
@@ -1127,13 +1151,13 @@ __global__ __launch_bounds__(256) void k_fbb_assign_lm_wave(segk_corpus c, segk_
                 const int64_t e = new_tok[(int64_t)utt * c.N_max + t];
                 const float *mrow = llmat + ((int64_t)item * c.N_max + t) * ll_ld;
                 const double inv_prev = j_prev >= 0 ? (1. - f.lm_lambda) / (bt.cnt[j_prev] + f.lm_b) : 0.0;
-                const double empty_ll = (double)mrow[KM] * LN2 - zc_empty - le + norm;
+                const double empty_ll = (double)mrow[cm[KM]] * LN2 - zc_empty - le + norm;
                 float mr[KPL];
                 long long bg[KPL];
 #pragma unroll
                 for (int j = 0; j < KPL; j++) {
                     const int k = lane + 64 * j, kc = k < KM ? k : KM - 1;
-                    mr[j] = mrow[kc];
+                    mr[j] = mrow[cm[kc]];
                     bg[j] = j_prev >= 0 ? f.lm_bigram[(int64_t)j_prev * KM + kc] : 0;
                 }
                 double zv[KPL], mx = NEG_INF_D;
@@ -1185,11 +1209,11 @@ __global__ __launch_bounds__(256) void k_fbb_assign_lm_wave(segk_corpus c, segk_
             const int64_t e = new_tok[(int64_t)utt * c.N_max + t];
             const float *mrow = llmat + ((int64_t)item * c.N_max + t) * ll_ld;
             const double inv_prev = j_prev >= 0 ? (1. - f.lm_lambda) / (bt.cnt[j_prev] + f.lm_b) : 0.0;
-            const double empty_ll = (double)mrow[KM] * LN2 - zc_empty - le + norm;
+            const double empty_ll = (double)mrow[cm[KM]] * LN2 - zc_empty - le + norm;
             double mx = NEG_INF_D;
             for (int k = lane; k < KM; k += 64) {
                 const double n = bt.cnt[k];
-                const double llv = n > 0.0 ? (double)mrow[k] * LN2 - (bt.zconst[k] - bt.lconst[k]) + norm : empty_ll;
+                const double llv = n > 0.0 ? (double)mrow[cm[k]] * LN2 - (bt.zconst[k] - bt.lconst[k]) + norm : empty_ll;
                 if constexpr (PROBE) probe_ll[((int64_t)utt * c.N_max + t) * probe_ld + k] = llv;
                 double pz;
                 if (j_prev < 0) pz = ((double)(__builtin_amdgcn_logf((float)(n + aK)) * 0.6931471805599453f) - ltot) * f.lms;      // bigram_lms.py:64-69
@@ -1237,8 +1261,8 @@ __global__ __launch_bounds__(256) void k_fbb_assign_lm_wave(segk_corpus c, segk_
         double mx = NEG_INF_D;
         for (int k = lane; k < KM; k += 64) {
             const double n = bt.cnt[k];
-            const double llv = n > 0.0 ? (double)mrow[k] * LN2 - (bt.zconst[k] - bt.lconst[k]) + norm
-                                       : (double)mrow[KM] * LN2 - zc_empty - log(n_empty) + norm;
+            const double llv = n > 0.0 ? (double)mrow[cm[k]] * LN2 - (bt.zconst[k] - bt.lconst[k]) + norm
+                                       : (double)mrow[cm[KM]] * LN2 - zc_empty - log(n_empty) + norm;
             if constexpr (PROBE) probe_ll[((int64_t)utt * c.N_max + t) * probe_ld + k] = llv;
             double pz;
             if (j_prev < 0) pz = (log(n + f.lm_a / (double)KM) - log(tot + f.lm_a)) * f.lms;                       // bigram_lms.py:64-69
@@ -1433,7 +1457,49 @@ __global__ void k_fbb_tiles32(segk_fbgmm f, segk_fbatch bt, int D, double prior_
 // [(K_max + 1), 2D] (interleaved [-pp/2, pp*mu] * log2 e) plus constants; consts16[K_max + 1] collects the
 // largest squared row norm (the exponent of the fp16 scaling follows it).  segk_sp_prepare_tiles turns
 // them into the operand image of k_kmeans_score_sp<.., 2, 1>.
-__global__ void k_fbb_rows16(segk_fbgmm f, segk_fbatch bt, int D, double prior_alpha)
+// Columns of the fp16x2 operand image: the occupied slots in slot order, then the pseudo-component of the empty ones; everything
+// behind is "absent".  (At configs[4] 419 of 1 000 slots are occupied in the settled chain: 14 tiles of components instead of 32
+// for the span scores and the token likelihoods -- an empty slot's score is the pseudo-component's, multiplying its tile was
+// wasted matrix work.)  One workgroup; also presets every constant to "absent".  The token-likelihood matrix has the same
+// columns: the kernels that read it go through the map.
+__global__ __launch_bounds__(1024) void k_fbb_compact(segk_fbatch bt, int KM, int32_t *cmap, int D2)
+{
+    __shared__ int wsum[16];
+    __shared__ int run;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) run = 0;
+    __syncthreads();
+    for (int k0 = 0; k0 < KM; k0 += 1024) {
+        const int k = k0 + tid;
+        const bool occ = k < KM && bt.cnt[k] > 0.0;
+        const unsigned long long m = __ballot(occ);
+        if (lane == 0) wsum[wv] = __popcll(m);
+        __syncthreads();
+        int off = run;
+        for (int w = 0; w < wv; w++) off += wsum[w];
+        const int col = off + __popcll(m & ((1ull << lane) - 1ull));
+        if (k < KM) cmap[k] = occ ? col : -1;
+        __syncthreads();
+        if (tid == 0) {
+            int t = 0;
+            for (int w = 0; w < 16; w++) t += wsum[w];
+            run += t;
+        }
+        __syncthreads();
+    }
+    const int n_col = run + 1, n_t = (n_col + 31) / 32;
+    if (tid == 0) {
+        cmap[KM] = run;                               // the pseudo-component's column
+        cmap[KM + 1] = n_t;                           // tiles in use
+    }
+    for (int k = tid; k <= KM; k += 1024) bt.consts16[k] = -3.0e38;
+    // the columns behind the pseudo-component inside the last tile in use are multiplied too: their rows (whatever an earlier
+    // step left there, scaled for another exponent) must not overflow the fp16 image
+    const int r_hi = n_t * 32 < KM + 1 ? n_t * 32 : KM + 1;
+    for (int i = tid; i < (r_hi - n_col) * D2; i += 1024) bt.rows32[(int64_t)n_col * D2 + i] = 0.f;
+}
+
+__global__ void k_fbb_rows16(segk_fbgmm f, segk_fbatch bt, int D, double prior_alpha, const int32_t *cmap)
 {
     const double LOG2E = 1.4426950408889634;
     const int KM = f.K_max, D2 = 2 * D;
@@ -1441,6 +1507,8 @@ __global__ void k_fbb_rows16(segk_fbgmm f, segk_fbatch bt, int D, double prior_a
     const int k = blockIdx.x * 4 + w;
     if (k > KM) return;
     const bool occupied = k < KM && bt.cnt[k] > 0.0;
+    const int col = cmap ? cmap[k] : k;               // (k == K_max: the pseudo-component's column)
+    if (col < 0) return;                              // an empty slot has no column
     double s = 0.0, n2 = 0.0;
     for (int d = lane; d < D; d += 64) {
         double t0 = 0.0, t1 = 0.0;
@@ -1455,8 +1523,8 @@ __global__ void k_fbb_rows16(segk_fbgmm f, segk_fbatch bt, int D, double prior_a
             s += f.prior_c[d] * f.prior_b[d] * f.prior_b[d];
         }
         const float r0 = (float)t0, r1 = (float)t1;
-        bt.rows32[(int64_t)k * D2 + 2 * d] = r0;
-        bt.rows32[(int64_t)k * D2 + 2 * d + 1] = r1;
+        bt.rows32[(int64_t)col * D2 + 2 * d] = r0;
+        bt.rows32[(int64_t)col * D2 + 2 * d + 1] = r1;
         n2 += (double)r0 * r0 + (double)r1 * r1;
     }
     s = fb_wave_sum(s);
@@ -1469,7 +1537,7 @@ __global__ void k_fbb_rows16(segk_fbgmm f, segk_fbatch bt, int D, double prior_a
             const double n_empty = (double)KM - bt.scal[1];
             if (n_empty > 0.0) v = (f.lms * log(prior_alpha / (double)KM) + log(n_empty) + f.kconst[KM] - 0.5 * s - norm) * LOG2E;
         }
-        bt.consts16[k] = v;
+        bt.consts16[col] = v;
         atomicMax((unsigned long long *)&bt.consts16[KM + 1], (unsigned long long)__double_as_longlong(n2));
     }
 }
@@ -1582,7 +1650,11 @@ int32_t segk_fbb_prepare(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *
     if (bt->tiles16 && bt->y16 && f->cov_type == 0) {
         SEGK_REQUIRE(bt->rows32 && bt->consts16, "rows32 / consts16 scratch missing");
         SEGK_CHECK_HIP(hipMemsetAsync(bt->consts16 + f->K_max + 1, 0, sizeof(double), st));
-        hipLaunchKernelGGL(k_fbb_rows16, dim3((f->K_max + 1 + 3) / 4), dim3(256), 0, st, *f, *bt, c->D, alpha);
+        // the occupied slots packed into the leading columns; the maps live behind the constants and are read by the score and
+        // token-score calls of this step
+        int32_t *cmap = fbb_cmap(bt, f->K_max);
+        hipLaunchKernelGGL(k_fbb_compact, dim3(1), dim3(1024), 0, st, *bt, f->K_max, cmap, 2 * c->D);
+        hipLaunchKernelGGL(k_fbb_rows16, dim3((f->K_max + 1 + 3) / 4), dim3(256), 0, st, *f, *bt, c->D, alpha, (const int32_t *)cmap);
         SEGK_LAUNCH_CHECK();
         return segk_sp_prepare_tiles(bt->rows32, bt->consts16, bt->consts16 + f->K_max + 1, f->K_max + 1, 2 * c->D,
                                      bt->tiles16, bt->y16, stream);
@@ -1630,7 +1702,7 @@ int32_t segk_fbb_score_f32(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm
     SEGK_REQUIRE(rows != NULL && n >= 0, "row list");
     if (bt->tiles16 && bt->y16)
         return segk_launch_score_lse_sp(ctx, bt->y16, 2 * c->D, rows, 0, n, bt->tiles16, segk_n_tiles(f->K_max + 1), 0.0, score,
-                                        stream);
+                                        stream, fbb_cmap(bt, f->K_max) + f->K_max + 1);
     return segk_launch_score_lse(ctx, bt->y, bt->ldy, 2 * c->D, rows, 0, n, bt->tiles32, segk_n_tiles(f->K_max + 1), 0.0, score,
                                  stream);
 }
@@ -1760,8 +1832,9 @@ int32_t segk_fbb_token_scores(segk_ctx *ctx, const segk_corpus *c, const segk_fb
     if (rc) return rc;
     SEGK_REQUIRE(f->cov_type == 0 && bt->y16 && bt->tiles16, "needs the fp16x2 images (fixed-variance components)");
     SEGK_REQUIRE(tok_rows && ll_mat && ll_ld >= 32 * segk_n_tiles(f->K_max + 1) && (ll_ld & 3) == 0, "matrix / leading dimension");
+    // (the matrix has the image's packed columns -- segk_fbb_prepare's map)
     return segk_launch_score_mat_sp(bt->y16, 2 * c->D, tok_rows, n, bt->tiles16, segk_n_tiles(f->K_max + 1), ll_mat, ll_ld,
-                                    stream);
+                                    stream, fbb_cmap(bt, f->K_max) + f->K_max + 1);
 }
 
 static int32_t fbb_assign_impl(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *f, const segk_fbatch *bt, int32_t s_lo,
@@ -1792,8 +1865,8 @@ static int32_t fbb_assign_impl(segk_ctx *ctx, const segk_corpus *c, const segk_f
     SEGK_REQUIRE(lds <= 160 * 1024, "K_max too large for the LDS logits buffer");
     // language model + matrix-core likelihoods: one wave per utterance (SEGK_FBB_ASSIGN_WAVE=0: the block-wide form)
     const char *awe = getenv("SEGK_FBB_ASSIGN_WAVE");
-    if (f->lm_unigram && ll_mat && dbg == 0 && !(awe && atoi(awe) == 0) && 4 * (size_t)f->K_max * sizeof(double) <= 150 * 1024) {
-        const size_t ldsw = 4 * (size_t)f->K_max * sizeof(double);
+    if (f->lm_unigram && ll_mat && dbg == 0 && !(awe && atoi(awe) == 0) && 4 * (size_t)f->K_max * sizeof(double) <= 146 * 1024) {
+        const size_t ldsw = 4 * (size_t)f->K_max * sizeof(double) + sizeof(int) * (size_t)(f->K_max + 2);
         const int n_items = m.off[s_n];
         // SEGK_FBB_ASSIGN_WAVE=2: the softmax with the fp64 library functions (the bits of the block-wide form)
         const bool lib64 = awe && atoi(awe) == 2;

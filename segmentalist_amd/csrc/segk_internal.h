@@ -216,6 +216,7 @@ int segk_sp_prepare_rows(const float *Y, int64_t ldy, int64_t n, int D2, void *i
 int segk_sp_prepare_tiles(const float *rows, const double *consts, const double *rowmax2, int K, int D2, float *tiles_sp,
                           const void *ximg, void *stream);
 int segk_launch_score_lse_sp(segk_ctx *ctx, const void *ximg, int D2, const int32_t *ids, int64_t row0, int64_t n,
-                             const float *tiles_sp, int n_tiles, double norm, double *out, void *stream);
+                             const float *tiles_sp, int n_tiles, double norm, double *out, void *stream,
+                             const int32_t *n_tiles_dev = nullptr);
 int segk_launch_score_mat_sp(const void *ximg, int D2, const int32_t *ids, int64_t n, const float *tiles_sp, int n_tiles,
-                             float *mat, int64_t mat_ld, void *stream);
+                             float *mat, int64_t mat_ld, void *stream, const int32_t *n_tiles_dev = nullptr);

@@ -336,6 +336,8 @@ struct ScoreArgs {
     int32_t *pre_queue, *pre_count;
     int pre_cap, K_max;
     const float *xerr;           /* pre-filter: |x - x1| per row (k_corpus_resid_sp) */
+    const int32_t *n_tiles_dev;  /* optional: the number of leading tiles that hold components, on the device (the batch sampler
+                                    packs the occupied slots into the first tiles); the kernels walk min(n_tiles, *n_tiles_dev) */
     unsigned long long *stamp;   /* -DSEGK_STAMP development builds: s_memtime at phase boundaries, 8 per workgroup */
 };
 

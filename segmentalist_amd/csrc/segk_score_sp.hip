@@ -65,7 +65,13 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_kmeans_score_sp(ScoreArgs A)
     constexpr int KP = KS * 16;
     constexpr int STRIDE = (KS * P * 256 + 32 + 1023) / 1024 * 1024;      // floats per tile image
     const float *__restrict__ tiles = A.tiles + 1024 + (int64_t)tile0 * STRIDE;
-    const int n_tiles = SPLIT ? (A.n_tiles - tile0 < A.tiles_per_split ? A.n_tiles - tile0 : A.tiles_per_split) : A.n_tiles;
+    int nt_all = A.n_tiles;
+    if (A.n_tiles_dev) {                  // (workgroup-uniform) the images' leading tiles alone hold components
+        const int nd = *A.n_tiles_dev;
+        nt_all = nd < nt_all ? nd : nt_all;
+    }
+    const int n_tiles = SPLIT ? (nt_all - tile0 < A.tiles_per_split ? nt_all - tile0 : A.tiles_per_split) : nt_all;
+    if (n_tiles <= 0) return;
     const int D = A.D;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
@@ -403,11 +409,12 @@ static int launch_score_mat_sp(const ScoreArgs &A, hipStream_t st)
 // mat[r][k] = acc_k of row ids[r] (r < n), k < 32 n_tiles: the contraction itself, for callers that need
 // every component's value (the token likelihoods of the batch sampler's assignment step)
 int segk_launch_score_mat_sp(const void *ximg, int D2, const int32_t *ids, int64_t n, const float *tiles_sp, int n_tiles,
-                             float *mat, int64_t mat_ld, void *stream)
+                             float *mat, int64_t mat_ld, void *stream, const int32_t *n_tiles_dev)
 {
     if (n <= 0) return SEGK_OK;
     ScoreArgs A{};
     memset(&A, 0, sizeof(A));
+    A.n_tiles_dev = n_tiles_dev;
     A.X32 = (const float *)ximg; A.ids = ids; A.row0 = 0; A.n = n;
     A.tiles = tiles_sp; A.n_tiles = n_tiles; A.tile_stride = segk_sp_tile_stride(D2, 2);
     A.D = D2;
@@ -427,11 +434,12 @@ int segk_launch_score_mat_sp(const void *ximg, int D2, const int32_t *ids, int64
 
 // the log-sum-exp score on fp16x2 images: out[row] = ln sum_k 2^(acc_k) - norm, D2 <= 208
 int segk_launch_score_lse_sp(segk_ctx *ctx, const void *ximg, int D2, const int32_t *ids, int64_t row0, int64_t n,
-                             const float *tiles_sp, int n_tiles, double norm, double *out, void *stream)
+                             const float *tiles_sp, int n_tiles, double norm, double *out, void *stream, const int32_t *n_tiles_dev)
 {
     if (n <= 0) return SEGK_OK;
     ScoreArgs A{};
     memset(&A, 0, sizeof(A));
+    A.n_tiles_dev = n_tiles_dev;
     A.X32 = (const float *)ximg; A.ids = ids; A.row0 = row0; A.n = n;
     A.tiles = tiles_sp; A.n_tiles = n_tiles; A.tile_stride = segk_sp_tile_stride(D2, 2);
     A.D = D2;

@@ -991,7 +991,7 @@ class FbgmmBatchSweeper(object):
             self.y16 = torch.zeros(int(L.segk_corpus_b3_bytes(c.n_emb, 2 * D)), dtype=torch.uint8, device=dev)
             self.tiles16 = torch.zeros(int(L.segk_kmeans_tiles_b3_floats(K + 1, 2 * D)), dtype=torch.float32, device=dev)
             self.rows32 = torch.zeros((K + 1, 2 * D), dtype=torch.float32, device=dev)
-            self.consts16 = torch.zeros(K + 2, dtype=f64, device=dev)
+            self.consts16 = torch.zeros(2 * (K + 2) + 32, dtype=f64, device=dev)
         # the prior predictive of every row (an empty slot's likelihood): a constant of corpus and prior, evaluated once
         # instead of in the score and assignment kernels of every Gibbs step (same values)
         self.prior_rows = torch.zeros(c.n_emb, dtype=f64, device=dev)
