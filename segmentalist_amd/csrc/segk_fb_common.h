@@ -72,6 +72,29 @@ static __device__ __forceinline__ double fb_wave_sum(double v)
     return (r0 + r1) + (r2 + r3);
 }
 
+// inclusive prefix sum over the 64 lanes (lane l: v_0 + ... + v_l): inside the rows of sixteen by DPP row shifts (the lanes
+// a shift leaves without a source add zero), then the totals of the rows before by v_readlane
+template <int CTRL>
+static __device__ __forceinline__ double fb_dpp_f64_z(double v)
+{
+    union { double d; int i[2]; } u, r;
+    u.d = v;
+    r.i[0] = __builtin_amdgcn_update_dpp(0, u.i[0], CTRL, 0xF, 0xF, true);
+    r.i[1] = __builtin_amdgcn_update_dpp(0, u.i[1], CTRL, 0xF, 0xF, true);
+    return r.d;
+}
+static __device__ __forceinline__ double fb_wave_scan(double v)
+{
+    v += fb_dpp_f64_z<0x111>(v);          // row_shr:1
+    v += fb_dpp_f64_z<0x112>(v);          // row_shr:2
+    v += fb_dpp_f64_z<0x114>(v);          // row_shr:4
+    v += fb_dpp_f64_z<0x118>(v);          // row_shr:8
+    const double t0 = fb_readlane(v, 15), t1 = fb_readlane(v, 31), t2 = fb_readlane(v, 47);
+    const int row = (int)(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) >> 4);
+    const double add = row == 0 ? 0.0 : (row == 1 ? t0 : (row == 2 ? t0 + t1 : (t0 + t1) + t2));
+    return v + add;
+}
+
 // ---------------------------------------------------------------------------------------
 // block-wide helpers (blockDim.x a multiple of 64, <= 1024; `red` has >= 16 doubles)
 // ---------------------------------------------------------------------------------------

@@ -45,7 +45,8 @@ struct FbbMap {
 };
 
 // Column maps of the packed fp16x2 image (k_fbb_compact), behind the constants: [K_max] column of slot k (-1: empty), [K_max] the
-// pseudo-component's, [K_max + 1] tiles in use.  The token-likelihood matrix has the image's columns.
+// pseudo-component's (= the number of occupied slots), [K_max + 1] tiles in use, then [K_max + 1] the slot of column c.  The
+// token-likelihood matrix has the image's columns.
 static __host__ __device__ __forceinline__ int32_t *fbb_cmap(const segk_fbatch *bt, int KM)
 {
     return reinterpret_cast<int32_t *>(bt->consts16 + KM + 2);
@@ -1095,13 +1096,20 @@ __global__ __launch_bounds__(256) void k_fbb_assign_lm_wave(segk_corpus c, segk_
     double *z = (double *)smem + (int64_t)w * KM;      // [K_max], this wave's
     // column of the token-likelihood matrix per slot (an empty slot: the pseudo-component's).  The table is the workgroup's, every
     // wave writes all of it (the same values) and waits for its own stores only -- waves leave early, no workgroup barrier here
+    // (the packed form below wants the other direction, slot of column c, in the same place)
     int *cm = (int *)((double *)smem + 4 * (int64_t)KM);   // [K_max + 1]
+    constexpr int KPL = 16;
+    const bool packed = F32 && KM <= 64 * KPL;
     {
         const int32_t *g = fbb_cmap(&bt, KM);
         const int pcol = g[KM];
-        for (int k = lane; k <= KM; k += 64) {
-            const int ck = g[k];
-            cm[k] = ck >= 0 ? ck : pcol;
+        if (packed) {
+            for (int q = lane; q <= pcol; q += 64) cm[q] = g[KM + 2 + q];
+        } else {
+            for (int k = lane; k <= KM; k += 64) {
+                const int ck = g[k];
+                cm[k] = ck >= 0 ? ck : pcol;
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -1135,71 +1143,167 @@ __global__ __launch_bounds__(256) void k_fbb_assign_lm_wave(segk_corpus c, segk_
         // relative error; a draw changes when the uniform falls that close to a cumulative boundary.
         const float LOG2E = 1.4426950408889634f;
         const double le = log(n_empty), ltot = log(tot + f.lm_a), inv_tot = 1. / (tot + f.lm_a), aK = f.lm_a / (double)KM, bK = f.lm_b / (double)KM;
-        if (KM <= 64 * 16) {
-            // up to 16 slots per lane: what does not change from token to token (counts, constants) stays in registers for
-            // the utterance, and a token's loads (likelihood row, bigram row) are all issued before the first is used --
-            // a plain loop over the slots waited for five loads per slot, sixteen times per token
-            constexpr int KPL = 16;
-            double cn[KPL], zl[KPL];
+        if (packed) {
+            // The softmax over the OCCUPIED slots only (419 of 1 000 at configs[4]): the empty ones share one logit -- no
+            // tokens, no bigram counts, the pseudo-component's likelihood -- which is evaluated once and enters the sum
+            // n_empty times.  Lane l holds the columns l, l + 64, ... of the packed matrix (up to 16; what does not change
+            // from token to token stays in registers for the utterance, and a token's loads are all issued before the
+            // first is used).  The draw walks the slots in slot order as utils.draw does: the columns' probabilities go to
+            // LDS, lane l sums the chunk [l per, (l + 1) per) of them plus the empty slots that lie between its first
+            // column's slot and the next chunk's, a scan over the lanes finds the chunk and one walk over it the slot.
+            const int *inv = cm;
+            const int n_occ = fbb_cmap(&bt, KM)[KM];
+            const int jmax = (n_occ + 63) >> 6, per = jmax > 0 ? jmax : 1;
+            const bool has_e = n_empty > 0.0;
+            // (per column: count + a/K for the prior's argument -- which goes through v_log_f32 and is formed in float32 --
+            // and the constant of the likelihood; float32 like the matrix's values they are added to)
+            float naK[KPL], c2[KPL];
 #pragma unroll
             for (int j = 0; j < KPL; j++) {
-                const int k = lane + 64 * j, kc = k < KM ? k : KM - 1;
-                cn[j] = bt.cnt[kc];
-                zl[j] = bt.zconst[kc] - bt.lconst[kc];
+                naK[j] = 1.f;
+                c2[j] = 0.f;
+                if (j < jmax) {
+                    const int q = lane + 64 * j, k = q < n_occ ? inv[q] : inv[0];
+                    naK[j] = (float)(bt.cnt[k] + aK);
+                    c2[j] = (float)(norm - (bt.zconst[k] - bt.lconst[k]));
+                }
             }
+            const float lam_it = (float)(f.lm_lambda * inv_tot), bKf = (float)bK, lmsf = (float)f.lms, LN2f = 0.6931471805599453f;
+            const int *bg32 = (const int *)f.lm_bigram;                         // (counts: the low words)
+            const int lo = lane * per < n_occ ? lane * per : n_occ, hi = lo + per < n_occ ? lo + per : n_occ;
+            const int b_lo = lane == 0 ? 0 : (lo < n_occ ? inv[lo] : KM);       // first slot of this lane's chunk
+            const int b_hi = hi < n_occ ? inv[hi] : KM;                         // ... of the next one's
+            const double n_gap = (double)((b_hi - b_lo) - (hi - lo));           // empty slots inside
             for (int t = 0; t < nn; t++) {
                 const int64_t e = new_tok[(int64_t)utt * c.N_max + t];
                 const float *mrow = llmat + ((int64_t)item * c.N_max + t) * ll_ld;
                 const double inv_prev = j_prev >= 0 ? (1. - f.lm_lambda) / (bt.cnt[j_prev] + f.lm_b) : 0.0;
-                const double empty_ll = (double)mrow[cm[KM]] * LN2 - zc_empty - le + norm;
+                const float mre = mrow[n_occ];
+                const float inv_prevf = (float)inv_prev;
                 float mr[KPL];
-                long long bg[KPL];
+                int bg[KPL];
 #pragma unroll
                 for (int j = 0; j < KPL; j++) {
-                    const int k = lane + 64 * j, kc = k < KM ? k : KM - 1;
-                    mr[j] = mrow[cm[kc]];
-                    bg[j] = j_prev >= 0 ? f.lm_bigram[(int64_t)j_prev * KM + kc] : 0;
+                    mr[j] = 0.f;
+                    bg[j] = 0;
+                    if (j < jmax) {
+                        const int q = lane + 64 * j;
+                        mr[j] = mrow[q < n_occ ? q : n_occ];
+                        bg[j] = j_prev >= 0 ? bg32[2 * ((int64_t)j_prev * KM + inv[q < n_occ ? q : 0])] : 0;
+                    }
                 }
-                double zv[KPL], mx = NEG_INF_D;
+                const double empty_ll = (double)mre * LN2 - zc_empty - le + norm;
+                double ze = NEG_INF_D;
+                if (has_e) {
+                    double pz;
+                    if (j_prev < 0) pz = ((double)(__builtin_amdgcn_logf((float)aK) * 0.6931471805599453f) - ltot) * f.lms;
+                    else pz = (double)(__builtin_amdgcn_logf((float)aK * lam_it + bKf * inv_prevf) * LN2f * lmsf);
+                    ze = pz + empty_ll;
+                }
+                if constexpr (PROBE) {
+                    const int32_t *g = fbb_cmap(&bt, KM);
+                    for (int k = lane; k < KM; k += 64)
+                        if (g[k] < 0) probe_ll[((int64_t)utt * c.N_max + t) * probe_ld + k] = empty_ll;
+                }
+                double zv[KPL], mx = ze;
 #pragma unroll
                 for (int j = 0; j < KPL; j++) {
-                    const double n = cn[j];
-                    const double llv = n > 0.0 ? (double)mr[j] * LN2 - zl[j] + norm : empty_ll;
-                    if constexpr (PROBE)
-                        if (lane + 64 * j < KM) probe_ll[((int64_t)utt * c.N_max + t) * probe_ld + lane + 64 * j] = llv;
-                    double pz;
-                    if (j_prev < 0) pz = ((double)(__builtin_amdgcn_logf((float)(n + aK)) * 0.6931471805599453f) - ltot) * f.lms;
-                    else pz = (double)(__builtin_amdgcn_logf((float)(f.lm_lambda * ((n + aK) * inv_tot) + ((double)bg[j] + bK) * inv_prev)) * 0.6931471805599453f) * f.lms;
-                    zv[j] = lane + 64 * j < KM ? pz + llv : NEG_INF_D;
-                    mx = zv[j] > mx ? zv[j] : mx;
+                    zv[j] = NEG_INF_D;
+                    if (j < jmax) {
+                        const double llv = (double)mr[j] * LN2 + (double)c2[j];
+                        const bool ok = lane + 64 * j < n_occ;
+                        if constexpr (PROBE)
+                            if (ok) probe_ll[((int64_t)utt * c.N_max + t) * probe_ld + inv[lane + 64 * j]] = llv;
+                        double pz;
+                        if (j_prev < 0) pz = ((double)(__builtin_amdgcn_logf(naK[j]) * LN2f) - ltot) * f.lms;
+                        else pz = (double)(__builtin_amdgcn_logf(naK[j] * lam_it + ((float)bg[j] + bKf) * inv_prevf) * LN2f * lmsf);
+                        zv[j] = ok ? pz + llv : NEG_INF_D;
+                        mx = zv[j] > mx ? zv[j] : mx;
+                    }
                 }
                 mx = fb_wave_max(mx, false);
                 auto sum_reg = [&](double shift) -> double {
                     double sv = 0.0;
 #pragma unroll
-                    for (int j = 0; j < KPL; j++) sv += (double)__builtin_amdgcn_exp2f((float)(zv[j] - shift) * LOG2E);      // 2^-inf = 0 for the slots beyond K_max
+                    for (int j = 0; j < KPL; j++)
+                        if (j < jmax) sv += (double)__builtin_amdgcn_exp2f((float)(zv[j] - shift) * LOG2E);      // 2^-inf = 0 behind the last column
                     sv = fb_wave_sum(sv);
+                    if (has_e) sv += n_empty * (double)__builtin_amdgcn_exp2f((float)(ze - shift) * LOG2E);
                     return sv;
                 };
                 double lse = log(sum_reg(mx)) + mx;
                 if (anneal_temp != 1.0) {                               // fbgmm.py:446-449
                     double mx2 = NEG_INF_D;
-#pragma unroll
-                    for (int j = 0; j < KPL; j++) {
-                        zv[j] = (1. / anneal_temp) * (zv[j] - lse);
-                        mx2 = zv[j] > mx2 ? zv[j] : mx2;
+                    if (has_e) {
+                        ze = (1. / anneal_temp) * (ze - lse);
+                        mx2 = ze;
                     }
+#pragma unroll
+                    for (int j = 0; j < KPL; j++)
+                        if (j < jmax) {
+                            zv[j] = (1. / anneal_temp) * (zv[j] - lse);
+                            mx2 = zv[j] > mx2 ? zv[j] : mx2;
+                        }
                     mx2 = fb_wave_max(mx2, false);
                     lse = log(sum_reg(mx2)) + mx2;
                 }
 #pragma unroll
                 for (int j = 0; j < KPL; j++)
-                    if (lane + 64 * j < KM) z[lane + 64 * j] = (double)__builtin_amdgcn_exp2f((float)(zv[j] - lse) * LOG2E);
+                    if (j < jmax && lane + 64 * j < n_occ) z[lane + 64 * j] = (double)__builtin_amdgcn_exp2f((float)(zv[j] - lse) * LOG2E);
+                const double p_e = has_e ? (double)__builtin_amdgcn_exp2f((float)(ze - lse) * LOG2E) : 0.0;
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                const int kd = fb_draw_chunked(z, KM, segk_u01(bt.seed, sweep, (uint64_t)utt, (uint64_t)(c.N_max + t)), lane);
+                // ---- the draw
+                double sl = 0.0;
+                for (int q = lo; q < hi; q++) sl += z[q];
+                sl += n_gap * p_e;
+                const double incl = fb_wave_scan(sl);
+                const double u = segk_u01(bt.seed, sweep, (uint64_t)utt, (uint64_t)(c.N_max + t));
+                const unsigned long long below = __ballot(u < incl);
+                int kd = KM - 1;
+                if (below) {
+                    const int run = __ffsll((long long)below) - 1;
+                    double r = u - (fb_readlane(incl, run) - fb_readlane(sl, run));
+                    const int rlo = run * per < n_occ ? run * per : n_occ, rhi = rlo + per < n_occ ? rlo + per : n_occ;
+                    int pos = __builtin_amdgcn_readlane(b_lo, run);
+                    const int end = __builtin_amdgcn_readlane(b_hi, run);
+                    bool found = false;
+                    for (int q = rlo; q < rhi && !found; q++) {
+                        const int k = inv[q];
+                        const int gap = k - pos;
+                        if (gap > 0) {
+                            const double m = (double)gap * p_e;
+                            if (r < m) {
+                                int o = (int)(r / p_e);
+                                o = o < 0 ? 0 : (o > gap - 1 ? gap - 1 : o);
+                                kd = pos + o;
+                                found = true;
+                                break;
+                            }
+                            r -= m;
+                        }
+                        const double pq = z[q];
+                        if (r < pq) {
+                            kd = k;
+                            found = true;
+                            break;
+                        }
+                        r -= pq;
+                        pos = k + 1;
+                    }
+                    if (!found) {
+                        const int gap = end - pos;
+                        if (gap > 0 && p_e > 0.0) {
+                            int o = (int)(r / p_e);
+                            o = o < 0 ? 0 : (o > gap - 1 ? gap - 1 : o);
+                            kd = pos + o;
+                        } else {
+                            kd = pos > 0 ? pos - 1 : 0;
+                        }
+                    }
+                }
                 if (lane == 0) bt.slot[e] = kd;
-                j_prev = __shfl(kd, 0);
+                j_prev = kd;
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
             }
@@ -1467,6 +1571,7 @@ __global__ __launch_bounds__(1024) void k_fbb_compact(segk_fbatch bt, int KM, in
     __shared__ int wsum[16];
     __shared__ int run;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int32_t *inv = cmap + KM + 2;                     // [K_max + 1] slot of column c (K_max: the pseudo-component's)
     if (tid == 0) run = 0;
     __syncthreads();
     for (int k0 = 0; k0 < KM; k0 += 1024) {
@@ -1479,6 +1584,7 @@ __global__ __launch_bounds__(1024) void k_fbb_compact(segk_fbatch bt, int KM, in
         for (int w = 0; w < wv; w++) off += wsum[w];
         const int col = off + __popcll(m & ((1ull << lane) - 1ull));
         if (k < KM) cmap[k] = occ ? col : -1;
+        if (occ) inv[col] = k;
         __syncthreads();
         if (tid == 0) {
             int t = 0;
@@ -1491,6 +1597,7 @@ __global__ __launch_bounds__(1024) void k_fbb_compact(segk_fbatch bt, int KM, in
     if (tid == 0) {
         cmap[KM] = run;                               // the pseudo-component's column
         cmap[KM + 1] = n_t;                           // tiles in use
+        inv[run] = KM;
     }
     for (int k = tid; k <= KM; k += 1024) bt.consts16[k] = -3.0e38;
     // the columns behind the pseudo-component inside the last tile in use are multiplied too: their rows (whatever an earlier

@@ -144,8 +144,9 @@ def test_token_likelihoods_and_forward_filter_within_the_contract(gpu, monkeypat
     alpha, ll = alpha.cpu().numpy(), ll.cpu().numpy().reshape(n_utt, N_max, K)
     score = seg._df.score.cpu().numpy()
     new_tok, n_new = seg._df.new_tok.cpu().numpy(), seg._df.n_new.cpu().numpy()
-    worst_ll = worst_a_own = worst_a_spec = 0.0
-    n_tok = n_occ = 0
+    worst_ll = worst_a_own = worst_a_spec = worst_draw = 0.0
+    n_tok = n_occ = n_drawn_empty = 0
+    slots = sw.slot.cpu().numpy()
     for b in range(sw.B):
         d = spec.derive(*spec.stats_excluding(b))
         uni = big = None
@@ -183,9 +184,30 @@ def test_token_likelihoods_and_forward_filter_within_the_contract(gpu, monkeypat
                     worst_ll = max(worst_ll, float(np.max(np.abs(g - want) / np.maximum(np.abs(want), 1.0))))
                     n_tok += 1
                     n_occ += int(d["active"].sum())
+                # --- the draws: slot k was drawn with the token's uniform u iff cum(k - 1) <= u < cum(k), cum the running sum
+                # of the probabilities in slot order (utils.draw).  Probabilities out of the device's own fp64 token
+                # log-likelihoods and the specification's prior (the device: v_log_f32 / v_exp_f32, ~3e-6 relative; the
+                # one-wave kernel sums the occupied slots and the block of equal empty ones separately)
+                if kind == "bigram":
+                    j_prev = None
+                    for t in range(n_new[i]):
+                        z = spec.prior_z(d, j_prev, uni, big) + ll[i, t]
+                        pr = np.exp(z - z.max())
+                        cum = np.cumsum(pr / pr.sum())
+                        k = int(slots[new_tok[i, t]])
+                        assert 0 <= k < K
+                        uu = nb.u01(spec.seed, 0, i, N_max + t)
+                        below = cum[k - 1] if k > 0 else 0.0
+                        worst_draw = max(worst_draw, below - uu, uu - cum[k])
+                        n_drawn_empty += int(not d["active"][k])
+                        j_prev = k
     print("%s %s D=%d K=%d: token log-likelihoods worst %.3g (over %d tokens x %d slots, %.0f occupied per token); "
           "alphas worst %.3g against fp64 on the device's scores, %.3g against the specification"
           % (kind, prec, D, K, worst_ll, n_tok, K, n_occ / max(n_tok, 1), worst_a_own, worst_a_spec))
+    if kind == "bigram":
+        print("draws: worst distance of a token's uniform from its slot's interval %.3g; %d of %d tokens drew an empty slot"
+              % (worst_draw, n_drawn_empty, n_tok))
+        assert worst_draw < 1e-4, worst_draw
     assert n_tok >= 4 * n_utt
     assert worst_ll < TOL, worst_ll
     assert worst_a_own < TOL, worst_a_own
