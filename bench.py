@@ -332,10 +332,18 @@ def main_fbgmm(args):
             if got > 0:
                 score_ms = float(np.mean(ms[:got]))
                 n_rows = float(np.mean(rows[:got]))
-                flops = 2.0 * n_rows * (K + 1) * (2 * D)     # [x^2, x] . [-pp/2, pp*mu] over K_max slots + the empty-slot row
+                # [x^2, x] . [-pp/2, pp*mu] over the occupied slots + the empty-slot row (the reference scores the components
+                # that exist, fbgmm.py:256-285); the fp16x2 image holds just those, packed into the leading tiles
+                # (segk.h: segk_fbatch.consts16), as of the last Gibbs step of the timed region
+                cols, tiles_used = occ + 1, (K + 1 + 31) // 32
+                if getattr(sw, "score_f16", False) and sw.consts16 is not None:
+                    import torch as _t
+                    cm = sw.consts16[K + 2:].view(_t.int32)[:K + 2].cpu()
+                    cols, tiles_used = int(cm[K]) + 1, int(cm[K + 1])
+                flops = 2.0 * n_rows * cols * (2 * D)
                 achieved = flops / (score_ms * 1e-3) / 1e12
                 if getattr(sw, "score_f16", False):
-                    kp, kpad = (2 * D + 15) // 16 * 16, (K + 1 + 31) // 32 * 32
+                    kp, kpad = (2 * D + 15) // 16 * 16, 32 * tiles_used
                     executed = 3 * 2.0 * n_rows * kpad * kp
                     ex_tf = executed / (score_ms * 1e-3) / 1e12
                     out["dtype"] = "fp16x2 span scores, f64 sampling"
@@ -343,6 +351,7 @@ def main_fbgmm(args):
                                        "splits, one launch per Gibbs step)" % (kp // 16), "achieved": achieved,
                                        "peak": PEAK_BF16_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_MATRIX_TFLOPS,
                                        "traffic": None, "ms_per_launch": score_ms, "flops_per_launch": flops,
+                                       "columns": cols, "tiles_of_32": tiles_used,
                                        "executed_flops_per_launch": executed, "executed_achieved": ex_tf,
                                        "executed_frac": ex_tf / PEAK_BF16_MATRIX_TFLOPS,
                                        "achieved_over_fp32_matrix_peak": achieved / PEAK_FP32_MATRIX_TFLOPS}
