@@ -108,7 +108,11 @@ typedef struct segk_corpus {
     /* optional banded image of vec_ids / durations (utterances.py:91-105 keeps the triangular tables; the
      * per-utterance kernels only ever read the band t - s <= n_slices_max): entry (t, w), t = 1..N_max the span's
      * end, w = 0..band_W-1 its length minus one, at [(utt * N_max + t - 1) * band_W + w] = the triangular entry
-     * t(t-1)/2 + (t-1-w) (-1 / NaN where that span does not exist).  Consecutive lanes read consecutive entries.  */
+     * t(t-1)/2 + (t-1-w) (-1 / NaN where that span does not exist).  Consecutive lanes read consecutive entries.
+     * The k-means kernels fall back to the triangle for a span outside the band; the FBGMM / bigram kernels
+     * (segk_fbgmm.hip, segk_fbbatch.hip) read the band alone when band_W equals the DP window and take it as
+     * COMPLETE: pass it to them only when no triangular entry outside it names an embedding
+     * (Utterances.complete_band_tables on the host side checks).                                    */
     const int32_t *band_ids; /* [dev] [n_utt, N_max, band_W] or NULL                          */
     const double *band_dur;  /* [dev] [n_utt, N_max, band_W] or NULL                          */
 } segk_corpus;

@@ -79,7 +79,8 @@ class BigramAcousticWordseg(object):
             p_boundary_init=p_boundary_init, n_slices_min=n_slices_min, n_slices_max=n_slices_max,
             min_duration=min_duration)
         u = self.utterances
-        self._corpus = DeviceCorpus(embeddings, u.vec_ids, u.durations, u.lengths)
+        # (banded span tables: what the segmentation kernels read when no embedding lies outside the window)
+        self._corpus = DeviceCorpus(embeddings, u.vec_ids, u.durations, u.lengths, band=u.complete_band_tables(n_slices_max))
 
         init_embeds = []
         for i in range(u.D):

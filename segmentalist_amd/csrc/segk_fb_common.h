@@ -290,6 +290,65 @@ struct CounterUniforms {       // the batch sampler's counter-based stream
     __device__ double next(int) { return segk_u01(seed, sweep, utt, j++); }
 };
 
+// Span tables of one utterance for a DP window of n_max slices: the banded image (segk_corpus.band_ids / band_dur: entry
+// (t, w), t = 1..N the span's end, w its length minus one, at [(t - 1) W + w]) when it was built for this window, else the
+// triangle (utterances.py:91-105).  The band is what the DP reads (spans of at most n_max slices): 120 entries instead of
+// 210 at N = 20, n_slices_max = 6, and entry i is read by thread i.  These kernels take the band as COMPLETE -- every
+// triangular entry outside it is -1 (no embedding); the host side checks that before it hands the band over (segk.h).
+struct FbSpanTab {
+    const int32_t *vid;      // triangle
+    const double *dur;
+    const int32_t *bandi;    // band, when `band`
+    const double *bandd;
+    int W;
+    bool band;
+};
+static __device__ __forceinline__ FbSpanTab fb_span_tab(const segk_corpus &c, int u, int N, int n_max)
+{
+    const int64_t triMax = (int64_t)c.N_max * (c.N_max + 1) / 2;
+    FbSpanTab T;
+    T.vid = c.vec_ids + (int64_t)u * triMax;
+    T.dur = c.durations + (int64_t)u * triMax;
+    T.W = (n_max > 0 && n_max < N) ? n_max : N;
+    T.band = c.band_ids != nullptr && c.band_dur != nullptr && c.band_W == T.W && T.W > 0 && T.W < N;
+    T.bandi = T.band ? c.band_ids + (int64_t)u * c.N_max * c.band_W : nullptr;
+    T.bandd = T.band ? c.band_dur + (int64_t)u * c.N_max * c.band_W : nullptr;
+    return T;
+}
+
+// vec (unigram_acoustic_wordseg.py:474-511), triangular in LDS: score * duration ** time_power_term + wip per span, -inf where
+// there is none.  `score_of(id)`: the span score of embedding id.  Every thread of the workgroup calls (a barrier inside).
+template <typename SC>
+static __device__ void fb_fill_vec(const FbSpanTab &T, int N, int tri, SC score_of, double time_power_term, double wip, double *vec,
+                                   int tid, int nt)
+{
+    // (x ** 1.0 is x -- numpy's power, the specification, returns it exactly; the software pow costs ~300 instructions per span)
+    if (T.band) {
+        for (int j = tid; j < tri; j += nt) vec[j] = NEG_INF_D;            // (-inf + wip)
+        __syncthreads();
+        const int W = T.W;
+        for (int i = tid; i < N * W; i += nt) {
+            const int t = i / W + 1, s = t - 1 - (i - (t - 1) * W);
+            if (s < 0) continue;
+            const int id = T.bandi[i];
+            if (id < 0) continue;
+            const double dd = T.bandd[i];
+            const double v = isnan(dd) ? NEG_INF_D : score_of(id) * (time_power_term == 1.0 ? dd : pow(dd, time_power_term));
+            vec[t * (t - 1) / 2 + s] = v + wip;
+        }
+    } else {
+        for (int j = tid; j < tri; j += nt) {
+            const int id = T.vid[j];
+            double v = NEG_INF_D;
+            if (id >= 0) {
+                const double dd = T.dur[j];
+                v = isnan(dd) ? NEG_INF_D : score_of(id) * (time_power_term == 1.0 ? dd : pow(dd, time_power_term));
+            }
+            vec[j] = v + wip;
+        }
+    }
+}
+
 // A6 / A7 by one full wave (unigram_acoustic_wordseg.py:653-864): forward filtering, then backward
 // sampling (or Viterbi back-tracking) writing the boundaries; returns the summed score of the chosen
 // segments.  Control flow and values are wave-uniform; the exponentials of each logsumexp /

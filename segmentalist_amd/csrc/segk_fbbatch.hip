@@ -807,23 +807,14 @@ __global__ __launch_bounds__(128) void k_fbb_segment(segk_corpus c, segk_fbatch 
     const int N = c.lengths[utt];
     const int tri = N * (N + 1) / 2;
     const int64_t triMax = (int64_t)c.N_max * (c.N_max + 1) / 2;
-    const int32_t *vid = c.vec_ids + (int64_t)utt * triMax;
-    const double *dur = c.durations + (int64_t)utt * triMax;
+    const FbSpanTab tab = fb_span_tab(c, utt, N, n_max);
+    const int32_t *vid = tab.vid;
     double *vec = (double *)smem;           // [tri]
     double *a = vec + triMax;               // [N]
     double *w = a + c.N_max;                // [N+1]
     double *pr = w + c.N_max + 1;           // [N+1]
     int32_t *old = (int32_t *)(pr + c.N_max + 1);      // [N_max]
-    for (int j = threadIdx.x; j < tri; j += blockDim.x) {       // unigram_acoustic_wordseg.py:474-511
-        const int id = vid[j];
-        double v = NEG_INF_D;
-        if (id >= 0) {
-            const double dd = dur[j];
-            // (x ** 1.0 is x -- numpy's power, the specification, returns it exactly; the software pow costs ~300 instructions per span)
-            v = isnan(dd) ? NEG_INF_D : score[id] * (time_power_term == 1.0 ? dd : pow(dd, time_power_term));
-        }
-        vec[j] = v + wip;
-    }
+    fb_fill_vec(tab, N, tri, [&](int id) { return score[id]; }, time_power_term, wip, vec, threadIdx.x, blockDim.x);
     __syncthreads();
     if (threadIdx.x >= 64) return;
     const int lane = threadIdx.x;

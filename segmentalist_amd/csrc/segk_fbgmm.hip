@@ -498,22 +498,13 @@ __global__ __launch_bounds__(128) void k_unigram_segment(segk_corpus c, int utt,
     const int N = c.lengths[utt];
     const int tri = N * (N + 1) / 2;
     const int64_t triMax = (int64_t)c.N_max * (c.N_max + 1) / 2;
-    const int32_t *vid = c.vec_ids + (int64_t)utt * triMax;
-    const double *dur = c.durations + (int64_t)utt * triMax;
+    const FbSpanTab tab = fb_span_tab(c, utt, N, viterbi == 2 ? 0 : n_max);
+    const int32_t *vid = tab.vid;
     double *vec = (double *)smem;           // [tri]
     double *a = vec + triMax;               // [N]
     double *w = a + c.N_max;                // [N+1]
     double *pr = w + c.N_max + 1;           // [N+1]
-    for (int j = threadIdx.x; j < tri; j += blockDim.x) {       // unigram_acoustic_wordseg.py:474-511
-        int id = vid[j];
-        double v = NEG_INF_D;
-        if (id >= 0) {
-            double dd = dur[j];
-            // (x ** 1.0 is x -- numpy's power, the specification, returns it exactly; the software pow costs ~300 instructions per span)
-            v = isnan(dd) ? NEG_INF_D : score[id] * (time_power_term == 1.0 ? dd : pow(dd, time_power_term));
-        }
-        vec[j] = v + wip;
-    }
+    fb_fill_vec(tab, N, tri, [&](int id) { return score[id]; }, time_power_term, wip, vec, threadIdx.x, blockDim.x);
     __syncthreads();
     if (threadIdx.x >= 64) return;
     // wave 0 runs the DP: control flow and values are wave-uniform, the exponentials of each
@@ -726,8 +717,7 @@ __global__ __launch_bounds__(512) void k_fb_chain(FbChainArgs A)
         const int N = c.lengths[u], tri = N * (N + 1) / 2;
         const int64_t row0 = A.row_start[u];
         const int nrows = A.row_start[u + 1] - (int)row0;
-        const int32_t *vid = c.vec_ids + (int64_t)u * triMax;
-        const double *dur = c.durations + (int64_t)u * triMax;
+        const FbSpanTab tab = fb_span_tab(c, u, N, A.n_max);
         // ---- (A) stage the utterance: labels of its rows, span table, old boundaries
         FBC_STAMP(0);
         for (int i = tid; i < nrows; i += nt) asg_l[i] = A.f.assignments[row0 + i];
@@ -737,7 +727,17 @@ __global__ __launch_bounds__(512) void k_fb_chain(FbChainArgs A)
             const int r = i / D, d = i - r * D;
             xs_l[i] = ((const XT *)c.X)[(row0 + r) * c.ldx + d];
         }
-        for (int j = tid; j < tri; j += nt) vid_l[j] = vid[j];
+        if (tab.band) {                                  // (the band is complete: no embedding outside it)
+            for (int j = tid; j < tri; j += nt) vid_l[j] = -1;
+            __syncthreads();
+            const int W = tab.W;
+            for (int i = tid; i < N * W; i += nt) {
+                const int t = i / W + 1, s = t - 1 - (i - (t - 1) * W);
+                if (s >= 0) vid_l[t * (t - 1) / 2 + s] = tab.bandi[i];
+            }
+        } else {
+            for (int j = tid; j < tri; j += nt) vid_l[j] = tab.vid[j];
+        }
         for (int j = tid; j < N; j += nt) bnd_l[j] = A.boundaries[(int64_t)u * NM + j];
         if (tid == 0) n_relog = 0;
         __syncthreads();
@@ -790,16 +790,9 @@ __global__ __launch_bounds__(512) void k_fb_chain(FbChainArgs A)
         if (!chain_barrier(A.ctl, ++phase, &sh_flag)) return;
         FBC_STAMP(4);
         // ---- (D) vec (unigram_acoustic_wordseg.py:474-511) from everybody's scores, the DP by wave 0 (replicated)
-        for (int j = tid; j < tri; j += nt) {
-            const int id = vid_l[j];
-            double v = NEG_INF_D;
-            if (id >= 0) {
-                const double dd = dur[j];
-                const double sc = __longlong_as_double((long long)__hip_atomic_load(&A.score[id], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                v = isnan(dd) ? NEG_INF_D : sc * (A.time_power_term == 1.0 ? dd : pow(dd, A.time_power_term));
-            }
-            vec[j] = v + A.wip;
-        }
+        fb_fill_vec(tab, N, tri, [&](int id) {
+            return __longlong_as_double((long long)__hip_atomic_load(&A.score[id], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        }, A.time_power_term, A.wip, vec, tid, nt);
         __syncthreads();
         if (tid < 64) {
             StreamUniforms usrc = {A.ustream, (int64_t)sh_cur, A.ucap, A.status};

@@ -89,6 +89,17 @@ class Utterances(object):
         dur = np.where(ok[None], self.durations[:, j], np.nan)
         return np.ascontiguousarray(ids), np.ascontiguousarray(dur)
 
+    def complete_band_tables(self, W):
+        """`band_tables(W)` when the band holds every embedding of the corpus -- no triangular entry outside it names one --
+        else None.  The FBGMM / bigram kernels read nothing but the band then (segk.h: segk_corpus.band_ids); with
+        embeddings outside the window they keep to the triangle."""
+        if not (1 <= W < self.N_max):
+            return None
+        ids, dur = self.band_tables(W)
+        if int(np.count_nonzero(ids >= 0)) != int(np.count_nonzero(np.asarray(self.vec_ids) >= 0)):
+            return None
+        return ids, dur
+
     # ---------------------------------------------------------------- device mirroring
     def bind_device(self, dev_boundaries, refresh=None):
         """`dev_boundaries`: torch uint8 [D, N_max] owned by the segmenter.  `refresh`: called before the device

@@ -296,3 +296,48 @@ def test_persistent_chain_equals_the_four_launches_per_utterance(gpu, monkeypatc
             assert np.array_equal(out["1"][k], out["0"][k]), k
         else:
             assert out["1"][k] == out["0"][k], k
+
+
+@pytest.mark.parametrize("sync", ["sequential", "batch"])
+def test_banded_span_tables_feed_the_fbgmm_kernels(gpu, monkeypatch, sync):
+    """The FBGMM segmentation kernels (k_unigram_segment, the persistent chain, k_fbb_segment) read the banded image of the
+    span tables (segk_corpus.band_ids / band_dur) when it holds every embedding; against the same run on the
+    triangular tables: boundaries, assignments, statistics and the RNG position bit for bit.  A corpus with embeddings
+    outside the window keeps to the triangle."""
+    from segmentalist_amd import fbgmm, unigram_acoustic_wordseg as uaw
+    from segmentalist_amd.niw import NIW
+    from segmentalist_amd.synth import make_corpus
+    from segmentalist_amd.utterances import Utterances
+    D, K = 12, 30
+    corpus = make_corpus(60, D, K, seed=9, ragged=True, n_slices_max=5, N_range=(3, 14))
+    prior = NIW(np.zeros(D), 0.05, D + 3, 0.002 * (D + 3) * np.ones(D))
+    args = dict(covariance_type="diag", fb_type="standard", n_slices_min=0, n_slices_max=5, p_boundary_init=0.5,
+                beta_sent_boundary=-1, lms=1.0, wip=-0.1, init_am_assignments="rand", time_power_term=1.1)
+    if sync == "batch":
+        args.update(sync="batch", n_gibbs_blocks=3, n_stat_blocks=4, batch_seed=11)
+    real = Utterances.complete_band_tables
+    out = {}
+    for mode in ("band", "triangle"):
+        monkeypatch.setattr(Utterances, "complete_band_tables", real if mode == "band" else (lambda self, W: None))
+        random.seed(3)
+        np.random.seed(3)
+        seg = uaw.UnigramAcousticWordseg(fbgmm.FBGMM, 1.0, K, prior, *corpus, **args)
+        assert seg._corpus.band_W == (5 if mode == "band" else 0)
+        rec = seg.gibbs_sample(3)
+        df = seg._df
+        out[mode] = dict(b=seg.utterances.boundaries.copy(), a=seg.acoustic_model.components.assignments.copy(),
+                         sa=df.stat_a.cpu().numpy(), sb=df.stat_b.cpu().numpy(), cn=df.counts.cpu().numpy(), K=int(df.K.item()),
+                         rec={k: list(v) for k, v in rec.items() if k != "sample_time"}, rnd=random.random())
+    for k in out["band"]:
+        if isinstance(out["band"][k], np.ndarray):
+            assert np.array_equal(out["band"][k], out["triangle"][k]), k
+        else:
+            assert out["band"][k] == out["triangle"][k], k
+    # embeddings for spans of up to seven slices, a window of five: the band would drop some -- the triangle stays
+    monkeypatch.setattr(Utterances, "complete_band_tables", real)
+    wide = make_corpus(20, D, K, seed=10, ragged=True, n_slices_max=7, N_range=(9, 14))
+    random.seed(3)
+    np.random.seed(3)
+    seg = uaw.UnigramAcousticWordseg(fbgmm.FBGMM, 1.0, K, prior, *wide, **args)
+    assert seg._corpus.band_W == 0
+    seg.gibbs_sample(1)

@@ -182,3 +182,28 @@ def test_host_init_stats_of_a_sharded_corpus_equal_the_reference_constructor():
         assert means.dtype == ref.means.dtype and np.array_equal(means, ref.means)
         assert np.array_equal(numer, ref.mean_numerators)
         assert np.array_equal(counts, ref.counts)
+
+
+def test_complete_band_tables_only_when_no_embedding_lies_outside_the_window():
+    """Utterances.complete_band_tables: the banded image of the span tables for the FBGMM kernels, which read nothing else --
+    handed over only when every embedding of the triangle is inside the band."""
+    from segmentalist_amd.synth import make_corpus
+    from segmentalist_amd.utterances import Utterances, process_embeddings
+    mats, vec_ids_dict, durations_dict, landmarks_dict = make_corpus(12, 4, 6, seed=1, ragged=True, n_slices_max=4, N_range=(3, 9))
+    _, vec_ids, labels = process_embeddings(mats, vec_ids_dict)
+    u = Utterances([len(landmarks_dict[i]) for i in labels], vec_ids, [durations_dict[i] for i in labels],
+                   [landmarks_dict[i] for i in labels], p_boundary_init=0.5, n_slices_min=0, n_slices_max=4)
+    band = u.complete_band_tables(4)
+    assert band is not None
+    ids, dur = band
+    assert ids.shape == (u.D, u.N_max, 4) and dur.shape == ids.shape
+    tri = np.asarray(u.vec_ids)
+    assert np.count_nonzero(ids >= 0) == np.count_nonzero(tri >= 0)
+    for i in range(u.D):
+        for t in range(1, u.N_max + 1):
+            for w in range(4):
+                s = t - 1 - w
+                want = tri[i, t * (t - 1) // 2 + s] if s >= 0 else -1
+                assert ids[i, t - 1, w] == want
+    assert u.complete_band_tables(3) is None            # spans of four slices have embeddings: a window of three drops them
+    assert u.complete_band_tables(0) is None and u.complete_band_tables(u.N_max) is None
