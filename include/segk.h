@@ -515,10 +515,14 @@ int32_t segk_fbgmm_assign(segk_ctx *ctx, const segk_corpus *c, segk_fbgmm *f, in
  * kernel per stretch of utterances between two emptied components (ABI 6): every workgroup keeps the whole model in LDS and
  * replays every update, only the span scores are shared out, one grid barrier per utterance.  Same device functions, same
  * order of operations, same uniforms (ustream / ucursor as in the per-utterance calls): the same bits as the four calls per
- * utterance.  row_start [dev] int32 [n_utt + 1]: first row of every utterance (an utterance's rows are contiguous);
+ * utterance.  With a language model attached (f->lm_unigram): BigramAcousticWordseg.gibbs_sample_i
+ * (bigram_acoustic_wordseg.py:386-551) -- the counts of the utterance's transcript removed first and those of the new one
+ * added last (segk_fbgmm_update op 5 / 6), spans scored and segments assigned under the language model; every workgroup
+ * keeps its own copy of the bigram counts (K_max^2 int64 in global memory, owned by the context).
+ * row_start [dev] int32 [n_utt + 1]: first row of every utterance (an utterance's rows are contiguous);
  * score [dev] double [n_emb] scratch.  Returns SEGK_ERR_UNSUPPORTED, with nothing enqueued, where the kernel does not apply
- * (a language model attached, more than 64 landmarks, 3 K_max D doubles beyond a workgroup's LDS, an utterance listed twice,
- * SEGK_FB_CHAIN=0): the caller then makes the four calls per utterance.  SYNCHRONISES the stream after every launch.       */
+ * (more than 64 landmarks, 3 K_max D doubles beyond a workgroup's LDS, an utterance listed twice, SEGK_FB_CHAIN=0): the
+ * caller then makes the calls per utterance.  SYNCHRONISES the stream after every launch.                                  */
 int32_t segk_fbgmm_sequential_sweep(segk_ctx *ctx, const segk_corpus *c, segk_fbgmm *f, const int32_t *order, int32_t n_order,
                                     const int32_t *row_start, int32_t viterbi, int32_t map_assign, int32_t n_slices_min,
                                     int32_t n_slices_max, double wip, double time_power_term, double log_p_continue,

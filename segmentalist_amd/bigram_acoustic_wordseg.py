@@ -244,8 +244,17 @@ class BigramAcousticWordseg(object):
             else:
                 self._leave_batch()
                 self._open_stream(utt_order)
-                for i_utt in utt_order:
-                    self._gibbs_i_async(i_utt, anneal_temp, anneal_gibbs_am, assignments_only)
+                # the whole chain of the sweep by one library call where it applies (unigram_acoustic_wordseg.py does the same)
+                whole = (os.environ.get("SEGK_SEQ_PER_UTT", "0") != "1" and not debug_gibbs_only and not assignments_only
+                         and self._df.sequential_sweep(self._dev_bounds, utt_order, self._row_start, False, self.n_slices_min,
+                                                       self.n_slices_max, self.wip, self.time_power_term,
+                                                       math.log(self.calc_p_continue()), anneal_temp,
+                                                       anneal_temp if anneal_gibbs_am else 1.0))
+                if whole:
+                    self.utterances.mark_device_dirty()
+                else:
+                    for i_utt in utt_order:
+                        self._gibbs_i_async(i_utt, anneal_temp, anneal_gibbs_am, assignments_only)
                 torch.cuda.synchronize()
                 self._close_stream()
                 self._df.check_status()

@@ -668,7 +668,37 @@ struct FbChainArgs {
     const double *ktab;             // fb_diag_const by count (diagonal components), [ktab_n], or NULL
     int64_t ktab_n;
     const double *lprior_tab;       // [n_emb] log prior predictive of every row (k_fb_prior_tab), or NULL
+    int64_t *lm_rep;                // language model: [gridDim.x][K_max^2] every workgroup's own copy of the bigram counts
 };
+
+// lm.remove_counts_from_utterance / lm.counts_from_utterance (bigram_lms.py:98-114) over the transcript the boundaries define
+// (sgn -1 / +1), by wave 0 of the workgroup on ITS copy of the counts: the components of the segments in order into `lmk`, then
+// one lane per token.  As k_fbgmm_update op 5 / 6: a segment without embedding names row -1 -- python's last row, `last_asg` when
+// that row is not the utterance's --, an unassigned row component -1 -- python's last count.  The bigram counts live in global
+// memory and take atomic adds (a pair may occur twice in a transcript); the caller fences before anybody reads them.
+static __device__ void fb_chain_lm_count(const int32_t *vid_l, const uint8_t *bnd_l, int N, const int32_t *asg_l, int64_t row0, int nrows,
+                                         int64_t n_emb, int last_asg, int KM, int32_t *lmk, int64_t *lmu, int64_t *rep, long long sgn, int lane)
+{
+    const unsigned long long mask = __ballot(lane < N && bnd_l[lane] != 0);
+    const bool bit = lane < N && ((mask >> lane) & 1ull);
+    const unsigned long long below = mask & ((1ull << lane) - 1ull);
+    if (bit) {
+        const int jp = below ? 64 - __clzll((long long)below) : 0;
+        int64_t id = vid_l[(lane + 1) * lane / 2 + jp];
+        if (id < 0) id += n_emb;
+        int k = (id >= row0 && id < row0 + nrows) ? asg_l[id - row0] : last_asg;
+        if (k < 0) k += KM;
+        lmk[__popcll(below)] = k;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int n = __popcll(mask);
+    if (lane < n) {
+        const int k = lmk[lane];
+        atomicAdd((unsigned long long *)&lmu[k], (unsigned long long)sgn);
+        if (lane > 0) atomicAdd((unsigned long long *)&rep[(int64_t)lmk[lane - 1] * KM + k], (unsigned long long)sgn);
+    }
+}
 #define FBC_STAMP(slot)                                                                                                   \
     do {                                                                                                                   \
         if (A.stamp && blockIdx.x == 0 && tid == 0 && q - A.q0 < 256) A.stamp[(q - A.q0) * 8 + (slot)] = wall_clock64();  \
@@ -699,6 +729,15 @@ __global__ __launch_bounds__(512) void k_fb_chain(FbChainArgs A)
     uint8_t *bnd_l = reinterpret_cast<uint8_t *>(tok_l + NM);             // [N_max] (rounded to 16 bytes)
     double *pri_l = reinterpret_cast<double *>(bnd_l + ((NM + 15) & ~15));    // [3][D] the prior's vectors
     XT *xs_l = reinterpret_cast<XT *>(pri_l + 3 * D);                     // [max_rows][D] the utterance's rows of X
+    // language model (bigram_acoustic_wordseg.py:386-551): the unigram counts in LDS like the model, the bigram counts
+    // (K_max^2: 80 KB at K = 100) in a copy of the workgroup's own in global memory -- replicated updates again, nothing shared
+    const bool lm = A.f.lm_unigram != nullptr;
+    // (aligned on 8 bytes whatever the buffers in front add up to: the counts take 64-bit LDS atomics, which -- unlike plain
+    // loads and stores -- fault on a misaligned address)
+    int64_t *lmu = reinterpret_cast<int64_t *>((reinterpret_cast<uintptr_t>(xs_l) + (size_t)A.max_rows * D * sizeof(XT) + 7) & ~(uintptr_t)7);   // [K_max]
+    int32_t *lmk = reinterpret_cast<int32_t *>(lmu + KM);                 // [N_max]
+    int64_t *rep = lm ? A.lm_rep + (int64_t)blockIdx.x * KM * KM : nullptr;
+    __shared__ int sh_last, sh_jprev;
     __shared__ int shK, ldsK, sh_i, sh_k, sh_flag, sh_nn, sh_nspan, n_relog;
     __shared__ int32_t relog[2 * FB_RELOG];
     __shared__ long long sh_cur;
@@ -710,6 +749,13 @@ __global__ __launch_bounds__(512) void k_fb_chain(FbChainArgs A)
     segk_fbgmm fl = A.f;
     fl.stat_a = sa; fl.stat_b = sb; fl.pred = pp; fl.log_prod = lp; fl.kconst = kc; fl.counts = cn; fl.K = &ldsK;
     fl.prior_a = pri_l; fl.prior_b = pri_l + D; fl.prior_c = pri_l + 2 * D;
+    if (lm) {
+        for (int i = tid; i < KM; i += nt) lmu[i] = A.f.lm_unigram[i];
+        for (int64_t i = tid; i < (int64_t)KM * KM; i += nt) rep[i] = A.f.lm_bigram[i];
+        if (tid == 0) sh_last = A.f.assignments[c.n_emb - 1];
+        fl.lm_unigram = lmu;
+        fl.lm_bigram = rep;
+    }
     __syncthreads();
     int phase = 0;
     for (int q = A.q0; q < A.q1; q++) {
@@ -757,8 +803,15 @@ __global__ __launch_bounds__(512) void k_fb_chain(FbChainArgs A)
             }
             if (lane == 0) sh_nspan = n;
         }
-        // ---- (B) remove the utterance's old segments (unigram_acoustic_wordseg.py:270-273), replicated
+        // ---- (B) remove the utterance's old segments (unigram_acoustic_wordseg.py:270-273), replicated; with a language model
+        // the counts of its transcript first (bigram_acoustic_wordseg.py:403-404)
         FBC_STAMP(1);
+        if (lm) {
+            __syncthreads();
+            if (tid < 64) fb_chain_lm_count(vid_l, bnd_l, N, asg_l, row0, nrows, c.n_emb, sh_last, KM, lmk, lmu, rep, -1, lane);
+            __threadfence();
+            __syncthreads();
+        }
         {
             int jp = 0;
             for (int j = 0; j < N; j++) {
@@ -777,7 +830,7 @@ __global__ __launch_bounds__(512) void k_fb_chain(FbChainArgs A)
         const int nspan = sh_nspan;
         for (int s = blockIdx.x; s < nspan; s += gridDim.x) {
             const int64_t e = vid_l[spans[s]];
-            fb_logits<XT>(cl, fl, e, 0, -1, xrow, z, red, A.lprior_tab);
+            fb_logits<XT>(cl, fl, e, lm ? 3 : 0, -1, xrow, z, red, A.lprior_tab);
             double mx = NEG_INF_D;
             for (int k = tid; k < KM; k += nt) mx = z[k] > mx ? z[k] : mx;
             mx = block_max(mx, red);
@@ -809,15 +862,33 @@ __global__ __launch_bounds__(512) void k_fb_chain(FbChainArgs A)
         // ---- (E) the new segments, in order (fbgmm.py:422-494), replicated
         FBC_STAMP(5);
         const int nn = sh_nn;
+        if (tid == 0) sh_jprev = -1;
         for (int t = 0; t < nn; t++) {
             const int64_t e = tok_l[t];
             if (tid == 0) ldsK = shK;
             __syncthreads();
-            fb_logits<XT>(cl, fl, e, A.map_assign ? 2 : 1, -1, xrow, z, red, A.lprior_tab);
+            const int j_prev = sh_jprev;
+            // (with a language model: lm.log_prob_vec_i for the first segment, then given the one before, :482-494)
+            fb_logits<XT>(cl, fl, e, lm ? (j_prev < 0 ? 3 : 4) : (A.map_assign ? 2 : 1), j_prev, xrow, z, red, A.lprior_tab);
             fb_draw_component(fl, z, red, A.map_assign, A.anneal_am, A.ustream, (int64_t *)&sh_cur, A.ucap, A.status, shK, &sh_k);
             __syncthreads();
             fb_add_item<XT>(cl, fl, e, sh_k, &shK, &sh_i, red, &loc);
+            if (tid == 0) sh_jprev = sh_k;
             __syncthreads();
+        }
+        if (lm) {                                    // the counts of the new transcript (:546-547)
+            // (the row python's -1 names, as the launches see it at this point: relabelled when a component moved)
+            if (tid == 0) {
+                int v = sh_last;
+                for (int i = 0; i < n_relog && i < FB_RELOG; i++)
+                    if (v == relog[2 * i]) v = relog[2 * i + 1];
+                sh_last = v;
+            }
+            __syncthreads();
+            if (tid < 64) fb_chain_lm_count(vid_l, bnd_l, N, asg_l, row0, nrows, c.n_emb, sh_last, KM, lmk, lmu, rep, 1, lane);
+            __threadfence();
+            __syncthreads();
+            if (tid == 0 && c.n_emb - 1 >= row0 && c.n_emb - 1 < row0 + nrows) sh_last = asg_l[c.n_emb - 1 - row0];
         }
         // ---- (F) what leaves the kernel, by workgroup 0
         FBC_STAMP(6);
@@ -847,6 +918,10 @@ __global__ __launch_bounds__(512) void k_fb_chain(FbChainArgs A)
         for (int64_t i = tid; i < KD; i += nt) { A.f.stat_a[i] = sa[i]; A.f.stat_b[i] = sb[i]; A.f.pred[i] = pp[i]; }
         for (int i = tid; i < KM; i += nt) { A.f.log_prod[i] = lp[i]; A.f.kconst[i] = kc[i]; A.f.counts[i] = cn[i]; }
         if (tid == 0) { *A.f.K = shK; *A.ucursor = (int64_t)sh_cur; }
+        if (lm) {
+            for (int i = tid; i < KM; i += nt) A.f.lm_unigram[i] = lmu[i];
+            for (int64_t i = tid; i < (int64_t)KM * KM; i += nt) A.f.lm_bigram[i] = rep[i];
+        }
     }
 }
 
@@ -1194,8 +1269,8 @@ int32_t segk_fbgmm_sequential_sweep(segk_ctx *ctx, const segk_corpus *c, segk_fb
     if (n_order == 0) return SEGK_OK;
     const char *env = getenv("SEGK_FB_CHAIN");
     if (env && atoi(env) == 0) { segk_set_error("segk_fbgmm_sequential_sweep: disabled (SEGK_FB_CHAIN=0)"); return SEGK_ERR_UNSUPPORTED; }
-    if (f->lm_unigram || c->N_max > 64 || ctx->capturing) {
-        segk_set_error("segk_fbgmm_sequential_sweep: no language-model variant, at most 64 landmarks");
+    if (c->N_max > 64 || ctx->capturing) {
+        segk_set_error("segk_fbgmm_sequential_sweep: at most 64 landmarks, not under stream capture");
         return SEGK_ERR_UNSUPPORTED;
     }
     // rows of an utterance (host copy of row_start: the caller passes the device array; the extent comes from the order's
@@ -1222,7 +1297,8 @@ int32_t segk_fbgmm_sequential_sweep(segk_ctx *ctx, const segk_corpus *c, segk_fb
     const int nt = fb_nt(f);
     const size_t lds = (size_t)(3 * KD + 3 * KM + 1 + KM + nt + triMax + 3 * NM + 2 + 3 * D) * sizeof(double) + xb +
                        (size_t)(2 * triMax + max_rows + NM) * sizeof(int32_t) + (size_t)((NM + 15) & ~15) +
-                       (size_t)max_rows * D * (c->x_dtype == SEGK_F32 ? 4 : 8) + 16;
+                       (size_t)max_rows * D * (c->x_dtype == SEGK_F32 ? 4 : 8) + 16 +
+                       (f->lm_unigram ? (size_t)KM * sizeof(int64_t) + (size_t)NM * sizeof(int32_t) + 16 : 0);
     if (lds > 150 * 1024) {
         segk_set_error("segk_fbgmm_sequential_sweep: the model (%d components x %d dimensions) does not fit a workgroup's LDS", KM, D);
         return SEGK_ERR_UNSUPPORTED;
@@ -1294,6 +1370,18 @@ int32_t segk_fbgmm_sequential_sweep(segk_ctx *ctx, const segk_corpus *c, segk_fb
     {
         const int64_t spans = (int64_t)max_rows < triMax ? max_rows : triMax;
         if (spans < G) G = (int)(spans > 0 ? spans : 1);
+    }
+    A.lm_rep = nullptr;
+    if (f->lm_unigram) {                               // every workgroup's copy of the bigram counts
+        const size_t nb = (size_t)G * KM * KM * sizeof(int64_t);
+        if (ctx->fbchain_lm_bytes < nb) {
+            if (ctx->fbchain_lm) (void)hipFree(ctx->fbchain_lm);
+            ctx->fbchain_lm = nullptr;
+            ctx->fbchain_lm_bytes = 0;
+            SEGK_CHECK_HIP(hipMalloc(&ctx->fbchain_lm, nb));
+            ctx->fbchain_lm_bytes = nb;
+        }
+        A.lm_rep = (int64_t *)ctx->fbchain_lm;
     }
     int q = 0;
     while (q < n_order) {

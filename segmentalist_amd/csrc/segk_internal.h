@@ -39,6 +39,8 @@ struct segk_ctx {
     double fb_ptab_k0, fb_ptab_v0;
     void *fbchain_buf;            // persistent FBGMM chain (segk_fbgmm.hip k_fb_chain): control words, the sweep's utterance order
     size_t fbchain_bytes;
+    void *fbchain_lm;             // ... with a language model: the workgroups' copies of the bigram counts
+    size_t fbchain_lm_bytes;
     // batch sampler: the block's tokens bucketed by slot (k_fbb_sort) + offsets
     int32_t *fbs_buf;
     size_t fbs_bytes;

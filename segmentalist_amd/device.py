@@ -870,10 +870,11 @@ class DeviceFbgmm(object):
     def sequential_sweep(self, boundaries, order, row_start, viterbi, n_slices_min, n_slices_max, wip, time_power_term,
                          log_p_continue, anneal_temp_fb, anneal_temp_am, map_assign=None):
         """gibbs_utt for every utterance of `order` in turn by ONE library call (segk_fbgmm_sequential_sweep: a persistent
-        kernel per stretch of utterances between two emptied components; the call synchronises the stream).  Returns False,
-        with nothing enqueued, where the kernel does not apply (a language model, a model too large for a workgroup's LDS,
-        ...): the caller then walks the utterances itself."""
-        if self.lm is not None or self.corpus.N_max > 64:
+        kernel per stretch of utterances between two emptied components; the call synchronises the stream; with a language
+        model attached the bigram sampler's gibbs_sample_i, bigram_acoustic_wordseg.py:386-551).  Returns False, with nothing
+        enqueued, where the kernel does not apply (a model too large for a workgroup's LDS, ...): the caller then walks the
+        utterances itself."""
+        if self.corpus.N_max > 64:
             return False
         if getattr(self, "_row_start_dev", None) is None:
             self._row_start_dev = to_dev(np.asarray(row_start, dtype=np.int32))

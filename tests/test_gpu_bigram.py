@@ -168,3 +168,37 @@ def test_reference_test_bigram_lms_on_device_counts(gpu):
         npt.assert_almost_equal(lm.log_prob_vec_given_j(3)[i], np.log(lm.prob_i_given_j(i, 3)))
     lm.remove_counts_from_utterance([3, 3, 1])
     assert lm.unigram_counts.sum() == 15 and lm.bigram_counts[3, 3] == 0
+
+
+def test_persistent_chain_with_a_language_model_equals_the_launches_per_utterance(gpu, monkeypatch):
+    """segk_fbgmm_sequential_sweep with a language model attached (every workgroup replays the updates on its own copy of
+    the bigram counts) against the six launches per utterance (SEGK_FB_CHAIN=0) from identical states: boundaries,
+    assignments, statistics, both count tables, K, the record values and the position of the RNG stream bit for bit, over
+    sweeps in which components empty (their rows and columns of the bigram table move)."""
+    from segmentalist_amd import bigram_acoustic_wordseg as baw
+    from segmentalist_amd.gaussian_components_fixedvar import FixedVarPrior
+    from segmentalist_amd.synth import make_corpus
+    D, K = 12, 30
+    corpus = make_corpus(60, D, K, seed=4, ragged=True, n_slices_max=5, N_range=(3, 14))
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SEGK_FB_CHAIN", mode)
+        random.seed(3)
+        np.random.seed(3)
+        seg = baw.BigramAcousticWordseg(K, FixedVarPrior(0.002 * np.ones(D), np.zeros(D), 0.002 / 0.05 * np.ones(D)),
+                                        dict(cases.BIGRAM_LM), *corpus, covariance_type="fixed", fb_type="unigram",
+                                        n_slices_min=0, n_slices_max=5, p_boundary_init=0.5, beta_sent_boundary=-1, lms=0.8,
+                                        wip=-0.1, init_am_assignments="rand", time_power_term=1.0)
+        rec = seg.gibbs_sample(4, anneal_schedule="linear", anneal_gibbs_am=True)
+        df = seg._df
+        out[mode] = dict(b=seg.utterances.boundaries.copy(), a=seg.acoustic_model.components.assignments.copy(),
+                         sa=df.stat_a.cpu().numpy(), sb=df.stat_b.cpu().numpy(), pr=df.pred.cpu().numpy(),
+                         cn=df.counts.cpu().numpy(), uni=np.array(seg.lm.unigram_counts), big=np.array(seg.lm.bigram_counts),
+                         K=int(df.K.item()), rec={k: list(v) for k, v in rec.items() if k != "sample_time"}, rnd=random.random())
+    assert min(out["1"]["rec"]["components"]) < K, "no component emptied: the test does not cover the relaunches"
+    assert out["1"]["big"].sum() > 0
+    for k in out["1"]:
+        if isinstance(out["1"][k], np.ndarray):
+            assert np.array_equal(out["1"][k], out["0"][k]), k
+        else:
+            assert out["1"][k] == out["0"][k], k
