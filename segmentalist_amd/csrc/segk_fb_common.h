@@ -72,6 +72,36 @@ static __device__ __forceinline__ double fb_wave_sum(double v)
     return (r0 + r1) + (r2 + r3);
 }
 
+// float32 maximum / sum over the 64 lanes, wave-uniform: rows of sixteen by DPP, the four rows by v_readlane (a __shfl_xor
+// butterfly is six ds_bpermute round trips: 96 of them per thread were 5 us of k_fbb_score_diag32's 30)
+template <int CTRL>
+static __device__ __forceinline__ float fb_dpp_f32(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+static __device__ __forceinline__ float fb_wave_max_f32(float v)
+{
+    v = fmaxf(v, fb_dpp_f32<0xB1>(v));
+    v = fmaxf(v, fb_dpp_f32<0x4E>(v));
+    v = fmaxf(v, fb_dpp_f32<0x141>(v));
+    v = fmaxf(v, fb_dpp_f32<0x140>(v));
+    const int i = __float_as_int(v);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(i, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(i, 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(i, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(i, 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+static __device__ __forceinline__ float fb_wave_sum_f32(float v)
+{
+    v += fb_dpp_f32<0xB1>(v);
+    v += fb_dpp_f32<0x4E>(v);
+    v += fb_dpp_f32<0x141>(v);
+    v += fb_dpp_f32<0x140>(v);
+    const int i = __float_as_int(v);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(i, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(i, 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(i, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(i, 48));
+    return (r0 + r1) + (r2 + r3);
+}
+
 // inclusive prefix sum over the 64 lanes (lane l: v_0 + ... + v_l): inside the rows of sixteen by DPP row shifts (the lanes
 // a shift leaves without a source add zero), then the totals of the rows before by v_readlane
 template <int CTRL>

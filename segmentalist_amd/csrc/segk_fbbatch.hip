@@ -641,7 +641,7 @@ __global__ __launch_bounds__(256) void k_fbb_score(segk_corpus c, segk_fbgmm f, 
 // round trip, which is where the first version of this kernel spent its time (9 % of what the ALUs sustain on the term).
 template <typename XT, int RPG, bool TLDS>
 __global__ __launch_bounds__(256) void k_fbb_score_diag32(segk_corpus c, segk_fbgmm f, segk_fbatch bt, FbbMap map, int b,
-                                                          double prior_alpha, double *score)
+                                                          double prior_alpha, double *score, int dbg)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NG = FBB_R32 / RPG;            // thread groups
@@ -650,21 +650,27 @@ __global__ __launch_bounds__(256) void k_fbb_score_diag32(segk_corpus c, segk_fb
     double *lpr = xs64 + 8 * D;                  // [R32]
     float *wm = (float *)(lpr + FBB_R32);        // [4 waves][R32] the waves' maxima
     float *ws = wm + 4 * FBB_R32;                // [4 waves][R32] and sums
-    float *xs = ws + 4 * FBB_R32;                // [R32][D]
+    float *xs = ws + 4 * FBB_R32;                // [D][R32]: the rows of a thread at one dimension are consecutive
     float *tm = xs + FBB_R32 * D;                // [D][KM] (TLDS)
     float *tq = tm + (TLDS ? D * KM : 0);        // [D][KM]
     int s, idx;
     if (!fbb_locate(map, blockIdx.x, &s, &idx)) return;
     const int slice = map.lo[s];
+    if (dbg & 32) return;
+    // (the workgroup is a chain of dependent round trips -- 15 of its 30 us with the table fill and the terms switched off: what
+    // does not depend on another load is requested here, together with the first one)
+    const int gsz = nt / NG, kk = tid % gsz, r0 = (tid / gsz) * RPG;       // this thread's slots kk, kk + gsz, ...; rows r0 .. r0 + RPG
+    const int k_first = kk < KM ? kk : 0;
+    const double cnt_first = bt.cnt[k_first], zc_first = bt.zconst[k_first], half_first = bt.half[k_first], total = bt.scal[0];
     const int64_t r_lo = bt.row_range[(slice * bt.n_blocks + b) * 2], r_hi = bt.row_range[(slice * bt.n_blocks + b) * 2 + 1];
     const int64_t row0 = r_lo + (int64_t)idx * FBB_R32;
     const int nr = (int)((r_hi - row0) < FBB_R32 ? (r_hi - row0) : FBB_R32);
     const XT *X = (const XT *)c.X;
     for (int j = tid; j < FBB_R32 * D; j += nt) {
         const int r = j / D, d = j - r * D;
-        xs[j] = r < nr ? (float)X[(row0 + r) * c.ldx + d] : 0.f;
+        xs[d * FBB_R32 + r] = r < nr ? (float)X[(row0 + r) * c.ldx + d] : 0.f;
     }
-    if (TLDS)
+    if (TLDS && !(dbg & 1))                       // (dbg, make DEV=1 only: 1 no table fill, 2 no terms, 4 no reductions -- timing)
         for (int j = tid; j < D * KM; j += nt) {
             tm[j] = (float)bt.mean_t[j];
             tq[j] = (float)bt.q_t[j];
@@ -689,19 +695,39 @@ __global__ __launch_bounds__(256) void k_fbb_score_diag32(segk_corpus c, segk_fb
         }
     }
     __syncthreads();
-    const double zc_empty = f.lms * log(prior_alpha / (double)KM);
-    const int gsz = nt / NG, kk = tid % gsz, r0 = (tid / gsz) * RPG;       // this thread's slots kk, kk + gsz, ...; rows r0 .. r0 + RPG
-    const float *xg = xs + r0 * D;
+    if (dbg & 16) return;
+    // (v_log_f32 for the two constants as for the terms: ~1e-7 relative, two fp64 library logarithms were 2 us of every workgroup)
+    const double zc_empty = f.lms * fb_log_fast(prior_alpha / (double)KM);
+    const double norm = f.lms * fb_log_fast(total + prior_alpha);
+    // The term log2(1 + (m - x)^2 q) on PAIRS of rows: subtract, multiply, multiply-add and the accumulation as packed float32
+    // operations (v_pk_*_f32: two rows per instruction), the logarithm per row -- three vector instructions per term instead of
+    // five, and one 16-byte LDS read for four rows
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+    static_assert(RPG % 4 == 0, "rows per thread in fours");
+    const float *xg = xs + r0;
     float mx[RPG], sm[RPG];                      // running maximum and sum of 2^(z log2 e - mx)
 #pragma unroll
     for (int r = 0; r < RPG; r++) { mx[r] = -3.0e38f; sm[r] = 0.f; }
     for (int k = kk; k < KM; k += gsz) {
         float z2[RPG];
-        if (bt.cnt[k] > 0.0) {
-            float acc[RPG];
+        if ((k == kk ? cnt_first : bt.cnt[k]) > 0.0) {
+            f32x2_t acc2[RPG / 2];
 #pragma unroll
-            for (int r = 0; r < RPG; r++) acc[r] = 0.f;
-            int d = 0;
+            for (int r = 0; r < RPG / 2; r++) acc2[r] = (f32x2_t){0.f, 0.f};
+            const f32x2_t one2 = {1.f, 1.f};
+            auto term = [&](int d, float m, float q) {
+                const f32x2_t m2 = {m, m}, q2 = {q, q};
+#pragma unroll
+                for (int r4 = 0; r4 < RPG / 4; r4++) {
+                    const f32x4_t xv = *reinterpret_cast<const f32x4_t *>(xg + d * FBB_R32 + 4 * r4);
+                    const f32x2_t d0 = m2 - xv.xy, d1 = m2 - xv.zw;
+                    const f32x2_t u0 = __builtin_elementwise_fma(d0 * d0, q2, one2), u1 = __builtin_elementwise_fma(d1 * d1, q2, one2);
+                    acc2[2 * r4] += (f32x2_t){__builtin_amdgcn_logf(u0.x), __builtin_amdgcn_logf(u0.y)};       // v_log_f32: log2
+                    acc2[2 * r4 + 1] += (f32x2_t){__builtin_amdgcn_logf(u1.x), __builtin_amdgcn_logf(u1.y)};
+                }
+            };
+            int d = (dbg & 2) ? D : 0;
             for (; d + 4 <= D; d += 4) {
                 float m[4], q[4];
 #pragma unroll
@@ -710,25 +736,13 @@ __global__ __launch_bounds__(256) void k_fbb_score_diag32(segk_corpus c, segk_fb
                     q[j] = TLDS ? tq[(d + j) * KM + k] : (float)bt.q_t[(int64_t)(d + j) * KM + k];
                 }
 #pragma unroll
-                for (int j = 0; j < 4; j++)
-#pragma unroll
-                    for (int r = 0; r < RPG; r++) {
-                        const float delta = m[j] - xg[r * D + d + j];
-                        acc[r] += __builtin_amdgcn_logf(1.f + (delta * delta) * q[j]);       // v_log_f32: log2
-                    }
+                for (int j = 0; j < 4; j++) term(d + j, m[j], q[j]);
             }
-            for (; d < D; d++) {
-                const float m = TLDS ? tm[d * KM + k] : (float)bt.mean_t[(int64_t)d * KM + k];
-                const float q = TLDS ? tq[d * KM + k] : (float)bt.q_t[(int64_t)d * KM + k];
+            for (; d < D; d++)
+                term(d, TLDS ? tm[d * KM + k] : (float)bt.mean_t[(int64_t)d * KM + k], TLDS ? tq[d * KM + k] : (float)bt.q_t[(int64_t)d * KM + k]);
+            const double zc = k == kk ? zc_first : bt.zconst[k], hl = (k == kk ? half_first : bt.half[k]) * 0.6931471805599453;
 #pragma unroll
-                for (int r = 0; r < RPG; r++) {
-                    const float delta = m - xg[r * D + d];
-                    acc[r] += __builtin_amdgcn_logf(1.f + (delta * delta) * q);
-                }
-            }
-            const double zc = bt.zconst[k], hl = bt.half[k] * 0.6931471805599453;
-#pragma unroll
-            for (int r = 0; r < RPG; r++) z2[r] = (float)((zc - hl * (double)acc[r]) * 1.4426950408889634);
+            for (int r = 0; r < RPG; r++) z2[r] = (float)((zc - hl * (double)acc2[r >> 1][r & 1]) * 1.4426950408889634);
         } else {
 #pragma unroll
             for (int r = 0; r < RPG; r++) z2[r] = (float)((zc_empty + lpr[r0 + r]) * 1.4426950408889634);
@@ -742,14 +756,13 @@ __global__ __launch_bounds__(256) void k_fbb_score_diag32(segk_corpus c, segk_fb
     }
     // per row: the waves' (maximum, sum) by shuffles, then the four waves' by the row's thread -- one barrier for all rows
     // (a block-wide maximum and a block-wide sum per row were 32 double barriers)
-    {
+    if (dbg & 8) return;
+    if (!(dbg & 4)) {
         const int w = tid >> 6, lane = tid & 63;
 #pragma unroll
         for (int r = 0; r < RPG; r++) {
-            float M = mx[r];
-            for (int o = 32; o > 0; o >>= 1) M = fmaxf(M, __shfl_xor(M, o));
-            float S = sm[r] == 0.f ? 0.f : sm[r] * __builtin_amdgcn_exp2f(mx[r] - M);
-            for (int o = 32; o > 0; o >>= 1) S += __shfl_xor(S, o);
+            const float M = fb_wave_max_f32(mx[r]);
+            const float S = fb_wave_sum_f32(sm[r] == 0.f ? 0.f : sm[r] * __builtin_amdgcn_exp2f(mx[r] - M));
             // (with two thread groups a wave lies inside one group: 128 threads each)
             if (lane == 0) { wm[w * FBB_R32 + r0 + r] = M; ws[w * FBB_R32 + r0 + r] = S; }
         }
@@ -760,12 +773,12 @@ __global__ __launch_bounds__(256) void k_fbb_score_diag32(segk_corpus c, segk_fb
     }
     __syncthreads();
     if (tid < nr) {
-        const double norm = f.lms * log(bt.scal[0] + prior_alpha);
         float M = wm[tid];
         for (int w = 1; w < 4; w++) M = fmaxf(M, wm[w * FBB_R32 + tid]);
-        double S = 0.0;
-        for (int w = 0; w < 4; w++) S += ws[w * FBB_R32 + tid] == 0.f ? 0.0 : (double)ws[w * FBB_R32 + tid] * exp2((double)wm[w * FBB_R32 + tid] - (double)M);
-        score[row0 + tid] = (log2(S) + (double)M) * 0.6931471805599453 - norm;
+        // (hardware exp2 / log2 like the terms above: the fp64 library calls were a dependent chain of ~2.5 us on sixteen lanes)
+        float S = 0.f;
+        for (int w = 0; w < 4; w++) S += ws[w * FBB_R32 + tid] == 0.f ? 0.f : ws[w * FBB_R32 + tid] * __builtin_amdgcn_exp2f(wm[w * FBB_R32 + tid] - M);
+        score[row0 + tid] = ((double)__builtin_amdgcn_logf(S) + (double)M) * 0.6931471805599453 - norm;
     }
 }
 
@@ -1845,6 +1858,7 @@ int32_t segk_fbb_score_diag32(segk_ctx *ctx, const segk_corpus *c, const segk_fb
     const bool tlds = lds0 + tbl <= 60 * 1024;                // two workgroups per CU keep their tables
     const bool two_groups = f->K_max <= 128;
     const size_t lds = lds0 + (tlds ? tbl : 0);
+    const int d32dbg = segk_dev_env("SEGK_D32_DBG");          // make DEV=1 builds only (timing ablations, results wrong)
     hipStream_t st = (hipStream_t)stream;
     const bool prof = ctx && segk_prof_now(ctx);
     const int slot = prof ? ctx->prof_n % SEGK_PROF_SLOTS : 0;
@@ -1856,10 +1870,10 @@ int32_t segk_fbb_score_diag32(segk_ctx *ctx, const segk_corpus *c, const segk_fb
             SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_fbb_score_diag32<XT, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             SEGK_CHECK_HIP(hipFuncSetAttribute((const void *)k_fbb_score_diag32<XT, 16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         }
-        if (tlds && two_groups) hipLaunchKernelGGL((k_fbb_score_diag32<XT, 8, true>), dim3(m.off[s_n]), dim3(256), lds, st, *c, *f, *bt, m, b, alpha, score);
-        else if (tlds) hipLaunchKernelGGL((k_fbb_score_diag32<XT, 16, true>), dim3(m.off[s_n]), dim3(256), lds, st, *c, *f, *bt, m, b, alpha, score);
-        else if (two_groups) hipLaunchKernelGGL((k_fbb_score_diag32<XT, 8, false>), dim3(m.off[s_n]), dim3(256), lds, st, *c, *f, *bt, m, b, alpha, score);
-        else hipLaunchKernelGGL((k_fbb_score_diag32<XT, 16, false>), dim3(m.off[s_n]), dim3(256), lds, st, *c, *f, *bt, m, b, alpha, score);
+        if (tlds && two_groups) hipLaunchKernelGGL((k_fbb_score_diag32<XT, 8, true>), dim3(m.off[s_n]), dim3(256), lds, st, *c, *f, *bt, m, b, alpha, score, d32dbg);
+        else if (tlds) hipLaunchKernelGGL((k_fbb_score_diag32<XT, 16, true>), dim3(m.off[s_n]), dim3(256), lds, st, *c, *f, *bt, m, b, alpha, score, d32dbg);
+        else if (two_groups) hipLaunchKernelGGL((k_fbb_score_diag32<XT, 8, false>), dim3(m.off[s_n]), dim3(256), lds, st, *c, *f, *bt, m, b, alpha, score, d32dbg);
+        else hipLaunchKernelGGL((k_fbb_score_diag32<XT, 16, false>), dim3(m.off[s_n]), dim3(256), lds, st, *c, *f, *bt, m, b, alpha, score, d32dbg);
     });
     if (prof) {
         SEGK_CHECK_HIP(hipEventRecord(ctx->prof_ev[slot][1], st));
