@@ -669,9 +669,9 @@ __global__ __launch_bounds__(SEGK_MERGE_THREADS) void k_hint_merge(ScoreArgs A, 
     const float unscale = ldexpf(1.f, -e_ab), scale = ldexpf(1.f, e_ab);
     const float M = (float)(sqrt(*A.mnorm2) * (1.0 + 1e-6)) + 1e-30f;
     const float Em = H.tiles_hdr[1];
-    // four rows per thread and trip, their loads in flight together (one row per trip was four dependent round trips per
-    // workgroup: 25 us for 55 MB)
-    constexpr int U = 4;
+    // five rows per thread and trip, their loads in flight together (one row per trip was four dependent round trips per
+    // workgroup: 25 us for 55 MB; with four the headline corpus -- 4 102 rows per workgroup -- took a second trip for six rows)
+    constexpr int U = 5;
     for (int64_t p0 = p_lo; p0 < p_hi; p0 += SEGK_MERGE_THREADS * U) {
         int32_t rid[U];
         float4 ho[U];
