@@ -49,8 +49,11 @@ const char *segk_last_error(void);
  *   4 round 3: scratch sizes of segk_kmeans_batch_partials from segk_kmeans_batch_scratch_words; segk_profile_enable(N)
  *   5 round 3: segk_fbatch.prior_rows, segk_fbb_prior_rows
  *   6 round 4: segk_kmeans_hint_feedback; flag_rows / flag_row_bytes of the batch statistics (sharded corpus);
- *              segk_fbgmm_sequential_sweep                                                                                     */
-#define SEGK_ABI_VERSION 6
+ *              segk_fbgmm_sequential_sweep
+ *   7 round 4: segk_fbatch.consts16 holds 2 (K_max + 2) + 32 doubles (the column maps of the packed operand image behind the
+ *              constants) and the token-likelihood matrix has the image's columns; the FBGMM / bigram kernels read
+ *              segk_corpus.band_ids / band_dur (a COMPLETE band only); segk_fbgmm_sequential_sweep with a language model         */
+#define SEGK_ABI_VERSION 7
 int32_t segk_abi_version(void);
 
 /* Timing of the MAIN launch of the MFMA score kernel (k_kmeans_score<..., 0>) with HIP events

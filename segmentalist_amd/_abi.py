@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("SEGK_LIB_PATH") or os.path.join(_HERE, "libsegk.so") 
 
 SEGK_F32, SEGK_F64 = 0, 1
 SEGK_ERR_UNSUPPORTED = -4          # include/segk.h
-ABI_VERSION = 6          # SEGK_ABI_VERSION of include/segk.h this binding was written against
+ABI_VERSION = 7          # SEGK_ABI_VERSION of include/segk.h this binding was written against
 
 
 class SegkError(RuntimeError):
