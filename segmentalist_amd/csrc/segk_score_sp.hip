@@ -38,6 +38,7 @@
 // n_chunks-th of the 32 dependent tile steps (~1.7 us each) a workgroup otherwise walks alone.  Partial candidates go
 // to part_f ([row block][split][row]: top1, top2, component); the workgroup that arrives last at the block's ticket
 // (part_k) merges them and runs the epilogue, and clears the ticket for the next call.
+#define SEGK_LSE_CHUNK 2            /* tiles per chunk of the log-sum-exp mode's association (see SEGK_LSE_CLOSE) */
 template <int KS, int WAVES, int P, int MODE = 0, int SPLIT = 0>
 __global__ __launch_bounds__(64 * WAVES, 2) void k_kmeans_score_sp(ScoreArgs A)
 {
@@ -97,6 +98,22 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_kmeans_score_sp(ScoreArgs A)
     // (finite start) and sum, as in k_kmeans_score
     float m1 = MODE == 1 ? -3.0e38f : NEG_INF_F, m2 = MODE == 1 ? 0.f : NEG_INF_F;
     int32_t irow = 0, itile = 0;
+    // MODE 1: the log-sum-exp is associated in CHUNKS of SEGK_LSE_CHUNK tiles whoever computes them -- (maximum, sum) of a
+    // chunk per lane half in tile order, the two halves merged, the chunks folded in order into (RM, RS) -- so that the rows
+    // behind the last whole round of workgroups can be split over the tiles (SPLIT = 1: one chunk per workgroup, the last to
+    // arrive folds them) and still give the bits of a row that one wave walked alone
+    float RM = -3.0e38f, RS = 0.f;
+#define SEGK_LSE_CLOSE()                                                                                        \
+    do {                                                                                                        \
+        const float om_ = __shfl_xor(m1, 32), os_ = __shfl_xor(m2, 32);                                         \
+        const float Mc_ = fmaxf(m1, om_);                                                                       \
+        const float Sc_ = m2 * __builtin_amdgcn_exp2f(m1 - Mc_) + os_ * __builtin_amdgcn_exp2f(om_ - Mc_);      \
+        const float Mn_ = fmaxf(RM, Mc_);                                                                       \
+        RS = RS * __builtin_amdgcn_exp2f(RM - Mn_) + Sc_ * __builtin_amdgcn_exp2f(Mc_ - Mn_);                   \
+        RM = Mn_;                                                                                               \
+        m1 = -3.0e38f;                                                                                          \
+        m2 = 0.f;                                                                                               \
+    } while (0)
 
     constexpr int PASS = WAVES * 256;
     constexpr int NPASS = (STRIDE + PASS - 1) / PASS;
@@ -199,6 +216,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_kmeans_score_sp(ScoreArgs A)
                 if (s * VPS + q < 16) SEGK_DRAIN(OLDM, OLDL, s * VPS + q);                            \
         }                                                                                             \
         itile = (m1 > m1s) ? ((t_) - 1) : itile;                                                      \
+        if constexpr (MODE == 1)            /* tile t_ - 1 (global number tile0 + t_ - 1) closed a chunk */          \
+            if ((t_) >= 1 && ((tile0 + (t_)) % SEGK_LSE_CHUNK) == 0) SEGK_LSE_CLOSE();                \
         SEGK_TILE_SYNC();                                                                             \
     } while (0)
 
@@ -228,11 +247,35 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_kmeans_score_sp(ScoreArgs A)
 #undef SEGK_TILE_SYNC
     if constexpr (MODE == 2) continue;
     if constexpr (MODE == 1) {
-        // the two lane halves summed disjoint component subsets of the same row
-        const float om = __shfl_xor(m1, 32), os = __shfl_xor(m2, 32);
-        const float M = fmaxf(m1, om);
-        const float S = m2 * exp2f(m1 - M) + os * exp2f(om - M);
-        if (h == 0 && rowid >= 0) A.lse_out[rowid] = (double)(M + log2f(S)) * 0.6931471805599453 - A.lse_norm;
+        SEGK_LSE_CLOSE();                      // the last chunk (the two lane halves summed disjoint components of the same row)
+        if constexpr (SPLIT) {
+            // one chunk per workgroup: (maximum, sum) per row to part_f; the last to arrive folds the chunks in order
+            __shared__ int s_last1;
+            const int S_dev = (nt_all + A.tiles_per_split - 1) / A.tiles_per_split;
+            float *part = A.part_f + ((int64_t)rblock * A.n_chunks * (WAVES * 32) + wave * 32 + j) * 2;
+            if (h == 0) {
+                float *pp = part + (int64_t)split * (WAVES * 32 * 2);
+                __hip_atomic_store(pp + 0, RM, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(pp + 1, RS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) s_last1 = __hip_atomic_fetch_add(A.part_k + rblock, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == S_dev - 1;
+            __syncthreads();
+            if (!s_last1) continue;
+            if (tid == 0) __hip_atomic_store(A.part_k + rblock, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            RM = -3.0e38f;
+            RS = 0.f;
+            for (int sp = 0; sp < S_dev; sp++) {
+                const float *pp = part + (int64_t)sp * (WAVES * 32 * 2);
+                const float Mc = __hip_atomic_load(pp + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const float Sc = __hip_atomic_load(pp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const float Mn = fmaxf(RM, Mc);
+                RS = RS * __builtin_amdgcn_exp2f(RM - Mn) + Sc * __builtin_amdgcn_exp2f(Mc - Mn);
+                RM = Mn;
+            }
+        }
+        if (h == 0 && rowid >= 0) A.lse_out[rowid] = (double)(RM + log2f(RS)) * 0.6931471805599453 - A.lse_norm;
         continue;
     }
     const int32_t i1 = (itile + tile0) * 32 + 4 * h + (irow & 3) + 8 * (irow >> 2);
@@ -298,6 +341,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_kmeans_score_sp(ScoreArgs A)
     }
     }   // row blocks of this workgroup
 }
+#undef SEGK_LSE_CLOSE
 
 // split-precision filter: whole rounds (and any larger remainder) to k_kmeans_score_sp, a remainder of
 // fewer than SEGK_TAIL_QUEUE rows to the ambiguity queue.
@@ -365,10 +409,50 @@ static int launch_score_lse_sp(segk_ctx *ctx, const ScoreArgs &A, hipStream_t st
     constexpr int STRIDE = (KS * 2 * 256 + 32 + 1023) / 1024 * 1024;
     const size_t lds = 2 * (size_t)STRIDE * sizeof(float);
     SEGK_CHECK_HIP(segk_dyn_lds((const void *)k_kmeans_score_sp<KS, 4, 2, 1>, lds));
+    SEGK_CHECK_HIP(segk_dyn_lds((const void *)k_kmeans_score_sp<KS, 4, 2, 1, 1>, lds));
     const int64_t chunks = (A.n + 127) / 128;
     const bool prof = ctx && segk_prof_now(ctx);
     const int slot = prof ? ctx->prof_n % SEGK_PROF_SLOTS : 0;
+    // The row blocks behind the last whole round of workgroups (configs[4]: 1 024 blocks on 512 slots in six of the eight Gibbs
+    // steps, 1 031 in the other two -- seven blocks would hold a third round of 38 us alone) go first, split over the tiles: one
+    // chunk of SEGK_LSE_CHUNK tiles per workgroup, 11 us for all of them; the association of a row's sum is the same either way
+    // (SEGK_LSE_CLOSE)
+    int64_t rem = 0;
+    if (ctx && ctx->n_cu > 0) {
+        int wg_per_cu = 1;
+        SEGK_CHECK_HIP(segk_occupancy((const void *)k_kmeans_score_sp<KS, 4, 2, 1>, 256, lds, &wg_per_cu));
+        const int64_t slots = (int64_t)wg_per_cu * ctx->n_cu;
+        const int64_t whole = (chunks / slots) * slots;
+        if (whole > 0 && chunks - whole > 0 && chunks - whole <= slots / 8 && !ctx->capturing) rem = chunks - whole;
+        const char *e = getenv("SEGK_LSE_SPLIT");               // 0: every row block by a workgroup of its own (same bits, the tests compare)
+        if (e && atoi(e) == 0) rem = 0;
+    }
+    if (rem > 0 && ctx->sp2_blocks < rem) {
+        if (ctx->sp2_part) (void)hipFree(ctx->sp2_part);
+        if (ctx->sp2_ticket) (void)hipFree(ctx->sp2_ticket);
+        ctx->sp2_part = nullptr; ctx->sp2_ticket = nullptr; ctx->sp2_blocks = 0;
+        const int64_t blocks = rem > 64 ? rem : 64;
+        SEGK_CHECK_HIP(hipMalloc((void **)&ctx->sp2_part, (size_t)blocks * 8 * 128 * 4 * sizeof(float)));
+        SEGK_CHECK_HIP(hipMalloc((void **)&ctx->sp2_ticket, (size_t)blocks * sizeof(int32_t)));
+        SEGK_CHECK_HIP(hipMemsetAsync(ctx->sp2_ticket, 0, (size_t)blocks * sizeof(int32_t), st));
+        ctx->sp2_blocks = blocks;
+    }
     if (prof) SEGK_CHECK_HIP(hipEventRecord(ctx->prof_ev[slot][0], st));
+    if (rem > 0) {
+        const int64_t n_main = (chunks - rem) * 128;
+        ScoreArgs S = A;
+        S.n = A.n - n_main;
+        S.row0 = A.row0 + n_main;
+        S.ids = A.ids ? A.ids + n_main : nullptr;
+        S.tiles_per_split = SEGK_LSE_CHUNK;
+        S.n_chunks = (A.n_tiles + SEGK_LSE_CHUNK - 1) / SEGK_LSE_CHUNK;         // 16 at most (32 tiles): 32 floats per row of part_f
+        S.part_f = ctx->sp2_part;
+        S.part_k = ctx->sp2_ticket;
+        hipLaunchKernelGGL((k_kmeans_score_sp<KS, 4, 2, 1, 1>), dim3((unsigned)(rem * S.n_chunks)), dim3(256), lds, st, S);
+        ScoreArgs M = A;
+        M.n = n_main;
+        hipLaunchKernelGGL((k_kmeans_score_sp<KS, 4, 2, 1>), dim3((unsigned)(chunks - rem)), dim3(256), lds, st, M);
+    } else
     hipLaunchKernelGGL((k_kmeans_score_sp<KS, 4, 2, 1>), dim3((unsigned)chunks), dim3(256), lds, st, A);
     if (prof) {
         SEGK_CHECK_HIP(hipEventRecord(ctx->prof_ev[slot][1], st));

@@ -152,3 +152,23 @@ def test_config5_full_size_span_scores_against_the_specification(gpu, prec, tol)
         worst = max(worst, abs(score[row] - want) / max(abs(want), 1.0))
     print("configs[4] full size, %s span scores: worst error relative to max(|log_marg_i|, 1) = %.3g" % (prec, worst))
     assert worst < tol, worst
+
+
+def test_config5_split_remainder_rows_give_the_bits_of_whole_row_blocks(gpu, monkeypatch):
+    """The log-sum-exp span score (k_kmeans_score_sp, MODE 1) sends the row blocks behind the last whole round of workgroups
+    -- two of 1 026 per Gibbs step at configs[4] -- through workgroups that take one chunk of tiles each; the association of
+    a row's sum is the same either way, so a sweep must leave the same scores, boundaries and slots bit for bit as with
+    SEGK_LSE_SPLIT=0 (every row block walked by one workgroup)."""
+    out = []
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SEGK_LSE_SPLIT", mode)
+        seg = _build("bigram", 10000, 100, 1000, "batch", n_gibbs_blocks=8, n_stat_blocks=8, batch_seed=1, score_precision="f16")
+        for _ in range(2):
+            seg.batch_sweep_async()
+        gpu.cuda.synchronize()
+        seg._df.check_status()
+        sw = seg._get_sweeper()
+        out.append((seg._df.score.cpu().numpy().copy(), seg._dev_bounds.cpu().numpy().copy(), sw.slot.cpu().numpy().copy()))
+    assert np.all(np.isfinite(out[0][0]))
+    for a, b in zip(out[0], out[1]):
+        assert np.array_equal(a, b)
