@@ -38,9 +38,12 @@
 // n_chunks-th of the 32 dependent tile steps (~1.7 us each) a workgroup otherwise walks alone.  Partial candidates go
 // to part_f ([row block][split][row]: top1, top2, component); the workgroup that arrives last at the block's ticket
 // (part_k) merges them and runs the epilogue, and clears the ticket for the next call.
+#ifndef SEGK_LSE_WAVES
+#define SEGK_LSE_WAVES 4
+#endif
 #define SEGK_LSE_CHUNK 2            /* tiles per chunk of the log-sum-exp mode's association (see SEGK_LSE_CLOSE) */
 template <int KS, int WAVES, int P, int MODE = 0, int SPLIT = 0>
-__global__ __launch_bounds__(64 * WAVES, 2) void k_kmeans_score_sp(ScoreArgs A)
+__global__ __launch_bounds__(64 * WAVES, WAVES >= 8 ? 1 : 2) void k_kmeans_score_sp(ScoreArgs A)
 {
     typedef typename SegkPiece<P>::T T;
     typedef typename SegkPiece<P>::V8 V8;
@@ -165,10 +168,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_kmeans_score_sp(ScoreArgs A)
                 *reinterpret_cast<float4 *>(A.mat_out + r * A.mat_ld + (dtile + tile0) * 32 + 4 * h + 8 * ((vi) >> 2)) = \
                     make_float4(st4[0], st4[1], st4[2], st4[3]);                      \
         } else if constexpr (MODE == 1) {                                                    \
-            v_ = fmaxf(v_ * unscale, -3.0e38f);                                       \
-            const float nm_ = vmax_f32(m1, v_);                                       \
-            m2 = m2 * __builtin_amdgcn_exp2f(m1 - nm_) + __builtin_amdgcn_exp2f(v_ - nm_); \
-            m1 = nm_;                                                                 \
+            (void)v_;                  /* the tile's maximum is in m1 already (SEGK_LSE_PREP): one exponential per value */ \
+            m2 += __builtin_amdgcn_exp2f(vv_[(vi)] - m1);                             \
         } else                                                                        \
         asm volatile("v_cmp_ngt_f32 vcc, %3, %0\n\t"                                  \
                      "v_med3_f32 %1, %0, %1, %3\n\t"                                  \
@@ -179,8 +180,23 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_kmeans_score_sp(ScoreArgs A)
                      : "vcc");                                                        \
     } while (0)
 
+    // MODE 1, a finished tile's sixteen values per lane: unscaled (absent components: -3e38), their maximum folded into the
+    // running one and the sum rescaled ONCE -- the drain proper is then one v_exp_f32 and one addition per value (two
+    // exponentials and a multiply-add per value, the maximum updated value by value, took as many vector cycles as the tile's
+    // MFMAs and did not hide behind them once only the occupied tiles are multiplied)
+#define SEGK_LSE_PREP(ACCM, ACCL)                                                                     \
+    do {                                                                                              \
+        _Pragma("unroll") for (int q_ = 0; q_ < 16; q_++) vv_[q_] = fmaxf((ACCM[q_] + ACCL[q_] * LS) * unscale, -3.0e38f); \
+        float g_ = fmaxf(vv_[0], vv_[1]);                                                             \
+        _Pragma("unroll") for (int q_ = 2; q_ < 16; q_ += 2) g_ = fmaxf(g_, fmaxf(vv_[q_], vv_[q_ + 1])); \
+        const float nm_ = fmaxf(m1, g_);                                                              \
+        m2 *= __builtin_amdgcn_exp2f(m1 - nm_);                                                       \
+        m1 = nm_;                                                                                     \
+    } while (0)
 #define SEGK_TILE(NEWM, NEWL, OLDM, OLDL, t_)                                                         \
     do {                                                                                              \
+        float vv_[16];                                                                                \
+        if constexpr (MODE == 1) SEGK_LSE_PREP(OLDM, OLDL);                                           \
         const float *Tt = lds + ((t_) & 1) * STRIDE;                                                  \
         const T *Tb = (const T *)Tt;                                                                  \
         if ((t_) + 1 < n_tiles) SEGK_STAGE((t_) + 1, ((t_) + 1) & 1);                                 \
@@ -228,20 +244,25 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_kmeans_score_sp(ScoreArgs A)
     }
     {
         float m1s = m1;
+        float vv_[16];
         if (t < n_tiles) {
             SEGK_TILE(accAm, accAl, accBm, accBl, t);
             m1s = m1;
             dtile = n_tiles - 1;
+            if constexpr (MODE == 1) SEGK_LSE_PREP(accAm, accAl);
 #pragma unroll
             for (int vi = 0; vi < 16; vi++) SEGK_DRAIN(accAm, accAl, vi);
         } else {
             dtile = n_tiles - 1;
+            if constexpr (MODE == 1) SEGK_LSE_PREP(accBm, accBl);
 #pragma unroll
             for (int vi = 0; vi < 16; vi++) SEGK_DRAIN(accBm, accBl, vi);
         }
+        (void)vv_;
         itile = (m1 > m1s) ? (n_tiles - 1) : itile;
     }
 #undef SEGK_TILE
+#undef SEGK_LSE_PREP
 #undef SEGK_DRAIN
 #undef SEGK_STAGE
 #undef SEGK_TILE_SYNC
@@ -408,9 +429,14 @@ static int launch_score_lse_sp(segk_ctx *ctx, const ScoreArgs &A, hipStream_t st
 {
     constexpr int STRIDE = (KS * 2 * 256 + 32 + 1023) / 1024 * 1024;
     const size_t lds = 2 * (size_t)STRIDE * sizeof(float);
-    SEGK_CHECK_HIP(segk_dyn_lds((const void *)k_kmeans_score_sp<KS, 4, 2, 1>, lds));
-    SEGK_CHECK_HIP(segk_dyn_lds((const void *)k_kmeans_score_sp<KS, 4, 2, 1, 1>, lds));
-    const int64_t chunks = (A.n + 127) / 128;
+    // waves per workgroup (row blocks of 32 LSE_W rows).  Eight -- one workgroup per CU, every tile staged once for 256 rows --
+    // measured the same as four (82.6 against 80 us at configs[4]): the kernel waits for its rows at the start of every block
+    // (SQ_WAIT_INST_ANY 44 % of the wave cycles, SQ_WAIT_INST_LDS 3 %, matrix pipe 41 % busy), not for the tiles
+    constexpr int LSE_W = SEGK_LSE_WAVES;
+    constexpr int RB = 32 * LSE_W;
+    SEGK_CHECK_HIP(segk_dyn_lds((const void *)k_kmeans_score_sp<KS, LSE_W, 2, 1>, lds));
+    SEGK_CHECK_HIP(segk_dyn_lds((const void *)k_kmeans_score_sp<KS, LSE_W, 2, 1, 1>, lds));
+    const int64_t chunks = (A.n + RB - 1) / RB;
     const bool prof = ctx && segk_prof_now(ctx);
     const int slot = prof ? ctx->prof_n % SEGK_PROF_SLOTS : 0;
     // The row blocks behind the last whole round of workgroups (configs[4]: 1 024 blocks on 512 slots in six of the eight Gibbs
@@ -420,18 +446,20 @@ static int launch_score_lse_sp(segk_ctx *ctx, const ScoreArgs &A, hipStream_t st
     int64_t rem = 0;
     if (ctx && ctx->n_cu > 0) {
         int wg_per_cu = 1;
-        SEGK_CHECK_HIP(segk_occupancy((const void *)k_kmeans_score_sp<KS, 4, 2, 1>, 256, lds, &wg_per_cu));
+        SEGK_CHECK_HIP(segk_occupancy((const void *)k_kmeans_score_sp<KS, LSE_W, 2, 1>, 64 * LSE_W, lds, &wg_per_cu));
         const int64_t slots = (int64_t)wg_per_cu * ctx->n_cu;
         const int64_t whole = (chunks / slots) * slots;
         if (whole > 0 && chunks - whole > 0 && chunks - whole <= slots / 8 && !ctx->capturing) rem = chunks - whole;
         const char *e = getenv("SEGK_LSE_SPLIT");               // 0: every row block by a workgroup of its own (same bits, the tests compare)
         if (e && atoi(e) == 0) rem = 0;
     }
-    if (rem > 0 && ctx->sp2_blocks < rem) {
+    // (the partials' buffer is the second stage's, in its units: 8 x 128 x 4 floats and one ticket per block of 128 rows)
+    const int64_t units = rem * (RB / 128);
+    if (rem > 0 && ctx->sp2_blocks < units) {
         if (ctx->sp2_part) (void)hipFree(ctx->sp2_part);
         if (ctx->sp2_ticket) (void)hipFree(ctx->sp2_ticket);
         ctx->sp2_part = nullptr; ctx->sp2_ticket = nullptr; ctx->sp2_blocks = 0;
-        const int64_t blocks = rem > 64 ? rem : 64;
+        const int64_t blocks = units > 64 ? units : 64;
         SEGK_CHECK_HIP(hipMalloc((void **)&ctx->sp2_part, (size_t)blocks * 8 * 128 * 4 * sizeof(float)));
         SEGK_CHECK_HIP(hipMalloc((void **)&ctx->sp2_ticket, (size_t)blocks * sizeof(int32_t)));
         SEGK_CHECK_HIP(hipMemsetAsync(ctx->sp2_ticket, 0, (size_t)blocks * sizeof(int32_t), st));
@@ -439,7 +467,7 @@ static int launch_score_lse_sp(segk_ctx *ctx, const ScoreArgs &A, hipStream_t st
     }
     if (prof) SEGK_CHECK_HIP(hipEventRecord(ctx->prof_ev[slot][0], st));
     if (rem > 0) {
-        const int64_t n_main = (chunks - rem) * 128;
+        const int64_t n_main = (chunks - rem) * RB;
         ScoreArgs S = A;
         S.n = A.n - n_main;
         S.row0 = A.row0 + n_main;
@@ -448,12 +476,12 @@ static int launch_score_lse_sp(segk_ctx *ctx, const ScoreArgs &A, hipStream_t st
         S.n_chunks = (A.n_tiles + SEGK_LSE_CHUNK - 1) / SEGK_LSE_CHUNK;         // 16 at most (32 tiles): 32 floats per row of part_f
         S.part_f = ctx->sp2_part;
         S.part_k = ctx->sp2_ticket;
-        hipLaunchKernelGGL((k_kmeans_score_sp<KS, 4, 2, 1, 1>), dim3((unsigned)(rem * S.n_chunks)), dim3(256), lds, st, S);
+        hipLaunchKernelGGL((k_kmeans_score_sp<KS, LSE_W, 2, 1, 1>), dim3((unsigned)(rem * S.n_chunks)), dim3(64 * LSE_W), lds, st, S);
         ScoreArgs M = A;
         M.n = n_main;
-        hipLaunchKernelGGL((k_kmeans_score_sp<KS, 4, 2, 1>), dim3((unsigned)(chunks - rem)), dim3(256), lds, st, M);
+        hipLaunchKernelGGL((k_kmeans_score_sp<KS, LSE_W, 2, 1>), dim3((unsigned)(chunks - rem)), dim3(64 * LSE_W), lds, st, M);
     } else
-    hipLaunchKernelGGL((k_kmeans_score_sp<KS, 4, 2, 1>), dim3((unsigned)chunks), dim3(256), lds, st, A);
+    hipLaunchKernelGGL((k_kmeans_score_sp<KS, LSE_W, 2, 1>), dim3((unsigned)chunks), dim3(64 * LSE_W), lds, st, A);
     if (prof) {
         SEGK_CHECK_HIP(hipEventRecord(ctx->prof_ev[slot][1], st));
         ctx->prof_rows[slot] = A.n;
