@@ -115,6 +115,7 @@ CASES = [
     ("bigram", "f16", 48, 100, 1000, None),        # configs[4] shape: one wave per utterance, hardware log / exp
     ("bigram", "f16", 48, 100, 1000, "0"),         # ... and the block-wide form it replaced (SEGK_FBB_ASSIGN_WAVE=0)
     ("fixed", "f16", 36, 100, 1000, None),
+    ("bigram", "f16", 40, 60, 1100, None),         # more than 1 024 slots: the wave kernel's per-slot loops behind the column table
 ]
 
 
