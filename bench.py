@@ -448,25 +448,32 @@ def main_sequential(args):
     }))
 
 
-def main_fbgmm_sequential(args):
+def main_fbgmm_sequential(args, bigram=False):
     """configs[1] through the reference's own serial Gibbs chain (UnigramAcousticWordseg + FBGMM with diagonal components, the API
     default sync='sequential'; draws identical to the reference, tests/test_gpu_chain_parity_fullshape.py): sweeps per second
     on ONE GPU -- the chain does not shard.  One persistent kernel per stretch of utterances between two emptied components
-    (segk_fbgmm_sequential_sweep)."""
+    (segk_fbgmm_sequential_sweep).  bigram: the same corpus through BigramAcousticWordseg (fixed-variance components, bigram
+    language model over the component labels), the kernel's language-model variant."""
     import torch
     assert args.gpus == 1, "the sequential chain is one Markov chain: one GPU"
     torch.cuda.set_device(0)
-    from segmentalist_amd import fbgmm, unigram_acoustic_wordseg as uaw
+    from segmentalist_amd import bigram_acoustic_wordseg as baw, fbgmm, unigram_acoustic_wordseg as uaw
+    from segmentalist_amd.gaussian_components_fixedvar import FixedVarPrior
     from segmentalist_amd.niw import NIW
     from segmentalist_amd.synth import make_corpus
     n_utt, D, K = 1000, 39, 100
     corpus = make_corpus(n_utt, D, K, seed=0, N=args.landmarks, n_slices_max=args.n_slices_max)
     random.seed(0)
     np.random.seed(0)
-    seg = uaw.UnigramAcousticWordseg(fbgmm.FBGMM, 1.0, K, NIW(np.zeros(D), 0.05, D + 3, 0.002 * (D + 3) * np.ones(D)), *corpus,
-                                     covariance_type="diag", fb_type="standard", n_slices_min=0, n_slices_max=args.n_slices_max,
-                                     p_boundary_init=0.5, beta_sent_boundary=-1, lms=1.0, wip=0.0, init_am_assignments="rand",
-                                     time_power_term=1.0)
+    common = dict(n_slices_min=0, n_slices_max=args.n_slices_max, p_boundary_init=0.5, beta_sent_boundary=-1, lms=1.0, wip=0.0,
+                  init_am_assignments="rand", time_power_term=1.0)
+    if bigram:
+        seg = baw.BigramAcousticWordseg(K, FixedVarPrior(0.002 * np.ones(D), np.zeros(D), 0.002 / 0.05 * np.ones(D)),
+                                        {"type": "smooth", "intrp_lambda": 0.1, "a": 0.5, "b": 0.5}, *corpus,
+                                        covariance_type="fixed", fb_type="unigram", **common)
+    else:
+        seg = uaw.UnigramAcousticWordseg(fbgmm.FBGMM, 1.0, K, NIW(np.zeros(D), 0.05, D + 3, 0.002 * (D + 3) * np.ones(D)), *corpus,
+                                         covariance_type="diag", fb_type="standard", **common)
     for _ in range(args.warmup):
         seg.gibbs_sample(1)
     torch.cuda.synchronize()
@@ -476,13 +483,17 @@ def main_fbgmm_sequential(args):
     elapsed = time.perf_counter() - t0
     t_loop = float(np.mean(rec["sample_time"]))
     print(json.dumps({
-        "metric": "Gibbs sweeps/sec (sequential reference chain, UnigramAcousticWordseg + FBGMM diag, 1k utts, D=39, K=100)",
+        "metric": "Gibbs sweeps/sec (sequential reference chain, %s, 1k utts, D=39, K=100)"
+                  % ("BigramAcousticWordseg fixed-variance" if bigram else "UnigramAcousticWordseg + FBGMM diag"),
         "value": args.steps / elapsed, "unit": "sweeps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "us_per_utterance": 1e6 * t_loop / n_utt,
         "higher_is_better": True, "scaling": "none (one chain)", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "UnigramAcousticWordseg sync='sequential' + FBGMM diag (BASELINE.json configs[1] through the "
-                               "reference's serial chain), one persistent kernel per stretch of utterances between two emptied "
-                               "components",
+        "config": {"workload": ("BigramAcousticWordseg sync='sequential' (fixed-variance components, bigram language model; the "
+                                "configs[1] corpus through the reference's serial chain), the persistent kernel's language-model "
+                                "variant" if bigram else
+                                "UnigramAcousticWordseg sync='sequential' + FBGMM diag (BASELINE.json configs[1] through the "
+                                "reference's serial chain), one persistent kernel per stretch of utterances between two emptied "
+                                "components"),
                    "utterances": n_utt, "landmarks_per_utt": args.landmarks, "n_slices_max": args.n_slices_max, "D": D, "K": K,
                    "components_after": int(rec["components"][-1]),
                    "sample_time_seconds": [float(t) for t in rec["sample_time"]]},
@@ -510,22 +521,25 @@ def main():
     ap.add_argument("--no-events", action="store_true", help="do not bracket the score kernel with events")
     ap.add_argument("--event-period", type=int, default=8,
                     help="bracket the score kernel of every Nth sweep of the timed region with HIP events (roofline.achieved)")
-    ap.add_argument("--workload", default="kmeans_c3", choices=["kmeans_c3", "fbgmm_diag_c2", "bigram_c5", "kmeans_c3_sequential", "fbgmm_c2_sequential"],
+    ap.add_argument("--workload", default="kmeans_c3", choices=["kmeans_c3", "fbgmm_diag_c2", "bigram_c5", "kmeans_c3_sequential", "fbgmm_c2_sequential",
+                             "bigram_c2_sequential"],
                     help="kmeans_c3 (default) is the headline of BASELINE.json (configs[2]); fbgmm_diag_c2 = configs[1] "
                          "(UnigramAcousticWordseg + FBGMM diag, 1k utterances, D=39, K=100), bigram_c5 = configs[4] "
                          "(BigramAcousticWordseg, 10k utterances, D=100, K=1000): the batch (blocked Gibbs) sampler; "
                          "kmeans_c3_sequential = the headline corpus through the reference's own sequential chain "
-                         "(sync='sequential', the API default; one GPU; --steps sweeps after --warmup, default 3 after 1)")
+                         "(sync='sequential', the API default; one GPU; --steps sweeps after --warmup, default 3 after 1); "
+                         "fbgmm_c2_sequential / bigram_c2_sequential = the configs[1] corpus through the serial Gibbs chain of "
+                         "UnigramAcousticWordseg + FBGMM / of BigramAcousticWordseg (one persistent kernel per stretch)")
     args = ap.parse_args()
-    seq = args.workload in ("kmeans_c3_sequential", "fbgmm_c2_sequential")
+    seq = args.workload in ("kmeans_c3_sequential", "fbgmm_c2_sequential", "bigram_c2_sequential")
     if args.steps is None:
         args.steps = 3 if seq else 50
     if args.warmup is None:
         args.warmup = 1 if seq else 5
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not seq:
         self_launch(args.gpus)                           # does not return
-    if args.workload == "fbgmm_c2_sequential":
-        return main_fbgmm_sequential(args)
+    if args.workload in ("fbgmm_c2_sequential", "bigram_c2_sequential"):
+        return main_fbgmm_sequential(args, bigram=args.workload == "bigram_c2_sequential")
     if seq:
         return main_sequential(args)
     if args.workload != "kmeans_c3":

@@ -51,7 +51,8 @@ workloads)
     timeout -k 10 400 python bench.py --workload bigram_c5 > $O/bench_bigram_c5.json 2> /dev/null; cut -c1-200 $O/bench_bigram_c5.json
     timeout -k 10 400 python bench.py --workload fbgmm_diag_c2 > $O/bench_fbgmm_diag_c2.json 2> /dev/null; cut -c1-200 $O/bench_fbgmm_diag_c2.json
     timeout -k 10 400 python bench.py --workload kmeans_c3_sequential > $O/bench_kmeans_c3_sequential.json 2> /dev/null; cut -c1-200 $O/bench_kmeans_c3_sequential.json
-    timeout -k 10 400 python bench.py --workload fbgmm_c2_sequential > $O/bench_fbgmm_c2_sequential.json 2> /dev/null; cut -c1-260 $O/bench_fbgmm_c2_sequential.json ;;
+    timeout -k 10 400 python bench.py --workload fbgmm_c2_sequential > $O/bench_fbgmm_c2_sequential.json 2> /dev/null; cut -c1-260 $O/bench_fbgmm_c2_sequential.json
+    timeout -k 10 400 python bench.py --workload bigram_c2_sequential > $O/bench_bigram_c2_sequential.json 2> /dev/null; cut -c1-260 $O/bench_bigram_c2_sequential.json ;;
 rehearse)   # the N > 1 launcher and transport on ONE card: `python bench.py --gpus N` starts its own torchrun child, gloo backend
     for n in 2 4; do timeout -k 10 500 python bench.py --gpus $n --cpu-utts 0 --steps 20 --warmup 5 > $O/bench_gpus${n}_gloo.json 2> $O/bench_gpus${n}_gloo.err || { tail -20 $O/bench_gpus${n}_gloo.err; exit 1; }; v "gpus=$n" $O/bench_gpus${n}_gloo.json; done ;;
 *) echo "unknown step $S"; exit 2 ;;
