@@ -236,16 +236,35 @@ __global__ void k_fbb_partials_sorted(segk_corpus c, segk_fbgmm f, segk_fbatch b
     double ax[FBB_MAXCH], axx[FBB_MAXCH];
 #pragma unroll
     for (int q = 0; q < FBB_MAXCH; q++) { ax[q] = 0.0; axx[q] = 0.0; }
-    for (int t = q0; t < q1; t++) {                     // token order
-        const int64_t e = list[t];
+    // token order.  The list entries of up to 64 tokens by one load, the rows of four tokens in flight together (an entry and
+    // then its row per token were two dependent round trips each: 30 us for three tokens per slot on average); the additions
+    // stay sequential
+    for (int t0 = q0; t0 < q1; t0 += 64) {
+        const int cnt = q1 - t0 < 64 ? q1 - t0 : 64;
+        const int my_e = lane < cnt ? list[t0 + lane] : 0;
+        for (int u0 = 0; u0 < cnt; u0 += 4) {
+            XT xv[4][FBB_MAXCH];
 #pragma unroll
-        for (int q = 0; q < FBB_MAXCH; q++) {
-            const int d = q * 64 + lane;
-            if (d < D) {
-                const XT x = X[e * c.ldx + d];
-                ax[q] += (double)x;
-                axx[q] += fbb_sq<XT>(x);
+            for (int u = 0; u < 4; u++) {
+                const int64_t e = __builtin_amdgcn_readlane(my_e, u0 + u < cnt ? u0 + u : cnt - 1);
+#pragma unroll
+                for (int q = 0; q < FBB_MAXCH; q++) {
+                    const int d = q * 64 + lane;
+                    xv[u][q] = d < D ? X[e * c.ldx + d] : (XT)0;
+                }
             }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (u0 + u < cnt) {
+#pragma unroll
+                    for (int q = 0; q < FBB_MAXCH; q++) {
+                        const int d = q * 64 + lane;
+                        if (d < D) {
+                            ax[q] += (double)xv[u][q];
+                            axx[q] += fbb_sq<XT>(xv[u][q]);
+                        }
+                    }
+                }
         }
     }
     double *rec = bt.partials + ((int64_t)b * bt.n_slices + s) * fbb_rec(f, D);
