@@ -161,10 +161,30 @@ __global__ __launch_bounds__(FBS_THREADS) void k_fbb_sort(segk_corpus c, segk_fb
         return key;
     };
     const int p_lo = wv * per, p_hi = p_lo + per < S ? p_lo + per : S;
-    for (int p0 = p_lo; p0 < p_hi; p0 += 64) {
-        int32_t id;
-        const int key = key_of(p0 + lane < p_hi ? p0 + lane : S, &id);
-        if (key >= 0) atomicAdd(&cntw[wv * KM + key], 1);
+    // (keys of four chunks of 64 positions at a time, stage by stage -- token count, token, slot: three round trips for 256
+    // positions; one chunk after the other was three DEPENDENT round trips per chunk, twelve for a wave's run, in both passes)
+    auto keys4 = [&](int p0, int key[4], int32_t id[4]) {
+        int u_[4], j_[4], nn_[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int p = p0 + 64 * q + lane < p_hi ? p0 + 64 * q + lane : S;
+            u_[q] = p < S ? u0 + p / c.N_max : -1;
+            j_[q] = p < S ? p % c.N_max : 0;
+            nn_[q] = u_[q] >= 0 ? n_new[u_[q]] : 0;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) id[q] = j_[q] < nn_[q] ? new_tok[(int64_t)u_[q] * c.N_max + j_[q]] : -1;
+#pragma unroll
+        for (int q = 0; q < 4; q++) key[q] = id[q] >= 0 ? bt.slot[id[q]] : -1;
+    };
+    (void)key_of;
+    for (int p0 = p_lo; p0 < p_hi; p0 += 256) {
+        int key[4];
+        int32_t id[4];
+        keys4(p0, key, id);
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (key[q] >= 0) atomicAdd(&cntw[wv * KM + key[q]], 1);
     }
     __syncthreads();
     // per slot: the waves' counts -> running offsets inside the slot; the slots' totals -> an exclusive scan over the slots
@@ -196,25 +216,32 @@ __global__ __launch_bounds__(FBS_THREADS) void k_fbb_sort(segk_corpus c, segk_fb
     if (tid == 0) ko[KM] = wsum[FBS_WAVES];
     __syncthreads();
     // placement: every wave walks its run again, 64 positions at a time in order
-    for (int p0 = p_lo; p0 < p_hi; p0 += 64) {
-        int32_t id;
-        const int key = key_of(p0 + lane < p_hi ? p0 + lane : S, &id);
-        const bool ok = key >= 0;
-        unsigned long long mask = __ballot(ok);
-        for (int bit = 0; bit < nbits; bit++) {
-            const unsigned long long bal = __ballot((key >> bit) & 1);
-            mask &= ((key >> bit) & 1) ? bal : ~bal;
+    for (int p0 = p_lo; p0 < p_hi; p0 += 256) {
+        int key4[4];
+        int32_t id4[4];
+        keys4(p0, key4, id4);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {               // the chunks of 64 in order
+            const int key = key4[q];
+            const int32_t id = id4[q];
+            const bool ok = key >= 0;
+            unsigned long long mask = __ballot(ok);
+            if (mask == 0ull) continue;
+            for (int bit = 0; bit < nbits; bit++) {
+                const unsigned long long bal = __ballot((key >> bit) & 1);
+                mask &= ((key >> bit) & 1) ? bal : ~bal;
+            }
+            if (ok) {
+                const int rank = __popcll(mask & ((1ull << lane) - 1ull));
+                const int o = cntw[wv * KM + key];
+                out[o + rank] = id;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (ok && (mask & ((1ull << lane) - 1ull)) == 0ull) cntw[wv * KM + key] += __popcll(mask);      // the first lane of every key
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
-        if (ok) {
-            const int rank = __popcll(mask & ((1ull << lane) - 1ull));
-            const int o = cntw[wv * KM + key];
-            out[o + rank] = id;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (ok && (mask & ((1ull << lane) - 1ull)) == 0ull) cntw[wv * KM + key] += __popcll(mask);      // the first lane of every key
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -1438,12 +1465,19 @@ __global__ void k_fbb_lm_apply(segk_fbgmm f, segk_fbatch bt, int N_max, int b, i
     if (row >= n_rows) return;
     const int32_t *t = bt.lm_tok + ((int64_t)b * n_rows + row) * N_max;
     int prev = -1;
-    for (int j = 0; j < N_max; j++) {
-        const int k = t[j];
-        if (k < 0) break;
-        if (prev >= 0)
-            atomicAdd((unsigned long long *)&f.lm_bigram[(int64_t)prev * f.K_max + k], (unsigned long long)(long long)sign);
-        prev = k;
+    // (eight slots per round trip: one load per token with the exit test in between was a chain of up to N_max of them)
+    for (int j0 = 0; j0 < N_max; j0 += 8) {
+        int kk[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) kk[u] = t[j0 + u < N_max ? j0 + u : N_max - 1];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int k = j0 + u < N_max ? kk[u] : -1;
+            if (k < 0) return;
+            if (prev >= 0)
+                atomicAdd((unsigned long long *)&f.lm_bigram[(int64_t)prev * f.K_max + k], (unsigned long long)(long long)sign);
+            prev = k;
+        }
     }
 }
 
@@ -1457,7 +1491,17 @@ __global__ void k_fbb_lm_fill(segk_corpus c, segk_fbatch bt, FbbMap map, int b, 
     const int utt = bt.utt_range[(slice * bt.n_blocks + b) * 2] + idx;
     int32_t *t = bt.lm_tok + (((int64_t)b * bt.n_slices + slice) * bt.u_max + idx) * c.N_max;
     const int nn = n_new[utt];
-    for (int j = 0; j < c.N_max; j++) t[j] = j < nn ? bt.slot[new_tok[(int64_t)utt * c.N_max + j]] : -1;
+    // (eight tokens per pair of round trips: the stores to t[] kept the compiler from moving any load of the next token up)
+    for (int j0 = 0; j0 < c.N_max; j0 += 8) {
+        int e[8], k[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) e[u] = j0 + u < nn ? new_tok[(int64_t)utt * c.N_max + j0 + u] : -1;
+#pragma unroll
+        for (int u = 0; u < 8; u++) k[u] = e[u] >= 0 ? bt.slot[e[u]] : -1;
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            if (j0 + u < c.N_max) t[j0 + u] = j0 + u < nn ? k[u] : -1;
+    }
 }
 
 // token lists of all utterances from the boundaries (entering batch mode)
