@@ -1272,16 +1272,18 @@ __global__ __launch_bounds__(256) void k_fbb_assign_lm_wave(segk_corpus c, segk_
                     }
                 }
                 mx = fb_wave_max(mx, false);
+                // (the sum of the exponentials in float32 like its terms, the logarithm by v_log_f32: the differences were formed in
+                // fp64, what is summed lies in [0, 1])
                 auto sum_reg = [&](double shift) -> double {
-                    double sv = 0.0;
+                    float sv = 0.f;
 #pragma unroll
                     for (int j = 0; j < KPL; j++)
-                        if (j < jmax) sv += (double)__builtin_amdgcn_exp2f((float)(zv[j] - shift) * LOG2E);      // 2^-inf = 0 behind the last column
-                    sv = fb_wave_sum(sv);
-                    if (has_e) sv += n_empty * (double)__builtin_amdgcn_exp2f((float)(ze - shift) * LOG2E);
-                    return sv;
+                        if (j < jmax) sv += __builtin_amdgcn_exp2f((float)(zv[j] - shift) * LOG2E);      // 2^-inf = 0 behind the last column
+                    sv = fb_wave_sum_f32(sv);
+                    if (has_e) sv += (float)n_empty * __builtin_amdgcn_exp2f((float)(ze - shift) * LOG2E);
+                    return (double)sv;
                 };
-                double lse = log(sum_reg(mx)) + mx;
+                double lse = fb_log_fast(sum_reg(mx)) + mx;
                 if (anneal_temp != 1.0) {                               // fbgmm.py:446-449
                     double mx2 = NEG_INF_D;
                     if (has_e) {
@@ -1295,7 +1297,7 @@ __global__ __launch_bounds__(256) void k_fbb_assign_lm_wave(segk_corpus c, segk_
                             mx2 = zv[j] > mx2 ? zv[j] : mx2;
                         }
                     mx2 = fb_wave_max(mx2, false);
-                    lse = log(sum_reg(mx2)) + mx2;
+                    lse = fb_log_fast(sum_reg(mx2)) + mx2;
                 }
 #pragma unroll
                 for (int j = 0; j < KPL; j++)
@@ -1667,6 +1669,7 @@ __global__ __launch_bounds__(1024) void k_fbb_compact(segk_fbatch bt, int KM, in
         inv[run] = KM;
     }
     for (int k = tid; k <= KM; k += 1024) bt.consts16[k] = -3.0e38;
+    if (tid == 0) bt.consts16[KM + 1] = 0.0;          // max |row|^2 of this step's image (k_fbb_rows16: atomic maximum)
     // the columns behind the pseudo-component inside the last tile in use are multiplied too: their rows (whatever an earlier
     // step left there, scaled for another exponent) must not overflow the fp16 image
     const int r_hi = n_t * 32 < KM + 1 ? n_t * 32 : KM + 1;
@@ -1823,7 +1826,8 @@ int32_t segk_fbb_prepare(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *
     hipLaunchKernelGGL(k_fbb_prepare, dim3(f->K_max), dim3(192), 0, st, *f, *bt, c->D, b, alpha);
     if (bt->tiles16 && bt->y16 && f->cov_type == 0) {
         SEGK_REQUIRE(bt->rows32 && bt->consts16, "rows32 / consts16 scratch missing");
-        SEGK_CHECK_HIP(hipMemsetAsync(bt->consts16 + f->K_max + 1, 0, sizeof(double), st));
+        // (k_fbb_compact also clears the running maximum of the rows' norms behind the constants: a memset of 8 bytes was a launch
+        // of 4.8 us)
         // the occupied slots packed into the leading columns; the maps live behind the constants and are read by the score and
         // token-score calls of this step
         int32_t *cmap = fbb_cmap(bt, f->K_max);
