@@ -84,26 +84,32 @@ __global__ void k_fbb_partials(segk_corpus c, segk_fbgmm f, segk_fbatch bt, int 
 #pragma unroll
     for (int q = 0; q < FBB_MAXCH; q++) { ax[q] = 0.0; axx[q] = 0.0; }
     double n = 0.0;
-    for (int u = u0; u < u1; u++) {
-        const int nn = n_new[u];
-        int id = -1, match = 0;
-        if (lane < nn) {
-            id = new_tok[(int64_t)u * c.N_max + lane];
-            match = bt.slot[id] == k;
-        }
-        unsigned long long bal = __ballot(match);
-        while (bal) {                                   // token order
-            const int src = __ffsll((long long)bal) - 1;
-            bal &= bal - 1;
-            const int64_t e = __shfl(id, src);
-            n += 1.0;
+    // four utterances per trip, stage by stage (token counts, tokens, slots: three round trips for four utterances instead of
+    // three per utterance); the matches are then taken in utterance and token order as before
+    for (int ub = u0; ub < u1; ub += 4) {
+        int nn4[4], id4[4], match4[4];
 #pragma unroll
-            for (int q = 0; q < FBB_MAXCH; q++) {
-                const int d = q * 64 + lane;
-                if (d < D) {
-                    const XT x = X[e * c.ldx + d];
-                    ax[q] += (double)x;
-                    axx[q] += fbb_sq<XT>(x);
+        for (int v = 0; v < 4; v++) nn4[v] = ub + v < u1 ? n_new[ub + v] : 0;
+#pragma unroll
+        for (int v = 0; v < 4; v++) id4[v] = lane < nn4[v] ? new_tok[(int64_t)(ub + v) * c.N_max + lane] : -1;
+#pragma unroll
+        for (int v = 0; v < 4; v++) match4[v] = id4[v] >= 0 ? (bt.slot[id4[v]] == k) : 0;
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            unsigned long long bal = __ballot(match4[v]);
+            while (bal) {                                   // token order
+                const int src = __ffsll((long long)bal) - 1;
+                bal &= bal - 1;
+                const int64_t e = __shfl(id4[v], src);
+                n += 1.0;
+#pragma unroll
+                for (int q = 0; q < FBB_MAXCH; q++) {
+                    const int d = q * 64 + lane;
+                    if (d < D) {
+                        const XT x = X[e * c.ldx + d];
+                        ax[q] += (double)x;
+                        axx[q] += fbb_sq<XT>(x);
+                    }
                 }
             }
         }
