@@ -879,11 +879,30 @@ __global__ __launch_bounds__(128) void k_fbb_segment(segk_corpus c, segk_fbatch 
     double *w = a + c.N_max;                // [N+1]
     double *pr = w + c.N_max + 1;           // [N+1]
     int32_t *old = (int32_t *)(pr + c.N_max + 1);      // [N_max]
+    // The span ids (triangular) and the boundary flags staged in LDS: the token lists before and after the DP are then taken from
+    // LDS -- from memory each was two dependent round trips, the second one behind the DP's own stores of the flags -- and the
+    // flags go back to memory once, at the end (the workgroup is a chain of round trips: 19 of its 25 us)
+    int32_t *vid_l = old + c.N_max;                    // [triMax]
+    uint8_t *bnd_l = (uint8_t *)(vid_l + triMax);      // [N_max]
+    uint8_t *bnd_g = boundaries + (int64_t)utt * c.N_max;
+    for (int j = threadIdx.x; j < N; j += blockDim.x) bnd_l[j] = bnd_g[j];
+    if (tab.band) {
+        for (int j = threadIdx.x; j < tri; j += blockDim.x) vid_l[j] = -1;
+        __syncthreads();
+        const int W = tab.W;
+        for (int i = threadIdx.x; i < N * W; i += blockDim.x) {
+            const int t = i / W + 1, s2 = t - 1 - (i - (t - 1) * W);
+            if (s2 >= 0) vid_l[t * (t - 1) / 2 + s2] = tab.bandi[i];
+        }
+    } else {
+        for (int j = threadIdx.x; j < tri; j += blockDim.x) vid_l[j] = vid[j];
+    }
     fb_fill_vec(tab, N, tri, [&](int id) { return score[id]; }, time_power_term, wip, vec, threadIdx.x, blockDim.x);
     __syncthreads();
     if (threadIdx.x >= 64) return;
     const int lane = threadIdx.x;
-    uint8_t *bnd = boundaries + (int64_t)utt * c.N_max;
+    uint8_t *bnd = bnd_l;
+    vid = vid_l;
     const int n_old = N <= 64 ? fb_collect_tokens_wave(vid, bnd, N, old, lane)
                               : __shfl(lane == 0 ? fb_collect_tokens(vid, bnd, N, old) : 0, 0);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -897,6 +916,7 @@ __global__ __launch_bounds__(128) void k_fbb_segment(segk_corpus c, segk_fbatch 
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const int nn = N <= 64 ? fb_collect_tokens_wave(vid, bnd, N, new_tok + (int64_t)utt * c.N_max, lane) : -1;
+    for (int j = lane; j < N; j += 64) bnd_g[j] = bnd_l[j];
     if (lane != 0) return;
     if (total == NEG_INF_D) atomicOr(status, 16);
     out_logprob[utt] = total;
@@ -2000,7 +2020,8 @@ int32_t segk_fbb_segment(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *
     if (rc) return rc;
     if (m.off[s_n] == 0) return SEGK_OK;
     const int64_t triMax = (int64_t)c->N_max * (c->N_max + 1) / 2;
-    const size_t lds = (size_t)(triMax + 3 * c->N_max + 2) * sizeof(double) + (size_t)c->N_max * sizeof(int32_t);
+    const size_t lds = (size_t)(triMax + 3 * c->N_max + 2) * sizeof(double) + (size_t)(c->N_max + triMax) * sizeof(int32_t) +
+                       (size_t)((c->N_max + 15) & ~15);
     SEGK_REQUIRE(lds <= 64 * 1024, "N_max too large for the LDS score vector");
     hipLaunchKernelGGL(k_fbb_segment, dim3(m.off[s_n]), dim3(128), lds, (hipStream_t)stream, *c, *bt, m, b, sweep,
                        n_slices_max, wip, time_power_term, anneal_temp, score, boundaries, new_tok, n_new, out_logprob,
