@@ -52,8 +52,9 @@ const char *segk_last_error(void);
  *              segk_fbgmm_sequential_sweep
  *   7 round 4: segk_fbatch.consts16 holds 2 (K_max + 2) + 32 doubles (the column maps of the packed operand image behind the
  *              constants) and the token-likelihood matrix has the image's columns; the FBGMM / bigram kernels read
- *              segk_corpus.band_ids / band_dur (a COMPLETE band only); segk_fbgmm_sequential_sweep with a language model         */
-#define SEGK_ABI_VERSION 7
+ *              segk_corpus.band_ids / band_dur (a COMPLETE band only); segk_fbgmm_sequential_sweep with a language model
+ *   8 round 4: segk_fbb_step_diag32                                                                                           */
+#define SEGK_ABI_VERSION 8
 int32_t segk_abi_version(void);
 
 /* Timing of the MAIN launch of the MFMA score kernel (k_kmeans_score<..., 0>) with HIP events
@@ -662,6 +663,20 @@ int32_t segk_fbb_assign_diag32(segk_ctx *ctx, const segk_corpus *c, const segk_f
                                const segk_fbatch *bt, int32_t s_lo, int32_t s_n, int32_t b,
                                const int32_t *n_utts, uint64_t sweep, double anneal_temp,
                                const int32_t *new_tok, const int32_t *n_new, void *stream);
+/* One Gibbs step of the diagonal (Student-t) sampler in float32 terms as ONE launch (ABI 8): segk_fbb_score_diag32,
+ * segk_fbb_segment and segk_fbb_assign_diag32 of block b fused -- the workgroup that owns an utterance scores its spans,
+ * samples its boundaries (the same uniforms, unigram_acoustic_wordseg.py:653-864) and draws the new segments' slots from the
+ * logits it already holds (fbgmm.py:422-463); `score` [dev] double [n_emb] still receives the span scores, bit for bit those
+ * of segk_fbb_score_diag32, and the boundaries are those segk_fbb_segment samples from them; the token likelihoods are
+ * float32 terms with one multiply-add where segk_fbb_assign_diag32 multiplies and adds (both within the 1e-4 contract).
+ * Needs bt->prior_rows; honours segk_fbb_set_probe.  Returns SEGK_ERR_UNSUPPORTED, with nothing enqueued, where it does not
+ * apply (a language model, K_max > 256, tables + logits beyond a workgroup's LDS, SEGK_FBB_FUSED=0): the caller then makes
+ * the three calls.                                                                                                        */
+int32_t segk_fbb_step_diag32(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *f, const segk_fbatch *bt,
+                             int32_t s_lo, int32_t s_n, int32_t b, const int32_t *n_utts, uint64_t sweep,
+                             int32_t n_slices_min, int32_t n_slices_max, double wip, double time_power_term,
+                             double anneal_temp_fb, double anneal_temp_am, double *score, uint8_t *boundaries,
+                             int32_t *new_tok, int32_t *n_new, double *out_logprob, int32_t *status, void *stream);
 /* ll_mat of segk_fbb_assign (optional; fixed-variance components with the fp16x2 images): the token
  * likelihoods come from the matrix-core contraction instead of the fp64 VALU loop.  Row j*N_max + t of
  * ll_mat [n, ll_ld] belongs to segment t of the j-th utterance of the block (local slices in order);

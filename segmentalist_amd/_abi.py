@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("SEGK_LIB_PATH") or os.path.join(_HERE, "libsegk.so") 
 
 SEGK_F32, SEGK_F64 = 0, 1
 SEGK_ERR_UNSUPPORTED = -4          # include/segk.h
-ABI_VERSION = 7          # SEGK_ABI_VERSION of include/segk.h this binding was written against
+ABI_VERSION = 8          # SEGK_ABI_VERSION of include/segk.h this binding was written against
 
 
 class SegkError(RuntimeError):
@@ -135,6 +135,8 @@ SIGNATURES = {
                                 _P, _P, _P, _P, _P]),
     "segk_fbb_assign": (_i32, [_P, _CP, _FP, _BP, _i32, _i32, _i32, _P, _u64, _f64, _P, _P, _P, _i64, _P]),
     "segk_fbb_assign_diag32": (_i32, [_P, _CP, _FP, _BP, _i32, _i32, _i32, _P, _u64, _f64, _P, _P, _P]),
+    "segk_fbb_step_diag32": (_i32, [_P, _CP, _FP, _BP, _i32, _i32, _i32, _P, _u64, _i32, _i32, _f64, _f64, _f64, _f64,
+                                    _P, _P, _P, _P, _P, _P, _P]),
     "segk_fbb_token_scores": (_i32, [_P, _CP, _FP, _BP, _P, _i64, _P, _i64, _P]),
     "segk_fbb_set_probe": (_i32, [_P, _P, _P, _i64]),
     "segk_fbb_lm_apply": (_i32, [_P, _CP, _FP, _BP, _i32, _i32, _P]),

@@ -834,6 +834,284 @@ __global__ __launch_bounds__(256) void k_fbb_score_diag32(segk_corpus c, segk_fb
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// One Gibbs step of the diagonal (Student-t) sampler in float32 terms as ONE kernel (round 4): span scores, boundaries and
+// slots of an utterance by the workgroup that owns it -- k_fbb_score_diag32, k_fbb_segment and k_fbb_assign back to back
+// were three launches of ~25 us each for 125 utterances (6.6 us of each the empty launch, the rest one workgroup's chain
+// of round trips), and the assignment kernel evaluated the token likelihoods a second time.  Here:
+//   (1) the utterance's spans that have an embedding are listed (band or triangle), their rows and the slot tables staged
+//       in LDS (float32, rows transposed as in k_fbb_score_diag32);
+//   (2) L[i][k] = (zconst_k - half_k ln 2 sum_d log2(1 + (m - x)^2 q)) log2 e for every (span, slot) -- the arithmetic of
+//       k_fbb_score_diag32 term for term (packed float32 on row pairs), kept in LDS: it is the span score's summand AND
+//       the assignment logit (zconst holds the prior's term already), empty slots carry zc_empty + the row's prior predictive;
+//   (3) the span score = log-sum-exp over the slots, per wave of 64 slots by DPP and the waves' pairs in order: the bits
+//       of k_fbb_score_diag32 (also written to `score`);
+//   (4) vec, forward filtering / backward sampling by wave 0 (fb_dp_sample, as k_fbb_segment), old tokens' slots cleared;
+//   (5) every new token's slot: one wave per token, softmax over L's row in the log2 domain (v_exp_f32 / v_log_f32), the
+//       draw walking the slots in order on the token's uniform (fb_draw_chunked, as k_fbb_assign).
+// Applies where the tables and L fit in LDS (K_max <= 256; the host checks), no language model; probes as the kernels
+// it replaces (segk_fbb_set_probe).  Token likelihoods differ from k_fbb_assign's float32 form in the last bits (one
+// multiply-add instead of multiply and add): both within the 1e-4 contract, the draws are checked against their
+// slots' intervals (tests/test_gpu_tolerance_modes.py).
+// ---------------------------------------------------------------------------------------
+struct FbbStepArgs {
+    uint64_t sweep;
+    int b, n_max, r_cap;               // r_cap: spans with an embedding per utterance at most (a multiple of 8)
+    double wip, time_power_term, anneal_fb, anneal_am, prior_alpha;
+    double *score;
+    uint8_t *boundaries;
+    int32_t *new_tok, *n_new;
+    double *out_logprob;
+    int32_t *status;
+    double *probe_alpha, *probe_ll;
+    int64_t probe_ld;
+};
+
+template <typename XT>
+__global__ __launch_bounds__(512) void k_fbb_step_diag32(segk_corpus c, segk_fbgmm f, segk_fbatch bt, FbbMap map, FbbStepArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+    const int D = c.D, KM = f.K_max, NM = c.N_max, tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wv = tid >> 6, nw = nt >> 6;
+    const int RC = A.r_cap, nch = (KM + 63) >> 6;
+    const int64_t triMax = (int64_t)NM * (NM + 1) / 2;
+    // ---- LDS
+    double *vec = (double *)smem;                       // [triMax]
+    double *al = vec + triMax;                          // [N_max]
+    double *ww = al + NM;                               // [N_max + 1]
+    double *pr = ww + NM + 1;                           // [N_max + 1]
+    double *dur_l = pr + NM + 1;                        // [triMax]
+    double *sc_l = dur_l + triMax;                      // [r_cap] span scores
+    double *lpr = sc_l + RC;                            // [r_cap] prior predictive of the spans' rows
+    double *zp = lpr + RC;                              // [waves][K_max] a token's probabilities
+    double *prk = zp + (int64_t)nw * KM;                // [K_max] the prior's term of every slot (probe only)
+    float *tm = (float *)(prk + KM);                    // [D][K_max]
+    float *tq = tm + D * KM;                            // [D][K_max]
+    float *xs = (float *)(((uintptr_t)(tq + D * KM) + 15) & ~(uintptr_t)15);    // [D][r_cap], 16-byte aligned (read as float4)
+    float *Lm = xs + D * RC;                            // [r_cap][K_max]
+    float *wm = Lm + (int64_t)RC * KM;                  // [r_cap][4] the chunks' maxima
+    float *ws = wm + RC * 4;                            // [r_cap][4] and sums
+    int32_t *vid_l = (int32_t *)(ws + RC * 4);          // [triMax]
+    int32_t *ent_j = vid_l + triMax;                    // [r_cap] triangular index of the i-th span with an embedding
+    int32_t *ent_id = ent_j + RC;                       // [r_cap] its embedding row
+    int32_t *old_l = ent_id + RC;                       // [N_max]
+    int32_t *tok_l = old_l + NM;                        // [N_max]
+    int32_t *tokj_l = tok_l + NM;                       // [N_max]
+    short *ent_of = (short *)(tokj_l + NM);             // [triMax] span -> its place in the list (-1)
+    uint8_t *bnd_l = (uint8_t *)(ent_of + ((triMax + 3) & ~(int64_t)3));    // [N_max]
+    __shared__ int sh_nent, sh_nn;
+    int s, idx;
+    if (!fbb_locate(map, blockIdx.x, &s, &idx)) return;
+    const int slice = map.lo[s];
+    const int utt = bt.utt_range[(slice * bt.n_blocks + A.b) * 2] + idx;
+    const double total_cnt = bt.scal[0];
+    const int N = c.lengths[utt];
+    const int tri = N * (N + 1) / 2;
+    const FbSpanTab tab = fb_span_tab(c, utt, N, A.n_max);
+    uint8_t *bnd_g = A.boundaries + (int64_t)utt * NM;
+    const XT *X = (const XT *)c.X;
+    // ---- (1) tables, span table, flags
+    for (int j = tid; j < D * KM; j += nt) {
+        tm[j] = (float)bt.mean_t[j];
+        tq[j] = (float)bt.q_t[j];
+    }
+    for (int j = tid; j < N; j += nt) bnd_l[j] = bnd_g[j];
+    for (int j = tid; j < tri; j += nt) { vid_l[j] = -1; dur_l[j] = 0.0; ent_of[j] = -1; }
+    __syncthreads();
+    if (tab.band) {
+        const int W = tab.W;
+        for (int i = tid; i < N * W; i += nt) {
+            const int t = i / W + 1, s2 = t - 1 - (i - (t - 1) * W);
+            if (s2 >= 0) {
+                vid_l[t * (t - 1) / 2 + s2] = tab.bandi[i];
+                dur_l[t * (t - 1) / 2 + s2] = tab.bandd[i];
+            }
+        }
+    } else {
+        for (int j = tid; j < tri; j += nt) { vid_l[j] = tab.vid[j]; dur_l[j] = tab.dur[j]; }
+    }
+    __syncthreads();
+    if (tid < 64) {                                     // the spans with an embedding, in table order (ballot + prefix count)
+        int n = 0;
+        for (int j0 = 0; j0 < tri; j0 += 64) {
+            const int j = j0 + lane;
+            const bool ok = j < tri && vid_l[j] >= 0;
+            const unsigned long long m = __ballot(ok);
+            const int pos = n + __popcll(m & ((1ull << lane) - 1ull));
+            if (ok && pos < RC) { ent_j[pos] = j; ent_id[pos] = vid_l[j]; ent_of[j] = (short)pos; }
+            n += __popcll(m);
+        }
+        if (lane == 0) sh_nent = n;
+    }
+    __syncthreads();
+    const int n_ent = sh_nent;
+    if (n_ent > RC) {                                   // (the host sized r_cap for the span tables: cannot happen)
+        if (tid == 0) atomicOr(A.status, 32);
+        return;
+    }
+    const int n_pad = (n_ent + 7) & ~7;
+    for (int j = tid; j < n_pad * D; j += nt) {
+        const int i = j / D, d = j - i * D;
+        xs[d * RC + i] = i < n_ent ? (float)X[(int64_t)ent_id[i] * c.ldx + d] : 0.f;
+    }
+    for (int i = tid; i < n_pad; i += nt) lpr[i] = i < n_ent ? bt.prior_rows[ent_id[i]] : 0.0;
+    const double zc_empty = f.lms * fb_log_fast(A.prior_alpha / (double)KM);
+    const double norm = f.lms * fb_log_fast(total_cnt + A.prior_alpha);
+    if (A.probe_ll)
+        for (int k = tid; k < KM; k += nt) prk[k] = bt.cnt[k] > 0.0 ? bt.zconst[k] - bt.lconst[k] : zc_empty;
+    __syncthreads();
+    // ---- (2) L: work item = (group of eight spans, slot)
+    {
+        const int n_items = (n_pad >> 3) * KM;
+        for (int item = tid; item < n_items; item += nt) {
+            const int g = item / KM, k = item - g * KM, r0 = 8 * g;
+            const float *xg = xs + r0;
+            float z2[8];
+            if (bt.cnt[k] > 0.0) {
+                f32x2_t acc2[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) acc2[r] = (f32x2_t){0.f, 0.f};
+                const f32x2_t one2 = {1.f, 1.f};
+                for (int d = 0; d < D; d++) {
+                    const float m = tm[d * KM + k], q = tq[d * KM + k];
+                    const f32x2_t m2 = {m, m}, q2 = {q, q};
+#pragma unroll
+                    for (int r4 = 0; r4 < 2; r4++) {
+                        const f32x4_t xv = *reinterpret_cast<const f32x4_t *>(xg + d * RC + 4 * r4);
+                        const f32x2_t d0 = m2 - xv.xy, d1 = m2 - xv.zw;
+                        const f32x2_t u0 = __builtin_elementwise_fma(d0 * d0, q2, one2), u1 = __builtin_elementwise_fma(d1 * d1, q2, one2);
+                        acc2[2 * r4] += (f32x2_t){__builtin_amdgcn_logf(u0.x), __builtin_amdgcn_logf(u0.y)};
+                        acc2[2 * r4 + 1] += (f32x2_t){__builtin_amdgcn_logf(u1.x), __builtin_amdgcn_logf(u1.y)};
+                    }
+                }
+                const double zc = bt.zconst[k], hl = bt.half[k] * 0.6931471805599453;
+#pragma unroll
+                for (int r = 0; r < 8; r++) z2[r] = (float)((zc - hl * (double)acc2[r >> 1][r & 1]) * 1.4426950408889634);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 8; r++) z2[r] = (float)((zc_empty + lpr[r0 + r]) * 1.4426950408889634);
+            }
+#pragma unroll
+            for (int r = 0; r < 8; r++) Lm[(int64_t)(r0 + r) * KM + k] = z2[r];
+        }
+    }
+    __syncthreads();
+    // ---- (3) span scores: (maximum, sum) per chunk of 64 slots by one wave, the chunks in order by the span's thread
+    for (int pair = wv; pair < n_ent * nch; pair += nw) {
+        const int i = pair / nch, ch = pair - i * nch, k = 64 * ch + lane;
+        const float v = k < KM ? Lm[(int64_t)i * KM + k] : -3.0e38f;
+        const float M = fb_wave_max_f32(v);
+        const float S = fb_wave_sum_f32(k < KM ? __builtin_amdgcn_exp2f(v - M) : 0.f);
+        if (lane == 0) { wm[i * 4 + ch] = M; ws[i * 4 + ch] = S; }
+    }
+    __syncthreads();
+    for (int i = tid; i < n_ent; i += nt) {
+        float M = wm[i * 4];
+        for (int ch = 1; ch < nch; ch++) M = fmaxf(M, wm[i * 4 + ch]);
+        float S = 0.f;
+        for (int ch = 0; ch < nch; ch++) S += ws[i * 4 + ch] == 0.f ? 0.f : ws[i * 4 + ch] * __builtin_amdgcn_exp2f(wm[i * 4 + ch] - M);
+        const double scv = ((double)__builtin_amdgcn_logf(S) + (double)M) * 0.6931471805599453 - norm;
+        sc_l[i] = scv;
+        A.score[ent_id[i]] = scv;
+    }
+    __syncthreads();
+    // ---- (4) vec (unigram_acoustic_wordseg.py:474-511), the DP by wave 0
+    for (int j = tid; j < tri; j += nt) {
+        const int i = ent_of[j];
+        double v = NEG_INF_D;
+        if (i >= 0) {
+            const double dd = dur_l[j];
+            v = isnan(dd) ? NEG_INF_D : sc_l[i] * (A.time_power_term == 1.0 ? dd : pow(dd, A.time_power_term));
+        }
+        vec[j] = v + A.wip;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const int n_old = N <= 64 ? fb_collect_tokens_wave(vid_l, bnd_l, N, old_l, lane)
+                                  : __shfl(lane == 0 ? fb_collect_tokens(vid_l, bnd_l, N, old_l) : 0, 0);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        CounterUniforms usrc = {bt.seed, A.sweep, (uint64_t)utt, 0};
+        const double total = fb_dp_sample(vec, al, ww, pr, N, tri, A.n_max, 0, 0.0, A.anneal_fb, bnd_l, lane, usrc, bt.fast_dp);
+        if (A.probe_alpha)
+            for (int j = lane; j < N; j += 64) A.probe_alpha[(int64_t)utt * NM + j] = al[j];
+        for (int j = lane; j < n_old; j += 64) bt.slot[old_l[j]] = -1;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // the new segments: embedding row and span, in order
+        int nn = 0;
+        if (N <= 64) {
+            const unsigned long long mask = __ballot(lane < N && bnd_l[lane < N ? lane : 0] != 0);
+            const bool bit = lane < N && ((mask >> lane) & 1ull);
+            const unsigned long long below = mask & ((1ull << lane) - 1ull);
+            const int jp = below ? 64 - __clzll((long long)below) : 0;
+            const int j = bit ? (lane + 1) * lane / 2 + jp : 0;
+            const int id = bit ? vid_l[j] : -1;
+            const unsigned long long keep = __ballot(bit && id >= 0);
+            if (bit && id >= 0) {
+                const int pos = __popcll(keep & ((1ull << lane) - 1ull));
+                tok_l[pos] = id;
+                tokj_l[pos] = j;
+            }
+            nn = __popcll(keep);
+        } else if (lane == 0) {
+            int jp = 0;
+            for (int j2 = 0; j2 < N; j2++)
+                if (bnd_l[j2]) {
+                    const int j = (j2 + 1) * j2 / 2 + jp;
+                    const int id = vid_l[j];
+                    if (id >= 0) { tok_l[nn] = id; tokj_l[nn] = j; nn++; }
+                    jp = j2 + 1;
+                }
+        }
+        if (N > 64) nn = __shfl(nn, 0);
+        for (int j = lane; j < N; j += 64) bnd_g[j] = bnd_l[j];
+        for (int t = lane; t < nn; t += 64) A.new_tok[(int64_t)utt * NM + t] = tok_l[t];
+        if (lane == 0) {
+            if (total == NEG_INF_D) atomicOr(A.status, 16);
+            A.out_logprob[utt] = total;
+            A.n_new[utt] = nn;
+            sh_nn = nn;
+        }
+    }
+    __syncthreads();
+    // ---- (5) the new segments' slots: one wave per token (fbgmm.py:422-463; no language model: the draws are independent)
+    const int nn = sh_nn;
+    const float inv_T = (float)(1. / A.anneal_am);
+    for (int t = wv; t < nn; t += nw) {
+        const int64_t e = tok_l[t];
+        const float *zr = Lm + (int64_t)ent_of[tokj_l[t]] * KM;
+        double *zq = zp + (int64_t)wv * KM;
+        float mx = -3.0e38f;
+        for (int k = lane; k < KM; k += 64) mx = fmaxf(mx, zr[k]);
+        mx = fb_wave_max_f32(mx);
+        float sm = 0.f;
+        for (int k = lane; k < KM; k += 64) sm += __builtin_amdgcn_exp2f(zr[k] - mx);
+        float lse2 = mx + __builtin_amdgcn_logf(fb_wave_sum_f32(sm));
+        if (A.anneal_am != 1.0) {                            // fbgmm.py:446-449
+            float mx2 = -3.0e38f;
+            for (int k = lane; k < KM; k += 64) mx2 = fmaxf(mx2, inv_T * (zr[k] - lse2));
+            mx2 = fb_wave_max_f32(mx2);
+            float sm2 = 0.f;
+            for (int k = lane; k < KM; k += 64) sm2 += __builtin_amdgcn_exp2f(inv_T * (zr[k] - lse2) - mx2);
+            const float lse3 = mx2 + __builtin_amdgcn_logf(fb_wave_sum_f32(sm2));
+            for (int k = lane; k < KM; k += 64) zq[k] = (double)__builtin_amdgcn_exp2f(inv_T * (zr[k] - lse2) - lse3);
+        } else {
+            for (int k = lane; k < KM; k += 64) zq[k] = (double)__builtin_amdgcn_exp2f(zr[k] - lse2);
+        }
+        if (A.probe_ll)
+            for (int k = lane; k < KM; k += 64)
+                A.probe_ll[((int64_t)utt * NM + t) * A.probe_ld + k] = (double)zr[k] * 0.6931471805599453 - prk[k];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int kd = fb_draw_chunked(zq, KM, segk_u01(bt.seed, A.sweep, (uint64_t)utt, (uint64_t)(NM + t)), lane);
+        if (lane == 0) bt.slot[e] = kd;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // calibration of the roofline of k_fbb_score_diag32: the same four float32 instructions per term (subtract, multiply,
 // multiply-add, v_log_f32) and the accumulate, operands in registers, eight independent chains per thread -- what the
 // vector ALUs deliver on this chip for the kernel's inner term with nothing else in the way
@@ -2133,6 +2411,61 @@ int32_t segk_fbb_assign_diag32(segk_ctx *ctx, const segk_corpus *c, const segk_f
 {
     SEGK_REQUIRE(f && f->cov_type == 1, "the float32 token likelihoods of this entry point are the diagonal (Student-t) ones");
     return fbb_assign_impl(ctx, c, f, bt, s_lo, s_n, b, n_utts, sweep, anneal_temp, new_tok, n_new, nullptr, 0, 1, stream);
+}
+
+int32_t segk_fbb_step_diag32(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *f, const segk_fbatch *bt, int32_t s_lo,
+                             int32_t s_n, int32_t b, const int32_t *n_utts, uint64_t sweep, int32_t n_slices_min,
+                             int32_t n_slices_max, double wip, double time_power_term, double anneal_temp_fb,
+                             double anneal_temp_am, double *score, uint8_t *boundaries, int32_t *new_tok, int32_t *n_new,
+                             double *out_logprob, int32_t *status, void *stream)
+{
+    SEGK_REQUIRE(ctx, "context");
+    int rc = check_fbb(c, f, bt);
+    if (rc) return rc;
+    SEGK_REQUIRE(f->cov_type == 1, "the fused float32 Gibbs step is the diagonal (Student-t) one");
+    SEGK_REQUIRE(n_slices_min == 0 || n_slices_min == 1, "n_slices_min must be 0 or 1");
+    SEGK_REQUIRE(score && boundaries && new_tok && n_new && out_logprob && status, "step operands");
+    const char *env = getenv("SEGK_FBB_FUSED");
+    if (env && atoi(env) == 0) { segk_set_error("segk_fbb_step_diag32: disabled (SEGK_FBB_FUSED=0)"); return SEGK_ERR_UNSUPPORTED; }
+    if (f->lm_unigram || !bt->prior_rows || f->K_max > 256 || c->D > 256) {
+        segk_set_error("segk_fbb_step_diag32: needs prior_rows, no language model, K_max <= 256, D <= 256");
+        return SEGK_ERR_UNSUPPORTED;
+    }
+    FbbMap m;
+    rc = make_map(&m, s_lo, s_n, n_utts, 1);
+    if (rc) return rc;
+    if (m.off[s_n] == 0) return SEGK_OK;
+    const int KM = f->K_max, D = c->D, NM = c->N_max, nw = 8;
+    const int64_t triMax = (int64_t)NM * (NM + 1) / 2;
+    // spans with an embedding per utterance at most: the band (an utterance longer than the window) or the triangle of a short one
+    int64_t r_cap = triMax;
+    if (c->band_ids && c->band_dur && n_slices_max > 0 && n_slices_max < NM && c->band_W == n_slices_max) {
+        const int64_t t_short = (int64_t)n_slices_max * (n_slices_max + 1) / 2;
+        r_cap = (int64_t)NM * c->band_W > t_short ? (int64_t)NM * c->band_W : t_short;
+        if (r_cap > triMax) r_cap = triMax;
+    }
+    r_cap = (r_cap + 7) & ~(int64_t)7;
+    const size_t lds = sizeof(double) * (size_t)(2 * triMax + 3 * NM + 2 + 2 * r_cap + (int64_t)nw * KM + KM) +
+                       sizeof(float) * (size_t)(2 * (int64_t)D * KM + D * r_cap + r_cap * KM + 8 * r_cap) + 16 +
+                       sizeof(int32_t) * (size_t)(triMax + 2 * r_cap + 3 * NM) + sizeof(short) * (size_t)((triMax + 3) & ~(int64_t)3) +
+                       (size_t)((NM + 15) & ~15);
+    if (lds > 150 * 1024) {
+        segk_set_error("segk_fbb_step_diag32: the slot tables and the logits of an utterance (%lld spans x %d slots) do not fit in LDS",
+                       (long long)r_cap, KM);
+        return SEGK_ERR_UNSUPPORTED;
+    }
+    FbbStepArgs A{};
+    A.sweep = sweep; A.b = b; A.n_max = n_slices_max; A.r_cap = (int)r_cap;
+    A.wip = wip; A.time_power_term = time_power_term; A.anneal_fb = anneal_temp_fb; A.anneal_am = anneal_temp_am;
+    A.prior_alpha = f->alpha;
+    A.score = score; A.boundaries = boundaries; A.new_tok = new_tok; A.n_new = n_new; A.out_logprob = out_logprob; A.status = status;
+    A.probe_alpha = ctx->probe_alpha; A.probe_ll = ctx->probe_ll; A.probe_ld = ctx->probe_ll_ld;
+    DISPATCH_XT(c, {
+        SEGK_CHECK_HIP(segk_dyn_lds((const void *)k_fbb_step_diag32<XT>, lds));
+        hipLaunchKernelGGL(k_fbb_step_diag32<XT>, dim3(m.off[s_n]), dim3(64 * nw), lds, (hipStream_t)stream, *c, *f, *bt, m, A);
+    });
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
 }
 
 int32_t segk_fbb_set_probe(segk_ctx *ctx, double *alpha_out, double *ll_out, int64_t ll_ld)

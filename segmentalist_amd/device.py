@@ -936,6 +936,7 @@ class FbgmmBatchSweeper(object):
         self.score_f32 = score_precision in ("f32", "f16") and df.cov_type == 0
         self.score_f16 = score_precision == "f16"
         self.score_diag32 = score_precision == "f32" and df.cov_type == 1
+        self._fused = None             # segk_fbb_step_diag32: None = not tried yet, False = the library refused (unsupported shape)
         c = df.corpus
         self.S, self.B = int(n_stat_blocks), int(n_gibbs_blocks)
         rank, world = self.comm.rank, self.comm.world
@@ -1095,6 +1096,20 @@ class FbgmmBatchSweeper(object):
             if self.lm_tok is not None:
                 check(L.segk_fbb_lm_apply(ctx, cp, fp, bp, b, -1, st))
             check(L.segk_fbb_prepare(ctx, cp, fp, bp, b, st))
+            if self.score_diag32 and self.lm_tok is None and self._fused is not False:
+                # span scores, boundaries and slots of the block by ONE launch where the library can (segk_fbb_step_diag32)
+                rc = L.segk_fbb_step_diag32(ctx, cp, fp, bp, self.s_lo, self.s_n, b, self._n_utts[b], sw, int(n_slices_min),
+                                            int(n_slices_max), float(wip), float(time_power_term), float(anneal_temp_fb),
+                                            float(anneal_temp_am), ptr(df.score), ptr(boundaries), ptr(df.new_tok),
+                                            ptr(df.n_new), ptr(df.out_logprob), ptr(df.status), st)
+                if rc == _abi.SEGK_ERR_UNSUPPORTED:
+                    self._fused = False
+                else:
+                    check(rc)
+                    self._fused = True
+                    check(L.segk_fbb_partials(ctx, cp, fp, bp, self.s_lo, self.s_n, b, ptr(df.new_tok), ptr(df.n_new), st))
+                    self._gather(self.partials, b)
+                    continue
             if self.score_f32:
                 check(L.segk_fbb_score_f32(ctx, cp, fp, bp, ptr(self._block_rows[b]), self._block_rows[b].numel(),
                                            ptr(df.score), st))

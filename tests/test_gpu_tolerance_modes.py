@@ -71,7 +71,7 @@ def _pair(kind, n_utt, D, K, prec, B=3, S=2, seed=5):
     return ref, nb.FbgmmBatch(ref, n_gibbs_blocks=B, n_stat_blocks=S, seed=11), seg
 
 
-def _one_step(sw, seg, b, sweep=0):
+def _one_step(sw, seg, b, sweep=0, fused=False):
     """Gibbs step b of the sampler as FbgmmBatchSweeper.sweep enqueues it, without the partial-sum refresh (so that every
     step of this test conditions on the INITIAL state of the other blocks, which is what the specification object holds)."""
     import torch
@@ -81,6 +81,13 @@ def _one_step(sw, seg, b, sweep=0):
     if sw.lm_tok is not None:
         check(L.segk_fbb_lm_apply(ctx, cp, fp, bp, b, -1, st))
     check(L.segk_fbb_prepare(ctx, cp, fp, bp, b, st))
+    if fused:                  # the three calls below as one launch (diagonal components, float32 terms)
+        check(L.segk_fbb_step_diag32(ctx, cp, fp, bp, sw.s_lo, sw.s_n, b, sw._n_utts[b], sweep, 0, 6, 0.0, 1.0, 1.0, 1.0,
+                                     ptr(df.score), ptr(seg._dev_bounds), ptr(df.new_tok), ptr(df.n_new), ptr(df.out_logprob),
+                                     ptr(df.status), st))
+        torch.cuda.synchronize()
+        df.check_status()
+        return
     if sw.score_f32:
         check(L.segk_fbb_score_f32(ctx, cp, fp, bp, ptr(sw._block_rows[b]), sw._block_rows[b].numel(), ptr(df.score), st))
     elif sw.score_diag32:
@@ -110,6 +117,8 @@ def _one_step(sw, seg, b, sweep=0):
 
 CASES = [
     ("diag", "f32", 48, 39, 100, None),            # configs[1] shape: float32 Student-t token likelihoods, fast_dp
+    ("diag", "f32", 48, 39, 100, "fused"),         # ... the Gibbs step as one launch (segk_fbb_step_diag32)
+    ("diag", "f32", 40, 20, 160, "fused"),         # ... with three chunks of 64 slots
     ("fixed", "f16", 48, 39, 100, None),           # fp16x2 token likelihoods, block-wide draw kernel, fast_dp
     ("fixed", "f32", 48, 39, 100, None),           # fp32 MFMA span scores, fp64 token likelihoods, fast_dp
     ("bigram", "f16", 48, 100, 1000, None),        # configs[4] shape: one wave per utterance, hardware log / exp
@@ -120,12 +129,14 @@ CASES = [
 
 
 @pytest.mark.parametrize("kind,prec,n_utt,D,K,wave", CASES,
-                         ids=["%s_%s_D%d_K%d%s" % (c[0], c[1], c[3], c[4], "" if c[5] is None else "_blockwide") for c in CASES])
+                         ids=["%s_%s_D%d_K%d%s" % (c[0], c[1], c[3], c[4], "" if c[5] is None else "_fused" if c[5] == "fused" else "_blockwide")
+                              for c in CASES])
 def test_token_likelihoods_and_forward_filter_within_the_contract(gpu, monkeypatch, kind, prec, n_utt, D, K, wave):
     torch = gpu
     from segmentalist_amd import _abi
     from segmentalist_amd._abi import check, ptr
-    if wave is not None:
+    fused = wave == "fused"
+    if wave is not None and not fused:
         monkeypatch.setenv("SEGK_FBB_ASSIGN_WAVE", wave)
     ref, spec, seg = _pair(kind, n_utt, D, K, prec)
     sw = seg._get_sweeper()
@@ -139,7 +150,7 @@ def test_token_likelihoods_and_forward_filter_within_the_contract(gpu, monkeypat
     check(L.segk_fbb_set_probe(ctx, ptr(alpha), ptr(ll), K))
     try:
         for b in range(sw.B):
-            _one_step(sw, seg, b)
+            _one_step(sw, seg, b, fused=fused)
     finally:
         check(L.segk_fbb_set_probe(ctx, None, None, 0))
     alpha, ll = alpha.cpu().numpy(), ll.cpu().numpy().reshape(n_utt, N_max, K)
@@ -189,7 +200,7 @@ def test_token_likelihoods_and_forward_filter_within_the_contract(gpu, monkeypat
                 # of the probabilities in slot order (utils.draw).  Probabilities out of the device's own fp64 token
                 # log-likelihoods and the specification's prior (the device: v_log_f32 / v_exp_f32, ~3e-6 relative; the
                 # one-wave kernel sums the occupied slots and the block of equal empty ones separately)
-                if kind == "bigram":
+                if kind == "bigram" or fused:
                     j_prev = None
                     for t in range(n_new[i]):
                         z = spec.prior_z(d, j_prev, uni, big) + ll[i, t]
@@ -201,11 +212,11 @@ def test_token_likelihoods_and_forward_filter_within_the_contract(gpu, monkeypat
                         below = cum[k - 1] if k > 0 else 0.0
                         worst_draw = max(worst_draw, below - uu, uu - cum[k])
                         n_drawn_empty += int(not d["active"][k])
-                        j_prev = k
+                        j_prev = k if kind == "bigram" else None
     print("%s %s D=%d K=%d: token log-likelihoods worst %.3g (over %d tokens x %d slots, %.0f occupied per token); "
           "alphas worst %.3g against fp64 on the device's scores, %.3g against the specification"
           % (kind, prec, D, K, worst_ll, n_tok, K, n_occ / max(n_tok, 1), worst_a_own, worst_a_spec))
-    if kind == "bigram":
+    if kind == "bigram" or fused:
         print("draws: worst distance of a token's uniform from its slot's interval %.3g; %d of %d tokens drew an empty slot"
               % (worst_draw, n_drawn_empty, n_tok))
         assert worst_draw < 1e-4, worst_draw
@@ -213,3 +224,25 @@ def test_token_likelihoods_and_forward_filter_within_the_contract(gpu, monkeypat
     assert worst_ll < TOL, worst_ll
     assert worst_a_own < TOL, worst_a_own
     assert worst_a_spec < TOL, worst_a_spec
+
+
+def test_fused_gibbs_step_gives_the_span_scores_and_boundaries_of_the_three_launches(gpu):
+    """segk_fbb_step_diag32 against segk_fbb_score_diag32 + segk_fbb_segment + segk_fbb_assign_diag32 from identical states,
+    every block of a sweep: the span scores and the boundaries bit for bit (the same arithmetic and the same uniforms); the
+    slots agree wherever the token's uniform does not fall within the last bits of a cumulative boundary (the token
+    likelihoods of the two forms differ in their last float32 bits)."""
+    out = []
+    for fused in (False, True):
+        ref, spec, seg = _pair("diag", 64, 39, 100, "f32")
+        sw = seg._get_sweeper()
+        sw.enter(seg._dev_bounds)
+        for b in range(sw.B):
+            _one_step(sw, seg, b, fused=fused)
+        out.append((seg._df.score.cpu().numpy().copy(), seg._dev_bounds.cpu().numpy().copy(), sw.slot.cpu().numpy().copy(),
+                    seg._df.out_logprob.cpu().numpy().copy(), seg._df.n_new.cpu().numpy().copy()))
+    a, b_ = out
+    assert np.array_equal(a[0], b_[0])
+    assert np.array_equal(a[1], b_[1])
+    assert np.array_equal(a[3], b_[3]) and np.array_equal(a[4], b_[4])
+    both = (a[2] >= 0) | (b_[2] >= 0)
+    assert np.mean(a[2][both] == b_[2][both]) > 0.98, np.mean(a[2][both] == b_[2][both])
