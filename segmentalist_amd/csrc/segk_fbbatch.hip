@@ -900,7 +900,8 @@ __global__ __launch_bounds__(512) void k_fbb_step_diag32(segk_corpus c, segk_fbg
     int32_t *tokj_l = tok_l + NM;                       // [N_max]
     short *ent_of = (short *)(tokj_l + NM);             // [triMax] span -> its place in the list (-1)
     uint8_t *bnd_l = (uint8_t *)(ent_of + ((triMax + 3) & ~(int64_t)3));    // [N_max]
-    __shared__ int sh_nent, sh_nn;
+    short *occ_l = (short *)(bnd_l + ((NM + 15) & ~15));                     // [K_max] the occupied slots, then the empty ones
+    __shared__ int sh_nent, sh_nn, sh_nocc;
     int s, idx;
     if (!fbb_locate(map, blockIdx.x, &s, &idx)) return;
     const int slice = map.lo[s];
@@ -932,6 +933,25 @@ __global__ __launch_bounds__(512) void k_fbb_step_diag32(segk_corpus c, segk_fbg
         for (int j = tid; j < tri; j += nt) { vid_l[j] = tab.vid[j]; dur_l[j] = tab.dur[j]; }
     }
     __syncthreads();
+    if (tid >= 64 && tid < 128) {                       // the occupied slots first, the empty ones behind them (a wave of 64
+        int no = 0;                                     // consecutive slots, half of them empty, paid the terms for all 64)
+        for (int k0 = 0; k0 < KM; k0 += 64) {
+            const int k = k0 + lane;
+            const bool occ = k < KM && bt.cnt[k] > 0.0;
+            const unsigned long long m = __ballot(occ);
+            if (occ) occ_l[no + __popcll(m & ((1ull << lane) - 1ull))] = (short)k;
+            no += __popcll(m);
+        }
+        int ne = 0;
+        for (int k0 = 0; k0 < KM; k0 += 64) {
+            const int k = k0 + lane;
+            const bool emp = k < KM && !(bt.cnt[k] > 0.0);
+            const unsigned long long m = __ballot(emp);
+            if (emp) occ_l[no + ne + __popcll(m & ((1ull << lane) - 1ull))] = (short)k;
+            ne += __popcll(m);
+        }
+        if (lane == 0) sh_nocc = no;
+    }
     if (tid < 64) {                                     // the spans with an embedding, in table order (ballot + prefix count)
         int n = 0;
         for (int j0 = 0; j0 < tri; j0 += 64) {
@@ -961,14 +981,19 @@ __global__ __launch_bounds__(512) void k_fbb_step_diag32(segk_corpus c, segk_fbg
     if (A.probe_ll)
         for (int k = tid; k < KM; k += nt) prk[k] = bt.cnt[k] > 0.0 ? bt.zconst[k] - bt.lconst[k] : zc_empty;
     __syncthreads();
-    // ---- (2) L: work item = (group of eight spans, slot)
+    // ---- (2) L: work item = (group of eight spans, occupied slot); the empty slots' logits need no terms
     {
-        const int n_items = (n_pad >> 3) * KM;
+        const int n_occ = sh_nocc;
+        for (int item = tid; item < n_pad * (KM - n_occ); item += nt) {
+            const int i = item / (KM - n_occ), k = occ_l[n_occ + item - i * (KM - n_occ)];
+            Lm[(int64_t)i * KM + k] = (float)((zc_empty + lpr[i]) * 1.4426950408889634);
+        }
+        const int n_items = (n_pad >> 3) * n_occ;
         for (int item = tid; item < n_items; item += nt) {
-            const int g = item / KM, k = item - g * KM, r0 = 8 * g;
+            const int g = item / n_occ, k = occ_l[item - g * n_occ], r0 = 8 * g;
             const float *xg = xs + r0;
             float z2[8];
-            if (bt.cnt[k] > 0.0) {
+            {
                 f32x2_t acc2[4];
 #pragma unroll
                 for (int r = 0; r < 4; r++) acc2[r] = (f32x2_t){0.f, 0.f};
@@ -988,9 +1013,6 @@ __global__ __launch_bounds__(512) void k_fbb_step_diag32(segk_corpus c, segk_fbg
                 const double zc = bt.zconst[k], hl = bt.half[k] * 0.6931471805599453;
 #pragma unroll
                 for (int r = 0; r < 8; r++) z2[r] = (float)((zc - hl * (double)acc2[r >> 1][r & 1]) * 1.4426950408889634);
-            } else {
-#pragma unroll
-                for (int r = 0; r < 8; r++) z2[r] = (float)((zc_empty + lpr[r0 + r]) * 1.4426950408889634);
             }
 #pragma unroll
             for (int r = 0; r < 8; r++) Lm[(int64_t)(r0 + r) * KM + k] = z2[r];
@@ -998,12 +1020,25 @@ __global__ __launch_bounds__(512) void k_fbb_step_diag32(segk_corpus c, segk_fbg
     }
     __syncthreads();
     // ---- (3) span scores: (maximum, sum) per chunk of 64 slots by one wave, the chunks in order by the span's thread
-    for (int pair = wv; pair < n_ent * nch; pair += nw) {
-        const int i = pair / nch, ch = pair - i * nch, k = 64 * ch + lane;
-        const float v = k < KM ? Lm[(int64_t)i * KM + k] : -3.0e38f;
-        const float M = fb_wave_max_f32(v);
-        const float S = fb_wave_sum_f32(k < KM ? __builtin_amdgcn_exp2f(v - M) : 0.f);
-        if (lane == 0) { wm[i * 4 + ch] = M; ws[i * 4 + ch] = S; }
+    // (four pairs per trip: the two reductions of a pair are one dependent chain of DPP steps)
+    for (int p0 = 4 * wv; p0 < n_ent * nch; p0 += 4 * nw) {
+        float v[4], M[4], S[4];
+        int ii[4], cc[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int pair = p0 + u < n_ent * nch ? p0 + u : n_ent * nch - 1;
+            ii[u] = pair / nch;
+            cc[u] = pair - ii[u] * nch;
+            const int k = 64 * cc[u] + lane;
+            v[u] = k < KM ? Lm[(int64_t)ii[u] * KM + k] : -3.0e38f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) M[u] = fb_wave_max_f32(v[u]);
+#pragma unroll
+        for (int u = 0; u < 4; u++) S[u] = fb_wave_sum_f32(64 * cc[u] + lane < KM ? __builtin_amdgcn_exp2f(v[u] - M[u]) : 0.f);
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (lane == 0 && p0 + u < n_ent * nch) { wm[ii[u] * 4 + cc[u]] = M[u]; ws[ii[u] * 4 + cc[u]] = S[u]; }
     }
     __syncthreads();
     for (int i = tid; i < n_ent; i += nt) {
@@ -2448,7 +2483,7 @@ int32_t segk_fbb_step_diag32(segk_ctx *ctx, const segk_corpus *c, const segk_fbg
     const size_t lds = sizeof(double) * (size_t)(2 * triMax + 3 * NM + 2 + 2 * r_cap + (int64_t)nw * KM + KM) +
                        sizeof(float) * (size_t)(2 * (int64_t)D * KM + D * r_cap + r_cap * KM + 8 * r_cap) + 16 +
                        sizeof(int32_t) * (size_t)(triMax + 2 * r_cap + 3 * NM) + sizeof(short) * (size_t)((triMax + 3) & ~(int64_t)3) +
-                       (size_t)((NM + 15) & ~15);
+                       (size_t)((NM + 15) & ~15) + sizeof(short) * (size_t)KM;
     if (lds > 150 * 1024) {
         segk_set_error("segk_fbb_step_diag32: the slot tables and the logits of an utterance (%lld spans x %d slots) do not fit in LDS",
                        (long long)r_cap, KM);
