@@ -865,6 +865,8 @@ struct FbbStepArgs {
     int32_t *status;
     double *probe_alpha, *probe_ll;
     int64_t probe_ld;
+    int dbg;                           // development (make DEV=1, SEGK_STEP_DBG; results wrong): 1 no terms, 2 no span-score reductions,
+                                       // 4 no DP, 8 no draws, 16 return behind the staging
 };
 
 template <typename XT>
@@ -981,9 +983,10 @@ __global__ __launch_bounds__(512) void k_fbb_step_diag32(segk_corpus c, segk_fbg
     if (A.probe_ll)
         for (int k = tid; k < KM; k += nt) prk[k] = bt.cnt[k] > 0.0 ? bt.zconst[k] - bt.lconst[k] : zc_empty;
     __syncthreads();
+    if (A.dbg & 16) return;
     // ---- (2) L: work item = (group of eight spans, occupied slot); the empty slots' logits need no terms
     {
-        const int n_occ = sh_nocc;
+        const int n_occ = (A.dbg & 1) ? 0 : sh_nocc;
         for (int item = tid; item < n_pad * (KM - n_occ); item += nt) {
             const int i = item / (KM - n_occ), k = occ_l[n_occ + item - i * (KM - n_occ)];
             Lm[(int64_t)i * KM + k] = (float)((zc_empty + lpr[i]) * 1.4426950408889634);
@@ -1021,7 +1024,7 @@ __global__ __launch_bounds__(512) void k_fbb_step_diag32(segk_corpus c, segk_fbg
     __syncthreads();
     // ---- (3) span scores: (maximum, sum) per chunk of 64 slots by one wave, the chunks in order by the span's thread
     // (four pairs per trip: the two reductions of a pair are one dependent chain of DPP steps)
-    for (int p0 = 4 * wv; p0 < n_ent * nch; p0 += 4 * nw) {
+    for (int p0 = 4 * wv; p0 < ((A.dbg & 2) ? 0 : n_ent * nch); p0 += 4 * nw) {
         float v[4], M[4], S[4];
         int ii[4], cc[4];
 #pragma unroll
@@ -1068,7 +1071,7 @@ __global__ __launch_bounds__(512) void k_fbb_step_diag32(segk_corpus c, segk_fbg
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         CounterUniforms usrc = {bt.seed, A.sweep, (uint64_t)utt, 0};
-        const double total = fb_dp_sample(vec, al, ww, pr, N, tri, A.n_max, 0, 0.0, A.anneal_fb, bnd_l, lane, usrc, bt.fast_dp);
+        const double total = (A.dbg & 4) ? 0.0 : fb_dp_sample(vec, al, ww, pr, N, tri, A.n_max, 0, 0.0, A.anneal_fb, bnd_l, lane, usrc, bt.fast_dp);
         if (A.probe_alpha)
             for (int j = lane; j < N; j += 64) A.probe_alpha[(int64_t)utt * NM + j] = al[j];
         for (int j = lane; j < n_old; j += 64) bt.slot[old_l[j]] = -1;
@@ -1112,7 +1115,7 @@ __global__ __launch_bounds__(512) void k_fbb_step_diag32(segk_corpus c, segk_fbg
     }
     __syncthreads();
     // ---- (5) the new segments' slots: one wave per token (fbgmm.py:422-463; no language model: the draws are independent)
-    const int nn = sh_nn;
+    const int nn = (A.dbg & 8) ? 0 : sh_nn;
     const float inv_T = (float)(1. / A.anneal_am);
     for (int t = wv; t < nn; t += nw) {
         const int64_t e = tok_l[t];
@@ -2495,6 +2498,7 @@ int32_t segk_fbb_step_diag32(segk_ctx *ctx, const segk_corpus *c, const segk_fbg
     A.prior_alpha = f->alpha;
     A.score = score; A.boundaries = boundaries; A.new_tok = new_tok; A.n_new = n_new; A.out_logprob = out_logprob; A.status = status;
     A.probe_alpha = ctx->probe_alpha; A.probe_ll = ctx->probe_ll; A.probe_ld = ctx->probe_ll_ld;
+    A.dbg = segk_dev_env("SEGK_STEP_DBG");
     DISPATCH_XT(c, {
         SEGK_CHECK_HIP(segk_dyn_lds((const void *)k_fbb_step_diag32<XT>, lds));
         hipLaunchKernelGGL(k_fbb_step_diag32<XT>, dim3(m.off[s_n]), dim3(64 * nw), lds, (hipStream_t)stream, *c, *f, *bt, m, A);
