@@ -383,12 +383,111 @@ static __device__ void fb_fill_vec(const FbSpanTab &T, int N, int tri, SC score_
 // sampling (or Viterbi back-tracking) writing the boundaries; returns the summed score of the chosen
 // segments.  Control flow and values are wave-uniform; the exponentials of each logsumexp /
 // normalisation are spread over the lanes, sums and draws keep the reference order.
+// The sampling DP of the tolerance modes (segk_fbatch.fast_dp; windows of at most sixteen slices, at most 64 landmarks) in
+// FLOAT32: lane w holds candidate s = t - 1 - w and alpha[s] (a delay line shifted by one lane per step), maximum and sum over
+// the window's lanes by DPP inside the row of sixteen, v_exp_f32 / v_log_f32 -- half the instructions of the fp64 form with
+// hardware exponentials, whose lone wave was 20 us of a Gibbs step's critical path.  alpha is of the order of 1e3: float32
+// carries it to ~1e-7 relative, the contract of these modes is 1e-4 (tests/test_gpu_tolerance_modes.py holds the values
+// against the fp64 recurrence).  The chosen segments' scores are summed in fp64 as before; a [N] receives alpha (probe).
+static __device__ __forceinline__ float fb_row16_max_f32(float v)
+{
+    v = fmaxf(v, fb_dpp_f32<0xB1>(v));
+    v = fmaxf(v, fb_dpp_f32<0x4E>(v));
+    v = fmaxf(v, fb_dpp_f32<0x141>(v));
+    v = fmaxf(v, fb_dpp_f32<0x140>(v));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+}
+static __device__ __forceinline__ float fb_row16_sum_f32(float v)
+{
+    v += fb_dpp_f32<0xB1>(v);
+    v += fb_dpp_f32<0x4E>(v);
+    v += fb_dpp_f32<0x141>(v);
+    v += fb_dpp_f32<0x140>(v);
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+}
+template <typename USRC>
+static __device__ double fb_dp_sample_fast32(const double *vec, double *a, int N, int tri, int n_max, float log_p_continue,
+                                             double anneal_temp, uint8_t *bnd, int lane, USRC &usrc)
+{
+    const float NINF = -__builtin_huge_valf(), LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+    for (int j = lane; j < N; j += 64) bnd[j] = (j == N - 1) ? 1 : 0;
+    if (lane == 0) a[0] = 0.0;
+    int i = 0;
+    float g = 0.f;                                                   // alpha[t - 1 - lane]
+    for (int t = 1; t < N; t++) {
+        const int lo = t - n_max < 0 ? 0 : t - n_max, n = t - lo;
+        const float v = lane < n ? (float)vec[i + t - 1 - lane] + g : NINF;
+        const bool all_inf = __ballot(lane < n && v != NINF) == 0ull;
+        float at = NINF;
+        if (!all_inf) {
+            const float m0 = fb_row16_max_f32(v);
+            const float sm = fb_row16_sum_f32(lane < n ? __builtin_amdgcn_exp2f((v - m0) * LOG2E) : 0.f);
+            at = __builtin_amdgcn_logf(sm) * LN2 + m0 + log_p_continue;
+        }
+        const float gs = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(g), 0x138, 0xF, 0xF, false));      // wave_shr:1
+        g = lane == 0 ? at : gs;
+        if (lane == 0) a[t] = (double)at;
+        i += t;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    int t = N;
+    double total = 0.0;
+    for (;;) {
+        i = (t - 1) * t / 2;
+        int lo = t - n_max < 0 ? 0 : t - n_max;
+        // lane w: candidate s = t - 1 - w (the shortest segment first: the order the draw walks)
+        float xw = lane < t - lo ? (float)vec[i + t - 1 - lane] + (float)a[t - 1 - lane] : NINF;
+        bool all_inf = __ballot(lane < t - lo && xw != NINF) == 0ull;
+        if (all_inf) {                                               // unigram_acoustic_wordseg.py:815-825: step back to a landmark that can end a segment
+            while (all_inf) {
+                t = t - 1;
+                if (t == 0) break;
+                i = (t - 1) * t / 2;
+                lo = t - n_max < 0 ? 0 : t - n_max;
+                xw = lane < t - lo ? (float)vec[i + t - 1 - lane] + (float)a[t - 1 - lane] : NINF;
+                all_inf = __ballot(lane < t - lo && xw != NINF) == 0ull;
+            }
+            if (lane == 0) bnd[(t - 1 + N) % N] = 1;
+        }
+        int k = 1;
+        if (t > 0) {
+            const int n = t - lo;
+            const float m0 = fb_row16_max_f32(xw);
+            float lse = __builtin_amdgcn_logf(fb_row16_sum_f32(lane < n ? __builtin_amdgcn_exp2f((xw - m0) * LOG2E) : 0.f)) * LN2 + m0;
+            if (anneal_temp != 1.0) {
+                const float inv = (float)(1. / anneal_temp);
+                xw = lane < n ? inv * (xw - lse) : NINF;
+                const float m1 = fb_row16_max_f32(xw);
+                lse = __builtin_amdgcn_logf(fb_row16_sum_f32(lane < n ? __builtin_amdgcn_exp2f((xw - m1) * LOG2E) : 0.f)) * LN2 + m1;
+            }
+            const float pl = lane < n ? __builtin_amdgcn_exp2f((xw - lse) * LOG2E) : 0.f;
+            double uu = usrc.next(lane);
+            int kk = n - 1;
+            for (int j = 0; j < n; j++) {
+                uu = uu - (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(pl), j));
+                if (uu < 0) { kk = j; break; }
+            }
+            k = kk + 1;
+        }
+        int idx = i + t - k;
+        if (idx < 0) idx += tri;
+        total += vec[idx];
+        if (t - k - 1 < 0) break;
+        if (lane == 0) bnd[t - k - 1] = 1;
+        t = t - k;
+    }
+    return total;
+}
+
 //   vec [tri] scores (LDS), a [N], w [N+1], pr [N+1] scratch (LDS), bnd [N] boundaries (global)
 template <typename USRC>
 static __device__ double fb_dp_sample(const double *vec, double *a, double *w, double *pr, int N, int tri, int n_max,
                                       int viterbi, double log_p_continue, double anneal_temp, uint8_t *bnd, int lane,
                                       USRC &usrc, int fast = 0)
 {
+    if (fast && !viterbi && n_max > 0 && n_max <= 16 && N <= 64)
+        return fb_dp_sample_fast32(vec, a, N, tri, n_max, (float)log_p_continue, anneal_temp, bnd, lane, usrc);
     for (int j = lane; j < N; j += 64) { a[j] = 1.0; bnd[j] = (j == N - 1) ? 1 : 0; }
     __builtin_amdgcn_wave_barrier();
     a[0] = 0.0;
