@@ -374,11 +374,17 @@ def main_fbgmm(args):
             _abi.check(_abi.lib().segk_calibrate_vlog(_abi.ctx(), C.byref(peak), _abi.stream()))
             if got > 0:
                 score_ms = float(np.mean(ms[:got]))
-                n_rows = float(np.mean(rows[:got]))
-                terms = n_rows * K * D
+                fused = getattr(sw, "_fused", None) is True
+                # (the fused step's events count utterances; its terms: every row of the block against the OCCUPIED slots --
+                # an empty slot's logit needs no term -- as of the final state)
+                n_rows = float(seg._corpus.n_emb) / sw.B if fused else float(np.mean(rows[:got]))
+                terms = n_rows * (occ if fused else K) * D
                 achieved = terms / (score_ms * 1e-3) / 1e9
-                out["roofline"] = {"bound": "valu", "kernel": "k_fbb_score_diag32 (float32 Student-t terms with v_log_f32, one launch per "
-                                   "Gibbs step: %d rows x %d slots x %d dimensions)" % (int(n_rows), K, D),
+                out["roofline"] = {"bound": "valu", "kernel": ("k_fbb_step_diag32 (one launch per Gibbs step: float32 Student-t terms with "
+                                   "v_log_f32 of %d rows x %d occupied slots x %d dimensions, then -- the same workgroups -- span "
+                                   "scores, the sampling DP and the draws, which are most of its time)" % (int(n_rows), occ, D)) if fused else
+                                   ("k_fbb_score_diag32 (float32 Student-t terms with v_log_f32, one launch per "
+                                    "Gibbs step: %d rows x %d slots x %d dimensions)" % (int(n_rows), K, D)),
                                    "achieved": achieved, "peak": peak.value / 1e9, "unit": "Gterm/s", "frac": achieved / (peak.value / 1e9),
                                    "traffic": None, "ms_per_launch": score_ms, "terms_per_launch": terms,
                                    "peak_source": "k_vlog_calibrate measured in this run: the kernel's inner term (v_sub, v_mul, v_fma, "

@@ -2499,10 +2499,20 @@ int32_t segk_fbb_step_diag32(segk_ctx *ctx, const segk_corpus *c, const segk_fbg
     A.score = score; A.boundaries = boundaries; A.new_tok = new_tok; A.n_new = n_new; A.out_logprob = out_logprob; A.status = status;
     A.probe_alpha = ctx->probe_alpha; A.probe_ll = ctx->probe_ll; A.probe_ld = ctx->probe_ll_ld;
     A.dbg = segk_dev_env("SEGK_STEP_DBG");
+    const bool prof = segk_prof_now(ctx);
+    const int slot = prof ? ctx->prof_n % SEGK_PROF_SLOTS : 0;
+    if (prof) SEGK_CHECK_HIP(hipEventRecord(ctx->prof_ev[slot][0], (hipStream_t)stream));
     DISPATCH_XT(c, {
         SEGK_CHECK_HIP(segk_dyn_lds((const void *)k_fbb_step_diag32<XT>, lds));
         hipLaunchKernelGGL(k_fbb_step_diag32<XT>, dim3(m.off[s_n]), dim3(64 * nw), lds, (hipStream_t)stream, *c, *f, *bt, m, A);
     });
+    if (prof) {
+        SEGK_CHECK_HIP(hipEventRecord(ctx->prof_ev[slot][1], (hipStream_t)stream));
+        ctx->prof_rows[slot] = m.off[s_n];             // (utterances: the rows are the caller's to count)
+        ctx->prof_kind = 6;
+        ctx->prof_launches = 1;
+        ctx->prof_n++;
+    }
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;
 }
