@@ -44,7 +44,7 @@ struct FbbMap {
     int off[17];
 };
 
-// Column maps of the packed fp16x2 image (k_fbb_compact), behind the constants: [K_max] column of slot k (-1: empty), [K_max] the
+// Column maps of the packed fp16x2 image (written by k_fbb_rows16), behind the constants: [K_max] column of slot k (-1: empty), [K_max] the
 // pseudo-component's (= the number of occupied slots), [K_max + 1] tiles in use, then [K_max + 1] the slot of column c.  The
 // token-likelihood matrix has the image's columns.
 static __host__ __device__ __forceinline__ int32_t *fbb_cmap(const segk_fbatch *bt, int KM)
@@ -339,6 +339,7 @@ __global__ __launch_bounds__(192) void k_fbb_prepare(segk_fbgmm f, segk_fbatch b
     const int k = blockIdx.x;
     const int S = bt.n_slices, B = bt.n_blocks, KM = f.K_max;
     const int64_t rec = fbb_rec(f, D);
+    if (k == 0 && threadIdx.x == 0 && bt.consts16) bt.consts16[KM + 1] = 0.0;      // max |row|^2 of the step's fp16x2 image (k_fbb_rows16)
     double (*my)[64] = scr[w];
     // my[s][lane] = sum over the blocks bp != b of partials[(bp * S + s) * rec + off], in block order, for every slice s: the
     // loads of eight slices x eight blocks are in flight together
@@ -1975,49 +1976,8 @@ __global__ void k_fbb_tiles32(segk_fbgmm f, segk_fbatch bt, int D, double prior_
 // Columns of the fp16x2 operand image: the occupied slots in slot order, then the pseudo-component of the empty ones; everything
 // behind is "absent".  (At configs[4] 419 of 1 000 slots are occupied in the settled chain: 14 tiles of components instead of 32
 // for the span scores and the token likelihoods -- an empty slot's score is the pseudo-component's, multiplying its tile was
-// wasted matrix work.)  One workgroup; also presets every constant to "absent".  The token-likelihood matrix has the same
-// columns: the kernels that read it go through the map.
-__global__ __launch_bounds__(1024) void k_fbb_compact(segk_fbatch bt, int KM, int32_t *cmap, int D2)
-{
-    __shared__ int wsum[16];
-    __shared__ int run;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    int32_t *inv = cmap + KM + 2;                     // [K_max + 1] slot of column c (K_max: the pseudo-component's)
-    if (tid == 0) run = 0;
-    __syncthreads();
-    for (int k0 = 0; k0 < KM; k0 += 1024) {
-        const int k = k0 + tid;
-        const bool occ = k < KM && bt.cnt[k] > 0.0;
-        const unsigned long long m = __ballot(occ);
-        if (lane == 0) wsum[wv] = __popcll(m);
-        __syncthreads();
-        int off = run;
-        for (int w = 0; w < wv; w++) off += wsum[w];
-        const int col = off + __popcll(m & ((1ull << lane) - 1ull));
-        if (k < KM) cmap[k] = occ ? col : -1;
-        if (occ) inv[col] = k;
-        __syncthreads();
-        if (tid == 0) {
-            int t = 0;
-            for (int w = 0; w < 16; w++) t += wsum[w];
-            run += t;
-        }
-        __syncthreads();
-    }
-    const int n_col = run + 1, n_t = (n_col + 31) / 32;
-    if (tid == 0) {
-        cmap[KM] = run;                               // the pseudo-component's column
-        cmap[KM + 1] = n_t;                           // tiles in use
-        inv[run] = KM;
-    }
-    for (int k = tid; k <= KM; k += 1024) bt.consts16[k] = -3.0e38;
-    if (tid == 0) bt.consts16[KM + 1] = 0.0;          // max |row|^2 of this step's image (k_fbb_rows16: atomic maximum)
-    // the columns behind the pseudo-component inside the last tile in use are multiplied too: their rows (whatever an earlier
-    // step left there, scaled for another exponent) must not overflow the fp16 image
-    const int r_hi = n_t * 32 < KM + 1 ? n_t * 32 : KM + 1;
-    for (int i = tid; i < (r_hi - n_col) * D2; i += 1024) bt.rows32[(int64_t)n_col * D2 + i] = 0.f;
-}
-
+// wasted matrix work.)  The token-likelihood matrix has the same columns: the kernels that read it go through the map
+// (fbb_cmap), which the waves of k_fbb_rows16 write.
 __global__ void k_fbb_rows16(segk_fbgmm f, segk_fbatch bt, int D, double prior_alpha, const int32_t *cmap)
 {
     const double LOG2E = 1.4426950408889634;
@@ -2026,7 +1986,31 @@ __global__ void k_fbb_rows16(segk_fbgmm f, segk_fbatch bt, int D, double prior_a
     const int k = blockIdx.x * 4 + w;
     if (k > KM) return;
     const bool occupied = k < KM && bt.cnt[k] > 0.0;
-    const int col = cmap ? cmap[k] : k;               // (k == K_max: the pseudo-component's column)
+    // The column of slot k = the number of occupied slots below it (k == K_max, the pseudo-component: all of them), counted by
+    // the slot's own wave -- sixteen counts per lane at K_max = 1 000 -- instead of a one-workgroup launch in front
+    // (k_fbb_compact, 4.8 us); every wave also writes its part of the maps behind the constants.
+    int col = k;
+    if (cmap) {
+        int below = 0;
+        for (int j0 = 0; j0 < k; j0 += 64) {
+            const int j = j0 + lane;
+            below += __popcll(__ballot(j < k && bt.cnt[j < k ? j : 0] > 0.0));
+        }
+        col = (occupied || k == KM) ? below : -1;
+        int32_t *cm = const_cast<int32_t *>(cmap), *inv = cm + KM + 2;
+        if (lane == 0) {
+            if (k < KM) cm[k] = col;
+            if (col >= 0) inv[col] = k;
+        }
+        if (k == KM) {                                // the pseudo-component's wave: the header, and what lies behind its column
+            const int n_col = below + 1, n_t = (n_col + 31) / 32;
+            if (lane == 0) { cm[KM] = below; cm[KM + 1] = n_t; }
+            // the columns behind it inside the last tile in use are multiplied too: "absent", and rows that cannot overflow the image
+            const int r_hi = n_t * 32 < KM + 1 ? n_t * 32 : KM + 1;
+            for (int c2 = n_col + lane; c2 < r_hi; c2 += 64) bt.consts16[c2] = -3.0e38;
+            for (int i = lane; i < (r_hi - n_col) * D2; i += 64) bt.rows32[(int64_t)n_col * D2 + i] = 0.f;
+        }
+    }
     if (col < 0) return;                              // an empty slot has no column
     double s = 0.0, n2 = 0.0;
     for (int d = lane; d < D; d += 64) {
@@ -2168,12 +2152,11 @@ int32_t segk_fbb_prepare(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *
     hipLaunchKernelGGL(k_fbb_prepare, dim3(f->K_max), dim3(192), 0, st, *f, *bt, c->D, b, alpha);
     if (bt->tiles16 && bt->y16 && f->cov_type == 0) {
         SEGK_REQUIRE(bt->rows32 && bt->consts16, "rows32 / consts16 scratch missing");
-        // (k_fbb_compact also clears the running maximum of the rows' norms behind the constants: a memset of 8 bytes was a launch
-        // of 4.8 us)
+        // (k_fbb_prepare cleared the running maximum of the rows' norms behind the constants: a memset of 8 bytes was a launch of
+        // 4.8 us, and so was the one-workgroup kernel that counted the columns -- every slot's wave of k_fbb_rows16 counts its own)
         // the occupied slots packed into the leading columns; the maps live behind the constants and are read by the score and
         // token-score calls of this step
         int32_t *cmap = fbb_cmap(bt, f->K_max);
-        hipLaunchKernelGGL(k_fbb_compact, dim3(1), dim3(1024), 0, st, *bt, f->K_max, cmap, 2 * c->D);
         hipLaunchKernelGGL(k_fbb_rows16, dim3((f->K_max + 1 + 3) / 4), dim3(256), 0, st, *f, *bt, c->D, alpha, (const int32_t *)cmap);
         SEGK_LAUNCH_CHECK();
         return segk_sp_prepare_tiles(bt->rows32, bt->consts16, bt->consts16 + f->K_max + 1, f->K_max + 1, 2 * c->D,
