@@ -1024,25 +1024,32 @@ __global__ __launch_bounds__(512) void k_fbb_step_diag32(segk_corpus c, segk_fbg
     }
     __syncthreads();
     // ---- (3) span scores: (maximum, sum) per chunk of 64 slots by one wave, the chunks in order by the span's thread
-    // (four pairs per trip: the two reductions of a pair are one dependent chain of DPP steps)
-    for (int p0 = 4 * wv; p0 < ((A.dbg & 2) ? 0 : n_ent * nch); p0 += 4 * nw) {
-        float v[4], M[4], S[4];
-        int ii[4], cc[4];
+    // One THREAD per (span, chunk): the maximum of the chunk's 64 logits, their exponentials and the sum in the order the wave
+    // reduction of k_fbb_score_diag32 adds them (fb_wave_sum_f32: a balanced tree over each sixteen lanes, then (r0 + r1) +
+    // (r2 + r3); float addition commutes, so the tree alone fixes the bits) -- a wave per pair was 240 dependent DPP chains,
+    // 7 us of the step.
+    for (int pair = tid; pair < ((A.dbg & 2) ? 0 : n_ent * nch); pair += nt) {
+        const int i = pair / nch, ch = pair - i * nch;
+        const float *Lr = Lm + (int64_t)i * KM + 64 * ch;
+        const int nv = KM - 64 * ch < 64 ? KM - 64 * ch : 64;
+        float M = -3.0e38f;
+        for (int q = 0; q < nv; q++) M = fmaxf(M, Lr[q]);
+        float r16[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int pair = p0 + u < n_ent * nch ? p0 + u : n_ent * nch - 1;
-            ii[u] = pair / nch;
-            cc[u] = pair - ii[u] * nch;
-            const int k = 64 * cc[u] + lane;
-            v[u] = k < KM ? Lm[(int64_t)ii[u] * KM + k] : -3.0e38f;
+        for (int b16 = 0; b16 < 4; b16++) {
+            float e[16];
+#pragma unroll
+            for (int q = 0; q < 16; q++) e[q] = 16 * b16 + q < nv ? __builtin_amdgcn_exp2f(Lr[16 * b16 + q] - M) : 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; q += 2) e[q] += e[q + 1];
+#pragma unroll
+            for (int q = 0; q < 16; q += 4) e[q] += e[q + 2];
+#pragma unroll
+            for (int q = 0; q < 16; q += 8) e[q] += e[q + 4];
+            r16[b16] = e[0] + e[8];
         }
-#pragma unroll
-        for (int u = 0; u < 4; u++) M[u] = fb_wave_max_f32(v[u]);
-#pragma unroll
-        for (int u = 0; u < 4; u++) S[u] = fb_wave_sum_f32(64 * cc[u] + lane < KM ? __builtin_amdgcn_exp2f(v[u] - M[u]) : 0.f);
-#pragma unroll
-        for (int u = 0; u < 4; u++)
-            if (lane == 0 && p0 + u < n_ent * nch) { wm[ii[u] * 4 + cc[u]] = M[u]; ws[ii[u] * 4 + cc[u]] = S[u]; }
+        wm[i * 4 + ch] = M;
+        ws[i * 4 + ch] = (r16[0] + r16[1]) + (r16[2] + r16[3]);
     }
     __syncthreads();
     for (int i = tid; i < n_ent; i += nt) {
