@@ -781,7 +781,7 @@ int segk_dispatch_score_f32(segk_ctx *ctx, const segk_corpus *c, const segk_kmea
 // segk_score_sp.hip: the split-precision filter (pieces = 2 fp16x2, 3 bf16x3) and the pre-filter's second stage
 int segk_dispatch_score_sp(segk_ctx *ctx, const ScoreArgs &A, int ks, int pieces, hipStream_t st);
 int segk_launch_sp_second(segk_ctx *ctx, const ScoreArgs &B, int ks, hipStream_t st);
-int segk_launch_clean(const segk_corpus *c, segk_kmeans *m, int32_t *status, hipStream_t st);
+int segk_launch_clean(const segk_corpus *c, segk_kmeans *m, int32_t *status, hipStream_t st, int32_t *relog = nullptr);
 int segk_launch_seq_chain(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m, const int32_t *order, int n_order, int n_slices_max,
                           double wip, uint8_t *boundaries, int32_t *old_tok, int32_t *new_tok, int32_t *new_k, int32_t *n_old,
                           int32_t *n_new, int32_t *n_flag, double *out_total, int32_t *status, hipStream_t st);

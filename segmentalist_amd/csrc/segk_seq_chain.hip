@@ -482,7 +482,9 @@ int segk_launch_seq_chain(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m, c
     if (G > ctx->n_cu || (int64_t)G * (n_order + 1) >= CH_STOP_BIT) return SEGK_ERR_UNSUPPORTED;
 
     const size_t key_bytes = 3 * (size_t)nbc * CH_KEY_PITCH * sizeof(unsigned long long), ctl_bytes = (8 + 32 * (CH_FLAGS + 1)) * sizeof(int32_t);
-    const size_t need = key_bytes + ctl_bytes + (size_t)n_order * sizeof(int32_t);
+    // (behind the order: the relabelling log of clean_components, 1 + 2 K_max words)
+    const size_t order_bytes = ((size_t)n_order * sizeof(int32_t) + 15) & ~(size_t)15;
+    const size_t need = key_bytes + ctl_bytes + order_bytes + (size_t)(2 * m->K_max + 2) * sizeof(int32_t);
     if (ctx->chain_bytes < need) {
         if (ctx->chain_buf) (void)hipFree(ctx->chain_buf);
         ctx->chain_buf = nullptr;
@@ -569,7 +571,7 @@ int segk_launch_seq_chain(segk_ctx *ctx, const segk_corpus *c, segk_kmeans *m, c
         }
         q = ctl[2];
         if (ctl[1] != 0) {               // a component emptied: clean_components, then on with the next utterance
-            int rc = segk_launch_clean(c, m, status, st);
+            int rc = segk_launch_clean(c, m, status, st, (int32_t *)(buf + key_bytes + ctl_bytes + order_bytes));
             if (rc) return rc;
         }
     }

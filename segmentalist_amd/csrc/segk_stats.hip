@@ -8,7 +8,7 @@
 // thread d owns dimension d (kmeans_components.py:93-166, 263-266).
 // ======================================================================================
 template <typename XT>
-__device__ void dev_del_component(const segk_corpus &c, segk_kmeans &m, int k, int *shK)
+__device__ void dev_del_component(const segk_corpus &c, segk_kmeans &m, int k, int *shK, int32_t *relog = nullptr)
 {
     // caller guarantees uniform control flow; K already decremented into *shK by thread 0
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -23,6 +23,16 @@ __device__ void dev_del_component(const segk_corpus &c, segk_kmeans &m, int k, i
             m.mean_numerators[(int64_t)k * D + d] = v;
             means[(int64_t)k * D + d] = (XT)(v / cntK);
         }
+        // (relog: the relabelling K -> k is only LOGGED -- one workgroup scanning a million labels is 1.3 ms; the caller applies
+        // the logged pairs, in order, with the whole chip: k_kmeans_relabel_log)
+        if (relog) {
+            if (tid == 0) {
+                const int n = relog[0];
+                relog[1 + 2 * n] = K;
+                relog[2 + 2 * n] = k;
+                relog[0] = n + 1;
+            }
+        } else
         for (int64_t e = tid; e < c.n_emb; e += nt)
             if (m.assignments[e] == K) m.assignments[e] = k;
     }
@@ -39,7 +49,7 @@ __device__ void dev_del_component(const segk_corpus &c, segk_kmeans &m, int k, i
 }
 
 template <typename XT>
-__device__ void dev_clean_components(const segk_corpus &c, segk_kmeans &m, int *shK, int *sh_i)
+__device__ void dev_clean_components(const segk_corpus &c, segk_kmeans &m, int *shK, int *sh_i, int32_t *relog = nullptr)
 {
     // kmeans_components.py:263-266: every empty component, highest index first.  The empties are
     // found with one parallel pass (a deletion moves the last ACTIVE row down, it never creates or
@@ -58,7 +68,7 @@ __device__ void dev_clean_components(const segk_corpus &c, segk_kmeans &m, int *
             if (empty) {
                 if (tid == 0) *shK = *shK - 1;
                 __syncthreads();
-                dev_del_component<XT>(c, m, k, shK);
+                dev_del_component<XT>(c, m, k, shK, relog);
             }
         }
         return;
@@ -76,9 +86,42 @@ __device__ void dev_clean_components(const segk_corpus &c, segk_kmeans &m, int *
             __syncthreads();
             if (tid == 0) *shK = *shK - 1;
             __syncthreads();
-            dev_del_component<XT>(c, m, w * 32 + bit, shK);
+            dev_del_component<XT>(c, m, w * 32 + bit, shK, relog);
         }
     }
+}
+
+// clean_components (kmeans_components.py:263-266) in two launches: the rows, numerators and counts of the emptied components by
+// one workgroup, the relabelling pairs (last active row -> emptied row, in the reference's order) logged; then every label
+// through the logged pairs in that order, by the whole chip.  relog: [0] pairs, then (from, to) x K_max at most.
+template <typename XT>
+__global__ __launch_bounds__(256) void k_kmeans_clean_log(segk_corpus c, segk_kmeans m, int32_t *relog)
+{
+    __shared__ int shK, sh_i;
+    if (threadIdx.x == 0) { shK = *m.K; relog[0] = 0; }
+    __syncthreads();
+    dev_clean_components<XT>(c, m, &shK, &sh_i, relog);
+    __syncthreads();
+    if (threadIdx.x == 0) *m.K = shK;
+}
+
+__global__ __launch_bounds__(256) void k_kmeans_relabel_log(int32_t *assignments, int64_t n, const int32_t *relog)
+{
+    __shared__ int32_t pf[256], pt[256];
+    const int np = relog[0];
+    if (np == 0) return;
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int a = e < n ? assignments[e] : -1;
+    const int a0 = a;
+    for (int p0 = 0; p0 < np; p0 += 256) {
+        __syncthreads();
+        if (p0 + (int)threadIdx.x < np) { pf[threadIdx.x] = relog[1 + 2 * (p0 + threadIdx.x)]; pt[threadIdx.x] = relog[2 + 2 * (p0 + threadIdx.x)]; }
+        __syncthreads();
+        const int m = np - p0 < 256 ? np - p0 : 256;
+        for (int i = 0; i < m; i++)
+            if (a == pf[i]) a = pt[i];
+    }
+    if (e < n && a != a0) assignments[e] = a;
 }
 
 template <typename XT>
@@ -1955,7 +1998,14 @@ int32_t segk_kmeans_init_stats(segk_ctx *ctx, const segk_corpus *c, segk_kmeans 
 }  // extern "C"
 
 // clean_components (kmeans_components.py:263-266) alone, no image refresh: the persistent sequential chain calls it between launches
-int segk_launch_clean(const segk_corpus *c, segk_kmeans *m, int32_t *status, hipStream_t st)
+int segk_launch_clean(const segk_corpus *c, segk_kmeans *m, int32_t *status, hipStream_t st, int32_t *relog)
 {
+    if (relog) {
+        DISPATCH_XT(c, hipLaunchKernelGGL(k_kmeans_clean_log<XT>, dim3(1), dim3(256), 0, st, *c, *m, relog););
+        hipLaunchKernelGGL(k_kmeans_relabel_log, dim3((unsigned)((c->n_emb + 255) / 256)), dim3(256), 0, st, m->assignments, c->n_emb,
+                           (const int32_t *)relog);
+        SEGK_LAUNCH_CHECK();
+        return SEGK_OK;
+    }
     return launch_update(c, m, 3, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, status, st);
 }
