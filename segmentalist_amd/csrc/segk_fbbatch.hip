@@ -1985,7 +1985,8 @@ __global__ void k_fbb_tiles32(segk_fbgmm f, segk_fbatch bt, int D, double prior_
 // for the span scores and the token likelihoods -- an empty slot's score is the pseudo-component's, multiplying its tile was
 // wasted matrix work.)  The token-likelihood matrix has the same columns: the kernels that read it go through the map
 // (fbb_cmap), which the waves of k_fbb_rows16 write.
-__global__ void k_fbb_rows16(segk_fbgmm f, segk_fbatch bt, int D, double prior_alpha, const int32_t *cmap)
+__global__ void k_fbb_rows16(segk_fbgmm f, segk_fbatch bt, int D, double prior_alpha, const int32_t *cmap,
+                             unsigned long long *tiles_fb)
 {
     const double LOG2E = 1.4426950408889634;
     const int KM = f.K_max, D2 = 2 * D;
@@ -2011,7 +2012,12 @@ __global__ void k_fbb_rows16(segk_fbgmm f, segk_fbatch bt, int D, double prior_a
         }
         if (k == KM) {                                // the pseudo-component's wave: the header, and what lies behind its column
             const int n_col = below + 1, n_t = (n_col + 31) / 32;
-            if (lane == 0) { cm[KM] = below; cm[KM + 1] = n_t; }
+            if (lane == 0) {
+                cm[KM] = below;
+                cm[KM + 1] = n_t;
+                // (a host-mapped word: the launcher of the token likelihoods sizes its tile split by the last count it saw)
+                if (tiles_fb) __hip_atomic_store(tiles_fb, (unsigned long long)n_t, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
             // the columns behind it inside the last tile in use are multiplied too: "absent", and rows that cannot overflow the image
             const int r_hi = n_t * 32 < KM + 1 ? n_t * 32 : KM + 1;
             for (int c2 = n_col + lane; c2 < r_hi; c2 += 64) bt.consts16[c2] = -3.0e38;
@@ -2164,7 +2170,8 @@ int32_t segk_fbb_prepare(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *
         // the occupied slots packed into the leading columns; the maps live behind the constants and are read by the score and
         // token-score calls of this step
         int32_t *cmap = fbb_cmap(bt, f->K_max);
-        hipLaunchKernelGGL(k_fbb_rows16, dim3((f->K_max + 1 + 3) / 4), dim3(256), 0, st, *f, *bt, c->D, alpha, (const int32_t *)cmap);
+        hipLaunchKernelGGL(k_fbb_rows16, dim3((f->K_max + 1 + 3) / 4), dim3(256), 0, st, *f, *bt, c->D, alpha, (const int32_t *)cmap,
+                           ctx && ctx->miss_dev ? ctx->miss_dev + 2 : (unsigned long long *)nullptr);
         SEGK_LAUNCH_CHECK();
         return segk_sp_prepare_tiles(bt->rows32, bt->consts16, bt->consts16 + f->K_max + 1, f->K_max + 1, 2 * c->D,
                                      bt->tiles16, bt->y16, stream);
@@ -2339,14 +2346,16 @@ int32_t segk_fbb_segment(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *
 int32_t segk_fbb_token_scores(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *f, const segk_fbatch *bt,
                               const int32_t *tok_rows, int64_t n, float *ll_mat, int64_t ll_ld, void *stream)
 {
-    (void)ctx;
     int rc = check_fbb(c, f, bt);
     if (rc) return rc;
     SEGK_REQUIRE(f->cov_type == 0 && bt->y16 && bt->tiles16, "needs the fp16x2 images (fixed-variance components)");
     SEGK_REQUIRE(tok_rows && ll_mat && ll_ld >= 32 * segk_n_tiles(f->K_max + 1) && (ll_ld & 3) == 0, "matrix / leading dimension");
-    // (the matrix has the image's packed columns -- segk_fbb_prepare's map)
+    // (the matrix has the image's packed columns -- segk_fbb_prepare's map; the tiles in use as the device last reported them:
+    // a hint for the split of the tiles over workgroups, nothing depends on it being current)
+    int tiles_hint = 0;
+    if (ctx && ctx->miss_host) tiles_hint = (int)ctx->miss_host[2];
     return segk_launch_score_mat_sp(bt->y16, 2 * c->D, tok_rows, n, bt->tiles16, segk_n_tiles(f->K_max + 1), ll_mat, ll_ld,
-                                    stream, fbb_cmap(bt, f->K_max) + f->K_max + 1);
+                                    stream, fbb_cmap(bt, f->K_max) + f->K_max + 1, tiles_hint);
 }
 
 static int32_t fbb_assign_impl(segk_ctx *ctx, const segk_corpus *c, const segk_fbgmm *f, const segk_fbatch *bt, int32_t s_lo,

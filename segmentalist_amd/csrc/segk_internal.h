@@ -221,4 +221,4 @@ int segk_launch_score_lse_sp(segk_ctx *ctx, const void *ximg, int D2, const int3
                              const float *tiles_sp, int n_tiles, double norm, double *out, void *stream,
                              const int32_t *n_tiles_dev = nullptr);
 int segk_launch_score_mat_sp(const void *ximg, int D2, const int32_t *ids, int64_t n, const float *tiles_sp, int n_tiles,
-                             float *mat, int64_t mat_ld, void *stream, const int32_t *n_tiles_dev = nullptr);
+                             float *mat, int64_t mat_ld, void *stream, const int32_t *n_tiles_dev = nullptr, int tiles_hint = 0);

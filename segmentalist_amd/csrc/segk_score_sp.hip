@@ -493,7 +493,7 @@ static int launch_score_lse_sp(segk_ctx *ctx, const ScoreArgs &A, hipStream_t st
 }
 
 template <int KS>
-static int launch_score_mat_sp(const ScoreArgs &A, hipStream_t st)
+static int launch_score_mat_sp(const ScoreArgs &A, hipStream_t st, int tiles_hint)
 {
     constexpr int STRIDE = (KS * 2 * 256 + 32 + 1023) / 1024 * 1024;
     const size_t lds = 2 * (size_t)STRIDE * sizeof(float);
@@ -504,10 +504,14 @@ static int launch_score_mat_sp(const ScoreArgs &A, hipStream_t st)
     int n_split = blocks > 0 ? (int)(512 / blocks) : 1;
     if (n_split > 8) n_split = 8;
     if (n_split > A.n_tiles) n_split = A.n_tiles;
+    // tiles that hold components (the packed images of the batch sampler: 14 of 32 at configs[4]), as the device last reported:
+    // the split is over THOSE -- two splits of sixteen left one of them the fourteen and the other nothing
+    const int t_used = tiles_hint > 0 && tiles_hint < A.n_tiles ? tiles_hint : A.n_tiles;
+    if (n_split > t_used) n_split = t_used;
     if (n_split >= 2) {
         SEGK_CHECK_HIP(segk_dyn_lds((const void *)k_kmeans_score_sp<KS, 4, 2, 2, 1>, lds));
         ScoreArgs S = A;
-        S.tiles_per_split = (A.n_tiles + n_split - 1) / n_split;
+        S.tiles_per_split = (t_used + n_split - 1) / n_split;
         S.n_chunks = (A.n_tiles + S.tiles_per_split - 1) / S.tiles_per_split;
         hipLaunchKernelGGL((k_kmeans_score_sp<KS, 4, 2, 2, 1>), dim3((unsigned)(blocks * S.n_chunks)), dim3(256), lds, st, S);
         SEGK_LAUNCH_CHECK();
@@ -521,7 +525,7 @@ static int launch_score_mat_sp(const ScoreArgs &A, hipStream_t st)
 // mat[r][k] = acc_k of row ids[r] (r < n), k < 32 n_tiles: the contraction itself, for callers that need
 // every component's value (the token likelihoods of the batch sampler's assignment step)
 int segk_launch_score_mat_sp(const void *ximg, int D2, const int32_t *ids, int64_t n, const float *tiles_sp, int n_tiles,
-                             float *mat, int64_t mat_ld, void *stream, const int32_t *n_tiles_dev)
+                             float *mat, int64_t mat_ld, void *stream, const int32_t *n_tiles_dev, int tiles_hint)
 {
     if (n <= 0) return SEGK_OK;
     ScoreArgs A{};
@@ -534,7 +538,7 @@ int segk_launch_score_mat_sp(const void *ximg, int D2, const int32_t *ids, int64
     hipStream_t st = (hipStream_t)stream;
     switch (segk_b3_kp(D2) / 16) {
 #define SEGK_CASE(k) \
-    case k: return launch_score_mat_sp<k>(A, st);
+    case k: return launch_score_mat_sp<k>(A, st, tiles_hint);
         SEGK_CASE(1) SEGK_CASE(2) SEGK_CASE(3) SEGK_CASE(4) SEGK_CASE(5) SEGK_CASE(6) SEGK_CASE(7) SEGK_CASE(8) SEGK_CASE(9)
         SEGK_CASE(10) SEGK_CASE(11) SEGK_CASE(12) SEGK_CASE(13)
 #undef SEGK_CASE
