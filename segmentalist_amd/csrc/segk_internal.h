@@ -186,7 +186,8 @@ static inline __host__ __device__ int segk_n_tiles(int K_max) { return (K_max + 
 //   rows   [SEGK_SP_HEADER bytes: int32 {P, exponent a, bits of max |x_d|, 0}, int64 n_emb * KP] then P planes
 //          [n_emb][KP] of 16-bit pieces (piece p of every row together), KP = D rounded up to 16 (zero padded,
 //          dimensions permuted by segk_b3_dim); for P = 2 the float [n_emb] residual norms follow the planes
-//   tiles  [1024 floats header: int32 exponent b at [0]] then per tile of 32 components:
+//   tiles  [1024 floats header: int32 exponent b at [0]; float E_m at [1]; [2], [3]: the batch finalize's residual
+//          maximum and the exponent it built its rows with (k_batch_post reads them)] then per tile of 32 components:
 //          16-bit [s][p][lane 64][8], s < KS = KP/16 (k-step), p < P (piece): piece p of
 //          2^b M[32*tile + (lane & 31)][segk_b3_dim(16 s + 8 (lane >> 5) + i)], i < 8 -- the A operand of
 //          v_mfma_f32_32x32x16_{f16,bf16} as one 16-byte load per lane; followed, at float offset KS*P*256,

@@ -1412,6 +1412,11 @@ __global__ __launch_bounds__(256) void k_batch_finalize(
     const int eb_prev = sp_spec ? ((const int *)m.tiles_b3)[0] : 0;
     const int ea_sp = sp_spec ? ((const int *)c.Xb3)[1] : 0;
     float *Tsp = sp_spec ? m.tiles_b3 + 1024 + (int64_t)(j0 >> 5) * segk_sp_tile_stride(D, 2) : nullptr;
+    // header word 3: the exponent THIS kernel built with -- what the post kernel compares the new exponent with.  (It
+    // compared with word 0 until round 4, which its own tile-0 workgroup rewrites when it rebuilds: a tile workgroup that
+    // read the word after that took its tile for built and left it in the old exponent under the new header -- scores of
+    // that tile's components off by a power of two, intermittently, in the sweep after the exponent moved.)
+    if (sp_spec && wg == 0 && tid == 0) ((int *)m.tiles_b3)[3] = eb_prev;
     {
         // three independent reductions over a row's elements, one per wave (8 lanes per component, the summation pattern of
         // dev_prepare_tile / dev_prepare_sp_tile): wave 0 |m|^2, wave 1 the fp16 residual, wave 2 the value hash
@@ -1513,7 +1518,7 @@ __global__ __launch_bounds__(256) void k_batch_post(segk_corpus c, segk_kmeans m
             bool built = false;
             if (P == 2 && sp_spec) {
                 const int eb_new = sp_exponent((float)(sqrt(*m.mnorm_max) * (1.0 + 1e-6)));
-                built = eb_new == ((const int *)tiles_sp)[0];
+                built = eb_new == ((const int *)tiles_sp)[3];           // (word 3: no workgroup of this kernel writes it)
             }
             if (!built)
                 dev_prepare_sp_tile<P>((const float *)m.means, m.K_max, c.D, tiles_sp, m.mnorm_max, (const unsigned char *)c.Xb3,
