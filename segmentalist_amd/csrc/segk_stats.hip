@@ -1070,7 +1070,7 @@ __device__ __forceinline__ double tree_reduce_d(double *v, int n)
                                      beyond go through the context's overflow arrays in global memory (identical values
                                      written by every workgroup) -- the only limit left is flag_cap per block              */
 #define FIN_ROWS 8                /* final rows per workgroup */
-#define FIN_ML 32                 /* flagged tokens of a new component listed per row (more: the general loop) */
+#define FIN_ML 128                /* flagged tokens of a new component listed per row (more: the general loop) */
 
 template <typename XT>
 __global__ __launch_bounds__(256) void k_batch_finalize(
@@ -1089,7 +1089,9 @@ __global__ __launch_bounds__(256) void k_batch_finalize(
     unsigned int *bitmap = reinterpret_cast<unsigned int *>(holes + K_max);      // 8 K_max bytes so far: 4-byte aligned
     double *mrow = reinterpret_cast<double *>(fin_lds + (((size_t)K_max * 8 + ((size_t)K_max / 32 + 2) * 4 + 15) & ~(size_t)15));
     __shared__ int32_t fl_slot[SEGK_FLAG_LDS], fl_row[SEGK_FLAG_LDS];
-    __shared__ unsigned short fl_k[SEGK_FLAG_LDS], fl_blk[SEGK_FLAG_LDS];
+    __shared__ __attribute__((aligned(16))) unsigned short fl_k[SEGK_FLAG_LDS];
+    __shared__ unsigned short fl_blk[SEGK_FLAG_LDS];
+    __shared__ unsigned short wsuf[8192 / 32 + 8];               // holes in the bitmap words above word w (K_max <= 8192)
     __shared__ int shK1, shK, n_holes, n_fl;
     __shared__ int32_t fl_cnt[64];
     __shared__ long long red[4];
@@ -1155,9 +1157,8 @@ __global__ __launch_bounds__(256) void k_batch_finalize(
     if (lane == 0) red[wv] = csum;
     __syncthreads();
     SEGK_TSTAMP(3, 1);
-    // the entries of all blocks are staged side by side first (raw labels; one round trip: thread t fetches entry t % 32 of
-    // block t / 32, whatever is beyond that in a plain loop), then one thread replays the clamp over the staged labels --
-    // fetched inside the replay loop, every flagged token cost that thread a dependent round trip
+    // the entries of all blocks are staged side by side first (raw labels), then one thread replays the clamp over the staged
+    // labels -- fetched inside the replay loop, every flagged token cost that thread a dependent round trip
     {
         auto put = [&](int at, int b, int slot, int kraw, int row) {
             if (at < SEGK_FLAG_LDS) {
@@ -1173,30 +1174,44 @@ __global__ __launch_bounds__(256) void k_batch_finalize(
                 ovg[3 * (int64_t)ovf_cap + o] = b;
             }
         };
-        const int pb = tid >> 5, pq = tid & 31;
-        int at0 = 0, mycnt = 0;                                  // start of block pb's entries in the global order, their number
+        // thread t takes entry q0 + t of EVERY block, eight blocks' loads issued together (their addresses always valid: entry
+        // 0 stands in where a block has no such entry): one round trip for a settled chain's handful of entries, and one per
+        // 256 entries and eight blocks where a fresh chain founds components by the hundred (a loop over the blocks with
+        // the loads inside cost a dependent round trip per block: 16 us of the second sweep)
+        int at = 0, maxcb = 0;
         for (int b = 0; b < n_blocks; b++) {
             const int cb = fl_cnt[b] < cap ? fl_cnt[b] : cap;
-            if (b < pb) at0 += cb;
-            if (b == pb) mycnt = cb;
+            maxcb = cb > maxcb ? cb : maxcb;
         }
-        if (pb < n_blocks && pq < mycnt) {
-            const int32_t *fl = reinterpret_cast<const int32_t *>(pack + pa.flg(pb));
-            // (row_words: the token's row travels in the record -- its place there, not its row of X, is what is kept)
-            const int sl = fl[2 + 3 * pq + 0], kr = fl[2 + 3 * pq + 1], rw = row_words ? pq : fl[2 + 3 * pq + 2];
-            put(at0 + pq, pb, sl, kr, rw);
-        }
-        int at = 0;
-        for (int b = 0; b < n_blocks; b++) {                     // (rare) entries 32.. of a block, blocks 8..
-            const int cb = fl_cnt[b] < cap ? fl_cnt[b] : cap;
-            const int32_t *fl = reinterpret_cast<const int32_t *>(pack + pa.flg(b));
-            for (int q = (b < nt / 32 ? 32 : 0) + tid; q < cb; q += nt) put(at + q, b, fl[2 + 3 * q + 0], fl[2 + 3 * q + 1], row_words ? q : fl[2 + 3 * q + 2]);
-            at += cb;
+        for (int b0 = 0; b0 < n_blocks; b0 += 8) {
+            int cbs[8], ats[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                cbs[i] = b0 + i < n_blocks ? (fl_cnt[b0 + i] < cap ? fl_cnt[b0 + i] : cap) : 0;
+                ats[i] = at;
+                at += cbs[i];
+            }
+            for (int q0 = 0; q0 < maxcb; q0 += nt) {
+                const int q = q0 + tid;
+                int sl[8], kr[8], rw[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const int32_t *fl = reinterpret_cast<const int32_t *>(pack + pa.flg(b0 + i < n_blocks ? b0 + i : 0));
+                    const int qi = q < cbs[i] ? q : 0;
+                    sl[i] = fl[2 + 3 * qi + 0];
+                    kr[i] = fl[2 + 3 * qi + 1];
+                    rw[i] = fl[2 + 3 * qi + 2];
+                }
+#pragma unroll
+                for (int i = 0; i < 8; i++)
+                    // (row_words: the token's row travels in the record -- its place there, not its row of X, is what is kept)
+                    if (q < cbs[i]) put(ats[i] + q, b0 + i, sl[i], kr[i], row_words ? q : rw[i]);
+            }
         }
         if (at > SEGK_FLAG_LDS) __threadfence();                  // overflow entries: written by many threads, read by others below
     }
     __syncthreads();
-    if (tid == 0) {
+    if (tid < 64) {
         int K = Kb, nf = 0, over = 0;
         for (int b = 0; b < n_blocks; b++) {
             if (fl_cnt[b] > cap) over = 1;
@@ -1204,16 +1219,35 @@ __global__ __launch_bounds__(256) void k_batch_finalize(
         }
         const int room = SEGK_FLAG_LDS + (ovf ? ovf_cap : 0);
         if (nf > room) { over = 1; nf = room; }
-        for (int q = 0; q < nf; q++) {
-            int k = q < SEGK_FLAG_LDS ? (int)fl_k[q] : ovg[2 * (int64_t)ovf_cap + q - SEGK_FLAG_LDS];
-            if (k > K) k = K;
-            if (k == K) K++;
-            if (q < SEGK_FLAG_LDS) fl_k[q] = (unsigned short)k;
-            else ovg[2 * (int64_t)ovf_cap + q - SEGK_FLAG_LDS] = k;
+        // The clamp (label k: k = min(k, K); k == K founds component K, K++), 64 tokens per trip by one wave.  A token founds
+        // a component iff its raw label >= K at its turn = K at the start of the trip + the founders among the lanes below
+        // it: bit q of that mask depends on the bits below q only, so iterating mask -> mask'(mask) from any start has the
+        // first t bits right after t rounds and its only fixed point is the sequential answer (one thread replaying label by
+        // label: 0.03-0.08 us per flagged token, 36-87 us of the second sweep of a fresh chain with its 1 082 of them).
+        for (int q0 = 0; q0 < nf; q0 += 64) {
+            const int q = q0 + lane;
+            const bool in = q < nf;
+            const int kr = !in ? 0 : q < SEGK_FLAG_LDS ? (int)fl_k[q] : ovg[2 * (int64_t)ovf_cap + q - SEGK_FLAG_LDS];
+            const unsigned long long lower = (1ull << lane) - 1ull;
+            unsigned long long mk = __ballot(in && kr >= K);
+            for (;;) {
+                const unsigned long long m2 = __ballot(in && kr >= K + __popcll(mk & lower));
+                if (m2 == mk) break;
+                mk = m2;
+            }
+            const int Kq = K + __popcll(mk & lower);
+            const int k = kr < Kq ? kr : Kq;
+            if (in) {
+                if (q < SEGK_FLAG_LDS) fl_k[q] = (unsigned short)k;
+                else ovg[2 * (int64_t)ovf_cap + q - SEGK_FLAG_LDS] = k;
+            }
+            K += __popcll(mk);
         }
-        if (over && wg == 0) atomicOr(status, 4);
-        shK1 = K;
-        n_fl = nf;
+        if (lane == 0) {
+            if (over && wg == 0) atomicOr(status, 4);
+            shK1 = K;
+            n_fl = nf;
+        }
         if (nf > SEGK_FLAG_LDS) __threadfence();      // the overflow entries are read back by the other threads below
     }
     __syncthreads();
@@ -1239,21 +1273,42 @@ __global__ __launch_bounds__(256) void k_batch_finalize(
         for (int k = tid; k < K1; k += nt)
             if (cnt32[k] == 0) atomicOr(&bitmap[k >> 5], 1u << (k & 31));
         __syncthreads();
-        if (tid == 0) {
-            int K = K1, nh = 0;
-            for (int w = nwords - 1; w >= 0; w--) {
-                unsigned int bits = bitmap[w];
-                while (bits) {
-                    const int bit = 31 - __clz((int)bits);
-                    bits &= ~(1u << bit);
-                    const int k = w * 32 + bit;
-                    K--;
-                    if (k != K) pos2orig[k] = pos2orig[K];
-                    holes[nh++] = (unsigned short)k;
+        // The walk in descending order, every hole by a thread of its own.  Hole number i (1 = the highest) is filled from
+        // position P_i = K1 - i, the last active row at that moment; that position holds its own component unless it is itself
+        // a hole -- then an earlier one, number j < i (a hole is never above the last row: k_j <= P_j), and it holds what hole
+        // j received: the component at P_j, and so on upwards until a position that is no hole.  The number of a hole is
+        // its rank in the bitmap (holes in the words above + bits above it in its word), so nothing is sequential: one thread
+        // walked the holes at 0.2 us each (30 us in the second sweep of a fresh chain, 2-14 us in the following ones).
+        if (tid < 64) {
+            int carry = 0;
+            for (int hi = nwords - 1; hi >= 0; hi -= 64) {
+                const int w = hi - lane;
+                const int cw = w >= 0 ? __popc(bitmap[w]) : 0;
+                int sc = cw;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int t = __shfl_up(sc, o);
+                    if (lane >= o) sc += t;
                 }
+                if (w >= 0) wsuf[w] = (unsigned short)(carry + sc - cw);
+                carry += __shfl(sc, 63);
             }
-            shK = K;
-            n_holes = nh;
+            if (lane == 0) {
+                shK = K1 - carry;
+                n_holes = carry;
+            }
+        }
+        __syncthreads();
+        for (int k = tid; k < K1; k += nt) {
+            auto is_hole = [&](int p) -> bool { return (bitmap[p >> 5] >> (p & 31)) & 1u; };
+            auto number = [&](int p) -> int { return (int)wsuf[p >> 5] + __popc((bitmap[p >> 5] >> (p & 31)) >> 1) + 1; };
+            if (!is_hole(k)) continue;
+            const int i = number(k);
+            holes[i - 1] = (unsigned short)k;
+            int p = K1 - i;
+            if (p == k) continue;                                  // the hole is the last row itself: nothing moves
+            while (is_hole(p)) p = K1 - number(p);
+            pos2orig[k] = (unsigned short)p;
         }
         __syncthreads();
     }
@@ -1289,18 +1344,23 @@ __global__ __launch_bounds__(256) void k_batch_finalize(
     // ---- (1) this workgroup's final rows, one element (row, dimension) per thread and step; the loads of four steps
     // (32 with the default eight blocks) are issued together
     // match lists of this workgroup's rows that hold a component founded in this sweep (its tokens are flagged ones only)
-    if (tid < FIN_ROWS) {
-        const int j = j0 + tid;
+    // (a wave per two rows, 64 flagged tokens per trip, the matches kept in token order by ballot and prefix count: one
+    // thread per row walked all flagged tokens -- up to 81 us of the second sweep of a fresh chain)
+    for (int r = wv * (FIN_ROWS / 4); r < (wv + 1) * (FIN_ROWS / 4); r++) {
+        const int j = j0 + r;
         int n = 0;
-        if (j < K && j < K_max && orig(j) >= Kb) {
+        if (j < K && j < K_max && orig(j) >= Kb) {                // (wave-uniform)
             const int sc = orig(j);
-            for (int q = 0; q < nfl; q++)
-                if (FL_K(q) == sc) {
-                    if (n < FIN_ML) ml[tid][n] = q;
-                    n++;
-                }
+            for (int q0 = 0; q0 < nfl; q0 += 64) {
+                const int q = q0 + lane;
+                const bool hit = q < nfl && FL_K(q) == sc;
+                const unsigned long long mk = __ballot(hit);
+                const int at = n + __popcll(mk & ((1ull << lane) - 1ull));
+                if (hit && at < FIN_ML) ml[r][at] = q;
+                n += __popcll(mk);
+            }
         }
-        ml_cnt[tid] = n;
+        if (lane == 0) ml_cnt[r] = n;
     }
     __syncthreads();
     SEGK_TSTAMP(3, 4);
@@ -1350,23 +1410,23 @@ __global__ __launch_bounds__(256) void k_batch_finalize(
             if (cls[u] == 2) {
                 v = ((tv[u][0] + tv[u][1]) + (tv[u][2] + tv[u][3])) + ((tv[u][4] + tv[u][5]) + (tv[u][6] + tv[u][7]));
             } else if (n_blocks == 8 && src[u] >= Kb && ml_cnt[r] <= FIN_ML) {
-                // a component founded this sweep: its flagged tokens, block by block -- the row's match list (LDS), four
+                // a component founded this sweep: its flagged tokens, block by block -- the row's match list (LDS), eight
                 // rows in flight, the block's accumulator chosen by predicate (a dynamically indexed array lives in scratch)
                 double g8[8];
 #pragma unroll
                 for (int b = 0; b < 8; b++) g8[b] = 0.0;
                 const int nmr = ml_cnt[r];
-                for (int i0 = 0; i0 < nmr; i0 += 4) {
-                    XT xq[4];
-                    int bq[4];
+                for (int i0 = 0; i0 < nmr; i0 += 8) {
+                    XT xq[8];
+                    int bq[8];
 #pragma unroll
-                    for (int i = 0; i < 4; i++) {
+                    for (int i = 0; i < 8; i++) {
                         const int qq = ml[r][i0 + i < nmr ? i0 + i : nmr - 1];
                         bq[i] = FL_BLK(qq);
                         xq[i] = FLX(qq, d);
                     }
 #pragma unroll
-                    for (int i = 0; i < 4; i++)
+                    for (int i = 0; i < 8; i++)
                         if (i0 + i < nmr) {
 #pragma unroll
                             for (int b = 0; b < 8; b++) g8[b] = bq[i] == b ? g8[b] + (double)xq[i] : g8[b];
