@@ -392,15 +392,16 @@ __global__ __launch_bounds__(BLS_THREADS) void k_kmeans_brute_ls(segk_corpus c, 
     }
     // ---- the workgroup that finishes last unpacks the (score, component) pairs into the candidates and clears the workspace
     // (round 3 launched k_brute_finish_ls for this: one more kernel boundary, ~5 us of a sweep even when the queue is empty)
-    // (EVERY thread's atomics must have been performed before the workgroup's ticket is taken: a fence by thread 0 alone orders
-    // only its own -- the last workgroup then read maxima that were still in flight, an intermittent wrong argmax)
+    // (EVERY wave's atomics must have been performed before the workgroup's ticket is taken -- a workgroup barrier orders
+    // issue, not completion: each wave waits for the acknowledgements of its own (s_waitcnt vmcnt(0); they are device-scope
+    // read-modify-writes, performed where the last workgroup's exchanges below read them).  A __threadfence() here instead
+    // writes the L2 back once per wave: 4 096 of them made every call with a non-empty queue 72 us, 8 rows or 1 500.)
     __shared__ int last;
-    __threadfence();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) last = atomicAdd(ticket, 1u) == gridDim.x - 1u;
     __syncthreads();
     if (last) {
-        __threadfence();
         for (int q = tid; q < nq; q += BLS_THREADS) {
             const unsigned long long pk = atomicExch(&ws[q], 0ull);      // (device scope: the maxima were formed by atomics of every XCD)
             const unsigned int ord = (unsigned int)(pk >> 32);

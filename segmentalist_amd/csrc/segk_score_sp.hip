@@ -279,12 +279,11 @@ __global__ __launch_bounds__(64 * WAVES, WAVES >= 8 ? 1 : 2) void k_kmeans_score
                 __hip_atomic_store(pp + 0, RM, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(pp + 1, RS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            __threadfence();               // (release: every thread's partials before the workgroup's ticket; see SPLIT of MODE 0)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (tid == 0) s_last1 = __hip_atomic_fetch_add(A.part_k + rblock, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == S_dev - 1;
             __syncthreads();
             if (!s_last1) continue;
-            __threadfence();               // (acquire)
             if (tid == 0) __hip_atomic_store(A.part_k + rblock, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             RM = -3.0e38f;
             RS = 0.f;
@@ -316,17 +315,15 @@ __global__ __launch_bounds__(64 * WAVES, WAVES >= 8 ? 1 : 2) void k_kmeans_score
             __hip_atomic_store(pp + 1, top2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(pp + 2, __int_as_float(idx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        // Release / acquire fences around the ticket.  (Round 3 had none -- at agent scope a fence writes back and invalidates
-        // the XCD's L2, ~1 us of everybody's time with the exact stage writing beside this kernel -- and relied on relaxed
-        // agent-scope stores being acknowledged before the ticket was taken: with four processes sharing the card the workgroup
-        // that merged read, once in ~25 runs, a partial whose score was new and whose component was the previous call's.  The
-        // stage is off the default path since the band stage of round 4; correctness first.)
-        __threadfence();
+        // No __threadfence here: at agent scope it writes back and invalidates the whole L2 of the XCD, and with the exact
+        // stage writing its results beside this kernel every such fence cost ~1 us of everybody's time (634 us for the
+        // stage).  The partials are write-through stores and coherent loads (agent-scope atomics, relaxed), ordered
+        // against the ticket by waiting for the stores' acknowledgements.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) s_last = __hip_atomic_fetch_add(A.part_k + rblock, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == S - 1;
         __syncthreads();
         if (!s_last) continue;
-        __threadfence();
         if (tid == 0) __hip_atomic_store(A.part_k + rblock, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // per row the largest filter value (ties: the lower component) and the second largest over everything else
         top1 = NEG_INF_F; top2 = NEG_INF_F; idx = 0x7fffffff;
