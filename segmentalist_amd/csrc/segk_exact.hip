@@ -571,8 +571,9 @@ __global__ __launch_bounds__(1024) void k_seq_score(segk_corpus c, segk_kmeans m
             if (cidx == 0 && jl < nj) atomicMax(&keys[s_j[v0 + jl]], key);
         }
     }
-    // last workgroup done: unpack (atomic exchanges read the keys where the atomic maxima were performed, and clear them)
-    __threadfence();
+    // last workgroup done: unpack (atomic exchanges read the keys where the atomic maxima were performed, and clear them);
+    // every wave waits for the acknowledgements of its own maxima before the barrier in front of the ticket (k_kmeans_brute_ls)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
         const unsigned long long arrived = atomicAdd(&keys[tri_max], 1ull);
@@ -580,7 +581,6 @@ __global__ __launch_bounds__(1024) void k_seq_score(segk_corpus c, segk_kmeans m
     }
     __syncthreads();
     if (!s_last) return;
-    __threadfence();
     for (int v = tid; v < nv; v += blockDim.x) {
         const unsigned long long key = atomicExch(&keys[s_j[v]], 0ull);
         const int32_t id = s_id[v];

@@ -215,7 +215,8 @@ static __device__ int fb_collect_tokens(const int32_t *vid, const uint8_t *bnd, 
 // The same by a whole wave (N <= 64): one load of the boundary flags, the lane of every set flag looks up its own segment
 // [jp, j + 1), the kept ids are compacted in order by a prefix count.  All 64 lanes must call it; returns the count in every
 // lane.  (The one-lane loop above is N dependent global loads: 5-10 us per call in the boundary kernels.)
-static __device__ int fb_collect_tokens_wave(const int32_t *vid, const uint8_t *bnd, int N, int32_t *tok, int lane)
+static __device__ int fb_collect_tokens_wave(const int32_t *vid, const uint8_t *bnd, int N, int32_t *tok, int lane,
+                                             int32_t *tokj = nullptr)         // tokj: the kept segments' triangular indices
 {
     // the flags may have been written a moment ago by other lanes of this wave: wait for those stores and read past the L1
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -227,7 +228,10 @@ static __device__ int fb_collect_tokens_wave(const int32_t *vid, const uint8_t *
     int id = -1;
     if (bit) id = vid[(lane + 1) * lane / 2 + jp];
     const unsigned long long keep = __ballot(bit && id >= 0);
-    if (bit && id >= 0) tok[__popcll(keep & ((1ull << lane) - 1ull))] = id;
+    if (bit && id >= 0) {
+        tok[__popcll(keep & ((1ull << lane) - 1ull))] = id;
+        if (tokj) tokj[__popcll(keep & ((1ull << lane) - 1ull))] = (lane + 1) * lane / 2 + jp;
+    }
     return __popcll(keep);
 }
 
@@ -306,9 +310,10 @@ struct StreamUniforms {        // the pre-drawn `random.random()` values of the 
     const double *us;
     int64_t cur, cap;
     int32_t *status;
+    int64_t base = 0;          // us[0] is value `base` of the stream (a window of it staged in LDS)
     __device__ double next(int lane)
     {
-        const double u = (cur < cap) ? us[cur] : 0.5;
+        const double u = (cur < cap) ? us[cur - base] : 0.5;
         if (cur >= cap && lane == 0) atomicOr(status, 8);
         cur++;
         return u;

@@ -68,14 +68,18 @@ __device__ void fb_update_derived(const segk_fbgmm &f, int D, int k, double *red
             part += log(var);
         }
     }
+    // (k_fb_chain: fb_diag_const by count from a table the same function filled once -- two lgamma calls by one thread
+    // were 2-4 us of every add_item / del_item; the reference reads its lgamma values from tables indexed by the count
+    // too, gaussian_components_diag.py:128-131.  The table is in global memory: the load is issued before the block-wide
+    // sum, not after it -- a dependent round trip of 1.5-2 us per add_item / del_item otherwise.)
+    const bool from_tab = f.cov_type != 0 && loc && loc->ktab && f.counts[k] >= 0 && f.counts[k] < loc->ktab_n;
+    double kc_tab = 0.0;
+    if (from_tab && tid == 0) kc_tab = loc->ktab[f.counts[k]];
     double tot = block_sum(part, red);
     if (tid == 0) {
         f.log_prod[k] = tot;
         if (f.cov_type == 0) f.kconst[k] = -0.5 * (double)D * LOG_2PI;
-        // (k_fb_chain: fb_diag_const by count from a table the same function filled once -- two lgamma calls by one thread
-        // were 2-4 us of every add_item / del_item; the reference reads its lgamma values from tables indexed by the count
-        // too, gaussian_components_diag.py:128-131)
-        else if (loc && loc->ktab && f.counts[k] >= 0 && f.counts[k] < loc->ktab_n) f.kconst[k] = loc->ktab[f.counts[k]];
+        else if (from_tab) f.kconst[k] = kc_tab;
         else f.kconst[k] = fb_diag_const(f, D, (double)f.counts[k]);
     }
     __syncthreads();
@@ -397,9 +401,14 @@ __device__ double fb_log_prior(const segk_fbgmm &f, int D, const XT *x)
 //   4  LM bigram:          lms*log(lm.prob_vec_given_j(j_prev))                          bigram_lms.py:84-91
 // Work split: a group of G lanes (G | 64, K_max*G <= blockDim where possible) shares one
 // component and strides over the dimensions; partial sums are combined by a butterfly.
+// pred_out (LDS, [K_max]): receives the predictive term of every active component (what is added to the assignment prior).
+// pred_in / K_in / modf: those terms as an EARLIER call for the same row computed them (with K_in active components); they
+// stand for components below K_in whose flag in modf is clear -- the caller vouches that their statistics have not changed
+// since --, the others are computed here, by the same lanes in the same order: the logits are the same bits either way.
 template <typename XT>
 __device__ void fb_logits(const segk_corpus &c, const segk_fbgmm &f, int64_t e, int mode, int j_prev, XT *xrow,
-                          double *z, double *red, const double *lprior_tab = nullptr)
+                          double *z, double *red, const double *lprior_tab = nullptr, double *pred_out = nullptr,
+                          const double *pred_in = nullptr, int K_in = 0, const uint8_t *modf = nullptr)
 {
     const int tid = threadIdx.x, nt = blockDim.x, D = c.D;
     const XT *X = (const XT *)c.X;
@@ -426,7 +435,8 @@ __device__ void fb_logits(const segk_corpus &c, const segk_fbgmm &f, int64_t e, 
     for (int kb = 0; kb < KM; kb += kstep) {
         const int k = kb + kk0;
         double s = 0.0;
-        if (k < K) s = fb_pred_sum<XT>(f, D, k, xrow, g, G);
+        const bool fresh = k < K && (!pred_in || k >= K_in || modf[k]);      // (the same for the G lanes of a component)
+        if (fresh) s = fb_pred_sum<XT>(f, D, k, xrow, g, G);
         // (the same xor butterfly, o = G/2 ... 1; the steps inside a quad by DPP instead of two ds_bpermute round trips)
         for (int o = G >> 1; o > 2; o >>= 1) s += __shfl_xor(s, o);
         if (G >= 4) s += fb_dpp_f64<0x4E>(s);            // xor 2
@@ -443,7 +453,12 @@ __device__ void fb_logits(const segk_corpus &c, const segk_fbgmm &f, int64_t e, 
                                    / ((double)f.lm_unigram[j_prev] + f.lm_b);
                 v = log(f.lm_lambda * pi + pij) * f.lms;
             }
-            z[k] = v + (k < K ? fb_pred_finish(f, k, s) : lprior);
+            double pk = lprior;
+            if (k < K) {
+                pk = fresh ? fb_pred_finish(f, k, s) : pred_in[k];
+                if (pred_out) pred_out[k] = pk;
+            }
+            z[k] = v + pk;
         }
     }
     __syncthreads();
@@ -534,7 +549,7 @@ __global__ __launch_bounds__(128) void k_unigram_segment(segk_corpus c, int utt,
 // first maximum when map_assign -- and the `k > K -> K` clamp (:459-460).  Result in *sh_k.
 __device__ void fb_draw_component(const segk_fbgmm &f, double *z, double *red, int map_assign, double anneal_temp,
                                   const double *ustream, int64_t *ucursor, int64_t ucap, int32_t *status, int shK,
-                                  int *sh_k_out)
+                                  int *sh_k_out, int64_t ubase = 0)      // ustream[0] is value `ubase` of the stream
 {
     // scipy logsumexp: max-shift, sum, log
     double mx = NEG_INF_D;
@@ -571,7 +586,7 @@ __device__ void fb_draw_component(const segk_fbgmm &f, double *z, double *red, i
             }
         } else {                                  // utils.draw (utils.py:10-21), forward order
             const int64_t cur = *ucursor;
-            const double uu = (cur < ucap) ? ustream[cur] : 0.5;
+            const double uu = (cur < ucap) ? ustream[cur - ubase] : 0.5;
             k = fb_draw_seq(z, f.K_max, uu);
             if (threadIdx.x == 0) {
                 if (cur >= ucap) atomicOr(status, 8);
@@ -669,6 +684,7 @@ struct FbChainArgs {
     int64_t ktab_n;
     const double *lprior_tab;       // [n_emb] log prior predictive of every row (k_fb_prior_tab), or NULL
     int64_t *lm_rep;                // language model: [gridDim.x][K_max^2] every workgroup's own copy of the bigram counts
+    unsigned long long *ptab;       // [N_max (N_max + 1) / 2][K_max] the spans' predictive terms as bit patterns (exchange), or NULL
 };
 
 // lm.remove_counts_from_utterance / lm.counts_from_utterance (bigram_lms.py:98-114) over the transcript the boundaries define
@@ -699,12 +715,25 @@ static __device__ void fb_chain_lm_count(const int32_t *vid_l, const uint8_t *bn
         if (lane > 0) atomicAdd((unsigned long long *)&rep[(int64_t)lmk[lane - 1] * KM + k], (unsigned long long)sgn);
     }
 }
+// development: accumulated ticks between sub-stamps of the assignment loop (row 256 of the stamp buffer: [p] += t_p - t_(p-1), [7] tokens)
+#define FBC_SUB(p)                                                                                                         \
+    do {                                                                                                                   \
+        if (A.stamp && blockIdx.x == 0 && tid == 0) {                                                                      \
+            const unsigned long long now_ = wall_clock64();                                                                \
+            if ((p) > 0) A.stamp[256 * 8 + (p)] += now_ - fbc_sub_t;                                                       \
+            else A.stamp[256 * 8 + 7] += 1;                                                                                \
+            fbc_sub_t = now_;                                                                                              \
+        }                                                                                                                  \
+    } while (0)
 #define FBC_STAMP(slot)                                                                                                   \
     do {                                                                                                                   \
         if (A.stamp && blockIdx.x == 0 && tid == 0 && q - A.q0 < 256) A.stamp[(q - A.q0) * 8 + (slot)] = wall_clock64();  \
     } while (0)
 
-template <typename XT>
+// COV, LM: the covariance type and the presence of a language model as compile-time constants (they are written into the
+// kernel's private copy of the model below, and the device functions it is handed to are inlined): one kernel for every case
+// was 18 400 instructions with every branch on f.cov_type / f.lm_unigram inside the per-segment loops.
+template <typename XT, int COV, bool LM>
 __global__ __launch_bounds__(512) void k_fb_chain(FbChainArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char fbc_lds[];
@@ -731,12 +760,27 @@ __global__ __launch_bounds__(512) void k_fb_chain(FbChainArgs A)
     XT *xs_l = reinterpret_cast<XT *>(pri_l + 3 * D);                     // [max_rows][D] the utterance's rows of X
     // language model (bigram_acoustic_wordseg.py:386-551): the unigram counts in LDS like the model, the bigram counts
     // (K_max^2: 80 KB at K = 100) in a copy of the workgroup's own in global memory -- replicated updates again, nothing shared
-    const bool lm = A.f.lm_unigram != nullptr;
+    constexpr bool lm = LM;
     // (aligned on 8 bytes whatever the buffers in front add up to: the counts take 64-bit LDS atomics, which -- unlike plain
     // loads and stores -- fault on a misaligned address)
     int64_t *lmu = reinterpret_cast<int64_t *>((reinterpret_cast<uintptr_t>(xs_l) + (size_t)A.max_rows * D * sizeof(XT) + 7) & ~(uintptr_t)7);   // [K_max]
     int32_t *lmk = reinterpret_cast<int32_t *>(lmu + KM);                 // [N_max]
     int64_t *rep = lm ? A.lm_rep + (int64_t)blockIdx.x * KM * KM : nullptr;
+    // The predictive terms of the span scores, kept for the assignment (A.ptab != NULL).  Scoring a span evaluates, for every
+    // component, the term the assignment of a segment made of that span needs again -- K_max x D logarithms (diagonal
+    // covariances) that the workgroups REPLICATE per new segment: 7 of the 10 us a segment's assignment took.  The
+    // workgroup that scores a span writes its row of terms; after the DP everybody reads the rows of the chosen spans
+    // (pl), and fb_logits evaluates only the components that received a segment of this utterance since.
+    const bool spec = A.ptab != nullptr;
+    double *pz = reinterpret_cast<double *>(lm ? (reinterpret_cast<uintptr_t>(lmk + NM) + 7) & ~(uintptr_t)7 : reinterpret_cast<uintptr_t>(lmu));   // [K_max]
+    double *pl = pz + KM;                                                 // [N_max][K_max] (with A.ptab; pz: always)
+    int32_t *tokj_l = reinterpret_cast<int32_t *>(pl + (size_t)NM * KM);  // [N_max] triangular index of the new segments' spans
+    uint8_t *modf = reinterpret_cast<uint8_t *>(tokj_l + NM);             // [K_max] component received a segment of this utterance
+    // what the serial steps would otherwise fetch from global memory one dependent round trip (1.5-2 us) at a time: the
+    // window of the uniform stream an utterance can consume (a draw per backward step and per new segment) and the log
+    // prior predictive of its rows
+    double *us_l = reinterpret_cast<double *>((reinterpret_cast<uintptr_t>(spec ? modf + KM : reinterpret_cast<uint8_t *>(pl)) + 7) & ~(uintptr_t)7);   // [2 N_max + 2]
+    double *lpr_l = us_l + 2 * NM + 2;                                    // [max_rows]
     __shared__ int sh_last, sh_jprev;
     __shared__ int shK, ldsK, sh_i, sh_k, sh_flag, sh_nn, sh_nspan, n_relog;
     __shared__ int32_t relog[2 * FB_RELOG];
@@ -747,6 +791,8 @@ __global__ __launch_bounds__(512) void k_fb_chain(FbChainArgs A)
     if (tid == 0) { kc[KM] = A.f.kconst[KM]; shK = *A.f.K; ldsK = shK; sh_cur = *A.ucursor; }
     for (int d = tid; d < D; d += nt) { pri_l[d] = A.f.prior_a[d]; pri_l[D + d] = A.f.prior_b[d]; pri_l[2 * D + d] = A.f.prior_c[d]; }
     segk_fbgmm fl = A.f;
+    fl.cov_type = COV;
+    if (!LM) { fl.lm_unigram = nullptr; fl.lm_bigram = nullptr; }
     fl.stat_a = sa; fl.stat_b = sb; fl.pred = pp; fl.log_prod = lp; fl.kconst = kc; fl.counts = cn; fl.K = &ldsK;
     fl.prior_a = pri_l; fl.prior_b = pri_l + D; fl.prior_c = pri_l + 2 * D;
     if (lm) {
@@ -758,6 +804,7 @@ __global__ __launch_bounds__(512) void k_fb_chain(FbChainArgs A)
     }
     __syncthreads();
     int phase = 0;
+    unsigned long long fbc_sub_t = 0;
     for (int q = A.q0; q < A.q1; q++) {
         const int u = A.order[q];
         const int N = c.lengths[u], tri = N * (N + 1) / 2;
@@ -786,11 +833,26 @@ __global__ __launch_bounds__(512) void k_fb_chain(FbChainArgs A)
         }
         for (int j = tid; j < N; j += nt) bnd_l[j] = A.boundaries[(int64_t)u * NM + j];
         if (tid == 0) n_relog = 0;
+        if (spec)
+            for (int k = tid; k < KM; k += nt) modf[k] = 0;
+        const int64_t ucur0 = (int64_t)sh_cur;
+        for (int i = tid; i < 2 * NM + 2; i += nt) us_l[i] = ucur0 + i < A.ucap ? A.ustream[ucur0 + i] : 0.5;
+        if (A.lprior_tab)
+            for (int i = tid; i < nrows; i += nt) lpr_l[i] = A.lprior_tab[row0 + i];
+        // (always an LDS address: a pointer that is either this or NULL makes every access through it a flat one)
+        const double *lprior_l = lpr_l - row0;
         __syncthreads();
         fl.assignments = asg_l - row0;                   // (only the utterance's rows are ever named)
         segk_corpus cl = c;                              // X as the device functions index it, backed by the staged rows
         cl.X = xs_l - row0 * D;
         cl.ldx = D;
+        if (!A.lprior_tab) {                             // (no table from the host: D > 512) fb_logits' own expression, row by row
+            for (int i = 0; i < nrows; i++) {
+                const double lp_i = fb_prior_finish(fl, block_sum(fb_prior_sum<XT>(fl, D, xs_l + (int64_t)i * D, tid, nt), red));
+                if (tid == 0) lpr_l[i] = lp_i;
+            }
+            __syncthreads();
+        }
         const FbLocal loc{asg_l, row0, nrows, relog, &n_relog, A.ktab, A.ktab_n};
         if (tid < 64) {                                  // the valid spans, in table order (one wave: ballot + prefix count)
             int n = 0;
@@ -828,9 +890,14 @@ __global__ __launch_bounds__(512) void k_fb_chain(FbChainArgs A)
         // ---- (C) this workgroup's share of the span scores: log_marg_i (fbgmm.py:256-285)
         FBC_STAMP(2);
         const int nspan = sh_nspan;
+        const int K_C = ldsK;                            // active components while the spans are scored
         for (int s = blockIdx.x; s < nspan; s += gridDim.x) {
             const int64_t e = vid_l[spans[s]];
-            fb_logits<XT>(cl, fl, e, lm ? 3 : 0, -1, xrow, z, red, A.lprior_tab);
+            fb_logits<XT>(cl, fl, e, lm ? 3 : 0, -1, xrow, z, red, lprior_l, pz);
+            if (spec)
+                for (int k = tid; k < K_C; k += nt)
+                    __hip_atomic_store(&A.ptab[(int64_t)spans[s] * KM + k], (unsigned long long)__double_as_longlong(pz[k]),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             double mx = NEG_INF_D;
             for (int k = tid; k < KM; k += nt) mx = z[k] > mx ? z[k] : mx;
             mx = block_max(mx, red);
@@ -848,9 +915,9 @@ __global__ __launch_bounds__(512) void k_fb_chain(FbChainArgs A)
         }, A.time_power_term, A.wip, vec, tid, nt);
         __syncthreads();
         if (tid < 64) {
-            StreamUniforms usrc = {A.ustream, (int64_t)sh_cur, A.ucap, A.status};
+            StreamUniforms usrc = {us_l, (int64_t)sh_cur, A.ucap, A.status, ucur0};
             const double total = fb_dp_sample(vec, al, ww, pr, N, tri, A.n_max, A.viterbi, A.log_p_continue, A.anneal_fb, bnd_l, lane, usrc);
-            const int nn = fb_collect_tokens_wave(vid_l, bnd_l, N, tok_l, lane);
+            const int nn = fb_collect_tokens_wave(vid_l, bnd_l, N, tok_l, lane, spec ? tokj_l : nullptr);
             if (lane == 0) {
                 if (!A.viterbi && total == NEG_INF_D) atomicOr(A.status, 16);      // unigram_acoustic_wordseg.py:753
                 sh_cur = usrc.cur;
@@ -863,18 +930,32 @@ __global__ __launch_bounds__(512) void k_fb_chain(FbChainArgs A)
         FBC_STAMP(5);
         const int nn = sh_nn;
         if (tid == 0) sh_jprev = -1;
+        if (spec)                                        // the chosen spans' rows of predictive terms, one round trip
+            for (int i = tid; i < nn * K_C; i += nt) {
+                const int t = i / K_C, k = i - t * K_C;
+                pl[t * KM + k] = __longlong_as_double((long long)__hip_atomic_load(&A.ptab[(int64_t)tokj_l[t] * KM + k], __ATOMIC_RELAXED,
+                                                                                    __HIP_MEMORY_SCOPE_AGENT));
+            }
         for (int t = 0; t < nn; t++) {
             const int64_t e = tok_l[t];
             if (tid == 0) ldsK = shK;
             __syncthreads();
+            FBC_SUB(0);
             const int j_prev = sh_jprev;
             // (with a language model: lm.log_prob_vec_i for the first segment, then given the one before, :482-494)
-            fb_logits<XT>(cl, fl, e, lm ? (j_prev < 0 ? 3 : 4) : (A.map_assign ? 2 : 1), j_prev, xrow, z, red, A.lprior_tab);
-            fb_draw_component(fl, z, red, A.map_assign, A.anneal_am, A.ustream, (int64_t *)&sh_cur, A.ucap, A.status, shK, &sh_k);
+            fb_logits<XT>(cl, fl, e, lm ? (j_prev < 0 ? 3 : 4) : (A.map_assign ? 2 : 1), j_prev, xrow, z, red, lprior_l, nullptr,
+                          pl + t * KM, spec ? K_C : 0, modf);      // (K_in = 0: every component evaluated, pl / modf not read)
+            FBC_SUB(1);
+            fb_draw_component(fl, z, red, A.map_assign, A.anneal_am, us_l, (int64_t *)&sh_cur, A.ucap, A.status, shK, &sh_k, ucur0);
             __syncthreads();
+            FBC_SUB(2);
             fb_add_item<XT>(cl, fl, e, sh_k, &shK, &sh_i, red, &loc);
-            if (tid == 0) sh_jprev = sh_k;
+            if (tid == 0) {
+                sh_jprev = sh_k;
+                if (spec) modf[sh_k] = 1;
+            }
             __syncthreads();
+            FBC_SUB(3);
         }
         if (lm) {                                    // the counts of the new transcript (:546-547)
             // (the row python's -1 names, as the launches see it at this point: relabelled when a component moved)
@@ -1298,11 +1379,18 @@ int32_t segk_fbgmm_sequential_sweep(segk_ctx *ctx, const segk_corpus *c, segk_fb
     const size_t lds = (size_t)(3 * KD + 3 * KM + 1 + KM + nt + triMax + 3 * NM + 2 + 3 * D) * sizeof(double) + xb +
                        (size_t)(2 * triMax + max_rows + NM) * sizeof(int32_t) + (size_t)((NM + 15) & ~15) +
                        (size_t)max_rows * D * (c->x_dtype == SEGK_F32 ? 4 : 8) + 16 +
-                       (f->lm_unigram ? (size_t)KM * sizeof(int64_t) + (size_t)NM * sizeof(int32_t) + 16 : 0);
+                       (f->lm_unigram ? (size_t)KM * sizeof(int64_t) + (size_t)NM * sizeof(int32_t) + 16 : 0) +
+                       (size_t)(2 * NM + 2 + max_rows + KM) * sizeof(double) + 16;  // the staged uniforms and log prior predictives, pz
     if (lds > 150 * 1024) {
         segk_set_error("segk_fbgmm_sequential_sweep: the model (%d components x %d dimensions) does not fit a workgroup's LDS", KM, D);
         return SEGK_ERR_UNSUPPORTED;
     }
+    // the spans' predictive terms kept for the assignment (k_fb_chain, `spec`): [K_max] + [N_max][K_max] doubles, the segments'
+    // span indices and the components' flags -- when they fit beside the model (SEGK_FB_CHAIN_TERMS=0: evaluate every
+    // component per segment as before; the same results)
+    const size_t lds_terms = (size_t)((size_t)NM * KM) * sizeof(double) + (size_t)NM * sizeof(int32_t) + (((size_t)KM + 15) & ~(size_t)15) + 16;
+    const char *et = getenv("SEGK_FB_CHAIN_TERMS");
+    const bool terms = lds + lds_terms <= 150 * 1024 && !(et && atoi(et) == 0);
     // control words + the order, owned by the context
     const size_t ctl_bytes = 32 * (1 + CH_FLAGS) * sizeof(int32_t), need = ctl_bytes + (size_t)n_order * sizeof(int32_t);
     if (ctx->fbchain_bytes < need) {
@@ -1383,14 +1471,35 @@ int32_t segk_fbgmm_sequential_sweep(segk_ctx *ctx, const segk_corpus *c, segk_fb
         }
         A.lm_rep = (int64_t *)ctx->fbchain_lm;
     }
+    A.ptab = nullptr;
+    if (terms) {
+        const size_t nb = (size_t)triMax * KM * sizeof(unsigned long long);
+        if (ctx->fbchain_terms_bytes < nb) {
+            if (ctx->fbchain_terms) (void)hipFree(ctx->fbchain_terms);
+            ctx->fbchain_terms = nullptr;
+            ctx->fbchain_terms_bytes = 0;
+            SEGK_CHECK_HIP(hipMalloc(&ctx->fbchain_terms, nb));
+            ctx->fbchain_terms_bytes = nb;
+        }
+        A.ptab = (unsigned long long *)ctx->fbchain_terms;
+    }
+    const size_t lds_all = lds + (terms ? lds_terms : 0);
     int q = 0;
     while (q < n_order) {
         SEGK_CHECK_HIP(hipMemsetAsync(buf, 0, ctl_bytes, st));
+        if (stamping) SEGK_CHECK_HIP(hipMemsetAsync(stamp_dev + 256 * 8, 0, 8 * sizeof(unsigned long long), st));
         A.q0 = q; A.q1 = n_order;
-        DISPATCH_XT(c, {
-            SEGK_CHECK_HIP(segk_dyn_lds((const void *)k_fb_chain<XT>, lds));
-            hipLaunchKernelGGL(k_fb_chain<XT>, dim3(G), dim3(nt), lds, st, A);
-        });
+#define FB_CHAIN_LAUNCH(COV, LM)                                                                      \
+    DISPATCH_XT(c, {                                                                                  \
+        SEGK_CHECK_HIP(segk_dyn_lds((const void *)k_fb_chain<XT, COV, LM>, lds_all));                 \
+        hipLaunchKernelGGL((k_fb_chain<XT, COV, LM>), dim3(G), dim3(nt), lds_all, st, A);             \
+    })
+        if (f->cov_type == 0) {
+            if (f->lm_unigram) FB_CHAIN_LAUNCH(0, true); else FB_CHAIN_LAUNCH(0, false);
+        } else {
+            if (f->lm_unigram) FB_CHAIN_LAUNCH(1, true); else FB_CHAIN_LAUNCH(1, false);
+        }
+#undef FB_CHAIN_LAUNCH
         SEGK_LAUNCH_CHECK();
         int32_t ctl[8 + 2 * FB_RELOG];
         SEGK_CHECK_HIP(hipMemcpyAsync(ctl, A.ctl, sizeof(ctl), hipMemcpyDeviceToHost, st));
@@ -1416,6 +1525,9 @@ int32_t segk_fbgmm_sequential_sweep(segk_ctx *ctx, const segk_corpus *c, segk_fb
             const double dn = 100.0 * (n1 - n0);
             fprintf(stderr, "fb chain stamps (us): stage %.2f  remove %.2f  scores %.2f  barrier %.2f  vec+dp %.2f  assign %.2f  write %.2f | per utterance %.2f\n",
                     acc[0] / dn, acc[1] / dn, acc[2] / dn, acc[3] / dn, acc[4] / dn, acc[5] / dn, acc[6] / dn, acc[7] / dn);
+            const double ntok = (double)hs[256 * 8 + 7] > 0 ? (double)hs[256 * 8 + 7] : 1.0;
+            fprintf(stderr, "  per new segment (us, %.0f segments over the launch): logits %.2f  draw %.2f  add_item %.2f\n", ntok,
+                    (double)hs[256 * 8 + 1] / 100.0 / ntok, (double)hs[256 * 8 + 2] / 100.0 / ntok, (double)hs[256 * 8 + 3] / 100.0 / ntok);
         }
         q = ctl[2];
         if (ctl[4] > 0) {                 // components emptied during utterance ctl[5]: the other utterances' rows follow

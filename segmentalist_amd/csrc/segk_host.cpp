@@ -109,6 +109,7 @@ int32_t segk_destroy(segk_ctx *ctx)
         if (ctx->chain_buf) (void)hipFree(ctx->chain_buf);
         if (ctx->fbchain_buf) (void)hipFree(ctx->fbchain_buf);
         if (ctx->fbchain_lm) (void)hipFree(ctx->fbchain_lm);
+        if (ctx->fbchain_terms) (void)hipFree(ctx->fbchain_terms);
         if (ctx->fb_ktab) (void)hipFree(ctx->fb_ktab);
         if (ctx->fb_ptab) (void)hipFree(ctx->fb_ptab);
         if (ctx->fbs_buf) (void)hipFree(ctx->fbs_buf);

@@ -41,6 +41,8 @@ struct segk_ctx {
     size_t fbchain_bytes;
     void *fbchain_lm;             // ... with a language model: the workgroups' copies of the bigram counts
     size_t fbchain_lm_bytes;
+    void *fbchain_terms;          // ... the spans' predictive terms of one utterance, the exchange between the workgroups
+    size_t fbchain_terms_bytes;
     // batch sampler: the block's tokens bucketed by slot (k_fbb_sort) + offsets
     int32_t *fbs_buf;
     size_t fbs_bytes;
@@ -79,7 +81,7 @@ struct segk_ctx {
     // full scan with the components in LDS (k_kmeans_brute_ls): (score, component) per queue entry, zero between uses
     unsigned long long *brute_ws;
     int64_t brute_ws_cap;
-    // k-means batch finalize: the flagged tokens of a sweep beyond the kernel's LDS list, [4][flag_ovf_cap] int32
+    // k-means batch finalize: the flagged tokens of a sweep beyond the kernel's LDS list, [5][flag_ovf_cap] int32
     int32_t *flag_ovf;
     int64_t flag_ovf_cap;
     // diagnostic probes of the batch sampler's tolerance modes (segk_fbb_set_probe); NULL = off

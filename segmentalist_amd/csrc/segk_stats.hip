@@ -1098,14 +1098,17 @@ __global__ __launch_bounds__(256) void k_batch_finalize(
     __shared__ int32_t ml[FIN_ROWS][FIN_ML];
     __shared__ int ml_cnt[FIN_ROWS];
     const PackAddr pa{nbl, K_max, D, cap, rank_stride, row_words};
-    // flagged token q of the sweep: the first SEGK_FLAG_LDS in LDS, the others in ovf [4][ovf_cap] (slot, row, k, block)
+    // flagged token q of the sweep: the first SEGK_FLAG_LDS in LDS, the others in ovf [5][ovf_cap] (slot, row, raw label, block,
+    // clamped label).  Every workgroup writes the same values into them; the clamped labels have a plane of their own -- written
+    // over the raw ones, a workgroup that stages late put raw labels back under a workgroup that had already replayed the clamp
+    // (seen once the replay took 7 us instead of 87: wrong sums of the components founded beyond the 2 048th flagged token)
     // (the overflow arrays through an explicitly global pointer: left generic, the compiler merges the two sources of an accessor
     // into one flat pointer, and the LDS-aperture test it then needs does not always survive instruction selection)
     typedef __attribute__((address_space(1))) int32_t gi32;
     gi32 *ovg = (gi32 *)(uintptr_t)ovf;
     auto FL_SLOT = [&](int q) -> int { return q < SEGK_FLAG_LDS ? fl_slot[q] : ovg[q - SEGK_FLAG_LDS]; };
     auto FL_ROW = [&](int q) -> int { return q < SEGK_FLAG_LDS ? fl_row[q] : ovg[(int64_t)ovf_cap + q - SEGK_FLAG_LDS]; };
-    auto FL_K = [&](int q) -> int { return q < SEGK_FLAG_LDS ? (int)fl_k[q] : ovg[2 * (int64_t)ovf_cap + q - SEGK_FLAG_LDS]; };
+    auto FL_K = [&](int q) -> int { return q < SEGK_FLAG_LDS ? (int)fl_k[q] : ovg[4 * (int64_t)ovf_cap + q - SEGK_FLAG_LDS]; };
     auto FL_BLK = [&](int q) -> int { return q < SEGK_FLAG_LDS ? (int)fl_blk[q] : ovg[3 * (int64_t)ovf_cap + q - SEGK_FLAG_LDS]; };
     // element d of flagged token q's embedding row: from X, or -- a sharded corpus -- from the rows the token's rank put into
     // its record (FL_ROW is then the token's place in its block's list)
@@ -1239,7 +1242,7 @@ __global__ __launch_bounds__(256) void k_batch_finalize(
             const int k = kr < Kq ? kr : Kq;
             if (in) {
                 if (q < SEGK_FLAG_LDS) fl_k[q] = (unsigned short)k;
-                else ovg[2 * (int64_t)ovf_cap + q - SEGK_FLAG_LDS] = k;
+                else ovg[4 * (int64_t)ovf_cap + q - SEGK_FLAG_LDS] = k;
             }
             K += __popcll(mk);
         }
@@ -1960,7 +1963,7 @@ int32_t segk_kmeans_batch_finalize(segk_ctx *ctx, const segk_corpus *c, segk_kme
             if (ctx->flag_ovf) (void)hipFree(ctx->flag_ovf);
             ctx->flag_ovf = nullptr;
             ctx->flag_ovf_cap = 0;
-            SEGK_CHECK_HIP(hipMalloc((void **)&ctx->flag_ovf, (size_t)need * 4 * sizeof(int32_t)));
+            SEGK_CHECK_HIP(hipMalloc((void **)&ctx->flag_ovf, (size_t)need * 5 * sizeof(int32_t)));
             ctx->flag_ovf_cap = need;
         }
         ovf = ctx->flag_ovf;
