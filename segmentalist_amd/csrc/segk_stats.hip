@@ -1070,6 +1070,7 @@ __device__ __forceinline__ double tree_reduce_d(double *v, int n)
                                      beyond go through the context's overflow arrays in global memory (identical values
                                      written by every workgroup) -- the only limit left is flag_cap per block              */
 #define FIN_ROWS 8                /* final rows per workgroup */
+#define FIN_MH 4                  /* ... of which the first FIN_MH are requested together with the records' sums when the list is that short */
 #define FIN_ML 128                /* flagged tokens of a new component listed per row (more: the general loop) */
 
 template <typename XT>
@@ -1121,6 +1122,20 @@ __global__ __launch_bounds__(256) void k_batch_finalize(
     const int wg = blockIdx.x;
     const int j0 = wg * FIN_ROWS;
     SEGK_TSTAMP(3, 0);
+    // issued with the first loads of the kernel, consumed after the counts below (each was a dependent round trip of its own
+    // behind them, ~1.5 us per sweep each): the blocks' numbers of flagged tokens, and -- on speculation, the addresses are
+    // valid whatever the numbers turn out to be -- entry (tid & 31) of block (tid >> 5): a settled chain flags a handful
+    int fc_early = 0;
+    if (tid < n_blocks) fc_early = reinterpret_cast<const int32_t *>(pack + pa.flg(tid))[0];
+    const int sp_b = tid >> 5, sp_q = tid & 31;
+    const bool sp_ok = sp_b < n_blocks && sp_q < cap;
+    int sp_sl = 0, sp_kr = 0, sp_rw = 0;
+    if (sp_ok) {
+        const int32_t *fl = reinterpret_cast<const int32_t *>(pack + pa.flg(sp_b));
+        sp_sl = fl[2 + 3 * sp_q + 0];
+        sp_kr = fl[2 + 3 * sp_q + 1];
+        sp_rw = fl[2 + 3 * sp_q + 2];
+    }
 
     // ---- (0a) combined counts of the un-flagged tokens (labels < Kb): every load of a thread issued before the first use
     long long csum = 0;
@@ -1155,7 +1170,7 @@ __global__ __launch_bounds__(256) void k_batch_finalize(
     }
     // ---- (0b) the flagged tokens of all blocks in global token order: clamp replay by one thread (the blocks'
     // counts are fetched side by side first: normally they are all zero and the replay is over at once)
-    if (tid < n_blocks) fl_cnt[tid] = reinterpret_cast<const int32_t *>(pack + pa.flg(tid))[0];
+    if (tid < n_blocks) fl_cnt[tid] = fc_early;
     for (int o = 32; o > 0; o >>= 1) csum += __shfl_xor(csum, o);
     if (lane == 0) red[wv] = csum;
     __syncthreads();
@@ -1193,8 +1208,11 @@ __global__ __launch_bounds__(256) void k_batch_finalize(
                 cbs[i] = b0 + i < n_blocks ? (fl_cnt[b0 + i] < cap ? fl_cnt[b0 + i] : cap) : 0;
                 ats[i] = at;
                 at += cbs[i];
+                // (entries 0..31 of the first nt / 32 blocks: fetched on speculation at the top of the kernel)
+                if (b0 + i == sp_b && sp_ok && sp_q < cbs[i]) put(ats[i] + sp_q, sp_b, sp_sl, sp_kr, row_words ? sp_q : sp_rw);
             }
-            for (int q0 = 0; q0 < maxcb; q0 += nt) {
+            const int q_lo = b0 < nt / 32 ? 32 : 0;          // (nt / 32 = 8 blocks: the whole group b0 = 0 or none of a later one)
+            for (int q0 = q_lo; q0 < maxcb; q0 += nt) {
                 const int q = q0 + tid;
                 int sl[8], kr[8], rw[8];
 #pragma unroll
@@ -1377,6 +1395,8 @@ __global__ __launch_bounds__(256) void k_batch_finalize(
         double tv[4][8];
         int cls[4], src[4];          // 0 nothing, 1 inactive row, 2 eight-block tree from the records, 3 general
         int el[4];
+        XT xh[4][FIN_MH];            // founded components with at most FIN_MH tokens: the tokens' elements, requested early
+        int bh[4][FIN_MH], nh[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int e = e0 + u * 256 + tid;
@@ -1396,6 +1416,20 @@ __global__ __launch_bounds__(256) void k_batch_finalize(
 #pragma unroll
                 for (int b = 0; b < 8; b++) tv[u][b] = rpack[pa.sum(b) + off];         // unconditional: always a valid address
             }
+            // a component founded this sweep with a short match list (the usual case: a settled chain founds one or two per
+            // sweep, of one or two tokens): its tokens' rows are requested HERE, with the records' sums of the other elements
+            // -- requested inside the loop below they were one more dependent round trip for the workgroup that holds the
+            // component, 4-6 us at the end of the kernel every sweep
+            nh[u] = -1;
+            if (cls[u] == 3 && n_blocks == 8 && src[u] >= Kb && ml_cnt[r] >= 1 && ml_cnt[r] <= FIN_MH) {
+                nh[u] = ml_cnt[r];
+#pragma unroll
+                for (int i = 0; i < FIN_MH; i++) {
+                    const int qq = ml[r][i < nh[u] ? i : nh[u] - 1];
+                    bh[u][i] = FL_BLK(qq);
+                    xh[u][i] = FLX(qq, d);
+                }
+            }
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -1412,6 +1446,17 @@ __global__ __launch_bounds__(256) void k_batch_finalize(
             double v;
             if (cls[u] == 2) {
                 v = ((tv[u][0] + tv[u][1]) + (tv[u][2] + tv[u][3])) + ((tv[u][4] + tv[u][5]) + (tv[u][6] + tv[u][7]));
+            } else if (nh[u] >= 0) {
+                double g8[8];
+#pragma unroll
+                for (int b = 0; b < 8; b++) g8[b] = 0.0;
+#pragma unroll
+                for (int i = 0; i < FIN_MH; i++)
+                    if (i < nh[u]) {
+#pragma unroll
+                        for (int b = 0; b < 8; b++) g8[b] = bh[u][i] == b ? g8[b] + (double)xh[u][i] : g8[b];
+                    }
+                v = ((g8[0] + g8[1]) + (g8[2] + g8[3])) + ((g8[4] + g8[5]) + (g8[6] + g8[7]));
             } else if (n_blocks == 8 && src[u] >= Kb && ml_cnt[r] <= FIN_ML) {
                 // a component founded this sweep: its flagged tokens, block by block -- the row's match list (LDS), eight
                 // rows in flight, the block's accumulator chosen by predicate (a dynamically indexed array lives in scratch)

@@ -277,8 +277,11 @@ def test_persistent_chain_equals_the_four_launches_per_utterance(gpu, monkeypatc
     prior = (FixedVarPrior(0.002 * np.ones(D), np.zeros(D), 0.002 / 0.05 * np.ones(D)) if cov == "fixed"
              else NIW(np.zeros(D), 0.05, D + 3, 0.002 * (D + 3) * np.ones(D)))
     out = {}
-    for mode in ("1", "0"):
-        monkeypatch.setenv("SEGK_FB_CHAIN", mode)
+    for mode in ("1", "terms0", "0"):
+        # "terms0": the chain evaluating every component's predictive term again for each new segment instead of keeping the
+        # spans' terms from the scoring phase (SEGK_FB_CHAIN_TERMS=0: also what runs when the kept rows do not fit in LDS)
+        monkeypatch.setenv("SEGK_FB_CHAIN", "0" if mode == "0" else "1")
+        monkeypatch.setenv("SEGK_FB_CHAIN_TERMS", "0" if mode == "terms0" else "1")
         random.seed(3)
         np.random.seed(3)
         seg = uaw.UnigramAcousticWordseg(fbgmm.FBGMM, 1.0, K, prior, *corpus, covariance_type=cov, fb_type=fb_type,
@@ -291,11 +294,12 @@ def test_persistent_chain_equals_the_four_launches_per_utterance(gpu, monkeypatc
                          lp=df.log_prod.cpu().numpy(), kc=df.kconst.cpu().numpy(), cn=df.counts.cpu().numpy(),
                          K=int(df.K.item()), rec={k: list(v) for k, v in rec.items() if k != "sample_time"}, rnd=random.random())
     assert min(out["1"]["rec"]["components"]) < K, "no component emptied: the test does not cover the relaunches"
-    for k in out["1"]:
-        if isinstance(out["1"][k], np.ndarray):
-            assert np.array_equal(out["1"][k], out["0"][k]), k
-        else:
-            assert out["1"][k] == out["0"][k], k
+    for other in ("0", "terms0"):
+        for k in out["1"]:
+            if isinstance(out["1"][k], np.ndarray):
+                assert np.array_equal(out["1"][k], out[other][k]), (other, k)
+            else:
+                assert out["1"][k] == out[other][k], (other, k)
 
 
 @pytest.mark.parametrize("sync", ["sequential", "batch"])
