@@ -207,3 +207,81 @@ def test_complete_band_tables_only_when_no_embedding_lies_outside_the_window():
                 assert ids[i, t - 1, w] == want
     assert u.complete_band_tables(3) is None            # spans of four slices have embeddings: a window of three drops them
     assert u.complete_band_tables(0) is None and u.complete_band_tables(u.N_max) is None
+
+
+def test_parallel_forms_of_the_finalize_kernels_serial_loops_equal_the_serial_loops():
+    """k_batch_finalize (csrc/segk_stats.hip) runs two loops of the reference in parallel; the formulas it relies on, restated
+    here in a few lines each, against the serial loops on random inputs (the kernel itself is held to the oracle by the GPU
+    parity tests; this pins the derivations, including the corner cases: adjacent holes, holes at the top, no holes, every row
+    a hole, labels far beyond K).
+    (1) clean_components on indices (kmeans_components.py:129-151, 263-266): holes walked in descending order, each filled
+        from the last active position.  Parallel: hole number i (1 = highest) is filled from position P = K1 - i; while P is
+        itself a hole, number j, it holds what hole j received: continue at K1 - j.
+    (2) add_item's `k > K -> K` clamp (kmeans_components.py:102-106) over the flagged tokens in order: token q founds a
+        component iff its raw label >= K + (founders before it); per 64 tokens the founders' mask is the fixed point of
+        mask -> [raw >= K + popcount(mask below)], reached from any start in at most 64 rounds."""
+    rs = np.random.RandomState(5)
+    for trial in range(300):
+        K1 = int(rs.randint(1, 200))
+        p_hole = rs.choice([0.0, 0.05, 0.3, 0.7, 1.0])
+        hole = rs.rand(K1) < p_hole
+        # serial walk
+        pos = list(range(K1))
+        K = K1
+        order = []
+        for k in range(K1 - 1, -1, -1):
+            if hole[k]:
+                K -= 1
+                if k != K:
+                    pos[k] = pos[K]
+                order.append(k)
+        # parallel form
+        above = np.concatenate([np.cumsum(hole[::-1])[::-1][1:], [0]]).astype(int)      # holes at positions > k
+        pos2 = list(range(K1))
+        holes2 = [None] * int(hole.sum())
+        for k in range(K1):
+            if not hole[k]:
+                continue
+            i = above[k] + 1
+            holes2[i - 1] = k
+            p = K1 - i
+            if p == k:
+                continue
+            while hole[p]:
+                p = K1 - (above[p] + 1)
+            pos2[k] = p
+        assert holes2 == order
+        assert K == K1 - int(hole.sum())
+        assert pos2[:K] == pos[:K], (trial, K1)
+        for k in order:                     # (what the relabel table is built from: holes below the final K)
+            if k < K:
+                assert pos2[k] == pos[k]
+    for trial in range(300):
+        Kb = int(rs.randint(0, 50))
+        n = int(rs.randint(0, 300))
+        raw = Kb + rs.randint(0, rs.choice([1, 3, 40, 1000]), size=n)
+        K = Kb
+        want = []
+        for r in raw:
+            k = min(int(r), K)
+            if k == K:
+                K += 1
+            want.append(k)
+        K2 = Kb
+        got = []
+        for q0 in range(0, n, 64):
+            kr = raw[q0:q0 + 64]
+            m = len(kr)
+            mask = kr >= K2
+            for _ in range(66):
+                below = np.concatenate([[0], np.cumsum(mask)[:-1]]) if m else np.zeros(0, int)
+                m2 = kr >= K2 + below
+                if np.array_equal(m2, mask):
+                    break
+                mask = m2
+            else:
+                raise AssertionError("no fixed point within 66 rounds")
+            below = np.concatenate([[0], np.cumsum(mask)[:-1]]) if m else np.zeros(0, int)
+            got.extend(np.minimum(kr, K2 + below).tolist())
+            K2 += int(mask.sum())
+        assert got == want and K2 == K, trial
