@@ -188,6 +188,7 @@ def early_sweeps(kaw, corpus, args, n_sweeps=10):
             np.random.seed(0)
             seg = kaw.SegmentalKMeansWordseg(args.K, *corpus, n_slices_max=args.n_slices_max,
                                              init_am_assignments="spread", sync="batch")
+            seg._get_sweeper()          # (as the main run does before its warm-up: the sweeper's tables are construction, not sweep 1)
             ms, second, full, comps = [], [], [], []
             sc = (C.c_int32 * 2)()
             for _ in range(n_sweeps):
