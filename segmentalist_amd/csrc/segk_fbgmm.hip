@@ -230,12 +230,16 @@ __device__ void fb_del_item(const segk_corpus &c, const segk_fbgmm &f, int64_t e
 
 // op 0: delete the OLD segments of utterance `utt` (listed from the boundaries + vec_ids)
 // op 1: add_item(item, k_item)   op 2: del_item(item)   op 4: del_component(k_item)
+// (fb_nt(f) threads, like the assignment kernel and the persistent chain: fb_update_derived's block-wide sum of D logarithms
+// associates by the number of threads once D > 256 -- launched with 256 threads whatever the bank's width, the removal of an
+// utterance's old segments left log_prod a last bit away from what the other kernels compute from the same statistics, and the
+// span scores of that utterance with it: tools/diag_chain_dsweep.py)
 template <typename XT>
-__global__ __launch_bounds__(256) void k_fbgmm_update(segk_corpus c, segk_fbgmm f, int op, int utt, int64_t item, int k_item,
+__global__ __launch_bounds__(512) void k_fbgmm_update(segk_corpus c, segk_fbgmm f, int op, int utt, int64_t item, int k_item,
                                const uint8_t *boundaries)
 {
     __shared__ int shK, sh_i;
-    __shared__ double red[256];
+    __shared__ double red[512];
     if (threadIdx.x == 0) shK = *f.K;
     __syncthreads();
     if (op == 0) {
@@ -1227,7 +1231,7 @@ int32_t segk_fbgmm_update(segk_ctx *ctx, const segk_corpus *c, segk_fbgmm *f, in
     int rc = check_fb(c, f);
     if (rc) return rc;
     SEGK_REQUIRE(op == 0 || op == 1 || op == 2 || op == 4 || op == 5 || op == 6, "op");
-    DISPATCH_XT(c, hipLaunchKernelGGL(k_fbgmm_update<XT>, dim3(1), dim3(256), 0, (hipStream_t)stream, *c, *f, op, utt,
+    DISPATCH_XT(c, hipLaunchKernelGGL(k_fbgmm_update<XT>, dim3(1), dim3(fb_nt(f)), 0, (hipStream_t)stream, *c, *f, op, utt,
                                        item, k, boundaries););
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;
