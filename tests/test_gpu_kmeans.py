@@ -426,16 +426,19 @@ def test_operand_images_after_a_batch_sweep_equal_a_fresh_prepare(gpu, n_utt, D,
 
 
 @pytest.mark.parametrize("n_utt,D,K,N,nmax,n_blocks,sweeps,p_b", [(150, 16, 2500, 0, 6, 8, 3, 0.5), (1700, 8, 12, 20, 4, 1, 2, 0.7),
-                                                                (1000, 8, 2, 20, 1, 1, 2, 1.0), (900, 12, 70, 20, 2, 2, 2, 0.8)],
+                                                                (1000, 8, 2, 20, 1, 1, 2, 1.0), (900, 12, 70, 20, 2, 2, 2, 0.8),
+                                                                (400, 16, 600, 0, 6, 16, 3, 0.5), (260, 12, 900, 0, 5, 12, 3, 0.5),
+                                                                (2000, 8, 300, 12, 4, 40, 3, 0.5)],
                          ids=["ranges_of_128_components", "block_beyond_the_preloaded_keys", "compaction_overflow",
-                              "two_large_blocks"])
+                              "two_large_blocks", "sixteen_blocks", "twelve_blocks", "forty_blocks"])
 def test_batch_statistics_kernel_fallbacks_vs_spec(gpu, n_utt, D, K, N, nmax, n_blocks, sweeps, p_b):
     """k_batch_sort_sum (csrc/segk_stats.hip) beyond the headline shape, against oracle/np_oracle.py kmeans_batch_sweep bit for bit:
     K_max > 2048 (ranges of 128 components instead of 32); a statistics block of more than 32 768 slots (its keys are not
     preloaded, the placement pass walks all slots again); more than 512 in-range tokens per wave (a window of one slice makes
     every landmark a token, two components share one range: the compacted list overflows and the workgroup falls back to the
     walk); two blocks of 9 000 slots with long per-component lists (several 32-row batches per list, component boundaries
-    inside a batch)."""
+    inside a batch); more than eight statistics blocks, with components founded in the first sweeps (the finalize kernel stages
+    the flagged tokens of blocks 8.. without the speculative fetch of the first eight, and sums by the general tree)."""
     from oracle import np_oracle as no
     from segmentalist_amd import kmeans_acoustic_wordseg as kaw
     from segmentalist_amd.synth import make_corpus
