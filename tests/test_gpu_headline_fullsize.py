@@ -221,6 +221,40 @@ def test_a_hinted_path_gives_the_oracle_bits_whatever_the_hints(gpu, headline, s
     assert hit >= 1
     check("duplicate of the winner", adv, ident, hit, hit + int(1.2 * scored["n_second"]) + 64)
 
+    # (6) a sub-range and (7) a row LIST (what a mini-batch step and an unsharded rank hand over): the rows named get the
+    # oracle's bits, every other row keeps what it held
+    import ctypes as C
+    from segmentalist_amd import _abi
+    L, ctx = _abi.lib(), _abi.ctx()
+
+    def sub(tag, ids, row0, n):
+        stale = (want_k + 3) % K
+        start = np.where(rs.rand(n_emb) < 0.9, want_k, stale).astype(np.int32)        # 10 % wrong hints
+        dk.cand_k.copy_(torch.from_numpy(start).to(dk.cand_k.device))
+        dk.cand_s.fill_(float("nan"))
+        _abi.check(L.segk_profile_enable(ctx, 1))
+        ids_t = None if ids is None else torch.from_numpy(np.ascontiguousarray(ids.astype(np.int32))).cuda()
+        dk.score_rows(ids=ids_t, row0=row0, n=n, hint_remap=ident)
+        kind = int(L.segk_profile_last_kind(ctx))
+        _abi.check(L.segk_profile_enable(ctx, 0))
+        gpu.cuda.synchronize()
+        dk.check_status()
+        assert kind == 5, "%s: the hinted path did not run (kind %d)" % (tag, kind)
+        k, sc = dk.cand_k.cpu().numpy(), dk.cand_s.cpu().numpy()
+        named = np.zeros(n_emb, dtype=bool)
+        if ids is None:
+            named[row0:row0 + n] = True
+        else:
+            named[ids] = True
+        assert np.array_equal(k[named], want_k[named]), tag
+        assert np.array_equal(sc[named], want_s[named]), tag
+        assert np.array_equal(k[~named], start[~named]), tag + ": rows outside the call were touched"
+        assert np.isnan(sc[~named]).all(), tag + ": scores outside the call were touched"
+
+    sub("sub-range", None, 300007, 400001)
+    sub("row list, ascending", np.arange(5, n_emb, 3), 0, None)
+    sub("row list, shuffled", rs.permutation(n_emb)[:300000], 0, None)
+
 
 def test_b_all_boundaries_match_the_oracle_viterbi(headline, scored):
     from oracle import c_oracle as co
