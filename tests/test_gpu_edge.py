@@ -138,3 +138,35 @@ def test_batch_sweep_with_thousands_of_new_components_in_one_sweep(gpu):
     small = kaw.SegmentalKMeansWordseg(K_max, *corpus, sync="batch", n_stat_blocks=8, flag_cap=64, **kw)
     with pytest.raises(_abi.SegkError, match="flag_cap"):
         small.segment(1)
+
+
+@pytest.mark.parametrize("n_range,nmax,sync,n_blocks", [((3, 34), 6, "sequential", 1), ((3, 45), 6, "batch", 8), ((3, 80), 6, "sequential", 1),
+                                                        ((3, 80), 6, "batch", 8), ((30, 80), 10, "batch", 4), ((30, 80), 10, "sequential", 1)])
+def test_utterances_beyond_the_fast_kernels_landmark_limits(gpu, n_range, nmax, sync, n_blocks):
+    """More than 32 landmarks (the persistent sequential chain and the chain's update kernel stop applying), more than 64 (the
+    eight-lane segment kernel too) and windows of more than eight slices: the fall-backs behind the fast kernels, against the
+    specification bit for bit -- boundaries, assignments, K, means and the record total over three sweeps, sequential mode (the
+    visiting order shuffled from the same stream position on both sides) and batch mode."""
+    from segmentalist_amd import kmeans_acoustic_wordseg as kaw
+    from segmentalist_amd.synth import make_corpus
+    corpus = make_corpus(40, 16, 30, seed=11, ragged=True, n_slices_max=nmax, N_range=n_range)
+    random.seed(5); np.random.seed(5)
+    ref = no.SegmentalKMeansWordseg(30, *corpus, n_slices_max=nmax, init_am_assignments="spread")
+    random.seed(5); np.random.seed(5)
+    kw = dict(sync="batch", n_stat_blocks=n_blocks) if sync == "batch" else {}
+    seg = kaw.SegmentalKMeansWordseg(30, *corpus, n_slices_max=nmax, init_am_assignments="spread", **kw)
+    assert seg.utterances.boundaries.shape[1] > 32
+    cr, cd = ref.acoustic_model.components, seg.acoustic_model.components
+    for it in range(3):
+        if sync == "batch":
+            want = no.kmeans_batch_sweep(ref, n_blocks=n_blocks)
+        else:
+            st = random.getstate()
+            want = ref.segment(1)["sum_neg_len_sqrd_norm"][0]
+            random.setstate(st)
+        rec = seg.segment(1)
+        assert np.array_equal(seg.utterances.boundaries, ref.utterances.boundaries), it
+        assert np.array_equal(cd.assignments, cr.assignments), it
+        assert cd.K == cr.K
+        assert np.array_equal(cd.means, cr.means), it
+        assert rec["sum_neg_len_sqrd_norm"][0] == want, it
