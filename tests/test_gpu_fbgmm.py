@@ -354,3 +354,37 @@ def test_banded_span_tables_feed_the_fbgmm_kernels(gpu, monkeypatch, sync):
     seg = uaw.UnigramAcousticWordseg(fbgmm.FBGMM, 1.0, K, prior, *wide, **args)
     assert seg._corpus.band_W == 0
     seg.gibbs_sample(1)
+
+
+@pytest.mark.parametrize("n_range,nmax,cov,fb_type", [((3, 80), 6, "diag", "standard"), ((3, 80), 6, "fixed", "standard"),
+                                                      ((3, 80), 6, "diag", "viterbi"), ((30, 80), 10, "fixed", "standard")])
+def test_serial_chain_with_utterances_beyond_the_persistent_kernels_limit(gpu, n_range, nmax, cov, fb_type):
+    """More than 64 landmarks per utterance (the persistent chain and the one-wave DP's fast forms stop applying) and a window
+    of ten slices: the launches per utterance against oracle/np_oracle.py draw for draw -- boundaries, assignments and K equal,
+    log_marg within 1e-12 relative -- over two sweeps from the same stream position."""
+    from oracle import np_oracle as no
+    from segmentalist_amd import fbgmm, unigram_acoustic_wordseg as uaw
+    from segmentalist_amd.gaussian_components_fixedvar import FixedVarPrior
+    from segmentalist_amd.niw import NIW
+    from segmentalist_amd.synth import make_corpus
+    D, K = 12, 20
+    corpus = make_corpus(30, D, K, seed=4, ragged=True, n_slices_max=nmax, N_range=n_range)
+    kw = dict(covariance_type=cov, fb_type=fb_type, n_slices_min=0, n_slices_max=nmax, p_boundary_init=0.5, beta_sent_boundary=-1,
+              lms=1.0, wip=0.0, init_am_assignments="rand", time_power_term=1.0)
+    pa = ((0.002 * np.ones(D), np.zeros(D), 0.002 / 0.05 * np.ones(D)) if cov == "fixed"
+          else (np.zeros(D), 0.05, D + 3, 0.002 * (D + 3) * np.ones(D)))
+    random.seed(3); np.random.seed(3)
+    ref = no.UnigramAcousticWordseg(no.FBGMM, 1.0, K, (no.FixedVarPrior if cov == "fixed" else no.NIW)(*pa), *corpus, **kw)
+    random.seed(3); np.random.seed(3)
+    seg = uaw.UnigramAcousticWordseg(fbgmm.FBGMM, 1.0, K, (FixedVarPrior if cov == "fixed" else NIW)(*pa), *corpus, **kw)
+    assert seg.utterances.boundaries.shape[1] > 64
+    st = random.getstate()
+    r0 = ref.gibbs_sample(2)
+    random.setstate(st)
+    r1 = seg.gibbs_sample(2)
+    cr, cd = ref.acoustic_model.components, seg.acoustic_model.components
+    assert np.array_equal(seg.utterances.boundaries, ref.utterances.boundaries)
+    assert np.array_equal(cd.assignments, cr.assignments)
+    assert cd.K == cr.K
+    for a, b in zip(r0["log_marg"], r1["log_marg"]):
+        assert abs(a - b) <= 1e-12 * max(1.0, abs(a))
