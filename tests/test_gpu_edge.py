@@ -170,3 +170,35 @@ def test_utterances_beyond_the_fast_kernels_landmark_limits(gpu, n_range, nmax, 
         assert cd.K == cr.K
         assert np.array_equal(cd.means, cr.means), it
         assert rec["sum_neg_len_sqrd_norm"][0] == want, it
+
+
+@pytest.mark.parametrize("D,K,sync,n_blocks,n_batches", [(16, 30, "sequential", 1, 1), (100, 130, "batch", 8, 1), (24, 40, "batch", 4, 3),
+                                                         (7, 9, "batch", 2, 1)])
+def test_float64_corpora_end_to_end(gpu, D, K, sync, n_blocks, n_batches):
+    """float64 embeddings (the reference's dtype when the caller passes doubles: every score and statistic in float64, none of
+    the matrix-core filters apply) through the sequential chain, whole-sweep batches and mini-batches, against the specification
+    bit for bit over three sweeps."""
+    from segmentalist_amd import kmeans_acoustic_wordseg as kaw
+    from segmentalist_amd.synth import make_corpus
+    corpus = make_corpus(120, D, K, seed=13, ragged=True, n_slices_max=6, N_range=(3, 14), dtype=np.float64)
+    random.seed(5); np.random.seed(5)
+    ref = no.SegmentalKMeansWordseg(K, *corpus, n_slices_max=6, init_am_assignments="spread")
+    random.seed(5); np.random.seed(5)
+    kw = dict(sync="batch", n_stat_blocks=n_blocks, n_batches=n_batches) if sync == "batch" else {}
+    seg = kaw.SegmentalKMeansWordseg(K, *corpus, n_slices_max=6, init_am_assignments="spread", **kw)
+    cr, cd = ref.acoustic_model.components, seg.acoustic_model.components
+    assert cd.means.dtype == np.float64
+    totals = np.zeros(ref.utterances.D)
+    for it in range(3):
+        if sync == "batch":
+            want = no.kmeans_batch_sweep(ref, n_blocks=n_blocks) if n_batches == 1 else no.kmeans_minibatch_sweep(ref, n_blocks, n_batches, totals)
+        else:
+            st = random.getstate()
+            want = ref.segment(1)["sum_neg_len_sqrd_norm"][0]
+            random.setstate(st)
+        rec = seg.segment(1)
+        assert np.array_equal(seg.utterances.boundaries, ref.utterances.boundaries), it
+        assert np.array_equal(cd.assignments, cr.assignments), it
+        assert cd.K == cr.K
+        assert np.array_equal(cd.means, cr.means), it
+        assert rec["sum_neg_len_sqrd_norm"][0] == want, it
