@@ -202,3 +202,35 @@ def test_persistent_chain_with_a_language_model_equals_the_launches_per_utteranc
             assert np.array_equal(out["1"][k], out["0"][k]), k
         else:
             assert out["1"][k] == out["0"][k], k
+
+
+@pytest.mark.parametrize("n_utt,D,K,n_range,nmax", [(20, 300, 8, (3, 14), 5), (24, 12, 9, (3, 80), 6), (24, 12, 9, (30, 80), 10),
+                                                   (30, 520, 6, (3, 6), 5)])
+def test_bigram_chain_vs_oracle_wide_rows_and_long_utterances(gpu, n_utt, D, K, n_range, nmax):
+    """Shapes the golden chains do not reach: D = 300 and D = 520 (more dimensions than threads in the update kernels; beyond
+    the tabulated log prior predictive), utterances of up to 80 landmarks and a window of ten slices (the launches per
+    utterance instead of the persistent kernel) -- boundaries, assignments and the language model's counts equal to the
+    oracle's, log_marg within 1e-8 relative, over three sweeps from the same stream positions."""
+    from segmentalist_amd import bigram_acoustic_wordseg as baw
+    from segmentalist_amd.gaussian_components_fixedvar import FixedVarPrior
+    from segmentalist_amd.synth import make_corpus
+    no.set_shuffle("py3")
+    corpus = make_corpus(n_utt, D, K, seed=77, ragged=True, n_slices_max=nmax, N_range=n_range)
+    sides = []
+    for mod, pc in ((no, no.FixedVarPrior), (baw, FixedVarPrior)):
+        random.seed(5); np.random.seed(5)
+        args = dict(covariance_type="fixed", n_slices_min=0, n_slices_max=nmax, p_boundary_init=0.5, beta_sent_boundary=-1,
+                    lms=1.0, wip=0.0, fb_type="unigram", init_am_assignments="rand", time_power_term=1.0)
+        sides.append(mod.BigramAcousticWordseg(K, pc(*cases.fixed_prior_params(D)), dict(cases.BIGRAM_LM), *corpus, **args))
+    ref, seg = sides
+    for it in range(3):
+        st, nst = random.getstate(), np.random.get_state()
+        ref.gibbs_sample(1)
+        random.setstate(st)
+        np.random.set_state(nst)
+        seg.gibbs_sample(1)
+        assert np.array_equal(seg.utterances.boundaries, ref.utterances.boundaries), it
+        assert np.array_equal(seg.acoustic_model.components.assignments, ref.acoustic_model.components.assignments), it
+        assert np.array_equal(seg.lm.unigram_counts, ref.lm.unigram_counts), it
+        assert np.array_equal(seg.lm.bigram_counts, ref.lm.bigram_counts), it
+        npt.assert_allclose(seg.log_marg(), ref.log_marg(), rtol=1e-8)

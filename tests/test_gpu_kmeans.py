@@ -428,9 +428,11 @@ def test_operand_images_after_a_batch_sweep_equal_a_fresh_prepare(gpu, n_utt, D,
 @pytest.mark.parametrize("n_utt,D,K,N,nmax,n_blocks,sweeps,p_b", [(150, 16, 2500, 0, 6, 8, 3, 0.5), (1700, 8, 12, 20, 4, 1, 2, 0.7),
                                                                 (1000, 8, 2, 20, 1, 1, 2, 1.0), (900, 12, 70, 20, 2, 2, 2, 0.8),
                                                                 (400, 16, 600, 0, 6, 16, 3, 0.5), (260, 12, 900, 0, 5, 12, 3, 0.5),
-                                                                (2000, 8, 300, 12, 4, 40, 3, 0.5)],
+                                                                (2000, 8, 300, 12, 4, 40, 3, 0.5), (200, 8, 8192, 0, 6, 8, 2, 0.5),
+                                                                (300, 16, 2049, 0, 6, 4, 2, 0.5)],
                          ids=["ranges_of_128_components", "block_beyond_the_preloaded_keys", "compaction_overflow",
-                              "two_large_blocks", "sixteen_blocks", "twelve_blocks", "forty_blocks"])
+                              "two_large_blocks", "sixteen_blocks", "twelve_blocks", "forty_blocks", "largest_bank_8192",
+                              "first_bank_beyond_the_band_stage_2049"])
 def test_batch_statistics_kernel_fallbacks_vs_spec(gpu, n_utt, D, K, N, nmax, n_blocks, sweeps, p_b):
     """k_batch_sort_sum (csrc/segk_stats.hip) beyond the headline shape, against oracle/np_oracle.py kmeans_batch_sweep bit for bit:
     K_max > 2048 (ranges of 128 components instead of 32); a statistics block of more than 32 768 slots (its keys are not
