@@ -69,6 +69,9 @@ CASES = [
     ("diag", 33, 70, 12, 80, 4, 2, 2, {}),          # D > 64: two dimension chunks
     ("fixed", 19, 6, 300, 81, 5, 5, 1, {}),         # K_max > workgroup width
     ("diag", 130, 8, 10, 82, 5, 9, 12, {}),         # more than eight blocks and more than eight slices: k_fbb_prepare's second load rounds
+    ("diag", 20, 256, 12, 83, 4, 2, 2, {}),         # the widest rows the batch sampler takes (D <= 256)
+    ("fixed", 20, 200, 12, 84, 4, 2, 2, {}),
+    ("bigram", 30, 100, 40, 85, 5, 3, 4, {}),
 ]
 
 
@@ -95,12 +98,12 @@ def test_batch_sweeps_match_specification(gpu, kind, n_utt, D, K, cseed, nmax, B
         assert np.array_equal(c.counts[:Kc], cnt[cnt > 0])
 
 
-@pytest.mark.parametrize("kind,nmax", [("fixed", 20), ("diag", 20), ("fixed", 12)])
-def test_batch_sweeps_with_a_wide_window(gpu, kind, nmax):
+@pytest.mark.parametrize("kind,nmax,n_landmarks", [("fixed", 20, 24), ("diag", 20, 24), ("fixed", 12, 24), ("diag", 6, 64), ("fixed", 30, 64)])
+def test_batch_sweeps_with_a_wide_window(gpu, kind, nmax, n_landmarks):
     """Utterances of 24 landmarks and windows of 20 and 12 slices: the boundary sampler's register path beyond one row of
     sixteen lanes (fb_dp_sample: delay line by wave_shr, maxima across rows) and inside it with more than eight candidates."""
-    ref, spec, seg = _pair(kind, 8, 8, 10, 93, nmax, 2, 2, n_landmarks=24)
-    assert int(np.max(seg.utterances.lengths)) == 24
+    ref, spec, seg = _pair(kind, 8, 8, 10, 93, nmax, 2, 2, n_landmarks=n_landmarks)
+    assert int(np.max(seg.utterances.lengths)) == n_landmarks          # (64: the most the batch sampler takes)
     for sw in range(2):
         lp = spec.sweep(sw)
         seg.batch_sweep_async()
