@@ -202,3 +202,29 @@ def test_float64_corpora_end_to_end(gpu, D, K, sync, n_blocks, n_batches):
         assert cd.K == cr.K
         assert np.array_equal(cd.means, cr.means), it
         assert rec["sum_neg_len_sqrd_norm"][0] == want, it
+
+
+@pytest.mark.parametrize("n_utt,D,K,n_blocks,n_batches,n_range", [(5, 8, 4, 8, 1, (3, 9)), (1, 8, 3, 8, 1, (3, 9)), (3, 8, 1, 2, 1, (1, 3)),
+                                                                  (9, 5, 6, 8, 4, (1, 4)), (2, 3, 2, 1, 1, (1, 2)), (17, 129, 7, 3, 2, (2, 6))])
+def test_batch_mode_on_tiny_corpora(gpu, n_utt, D, K, n_blocks, n_batches, n_range):
+    """Fewer utterances than statistics blocks (empty blocks), one utterance, one component, one- and two-landmark utterances,
+    three to 129 dimensions, more mini-batches than a block has utterances: whole-sweep and mini-batch steps against the
+    specification bit for bit."""
+    from segmentalist_amd import kmeans_acoustic_wordseg as kaw
+    from segmentalist_amd.synth import make_corpus
+    corpus = make_corpus(n_utt, D, K, seed=31, ragged=True, n_slices_max=4, N_range=n_range)
+    random.seed(5); np.random.seed(5)
+    ref = no.SegmentalKMeansWordseg(K, *corpus, n_slices_max=4, init_am_assignments="spread")
+    random.seed(5); np.random.seed(5)
+    seg = kaw.SegmentalKMeansWordseg(K, *corpus, n_slices_max=4, init_am_assignments="spread", sync="batch", n_stat_blocks=n_blocks,
+                                     n_batches=n_batches)
+    cr, cd = ref.acoustic_model.components, seg.acoustic_model.components
+    totals = np.zeros(ref.utterances.D)
+    for it in range(3):
+        want = no.kmeans_batch_sweep(ref, n_blocks=n_blocks) if n_batches == 1 else no.kmeans_minibatch_sweep(ref, n_blocks, n_batches, totals)
+        rec = seg.segment(1)
+        assert np.array_equal(seg.utterances.boundaries, ref.utterances.boundaries), it
+        assert np.array_equal(cd.assignments, cr.assignments), it
+        assert cd.K == cr.K
+        assert np.array_equal(cd.means, cr.means), it
+        assert rec["sum_neg_len_sqrd_norm"][0] == want, it
