@@ -261,8 +261,10 @@ def test_unigram_chain_with_am_iterations_vs_reference(gpu, golden, chain):
 
 
 @pytest.mark.parametrize("cov,fb_type,D,K", [("diag", "standard", 12, 30), ("fixed", "standard", 12, 30), ("diag", "viterbi", 12, 30),
-                                             ("fixed", "viterbi", 12, 30), ("diag", "standard", 520, 6), ("fixed", "standard", 520, 6)],
-                         ids=["diag-standard", "fixed-standard", "diag-viterbi", "fixed-viterbi", "diag-D520", "fixed-D520"])
+                                             ("fixed", "viterbi", 12, 30), ("diag", "standard", 520, 6), ("fixed", "standard", 520, 6),
+                                             ("diag", "standard", 12, 300), ("fixed", "standard", 16, 256)],
+                         ids=["diag-standard", "fixed-standard", "diag-viterbi", "fixed-viterbi", "diag-D520", "fixed-D520", "diag-K300",
+                              "fixed-K256"])
 def test_persistent_chain_equals_the_four_launches_per_utterance(gpu, monkeypatch, cov, fb_type, D, K):
     """segk_fbgmm_sequential_sweep (one persistent kernel per stretch of utterances between two emptied components: every
     workgroup replays every update on a model held in LDS, only the span scores are shared out) against the four launches
