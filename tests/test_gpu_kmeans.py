@@ -832,7 +832,8 @@ def test_duplicate_means_are_taken_out_of_the_filters(gpu, monkeypatch, pre):
 @pytest.mark.parametrize("n_utt,D,K,N,nmax,ragged,mindur", [(300, 100, 1000, 20, 6, False, 0), (200, 40, 130, 0, 5, True, 0),
                                                              (150, 16, 9, 12, 8, False, 0), (120, 8, 300, 0, 3, True, 0),
                                                              (150, 8, 20, 0, 4, True, 9), (100, 12, 40, 0, 6, True, 14),
-                                                             (120, 8, 1500, 10, 5, False, 0), (100, 8, 5000, 0, 4, True, 0)])
+                                                             (120, 8, 1500, 10, 5, False, 0), (100, 8, 5000, 0, 4, True, 0),
+                                                             (60, 128, 50, 32, 6, False, 0)])
 def test_persistent_sequential_chain_equals_the_three_launch_form(gpu, monkeypatch, n_utt, D, K, N, nmax, ragged, mindur):
     """segk_seq_chain.hip (one persistent kernel per sweep: owner-computes components, one grid barrier per utterance, the DP
     replicated in every workgroup) against the three launches per utterance it replaces (SEGK_SEQ_CHAIN=0), which
@@ -841,9 +842,13 @@ def test_persistent_sequential_chain_equals_the_three_launch_form(gpu, monkeypat
     the window (no banded table), a window of eight, many components emptying (the stop / clean / relaunch path), spans
     shorter than min_duration (NaN durations, utterances.py:96-101: span ends whose candidates are all -inf, the backward
     pass's step-back branch, kmeans_acoustic_wordseg.py:516-530), K_max = 1 500 and 5 000 (sixteen and sixty-four components per
-    workgroup: the score phase's lane groups of eight and thirty-two)."""
-    from segmentalist_amd import kmeans_acoustic_wordseg as kaw
+    workgroup: the score phase's lane groups of eight and thirty-two), and the largest shape the kernel takes (32 landmarks,
+    128 dimensions)."""
+    from segmentalist_amd import device as dev_mod, kmeans_acoustic_wordseg as kaw
     corpus = cases.chain_corpus(n_utt, D, K, 7 * n_utt + D, ragged, N, nmax, "float32")
+    ran = []
+    real = dev_mod.DeviceKMeans.sequential_sweep
+    monkeypatch.setattr(dev_mod.DeviceKMeans, "sequential_sweep", lambda self, *a, **k: ran.append(real(self, *a, **k)) or ran[-1])
     out = {}
     for mode in ("0", "1"):
         monkeypatch.setenv("SEGK_SEQ_CHAIN", mode)
@@ -862,6 +867,9 @@ def test_persistent_sequential_chain_equals_the_three_launch_form(gpu, monkeypat
             states.append((seg.utterances.boundaries.copy(), c.assignments.copy(), c.means.copy(), c.mean_numerators.copy(),
                            c.counts.copy(), c.K, rec["sum_neg_len_sqrd_norm"][0], rec["n_tokens"][0]))
         out[mode] = states
+        if mode == "1":
+            assert ran and all(ran), "the persistent kernel did not take the sweeps"
+        ran.clear()
     for it in range(3):
         a, b = out["0"][it], out["1"][it]
         for x, y in zip(a[:5], b[:5]):
