@@ -939,3 +939,41 @@ def test_segment_kernels_agree(gpu, monkeypatch, n_utt, D, K, N, nmax, ragged):
         for a, b in zip(out[0][:4], other[:4]):
             assert np.array_equal(a, b)
         assert out[0][4] == other[4]
+
+
+def test_two_models_on_one_context_with_interleaved_sweeps(gpu):
+    """Two segmenters alive on the process's one library context (its workspaces, queues, hint buffers and feedback words are
+    shared), whole-sweep batches on one and mini-batches on the other, both at sizes where the hinted score path runs, sweeps
+    interleaved: each ends in the state it reaches alone."""
+    import torch
+    from segmentalist_amd import kmeans_acoustic_wordseg as kaw
+    from segmentalist_amd.synth import make_corpus
+
+    def build(seed, n_utt, K, n_batches):
+        corpus = make_corpus(n_utt, 100, K, seed=seed, N=20, n_slices_max=6)
+        random.seed(seed); np.random.seed(seed)
+        return kaw.SegmentalKMeansWordseg(K, *corpus, n_slices_max=6, init_am_assignments="spread", sync="batch", n_batches=n_batches)
+
+    def state(seg):
+        torch.cuda.synchronize()
+        seg._dk.check_status()
+        c = seg.acoustic_model.components
+        return seg.utterances.boundaries.copy(), c.assignments.copy(), c.means.copy(), c.K
+
+    specs = ((1, 3000, 1000, 1), (2, 2500, 700, 2))
+    alone = []
+    for sp in specs:
+        s = build(*sp)
+        for _ in range(6):
+            s.batch_sweep_async()
+        alone.append(state(s))
+        del s
+    segs = [build(*sp) for sp in specs]
+    for _ in range(6):
+        for s in segs:
+            s.batch_sweep_async()
+    for i, s in enumerate(segs):
+        st = state(s)
+        for a, b in zip(st[:3], alone[i][:3]):
+            assert np.array_equal(a, b), i
+        assert st[3] == alone[i][3]
