@@ -1010,6 +1010,37 @@ __global__ __launch_bounds__(512) void k_fb_chain(FbChainArgs A)
     }
 }
 
+// Fingerprint of everything the table of log prior predictives is computed from: the rows of X (as stored, every 32-bit word
+// mixed with its index) and the prior's three vectors.  A sum, so the order of the threads does not matter.  The table used
+// to be keyed by the ADDRESSES of X and of the prior: a second model built after the first was freed gets the same addresses
+// from a caching allocator -- another corpus of the same shape then ran on the first one's table, silently.
+__global__ __launch_bounds__(256) void k_fb_fingerprint(segk_corpus c, segk_fbgmm f, unsigned long long *out)
+{
+    const int64_t wpr = (int64_t)c.D * (c.x_dtype == SEGK_F32 ? 1 : 2);            // 32-bit words per row
+    const int64_t ldw = (int64_t)c.ldx * (c.x_dtype == SEGK_F32 ? 1 : 2);
+    const int64_t n = c.n_emb * wpr;
+    const uint32_t *X = (const uint32_t *)c.X;
+    unsigned long long h = 0ull;
+    auto mix = [](unsigned long long v, unsigned long long i) -> unsigned long long {
+        unsigned long long z = (v + 0x9E3779B97F4A7C15ull) ^ (i * 0xBF58476D1CE4E5B9ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    };
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / wpr, w = i - r * wpr;
+        h += mix(X[r * ldw + w], (unsigned long long)i);
+    }
+    if (blockIdx.x == 0)
+        for (int d = threadIdx.x; d < c.D; d += blockDim.x) {
+            h += mix((unsigned long long)__double_as_longlong(f.prior_a[d]), 0x1000000000ull + d);
+            h += mix((unsigned long long)__double_as_longlong(f.prior_b[d]), 0x2000000000ull + d);
+            if (f.cov_type == 0) h += mix((unsigned long long)__double_as_longlong(f.prior_c[d]), 0x3000000000ull + d);
+        }
+    for (int o = 32; o > 0; o >>= 1) h += __shfl_xor(h, o);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, h);
+}
+
 // out[e] = log prior predictive of row e, by the expression (and the number of threads) fb_logits uses: one workgroup per row
 template <typename XT>
 __global__ __launch_bounds__(512) void k_fb_prior_tab(segk_corpus c, segk_fbgmm f, double *out)
@@ -1363,6 +1394,18 @@ int32_t segk_fbgmm_sequential_sweep(segk_ctx *ctx, const segk_corpus *c, segk_fb
     std::vector<int32_t> rs((size_t)c->n_utt + 1);
     hipStream_t st = (hipStream_t)stream;
     SEGK_CHECK_HIP(hipMemcpyAsync(rs.data(), row_start, rs.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    // (under the same synchronisation) the fingerprint of the rows and the prior, for the table of log prior predictives below
+    unsigned long long fp = 0ull;
+    if (c->D <= 512) {
+        if (!ctx->fb_fp_dev) SEGK_CHECK_HIP(hipMalloc((void **)&ctx->fb_fp_dev, sizeof(unsigned long long)));
+        SEGK_CHECK_HIP(hipMemsetAsync(ctx->fb_fp_dev, 0, sizeof(unsigned long long), st));
+        const int64_t words = c->n_emb * c->D * (c->x_dtype == SEGK_F32 ? 1 : 2);
+        int64_t grid = (words + 256 * 16 - 1) / (256 * 16);
+        if (grid > 4 * ctx->n_cu) grid = 4 * ctx->n_cu;
+        if (grid < 1) grid = 1;
+        hipLaunchKernelGGL(k_fb_fingerprint, dim3((unsigned)grid), dim3(256), 0, st, *c, *f, ctx->fb_fp_dev);
+        SEGK_CHECK_HIP(hipMemcpyAsync(&fp, ctx->fb_fp_dev, sizeof(fp), hipMemcpyDeviceToHost, st));
+    }
     SEGK_CHECK_HIP(hipStreamSynchronize(st));
     int max_rows = 1;
     {
@@ -1441,7 +1484,7 @@ int32_t segk_fbgmm_sequential_sweep(segk_ctx *ctx, const segk_corpus *c, segk_fb
     // the rows' log prior predictive, once per (corpus, prior, number of threads)
     A.lprior_tab = nullptr;
     if (D <= 512) {
-        if (!ctx->fb_ptab || ctx->fb_ptab_n < c->n_emb || ctx->fb_ptab_X != c->X || ctx->fb_ptab_prior != (const void *)f->prior_a ||
+        if (!ctx->fb_ptab || ctx->fb_ptab_n < c->n_emb || ctx->fb_ptab_rows != c->n_emb || ctx->fb_ptab_fp != fp || ctx->fb_ptab_D != c->D ||
             ctx->fb_ptab_nt != nt || ctx->fb_ptab_cov != f->cov_type || ctx->fb_ptab_k0 != f->k_0 || ctx->fb_ptab_v0 != f->v_0) {
             if (ctx->fb_ptab_n < c->n_emb) {
                 if (ctx->fb_ptab) (void)hipFree(ctx->fb_ptab);
@@ -1452,7 +1495,7 @@ int32_t segk_fbgmm_sequential_sweep(segk_ctx *ctx, const segk_corpus *c, segk_fb
             }
             DISPATCH_XT(c, hipLaunchKernelGGL(k_fb_prior_tab<XT>, dim3((unsigned)c->n_emb), dim3(nt), 0, st, *c, *f, ctx->fb_ptab););
             SEGK_LAUNCH_CHECK();
-            ctx->fb_ptab_X = c->X; ctx->fb_ptab_prior = (const void *)f->prior_a; ctx->fb_ptab_nt = nt; ctx->fb_ptab_cov = f->cov_type;
+            ctx->fb_ptab_fp = fp; ctx->fb_ptab_rows = c->n_emb; ctx->fb_ptab_D = c->D; ctx->fb_ptab_nt = nt; ctx->fb_ptab_cov = f->cov_type;
             ctx->fb_ptab_k0 = f->k_0; ctx->fb_ptab_v0 = f->v_0;
         }
         A.lprior_tab = ctx->fb_ptab;

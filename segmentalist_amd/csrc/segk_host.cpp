@@ -112,6 +112,7 @@ int32_t segk_destroy(segk_ctx *ctx)
         if (ctx->fbchain_terms) (void)hipFree(ctx->fbchain_terms);
         if (ctx->fb_ktab) (void)hipFree(ctx->fb_ktab);
         if (ctx->fb_ptab) (void)hipFree(ctx->fb_ptab);
+        if (ctx->fb_fp_dev) (void)hipFree(ctx->fb_fp_dev);
         if (ctx->fbs_buf) (void)hipFree(ctx->fbs_buf);
         if (ctx->flag_ovf) (void)hipFree(ctx->flag_ovf);
         if (ctx->hint_part) (void)hipFree(ctx->hint_part);

@@ -34,7 +34,10 @@ struct segk_ctx {
     int fb_ktab_D;
     double *fb_ptab;              // persistent FBGMM chain: log prior predictive of every row, and what it was computed from
     int64_t fb_ptab_n;
-    const void *fb_ptab_X, *fb_ptab_prior;
+    unsigned long long fb_ptab_fp;     // fingerprint of the rows and the prior it was computed from (k_fb_fingerprint), and their shape
+    int64_t fb_ptab_rows;
+    int fb_ptab_D;
+    unsigned long long *fb_fp_dev;     // [dev] the fingerprint's accumulator
     int fb_ptab_nt, fb_ptab_cov;
     double fb_ptab_k0, fb_ptab_v0;
     void *fbchain_buf;            // persistent FBGMM chain (segk_fbgmm.hip k_fb_chain): control words, the sweep's utterance order

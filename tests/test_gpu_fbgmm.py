@@ -390,3 +390,39 @@ def test_serial_chain_with_utterances_beyond_the_persistent_kernels_limit(gpu, n
     assert cd.K == cr.K
     for a, b in zip(r0["log_marg"], r1["log_marg"]):
         assert abs(a - b) <= 1e-12 * max(1.0, abs(a))
+
+
+def test_a_second_model_at_the_first_ones_addresses_gets_its_own_tables(gpu, monkeypatch):
+    """The persistent chain reads the rows' log prior predictive from a table the context caches.  The table is keyed by a
+    fingerprint of the rows and the prior -- it was keyed by their ADDRESSES, and a model built after another was freed gets the
+    same addresses from the caching allocator: a different corpus of the same shape then ran on the first corpus's table
+    (boundaries, assignments and log_marg wrong, silently).  Model A through the chain, freed; model B (another corpus, same
+    shape) through the chain must equal model B through the launches, which use no table."""
+    import gc
+    import torch
+    from segmentalist_amd import fbgmm, unigram_acoustic_wordseg as uaw
+    from segmentalist_amd.niw import NIW
+    from segmentalist_amd.synth import make_corpus
+    D, K = 12, 30
+
+    def run(cseed, chain, scale):
+        monkeypatch.setenv("SEGK_FB_CHAIN", "1" if chain else "0")
+        corpus = list(make_corpus(60, D, K, seed=cseed, N=10, n_slices_max=5))
+        corpus[0] = {k: (v * scale).astype(np.float32) for k, v in corpus[0].items()}
+        random.seed(3); np.random.seed(3)
+        seg = uaw.UnigramAcousticWordseg(fbgmm.FBGMM, 1.0, K, NIW(np.zeros(D), 0.05, D + 3, 0.002 * (D + 3) * np.ones(D)), *corpus,
+                                         covariance_type="diag", fb_type="standard", n_slices_min=0, n_slices_max=5, p_boundary_init=0.5,
+                                         beta_sent_boundary=-1, lms=1.0, wip=0.0, init_am_assignments="rand", time_power_term=1.0)
+        rec = seg.gibbs_sample(3)
+        out = (seg.utterances.boundaries.copy(), seg.acoustic_model.components.assignments.copy(), list(rec["log_marg"]))
+        del seg
+        gc.collect()
+        torch.cuda.synchronize()
+        return out
+
+    run(4, True, 1.0)
+    b_chain = run(5, True, 1.7)
+    b_launch = run(5, False, 1.7)
+    assert np.array_equal(b_chain[0], b_launch[0])
+    assert np.array_equal(b_chain[1], b_launch[1])
+    assert b_chain[2] == b_launch[2]
