@@ -141,7 +141,8 @@ def test_batch_sweep_with_thousands_of_new_components_in_one_sweep(gpu):
 
 
 @pytest.mark.parametrize("n_range,nmax,sync,n_blocks", [((3, 34), 6, "sequential", 1), ((3, 45), 6, "batch", 8), ((3, 80), 6, "sequential", 1),
-                                                        ((3, 80), 6, "batch", 8), ((30, 80), 10, "batch", 4), ((30, 80), 10, "sequential", 1)])
+                                                        ((3, 80), 6, "batch", 8), ((30, 80), 10, "batch", 4), ((30, 80), 10, "sequential", 1),
+                                                        ((60, 80), 70, "sequential", 1), ((60, 80), 70, "batch", 4)])
 def test_utterances_beyond_the_fast_kernels_landmark_limits(gpu, n_range, nmax, sync, n_blocks):
     """More than 32 landmarks (the persistent sequential chain and the chain's update kernel stop applying), more than 64 (the
     eight-lane segment kernel too) and windows of more than eight slices: the fall-backs behind the fast kernels, against the

@@ -426,3 +426,31 @@ def test_a_second_model_at_the_first_ones_addresses_gets_its_own_tables(gpu, mon
     assert np.array_equal(b_chain[0], b_launch[0])
     assert np.array_equal(b_chain[1], b_launch[1])
     assert b_chain[2] == b_launch[2]
+
+
+@pytest.mark.parametrize("n_range,nmax,fb_type", [((60, 80), 70, "standard"), ((60, 80), 70, "viterbi"), ((20, 40), 30, "standard"),
+                                                  ((60, 80), 17, "standard")])
+def test_serial_chain_with_wide_windows(gpu, n_range, nmax, fb_type):
+    """Windows of 17, 30 and 70 slices on utterances of up to 80 landmarks (the DP's general form: more candidates per step than
+    a wave has lanes) against the oracle draw for draw."""
+    from oracle import np_oracle as no
+    from segmentalist_amd import fbgmm, unigram_acoustic_wordseg as uaw
+    from segmentalist_amd.niw import NIW
+    from segmentalist_amd.synth import make_corpus
+    D, K = 8, 10
+    corpus = make_corpus(10, D, K, seed=4, ragged=True, n_slices_max=nmax, N_range=n_range)
+    kw = dict(covariance_type="diag", fb_type=fb_type, n_slices_min=0, n_slices_max=nmax, p_boundary_init=0.5, beta_sent_boundary=-1,
+              lms=1.0, wip=0.0, init_am_assignments="rand", time_power_term=1.0)
+    pa = (np.zeros(D), 0.05, D + 3, 0.002 * (D + 3) * np.ones(D))
+    random.seed(3); np.random.seed(3)
+    ref = no.UnigramAcousticWordseg(no.FBGMM, 1.0, K, no.NIW(*pa), *corpus, **kw)
+    random.seed(3); np.random.seed(3)
+    seg = uaw.UnigramAcousticWordseg(fbgmm.FBGMM, 1.0, K, NIW(*pa), *corpus, **kw)
+    st = random.getstate()
+    r0 = ref.gibbs_sample(2)
+    random.setstate(st)
+    r1 = seg.gibbs_sample(2)
+    assert np.array_equal(seg.utterances.boundaries, ref.utterances.boundaries)
+    assert np.array_equal(seg.acoustic_model.components.assignments, ref.acoustic_model.components.assignments)
+    for a, b in zip(r0["log_marg"], r1["log_marg"]):
+        assert abs(a - b) <= 1e-12 * max(1.0, abs(a))
