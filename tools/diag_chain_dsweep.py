@@ -1,4 +1,4 @@
-"""Development: the persistent FBGMM chain against the four launches per utterance at one D, sweep by sweep: which utterances'
+"""Development (diag_chain_dsweep.py D [K_max [f64]]): the persistent FBGMM chain against the four launches per utterance at one D, sweep by sweep: which utterances'
 log-probabilities and which spans' scores differ (bits)."""
 import os, random, sys
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
@@ -8,7 +8,8 @@ from segmentalist_amd.niw import NIW
 from segmentalist_amd.synth import make_corpus
 D = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 6
-corpus = make_corpus(24, D, K, seed=4, ragged=True, n_slices_max=5, N_range=(3, 6))
+DT = np.float64 if (len(sys.argv) > 3 and sys.argv[3] == 'f64') else np.float32
+corpus = make_corpus(24, D, K, seed=4, ragged=True, n_slices_max=5, N_range=(3, 6), dtype=DT)
 prior = NIW(np.zeros(D), 0.05, D + 3, 0.002 * (D + 3) * np.ones(D))
 out = {}
 for mode in ("1", "0"):
